@@ -1,0 +1,56 @@
+"""Shared test helpers: regenerate the seeded inputs/weights of a golden case and
+check their digests against the fixture."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from rift_amd import synthetic as syn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+CASES = {
+    "small": (list(range(100, 106)), 12, 8, 1, 4),
+    "full": ([7, 8], 64, 20, 1, 6),
+}
+
+
+def manifest():
+    with open(os.path.join(GOLDEN, "state_dict_manifest.json")) as f:
+        return json.load(f)
+
+
+_sd_cache = {}
+
+
+def weights():
+    if "sd" not in _sd_cache:
+        _sd_cache["sd"] = syn.perturbed_state_dict(manifest())
+    return _sd_cache["sd"]
+
+
+def build_batch(case):
+    idx, A, Mp, r0, r1 = CASES[case]
+    return syn.collate_scenes([syn.make_scene(i, A, Mp, r0, r1) for i in idx])
+
+
+def load_case(case):
+    gold = dict(np.load(os.path.join(GOLDEN, f"pluto_{case}.npz")))
+    batch = build_batch(case)
+    sd = weights()
+    assert syn.digest(sd) == str(gold["weight_digest"]), "regenerated weights differ from the fixture's"
+    assert syn.digest(syn.flatten_dict(batch)) == str(gold["input_digest"]), "regenerated inputs differ"
+    return gold, batch, sd
+
+
+def clone_tree(d):
+    return {k: clone_tree(v) if isinstance(v, dict) else (v.clone() if torch.is_tensor(v) else v)
+            for k, v in d.items()}
+
+
+def max_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
