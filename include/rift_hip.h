@@ -1,0 +1,200 @@
+/*
+ * librift_hip.so -- C-ABI of the MI355X-native RIFT train_cbv policy-update hot path.
+ *
+ * The reference (CurryChen77/RIFT) is pure Python over PyTorch and has no FFI; these
+ * entry points are what a maintainer binds (ctypes) to replace
+ * the device work behind the reference's own Python interfaces.  Each entry cites the
+ * reference interface it replaces (paths relative to the upstream checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; tensors are caller-owned,
+ *     dense row-major with the reference's shapes; bool tensors are 1 byte per element
+ *     (torch.bool), categories are int8.
+ *   - all work is enqueued on the hipStream_t passed by the caller (void*; NULL = the
+ *     default stream); no hidden synchronisation unless stated.
+ *   - return value: 0 = ok, <0 = error; message via rift_last_error().
+ *   - one context per (process, device); not thread-safe.
+ */
+#ifndef RIFT_HIP_H
+#define RIFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RiftCtx RiftCtx;
+
+enum { RIFT_OK = 0, RIFT_ERR_ARG = -1, RIFT_ERR_HIP = -2, RIFT_ERR_STATE = -3, RIFT_ERR_NONFINITE = -4 };
+
+/* forward flags */
+enum {
+  RIFT_F_TRAIN      = 1,   /* Lightning .train(): dropout / DropPath / state-dropout on, BatchNorm batch statistics */
+  RIFT_F_NEED_TRAJ  = 2,   /* also produce trajectory / prediction / ref_free_trajectory (unused by the RLFT losses) */
+  RIFT_F_FP32       = 4,   /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of bf16 MFMA for the trunk GEMMs */
+  RIFT_F_NO_DROP    = 8,   /* with TRAIN: every drop probability 0 (BatchNorm batch statistics only) */
+  RIFT_F_NO_BN_UPDATE = 16 /* with TRAIN: do not update BatchNorm running statistics */
+};
+
+/* loss kinds */
+enum { RIFT_LOSS_RIFT = 0, RIFT_LOSS_GRPO = 1, RIFT_LOSS_PPO = 2, RIFT_LOSS_REINFORCE = 3 };
+
+/* A named view onto one tensor of PlanningModel.state_dict()
+ * (rift/cbv/planning/pluto/model/pluto_model.py:22-120; names as in SURVEY.md Appendix B). */
+typedef struct RiftTensorDesc {
+  const char* name;     /* host string */
+  void* data;           /* device pointer (fp32; num_batches_tracked int64) */
+  int64_t numel;
+  int32_t ndim;
+  int64_t shape[4];
+} RiftTensorDesc;
+
+/* The collated feature batch that PlanningModel.forward(data) consumes
+ * (pluto_model.py:122-138; produced by PlutoFeature.collate, pluto_feature.py:25-96;
+ * schema in SURVEY.md Appendix A). */
+typedef struct RiftFeatureBatch {
+  int32_t bs, A, Mp, R, S;           /* scenes, padded agents / polygons / ref lines / static objects */
+  int32_t T;                          /* time extent of the agent tensors (>= 21; first 21 steps are used) */
+  const float*   agent_position;      /* (bs,A,T,2) */
+  const float*   agent_heading;       /* (bs,A,T)   */
+  const float*   agent_velocity;      /* (bs,A,T,2) */
+  const float*   agent_shape;         /* (bs,A,T,2) */
+  const int8_t*  agent_category;      /* (bs,A)     */
+  const uint8_t* agent_valid_mask;    /* (bs,A,T)   */
+  const float*   map_point_position;  /* (bs,Mp,3,20,2) */
+  const float*   map_point_vector;    /* (bs,Mp,3,20,2) */
+  const float*   map_point_orientation; /* (bs,Mp,3,20) */
+  const float*   map_polygon_center;  /* (bs,Mp,3) */
+  const int8_t*  map_polygon_type;    /* (bs,Mp) */
+  const uint8_t* map_polygon_on_route; /* (bs,Mp) */
+  const int8_t*  map_polygon_tl_status; /* (bs,Mp) */
+  const uint8_t* map_polygon_has_speed_limit; /* (bs,Mp) */
+  const float*   map_polygon_speed_limit; /* (bs,Mp) */
+  const uint8_t* map_valid_mask;      /* (bs,Mp,20) */
+  const float*   ref_position;        /* (bs,R,120,2) */
+  const float*   ref_vector;          /* (bs,R,120,2) */
+  const float*   ref_orientation;     /* (bs,R,120) */
+  const uint8_t* ref_valid_mask;      /* (bs,R,120) */
+  const float*   static_position;     /* (bs,S,2)  (may be NULL when S == 0) */
+  const float*   static_heading;      /* (bs,S) */
+  const float*   static_shape;        /* (bs,S,2) */
+  const int8_t*  static_category;     /* (bs,S) */
+  const uint8_t* static_valid_mask;   /* (bs,S) */
+  const float*   current_state;       /* (bs,cs_ld) first 6 used */
+  int32_t cs_ld;
+} RiftFeatureBatch;
+
+/* Outputs of PlanningModel.forward (pluto_model.py:167-223).  NULL pointers are skipped. */
+typedef struct RiftOutputs {
+  float* probability;          /* (bs,R,12) logits, -1e6 on padded reference lines */
+  float* hidden;               /* (bs,128) */
+  float* trajectory;           /* (bs,R,12,80,6)  [NEED_TRAJ] */
+  float* prediction;           /* (bs,A-1,80,6)   [NEED_TRAJ] */
+  float* ref_free_trajectory;  /* (bs,80,4)       [NEED_TRAJ] */
+} RiftOutputs;
+
+/* Inputs of the RLFT objectives:
+ *   RIFT      get_rift_loss      fine_tuner/rlft/rift_pluto/rift_trainer.py:140-182
+ *   GRPO      get_grpo_loss      fine_tuner/rlft/grpo_pluto/grpo_trainer.py:140-194
+ *   PPO       get_ppo_loss       fine_tuner/rlft/ppo_pluto/ppo_trainer.py:161-183 (actor part)
+ *   REINFORCE get_reinforce_loss fine_tuner/rlft/reinforce_pluto/reinforce_trainer.py:125-170 */
+typedef struct RiftLossIn {
+  const float*   old_group_logits;   /* (bs,R,12) f32   RIFT, GRPO */
+  const float*   ref_group_logits;   /* (bs,R,12) f32   GRPO */
+  const double*  group_advantage;    /* (bs,R,12) f64   RIFT, GRPO */
+  const uint8_t* group_valid_mask;   /* (bs,R,12) bool  RIFT, GRPO */
+  const int64_t* action_mode;        /* (bs,2) int64    PPO */
+  const float*   advantage;          /* (bs)            PPO */
+  const float*   old_log_prob;       /* (bs)            PPO */
+  const float*   returns;            /* (bs)            REINFORCE */
+  float clip_epsilon;                /* PPO, default 0.2 */
+  float lambda_entropy;              /* PPO, default 0.01 */
+} RiftLossIn;
+
+/* Gradients of planning_decoder.pi_head (the trainable set of rift_training.yaml:26-27) are
+ * written into caller-owned buffers (the torch .grad tensors), so clip_grad_norm_ and
+ * torch.optim.AdamW run unchanged (rift_trainer.py:279-362). */
+typedef struct RiftLossOut {
+  double* loss;            /* device scalar, f64: -(sum objective)/(count) */
+  double* stats;           /* device [2] f64: (sum objective, count) -- all-reduce these for DP */
+  float*  flat_grad_sum;   /* device [16897] unnormalised d(sum objective)/d(pi_head params): all-reduce for DP */
+  float*  grad_w1;  float* grad_b1;      /* mlp.0.weight (128,128), mlp.0.bias (128) */
+  float*  grad_ln_w; float* grad_ln_b;   /* mlp.1.weight (128), mlp.1.bias (128) */
+  float*  grad_w2;  float* grad_b2;      /* mlp.3.weight (1,128), mlp.3.bias (1) */
+  int64_t* argmax_rm;      /* (bs,2) int64 chosen (r,m) -- REINFORCE, bit-exact integer output */
+} RiftLossOut;
+
+int  rift_ctx_create(int device, RiftCtx** ctx);
+void rift_ctx_destroy(RiftCtx* ctx);
+const char* rift_last_error(RiftCtx* ctx);
+
+/* Bind the model parameters (views onto the torch state_dict storage) and build the packed
+ * bf16 / fp32 weight images.  Replaces PlanningModel.load_state_dict for the device side
+ * (pluto.py:130-141).  Call again after the frozen trunk changes; pi_head.* is read live. */
+int rift_model_load(RiftCtx* ctx, const RiftTensorDesc* params, int n, void* stream);
+
+/* PlanningModel.forward (pluto_model.py:122-225). */
+int rift_forward(RiftCtx* ctx, const RiftFeatureBatch* batch, const RiftOutputs* out, int flags,
+                 uint32_t seed, void* stream);
+
+/* Objective + analytic backward into pi_head, using the activations of the last rift_forward.
+ * Two phases so that a data-parallel host can all-reduce (flat_grad_sum, stats) in between:
+ *   rift_loss_backward : fills stats, flat_grad_sum (and argmax_rm)
+ *   rift_loss_finalize : loss = -S/count, grads = -flat/count into the .grad buffers        */
+int rift_loss_backward(RiftCtx* ctx, int kind, const RiftLossIn* in, const RiftLossOut* out, void* stream);
+int rift_loss_finalize(RiftCtx* ctx, const RiftLossOut* out, int accumulate, void* stream);
+
+/* Debug / parity taps: copy a named intermediate of the last forward to `dst` (device, fp32).
+ * *numel receives the element count; dst may be NULL to query the size only. */
+int rift_tap(RiftCtx* ctx, const char* name, float* dst, int64_t* numel, void* stream);
+
+/* Single GEMM through the same kernel the forward uses (parity tests of the MFMA path):
+ * Y[M,N] = act(LN?(X)[M,K] . W[N,K]^T + bias).  W/bias fp32 device pointers. */
+int rift_op_linear(RiftCtx* ctx, const float* X, int M, int K, const float* W, const float* bias, int N,
+                   const float* ln_w, const float* ln_b, int act, int fp32, float* Y, void* stream);
+
+/* get_advantages_GAE (fine_tuner/rlft/ppo_pluto/ppo_datamodule.py:22-37): reverse scan over n fp32 entries. */
+int rift_gae(RiftCtx* ctx, const double* rewards /*f64, as np.stack of python floats*/, const float* undones,
+             const float* values, const float* next_values, const float* unterminated, float gamma, float lambda_,
+             int n, float* advantages, void* stream);
+
+/* compute_return (fine_tuner/rlft/reinforce_pluto/reinforce_datamodule.py:19-38). */
+int rift_discounted_return(RiftCtx* ctx, const double* rewards /*f64*/, const float* dones /*0/1 as f32*/,
+                           double gamma, int n, double* returns /*f64*/, void* stream);
+
+/* Buffer-wide advantage normalisation (ppo_datamodule.py:166): (x - mean) / (std_unbiased + 1e-5), in place. */
+int rift_normalize_advantage(RiftCtx* ctx, float* x, int n, void* stream);
+
+/* Group z-score of GRPO returns (traj_eval/traj_evaluator.py:467-470): per group of G fp64 returns,
+ * adv = (ret - mean) / (std_ddof0 + 1e-5). */
+int rift_group_advantage(RiftCtx* ctx, const double* returns, int n_groups, int G, double* advantage, void* stream);
+
+/* Discounted dense-reward return of candidate rollouts (traj_evaluator.py:333-370 with
+ * gym_carla/reward/reward_model.py:34-50): inputs (G,Ts) f32, flags (G,*) bool with row strides. */
+int rift_rollout_return(RiftCtx* ctx, const float* delta_dis, const float* delta_angle, const float* speed,
+                        const float* acc, const float* ang_vel, const float* ang_acc, const uint8_t* collision,
+                        int collision_ld, const uint8_t* off_road, int off_road_ld, int G, int Ts, double gamma,
+                        double* returns, void* stream);
+
+/* Device-side collation (PlutoFeature.collate, pluto_feature.py:83-94 + RIFTCollate,
+ * rift_datamodule.py:33-49): gather `bs` scenes by index from a replay arena whose tensors
+ * are stored padded to (A, Mp, Rcap, S) per scene, writing a batch padded to R = batch max. */
+typedef struct RiftReplayArena {
+  int32_t n_scenes, A, Mp, Rcap, S, T, cs_ld;
+  RiftFeatureBatch scenes;            /* same pointers, leading dim n_scenes, R = Rcap */
+  const int32_t* r_count;             /* (n_scenes) valid reference lines per scene */
+  const float*   old_group_logits;    /* (n_scenes,Rcap,12) */
+  const float*   ref_group_logits;    /* (n_scenes,Rcap,12) or NULL */
+  const double*  group_advantage;     /* (n_scenes,Rcap,12) */
+  const uint8_t* group_valid_mask;    /* (n_scenes,Rcap,12) */
+} RiftReplayArena;
+
+int rift_collate(RiftCtx* ctx, const RiftReplayArena* arena, const int32_t* scene_idx /*device (bs)*/, int bs,
+                 int R_out, const RiftFeatureBatch* out_batch /*caller-allocated*/, float* out_old_logits,
+                 float* out_ref_logits, double* out_advantage, uint8_t* out_valid_mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIFT_HIP_H */

@@ -1,0 +1,359 @@
+"""ctypes binding of ``librift_hip.so`` (C-ABI in ``include/rift_hip.h``).
+
+The product path has NO CPU fallback: if the shared library is missing or fails
+to load, importing the engine raises immediately.
+"""
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librift_hip.so")
+
+# forward flags / loss kinds (include/rift_hip.h)
+F_TRAIN, F_NEED_TRAJ, F_FP32, F_NO_DROP, F_NO_BN_UPDATE = 1, 2, 4, 8, 16
+LOSS_KINDS = {"rift": 0, "grpo": 1, "ppo": 2, "reinforce": 3}
+PI_NPARAM = 16897
+
+vp = C.c_void_p
+
+
+class RiftTensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", vp), ("numel", C.c_int64), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
+_FB_PTRS = [
+    "agent_position", "agent_heading", "agent_velocity", "agent_shape", "agent_category", "agent_valid_mask",
+    "map_point_position", "map_point_vector", "map_point_orientation", "map_polygon_center", "map_polygon_type",
+    "map_polygon_on_route", "map_polygon_tl_status", "map_polygon_has_speed_limit", "map_polygon_speed_limit",
+    "map_valid_mask", "ref_position", "ref_vector", "ref_orientation", "ref_valid_mask", "static_position",
+    "static_heading", "static_shape", "static_category", "static_valid_mask", "current_state",
+]
+
+
+class RiftFeatureBatch(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("bs", "A", "Mp", "R", "S", "T")] + [(n, vp) for n in _FB_PTRS]
+                + [("cs_ld", C.c_int32)])
+
+
+class RiftOutputs(C.Structure):
+    _fields_ = [(n, vp) for n in ("probability", "hidden", "trajectory", "prediction", "ref_free_trajectory")]
+
+
+class RiftLossIn(C.Structure):
+    _fields_ = [(n, vp) for n in ("old_group_logits", "ref_group_logits", "group_advantage", "group_valid_mask",
+                                  "action_mode", "advantage", "old_log_prob", "returns")] + \
+               [("clip_epsilon", C.c_float), ("lambda_entropy", C.c_float)]
+
+
+class RiftLossOut(C.Structure):
+    _fields_ = [(n, vp) for n in ("loss", "stats", "flat_grad_sum", "grad_w1", "grad_b1", "grad_ln_w", "grad_ln_b",
+                                  "grad_w2", "grad_b2", "argmax_rm")]
+
+
+class RiftReplayArena(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_scenes", "A", "Mp", "Rcap", "S", "T", "cs_ld")] + \
+               [("scenes", RiftFeatureBatch)] + \
+               [(n, vp) for n in ("r_count", "old_group_logits", "ref_group_logits", "group_advantage",
+                                  "group_valid_mask")]
+
+
+EXPORTS = [
+    "rift_ctx_create", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_loss_backward",
+    "rift_loss_finalize", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
+    "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
+]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load librift_hip.so; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). rift_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise RuntimeError(f"librift_hip.so does not export {name}")
+    lib.rift_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.rift_ctx_destroy.argtypes = [vp]
+    lib.rift_ctx_destroy.restype = None
+    lib.rift_last_error.argtypes = [vp]
+    lib.rift_last_error.restype = C.c_char_p
+    lib.rift_model_load.argtypes = [vp, C.POINTER(RiftTensorDesc), C.c_int, vp]
+    lib.rift_forward.argtypes = [vp, C.POINTER(RiftFeatureBatch), C.POINTER(RiftOutputs), C.c_int, C.c_uint32, vp]
+    lib.rift_loss_backward.argtypes = [vp, C.c_int, C.POINTER(RiftLossIn), C.POINTER(RiftLossOut), vp]
+    lib.rift_loss_finalize.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, vp]
+    lib.rift_tap.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), vp]
+    lib.rift_op_linear.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.rift_gae.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp]
+    lib.rift_discounted_return.argtypes = [vp, vp, vp, C.c_double, C.c_int, vp, vp]
+    lib.rift_normalize_advantage.argtypes = [vp, vp, C.c_int, vp]
+    lib.rift_group_advantage.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.rift_rollout_return.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,
+                                        C.c_double, vp, vp]
+    lib.rift_collate.argtypes = [vp, C.POINTER(RiftReplayArena), vp, C.c_int, C.c_int, C.POINTER(RiftFeatureBatch),
+                                 vp, vp, vp, vp, vp]
+    for name in EXPORTS:
+        if name not in ("rift_ctx_destroy", "rift_last_error"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, dtype, device) -> torch.Tensor:
+    if t.dtype != dtype or t.device != device or not t.is_contiguous():
+        t = t.to(device=device, dtype=dtype).contiguous()
+    return t
+
+
+def feature_batch(data: Dict, device) -> (RiftFeatureBatch, list):
+    """Build the POD descriptor of a collated feature dict.
+    Returns (struct, keepalive list of the tensors whose pointers it holds)."""
+    f32, i8, u8 = torch.float32, torch.int8, torch.bool
+    ag, mp, rl = data["agent"], data["map"], data["reference_line"]
+    so = data.get("static_objects")
+    keep = []
+
+    def put(t, dt):
+        t = _dev(t, dt, device)
+        keep.append(t)
+        return t
+
+    fb = RiftFeatureBatch()
+    pos = put(ag["position"], f32)
+    bs, A, T = pos.shape[:3]
+    Mp = mp["point_position"].shape[1]
+    R = rl["position"].shape[1]
+    S = so["position"].shape[1] if so is not None else 0
+    fb.bs, fb.A, fb.Mp, fb.R, fb.S, fb.T = bs, A, Mp, R, S, T
+    t = {
+        "agent_position": pos, "agent_heading": put(ag["heading"], f32), "agent_velocity": put(ag["velocity"], f32),
+        "agent_shape": put(ag["shape"], f32), "agent_category": put(ag["category"], i8),
+        "agent_valid_mask": put(ag["valid_mask"], u8),
+        "map_point_position": put(mp["point_position"], f32), "map_point_vector": put(mp["point_vector"], f32),
+        "map_point_orientation": put(mp["point_orientation"], f32), "map_polygon_center": put(mp["polygon_center"], f32),
+        "map_polygon_type": put(mp["polygon_type"], i8), "map_polygon_on_route": put(mp["polygon_on_route"], u8),
+        "map_polygon_tl_status": put(mp["polygon_tl_status"], i8),
+        "map_polygon_has_speed_limit": put(mp["polygon_has_speed_limit"], u8),
+        "map_polygon_speed_limit": put(mp["polygon_speed_limit"], f32), "map_valid_mask": put(mp["valid_mask"], u8),
+        "ref_position": put(rl["position"], f32), "ref_vector": put(rl["vector"], f32),
+        "ref_orientation": put(rl["orientation"], f32), "ref_valid_mask": put(rl["valid_mask"], u8),
+        "current_state": put(data["current_state"], f32),
+    }
+    if S > 0:
+        t.update({"static_position": put(so["position"], f32), "static_heading": put(so["heading"], f32),
+                  "static_shape": put(so["shape"], f32), "static_category": put(so["category"], i8),
+                  "static_valid_mask": put(so["valid_mask"], u8)})
+    for name in _FB_PTRS:
+        setattr(fb, name, t[name].data_ptr() if name in t else None)
+    fb.cs_ld = t["current_state"].shape[1]
+    return fb, keep
+
+
+class Engine:
+    """One RiftCtx bound to one device + the torch tensors it borrows."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("rift_amd.Engine needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = load_library()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.ctx = vp()
+        rc = self.lib.rift_ctx_create(self.device.index or 0, C.byref(self.ctx))
+        if rc != 0:
+            raise RuntimeError(f"rift_ctx_create failed ({rc})")
+        self._params = None
+        self._names = None
+        self._keep = []
+
+    def close(self):
+        if self.ctx:
+            self.lib.rift_ctx_destroy(self.ctx)
+            self.ctx = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.rift_last_error(self.ctx)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # ---- parameters -------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Bind views onto `sd`'s tensors (moved to the device if necessary; the engine keeps
+        references, pi_head.* and BatchNorm running statistics are read / written in place)."""
+        params = {}
+        for k, v in sd.items():
+            dt = torch.int64 if v.dtype == torch.int64 else torch.float32
+            params[k] = _dev(v, dt, self.device)
+        descs = (RiftTensorDesc * len(params))()
+        names = []
+        for i, (k, v) in enumerate(params.items()):
+            nb = k.encode()
+            names.append(nb)
+            descs[i].name = nb
+            descs[i].data = v.data_ptr()
+            descs[i].numel = v.numel()
+            descs[i].ndim = min(v.dim(), 4)
+            shp = list(v.shape)[-4:] if v.dim() > 4 else list(v.shape)
+            # collapse leading singleton dims of (1,1,12,128)-style parameters to at most 4 dims
+            for d in range(4):
+                descs[i].shape[d] = shp[d] if d < len(shp) else 1
+        self._params, self._names = params, names
+        self._check(self.lib.rift_model_load(self.ctx, descs, len(params), _stream()), "rift_model_load")
+        return params
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, data: Dict, train=False, need_traj=False, fp32=False, no_drop=False, bn_update=True,
+                seed: int = 0) -> Dict[str, torch.Tensor]:
+        fb, keep = feature_batch(data, self.device)
+        bs, A, R = fb.bs, fb.A, fb.R
+        o = RiftOutputs()
+        out = {"probability": torch.empty(bs, R, 12, device=self.device),
+               "hidden": torch.empty(bs, 128, device=self.device)}
+        if need_traj:
+            out["trajectory"] = torch.empty(bs, R, 12, 80, 6, device=self.device)
+            out["prediction"] = torch.empty(bs, max(A - 1, 0), 80, 6, device=self.device)
+            out["ref_free_trajectory"] = torch.empty(bs, 80, 4, device=self.device)
+        for k, v in out.items():
+            setattr(o, k, v.data_ptr())
+        flags = (F_TRAIN if train else 0) | (F_NEED_TRAJ if need_traj else 0) | (F_FP32 if fp32 else 0) | \
+                (F_NO_DROP if no_drop else 0) | (0 if bn_update else F_NO_BN_UPDATE)
+        self._check(self.lib.rift_forward(self.ctx, C.byref(fb), C.byref(o), flags, C.c_uint32(seed & 0xFFFFFFFF),
+                                          _stream()), "rift_forward")
+        self._keep = keep + list(out.values())
+        self._bs = bs
+        return out
+
+    def tap(self, name: str) -> torch.Tensor:
+        n = C.c_int64(0)
+        self._check(self.lib.rift_tap(self.ctx, name.encode(), None, C.byref(n), _stream()), "rift_tap")
+        t = torch.empty(n.value, device=self.device)
+        self._check(self.lib.rift_tap(self.ctx, name.encode(), _ptr(t), C.byref(n), _stream()), "rift_tap")
+        return t
+
+    # ---- loss + backward ---------------------------------------------------------------------
+    def loss_backward(self, kind: str, batch: Dict[str, torch.Tensor], clip_epsilon=0.2, lambda_entropy=0.01):
+        """Phase 1: per-rank sums.  Returns (stats[2] f64, flat_grad_sum[16897] f32, argmax_rm or None)."""
+        dev = self.device
+        li = RiftLossIn()
+        keep = []
+
+        def put(key, dt):
+            if key not in batch or batch[key] is None:
+                return None
+            t = _dev(batch[key], dt, dev)
+            keep.append(t)
+            return t.data_ptr()
+
+        li.old_group_logits = put("old_group_logits_torch", torch.float32)
+        li.ref_group_logits = put("ref_group_logits_torch", torch.float32)
+        li.group_advantage = put("group_advantage_torch", torch.float64)
+        li.group_valid_mask = put("group_advantage_mask_torch", torch.bool)
+        li.action_mode = put("action_mode_torch", torch.int64)
+        li.advantage = put("advantage_torch", torch.float32)
+        li.old_log_prob = put("old_log_prob_torch", torch.float32)
+        li.returns = put("return_torch", torch.float32)
+        li.clip_epsilon, li.lambda_entropy = clip_epsilon, lambda_entropy
+        lo = RiftLossOut()
+        stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        flat = torch.zeros(PI_NPARAM, dtype=torch.float32, device=dev)
+        lo.stats, lo.flat_grad_sum = stats.data_ptr(), flat.data_ptr()
+        argmax = None
+        if kind == "reinforce":
+            argmax = torch.zeros(self._bs, 2, dtype=torch.int64, device=dev)
+            lo.argmax_rm = argmax.data_ptr()
+        self._check(self.lib.rift_loss_backward(self.ctx, LOSS_KINDS[kind], C.byref(li), C.byref(lo), _stream()),
+                    "rift_loss_backward")
+        self._keep_loss = keep
+        return stats, flat, argmax
+
+    def loss_finalize(self, stats, flat, grads: Dict[str, torch.Tensor], accumulate=False) -> torch.Tensor:
+        """Phase 2: loss = -S/count and grads = -flat/count into the six pi_head .grad tensors
+        (`grads` keyed by 'mlp.0.weight', 'mlp.0.bias', 'mlp.1.weight', 'mlp.1.bias', 'mlp.3.weight', 'mlp.3.bias')."""
+        lo = RiftLossOut()
+        loss = torch.zeros(1, dtype=torch.float64, device=self.device)
+        lo.loss, lo.stats, lo.flat_grad_sum = loss.data_ptr(), stats.data_ptr(), flat.data_ptr()
+        lo.grad_w1, lo.grad_b1 = _ptr(grads.get("mlp.0.weight")), _ptr(grads.get("mlp.0.bias"))
+        lo.grad_ln_w, lo.grad_ln_b = _ptr(grads.get("mlp.1.weight")), _ptr(grads.get("mlp.1.bias"))
+        lo.grad_w2, lo.grad_b2 = _ptr(grads.get("mlp.3.weight")), _ptr(grads.get("mlp.3.bias"))
+        self._check(self.lib.rift_loss_finalize(self.ctx, C.byref(lo), 1 if accumulate else 0, _stream()),
+                    "rift_loss_finalize")
+        return loss
+
+    # ---- single ops ---------------------------------------------------------------------------
+    def op_linear(self, x, w, b=None, ln_w=None, ln_b=None, act=0, fp32=False):
+        x = _dev(x, torch.float32, self.device)
+        w = _dev(w, torch.float32, self.device)
+        b = None if b is None else _dev(b, torch.float32, self.device)
+        ln_w = None if ln_w is None else _dev(ln_w, torch.float32, self.device)
+        ln_b = None if ln_b is None else _dev(ln_b, torch.float32, self.device)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, device=self.device)
+        self._check(self.lib.rift_op_linear(self.ctx, _ptr(x), M, K, _ptr(w), _ptr(b), N, _ptr(ln_w), _ptr(ln_b), act,
+                                            1 if fp32 else 0, _ptr(y), _stream()), "rift_op_linear")
+        return y
+
+    def gae(self, rewards, undones, values, next_values, unterminated, gamma=0.98, lambda_=0.98):
+        dev = self.device
+        r = _dev(rewards, torch.float64, dev)
+        a = [_dev(t, torch.float32, dev) for t in (undones, values, next_values, unterminated)]
+        n = r.numel()
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        self._check(self.lib.rift_gae(self.ctx, _ptr(r), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), gamma, lambda_, n,
+                                      _ptr(out), _stream()), "rift_gae")
+        return out
+
+    def discounted_return(self, rewards, dones, gamma=0.98):
+        dev = self.device
+        r = _dev(rewards, torch.float64, dev)
+        d = _dev(dones, torch.float32, dev)
+        out = torch.empty(r.numel(), dtype=torch.float64, device=dev)
+        self._check(self.lib.rift_discounted_return(self.ctx, _ptr(r), _ptr(d), gamma, r.numel(), _ptr(out), _stream()),
+                    "rift_discounted_return")
+        return out
+
+    def normalize_advantage_(self, x):
+        assert x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+        self._check(self.lib.rift_normalize_advantage(self.ctx, _ptr(x), x.numel(), _stream()), "rift_normalize_advantage")
+        return x
+
+    def group_advantage(self, returns):
+        r = _dev(returns, torch.float64, self.device)
+        ng, G = r.shape
+        out = torch.empty_like(r)
+        self._check(self.lib.rift_group_advantage(self.ctx, _ptr(r), ng, G, _ptr(out), _stream()), "rift_group_advantage")
+        return out
+
+    def rollout_return(self, delta_dis, delta_angle, speed, acc, ang_vel, ang_acc, collision, off_road, gamma=0.98):
+        dev = self.device
+        f = [_dev(t, torch.float32, dev) for t in (delta_dis, delta_angle, speed, acc, ang_vel, ang_acc)]
+        col, off = _dev(collision, torch.bool, dev), _dev(off_road, torch.bool, dev)
+        G, Ts = f[1].shape
+        out = torch.empty(G, dtype=torch.float64, device=dev)
+        self._check(self.lib.rift_rollout_return(self.ctx, *[_ptr(t) for t in f], _ptr(col), col.shape[1], _ptr(off),
+                                                 off.shape[1], G, Ts, gamma, _ptr(out), _stream()), "rift_rollout_return")
+        return out

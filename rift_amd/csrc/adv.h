@@ -1,0 +1,160 @@
+// Advantage / return kernels of the RLFT update (gfx950): GAE and discounted-return reverse
+// scans as wavefront scans of affine maps, buffer-wide and per-group z-scores with shuffle
+// reductions, the dense-reward rollout return, and the replay-arena gather (collation).
+// All of them are latency / HBM bound scalar work -- no MFMA.
+#pragma once
+#include "common.h"
+
+namespace rift {
+
+// ---------------------------------------------------------------------------
+// Reverse affine scan  x_t = b_t + a_t * x_{t+1},  x_n = 0, in fp64, by ONE wave:
+// lane l owns the contiguous chunk [l*ch, (l+1)*ch); pass 1 composes the chunk map,
+// a shuffle scan (right to left) yields each chunk's incoming x, pass 2 replays the chunk.
+// ---------------------------------------------------------------------------
+struct GaeCoef {    // get_advantages_GAE, ppo_datamodule.py:22-37 (dtype promotion mirrored: fp64 rewards, fp32 rest)
+  const double* rewards; const float* undones; const float* values; const float* next_values; const float* unterminated;
+  float gamma, lambda_;
+  __device__ __forceinline__ void get(int t, double& a, double& b) const {
+    const float t2 = (unterminated[t] * gamma) * next_values[t];
+    b = rewards[t] + (double)t2 - (double)values[t];
+    a = (double)((undones[t] * gamma) * lambda_);
+  }
+};
+struct ReturnCoef { // compute_return, reinforce_datamodule.py:19-38
+  const double* rewards; const float* dones; double gamma;
+  __device__ __forceinline__ void get(int t, double& a, double& b) const {
+    b = rewards[t];
+    a = (dones[t] == 1.0f) ? 0.0 : gamma;
+  }
+};
+
+template <class Coef, class OutT>
+__global__ __launch_bounds__(64) void affine_scan_reverse_kernel(Coef c, int n, OutT* __restrict__ out) {
+  const int lane = threadIdx.x;
+  const int ch = (n + 63) / 64;
+  const int lo = lane * ch, hi = min(n, lo + ch);
+  // chunk composite: x_lo = B + A * x_hi
+  double A = 1.0, B = 0.0;
+  for (int t = hi - 1; t >= lo; --t) { double a, b; c.get(t, a, b); B = b + a * B; A = a * A; }
+  // inclusive scan from the right: after it, (A,B) maps x_n(=0) to x at this lane's chunk start
+  for (int o = 1; o < 64; o <<= 1) {
+    const double Ar = __shfl_down(A, o, 64), Br = __shfl_down(B, o, 64);
+    if (lane + o < 64) { B = B + A * Br; A = A * Ar; }
+  }
+  // incoming value for this chunk = x at the start of the next lane's chunk
+  double x = __shfl_down(B, 1, 64);
+  if (lane == 63) x = 0.0;
+  for (int t = hi - 1; t >= lo; --t) { double a, b; c.get(t, a, b); x = b + a * x; out[t] = (OutT)x; }
+}
+
+// (x - mean) / (std_unbiased + 1e-5) in place over n fp32 values (ppo_datamodule.py:166); one workgroup.
+__global__ __launch_bounds__(256) void normalize_unbiased_kernel(float* __restrict__ x, int n) {
+  __shared__ double s_a[4], s_b[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0.0;
+  for (int i = tid; i < n; i += 256) s += (double)x[i];
+  s = wave_sum_d(s);
+  if (lane == 0) s_a[wave] = s;
+  __syncthreads();
+  const double mean = (s_a[0] + s_a[1] + s_a[2] + s_a[3]) / (double)n;
+  double q = 0.0;
+  for (int i = tid; i < n; i += 256) { const double d = (double)x[i] - mean; q += d * d; }
+  q = wave_sum_d(q);
+  if (lane == 0) s_b[wave] = q;
+  __syncthreads();
+  const double var = (s_b[0] + s_b[1] + s_b[2] + s_b[3]) / (double)(n > 1 ? n - 1 : 1);
+  const float meanf = (float)mean, den = (float)sqrt(var) + 1e-5f;
+  for (int i = tid; i < n; i += 256) x[i] = (x[i] - meanf) / den;
+}
+
+// GRPO group z-score (traj_evaluator.py:467-470): one wave per group of G fp64 returns, ddof 0, +1e-5.
+__global__ void group_zscore_kernel(const double* __restrict__ ret, int n_groups, int G, double* __restrict__ adv) {
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (g >= n_groups) return;
+  double s = 0.0;
+  for (int i = lane; i < G; i += 64) s += ret[(size_t)g * G + i];
+  const double mean = wave_sum_d(s) / (double)G;
+  double q = 0.0;
+  for (int i = lane; i < G; i += 64) { const double d = ret[(size_t)g * G + i] - mean; q += d * d; }
+  const double sd = sqrt(wave_sum_d(q) / (double)G) + 1e-5;
+  for (int i = lane; i < G; i += 64) adv[(size_t)g * G + i] = (ret[(size_t)g * G + i] - mean) / sd;
+}
+
+// Dense reward (gym_carla/reward/reward_model.py:34-50) with the dtype promotion of the
+// reference environment (numpy 1.24: np.float32 scalar (op) python float -> float64; f32 (op) f32 -> f32).
+__device__ __forceinline__ double dense_reward(float dd_abs, float da_abs, float speed, float acc, float ang_acc,
+                                               int collision, int offroad) {
+  const float aspeed = fabsf(speed);
+  const double r_collision = -(20.0 + (double)aspeed) * (double)collision;
+  const double r_offroad = -5.0 * (double)offroad;
+  const double r_comfort = -0.8 * (double)((fabsf(acc) > 4.f ? 1 : 0) + (fabsf(ang_acc) > 4.f ? 1 : 0));
+  const float c = cosf(da_abs);
+  const float cs = c * speed;                                  // f32 * f32
+  const double r_l_align = 0.5 * ((double)fminf(c, 0.f) + 0.05 * (double)fminf(cs, 0.f) +
+                                  0.25 * (1.0 - (double)da_abs / (3.141592653589793 / 2.0)));
+  const double dd = (double)dd_abs;                            // abs(delta_dis - 0.0) in f64
+  const double r_l_center = -0.6 * (double)(c > 0.5f ? 1 : 0) * (dd - 0.05 / exp(dd - 0.5));
+  const double r_velocity = 0.1 * (double)fmaxf(c, 0.f) * (double)((aspeed > 3.f && aspeed < 20.f) ? 1 : 0) * (double)aspeed;
+  const double r_timestep = -0.1 * (double)((aspeed > 0.f || fabsf(acc) > 0.f) ? 1 : 0);
+  return r_collision + r_offroad + r_comfort + r_l_align + r_l_center + r_velocity + r_timestep;
+}
+
+// get_rollout_return (traj_evaluator.py:333-370): one thread per candidate, sequential over Ts,
+// stop after the first colliding step (inclusive).
+__global__ void rollout_return_kernel(const float* __restrict__ delta_dis, const float* __restrict__ delta_angle,
+                                      const float* __restrict__ speed, const float* __restrict__ acc,
+                                      const float* __restrict__ ang_vel, const float* __restrict__ ang_acc,
+                                      const uint8_t* __restrict__ collision, int col_ld,
+                                      const uint8_t* __restrict__ off_road, int off_ld, int G, int Ts, double gamma,
+                                      double* __restrict__ ret) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G) return;
+  (void)ang_vel;
+  double r = 0.0;
+  for (int j = 0; j < Ts; ++j) {
+    const size_t o = (size_t)i * Ts + j;
+    const int col = collision[(size_t)i * col_ld + j] ? 1 : 0;
+    const int off = off_road[(size_t)i * off_ld + j] ? 1 : 0;
+    r += dense_reward(fabsf(delta_dis[o]), fabsf(delta_angle[o]), speed[o], acc[o], ang_acc[o], col, off) *
+         pow(gamma, (double)j);
+    if (col) break;
+  }
+  ret[i] = r;
+}
+
+// ---------------------------------------------------------------------------
+// Replay-arena gather (collation): for tensor k, scene b:
+//   dst_k[b*dst_bytes .. +dst_bytes) = src_k[idx[b]*src_bytes .. +dst_bytes)
+// (the ragged dimension R leads each per-scene block, so cropping to the batch
+// maximum is a prefix copy; arena rows beyond a scene's own count are stored as zeros).
+// ---------------------------------------------------------------------------
+#define RIFT_COLLATE_MAXT 40
+struct CollateP {
+  int nt;
+  const unsigned char* src[RIFT_COLLATE_MAXT];
+  unsigned char* dst[RIFT_COLLATE_MAXT];
+  int src_bytes[RIFT_COLLATE_MAXT];
+  int dst_bytes[RIFT_COLLATE_MAXT];
+};
+
+__global__ void collate_kernel(CollateP p, const int32_t* __restrict__ scene_idx) {
+  const int k = blockIdx.y, b = blockIdx.x;
+  const unsigned char* s = p.src[k] + (size_t)scene_idx[b] * p.src_bytes[k];
+  unsigned char* d = p.dst[k] + (size_t)b * p.dst_bytes[k];
+  const int n = p.dst_bytes[k];
+  if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)n) & 15) == 0) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    uint4* d4 = reinterpret_cast<uint4*>(d);
+    for (int i = threadIdx.x; i < (n >> 4); i += blockDim.x) d4[i] = s4[i];
+  } else if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)n) & 3) == 0) {
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
+    for (int i = threadIdx.x; i < (n >> 2); i += blockDim.x) d4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+  }
+}
+
+}  // namespace rift

@@ -1,0 +1,975 @@
+// librift_hip.so : host orchestration + C-ABI of the MI355X-native RIFT policy-update path.
+// See include/rift_hip.h for the interface and DESIGN.md for the kernel inventory.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rift_hip.h"
+#include "adv.h"
+#include "gemm.h"
+#include "kernels.h"
+#include "loss.h"
+
+using namespace rift;
+
+namespace {
+
+struct Param { void* data; int64_t numel; int ndim; int64_t shape[4]; };
+
+struct PW {   // packed weight image of one linear map Y = X W^T (+ b)
+  void* bf = nullptr; float* f32 = nullptr; const float* bias = nullptr;
+  int N = 0, K = 0, Kp = 0, Npad = 0;
+};
+
+struct Tap { float* p; int64_t numel; };
+
+}  // namespace
+
+struct RiftCtx {
+  int device = 0;
+  std::string err;
+  std::unordered_map<std::string, Param> params;
+  std::unordered_map<std::string, PW> pw;
+  std::vector<void*> owned;          // packed weight allocations
+  // activation arena (bump allocator, reset every forward)
+  char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
+  bool dry = false;
+  hipStream_t stream = nullptr;
+  std::unordered_map<std::string, Tap> taps;
+  // state of the last forward, consumed by rift_loss_backward
+  float* last_qfinal = nullptr; float* last_hpi = nullptr; float* last_prob = nullptr;
+  uint8_t* last_rkpm = nullptr; int last_bs = 0, last_R = 0;
+  // loss scratch
+  double* l_S = nullptr; double* l_cnt = nullptr; float* l_dz = nullptr; float* l_partial = nullptr;
+  size_t l_cap_bs = 0, l_cap_rows = 0, l_cap_wg = 0;
+  float* ego_w = nullptr; float* ego_b = nullptr;   // packed (6,128) linears of StateAttentionEncoder
+  bool loaded = false;
+};
+
+#define HIPCHK(ctx, expr)                                                                 \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess) {                                                              \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                    \
+      return RIFT_ERR_HIP;                                                                \
+    }                                                                                     \
+  } while (0)
+
+namespace {
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+template <class T>
+T* A_alloc(RiftCtx* c, size_t n) {
+  size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+  char* p = c->dry ? nullptr : c->arena + c->arena_off;
+  c->arena_off += bytes;
+  return reinterpret_cast<T*>(p);
+}
+
+void tap(RiftCtx* c, const char* name, float* p, int64_t numel) {
+  if (!c->dry) c->taps[name] = Tap{p, numel};
+}
+
+template <class... KArgs, class... Args>
+void launch(RiftCtx* c, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
+  if (c->dry || grid.x == 0 || grid.y == 0) return;
+  hipLaunchKernelGGL(kern, grid, block, shmem, c->stream, static_cast<KArgs>(args)...);
+}
+
+const Param* find(RiftCtx* c, const std::string& name) {
+  auto it = c->params.find(name);
+  return it == c->params.end() ? nullptr : &it->second;
+}
+
+const float* fptr(RiftCtx* c, const std::string& name) {
+  const Param* p = find(c, name);
+  if (!p) { if (c->err.empty()) c->err = "missing parameter: " + name; return nullptr; }
+  return reinterpret_cast<const float*>(p->data);
+}
+
+// ---- weight packing -------------------------------------------------------------------
+int pack(RiftCtx* c, const std::string& key, const float* src, int n_src, int N, int K, int src_row_off,
+         int src_col_off, int src_ld, int conv_C, int tap_lo, int tap_n, const float* bias) {
+  PW w;
+  w.N = N; w.K = K; w.Kp = (K + 31) & ~31; w.Npad = (N + 15) & ~15; w.bias = bias;
+  const size_t cnt = (size_t)w.Npad * w.Kp;
+  HIPCHK(c, hipMalloc(&w.bf, cnt * 2));
+  HIPCHK(c, hipMalloc((void**)&w.f32, cnt * 4));
+  c->owned.push_back(w.bf); c->owned.push_back(w.f32);
+  const int blocks = cdiv((long long)cnt, 256);
+  hipLaunchKernelGGL(pack_weight_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, src + src_col_off, w.bf, n_src, K,
+                     w.Npad, w.Kp, conv_C, tap_lo, tap_n, src_row_off, src_ld);
+  hipLaunchKernelGGL(pack_weight_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, src + src_col_off, (void*)w.f32,
+                     n_src, K, w.Npad, w.Kp, conv_C, tap_lo, tap_n, src_row_off, src_ld);
+  c->pw[key] = w;
+  return RIFT_OK;
+}
+
+int pack_linear(RiftCtx* c, const std::string& prefix) {   // nn.Linear
+  const Param* w = find(c, prefix + ".weight");
+  if (!w || w->ndim != 2) { c->err = "missing linear " + prefix; return RIFT_ERR_ARG; }
+  const Param* b = find(c, prefix + ".bias");
+  return pack(c, prefix, (const float*)w->data, (int)w->shape[0], (int)w->shape[0], (int)w->shape[1], 0, 0,
+              (int)w->shape[1], 0, 0, 0, b ? (const float*)b->data : nullptr);
+}
+
+int pack_conv(RiftCtx* c, const std::string& prefix) {     // nn.Conv1d k=3 -> tap-major [N][3*C]
+  const Param* w = find(c, prefix + ".weight");
+  if (!w || w->ndim != 3 || w->shape[2] != 3) { c->err = "missing conv " + prefix; return RIFT_ERR_ARG; }
+  const Param* b = find(c, prefix + ".bias");
+  const int C = (int)w->shape[1];
+  return pack(c, prefix, (const float*)w->data, (int)w->shape[0], (int)w->shape[0], 3 * C, 0, 0, 0, C, 0, 3,
+              b ? (const float*)b->data : nullptr);
+}
+
+// rows [r0, r0+n_src) of an (R, K) matrix as a GEMM with N output columns (rows beyond n_src are zero)
+int pack_rows(RiftCtx* c, const std::string& key, const std::string& wname, const std::string& bname, int r0,
+              int n_src, int N) {
+  const Param* w = find(c, wname);
+  if (!w || w->ndim != 2) { c->err = "missing matrix " + wname; return RIFT_ERR_ARG; }
+  const Param* b = bname.empty() ? nullptr : find(c, bname);
+  return pack(c, key, (const float*)w->data, n_src, N, (int)w->shape[1], r0, 0, (int)w->shape[1], 0, 0, 0,
+              b ? (const float*)b->data + r0 : nullptr);
+}
+
+// columns [c0, c0+K) of a Linear weight (N, Ktot)
+int pack_cols(RiftCtx* c, const std::string& key, const std::string& prefix, int c0, int K, bool with_bias) {
+  const Param* w = find(c, prefix + ".weight");
+  if (!w || w->ndim != 2) { c->err = "missing linear " + prefix; return RIFT_ERR_ARG; }
+  const Param* b = with_bias ? find(c, prefix + ".bias") : nullptr;
+  return pack(c, key, (const float*)w->data, (int)w->shape[0], (int)w->shape[0], K, 0, c0, (int)w->shape[1], 0, 0, 0,
+              b ? (const float*)b->data : nullptr);
+}
+
+#define TRY(x) do { int rc__ = (x); if (rc__ != RIFT_OK) return rc__; } while (0)
+
+int pack_mlp_layer(RiftCtx* c, const std::string& p) { TRY(pack_linear(c, p + ".mlp.0")); return pack_linear(c, p + ".mlp.3"); }
+
+int pack_fourier(RiftCtx* c, const std::string& p, int D) {
+  for (int d = 0; d < D; ++d) {
+    TRY(pack_linear(c, p + ".mlps." + std::to_string(d) + ".0"));
+    TRY(pack_linear(c, p + ".mlps." + std::to_string(d) + ".3"));
+  }
+  return pack_linear(c, p + ".to_out.2");
+}
+
+int pack_points_encoder(RiftCtx* c, const std::string& p) {
+  TRY(pack_linear(c, p + ".first_mlp.0"));
+  TRY(pack_linear(c, p + ".first_mlp.3"));
+  TRY(pack_cols(c, p + ".second_mlp.0.feat", p + ".second_mlp.0", 0, 256, true));
+  TRY(pack_cols(c, p + ".second_mlp.0.pool", p + ".second_mlp.0", 256, 256, false));
+  return pack_linear(c, p + ".second_mlp.3");
+}
+
+int pack_self_mha(RiftCtx* c, const std::string& p) {
+  TRY(pack_rows(c, p + ".qkv", p + ".in_proj_weight", p + ".in_proj_bias", 0, 384, 384));
+  return pack_linear(c, p + ".out_proj");
+}
+
+// ---- GEMM dispatch -----------------------------------------------------------------------
+GemmP mk(const float* X, int ldx, int M, const PW& w, float* Y, int ldy) {
+  GemmP g;
+  memset(&g, 0, sizeof(g));
+  g.X = X; g.ldx = ldx; g.M = M; g.N = w.N; g.K = w.K; g.Kp = w.Kp; g.bias = w.bias; g.Y = Y; g.ldy = ldy;
+  g.ln_eps = 1e-5f; g.gb_div = 1; g.dp_div = 1; g.rz_div = 1;
+  return g;
+}
+
+template <bool BF16>
+void gemm_launch(RiftCtx* c, const GemmP& g) {
+  const size_t lds = (size_t)64 * (g.Kp + Prec<BF16>::PAD) * sizeof(typename Prec<BF16>::lds_t);
+  const dim3 grid(cdiv(g.M, 64)), block(256);
+  if (g.N <= 128) launch(c, gemm_rows_kernel<BF16, 1, 8, 4, 1>, grid, block, lds, g);
+  else if (g.N <= 192) launch(c, gemm_rows_kernel<BF16, 2, 6, 2, 2>, grid, block, lds, g);
+  else launch(c, gemm_rows_kernel<BF16, 4, 4, 1, 4>, grid, block, lds, g);
+}
+
+void gemm(RiftCtx* c, GemmP g, const PW& w, bool fp32) {
+  if (g.M <= 0) return;
+  if (fp32) { g.W = w.f32; gemm_launch<false>(c, g); }
+  else { g.W = w.bf; gemm_launch<true>(c, g); }
+}
+
+int set_lds_attrs(RiftCtx* c) {
+  const int big = 160 * 1024;
+#define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
+  SETATTR((gemm_rows_kernel<true, 1, 8, 4, 1>));
+  SETATTR((gemm_rows_kernel<true, 2, 6, 2, 2>));
+  SETATTR((gemm_rows_kernel<true, 4, 4, 1, 4>));
+  SETATTR((gemm_rows_kernel<false, 1, 8, 4, 1>));
+  SETATTR((gemm_rows_kernel<false, 2, 6, 2, 2>));
+  SETATTR((gemm_rows_kernel<false, 4, 4, 1, 4>));
+#undef SETATTR
+  return RIFT_OK;
+}
+
+struct Fwd {   // per-forward context
+  RiftCtx* c; bool train, drop, fp32, need_traj, bn_update; uint32_t seed; uint32_t stream_id = 1;
+  uint32_t next_stream() { return stream_id++; }
+};
+
+void layernorm(Fwd& f, const float* X, int ldx, float* Y, int ldy, int rows, int C, const std::string& name, int relu = 0) {
+  RiftCtx* c = f.c;
+  launch(c, layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, X, ldx, Y, ldy, rows, C, fptr(c, name + ".weight"),
+         fptr(c, name + ".bias"), 1e-5f, relu);
+}
+
+// FourierEmbedding (fourier_embedding.py:45-55): in (rows, D) -> out (rows, 128)
+float* fourier(Fwd& f, const float* in, int in_ld, int rows, int D, const std::string& p, int wrap_dim) {
+  RiftCtx* c = f.c;
+  float* FF = A_alloc<float>(c, (size_t)D * rows * 129);
+  launch(c, fourier_feature_kernel, dim3(cdiv((long long)D * rows * 65, 256)), dim3(256), 0, in, in_ld, rows, D,
+         fptr(c, p + ".freqs.weight"), wrap_dim, FF);
+  float* T1 = A_alloc<float>(c, (size_t)rows * 128);
+  float* acc = A_alloc<float>(c, (size_t)rows * 128);
+  for (int d = 0; d < D; ++d) {
+    const std::string m = p + ".mlps." + std::to_string(d);
+    GemmP g = mk(FF + (size_t)d * rows * 129, 129, rows, c->pw[m + ".0"], T1, 128);
+    gemm(c, g, c->pw[m + ".0"], f.fp32);
+    GemmP g2 = mk(T1, 128, rows, c->pw[m + ".3"], acc, 128);
+    g2.pro = PRO_LN; g2.pg = fptr(c, m + ".1.weight"); g2.pb = fptr(c, m + ".1.bias"); g2.pro_relu = 1;
+    if (d > 0) { g2.residual = acc; g2.ldr = 128; }
+    gemm(c, g2, c->pw[m + ".3"], f.fp32);
+  }
+  float* out = A_alloc<float>(c, (size_t)rows * 128);
+  GemmP g3 = mk(acc, 128, rows, c->pw[p + ".to_out.2"], out, 128);
+  g3.pro = PRO_LN; g3.pg = fptr(c, p + ".to_out.0.weight"); g3.pb = fptr(c, p + ".to_out.0.bias"); g3.pro_relu = 1;
+  gemm(c, g3, c->pw[p + ".to_out.2"], f.fp32);
+  return out;
+}
+
+// BatchNorm1d folded to an affine (scale, shift) for the next GEMM prologue.
+void batchnorm_affine(Fwd& f, const float* X, int rows, int C, const uint8_t* valid, const std::string& name,
+                      float** scale, float** shift) {
+  RiftCtx* c = f.c;
+  *scale = A_alloc<float>(c, C); *shift = A_alloc<float>(c, C);
+  const int rows_per_blk = 512;
+  const int nblk = cdiv(rows, rows_per_blk);
+  double* part = A_alloc<double>(c, (size_t)nblk * 2 * C);
+  int* cnt = A_alloc<int>(c, nblk);
+  if (f.train) launch(c, bn_partial_kernel, dim3(nblk), dim3(C), 0, X, C, rows, C, valid, part, cnt, rows_per_blk);
+  const Param* nb = find(c, name + ".num_batches_tracked");
+  launch(c, bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (const double*)part, (const int*)cnt, nblk, C,
+         fptr(c, name + ".weight"), fptr(c, name + ".bias"), (float*)fptr(c, name + ".running_mean"),
+         (float*)fptr(c, name + ".running_var"), nb ? (long long*)nb->data : (long long*)nullptr, f.train ? 1 : 0,
+         f.bn_update ? 1 : 0, 1e-5f, *scale, *shift);
+}
+
+// PointsEncoder (embedding.py:271-296): F (groups*n, Cin) -> (groups, 128)
+float* points_encoder(Fwd& f, const float* F, int Cin, int groups, int n, const uint8_t* valid, const std::string& p) {
+  RiftCtx* c = f.c;
+  const int rows = groups * n;
+  float* H1 = A_alloc<float>(c, (size_t)rows * 128);
+  gemm(c, mk(F, Cin, rows, c->pw[p + ".first_mlp.0"], H1, 128), c->pw[p + ".first_mlp.0"], f.fp32);
+  float *s1, *t1;
+  batchnorm_affine(f, H1, rows, 128, valid, p + ".first_mlp.1", &s1, &t1);
+  float* F256 = A_alloc<float>(c, (size_t)rows * 256);
+  GemmP g = mk(H1, 128, rows, c->pw[p + ".first_mlp.3"], F256, 256);
+  g.pro = PRO_AFFINE; g.pg = s1; g.pb = t1; g.pro_relu = 1;
+  gemm(c, g, c->pw[p + ".first_mlp.3"], f.fp32);
+  float* pooled = A_alloc<float>(c, (size_t)groups * 256);
+  launch(c, masked_maxpool_kernel, dim3(cdiv((long long)groups * 256, 256)), dim3(256), 0, (const float*)F256, 256, groups, n, 256,
+         valid, pooled);
+  float* G1 = A_alloc<float>(c, (size_t)groups * 256);
+  gemm(c, mk(pooled, 256, groups, c->pw[p + ".second_mlp.0.pool"], G1, 256), c->pw[p + ".second_mlp.0.pool"], f.fp32);
+  float* H2 = A_alloc<float>(c, (size_t)rows * 256);
+  GemmP g2 = mk(F256, 256, rows, c->pw[p + ".second_mlp.0.feat"], H2, 256);
+  g2.gbias = G1; g2.gb_div = n; g2.gb_mod = 0;
+  gemm(c, g2, c->pw[p + ".second_mlp.0.feat"], f.fp32);
+  float *s2, *t2;
+  batchnorm_affine(f, H2, rows, 256, valid, p + ".second_mlp.1", &s2, &t2);
+  float* O = A_alloc<float>(c, (size_t)rows * 128);
+  GemmP g3 = mk(H2, 256, rows, c->pw[p + ".second_mlp.3"], O, 128);
+  g3.pro = PRO_AFFINE; g3.pg = s2; g3.pb = t2; g3.pro_relu = 1;
+  gemm(c, g3, c->pw[p + ".second_mlp.3"], f.fp32);
+  float* out = A_alloc<float>(c, (size_t)groups * 128);
+  launch(c, masked_maxpool_kernel, dim3(cdiv((long long)groups * 128, 256)), dim3(256), 0, (const float*)O, 128, groups, n, 128,
+         valid, out);
+  return out;
+}
+
+void run_mha(RiftCtx* c, const MhaP& p) {
+  const long long total = (long long)p.nb_outer * p.nb_inner * p.H * p.Lq;
+  launch(c, mha_kernel, dim3(cdiv(total, 64)), dim3(64), 0, p);
+}
+
+// NAT block (embedding.py:196-202) on X (rows, C) in place
+void nat_layer(Fwd& f, float* X, int rows, int C, int H, int ksz, int L, const std::string& p, float droppath) {
+  RiftCtx* c = f.c;
+  float* QKV = A_alloc<float>(c, (size_t)rows * 3 * C);
+  GemmP g = mk(X, C, rows, c->pw[p + ".attn.qkv"], QKV, 3 * C);
+  g.pro = PRO_LN; g.pg = fptr(c, p + ".norm1.weight"); g.pb = fptr(c, p + ".norm1.bias");
+  gemm(c, g, c->pw[p + ".attn.qkv"], f.fp32);
+  float* AO = A_alloc<float>(c, (size_t)rows * C);
+  const int nthreads = rows * H;
+  if (ksz == 3) launch(c, nat_attention_kernel<3>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (const float*)QKV, fptr(c, p + ".attn.rpb"), rows / L, L, H, AO);
+  else launch(c, nat_attention_kernel<5>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (const float*)QKV, fptr(c, p + ".attn.rpb"), rows / L, L, H, AO);
+  GemmP g2 = mk(AO, C, rows, c->pw[p + ".attn.proj"], X, C);
+  g2.residual = X; g2.ldr = C;
+  if (f.drop && droppath > 0.f) { g2.droppath_p = droppath; g2.dp_div = L; g2.seed = f.seed; g2.stream = f.next_stream(); }
+  gemm(c, g2, c->pw[p + ".attn.proj"], f.fp32);
+  float* Hh = A_alloc<float>(c, (size_t)rows * 3 * C);
+  GemmP g3 = mk(X, C, rows, c->pw[p + ".mlp.fc1"], Hh, 3 * C);
+  g3.pro = PRO_LN; g3.pg = fptr(c, p + ".norm2.weight"); g3.pb = fptr(c, p + ".norm2.bias"); g3.act = ACT_GELU;
+  gemm(c, g3, c->pw[p + ".mlp.fc1"], f.fp32);
+  GemmP g4 = mk(Hh, 3 * C, rows, c->pw[p + ".mlp.fc2"], X, C);
+  g4.residual = X; g4.ldr = C;
+  if (f.drop && droppath > 0.f) { g4.droppath_p = droppath; g4.dp_div = L; g4.seed = f.seed; g4.stream = f.next_stream(); }
+  gemm(c, g4, c->pw[p + ".mlp.fc2"], f.fp32);
+}
+
+// MLPLayer (mlp_layer.py:8-16): X (rows,128) -> out (rows, Nout) with hidden width Hd
+void mlp_layer(Fwd& f, const float* X, int ldx, int rows, const std::string& p, float* out, int ldo, bool fp32) {
+  RiftCtx* c = f.c;
+  const PW& w0 = c->pw[p + ".mlp.0"];
+  float* T = A_alloc<float>(c, (size_t)rows * w0.N);
+  gemm(c, mk(X, ldx, rows, w0, T, w0.N), w0, fp32);
+  const PW& w3 = c->pw[p + ".mlp.3"];
+  GemmP g = mk(T, w0.N, rows, w3, out, ldo);
+  g.pro = PRO_LN; g.pg = fptr(c, p + ".mlp.1.weight"); g.pb = fptr(c, p + ".mlp.1.bias"); g.pro_relu = 1;
+  gemm(c, g, w3, fp32);
+}
+
+__global__ void interleave_traj_kernel(const float* __restrict__ loc, const float* __restrict__ yaw,
+                                       const float* __restrict__ vel, int rows, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (row, t, c6)
+  if (idx >= rows * 480) return;
+  const int c6 = idx % 6, t = (idx / 6) % 80, r = idx / 480;
+  const float* src = c6 < 2 ? loc : (c6 < 4 ? yaw : vel);
+  out[idx] = src[(size_t)r * 160 + t * 2 + (c6 & 1)];
+}
+
+int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, int flags, uint32_t seed) {
+  Fwd f;
+  f.c = c; f.train = (flags & RIFT_F_TRAIN) != 0; f.drop = f.train && !(flags & RIFT_F_NO_DROP);
+  f.fp32 = (flags & RIFT_F_FP32) != 0; f.need_traj = (flags & RIFT_F_NEED_TRAJ) != 0;
+  f.bn_update = f.train && !(flags & RIFT_F_NO_BN_UPDATE); f.seed = seed;
+  const int bs = B->bs, A = B->A, Mp = B->Mp, R = B->R, S = B->S, T = B->T;
+  const int N = A + Mp + S, M = 12;
+  const int nA = bs * A, nP = bs * Mp, nL = bs * R, nQ = nL * M, nT = bs * N;
+  const std::string HE = "agent_encoder.history_encoder";
+
+  // ================= agent encoder (agent_encoder.py:54-96, embedding.py:62-87) =================
+  float* F9 = A_alloc<float>(c, (size_t)nA * 20 * 9);
+  uint8_t* valid_agent = A_alloc<uint8_t>(c, nA);
+  launch(c, agent_feature_kernel, dim3(cdiv((long long)nA * 20, 256)), dim3(256), 0, B->agent_position, B->agent_heading,
+         B->agent_velocity, B->agent_shape, B->agent_valid_mask, nA, T, F9, valid_agent);
+  float* X0 = A_alloc<float>(c, (size_t)nA * 20 * 32);
+  {
+    GemmP g = mk(F9, 9, nA * 20, c->pw[HE + ".embed.proj"], X0, 32);
+    g.amode = AMODE_CONV3; g.cv_C = 9; g.cv_Lin = 20; g.cv_nout = 20; g.cv_t0 = 0; g.cv_stride = 1;
+    gemm(c, g, c->pw[HE + ".embed.proj"], f.fp32);
+  }
+  static const float dpr[6] = {0.f, 0.04f, 0.08f, 0.12f, 0.16f, 0.2f};   // linspace(0, 0.2, 6), embedding.py:30
+  nat_layer(f, X0, nA * 20, 32, 2, 3, 20, HE + ".levels.0.blocks.0", dpr[0]);
+  nat_layer(f, X0, nA * 20, 32, 2, 3, 20, HE + ".levels.0.blocks.1", dpr[1]);
+  float* X1 = A_alloc<float>(c, (size_t)nA * 10 * 64);
+  {
+    GemmP g = mk(X0, 32, nA * 10, c->pw[HE + ".levels.0.downsample.reduction"], X1, 64);
+    g.amode = AMODE_CONV3; g.cv_C = 32; g.cv_Lin = 20; g.cv_nout = 10; g.cv_t0 = 0; g.cv_stride = 2;
+    gemm(c, g, c->pw[HE + ".levels.0.downsample.reduction"], f.fp32);
+    layernorm(f, X1, 64, X1, 64, nA * 10, 64, HE + ".levels.0.downsample.norm");
+  }
+  nat_layer(f, X1, nA * 10, 64, 4, 3, 10, HE + ".levels.1.blocks.0", dpr[2]);
+  nat_layer(f, X1, nA * 10, 64, 4, 3, 10, HE + ".levels.1.blocks.1", dpr[3]);
+  // level outputs are the PRE-downsample activations (NATBlock returns (downsample(x), x)); X0/X1 are
+  // still needed below, so the downsample writes new buffers.
+  float* X2 = A_alloc<float>(c, (size_t)nA * 5 * 128);
+  {
+    GemmP g = mk(X1, 64, nA * 5, c->pw[HE + ".levels.1.downsample.reduction"], X2, 128);
+    g.amode = AMODE_CONV3; g.cv_C = 64; g.cv_Lin = 10; g.cv_nout = 5; g.cv_t0 = 0; g.cv_stride = 2;
+    gemm(c, g, c->pw[HE + ".levels.1.downsample.reduction"], f.fp32);
+    layernorm(f, X2, 128, X2, 128, nA * 5, 128, HE + ".levels.1.downsample.norm");
+  }
+  nat_layer(f, X2, nA * 5, 128, 8, 5, 5, HE + ".levels.2.blocks.0", dpr[4]);
+  nat_layer(f, X2, nA * 5, 128, 8, 5, 5, HE + ".levels.2.blocks.1", dpr[5]);
+  tap(c, "nat_level2", X2, (int64_t)nA * 5 * 128);
+  // FPN restricted to what out[:, :, -1] depends on: the last 3 steps of each normalised level
+  float* lat[3];
+  {
+    float* Xl[3] = {X0, X1, X2};
+    const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128};
+    for (int i = 0; i < 3; ++i) {
+      float* Oc = A_alloc<float>(c, (size_t)nA * 3 * Cl[i]);
+      // rows (a, j) <- level rows (a*L + L-3 + j): per-agent window via ldx trick is not possible -> 3 strided LN calls
+      for (int j = 0; j < 3; ++j)
+        launch(c, layernorm_kernel, dim3(cdiv(nA, 4)), dim3(256), 0, (const float*)(Xl[i] + (size_t)(Ll[i] - 3 + j) * Cl[i]),
+               Ll[i] * Cl[i], Oc + (size_t)j * Cl[i], 3 * Cl[i], nA, Cl[i],
+               fptr(c, HE + ".norm" + std::to_string(i) + ".weight"), fptr(c, HE + ".norm" + std::to_string(i) + ".bias"),
+               1e-5f, 0);
+      lat[i] = A_alloc<float>(c, (size_t)nA * 2 * 128);
+      const std::string lc = HE + ".lateral_convs." + std::to_string(i);
+      GemmP g = mk(Oc, Cl[i], nA * 2, c->pw[lc], lat[i], 128);
+      g.amode = AMODE_CONV3; g.cv_C = Cl[i]; g.cv_Lin = 3; g.cv_nout = 2; g.cv_t0 = 1; g.cv_stride = 1;
+      gemm(c, g, c->pw[lc], f.fp32);
+    }
+  }
+  float* Z = A_alloc<float>(c, (size_t)nA * 256);
+  launch(c, fpn_merge_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)lat[0], (const float*)lat[1],
+         (const float*)lat[2], nA, Z);
+  float* nat_out = A_alloc<float>(c, (size_t)nA * 128);
+  gemm(c, mk(Z, 256, nA, c->pw[HE + ".fpn_conv.last"], nat_out, 128), c->pw[HE + ".fpn_conv.last"], f.fp32);
+  tap(c, "nat_out", nat_out, (int64_t)nA * 128);
+
+  // ego state token (StateAttentionEncoder, agent_encoder.py:99-140)
+  const std::string EG = "agent_encoder.ego_state_emb";
+  float* E = A_alloc<float>(c, (size_t)bs * 6 * 128);
+  launch(c, ego_token_kernel, dim3(cdiv((long long)bs * 6 * 128, 256)), dim3(256), 0, B->current_state, B->cs_ld,
+         (const float*)c->ego_w, (const float*)c->ego_b, fptr(c, EG + ".pos_embed"), bs, E);
+  float* EKV = A_alloc<float>(c, (size_t)bs * 6 * 256);
+  gemm(c, mk(E, 128, bs * 6, c->pw[EG + ".attn.kv"], EKV, 256), c->pw[EG + ".attn.kv"], f.fp32);
+  float* eq = A_alloc<float>(c, 128);
+  gemm(c, mk(fptr(c, EG + ".query"), 128, 1, c->pw[EG + ".attn.q"], eq, 128), c->pw[EG + ".attn.q"], f.fp32);
+  uint8_t* edrop = nullptr;
+  if (f.drop) {
+    edrop = A_alloc<uint8_t>(c, (size_t)bs * 6);
+    launch(c, ego_dropmask_kernel, dim3(cdiv(bs * 6, 256)), dim3(256), 0, bs, 0.75f, f.seed, f.next_stream(), edrop);
+  }
+  float* EAO = A_alloc<float>(c, (size_t)bs * 128);
+  {
+    MhaP p; memset(&p, 0, sizeof(p));
+    p.Q = eq; p.ldq = 128; p.K = EKV; p.V = EKV + 128; p.ldkv = 256; p.O = EAO; p.ldo = 128;
+    p.nb_outer = bs; p.nb_inner = 1; p.H = 4; p.Lq = 1; p.Lk = 6;
+    p.q_outer = 0; p.q_inner = 0; p.q_stride = 0; p.kv_outer = 6; p.kv_inner = 0; p.kv_stride = 1;
+    p.o_outer = 1; p.o_inner = 0; p.o_stride = 0; p.mask = edrop; p.mask_quirk = 0; p.mask_mod = 1;
+    run_mha(c, p);
+  }
+  float* x_ego = A_alloc<float>(c, (size_t)bs * 128);
+  gemm(c, mk(EAO, 128, bs, c->pw[EG + ".attn.out_proj"], x_ego, 128), c->pw[EG + ".attn.out_proj"], f.fp32);
+
+  // ================= tokens =================
+  float* X = A_alloc<float>(c, (size_t)nT * 128);
+  launch(c, agent_token_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)nat_out, (const float*)x_ego,
+         (const uint8_t*)valid_agent, B->agent_category, fptr(c, "agent_encoder.type_emb.weight"), bs, A, N, X);
+
+  // map encoder (map_encoder.py:31-93)
+  float* F10 = A_alloc<float>(c, (size_t)nP * 20 * 10);
+  launch(c, map_feature_kernel, dim3(cdiv((long long)nP * 20, 256)), dim3(256), 0, B->map_point_position, B->map_point_vector,
+         B->map_point_orientation, B->map_polygon_center, nP, F10);
+  float* poly = points_encoder(f, F10, 10, nP, 20, B->map_valid_mask, "map_encoder.polygon_encoder");
+  float* speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
+  launch(c, polygon_token_kernel, dim3(cdiv((long long)nP * 128, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
+         B->map_polygon_on_route, B->map_polygon_tl_status, B->map_polygon_has_speed_limit, (const float*)speed_emb,
+         fptr(c, "map_encoder.type_emb.weight"), fptr(c, "map_encoder.on_route_emb.weight"),
+         fptr(c, "map_encoder.traffic_light_emb.weight"), fptr(c, "map_encoder.unknown_speed_emb.weight"), bs, A, Mp, N, X);
+  if (S > 0) {
+    float* semb = fourier(f, B->static_shape, 2, bs * S, 2, "static_objects_encoder.obj_encoder", -1);
+    launch(c, static_token_kernel, dim3(cdiv((long long)bs * S * 128, 256)), dim3(256), 0, (const float*)semb, B->static_category,
+           B->static_valid_mask, fptr(c, "static_objects_encoder.type_emb.weight"), bs, A, Mp, S, N, X);
+  }
+  tap(c, "x_tokens_nopos", X, (int64_t)nT * 128);
+  uint8_t* kpm = A_alloc<uint8_t>(c, nT);
+  launch(c, token_mask_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, (const uint8_t*)valid_agent, B->map_valid_mask,
+         B->static_valid_mask, bs, A, Mp, S, kpm);
+  float* pos = A_alloc<float>(c, (size_t)nT * 3);
+  launch(c, token_pos_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, B->agent_position, B->agent_heading, T, B->map_polygon_center,
+         B->static_position, B->static_heading, bs, A, Mp, S, pos);
+  float* PE = fourier(f, pos, 3, nT, 3, "pos_emb", 2);
+  launch(c, add_inplace_kernel, dim3(cdiv((long long)nT * 128, 256)), dim3(256), 0, X, (const float*)PE, (size_t)nT * 128);
+  tap(c, "x_tokens", X, (int64_t)nT * 128);
+
+  // ================= encoder blocks (transformer.py:73-94) =================
+  static const float edpr[4] = {0.f, 0.2f / 3.f, 0.4f / 3.f, 0.2f};   // linspace(0, 0.2, 4), pluto_model.py:80-83
+  float* QKV = A_alloc<float>(c, (size_t)nT * 384);
+  float* AO = A_alloc<float>(c, (size_t)nT * 128);
+  float* H512 = A_alloc<float>(c, (size_t)nT * 512);
+  for (int i = 0; i < 4; ++i) {
+    const std::string p = "encoder_blocks." + std::to_string(i);
+    GemmP g = mk(X, 128, nT, c->pw[p + ".attn.qkv"], QKV, 384);
+    g.pro = PRO_LN; g.pg = fptr(c, p + ".norm1.weight"); g.pb = fptr(c, p + ".norm1.bias");
+    gemm(c, g, c->pw[p + ".attn.qkv"], f.fp32);
+    MhaP m; memset(&m, 0, sizeof(m));
+    m.Q = QKV; m.ldq = 384; m.K = QKV + 128; m.V = QKV + 256; m.ldkv = 384; m.O = AO; m.ldo = 128;
+    m.nb_outer = bs; m.nb_inner = 1; m.H = 4; m.Lq = N; m.Lk = N;
+    m.q_outer = N; m.q_stride = 1; m.kv_outer = N; m.kv_stride = 1; m.o_outer = N; m.o_stride = 1;
+    m.mask = kpm; m.mask_mod = 1;
+    run_mha(c, m);
+    GemmP g2 = mk(AO, 128, nT, c->pw[p + ".attn.out_proj"], X, 128);
+    g2.residual = X; g2.ldr = 128;
+    if (f.drop && edpr[i] > 0.f) { g2.droppath_p = edpr[i]; g2.dp_div = N; g2.seed = f.seed; g2.stream = f.next_stream(); }
+    gemm(c, g2, c->pw[p + ".attn.out_proj"], f.fp32);
+    GemmP g3 = mk(X, 128, nT, c->pw[p + ".mlp.fc1"], H512, 512);
+    g3.pro = PRO_LN; g3.pg = fptr(c, p + ".norm2.weight"); g3.pb = fptr(c, p + ".norm2.bias"); g3.act = ACT_GELU;
+    gemm(c, g3, c->pw[p + ".mlp.fc1"], f.fp32);
+    GemmP g4 = mk(H512, 512, nT, c->pw[p + ".mlp.fc2"], X, 128);
+    g4.residual = X; g4.ldr = 128;
+    if (f.drop && edpr[i] > 0.f) { g4.droppath_p = edpr[i]; g4.dp_div = N; g4.seed = f.seed; g4.stream = f.next_stream(); }
+    gemm(c, g4, c->pw[p + ".mlp.fc2"], f.fp32);
+  }
+  float* ENC = A_alloc<float>(c, (size_t)nT * 128);
+  layernorm(f, X, 128, ENC, 128, nT, 128, "norm");
+  tap(c, "enc_out", ENC, (int64_t)nT * 128);
+
+  // ================= agent predictor (agent_predictor.py:17-29) =================
+  if (f.need_traj && out->prediction && A > 1) {
+    const int rows = bs * (A - 1);
+    float* Xa = A_alloc<float>(c, (size_t)rows * 128);
+    launch(c, gather_rows_kernel, dim3(cdiv((long long)rows * 128, 256)), dim3(256), 0, (const float*)ENC, 128, Xa, 128, rows, 128,
+           A - 1, N, 1);
+    float* o3[3];
+    const char* nm[3] = {"loc_predictor", "yaw_predictor", "vel_predictor"};
+    for (int i = 0; i < 3; ++i) {
+      o3[i] = A_alloc<float>(c, (size_t)rows * 160);
+      mlp_layer(f, Xa, 128, rows, std::string("agent_predictor.") + nm[i], o3[i], 160, f.fp32);
+    }
+    launch(c, interleave_traj_kernel, dim3(cdiv((long long)rows * 480, 256)), dim3(256), 0, (const float*)o3[0], (const float*)o3[1],
+           (const float*)o3[2], rows, out->prediction);
+  }
+
+  // ================= planning decoder (planning_decoder.py:135-188) =================
+  const std::string PD = "planning_decoder";
+  float* F6 = A_alloc<float>(c, (size_t)nL * 120 * 6);
+  launch(c, ref_feature_kernel, dim3(cdiv((long long)nL * 120, 256)), dim3(256), 0, B->ref_position, B->ref_vector,
+         B->ref_orientation, nL, F6);
+  uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
+  launch(c, refline_mask_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_valid_mask, nL, r_kpm);
+  float* r_emb = points_encoder(f, F6, 6, nL, 120, B->ref_valid_mask, PD + ".r_encoder");
+  float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
+  launch(c, refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
+  float* RPE = fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1);
+  launch(c, add_inplace_kernel, dim3(cdiv((long long)nL * 128, 256)), dim3(256), 0, r_emb, (const float*)RPE, (size_t)nL * 128);
+  tap(c, "r_emb", r_emb, (int64_t)nL * 128);
+  float* Ra = A_alloc<float>(c, (size_t)nL * 128);
+  gemm(c, mk(r_emb, 128, nL, c->pw[PD + ".q_proj.r"], Ra, 128), c->pw[PD + ".q_proj.r"], f.fp32);
+  float* Mb = A_alloc<float>(c, (size_t)M * 128);
+  gemm(c, mk(fptr(c, PD + ".m_emb"), 128, M, c->pw[PD + ".q_proj.m"], Mb, 128), c->pw[PD + ".q_proj.m"], f.fp32);
+  float* Q = A_alloc<float>(c, (size_t)nQ * 128);
+  launch(c, build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
+
+  float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
+  float* DAO = A_alloc<float>(c, (size_t)nQ * 128);
+  float* DQc = A_alloc<float>(c, (size_t)nQ * 128);
+  float* DH = A_alloc<float>(c, (size_t)nQ * 512);
+  float* KVm = A_alloc<float>(c, (size_t)nT * 256);
+  float* MP = A_alloc<float>(c, (size_t)M * 384);
+  const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
+  for (int i = 0; i < 4; ++i) {
+    const std::string p = PD + ".decoder_blocks." + std::to_string(i);
+    // ---- r2r self attention over the R reference lines of each (scene, mode), with the mask quirk
+    GemmP g = mk(Q, 128, nQ, c->pw[p + ".r2r_attn.qkv"], DQKV, 384);
+    g.pro = PRO_LN; g.pg = fptr(c, p + ".norm1.weight"); g.pb = fptr(c, p + ".norm1.bias");
+    gemm(c, g, c->pw[p + ".r2r_attn.qkv"], f.fp32);
+    {
+      MhaP m; memset(&m, 0, sizeof(m));
+      m.Q = DQKV; m.ldq = 384; m.K = DQKV + 128; m.V = DQKV + 256; m.ldkv = 384; m.O = DAO; m.ldo = 128;
+      m.nb_outer = bs; m.nb_inner = M; m.H = 4; m.Lq = R; m.Lk = R;
+      m.q_outer = R * M; m.q_inner = 1; m.q_stride = M; m.kv_outer = R * M; m.kv_inner = 1; m.kv_stride = M;
+      m.o_outer = R * M; m.o_inner = 1; m.o_stride = M;
+      m.mask = r_kpm; m.mask_quirk = 1; m.mask_mod = bs;   // tgt_key_padding_mask.repeat(M, 1), planning_decoder.py:56-60
+      if (dp > 0.f) { m.dropout_p = dp; m.seed = f.seed; m.stream = f.next_stream(); }
+      run_mha(c, m);
+    }
+    GemmP g2 = mk(DAO, 128, nQ, c->pw[p + ".r2r_attn.out_proj"], Q, 128);
+    g2.residual = Q; g2.ldr = 128;
+    if (dp > 0.f) { g2.dropout_p = dp; g2.seed = f.seed; g2.stream = f.next_stream(); }
+    gemm(c, g2, c->pw[p + ".r2r_attn.out_proj"], f.fp32);
+    // ---- m2m self attention over the 12 modes: q = k = (h + m_pos) W + b, v = h W + b
+    gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MP, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
+    GemmP g3 = mk(Q, 128, nQ, c->pw[p + ".m2m_attn.qkv"], DQKV, 384);
+    g3.pro = PRO_LN; g3.pg = fptr(c, p + ".norm2.weight"); g3.pb = fptr(c, p + ".norm2.bias");
+    g3.gbias = MP; g3.gb_div = 1; g3.gb_mod = M;
+    gemm(c, g3, c->pw[p + ".m2m_attn.qkv"], f.fp32);
+    {
+      MhaP m; memset(&m, 0, sizeof(m));
+      m.Q = DQKV; m.ldq = 384; m.K = DQKV + 128; m.V = DQKV + 256; m.ldkv = 384; m.O = DAO; m.ldo = 128;
+      m.nb_outer = nL; m.nb_inner = 1; m.H = 4; m.Lq = M; m.Lk = M;
+      m.q_outer = M; m.q_stride = 1; m.kv_outer = M; m.kv_stride = 1; m.o_outer = M; m.o_stride = 1;
+      if (dp > 0.f) { m.dropout_p = dp; m.seed = f.seed; m.stream = f.next_stream(); }
+      run_mha(c, m);
+    }
+    GemmP g4 = mk(DAO, 128, nQ, c->pw[p + ".m2m_attn.out_proj"], Q, 128);
+    g4.residual = Q; g4.ldr = 128; g4.rowzero = r_kpm; g4.rz_div = M;   // rows of padded ref lines become 0 (:65-72)
+    if (dp > 0.f) { g4.dropout_p = dp; g4.seed = f.seed; g4.stream = f.next_stream(); }
+    gemm(c, g4, c->pw[p + ".m2m_attn.out_proj"], f.fp32);
+    // ---- cross attention: R*12 queries per scene against the encoder tokens
+    GemmP g5 = mk(Q, 128, nQ, c->pw[p + ".cross_attn.q"], DQc, 128);
+    g5.pro = PRO_LN; g5.pg = fptr(c, p + ".norm3.weight"); g5.pb = fptr(c, p + ".norm3.bias");
+    gemm(c, g5, c->pw[p + ".cross_attn.q"], f.fp32);
+    gemm(c, mk(ENC, 128, nT, c->pw[p + ".cross_attn.kv"], KVm, 256), c->pw[p + ".cross_attn.kv"], f.fp32);
+    {
+      MhaP m; memset(&m, 0, sizeof(m));
+      m.Q = DQc; m.ldq = 128; m.K = KVm; m.V = KVm + 128; m.ldkv = 256; m.O = DAO; m.ldo = 128;
+      m.nb_outer = bs; m.nb_inner = 1; m.H = 4; m.Lq = R * M; m.Lk = N;
+      m.q_outer = R * M; m.q_stride = 1; m.kv_outer = N; m.kv_stride = 1; m.o_outer = R * M; m.o_stride = 1;
+      m.mask = kpm; m.mask_mod = 1;
+      if (dp > 0.f) { m.dropout_p = dp; m.seed = f.seed; m.stream = f.next_stream(); }
+      run_mha(c, m);
+    }
+    GemmP g6 = mk(DAO, 128, nQ, c->pw[p + ".cross_attn.out_proj"], Q, 128);
+    g6.residual = Q; g6.ldr = 128;
+    if (dp > 0.f) { g6.dropout_p = dp; g6.seed = f.seed; g6.stream = f.next_stream(); }
+    gemm(c, g6, c->pw[p + ".cross_attn.out_proj"], f.fp32);
+    // ---- FFN
+    GemmP g7 = mk(Q, 128, nQ, c->pw[p + ".ffn.0"], DH, 512);
+    g7.pro = PRO_LN; g7.pg = fptr(c, p + ".norm4.weight"); g7.pb = fptr(c, p + ".norm4.bias"); g7.act = ACT_RELU;
+    if (dp > 0.f) { g7.dropout_p = dp; g7.seed = f.seed; g7.stream = f.next_stream(); }
+    gemm(c, g7, c->pw[p + ".ffn.0"], f.fp32);
+    GemmP g8 = mk(DH, 512, nQ, c->pw[p + ".ffn.3"], Q, 128);
+    g8.residual = Q; g8.ldr = 128;
+    if (dp > 0.f) { g8.dropout_p = dp; g8.seed = f.seed; g8.stream = f.next_stream(); }
+    gemm(c, g8, c->pw[p + ".ffn.3"], f.fp32);
+  }
+  tap(c, "dec3", Q, (int64_t)nQ * 128);
+  // cat_x_proj(cat[q, enc_emb[:, 0]]) (planning_decoder.py:177-179): ego-token part is a per-scene bias
+  float* x0p = A_alloc<float>(c, (size_t)bs * 128);
+  gemm(c, mk(ENC, N * 128, bs, c->pw[PD + ".cat_x_proj.x"], x0p, 128), c->pw[PD + ".cat_x_proj.x"], f.fp32);
+  float* QF = A_alloc<float>(c, (size_t)nQ * 128);
+  {
+    GemmP g = mk(Q, 128, nQ, c->pw[PD + ".cat_x_proj.q"], QF, 128);
+    g.gbias = x0p; g.gb_div = R * M; g.gb_mod = 0;
+    gemm(c, g, c->pw[PD + ".cat_x_proj.q"], f.fp32);
+  }
+  tap(c, "q_final", QF, (int64_t)nQ * 128);
+  // pi head: first Linear straight from the live (trainable) fp32 parameters, exact-fp32 MFMA
+  float* Hpi = A_alloc<float>(c, (size_t)nQ * 128);
+  {
+    PW w; w.N = 128; w.K = 128; w.Kp = 128; w.Npad = 128;
+    w.f32 = (float*)fptr(c, PD + ".pi_head.mlp.0.weight"); w.bias = fptr(c, PD + ".pi_head.mlp.0.bias");
+    gemm(c, mk(QF, 128, nQ, w, Hpi, 128), w, true);
+  }
+  float* prob = out->probability ? out->probability : A_alloc<float>(c, nQ);
+  launch(c, pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
+         fptr(c, PD + ".pi_head.mlp.1.bias"), fptr(c, PD + ".pi_head.mlp.3.weight"), fptr(c, PD + ".pi_head.mlp.3.bias"),
+         (const uint8_t*)r_kpm, 1e-5f, prob);
+  if (f.need_traj && out->trajectory) {
+    float* o3[3];
+    const char* nm[3] = {"loc_head", "yaw_head", "vel_head"};
+    for (int i = 0; i < 3; ++i) {
+      o3[i] = A_alloc<float>(c, (size_t)nQ * 160);
+      mlp_layer(f, QF, 128, nQ, PD + "." + nm[i], o3[i], 160, f.fp32);
+    }
+    launch(c, interleave_traj_kernel, dim3(cdiv((long long)nQ * 480, 256)), dim3(256), 0, (const float*)o3[0], (const float*)o3[1],
+           (const float*)o3[2], nQ, out->trajectory);
+  }
+  // hidden_proj / ref_free_decoder on the ego token (pluto_model.py:173-180)
+  if (out->hidden) {
+    float* Th = A_alloc<float>(c, (size_t)bs * 128);
+    GemmP g = mk(ENC, N * 128, bs, c->pw["hidden_proj.0"], Th, 128);
+    g.act = ACT_RELU;
+    gemm(c, g, c->pw["hidden_proj.0"], f.fp32);
+    gemm(c, mk(Th, 128, bs, c->pw["hidden_proj.2"], out->hidden, 128), c->pw["hidden_proj.2"], f.fp32);
+  }
+  if (f.need_traj && out->ref_free_trajectory)
+    mlp_layer(f, ENC, N * 128, bs, "ref_free_decoder", out->ref_free_trajectory, 320, f.fp32);
+
+  if (!c->dry) {
+    c->last_qfinal = QF; c->last_hpi = Hpi; c->last_prob = prob; c->last_rkpm = r_kpm; c->last_bs = bs; c->last_R = R;
+  }
+  return RIFT_OK;
+}
+
+}  // namespace
+
+// ============================================================================================
+// C-ABI
+// ============================================================================================
+extern "C" {
+
+int rift_ctx_create(int device, RiftCtx** ctx) {
+  if (!ctx) return RIFT_ERR_ARG;
+  RiftCtx* c = new RiftCtx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
+  int rc = set_lds_attrs(c);
+  if (rc != RIFT_OK) { fprintf(stderr, "rift_ctx_create: %s\n", c->err.c_str()); delete c; return rc; }
+  *ctx = c;
+  return RIFT_OK;
+}
+
+void rift_ctx_destroy(RiftCtx* c) {
+  if (!c) return;
+  for (void* p : c->owned) (void)hipFree(p);
+  if (c->arena) (void)hipFree(c->arena);
+  if (c->l_S) (void)hipFree(c->l_S);
+  if (c->l_cnt) (void)hipFree(c->l_cnt);
+  if (c->l_dz) (void)hipFree(c->l_dz);
+  if (c->l_partial) (void)hipFree(c->l_partial);
+  if (c->ego_w) (void)hipFree(c->ego_w);
+  if (c->ego_b) (void)hipFree(c->ego_b);
+  delete c;
+}
+
+const char* rift_last_error(RiftCtx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* stream) {
+  if (!c || !params) return RIFT_ERR_ARG;
+  c->err.clear();
+  c->stream = (hipStream_t)stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (void* p : c->owned) (void)hipFree(p);
+  c->owned.clear(); c->pw.clear(); c->params.clear();
+  for (int i = 0; i < n; ++i) {
+    Param p; p.data = params[i].data; p.numel = params[i].numel; p.ndim = params[i].ndim;
+    for (int d = 0; d < 4; ++d) p.shape[d] = params[i].shape[d];
+    c->params[params[i].name] = p;
+  }
+  const std::string HE = "agent_encoder.history_encoder";
+  TRY(pack_conv(c, HE + ".embed.proj"));
+  for (int lv = 0; lv < 3; ++lv) {
+    for (int b = 0; b < 2; ++b) {
+      const std::string p = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b);
+      TRY(pack_linear(c, p + ".attn.qkv")); TRY(pack_linear(c, p + ".attn.proj"));
+      TRY(pack_linear(c, p + ".mlp.fc1")); TRY(pack_linear(c, p + ".mlp.fc2"));
+    }
+    if (lv < 2) TRY(pack_conv(c, HE + ".levels." + std::to_string(lv) + ".downsample.reduction"));
+    TRY(pack_conv(c, HE + ".lateral_convs." + std::to_string(lv)));
+  }
+  {  // fpn_conv at the last step: taps 0,1 only -> [128][256]
+    const Param* w = find(c, HE + ".fpn_conv.weight");
+    const Param* b = find(c, HE + ".fpn_conv.bias");
+    if (!w || !b) { c->err = "missing fpn_conv"; return RIFT_ERR_ARG; }
+    TRY(pack(c, HE + ".fpn_conv.last", (const float*)w->data, 128, 128, 256, 0, 0, 0, 128, 0, 2, (const float*)b->data));
+  }
+  const std::string EG = "agent_encoder.ego_state_emb";
+  TRY(pack_rows(c, EG + ".attn.q", EG + ".attn.in_proj_weight", EG + ".attn.in_proj_bias", 0, 128, 128));
+  TRY(pack_rows(c, EG + ".attn.kv", EG + ".attn.in_proj_weight", EG + ".attn.in_proj_bias", 128, 256, 256));
+  TRY(pack_linear(c, EG + ".attn.out_proj"));
+  if (!c->ego_w) { HIPCHK(c, hipMalloc((void**)&c->ego_w, 6 * 128 * 4)); HIPCHK(c, hipMalloc((void**)&c->ego_b, 6 * 128 * 4)); }
+  for (int i = 0; i < 6; ++i) {
+    const float* w = fptr(c, EG + ".linears." + std::to_string(i) + ".weight");
+    const float* b = fptr(c, EG + ".linears." + std::to_string(i) + ".bias");
+    if (!w || !b) return RIFT_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(c->ego_w + i * 128, w, 128 * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ego_b + i * 128, b, 128 * 4, hipMemcpyDeviceToDevice, c->stream));
+  }
+  TRY(pack_points_encoder(c, "map_encoder.polygon_encoder"));
+  TRY(pack_fourier(c, "map_encoder.speed_limit_emb", 1));
+  TRY(pack_fourier(c, "static_objects_encoder.obj_encoder", 2));
+  TRY(pack_fourier(c, "pos_emb", 3));
+  for (int i = 0; i < 4; ++i) {
+    const std::string p = "encoder_blocks." + std::to_string(i);
+    TRY(pack_self_mha(c, p + ".attn"));
+    TRY(pack_linear(c, p + ".mlp.fc1")); TRY(pack_linear(c, p + ".mlp.fc2"));
+  }
+  const char* ap[3] = {"loc_predictor", "yaw_predictor", "vel_predictor"};
+  for (int i = 0; i < 3; ++i) TRY(pack_mlp_layer(c, std::string("agent_predictor.") + ap[i]));
+  const std::string PD = "planning_decoder";
+  TRY(pack_points_encoder(c, PD + ".r_encoder"));
+  TRY(pack_fourier(c, PD + ".r_pos_emb", 3));
+  TRY(pack_cols(c, PD + ".q_proj.r", PD + ".q_proj", 0, 128, true));
+  TRY(pack_cols(c, PD + ".q_proj.m", PD + ".q_proj", 128, 128, false));
+  for (int i = 0; i < 4; ++i) {
+    const std::string p = PD + ".decoder_blocks." + std::to_string(i);
+    TRY(pack_self_mha(c, p + ".r2r_attn"));
+    TRY(pack_self_mha(c, p + ".m2m_attn"));
+    TRY(pack_rows(c, p + ".m2m_attn.qk0", p + ".m2m_attn.in_proj_weight", "", 0, 256, 384));
+    TRY(pack_rows(c, p + ".cross_attn.q", p + ".cross_attn.in_proj_weight", p + ".cross_attn.in_proj_bias", 0, 128, 128));
+    TRY(pack_rows(c, p + ".cross_attn.kv", p + ".cross_attn.in_proj_weight", p + ".cross_attn.in_proj_bias", 128, 256, 256));
+    TRY(pack_linear(c, p + ".cross_attn.out_proj"));
+    TRY(pack_linear(c, p + ".ffn.0")); TRY(pack_linear(c, p + ".ffn.3"));
+  }
+  TRY(pack_cols(c, PD + ".cat_x_proj.q", PD + ".cat_x_proj", 0, 128, true));
+  TRY(pack_cols(c, PD + ".cat_x_proj.x", PD + ".cat_x_proj", 128, 128, false));
+  const char* hd[3] = {"loc_head", "yaw_head", "vel_head"};
+  for (int i = 0; i < 3; ++i) TRY(pack_mlp_layer(c, PD + "." + hd[i]));
+  TRY(pack_linear(c, "hidden_proj.0")); TRY(pack_linear(c, "hidden_proj.2"));
+  TRY(pack_mlp_layer(c, "ref_free_decoder"));
+  // required unpacked tensors: fail early and loudly
+  const char* need[] = {"norm.weight", "agent_encoder.type_emb.weight", "map_encoder.type_emb.weight",
+                        "planning_decoder.m_emb", "planning_decoder.m_pos", "planning_decoder.pi_head.mlp.0.weight",
+                        "planning_decoder.pi_head.mlp.3.weight", "agent_encoder.ego_state_emb.query"};
+  for (const char* nme : need) if (!fptr(c, nme)) return RIFT_ERR_ARG;
+  HIPCHK(c, hipGetLastError());
+  c->loaded = true;
+  return RIFT_OK;
+}
+
+int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, int flags, uint32_t seed, void* stream) {
+  if (!c || !B || !out) return RIFT_ERR_ARG;
+  c->err.clear();
+  if (!c->loaded) { c->err = "rift_forward before rift_model_load"; return RIFT_ERR_STATE; }
+  if (B->bs <= 0 || B->A <= 0 || B->Mp <= 0 || B->R <= 0 || B->S < 0 || B->T < 21) { c->err = "bad batch dims"; return RIFT_ERR_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream;
+  // pass 1 (dry): size the activation arena; pass 2: launch
+  c->dry = true; c->arena_off = 0;
+  int rc = forward_impl(c, B, out, flags, seed);
+  if (rc != RIFT_OK) { c->dry = false; return rc; }
+  const size_t need = c->arena_off;
+  if (need > c->arena_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->arena) HIPCHK(c, hipFree(c->arena));
+    c->arena = nullptr; c->arena_cap = 0;
+    const size_t cap = need + (need >> 3);
+    HIPCHK(c, hipMalloc((void**)&c->arena, cap));
+    c->arena_cap = cap;
+  }
+  c->dry = false; c->arena_off = 0; c->taps.clear();
+  rc = forward_impl(c, B, out, flags, seed);
+  if (rc != RIFT_OK) return rc;
+  if (!c->err.empty()) return RIFT_ERR_ARG;
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_loss_backward(RiftCtx* c, int kind, const RiftLossIn* in, const RiftLossOut* out, void* stream) {
+  if (!c || !in || !out || !out->stats || !out->flat_grad_sum) return RIFT_ERR_ARG;
+  c->err.clear();
+  if (!c->last_qfinal) { c->err = "rift_loss_backward before rift_forward"; return RIFT_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream; c->dry = false;
+  const int bs = c->last_bs, R = c->last_R, M = 12, G = R * M, rows = bs * G;
+  if (G > 64 * 16) { c->err = "group too large"; return RIFT_ERR_ARG; }
+  const int nwg = cdiv(rows, RIFT_PI_BWD_ROWS);
+  if ((size_t)bs > c->l_cap_bs) {
+    if (c->l_S) { (void)hipFree(c->l_S); (void)hipFree(c->l_cnt); }
+    HIPCHK(c, hipMalloc((void**)&c->l_S, bs * 8)); HIPCHK(c, hipMalloc((void**)&c->l_cnt, bs * 8)); c->l_cap_bs = bs;
+  }
+  if ((size_t)rows > c->l_cap_rows) {
+    if (c->l_dz) (void)hipFree(c->l_dz);
+    HIPCHK(c, hipMalloc((void**)&c->l_dz, (size_t)rows * 4)); c->l_cap_rows = rows;
+  }
+  if ((size_t)nwg > c->l_cap_wg) {
+    if (c->l_partial) (void)hipFree(c->l_partial);
+    HIPCHK(c, hipMalloc((void**)&c->l_partial, (size_t)nwg * RIFT_PI_NPARAM * 4)); c->l_cap_wg = nwg;
+  }
+  LossP p; memset(&p, 0, sizeof(p));
+  p.kind = kind; p.bs = bs; p.G = G; p.M = M; p.prob = c->last_prob; p.r_kpm = c->last_rkpm;
+  p.old_logits = in->old_group_logits; p.ref_logits = in->ref_group_logits; p.adv64 = in->group_advantage;
+  p.valid = in->group_valid_mask; p.action_mode = (const long long*)in->action_mode;
+  p.scal_a = kind == RIFT_LOSS_PPO ? in->advantage : in->returns; p.old_log_prob = in->old_log_prob;
+  p.clip_eps = in->clip_epsilon; p.lambda_entropy = in->lambda_entropy;
+  p.S = c->l_S; p.cnt = c->l_cnt; p.dlogit = c->l_dz; p.argmax_rm = (long long*)out->argmax_rm;
+  if ((kind == RIFT_LOSS_RIFT || kind == RIFT_LOSS_GRPO) && (!p.old_logits || !p.adv64 || !p.valid)) { c->err = "missing loss inputs"; return RIFT_ERR_ARG; }
+  if (kind == RIFT_LOSS_GRPO && !p.ref_logits) { c->err = "missing ref logits"; return RIFT_ERR_ARG; }
+  if (kind == RIFT_LOSS_PPO && (!p.action_mode || !p.scal_a || !p.old_log_prob)) { c->err = "missing ppo inputs"; return RIFT_ERR_ARG; }
+  if (kind == RIFT_LOSS_REINFORCE && !p.scal_a) { c->err = "missing returns"; return RIFT_ERR_ARG; }
+  const dim3 lgrid(cdiv(bs, 4)), lblock(256);
+  if (G <= 64 * 2) launch(c, loss_kernel<2>, lgrid, lblock, 0, p);
+  else if (G <= 64 * 4) launch(c, loss_kernel<4>, lgrid, lblock, 0, p);
+  else launch(c, loss_kernel<16>, lgrid, lblock, 0, p);
+  const std::string PH = "planning_decoder.pi_head.mlp.";
+  launch(c, pi_backward_kernel, dim3(nwg), dim3(256), 0, (const float*)c->last_qfinal, (const float*)c->last_hpi,
+         (const float*)c->l_dz, rows, fptr(c, PH + "1.weight"), fptr(c, PH + "1.bias"), fptr(c, PH + "3.weight"), 1e-5f,
+         c->l_partial);
+  launch(c, loss_reduce_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)c->l_partial, nwg,
+         out->flat_grad_sum, (const double*)c->l_S, (const double*)c->l_cnt, bs, out->stats);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void* stream) {
+  if (!c || !out || !out->stats || !out->flat_grad_sum) return RIFT_ERR_ARG;
+  c->stream = (hipStream_t)stream; c->dry = false;
+  launch(c, loss_finalize_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)out->flat_grad_sum,
+         (const double*)out->stats, out->grad_w1, out->grad_b1, out->grad_ln_w, out->grad_ln_b, out->grad_w2, out->grad_b2,
+         out->loss, accumulate);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_tap(RiftCtx* c, const char* name, float* dst, int64_t* numel, void* stream) {
+  if (!c || !name) return RIFT_ERR_ARG;
+  auto it = c->taps.find(name);
+  if (it == c->taps.end()) { c->err = std::string("unknown tap ") + name; return RIFT_ERR_ARG; }
+  if (numel) *numel = it->second.numel;
+  if (dst && it->second.numel > 0)
+    HIPCHK(c, hipMemcpyAsync(dst, it->second.p, it->second.numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return RIFT_OK;
+}
+
+int rift_op_linear(RiftCtx* c, const float* X, int M, int K, const float* W, const float* bias, int N,
+                   const float* ln_w, const float* ln_b, int act, int fp32, float* Y, void* stream) {
+  if (!c || !X || !W || !Y || K > 512) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream; c->dry = false;
+  const std::string key = "__op_linear__";
+  // transient pack (test entry point; not on the hot path)
+  TRY(pack(c, key, W, N, N, K, 0, 0, K, 0, 0, 0, bias));
+  PW w = c->pw[key];
+  GemmP g = mk(X, K, M, w, Y, N);
+  if (ln_w) { g.pro = PRO_LN; g.pg = ln_w; g.pb = ln_b; }
+  g.act = act;
+  gemm(c, g, w, fp32 != 0);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(w.bf); (void)hipFree(w.f32);
+  c->owned.pop_back(); c->owned.pop_back();
+  c->pw.erase(key);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_gae(RiftCtx* c, const double* rewards, const float* undones, const float* values, const float* next_values,
+             const float* unterminated, float gamma, float lambda_, int n, float* advantages, void* stream) {
+  if (!c || n <= 0) return RIFT_ERR_ARG;
+  GaeCoef k{rewards, undones, values, next_values, unterminated, gamma, lambda_};
+  hipLaunchKernelGGL((affine_scan_reverse_kernel<GaeCoef, float>), dim3(1), dim3(64), 0, (hipStream_t)stream, k, n, advantages);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_discounted_return(RiftCtx* c, const double* rewards, const float* dones, double gamma, int n, double* returns,
+                           void* stream) {
+  if (!c || n <= 0) return RIFT_ERR_ARG;
+  ReturnCoef k{rewards, dones, gamma};
+  hipLaunchKernelGGL((affine_scan_reverse_kernel<ReturnCoef, double>), dim3(1), dim3(64), 0, (hipStream_t)stream, k, n, returns);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_normalize_advantage(RiftCtx* c, float* x, int n, void* stream) {
+  if (!c || n <= 0) return RIFT_ERR_ARG;
+  hipLaunchKernelGGL(normalize_unbiased_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_group_advantage(RiftCtx* c, const double* returns, int n_groups, int G, double* advantage, void* stream) {
+  if (!c || n_groups <= 0 || G <= 0) return RIFT_ERR_ARG;
+  hipLaunchKernelGGL(group_zscore_kernel, dim3(cdiv(n_groups, 4)), dim3(256), 0, (hipStream_t)stream, returns, n_groups, G, advantage);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_rollout_return(RiftCtx* c, const float* delta_dis, const float* delta_angle, const float* speed, const float* acc,
+                        const float* ang_vel, const float* ang_acc, const uint8_t* collision, int collision_ld,
+                        const uint8_t* off_road, int off_road_ld, int G, int Ts, double gamma, double* returns, void* stream) {
+  if (!c || G <= 0 || Ts <= 0) return RIFT_ERR_ARG;
+  hipLaunchKernelGGL(rollout_return_kernel, dim3(cdiv(G, 64)), dim3(64), 0, (hipStream_t)stream, delta_dis, delta_angle, speed,
+                     acc, ang_vel, ang_acc, collision, collision_ld, off_road, off_road_ld, G, Ts, gamma, returns);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_collate(RiftCtx* c, const RiftReplayArena* ar, const int32_t* scene_idx, int bs, int R_out,
+                 const RiftFeatureBatch* ob, float* out_old_logits, float* out_ref_logits, double* out_advantage,
+                 uint8_t* out_valid_mask, void* stream) {
+  if (!c || !ar || !scene_idx || !ob || bs <= 0 || R_out <= 0 || R_out > ar->Rcap) return RIFT_ERR_ARG;
+  const RiftFeatureBatch& s = ar->scenes;
+  const int A = ar->A, Mp = ar->Mp, Rc = ar->Rcap, S = ar->S, T = ar->T;
+  CollateP p; memset(&p, 0, sizeof(p));
+  int k = 0;
+  auto add = [&](const void* src, void* dst, long long src_bytes, long long dst_bytes) {
+    if (!src || !dst || dst_bytes <= 0) return;
+    p.src[k] = (const unsigned char*)src; p.dst[k] = (unsigned char*)dst; p.src_bytes[k] = (int)src_bytes; p.dst_bytes[k] = (int)dst_bytes; ++k;
+  };
+#define FIX(field, bytes) add(s.field, (void*)ob->field, (bytes), (bytes))
+  FIX(agent_position, (long long)A * T * 8); FIX(agent_heading, (long long)A * T * 4); FIX(agent_velocity, (long long)A * T * 8);
+  FIX(agent_shape, (long long)A * T * 8); FIX(agent_category, A); FIX(agent_valid_mask, (long long)A * T);
+  FIX(map_point_position, (long long)Mp * 3 * 20 * 8); FIX(map_point_vector, (long long)Mp * 3 * 20 * 8);
+  FIX(map_point_orientation, (long long)Mp * 3 * 20 * 4); FIX(map_polygon_center, (long long)Mp * 12);
+  FIX(map_polygon_type, Mp); FIX(map_polygon_on_route, Mp); FIX(map_polygon_tl_status, Mp);
+  FIX(map_polygon_has_speed_limit, Mp); FIX(map_polygon_speed_limit, (long long)Mp * 4); FIX(map_valid_mask, (long long)Mp * 20);
+  FIX(static_position, (long long)S * 8); FIX(static_heading, (long long)S * 4); FIX(static_shape, (long long)S * 8);
+  FIX(static_category, S); FIX(static_valid_mask, S); FIX(current_state, (long long)ar->cs_ld * 4);
+#undef FIX
+#define RAG(srcp, dstp, per_line) add((srcp), (void*)(dstp), (long long)Rc * (per_line), (long long)R_out * (per_line))
+  RAG(s.ref_position, ob->ref_position, 120 * 8); RAG(s.ref_vector, ob->ref_vector, 120 * 8);
+  RAG(s.ref_orientation, ob->ref_orientation, 120 * 4); RAG(s.ref_valid_mask, ob->ref_valid_mask, 120);
+  RAG(ar->old_group_logits, out_old_logits, 12 * 4); RAG(ar->ref_group_logits, out_ref_logits, 12 * 4);
+  RAG(ar->group_advantage, out_advantage, 12 * 8); RAG(ar->group_valid_mask, out_valid_mask, 12);
+#undef RAG
+  p.nt = k;
+  hipLaunchKernelGGL(collate_kernel, dim3(bs, k), dim3(256), 0, (hipStream_t)stream, p, scene_idx);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+}  // extern "C"

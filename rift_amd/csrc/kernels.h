@@ -1,0 +1,484 @@
+// Non-GEMM kernels of the Pluto forward for gfx950: feature builders, small-sequence
+// attention, LayerNorm, BatchNorm statistics, masked max-pool, token assembly.
+// All activations are fp32 row-major in HBM; every kernel is HBM/latency bound
+// (tiny arithmetic), so the rules that matter are coalesced rows and one pass.
+#pragma once
+#include "common.h"
+
+namespace rift {
+
+#define RIFT_PI 3.14159265358979323846f
+
+// ---------------------------------------------------------------------------
+// weight packing: fp32 [N][K] (row stride K) -> [Npad][Kp] bf16 / fp32, zero padded.
+// conv mode: src [N][C][3] -> dst[n][j*C + c]  (tap-major, matches AMODE_CONV3)
+// tap_lo/tap_n select a subset of taps (fpn_conv only needs taps 0,1 at the last step).
+// ---------------------------------------------------------------------------
+template <bool BF16>
+__global__ void pack_weight_kernel(const float* __restrict__ src, void* dst, int N, int K, int Npad, int Kp,
+                                   int conv_C, int tap_lo, int tap_n, int src_row_off, int src_ld) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Npad * Kp) return;
+  const int n = idx / Kp, k = idx - n * Kp;
+  float v = 0.f;
+  if (n < N && k < K) {
+    if (conv_C > 0) {
+      const int j = k / conv_C, c = k - j * conv_C;
+      if (j < tap_n) v = src[((size_t)n * conv_C + c) * 3 + tap_lo + j];
+    } else {
+      v = src[(size_t)(n + src_row_off) * src_ld + k];
+    }
+  }
+  if (BF16) reinterpret_cast<unsigned short*>(dst)[idx] = f2bf(v);
+  else reinterpret_cast<float*>(dst)[idx] = v;
+}
+
+// ---------------------------------------------------------------------------
+// feature builders
+// ---------------------------------------------------------------------------
+// agent 9-channel difference features (agent_encoder.py:54-75) -> F[(b*A+a)*20 + t][9]
+// also valid_agent[b*A+a] = any(valid[:21])
+__global__ void agent_feature_kernel(const float* __restrict__ pos, const float* __restrict__ head,
+                                     const float* __restrict__ vel, const float* __restrict__ shp,
+                                     const uint8_t* __restrict__ valid, int nA, int Tfull,
+                                     float* __restrict__ F, uint8_t* __restrict__ valid_agent) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (agent, t) t in [0,20)
+  if (idx >= nA * 20) return;
+  const int a = idx / 20, t = idx - a * 20;
+  const size_t b1 = (size_t)a * Tfull + t + 1, b0 = b1 - 1;
+  const bool vm = valid[b0] && valid[b1];
+  float* o = F + (size_t)idx * 9;
+  const float dh = vm ? head[b1] - head[b0] : 0.f;
+  o[0] = vm ? pos[b1 * 2] - pos[b0 * 2] : 0.f;
+  o[1] = vm ? pos[b1 * 2 + 1] - pos[b0 * 2 + 1] : 0.f;
+  o[2] = vm ? vel[b1 * 2] - vel[b0 * 2] : 0.f;
+  o[3] = vm ? vel[b1 * 2 + 1] - vel[b0 * 2 + 1] : 0.f;
+  o[4] = cosf(dh);
+  o[5] = sinf(dh);
+  o[6] = shp[b1 * 2];
+  o[7] = shp[b1 * 2 + 1];
+  o[8] = vm ? 1.f : 0.f;
+  if (t == 0) {
+    bool any = false;
+    for (int i = 0; i < 21; ++i) any |= (valid[(size_t)a * Tfull + i] != 0);
+    valid_agent[a] = any ? 1 : 0;
+  }
+}
+
+// map 10-channel point features (map_encoder.py:43-59) -> F[(b*Mp+m)*20 + p][10]
+__global__ void map_feature_kernel(const float* __restrict__ pp, const float* __restrict__ pv,
+                                   const float* __restrict__ po, const float* __restrict__ center,
+                                   int nPoly, float* __restrict__ F) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (poly, p)
+  if (idx >= nPoly * 20) return;
+  const int m = idx / 20, p = idx - m * 20;
+  const float* P0 = pp + ((size_t)(m * 3 + 0) * 20 + p) * 2;
+  const float* P1 = pp + ((size_t)(m * 3 + 1) * 20 + p) * 2;
+  const float* P2 = pp + ((size_t)(m * 3 + 2) * 20 + p) * 2;
+  const float* V0 = pv + ((size_t)(m * 3 + 0) * 20 + p) * 2;
+  const float o0 = po[(size_t)(m * 3 + 0) * 20 + p];
+  float* o = F + (size_t)idx * 10;
+  o[0] = P0[0] - center[m * 3 + 0];
+  o[1] = P0[1] - center[m * 3 + 1];
+  o[2] = V0[0]; o[3] = V0[1];
+  o[4] = cosf(o0); o[5] = sinf(o0);
+  o[6] = P1[0] - P0[0]; o[7] = P1[1] - P0[1];
+  o[8] = P2[0] - P0[0]; o[9] = P2[1] - P0[1];
+}
+
+// reference-line 6-channel features (planning_decoder.py:145-153) -> F[(b*R+r)*120 + p][6]
+__global__ void ref_feature_kernel(const float* __restrict__ rp, const float* __restrict__ rv,
+                                   const float* __restrict__ ro, int nLine, float* __restrict__ F) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nLine * 120) return;
+  const int l = idx / 120;
+  const float* p0 = rp + (size_t)l * 120 * 2;
+  float* o = F + (size_t)idx * 6;
+  o[0] = rp[(size_t)idx * 2] - p0[0];
+  o[1] = rp[(size_t)idx * 2 + 1] - p0[1];
+  o[2] = rv[(size_t)idx * 2]; o[3] = rv[(size_t)idx * 2 + 1];
+  const float a = ro[idx];
+  o[4] = cosf(a); o[5] = sinf(a);
+}
+
+// Fourier features (fourier_embedding.py:49-50): row r, input dim d -> F[d][r][129] = [cos(2pi f x), sin(..), x]
+// x = in[r*in_ld + d]; optional angle wrap on dim `wrap_dim` ((a + pi) mod 2pi - pi, pluto_model.py:133)
+__global__ void fourier_feature_kernel(const float* __restrict__ in, int in_ld, int rows, int D,
+                                       const float* __restrict__ freqs /*[D][64]*/, int wrap_dim,
+                                       float* __restrict__ F /*[D][rows][129]*/) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (d, r, f) f in [0,65)
+  if (idx >= D * rows * 65) return;
+  const int f = idx % 65, r = (idx / 65) % rows, d = idx / (65 * rows);
+  float x = in[(size_t)r * in_ld + d];
+  if (d == wrap_dim) { x = fmodf(x + RIFT_PI, 2.f * RIFT_PI); if (x < 0.f) x += 2.f * RIFT_PI; x -= RIFT_PI; }
+  float* o = F + ((size_t)d * rows + r) * 129;
+  if (f == 64) { o[128] = x; return; }
+  const float arg = x * freqs[d * 64 + f] * 2.f * RIFT_PI;   // same association as the reference expression
+  o[f] = cosf(arg);
+  o[64 + f] = sinf(arg);
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over rows (C <= 512), one wave per row; optional ReLU; in-place safe.
+// ---------------------------------------------------------------------------
+__global__ void layernorm_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int rows, int C,
+                                 const float* __restrict__ g, const float* __restrict__ b, float eps, int relu) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int k = lane + i * 64; v[i] = (k < C) ? X[(size_t)row * ldx + k] : 0.f; s += v[i]; }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int k = lane + i * 64; const float d = (k < C) ? v[i] - mean : 0.f; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = lane + i * 64;
+    if (k < C) { float y = (v[i] - mean) * rstd * g[k] + b[k]; if (relu) y = fmaxf(y, 0.f); Y[(size_t)row * ldy + k] = y; }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// NAT 1-D neighbourhood attention (natten 0.14.6 semantics; head_dim 16).
+// QKV rows [nseq*L][3C] laid out (q | k | v), each (H, 16).  One thread per (seq, pos, head).
+// ---------------------------------------------------------------------------
+template <int ksz>
+__global__ void nat_attention_kernel(const float* __restrict__ QKV, const float* __restrict__ rpb, int nseq, int L,
+                                     int H, float* __restrict__ O) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nseq * L * H) return;
+  const int h = idx % H, i = (idx / H) % L, s = idx / (H * L);
+  const int C = H * 16;
+  const float scale = 0.25f;   // 16^-0.5
+  const float* qp = QKV + ((size_t)(s * L + i)) * 3 * C + h * 16;
+  float q[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) q[d] = qp[d] * scale;
+  int start = i - ksz / 2;
+  start = start < 0 ? 0 : start;
+  start = start > L - ksz ? L - ksz : start;
+  float sc[ksz];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < ksz; ++j) {
+    const int nb = start + j;
+    const float* kp = QKV + ((size_t)(s * L + nb)) * 3 * C + C + h * 16;
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d += q[e] * kp[e];
+    d += rpb[h * (2 * ksz - 1) + (nb - i) + ksz - 1];
+    sc[j] = d;
+    mx = fmaxf(mx, d);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < ksz; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+  float o[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < ksz; ++j) {
+    const float* vp = QKV + ((size_t)(s * L + start + j)) * 3 * C + 2 * C + h * 16;
+    const float w = sc[j] / den;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] += w * vp[e];
+  }
+  float* op = O + ((size_t)(s * L + i)) * C + h * 16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) op[e] = o[e];
+}
+
+// ---------------------------------------------------------------------------
+// Generic small-sequence multi-head attention (head_dim 32), fp32, online softmax.
+// batch index = (bo, bi); query row = bo*q_outer + bi*q_inner + i*q_stride, key row likewise.
+// mask (True = ignore): mask[mb*Lk + j], mb = quirk ? (bo*nb_inner + bi) % mask_mod : bo.
+// One thread per (batch, head, query).
+// ---------------------------------------------------------------------------
+struct MhaP {
+  const float* Q; int ldq; const float* K; const float* V; int ldkv; float* O; int ldo;
+  int nb_outer, nb_inner, H, Lq, Lk;
+  int q_outer, q_inner, q_stride;      // in rows
+  int kv_outer, kv_inner, kv_stride;
+  int o_outer, o_inner, o_stride;
+  const uint8_t* mask; int mask_quirk, mask_mod;
+  float dropout_p; uint32_t seed, stream;
+};
+
+__global__ void mha_kernel(MhaP p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = p.nb_outer * p.nb_inner * p.H * p.Lq;
+  if (idx >= total) return;
+  // query index fastest so that a wave shares (batch, head) -> K/V rows are wave-uniform broadcasts
+  const int i = idx % p.Lq;
+  const int h = (idx / p.Lq) % p.H;
+  const int bi = (idx / (p.Lq * p.H)) % p.nb_inner;
+  const int bo = idx / (p.Lq * p.H * p.nb_inner);
+  const float scale = 0.17677669529663687f;   // 32^-0.5
+  const float* qp = p.Q + ((size_t)bo * p.q_outer + (size_t)bi * p.q_inner + (size_t)i * p.q_stride) * p.ldq + h * 32;
+  float q[32], acc[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) { q[d] = qp[d] * scale; acc[d] = 0.f; }
+  const size_t kv0 = (size_t)bo * p.kv_outer + (size_t)bi * p.kv_inner;
+  const int mb = p.mask ? (p.mask_quirk ? (bo * p.nb_inner + bi) % p.mask_mod : bo) : 0;
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < p.Lk; ++j) {
+    if (p.mask && p.mask[(size_t)mb * p.Lk + j]) continue;
+    const float* kp = p.K + (kv0 + (size_t)j * p.kv_stride) * p.ldkv + h * 32;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) s += q[d] * kp[d];
+    const float mn = fmaxf(m, s);
+    const float corr = expf(m - mn);     // exp(-inf) = 0 on the first key
+    const float pj = expf(s - mn);
+    l = l * corr + pj;
+    float w = pj;
+    if (p.dropout_p > 0.f) {
+      const float u = uniform01(p.seed, p.stream, (uint32_t)idx * (uint32_t)p.Lk + (uint32_t)j);
+      w = (u < p.dropout_p) ? 0.f : pj * (1.0f / (1.0f - p.dropout_p));
+    }
+    const float* vp = p.V + (kv0 + (size_t)j * p.kv_stride) * p.ldkv + h * 32;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) acc[d] = acc[d] * corr + w * vp[d];
+    m = mn;
+  }
+  const float inv = 1.0f / l;   // all keys masked -> NaN, as torch
+  float* op = p.O + ((size_t)bo * p.o_outer + (size_t)bi * p.o_inner + (size_t)i * p.o_stride) * p.ldo + h * 32;
+#pragma unroll
+  for (int d = 0; d < 32; ++d) op[d] = acc[d] * inv;
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm1d over valid rows (embedding.py:260,266): column sum / sum of squares in fp64,
+// then fold into a per-channel affine  y = x*scale + shift  for the next GEMM's prologue.
+// ---------------------------------------------------------------------------
+__global__ void bn_partial_kernel(const float* __restrict__ X, int ld, int rows, int C,
+                                  const uint8_t* __restrict__ valid, double* __restrict__ part /*[nblk][2][C]*/,
+                                  int* __restrict__ cnt /*[nblk]*/, int rows_per_blk) {
+  const int c = threadIdx.x;   // blockDim.x == C (128 or 256)
+  const int r0 = blockIdx.x * rows_per_blk;
+  const int r1 = min(rows, r0 + rows_per_blk);
+  double s = 0.0, q = 0.0;
+  int n = 0;
+  for (int r = r0; r < r1; ++r) {
+    if (!valid[r]) continue;
+    const double x = (double)X[(size_t)r * ld + c];
+    s += x; q += x * x; ++n;
+  }
+  part[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
+  part[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+  if (c == 0) cnt[blockIdx.x] = n;
+}
+
+// train != 0: batch statistics (+ running-stat update, momentum 0.1, unbiased var); else running stats.
+__global__ void bn_finalize_kernel(const double* __restrict__ part, const int* __restrict__ cnt, int nblk, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, long long* num_batches, int train,
+                                   int update_running, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (train) {
+    double s = 0.0, q = 0.0;
+    long long n = 0;
+    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; n += cnt[b]; }
+    const double mu = s / (double)n;
+    double v = q / (double)n - mu * mu;
+    v = v < 0.0 ? 0.0 : v;
+    mean = (float)mu; var = (float)v;
+    if (update_running) {
+      const double unb = n > 1 ? v * (double)n / (double)(n - 1) : v;
+      running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean;
+      running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unb;
+      if (c == 0 && num_batches) *num_batches += 1;
+    }
+  } else { mean = running_mean[c]; var = running_var[c]; }
+  const float sc = gamma[c] * rsqrtf(var + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+}
+
+// masked max-pool over the n points of each group (PointsEncoder: invalid points are all-zero rows)
+// optional on-the-fly affine+relu is NOT applied here: X is the post-Linear feature.
+__global__ void masked_maxpool_kernel(const float* __restrict__ X, int ld, int groups, int n, int C,
+                                      const uint8_t* __restrict__ valid, float* __restrict__ Y) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= groups * C) return;
+  const int c = idx % C, g = idx / C;
+  float m = -INFINITY;
+  bool any_invalid = false;
+  for (int i = 0; i < n; ++i) {
+    const int r = g * n + i;
+    if (valid[r]) m = fmaxf(m, X[(size_t)r * ld + c]); else any_invalid = true;
+  }
+  if (any_invalid) m = fmaxf(m, 0.f);
+  Y[(size_t)g * C + c] = m;
+}
+
+// ---------------------------------------------------------------------------
+// small assembly kernels
+// ---------------------------------------------------------------------------
+// key padding masks: kpm[b][tok] for tok in agents | polygons | static (True = padded)
+__global__ void token_mask_kernel(const uint8_t* __restrict__ valid_agent, const uint8_t* __restrict__ map_valid,
+                                  const uint8_t* __restrict__ static_valid, int bs, int A, int Mp, int S,
+                                  uint8_t* __restrict__ kpm) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = A + Mp + S;
+  if (idx >= bs * N) return;
+  const int b = idx / N, t = idx - b * N;
+  uint8_t pad;
+  if (t < A) pad = !valid_agent[b * A + t];
+  else if (t < A + Mp) {
+    bool any = false;
+    const uint8_t* v = map_valid + ((size_t)b * Mp + (t - A)) * 20;
+    for (int i = 0; i < 20; ++i) any |= (v[i] != 0);
+    pad = !any;
+  } else pad = !static_valid[b * S + (t - A - Mp)];
+  kpm[idx] = pad;
+}
+
+// ref-line key padding: r_kpm[b*R + r] = !any(valid[b,r,:120])
+__global__ void refline_mask_kernel(const uint8_t* __restrict__ rvalid, int nLine, uint8_t* __restrict__ r_kpm) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nLine) return;
+  bool any = false;
+  for (int i = 0; i < 120; ++i) any |= (rvalid[(size_t)l * 120 + i] != 0);
+  r_kpm[l] = !any;
+}
+
+// token positions for pos_emb: pos[b][tok][3] = (x, y, angle) (pluto_model.py:131-146; wrap applied in fourier kernel)
+__global__ void token_pos_kernel(const float* __restrict__ agent_pos, const float* __restrict__ agent_head, int Tfull,
+                                 const float* __restrict__ center, const float* __restrict__ st_pos,
+                                 const float* __restrict__ st_head, int bs, int A, int Mp, int S, float* __restrict__ pos) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = A + Mp + S;
+  if (idx >= bs * N) return;
+  const int b = idx / N, t = idx - b * N;
+  float x, y, a;
+  if (t < A) {
+    const size_t o = ((size_t)(b * A + t)) * Tfull + 20;
+    x = agent_pos[o * 2]; y = agent_pos[o * 2 + 1]; a = agent_head[o];
+  } else if (t < A + Mp) {
+    const float* c = center + ((size_t)b * Mp + (t - A)) * 3;
+    x = c[0]; y = c[1]; a = c[2];
+  } else {
+    const size_t o = (size_t)b * S + (t - A - Mp);
+    x = st_pos[o * 2]; y = st_pos[o * 2 + 1]; a = st_head[o];
+  }
+  pos[(size_t)idx * 3] = x; pos[(size_t)idx * 3 + 1] = y; pos[(size_t)idx * 3 + 2] = a;
+}
+
+// FPN top-down merge restricted to the positions the last output step depends on
+// (embedding.py:79-87 with F.interpolate(scale 2, linear, align_corners=False)):
+//   l1'[8] = l1[8] + .25 l2[3] + .75 l2[4];  l1'[9] = l1[9] + l2[4]
+//   l0'[18] = l0[18] + .25 l1'[8] + .75 l1'[9];  l0'[19] = l0[19] + l1'[9]
+// lat buffers hold 2 positions per agent: lat2 rows (a*2+{0,1}) = t {3,4}; lat1 = {8,9}; lat0 = {18,19}.
+// out Z[a][256] = [l0'[18] | l0'[19]]  (input of the pruned fpn_conv GEMM)
+__global__ void fpn_merge_kernel(const float* __restrict__ lat0, const float* __restrict__ lat1,
+                                 const float* __restrict__ lat2, int nA, float* __restrict__ Z) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nA * 128) return;
+  const int c = idx & 127, a = idx >> 7;
+  const float l2a = lat2[((size_t)a * 2 + 0) * 128 + c], l2b = lat2[((size_t)a * 2 + 1) * 128 + c];
+  const float l1a = lat1[((size_t)a * 2 + 0) * 128 + c] + (0.25f * l2a + 0.75f * l2b);
+  const float l1b = lat1[((size_t)a * 2 + 1) * 128 + c] + l2b;
+  Z[(size_t)a * 256 + c] = lat0[((size_t)a * 2 + 0) * 128 + c] + (0.25f * l1a + 0.75f * l1b);
+  Z[(size_t)a * 256 + 128 + c] = lat0[((size_t)a * 2 + 1) * 128 + c] + l1b;
+}
+
+// ego state tokens (agent_encoder.py:113-118): E[b][i][:] = cs[b][i] * w_i + b_i + pos_embed[i]
+__global__ void ego_token_kernel(const float* __restrict__ cs, int cs_ld, const float* __restrict__ lw /*[6][128]*/,
+                                 const float* __restrict__ lb /*[6][128]*/, const float* __restrict__ pos_embed, int bs,
+                                 float* __restrict__ E) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= bs * 6 * 128) return;
+  const int c = idx & 127, i = (idx >> 7) % 6, b = idx / (6 * 128);
+  E[idx] = (cs[(size_t)b * cs_ld + i] * lw[i * 128 + c] + lb[i * 128 + c]) + pos_embed[i * 128 + c];
+}
+
+// state dropout key mask (agent_encoder.py:119-129): first 3 tokens visible, others dropped w.p. p
+__global__ void ego_dropmask_kernel(int bs, float p, uint32_t seed, uint32_t stream, uint8_t* __restrict__ mask) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= bs * 6) return;
+  const int i = idx % 6;
+  mask[idx] = (i >= 3 && uniform01(seed, stream, (uint32_t)idx) < p) ? 1 : 0;
+}
+
+// agent tokens: x[b][a] = (a == 0 ? x_ego[b] : valid ? nat[b*A+a] : 0) + type_emb[cat] ; written into token row (b*N + a)
+__global__ void agent_token_kernel(const float* __restrict__ nat, const float* __restrict__ x_ego,
+                                   const uint8_t* __restrict__ valid_agent, const int8_t* __restrict__ category,
+                                   const float* __restrict__ type_emb, int bs, int A, int N, float* __restrict__ X) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= bs * A * 128) return;
+  const int c = idx & 127, a = (idx >> 7) % A, b = idx / (A * 128);
+  const int ag = b * A + a;
+  float v = (a == 0) ? x_ego[(size_t)b * 128 + c] : (valid_agent[ag] ? nat[(size_t)ag * 128 + c] : 0.f);
+  v += type_emb[(int)category[ag] * 128 + c];
+  X[((size_t)b * N + a) * 128 + c] = v;
+}
+
+// polygon tokens (map_encoder.py:82-91): x = pooled + type + on_route + tl + (has ? speed_emb : unknown)
+__global__ void polygon_token_kernel(const float* __restrict__ pooled, const int8_t* __restrict__ ptype,
+                                     const uint8_t* __restrict__ on_route, const int8_t* __restrict__ tl,
+                                     const uint8_t* __restrict__ has_sl, const float* __restrict__ speed_emb,
+                                     const float* __restrict__ type_emb, const float* __restrict__ route_emb,
+                                     const float* __restrict__ tl_emb, const float* __restrict__ unk_emb, int bs,
+                                     int A, int Mp, int N, float* __restrict__ X) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= bs * Mp * 128) return;
+  const int c = idx & 127, m = (idx >> 7) % Mp, b = idx / (Mp * 128);
+  const int pg = b * Mp + m;
+  float v = pooled[(size_t)pg * 128 + c] + type_emb[(int)ptype[pg] * 128 + c] +
+            route_emb[(on_route[pg] ? 1 : 0) * 128 + c] + tl_emb[(int)tl[pg] * 128 + c];
+  v += has_sl[pg] ? speed_emb[(size_t)pg * 128 + c] : unk_emb[c];
+  X[((size_t)b * N + A + m) * 128 + c] = v;
+}
+
+// static-object tokens (static_objects_encoder.py:24-26): valid ? fourier(shape) + type_emb : 0
+__global__ void static_token_kernel(const float* __restrict__ emb, const int8_t* __restrict__ cat,
+                                    const uint8_t* __restrict__ valid, const float* __restrict__ type_emb, int bs,
+                                    int A, int Mp, int S, int N, float* __restrict__ X) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= bs * S * 128) return;
+  const int c = idx & 127, s = (idx >> 7) % S, b = idx / (S * 128);
+  const int o = b * S + s;
+  X[((size_t)b * N + A + Mp + s) * 128 + c] = valid[o] ? emb[(size_t)o * 128 + c] + type_emb[(int)cat[o] * 128 + c] : 0.f;
+}
+
+// Y[r][c] += Z[r][c]   (pos-embedding add)
+__global__ void add_inplace_kernel(float* __restrict__ Y, const float* __restrict__ Z, size_t n) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) Y[idx] += Z[idx];
+}
+
+// decoder query init (planning_decoder.py:162-165): q0[(b,r,m)] = Ra[(b,r)] + Mb[m]
+__global__ void build_q0_kernel(const float* __restrict__ Ra, const float* __restrict__ Mb, int nLine, int M,
+                                float* __restrict__ Q) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nLine * M * 128) return;
+  const int c = idx & 127, m = (idx >> 7) % M, l = idx / (M * 128);
+  Q[idx] = Ra[(size_t)l * 128 + c] + Mb[(size_t)m * 128 + c];
+}
+
+// r_pos[(b,r)] = (position[b,r,0,:], orientation[b,r,0])  (planning_decoder.py:159)
+__global__ void refline_pos_kernel(const float* __restrict__ rp, const float* __restrict__ ro, int nLine,
+                                   float* __restrict__ pos) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nLine) return;
+  pos[l * 3] = rp[(size_t)l * 240]; pos[l * 3 + 1] = rp[(size_t)l * 240 + 1]; pos[l * 3 + 2] = ro[(size_t)l * 120];
+}
+
+// gather rows: Y[i] = X[rowidx(i)] with rowidx = (i / per) * stride_rows + off  (token 0 of each scene etc.)
+__global__ void gather_rows_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int rows,
+                                   int C, int per, int stride_rows, int off) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C) return;
+  const int c = idx % C, r = idx / C;
+  const size_t src = (size_t)(r / per) * stride_rows + off + (r % per);
+  Y[(size_t)r * ldy + c] = X[src * ldx + c];
+}
+
+}  // namespace rift

@@ -1,0 +1,320 @@
+// pi-head tail, RLFT objectives (RIFT / GRPO / PPO-actor / REINFORCE) and the analytic
+// backward into the only trainable tensors (planning_decoder.pi_head.*) for gfx950.
+// Row softmax / LayerNorm reductions are wavefront shuffles; objective sums are fp64
+// (the reference promotes fp64 advantage x fp32 ratio, rift_trainer.py:160-178).
+#pragma once
+#include "common.h"
+
+namespace rift {
+
+enum { LOSS_RIFT = 0, LOSS_GRPO = 1, LOSS_PPO = 2, LOSS_REINFORCE = 3 };
+
+// pi_head tail (mlp_layer.py:8-13 after the first Linear): per row  LN(128) -> ReLU -> dot(w2) + b2.
+// One wave per row.  Writes raw logits and the -1e6-masked `probability` (pluto_model.py:203).
+__global__ void pi_tail_kernel(const float* __restrict__ Hpi /*[rows][128]*/, int rows, int M,
+                               const float* __restrict__ g, const float* __restrict__ be,
+                               const float* __restrict__ w2, const float* __restrict__ b2,
+                               const uint8_t* __restrict__ r_kpm /*[rows/M]*/, float eps,
+                               float* __restrict__ prob /*[rows]*/) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float h0 = Hpi[(size_t)row * 128 + lane], h1 = Hpi[(size_t)row * 128 + 64 + lane];
+  const float mean = wave_sum(h0 + h1) * (1.f / 128.f);
+  const float d0 = h0 - mean, d1 = h1 - mean;
+  const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f) + eps);
+  const float a0 = fmaxf(d0 * rstd * g[lane] + be[lane], 0.f);
+  const float a1 = fmaxf(d1 * rstd * g[lane + 64] + be[lane + 64], 0.f);
+  const float z = wave_sum(a0 * w2[lane] + a1 * w2[lane + 64]) + b2[0];
+  if (lane == 0) prob[row] = r_kpm[row / M] ? -1e6f : z;
+}
+
+struct LossP {
+  int kind, bs, G, M;                 // G = R*M candidates per scene
+  const float* prob;                  // [bs][G]  model output (already -1e6 on padded ref lines)
+  const uint8_t* r_kpm;               // [bs][R]
+  const float* old_logits;            // [bs][G]  (RIFT, GRPO)
+  const float* ref_logits;            // [bs][G]  (GRPO)
+  const double* adv64;                // [bs][G]  (RIFT, GRPO) fp64 group advantage
+  const uint8_t* valid;               // [bs][G]  (RIFT, GRPO)
+  const long long* action_mode;       // [bs][2]  (PPO) int64 (r_idx, m_idx)
+  const float* scal_a;                // [bs]     PPO advantage / REINFORCE return
+  const float* old_log_prob;          // [bs]     (PPO)
+  float clip_eps, lambda_entropy;
+  double* S;                          // [bs] per-scene objective sum
+  double* cnt;                        // [bs] per-scene normaliser count
+  float* dlogit;                      // [bs][G]  dS/dlogit
+  long long* argmax_rm;               // [bs][2]  (REINFORCE) chosen (r, m), bit-exact integer output
+};
+
+// One 64-lane wave per scene (G <= 64*MAXPL candidates held in registers).
+template <int MAXPL>
+__global__ void loss_kernel(LossP p) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= p.bs) return;
+  const int G = p.G;
+  float z[MAXPL], lp[MAXPL];
+  bool pad[MAXPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int j = lane + i * 64;
+    pad[i] = true; z[i] = -INFINITY;
+    if (j < G) {
+      pad[i] = p.r_kpm[(size_t)b * (G / p.M) + j / p.M] != 0;
+      z[i] = pad[i] ? -1e8f : p.prob[(size_t)b * G + j];     // masked_fill_(-1e8), rift_trainer.py:153
+      mx = fmaxf(mx, z[i]);
+    }
+  }
+  mx = wave_max(mx);
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) if (lane + i * 64 < G) se += expf(z[i] - mx);
+  const float lse = mx + logf(wave_sum(se));
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) lp[i] = z[i] - lse;
+
+  double S = 0.0, cnt = 0.0;
+  float gi[MAXPL];   // dS/dlp_i
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) gi[i] = 0.f;
+
+  if (p.kind == LOSS_RIFT || p.kind == LOSS_GRPO) {
+    // old-policy log-softmax
+    float zo[MAXPL], zr[MAXPL];
+    float mo = -INFINITY, mr = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int j = lane + i * 64;
+      zo[i] = -INFINITY; zr[i] = -INFINITY;
+      if (j < G) {
+        zo[i] = pad[i] ? -1e8f : p.old_logits[(size_t)b * G + j];
+        mo = fmaxf(mo, zo[i]);
+        if (p.kind == LOSS_GRPO) { zr[i] = pad[i] ? -1e8f : p.ref_logits[(size_t)b * G + j]; mr = fmaxf(mr, zr[i]); }
+      }
+    }
+    mo = wave_max(mo);
+    float so = 0.f, sr = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) if (lane + i * 64 < G) so += expf(zo[i] - mo);
+    const float lseo = mo + logf(wave_sum(so));
+    float lser = 0.f;
+    if (p.kind == LOSS_GRPO) {
+      mr = wave_max(mr);
+#pragma unroll
+      for (int i = 0; i < MAXPL; ++i) if (lane + i * 64 < G) sr += expf(zr[i] - mr);
+      lser = mr + logf(wave_sum(sr));
+    }
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int j = lane + i * 64;
+      if (j >= G || !p.valid[(size_t)b * G + j]) continue;
+      const double A = p.adv64[(size_t)b * G + j];
+      const float ratio = expf(lp[i] - (zo[i] - lseo));
+      const double u = A * (double)ratio;
+      const double c = A * (double)fminf(fmaxf(ratio, 0.8f), 1.2f);
+      double obj = u < c ? u : c;
+      // d min(u,c)/d lp: u is active (or tied with c inside the clamp range) -> A*ratio
+      bool pass = (ratio >= 0.8f && ratio <= 1.2f) || (u < c);
+      if (p.kind == LOSS_RIFT) {
+        if (A < 0.0) {                                   // dual clip, rift_trainer.py:168-170
+          const double lo = A * 3.0;
+          if (obj < lo) { obj = lo; pass = false; }
+        }
+      } else {
+        const float rp = expf(zr[i] - lser);             // softmax(ref logits)
+        // F.kl_div(log p, ref_p) = ref_p * (log ref_p - log p); xlogy(0, 0) = 0
+        const double kl = rp > 0.f ? (double)(rp * (logf(rp) - lp[i])) : 0.0;
+        obj -= 0.2 * kl;
+        gi[i] += 0.2f * rp;
+      }
+      if (pass) gi[i] += (float)(A * (double)ratio);
+      S += obj; cnt += 1.0;
+    }
+  } else if (p.kind == LOSS_PPO) {
+    const int ridx = (int)p.action_mode[(size_t)b * 2], midx = (int)p.action_mode[(size_t)b * 2 + 1];
+    const int chosen = ridx * p.M + midx;
+    float ent_part = 0.f, cur = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int j = lane + i * 64;
+      if (j < G) { ent_part += expf(lp[i]) * lp[i]; if (j == chosen) cur = lp[i]; }
+    }
+    const float ent = -wave_sum(ent_part);
+    cur = wave_sum(cur);
+    const float A = p.scal_a[b];
+    const float ratio = expf(cur - p.old_log_prob[b]);
+    const float l1 = A * ratio, l2 = A * fminf(fmaxf(ratio, 1.f - p.clip_eps), 1.f + p.clip_eps);
+    const bool pass = (ratio >= 1.f - p.clip_eps && ratio <= 1.f + p.clip_eps) || (l1 < l2);
+    const float gsel = pass ? A * ratio : 0.f;
+    S = (double)(l1 < l2 ? l1 : l2) + (double)p.lambda_entropy * (double)ent;
+    cnt = 1.0;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int j = lane + i * 64;
+      if (j >= G) continue;
+      // dH/dlp_j routed through dlogit below: dH/dz_j = -p_j (lp_j + H); expressed as gi on lp: g_j = -(p_j (lp_j + 1))
+      gi[i] = -p.lambda_entropy * expf(lp[i]) * (lp[i] + 1.f) + (j == chosen ? gsel : 0.f);
+    }
+  } else {   // REINFORCE, reinforce_trainer.py:125-170
+    // argmax over the masked logits, first index on ties (torch.argmax)
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int j = lane + i * 64;
+      if (j < G && (z[i] > bv)) { bv = z[i]; bi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    float cur = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) if (lane + i * 64 == bi) cur = lp[i];
+    cur = wave_sum(cur);
+    const float ret = p.scal_a[b];
+    S = (double)(cur * ret); cnt = 1.0;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) if (lane + i * 64 == bi) gi[i] = ret;
+    if (lane == 0 && p.argmax_rm) { p.argmax_rm[(size_t)b * 2] = bi / p.M; p.argmax_rm[(size_t)b * 2 + 1] = bi % p.M; }
+  }
+
+  // dS/dz_j = g_j - p_j * sum_i g_i   (lp_i = z_i - lse)
+  float gs = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) gs += gi[i];
+  gs = wave_sum(gs);
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int j = lane + i * 64;
+    if (j < G) p.dlogit[(size_t)b * G + j] = pad[i] ? 0.f : gi[i] - expf(lp[i]) * gs;
+  }
+  if (p.kind == LOSS_RIFT || p.kind == LOSS_GRPO) { S = wave_sum_d(S); cnt = wave_sum_d(cnt); }
+  if (lane == 0) { p.S[b] = S; p.cnt[b] = cnt; }
+}
+
+// Backward through pi_head for a chunk of rows.  partial layout per workgroup (floats):
+//   [0,16384) dW1[c][k] | +128 db1 | +128 dgamma | +128 dbeta | +128 dw2 | +1 db2      (= 16897)
+#define RIFT_PI_NPARAM 16897
+#define RIFT_PI_BWD_ROWS 256
+__global__ __launch_bounds__(256) void pi_backward_kernel(
+    const float* __restrict__ Q /*[rows][128] pi_head input*/, const float* __restrict__ Hpi /*[rows][128]*/,
+    const float* __restrict__ dz /*[rows]*/, int rows, const float* __restrict__ g, const float* __restrict__ be,
+    const float* __restrict__ w2, float eps, float* __restrict__ partial) {
+  __shared__ float s_dh[32][132];
+  __shared__ float s_q[32][132];
+  __shared__ float s_red[4][4][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * RIFT_PI_BWD_ROWS;
+  const int r1 = min(rows, r0 + RIFT_PI_BWD_ROWS);
+  float accW[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accW[i][j] = 0.f;
+  float a_db1[2] = {0.f, 0.f}, a_dg[2] = {0.f, 0.f}, a_dbe[2] = {0.f, 0.f}, a_dw2[2] = {0.f, 0.f};
+  float a_db2 = 0.f;
+  const int c0 = (tid >> 4) * 8, k0 = (tid & 15) * 8;
+  const float g0 = g[lane], g1 = g[lane + 64], be0 = be[lane], be1 = be[lane + 64];
+  const float w20 = w2[lane], w21 = w2[lane + 64];
+  for (int base = r0; base < r1; base += 32) {
+    for (int rr = wave; rr < 32; rr += 4) {
+      const int row = base + rr;
+      float dh0 = 0.f, dh1 = 0.f, q0 = 0.f, q1 = 0.f;
+      if (row < r1) {
+        const float h0 = Hpi[(size_t)row * 128 + lane], h1 = Hpi[(size_t)row * 128 + 64 + lane];
+        q0 = Q[(size_t)row * 128 + lane]; q1 = Q[(size_t)row * 128 + 64 + lane];
+        const float d = dz[row];
+        const float mean = wave_sum(h0 + h1) * (1.f / 128.f);
+        const float e0 = h0 - mean, e1 = h1 - mean;
+        const float rstd = rsqrtf(wave_sum(e0 * e0 + e1 * e1) * (1.f / 128.f) + eps);
+        const float n0 = e0 * rstd, n1 = e1 * rstd;
+        const float y0 = n0 * g0 + be0, y1 = n1 * g1 + be1;
+        const float dy0 = y0 > 0.f ? d * w20 : 0.f, dy1 = y1 > 0.f ? d * w21 : 0.f;
+        a_dw2[0] += d * fmaxf(y0, 0.f); a_dw2[1] += d * fmaxf(y1, 0.f);
+        a_dg[0] += dy0 * n0; a_dg[1] += dy1 * n1;
+        a_dbe[0] += dy0; a_dbe[1] += dy1;
+        if (lane == 0) a_db2 += d;
+        const float dn0 = dy0 * g0, dn1 = dy1 * g1;
+        const float m1 = wave_sum(dn0 + dn1) * (1.f / 128.f);
+        const float m2 = wave_sum(dn0 * n0 + dn1 * n1) * (1.f / 128.f);
+        dh0 = rstd * (dn0 - m1 - n0 * m2); dh1 = rstd * (dn1 - m1 - n1 * m2);
+        a_db1[0] += dh0; a_db1[1] += dh1;
+      }
+      s_dh[rr][lane] = dh0; s_dh[rr][lane + 64] = dh1;
+      s_q[rr][lane] = q0; s_q[rr][lane + 64] = q1;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 32; ++rr) {
+      float dv[8], qv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { dv[i] = s_dh[rr][c0 + i]; qv[i] = s_q[rr][k0 + i]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accW[i][j] += dv[i] * qv[j];
+    }
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.x * RIFT_PI_NPARAM;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[(c0 + i) * 128 + k0 + j] = accW[i][j];
+  // cross-wave reduction of the per-channel vectors
+  s_red[wave][0][lane] = a_db1[0]; s_red[wave][0][lane + 64] = a_db1[1];
+  s_red[wave][1][lane] = a_dg[0];  s_red[wave][1][lane + 64] = a_dg[1];
+  s_red[wave][2][lane] = a_dbe[0]; s_red[wave][2][lane + 64] = a_dbe[1];
+  s_red[wave][3][lane] = a_dw2[0]; s_red[wave][3][lane + 64] = a_dw2[1];
+  __shared__ float s_db2[4];
+  if (lane == 0) s_db2[wave] = a_db2;
+  __syncthreads();
+  for (int i = tid; i < 512; i += 256) {
+    const int v = i >> 7, c = i & 127;
+    out[16384 + v * 128 + c] = s_red[0][v][c] + s_red[1][v][c] + s_red[2][v][c] + s_red[3][v][c];
+  }
+  if (tid == 0) out[16384 + 512] = s_db2[0] + s_db2[1] + s_db2[2] + s_db2[3];
+}
+
+// flat[i] = sum_wg partial[wg][i]; stats[0] = sum S_b, stats[1] = sum cnt_b  (deterministic order)
+__global__ void loss_reduce_kernel(const float* __restrict__ partial, int nwg, float* __restrict__ flat,
+                                   const double* __restrict__ S, const double* __restrict__ cnt, int bs,
+                                   double* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < RIFT_PI_NPARAM) {
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * RIFT_PI_NPARAM + i];
+    flat[i] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double a = 0.0, c = 0.0;
+    for (int b = threadIdx.x; b < bs; b += 64) { a += S[b]; c += cnt[b]; }
+    a = wave_sum_d(a); c = wave_sum_d(c);
+    if (threadIdx.x == 0) { stats[0] = a; stats[1] = c; }
+  }
+}
+
+// loss = -S/cnt ; grads = -flat/cnt scattered into the six caller-owned .grad tensors (accumulate or overwrite)
+__global__ void loss_finalize_kernel(const float* __restrict__ flat, const double* __restrict__ stats,
+                                     float* gW1, float* gb1, float* gg, float* gbe, float* gw2, float* gb2,
+                                     double* __restrict__ loss_out, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double cnt = stats[1];
+  const float sc = cnt > 0.0 ? (float)(-1.0 / cnt) : 0.f;
+  if (i == 0 && loss_out) loss_out[0] = cnt > 0.0 ? -stats[0] / cnt : 0.0;
+  if (i >= RIFT_PI_NPARAM) return;
+  float* dst; int o;
+  if (i < 16384) { dst = gW1; o = i; }
+  else if (i < 16384 + 128) { dst = gb1; o = i - 16384; }
+  else if (i < 16384 + 256) { dst = gg; o = i - 16384 - 128; }
+  else if (i < 16384 + 384) { dst = gbe; o = i - 16384 - 256; }
+  else if (i < 16384 + 512) { dst = gw2; o = i - 16384 - 384; }
+  else { dst = gb2; o = 0; }
+  if (!dst) return;
+  const float v = flat[i] * sc;
+  dst[o] = accumulate ? dst[o] + v : v;
+}
+
+}  // namespace rift

@@ -177,5 +177,61 @@ def _load_ppo_loss_fn():
     return ns["get_ppo_loss"]
 
 
+
+
+# ------------------------------------------------------------------------------------------
+# advantage / return fixtures (GAE, discounted return, dense-reward rollout return, z-score)
+# ------------------------------------------------------------------------------------------
+def _ref_function(rel_path, name, extra_ns=None):
+    """Compile ONE function of a reference file in memory (its module top imports carla/hydra-bound code)."""
+    import ast
+    path = os.path.join(ref_loader.REF_ROOT, rel_path)
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = {"torch": torch, "np": np}
+    ns.update(extra_ns or {})
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def gen_advantage():
+    ref_loader.install()
+    import types as _t
+    from tests.helpers import advantage_inputs
+    inp = advantage_inputs()
+    gae = _ref_function("rift/cbv/planning/fine_tuner/rlft/ppo_pluto/ppo_datamodule.py", "get_advantages_GAE")
+    cret = _ref_function("rift/cbv/planning/fine_tuner/rlft/reinforce_pluto/reinforce_datamodule.py", "compute_return")
+    rr = _ref_function("rift/cbv/planning/fine_tuner/rlft/traj_eval/traj_evaluator.py", "get_rollout_return")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_reward_model", os.path.join(ref_loader.REF_ROOT, "rift/gym_carla/reward/reward_model.py"))
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    out = {}
+    adv = gae(inp["rewards"], inp["undones"], inp["values"], inp["next_values"], inp["unterminated"], 0.98, 0.98)
+    out["gae"] = adv.numpy()
+    out["gae_normalized"] = ((adv - adv.mean()) / (adv.std(dim=0) + 1e-5)).numpy()   # ppo_datamodule.py:166
+    out["returns"] = cret(inp["rewards"], inp["dones"], 0.98).numpy()
+    fake_self = _t.SimpleNamespace(reward_model=rm.DenseRewardModel())
+    ret = rr(fake_self, inp["delta_dis"], inp["delta_angle"], inp["speed"], inp["acc"], inp["ang_vel"], inp["ang_acc"],
+             inp["collision"], inp["off_road"])
+    out["rollout_return"] = ret
+    out["group_advantage"] = (ret - np.mean(ret)) / (np.std(ret) + 1e-5)            # traj_evaluator.py:467-470
+    # WarmupCosLR table (warmup_cos_lr.py:39-54) for the RLFT config: lr 1e-4, min 0.9e-4, 3 warmup, 16 epochs
+    wl = importlib.import_module("rift.cbv.planning.pluto.optim.warmup_cos_lr")
+    # torch 2.10 dropped the `verbose` ctor argument the reference passes on, so its get_lr is
+    # evaluated on a duck-typed scheduler state instead of a constructed instance
+    lrs = []
+    for e in range(16):
+        fake = _t.SimpleNamespace(last_epoch=e, warmup_epochs=3, lr=1e-4, min_lr=0.9e-4, epochs=16,
+                                  optimizer=_t.SimpleNamespace(param_groups=[{}]))
+        lrs.append(wl.WarmupCosLR.get_lr(fake)[0])
+    out["warmup_cos_lr"] = np.array(lrs)
+    path = os.path.join(HERE, "advantage.npz")
+    np.savez_compressed(path, **out)
+    print("advantage ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB")
+
+
 if __name__ == "__main__":
     main()
+    gen_advantage()

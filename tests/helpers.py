@@ -54,3 +54,29 @@ def max_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+def advantage_inputs(n=4096, G=48, Ts=40, seed=424242):
+    """Seeded inputs shared by gen_golden and the tests (regenerated, not stored)."""
+    g = torch.Generator().manual_seed(seed)
+    r = {}
+    r["rewards"] = torch.randn(n, generator=g, dtype=torch.float64)
+    done = torch.rand(n, generator=g) < 0.05
+    term = done & (torch.rand(n, generator=g) < 0.4)
+    r["dones"] = done.float()
+    r["undones"] = 1.0 - done.float()
+    r["unterminated"] = 1.0 - term.float()
+    r["values"] = torch.randn(n, generator=g)
+    r["next_values"] = torch.randn(n, generator=g)
+    f = lambda *s: torch.randn(*s, generator=g)
+    r["delta_dis"] = (f(G, Ts) * 1.5).numpy()
+    r["delta_angle"] = (f(G, Ts) * 0.8).numpy()
+    r["speed"] = (f(G, Ts) * 6.0 + 5.0).numpy()
+    r["acc"] = (f(G, Ts) * 3.0).numpy()
+    r["ang_vel"] = (f(G, Ts) * 0.5).numpy()
+    r["ang_acc"] = (f(G, Ts) * 3.0).numpy()
+    r["collision"] = (torch.rand(G, Ts, generator=g) < 0.02).numpy()
+    r["off_road"] = (torch.rand(G, 2 * Ts, generator=g) < 0.05).numpy()
+    return r
+
+
