@@ -145,6 +145,11 @@ int rift_forward(RiftCtx* ctx, const RiftFeatureBatch* batch, const RiftOutputs*
 int rift_loss_backward(RiftCtx* ctx, int kind, const RiftLossIn* in, const RiftLossOut* out, void* stream);
 int rift_loss_finalize(RiftCtx* ctx, const RiftLossOut* out, int accumulate, void* stream);
 
+/* Per-launch HIP-event profiling of the forward/loss kernels on the caller's stream (bench roofline leg).
+ * rift_prof_report synchronises and writes a JSON object {label: {count, ms, flops}} into buf. */
+int rift_prof_enable(RiftCtx* ctx, int on);
+int rift_prof_report(RiftCtx* ctx, char* buf /*host*/, int buflen);
+
 /* Debug / parity taps: copy a named intermediate of the last forward to `dst` (device, fp32).
  * *numel receives the element count; dst may be NULL to query the size only. */
 int rift_tap(RiftCtx* ctx, const char* name, float* dst, int64_t* numel, void* stream);

@@ -65,6 +65,7 @@ EXPORTS = [
     "rift_ctx_create", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_loss_backward",
     "rift_loss_finalize", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
+    "rift_prof_enable", "rift_prof_report",
 ]
 
 _lib = None
@@ -102,6 +103,8 @@ def load_library() -> C.CDLL:
                                         C.c_double, vp, vp]
     lib.rift_collate.argtypes = [vp, C.POINTER(RiftReplayArena), vp, C.c_int, C.c_int, C.POINTER(RiftFeatureBatch),
                                  vp, vp, vp, vp, vp]
+    lib.rift_prof_enable.argtypes = [vp, C.c_int]
+    lib.rift_prof_report.argtypes = [vp, C.c_char_p, C.c_int]
     for name in EXPORTS:
         if name not in ("rift_ctx_destroy", "rift_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -246,6 +249,32 @@ class Engine:
         self._keep = keep + list(out.values())
         self._bs = bs
         return out
+
+    def forward_raw(self, fb: RiftFeatureBatch, out: RiftOutputs, flags: int, seed: int):
+        """Hot-loop entry: prebuilt descriptors, no tensor conversion, no allocation."""
+        rc = self.lib.rift_forward(self.ctx, C.byref(fb), C.byref(out), flags, C.c_uint32(seed & 0xFFFFFFFF), _stream())
+        if rc != 0:
+            self._check(rc, "rift_forward")
+        self._bs = fb.bs
+
+    def loss_backward_raw(self, kind: int, li: RiftLossIn, lo: RiftLossOut):
+        rc = self.lib.rift_loss_backward(self.ctx, kind, C.byref(li), C.byref(lo), _stream())
+        if rc != 0:
+            self._check(rc, "rift_loss_backward")
+
+    def loss_finalize_raw(self, lo: RiftLossOut, accumulate: int = 0):
+        rc = self.lib.rift_loss_finalize(self.ctx, C.byref(lo), accumulate, _stream())
+        if rc != 0:
+            self._check(rc, "rift_loss_finalize")
+
+    def prof_enable(self, on: bool):
+        self._check(self.lib.rift_prof_enable(self.ctx, 1 if on else 0), "rift_prof_enable")
+
+    def prof_report(self) -> dict:
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        self._check(self.lib.rift_prof_report(self.ctx, buf, len(buf)), "rift_prof_report")
+        return json.loads(buf.value.decode())
 
     def tap(self, name: str) -> torch.Tensor:
         n = C.c_int64(0)

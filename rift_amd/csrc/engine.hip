@@ -49,7 +49,20 @@ struct RiftCtx {
   size_t l_cap_bs = 0, l_cap_rows = 0, l_cap_wg = 0;
   float* ego_w = nullptr; float* ego_b = nullptr;   // packed (6,128) linears of StateAttentionEncoder
   bool loaded = false;
+  // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
+  bool prof_on = false; double prof_flops = 0.0;
+  std::vector<hipEvent_t> prof_pool; size_t prof_used = 0;
+  struct Rec { const char* label; hipEvent_t e0, e1; double flops; };
+  std::vector<Rec> prof_recs;
 };
+
+static void prof_events(RiftCtx* c, hipEvent_t* e0, hipEvent_t* e1) {
+  while (c->prof_pool.size() < c->prof_used + 2) { hipEvent_t e; (void)hipEventCreate(&e); c->prof_pool.push_back(e); }
+  *e0 = c->prof_pool[c->prof_used++]; *e1 = c->prof_pool[c->prof_used++];
+}
+static void prof_push(RiftCtx* c, const char* label, hipEvent_t e0, hipEvent_t e1, double flops) {
+  c->prof_recs.push_back(RiftCtx::Rec{label, e0, e1, flops});
+}
 
 #define HIPCHK(ctx, expr)                                                                 \
   do {                                                                                    \
@@ -77,9 +90,25 @@ void tap(RiftCtx* c, const char* name, float* p, int64_t numel) {
 }
 
 template <class... KArgs, class... Args>
-void launch(RiftCtx* c, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
+void launch(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
   if (c->dry || grid.x == 0 || grid.y == 0) return;
+  if (c->prof_on) {
+    hipEvent_t e0, e1;
+    prof_events(c, &e0, &e1);
+    (void)hipEventRecord(e0, c->stream);
+    hipLaunchKernelGGL(kern, grid, block, shmem, c->stream, static_cast<KArgs>(args)...);
+    (void)hipEventRecord(e1, c->stream);
+    prof_push(c, label, e0, e1, c->prof_flops);
+    c->prof_flops = 0.0;
+    return;
+  }
   hipLaunchKernelGGL(kern, grid, block, shmem, c->stream, static_cast<KArgs>(args)...);
+}
+
+template <class... KArgs>
+void launch_gemm(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, const GemmP& g) {
+  c->prof_flops = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+  launch(c, label, kern, grid, block, shmem, g);
 }
 
 const Param* find(RiftCtx* c, const std::string& name) {
@@ -185,9 +214,9 @@ template <bool BF16>
 void gemm_launch(RiftCtx* c, const GemmP& g) {
   const size_t lds = (size_t)64 * (g.Kp + Prec<BF16>::PAD) * sizeof(typename Prec<BF16>::lds_t);
   const dim3 grid(cdiv(g.M, 64)), block(256);
-  if (g.N <= 128) launch(c, gemm_rows_kernel<BF16, 1, 8, 4, 1>, grid, block, lds, g);
-  else if (g.N <= 192) launch(c, gemm_rows_kernel<BF16, 2, 6, 2, 2>, grid, block, lds, g);
-  else launch(c, gemm_rows_kernel<BF16, 4, 4, 1, 4>, grid, block, lds, g);
+  if (g.N <= 128) launch_gemm(c, BF16 ? "gemm_bf16_m1n8" : "gemm_fp32_m1n8", gemm_rows_kernel<BF16, 1, 8, 4, 1>, grid, block, lds, g);
+  else if (g.N <= 192) launch_gemm(c, BF16 ? "gemm_bf16_m2n6" : "gemm_fp32_m2n6", gemm_rows_kernel<BF16, 2, 6, 2, 2>, grid, block, lds, g);
+  else launch_gemm(c, BF16 ? "gemm_bf16_m4n4" : "gemm_fp32_m4n4", gemm_rows_kernel<BF16, 4, 4, 1, 4>, grid, block, lds, g);
 }
 
 void gemm(RiftCtx* c, GemmP g, const PW& w, bool fp32) {
@@ -216,7 +245,7 @@ struct Fwd {   // per-forward context
 
 void layernorm(Fwd& f, const float* X, int ldx, float* Y, int ldy, int rows, int C, const std::string& name, int relu = 0) {
   RiftCtx* c = f.c;
-  launch(c, layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, X, ldx, Y, ldy, rows, C, fptr(c, name + ".weight"),
+  launch(c, "layernorm_kernel", layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, X, ldx, Y, ldy, rows, C, fptr(c, name + ".weight"),
          fptr(c, name + ".bias"), 1e-5f, relu);
 }
 
@@ -224,7 +253,7 @@ void layernorm(Fwd& f, const float* X, int ldx, float* Y, int ldy, int rows, int
 float* fourier(Fwd& f, const float* in, int in_ld, int rows, int D, const std::string& p, int wrap_dim) {
   RiftCtx* c = f.c;
   float* FF = A_alloc<float>(c, (size_t)D * rows * 129);
-  launch(c, fourier_feature_kernel, dim3(cdiv((long long)D * rows * 65, 256)), dim3(256), 0, in, in_ld, rows, D,
+  launch(c, "fourier_feature_kernel", fourier_feature_kernel, dim3(cdiv((long long)D * rows * 65, 256)), dim3(256), 0, in, in_ld, rows, D,
          fptr(c, p + ".freqs.weight"), wrap_dim, FF);
   float* T1 = A_alloc<float>(c, (size_t)rows * 128);
   float* acc = A_alloc<float>(c, (size_t)rows * 128);
@@ -253,9 +282,9 @@ void batchnorm_affine(Fwd& f, const float* X, int rows, int C, const uint8_t* va
   const int nblk = cdiv(rows, rows_per_blk);
   double* part = A_alloc<double>(c, (size_t)nblk * 2 * C);
   int* cnt = A_alloc<int>(c, nblk);
-  if (f.train) launch(c, bn_partial_kernel, dim3(nblk), dim3(C), 0, X, C, rows, C, valid, part, cnt, rows_per_blk);
+  if (f.train) launch(c, "bn_partial_kernel", bn_partial_kernel, dim3(nblk), dim3(C), 0, X, C, rows, C, valid, part, cnt, rows_per_blk);
   const Param* nb = find(c, name + ".num_batches_tracked");
-  launch(c, bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (const double*)part, (const int*)cnt, nblk, C,
+  launch(c, "bn_finalize_kernel", bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (const double*)part, (const int*)cnt, nblk, C,
          fptr(c, name + ".weight"), fptr(c, name + ".bias"), (float*)fptr(c, name + ".running_mean"),
          (float*)fptr(c, name + ".running_var"), nb ? (long long*)nb->data : (long long*)nullptr, f.train ? 1 : 0,
          f.bn_update ? 1 : 0, 1e-5f, *scale, *shift);
@@ -274,7 +303,7 @@ float* points_encoder(Fwd& f, const float* F, int Cin, int groups, int n, const 
   g.pro = PRO_AFFINE; g.pg = s1; g.pb = t1; g.pro_relu = 1;
   gemm(c, g, c->pw[p + ".first_mlp.3"], f.fp32);
   float* pooled = A_alloc<float>(c, (size_t)groups * 256);
-  launch(c, masked_maxpool_kernel, dim3(cdiv((long long)groups * 256, 256)), dim3(256), 0, (const float*)F256, 256, groups, n, 256,
+  launch(c, "masked_maxpool_kernel", masked_maxpool_kernel, dim3(cdiv((long long)groups * 256, 256)), dim3(256), 0, (const float*)F256, 256, groups, n, 256,
          valid, pooled);
   float* G1 = A_alloc<float>(c, (size_t)groups * 256);
   gemm(c, mk(pooled, 256, groups, c->pw[p + ".second_mlp.0.pool"], G1, 256), c->pw[p + ".second_mlp.0.pool"], f.fp32);
@@ -289,14 +318,14 @@ float* points_encoder(Fwd& f, const float* F, int Cin, int groups, int n, const 
   g3.pro = PRO_AFFINE; g3.pg = s2; g3.pb = t2; g3.pro_relu = 1;
   gemm(c, g3, c->pw[p + ".second_mlp.3"], f.fp32);
   float* out = A_alloc<float>(c, (size_t)groups * 128);
-  launch(c, masked_maxpool_kernel, dim3(cdiv((long long)groups * 128, 256)), dim3(256), 0, (const float*)O, 128, groups, n, 128,
+  launch(c, "masked_maxpool_kernel", masked_maxpool_kernel, dim3(cdiv((long long)groups * 128, 256)), dim3(256), 0, (const float*)O, 128, groups, n, 128,
          valid, out);
   return out;
 }
 
 void run_mha(RiftCtx* c, const MhaP& p) {
   const long long total = (long long)p.nb_outer * p.nb_inner * p.H * p.Lq;
-  launch(c, mha_kernel, dim3(cdiv(total, 64)), dim3(64), 0, p);
+  launch(c, "mha_kernel", mha_kernel, dim3(cdiv(total, 64)), dim3(64), 0, p);
 }
 
 // NAT block (embedding.py:196-202) on X (rows, C) in place
@@ -308,8 +337,8 @@ void nat_layer(Fwd& f, float* X, int rows, int C, int H, int ksz, int L, const s
   gemm(c, g, c->pw[p + ".attn.qkv"], f.fp32);
   float* AO = A_alloc<float>(c, (size_t)rows * C);
   const int nthreads = rows * H;
-  if (ksz == 3) launch(c, nat_attention_kernel<3>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (const float*)QKV, fptr(c, p + ".attn.rpb"), rows / L, L, H, AO);
-  else launch(c, nat_attention_kernel<5>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (const float*)QKV, fptr(c, p + ".attn.rpb"), rows / L, L, H, AO);
+  if (ksz == 3) launch(c, "nat_attention_kernel", nat_attention_kernel<3>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (const float*)QKV, fptr(c, p + ".attn.rpb"), rows / L, L, H, AO);
+  else launch(c, "nat_attention_kernel", nat_attention_kernel<5>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (const float*)QKV, fptr(c, p + ".attn.rpb"), rows / L, L, H, AO);
   GemmP g2 = mk(AO, C, rows, c->pw[p + ".attn.proj"], X, C);
   g2.residual = X; g2.ldr = C;
   if (f.drop && droppath > 0.f) { g2.droppath_p = droppath; g2.dp_div = L; g2.seed = f.seed; g2.stream = f.next_stream(); }
@@ -358,7 +387,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // ================= agent encoder (agent_encoder.py:54-96, embedding.py:62-87) =================
   float* F9 = A_alloc<float>(c, (size_t)nA * 20 * 9);
   uint8_t* valid_agent = A_alloc<uint8_t>(c, nA);
-  launch(c, agent_feature_kernel, dim3(cdiv((long long)nA * 20, 256)), dim3(256), 0, B->agent_position, B->agent_heading,
+  launch(c, "agent_feature_kernel", agent_feature_kernel, dim3(cdiv((long long)nA * 20, 256)), dim3(256), 0, B->agent_position, B->agent_heading,
          B->agent_velocity, B->agent_shape, B->agent_valid_mask, nA, T, F9, valid_agent);
   float* X0 = A_alloc<float>(c, (size_t)nA * 20 * 32);
   {
@@ -399,7 +428,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       float* Oc = A_alloc<float>(c, (size_t)nA * 3 * Cl[i]);
       // rows (a, j) <- level rows (a*L + L-3 + j): per-agent window via ldx trick is not possible -> 3 strided LN calls
       for (int j = 0; j < 3; ++j)
-        launch(c, layernorm_kernel, dim3(cdiv(nA, 4)), dim3(256), 0, (const float*)(Xl[i] + (size_t)(Ll[i] - 3 + j) * Cl[i]),
+        launch(c, "layernorm_kernel", layernorm_kernel, dim3(cdiv(nA, 4)), dim3(256), 0, (const float*)(Xl[i] + (size_t)(Ll[i] - 3 + j) * Cl[i]),
                Ll[i] * Cl[i], Oc + (size_t)j * Cl[i], 3 * Cl[i], nA, Cl[i],
                fptr(c, HE + ".norm" + std::to_string(i) + ".weight"), fptr(c, HE + ".norm" + std::to_string(i) + ".bias"),
                1e-5f, 0);
@@ -411,7 +440,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     }
   }
   float* Z = A_alloc<float>(c, (size_t)nA * 256);
-  launch(c, fpn_merge_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)lat[0], (const float*)lat[1],
+  launch(c, "fpn_merge_kernel", fpn_merge_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)lat[0], (const float*)lat[1],
          (const float*)lat[2], nA, Z);
   float* nat_out = A_alloc<float>(c, (size_t)nA * 128);
   gemm(c, mk(Z, 256, nA, c->pw[HE + ".fpn_conv.last"], nat_out, 128), c->pw[HE + ".fpn_conv.last"], f.fp32);
@@ -420,7 +449,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // ego state token (StateAttentionEncoder, agent_encoder.py:99-140)
   const std::string EG = "agent_encoder.ego_state_emb";
   float* E = A_alloc<float>(c, (size_t)bs * 6 * 128);
-  launch(c, ego_token_kernel, dim3(cdiv((long long)bs * 6 * 128, 256)), dim3(256), 0, B->current_state, B->cs_ld,
+  launch(c, "ego_token_kernel", ego_token_kernel, dim3(cdiv((long long)bs * 6 * 128, 256)), dim3(256), 0, B->current_state, B->cs_ld,
          (const float*)c->ego_w, (const float*)c->ego_b, fptr(c, EG + ".pos_embed"), bs, E);
   float* EKV = A_alloc<float>(c, (size_t)bs * 6 * 256);
   gemm(c, mk(E, 128, bs * 6, c->pw[EG + ".attn.kv"], EKV, 256), c->pw[EG + ".attn.kv"], f.fp32);
@@ -429,7 +458,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   uint8_t* edrop = nullptr;
   if (f.drop) {
     edrop = A_alloc<uint8_t>(c, (size_t)bs * 6);
-    launch(c, ego_dropmask_kernel, dim3(cdiv(bs * 6, 256)), dim3(256), 0, bs, 0.75f, f.seed, f.next_stream(), edrop);
+    launch(c, "ego_dropmask_kernel", ego_dropmask_kernel, dim3(cdiv(bs * 6, 256)), dim3(256), 0, bs, 0.75f, f.seed, f.next_stream(), edrop);
   }
   float* EAO = A_alloc<float>(c, (size_t)bs * 128);
   {
@@ -445,33 +474,33 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 
   // ================= tokens =================
   float* X = A_alloc<float>(c, (size_t)nT * 128);
-  launch(c, agent_token_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)nat_out, (const float*)x_ego,
+  launch(c, "agent_token_kernel", agent_token_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)nat_out, (const float*)x_ego,
          (const uint8_t*)valid_agent, B->agent_category, fptr(c, "agent_encoder.type_emb.weight"), bs, A, N, X);
 
   // map encoder (map_encoder.py:31-93)
   float* F10 = A_alloc<float>(c, (size_t)nP * 20 * 10);
-  launch(c, map_feature_kernel, dim3(cdiv((long long)nP * 20, 256)), dim3(256), 0, B->map_point_position, B->map_point_vector,
+  launch(c, "map_feature_kernel", map_feature_kernel, dim3(cdiv((long long)nP * 20, 256)), dim3(256), 0, B->map_point_position, B->map_point_vector,
          B->map_point_orientation, B->map_polygon_center, nP, F10);
   float* poly = points_encoder(f, F10, 10, nP, 20, B->map_valid_mask, "map_encoder.polygon_encoder");
   float* speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
-  launch(c, polygon_token_kernel, dim3(cdiv((long long)nP * 128, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
+  launch(c, "polygon_token_kernel", polygon_token_kernel, dim3(cdiv((long long)nP * 128, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
          B->map_polygon_on_route, B->map_polygon_tl_status, B->map_polygon_has_speed_limit, (const float*)speed_emb,
          fptr(c, "map_encoder.type_emb.weight"), fptr(c, "map_encoder.on_route_emb.weight"),
          fptr(c, "map_encoder.traffic_light_emb.weight"), fptr(c, "map_encoder.unknown_speed_emb.weight"), bs, A, Mp, N, X);
   if (S > 0) {
     float* semb = fourier(f, B->static_shape, 2, bs * S, 2, "static_objects_encoder.obj_encoder", -1);
-    launch(c, static_token_kernel, dim3(cdiv((long long)bs * S * 128, 256)), dim3(256), 0, (const float*)semb, B->static_category,
+    launch(c, "static_token_kernel", static_token_kernel, dim3(cdiv((long long)bs * S * 128, 256)), dim3(256), 0, (const float*)semb, B->static_category,
            B->static_valid_mask, fptr(c, "static_objects_encoder.type_emb.weight"), bs, A, Mp, S, N, X);
   }
   tap(c, "x_tokens_nopos", X, (int64_t)nT * 128);
   uint8_t* kpm = A_alloc<uint8_t>(c, nT);
-  launch(c, token_mask_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, (const uint8_t*)valid_agent, B->map_valid_mask,
+  launch(c, "token_mask_kernel", token_mask_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, (const uint8_t*)valid_agent, B->map_valid_mask,
          B->static_valid_mask, bs, A, Mp, S, kpm);
   float* pos = A_alloc<float>(c, (size_t)nT * 3);
-  launch(c, token_pos_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, B->agent_position, B->agent_heading, T, B->map_polygon_center,
+  launch(c, "token_pos_kernel", token_pos_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, B->agent_position, B->agent_heading, T, B->map_polygon_center,
          B->static_position, B->static_heading, bs, A, Mp, S, pos);
   float* PE = fourier(f, pos, 3, nT, 3, "pos_emb", 2);
-  launch(c, add_inplace_kernel, dim3(cdiv((long long)nT * 128, 256)), dim3(256), 0, X, (const float*)PE, (size_t)nT * 128);
+  launch(c, "add_inplace_kernel", add_inplace_kernel, dim3(cdiv((long long)nT * 128, 256)), dim3(256), 0, X, (const float*)PE, (size_t)nT * 128);
   tap(c, "x_tokens", X, (int64_t)nT * 128);
 
   // ================= encoder blocks (transformer.py:73-94) =================
@@ -510,7 +539,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (f.need_traj && out->prediction && A > 1) {
     const int rows = bs * (A - 1);
     float* Xa = A_alloc<float>(c, (size_t)rows * 128);
-    launch(c, gather_rows_kernel, dim3(cdiv((long long)rows * 128, 256)), dim3(256), 0, (const float*)ENC, 128, Xa, 128, rows, 128,
+    launch(c, "gather_rows_kernel", gather_rows_kernel, dim3(cdiv((long long)rows * 128, 256)), dim3(256), 0, (const float*)ENC, 128, Xa, 128, rows, 128,
            A - 1, N, 1);
     float* o3[3];
     const char* nm[3] = {"loc_predictor", "yaw_predictor", "vel_predictor"};
@@ -518,29 +547,29 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       o3[i] = A_alloc<float>(c, (size_t)rows * 160);
       mlp_layer(f, Xa, 128, rows, std::string("agent_predictor.") + nm[i], o3[i], 160, f.fp32);
     }
-    launch(c, interleave_traj_kernel, dim3(cdiv((long long)rows * 480, 256)), dim3(256), 0, (const float*)o3[0], (const float*)o3[1],
+    launch(c, "interleave_traj_kernel", interleave_traj_kernel, dim3(cdiv((long long)rows * 480, 256)), dim3(256), 0, (const float*)o3[0], (const float*)o3[1],
            (const float*)o3[2], rows, out->prediction);
   }
 
   // ================= planning decoder (planning_decoder.py:135-188) =================
   const std::string PD = "planning_decoder";
   float* F6 = A_alloc<float>(c, (size_t)nL * 120 * 6);
-  launch(c, ref_feature_kernel, dim3(cdiv((long long)nL * 120, 256)), dim3(256), 0, B->ref_position, B->ref_vector,
+  launch(c, "ref_feature_kernel", ref_feature_kernel, dim3(cdiv((long long)nL * 120, 256)), dim3(256), 0, B->ref_position, B->ref_vector,
          B->ref_orientation, nL, F6);
   uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
-  launch(c, refline_mask_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_valid_mask, nL, r_kpm);
+  launch(c, "refline_mask_kernel", refline_mask_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_valid_mask, nL, r_kpm);
   float* r_emb = points_encoder(f, F6, 6, nL, 120, B->ref_valid_mask, PD + ".r_encoder");
   float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
-  launch(c, refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
+  launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
   float* RPE = fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1);
-  launch(c, add_inplace_kernel, dim3(cdiv((long long)nL * 128, 256)), dim3(256), 0, r_emb, (const float*)RPE, (size_t)nL * 128);
+  launch(c, "add_inplace_kernel", add_inplace_kernel, dim3(cdiv((long long)nL * 128, 256)), dim3(256), 0, r_emb, (const float*)RPE, (size_t)nL * 128);
   tap(c, "r_emb", r_emb, (int64_t)nL * 128);
   float* Ra = A_alloc<float>(c, (size_t)nL * 128);
   gemm(c, mk(r_emb, 128, nL, c->pw[PD + ".q_proj.r"], Ra, 128), c->pw[PD + ".q_proj.r"], f.fp32);
   float* Mb = A_alloc<float>(c, (size_t)M * 128);
   gemm(c, mk(fptr(c, PD + ".m_emb"), 128, M, c->pw[PD + ".q_proj.m"], Mb, 128), c->pw[PD + ".q_proj.m"], f.fp32);
   float* Q = A_alloc<float>(c, (size_t)nQ * 128);
-  launch(c, build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
+  launch(c, "build_q0_kernel", build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
 
   float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
   float* DAO = A_alloc<float>(c, (size_t)nQ * 128);
@@ -634,7 +663,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     gemm(c, mk(QF, 128, nQ, w, Hpi, 128), w, true);
   }
   float* prob = out->probability ? out->probability : A_alloc<float>(c, nQ);
-  launch(c, pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
+  launch(c, "pi_tail_kernel", pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
          fptr(c, PD + ".pi_head.mlp.1.bias"), fptr(c, PD + ".pi_head.mlp.3.weight"), fptr(c, PD + ".pi_head.mlp.3.bias"),
          (const uint8_t*)r_kpm, 1e-5f, prob);
   if (f.need_traj && out->trajectory) {
@@ -644,7 +673,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       o3[i] = A_alloc<float>(c, (size_t)nQ * 160);
       mlp_layer(f, QF, 128, nQ, PD + "." + nm[i], o3[i], 160, f.fp32);
     }
-    launch(c, interleave_traj_kernel, dim3(cdiv((long long)nQ * 480, 256)), dim3(256), 0, (const float*)o3[0], (const float*)o3[1],
+    launch(c, "interleave_traj_kernel", interleave_traj_kernel, dim3(cdiv((long long)nQ * 480, 256)), dim3(256), 0, (const float*)o3[0], (const float*)o3[1],
            (const float*)o3[2], nQ, out->trajectory);
   }
   // hidden_proj / ref_free_decoder on the ego token (pluto_model.py:173-180)
@@ -841,14 +870,14 @@ int rift_loss_backward(RiftCtx* c, int kind, const RiftLossIn* in, const RiftLos
   if (kind == RIFT_LOSS_PPO && (!p.action_mode || !p.scal_a || !p.old_log_prob)) { c->err = "missing ppo inputs"; return RIFT_ERR_ARG; }
   if (kind == RIFT_LOSS_REINFORCE && !p.scal_a) { c->err = "missing returns"; return RIFT_ERR_ARG; }
   const dim3 lgrid(cdiv(bs, 4)), lblock(256);
-  if (G <= 64 * 2) launch(c, loss_kernel<2>, lgrid, lblock, 0, p);
-  else if (G <= 64 * 4) launch(c, loss_kernel<4>, lgrid, lblock, 0, p);
-  else launch(c, loss_kernel<16>, lgrid, lblock, 0, p);
+  if (G <= 64 * 2) launch(c, "loss_kernel", loss_kernel<2>, lgrid, lblock, 0, p);
+  else if (G <= 64 * 4) launch(c, "loss_kernel", loss_kernel<4>, lgrid, lblock, 0, p);
+  else launch(c, "loss_kernel", loss_kernel<16>, lgrid, lblock, 0, p);
   const std::string PH = "planning_decoder.pi_head.mlp.";
-  launch(c, pi_backward_kernel, dim3(nwg), dim3(256), 0, (const float*)c->last_qfinal, (const float*)c->last_hpi,
+  launch(c, "pi_backward_kernel", pi_backward_kernel, dim3(nwg), dim3(256), 0, (const float*)c->last_qfinal, (const float*)c->last_hpi,
          (const float*)c->l_dz, rows, fptr(c, PH + "1.weight"), fptr(c, PH + "1.bias"), fptr(c, PH + "3.weight"), 1e-5f,
          c->l_partial);
-  launch(c, loss_reduce_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)c->l_partial, nwg,
+  launch(c, "loss_reduce_kernel", loss_reduce_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)c->l_partial, nwg,
          out->flat_grad_sum, (const double*)c->l_S, (const double*)c->l_cnt, bs, out->stats);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
@@ -857,10 +886,41 @@ int rift_loss_backward(RiftCtx* c, int kind, const RiftLossIn* in, const RiftLos
 int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void* stream) {
   if (!c || !out || !out->stats || !out->flat_grad_sum) return RIFT_ERR_ARG;
   c->stream = (hipStream_t)stream; c->dry = false;
-  launch(c, loss_finalize_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)out->flat_grad_sum,
+  launch(c, "loss_finalize_kernel", loss_finalize_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)out->flat_grad_sum,
          (const double*)out->stats, out->grad_w1, out->grad_b1, out->grad_ln_w, out->grad_ln_b, out->grad_w2, out->grad_b2,
          out->loss, accumulate);
   HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_prof_enable(RiftCtx* c, int on) {
+  if (!c) return RIFT_ERR_ARG;
+  c->prof_on = on != 0;
+  if (on) { c->prof_recs.clear(); c->prof_used = 0; }
+  return RIFT_OK;
+}
+
+// JSON: {"label": {"count": n, "ms": total_ms, "flops": total_flops}, ...}; synchronises the device.
+int rift_prof_report(RiftCtx* c, char* buf, int buflen) {
+  if (!c || !buf || buflen <= 0) return RIFT_ERR_ARG;
+  HIPCHK(c, hipDeviceSynchronize());
+  struct Agg { long n = 0; double ms = 0, fl = 0; };
+  std::unordered_map<std::string, Agg> agg;
+  for (auto& r : c->prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    Agg& a = agg[r.label]; a.n++; a.ms += ms; a.fl += r.flops;
+  }
+  std::string js = "{";
+  bool first = true;
+  for (auto& kv : agg) {
+    char tmp[256];
+    snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"count\": %ld, \"ms\": %.6f, \"flops\": %.6e}", first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.fl);
+    js += tmp; first = false;
+  }
+  js += "}";
+  if ((int)js.size() + 1 > buflen) { c->err = "prof buffer too small"; return RIFT_ERR_ARG; }
+  memcpy(buf, js.c_str(), js.size() + 1);
   return RIFT_OK;
 }
 

@@ -1,0 +1,189 @@
+"""RLFT trainer core: the policy-update step of the reference's four LightningTrainers
+(rift_pluto/rift_trainer.py, grpo_pluto/grpo_trainer.py, ppo_pluto/ppo_trainer.py,
+reinforce_pluto/reinforce_trainer.py) on the HIP engine, without Lightning.
+
+One step = train-mode forward (HIP) -> objective + analytic pi_head backward (HIP)
+-> [DP: one fused RCCL all-reduce of (grad sums | objective sum | count)] -> loss / grads
+-> clip_grad_norm_(0.5) -> AdamW.  The optimizer and the collective stay in
+PyTorch-ROCm, as the reference's optimizer does (rift_trainer.py:279-362).
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from rift_amd import _ffi
+
+PI_HEAD = "planning_decoder.pi_head"
+PI_KEYS = ("mlp.0.weight", "mlp.0.bias", "mlp.1.weight", "mlp.1.bias", "mlp.3.weight", "mlp.3.bias")
+
+
+class WarmupCosLR:
+    """Per-epoch schedule of pluto/optim/warmup_cos_lr.py:39-54."""
+
+    def __init__(self, optimizer, lr, min_lr, warmup_epochs, epochs):
+        self.optimizer, self.lr, self.min_lr, self.warmup_epochs, self.epochs = optimizer, lr, min_lr, warmup_epochs, epochs
+        self.last_epoch = 0
+        self._apply()
+
+    def get_lr(self):
+        e = self.last_epoch
+        if e < self.warmup_epochs:
+            return self.lr * (e + 1) / self.warmup_epochs
+        return self.min_lr + 0.5 * (self.lr - self.min_lr) * (
+            1 + math.cos(math.pi * (e - self.warmup_epochs) / (self.epochs - self.warmup_epochs)))
+
+    def _apply(self):
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.get_lr() * g.get("lr_scale", 1.0)
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+
+def freeze_parameters(model: nn.Module, trainable_layers: List[str]):
+    """rift_trainer.py:78-90."""
+    for p in model.parameters():
+        p.requires_grad = False
+    mods = dict(model.named_modules())
+    for name in trainable_layers:
+        layer = mods.get(name)
+        if layer is None:
+            raise ValueError(f"Layer {name} not found in the model.")
+        for p in layer.parameters():
+            p.requires_grad = True
+
+
+def configure_optimizer(model: nn.Module, lr: float, weight_decay: float):
+    """Parameter grouping of rift_trainer.py:279-362: trainable Linear/Conv/MHA weights decay,
+    biases / norm / embedding weights do not; AdamW."""
+    white = (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.MultiheadAttention, nn.LSTM, nn.GRU)
+    black = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm, nn.LayerNorm, nn.Embedding)
+    decay, no_decay = set(), set()
+    for mn, m in model.named_modules():
+        for pn, p in m.named_parameters():
+            fpn = f"{mn}.{pn}" if mn else pn
+            if not p.requires_grad:
+                continue
+            if "bias" in pn:
+                no_decay.add(fpn)
+            elif "weight" in pn:
+                if isinstance(m, white):
+                    decay.add(fpn)
+                elif isinstance(m, black):
+                    no_decay.add(fpn)
+            else:
+                no_decay.add(fpn)
+    pd = {n: p for n, p in model.named_parameters() if p.requires_grad}
+    assert not (decay & no_decay) and not (pd.keys() - (decay | no_decay))
+    groups = [{"params": [pd[n] for n in sorted(decay)], "weight_decay": weight_decay},
+              {"params": [pd[n] for n in sorted(no_decay)], "weight_decay": 0.0}]
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+
+
+class RLFTTrainer:
+    """Update-step driver for kind in {'rift','grpo','ppo','reinforce'}.
+
+    `process_group` (torch.distributed, backend nccl = RCCL on ROCm) enables data parallelism:
+    scenes are sharded across ranks, the exchange step is one all-reduce per optimizer step."""
+
+    def __init__(self, model, kind: str = "rift", lr=1e-4, cl_lr_decay=0.9, weight_decay=1e-5, epochs=16,
+                 warmup_epochs=3, trainable_layers=(PI_HEAD,), gradient_clip_val=0.5, process_group=None,
+                 clip_epsilon=0.2, lambda_entropy=0.01):
+        if kind not in _ffi.LOSS_KINDS:
+            raise ValueError(kind)
+        if tuple(trainable_layers) != (PI_HEAD,):
+            raise NotImplementedError(
+                "the HIP backward covers the reference's configured trainable set "
+                "['planning_decoder.pi_head'] (rift_training.yaml:26-27); other layers are not implemented")
+        self.model, self.kind, self.kind_id = model, kind, _ffi.LOSS_KINDS[kind]
+        self.lr, self.epochs, self.warmup_epochs = lr, epochs, warmup_epochs
+        self.gradient_clip_val = gradient_clip_val
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        freeze_parameters(model, list(trainable_layers))
+        self.optimizer = configure_optimizer(model, lr, weight_decay)
+        self.scheduler = WarmupCosLR(self.optimizer, lr=lr, min_lr=lr * cl_lr_decay, warmup_epochs=warmup_epochs,
+                                     epochs=epochs)
+        self.engine = model.engine()
+        dev = self.engine.device
+        head = dict(model.named_modules())[PI_HEAD]
+        self.params = {k: dict(head.named_parameters())[k] for k in PI_KEYS}
+        for p in self.params.values():
+            p.grad = torch.zeros_like(p)
+        self.train_params = list(self.params.values())
+        # fused exchange buffer: [flat grad sums (16897 f32 as f64? no) ...] kept as two tensors
+        self.flat = torch.zeros(_ffi.PI_NPARAM, dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.lo = _ffi.RiftLossOut()
+        self.lo.loss, self.lo.stats, self.lo.flat_grad_sum = self.loss.data_ptr(), self.stats.data_ptr(), self.flat.data_ptr()
+        g = self.params
+        self.lo.grad_w1, self.lo.grad_b1 = g["mlp.0.weight"].grad.data_ptr(), g["mlp.0.bias"].grad.data_ptr()
+        self.lo.grad_ln_w, self.lo.grad_ln_b = g["mlp.1.weight"].grad.data_ptr(), g["mlp.1.bias"].grad.data_ptr()
+        self.lo.grad_w2, self.lo.grad_b2 = g["mlp.3.weight"].grad.data_ptr(), g["mlp.3.bias"].grad.data_ptr()
+        self.li = _ffi.RiftLossIn()
+        self.li.clip_epsilon, self.li.lambda_entropy = clip_epsilon, lambda_entropy
+        self.out = _ffi.RiftOutputs()
+        self._prob = None
+        self._hidden = None
+        self._argmax = None
+        self.step_count = 0
+        self.training = True
+
+    # ------------------------------------------------------------------------------------
+    def _outputs(self, bs, R):
+        if self._prob is None or self._prob.shape[:2] != (bs, R):
+            dev = self.engine.device
+            self._prob = torch.empty(bs, R, 12, device=dev)
+            self._hidden = torch.empty(bs, 128, device=dev)
+            self._argmax = torch.zeros(bs, 2, dtype=torch.int64, device=dev)
+            self.out.probability, self.out.hidden = self._prob.data_ptr(), self._hidden.data_ptr()
+            self.lo.argmax_rm = self._argmax.data_ptr()
+        return self._prob
+
+    def set_loss_inputs(self, b: Dict[str, torch.Tensor]):
+        p = _ffi._ptr
+        self._li_keep = b
+        self.li.old_group_logits = p(b.get("old_group_logits"))
+        self.li.ref_group_logits = p(b.get("ref_group_logits"))
+        self.li.group_advantage = p(b.get("group_advantage"))
+        self.li.group_valid_mask = p(b.get("group_valid_mask"))
+        self.li.action_mode = p(b.get("action_mode"))
+        self.li.advantage = p(b.get("advantage"))
+        self.li.old_log_prob = p(b.get("old_log_prob"))
+        self.li.returns = p(b.get("returns"))
+
+    def forward_loss(self, fb: "_ffi.RiftFeatureBatch", extras: Dict[str, torch.Tensor], train: bool = True,
+                     backward: bool = True, flags_extra: int = 0):
+        """forward + objective (+ pi_head backward into .grad).  Returns the device f64 loss scalar."""
+        eng = self.engine
+        self._outputs(fb.bs, fb.R)
+        flags = (_ffi.F_TRAIN if train else 0) | (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | \
+                (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0) | flags_extra
+        self.step_count += 1
+        eng.forward_raw(fb, self.out, flags, self.step_count)
+        self.set_loss_inputs(extras)
+        eng.loss_backward_raw(self.kind_id, self.li, self.lo)
+        if self.pg is not None and self.world > 1:
+            torch.distributed.all_reduce(self.flat, group=self.pg)
+            torch.distributed.all_reduce(self.stats, group=self.pg)
+        eng.loss_finalize_raw(self.lo, 0)
+        return self.loss
+
+    def training_step(self, fb, extras):
+        """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step)."""
+        loss = self.forward_loss(fb, extras, train=True)
+        if self.gradient_clip_val:
+            torch.nn.utils.clip_grad_norm_(self.train_params, self.gradient_clip_val)
+        self.optimizer.step()
+        return loss
+
+    def validation_step(self, fb, extras):
+        return self.forward_loss(fb, extras, train=False)
+
+    def on_epoch_end(self):
+        self.scheduler.step()
