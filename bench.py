@@ -159,7 +159,7 @@ def main():
                 "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                 "gpu_ms_per_step_sum_of_kernels": tot_ms / nprof,
                 "per_kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in
-                                           sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
+                                           sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("RIFT_PROF_TOP", "12"))]}}
 
     if rank == 0:
         steps_per_sec = args.steps / dt

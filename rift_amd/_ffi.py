@@ -272,7 +272,7 @@ class Engine:
 
     def prof_report(self) -> dict:
         import json
-        buf = C.create_string_buffer(1 << 16)
+        buf = C.create_string_buffer(1 << 18)
         self._check(self.lib.rift_prof_report(self.ctx, buf, len(buf)), "rift_prof_report")
         return json.loads(buf.value.decode())
 

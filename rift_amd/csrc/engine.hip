@@ -3,8 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -50,7 +52,8 @@ struct RiftCtx {
   float* ego_w = nullptr; float* ego_b = nullptr;   // packed (6,128) linears of StateAttentionEncoder
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
-  bool prof_on = false; double prof_flops = 0.0;
+  bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
+  std::set<std::string> prof_names;
   std::vector<hipEvent_t> prof_pool; size_t prof_used = 0;
   struct Rec { const char* label; hipEvent_t e0, e1; double flops; };
   std::vector<Rec> prof_recs;
@@ -108,6 +111,12 @@ void launch(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 grid, di
 template <class... KArgs>
 void launch_gemm(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, const GemmP& g) {
   c->prof_flops = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+  if (c->prof_on && c->prof_shapes) {   // RIFT_PROF_SHAPES=1: one label per GEMM shape (interned)
+    char tmp[160];
+    snprintf(tmp, sizeof(tmp), "%s:%dx%dx%d%s%s%s", label, g.M, g.N, g.K, g.pro == PRO_LN ? ":ln" : (g.pro == PRO_AFFINE ? ":bn" : ""),
+             g.amode == AMODE_CONV3 ? ":conv" : "", g.stage == 0 ? ":scalar" : "");
+    label = c->prof_names.insert(tmp).first->c_str();
+  }
   launch(c, label, kern, grid, block, shmem, g);
 }
 
@@ -210,17 +219,44 @@ GemmP mk(const float* X, int ldx, int M, const PW& w, float* Y, int ldy) {
   return g;
 }
 
+// Tile shapes (64 rows per workgroup, 4 waves):
+//   m1n8 : wave = 16 rows x 128 cols   -- small K (B fragments are few, A fragments read once)
+//   m4n2 : wave = 64 rows x  32 cols   -- N <= 128 with K >= 128 (each weight fragment feeds 4 MFMAs)
+//   m2n6 : wave = 32 rows x  96 cols   -- 128 < N <= 192
+//   m4n4 : wave = 64 rows x  64 cols   -- N > 192, 256 columns per pass
 template <bool BF16>
-void gemm_launch(RiftCtx* c, const GemmP& g) {
-  const size_t lds = (size_t)64 * (g.Kp + Prec<BF16>::PAD) * sizeof(typename Prec<BF16>::lds_t);
+void gemm_launch(RiftCtx* c, GemmP g) {
+  const size_t a_bytes = (((size_t)64 * (g.Kp + Prec<BF16>::PAD) * sizeof(typename Prec<BF16>::lds_t)) + 15) & ~(size_t)15;
+  int variant;   // 0 m1n8, 1 m4n2, 2 m2n6, 3 m4n4
+  if (g.N <= 128) variant = (g.Kp >= 128 && g.N > 32) ? 1 : 0;
+  else if (g.N <= 192) variant = 2;
+  else variant = 3;
+  static const int NTs[4] = {8, 2, 6, 4}, WNs[4] = {1, 4, 2, 4};
+  const int NT = NTs[variant], WN = WNs[variant];
+  const size_t c_bytes = (size_t)4 * 16 * (16 * NT + 4) * 4;
+  const bool single = g.N <= 16 * NT * WN;
+  g.cs_off = single ? 0 : (int)a_bytes;
+  const size_t lds = single ? (a_bytes > c_bytes ? a_bytes : c_bytes) : a_bytes + c_bytes;
   const dim3 grid(cdiv(g.M, 64)), block(256);
-  if (g.N <= 128) launch_gemm(c, BF16 ? "gemm_bf16_m1n8" : "gemm_fp32_m1n8", gemm_rows_kernel<BF16, 1, 8, 4, 1>, grid, block, lds, g);
-  else if (g.N <= 192) launch_gemm(c, BF16 ? "gemm_bf16_m2n6" : "gemm_fp32_m2n6", gemm_rows_kernel<BF16, 2, 6, 2, 2>, grid, block, lds, g);
-  else launch_gemm(c, BF16 ? "gemm_bf16_m4n4" : "gemm_fp32_m4n4", gemm_rows_kernel<BF16, 4, 4, 1, 4>, grid, block, lds, g);
+  switch (variant) {
+    case 0: launch_gemm(c, BF16 ? "gemm_bf16_m1n8" : "gemm_fp32_m1n8", gemm_rows_kernel<BF16, 1, 8, 4, 1>, grid, block, lds, g); break;
+    case 1: launch_gemm(c, BF16 ? "gemm_bf16_m4n2" : "gemm_fp32_m4n2", gemm_rows_kernel<BF16, 4, 2, 1, 4>, grid, block, lds, g); break;
+    case 2: launch_gemm(c, BF16 ? "gemm_bf16_m2n6" : "gemm_fp32_m2n6", gemm_rows_kernel<BF16, 2, 6, 2, 2>, grid, block, lds, g); break;
+    default: launch_gemm(c, BF16 ? "gemm_bf16_m4n4" : "gemm_fp32_m4n4", gemm_rows_kernel<BF16, 4, 4, 1, 4>, grid, block, lds, g); break;
+  }
 }
 
 void gemm(RiftCtx* c, GemmP g, const PW& w, bool fp32) {
   if (g.M <= 0) return;
+  // vectorised A staging needs 16-byte aligned rows: dense conv windows (C % 4 == 0) or ldx % 4 == 0, K % 4 == 0
+  const bool conv = g.amode == AMODE_CONV3;
+  const bool al = (((uintptr_t)g.X) & 15) == 0 && (g.K % 4 == 0) && (conv ? (g.cv_C % 4 == 0 && g.ldx == g.cv_C) : (g.ldx % 4 == 0)) &&
+                  (g.pro == PRO_NONE || ((((uintptr_t)g.pg) | ((uintptr_t)g.pb)) & 15) == 0);
+  const int KV = g.Kp / 4;
+  g.stage = !al ? 0 : (KV <= 8 ? 1 : KV <= 16 ? 2 : KV <= 32 ? 3 : KV <= 64 ? 4 : 5);
+  g.evec = (g.N % 4 == 0) && (g.ldy % 4 == 0) && ((((uintptr_t)g.Y) & 15) == 0) &&
+           (!g.bias || (((uintptr_t)g.bias) & 15) == 0) && (!g.gbias || (((uintptr_t)g.gbias) & 15) == 0) &&
+           (!g.residual || ((g.ldr % 4 == 0) && (((uintptr_t)g.residual) & 15) == 0));
   if (fp32) { g.W = w.f32; gemm_launch<false>(c, g); }
   else { g.W = w.bf; gemm_launch<true>(c, g); }
 }
@@ -229,6 +265,8 @@ int set_lds_attrs(RiftCtx* c) {
   const int big = 160 * 1024;
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
   SETATTR((gemm_rows_kernel<true, 1, 8, 4, 1>));
+  SETATTR((gemm_rows_kernel<true, 4, 2, 1, 4>));
+  SETATTR((gemm_rows_kernel<false, 4, 2, 1, 4>));
   SETATTR((gemm_rows_kernel<true, 2, 6, 2, 2>));
   SETATTR((gemm_rows_kernel<true, 4, 4, 1, 4>));
   SETATTR((gemm_rows_kernel<false, 1, 8, 4, 1>));
@@ -278,13 +316,13 @@ void batchnorm_affine(Fwd& f, const float* X, int rows, int C, const uint8_t* va
                       float** scale, float** shift) {
   RiftCtx* c = f.c;
   *scale = A_alloc<float>(c, C); *shift = A_alloc<float>(c, C);
-  const int rows_per_blk = 512;
+  const int rows_per_blk = 128;
   const int nblk = cdiv(rows, rows_per_blk);
   double* part = A_alloc<double>(c, (size_t)nblk * 2 * C);
   int* cnt = A_alloc<int>(c, nblk);
   if (f.train) launch(c, "bn_partial_kernel", bn_partial_kernel, dim3(nblk), dim3(C), 0, X, C, rows, C, valid, part, cnt, rows_per_blk);
   const Param* nb = find(c, name + ".num_batches_tracked");
-  launch(c, "bn_finalize_kernel", bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (const double*)part, (const int*)cnt, nblk, C,
+  launch(c, "bn_finalize_kernel", bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (const double*)part, (const int*)cnt, nblk, C,
          fptr(c, name + ".weight"), fptr(c, name + ".bias"), (float*)fptr(c, name + ".running_mean"),
          (float*)fptr(c, name + ".running_var"), nb ? (long long*)nb->data : (long long*)nullptr, f.train ? 1 : 0,
          f.bn_update ? 1 : 0, 1e-5f, *scale, *shift);
@@ -323,7 +361,23 @@ float* points_encoder(Fwd& f, const float* F, int Cin, int groups, int n, const 
   return out;
 }
 
-void run_mha(RiftCtx* c, const MhaP& p) {
+template <int NKT>
+void run_mha_mfma(RiftCtx* c, const MhaP& p) {
+  const int nqt = (p.Lq + 15) / 16;
+  const int waves = nqt < 4 ? nqt : 4;
+  const size_t lds = (size_t)NKT * 16 * 40 * 2 + (size_t)32 * (NKT * 16 + 8) * 2 + NKT * 16;
+  launch(c, "mha_mfma_kernel", mha_mfma_kernel<NKT>, dim3(p.nb_outer * p.nb_inner * p.H), dim3(64 * waves), lds, p);
+}
+
+// bf16 mode: MFMA attention; fp32 mode (or unaligned / very long inputs): exact-fp32 VALU kernel
+void run_mha(RiftCtx* c, const MhaP& p, bool fp32) {
+  const bool al = ((((uintptr_t)p.Q) | ((uintptr_t)p.K) | ((uintptr_t)p.V)) & 15) == 0 && p.ldq % 4 == 0 && p.ldkv % 4 == 0;
+  if (!fp32 && al && p.Lk <= 192) {
+    if (p.Lk <= 32) run_mha_mfma<2>(c, p);
+    else if (p.Lk <= 96) run_mha_mfma<6>(c, p);
+    else run_mha_mfma<12>(c, p);
+    return;
+  }
   const long long total = (long long)p.nb_outer * p.nb_inner * p.H * p.Lq;
   launch(c, "mha_kernel", mha_kernel, dim3(cdiv(total, 64)), dim3(64), 0, p);
 }
@@ -467,7 +521,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     p.nb_outer = bs; p.nb_inner = 1; p.H = 4; p.Lq = 1; p.Lk = 6;
     p.q_outer = 0; p.q_inner = 0; p.q_stride = 0; p.kv_outer = 6; p.kv_inner = 0; p.kv_stride = 1;
     p.o_outer = 1; p.o_inner = 0; p.o_stride = 0; p.mask = edrop; p.mask_quirk = 0; p.mask_mod = 1;
-    run_mha(c, p);
+    run_mha(c, p, f.fp32);
   }
   float* x_ego = A_alloc<float>(c, (size_t)bs * 128);
   gemm(c, mk(EAO, 128, bs, c->pw[EG + ".attn.out_proj"], x_ego, 128), c->pw[EG + ".attn.out_proj"], f.fp32);
@@ -518,7 +572,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     m.nb_outer = bs; m.nb_inner = 1; m.H = 4; m.Lq = N; m.Lk = N;
     m.q_outer = N; m.q_stride = 1; m.kv_outer = N; m.kv_stride = 1; m.o_outer = N; m.o_stride = 1;
     m.mask = kpm; m.mask_mod = 1;
-    run_mha(c, m);
+    run_mha(c, m, f.fp32);
     GemmP g2 = mk(AO, 128, nT, c->pw[p + ".attn.out_proj"], X, 128);
     g2.residual = X; g2.ldr = 128;
     if (f.drop && edpr[i] > 0.f) { g2.droppath_p = edpr[i]; g2.dp_div = N; g2.seed = f.seed; g2.stream = f.next_stream(); }
@@ -592,7 +646,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       m.o_outer = R * M; m.o_inner = 1; m.o_stride = M;
       m.mask = r_kpm; m.mask_quirk = 1; m.mask_mod = bs;   // tgt_key_padding_mask.repeat(M, 1), planning_decoder.py:56-60
       if (dp > 0.f) { m.dropout_p = dp; m.seed = f.seed; m.stream = f.next_stream(); }
-      run_mha(c, m);
+      run_mha(c, m, f.fp32);
     }
     GemmP g2 = mk(DAO, 128, nQ, c->pw[p + ".r2r_attn.out_proj"], Q, 128);
     g2.residual = Q; g2.ldr = 128;
@@ -610,7 +664,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       m.nb_outer = nL; m.nb_inner = 1; m.H = 4; m.Lq = M; m.Lk = M;
       m.q_outer = M; m.q_stride = 1; m.kv_outer = M; m.kv_stride = 1; m.o_outer = M; m.o_stride = 1;
       if (dp > 0.f) { m.dropout_p = dp; m.seed = f.seed; m.stream = f.next_stream(); }
-      run_mha(c, m);
+      run_mha(c, m, f.fp32);
     }
     GemmP g4 = mk(DAO, 128, nQ, c->pw[p + ".m2m_attn.out_proj"], Q, 128);
     g4.residual = Q; g4.ldr = 128; g4.rowzero = r_kpm; g4.rz_div = M;   // rows of padded ref lines become 0 (:65-72)
@@ -628,7 +682,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       m.q_outer = R * M; m.q_stride = 1; m.kv_outer = N; m.kv_stride = 1; m.o_outer = R * M; m.o_stride = 1;
       m.mask = kpm; m.mask_mod = 1;
       if (dp > 0.f) { m.dropout_p = dp; m.seed = f.seed; m.stream = f.next_stream(); }
-      run_mha(c, m);
+      run_mha(c, m, f.fp32);
     }
     GemmP g6 = mk(DAO, 128, nQ, c->pw[p + ".cross_attn.out_proj"], Q, 128);
     g6.residual = Q; g6.ldr = 128;
@@ -896,6 +950,8 @@ int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void*
 int rift_prof_enable(RiftCtx* c, int on) {
   if (!c) return RIFT_ERR_ARG;
   c->prof_on = on != 0;
+  const char* ev = getenv("RIFT_PROF_SHAPES");
+  c->prof_shapes = ev && ev[0] == '1';
   if (on) { c->prof_recs.clear(); c->prof_used = 0; }
   return RIFT_OK;
 }

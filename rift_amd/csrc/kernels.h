@@ -252,6 +252,126 @@ __global__ void mha_kernel(MhaP p) {
 }
 
 // ---------------------------------------------------------------------------
+// MFMA small-sequence attention (bf16 operands, fp32 softmax / accumulate), head_dim 32.
+// One workgroup per (batch, head): K [Lk][32] and V^T [32][Lk] are staged once in LDS as bf16;
+// each wave owns 16-query tiles.  S^T = K Q^T is computed "swapped" (v_mfma_f32_16x16x32_bf16 with the
+// key tile as A and the query tile as B), so a lane holds, for ONE query (column lane&15), the scores of
+// keys 4*(lane>>4)+r of every 16-key tile: the row softmax is lane-local plus two xor-shuffles, and the
+// probabilities already sit in the A-fragment layout of the P.V MFMA (k-slot (lane>>4, j) <-> key
+// tile(j>>2)*16 + 4*(lane>>4) + (j&3); V^T fragments are read with the same slot->key map).
+// NKT = compile-time number of 16-key tiles (keys padded to 32).
+// ---------------------------------------------------------------------------
+template <int NKT>
+__global__ void mha_mfma_kernel(MhaP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int LKP = NKT * 16;
+  constexpr int KS = 40;            // K row stride (bf16 elements): 32 + 8 pad -> conflict-free 16-byte fragment reads
+  constexpr int VS = LKP + 8;       // V^T row stride
+  unsigned short* Ks = reinterpret_cast<unsigned short*>(smem_raw);
+  unsigned short* Vt = Ks + LKP * KS;
+  unsigned char* smask = reinterpret_cast<unsigned char*>(Vt + 32 * VS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+  const int h = blockIdx.x % p.H;
+  const int bi = (blockIdx.x / p.H) % p.nb_inner;
+  const int bo = blockIdx.x / (p.H * p.nb_inner);
+  const size_t kv0 = (size_t)bo * p.kv_outer + (size_t)bi * p.kv_inner;
+  const int mb = p.mask ? (p.mask_quirk ? (bo * p.nb_inner + bi) % p.mask_mod : bo) : 0;
+  // ---- stage K (row-major) and V (transposed) as bf16; keys >= Lk are zero and masked
+  for (int i = tid; i < LKP * 8; i += blockDim.x) {
+    const int key = i >> 3, d4 = (i & 7) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (key < p.Lk) {
+      const size_t row = kv0 + (size_t)key * p.kv_stride;
+      kv = *reinterpret_cast<const float4*>(p.K + row * p.ldkv + h * 32 + d4);
+      vv = *reinterpret_cast<const float4*>(p.V + row * p.ldkv + h * 32 + d4);
+    }
+    uint2 u;
+    u.x = (unsigned)f2bf(kv.x) | ((unsigned)f2bf(kv.y) << 16);
+    u.y = (unsigned)f2bf(kv.z) | ((unsigned)f2bf(kv.w) << 16);
+    *reinterpret_cast<uint2*>(Ks + key * KS + d4) = u;
+    Vt[(d4 + 0) * VS + key] = f2bf(vv.x); Vt[(d4 + 1) * VS + key] = f2bf(vv.y);
+    Vt[(d4 + 2) * VS + key] = f2bf(vv.z); Vt[(d4 + 3) * VS + key] = f2bf(vv.w);
+  }
+  for (int i = tid; i < LKP; i += blockDim.x)
+    smask[i] = (i >= p.Lk) || (p.mask && p.mask[(size_t)mb * p.Lk + i]);
+  __syncthreads();
+
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const float scale = 0.17677669529663687f;   // 32^-0.5
+  const int nqt = (p.Lq + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += nwave) {
+    const int q = qt * 16 + l15;
+    bf16x8 qf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (q < p.Lq) {
+      const float* qp = p.Q + ((size_t)bo * p.q_outer + (size_t)bi * p.q_inner + (size_t)q * p.q_stride) * p.ldq + h * 32 + l4 * 8;
+      const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
+      qf[0] = (short)f2bf(a.x * scale); qf[1] = (short)f2bf(a.y * scale); qf[2] = (short)f2bf(a.z * scale); qf[3] = (short)f2bf(a.w * scale);
+      qf[4] = (short)f2bf(b.x * scale); qf[5] = (short)f2bf(b.y * scale); qf[6] = (short)f2bf(b.z * scale); qf[7] = (short)f2bf(b.w * scale);
+    }
+    f32x4 s[NKT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + l15) * KS + l4 * 8);
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (smask[kt * 16 + l4 * 4 + r]) s[kt][r] = -INFINITY;
+        m = fmaxf(m, s[kt][r]);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(s[kt][r] - m);
+        lsum += e;
+        float w = e;
+        if (p.dropout_p > 0.f) {
+          const uint32_t qid = (uint32_t)((blockIdx.x * p.Lq + q) * LKP + kt * 16 + l4 * 4 + r);
+          w = (uniform01(p.seed, p.stream, qid) < p.dropout_p) ? 0.f : e * (1.0f / (1.0f - p.dropout_p));
+        }
+        s[kt][r] = w;
+      }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+    for (int pt = 0; pt < NKT / 2; ++pt) {
+      bf16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { pf[j] = (short)f2bf(s[2 * pt][j]); pf[4 + j] = (short)f2bf(s[2 * pt + 1][j]); }
+      const unsigned short* v0 = Vt + l15 * VS + pt * 32 + l4 * 4;
+      const unsigned short* v1 = Vt + (16 + l15) * VS + pt * 32 + l4 * 4;
+      bf16x8 b0, b1;
+      const uint2 x0 = *reinterpret_cast<const uint2*>(v0), x1 = *reinterpret_cast<const uint2*>(v0 + 16);
+      const uint2 y0 = *reinterpret_cast<const uint2*>(v1), y1 = *reinterpret_cast<const uint2*>(v1 + 16);
+      b0[0] = (short)(x0.x & 0xffff); b0[1] = (short)(x0.x >> 16); b0[2] = (short)(x0.y & 0xffff); b0[3] = (short)(x0.y >> 16);
+      b0[4] = (short)(x1.x & 0xffff); b0[5] = (short)(x1.x >> 16); b0[6] = (short)(x1.y & 0xffff); b0[7] = (short)(x1.y >> 16);
+      b1[0] = (short)(y0.x & 0xffff); b1[1] = (short)(y0.x >> 16); b1[2] = (short)(y0.y & 0xffff); b1[3] = (short)(y0.y >> 16);
+      b1[4] = (short)(y1.x & 0xffff); b1[5] = (short)(y1.x >> 16); b1[6] = (short)(y1.y & 0xffff); b1[7] = (short)(y1.y >> 16);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b0, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b1, o1, 0, 0, 0);
+    }
+    // O[q = 4*l4 + r][d = l15 (+16)] ; the softmax denominator of query qq lives in lane qq
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = l4 * 4 + r;
+      const float inv = 1.0f / __shfl(lsum, qq, 64);
+      const int qo = qt * 16 + qq;
+      if (qo < p.Lq) {
+        float* op = p.O + ((size_t)bo * p.o_outer + (size_t)bi * p.o_inner + (size_t)qo * p.o_stride) * p.ldo + h * 32;
+        op[l15] = o0[r] * inv;
+        op[16 + l15] = o1[r] * inv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // BatchNorm1d over valid rows (embedding.py:260,266): column sum / sum of squares in fp64,
 // then fold into a per-channel affine  y = x*scale + shift  for the next GEMM's prologue.
 // ---------------------------------------------------------------------------
@@ -274,31 +394,38 @@ __global__ void bn_partial_kernel(const float* __restrict__ X, int ld, int rows,
 }
 
 // train != 0: batch statistics (+ running-stat update, momentum 0.1, unbiased var); else running stats.
+// One wave per channel: lanes stride over the per-block partial sums (deterministic order).
 __global__ void bn_finalize_kernel(const double* __restrict__ part, const int* __restrict__ cnt, int nblk, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long long* num_batches, int train,
                                    int update_running, float eps, float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c >= C) return;
   float mean, var;
   if (train) {
     double s = 0.0, q = 0.0;
     long long n = 0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; n += cnt[b]; }
+    for (int b = lane; b < nblk; b += 64) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; n += cnt[b]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
     const double mu = s / (double)n;
     double v = q / (double)n - mu * mu;
     v = v < 0.0 ? 0.0 : v;
     mean = (float)mu; var = (float)v;
-    if (update_running) {
+    if (update_running && lane == 0) {
       const double unb = n > 1 ? v * (double)n / (double)(n - 1) : v;
       running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean;
       running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unb;
       if (c == 0 && num_batches) *num_batches += 1;
     }
   } else { mean = running_mean[c]; var = running_var[c]; }
-  const float sc = gamma[c] * rsqrtf(var + eps);
-  scale[c] = sc;
-  shift[c] = beta[c] - mean * sc;
+  if (lane == 0) {
+    const float sc = gamma[c] * rsqrtf(var + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+  }
 }
 
 // masked max-pool over the n points of each group (PointsEncoder: invalid points are all-zero rows)
