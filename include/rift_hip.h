@@ -159,6 +159,11 @@ int rift_tap(RiftCtx* ctx, const char* name, float* dst, int64_t* numel, void* s
 int rift_op_linear(RiftCtx* ctx, const float* X, int M, int K, const float* W, const float* bias, int N,
                    const float* ln_w, const float* ln_b, int act, int fp32, float* Y, void* stream);
 
+/* Diagnostic: the same GEMM launched `reps` times back to back; *ms_out = average milliseconds per launch. */
+int rift_op_linear_bench(RiftCtx* ctx, const float* X, int M, int K, const float* W, const float* bias, int N,
+                         const float* ln_w, const float* ln_b, int act, const float* residual, float* Y, int reps,
+                         float* ms_out /*host*/, void* stream);
+
 /* get_advantages_GAE (fine_tuner/rlft/ppo_pluto/ppo_datamodule.py:22-37): reverse scan over n fp32 entries. */
 int rift_gae(RiftCtx* ctx, const double* rewards /*f64, as np.stack of python floats*/, const float* undones,
              const float* values, const float* next_values, const float* unterminated, float gamma, float lambda_,

@@ -65,7 +65,7 @@ EXPORTS = [
     "rift_ctx_create", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_loss_backward",
     "rift_loss_finalize", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
-    "rift_prof_enable", "rift_prof_report",
+    "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench",
 ]
 
 _lib = None
@@ -103,6 +103,8 @@ def load_library() -> C.CDLL:
                                         C.c_double, vp, vp]
     lib.rift_collate.argtypes = [vp, C.POINTER(RiftReplayArena), vp, C.c_int, C.c_int, C.POINTER(RiftFeatureBatch),
                                  vp, vp, vp, vp, vp]
+    lib.rift_op_linear_bench.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int,
+                                         C.POINTER(C.c_float), vp]
     lib.rift_prof_enable.argtypes = [vp, C.c_int]
     lib.rift_prof_report.argtypes = [vp, C.c_char_p, C.c_int]
     for name in EXPORTS:
@@ -345,6 +347,19 @@ class Engine:
         self._check(self.lib.rift_op_linear(self.ctx, _ptr(x), M, K, _ptr(w), _ptr(b), N, _ptr(ln_w), _ptr(ln_b), act,
                                             1 if fp32 else 0, _ptr(y), _stream()), "rift_op_linear")
         return y
+
+    def op_linear_bench(self, x, w, b=None, ln_w=None, ln_b=None, act=0, residual=None, reps=50):
+        """Average microseconds per launch of the forward's GEMM kernel on this shape (diagnostic)."""
+        dev = self.device
+        x, w = _dev(x, torch.float32, dev), _dev(w, torch.float32, dev)
+        opt = [None if t is None else _dev(t, torch.float32, dev) for t in (b, ln_w, ln_b, residual)]
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, device=dev)
+        ms = C.c_float(0)
+        self._check(self.lib.rift_op_linear_bench(self.ctx, _ptr(x), M, K, _ptr(w), _ptr(opt[0]), N, _ptr(opt[1]), _ptr(opt[2]),
+                                                  act, _ptr(opt[3]), _ptr(y), reps, C.byref(ms), _stream()), "rift_op_linear_bench")
+        return ms.value * 1e3
 
     def gae(self, rewards, undones, values, next_values, unterminated, gamma=0.98, lambda_=0.98):
         dev = self.device

@@ -16,6 +16,7 @@
 #include "gemm.h"
 #include "kernels.h"
 #include "loss.h"
+#include "nat_fused.h"
 
 using namespace rift;
 
@@ -50,6 +51,9 @@ struct RiftCtx {
   double* l_S = nullptr; double* l_cnt = nullptr; float* l_dz = nullptr; float* l_partial = nullptr;
   size_t l_cap_bs = 0, l_cap_rows = 0, l_cap_wg = 0;
   float* ego_w = nullptr; float* ego_b = nullptr;   // packed (6,128) linears of StateAttentionEncoder
+  unsigned short* nat_wqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // head-major bf16 qkv weights
+  float* nat_bqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  bool nat_fused = true; int nat_dbg = 0; int gemm_dbg = 0;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -253,6 +257,7 @@ void gemm(RiftCtx* c, GemmP g, const PW& w, bool fp32) {
   const bool al = (((uintptr_t)g.X) & 15) == 0 && (g.K % 4 == 0) && (conv ? (g.cv_C % 4 == 0 && g.ldx == g.cv_C) : (g.ldx % 4 == 0)) &&
                   (g.pro == PRO_NONE || ((((uintptr_t)g.pg) | ((uintptr_t)g.pb)) & 15) == 0);
   const int KV = g.Kp / 4;
+  g.dbg = c->gemm_dbg;
   g.stage = !al ? 0 : (KV <= 8 ? 1 : KV <= 16 ? 2 : KV <= 32 ? 3 : KV <= 64 ? 4 : 5);
   g.evec = (g.N % 4 == 0) && (g.ldy % 4 == 0) && ((((uintptr_t)g.Y) & 15) == 0) &&
            (!g.bias || (((uintptr_t)g.bias) & 15) == 0) && (!g.gbias || (((uintptr_t)g.gbias) & 15) == 0) &&
@@ -264,6 +269,9 @@ void gemm(RiftCtx* c, GemmP g, const PW& w, bool fp32) {
 int set_lds_attrs(RiftCtx* c) {
   const int big = 160 * 1024;
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
+  SETATTR((nat_level_kernel<32, 2, 20, 3>));
+  SETATTR((nat_level_kernel<64, 4, 10, 3>));
+  SETATTR((nat_level_kernel<128, 8, 5, 5>));
   SETATTR((gemm_rows_kernel<true, 1, 8, 4, 1>));
   SETATTR((gemm_rows_kernel<true, 4, 2, 1, 4>));
   SETATTR((gemm_rows_kernel<false, 4, 2, 1, 4>));
@@ -450,8 +458,35 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     gemm(c, g, c->pw[HE + ".embed.proj"], f.fp32);
   }
   static const float dpr[6] = {0.f, 0.04f, 0.08f, 0.12f, 0.16f, 0.2f};   // linspace(0, 0.2, 6), embedding.py:30
-  nat_layer(f, X0, nA * 20, 32, 2, 3, 20, HE + ".levels.0.blocks.0", dpr[0]);
-  nat_layer(f, X0, nA * 20, 32, 2, 3, 20, HE + ".levels.0.blocks.1", dpr[1]);
+  const bool fused = c->nat_fused && !f.fp32;
+  auto nat_level = [&](float* Xl, int lv, int rows, int C, int H, int ksz, int L) {
+    if (!fused) {
+      nat_layer(f, Xl, rows, C, H, ksz, L, HE + ".levels." + std::to_string(lv) + ".blocks.0", dpr[2 * lv]);
+      nat_layer(f, Xl, rows, C, H, ksz, L, HE + ".levels." + std::to_string(lv) + ".blocks.1", dpr[2 * lv + 1]);
+      return;
+    }
+    NatLevelP p; memset(&p, 0, sizeof(p));
+    p.dbg = c->nat_dbg;
+    p.X = Xl; p.nseq = rows / L; p.seed = f.seed; p.stream = f.next_stream(); f.stream_id += 4;
+    for (int b = 0; b < 2; ++b) {
+      const std::string bp = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b);
+      NatBlockW& w = p.blk[b];
+      w.ln1_g = fptr(c, bp + ".norm1.weight"); w.ln1_b = fptr(c, bp + ".norm1.bias");
+      w.ln2_g = fptr(c, bp + ".norm2.weight"); w.ln2_b = fptr(c, bp + ".norm2.bias");
+      w.wqkv = c->nat_wqkv[lv][b]; w.bqkv = c->nat_bqkv[lv][b]; w.rpb = fptr(c, bp + ".attn.rpb");
+      w.wproj = (const unsigned short*)c->pw[bp + ".attn.proj"].bf; w.bproj = c->pw[bp + ".attn.proj"].bias;
+      w.w1 = (const unsigned short*)c->pw[bp + ".mlp.fc1"].bf; w.b1 = c->pw[bp + ".mlp.fc1"].bias;
+      w.w2 = (const unsigned short*)c->pw[bp + ".mlp.fc2"].bf; w.b2 = c->pw[bp + ".mlp.fc2"].bias;
+      w.droppath = f.drop ? dpr[2 * lv + b] : 0.f;
+    }
+    const int CWK = 3 * C < 192 ? 3 * C : 192;
+    const size_t lds = (size_t)80 * (C + 4) * 4 + (size_t)80 * (C + 8) * 2 * 2 + (size_t)80 * (CWK + 8) * 2;
+    const dim3 grid(cdiv(rows, 80)), block(256);
+    if (lv == 0) launch(c, "nat_level_kernel_L0", nat_level_kernel<32, 2, 20, 3>, grid, block, lds, p);
+    else if (lv == 1) launch(c, "nat_level_kernel_L1", nat_level_kernel<64, 4, 10, 3>, grid, block, lds, p);
+    else launch(c, "nat_level_kernel_L2", nat_level_kernel<128, 8, 5, 5>, grid, block, lds, p);
+  };
+  nat_level(X0, 0, nA * 20, 32, 2, 3, 20);
   float* X1 = A_alloc<float>(c, (size_t)nA * 10 * 64);
   {
     GemmP g = mk(X0, 32, nA * 10, c->pw[HE + ".levels.0.downsample.reduction"], X1, 64);
@@ -459,8 +494,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     gemm(c, g, c->pw[HE + ".levels.0.downsample.reduction"], f.fp32);
     layernorm(f, X1, 64, X1, 64, nA * 10, 64, HE + ".levels.0.downsample.norm");
   }
-  nat_layer(f, X1, nA * 10, 64, 4, 3, 10, HE + ".levels.1.blocks.0", dpr[2]);
-  nat_layer(f, X1, nA * 10, 64, 4, 3, 10, HE + ".levels.1.blocks.1", dpr[3]);
+  nat_level(X1, 1, nA * 10, 64, 4, 3, 10);
   // level outputs are the PRE-downsample activations (NATBlock returns (downsample(x), x)); X0/X1 are
   // still needed below, so the downsample writes new buffers.
   float* X2 = A_alloc<float>(c, (size_t)nA * 5 * 128);
@@ -470,8 +504,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     gemm(c, g, c->pw[HE + ".levels.1.downsample.reduction"], f.fp32);
     layernorm(f, X2, 128, X2, 128, nA * 5, 128, HE + ".levels.1.downsample.norm");
   }
-  nat_layer(f, X2, nA * 5, 128, 8, 5, 5, HE + ".levels.2.blocks.0", dpr[4]);
-  nat_layer(f, X2, nA * 5, 128, 8, 5, 5, HE + ".levels.2.blocks.1", dpr[5]);
+  nat_level(X2, 2, nA * 5, 128, 8, 5, 5);
   tap(c, "nat_level2", X2, (int64_t)nA * 5 * 128);
   // FPN restricted to what out[:, :, -1] depends on: the last 3 steps of each normalised level
   float* lat[3];
@@ -759,6 +792,9 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   RiftCtx* c = new RiftCtx();
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
+  { const char* ev = getenv("RIFT_NAT_UNFUSED"); c->nat_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
+  { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   int rc = set_lds_attrs(c);
   if (rc != RIFT_OK) { fprintf(stderr, "rift_ctx_create: %s\n", c->err.c_str()); delete c; return rc; }
   *ctx = c;
@@ -775,6 +811,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->l_partial) (void)hipFree(c->l_partial);
   if (c->ego_w) (void)hipFree(c->ego_w);
   if (c->ego_b) (void)hipFree(c->ego_b);
+  for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
   delete c;
 }
 
@@ -799,6 +836,18 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
       const std::string p = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b);
       TRY(pack_linear(c, p + ".attn.qkv")); TRY(pack_linear(c, p + ".attn.proj"));
       TRY(pack_linear(c, p + ".mlp.fc1")); TRY(pack_linear(c, p + ".mlp.fc2"));
+    }
+    for (int b = 0; b < 2; ++b) {   // head-major bf16 qkv image for the fused level kernel
+      const std::string p = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b) + ".attn.qkv";
+      const int C = 32 << lv, H = 2 << lv;
+      const float* w = fptr(c, p + ".weight"); const float* bsrc = fptr(c, p + ".bias");
+      if (!w || !bsrc) return RIFT_ERR_ARG;
+      if (!c->nat_wqkv[lv][b]) {
+        HIPCHK(c, hipMalloc((void**)&c->nat_wqkv[lv][b], (size_t)3 * C * C * 2));
+        HIPCHK(c, hipMalloc((void**)&c->nat_bqkv[lv][b], (size_t)3 * C * 4));
+      }
+      hipLaunchKernelGGL(pack_qkv_headmajor_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, c->stream, w, bsrc, C, H,
+                         c->nat_wqkv[lv][b], c->nat_bqkv[lv][b]);
     }
     if (lv < 2) TRY(pack_conv(c, HE + ".levels." + std::to_string(lv) + ".downsample.reduction"));
     TRY(pack_conv(c, HE + ".lateral_convs." + std::to_string(lv)));
@@ -1009,6 +1058,38 @@ int rift_op_linear(RiftCtx* c, const float* X, int M, int K, const float* W, con
   c->owned.pop_back(); c->owned.pop_back();
   c->pw.erase(key);
   HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+// Diagnostic: pack once, launch the GEMM `reps` times back to back, return the average milliseconds per launch.
+int rift_op_linear_bench(RiftCtx* c, const float* X, int M, int K, const float* W, const float* bias, int N,
+                         const float* ln_w, const float* ln_b, int act, const float* residual, float* Y, int reps,
+                         float* ms_out, void* stream) {
+  if (!c || !X || !W || !Y || K > 512 || reps <= 0) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream; c->dry = false;
+  const std::string key = "__op_linear_bench__";
+  TRY(pack(c, key, W, N, N, K, 0, 0, K, 0, 0, 0, bias));
+  PW w = c->pw[key];
+  GemmP g = mk(X, K, M, w, Y, N);
+  if (ln_w) { g.pro = PRO_LN; g.pg = ln_w; g.pb = ln_b; }
+  g.act = act;
+  if (residual) { g.residual = residual; g.ldr = N; }
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) gemm(c, g, w, false);
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < reps; ++i) gemm(c, g, w, false);
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  if (ms_out) *ms_out = ms / reps;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(w.bf); (void)hipFree(w.f32);
+  c->owned.pop_back(); c->owned.pop_back();
+  c->pw.erase(key);
   return RIFT_OK;
 }
 

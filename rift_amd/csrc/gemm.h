@@ -29,6 +29,7 @@ struct GemmP {
   int cv_C, cv_Lin, cv_nout, cv_t0, cv_stride;   // conv3: row r -> (seq = r / nout, t = t0 + r % nout), K = 3*C
   int cs_off;                                    // byte offset of the C staging area in dynamic LDS (0 = aliases the A tile)
   int evec;                                      // epilogue may use 16-byte accesses (N, ldy, ldr % 4 == 0, aligned pointers)
+  int dbg;                                       // timing experiments only; 0 in production
   int stage;                                     // 0 scalar staging; 1..5 vectorised (LPR,CH) = (8,1)(16,1)(32,1)(64,1)(64,2)
   // prologue over the K extent of each row
   int pro; const float* pg; const float* pb; int pro_relu; float ln_eps;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmP p) {
           for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
         } else if (p.act == ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) val[e] = gelu_erf(val[e]);
+          for (int e = 0; e < 4; ++e) val[e] = BF16 ? gelu_fast(val[e]) : gelu_erf(val[e]);
         }
         if (p.dropout_p > 0.f) {
           const float sc = 1.0f / (1.0f - p.dropout_p);

@@ -1,0 +1,326 @@
+// Fused NAT level for gfx950: both NATLayers of one level of the agent history encoder
+// (embedding.py:196-202 x2: LN -> qkv -> 1-D neighbourhood attention -> proj -> +res, LN -> fc1 -> GELU
+// -> fc2 -> +res) in ONE kernel.  A workgroup keeps 80 rows (= 4/8/16 whole agent sequences at
+// L = 20/10/5) resident in LDS for the whole level: the fp32 residual stream, the bf16 LayerNorm output,
+// a 192-column bf16 chunk buffer (q|k|v of 4 heads, or a slice of the MLP hidden layer) and the attention
+// output.  HBM traffic of a level drops from ~26 activation passes to one read + one write; weights
+// (<= 0.65 MB per level) stream from L2 as MFMA B fragments, each fragment feeding 5 MFMAs.
+#pragma once
+#include "common.h"
+
+namespace rift {
+
+struct NatBlockW {
+  const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
+  const unsigned short* wqkv;   // bf16 [3C][C], rows in head-major order (head, part{q,k,v}, 16)
+  const float* bqkv;            // fp32 [3C] same order
+  const float* rpb;             // fp32 [H][2K-1]
+  const unsigned short* wproj;  // bf16 [C][C]
+  const float* bproj;
+  const unsigned short* w1;     // bf16 [3C][C]
+  const float* b1;
+  const unsigned short* w2;     // bf16 [C][3C]
+  const float* b2;
+  float droppath;               // train-mode stochastic depth probability of this layer
+};
+
+struct NatLevelP {
+  float* X;                     // (nseq*L, C) fp32, updated in place
+  int nseq;
+  NatBlockW blk[2];
+  uint32_t seed, stream;
+  int dbg;                      // timing experiments only (RIFT_NAT_DBG bitmask); 0 in production
+};
+
+// reorder qkv rows of natten's (3, H, 16) layout to (H, 3, 16) and convert to bf16 (+ bias reorder)
+__global__ void pack_qkv_headmajor_kernel(const float* __restrict__ w, const float* __restrict__ b, int C, int H,
+                                          unsigned short* __restrict__ wo, float* __restrict__ bo) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 3 * C * C) return;
+  const int pr = idx / C, k = idx - pr * C;
+  const int head = pr / 48, part = (pr % 48) / 16, d = pr % 16;
+  const int src = part * C + head * 16 + d;
+  wo[idx] = f2bf(w[(size_t)src * C + k]);
+  if (k == 0) bo[pr] = b[src];
+}
+
+// B fragments (weights) of one GEMM phase, fetched from L2 ahead of time so that the latency hides under
+// the preceding LayerNorm / attention / epilogue phase.  W: bf16 [rows][ldw]; this wave's n-tiles are
+// nt = j*4 + wave (j < NTW), n-tile nt covers rows n0 + nt*16 .. +15; k-step ks covers k0 + ks*32 .. +31.
+template <int KS, int NTW>
+struct BFrags { bf16x8 f[KS][NTW]; };
+
+template <int KS, int NTW>
+__device__ __forceinline__ void load_b(BFrags<KS, NTW>& B, const unsigned short* W, int ldw, int n0, int k0, int ntiles,
+                                       int wave, int l15, int l4) {
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int nt = j * 4 + wave;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      B.f[ks][j] = (nt < ntiles) ? *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + nt * 16 + l15) * ldw + k0 + ks * 32 + l4 * 8)
+                                 : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+
+// acc[5][NTW] += A[80][K] (bf16 in LDS, row stride lda) . B
+template <int KS, int NTW>
+__device__ __forceinline__ void mma80(f32x4 (&acc)[5][NTW], const unsigned short* A, int lda, const BFrags<KS, NTW>& B,
+                                      int l15, int l4) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 a[5];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + l15) * lda + ks * 32 + l4 * 8);
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0);
+  }
+}
+
+template <int C, int NHEAD, int L, int KSZ>
+__global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
+  constexpr int ROWS = 80, MT = 5;
+  constexpr int C3 = 3 * C;
+  constexpr int CWK = C3 < 192 ? C3 : 192;        // chunk width (columns of qkv / hidden processed at once)
+  constexpr int NCH = C3 / CWK;                   // 1, 1, 2
+  constexpr int HPC = CWK / 48;                   // heads per qkv chunk
+  constexpr int XS = C + 4, XN = C + 8, CB = CWK + 8;
+  constexpr int KS1 = C / 32;                     // k-steps with K = C
+  constexpr int KSC = CWK / 32;                   // k-steps with K = chunk
+  constexpr int NT_CH = CWK / 16;                 // n-tiles of a chunk (6 or 12)
+  constexpr int NTW_CH = (NT_CH + 3) / 4;         // per wave (2 or 3)
+  constexpr int NT_C = C / 16;                    // n-tiles of a C-wide output (2, 4, 8)
+  constexpr int NTW_C = (NT_C + 3) / 4;           // per wave (1, 1, 2)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* xs = reinterpret_cast<float*>(smem_raw);
+  unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
+  unsigned short* cb = xn + ROWS * XN;
+  unsigned short* ao = cb + ROWS * CB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int row0 = blockIdx.x * ROWS;
+  const int total_rows = p.nseq * L;
+
+  BFrags<KS1, NTW_CH> Bq;      // qkv / fc1 weights of the current chunk
+  BFrags<KS1, NTW_C> Bp;       // proj weights
+  BFrags<KSC, NTW_C> B2;       // fc2 weights of the current hidden chunk
+  load_b(Bq, p.blk[0].wqkv, C, 0, 0, NT_CH, wave, l15, l4);
+
+  // ---- load the residual stream tile
+  for (int i = tid; i < ROWS * (C / 4); i += 256) {
+    const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < total_rows) v = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + c4);
+    *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
+  }
+  __syncthreads();
+
+  // LayerNorm xs -> xn (bf16): C/4 lanes per row (16-byte LDS reads), xor-shuffle statistics
+  auto layer_norm = [&](const float* g, const float* b) {
+    constexpr int LPR = C / 4, RPS = 64 / LPR;            // lanes per row, rows per wave step
+    const int lr = lane % LPR, rsub = lane / LPR;
+    const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(b + lr * 4);
+#pragma unroll 2
+    for (int r = wave * RPS + rsub; r < ROWS; r += 4 * RPS) {
+      const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
+      float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s * (1.0f / C);
+      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+      float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
+      uint2 u;
+      u.x = (unsigned)f2bf(d0 * rstd * g4.x + b4.x) | ((unsigned)f2bf(d1 * rstd * g4.y + b4.y) << 16);
+      u.y = (unsigned)f2bf(d2 * rstd * g4.z + b4.z) | ((unsigned)f2bf(d3 * rstd * g4.w + b4.w) << 16);
+      *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) = u;
+    }
+  };
+
+  for (int bi = 0; bi < 2; ++bi) {
+    const NatBlockW& w = p.blk[bi];
+    // ======== attention half ========
+    if (!(p.dbg & 1)) layer_norm(w.ln1_g, w.ln1_b);
+    __syncthreads();
+    for (int ch = 0; ch < NCH; ++ch) {
+      // ---- qkv chunk GEMM: cb[80][CWK] = xn[80][C] . Wqkv[ch*CWK .. +CWK][C]^T + b ; q pre-scaled by 16^-0.5
+      {
+        f32x4 acc[MT][NTW_CH];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < NTW_CH; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(p.dbg & 8)) mma80<KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
+        // prefetch the next phase's weights (next qkv chunk, or proj)
+        if (ch + 1 < NCH) load_b(Bq, w.wqkv, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4);
+        else load_b(Bp, w.wproj, C, 0, 0, NT_C, wave, l15, l4);
+#pragma unroll
+        for (int j = 0; j < NTW_CH; ++j) {
+          const int nt = j * 4 + wave;
+          if (nt >= NT_CH) continue;
+          const int col = nt * 16 + l15;
+          const float bias = w.bqkv[ch * CWK + col];
+          const float sc = ((col % 48) < 16) ? 0.25f : 1.0f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cb[(mt * 16 + l4 * 4 + r) * CB + col] = f2bf((acc[mt][j][r] + bias) * sc);
+        }
+      }
+      __syncthreads();
+      // ---- neighbourhood attention of the chunk's heads (VALU, fp32 softmax); one (row, head) per work item
+      for (int it = tid; it < ((p.dbg & 2) ? 0 : ROWS * HPC); it += 256) {
+        const int hh = it % HPC, row = it / HPC;
+        const int a0 = (row / L) * L, i = row - a0;
+        const int head = ch * HPC + hh;
+        float q[16];
+        {
+          const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(cb + row * CB + hh * 48);
+          const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(cb + row * CB + hh * 48 + 8);
+#pragma unroll
+          for (int d = 0; d < 8; ++d) { q[d] = bf2f((unsigned short)q0[d]); q[8 + d] = bf2f((unsigned short)q1[d]); }
+        }
+        int start = i - KSZ / 2;
+        start = start < 0 ? 0 : start;
+        start = start > L - KSZ ? L - KSZ : start;
+        float sc[KSZ];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < KSZ; ++j) {
+          const int nb = start + j;
+          const unsigned short* kp = cb + (a0 + nb) * CB + hh * 48 + 16;
+          const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp), k1 = *reinterpret_cast<const bf16x8*>(kp + 8);
+          float s = 0.f;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) s += q[d] * bf2f((unsigned short)k0[d]) + q[8 + d] * bf2f((unsigned short)k1[d]);
+          s += w.rpb[head * (2 * KSZ - 1) + (nb - i) + KSZ - 1];
+          sc[j] = s;
+          mx = fmaxf(mx, s);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < KSZ; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+        const float inv = 1.0f / den;
+        float o[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) o[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KSZ; ++j) {
+          const unsigned short* vp = cb + (a0 + start + j) * CB + hh * 48 + 32;
+          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vp), v1 = *reinterpret_cast<const bf16x8*>(vp + 8);
+          const float wj = sc[j] * inv;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) { o[d] += wj * bf2f((unsigned short)v0[d]); o[8 + d] += wj * bf2f((unsigned short)v1[d]); }
+        }
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { o0[d] = (short)f2bf(o[d]); o1[d] = (short)f2bf(o[8 + d]); }
+        *reinterpret_cast<bf16x8*>(ao + row * XN + head * 16) = o0;
+        *reinterpret_cast<bf16x8*>(ao + row * XN + head * 16 + 8) = o1;
+      }
+      __syncthreads();
+    }
+    // ---- proj GEMM + residual: xs += droppath( ao . Wproj^T + b )
+    {
+      f32x4 acc[MT][NTW_C];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW_C; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mma80<KS1, NTW_C>(acc, ao, XN, Bp, l15, l4);
+      load_b(Bq, w.w1, C, 0, 0, NT_CH, wave, l15, l4);     // fc1 weights of hidden chunk 0
+#pragma unroll
+      for (int j = 0; j < NTW_C; ++j) {
+        const int nt = j * 4 + wave;
+        if (nt >= NT_C) continue;
+        const int col = nt * 16 + l15;
+        const float bias = w.bproj[col];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + l4 * 4 + r;
+            float v = acc[mt][j][r] + bias;
+            if (w.droppath > 0.f) {
+              const float u = uniform01(p.seed, p.stream + 2 * bi, (uint32_t)((row0 + row) / L));
+              v = (u < w.droppath) ? 0.f : v * (1.0f / (1.0f - w.droppath));
+            }
+            xs[row * XS + col] += v;
+          }
+      }
+    }
+    __syncthreads();
+    // ======== MLP half ========
+    if (!(p.dbg & 1)) layer_norm(w.ln2_g, w.ln2_b);
+    __syncthreads();
+    {
+      f32x4 acc2[MT][NTW_C];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW_C; ++j) acc2[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ch = 0; ch < NCH; ++ch) {
+        // ---- fc1 chunk: cb = gelu( xn . W1[ch*CWK..]^T + b1 )
+        {
+          f32x4 acc[MT][NTW_CH];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < NTW_CH; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (!(p.dbg & 8)) mma80<KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
+          load_b(B2, w.w2, C3, 0, ch * CWK, NT_C, wave, l15, l4);          // fc2 weights of this hidden chunk
+          if (ch > 0) __syncthreads();   // the previous chunk's fc2 reads of cb are complete
+#pragma unroll
+          for (int j = 0; j < NTW_CH; ++j) {
+            const int nt = j * 4 + wave;
+            if (nt >= NT_CH) continue;
+            const int col = nt * 16 + l15;
+            const float bias = w.b1[ch * CWK + col];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) cb[(mt * 16 + l4 * 4 + r) * CB + col] = f2bf((p.dbg & 4) ? fmaxf(acc[mt][j][r] + bias, 0.f) : gelu_erf(acc[mt][j][r] + bias));
+          }
+        }
+        // weights needed after this fc2: next hidden chunk's fc1, or the next block's qkv chunk 0
+        if (ch + 1 < NCH) load_b(Bq, w.w1, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4);
+        else if (bi == 0) load_b(Bq, p.blk[1].wqkv, C, 0, 0, NT_CH, wave, l15, l4);
+        __syncthreads();
+        // ---- fc2 partial: acc2 += cb[80][CWK] . W2[:, ch*CWK..]^T
+        if (!(p.dbg & 8)) mma80<KSC, NTW_C>(acc2, cb, CB, B2, l15, l4);
+      }
+#pragma unroll
+      for (int j = 0; j < NTW_C; ++j) {
+        const int nt = j * 4 + wave;
+        if (nt >= NT_C) continue;
+        const int col = nt * 16 + l15;
+        const float bias = w.b2[col];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + l4 * 4 + r;
+            float v = acc2[mt][j][r] + bias;
+            if (w.droppath > 0.f) {
+              const float u = uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)((row0 + row) / L));
+              v = (u < w.droppath) ? 0.f : v * (1.0f / (1.0f - w.droppath));
+            }
+            xs[row * XS + col] += v;
+          }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- write the level output back
+  for (int i = tid; i < ROWS * (C / 4); i += 256) {
+    const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+    if (row0 + r < total_rows)
+      *reinterpret_cast<float4*>(p.X + (size_t)(row0 + r) * C + c4) = *reinterpret_cast<const float4*>(xs + r * XS + c4);
+  }
+}
+
+}  // namespace rift

@@ -233,3 +233,23 @@ def test_device_collation_matches_pad_sequence(ffi):
     assert torch.equal(b["group_advantage"].cpu(), ref["group_advantage_torch"])
     assert torch.equal(b["group_valid_mask"].cpu(), ref["group_advantage_mask_torch"])
     eng.close()
+
+
+def test_fused_nat_level_matches_layerwise_path(ffi, monkeypatch):
+    """The fused NAT level kernel (80 rows resident in LDS) against the layer-by-layer GEMM path and
+    against the exact-fp32 path, on the history-encoder output of every agent."""
+    gold, batch, sd = H.load_case("full")
+    data = batch["cur_pluto_feature_torch"]
+    outs = {}
+    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+        monkeypatch.setenv("RIFT_NAT_UNFUSED", env)
+        eng = ffi.Engine("cuda:0")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        eng.forward(data, fp32=fp32)
+        outs[name] = eng.tap("nat_out").cpu().clone()
+        eng.close()
+    scale = float(outs["fp32"].abs().max())
+    assert err(outs["fused"], outs["fp32"]) < 3e-2 * max(1.0, scale)
+    assert err(outs["fused"], outs["layerwise"]) < 3e-2 * max(1.0, scale)
+    # the fused kernel must not be a no-op: its bf16 rounding points differ from the layer-wise path
+    assert not torch.equal(outs["fused"], outs["layerwise"])
