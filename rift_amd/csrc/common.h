@@ -16,6 +16,16 @@ __device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
+// two fp32 -> packed bf16x2 (round-to-nearest-even) in ONE instruction (gfx950 v_cvt_pk_bf16_f32; no builtin)
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  unsigned int r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+  uint2 u; u.x = pack_bf16x2(a, b); u.y = pack_bf16x2(c, d); return u;
+}
+
 // counter-based RNG for dropout / drop-path / state-dropout: one 32-bit hash per element
 // (two rounds of the lowbias32 integer finaliser over (seed, stream, element index); 32-bit multiplies only).
 __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t stream, uint32_t idx) {
@@ -40,11 +50,28 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erfz, x));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums.  __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100 cycles of dependent
+// latency per step); within a 16-lane row the same exchange is a DPP modifier on a VALU op (a few cycles):
+// quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum4(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); return v; }
+__device__ __forceinline__ float sum8(float v) { v = sum4(v); v += dpp_f<0x141>(v); return v; }
+__device__ __forceinline__ float sum16(float v) { v = sum8(v); v += dpp_f<0x140>(v); return v; }
+__device__ __forceinline__ float sum32(float v) { v = sum16(v); v += __shfl_xor(v, 16, 64); return v; }
+// sum over groups of LPR consecutive lanes (LPR = 8, 16, 32, 64), result in every lane of the group
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  if (LPR == 4) return sum4(v);
+  if (LPR == 8) return sum8(v);
+  if (LPR == 16) return sum16(v);
+  v = sum32(v);
+  if (LPR == 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

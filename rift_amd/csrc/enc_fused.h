@@ -1,0 +1,360 @@
+// Fused scene encoder for gfx950: the 4 TransformerEncoderLayers (transformer.py:73-94) and the final LayerNorm
+// (pluto_model.py:152-154) of ONE scene in ONE workgroup, one launch for the whole batch.
+// The scene's N = A + Mp + S <= 96 tokens stay resident in LDS (fp32 residual stream, bf16 LayerNorm output,
+// a q|k chunk of two heads, V^T of those heads, the attention output); per layer the workgroup runs
+// LN -> qkv (2 heads at a time) -> MFMA attention -> out_proj -> +res -> LN -> fc1 -> GELU -> fc2 -> +res with
+// bf16 MFMA (fp32 accumulate) and never touches HBM in between.  Weights (0.39 MB bf16 per layer) stream from
+// L2 as MFMA B fragments requested one phase ahead.  Replaces ~44 launches and ~1 GB of HBM traffic per step.
+#pragma once
+#include "common.h"
+
+namespace rift {
+
+struct EncBlockW {
+  const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
+  const unsigned short* wqkv;   // bf16 [384][128]: per 2-head chunk rows (q_h0 | k_h0 | q_h1 | k_h1 | v_h0 | v_h1), 32 rows each
+  const float* bqkv;            // fp32 [384] same order
+  const unsigned short* wo;     // bf16 [128][128]
+  const float* bo;
+  const unsigned short* w1;     // bf16 [512][128]
+  const float* b1;
+  const unsigned short* w2;     // bf16 [128][512]
+  const float* b2;
+  float droppath;
+};
+
+struct EncFusedP {
+  const float* X;               // (bs*N, 128) tokens + positional embedding
+  float* Y;                     // (bs*N, 128) encoder output after the final LayerNorm
+  const uint8_t* kpm;           // (bs*N) key padding mask (1 = padded)
+  int bs, N;
+  EncBlockW blk[4];
+  const float* norm_g; const float* norm_b;
+  uint32_t seed, stream;
+  long long* ts;                // optional phase timestamps of workgroup 0 (diagnostic)
+};
+
+// row-gather weight packer: dst[r][k] = bf16(src[idx[r]][k]); bias_out[r] = bias[idx[r]]
+__global__ void pack_rows_indexed_kernel(const float* __restrict__ src, const float* __restrict__ bias,
+                                         const int* __restrict__ idx, int nrows, int K,
+                                         unsigned short* __restrict__ dst, float* __restrict__ bias_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows * K) return;
+  const int r = i / K, k = i - r * K;
+  dst[i] = f2bf(src[(size_t)idx[r] * K + k]);
+  if (k == 0 && bias) bias_out[r] = bias[idx[r]];
+}
+
+template <int KS, int NTW>
+struct EFrags { bf16x8 f[KS][NTW]; };
+
+template <int KS, int NTW>
+__device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned short* W, int ldw, int n0, int k0, int wave,
+                                         int l15, int l4) {
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      B.f[ks][j] = *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + (j * 4 + wave) * 16 + l15) * ldw + k0 + ks * 32 + l4 * 8);
+}
+
+// acc[mt][j] (+)= X[mt-tile] . W[n-tile j]^T.  Operands are issued "swapped" (weight fragment as the MFMA A operand,
+// activation fragment as B), so the C/D layout holds, per lane, FOUR CONSECUTIVE OUTPUT COLUMNS of one row:
+//   acc[mt][j][r] = out[row = mt*16 + (lane&15)][col = ntile*16 + 4*(lane>>4) + r]
+// -> epilogues are 8/16-byte row-contiguous LDS accesses (2 v_cvt_pk + 1 ds_write_b64 per tile) instead of four
+// scattered 2-byte stores.  NSWAP trailing n-tiles (j >= NTW - NSWAP... see call sites) may keep the plain order:
+//   plain: acc[r] = out[row = mt*16 + 4*(lane>>4) + r][col = ntile*16 + (lane&15)]   (4 consecutive ROWS: transposed stores)
+template <int MT, int KS, int NTW, int NPLAIN = 0>
+__device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned short* A, int lda, const EFrags<KS, NTW>& B,
+                                      int l15, int l4) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + l15) * lda + ks * 32 + l4 * 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+        acc[mt][j] = (j >= NTW - NPLAIN) ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+  }
+}
+
+#define RIFT_ENC_NPAR 1664   // per-layer vectors kept in LDS: ln1 g,b | ln2 g,b | bqkv 384 | bo 128 | b1 512 | b2 128
+#define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * 136 * 2 * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 128 + RIFT_ENC_NPAR * 4)
+
+__global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
+  constexpr int ROWS = 96, MT = 6, C = 128;
+  constexpr int XS = 132, XN = 136, CB = 200, VS = 104, NKT = 6;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* xs = reinterpret_cast<float*>(smem_raw);
+  unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
+  unsigned short* cb = xn + ROWS * XN;
+  unsigned short* ao = cb + ROWS * CB;
+  unsigned short* vt = ao + ROWS * XN;            // [2][32][VS]
+  unsigned char* smask = reinterpret_cast<unsigned char*>(vt + 2 * 32 * VS);
+  float* par = reinterpret_cast<float*>(smask + 128);   // [RIFT_ENC_NPAR] this layer's bias / LayerNorm vectors
+  constexpr int P_LN1G = 0, P_LN1B = 128, P_LN2G = 256, P_LN2B = 384, P_BQKV = 512, P_BO = 896, P_B1 = 1024, P_B2 = 1536;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int b = blockIdx.x, N = p.N;
+  const size_t grow0 = (size_t)b * N;
+  int tsn = 0;
+#define TS() do { if (p.ts && b == 0 && tid == 0) p.ts[tsn++] = clock64(); } while (0)
+  TS();
+
+  // Per-layer vectors are fetched into registers one layer ahead and dropped into LDS at the top of the layer, so
+  // that no epilogue / LayerNorm starts with a dependent global load (each costs ~4k cycles at 1 workgroup per CU).
+  float pre[7];
+  auto par_fetch = [&](const EncBlockW& w) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int e = tid + 256 * i;
+      const float* src = e < 128 ? w.ln1_g + e : e < 256 ? w.ln1_b + (e - 128) : e < 384 ? w.ln2_g + (e - 256)
+                       : e < 512 ? w.ln2_b + (e - 384) : e < 896 ? w.bqkv + (e - 512) : e < 1024 ? w.bo + (e - 896)
+                       : e < 1536 ? w.b1 + (e - 1024) : w.b2 + (e - 1536);
+      pre[i] = e < RIFT_ENC_NPAR ? *src : 0.f;
+    }
+  };
+  auto par_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const int e = tid + 256 * i; if (e < RIFT_ENC_NPAR) par[e] = pre[i]; }
+  };
+  par_fetch(p.blk[0]);
+  EFrags<4, 3> Bqkv;
+  EFrags<4, 2> Bw;       // out_proj / fc1 chunk (128 output columns, K = 128)
+  EFrags<4, 2> B2;       // fc2 partial (128 output columns, K = 128-wide hidden chunk)
+  e_load_b(Bqkv, p.blk[0].wqkv, C, 0, 0, wave, l15, l4);
+
+  for (int i = tid; i < ROWS * 32; i += 256) {
+    const int r = i >> 5, c4 = (i & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < N) v = *reinterpret_cast<const float4*>(p.X + (grow0 + r) * C + c4);
+    *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
+  }
+  for (int i = tid; i < ROWS; i += 256) smask[i] = (i >= N) || p.kpm[grow0 + i];
+  __syncthreads();
+  TS();
+
+  auto layer_norm = [&](const float* g, const float* be) {   // xs -> xn (bf16); 32 lanes per row; g/be in LDS
+    const int lr = lane & 31, rsub = lane >> 5;
+    const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(be + lr * 4);
+#pragma unroll 2
+    for (int r = wave * 2 + rsub; r < ROWS; r += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
+      float s = (v.x + v.y) + (v.z + v.w);
+      s = group_sum<32>(s);
+      const float mean = s * (1.0f / C);
+      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+      float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      q = group_sum<32>(q);
+      const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
+      *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) =
+          pack_bf16x4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
+    }
+  };
+
+  for (int bi = 0; bi < 4; ++bi) {
+    const EncBlockW& w = p.blk[bi];
+    float dpscale = 1.f, dpscale2 = 1.f;
+    if (w.droppath > 0.f) {
+      dpscale = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)b) < w.droppath) ? 0.f : 1.0f / (1.0f - w.droppath);
+      dpscale2 = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)b) < w.droppath) ? 0.f : 1.0f / (1.0f - w.droppath);
+    }
+    par_commit();
+    __syncthreads();
+    // ======== self attention ========
+    layer_norm(par + P_LN1G, par + P_LN1B);
+    __syncthreads();
+    TS();
+    for (int ch = 0; ch < 2; ++ch) {
+      {
+        f32x4 acc[MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        e_mma<MT, 4, 3, 1>(acc, xn, XN, Bqkv, l15, l4);     // q|k tiles swapped (row-major stores), V tile plain (transposed stores)
+        if (ch == 0) e_load_b(Bqkv, w.wqkv, C, 192, 0, wave, l15, l4);
+        else e_load_b(Bw, w.wo, C, 0, 0, wave, l15, l4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {       // n-tiles 0..7: q|k of the two heads -> cb[row][col..col+3]
+          const int nt = j * 4 + wave;
+          const int col = nt * 16 + l4 * 4;
+          const float4 b4 = *reinterpret_cast<const float4*>(par + P_BQKV + ch * 192 + col);
+          const float sc = ((nt & 3) < 2) ? 0.17677669529663687f : 1.0f;   // q pre-scaled by 32^-0.5
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+                pack_bf16x4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
+        }
+        {                                   // n-tiles 8..11: V -> vt[head][d][key..key+3]
+          const int nt = 8 + wave;
+          const int hh = (nt - 8) >> 1, d = ((nt - 8) & 1) * 16 + l15;
+          const float bias = par[P_BQKV + ch * 192 + nt * 16 + l15];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + mt * 16 + l4 * 4) =
+                pack_bf16x4(acc[mt][2][0] + bias, acc[mt][2][1] + bias, acc[mt][2][2] + bias, acc[mt][2][3] + bias);
+        }
+      }
+      __syncthreads();
+      TS();
+      // ---- MFMA attention: 2 heads x 6 query tiles = 12 (head, tile) pairs, 3 per wave (see mha_mfma_kernel)
+      for (int pr = wave; pr < 12; pr += 4) {
+        const int hh = pr / 6, qt = pr - hh * 6;
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + (qt * 16 + l15) * CB + hh * 64 + l4 * 8);
+        f32x4 s[NKT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cb + (kt * 16 + l15) * CB + hh * 64 + 32 + l4 * 8);
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (smask[kt * 16 + l4 * 4 + r]) s[kt][r] = -INFINITY;
+            m = fmaxf(m, s[kt][r]);
+          }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float e = __expf(s[kt][r] - m); lsum += e; s[kt][r] = e; }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+        for (int pt = 0; pt < NKT / 2; ++pt) {
+          bf16x8 pf;
+          const unsigned int p0 = pack_bf16x2(s[2 * pt][0], s[2 * pt][1]), p1 = pack_bf16x2(s[2 * pt][2], s[2 * pt][3]);
+          const unsigned int p2 = pack_bf16x2(s[2 * pt + 1][0], s[2 * pt + 1][1]), p3 = pack_bf16x2(s[2 * pt + 1][2], s[2 * pt + 1][3]);
+          pf[0] = (short)(p0 & 0xffff); pf[1] = (short)(p0 >> 16); pf[2] = (short)(p1 & 0xffff); pf[3] = (short)(p1 >> 16);
+          pf[4] = (short)(p2 & 0xffff); pf[5] = (short)(p2 >> 16); pf[6] = (short)(p3 & 0xffff); pf[7] = (short)(p3 >> 16);
+          const unsigned short* v0 = vt + (hh * 32 + l15) * VS + pt * 32 + l4 * 4;
+          const unsigned short* v1 = vt + (hh * 32 + 16 + l15) * VS + pt * 32 + l4 * 4;
+          const uint2 x0 = *reinterpret_cast<const uint2*>(v0), x1 = *reinterpret_cast<const uint2*>(v0 + 16);
+          const uint2 y0 = *reinterpret_cast<const uint2*>(v1), y1 = *reinterpret_cast<const uint2*>(v1 + 16);
+          bf16x8 b0, b1;
+          b0[0] = (short)(x0.x & 0xffff); b0[1] = (short)(x0.x >> 16); b0[2] = (short)(x0.y & 0xffff); b0[3] = (short)(x0.y >> 16);
+          b0[4] = (short)(x1.x & 0xffff); b0[5] = (short)(x1.x >> 16); b0[6] = (short)(x1.y & 0xffff); b0[7] = (short)(x1.y >> 16);
+          b1[0] = (short)(y0.x & 0xffff); b1[1] = (short)(y0.x >> 16); b1[2] = (short)(y0.y & 0xffff); b1[3] = (short)(y0.y >> 16);
+          b1[4] = (short)(y1.x & 0xffff); b1[5] = (short)(y1.x >> 16); b1[6] = (short)(y1.y & 0xffff); b1[7] = (short)(y1.y >> 16);
+          // O^T = V^T . P^T : lane holds out dims 4*(lane>>4)..+3 (+16) of ITS query (lane&15) -> 8-byte stores, own denominator
+          o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, pf, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, pf, o1, 0, 0, 0);
+        }
+        const int head = ch * 2 + hh;
+        const float inv = 1.0f / lsum;
+        unsigned short* op = ao + (qt * 16 + l15) * XN + head * 32 + l4 * 4;
+        *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+        *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+      }
+      __syncthreads();
+      TS();
+    }
+    // ---- out_proj + residual
+    {
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, 2>(acc, ao, XN, Bw, l15, l4);
+      e_load_b(Bw, w.w1, C, 0, 0, wave, l15, l4);             // fc1 weights of hidden chunk 0
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (j * 4 + wave) * 16 + l4 * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(par + P_BO + col);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float4* xp = reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col);
+          float4 x = *xp;
+          x.x += (acc[mt][j][0] + b4.x) * dpscale; x.y += (acc[mt][j][1] + b4.y) * dpscale;
+          x.z += (acc[mt][j][2] + b4.z) * dpscale; x.w += (acc[mt][j][3] + b4.w) * dpscale;
+          *xp = x;
+        }
+      }
+    }
+    __syncthreads();
+    TS();
+    // ======== MLP ========
+    layer_norm(par + P_LN2G, par + P_LN2B);
+    if (bi + 1 < 4) par_fetch(p.blk[bi + 1]);
+    __syncthreads();
+    TS();
+    {
+      f32x4 acc2[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int hc = 0; hc < 4; ++hc) {
+        {
+          f32x4 acc[MT][2];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          e_mma<MT, 4, 2>(acc, xn, XN, Bw, l15, l4);
+          e_load_b(B2, w.w2, 512, 0, hc * 128, wave, l15, l4);
+          if (hc > 0) __syncthreads();   // previous chunk's fc2 reads of cb are complete
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = (j * 4 + wave) * 16 + l4 * 4;
+            const float4 b4 = *reinterpret_cast<const float4*>(par + P_B1 + hc * 128 + col);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+                  pack_bf16x4(gelu_fast(acc[mt][j][0] + b4.x), gelu_fast(acc[mt][j][1] + b4.y), gelu_fast(acc[mt][j][2] + b4.z),
+                              gelu_fast(acc[mt][j][3] + b4.w));
+          }
+        }
+        if (hc + 1 < 4) e_load_b(Bw, w.w1, C, (hc + 1) * 128, 0, wave, l15, l4);
+        else if (bi + 1 < 4) e_load_b(Bqkv, p.blk[bi + 1].wqkv, C, 0, 0, wave, l15, l4);
+        __syncthreads();
+        TS();
+        e_mma<MT, 4, 2>(acc2, cb, CB, B2, l15, l4);
+        TS();
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (j * 4 + wave) * 16 + l4 * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(par + P_B2 + col);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float4* xp = reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col);
+          float4 x = *xp;
+          x.x += (acc2[mt][j][0] + b4.x) * dpscale2; x.y += (acc2[mt][j][1] + b4.y) * dpscale2;
+          x.z += (acc2[mt][j][2] + b4.z) * dpscale2; x.w += (acc2[mt][j][3] + b4.w) * dpscale2;
+          *xp = x;
+        }
+      }
+    }
+    __syncthreads();
+    TS();
+  }
+  // ---- final LayerNorm (fp32 out) -> global
+  {
+    const int lr = lane & 31, rsub = lane >> 5;
+    const float4 g4 = *reinterpret_cast<const float4*>(p.norm_g + lr * 4), b4 = *reinterpret_cast<const float4*>(p.norm_b + lr * 4);
+    for (int r = wave * 2 + rsub; r < ROWS; r += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
+      float s = (v.x + v.y) + (v.z + v.w);
+      s = group_sum<32>(s);
+      const float mean = s * (1.0f / C);
+      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+      float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      q = group_sum<32>(q);
+      const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
+      if (r < N)
+        *reinterpret_cast<float4*>(p.Y + (grow0 + r) * C + lr * 4) =
+            make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
+    }
+  }
+}
+
+}  // namespace rift

@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "loss.h"
 #include "nat_fused.h"
+#include "enc_fused.h"
 
 using namespace rift;
 
@@ -54,6 +55,9 @@ struct RiftCtx {
   unsigned short* nat_wqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // head-major bf16 qkv weights
   float* nat_bqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool nat_fused = true; int nat_dbg = 0; int gemm_dbg = 0;
+  unsigned short* enc_wqkv[4] = {nullptr, nullptr, nullptr, nullptr};   // chunked (q|k|q|k|v|v) bf16 in_proj images
+  float* enc_bqkv[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* enc_idx = nullptr; bool enc_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -269,6 +273,7 @@ void gemm(RiftCtx* c, GemmP g, const PW& w, bool fp32) {
 int set_lds_attrs(RiftCtx* c) {
   const int big = 160 * 1024;
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
+  SETATTR(enc_fused_kernel);
   SETATTR((nat_level_kernel<32, 2, 20, 3>));
   SETATTR((nat_level_kernel<64, 4, 10, 3>));
   SETATTR((nat_level_kernel<128, 8, 5, 5>));
@@ -592,6 +597,25 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 
   // ================= encoder blocks (transformer.py:73-94) =================
   static const float edpr[4] = {0.f, 0.2f / 3.f, 0.4f / 3.f, 0.2f};   // linspace(0, 0.2, 4), pluto_model.py:80-83
+  float* ENC = A_alloc<float>(c, (size_t)nT * 128);
+  if (c->enc_fused && !f.fp32 && N <= 96) {
+    EncFusedP ep; memset(&ep, 0, sizeof(ep));
+    ep.X = X; ep.Y = ENC; ep.kpm = kpm; ep.bs = bs; ep.N = N; ep.seed = f.seed; ep.stream = f.next_stream(); f.stream_id += 8;
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = "encoder_blocks." + std::to_string(i);
+      EncBlockW& w = ep.blk[i];
+      w.ln1_g = fptr(c, p + ".norm1.weight"); w.ln1_b = fptr(c, p + ".norm1.bias");
+      w.ln2_g = fptr(c, p + ".norm2.weight"); w.ln2_b = fptr(c, p + ".norm2.bias");
+      w.wqkv = c->enc_wqkv[i]; w.bqkv = c->enc_bqkv[i];
+      w.wo = (const unsigned short*)c->pw[p + ".attn.out_proj"].bf; w.bo = c->pw[p + ".attn.out_proj"].bias;
+      w.w1 = (const unsigned short*)c->pw[p + ".mlp.fc1"].bf; w.b1 = c->pw[p + ".mlp.fc1"].bias;
+      w.w2 = (const unsigned short*)c->pw[p + ".mlp.fc2"].bf; w.b2 = c->pw[p + ".mlp.fc2"].bias;
+      w.droppath = f.drop ? edpr[i] : 0.f;
+    }
+    ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias");
+    if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
+    launch(c, "enc_fused_kernel", enc_fused_kernel, dim3(bs), dim3(256), (size_t)RIFT_ENC_LDS_BYTES, ep);
+  } else {
   float* QKV = A_alloc<float>(c, (size_t)nT * 384);
   float* AO = A_alloc<float>(c, (size_t)nT * 128);
   float* H512 = A_alloc<float>(c, (size_t)nT * 512);
@@ -618,8 +642,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     if (f.drop && edpr[i] > 0.f) { g4.droppath_p = edpr[i]; g4.dp_div = N; g4.seed = f.seed; g4.stream = f.next_stream(); }
     gemm(c, g4, c->pw[p + ".mlp.fc2"], f.fp32);
   }
-  float* ENC = A_alloc<float>(c, (size_t)nT * 128);
   layernorm(f, X, 128, ENC, 128, nT, 128, "norm");
+  }
   tap(c, "enc_out", ENC, (int64_t)nT * 128);
 
   // ================= agent predictor (agent_predictor.py:17-29) =================
@@ -793,6 +817,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   { const char* ev = getenv("RIFT_NAT_UNFUSED"); c->nat_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   int rc = set_lds_attrs(c);
@@ -811,6 +836,8 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->l_partial) (void)hipFree(c->l_partial);
   if (c->ego_w) (void)hipFree(c->ego_w);
   if (c->ego_b) (void)hipFree(c->ego_b);
+  if (c->enc_idx) (void)hipFree(c->enc_idx);
+  for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
   delete c;
 }
@@ -878,6 +905,26 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     const std::string p = "encoder_blocks." + std::to_string(i);
     TRY(pack_self_mha(c, p + ".attn"));
     TRY(pack_linear(c, p + ".mlp.fc1")); TRY(pack_linear(c, p + ".mlp.fc2"));
+  }
+  {  // chunked in_proj image for the fused encoder kernel: per 2-head chunk (q_h0 | k_h0 | q_h1 | k_h1 | v_h0 | v_h1)
+    int idx[384];
+    for (int ch = 0; ch < 2; ++ch)
+      for (int seg = 0; seg < 6; ++seg) {
+        const int part = seg < 4 ? (seg & 1) : 2;                 // 0 q, 1 k, 2 v
+        const int head = 2 * ch + (seg < 4 ? (seg >> 1) : (seg - 4));
+        for (int d = 0; d < 32; ++d) idx[ch * 192 + seg * 32 + d] = part * 128 + head * 32 + d;
+      }
+    if (!c->enc_idx) HIPCHK(c, hipMalloc((void**)&c->enc_idx, sizeof(idx)));
+    HIPCHK(c, hipMemcpyAsync(c->enc_idx, idx, sizeof(idx), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // idx is a stack buffer
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = "encoder_blocks." + std::to_string(i) + ".attn";
+      const float* w = fptr(c, p + ".in_proj_weight"); const float* bsrc = fptr(c, p + ".in_proj_bias");
+      if (!w || !bsrc) return RIFT_ERR_ARG;
+      if (!c->enc_wqkv[i]) { HIPCHK(c, hipMalloc((void**)&c->enc_wqkv[i], 384 * 128 * 2)); HIPCHK(c, hipMalloc((void**)&c->enc_bqkv[i], 384 * 4)); }
+      hipLaunchKernelGGL(pack_rows_indexed_kernel, dim3(cdiv(384 * 128, 256)), dim3(256), 0, c->stream, w, bsrc, (const int*)c->enc_idx,
+                         384, 128, c->enc_wqkv[i], c->enc_bqkv[i]);
+    }
   }
   const char* ap[3] = {"loc_predictor", "yaw_predictor", "vel_predictor"};
   for (int i = 0; i < 3; ++i) TRY(pack_mlp_layer(c, std::string("agent_predictor.") + ap[i]));

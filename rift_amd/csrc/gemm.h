@@ -124,8 +124,7 @@ __device__ __forceinline__ void stage_rows_vec(const GemmP& p, typename Prec<BF1
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) sum += (v[s][c].x + v[s][c].y) + (v[s][c].z + v[s][c].w);
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        sum = group_sum<LPR>(sum);
         const float mean = sum * invK;
         float q = 0.f;
 #pragma unroll
@@ -135,8 +134,7 @@ __device__ __forceinline__ void stage_rows_vec(const GemmP& p, typename Prec<BF1
             q += (a * a + b * b) + (cc * cc + dd * dd);
           }
         }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        q = group_sum<LPR>(q);
         const float rstd = rsqrtf(q * invK + p.ln_eps);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {

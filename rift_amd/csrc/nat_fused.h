@@ -126,13 +126,11 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
     for (int r = wave * RPS + rsub; r < ROWS; r += 4 * RPS) {
       const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
       float s = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = group_sum<LPR>(s);
       const float mean = s * (1.0f / C);
       const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
       float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      q = group_sum<LPR>(q);
       const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
       uint2 u;
       u.x = (unsigned)f2bf(d0 * rstd * g4.x + b4.x) | ((unsigned)f2bf(d1 * rstd * g4.y + b4.y) << 16);

@@ -253,3 +253,24 @@ def test_fused_nat_level_matches_layerwise_path(ffi, monkeypatch):
     assert err(outs["fused"], outs["layerwise"]) < 3e-2 * max(1.0, scale)
     # the fused kernel must not be a no-op: its bf16 rounding points differ from the layer-wise path
     assert not torch.equal(outs["fused"], outs["layerwise"])
+
+
+def test_fused_encoder_matches_layerwise_path(ffi, monkeypatch):
+    """The fused scene-encoder kernel (4 layers + final LN, one workgroup per scene) against the layer-wise
+    GEMM/attention path and the exact-fp32 path, on the encoder output of every valid token."""
+    gold, batch, sd = H.load_case("full")
+    data = batch["cur_pluto_feature_torch"]
+    bs, A = data["agent"]["position"].shape[:2]
+    va = data["agent"]["valid_mask"].any(-1)
+    kpm = torch.cat([~va, ~data["map"]["valid_mask"].any(-1)], dim=-1)
+    outs = {}
+    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+        monkeypatch.setenv("RIFT_ENC_UNFUSED", env)
+        eng = ffi.Engine("cuda:0")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        eng.forward(data, fp32=fp32)
+        outs[name] = eng.tap("enc_out").view(bs, -1, 128).cpu().clone()[~kpm]
+        eng.close()
+    assert err(outs["fused"], outs["fp32"]) < 5e-2
+    assert err(outs["fused"], outs["layerwise"]) < 5e-2
+    assert not torch.equal(outs["fused"], outs["layerwise"])
