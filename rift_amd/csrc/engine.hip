@@ -485,7 +485,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       w.droppath = f.drop ? dpr[2 * lv + b] : 0.f;
     }
     const int CWK = 3 * C < 192 ? 3 * C : 192;
-    const size_t lds = (size_t)80 * (C + 4) * 4 + (size_t)80 * (C + 8) * 2 * 2 + (size_t)80 * (CWK + 8) * 2;
+    const int nrpb = H * (2 * ksz - 1);
+    const size_t lds = (size_t)80 * (C + 4) * 4 + (size_t)80 * (C + 8) * 2 * 2 + (size_t)80 * (CWK + 8) * 2 +
+                       (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4;
     const dim3 grid(cdiv(rows, 80)), block(256);
     if (lv == 0) launch(c, "nat_level_kernel_L0", nat_level_kernel<32, 2, 20, 3>, grid, block, lds, p);
     else if (lv == 1) launch(c, "nat_level_kernel_L1", nat_level_kernel<64, 4, 10, 3>, grid, block, lds, p);

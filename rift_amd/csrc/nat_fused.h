@@ -75,7 +75,8 @@ __device__ __forceinline__ void mma80(f32x4 (&acc)[5][NTW], const unsigned short
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0);
+      for (int j = 0; j < NTW; ++j)   // swapped operands: acc[r] = out[row = mt*16 + (lane&15)][col = ntile*16 + 4*(lane>>4) + r]
+        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
   }
 }
 
@@ -98,6 +99,12 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
   unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
   unsigned short* cb = xn + ROWS * XN;
   unsigned short* ao = cb + ROWS * CB;
+  // both layers' bias / LayerNorm / rpb vectors live in LDS (fetched once at kernel start): no epilogue or
+  // LayerNorm begins with a dependent global load
+  constexpr int NRPB = NHEAD * (2 * KSZ - 1);
+  constexpr int P_LN1G = 0, P_LN1B = C, P_LN2G = 2 * C, P_LN2B = 3 * C, P_BQKV = 4 * C, P_BP = 7 * C, P_B1 = 8 * C,
+                P_B2 = 11 * C, P_RPB = 12 * C, NPAR = 12 * C + ((NRPB + 3) & ~3);
+  float* par = reinterpret_cast<float*>(ao + ROWS * XN);    // [2][NPAR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int row0 = blockIdx.x * ROWS;
@@ -107,6 +114,14 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
   BFrags<KS1, NTW_C> Bp;       // proj weights
   BFrags<KSC, NTW_C> B2;       // fc2 weights of the current hidden chunk
   load_b(Bq, p.blk[0].wqkv, C, 0, 0, NT_CH, wave, l15, l4);
+  for (int i = tid; i < 2 * NPAR; i += 256) {
+    const NatBlockW& w = p.blk[i / NPAR];
+    const int e = i % NPAR;
+    const float* src = e < C ? w.ln1_g + e : e < 2 * C ? w.ln1_b + (e - C) : e < 3 * C ? w.ln2_g + (e - 2 * C)
+                     : e < 4 * C ? w.ln2_b + (e - 3 * C) : e < 7 * C ? w.bqkv + (e - 4 * C) : e < 8 * C ? w.bproj + (e - 7 * C)
+                     : e < 11 * C ? w.b1 + (e - 8 * C) : e < 12 * C ? w.b2 + (e - 11 * C) : w.rpb + (e - 12 * C);
+    par[i] = (e < 12 * C + NRPB) ? *src : 0.f;
+  }
 
   // ---- load the residual stream tile
   for (int i = tid; i < ROWS * (C / 4); i += 256) {
@@ -132,17 +147,16 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
       float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       q = group_sum<LPR>(q);
       const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
-      uint2 u;
-      u.x = (unsigned)f2bf(d0 * rstd * g4.x + b4.x) | ((unsigned)f2bf(d1 * rstd * g4.y + b4.y) << 16);
-      u.y = (unsigned)f2bf(d2 * rstd * g4.z + b4.z) | ((unsigned)f2bf(d3 * rstd * g4.w + b4.w) << 16);
-      *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) = u;
+      *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) =
+          pack_bf16x4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
     }
   };
 
   for (int bi = 0; bi < 2; ++bi) {
     const NatBlockW& w = p.blk[bi];
+    const float* pb = par + bi * NPAR;
     // ======== attention half ========
-    if (!(p.dbg & 1)) layer_norm(w.ln1_g, w.ln1_b);
+    if (!(p.dbg & 1)) layer_norm(pb + P_LN1G, pb + P_LN1B);
     __syncthreads();
     for (int ch = 0; ch < NCH; ++ch) {
       // ---- qkv chunk GEMM: cb[80][CWK] = xn[80][C] . Wqkv[ch*CWK .. +CWK][C]^T + b ; q pre-scaled by 16^-0.5
@@ -160,13 +174,13 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
         for (int j = 0; j < NTW_CH; ++j) {
           const int nt = j * 4 + wave;
           if (nt >= NT_CH) continue;
-          const int col = nt * 16 + l15;
-          const float bias = w.bqkv[ch * CWK + col];
-          const float sc = ((col % 48) < 16) ? 0.25f : 1.0f;
+          const int col = nt * 16 + l4 * 4;
+          const float4 b4 = *reinterpret_cast<const float4*>(pb + P_BQKV + ch * CWK + col);
+          const float sc = ((col % 48) < 16) ? 0.25f : 1.0f;    // q pre-scaled by 16^-0.5
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cb[(mt * 16 + l4 * 4 + r) * CB + col] = f2bf((acc[mt][j][r] + bias) * sc);
+            *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+                pack_bf16x4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
         }
       }
       __syncthreads();
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
           float s = 0.f;
 #pragma unroll
           for (int d = 0; d < 8; ++d) s += q[d] * bf2f((unsigned short)k0[d]) + q[8 + d] * bf2f((unsigned short)k1[d]);
-          s += w.rpb[head * (2 * KSZ - 1) + (nb - i) + KSZ - 1];
+          s += pb[P_RPB + head * (2 * KSZ - 1) + (nb - i) + KSZ - 1];
           sc[j] = s;
           mx = fmaxf(mx, s);
         }
@@ -214,11 +228,11 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
 #pragma unroll
           for (int d = 0; d < 8; ++d) { o[d] += wj * bf2f((unsigned short)v0[d]); o[8 + d] += wj * bf2f((unsigned short)v1[d]); }
         }
-        bf16x8 o0, o1;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) { o0[d] = (short)f2bf(o[d]); o1[d] = (short)f2bf(o[8 + d]); }
-        *reinterpret_cast<bf16x8*>(ao + row * XN + head * 16) = o0;
-        *reinterpret_cast<bf16x8*>(ao + row * XN + head * 16 + 8) = o1;
+        uint4 o0, o1;
+        o0.x = pack_bf16x2(o[0], o[1]); o0.y = pack_bf16x2(o[2], o[3]); o0.z = pack_bf16x2(o[4], o[5]); o0.w = pack_bf16x2(o[6], o[7]);
+        o1.x = pack_bf16x2(o[8], o[9]); o1.y = pack_bf16x2(o[10], o[11]); o1.z = pack_bf16x2(o[12], o[13]); o1.w = pack_bf16x2(o[14], o[15]);
+        *reinterpret_cast<uint4*>(ao + row * XN + head * 16) = o0;
+        *reinterpret_cast<uint4*>(ao + row * XN + head * 16 + 8) = o1;
       }
       __syncthreads();
     }
@@ -231,29 +245,32 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
         for (int j = 0; j < NTW_C; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       mma80<KS1, NTW_C>(acc, ao, XN, Bp, l15, l4);
       load_b(Bq, w.w1, C, 0, 0, NT_CH, wave, l15, l4);     // fc1 weights of hidden chunk 0
+      float dps[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        dps[mt] = 1.f;
+        if (w.droppath > 0.f)
+          dps[mt] = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)((row0 + mt * 16 + l15) / L)) < w.droppath) ? 0.f : 1.0f / (1.0f - w.droppath);
+      }
 #pragma unroll
       for (int j = 0; j < NTW_C; ++j) {
         const int nt = j * 4 + wave;
         if (nt >= NT_C) continue;
-        const int col = nt * 16 + l15;
-        const float bias = w.bproj[col];
+        const int col = nt * 16 + l4 * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(pb + P_BP + col);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = mt * 16 + l4 * 4 + r;
-            float v = acc[mt][j][r] + bias;
-            if (w.droppath > 0.f) {
-              const float u = uniform01(p.seed, p.stream + 2 * bi, (uint32_t)((row0 + row) / L));
-              v = (u < w.droppath) ? 0.f : v * (1.0f / (1.0f - w.droppath));
-            }
-            xs[row * XS + col] += v;
-          }
+        for (int mt = 0; mt < MT; ++mt) {
+          float4* xp = reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col);
+          float4 x = *xp;
+          x.x += (acc[mt][j][0] + b4.x) * dps[mt]; x.y += (acc[mt][j][1] + b4.y) * dps[mt];
+          x.z += (acc[mt][j][2] + b4.z) * dps[mt]; x.w += (acc[mt][j][3] + b4.w) * dps[mt];
+          *xp = x;
+        }
       }
     }
     __syncthreads();
     // ======== MLP half ========
-    if (!(p.dbg & 1)) layer_norm(w.ln2_g, w.ln2_b);
+    if (!(p.dbg & 1)) layer_norm(pb + P_LN2G, pb + P_LN2B);
     __syncthreads();
     {
       f32x4 acc2[MT][NTW_C];
@@ -276,12 +293,15 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
           for (int j = 0; j < NTW_CH; ++j) {
             const int nt = j * 4 + wave;
             if (nt >= NT_CH) continue;
-            const int col = nt * 16 + l15;
-            const float bias = w.b1[ch * CWK + col];
+            const int col = nt * 16 + l4 * 4;
+            const float4 b4 = *reinterpret_cast<const float4*>(pb + P_B1 + ch * CWK + col);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) cb[(mt * 16 + l4 * 4 + r) * CB + col] = f2bf((p.dbg & 4) ? fmaxf(acc[mt][j][r] + bias, 0.f) : gelu_erf(acc[mt][j][r] + bias));
+            for (int mt = 0; mt < MT; ++mt) {
+              float v0 = acc[mt][j][0] + b4.x, v1 = acc[mt][j][1] + b4.y, v2 = acc[mt][j][2] + b4.z, v3 = acc[mt][j][3] + b4.w;
+              if (p.dbg & 4) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+              else { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+              *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) = pack_bf16x4(v0, v1, v2, v3);
+            }
           }
         }
         // weights needed after this fc2: next hidden chunk's fc1, or the next block's qkv chunk 0
@@ -291,24 +311,27 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
         // ---- fc2 partial: acc2 += cb[80][CWK] . W2[:, ch*CWK..]^T
         if (!(p.dbg & 8)) mma80<KSC, NTW_C>(acc2, cb, CB, B2, l15, l4);
       }
+      float dps[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        dps[mt] = 1.f;
+        if (w.droppath > 0.f)
+          dps[mt] = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)((row0 + mt * 16 + l15) / L)) < w.droppath) ? 0.f : 1.0f / (1.0f - w.droppath);
+      }
 #pragma unroll
       for (int j = 0; j < NTW_C; ++j) {
         const int nt = j * 4 + wave;
         if (nt >= NT_C) continue;
-        const int col = nt * 16 + l15;
-        const float bias = w.b2[col];
+        const int col = nt * 16 + l4 * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(pb + P_B2 + col);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = mt * 16 + l4 * 4 + r;
-            float v = acc2[mt][j][r] + bias;
-            if (w.droppath > 0.f) {
-              const float u = uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)((row0 + row) / L));
-              v = (u < w.droppath) ? 0.f : v * (1.0f / (1.0f - w.droppath));
-            }
-            xs[row * XS + col] += v;
-          }
+        for (int mt = 0; mt < MT; ++mt) {
+          float4* xp = reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col);
+          float4 x = *xp;
+          x.x += (acc2[mt][j][0] + b4.x) * dps[mt]; x.y += (acc2[mt][j][1] + b4.y) * dps[mt];
+          x.z += (acc2[mt][j][2] + b4.z) * dps[mt]; x.w += (acc2[mt][j][3] + b4.w) * dps[mt];
+          *xp = x;
+        }
       }
     }
     __syncthreads();
