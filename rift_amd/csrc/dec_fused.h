@@ -1,0 +1,434 @@
+// Fused planning decoder for gfx950: the 4 DecoderLayers (planning_decoder.py:42-86) of ONE scene in ONE
+// workgroup.  The scene's R*12 <= 80 mode queries stay resident in LDS (fp32 residual stream + bf16 operand
+// buffers) across   r2r self-attention over the R reference lines (with the reference's
+// `tgt_key_padding_mask.repeat(M, 1)` mask quirk, :56-60)  ->  m2m self-attention over the 12 modes (+m_pos on
+// q/k, padded lines zeroed, :62-72)  ->  cross attention against the scene's encoder tokens (MFMA, :74-79)  ->
+// FFN (:81-83).  The cross-attention K/V projections of the encoder tokens are produced beforehand by the
+// generic GEMM (one per layer) and streamed into LDS per 2-head chunk.  All GEMMs are bf16 MFMA with swapped
+// operands (row-contiguous epilogues); the two tiny self-attentions are fp32 VALU over LDS.
+#pragma once
+#include "enc_fused.h"
+
+namespace rift {
+
+struct DecBlockW {
+  const float* ln_g[4]; const float* ln_b[4];
+  const unsigned short* w_r2r;  const float* b_r2r;    // bf16 [384][128], per 2-head chunk rows (q|k|v of head a, q|k|v of head b)
+  const unsigned short* w_r2ro; const float* b_r2ro;   // out_proj [128][128]
+  const unsigned short* w_m2m;  const float* b_m2m;
+  const unsigned short* w_m2mo; const float* b_m2mo;
+  const unsigned short* w_cq;   const float* b_cq;     // cross_attn in_proj rows 0:128
+  const unsigned short* w_co;   const float* b_co;
+  const unsigned short* w_f1;   const float* b_f1;     // ffn.0 [512][128]
+  const unsigned short* w_f2;   const float* b_f2;     // ffn.3 [128][512]
+  const float* mp;                                     // (12, 384) fp32: m_pos . Wqk^T in ORIGINAL column order (v part zero)
+  const float* kv;                                     // (bs*N, 256) fp32: cross-attention K | V projections of the encoder tokens
+};
+
+struct DecFusedP {
+  float* Q;                     // (bs*R*12, 128) fp32 decoder queries, updated in place
+  const uint8_t* kpm;           // (bs*N) encoder key padding
+  const uint8_t* r_kpm;         // (bs*R) reference-line padding
+  int bs, N, R;
+  DecBlockW blk[4];
+  float dropout;                // 0.1 in train mode
+  uint32_t seed, stream;
+};
+
+#define RIFT_DEC_NPAR 2944   // ln1..4 g,b (1024) | b_r2r 384 | b_r2ro 128 | b_m2m 384 | b_m2mo 128 | b_cq 128 | b_co 128 | b_f1 512 | b_f2 128
+#define RIFT_DEC_LDS_BYTES (80 * 132 * 4 + 80 * 136 * 2 * 2 + 80 * 200 * 2 + 96 * 72 * 2 + 64 * 104 * 2 + RIFT_DEC_NPAR * 4 + 96 + 96 + 16)
+
+__global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
+  constexpr int ROWS = 80, MT = 5, C = 128, M = 12;
+  constexpr int XS = 132, XN = 136, CB = 200, KC = 72, VS = 104, NKT = 6;
+  constexpr int P_LN = 0, P_BR2R = 1024, P_BR2RO = 1408, P_BM2M = 1536, P_BM2MO = 1920, P_BCQ = 2048, P_BCO = 2176,
+                P_BF1 = 2304, P_BF2 = 2816;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* xs = reinterpret_cast<float*>(smem_raw);
+  unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
+  unsigned short* cb = xn + ROWS * XN;
+  unsigned short* ao = cb + ROWS * CB;
+  unsigned short* kc = ao + ROWS * XN;             // [96][KC]  cross K of two heads (row-major, 64 dims + pad)
+  unsigned short* vtc = kc + 96 * KC;              // [64][VS]  cross V^T of two heads
+  float* par = reinterpret_cast<float*>(vtc + 64 * VS);
+  unsigned char* smask = reinterpret_cast<unsigned char*>(par + RIFT_DEC_NPAR);   // [96] encoder key mask
+  unsigned char* qmask = smask + 96;               // [12][8] r2r quirk mask rows
+  unsigned char* rz = qmask + 96;                  // [8] padded reference lines of this scene
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
+  const size_t qrow0 = (size_t)b * NQ;
+  const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
+
+  float pre[12];
+  auto par_fetch = [&](const DecBlockW& w) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int e = tid + 256 * i;
+      const float* src;
+      if (e < 1024) { const int k = e >> 7, c = e & 127; src = ((k & 1) ? w.ln_b[k >> 1] : w.ln_g[k >> 1]) + c; }
+      else if (e < P_BR2RO) src = w.b_r2r + (e - P_BR2R);
+      else if (e < P_BM2M) src = w.b_r2ro + (e - P_BR2RO);
+      else if (e < P_BM2MO) src = w.b_m2m + (e - P_BM2M);
+      else if (e < P_BCQ) src = w.b_m2mo + (e - P_BM2MO);
+      else if (e < P_BCO) src = w.b_cq + (e - P_BCQ);
+      else if (e < P_BF1) src = w.b_co + (e - P_BCO);
+      else if (e < P_BF2) src = w.b_f1 + (e - P_BF1);
+      else src = w.b_f2 + (e - P_BF2);
+      pre[i] = e < RIFT_DEC_NPAR ? *src : 0.f;
+    }
+  };
+  auto par_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const int e = tid + 256 * i; if (e < RIFT_DEC_NPAR) par[e] = pre[i]; }
+  };
+  par_fetch(p.blk[0]);
+  EFrags<4, 3> Bqkv;         // 192-column qkv chunk
+  EFrags<4, 2> Bw;           // 128-column projections / ffn.0 chunk
+  EFrags<4, 2> B2;           // ffn.3 partial
+  e_load_b(Bqkv, p.blk[0].w_r2r, C, 0, 0, wave, l15, l4);
+
+  for (int i = tid; i < ROWS * 32; i += 256) {
+    const int r = i >> 5, c4 = (i & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < NQ) v = *reinterpret_cast<const float4*>(p.Q + (qrow0 + r) * C + c4);
+    *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
+  }
+  for (int i = tid; i < 96; i += 256) smask[i] = (i >= N) || p.kpm[(size_t)b * N + i];
+  for (int i = tid; i < 96; i += 256) {            // quirk: mode m of scene b uses the padding row of scene (b*12+m) % bs
+    const int m = i >> 3, r = i & 7;
+    qmask[i] = (r >= R) || p.r_kpm[(size_t)((b * M + m) % p.bs) * R + r];
+  }
+  if (tid < 8) rz[tid] = (tid >= R) || p.r_kpm[(size_t)b * R + tid];
+  __syncthreads();
+
+  auto layer_norm = [&](const float* g, const float* be) {   // xs -> xn (bf16); 32 lanes per row; g/be in LDS
+    const int lr = lane & 31, rsub = lane >> 5;
+    const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(be + lr * 4);
+#pragma unroll 2
+    for (int r = wave * 2 + rsub; r < ROWS; r += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
+      float s = group_sum<32>((v.x + v.y) + (v.z + v.w));
+      const float mean = s * (1.0f / C);
+      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+      const float q = group_sum<32>((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
+      *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) =
+          pack_bf16x4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
+    }
+  };
+
+  // x += dropout(acc + bias) for a 128-column projection held as acc[MT][2]; optional row zeroing (m2m)
+  auto residual_epilogue = [&](f32x4 (&acc)[MT][2], const float* bias, uint32_t stream, bool zero_padded) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (j * 4 + wave) * 16 + l4 * 4;
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + l15;
+        float v[4] = {acc[mt][j][0] + b4.x, acc[mt][j][1] + b4.y, acc[mt][j][2] + b4.z, acc[mt][j][3] + b4.w};
+        if (dp > 0.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = (uniform01(p.seed, stream, (uint32_t)((b * ROWS + row) * C + col + e)) < dp) ? 0.f : v[e] * dpk;
+        }
+        float4* xp = reinterpret_cast<float4*>(xs + row * XS + col);
+        float4 x = *xp;
+        x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+        if (zero_padded && rz[(row / M) & 7]) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        *xp = x;
+      }
+    }
+  };
+
+  // fp32 VALU self-attention over <= 12 keys of a (row, head) work item; q|k|v of head hh at cb[row][hh*96 + {0,32,64}]
+  auto small_attention = [&](int ch, bool over_modes, uint32_t stream) {
+    for (int it = tid; it < NQ * 2; it += 256) {
+      const int hh = it & 1, row = it >> 1;
+      const int r = row / M, m = row - r * M;
+      const int nkeys = over_modes ? M : R;
+      float q[32], o[32];
+      {
+        const unsigned short* qp = cb + row * CB + hh * 96;
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+          const bf16x8 t = *reinterpret_cast<const bf16x8*>(qp + c8 * 8);
+#pragma unroll
+          for (int d = 0; d < 8; ++d) { q[c8 * 8 + d] = bf2f((unsigned short)t[d]); o[c8 * 8 + d] = 0.f; }
+        }
+      }
+      float mx = -INFINITY, l = 0.f;
+      for (int j = 0; j < nkeys; ++j) {
+        if (!over_modes && qmask[m * 8 + j]) continue;
+        const int krow = over_modes ? r * M + j : j * M + m;
+        const unsigned short* kp = cb + krow * CB + hh * 96 + 32;
+        float s = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+          const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + c8 * 8);
+#pragma unroll
+          for (int d = 0; d < 8; ++d) s += q[c8 * 8 + d] * bf2f((unsigned short)t[d]);
+        }
+        const float mn = fmaxf(mx, s);
+        const float corr = __expf(mx - mn), pj = __expf(s - mn);
+        l = l * corr + pj;
+        float wj = pj;
+        if (dp > 0.f) wj = (uniform01(p.seed, stream, (uint32_t)(((b * ROWS + row) * 4 + ch * 2 + hh) * 16 + j)) < dp) ? 0.f : pj * dpk;
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+          const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + 32 + c8 * 8);
+#pragma unroll
+          for (int d = 0; d < 8; ++d) o[c8 * 8 + d] = o[c8 * 8 + d] * corr + wj * bf2f((unsigned short)t[d]);
+        }
+        mx = mn;
+      }
+      const float inv = 1.0f / l;
+      unsigned short* op = ao + row * XN + (ch * 2 + hh) * 32;
+#pragma unroll
+      for (int c8 = 0; c8 < 4; ++c8) {
+        uint4 u;
+        u.x = pack_bf16x2(o[c8 * 8 + 0] * inv, o[c8 * 8 + 1] * inv); u.y = pack_bf16x2(o[c8 * 8 + 2] * inv, o[c8 * 8 + 3] * inv);
+        u.z = pack_bf16x2(o[c8 * 8 + 4] * inv, o[c8 * 8 + 5] * inv); u.w = pack_bf16x2(o[c8 * 8 + 6] * inv, o[c8 * 8 + 7] * inv);
+        *reinterpret_cast<uint4*>(op + c8 * 8) = u;
+      }
+    }
+  };
+
+  // qkv chunk GEMM of a self-attention: cb[row][hh*96 + part*32 + d]; q pre-scaled; optional per-mode bias (m2m)
+  auto qkv_chunk = [&](int ch, const float* bias, const float* mp) {
+    f32x4 acc[MT][3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    e_mma<MT, 4, 3>(acc, xn, XN, Bqkv, l15, l4);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int nt = j * 4 + wave;                          // 12 n-tiles: head (nt/6), part ((nt%6)/2), half (nt&1)
+      const int hh = nt / 6, part = (nt % 6) >> 1, half = nt & 1;
+      const int col = nt * 16 + l4 * 4;
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + ch * 192 + col);
+      const float sc = part == 0 ? 0.17677669529663687f : 1.0f;
+      const int ocol = part * 128 + (ch * 2 + hh) * 32 + half * 16 + l4 * 4;   // column in the ORIGINAL (q|k|v) order
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mp && part < 2) m4 = *reinterpret_cast<const float4*>(mp + ((mt * 16 + l15) % M) * 384 + ocol);
+        *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+            pack_bf16x4((acc[mt][j][0] + b4.x + m4.x) * sc, (acc[mt][j][1] + b4.y + m4.y) * sc,
+                        (acc[mt][j][2] + b4.z + m4.z) * sc, (acc[mt][j][3] + b4.w + m4.w) * sc);
+      }
+    }
+  };
+
+  for (int li = 0; li < 4; ++li) {
+    const DecBlockW& w = p.blk[li];
+    const uint32_t st = p.stream + 16 * li;
+    par_commit();
+    __syncthreads();
+    // ================= r2r =================
+    layer_norm(par + P_LN + 0, par + P_LN + 128);
+    __syncthreads();
+    for (int ch = 0; ch < 2; ++ch) {
+      qkv_chunk(ch, par + P_BR2R, nullptr);
+      if (ch == 0) e_load_b(Bqkv, w.w_r2r, C, 192, 0, wave, l15, l4);
+      else e_load_b(Bw, w.w_r2ro, C, 0, 0, wave, l15, l4);
+      __syncthreads();
+      small_attention(ch, false, st + 0);
+      __syncthreads();
+    }
+    {
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, 2>(acc, ao, XN, Bw, l15, l4);
+      e_load_b(Bqkv, w.w_m2m, C, 0, 0, wave, l15, l4);
+      residual_epilogue(acc, par + P_BR2RO, st + 1, false);
+    }
+    __syncthreads();
+    // ================= m2m =================
+    layer_norm(par + P_LN + 256, par + P_LN + 384);
+    __syncthreads();
+    for (int ch = 0; ch < 2; ++ch) {
+      qkv_chunk(ch, par + P_BM2M, w.mp);
+      if (ch == 0) e_load_b(Bqkv, w.w_m2m, C, 192, 0, wave, l15, l4);
+      else e_load_b(Bw, w.w_m2mo, C, 0, 0, wave, l15, l4);
+      __syncthreads();
+      small_attention(ch, true, st + 2);
+      __syncthreads();
+    }
+    {
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, 2>(acc, ao, XN, Bw, l15, l4);
+      e_load_b(Bw, w.w_cq, C, 0, 0, wave, l15, l4);
+      residual_epilogue(acc, par + P_BM2MO, st + 3, true);
+    }
+    __syncthreads();
+    // ================= cross attention =================
+    layer_norm(par + P_LN + 512, par + P_LN + 640);
+    __syncthreads();
+    {
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, 2>(acc, xn, XN, Bw, l15, l4);
+      e_load_b(Bw, w.w_co, C, 0, 0, wave, l15, l4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (j * 4 + wave) * 16 + l4 * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(par + P_BCQ + col);
+        const float sc = 0.17677669529663687f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+              pack_bf16x4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
+      }
+    }
+    for (int ch = 0; ch < 2; ++ch) {
+      __syncthreads();          // previous chunk's reads of kc / vtc (and the q writes) are complete
+      // stream K (row-major) and V (transposed) of heads 2ch, 2ch+1 into LDS as bf16
+      for (int i = tid; i < 96 * 16; i += 256) {
+        const int key = i >> 4, c4 = (i & 15) * 4;
+        float4 kq = make_float4(0.f, 0.f, 0.f, 0.f), vq = kq;
+        if (key < N) {
+          const float* src = w.kv + ((size_t)b * N + key) * 256 + ch * 64 + c4;
+          kq = *reinterpret_cast<const float4*>(src);
+          vq = *reinterpret_cast<const float4*>(src + 128);
+        }
+        *reinterpret_cast<uint2*>(kc + key * KC + c4) = pack_bf16x4(kq.x, kq.y, kq.z, kq.w);
+        vtc[(c4 + 0) * VS + key] = f2bf(vq.x); vtc[(c4 + 1) * VS + key] = f2bf(vq.y);
+        vtc[(c4 + 2) * VS + key] = f2bf(vq.z); vtc[(c4 + 3) * VS + key] = f2bf(vq.w);
+      }
+      __syncthreads();
+      for (int pr = wave; pr < 2 * MT; pr += 4) {            // (head, query tile) pairs
+        const int hh = pr / MT, qt = pr - hh * MT;
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + (qt * 16 + l15) * CB + (ch * 2 + hh) * 32 + l4 * 8);
+        f32x4 s[NKT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kc + (kt * 16 + l15) * KC + hh * 32 + l4 * 8);
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (smask[kt * 16 + l4 * 4 + r]) s[kt][r] = -INFINITY;
+            m = fmaxf(m, s[kt][r]);
+          }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __expf(s[kt][r] - m);
+            lsum += e;
+            float wv = e;
+            if (dp > 0.f)
+              wv = (uniform01(p.seed, st + 4, (uint32_t)((((b * ROWS + qt * 16 + l15) * 4 + ch * 2 + hh) * 96) + kt * 16 + l4 * 4 + r)) < dp) ? 0.f : e * dpk;
+            s[kt][r] = wv;
+          }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+        for (int pt = 0; pt < NKT / 2; ++pt) {
+          bf16x8 pf;
+          const unsigned int p0 = pack_bf16x2(s[2 * pt][0], s[2 * pt][1]), p1 = pack_bf16x2(s[2 * pt][2], s[2 * pt][3]);
+          const unsigned int p2 = pack_bf16x2(s[2 * pt + 1][0], s[2 * pt + 1][1]), p3 = pack_bf16x2(s[2 * pt + 1][2], s[2 * pt + 1][3]);
+          pf[0] = (short)(p0 & 0xffff); pf[1] = (short)(p0 >> 16); pf[2] = (short)(p1 & 0xffff); pf[3] = (short)(p1 >> 16);
+          pf[4] = (short)(p2 & 0xffff); pf[5] = (short)(p2 >> 16); pf[6] = (short)(p3 & 0xffff); pf[7] = (short)(p3 >> 16);
+          const unsigned short* v0 = vtc + (hh * 32 + l15) * VS + pt * 32 + l4 * 4;
+          const unsigned short* v1 = vtc + (hh * 32 + 16 + l15) * VS + pt * 32 + l4 * 4;
+          const uint2 x0 = *reinterpret_cast<const uint2*>(v0), x1 = *reinterpret_cast<const uint2*>(v0 + 16);
+          const uint2 y0 = *reinterpret_cast<const uint2*>(v1), y1 = *reinterpret_cast<const uint2*>(v1 + 16);
+          bf16x8 b0, b1;
+          b0[0] = (short)(x0.x & 0xffff); b0[1] = (short)(x0.x >> 16); b0[2] = (short)(x0.y & 0xffff); b0[3] = (short)(x0.y >> 16);
+          b0[4] = (short)(x1.x & 0xffff); b0[5] = (short)(x1.x >> 16); b0[6] = (short)(x1.y & 0xffff); b0[7] = (short)(x1.y >> 16);
+          b1[0] = (short)(y0.x & 0xffff); b1[1] = (short)(y0.x >> 16); b1[2] = (short)(y0.y & 0xffff); b1[3] = (short)(y0.y >> 16);
+          b1[4] = (short)(y1.x & 0xffff); b1[5] = (short)(y1.x >> 16); b1[6] = (short)(y1.y & 0xffff); b1[7] = (short)(y1.y >> 16);
+          o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, pf, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, pf, o1, 0, 0, 0);
+        }
+        const float inv = 1.0f / lsum;
+        unsigned short* op = ao + (qt * 16 + l15) * XN + (ch * 2 + hh) * 32 + l4 * 4;
+        *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+        *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+      }
+    }
+    __syncthreads();
+    {
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, 2>(acc, ao, XN, Bw, l15, l4);
+      e_load_b(Bw, w.w_f1, C, 0, 0, wave, l15, l4);
+      residual_epilogue(acc, par + P_BCO, st + 5, false);
+    }
+    __syncthreads();
+    // ================= FFN =================
+    layer_norm(par + P_LN + 768, par + P_LN + 896);
+    if (li + 1 < 4) par_fetch(p.blk[li + 1]);
+    __syncthreads();
+    {
+      f32x4 acc2[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int hc = 0; hc < 4; ++hc) {
+        {
+          f32x4 acc[MT][2];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          e_mma<MT, 4, 2>(acc, xn, XN, Bw, l15, l4);
+          e_load_b(B2, w.w_f2, 512, 0, hc * 128, wave, l15, l4);
+          if (hc > 0) __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = (j * 4 + wave) * 16 + l4 * 4;
+            const float4 b4 = *reinterpret_cast<const float4*>(par + P_BF1 + hc * 128 + col);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const int row = mt * 16 + l15;
+              float v[4] = {fmaxf(acc[mt][j][0] + b4.x, 0.f), fmaxf(acc[mt][j][1] + b4.y, 0.f), fmaxf(acc[mt][j][2] + b4.z, 0.f),
+                            fmaxf(acc[mt][j][3] + b4.w, 0.f)};
+              if (dp > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  v[e] = (uniform01(p.seed, st + 6, (uint32_t)((b * ROWS + row) * 512 + hc * 128 + col + e)) < dp) ? 0.f : v[e] * dpk;
+              }
+              *reinterpret_cast<uint2*>(cb + row * CB + col) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+        if (hc + 1 < 4) e_load_b(Bw, w.w_f1, C, (hc + 1) * 128, 0, wave, l15, l4);
+        else if (li + 1 < 4) e_load_b(Bqkv, p.blk[li + 1].w_r2r, C, 0, 0, wave, l15, l4);
+        __syncthreads();
+        e_mma<MT, 4, 2>(acc2, cb, CB, B2, l15, l4);
+      }
+      residual_epilogue(acc2, par + P_BF2, st + 7, false);
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < ROWS * 32; i += 256) {
+    const int r = i >> 5, c4 = (i & 31) * 4;
+    if (r < NQ) *reinterpret_cast<float4*>(p.Q + (qrow0 + r) * C + c4) = *reinterpret_cast<const float4*>(xs + r * XS + c4);
+  }
+}
+
+}  // namespace rift

@@ -18,6 +18,7 @@
 #include "loss.h"
 #include "nat_fused.h"
 #include "enc_fused.h"
+#include "dec_fused.h"
 
 using namespace rift;
 
@@ -58,6 +59,9 @@ struct RiftCtx {
   unsigned short* enc_wqkv[4] = {nullptr, nullptr, nullptr, nullptr};   // chunked (q|k|q|k|v|v) bf16 in_proj images
   float* enc_bqkv[4] = {nullptr, nullptr, nullptr, nullptr};
   int* enc_idx = nullptr; bool enc_fused = true;
+  unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
+  float* dec_bqkv[4][2] = {};
+  int* dec_idx = nullptr; bool dec_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -274,6 +278,7 @@ int set_lds_attrs(RiftCtx* c) {
   const int big = 160 * 1024;
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
   SETATTR(enc_fused_kernel);
+  SETATTR(dec_fused_kernel);
   SETATTR((nat_level_kernel<32, 2, 20, 3>));
   SETATTR((nat_level_kernel<64, 4, 10, 3>));
   SETATTR((nat_level_kernel<128, 8, 5, 5>));
@@ -684,13 +689,42 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* Q = A_alloc<float>(c, (size_t)nQ * 128);
   launch(c, "build_q0_kernel", build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
 
+  const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
+  if (c->dec_fused && !f.fp32 && R * M <= 80 && N <= 96) {
+    DecFusedP dq; memset(&dq, 0, sizeof(dq));
+    dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
+    dq.stream = f.next_stream(); f.stream_id += 64;
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = PD + ".decoder_blocks." + std::to_string(i);
+      DecBlockW& w = dq.blk[i];
+      for (int k = 0; k < 4; ++k) {
+        w.ln_g[k] = fptr(c, p + ".norm" + std::to_string(k + 1) + ".weight");
+        w.ln_b[k] = fptr(c, p + ".norm" + std::to_string(k + 1) + ".bias");
+      }
+      w.w_r2r = c->dec_wqkv[i][0]; w.b_r2r = c->dec_bqkv[i][0];
+      w.w_m2m = c->dec_wqkv[i][1]; w.b_m2m = c->dec_bqkv[i][1];
+      auto bf = [&](const std::string& k) { return (const unsigned short*)c->pw[k].bf; };
+      w.w_r2ro = bf(p + ".r2r_attn.out_proj"); w.b_r2ro = c->pw[p + ".r2r_attn.out_proj"].bias;
+      w.w_m2mo = bf(p + ".m2m_attn.out_proj"); w.b_m2mo = c->pw[p + ".m2m_attn.out_proj"].bias;
+      w.w_cq = bf(p + ".cross_attn.q"); w.b_cq = c->pw[p + ".cross_attn.q"].bias;
+      w.w_co = bf(p + ".cross_attn.out_proj"); w.b_co = c->pw[p + ".cross_attn.out_proj"].bias;
+      w.w_f1 = bf(p + ".ffn.0"); w.b_f1 = c->pw[p + ".ffn.0"].bias;
+      w.w_f2 = bf(p + ".ffn.3"); w.b_f2 = c->pw[p + ".ffn.3"].bias;
+      // per-layer operands produced by the generic GEMM: m_pos.Wqk^T (12x384) and the K|V projections of the encoder tokens
+      float* MPl = A_alloc<float>(c, (size_t)M * 384);
+      gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MPl, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
+      float* KVl = A_alloc<float>(c, (size_t)nT * 256);
+      gemm(c, mk(ENC, 128, nT, c->pw[p + ".cross_attn.kv"], KVl, 256), c->pw[p + ".cross_attn.kv"], f.fp32);
+      w.mp = MPl; w.kv = KVl;
+    }
+    launch(c, "dec_fused_kernel", dec_fused_kernel, dim3(bs), dim3(256), (size_t)RIFT_DEC_LDS_BYTES, dq);
+  } else {
   float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
   float* DAO = A_alloc<float>(c, (size_t)nQ * 128);
   float* DQc = A_alloc<float>(c, (size_t)nQ * 128);
   float* DH = A_alloc<float>(c, (size_t)nQ * 512);
   float* KVm = A_alloc<float>(c, (size_t)nT * 256);
   float* MP = A_alloc<float>(c, (size_t)M * 384);
-  const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
   for (int i = 0; i < 4; ++i) {
     const std::string p = PD + ".decoder_blocks." + std::to_string(i);
     // ---- r2r self attention over the R reference lines of each (scene, mode), with the mask quirk
@@ -757,6 +791,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     if (dp > 0.f) { g8.dropout_p = dp; g8.seed = f.seed; g8.stream = f.next_stream(); }
     gemm(c, g8, c->pw[p + ".ffn.3"], f.fp32);
   }
+  }
   tap(c, "dec3", Q, (int64_t)nQ * 128);
   // cat_x_proj(cat[q, enc_emb[:, 0]]) (planning_decoder.py:177-179): ego-token part is a per-scene bias
   float* x0p = A_alloc<float>(c, (size_t)bs * 128);
@@ -819,6 +854,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   { const char* ev = getenv("RIFT_NAT_UNFUSED"); c->nat_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_DEC_UNFUSED"); c->dec_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
@@ -839,6 +875,8 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->ego_w) (void)hipFree(c->ego_w);
   if (c->ego_b) (void)hipFree(c->ego_b);
   if (c->enc_idx) (void)hipFree(c->enc_idx);
+  if (c->dec_idx) (void)hipFree(c->dec_idx);
+  for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
   delete c;
@@ -944,6 +982,26 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     TRY(pack_rows(c, p + ".cross_attn.kv", p + ".cross_attn.in_proj_weight", p + ".cross_attn.in_proj_bias", 128, 256, 256));
     TRY(pack_linear(c, p + ".cross_attn.out_proj"));
     TRY(pack_linear(c, p + ".ffn.0")); TRY(pack_linear(c, p + ".ffn.3"));
+  }
+  {  // chunk-ordered in_proj images of the two decoder self-attentions: per 2-head chunk (q|k|v of head a, q|k|v of head b)
+    int idx[384];
+    for (int ch = 0; ch < 2; ++ch)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int part = 0; part < 3; ++part)
+          for (int d = 0; d < 32; ++d) idx[ch * 192 + hh * 96 + part * 32 + d] = part * 128 + (2 * ch + hh) * 32 + d;
+    if (!c->dec_idx) HIPCHK(c, hipMalloc((void**)&c->dec_idx, sizeof(idx)));
+    HIPCHK(c, hipMemcpyAsync(c->dec_idx, idx, sizeof(idx), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const char* nm[2] = {".r2r_attn", ".m2m_attn"};
+    for (int i = 0; i < 4; ++i)
+      for (int k = 0; k < 2; ++k) {
+        const std::string p = PD + ".decoder_blocks." + std::to_string(i) + nm[k];
+        const float* w = fptr(c, p + ".in_proj_weight"); const float* bsrc = fptr(c, p + ".in_proj_bias");
+        if (!w || !bsrc) return RIFT_ERR_ARG;
+        if (!c->dec_wqkv[i][k]) { HIPCHK(c, hipMalloc((void**)&c->dec_wqkv[i][k], 384 * 128 * 2)); HIPCHK(c, hipMalloc((void**)&c->dec_bqkv[i][k], 384 * 4)); }
+        hipLaunchKernelGGL(pack_rows_indexed_kernel, dim3(cdiv(384 * 128, 256)), dim3(256), 0, c->stream, w, bsrc, (const int*)c->dec_idx,
+                           384, 128, c->dec_wqkv[i][k], c->dec_bqkv[i][k]);
+      }
   }
   TRY(pack_cols(c, PD + ".cat_x_proj.q", PD + ".cat_x_proj", 0, 128, true));
   TRY(pack_cols(c, PD + ".cat_x_proj.x", PD + ".cat_x_proj", 128, 128, false));

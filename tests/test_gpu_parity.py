@@ -274,3 +274,25 @@ def test_fused_encoder_matches_layerwise_path(ffi, monkeypatch):
     assert err(outs["fused"], outs["fp32"]) < 5e-2
     assert err(outs["fused"], outs["layerwise"]) < 5e-2
     assert not torch.equal(outs["fused"], outs["layerwise"])
+
+
+@pytest.mark.parametrize("case", ["small", "full"])
+def test_fused_decoder_matches_layerwise_path(ffi, monkeypatch, case):
+    """The fused planning-decoder kernel (4 layers, one workgroup per scene, incl. the r2r mask quirk on
+    heterogeneous reference-line counts) against the layer-wise path and the exact-fp32 path."""
+    gold, batch, sd = H.load_case(case)
+    data = batch["cur_pluto_feature_torch"]
+    rv = data["reference_line"]["valid_mask"].any(-1)
+    assert len(set(rv.sum(-1).tolist())) > 1, "fixture must mix reference-line counts (exercises the quirk)"
+    outs = {}
+    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+        monkeypatch.setenv("RIFT_DEC_UNFUSED", env)
+        eng = ffi.Engine("cuda:0")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        eng.forward(data, fp32=fp32)
+        outs[name] = eng.tap("dec3").view(rv.shape[0], rv.shape[1], 12, 128).cpu().clone()[rv]
+        eng.close()
+    scale = max(1.0, float(outs["fp32"].abs().max()))
+    assert err(outs["fused"], outs["fp32"]) < 4e-2 * scale
+    assert err(outs["fused"], outs["layerwise"]) < 4e-2 * scale
+    assert not torch.equal(outs["fused"], outs["layerwise"])
