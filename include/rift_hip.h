@@ -187,6 +187,31 @@ int rift_rollout_return(RiftCtx* ctx, const float* delta_dis, const float* delta
                         int collision_ld, const uint8_t* off_road, int off_road_ld, int G, int Ts, double gamma,
                         double* returns, void* stream);
 
+/* Reference-line deviation of every candidate (TrajEvaluator.get_ref_line_info, traj_eval/traj_evaluator.py:372-420):
+ * trajectories (G = R*M, Tfull, 6) -> first Ts frames; ragged reference lines padded to Pmax with lengths ref_len (R).
+ * closest_idx (G,Ts) int32 is the bit-exact integer output (argmin over the line's points). */
+int rift_ref_line_info(RiftCtx* ctx, const float* trajectories, int G, int Tfull, int Ts, int M, const float* ref_pos /*(R,Pmax,2)*/,
+                       const float* ref_angle /*(R,Pmax)*/, const int32_t* ref_len /*(R)*/, int Pmax, float* delta_dis /*(G,Ts)*/,
+                       float* delta_angle /*(G,Ts)*/, int32_t* closest_idx /*(G,Ts)*/, void* stream);
+
+/* Candidate closed-loop rollout (TrajEvaluator.get_center_rollout -> TrackPropagate.propagate,
+ * traj_eval/traj_evaluator.py:115-158, traj_eval/track_propogate.py:599-780): global transform of the candidate
+ * path, 79 PID + kinematic-bicycle steps, Savitzky-Golay kinematics, box corners.  The two PID ring buffers
+ * (BatchPIDTorch, :318-400) are persistent caller-owned state, as in the reference (never reset between calls). */
+typedef struct RiftRolloutIO {
+  const float* trajectories;   /* (G, Tfull, 6) raw model trajectories (x, y, cos, sin, vx, vy); Tfull >= 40 */
+  int32_t G, Tfull, G_per_group;
+  const float* center_state;   /* (G / G_per_group, 6): x, y, heading, speed, width, length of the centre vehicle */
+  float* turn_buf;  int32_t* turn_ptr;  int32_t* turn_len;    /* (G,20) f32, (G) i32, (G) i32 : turn PID state, in/out */
+  float* speed_buf; int32_t* speed_ptr; int32_t* speed_len;   /* speed PID state, in/out */
+  float* center;    /* (G,80,2) */
+  float* angle; float* speed; float* acc; float* ang_vel; float* ang_acc;   /* (G,80) each */
+  float* vertices;  /* (G,80,4,2) FL, RL, RR, FR */
+  int32_t* closest_index;      /* (G,79) closest reference-path index after each step (bit-exact integer output) */
+  int32_t* aim_idx;            /* (G,79) PID aim waypoint index of each step (bit-exact integer output) */
+} RiftRolloutIO;
+int rift_rollout(RiftCtx* ctx, const RiftRolloutIO* io, void* stream);
+
 /* Device-side collation (PlutoFeature.collate, pluto_feature.py:83-94 + RIFTCollate,
  * rift_datamodule.py:33-49): gather `bs` scenes by index from a replay arena whose tensors
  * are stored padded to (A, Mp, Rcap, S) per scene, writing a batch padded to R = batch max. */

@@ -61,11 +61,18 @@ class RiftReplayArena(C.Structure):
                                   "group_valid_mask")]
 
 
+class RiftRolloutIO(C.Structure):
+    _fields_ = [("trajectories", vp), ("G", C.c_int32), ("Tfull", C.c_int32), ("G_per_group", C.c_int32), ("center_state", vp),
+                ("turn_buf", vp), ("turn_ptr", vp), ("turn_len", vp), ("speed_buf", vp), ("speed_ptr", vp), ("speed_len", vp),
+                ("center", vp), ("angle", vp), ("speed", vp), ("acc", vp), ("ang_vel", vp), ("ang_acc", vp), ("vertices", vp),
+                ("closest_index", vp), ("aim_idx", vp)]
+
+
 EXPORTS = [
     "rift_ctx_create", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_loss_backward",
     "rift_loss_finalize", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
-    "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench",
+    "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
 ]
 
 _lib = None
@@ -105,6 +112,8 @@ def load_library() -> C.CDLL:
                                  vp, vp, vp, vp, vp]
     lib.rift_op_linear_bench.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int,
                                          C.POINTER(C.c_float), vp]
+    lib.rift_ref_line_info.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    lib.rift_rollout.argtypes = [vp, C.POINTER(RiftRolloutIO), vp]
     lib.rift_prof_enable.argtypes = [vp, C.c_int]
     lib.rift_prof_report.argtypes = [vp, C.c_char_p, C.c_int]
     for name in EXPORTS:
@@ -360,6 +369,59 @@ class Engine:
         self._check(self.lib.rift_op_linear_bench(self.ctx, _ptr(x), M, K, _ptr(w), _ptr(opt[0]), N, _ptr(opt[1]), _ptr(opt[2]),
                                                   act, _ptr(opt[3]), _ptr(y), reps, C.byref(ms), _stream()), "rift_op_linear_bench")
         return ms.value * 1e3
+
+    def ref_line_info(self, trajectories, ref_pos_list, ref_angle_list, Ts=40):
+        """TrajEvaluator.get_ref_line_info on device.  trajectories (R, M, Tfull, C>=6 or 4)."""
+        dev = self.device
+        traj = _dev(trajectories, torch.float32, dev)
+        R, M, Tfull, Cc = traj.shape
+        assert Cc == 6
+        Pmax = max(p.shape[0] for p in ref_pos_list)
+        rp = torch.zeros(R, Pmax, 2, device=dev)
+        ra = torch.zeros(R, Pmax, device=dev)
+        for r in range(R):
+            n = ref_pos_list[r].shape[0]
+            rp[r, :n] = ref_pos_list[r].to(dev)
+            ra[r, :n] = ref_angle_list[r].to(dev)
+        rl = torch.tensor([p.shape[0] for p in ref_pos_list], dtype=torch.int32, device=dev)
+        G = R * M
+        dd = torch.empty(G, Ts, device=dev)
+        da = torch.empty(G, Ts, device=dev)
+        ci = torch.empty(G, Ts, dtype=torch.int32, device=dev)
+        self._check(self.lib.rift_ref_line_info(self.ctx, _ptr(traj), G, Tfull, Ts, M, _ptr(rp), _ptr(ra), _ptr(rl), Pmax, _ptr(dd),
+                                                _ptr(da), _ptr(ci), _stream()), "rift_ref_line_info")
+        return dd, da, ci
+
+    def new_pid_state(self, capacity: int):
+        """Persistent state of the two BatchPIDTorch filters of TrackPropagate (zero-initialised, never reset)."""
+        dev = self.device
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        return {"turn_buf": z(capacity, 20), "turn_ptr": z(capacity, dt=torch.int32), "turn_len": z(capacity, dt=torch.int32),
+                "speed_buf": z(capacity, 20), "speed_ptr": z(capacity, dt=torch.int32), "speed_len": z(capacity, dt=torch.int32)}
+
+    def rollout(self, trajectories, center_state, pid_state, g_per_group=None):
+        """TrajEvaluator.get_center_rollout / TrackPropagate.propagate on device.
+        trajectories (G, Tfull, 6); center_state (n_groups, 6) = x, y, heading, speed, width, length."""
+        dev = self.device
+        traj = _dev(trajectories, torch.float32, dev)
+        G, Tfull, _ = traj.shape
+        cs = _dev(center_state, torch.float32, dev).view(-1, 6)
+        gper = g_per_group or G // cs.shape[0]
+        io = RiftRolloutIO()
+        io.trajectories, io.G, io.Tfull, io.G_per_group, io.center_state = traj.data_ptr(), G, Tfull, gper, cs.data_ptr()
+        for k in ("turn_buf", "turn_ptr", "turn_len", "speed_buf", "speed_ptr", "speed_len"):
+            assert pid_state[k].shape[0] >= G
+            setattr(io, k, pid_state[k].data_ptr())
+        out = {"center": torch.empty(G, 80, 2, device=dev), "vertices": torch.empty(G, 80, 4, 2, device=dev),
+               "closest_index": torch.empty(G, 79, dtype=torch.int32, device=dev),
+               "aim_idx": torch.empty(G, 79, dtype=torch.int32, device=dev)}
+        for k in ("angle", "speed", "acc", "ang_vel", "ang_acc"):
+            out[k] = torch.empty(G, 80, device=dev)
+        for k, v in out.items():
+            setattr(io, k, v.data_ptr())
+        self._check(self.lib.rift_rollout(self.ctx, C.byref(io), _stream()), "rift_rollout")
+        self._keep_ro = (traj, cs)
+        return out
 
     def gae(self, rewards, undones, values, next_values, unterminated, gamma=0.98, lambda_=0.98):
         dev = self.device

@@ -19,6 +19,7 @@
 #include "nat_fused.h"
 #include "enc_fused.h"
 #include "dec_fused.h"
+#include "rollout.h"
 
 using namespace rift;
 
@@ -277,6 +278,7 @@ void gemm(RiftCtx* c, GemmP g, const PW& w, bool fp32) {
 int set_lds_attrs(RiftCtx* c) {
   const int big = 160 * 1024;
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
+  SETATTR(rollout_kernel);
   SETATTR(enc_fused_kernel);
   SETATTR(dec_fused_kernel);
   SETATTR((nat_level_kernel<32, 2, 20, 3>));
@@ -1238,6 +1240,28 @@ int rift_rollout_return(RiftCtx* c, const float* delta_dis, const float* delta_a
   if (!c || G <= 0 || Ts <= 0) return RIFT_ERR_ARG;
   hipLaunchKernelGGL(rollout_return_kernel, dim3(cdiv(G, 64)), dim3(64), 0, (hipStream_t)stream, delta_dis, delta_angle, speed,
                      acc, ang_vel, ang_acc, collision, collision_ld, off_road, off_road_ld, G, Ts, gamma, returns);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_ref_line_info(RiftCtx* c, const float* traj, int G, int Tfull, int Ts, int M, const float* ref_pos, const float* ref_ang,
+                       const int32_t* ref_len, int Pmax, float* delta_dis, float* delta_angle, int32_t* closest_idx, void* stream) {
+  if (!c || !traj || !ref_pos || !ref_ang || !ref_len || G <= 0 || Ts <= 0 || M <= 0) return RIFT_ERR_ARG;
+  hipLaunchKernelGGL(ref_line_info_kernel, dim3(cdiv((long long)G * Ts, 128)), dim3(128), 0, (hipStream_t)stream, traj, G, Tfull, Ts, M,
+                     ref_pos, ref_ang, (const int*)ref_len, Pmax, delta_dis, delta_angle, (int*)closest_idx);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_rollout(RiftCtx* c, const RiftRolloutIO* io, void* stream) {
+  if (!c || !io || !io->trajectories || !io->center_state || io->G <= 0 || io->Tfull < 40 || io->G_per_group <= 0) return RIFT_ERR_ARG;
+  RolloutP p; memset(&p, 0, sizeof(p));
+  p.traj = io->trajectories; p.G = io->G; p.Tfull = io->Tfull; p.Gper = io->G_per_group; p.state = io->center_state;
+  p.turn_buf = io->turn_buf; p.turn_ptr = (int*)io->turn_ptr; p.turn_len = (int*)io->turn_len;
+  p.speed_buf = io->speed_buf; p.speed_ptr = (int*)io->speed_ptr; p.speed_len = (int*)io->speed_len;
+  p.center = io->center; p.angle = io->angle; p.speed = io->speed; p.acc = io->acc; p.ang_vel = io->ang_vel; p.ang_acc = io->ang_acc;
+  p.vertices = io->vertices; p.closest_index = (int*)io->closest_index; p.aim_idx = (int*)io->aim_idx;
+  hipLaunchKernelGGL(rollout_kernel, dim3(cdiv(io->G, 64)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, (hipStream_t)stream, p);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }

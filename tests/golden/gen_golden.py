@@ -232,6 +232,56 @@ def gen_advantage():
     print("advantage ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB")
 
 
+
+
+# ------------------------------------------------------------------------------------------
+# candidate rollout fixtures (reference TrackPropagate + TrajEvaluator.get_ref_line_info)
+# ------------------------------------------------------------------------------------------
+def gen_rollout():
+    ref_loader.install()
+    import types as _t
+    from tests.helpers import rollout_inputs
+    sys.modules.setdefault("rift.cbv.planning.pluto.utils.nuplan_state_utils",
+                           _t.ModuleType("rift.cbv.planning.pluto.utils.nuplan_state_utils")).CarlaAgentState = object
+    tu = _t.ModuleType("rift.util.torch_util")
+    tu.get_device_name = lambda: "cpu"
+    sys.modules["rift.util.torch_util"] = tu
+    tp = importlib.import_module("rift.cbv.planning.fine_tuner.rlft.traj_eval.track_propogate")
+    ref_info = _ref_function("rift/cbv/planning/fine_tuner/rlft/traj_eval/traj_evaluator.py", "get_ref_line_info")
+    out = {}
+    prop = tp.TrackPropagate(virtual_time_step=0.1)
+    for call, seed in enumerate((777, 778)):          # two consecutive calls: the PID filters keep their state
+        traj, ref_pos, ref_ang, st = rollout_inputs(seed)
+        t40 = traj[:, :, :40, :]
+        dd, da = ref_info(None, t40, ref_pos, ref_ang)
+        out[f"c{call}.delta_dis"], out[f"c{call}.delta_angle"] = dd, da
+        # get_center_rollout preprocessing (traj_evaluator.py:115-153), reproduced with the reference's own ops
+        heading = torch.atan2(t40[..., 3], t40[..., 2])
+        o = torch.cat([t40[..., :2], heading[..., None]], axis=-1)
+        R, M, T, C = o.shape
+        o = o.reshape(-1, T, C)
+        cpos = torch.tensor(st["pos"], dtype=torch.float32)
+        ch = torch.tensor(st["heading"], dtype=torch.float32)
+        first = o[:, 0, :2]
+        o[:, :, :2] -= first.unsqueeze(1)
+        cos_h, sin_h = torch.cos(ch), torch.sin(ch)
+        rot = torch.stack((torch.stack([cos_h, sin_h], dim=-1), torch.stack([-sin_h, cos_h], dim=-1)), dim=-2)
+        gpos = torch.matmul(o[..., :2], rot) + cpos
+        ghead = o[..., 2] + ch
+        ego = _t.SimpleNamespace(dynamic_car_state=_t.SimpleNamespace(speed=st["speed"]),
+                                 car_footprint=_t.SimpleNamespace(width=st["width"], length=st["length"]))
+        res = prop.propagate(gpos, ghead, [ego])
+        for k, v in zip(("center", "angle", "speed", "acc", "ang_vel", "ang_acc", "vertices"), res):
+            out[f"c{call}.{k}"] = v
+    path = os.path.join(HERE, "rollout.npz")
+    np.savez_compressed(path, **out)
+    print("rollout ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB")
+
+
 if __name__ == "__main__":
-    main()
-    gen_advantage()
+    if len(sys.argv) > 1 and sys.argv[1] == "rollout":
+        gen_rollout()
+    else:
+        main()
+        gen_advantage()
+        gen_rollout()

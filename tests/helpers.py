@@ -80,3 +80,30 @@ def advantage_inputs(n=4096, G=48, Ts=40, seed=424242):
     return r
 
 
+
+
+def rollout_inputs(seed=777, R=3, M=12, T=80):
+    """Seeded candidate trajectories (R, M, T, 6) = (x, y, cos, sin, vx, vy), ragged reference lines and the
+    centre-vehicle state used by the rollout fixtures (regenerated, not stored)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    v = 2.0 + 10.0 * torch.rand(R, M, generator=g)
+    kappa = torch.randn(R, M, generator=g) * 0.02
+    t = torch.arange(T, dtype=torch.float32) * 0.1
+    s = v[..., None] * t
+    th = kappa[..., None] * s + torch.randn(R, M, 1, generator=g) * 0.05
+    step = torch.stack([th.cos(), th.sin()], -1) * (v[..., None, None] * 0.1)
+    pos = torch.cumsum(step, dim=2) + torch.randn(R, M, 1, 2, generator=g) * 0.2
+    traj = torch.cat([pos, th.cos()[..., None], th.sin()[..., None], step * 10.0], dim=-1).float().contiguous()
+    ref_pos, ref_ang = [], []
+    for r in range(R):
+        n = int(torch.randint(60, 121, (1,), generator=g))
+        a = float(torch.randn((), generator=g) * 0.1)
+        k = float(torch.randn((), generator=g) * 0.005)
+        ss = torch.arange(n, dtype=torch.float32)
+        ang = a + k * ss
+        p = torch.cumsum(torch.stack([ang.cos(), ang.sin()], -1), dim=0) + torch.randn(1, 2, generator=g) * 0.5
+        ref_pos.append(p.float().contiguous())
+        ref_ang.append(ang.float().contiguous())
+    state = {"pos": (10.0, -5.0), "heading": 0.3, "speed": 6.0, "width": 2.0, "length": 4.6}
+    return traj, ref_pos, ref_ang, state

@@ -296,3 +296,32 @@ def test_fused_decoder_matches_layerwise_path(ffi, monkeypatch, case):
     assert err(outs["fused"], outs["fp32"]) < 4e-2 * scale
     assert err(outs["fused"], outs["layerwise"]) < 4e-2 * scale
     assert not torch.equal(outs["fused"], outs["layerwise"])
+
+
+def test_candidate_rollout_and_ref_line_info(ffi):
+    """rift_ref_line_info / rift_rollout against the oracle (bit-exact with the reference on CPU) on two
+    consecutive calls (persistent PID state).  Integer outputs (closest reference indices, PID aim indices):
+    bit-exact; trajectories / kinematics: 1e-3 abs (GPU libm differs from the host's in the last ulp and the
+    79-step loop is iterative)."""
+    from oracle import rollout as orl
+    eng = ffi.Engine("cuda:0")
+    ro = orl.Rollout()
+    pid = eng.new_pid_state(64)
+    for call, seed in enumerate((777, 778)):
+        traj, ref_pos, ref_ang, st = H.rollout_inputs(seed)
+        t40 = traj[:, :, :40, :]
+        dd, da, ci = orl.ref_line_info(t40, ref_pos, ref_ang)
+        hdd, hda, hci = eng.ref_line_info(traj, ref_pos, ref_ang, Ts=40)
+        assert np.array_equal(hci.cpu().numpy(), ci.numpy().astype(np.int32))          # bit-exact integer indices
+        assert err(hdd, dd) < 1e-4 and err(hda, da) < 1e-4
+        gpos, ghead = orl.to_global(t40, torch.tensor(st["pos"]), torch.tensor(st["heading"]))
+        ref = ro.propagate(gpos, ghead, st["speed"], st["width"], st["length"])
+        cs = torch.tensor([[st["pos"][0], st["pos"][1], st["heading"], st["speed"], st["width"], st["length"]]])
+        out = eng.rollout(traj.reshape(-1, 80, 6), cs, pid)
+        torch.cuda.synchronize()
+        assert np.array_equal(out["closest_index"].cpu().numpy(), ref["closest_index"].numpy().astype(np.int32)), call
+        assert np.array_equal(out["aim_idx"].cpu().numpy(), ref["aim_idx"].numpy().astype(np.int32)), call
+        for k, tol in (("center", 1e-3), ("angle", 1e-4), ("speed", 1e-3), ("acc", 2e-2), ("ang_vel", 2e-3), ("ang_acc", 5e-2),
+                       ("vertices", 1e-3)):
+            assert err(out[k], ref[k]) < tol, (call, k, err(out[k], ref[k]))
+    eng.close()
