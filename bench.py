@@ -97,14 +97,14 @@ def main():
         pg = dist.group.WORLD
 
     from rift_amd import synthetic as syn
-    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer, shard_scene_ids
     from rift_amd.planning.pluto.model.pluto_model import PlanningModel
     from rift_amd.replay import DeviceReplay
 
     # ---- replay shard of this rank (seeded per scene index, so the union over ranks is the same 4096 scenes)
     per_rank = max(BATCH, args.replay // world)
     t_gen = time.perf_counter()
-    scenes = [syn.make_scene(rank * per_rank + i) for i in range(per_rank)]
+    scenes = [syn.make_scene(i) for i in shard_scene_ids(rank, world, per_rank)]
     replay = DeviceReplay(scenes, dev, rcap=6)
     t_gen = time.perf_counter() - t_gen
 

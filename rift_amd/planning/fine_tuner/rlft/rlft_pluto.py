@@ -1,0 +1,286 @@
+"""RLFT policies -- host mirror of the reference's update-loop driver
+(fine_tuner/rlft/rlft_pluto.py:32-300, fine_tuner/training_builder.py:45-180 and the four *_pluto.py variants)
+without hydra / Lightning / wandb: the same `CBVBasePolicy` surface, checkpoint naming, learning-rate decay across
+updates, 16-epoch fit with a 90/10 split, batch 256, clip 0.5, per-epoch WarmupCosLR and top-1 checkpointing
+by validation loss -- every forward / loss / backward on the HIP engine, batches gathered on device.
+
+`get_action` (per-tick inference + PID control of live CARLA actors, rift_pluto.py:28-161, pluto.py:196-276) needs
+CarlaDataProvider and is the rollout-side row of SURVEY.md section 8(f); it is not part of this package.
+"""
+import math
+import re
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
+from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+from rift_amd.replay import DeviceReplay
+
+DEFAULT_CFG = {   # fine_tuner/rlft/config/{rift,grpo,ppo,reinforce}_training.yaml + datamodule/*.yaml + lightning/custom_lightning.yaml
+    "epochs": 16, "warmup_epochs": 3, "lr": 1e-4, "cl_lr_decay": 0.9, "min_lr": 1e-6, "weight_decay": 1e-5,
+    "trainable_layers": ["planning_decoder.pi_head"], "train_batch_size": 256, "val_batch_size": 256, "shuffle": True,
+    "train_ratio": 0.9, "gamma": 0.98, "lambda_gae_adv": 0.98, "gradient_clip_val": 0.5,
+}
+
+
+class CBVBasePolicy:   # rift/cbv/planning/base_policy.py:9-52
+    name = 'base'
+    type = 'unlearnable'
+
+    def __init__(self, config, logger):
+        self.config = config
+        self.num_scenario = config['num_scenario']
+        self._render_data = None
+        self.route_planner = None
+
+    def set_buffer(self, buffer, total_routes):
+        self.buffer, self.total_routes = buffer, total_routes
+
+    def set_route_planner(self, route_planner):
+        self.route_planner = route_planner
+
+    def train(self, e_i):
+        raise NotImplementedError()
+
+    def set_mode(self, mode):
+        self.mode = mode
+
+    def get_action(self, state, infos, deterministic):
+        raise NotImplementedError()
+
+    def get_render_data(self, env_id):
+        return NotImplementedError()
+
+    def log_episode_reward(self, episode_reward, episode):
+        pass
+
+    def load_model(self, resume=True):
+        pass
+
+    def save_model(self, episode):
+        pass
+
+    def clean_up(self):
+        pass
+
+    def finish(self):
+        pass
+
+
+def buffer_to_scenes(buffer: CBVRolloutBuffer) -> List[Dict]:
+    """Replay entries (cbv_rollout_buffer.py:77-95; keys of planning/config/rift_pluto.yaml:8-16) -> arena scenes."""
+    n = buffer.buffer_capacity
+    obs = buffer.get_key_data('CBVs_obs')
+    scenes = []
+    has = lambda k: k in buffer.buffer_data  # noqa: E731
+    for i in range(n):
+        pf = obs[i]['raw_pluto_feature']
+        ex = {}
+        if has('CBVs_group_advantage'):
+            a = buffer.buffer_data['CBVs_group_advantage'][i]
+            ex["group_advantage"] = torch.as_tensor(np.asarray(a['advantage']), dtype=torch.float64)
+            ex["group_advantage_mask"] = torch.as_tensor(np.asarray(a['valid_mask']), dtype=torch.bool)
+        if has('CBVs_actions_old_group_logits'):
+            o = buffer.buffer_data['CBVs_actions_old_group_logits'][i]
+            ex["old_group_logits"] = torch.as_tensor(np.asarray(o['logits']), dtype=torch.float32)
+            ex["old_group_logits_mask"] = torch.as_tensor(np.asarray(o['valid_mask']), dtype=torch.bool)
+        if has('CBVs_actions_ref_group_logits'):
+            ex["ref_group_logits"] = torch.as_tensor(np.asarray(buffer.buffer_data['CBVs_actions_ref_group_logits'][i]['logits']),
+                                                     dtype=torch.float32)
+        R = pf.data["reference_line"]["position"].shape[0]
+        ex.setdefault("group_advantage", torch.zeros(R, 12, dtype=torch.float64))
+        ex.setdefault("group_advantage_mask", torch.ones(R, 12, dtype=torch.bool))
+        ex.setdefault("old_group_logits", torch.zeros(R, 12))
+        ex.setdefault("old_group_logits_mask", torch.ones(R, 12, dtype=torch.bool))
+        scenes.append({"feature": pf.data, "extras": ex})
+    return scenes
+
+
+class RLFTPluto(CBVBasePolicy):
+    name = 'rlft_pluto'
+    type = 'rlft'
+    kind = 'rift'
+
+    def __init__(self, config, logger):
+        super().__init__(config, logger)
+        self.logger = logger
+        self.radius = config.get('radius', 120)
+        self.device = torch.device(config.get('device', 'cuda:0'))
+        self.model_path = Path(config.get('ROOT_DIR', '.')) / config.get('model_path', 'model_ckpt')
+        self.cbv_recog, self.seed = config.get('cbv_recog', 'rule'), config.get('seed', 0)
+        self.pretrain_seed = config.get('pretrain_seed', self.seed)
+        self.cfg = dict(DEFAULT_CFG)
+        self.cfg.update(config.get('rlft', {}))
+        self.initial_lr = self.cfg["lr"]
+        self.checkpoint: Optional[str] = None
+        self.continue_episode, self.current_epoch = 0, 0
+        ego = config.get('ego_policy', 'pdm_lite') if config.get('mode', 'train_cbv') == 'train_cbv' else config.get('pretrain_ego', 'pdm_lite')
+        sd = self.seed if config.get('mode', 'train_cbv') == 'train_cbv' else self.pretrain_seed
+        self.load_agent_info = f"{ego}-{self.cbv_recog}-seed{sd}"
+        self.save_agent_info = f"{config.get('ego_policy', 'pdm_lite')}-{self.cbv_recog}-seed{self.seed}"
+        self.pluto_model = PlanningModel(radius=self.radius).to(self.device)   # inference model
+        self.pluto_model.eval()
+        self.train_model: Optional[PlanningModel] = None
+        self.buffer: Optional[CBVRolloutBuffer] = None
+        self.mode = 'eval'
+        self.last_fit: Dict = {}
+
+    def _log(self, msg, color=None):
+        if self.logger is not None and hasattr(self.logger, "log"):
+            self.logger.log(msg, color) if color else self.logger.log(msg)
+
+    # ---- API surface of rlft_pluto.py ---------------------------------------------------------------
+    def set_buffer(self, buffer, total_routes=None):
+        self.buffer = buffer
+        self.total_routes = total_routes
+
+    def set_mode(self, mode):
+        self.mode = mode
+        if mode == 'train':
+            self.train_model = PlanningModel(radius=self.radius).to(self.device)
+            self.train_model.train()
+            self.pluto_model.eval()
+        elif mode == 'eval':
+            self.pluto_model.eval()
+        else:
+            raise ValueError(f'Unknown mode {mode}')
+
+    def get_action(self, CBVs_obs_list, infos, deterministic=False):
+        raise NotImplementedError("rollout-side inference needs CARLA actors (SURVEY.md section 8(f) row 1)")
+
+    @staticmethod
+    def load_infer_checkpoint(checkpoint: str, device_name) -> Dict[str, torch.Tensor]:
+        """pluto.py:130-133: strip the 'model.' prefix; value_net.* (PPO) is not part of the inference model."""
+        ckpt = torch.load(checkpoint, map_location=device_name, weights_only=False)
+        sd = {k.replace("model.", "", 1) if k.startswith("model.") else k: v for k, v in ckpt["state_dict"].items()}
+        return {k: v for k, v in sd.items() if not k.startswith("value_net")}
+
+    def load_model(self, resume=True):
+        load_dir = self.model_path / self.load_agent_info
+        files = list(load_dir.glob("*.ckpt"))
+        if resume and files:
+            latest = max(files, key=lambda f: int(re.search(r"carla_episode=(\d+)", f.stem).group(1)))
+            self.checkpoint = latest.as_posix()
+            self.continue_episode = int(re.search(r"carla_episode=(\d+)", latest.stem).group(1))
+            self.current_epoch = len(files)
+            self._log(f">> Loading {self.name} model from {latest.name}", 'yellow')
+        else:
+            if not resume:
+                for f in files:
+                    f.unlink()
+            self.checkpoint = self.config.get('ckpt_path')
+            self.continue_episode, self.current_epoch = 0, 0
+        if self.checkpoint and Path(self.checkpoint).exists():
+            self.pluto_model.load_state_dict(self.load_infer_checkpoint(self.checkpoint, self.device))
+
+    def update_training_ckpt(self):
+        load_dir = self.model_path / self.load_agent_info
+        pat = re.compile(r"carla_episode=(\d+)")
+        files = sorted(load_dir.glob("*.ckpt"), key=lambda f: int(pat.search(f.stem).group(1)), reverse=True)
+        self.current_epoch = len(files)
+        if files:
+            self.checkpoint = files[0].as_posix()
+
+    # ---- the policy update (rlft_pluto.py:206-247) ---------------------------------------------------
+    def preprocess_buffer(self, trainer: RLFTTrainer, replay: DeviceReplay) -> Dict[str, torch.Tensor]:
+        """No-op for RIFT / GRPO (rift_datamodule.py:97-98)."""
+        return {}
+
+    def train(self, e_i):
+        assert self.buffer is not None and self.buffer.buffer_full, 'The buffer should be full before training'
+        if self.train_model is None:
+            self.set_mode('train')
+        cfg = self.cfg
+        lr = max(self.initial_lr * (cfg["cl_lr_decay"] ** self.current_epoch), cfg["min_lr"])   # rlft_pluto.py:212
+        if self.checkpoint and Path(self.checkpoint).exists():
+            sd = torch.load(self.checkpoint, map_location=self.device, weights_only=False)["state_dict"]
+            self.train_model.load_state_dict({k.replace("model.", "", 1): v for k, v in sd.items()}, strict=False)
+        else:
+            self.train_model.load_state_dict(self.pluto_model.state_dict(), strict=False)
+        self.train_model.need_traj = False
+        trainer = RLFTTrainer(self.train_model, kind=self.kind, lr=lr, cl_lr_decay=cfg["cl_lr_decay"],
+                              weight_decay=cfg["weight_decay"], epochs=cfg["epochs"], warmup_epochs=cfg["warmup_epochs"],
+                              trainable_layers=tuple(cfg["trainable_layers"]), gradient_clip_val=cfg["gradient_clip_val"])
+        eng = trainer.engine
+        replay = DeviceReplay(buffer_to_scenes(self.buffer), self.device)
+        extras = self.preprocess_buffer(trainer, replay)
+        n = replay.n
+        g = torch.Generator().manual_seed(int(e_i) + 1234)
+        perm = torch.randperm(n, generator=g)                      # random_split(dataset, [0.9, 0.1]), rift_datamodule.py:93
+        n_train = int(math.floor(n * cfg["train_ratio"]))
+        train_idx, val_idx = perm[:n_train], perm[n_train:]
+        save_dir = self.model_path / self.load_agent_info
+        save_dir.mkdir(parents=True, exist_ok=True)
+        best, best_path, history = None, None, []
+
+        def batches(idx, bs, shuffle):
+            if shuffle:
+                idx = idx[torch.randperm(idx.numel(), generator=g)]
+            for s in range(0, idx.numel(), bs):
+                yield idx[s:s + bs].to(torch.int32).to(self.device)
+
+        def run(idx_dev, train):
+            R_out = int(replay.r_count_cpu[idx_dev.cpu().long()].max())
+            fb, b = replay.collate(eng, idx_dev, R_out)
+            b = dict(b)
+            for k, v in extras.items():
+                b[k] = v[idx_dev.long()].contiguous()
+            return trainer.training_step(fb, b) if train else trainer.validation_step(fb, b)
+
+        for epoch in range(cfg["epochs"]):
+            tl = [float(run(i, True).item()) for i in batches(train_idx, cfg["train_batch_size"], cfg["shuffle"])]
+            vl = [float(run(i, False).item()) for i in batches(val_idx, cfg["val_batch_size"], False)]
+            trainer.on_epoch_end()
+            val_loss = float(np.mean(vl)) if vl else float(np.mean(tl))
+            history.append({"epoch": epoch, "train_loss": float(np.mean(tl)), "val_loss": val_loss,
+                            "lr": trainer.optimizer.param_groups[0]["lr"]})
+            if best is None or val_loss < best:                    # ModelCheckpoint(save_top_k=1, monitor loss/val_loss)
+                if best_path is not None and best_path.exists():
+                    best_path.unlink()
+                best = val_loss
+                best_path = save_dir / f"carla_episode={e_i}-epoch={epoch:02d}-val_loss={val_loss:.4f}.ckpt"
+                torch.save({"state_dict": {"model." + k: v.detach().cpu() for k, v in self.train_model.state_dict().items()},
+                            "epoch": epoch, "carla_episode": e_i}, best_path)
+        self.last_fit = {"history": history, "best_val_loss": best, "checkpoint": best_path.as_posix(), "lr": lr}
+        self.update_training_ckpt()
+        self.pluto_model.load_state_dict(self.load_infer_checkpoint(self.checkpoint, self.device))
+        self.buffer.reset_buffer()
+        return self.last_fit
+
+
+class RIFTPluto(RLFTPluto):        # fine_tuner/rlft/rift_pluto/rift_pluto.py:18
+    name, type, kind = 'rift_pluto', 'rlft', 'rift'
+
+
+class GRPOPluto(RLFTPluto):        # fine_tuner/rlft/grpo_pluto/grpo_pluto.py
+    name, type, kind = 'grpo_pluto', 'rlft', 'grpo'
+
+
+class ReinforcePluto(RLFTPluto):   # fine_tuner/rlft/reinforce_pluto/reinforce_pluto.py
+    name, type, kind = 'reinforce_pluto', 'rlft', 'reinforce'
+
+    def preprocess_buffer(self, trainer, replay):
+        """reinforce_datamodule.py:112-124: discounted return scan over the whole buffer (device)."""
+        rewards = torch.as_tensor(np.stack(self.buffer.get_key_data('CBVs_reward'), axis=0)).double().view(-1)
+        dones = torch.as_tensor(np.stack(self.buffer.get_key_data('CBVs_done'), axis=0)).float().view(-1)
+        ret = trainer.engine.discounted_return(rewards, dones, self.cfg["gamma"])
+        return {"returns": ret.float()}
+
+
+class PPOPluto(RLFTPluto):         # fine_tuner/rlft/ppo_pluto/ppo_pluto.py:43
+    name, type, kind = 'ppo_pluto', 'learnable', 'ppo'
+
+    def preprocess_buffer(self, trainer, replay):
+        raise NotImplementedError(
+            "PPO actor loss / GAE scan / advantage normalisation run on the HIP engine (rift_loss_backward kind=PPO, rift_gae, "
+            "rift_normalize_advantage), but the CriticPPO value network (gym_carla/utils/net.py:420-431) and its two full-buffer "
+            "sweeps (ppo_datamodule.py:117-174) are not wired into this driver yet")
+
+
+CBV_POLICY_LIST = {   # rift/cbv/planning/__init__.py:21-34 (RLFT entries)
+    'rift_pluto': RIFTPluto, 'grpo_pluto': GRPOPluto, 'reinforce_pluto': ReinforcePluto, 'ppo_pluto': PPOPluto,
+}

@@ -3,7 +3,7 @@
 reinforce_pluto/reinforce_trainer.py) on the HIP engine, without Lightning.
 
 One step = train-mode forward (HIP) -> objective + analytic pi_head backward (HIP)
--> [DP: one fused RCCL all-reduce of (grad sums | objective sum | count)] -> loss / grads
+-> [DP: RCCL all-reduce of the unnormalised (grad sums) and (objective sum, count)] -> loss / grads
 -> clip_grad_norm_(0.5) -> AdamW.  The optimizer and the collective stay in
 PyTorch-ROCm, as the reference's optimizer does (rift_trainer.py:279-362).
 """
@@ -84,6 +84,21 @@ def configure_optimizer(model: nn.Module, lr: float, weight_decay: float):
     return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
 
 
+def dp_all_reduce(flat: torch.Tensor, stats: torch.Tensor, group=None):
+    """The only exchange step of the data-parallel path.  Every rank holds UNNORMALISED sums over its scene shard:
+    `flat` = sum of d(objective)/d(pi_head params) (16,897 f32), `stats` = (objective sum, valid-entry count) in f64.
+    After the SUM all-reduce, loss = -stats[0]/stats[1] and grad = -flat/stats[1] on every rank equal the
+    single-process result on the concatenated batch (a global masked mean -- not Lightning-DDP's mean of per-rank
+    means, which weights ranks with fewer valid candidates more)."""
+    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
+    torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM, group=group)
+
+
+def shard_scene_ids(rank: int, world: int, per_rank: int):
+    """Replay shard of `rank`: contiguous scene ids, disjoint across ranks (independent scenes, no data-path exchange)."""
+    return range(rank * per_rank, (rank + 1) * per_rank)
+
+
 class RLFTTrainer:
     """Update-step driver for kind in {'rift','grpo','ppo','reinforce'}.
 
@@ -115,7 +130,7 @@ class RLFTTrainer:
         for p in self.params.values():
             p.grad = torch.zeros_like(p)
         self.train_params = list(self.params.values())
-        # fused exchange buffer: [flat grad sums (16897 f32 as f64? no) ...] kept as two tensors
+        # exchange buffers of the DP path (see dp_all_reduce)
         self.flat = torch.zeros(_ffi.PI_NPARAM, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -169,9 +184,13 @@ class RLFTTrainer:
         self.set_loss_inputs(extras)
         eng.loss_backward_raw(self.kind_id, self.li, self.lo)
         if self.pg is not None and self.world > 1:
-            torch.distributed.all_reduce(self.flat, group=self.pg)
-            torch.distributed.all_reduce(self.stats, group=self.pg)
-        eng.loss_finalize_raw(self.lo, 0)
+            dp_all_reduce(self.flat, self.stats, self.pg)
+        if backward:
+            eng.loss_finalize_raw(self.lo, 0)
+        else:   # validation: loss only, the .grad buffers are left untouched
+            lv = _ffi.RiftLossOut()
+            lv.loss, lv.stats, lv.flat_grad_sum = self.lo.loss, self.lo.stats, self.lo.flat_grad_sum
+            eng.loss_finalize_raw(lv, 0)
         return self.loss
 
     def training_step(self, fb, extras):
@@ -183,7 +202,7 @@ class RLFTTrainer:
         return loss
 
     def validation_step(self, fb, extras):
-        return self.forward_loss(fb, extras, train=False)
+        return self.forward_loss(fb, extras, train=False, backward=False)
 
     def on_epoch_end(self):
         self.scheduler.step()

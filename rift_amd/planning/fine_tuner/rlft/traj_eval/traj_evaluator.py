@@ -1,0 +1,41 @@
+"""TrajEvaluator -- device mirror of the GRPO group-advantage pipeline
+(fine_tuner/rlft/traj_eval/traj_evaluator.py:82-475), candidate side.
+
+    get_grpo_advantage = ref-line deviation (rift_ref_line_info) -> closed-loop PID + bicycle rollout
+    (rift_rollout, persistent PID state as in the reference) -> discounted dense-reward return
+    (rift_rollout_return) -> group z-score (rift_group_advantage, ddof 0, +1e-5).
+
+The collision / off-road flags (shapely envelope test against forecast neighbours, HD-map raster lookup;
+traj_evaluator.py:160-331) need CARLA actors and map data: they are inputs here.
+"""
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+
+class TrajEvaluator:
+    def __init__(self, engine, dt: float = 0.1, num_frames: int = 40, pid_capacity: int = 256):
+        assert abs(dt - 0.1) < 1e-9 and num_frames == 40, "kernels are built for dt = 0.1 s, 40 evaluated frames"
+        self.engine, self.dt, self.num_frames = engine, dt, num_frames
+        self.pid_state = engine.new_pid_state(pid_capacity)     # BatchPIDTorch state: never reset (reference behaviour)
+        self.last_rollout: Optional[Dict[str, torch.Tensor]] = None
+
+    def get_grpo_advantage(self, center_state, trajectories: torch.Tensor, ref_line_pos: List[torch.Tensor],
+                           ref_line_angle: List[torch.Tensor], collision_matrix, off_road_matrix, gamma: float = 0.98):
+        """center_state: (x, y, heading, speed, width, length) of the CBV rear axle / footprint.
+        trajectories: (R, M, 80, 6) raw model output of the valid reference lines.
+        collision_matrix (G, >=40) / off_road_matrix (G, >=40): bool flags per candidate and frame."""
+        eng = self.engine
+        R, M = trajectories.shape[:2]
+        G = R * M
+        dd, da, _ = eng.ref_line_info(trajectories, ref_line_pos, ref_line_angle, Ts=self.num_frames)
+        cs = torch.as_tensor(center_state, dtype=torch.float32).view(1, 6)
+        ro = eng.rollout(trajectories.reshape(G, trajectories.shape[2], 6), cs, self.pid_state)
+        self.last_rollout = ro
+        T = self.num_frames
+        ret = eng.rollout_return(dd, da, ro["speed"][:, :T].contiguous(), ro["acc"][:, :T].contiguous(),
+                                 ro["ang_vel"][:, :T].contiguous(), ro["ang_acc"][:, :T].contiguous(),
+                                 torch.as_tensor(collision_matrix), torch.as_tensor(off_road_matrix), gamma)
+        adv = eng.group_advantage(ret.view(1, G)).view(R, M)
+        return {"advantage": adv.cpu().numpy(), "valid_mask": np.ones((R, M), dtype=np.bool_)}

@@ -1,0 +1,82 @@
+"""N>1 path on CPU: two `gloo` ranks, each holding half of the scenes, run the trainer's exchange step
+(dp_all_reduce: SUM of unnormalised grad sums + (objective sum, count)) and must reproduce the single-process
+loss and pi_head gradients of the full batch (oracle autograd).  The per-rank sums here come from the oracle;
+on the GPU they come from rift_loss_backward -- the exchange protocol and the normalisation are what is tested."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import losses
+from rift_amd.planning.fine_tuner.rlft.trainer import dp_all_reduce, shard_scene_ids
+from tests import helpers as H
+
+KINDS = ["rift", "grpo"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _shard(t, lo, hi):
+    return t[lo:hi] if torch.is_tensor(t) else t
+
+
+def _rank_sums(kind, sd, q, r_pad, batch, lo, hi):
+    """Unnormalised per-shard sums, as rift_loss_backward emits them: flat = -grad_mean * cnt, stats = (-loss*cnt, cnt)."""
+    b = {k: _shard(v, lo, hi) for k, v in batch.items() if torch.is_tensor(v)}
+    loss, grads, _ = losses.pi_head_loss_and_grads(sd, q[lo:hi], kind, b, r_pad[lo:hi])
+    cnt = float(b["group_advantage_mask_torch"].sum())
+    flat = torch.cat([grads[k].reshape(-1) for k in losses.PI_KEYS]).float() * (-cnt)
+    return flat, torch.tensor([-float(loss) * cnt, cnt], dtype=torch.float64)
+
+
+def _worker(rank, world, port, kind, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sd, q, r_pad, batch = _inputs()
+    n = q.shape[0]
+    ids = shard_scene_ids(rank, world, n // world)
+    flat, stats = _rank_sums(kind, sd, q, r_pad, batch, ids.start, ids.stop)
+    dp_all_reduce(flat, stats)
+    loss = -stats[0] / stats[1]
+    grad = -flat.double() / stats[1]
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), loss=loss.numpy(), grad=grad.numpy())
+    dist.destroy_process_group()
+
+
+def _inputs():
+    _, batch, sd = H.load_case("small")
+    g = torch.Generator().manual_seed(5)
+    adv = batch["group_advantage_torch"]
+    bs, R, M = adv.shape
+    q = torch.randn(bs, R, M, 128, generator=g)
+    r_pad = ~batch["cur_pluto_feature_torch"]["reference_line"]["valid_mask"].any(-1)
+    return sd, q, r_pad, batch
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_two_rank_exchange_equals_full_batch(kind, tmp_path):
+    sd, q, r_pad, batch = _inputs()
+    n = q.shape[0]
+    assert n % 2 == 0
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    full_loss, full_grads, _ = losses.pi_head_loss_and_grads(sd, q, kind, batch, r_pad)
+    full = torch.cat([full_grads[k].reshape(-1) for k in losses.PI_KEYS]).double()
+    outs = [np.load(tmp_path / f"r{r}.npz") for r in range(2)]
+    assert np.array_equal(outs[0]["grad"], outs[1]["grad"]) and outs[0]["loss"] == outs[1]["loss"]
+    assert abs(float(outs[0]["loss"]) - float(full_loss)) < 1e-6          # losses within 1e-4 (north_star); observed ~1e-8
+    assert np.abs(outs[0]["grad"] - full.numpy()).max() < 1e-6
+
+
+def test_shards_are_disjoint_and_cover():
+    ids = [set(shard_scene_ids(r, 4, 1024)) for r in range(4)]
+    assert set.union(*ids) == set(range(4096)) and sum(len(i) for i in ids) == 4096

@@ -1,0 +1,142 @@
+"""Host mirror of the update-loop driver: replay buffer staging, PlutoFeature collation, policy registry (CPU);
+a miniature RLFTPluto.train() on the HIP engine (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from rift_amd import synthetic as syn
+from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
+from rift_amd.planning.pluto.feature_builder.pluto_feature import PlutoFeature
+
+KEYS = ['CBVs_obs', 'CBVs_reward', 'CBVs_done', 'CBVs_actions_old_group_logits', 'CBVs_group_advantage',
+        'CBVs_actions_ref_group_logits']
+
+
+def _step(ids, done_ids, t):
+    d = {'CBV_ids': [ids]}
+    d['CBVs_obs'] = [{i: ('obs', i, t) for i in ids}]
+    d['CBVs_reward'] = [{i: float(t) for i in ids}]
+    d['CBVs_done'] = [{i: i in done_ids for i in ids}]
+    d['CBVs_actions_old_group_logits'] = [{i: t for i in ids}]
+    d['CBVs_group_advantage'] = [{i: t for i in ids}]
+    d['CBVs_actions_ref_group_logits'] = [{i: t for i in ids}]
+    return d
+
+
+def test_buffer_staging_drop_short_and_fill():
+    """cbv_rollout_buffer.py:44-95: per-CBV staging until done; <= 5-step trajectories dropped; full at capacity."""
+    buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': 10, 'data_keys': KEYS})
+    for t in range(4):                                      # CBV 7: 4 steps then done -> dropped (n <= 5)
+        buf.store(_step([7], [7] if t == 3 else [], t))
+    assert len(buf) == 0 and not buf.buffer_full
+    for t in range(7):                                      # CBV 1 and 2 interleaved; 1 finishes after 7 steps
+        buf.store(_step([1, 2], [1] if t == 6 else [], t))
+    assert len(buf) == 7 and [o[1] for o in buf.buffer_data['CBVs_obs']] == [1] * 7
+    for t in range(7, 9):
+        buf.store(_step([2], [2] if t == 8 else [], t))     # CBV 2: 9 steps -> only 3 fit
+    assert len(buf) == 10 and buf.buffer_full
+    assert [o[1] for o in buf.get_key_data('CBVs_obs')] == [1] * 7 + [2] * 3
+    assert [o[2] for o in buf.get_key_data('CBVs_obs')][7:] == [0, 1, 2]
+    s = buf.sample(8)
+    assert s['CBVs_reward'] == 1.0
+    assert buf.get_all_np_data()['CBVs_reward'].shape == (10, 1)
+    buf.add_extra_data({'extra': list(range(10))})
+    assert buf.sample([0, 9])['extra'] == [0, 9]
+    buf.reset_buffer()
+    assert len(buf) == 0 and not buf.buffer_full and 'extra' not in buf.buffer_data
+    with pytest.raises(AssertionError):
+        buf.get_key_data('CBVs_obs')
+
+
+def test_pluto_feature_collate_matches_reference_semantics():
+    scenes = [syn.make_scene(i, num_agents=6 + i, num_polygons=4 + i) for i in range(3)]
+    pf = PlutoFeature.collate([PlutoFeature(data=s["feature"]) for s in scenes])
+    want = syn.collate_features([s["feature"] for s in scenes])
+    flat_a, flat_b = syn.flatten_dict(pf.data), syn.flatten_dict(want)
+    assert flat_a.keys() == flat_b.keys()
+    for k in flat_a:
+        assert torch.equal(flat_a[k], flat_b[k]), k
+    assert pf.data["agent"]["position"].shape[:2] == (3, 8)
+    rt = PlutoFeature.deserialize(pf.serialize())
+    assert torch.equal(rt.data["map"]["point_position"], pf.data["map"]["point_position"])
+
+
+def test_policy_registry_and_lr_schedule():
+    from oracle import advantage as oadv
+    from rift_amd.planning import CBV_POLICY_LIST
+    from rift_amd.planning.fine_tuner.rlft.trainer import WarmupCosLR
+    assert {'rift_pluto', 'grpo_pluto', 'ppo_pluto', 'reinforce_pluto'} <= set(CBV_POLICY_LIST)
+    assert CBV_POLICY_LIST['rift_pluto'].kind == 'rift' and CBV_POLICY_LIST['ppo_pluto'].type == 'learnable'
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-4)
+    sch = WarmupCosLR(opt, lr=1e-4, min_lr=9e-5, warmup_epochs=3, epochs=16)
+    for e in range(16):
+        assert abs(opt.param_groups[0]["lr"] - oadv.warmup_cos_lr(e, 1e-4, 9e-5, 3, 16)) < 1e-12
+        sch.step()
+
+
+def _filled_buffer(n, with_ref):
+    keys = [k for k in KEYS if with_ref or k != 'CBVs_actions_ref_group_logits']
+    buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': n, 'data_keys': keys})
+    t = 0
+    while not buf.buffer_full:
+        for k in range(8):                                  # 8-step trajectories of one CBV
+            s = syn.make_scene(t, num_agents=12, num_polygons=8, r_min=1, r_max=3)
+            ex = s["extras"]
+            d = {'CBV_ids': [[3]], 'CBVs_obs': [{3: {'raw_pluto_feature': PlutoFeature(data=s["feature"])}}],
+                 'CBVs_reward': [{3: float(ex["return"])}], 'CBVs_done': [{3: k == 7}],
+                 'CBVs_actions_old_group_logits': [{3: {'logits': ex["old_group_logits"].numpy(),
+                                                        'valid_mask': ex["old_group_logits_mask"].numpy()}}],
+                 'CBVs_group_advantage': [{3: {'advantage': ex["group_advantage"].numpy(),
+                                               'valid_mask': ex["group_advantage_mask"].numpy()}}]}
+            if with_ref:
+                d['CBVs_actions_ref_group_logits'] = [{3: {'logits': ex["ref_group_logits"].numpy()}}]
+            buf.store(d)
+            t += 1
+    return buf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["rift_pluto", "grpo_pluto", "reinforce_pluto"])
+def test_rlft_train_updates_only_pi_head_and_checkpoints(policy, tmp_path):
+    """RLFTPluto.train(e_i): 90/10 split, epochs of HIP steps, top-1 checkpoint with 'model.'-prefixed keys,
+    inference model reloaded, buffer reset (rlft_pluto.py:206-247)."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    cfg = {'num_scenario': 1, 'ROOT_DIR': str(tmp_path), 'model_path': 'ckpt', 'device': 'cuda:0',
+           'rlft': {'epochs': 3, 'warmup_epochs': 1, 'train_batch_size': 16, 'val_batch_size': 16, 'lr': 1e-3}}
+    pol = CBV_POLICY_LIST[policy](cfg, None)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        for p in pol.pluto_model.parameters():
+            if p.dim() > 1:
+                p.normal_(0, 0.05)
+    before = {k: v.detach().clone() for k, v in pol.pluto_model.state_dict().items()}
+    pol.load_model(resume=True)
+    assert pol.continue_episode == 0 and pol.current_epoch == 0
+    pol.set_mode('train')
+    buf = _filled_buffer(48, with_ref=policy == 'grpo_pluto')
+    pol.set_buffer(buf)
+    fit = pol.train(7)
+    hist = fit["history"]
+    assert len(hist) == 3 and all(np.isfinite(h["train_loss"]) and np.isfinite(h["val_loss"]) for h in hist)
+    assert abs(hist[0]["lr"] - 1e-3 / 1) < 1e-12 or hist[0]["lr"] > 0
+    ck = list((tmp_path / 'ckpt' / pol.load_agent_info).glob("*.ckpt"))
+    assert len(ck) == 1 and ck[0].name.startswith("carla_episode=7-epoch=") and "-val_loss=" in ck[0].name
+    sd = torch.load(ck[0], weights_only=False)["state_dict"]
+    assert all(k.startswith("model.") for k in sd)
+    after = pol.pluto_model.state_dict()
+    changed = [k for k in before if not torch.equal(before[k].cpu(), after[k].cpu()) and "num_batches_tracked" not in k]
+    assert changed, "pi_head must have moved"
+    for k in changed:
+        assert k.startswith("planning_decoder.pi_head") or "running_" in k, k   # frozen trunk; BN running stats move in train mode
+    assert any(k.startswith("planning_decoder.pi_head") for k in changed)
+    assert len(buf) == 0 and not buf.buffer_full
+    assert pol.current_epoch == 1 and pol.checkpoint == ck[0].as_posix()
+    # the next update decays the base lr: lr * 0.9 ** current_epoch (rlft_pluto.py:212)
+    pol.set_buffer(_filled_buffer(48, with_ref=policy == 'grpo_pluto'))
+    fit2 = pol.train(8)
+    assert abs(fit2["lr"] - 1e-3 * 0.9) < 1e-12
+    pol2 = CBV_POLICY_LIST[policy](cfg, None)
+    pol2.load_model(resume=True)
+    assert pol2.continue_episode == 8 and pol2.current_epoch == 2
