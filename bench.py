@@ -146,6 +146,19 @@ def main():
     dt = float(tmax.item())
     final_loss = float(loss.item())
 
+    # ---- companion figure: the same K steps with EVERY output of PlanningModel.forward computed (trajectory / prediction /
+    # ref-free heads -- outputs the RLFT losses never read; the reference's training_step computes them)
+    model.need_traj = True
+    for i in range(2):
+        step(i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt_all = time.perf_counter() - t1
+    model.need_traj = False
+
     # ---- roofline leg: per-launch HIP events on the launch stream (separate short pass, rank 0)
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -185,6 +198,8 @@ def main():
                        "parallelism": f"dp{world}", "train_mode": "dropout+droppath+state-dropout, BN batch stats",
                        "outputs": "probability+hidden (trajectory heads are dead work for the RIFT loss)"},
             "whole_step_mfma_frac": scenes_per_sec / world * FLOPS_PER_SCENE / (PEAK_BF16_TFLOPS * 1e12),
+            "all_outputs": {"ms_per_step": dt_all / args.steps * 1e3, "value": args.steps / dt_all * BATCH * world,
+                            "note": "this rank's rate x N with the dead trajectory/prediction/ref-free heads also computed"},
             "final_loss": final_loss, "replay_gen_s": round(t_gen, 2), "replay_hbm_mb": round(replay.nbytes() / 1e6, 1),
         }
         if roof is not None:

@@ -146,6 +146,7 @@ class RLFTTrainer:
         self._prob = None
         self._hidden = None
         self._argmax = None
+        self._traj, self._A = None, 0
         self.step_count = 0
         self.training = True
 
@@ -158,6 +159,13 @@ class RLFTTrainer:
             self._argmax = torch.zeros(bs, 2, dtype=torch.int64, device=dev)
             self.out.probability, self.out.hidden = self._prob.data_ptr(), self._hidden.data_ptr()
             self.lo.argmax_rm = self._argmax.data_ptr()
+            self._traj = None
+        if getattr(self.model, "need_traj", False) and self._traj is None:
+            # every output of PlanningModel.forward (pluto_model.py:167-223), as the reference's training_step computes them
+            dev, A = self.engine.device, self._A
+            self._traj = (torch.empty(bs, R, 12, 80, 6, device=dev), torch.empty(bs, max(A - 1, 0), 80, 6, device=dev),
+                          torch.empty(bs, 80, 4, device=dev))
+            self.out.trajectory, self.out.prediction, self.out.ref_free_trajectory = (t.data_ptr() for t in self._traj)
         return self._prob
 
     def set_loss_inputs(self, b: Dict[str, torch.Tensor]):
@@ -176,8 +184,10 @@ class RLFTTrainer:
                      backward: bool = True, flags_extra: int = 0):
         """forward + objective (+ pi_head backward into .grad).  Returns the device f64 loss scalar."""
         eng = self.engine
+        self._A = fb.A
         self._outputs(fb.bs, fb.R)
-        flags = (_ffi.F_TRAIN if train else 0) | (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | \
+        flags = (_ffi.F_TRAIN if train else 0) | (_ffi.F_NEED_TRAJ if getattr(self.model, "need_traj", False) else 0) | \
+                 (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | \
                 (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0) | flags_extra
         self.step_count += 1
         eng.forward_raw(fb, self.out, flags, self.step_count)
