@@ -50,3 +50,15 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_ffi.RiftLossIn) == 72
     assert ctypes.sizeof(_ffi.RiftLossOut) == 80
     assert ctypes.sizeof(_ffi.RiftTensorDesc) == 8 + 8 + 8 + 8 + 32
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under rift_amd/ may import or reference it."""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1] / "rift_amd"
+    offenders = []
+    for f in list(root.rglob("*.py")) + list(root.rglob("*.h")) + list(root.rglob("*.hip")):
+        txt = f.read_text()
+        if "import oracle" in txt or "from oracle" in txt or "oracle/" in txt:
+            offenders.append(str(f))
+    assert not offenders, offenders
