@@ -19,6 +19,7 @@
 #include "nat_fused.h"
 #include "enc_fused.h"
 #include "dec_fused.h"
+#include "pe_fused.h"
 #include "rollout.h"
 
 using namespace rift;
@@ -63,6 +64,7 @@ struct RiftCtx {
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
   int* dec_idx = nullptr; bool dec_fused = true;
+  bool pe_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -293,6 +295,12 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR((gemm_rows_kernel<false, 2, 6, 2, 2>));
   SETATTR((gemm_rows_kernel<false, 4, 4, 1, 4>));
 #undef SETATTR
+#define SETATTR_N(K, N) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(N)))
+  SETATTR_N(pe_mid_kernel<20>, PE_MID_LDS);   // these kernels also hold a few hundred bytes of static LDS
+  SETATTR_N(pe_mid_kernel<120>, PE_MID_LDS);
+  SETATTR_N(pe_out_kernel<20>, PE_OUT_LDS);
+  SETATTR_N(pe_out_kernel<120>, PE_OUT_LDS);
+#undef SETATTR_N
   return RIFT_OK;
 }
 
@@ -348,9 +356,54 @@ void batchnorm_affine(Fwd& f, const float* X, int rows, int C, const uint8_t* va
          f.bn_update ? 1 : 0, 1e-5f, *scale, *shift);
 }
 
+// PointsEncoder, fused three-pass form (pe_fused.h); bf16 mode, n in {20, 120}
+float* points_encoder_fused(Fwd& f, const float* F, int Cin, int groups, int n, const uint8_t* valid, const std::string& p) {
+  RiftCtx* c = f.c;
+  const int rows = groups * n;
+  const int ntiles = cdiv(rows, 120);
+  PeP q; memset(&q, 0, sizeof(q));
+  q.F = F; q.Cin = Cin; q.valid = valid; q.rows = rows; q.ntiles = ntiles;
+  const PW &w1 = c->pw[p + ".first_mlp.0"], &w2 = c->pw[p + ".first_mlp.3"], &w3a = c->pw[p + ".second_mlp.0.feat"],
+           &w3b = c->pw[p + ".second_mlp.0.pool"], &w4 = c->pw[p + ".second_mlp.3"];
+  q.w1 = (const unsigned short*)w1.bf; q.w2 = (const unsigned short*)w2.bf; q.w3a = (const unsigned short*)w3a.bf;
+  q.w3b = (const unsigned short*)w3b.bf; q.w4 = (const unsigned short*)w4.bf;
+  q.b1 = w1.bias; q.b2 = w2.bias; q.b3 = w3a.bias; q.b4 = w4.bias;
+  float* s1 = A_alloc<float>(c, 128); float* t1 = A_alloc<float>(c, 128);
+  float* s2 = A_alloc<float>(c, 256); float* t2 = A_alloc<float>(c, 256);
+  q.s1 = s1; q.t1 = t1; q.s2 = s2; q.t2 = t2;
+  q.part1 = A_alloc<float>(c, (size_t)2 * 128 * ntiles);
+  q.part2 = A_alloc<float>(c, (size_t)2 * 256 * ntiles);
+  q.cnt = A_alloc<int>(c, ntiles);
+  q.Fmid = A_alloc<unsigned short>(c, (size_t)rows * 256);
+  q.gp = A_alloc<float>(c, (size_t)groups * 256);
+  q.out = A_alloc<float>(c, (size_t)groups * 128);
+  q.do_stats = f.train ? 1 : 0;
+  auto finalize = [&](const std::string& name, int C, const float* part, float* sc, float* sh) {
+    const Param* nb = find(c, name + ".num_batches_tracked");
+    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(cdiv(C, 4)), dim3(256), 0, part, (const int*)q.cnt, ntiles, C,
+           fptr(c, name + ".weight"), fptr(c, name + ".bias"), (float*)fptr(c, name + ".running_mean"),
+           (float*)fptr(c, name + ".running_var"), nb ? (long long*)nb->data : (long long*)nullptr, f.train ? 1 : 0,
+           f.bn_update ? 1 : 0, 1e-5f, sc, sh);
+  };
+  if (f.train) {
+    c->prof_flops = 2.0 * rows * 128.0 * Cin;
+    launch(c, "pe_stats1_kernel", pe_stats1_kernel, dim3(ntiles), dim3(256), 0, q);
+  }
+  finalize(p + ".first_mlp.1", 128, q.part1, s1, t1);
+  c->prof_flops = 2.0 * rows * (128.0 * Cin + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;
+  if (n == 20) launch(c, "pe_mid_kernel", pe_mid_kernel<20>, dim3(ntiles), dim3(512), (size_t)PE_MID_LDS, q);
+  else launch(c, "pe_mid_kernel", pe_mid_kernel<120>, dim3(ntiles), dim3(512), (size_t)PE_MID_LDS, q);
+  finalize(p + ".second_mlp.1", 256, q.part2, s2, t2);
+  c->prof_flops = 2.0 * rows * (256.0 * 256 + 256.0 * 128);
+  if (n == 20) launch(c, "pe_out_kernel", pe_out_kernel<20>, dim3(ntiles), dim3(512), (size_t)PE_OUT_LDS, q);
+  else launch(c, "pe_out_kernel", pe_out_kernel<120>, dim3(ntiles), dim3(512), (size_t)PE_OUT_LDS, q);
+  return q.out;
+}
+
 // PointsEncoder (embedding.py:271-296): F (groups*n, Cin) -> (groups, 128)
 float* points_encoder(Fwd& f, const float* F, int Cin, int groups, int n, const uint8_t* valid, const std::string& p) {
   RiftCtx* c = f.c;
+  if (!f.fp32 && c->pe_fused && (n == 20 || n == 120) && Cin <= 32) return points_encoder_fused(f, F, Cin, groups, n, valid, p);
   const int rows = groups * n;
   float* H1 = A_alloc<float>(c, (size_t)rows * 128);
   gemm(c, mk(F, Cin, rows, c->pw[p + ".first_mlp.0"], H1, 128), c->pw[p + ".first_mlp.0"], f.fp32);
@@ -583,6 +636,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   launch(c, "map_feature_kernel", map_feature_kernel, dim3(cdiv((long long)nP * 20, 256)), dim3(256), 0, B->map_point_position, B->map_point_vector,
          B->map_point_orientation, B->map_polygon_center, nP, F10);
   float* poly = points_encoder(f, F10, 10, nP, 20, B->map_valid_mask, "map_encoder.polygon_encoder");
+  tap(c, "poly_pe", poly, (int64_t)nP * 128);
   float* speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
   launch(c, "polygon_token_kernel", polygon_token_kernel, dim3(cdiv((long long)nP * 128, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
          B->map_polygon_on_route, B->map_polygon_tl_status, B->map_polygon_has_speed_limit, (const float*)speed_emb,
@@ -679,6 +733,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
   launch(c, "refline_mask_kernel", refline_mask_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_valid_mask, nL, r_kpm);
   float* r_emb = points_encoder(f, F6, 6, nL, 120, B->ref_valid_mask, PD + ".r_encoder");
+  tap(c, "r_pe", r_emb, (int64_t)nL * 128);
   float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
   launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
   float* RPE = fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1);
@@ -858,6 +913,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_UNFUSED"); c->nat_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_DEC_UNFUSED"); c->dec_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_PE_UNFUSED"); c->pe_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   int rc = set_lds_attrs(c);

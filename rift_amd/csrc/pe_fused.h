@@ -1,0 +1,457 @@
+// Fused PointsEncoder for gfx950 (embedding.py:254-296: first_mlp Linear-BN-ReLU-Linear -> max-pool over the points
+// of a polyline -> concat -> second_mlp Linear-BN-ReLU-Linear -> max-pool), used for the map polygons
+// (map_encoder.py:42-44, 20 points each) and the reference lines (planning_decoder.py:143-147, 120 points each).
+//
+// BatchNorm's batch statistics are a dependency on EVERY valid point of the minibatch, so the encoder is cut
+// into three passes around the two statistics; inside a pass a tile of 120 point rows (6 polygons or 1 reference
+// line) stays in LDS and nothing but the bf16 256-wide intermediate `f` goes to HBM, once:
+//   pass A  pe_stats1_kernel : h1 = x W1^T + b1                         -> per-tile sum / sum of squares (BN1)
+//   pass B  pe_mid_kernel    : h1 -> BN1 -> ReLU -> f = . W2^T + b2 (invalid rows 0) -> pooled = max over points
+//                              gp = pooled W3b^T + b3 ;  g = f W3a^T + gp   -> per-tile sum / sum of squares (BN2)
+//                              writes f (bf16) and gp (fp32, one row per polyline)
+//   pass C  pe_out_kernel    : g recomputed from f, gp -> BN2 -> ReLU -> o = . W4^T + b4 (invalid rows 0)
+//                              -> max over points -> out
+// `g` (rows x 256 fp32, the largest intermediate) never exists in memory: recomputing its K=256 contraction on the
+// MFMA pipe is cheaper than one HBM round trip.  Storing f as bf16 loses nothing: its only consumers are bf16 MFMA
+// operands and a max-pool (rounding is monotonic, so max(round(f)) = round(max(f))).
+// All contractions are issued with the weight fragment as the MFMA A operand (see enc_fused.h): a lane holds four
+// consecutive output channels of one point row.
+#pragma once
+#include "common.h"
+
+namespace rift {
+
+struct PeP {
+  const float* F; int Cin;              // (rows, Cin) fp32 point features, Cin <= 32
+  const uint8_t* valid;                 // (rows) 1 = valid point
+  int rows, ntiles;                     // tile t covers rows [120 t, 120 t + 120)
+  const unsigned short *w1, *w2, *w3a, *w3b, *w4;   // bf16 [128][32] [256][128] [256][256] [256][256] [128][256]
+  const float *b1, *b2, *b3, *b4;
+  const float *s1, *t1, *s2, *t2;       // BatchNorm folded to y = x * s + t
+  float* part1;                         // [2][128][ntiles] tile sums of h1, h1^2 over valid rows
+  float* part2;                         // [2][256][ntiles] tile sums of g, g^2
+  int* cnt;                             // [ntiles] valid rows per tile
+  unsigned short* Fmid;                 // (rows, 256) bf16
+  float* gp;                            // (rows / NPTS, 256)
+  float* out;                           // (rows / NPTS, 128)
+  int do_stats;
+};
+
+template <int KS, int NTW>
+struct PFrags { bf16x8 f[KS][NTW]; };
+
+// weight fragments of n-tiles (j * NW + wave), j < NTW, k in [k0, k0 + 32 KS)
+template <int NW, int KS, int NTW>
+__device__ __forceinline__ void p_load_w(PFrags<KS, NTW>& B, const unsigned short* W, int ldw, int k0, int wave, int l15, int l4) {
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      B.f[ks][j] = *reinterpret_cast<const bf16x8*>(W + (size_t)((j * NW + wave) * 16 + l15) * ldw + k0 + ks * 32 + l4 * 8);
+}
+
+// acc[mt][j][r] (+)= sum_k A[mt*16 + l15][k0 + k] * W[ntile*16 + 4*l4 + r][k0 + k]
+template <int MT, int KS, int NTW>
+__device__ __forceinline__ void p_mma(f32x4 (&acc)[MT][NTW], const unsigned short* A, int lda, int k0, const PFrags<KS, NTW>& B,
+                                      int l15, int l4) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + l15) * lda + k0 + ks * 32 + l4 * 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+  }
+}
+
+template <int MT, int NTW>
+__device__ __forceinline__ void p_zero(f32x4 (&acc)[MT][NTW]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+#define PE_ROWS 128
+#define PE_USED 120
+#define PE_XS 40
+#define PE_HS 136
+#define PE_FS 264
+
+// stage the tile's point features as bf16 [128][PE_XS] (k >= Cin and unused rows zero) and the row flags
+// (0 = not a row of this tile, 1 = valid point, 2 = invalid point: an all-zero row that still takes part in the max)
+template <int NT>
+__device__ __forceinline__ int pe_stage_x(const PeP& p, int tile, unsigned short* xin, unsigned char* sval, int tid) {
+  const int row0 = tile * PE_USED;
+  int nvalid = 0;
+  for (int r = tid; r < PE_ROWS; r += NT) {
+    unsigned char fl = 0;
+    if (r < PE_USED && row0 + r < p.rows) fl = p.valid[row0 + r] ? 1 : 2;
+    sval[r] = fl;
+    nvalid += fl == 1;
+  }
+  for (int i = tid; i < PE_ROWS * 32; i += NT) {
+    const int r = i >> 5, k = i & 31;
+    float v = 0.f;
+    if (k < p.Cin && r < PE_USED && row0 + r < p.rows) v = p.F[(size_t)(row0 + r) * p.Cin + k];
+    xin[r * PE_XS + k] = f2bf(v);
+  }
+  return __syncthreads_count(nvalid);   // also the barrier after staging
+}
+
+// per-channel sum and sum of squares over the valid rows of the tile: acc layout as p_mma; every wave owns its columns
+template <int MT, int NTW, int NW, class F>
+__device__ __forceinline__ void pe_tile_stats(const f32x4 (&acc)[MT][NTW], const unsigned char* sval, F&& value, float* part, int C,
+                                              int ntiles, int tile, int wave, int l15, int l4) {
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int col = (j * NW + wave) * 16 + l4 * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 16 + l15;
+      const bool ok = sval[row] == 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ok ? value(acc[mt][j][r], row, col + r) : 0.f;
+        s[r] += v; q[r] += v * v;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = sum16(s[r]); q[r] = sum16(q[r]); }
+    if (l15 == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        part[(size_t)(col + r) * ntiles + tile] = s[r];
+        part[(size_t)(C + col + r) * ntiles + tile] = q[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass A: BatchNorm-1 statistics of h1 = x W1^T + b1 (bf16 MFMA, exactly the values pass B recomputes)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pe_stats1_kernel(PeP p) {
+  __shared__ __attribute__((aligned(16))) unsigned short xin[PE_ROWS * PE_XS];
+  __shared__ unsigned char sval[PE_ROWS];
+  __shared__ float b1s[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int tile = blockIdx.x;
+  PFrags<1, 2> W1;
+  p_load_w<4, 1, 2>(W1, p.w1, 32, 0, wave, l15, l4);
+  if (tid < 128) b1s[tid] = p.b1[tid];
+  const int nv = pe_stage_x<256>(p, tile, xin, sval, tid);
+  if (tid == 0) p.cnt[tile] = nv;
+  if (nv == 0) {
+    for (int i = tid; i < 256; i += 256) p.part1[(size_t)i * p.ntiles + tile] = 0.f;
+    return;
+  }
+  f32x4 acc[8][2];
+  p_zero(acc);
+  p_mma<8, 1, 2>(acc, xin, PE_XS, 0, W1, l15, l4);
+  pe_tile_stats<8, 2, 4>(acc, sval, [&](float a, int, int c) { return a + b1s[c]; }, p.part1, 128, p.ntiles, tile, wave, l15, l4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass B
+// ---------------------------------------------------------------------------------------------------------------
+#define PE_MID_LDS (PE_ROWS * PE_XS * 2 + PE_ROWS * PE_HS * 2 + PE_ROWS * PE_FS * 2 + 16 * PE_FS * 2 + 8 * 256 * 4 + 1024 * 4 + PE_ROWS)
+
+template <int NPTS>
+__global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
+  constexpr int MT = 8, GPT = PE_USED / NPTS, NW = 8;
+  constexpr int SPL = GPT >= 4 ? 1 : 4;            // row splits per polyline for the max-pool (units = GPT * SPL >= 4)
+  constexpr int UNITS = GPT * SPL, RPU = NPTS / SPL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* xin = reinterpret_cast<unsigned short*>(smem_raw);
+  unsigned short* h1 = xin + PE_ROWS * PE_XS;
+  unsigned short* fl = h1 + PE_ROWS * PE_HS;
+  unsigned short* pool = fl + PE_ROWS * PE_FS;                     // [16][PE_FS] bf16 (rows >= GPT zero)
+  float* gpl = reinterpret_cast<float*>(pool + 16 * PE_FS);        // [8][256]: gp of the tile's polylines; max-pool scratch before
+  float* par = gpl + 8 * 256;                                      // b1 128 | s1 128 | t1 128 | b2 256 | b3 256
+  unsigned char* sval = reinterpret_cast<unsigned char*>(par + 1024);
+  constexpr int P_B1 = 0, P_S1 = 128, P_T1 = 256, P_B2 = 384, P_B3 = 640;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int tile = blockIdx.x, row0 = tile * PE_USED;
+
+  PFrags<1, 1> W1;
+  PFrags<4, 2> Wa, Wb;
+  p_load_w<NW, 1, 1>(W1, p.w1, 32, 0, wave, l15, l4);
+  p_load_w<NW, 4, 2>(Wa, p.w2, 128, 0, wave, l15, l4);
+  for (int e = tid; e < 896; e += 512) {
+    const float* src = e < 128 ? p.b1 + e : e < 256 ? p.s1 + (e - 128) : e < 384 ? p.t1 + (e - 256) : e < 640 ? p.b2 + (e - 384) : p.b3 + (e - 640);
+    par[e] = *src;
+  }
+  for (int i = tid; i < 16 * PE_FS / 2; i += 512) reinterpret_cast<unsigned int*>(pool)[i] = 0u;
+  const int nv = pe_stage_x<512>(p, tile, xin, sval, tid);
+  if (nv == 0) {   // no valid point: f = 0, gp unused, zero statistics
+    if (p.do_stats) for (int i = tid; i < 512; i += 512) p.part2[(size_t)i * p.ntiles + tile] = 0.f;
+    return;
+  }
+
+  // ---- h1 = relu(bn1(x W1^T + b1)) -> LDS bf16
+  {
+    f32x4 acc[MT][1];
+    p_zero(acc);
+    p_mma<MT, 1, 1>(acc, xin, PE_XS, 0, W1, l15, l4);
+    const int col = wave * 16 + l4 * 4;
+    const float4 b = *reinterpret_cast<const float4*>(par + P_B1 + col), s = *reinterpret_cast<const float4*>(par + P_S1 + col),
+                 t = *reinterpret_cast<const float4*>(par + P_T1 + col);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      *reinterpret_cast<uint2*>(h1 + (mt * 16 + l15) * PE_HS + col) =
+          pack_bf16x4(fmaxf((acc[mt][0][0] + b.x) * s.x + t.x, 0.f), fmaxf((acc[mt][0][1] + b.y) * s.y + t.y, 0.f),
+                      fmaxf((acc[mt][0][2] + b.z) * s.z + t.z, 0.f), fmaxf((acc[mt][0][3] + b.w) * s.w + t.w, 0.f));
+  }
+  __syncthreads();
+
+  // ---- f = h1 W2^T + b2, invalid rows zero -> LDS bf16
+  {
+    f32x4 acc[MT][2];
+    p_zero(acc);
+    p_mma<MT, 4, 2>(acc, h1, PE_HS, 0, Wa, l15, l4);
+    p_load_w<NW, 4, 2>(Wa, p.w3b, 256, 0, wave, l15, l4);
+    p_load_w<NW, 4, 2>(Wb, p.w3b, 256, 128, wave, l15, l4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (j * NW + wave) * 16 + l4 * 4;
+      const float4 b = *reinterpret_cast<const float4*>(par + P_B2 + col);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + l15;
+        const bool ok = sval[row] == 1;
+        *reinterpret_cast<uint2*>(fl + row * PE_FS + col) =
+            ok ? pack_bf16x4(acc[mt][j][0] + b.x, acc[mt][j][1] + b.y, acc[mt][j][2] + b.z, acc[mt][j][3] + b.w) : make_uint2(0u, 0u);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- f -> HBM (bf16, 16 B per lane), and the per-polyline max over its points
+  for (int i = tid; i < PE_USED * 32; i += 512) {
+    const int r = i >> 5, c8 = (i & 31) * 8;
+    if (row0 + r < p.rows) *reinterpret_cast<uint4*>(p.Fmid + (size_t)(row0 + r) * 256 + c8) = *reinterpret_cast<const uint4*>(fl + r * PE_FS + c8);
+  }
+  {
+    const int cp = (tid & 127) * 2, sub = tid >> 7;
+    for (int u = sub; u < UNITS; u += 4) {
+      const int g = u / SPL, r0 = g * NPTS + (u % SPL) * RPU;
+      float m0 = -INFINITY, m1 = -INFINITY;
+      for (int r = r0; r < r0 + RPU; ++r) {
+        const unsigned int v = *reinterpret_cast<const unsigned int*>(fl + r * PE_FS + cp);
+        m0 = fmaxf(m0, __uint_as_float(v << 16));
+        m1 = fmaxf(m1, __uint_as_float(v & 0xffff0000u));
+      }
+      gpl[u * 256 + cp] = m0; gpl[u * 256 + cp + 1] = m1;
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) {
+      float m = gpl[g * SPL * 256 + tid];
+#pragma unroll
+      for (int s = 1; s < SPL; ++s) m = fmaxf(m, gpl[(g * SPL + s) * 256 + tid]);
+      pool[g * PE_FS + tid] = (unsigned short)(__float_as_uint(m) >> 16);   // already a bf16 value
+    }
+  }
+  __syncthreads();
+
+  // ---- gp = pooled W3b^T + b3 (one row per polyline)
+  {
+    f32x4 acc[1][2];
+    p_zero(acc);
+    p_mma<1, 4, 2>(acc, pool, PE_FS, 0, Wa, l15, l4);
+    p_mma<1, 4, 2>(acc, pool, PE_FS, 128, Wb, l15, l4);
+    p_load_w<NW, 4, 2>(Wa, p.w3a, 256, 0, wave, l15, l4);
+    p_load_w<NW, 4, 2>(Wb, p.w3a, 256, 128, wave, l15, l4);
+    if (l15 < GPT) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (j * NW + wave) * 16 + l4 * 4;
+        const float4 b = *reinterpret_cast<const float4*>(par + P_B3 + col);
+        const float4 v = make_float4(acc[0][j][0] + b.x, acc[0][j][1] + b.y, acc[0][j][2] + b.z, acc[0][j][3] + b.w);
+        *reinterpret_cast<float4*>(gpl + l15 * 256 + col) = v;
+        const int grp = tile * GPT + l15;
+        if ((size_t)grp * NPTS < (size_t)p.rows) *reinterpret_cast<float4*>(p.gp + (size_t)grp * 256 + col) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- g = f W3a^T + gp: only its statistics are needed here
+  if (p.do_stats) {
+    f32x4 acc[MT][2];
+    p_zero(acc);
+    p_mma<MT, 4, 2>(acc, fl, PE_FS, 0, Wa, l15, l4);
+    p_mma<MT, 4, 2>(acc, fl, PE_FS, 128, Wb, l15, l4);
+    pe_tile_stats<MT, 2, NW>(acc, sval, [&](float a, int row, int c) { return a + gpl[(row / NPTS) * 256 + c]; }, p.part2, 256, p.ntiles,
+                             tile, wave, l15, l4);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass C
+// ---------------------------------------------------------------------------------------------------------------
+#define PE_OUT_LDS (PE_ROWS * PE_FS * 2 + 8 * 256 * 4 + 640 * 4 + PE_ROWS)
+
+template <int NPTS>
+__global__ __launch_bounds__(512) void pe_out_kernel(PeP p) {
+  constexpr int MT = 8, GPT = PE_USED / NPTS, NW = 8, OS = 132;
+  constexpr int SPL = GPT >= 4 ? 1 : 4;
+  constexpr int UNITS = GPT * SPL, RPU = NPTS / SPL;
+  static_assert(PE_ROWS * OS * 4 <= PE_ROWS * PE_FS * 2, "o tile must fit the f tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* fl = reinterpret_cast<unsigned short*>(smem_raw);      // f, then relu(bn2(g)) in place, then o (fp32)
+  float* ol = reinterpret_cast<float*>(smem_raw);
+  float* gpl = reinterpret_cast<float*>(fl + PE_ROWS * PE_FS);           // [8][256]
+  float* par = gpl + 8 * 256;                                            // s2 256 | t2 256 | b4 128
+  unsigned char* sval = reinterpret_cast<unsigned char*>(par + 640);
+  constexpr int P_S2 = 0, P_T2 = 256, P_B4 = 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int tile = blockIdx.x, row0 = tile * PE_USED;
+
+  PFrags<4, 2> Wa, Wb;
+  p_load_w<NW, 4, 2>(Wa, p.w3a, 256, 0, wave, l15, l4);
+  p_load_w<NW, 4, 2>(Wb, p.w3a, 256, 128, wave, l15, l4);
+  int nvalid = 0;
+  for (int r = tid; r < PE_ROWS; r += 512) {
+    unsigned char f = 0;
+    if (r < PE_USED && row0 + r < p.rows) f = p.valid[row0 + r] ? 1 : 2;
+    sval[r] = f;
+    nvalid += f == 1;
+  }
+  const int nv = __syncthreads_count(nvalid);
+  if (nv == 0) {   // every row zero -> the max is zero
+    for (int i = tid; i < GPT * 128; i += 512) {
+      const int grp = tile * GPT + i / 128;
+      if ((size_t)grp * NPTS < (size_t)p.rows) p.out[(size_t)grp * 128 + (i & 127)] = 0.f;
+    }
+    return;
+  }
+  for (int e = tid; e < 640; e += 512) par[e] = e < 256 ? p.s2[e] : e < 512 ? p.t2[e - 256] : p.b4[e - 512];
+  for (int i = tid; i < PE_ROWS * 32; i += 512) {
+    const int r = i >> 5, c8 = (i & 31) * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < PE_USED && row0 + r < p.rows) v = *reinterpret_cast<const uint4*>(p.Fmid + (size_t)(row0 + r) * 256 + c8);
+    *reinterpret_cast<uint4*>(fl + r * PE_FS + c8) = v;
+  }
+  for (int i = tid; i < 8 * 64; i += 512) {
+    const int g = i >> 6, c4 = (i & 63) * 4;
+    const int grp = tile * GPT + g;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < GPT && (size_t)grp * NPTS < (size_t)p.rows) v = *reinterpret_cast<const float4*>(p.gp + (size_t)grp * 256 + c4);
+    *reinterpret_cast<float4*>(gpl + g * 256 + c4) = v;
+  }
+  __syncthreads();
+
+  // ---- g = f W3a^T + gp -> relu(bn2(g)) written over f
+  {
+    f32x4 acc[MT][2];
+    p_zero(acc);
+    p_mma<MT, 4, 2>(acc, fl, PE_FS, 0, Wa, l15, l4);
+    p_mma<MT, 4, 2>(acc, fl, PE_FS, 128, Wb, l15, l4);
+    __syncthreads();    // every wave has read all of f
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (j * NW + wave) * 16 + l4 * 4;
+      const float4 s = *reinterpret_cast<const float4*>(par + P_S2 + col), t = *reinterpret_cast<const float4*>(par + P_T2 + col);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + l15;
+        const float4 gv = *reinterpret_cast<const float4*>(gpl + (row / NPTS < GPT ? row / NPTS : 0) * 256 + col);
+        *reinterpret_cast<uint2*>(fl + row * PE_FS + col) =
+            pack_bf16x4(fmaxf((acc[mt][j][0] + gv.x) * s.x + t.x, 0.f), fmaxf((acc[mt][j][1] + gv.y) * s.y + t.y, 0.f),
+                        fmaxf((acc[mt][j][2] + gv.z) * s.z + t.z, 0.f), fmaxf((acc[mt][j][3] + gv.w) * s.w + t.w, 0.f));
+      }
+    }
+  }
+  PFrags<4, 1> Wc, Wd;
+  p_load_w<NW, 4, 1>(Wc, p.w4, 256, 0, wave, l15, l4);
+  p_load_w<NW, 4, 1>(Wd, p.w4, 256, 128, wave, l15, l4);
+  __syncthreads();
+
+  // ---- o = . W4^T + b4, invalid rows zero (fp32 tile over the same LDS), then the max over each polyline
+  {
+    f32x4 acc[MT][1];
+    p_zero(acc);
+    p_mma<MT, 4, 1>(acc, fl, PE_FS, 0, Wc, l15, l4);
+    p_mma<MT, 4, 1>(acc, fl, PE_FS, 128, Wd, l15, l4);
+    __syncthreads();
+    const int col = wave * 16 + l4 * 4;
+    const float4 b = *reinterpret_cast<const float4*>(par + P_B4 + col);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 16 + l15;
+      const bool ok = sval[row] == 1;
+      *reinterpret_cast<float4*>(ol + row * OS + col) =
+          ok ? make_float4(acc[mt][0][0] + b.x, acc[mt][0][1] + b.y, acc[mt][0][2] + b.z, acc[mt][0][3] + b.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  {
+    const int c = tid & 127, sub = tid >> 7;
+    for (int u = sub; u < UNITS; u += 4) {
+      const int g = u / SPL, r0 = g * NPTS + (u % SPL) * RPU;
+      float m = -INFINITY;
+      for (int r = r0; r < r0 + RPU; ++r) m = fmaxf(m, ol[r * OS + c]);
+      if (SPL == 1) {
+        const int grp = tile * GPT + g;
+        if ((size_t)grp * NPTS < (size_t)p.rows) p.out[(size_t)grp * 128 + c] = m;
+      } else gpl[u * 128 + c] = m;
+    }
+  }
+  if (SPL > 1) {
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+      for (int g = 0; g < GPT; ++g) {
+        float m = gpl[g * SPL * 128 + tid];
+#pragma unroll
+        for (int s = 1; s < SPL; ++s) m = fmaxf(m, gpl[(g * SPL + s) * 128 + tid]);
+        const int grp = tile * GPT + g;
+        if ((size_t)grp * NPTS < (size_t)p.rows) p.out[(size_t)grp * 128 + tid] = m;
+      }
+    }
+  }
+}
+
+// BatchNorm finalize over tile partials laid out [2][C][nblk] (fp32 tile sums, fp64 accumulation; one wave per channel,
+// coalesced over the tiles).  Same semantics as bn_finalize_kernel.
+__global__ void bn_finalize_t_kernel(const float* __restrict__ part, const int* __restrict__ cnt, int nblk, int C,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                     float* running_var, long long* num_batches, int train, int update_running, float eps,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  float mean, var;
+  if (train) {
+    double s = 0.0, q = 0.0;
+    long long n = 0;
+    for (int b = lane; b < nblk; b += 64) { s += (double)part[(size_t)c * nblk + b]; q += (double)part[(size_t)(C + c) * nblk + b]; n += cnt[b]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    const double mu = s / (double)n;
+    double v = q / (double)n - mu * mu;
+    v = v < 0.0 ? 0.0 : v;
+    mean = (float)mu; var = (float)v;
+    if (update_running && lane == 0) {
+      const double unb = n > 1 ? v * (double)n / (double)(n - 1) : v;
+      running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean;
+      running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unb;
+      if (c == 0 && num_batches) *num_batches += 1;
+    }
+  } else { mean = running_mean[c]; var = running_var[c]; }
+  if (lane == 0) {
+    const float sc = gamma[c] * rsqrtf(var + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+  }
+}
+
+}  // namespace rift

@@ -276,6 +276,41 @@ def test_fused_encoder_matches_layerwise_path(ffi, monkeypatch):
     assert not torch.equal(outs["fused"], outs["layerwise"])
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_fused_points_encoder_matches_layerwise_path(ffi, monkeypatch, train):
+    """The three-pass fused PointsEncoder (map polygons, reference lines; BatchNorm batch statistics in train mode,
+    running statistics in eval mode) against the layer-wise GEMM / bn / max-pool path and the exact-fp32 path,
+    including the BatchNorm running-statistic update."""
+    gold, batch, sd = H.load_case("full")
+    data = batch["cur_pluto_feature_torch"]
+    outs = {}
+    bn_keys = [k for k in sd if ("polygon_encoder" in k or "r_encoder" in k) and "running_" in k]
+    assert len(bn_keys) == 8
+    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+        monkeypatch.setenv("RIFT_PE_UNFUSED", env)
+        eng = ffi.Engine("cuda:0")
+        live = {k: v.clone().cuda() for k, v in sd.items()}
+        eng.load_state_dict(live)
+        eng.prof_enable(True)
+        eng.forward(data, train=train, no_drop=True, fp32=fp32)
+        assert ("pe_mid_kernel" in eng.prof_report()) == (name == "fused")
+        eng.prof_enable(False)
+        outs[name] = (eng.tap("poly_pe").cpu().clone(), eng.tap("r_pe").cpu().clone(),
+                      {k: live[k].cpu().clone() for k in bn_keys})
+        eng.close()
+    for i in (0, 1):
+        scale = max(1.0, float(outs["fp32"][i].abs().max()))
+        assert err(outs["fused"][i], outs["fp32"][i]) < 3e-2 * scale
+        assert err(outs["fused"][i], outs["layerwise"][i]) < 3e-2 * scale   # (eval mode: same rounding points, bit-identical)
+    for k in bn_keys:   # running statistics: unchanged in eval mode, momentum-0.1 update of the same batch statistics in train mode
+        tol = 2e-2 * max(1.0, float(outs["fp32"][2][k].abs().max()))
+        assert err(outs["fused"][2][k], outs["fp32"][2][k]) < tol, k
+        if not train:
+            assert torch.equal(outs["fused"][2][k], sd[k]), k
+        else:
+            assert not torch.equal(outs["fused"][2][k], sd[k]), k
+
+
 @pytest.mark.parametrize("case", ["small", "full"])
 def test_fused_decoder_matches_layerwise_path(ffi, monkeypatch, case):
     """The fused planning-decoder kernel (4 layers, one workgroup per scene, incl. the r2r mask quirk on
