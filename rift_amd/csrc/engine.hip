@@ -20,6 +20,7 @@
 #include "enc_fused.h"
 #include "dec_fused.h"
 #include "pe_fused.h"
+#include "fourier_fused.h"
 #include "rollout.h"
 
 using namespace rift;
@@ -43,6 +44,8 @@ struct RiftCtx {
   std::unordered_map<std::string, Param> params;
   std::unordered_map<std::string, PW> pw;
   std::vector<void*> owned;          // packed weight allocations
+  struct WConst { float* p = nullptr; bool ready = false; };
+  std::unordered_map<std::string, WConst> wconst;   // activations that depend on (frozen) weights only, computed once per model load
   // activation arena (bump allocator, reset every forward)
   char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
   bool dry = false;
@@ -64,7 +67,7 @@ struct RiftCtx {
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
   int* dec_idx = nullptr; bool dec_fused = true;
-  bool pe_fused = true;
+  bool pe_fused = true; bool fo_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -133,6 +136,17 @@ void launch_gemm(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 gri
     label = c->prof_names.insert(tmp).first->c_str();
   }
   launch(c, label, kern, grid, block, shmem, g);
+}
+
+// Weight-only products (mode embeddings through q_proj / m2m in-projection, the ego query projection): input
+// independent, so they are computed by the first forward after rift_model_load and kept (per precision mode).
+// Returns the buffer and whether the caller must fill it now.
+float* wconst_get(RiftCtx* c, const std::string& key, size_t n, bool fp32, bool* fill) {
+  RiftCtx::WConst& w = c->wconst[key + (fp32 ? "#32" : "#16")];
+  if (!w.p) { if (hipMalloc((void**)&w.p, n * sizeof(float)) != hipSuccess) { w.p = nullptr; *fill = false; return nullptr; } c->owned.push_back(w.p); }
+  *fill = !w.ready && !c->dry;
+  if (!c->dry) w.ready = true;
+  return w.p;
 }
 
 const Param* find(RiftCtx* c, const std::string& name) {
@@ -207,6 +221,8 @@ int pack_mlp_layer(RiftCtx* c, const std::string& p) { TRY(pack_linear(c, p + ".
 int pack_fourier(RiftCtx* c, const std::string& p, int D) {
   for (int d = 0; d < D; ++d) {
     TRY(pack_linear(c, p + ".mlps." + std::to_string(d) + ".0"));
+    TRY(pack_cols(c, p + ".mlps." + std::to_string(d) + ".0.lo", p + ".mlps." + std::to_string(d) + ".0", 0, 128, true));     // fused kernel:
+    TRY(pack_cols(c, p + ".mlps." + std::to_string(d) + ".0.last", p + ".mlps." + std::to_string(d) + ".0", 128, 1, false));  // K = 128 + rank-1
     TRY(pack_linear(c, p + ".mlps." + std::to_string(d) + ".3"));
   }
   return pack_linear(c, p + ".to_out.2");
@@ -300,6 +316,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR_N(pe_mid_kernel<120>, PE_MID_LDS);
   SETATTR_N(pe_out_kernel<20>, PE_OUT_LDS);
   SETATTR_N(pe_out_kernel<120>, PE_OUT_LDS);
+  SETATTR_N(fourier_fused_kernel, FO_LDS);
 #undef SETATTR_N
   return RIFT_OK;
 }
@@ -316,8 +333,27 @@ void layernorm(Fwd& f, const float* X, int ldx, float* Y, int ldy, int rows, int
 }
 
 // FourierEmbedding (fourier_embedding.py:45-55): in (rows, D) -> out (rows, 128)
-float* fourier(Fwd& f, const float* in, int in_ld, int rows, int D, const std::string& p, int wrap_dim) {
+// add_to != nullptr: the embedding is added into that (rows, 128) buffer, which is returned
+float* fourier(Fwd& f, const float* in, int in_ld, int rows, int D, const std::string& p, int wrap_dim, float* add_to = nullptr) {
   RiftCtx* c = f.c;
+  if (!f.fp32 && c->fo_fused && D <= 3) {
+    FourierP q; memset(&q, 0, sizeof(q));
+    q.in = in; q.in_ld = in_ld; q.rows = rows; q.D = D; q.wrap_dim = wrap_dim; q.freqs = fptr(c, p + ".freqs.weight");
+    for (int d = 0; d < D; ++d) {
+      const std::string m = p + ".mlps." + std::to_string(d);
+      const PW &lo = c->pw[m + ".0.lo"], &last = c->pw[m + ".0.last"], &w3 = c->pw[m + ".3"];
+      q.w0[d] = (const unsigned short*)lo.bf; q.b0[d] = lo.bias; q.wl[d] = last.f32; q.wl_ld = last.Kp;
+      q.lng[d] = fptr(c, m + ".1.weight"); q.lnb[d] = fptr(c, m + ".1.bias");
+      q.w3[d] = (const unsigned short*)w3.bf; q.b3[d] = w3.bias;
+    }
+    q.og = fptr(c, p + ".to_out.0.weight"); q.ob = fptr(c, p + ".to_out.0.bias");
+    q.wo = (const unsigned short*)c->pw[p + ".to_out.2"].bf; q.bo = c->pw[p + ".to_out.2"].bias;
+    q.Y = add_to ? add_to : A_alloc<float>(c, (size_t)rows * 128);
+    q.accumulate = add_to ? 1 : 0;
+    c->prof_flops = 2.0 * rows * 128.0 * (D * (129.0 + 128.0) + 128.0);
+    launch(c, "fourier_fused_kernel", fourier_fused_kernel, dim3(cdiv(rows, FO_ROWS)), dim3(256), (size_t)FO_LDS, q);
+    return q.Y;
+  }
   float* FF = A_alloc<float>(c, (size_t)D * rows * 129);
   launch(c, "fourier_feature_kernel", fourier_feature_kernel, dim3(cdiv((long long)D * rows * 65, 256)), dim3(256), 0, in, in_ld, rows, D,
          fptr(c, p + ".freqs.weight"), wrap_dim, FF);
@@ -336,6 +372,10 @@ float* fourier(Fwd& f, const float* in, int in_ld, int rows, int D, const std::s
   GemmP g3 = mk(acc, 128, rows, c->pw[p + ".to_out.2"], out, 128);
   g3.pro = PRO_LN; g3.pg = fptr(c, p + ".to_out.0.weight"); g3.pb = fptr(c, p + ".to_out.0.bias"); g3.pro_relu = 1;
   gemm(c, g3, c->pw[p + ".to_out.2"], f.fp32);
+  if (add_to) {
+    launch(c, "add_inplace_kernel", add_inplace_kernel, dim3(cdiv((long long)rows * 128, 256)), dim3(256), 0, add_to, (const float*)out, (size_t)rows * 128);
+    return add_to;
+  }
   return out;
 }
 
@@ -607,8 +647,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
          (const float*)c->ego_w, (const float*)c->ego_b, fptr(c, EG + ".pos_embed"), bs, E);
   float* EKV = A_alloc<float>(c, (size_t)bs * 6 * 256);
   gemm(c, mk(E, 128, bs * 6, c->pw[EG + ".attn.kv"], EKV, 256), c->pw[EG + ".attn.kv"], f.fp32);
-  float* eq = A_alloc<float>(c, 128);
-  gemm(c, mk(fptr(c, EG + ".query"), 128, 1, c->pw[EG + ".attn.q"], eq, 128), c->pw[EG + ".attn.q"], f.fp32);
+  bool fill_eq;
+  float* eq = wconst_get(c, "ego_q", 128, f.fp32, &fill_eq);
+  if (fill_eq) gemm(c, mk(fptr(c, EG + ".query"), 128, 1, c->pw[EG + ".attn.q"], eq, 128), c->pw[EG + ".attn.q"], f.fp32);
   uint8_t* edrop = nullptr;
   if (f.drop) {
     edrop = A_alloc<uint8_t>(c, (size_t)bs * 6);
@@ -654,8 +695,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* pos = A_alloc<float>(c, (size_t)nT * 3);
   launch(c, "token_pos_kernel", token_pos_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, B->agent_position, B->agent_heading, T, B->map_polygon_center,
          B->static_position, B->static_heading, bs, A, Mp, S, pos);
-  float* PE = fourier(f, pos, 3, nT, 3, "pos_emb", 2);
-  launch(c, "add_inplace_kernel", add_inplace_kernel, dim3(cdiv((long long)nT * 128, 256)), dim3(256), 0, X, (const float*)PE, (size_t)nT * 128);
+  fourier(f, pos, 3, nT, 3, "pos_emb", 2, X);
   tap(c, "x_tokens", X, (int64_t)nT * 128);
 
   // ================= encoder blocks (transformer.py:73-94) =================
@@ -736,13 +776,13 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   tap(c, "r_pe", r_emb, (int64_t)nL * 128);
   float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
   launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
-  float* RPE = fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1);
-  launch(c, "add_inplace_kernel", add_inplace_kernel, dim3(cdiv((long long)nL * 128, 256)), dim3(256), 0, r_emb, (const float*)RPE, (size_t)nL * 128);
+  fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1, r_emb);
   tap(c, "r_emb", r_emb, (int64_t)nL * 128);
   float* Ra = A_alloc<float>(c, (size_t)nL * 128);
   gemm(c, mk(r_emb, 128, nL, c->pw[PD + ".q_proj.r"], Ra, 128), c->pw[PD + ".q_proj.r"], f.fp32);
-  float* Mb = A_alloc<float>(c, (size_t)M * 128);
-  gemm(c, mk(fptr(c, PD + ".m_emb"), 128, M, c->pw[PD + ".q_proj.m"], Mb, 128), c->pw[PD + ".q_proj.m"], f.fp32);
+  bool fill;
+  float* Mb = wconst_get(c, "Mb", (size_t)M * 128, f.fp32, &fill);
+  if (fill) gemm(c, mk(fptr(c, PD + ".m_emb"), 128, M, c->pw[PD + ".q_proj.m"], Mb, 128), c->pw[PD + ".q_proj.m"], f.fp32);
   float* Q = A_alloc<float>(c, (size_t)nQ * 128);
   launch(c, "build_q0_kernel", build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
 
@@ -768,8 +808,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       w.w_f1 = bf(p + ".ffn.0"); w.b_f1 = c->pw[p + ".ffn.0"].bias;
       w.w_f2 = bf(p + ".ffn.3"); w.b_f2 = c->pw[p + ".ffn.3"].bias;
       // per-layer operands produced by the generic GEMM: m_pos.Wqk^T (12x384) and the K|V projections of the encoder tokens
-      float* MPl = A_alloc<float>(c, (size_t)M * 384);
-      gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MPl, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
+      bool fill_mp;
+      float* MPl = wconst_get(c, p + ".mp", (size_t)M * 384, f.fp32, &fill_mp);
+      if (fill_mp) gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MPl, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
       float* KVl = A_alloc<float>(c, (size_t)nT * 256);
       gemm(c, mk(ENC, 128, nT, c->pw[p + ".cross_attn.kv"], KVl, 256), c->pw[p + ".cross_attn.kv"], f.fp32);
       w.mp = MPl; w.kv = KVl;
@@ -803,7 +844,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     if (dp > 0.f) { g2.dropout_p = dp; g2.seed = f.seed; g2.stream = f.next_stream(); }
     gemm(c, g2, c->pw[p + ".r2r_attn.out_proj"], f.fp32);
     // ---- m2m self attention over the 12 modes: q = k = (h + m_pos) W + b, v = h W + b
-    gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MP, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
+    bool fill_mp;
+    float* MP = wconst_get(c, p + ".mp", (size_t)M * 384, f.fp32, &fill_mp);
+    if (fill_mp) gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MP, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
     GemmP g3 = mk(Q, 128, nQ, c->pw[p + ".m2m_attn.qkv"], DQKV, 384);
     g3.pro = PRO_LN; g3.pg = fptr(c, p + ".norm2.weight"); g3.pb = fptr(c, p + ".norm2.bias");
     g3.gbias = MP; g3.gb_div = 1; g3.gb_mod = M;
@@ -914,6 +957,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_DEC_UNFUSED"); c->dec_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_UNFUSED"); c->pe_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   int rc = set_lds_attrs(c);
@@ -948,7 +992,7 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
   c->stream = (hipStream_t)stream;
   HIPCHK(c, hipSetDevice(c->device));
   for (void* p : c->owned) (void)hipFree(p);
-  c->owned.clear(); c->pw.clear(); c->params.clear();
+  c->owned.clear(); c->pw.clear(); c->params.clear(); c->wconst.clear();
   for (int i = 0; i < n; ++i) {
     Param p; p.data = params[i].data; p.numel = params[i].numel; p.ndim = params[i].ndim;
     for (int d = 0; d < 4; ++d) p.shape[d] = params[i].shape[d];

@@ -276,6 +276,31 @@ def test_fused_encoder_matches_layerwise_path(ffi, monkeypatch):
     assert not torch.equal(outs["fused"], outs["layerwise"])
 
 
+def test_fused_fourier_embedding_matches_layerwise_path(ffi, monkeypatch):
+    """The one-launch FourierEmbedding (features, 3 x (Linear-LN-ReLU-Linear), sum, LN-ReLU-Linear in LDS; the 129th
+    input as an fp32 rank-1 update) against the layer-wise GEMM path and the exact-fp32 path, on the token position
+    embedding (3 dims incl. the wrapped heading), the reference-line embedding and the 1-dim speed-limit embedding
+    (seen through the map tokens)."""
+    gold, batch, sd = H.load_case("full")
+    data = batch["cur_pluto_feature_torch"]
+    outs = {}
+    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+        monkeypatch.setenv("RIFT_FOURIER_UNFUSED", env)
+        eng = ffi.Engine("cuda:0")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        eng.prof_enable(True)
+        eng.forward(data, fp32=fp32)
+        assert ("fourier_fused_kernel" in eng.prof_report()) == (name == "fused")
+        eng.prof_enable(False)
+        # x_tokens is only meaningful where the (fused) encoder leaves its input untouched, i.e. in the two bf16 runs
+        outs[name] = (eng.tap("r_emb").cpu().clone(), eng.tap("x_tokens").cpu().clone())
+        eng.close()
+    scale = max(1.0, float(outs["fp32"][0].abs().max()))
+    assert err(outs["fused"][0], outs["fp32"][0]) < 3e-2 * scale
+    assert err(outs["fused"][0], outs["layerwise"][0]) < 3e-2 * scale
+    assert err(outs["fused"][1], outs["layerwise"][1]) < 3e-2 * max(1.0, float(outs["layerwise"][1].abs().max()))
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_fused_points_encoder_matches_layerwise_path(ffi, monkeypatch, train):
     """The three-pass fused PointsEncoder (map polygons, reference lines; BatchNorm batch statistics in train mode,
