@@ -556,82 +556,93 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   uint8_t* valid_agent = A_alloc<uint8_t>(c, nA);
   launch(c, "agent_feature_kernel", agent_feature_kernel, dim3(cdiv((long long)nA * 20, 256)), dim3(256), 0, B->agent_position, B->agent_heading,
          B->agent_velocity, B->agent_shape, B->agent_valid_mask, nA, T, F9, valid_agent);
-  float* X0 = A_alloc<float>(c, (size_t)nA * 20 * 32);
-  {
-    GemmP g = mk(F9, 9, nA * 20, c->pw[HE + ".embed.proj"], X0, 32);
-    g.amode = AMODE_CONV3; g.cv_C = 9; g.cv_Lin = 20; g.cv_nout = 20; g.cv_t0 = 0; g.cv_stride = 1;
-    gemm(c, g, c->pw[HE + ".embed.proj"], f.fp32);
-  }
   static const float dpr[6] = {0.f, 0.04f, 0.08f, 0.12f, 0.16f, 0.2f};   // linspace(0, 0.2, 6), embedding.py:30
   const bool fused = c->nat_fused && !f.fp32;
-  auto nat_level = [&](float* Xl, int lv, int rows, int C, int H, int ksz, int L) {
-    if (!fused) {
+  static const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128}, Hl[3] = {2, 4, 8}, Kl[3] = {3, 3, 5};
+  float* Oc[3];   // LayerNorm(norm_i) of the last 3 steps of level i: all that out[:, :, -1] of the FPN depends on
+  for (int i = 0; i < 3; ++i) Oc[i] = A_alloc<float>(c, (size_t)nA * 3 * Cl[i]);
+  if (fused) {
+    // one launch per level: [ConvTokenizer ->] 2 NAT blocks -> {FPN LayerNorm of the last 3 steps, downsample conv + LN}
+    float* Xin[3] = {nullptr, A_alloc<float>(c, (size_t)nA * 10 * 64), A_alloc<float>(c, (size_t)nA * 5 * 128)};
+    for (int lv = 0; lv < 3; ++lv) {
+      const int C = Cl[lv], H = Hl[lv], ksz = Kl[lv], L = Ll[lv], rows = nA * L;
+      NatLevelP p; memset(&p, 0, sizeof(p));
+      p.dbg = c->nat_dbg;
+      p.X = Xin[lv]; p.nseq = nA; p.seed = f.seed; p.stream = f.next_stream(); f.stream_id += 4;
+      for (int b = 0; b < 2; ++b) {
+        const std::string bp = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b);
+        NatBlockW& w = p.blk[b];
+        w.ln1_g = fptr(c, bp + ".norm1.weight"); w.ln1_b = fptr(c, bp + ".norm1.bias");
+        w.ln2_g = fptr(c, bp + ".norm2.weight"); w.ln2_b = fptr(c, bp + ".norm2.bias");
+        w.wqkv = c->nat_wqkv[lv][b]; w.bqkv = c->nat_bqkv[lv][b]; w.rpb = fptr(c, bp + ".attn.rpb");
+        w.wproj = (const unsigned short*)c->pw[bp + ".attn.proj"].bf; w.bproj = c->pw[bp + ".attn.proj"].bias;
+        w.w1 = (const unsigned short*)c->pw[bp + ".mlp.fc1"].bf; w.b1 = c->pw[bp + ".mlp.fc1"].bias;
+        w.w2 = (const unsigned short*)c->pw[bp + ".mlp.fc2"].bf; w.b2 = c->pw[bp + ".mlp.fc2"].bias;
+        w.droppath = f.drop ? dpr[2 * lv + b] : 0.f;
+      }
+      if (lv == 0) { p.F9 = F9; p.w_tok = (const unsigned short*)c->pw[HE + ".embed.proj"].bf; p.b_tok = c->pw[HE + ".embed.proj"].bias; }
+      p.Oc = Oc[lv]; p.fn_g = fptr(c, HE + ".norm" + std::to_string(lv) + ".weight"); p.fn_b = fptr(c, HE + ".norm" + std::to_string(lv) + ".bias");
+      if (lv < 2) {
+        const std::string dn = HE + ".levels." + std::to_string(lv) + ".downsample";
+        p.Xnext = Xin[lv + 1]; p.w_ds = (const unsigned short*)c->pw[dn + ".reduction"].bf;
+        p.ds_g = fptr(c, dn + ".norm.weight"); p.ds_b = fptr(c, dn + ".norm.bias");
+      }
+      const int CWK = 3 * C < 192 ? 3 * C : 192;
+      const int nrpb = H * (2 * ksz - 1);
+      const size_t lds = (size_t)80 * (C + 4) * 4 + (size_t)80 * (C + 8) * 2 * 2 + (size_t)80 * (CWK + 8) * 2 +
+                         (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4 + (size_t)6 * C * 4;
+      const dim3 grid(cdiv(rows, 80)), block(256);
+      if (lv == 0) launch(c, "nat_level_kernel_L0", nat_level_kernel<32, 2, 20, 3>, grid, block, lds, p);
+      else if (lv == 1) launch(c, "nat_level_kernel_L1", nat_level_kernel<64, 4, 10, 3>, grid, block, lds, p);
+      else launch(c, "nat_level_kernel_L2", nat_level_kernel<128, 8, 5, 5>, grid, block, lds, p);
+    }
+  } else {
+    float* X0 = A_alloc<float>(c, (size_t)nA * 20 * 32);
+    {
+      GemmP g = mk(F9, 9, nA * 20, c->pw[HE + ".embed.proj"], X0, 32);
+      g.amode = AMODE_CONV3; g.cv_C = 9; g.cv_Lin = 20; g.cv_nout = 20; g.cv_t0 = 0; g.cv_stride = 1;
+      gemm(c, g, c->pw[HE + ".embed.proj"], f.fp32);
+    }
+    auto nat_level = [&](float* Xl, int lv, int rows, int C, int H, int ksz, int L) {
       nat_layer(f, Xl, rows, C, H, ksz, L, HE + ".levels." + std::to_string(lv) + ".blocks.0", dpr[2 * lv]);
       nat_layer(f, Xl, rows, C, H, ksz, L, HE + ".levels." + std::to_string(lv) + ".blocks.1", dpr[2 * lv + 1]);
-      return;
+    };
+    nat_level(X0, 0, nA * 20, 32, 2, 3, 20);
+    float* X1 = A_alloc<float>(c, (size_t)nA * 10 * 64);
+    {
+      GemmP g = mk(X0, 32, nA * 10, c->pw[HE + ".levels.0.downsample.reduction"], X1, 64);
+      g.amode = AMODE_CONV3; g.cv_C = 32; g.cv_Lin = 20; g.cv_nout = 10; g.cv_t0 = 0; g.cv_stride = 2;
+      gemm(c, g, c->pw[HE + ".levels.0.downsample.reduction"], f.fp32);
+      layernorm(f, X1, 64, X1, 64, nA * 10, 64, HE + ".levels.0.downsample.norm");
     }
-    NatLevelP p; memset(&p, 0, sizeof(p));
-    p.dbg = c->nat_dbg;
-    p.X = Xl; p.nseq = rows / L; p.seed = f.seed; p.stream = f.next_stream(); f.stream_id += 4;
-    for (int b = 0; b < 2; ++b) {
-      const std::string bp = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b);
-      NatBlockW& w = p.blk[b];
-      w.ln1_g = fptr(c, bp + ".norm1.weight"); w.ln1_b = fptr(c, bp + ".norm1.bias");
-      w.ln2_g = fptr(c, bp + ".norm2.weight"); w.ln2_b = fptr(c, bp + ".norm2.bias");
-      w.wqkv = c->nat_wqkv[lv][b]; w.bqkv = c->nat_bqkv[lv][b]; w.rpb = fptr(c, bp + ".attn.rpb");
-      w.wproj = (const unsigned short*)c->pw[bp + ".attn.proj"].bf; w.bproj = c->pw[bp + ".attn.proj"].bias;
-      w.w1 = (const unsigned short*)c->pw[bp + ".mlp.fc1"].bf; w.b1 = c->pw[bp + ".mlp.fc1"].bias;
-      w.w2 = (const unsigned short*)c->pw[bp + ".mlp.fc2"].bf; w.b2 = c->pw[bp + ".mlp.fc2"].bias;
-      w.droppath = f.drop ? dpr[2 * lv + b] : 0.f;
+    nat_level(X1, 1, nA * 10, 64, 4, 3, 10);
+    // level outputs are the PRE-downsample activations (NATBlock returns (downsample(x), x)); X0/X1 are
+    // still needed below, so the downsample writes new buffers.
+    float* X2 = A_alloc<float>(c, (size_t)nA * 5 * 128);
+    {
+      GemmP g = mk(X1, 64, nA * 5, c->pw[HE + ".levels.1.downsample.reduction"], X2, 128);
+      g.amode = AMODE_CONV3; g.cv_C = 64; g.cv_Lin = 10; g.cv_nout = 5; g.cv_t0 = 0; g.cv_stride = 2;
+      gemm(c, g, c->pw[HE + ".levels.1.downsample.reduction"], f.fp32);
+      layernorm(f, X2, 128, X2, 128, nA * 5, 128, HE + ".levels.1.downsample.norm");
     }
-    const int CWK = 3 * C < 192 ? 3 * C : 192;
-    const int nrpb = H * (2 * ksz - 1);
-    const size_t lds = (size_t)80 * (C + 4) * 4 + (size_t)80 * (C + 8) * 2 * 2 + (size_t)80 * (CWK + 8) * 2 +
-                       (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4;
-    const dim3 grid(cdiv(rows, 80)), block(256);
-    if (lv == 0) launch(c, "nat_level_kernel_L0", nat_level_kernel<32, 2, 20, 3>, grid, block, lds, p);
-    else if (lv == 1) launch(c, "nat_level_kernel_L1", nat_level_kernel<64, 4, 10, 3>, grid, block, lds, p);
-    else launch(c, "nat_level_kernel_L2", nat_level_kernel<128, 8, 5, 5>, grid, block, lds, p);
-  };
-  nat_level(X0, 0, nA * 20, 32, 2, 3, 20);
-  float* X1 = A_alloc<float>(c, (size_t)nA * 10 * 64);
-  {
-    GemmP g = mk(X0, 32, nA * 10, c->pw[HE + ".levels.0.downsample.reduction"], X1, 64);
-    g.amode = AMODE_CONV3; g.cv_C = 32; g.cv_Lin = 20; g.cv_nout = 10; g.cv_t0 = 0; g.cv_stride = 2;
-    gemm(c, g, c->pw[HE + ".levels.0.downsample.reduction"], f.fp32);
-    layernorm(f, X1, 64, X1, 64, nA * 10, 64, HE + ".levels.0.downsample.norm");
-  }
-  nat_level(X1, 1, nA * 10, 64, 4, 3, 10);
-  // level outputs are the PRE-downsample activations (NATBlock returns (downsample(x), x)); X0/X1 are
-  // still needed below, so the downsample writes new buffers.
-  float* X2 = A_alloc<float>(c, (size_t)nA * 5 * 128);
-  {
-    GemmP g = mk(X1, 64, nA * 5, c->pw[HE + ".levels.1.downsample.reduction"], X2, 128);
-    g.amode = AMODE_CONV3; g.cv_C = 64; g.cv_Lin = 10; g.cv_nout = 5; g.cv_t0 = 0; g.cv_stride = 2;
-    gemm(c, g, c->pw[HE + ".levels.1.downsample.reduction"], f.fp32);
-    layernorm(f, X2, 128, X2, 128, nA * 5, 128, HE + ".levels.1.downsample.norm");
-  }
-  nat_level(X2, 2, nA * 5, 128, 8, 5, 5);
-  tap(c, "nat_level2", X2, (int64_t)nA * 5 * 128);
-  // FPN restricted to what out[:, :, -1] depends on: the last 3 steps of each normalised level
-  float* lat[3];
-  {
+    nat_level(X2, 2, nA * 5, 128, 8, 5, 5);
+    tap(c, "nat_level2", X2, (int64_t)nA * 5 * 128);
     float* Xl[3] = {X0, X1, X2};
-    const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128};
-    for (int i = 0; i < 3; ++i) {
-      float* Oc = A_alloc<float>(c, (size_t)nA * 3 * Cl[i]);
-      // rows (a, j) <- level rows (a*L + L-3 + j): per-agent window via ldx trick is not possible -> 3 strided LN calls
-      for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)   // rows (a, j) <- level rows (a*L + L-3 + j): 3 strided LN calls
         launch(c, "layernorm_kernel", layernorm_kernel, dim3(cdiv(nA, 4)), dim3(256), 0, (const float*)(Xl[i] + (size_t)(Ll[i] - 3 + j) * Cl[i]),
-               Ll[i] * Cl[i], Oc + (size_t)j * Cl[i], 3 * Cl[i], nA, Cl[i],
+               Ll[i] * Cl[i], Oc[i] + (size_t)j * Cl[i], 3 * Cl[i], nA, Cl[i],
                fptr(c, HE + ".norm" + std::to_string(i) + ".weight"), fptr(c, HE + ".norm" + std::to_string(i) + ".bias"),
                1e-5f, 0);
-      lat[i] = A_alloc<float>(c, (size_t)nA * 2 * 128);
-      const std::string lc = HE + ".lateral_convs." + std::to_string(i);
-      GemmP g = mk(Oc, Cl[i], nA * 2, c->pw[lc], lat[i], 128);
-      g.amode = AMODE_CONV3; g.cv_C = Cl[i]; g.cv_Lin = 3; g.cv_nout = 2; g.cv_t0 = 1; g.cv_stride = 1;
-      gemm(c, g, c->pw[lc], f.fp32);
-    }
+  }
+  // FPN restricted to what out[:, :, -1] depends on
+  float* lat[3];
+  for (int i = 0; i < 3; ++i) {
+    lat[i] = A_alloc<float>(c, (size_t)nA * 2 * 128);
+    const std::string lc = HE + ".lateral_convs." + std::to_string(i);
+    GemmP g = mk(Oc[i], Cl[i], nA * 2, c->pw[lc], lat[i], 128);
+    g.amode = AMODE_CONV3; g.cv_C = Cl[i]; g.cv_Lin = 3; g.cv_nout = 2; g.cv_t0 = 1; g.cv_stride = 1;
+    gemm(c, g, c->pw[lc], f.fp32);
   }
   float* Z = A_alloc<float>(c, (size_t)nA * 256);
   launch(c, "fpn_merge_kernel", fpn_merge_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)lat[0], (const float*)lat[1],

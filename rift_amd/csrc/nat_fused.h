@@ -25,11 +25,21 @@ struct NatBlockW {
 };
 
 struct NatLevelP {
-  float* X;                     // (nseq*L, C) fp32, updated in place
+  float* X;                     // (nseq*L, C) fp32 level input (read unless F9 is set); written back only if write_x
   int nseq;
   NatBlockW blk[2];
   uint32_t seed, stream;
   int dbg;                      // timing experiments only (RIFT_NAT_DBG bitmask); 0 in production
+  // ---- fused neighbours of the level (all optional) ----
+  const float* F9;              // level 0: (nseq*L, 9) agent features; the ConvTokenizer (embedding.py:57, k=3 pad 1) runs as prologue
+  const unsigned short* w_tok;  // bf16 [32][32] tap-major (k, cin), K = 27 padded
+  const float* b_tok;
+  float* Oc;                    // (nseq*3, C): LayerNorm(norm_lv) of the last 3 steps -- all the FPN reads of this level
+  const float* fn_g; const float* fn_b;
+  float* Xnext;                 // (nseq*L/2, 2C): downsample conv (k=3 stride 2 pad 1, no bias) + LayerNorm(2C) (embedding.py:93-99)
+  const unsigned short* w_ds;   // bf16 [2C][3C] tap-major
+  const float* ds_g; const float* ds_b;
+  int write_x;
 };
 
 // reorder qkv rows of natten's (3, H, 16) layout to (H, 3, 16) and convert to bf16 (+ bias reorder)
@@ -80,6 +90,21 @@ __device__ __forceinline__ void mma80(f32x4 (&acc)[5][NTW], const unsigned short
   }
 }
 
+template <int MTN, int KS, int NTW>
+__device__ __forceinline__ void mma_rows(f32x4 (&acc)[MTN][NTW], const unsigned short* A, int lda, const BFrags<KS, NTW>& B,
+                                         int l15, int l4) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 a[MTN];
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + l15) * lda + ks * 32 + l4 * 8);
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+  }
+}
+
 template <int C, int NHEAD, int L, int KSZ>
 __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
   constexpr int ROWS = 80, MT = 5;
@@ -105,6 +130,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
   constexpr int P_LN1G = 0, P_LN1B = C, P_LN2G = 2 * C, P_LN2B = 3 * C, P_BQKV = 4 * C, P_BP = 7 * C, P_B1 = 8 * C,
                 P_B2 = 11 * C, P_RPB = 12 * C, NPAR = 12 * C + ((NRPB + 3) & ~3);
   float* par = reinterpret_cast<float*>(ao + ROWS * XN);    // [2][NPAR]
+  float* par2 = par + 2 * NPAR;                             // fn_g C | fn_b C | ds_g 2C | ds_b 2C
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int row0 = blockIdx.x * ROWS;
@@ -123,12 +149,54 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
     par[i] = (e < 12 * C + NRPB) ? *src : 0.f;
   }
 
-  // ---- load the residual stream tile
-  for (int i = tid; i < ROWS * (C / 4); i += 256) {
-    const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < total_rows) v = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + c4);
-    *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
+  for (int i = tid; i < 6 * C; i += 256) {
+    float v = 0.f;
+    if (i < 2 * C) { if (p.Oc) v = i < C ? p.fn_g[i] : p.fn_b[i - C]; }
+    else if (p.Xnext) v = i < 4 * C ? p.ds_g[i - 2 * C] : p.ds_b[i - 4 * C];
+    par2[i] = v;
+  }
+
+  bool tokenized = false;
+  if constexpr (C == 32) tokenized = p.F9 != nullptr;
+  if constexpr (C == 32) if (tokenized) {
+    // ---- ConvTokenizer prologue: xs = conv1d(F9, k=3, pad 1) + b as one K=32 MFMA step over the 3x9 window
+    BFrags<1, NTW_C> Wt;
+    load_b(Wt, p.w_tok, 32, 0, 0, NT_C, wave, l15, l4);
+    for (int i = tid; i < ROWS * 32; i += 256) {
+      const int r = i >> 5, kk = i & 31;
+      const int tap = kk / 9, cin = kk - tap * 9;
+      const int t = r % L, tt = t - 1 + tap;
+      float v = 0.f;
+      if (kk < 27 && tt >= 0 && tt < L && row0 + r < total_rows) v = p.F9[(size_t)(row0 + r - t + tt) * 9 + cin];
+      xn[r * XN + kk] = f2bf(v);
+    }
+    __syncthreads();
+    f32x4 acc[MT][NTW_C];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < NTW_C; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mma80<1, NTW_C>(acc, xn, XN, Wt, l15, l4);
+#pragma unroll
+    for (int j = 0; j < NTW_C; ++j) {
+      const int nt = j * 4 + wave;
+      if (nt >= NT_C) continue;
+      const int col = nt * 16 + l4 * 4;
+      const float4 b4 = *reinterpret_cast<const float4*>(p.b_tok + col);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col) =
+            make_float4(acc[mt][j][0] + b4.x, acc[mt][j][1] + b4.y, acc[mt][j][2] + b4.z, acc[mt][j][3] + b4.w);
+    }
+  }
+  if (!tokenized) {
+    // ---- load the residual stream tile
+    for (int i = tid; i < ROWS * (C / 4); i += 256) {
+      const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < total_rows) v = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + c4);
+      *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
+    }
   }
   __syncthreads();
 
@@ -336,11 +404,90 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
     }
     __syncthreads();
   }
-  // ---- write the level output back
-  for (int i = tid; i < ROWS * (C / 4); i += 256) {
-    const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-    if (row0 + r < total_rows)
-      *reinterpret_cast<float4*>(p.X + (size_t)(row0 + r) * C + c4) = *reinterpret_cast<const float4*>(xs + r * XS + c4);
+  // ---- level output: what the FPN reads (normalised last 3 steps), the next level's input (downsample + LN), and X itself
+  if (p.write_x) {
+    for (int i = tid; i < ROWS * (C / 4); i += 256) {
+      const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+      if (row0 + r < total_rows)
+        *reinterpret_cast<float4*>(p.X + (size_t)(row0 + r) * C + c4) = *reinterpret_cast<const float4*>(xs + r * XS + c4);
+    }
+  }
+  if (p.Oc) {
+    constexpr int LPR = C / 4, RPS = 64 / LPR, NSEQ = ROWS / L;
+    const int lr = lane % LPR, rsub = lane / LPR;
+    const float4 g4 = *reinterpret_cast<const float4*>(par2 + lr * 4), b4 = *reinterpret_cast<const float4*>(par2 + C + lr * 4);
+    for (int it = wave * RPS + rsub; it < NSEQ * 3; it += 4 * RPS) {
+      const int a = it / 3, j = it - a * 3;
+      const int r = a * L + L - 3 + j;
+      const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
+      float sm = (v.x + v.y) + (v.z + v.w);
+      sm = group_sum<LPR>(sm);
+      const float mean = sm * (1.0f / C);
+      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+      float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      q = group_sum<LPR>(q);
+      const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
+      const int seq = row0 / L + a;
+      if (seq < p.nseq)
+        *reinterpret_cast<float4*>(p.Oc + ((size_t)seq * 3 + j) * C + lr * 4) =
+            make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
+    }
+  }
+  if constexpr (C <= 64) {
+    if (p.Xnext) {
+      constexpr int MD = 3, RD = ROWS / 2, L2 = L / 2, C2 = 2 * C;       // 40 output rows in 3 m-tiles
+      constexpr int NT2 = C2 / 16, NTW2 = (NT2 + 3) / 4, DS = C2 + 4;
+      static_assert(C > 64 || C3 == CWK, "downsample A tile is staged in the chunk buffer");
+      static_assert(C > 64 || RD * DS <= ROWS * XS, "downsample output tile must fit the residual tile");
+      BFrags<KSC, NTW2> Wd;
+      load_b(Wd, p.w_ds, C3, 0, 0, NT2, wave, l15, l4);
+      for (int i = tid; i < 48 * (C3 / 4); i += 256) {
+        const int m = i / (C3 / 4), k4 = (i - m * (C3 / 4)) * 4;
+        const int tap = k4 / C, cin = k4 - tap * C;
+        const int a = m / L2, j = m - a * L2;
+        const int t = 2 * j - 1 + tap;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < RD && t >= 0 && t < L) v = *reinterpret_cast<const float4*>(xs + (a * L + t) * XS + cin);
+        *reinterpret_cast<uint2*>(cb + m * CB + k4) = pack_bf16x4(v.x, v.y, v.z, v.w);
+      }
+      __syncthreads();
+      f32x4 acc[MD][NTW2];
+#pragma unroll
+      for (int mt = 0; mt < MD; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mma_rows<MD, KSC, NTW2>(acc, cb, CB, Wd, l15, l4);
+      float* ds = xs;                                                      // [40][DS] fp32 over the (dead) residual tile
+#pragma unroll
+      for (int j = 0; j < NTW2; ++j) {
+        const int nt = j * 4 + wave;
+        if (nt >= NT2) continue;
+        const int col = nt * 16 + l4 * 4;
+#pragma unroll
+        for (int mt = 0; mt < MD; ++mt) {
+          const int m = mt * 16 + l15;
+          if (m < RD) *reinterpret_cast<float4*>(ds + m * DS + col) = make_float4(acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]);
+        }
+      }
+      __syncthreads();
+      constexpr int LPR = C2 / 4, RPS = 64 / LPR;
+      const int lr = lane % LPR, rsub = lane / LPR;
+      const float4 g4 = *reinterpret_cast<const float4*>(par2 + 2 * C + lr * 4), b4 = *reinterpret_cast<const float4*>(par2 + 4 * C + lr * 4);
+      const int orow0 = row0 / 2, ototal = total_rows / 2;
+      for (int m = wave * RPS + rsub; m < RD; m += 4 * RPS) {
+        const float4 v = *reinterpret_cast<const float4*>(ds + m * DS + lr * 4);
+        float sm = (v.x + v.y) + (v.z + v.w);
+        sm = group_sum<LPR>(sm);
+        const float mean = sm * (1.0f / C2);
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        q = group_sum<LPR>(q);
+        const float rstd = rsqrtf(q * (1.0f / C2) + 1e-5f);
+        if (orow0 + m < ototal)
+          *reinterpret_cast<float4*>(p.Xnext + (size_t)(orow0 + m) * C2 + lr * 4) =
+              make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
+      }
+    }
   }
 }
 
