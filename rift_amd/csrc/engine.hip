@@ -23,6 +23,18 @@
 #include "fourier_fused.h"
 #include "rollout.h"
 
+// fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
+// workgroups share a CU; 8 waves give a single resident workgroup two waves per SIMD)
+#define NAT_L0_NW 8
+#define NAT_L0_CW 192
+#define NAT_L1_NW 8
+#define NAT_L1_CW 192
+#define NAT_L2_NW 8
+#define NAT_L2_CW 192
+#define NAT_L0 (rift::nat_level_kernel<32, 2, 20, 3, NAT_L0_NW, NAT_L0_CW>)
+#define NAT_L1 (rift::nat_level_kernel<64, 4, 10, 3, NAT_L1_NW, NAT_L1_CW>)
+#define NAT_L2 (rift::nat_level_kernel<128, 8, 5, 5, NAT_L2_NW, NAT_L2_CW>)
+
 using namespace rift;
 
 namespace {
@@ -299,9 +311,9 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR(rollout_kernel);
   SETATTR(enc_fused_kernel);
   SETATTR(dec_fused_kernel);
-  SETATTR((nat_level_kernel<32, 2, 20, 3>));
-  SETATTR((nat_level_kernel<64, 4, 10, 3>));
-  SETATTR((nat_level_kernel<128, 8, 5, 5>));
+  SETATTR(NAT_L0);
+  SETATTR(NAT_L1);
+  SETATTR(NAT_L2);
   SETATTR((gemm_rows_kernel<true, 1, 8, 4, 1>));
   SETATTR((gemm_rows_kernel<true, 4, 2, 1, 4>));
   SETATTR((gemm_rows_kernel<false, 4, 2, 1, 4>));
@@ -587,14 +599,12 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         p.Xnext = Xin[lv + 1]; p.w_ds = (const unsigned short*)c->pw[dn + ".reduction"].bf;
         p.ds_g = fptr(c, dn + ".norm.weight"); p.ds_b = fptr(c, dn + ".norm.bias");
       }
-      const int CWK = 3 * C < 192 ? 3 * C : 192;
-      const int nrpb = H * (2 * ksz - 1);
-      const size_t lds = (size_t)80 * (C + 4) * 4 + (size_t)80 * (C + 8) * 2 * 2 + (size_t)80 * (CWK + 8) * 2 +
-                         (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4 + (size_t)6 * C * 4;
-      const dim3 grid(cdiv(rows, 80)), block(256);
-      if (lv == 0) launch(c, "nat_level_kernel_L0", nat_level_kernel<32, 2, 20, 3>, grid, block, lds, p);
-      else if (lv == 1) launch(c, "nat_level_kernel_L1", nat_level_kernel<64, 4, 10, 3>, grid, block, lds, p);
-      else launch(c, "nat_level_kernel_L2", nat_level_kernel<128, 8, 5, 5>, grid, block, lds, p);
+      { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == lv + 1) { p.ts = A_alloc<long long>(c, 256); tap(c, "nat_ts", (float*)p.ts, 512); } }
+      const dim3 grid(cdiv(rows, 80));
+      (void)H; (void)ksz;
+      if (lv == 0) launch(c, "nat_level_kernel_L0", NAT_L0, grid, dim3(64 * NAT_L0_NW), nat_lds_bytes(32, 2, 3, NAT_L0_CW), p);
+      else if (lv == 1) launch(c, "nat_level_kernel_L1", NAT_L1, grid, dim3(64 * NAT_L1_NW), nat_lds_bytes(64, 4, 3, NAT_L1_CW), p);
+      else launch(c, "nat_level_kernel_L2", NAT_L2, grid, dim3(64 * NAT_L2_NW), nat_lds_bytes(128, 8, 5, NAT_L2_CW), p);
     }
   } else {
     float* X0 = A_alloc<float>(c, (size_t)nA * 20 * 32);

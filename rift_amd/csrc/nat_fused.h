@@ -40,6 +40,7 @@ struct NatLevelP {
   const unsigned short* w_ds;   // bf16 [2C][3C] tap-major
   const float* ds_g; const float* ds_b;
   int write_x;
+  long long* ts;                // optional phase timestamps of workgroup 0 (diagnostic)
 };
 
 // reorder qkv rows of natten's (3, H, 16) layout to (H, 3, 16) and convert to bf16 (+ bias reorder)
@@ -60,12 +61,14 @@ __global__ void pack_qkv_headmajor_kernel(const float* __restrict__ w, const flo
 template <int KS, int NTW>
 struct BFrags { bf16x8 f[KS][NTW]; };
 
-template <int KS, int NTW>
+template <int NWV> struct NWaves {};
+template <int KS, int NTW, int NW>
 __device__ __forceinline__ void load_b(BFrags<KS, NTW>& B, const unsigned short* W, int ldw, int n0, int k0, int ntiles,
-                                       int wave, int l15, int l4) {
+                                       int wave, int l15, int l4, bool skip, NWaves<NW>) {
+  if (skip) ntiles = 0;
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
-    const int nt = j * 4 + wave;
+    const int nt = j * NW + wave;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       B.f[ks][j] = (nt < ntiles) ? *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + nt * 16 + l15) * ldw + k0 + ks * 32 + l4 * 8)
@@ -105,25 +108,37 @@ __device__ __forceinline__ void mma_rows(f32x4 (&acc)[MTN][NTW], const unsigned 
   }
 }
 
-template <int C, int NHEAD, int L, int KSZ>
-__global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
+// dynamic LDS bytes of nat_level_kernel<C, NHEAD, L, KSZ, NW, CWMAX>
+constexpr size_t nat_lds_bytes(int C, int NHEAD, int KSZ, int CWMAX) {
+  const int C3 = 3 * C, CWK = C3 < CWMAX ? C3 : CWMAX, CB = CWK + 8, DSB = C3 + 8;
+  const int cbsz = (C <= 64 && 48 * DSB > 80 * CB) ? 48 * DSB : 80 * CB;
+  const int nrpb = NHEAD * (2 * KSZ - 1);
+  return (size_t)80 * (C + 4) * 4 + (size_t)80 * (C + 8) * 2 * 2 + (size_t)cbsz * 2 + (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4 + (size_t)6 * C * 4;
+}
+
+// NW waves per workgroup (n-tiles and rows are dealt round-robin to the waves); CWMAX = widest qkv / hidden chunk
+template <int C, int NHEAD, int L, int KSZ, int NW = 4, int CWMAX = 192>
+__global__ __launch_bounds__(64 * NW) void nat_level_kernel(NatLevelP p) {
   constexpr int ROWS = 80, MT = 5;
   constexpr int C3 = 3 * C;
-  constexpr int CWK = C3 < 192 ? C3 : 192;        // chunk width (columns of qkv / hidden processed at once)
+  constexpr int NTH = 64 * NW;
+  constexpr int CWK = C3 < CWMAX ? C3 : CWMAX;        // chunk width (columns of qkv / hidden processed at once)
   constexpr int NCH = C3 / CWK;                   // 1, 1, 2
   constexpr int HPC = CWK / 48;                   // heads per qkv chunk
   constexpr int XS = C + 4, XN = C + 8, CB = CWK + 8;
   constexpr int KS1 = C / 32;                     // k-steps with K = C
   constexpr int KSC = CWK / 32;                   // k-steps with K = chunk
   constexpr int NT_CH = CWK / 16;                 // n-tiles of a chunk (6 or 12)
-  constexpr int NTW_CH = (NT_CH + 3) / 4;         // per wave (2 or 3)
+  constexpr int NTW_CH = (NT_CH + NW - 1) / NW;         // per wave (2 or 3)
   constexpr int NT_C = C / 16;                    // n-tiles of a C-wide output (2, 4, 8)
-  constexpr int NTW_C = (NT_C + 3) / 4;           // per wave (1, 1, 2)
+  constexpr int NTW_C = (NT_C + NW - 1) / NW;           // per wave (1, 1, 2)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* xs = reinterpret_cast<float*>(smem_raw);
   unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
   unsigned short* cb = xn + ROWS * XN;
-  unsigned short* ao = cb + ROWS * CB;
+  constexpr int DSB = C3 + 8;                     // row stride of the downsample conv's A tile (staged in cb)
+  constexpr int CBSZ = (C <= 64 && 48 * DSB > ROWS * CB) ? 48 * DSB : ROWS * CB;
+  unsigned short* ao = cb + CBSZ;
   // both layers' bias / LayerNorm / rpb vectors live in LDS (fetched once at kernel start): no epilogue or
   // LayerNorm begins with a dependent global load
   constexpr int NRPB = NHEAD * (2 * KSZ - 1);
@@ -135,25 +150,44 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
   const int l15 = lane & 15, l4 = lane >> 4;
   const int row0 = blockIdx.x * ROWS;
   const int total_rows = p.nseq * L;
+  int tsn = 0;
+#define NTS() do { if (p.ts && blockIdx.x == 0 && tid == 0) p.ts[tsn++] = clock64(); } while (0)
+  NTS();
 
   BFrags<KS1, NTW_CH> Bq;      // qkv / fc1 weights of the current chunk
   BFrags<KS1, NTW_C> Bp;       // proj weights
   BFrags<KSC, NTW_C> B2;       // fc2 weights of the current hidden chunk
-  load_b(Bq, p.blk[0].wqkv, C, 0, 0, NT_CH, wave, l15, l4);
-  for (int i = tid; i < 2 * NPAR; i += 256) {
-    const NatBlockW& w = p.blk[i / NPAR];
-    const int e = i % NPAR;
-    const float* src = e < C ? w.ln1_g + e : e < 2 * C ? w.ln1_b + (e - C) : e < 3 * C ? w.ln2_g + (e - 2 * C)
-                     : e < 4 * C ? w.ln2_b + (e - 3 * C) : e < 7 * C ? w.bqkv + (e - 4 * C) : e < 8 * C ? w.bproj + (e - 7 * C)
-                     : e < 11 * C ? w.b1 + (e - 8 * C) : e < 12 * C ? w.b2 + (e - 11 * C) : w.rpb + (e - 12 * C);
-    par[i] = (e < 12 * C + NRPB) ? *src : 0.f;
+  load_b(Bq, p.blk[0].wqkv, C, 0, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
+  // all parameter vectors and the activation tile are requested up front (independent loads into registers, one
+  // wait), never as load -> LDS-store pairs: at one wave per SIMD each exposed global round trip costs microseconds
+  {
+    constexpr int NPV = (2 * NPAR + NTH - 1) / NTH;
+    float pv[NPV];
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) {
+      const int i = tid + u * NTH;
+      const NatBlockW& w = p.blk[i >= NPAR ? 1 : 0];
+      const int e = i >= NPAR ? i - NPAR : i;
+      const float* src = e < C ? w.ln1_g + e : e < 2 * C ? w.ln1_b + (e - C) : e < 3 * C ? w.ln2_g + (e - 2 * C)
+                       : e < 4 * C ? w.ln2_b + (e - 3 * C) : e < 7 * C ? w.bqkv + (e - 4 * C) : e < 8 * C ? w.bproj + (e - 7 * C)
+                       : e < 11 * C ? w.b1 + (e - 8 * C) : e < 12 * C ? w.b2 + (e - 11 * C) : w.rpb + (e - 12 * C);
+      pv[u] = (i < 2 * NPAR && e < 12 * C + NRPB) ? *src : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) { const int i = tid + u * NTH; if (i < 2 * NPAR) par[i] = pv[u]; }
   }
-
-  for (int i = tid; i < 6 * C; i += 256) {
-    float v = 0.f;
-    if (i < 2 * C) { if (p.Oc) v = i < C ? p.fn_g[i] : p.fn_b[i - C]; }
-    else if (p.Xnext) v = i < 4 * C ? p.ds_g[i - 2 * C] : p.ds_b[i - 4 * C];
-    par2[i] = v;
+  {
+    constexpr int NP2 = (6 * C + NTH - 1) / NTH;
+    float pv[NP2];
+#pragma unroll
+    for (int u = 0; u < NP2; ++u) {
+      const int i = tid + u * NTH;
+      pv[u] = 0.f;
+      if (i < 2 * C) { if (p.Oc) pv[u] = i < C ? p.fn_g[i] : p.fn_b[i - C]; }
+      else if (i < 6 * C && p.Xnext) pv[u] = i < 4 * C ? p.ds_g[i - 2 * C] : p.ds_b[i - 4 * C];
+    }
+#pragma unroll
+    for (int u = 0; u < NP2; ++u) { const int i = tid + u * NTH; if (i < 6 * C) par2[i] = pv[u]; }
   }
 
   bool tokenized = false;
@@ -161,15 +195,19 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
   if constexpr (C == 32) if (tokenized) {
     // ---- ConvTokenizer prologue: xs = conv1d(F9, k=3, pad 1) + b as one K=32 MFMA step over the 3x9 window
     BFrags<1, NTW_C> Wt;
-    load_b(Wt, p.w_tok, 32, 0, 0, NT_C, wave, l15, l4);
-    for (int i = tid; i < ROWS * 32; i += 256) {
+    load_b(Wt, p.w_tok, 32, 0, 0, NT_C, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
+    float fv[ROWS * 32 / NTH];
+#pragma unroll
+    for (int u = 0; u < ROWS * 32 / NTH; ++u) {
+      const int i = tid + u * NTH;
       const int r = i >> 5, kk = i & 31;
       const int tap = kk / 9, cin = kk - tap * 9;
       const int t = r % L, tt = t - 1 + tap;
-      float v = 0.f;
-      if (kk < 27 && tt >= 0 && tt < L && row0 + r < total_rows) v = p.F9[(size_t)(row0 + r - t + tt) * 9 + cin];
-      xn[r * XN + kk] = f2bf(v);
+      fv[u] = 0.f;
+      if (kk < 27 && tt >= 0 && tt < L && row0 + r < total_rows) fv[u] = p.F9[(size_t)(row0 + r - t + tt) * 9 + cin];
     }
+#pragma unroll
+    for (int u = 0; u < ROWS * 32 / NTH; ++u) { const int i = tid + u * NTH; xn[(i >> 5) * XN + (i & 31)] = f2bf(fv[u]); }
     __syncthreads();
     f32x4 acc[MT][NTW_C];
 #pragma unroll
@@ -179,7 +217,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
     mma80<1, NTW_C>(acc, xn, XN, Wt, l15, l4);
 #pragma unroll
     for (int j = 0; j < NTW_C; ++j) {
-      const int nt = j * 4 + wave;
+      const int nt = j * NW + wave;
       if (nt >= NT_C) continue;
       const int col = nt * 16 + l4 * 4;
       const float4 b4 = *reinterpret_cast<const float4*>(p.b_tok + col);
@@ -191,14 +229,24 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
   }
   if (!tokenized) {
     // ---- load the residual stream tile
-    for (int i = tid; i < ROWS * (C / 4); i += 256) {
+    constexpr int NV = (ROWS * (C / 4) + NTH - 1) / NTH;
+    float4 tv[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * NTH;
       const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < total_rows) v = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + c4);
-      *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
+      tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < ROWS * (C / 4) && row0 + r < total_rows) tv[u] = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + c4);
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * NTH;
+      const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+      if (i < ROWS * (C / 4)) *reinterpret_cast<float4*>(xs + r * XS + c4) = tv[u];
     }
   }
   __syncthreads();
+  NTS();
 
   // LayerNorm xs -> xn (bf16): C/4 lanes per row (16-byte LDS reads), xor-shuffle statistics
   auto layer_norm = [&](const float* g, const float* b) {
@@ -206,7 +254,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
     const int lr = lane % LPR, rsub = lane / LPR;
     const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(b + lr * 4);
 #pragma unroll 2
-    for (int r = wave * RPS + rsub; r < ROWS; r += 4 * RPS) {
+    for (int r = wave * RPS + rsub; r < ROWS; r += NW * RPS) {
       const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
       float s = (v.x + v.y) + (v.z + v.w);
       s = group_sum<LPR>(s);
@@ -226,6 +274,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
     // ======== attention half ========
     if (!(p.dbg & 1)) layer_norm(pb + P_LN1G, pb + P_LN1B);
     __syncthreads();
+    NTS();
     for (int ch = 0; ch < NCH; ++ch) {
       // ---- qkv chunk GEMM: cb[80][CWK] = xn[80][C] . Wqkv[ch*CWK .. +CWK][C]^T + b ; q pre-scaled by 16^-0.5
       {
@@ -236,11 +285,11 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
           for (int j = 0; j < NTW_CH; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (!(p.dbg & 8)) mma80<KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
         // prefetch the next phase's weights (next qkv chunk, or proj)
-        if (ch + 1 < NCH) load_b(Bq, w.wqkv, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4);
-        else load_b(Bp, w.wproj, C, 0, 0, NT_C, wave, l15, l4);
+        if (ch + 1 < NCH) load_b(Bq, w.wqkv, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
+        else load_b(Bp, w.wproj, C, 0, 0, NT_C, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
 #pragma unroll
         for (int j = 0; j < NTW_CH; ++j) {
-          const int nt = j * 4 + wave;
+          const int nt = j * NW + wave;
           if (nt >= NT_CH) continue;
           const int col = nt * 16 + l4 * 4;
           const float4 b4 = *reinterpret_cast<const float4*>(pb + P_BQKV + ch * CWK + col);
@@ -252,8 +301,9 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
         }
       }
       __syncthreads();
+      NTS();
       // ---- neighbourhood attention of the chunk's heads (VALU, fp32 softmax); one (row, head) per work item
-      for (int it = tid; it < ((p.dbg & 2) ? 0 : ROWS * HPC); it += 256) {
+      for (int it = tid; it < ((p.dbg & 2) ? 0 : ROWS * HPC); it += NTH) {
         const int hh = it % HPC, row = it / HPC;
         const int a0 = (row / L) * L, i = row - a0;
         const int head = ch * HPC + hh;
@@ -303,6 +353,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
         *reinterpret_cast<uint4*>(ao + row * XN + head * 16 + 8) = o1;
       }
       __syncthreads();
+      NTS();
     }
     // ---- proj GEMM + residual: xs += droppath( ao . Wproj^T + b )
     {
@@ -312,7 +363,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
 #pragma unroll
         for (int j = 0; j < NTW_C; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       mma80<KS1, NTW_C>(acc, ao, XN, Bp, l15, l4);
-      load_b(Bq, w.w1, C, 0, 0, NT_CH, wave, l15, l4);     // fc1 weights of hidden chunk 0
+      load_b(Bq, w.w1, C, 0, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());     // fc1 weights of hidden chunk 0
       float dps[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -322,7 +373,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
       }
 #pragma unroll
       for (int j = 0; j < NTW_C; ++j) {
-        const int nt = j * 4 + wave;
+        const int nt = j * NW + wave;
         if (nt >= NT_C) continue;
         const int col = nt * 16 + l4 * 4;
         const float4 b4 = *reinterpret_cast<const float4*>(pb + P_BP + col);
@@ -337,9 +388,11 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
       }
     }
     __syncthreads();
+    NTS();
     // ======== MLP half ========
     if (!(p.dbg & 1)) layer_norm(pb + P_LN2G, pb + P_LN2B);
     __syncthreads();
+    NTS();
     {
       f32x4 acc2[MT][NTW_C];
 #pragma unroll
@@ -355,11 +408,11 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
 #pragma unroll
             for (int j = 0; j < NTW_CH; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (!(p.dbg & 8)) mma80<KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
-          load_b(B2, w.w2, C3, 0, ch * CWK, NT_C, wave, l15, l4);          // fc2 weights of this hidden chunk
+          load_b(B2, w.w2, C3, 0, ch * CWK, NT_C, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());          // fc2 weights of this hidden chunk
           if (ch > 0) __syncthreads();   // the previous chunk's fc2 reads of cb are complete
 #pragma unroll
           for (int j = 0; j < NTW_CH; ++j) {
-            const int nt = j * 4 + wave;
+            const int nt = j * NW + wave;
             if (nt >= NT_CH) continue;
             const int col = nt * 16 + l4 * 4;
             const float4 b4 = *reinterpret_cast<const float4*>(pb + P_B1 + ch * CWK + col);
@@ -373,11 +426,13 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
           }
         }
         // weights needed after this fc2: next hidden chunk's fc1, or the next block's qkv chunk 0
-        if (ch + 1 < NCH) load_b(Bq, w.w1, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4);
-        else if (bi == 0) load_b(Bq, p.blk[1].wqkv, C, 0, 0, NT_CH, wave, l15, l4);
+        if (ch + 1 < NCH) load_b(Bq, w.w1, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
+        else if (bi == 0) load_b(Bq, p.blk[1].wqkv, C, 0, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
         __syncthreads();
+        NTS();
         // ---- fc2 partial: acc2 += cb[80][CWK] . W2[:, ch*CWK..]^T
         if (!(p.dbg & 8)) mma80<KSC, NTW_C>(acc2, cb, CB, B2, l15, l4);
+        NTS();
       }
       float dps[MT];
 #pragma unroll
@@ -388,7 +443,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
       }
 #pragma unroll
       for (int j = 0; j < NTW_C; ++j) {
-        const int nt = j * 4 + wave;
+        const int nt = j * NW + wave;
         if (nt >= NT_C) continue;
         const int col = nt * 16 + l4 * 4;
         const float4 b4 = *reinterpret_cast<const float4*>(pb + P_B2 + col);
@@ -403,10 +458,11 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
       }
     }
     __syncthreads();
+    NTS();
   }
   // ---- level output: what the FPN reads (normalised last 3 steps), the next level's input (downsample + LN), and X itself
   if (p.write_x) {
-    for (int i = tid; i < ROWS * (C / 4); i += 256) {
+    for (int i = tid; i < ROWS * (C / 4); i += NTH) {
       const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
       if (row0 + r < total_rows)
         *reinterpret_cast<float4*>(p.X + (size_t)(row0 + r) * C + c4) = *reinterpret_cast<const float4*>(xs + r * XS + c4);
@@ -416,7 +472,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
     constexpr int LPR = C / 4, RPS = 64 / LPR, NSEQ = ROWS / L;
     const int lr = lane % LPR, rsub = lane / LPR;
     const float4 g4 = *reinterpret_cast<const float4*>(par2 + lr * 4), b4 = *reinterpret_cast<const float4*>(par2 + C + lr * 4);
-    for (int it = wave * RPS + rsub; it < NSEQ * 3; it += 4 * RPS) {
+    for (int it = wave * RPS + rsub; it < NSEQ * 3; it += NW * RPS) {
       const int a = it / 3, j = it - a * 3;
       const int r = a * L + L - 3 + j;
       const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
@@ -436,19 +492,18 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
   if constexpr (C <= 64) {
     if (p.Xnext) {
       constexpr int MD = 3, RD = ROWS / 2, L2 = L / 2, C2 = 2 * C;       // 40 output rows in 3 m-tiles
-      constexpr int NT2 = C2 / 16, NTW2 = (NT2 + 3) / 4, DS = C2 + 4;
-      static_assert(C > 64 || C3 == CWK, "downsample A tile is staged in the chunk buffer");
+      constexpr int NT2 = C2 / 16, NTW2 = (NT2 + NW - 1) / NW, DS = C2 + 4;
       static_assert(C > 64 || RD * DS <= ROWS * XS, "downsample output tile must fit the residual tile");
-      BFrags<KSC, NTW2> Wd;
-      load_b(Wd, p.w_ds, C3, 0, 0, NT2, wave, l15, l4);
-      for (int i = tid; i < 48 * (C3 / 4); i += 256) {
+      BFrags<C3 / 32, NTW2> Wd;
+      load_b(Wd, p.w_ds, C3, 0, 0, NT2, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
+      for (int i = tid; i < 48 * (C3 / 4); i += NTH) {
         const int m = i / (C3 / 4), k4 = (i - m * (C3 / 4)) * 4;
         const int tap = k4 / C, cin = k4 - tap * C;
         const int a = m / L2, j = m - a * L2;
         const int t = 2 * j - 1 + tap;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m < RD && t >= 0 && t < L) v = *reinterpret_cast<const float4*>(xs + (a * L + t) * XS + cin);
-        *reinterpret_cast<uint2*>(cb + m * CB + k4) = pack_bf16x4(v.x, v.y, v.z, v.w);
+        *reinterpret_cast<uint2*>(cb + m * DSB + k4) = pack_bf16x4(v.x, v.y, v.z, v.w);
       }
       __syncthreads();
       f32x4 acc[MD][NTW2];
@@ -456,11 +511,11 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
       for (int mt = 0; mt < MD; ++mt)
 #pragma unroll
         for (int j = 0; j < NTW2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      mma_rows<MD, KSC, NTW2>(acc, cb, CB, Wd, l15, l4);
+      mma_rows<MD, C3 / 32, NTW2>(acc, cb, DSB, Wd, l15, l4);
       float* ds = xs;                                                      // [40][DS] fp32 over the (dead) residual tile
 #pragma unroll
       for (int j = 0; j < NTW2; ++j) {
-        const int nt = j * 4 + wave;
+        const int nt = j * NW + wave;
         if (nt >= NT2) continue;
         const int col = nt * 16 + l4 * 4;
 #pragma unroll
@@ -474,7 +529,7 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
       const int lr = lane % LPR, rsub = lane / LPR;
       const float4 g4 = *reinterpret_cast<const float4*>(par2 + 2 * C + lr * 4), b4 = *reinterpret_cast<const float4*>(par2 + 4 * C + lr * 4);
       const int orow0 = row0 / 2, ototal = total_rows / 2;
-      for (int m = wave * RPS + rsub; m < RD; m += 4 * RPS) {
+      for (int m = wave * RPS + rsub; m < RD; m += NW * RPS) {
         const float4 v = *reinterpret_cast<const float4*>(ds + m * DS + lr * 4);
         float sm = (v.x + v.y) + (v.z + v.w);
         sm = group_sum<LPR>(sm);
@@ -489,6 +544,8 @@ __global__ __launch_bounds__(256) void nat_level_kernel(NatLevelP p) {
       }
     }
   }
+  NTS();
+#undef NTS
 }
 
 }  // namespace rift
