@@ -26,6 +26,20 @@ __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
   uint2 u; u.x = pack_bf16x2(a, b); u.y = pack_bf16x2(c, d); return u;
 }
 
+// ---- bf16 weight images are stored FRAGMENT-MAJOR ---------------------------------------------------------------------
+// A weight matrix W[N][Kp] (N padded to 16, Kp to 32) is cut into MFMA operand fragments: fragment (nt, ks) = rows
+// 16 nt..+15, columns 32 ks..+31, 1 KiB, holding lane l's 8 bf16 (row 16 nt + (l & 15), columns 32 ks + 8 (l >> 4)..+7)
+// at byte offset 16 l.  One wave-wide fragment load is then ONE contiguous 1 KiB request instead of 16 rows x 64 B:
+// measured 60-65 B/cycle/CU against 16 B/cycle/CU for the row-major image (tools/ubench/l2_stream.hip), which is what
+// bounds kernels that stream their weights from L2 once per row tile.
+__host__ __device__ __forceinline__ size_t fm_index(int n, int k, int Kp) {
+  return ((size_t)((n >> 4) * (Kp >> 5) + (k >> 5)) * 64 + (size_t)(((k >> 3) & 3) * 16 + (n & 15))) * 8 + (k & 7);
+}
+// fragment (rows n0.., columns k0..) of a fragment-major image with row length Kp; n0 % 16 == 0, k0 % 32 == 0
+__device__ __forceinline__ bf16x8 fm_load(const unsigned short* W, int Kp, int n0, int k0, int lane) {
+  return *reinterpret_cast<const bf16x8*>(W + ((size_t)((n0 >> 4) * (Kp >> 5) + (k0 >> 5)) * 64 + lane) * 8);
+}
+
 // counter-based RNG for dropout / drop-path / state-dropout: one 32-bit hash per element
 // (two rounds of the lowbias32 integer finaliser over (seed, stream, element index); 32-bit multiplies only).
 __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t stream, uint32_t idx) {

@@ -41,7 +41,7 @@ __global__ void pack_rows_indexed_kernel(const float* __restrict__ src, const fl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrows * K) return;
   const int r = i / K, k = i - r * K;
-  dst[i] = f2bf(src[(size_t)idx[r] * K + k]);
+  dst[fm_index(r, k, K)] = f2bf(src[(size_t)idx[r] * K + k]);   // fragment-major image
   if (k == 0 && bias) bias_out[r] = bias[idx[r]];
 }
 
@@ -55,7 +55,7 @@ __device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned shor
   for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      B.f[ks][j] = *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + (j * 4 + wave) * 16 + l15) * ldw + k0 + ks * 32 + l4 * 8);
+      B.f[ks][j] = fm_load(W, ldw, n0 + (j * 4 + wave) * 16, k0 + ks * 32, l4 * 16 + l15);
 }
 
 // acc[mt][j] (+)= X[mt-tile] . W[n-tile j]^T.  Operands are issued "swapped" (weight fragment as the MFMA A operand,

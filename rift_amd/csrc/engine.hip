@@ -430,6 +430,7 @@ float* points_encoder_fused(Fwd& f, const float* F, int Cin, int groups, int n, 
   q.gp = A_alloc<float>(c, (size_t)groups * 256);
   q.out = A_alloc<float>(c, (size_t)groups * 128);
   q.do_stats = f.train ? 1 : 0;
+  { const char* ev = getenv("RIFT_PE_TS"); if (ev && atoi(ev) == n) { q.ts = A_alloc<long long>(c, 64); q.ts_tile = 0; tap(c, "pe_ts", (float*)q.ts, 128); } }
   auto finalize = [&](const std::string& name, int C, const float* part, float* sc, float* sh) {
     const Param* nb = find(c, name + ".num_batches_tracked");
     launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(cdiv(C, 4)), dim3(256), 0, part, (const int*)q.cnt, ntiles, C,

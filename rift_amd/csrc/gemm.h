@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmP p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int nb = ncol0 + nt * 16;
-          if (nb < Npad) b[nt] = *reinterpret_cast<const bf16x8*>(W + (size_t)(nb + l15) * p.Kp + ks * 32 + l4 * 8);
+          if (nb < Npad) b[nt] = fm_load(W, p.Kp, nb, ks * 32, l4 * 16 + l15);   // fragment-major weight image (common.h)
           else b[nt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll

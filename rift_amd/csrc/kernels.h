@@ -29,7 +29,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* dst, int
       v = src[(size_t)(n + src_row_off) * src_ld + k];
     }
   }
-  if (BF16) reinterpret_cast<unsigned short*>(dst)[idx] = f2bf(v);
+  if (BF16) reinterpret_cast<unsigned short*>(dst)[fm_index(n, k, Kp)] = f2bf(v);   // fragment-major (common.h)
   else reinterpret_cast<float*>(dst)[idx] = v;
 }
 

@@ -51,7 +51,7 @@ __global__ void pack_qkv_headmajor_kernel(const float* __restrict__ w, const flo
   const int pr = idx / C, k = idx - pr * C;
   const int head = pr / 48, part = (pr % 48) / 16, d = pr % 16;
   const int src = part * C + head * 16 + d;
-  wo[idx] = f2bf(w[(size_t)src * C + k]);
+  wo[fm_index(pr, k, C)] = f2bf(w[(size_t)src * C + k]);   // fragment-major image
   if (k == 0) bo[pr] = b[src];
 }
 
@@ -71,7 +71,7 @@ __device__ __forceinline__ void load_b(BFrags<KS, NTW>& B, const unsigned short*
     const int nt = j * NW + wave;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      B.f[ks][j] = (nt < ntiles) ? *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + nt * 16 + l15) * ldw + k0 + ks * 32 + l4 * 8)
+      B.f[ks][j] = (nt < ntiles) ? fm_load(W, ldw, n0 + nt * 16, k0 + ks * 32, l4 * 16 + l15)
                                  : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
   }
 }

@@ -35,6 +35,8 @@ struct PeP {
   float* gp;                            // (rows / NPTS, 256)
   float* out;                           // (rows / NPTS, 128)
   int do_stats;
+  long long* ts;                        // optional phase timestamps of one workgroup (diagnostic)
+  int ts_tile;
 };
 
 template <int KS, int NTW>
@@ -47,7 +49,7 @@ __device__ __forceinline__ void p_load_w(PFrags<KS, NTW>& B, const unsigned shor
   for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      B.f[ks][j] = *reinterpret_cast<const bf16x8*>(W + (size_t)((j * NW + wave) * 16 + l15) * ldw + k0 + ks * 32 + l4 * 8);
+      B.f[ks][j] = fm_load(W, ldw, (j * NW + wave) * 16, k0 + ks * 32, l4 * 16 + l15);
 }
 
 // acc[mt][j][r] (+)= sum_k A[mt*16 + l15][k0 + k] * W[ntile*16 + 4*l4 + r][k0 + k]
@@ -176,6 +178,9 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
   constexpr int P_B1 = 0, P_S1 = 128, P_T1 = 256, P_B2 = 384, P_B3 = 640;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int tile = blockIdx.x, row0 = tile * PE_USED;
+  int tsn = 0;
+#define PTS() do { if (p.ts && tile == p.ts_tile && tid == 0) p.ts[tsn++] = clock64(); } while (0)
+  PTS();
 
   PFrags<1, 1> W1;
   PFrags<4, 2> Wa, Wb;
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
     return;
   }
 
+  PTS();
   // ---- h1 = relu(bn1(x W1^T + b1)) -> LDS bf16
   {
     f32x4 acc[MT][1];
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
                       fmaxf((acc[mt][0][2] + b.z) * s.z + t.z, 0.f), fmaxf((acc[mt][0][3] + b.w) * s.w + t.w, 0.f));
   }
   __syncthreads();
+  PTS();
 
   // ---- f = h1 W2^T + b2, invalid rows zero -> LDS bf16
   {
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
     }
   }
   __syncthreads();
+  PTS();
 
   // ---- f -> HBM (bf16, 16 B per lane), and the per-polyline max over its points
   for (int i = tid; i < PE_USED * 32; i += 512) {
@@ -259,6 +267,7 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
     }
   }
   __syncthreads();
+  PTS();
 
   // ---- gp = pooled W3b^T + b3 (one row per polyline)
   {
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
     }
   }
   __syncthreads();
+  PTS();
 
   // ---- g = f W3a^T + gp: only its statistics are needed here
   if (p.do_stats) {
@@ -291,6 +301,8 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
     pe_tile_stats<MT, 2, NW>(acc, sval, [&](float a, int row, int c) { return a + gpl[(row / NPTS) * 256 + c]; }, p.part2, 256, p.ntiles,
                              tile, wave, l15, l4);
   }
+  PTS();
+#undef PTS
 }
 
 // ---------------------------------------------------------------------------------------------------------------
