@@ -87,39 +87,42 @@ __device__ __forceinline__ void p_zero(f32x4 (&acc)[MT][NTW]) {
 template <int NT>
 __device__ __forceinline__ int pe_stage_x(const PeP& p, int tile, unsigned short* xin, unsigned char* sval, int tid) {
   const int row0 = tile * PE_USED;
-  int nvalid = 0;
-  for (int r = tid; r < PE_ROWS; r += NT) {
-    unsigned char fl = 0;
-    if (r < PE_USED && row0 + r < p.rows) fl = p.valid[row0 + r] ? 1 : 2;
-    sval[r] = fl;
-    nvalid += fl == 1;
-  }
-  for (int i = tid; i < PE_ROWS * 32; i += NT) {
+  // every global load of the phase is issued before the first LDS store (no load -> store round trips)
+  unsigned char fl = 0;
+  if (tid < PE_ROWS && tid < PE_USED && row0 + tid < p.rows) fl = p.valid[row0 + tid] ? 1 : 2;
+  constexpr int NX = PE_ROWS * 32 / NT;
+  float xv[NX];
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int i = tid + u * NT;
     const int r = i >> 5, k = i & 31;
-    float v = 0.f;
-    if (k < p.Cin && r < PE_USED && row0 + r < p.rows) v = p.F[(size_t)(row0 + r) * p.Cin + k];
-    xin[r * PE_XS + k] = f2bf(v);
+    xv[u] = 0.f;
+    if (k < p.Cin && r < PE_USED && row0 + r < p.rows) xv[u] = p.F[(size_t)(row0 + r) * p.Cin + k];
   }
-  return __syncthreads_count(nvalid);   // also the barrier after staging
+  if (tid < PE_ROWS) sval[tid] = fl;
+#pragma unroll
+  for (int u = 0; u < NX; ++u) { const int i = tid + u * NT; xin[(i >> 5) * PE_XS + (i & 31)] = f2bf(xv[u]); }
+  return __syncthreads_count(fl == 1);   // also the barrier after staging
 }
 
-// per-channel sum and sum of squares over the valid rows of the tile: acc layout as p_mma; every wave owns its columns
+// per-channel sum and sum of squares over the valid rows of the tile: acc layout as p_mma; every wave owns its columns.
+// addend(row, col) returns the four per-column terms added to acc[.][.][0..3] (bias / per-polyline term) as one float4.
 template <int MT, int NTW, int NW, class F>
-__device__ __forceinline__ void pe_tile_stats(const f32x4 (&acc)[MT][NTW], const unsigned char* sval, F&& value, float* part, int C,
+__device__ __forceinline__ void pe_tile_stats(const f32x4 (&acc)[MT][NTW], const unsigned char* sval, F&& addend, float* part, int C,
                                               int ntiles, int tile, int wave, int l15, int l4) {
+  bool ok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) ok[mt] = sval[mt * 16 + l15] == 1;
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int col = (j * NW + wave) * 16 + l4 * 4;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int row = mt * 16 + l15;
-      const bool ok = sval[row] == 1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = ok ? value(acc[mt][j][r], row, col + r) : 0.f;
-        s[r] += v; q[r] += v * v;
-      }
+      const float4 a = addend(mt * 16 + l15, col);
+      const float v0 = ok[mt] ? acc[mt][j][0] + a.x : 0.f, v1 = ok[mt] ? acc[mt][j][1] + a.y : 0.f;
+      const float v2 = ok[mt] ? acc[mt][j][2] + a.z : 0.f, v3 = ok[mt] ? acc[mt][j][3] + a.w : 0.f;
+      s[0] += v0; q[0] += v0 * v0; s[1] += v1; q[1] += v1 * v1; s[2] += v2; q[2] += v2 * v2; s[3] += v3; q[3] += v3 * v3;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s[r] = sum16(s[r]); q[r] = sum16(q[r]); }
@@ -139,7 +142,7 @@ __device__ __forceinline__ void pe_tile_stats(const f32x4 (&acc)[MT][NTW], const
 __global__ __launch_bounds__(256) void pe_stats1_kernel(PeP p) {
   __shared__ __attribute__((aligned(16))) unsigned short xin[PE_ROWS * PE_XS];
   __shared__ unsigned char sval[PE_ROWS];
-  __shared__ float b1s[128];
+  __shared__ __attribute__((aligned(16))) float b1s[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int tile = blockIdx.x;
   PFrags<1, 2> W1;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void pe_stats1_kernel(PeP p) {
   f32x4 acc[8][2];
   p_zero(acc);
   p_mma<8, 1, 2>(acc, xin, PE_XS, 0, W1, l15, l4);
-  pe_tile_stats<8, 2, 4>(acc, sval, [&](float a, int, int c) { return a + b1s[c]; }, p.part1, 128, p.ntiles, tile, wave, l15, l4);
+  pe_tile_stats<8, 2, 4>(acc, sval, [&](int, int c) { return *reinterpret_cast<const float4*>(b1s + c); }, p.part1, 128, p.ntiles, tile, wave, l15, l4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -186,9 +189,16 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
   PFrags<4, 2> Wa, Wb;
   p_load_w<NW, 1, 1>(W1, p.w1, 32, 0, wave, l15, l4);
   p_load_w<NW, 4, 2>(Wa, p.w2, 128, 0, wave, l15, l4);
-  for (int e = tid; e < 896; e += 512) {
-    const float* src = e < 128 ? p.b1 + e : e < 256 ? p.s1 + (e - 128) : e < 384 ? p.t1 + (e - 256) : e < 640 ? p.b2 + (e - 384) : p.b3 + (e - 640);
-    par[e] = *src;
+  {
+    float pv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * 512;
+      const float* src = e < 128 ? p.b1 + e : e < 256 ? p.s1 + (e - 128) : e < 384 ? p.t1 + (e - 256) : e < 640 ? p.b2 + (e - 384) : p.b3 + (e - 640);
+      pv[u] = e < 896 ? *src : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int e = tid + u * 512; if (e < 896) par[e] = pv[u]; }
   }
   for (int i = tid; i < 16 * PE_FS / 2; i += 512) reinterpret_cast<unsigned int*>(pool)[i] = 0u;
   const int nv = pe_stage_x<512>(p, tile, xin, sval, tid);
@@ -298,8 +308,8 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
     p_zero(acc);
     p_mma<MT, 4, 2>(acc, fl, PE_FS, 0, Wa, l15, l4);
     p_mma<MT, 4, 2>(acc, fl, PE_FS, 128, Wb, l15, l4);
-    pe_tile_stats<MT, 2, NW>(acc, sval, [&](float a, int row, int c) { return a + gpl[(row / NPTS) * 256 + c]; }, p.part2, 256, p.ntiles,
-                             tile, wave, l15, l4);
+    pe_tile_stats<MT, 2, NW>(acc, sval, [&](int row, int c) { return *reinterpret_cast<const float4*>(gpl + (GPT == 1 ? 0 : row / NPTS) * 256 + c); },
+                             p.part2, 256, p.ntiles, tile, wave, l15, l4);
   }
   PTS();
 #undef PTS
