@@ -38,8 +38,11 @@ struct DecFusedP {
 #define RIFT_DEC_NPAR 2944   // ln1..4 g,b (1024) | b_r2r 384 | b_r2ro 128 | b_m2m 384 | b_m2mo 128 | b_cq 128 | b_co 128 | b_f1 512 | b_f2 128
 #define RIFT_DEC_LDS_BYTES (80 * 132 * 4 + 80 * 136 * 2 * 2 + 80 * 200 * 2 + 96 * 72 * 2 + 64 * 104 * 2 + RIFT_DEC_NPAR * 4 + 96 + 96 + 16)
 
-__global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
+// NW waves per workgroup: one scene is one workgroup on one CU, so the wave count is the only occupancy lever
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   constexpr int ROWS = 80, MT = 5, C = 128, M = 12;
+  constexpr int NTH = 64 * NW, NTQ = (12 + NW - 1) / NW, NTC = 8 / NW;   // n-tiles per wave: 192-column chunk, 128-column output
   constexpr int XS = 132, XN = 136, CB = 200, KC = 72, VS = 104, NKT = 6;
   constexpr int P_LN = 0, P_BR2R = 1024, P_BR2RO = 1408, P_BM2M = 1536, P_BM2MO = 1920, P_BCQ = 2048, P_BCO = 2176,
                 P_BF1 = 2304, P_BF2 = 2816;
@@ -60,11 +63,12 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
   const size_t qrow0 = (size_t)b * NQ;
   const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
 
-  float pre[12];
+  constexpr int NPRE = (RIFT_DEC_NPAR + NTH - 1) / NTH;
+  float pre[NPRE];
   auto par_fetch = [&](const DecBlockW& w) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int e = tid + 256 * i;
+    for (int i = 0; i < NPRE; ++i) {
+      const int e = tid + NTH * i;
       const float* src;
       if (e < 1024) { const int k = e >> 7, c = e & 127; src = ((k & 1) ? w.ln_b[k >> 1] : w.ln_g[k >> 1]) + c; }
       else if (e < P_BR2RO) src = w.b_r2r + (e - P_BR2R);
@@ -80,22 +84,22 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
   };
   auto par_commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { const int e = tid + 256 * i; if (e < RIFT_DEC_NPAR) par[e] = pre[i]; }
+    for (int i = 0; i < NPRE; ++i) { const int e = tid + NTH * i; if (e < RIFT_DEC_NPAR) par[e] = pre[i]; }
   };
   par_fetch(p.blk[0]);
-  EFrags<4, 3> Bqkv;         // 192-column qkv chunk
-  EFrags<4, 2> Bw;           // 128-column projections / ffn.0 chunk
-  EFrags<4, 2> B2;           // ffn.3 partial
-  e_load_b(Bqkv, p.blk[0].w_r2r, C, 0, 0, wave, l15, l4);
+  EFrags<4, NTQ> Bqkv;       // 192-column qkv chunk
+  EFrags<4, NTC> Bw;         // 128-column projections / ffn.0 chunk
+  EFrags<4, NTC> B2;         // ffn.3 partial
+  e_load_b(Bqkv, p.blk[0].w_r2r, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
 
-  for (int i = tid; i < ROWS * 32; i += 256) {
+  for (int i = tid; i < ROWS * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < NQ) v = *reinterpret_cast<const float4*>(p.Q + (qrow0 + r) * C + c4);
     *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
   }
-  for (int i = tid; i < 96; i += 256) smask[i] = (i >= N) || p.kpm[(size_t)b * N + i];
-  for (int i = tid; i < 96; i += 256) {            // quirk: mode m of scene b uses the padding row of scene (b*12+m) % bs
+  for (int i = tid; i < 96; i += NTH) smask[i] = (i >= N) || p.kpm[(size_t)b * N + i];
+  for (int i = tid; i < 96; i += NTH) {            // quirk: mode m of scene b uses the padding row of scene (b*12+m) % bs
     const int m = i >> 3, r = i & 7;
     qmask[i] = (r >= R) || p.r_kpm[(size_t)((b * M + m) % p.bs) * R + r];
   }
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
     const int lr = lane & 31, rsub = lane >> 5;
     const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(be + lr * 4);
 #pragma unroll 2
-    for (int r = wave * 2 + rsub; r < ROWS; r += 8) {
+    for (int r = wave * 2 + rsub; r < ROWS; r += 2 * NW) {
       const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
       float s = group_sum<32>((v.x + v.y) + (v.z + v.w));
       const float mean = s * (1.0f / C);
@@ -119,10 +123,10 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
   };
 
   // x += dropout(acc + bias) for a 128-column projection held as acc[MT][2]; optional row zeroing (m2m)
-  auto residual_epilogue = [&](f32x4 (&acc)[MT][2], const float* bias, uint32_t stream, bool zero_padded) {
+  auto residual_epilogue = [&](f32x4 (&acc)[MT][NTC], const float* bias, uint32_t stream, bool zero_padded) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = (j * 4 + wave) * 16 + l4 * 4;
+    for (int j = 0; j < NTC; ++j) {
+      const int col = (j * NW + wave) * 16 + l4 * 4;
       const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
 
   // fp32 VALU self-attention over <= 12 keys of a (row, head) work item; q|k|v of head hh at cb[row][hh*96 + {0,32,64}]
   auto small_attention = [&](int ch, bool over_modes, uint32_t stream) {
-    for (int it = tid; it < NQ * 2; it += 256) {
+    for (int it = tid; it < NQ * 2; it += NTH) {
       const int hh = it & 1, row = it >> 1;
       const int r = row / M, m = row - r * M;
       const int nkeys = over_modes ? M : R;
@@ -197,15 +201,16 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
 
   // qkv chunk GEMM of a self-attention: cb[row][hh*96 + part*32 + d]; q pre-scaled; optional per-mode bias (m2m)
   auto qkv_chunk = [&](int ch, const float* bias, const float* mp) {
-    f32x4 acc[MT][3];
+    f32x4 acc[MT][NTQ];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    e_mma<MT, 4, 3>(acc, xn, XN, Bqkv, l15, l4);
+      for (int j = 0; j < NTQ; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    e_mma<MT, 4, NTQ>(acc, xn, XN, Bqkv, l15, l4);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int nt = j * 4 + wave;                          // 12 n-tiles: head (nt/6), part ((nt%6)/2), half (nt&1)
+    for (int j = 0; j < NTQ; ++j) {
+      const int nt = j * NW + wave;                         // 12 n-tiles: head (nt/6), part ((nt%6)/2), half (nt&1)
+      if (nt >= 12) continue;
       const int hh = nt / 6, part = (nt % 6) >> 1, half = nt & 1;
       const int col = nt * 16 + l4 * 4;
       const float4 b4 = *reinterpret_cast<const float4*>(bias + ch * 192 + col);
@@ -232,20 +237,20 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
     __syncthreads();
     for (int ch = 0; ch < 2; ++ch) {
       qkv_chunk(ch, par + P_BR2R, nullptr);
-      if (ch == 0) e_load_b(Bqkv, w.w_r2r, C, 192, 0, wave, l15, l4);
-      else e_load_b(Bw, w.w_r2ro, C, 0, 0, wave, l15, l4);
+      if (ch == 0) e_load_b(Bqkv, w.w_r2r, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
+      else e_load_b(Bw, w.w_r2ro, C, 0, 0, wave, l15, l4, EWaves<NW>());
       __syncthreads();
       small_attention(ch, false, st + 0);
       __syncthreads();
     }
     {
-      f32x4 acc[MT][2];
+      f32x4 acc[MT][NTC];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      e_mma<MT, 4, 2>(acc, ao, XN, Bw, l15, l4);
-      e_load_b(Bqkv, w.w_m2m, C, 0, 0, wave, l15, l4);
+        for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, NTC>(acc, ao, XN, Bw, l15, l4);
+      e_load_b(Bqkv, w.w_m2m, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
       residual_epilogue(acc, par + P_BR2RO, st + 1, false);
     }
     __syncthreads();
@@ -254,20 +259,20 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
     __syncthreads();
     for (int ch = 0; ch < 2; ++ch) {
       qkv_chunk(ch, par + P_BM2M, w.mp);
-      if (ch == 0) e_load_b(Bqkv, w.w_m2m, C, 192, 0, wave, l15, l4);
-      else e_load_b(Bw, w.w_m2mo, C, 0, 0, wave, l15, l4);
+      if (ch == 0) e_load_b(Bqkv, w.w_m2m, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
+      else e_load_b(Bw, w.w_m2mo, C, 0, 0, wave, l15, l4, EWaves<NW>());
       __syncthreads();
       small_attention(ch, true, st + 2);
       __syncthreads();
     }
     {
-      f32x4 acc[MT][2];
+      f32x4 acc[MT][NTC];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      e_mma<MT, 4, 2>(acc, ao, XN, Bw, l15, l4);
-      e_load_b(Bw, w.w_cq, C, 0, 0, wave, l15, l4);
+        for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, NTC>(acc, ao, XN, Bw, l15, l4);
+      e_load_b(Bw, w.w_cq, C, 0, 0, wave, l15, l4, EWaves<NW>());
       residual_epilogue(acc, par + P_BM2MO, st + 3, true);
     }
     __syncthreads();
@@ -275,16 +280,16 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
     layer_norm(par + P_LN + 512, par + P_LN + 640);
     __syncthreads();
     {
-      f32x4 acc[MT][2];
+      f32x4 acc[MT][NTC];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      e_mma<MT, 4, 2>(acc, xn, XN, Bw, l15, l4);
-      e_load_b(Bw, w.w_co, C, 0, 0, wave, l15, l4);
+        for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
+      e_load_b(Bw, w.w_co, C, 0, 0, wave, l15, l4, EWaves<NW>());
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = (j * 4 + wave) * 16 + l4 * 4;
+      for (int j = 0; j < NTC; ++j) {
+        const int col = (j * NW + wave) * 16 + l4 * 4;
         const float4 b4 = *reinterpret_cast<const float4*>(par + P_BCQ + col);
         const float sc = 0.17677669529663687f;
 #pragma unroll
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
     for (int ch = 0; ch < 2; ++ch) {
       __syncthreads();          // previous chunk's reads of kc / vtc (and the q writes) are complete
       // stream K (row-major) and V (transposed) of heads 2ch, 2ch+1 into LDS as bf16
-      for (int i = tid; i < 96 * 16; i += 256) {
+      for (int i = tid; i < 96 * 16; i += NTH) {
         const int key = i >> 4, c4 = (i & 15) * 4;
         float4 kq = make_float4(0.f, 0.f, 0.f, 0.f), vq = kq;
         if (key < N) {
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
         vtc[(c4 + 2) * VS + key] = f2bf(vq.z); vtc[(c4 + 3) * VS + key] = f2bf(vq.w);
       }
       __syncthreads();
-      for (int pr = wave; pr < 2 * MT; pr += 4) {            // (head, query tile) pairs
+      for (int pr = wave; pr < 2 * MT; pr += NW) {           // (head, query tile) pairs
         const int hh = pr / MT, qt = pr - hh * MT;
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + (qt * 16 + l15) * CB + (ch * 2 + hh) * 32 + l4 * 8);
         f32x4 s[NKT];
@@ -368,13 +373,13 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
     }
     __syncthreads();
     {
-      f32x4 acc[MT][2];
+      f32x4 acc[MT][NTC];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      e_mma<MT, 4, 2>(acc, ao, XN, Bw, l15, l4);
-      e_load_b(Bw, w.w_f1, C, 0, 0, wave, l15, l4);
+        for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, NTC>(acc, ao, XN, Bw, l15, l4);
+      e_load_b(Bw, w.w_f1, C, 0, 0, wave, l15, l4, EWaves<NW>());
       residual_epilogue(acc, par + P_BCO, st + 5, false);
     }
     __syncthreads();
@@ -383,24 +388,24 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
     if (li + 1 < 4) par_fetch(p.blk[li + 1]);
     __syncthreads();
     {
-      f32x4 acc2[MT][2];
+      f32x4 acc2[MT][NTC];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc2[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTC; ++j) acc2[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int hc = 0; hc < 4; ++hc) {
         {
-          f32x4 acc[MT][2];
+          f32x4 acc[MT][NTC];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          e_mma<MT, 4, 2>(acc, xn, XN, Bw, l15, l4);
-          e_load_b(B2, w.w_f2, 512, 0, hc * 128, wave, l15, l4);
+            for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
+          e_load_b(B2, w.w_f2, 512, 0, hc * 128, wave, l15, l4, EWaves<NW>());
           if (hc > 0) __syncthreads();
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int col = (j * 4 + wave) * 16 + l4 * 4;
+          for (int j = 0; j < NTC; ++j) {
+            const int col = (j * NW + wave) * 16 + l4 * 4;
             const float4 b4 = *reinterpret_cast<const float4*>(par + P_BF1 + hc * 128 + col);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -416,16 +421,16 @@ __global__ __launch_bounds__(256) void dec_fused_kernel(DecFusedP p) {
             }
           }
         }
-        if (hc + 1 < 4) e_load_b(Bw, w.w_f1, C, (hc + 1) * 128, 0, wave, l15, l4);
-        else if (li + 1 < 4) e_load_b(Bqkv, p.blk[li + 1].w_r2r, C, 0, 0, wave, l15, l4);
+        if (hc + 1 < 4) e_load_b(Bw, w.w_f1, C, (hc + 1) * 128, 0, wave, l15, l4, EWaves<NW>());
+        else if (li + 1 < 4) e_load_b(Bqkv, p.blk[li + 1].w_r2r, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
         __syncthreads();
-        e_mma<MT, 4, 2>(acc2, cb, CB, B2, l15, l4);
+        e_mma<MT, 4, NTC>(acc2, cb, CB, B2, l15, l4);
       }
       residual_epilogue(acc2, par + P_BF2, st + 7, false);
     }
     __syncthreads();
   }
-  for (int i = tid; i < ROWS * 32; i += 256) {
+  for (int i = tid; i < ROWS * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     if (r < NQ) *reinterpret_cast<float4*>(p.Q + (qrow0 + r) * C + c4) = *reinterpret_cast<const float4*>(xs + r * XS + c4);
   }

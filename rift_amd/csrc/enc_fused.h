@@ -48,14 +48,22 @@ __global__ void pack_rows_indexed_kernel(const float* __restrict__ src, const fl
 template <int KS, int NTW>
 struct EFrags { bf16x8 f[KS][NTW]; };
 
-template <int KS, int NTW>
+template <int NWV> struct EWaves {};
+// this wave's n-tiles are (j * NW + wave), j < NTW; tiles at or beyond `ntiles` are skipped (zero fragments)
+template <int KS, int NTW, int NW>
 __device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned short* W, int ldw, int n0, int k0, int wave,
-                                         int l15, int l4) {
+                                         int l15, int l4, EWaves<NW>, int ntiles = 1 << 30) {
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      B.f[ks][j] = fm_load(W, ldw, n0 + (j * 4 + wave) * 16, k0 + ks * 32, l4 * 16 + l15);
+      B.f[ks][j] = (j * NW + wave < ntiles) ? fm_load(W, ldw, n0 + (j * NW + wave) * 16, k0 + ks * 32, l4 * 16 + l15)
+                                            : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+}
+template <int KS, int NTW>
+__device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned short* W, int ldw, int n0, int k0, int wave,
+                                         int l15, int l4) {
+  e_load_b(B, W, ldw, n0, k0, wave, l15, l4, EWaves<4>());
 }
 
 // acc[mt][j] (+)= X[mt-tile] . W[n-tile j]^T.  Operands are issued "swapped" (weight fragment as the MFMA A operand,

@@ -25,6 +25,7 @@
 
 // fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
 // workgroups share a CU; 8 waves give a single resident workgroup two waves per SIMD)
+#define DEC_NW 8
 #define NAT_L0_NW 8
 #define NAT_L0_CW 192
 #define NAT_L1_NW 8
@@ -310,7 +311,7 @@ int set_lds_attrs(RiftCtx* c) {
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
   SETATTR(rollout_kernel);
   SETATTR(enc_fused_kernel);
-  SETATTR(dec_fused_kernel);
+  SETATTR(dec_fused_kernel<DEC_NW>);
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
   SETATTR(NAT_L2);
@@ -837,7 +838,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       gemm(c, mk(ENC, 128, nT, c->pw[p + ".cross_attn.kv"], KVl, 256), c->pw[p + ".cross_attn.kv"], f.fp32);
       w.mp = MPl; w.kv = KVl;
     }
-    launch(c, "dec_fused_kernel", dec_fused_kernel, dim3(bs), dim3(256), (size_t)RIFT_DEC_LDS_BYTES, dq);
+    launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
   } else {
   float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
   float* DAO = A_alloc<float>(c, (size_t)nQ * 128);
