@@ -22,7 +22,7 @@ struct DecBlockW {
   const unsigned short* w_f1;   const float* b_f1;     // ffn.0 [512][128]
   const unsigned short* w_f2;   const float* b_f2;     // ffn.3 [128][512]
   const float* mp;                                     // (12, 384) fp32: m_pos . Wqk^T in ORIGINAL column order (v part zero)
-  const float* kv;                                     // (bs*N, 256) fp32: cross-attention K | V projections of the encoder tokens
+  const float* kv;                                     // (bs*N, kv_ld) fp32: cross-attention K | V projections of the encoder tokens (256 columns of this layer)
 };
 
 struct DecFusedP {
@@ -30,6 +30,7 @@ struct DecFusedP {
   const uint8_t* kpm;           // (bs*N) encoder key padding
   const uint8_t* r_kpm;         // (bs*R) reference-line padding
   int bs, N, R;
+  int kv_ld;                    // row stride of the kv matrices (1024 when the four layers share one GEMM)
   DecBlockW blk[4];
   float dropout;                // 0.1 in train mode
   uint32_t seed, stream;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         const int key = i >> 4, c4 = (i & 15) * 4;
         float4 kq = make_float4(0.f, 0.f, 0.f, 0.f), vq = kq;
         if (key < N) {
-          const float* src = w.kv + ((size_t)b * N + key) * 256 + ch * 64 + c4;
+          const float* src = w.kv + ((size_t)b * N + key) * p.kv_ld + ch * 64 + c4;
           kq = *reinterpret_cast<const float4*>(src);
           vq = *reinterpret_cast<const float4*>(src + 128);
         }

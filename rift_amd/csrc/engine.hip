@@ -229,6 +229,38 @@ int pack_cols(RiftCtx* c, const std::string& key, const std::string& prefix, int
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != RIFT_OK) return rc__; } while (0)
 
+// rows [r0, r0+n) of `nsrc` (N_src, K) matrices stacked into one (nsrc*n, K) GEMM weight (+ stacked bias, engine-owned)
+int pack_stacked_rows(RiftCtx* c, const std::string& key, const std::vector<std::string>& wnames, const std::vector<std::string>& bnames,
+                      int r0, int n) {
+  const Param* w0 = find(c, wnames[0]);
+  if (!w0 || w0->ndim != 2) { c->err = "missing matrix " + wnames[0]; return RIFT_ERR_ARG; }
+  const int K = (int)w0->shape[1], ns = (int)wnames.size();
+  PW w;
+  w.N = ns * n; w.K = K; w.Kp = (K + 31) & ~31; w.Npad = (w.N + 15) & ~15;
+  if (n % 16) { c->err = "pack_stacked_rows: n % 16"; return RIFT_ERR_ARG; }
+  const size_t cnt = (size_t)w.Npad * w.Kp;
+  float* bias = nullptr;
+  HIPCHK(c, hipMalloc(&w.bf, cnt * 2));
+  HIPCHK(c, hipMalloc((void**)&w.f32, cnt * 4));
+  HIPCHK(c, hipMalloc((void**)&bias, (size_t)w.N * 4));
+  c->owned.push_back(w.bf); c->owned.push_back(w.f32); c->owned.push_back(bias);
+  for (int i = 0; i < ns; ++i) {
+    const Param* wi = find(c, wnames[i]);
+    const Param* bi = find(c, bnames[i]);
+    if (!wi || !bi || wi->shape[1] != K) { c->err = "missing matrix " + wnames[i]; return RIFT_ERR_ARG; }
+    const size_t off = (size_t)i * n * w.Kp;     // a 16-row block of a fragment-major image starts at the row-major offset of its first row
+    const int blocks = cdiv((long long)n * w.Kp, 256);
+    hipLaunchKernelGGL(pack_weight_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, (const float*)wi->data, (void*)((unsigned short*)w.bf + off),
+                       n, K, n, w.Kp, 0, 0, 0, r0, K);
+    hipLaunchKernelGGL(pack_weight_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, (const float*)wi->data, (void*)(w.f32 + off),
+                       n, K, n, w.Kp, 0, 0, 0, r0, K);
+    HIPCHK(c, hipMemcpyAsync(bias + (size_t)i * n, (const float*)bi->data + r0, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+  }
+  w.bias = bias;
+  c->pw[key] = w;
+  return RIFT_OK;
+}
+
 int pack_mlp_layer(RiftCtx* c, const std::string& p) { TRY(pack_linear(c, p + ".mlp.0")); return pack_linear(c, p + ".mlp.3"); }
 
 int pack_fourier(RiftCtx* c, const std::string& p, int D) {
@@ -814,6 +846,10 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     DecFusedP dq; memset(&dq, 0, sizeof(dq));
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
     dq.stream = f.next_stream(); f.stream_id += 64;
+    // the cross-attention K | V projections of all four layers read the same encoder output: one N = 1024 GEMM
+    float* KVall = A_alloc<float>(c, (size_t)nT * 1024);
+    gemm(c, mk(ENC, 128, nT, c->pw[PD + ".kv_all"], KVall, 1024), c->pw[PD + ".kv_all"], f.fp32);
+    dq.kv_ld = 1024;
     for (int i = 0; i < 4; ++i) {
       const std::string p = PD + ".decoder_blocks." + std::to_string(i);
       DecBlockW& w = dq.blk[i];
@@ -834,9 +870,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       bool fill_mp;
       float* MPl = wconst_get(c, p + ".mp", (size_t)M * 384, f.fp32, &fill_mp);
       if (fill_mp) gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MPl, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
-      float* KVl = A_alloc<float>(c, (size_t)nT * 256);
-      gemm(c, mk(ENC, 128, nT, c->pw[p + ".cross_attn.kv"], KVl, 256), c->pw[p + ".cross_attn.kv"], f.fp32);
-      w.mp = MPl; w.kv = KVl;
+      w.mp = MPl; w.kv = KVall + i * 256;
     }
     launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
   } else {
@@ -1107,6 +1141,14 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     TRY(pack_rows(c, p + ".cross_attn.kv", p + ".cross_attn.in_proj_weight", p + ".cross_attn.in_proj_bias", 128, 256, 256));
     TRY(pack_linear(c, p + ".cross_attn.out_proj"));
     TRY(pack_linear(c, p + ".ffn.0")); TRY(pack_linear(c, p + ".ffn.3"));
+  }
+  {
+    std::vector<std::string> wn, bn;
+    for (int i = 0; i < 4; ++i) {
+      wn.push_back(PD + ".decoder_blocks." + std::to_string(i) + ".cross_attn.in_proj_weight");
+      bn.push_back(PD + ".decoder_blocks." + std::to_string(i) + ".cross_attn.in_proj_bias");
+    }
+    TRY(pack_stacked_rows(c, PD + ".kv_all", wn, bn, 128, 256));
   }
   {  // chunk-ordered in_proj images of the two decoder self-attentions: per 2-head chunk (q|k|v of head a, q|k|v of head b)
     int idx[384];
