@@ -72,6 +72,24 @@ def cpu_baseline(scenes, sd, steps=6):
                       f"{dt:.1f}s", "steps_per_sec": n / dt}
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of the kernel behind an engine profiler label, from the committed PMC passes (None if absent)."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    kern = json.load(open(path))["kernels"]
+    nat = {"nat_level_kernel_L0": "nat_level_kernel<32,", "nat_level_kernel_L1": "nat_level_kernel<64,", "nat_level_kernel_L2": "nat_level_kernel<128,"}
+    key = nat.get(label, label.split(":")[0])
+    gemm = {"gemm_bf16_m1n8": "gemm_rows_kernel<true, 1, 8", "gemm_bf16_m4n2": "gemm_rows_kernel<true, 4, 2", "gemm_bf16_m2n6": "gemm_rows_kernel<true, 2, 6",
+            "gemm_bf16_m4n4": "gemm_rows_kernel<true, 4, 4"}
+    key = gemm.get(key, key)
+    hit = [v for k, v in kern.items() if key in k]
+    if not hit:
+        return None
+    n = sum(v["launches"] for v in hit)
+    return sum((2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 * v["launches"] for v in hit) / max(n, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +192,9 @@ def main():
         gemm_fl = sum(v["flops"] for k, v in rep.items() if k.startswith("gemm_"))
         ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12 if dom[1]["ms"] > 0 else 0.0
         roof = {"bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom[0]),
+                "traffic_source": "profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from separate rocprofv3 --pmc "
+                                  "passes of this bench (tools/profile_round.sh)",
                 "avg_launch_us": dom[1]["ms"] * 1e3 / dom[1]["count"], "launches_per_step": dom[1]["count"] / nprof,
                 "kernel_share_of_gpu_time": dom[1]["ms"] / tot_ms,
                 "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,

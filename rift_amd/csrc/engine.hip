@@ -635,7 +635,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       }
       { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == lv + 1) { p.ts = A_alloc<long long>(c, 256); tap(c, "nat_ts", (float*)p.ts, 512); } }
       const dim3 grid(cdiv(rows, 80));
-      (void)H; (void)ksz;
+      (void)H;
+      c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (lv == 0 ? 2.0 * rows * 27 * 32 : 0.0) + (lv < 2 ? (rows / 2) * 2.0 * 3 * C * 2 * C : 0.0);
       if (lv == 0) launch(c, "nat_level_kernel_L0", NAT_L0, grid, dim3(64 * NAT_L0_NW), nat_lds_bytes(32, 2, 3, NAT_L0_CW), p);
       else if (lv == 1) launch(c, "nat_level_kernel_L1", NAT_L1, grid, dim3(64 * NAT_L1_NW), nat_lds_bytes(64, 4, 3, NAT_L1_CW), p);
       else launch(c, "nat_level_kernel_L2", NAT_L2, grid, dim3(64 * NAT_L2_NW), nat_lds_bytes(128, 8, 5, NAT_L2_CW), p);
@@ -772,6 +773,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     }
     ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias");
     if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
+    c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
     launch(c, "enc_fused_kernel", enc_fused_kernel, dim3(bs), dim3(256), (size_t)RIFT_ENC_LDS_BYTES, ep);
   } else {
   float* QKV = A_alloc<float>(c, (size_t)nT * 384);
@@ -872,6 +874,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       if (fill_mp) gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MPl, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
       w.mp = MPl; w.kv = KVall + i * 256;
     }
+    // algorithmic FLOPs of the 4 layers on the padded (R x 12) query block, as the reference computes them
+    c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
     launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
   } else {
   float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
