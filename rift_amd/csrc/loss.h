@@ -198,15 +198,19 @@ __global__ void loss_kernel(LossP p) {
 // Backward through pi_head for a chunk of rows.  partial layout per workgroup (floats):
 //   [0,16384) dW1[c][k] | +128 db1 | +128 dgamma | +128 dbeta | +128 dw2 | +1 db2      (= 16897)
 #define RIFT_PI_NPARAM 16897
-#define RIFT_PI_BWD_ROWS 256
+#define RIFT_PI_BWD_ROWS 128
+// Rows are handled 16 lanes per row (8 channels per lane): the LayerNorm-backward reductions are DPP row sums, four
+// rows per wave in flight; dW1 += dh^T q accumulates an 8 x 8 register block per thread from LDS-staged 32-row slabs.
 __global__ __launch_bounds__(256) void pi_backward_kernel(
     const float* __restrict__ Q /*[rows][128] pi_head input*/, const float* __restrict__ Hpi /*[rows][128]*/,
     const float* __restrict__ dz /*[rows]*/, int rows, const float* __restrict__ g, const float* __restrict__ be,
     const float* __restrict__ w2, float eps, float* __restrict__ partial) {
-  __shared__ float s_dh[32][132];
-  __shared__ float s_q[32][132];
-  __shared__ float s_red[4][4][128];
+  __shared__ __attribute__((aligned(16))) float s_dh[32][132];
+  __shared__ __attribute__((aligned(16))) float s_q[32][132];
+  __shared__ float s_red[16][4][128];
+  __shared__ float s_db2[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, rsub = lane >> 4;
   const int r0 = blockIdx.x * RIFT_PI_BWD_ROWS;
   const int r1 = min(rows, r0 + RIFT_PI_BWD_ROWS);
   float accW[8][8];
@@ -214,43 +218,68 @@ __global__ __launch_bounds__(256) void pi_backward_kernel(
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) accW[i][j] = 0.f;
-  float a_db1[2] = {0.f, 0.f}, a_dg[2] = {0.f, 0.f}, a_dbe[2] = {0.f, 0.f}, a_dw2[2] = {0.f, 0.f};
+  float a_db1[8], a_dg[8], a_dbe[8], a_dw2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a_db1[i] = 0.f; a_dg[i] = 0.f; a_dbe[i] = 0.f; a_dw2[i] = 0.f; }
   float a_db2 = 0.f;
   const int c0 = (tid >> 4) * 8, k0 = (tid & 15) * 8;
-  const float g0 = g[lane], g1 = g[lane + 64], be0 = be[lane], be1 = be[lane + 64];
-  const float w20 = w2[lane], w21 = w2[lane + 64];
+  float gv[8], bv[8], wv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { gv[i] = g[l15 * 8 + i]; bv[i] = be[l15 * 8 + i]; wv[i] = w2[l15 * 8 + i]; }
   for (int base = r0; base < r1; base += 32) {
-    for (int rr = wave; rr < 32; rr += 4) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int rr = st * 16 + wave * 4 + rsub;
       const int row = base + rr;
-      float dh0 = 0.f, dh1 = 0.f, q0 = 0.f, q1 = 0.f;
-      if (row < r1) {
-        const float h0 = Hpi[(size_t)row * 128 + lane], h1 = Hpi[(size_t)row * 128 + 64 + lane];
-        q0 = Q[(size_t)row * 128 + lane]; q1 = Q[(size_t)row * 128 + 64 + lane];
-        const float d = dz[row];
-        const float mean = wave_sum(h0 + h1) * (1.f / 128.f);
-        const float e0 = h0 - mean, e1 = h1 - mean;
-        const float rstd = rsqrtf(wave_sum(e0 * e0 + e1 * e1) * (1.f / 128.f) + eps);
-        const float n0 = e0 * rstd, n1 = e1 * rstd;
-        const float y0 = n0 * g0 + be0, y1 = n1 * g1 + be1;
-        const float dy0 = y0 > 0.f ? d * w20 : 0.f, dy1 = y1 > 0.f ? d * w21 : 0.f;
-        a_dw2[0] += d * fmaxf(y0, 0.f); a_dw2[1] += d * fmaxf(y1, 0.f);
-        a_dg[0] += dy0 * n0; a_dg[1] += dy1 * n1;
-        a_dbe[0] += dy0; a_dbe[1] += dy1;
-        if (lane == 0) a_db2 += d;
-        const float dn0 = dy0 * g0, dn1 = dy1 * g1;
-        const float m1 = wave_sum(dn0 + dn1) * (1.f / 128.f);
-        const float m2 = wave_sum(dn0 * n0 + dn1 * n1) * (1.f / 128.f);
-        dh0 = rstd * (dn0 - m1 - n0 * m2); dh1 = rstd * (dn1 - m1 - n1 * m2);
-        a_db1[0] += dh0; a_db1[1] += dh1;
+      float dh[8], q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { dh[i] = 0.f; q[i] = 0.f; }
+      float hsum = 0.f, h[8], d = 0.f;
+      const bool live = row < r1;
+      if (live) {
+        const float4 h0 = *reinterpret_cast<const float4*>(Hpi + (size_t)row * 128 + l15 * 8), h1 = *reinterpret_cast<const float4*>(Hpi + (size_t)row * 128 + l15 * 8 + 4);
+        const float4 q0 = *reinterpret_cast<const float4*>(Q + (size_t)row * 128 + l15 * 8), q1 = *reinterpret_cast<const float4*>(Q + (size_t)row * 128 + l15 * 8 + 4);
+        h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
+        q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w; q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+        d = dz[row];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hsum += h[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = 0.f;
       }
-      s_dh[rr][lane] = dh0; s_dh[rr][lane + 64] = dh1;
-      s_q[rr][lane] = q0; s_q[rr][lane + 64] = q1;
+      // the reductions run for every lane (DPP needs full rows of 16 lanes); dead rows contribute zeros
+      const float mean = sum16(hsum) * (1.f / 128.f);
+      float e[8], vs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { e[i] = h[i] - mean; vs += e[i] * e[i]; }
+      const float rstd = rsqrtf(sum16(vs) * (1.f / 128.f) + eps);
+      float n[8], dn[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        n[i] = e[i] * rstd;
+        const float y = n[i] * gv[i] + bv[i];
+        const float dy = (live && y > 0.f) ? d * wv[i] : 0.f;
+        if (live) { a_dw2[i] += d * fmaxf(y, 0.f); a_dg[i] += dy * n[i]; a_dbe[i] += dy; }
+        dn[i] = dy * gv[i];
+        s1 += dn[i]; s2 += dn[i] * n[i];
+      }
+      if (live && l15 == 0) a_db2 += d;
+      const float m1 = sum16(s1) * (1.f / 128.f), m2 = sum16(s2) * (1.f / 128.f);
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dh[i] = rstd * (dn[i] - m1 - n[i] * m2); a_db1[i] += dh[i]; }
+      }
+      *reinterpret_cast<float4*>(&s_dh[rr][l15 * 8]) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+      *reinterpret_cast<float4*>(&s_dh[rr][l15 * 8 + 4]) = make_float4(dh[4], dh[5], dh[6], dh[7]);
+      *reinterpret_cast<float4*>(&s_q[rr][l15 * 8]) = make_float4(q[0], q[1], q[2], q[3]);
+      *reinterpret_cast<float4*>(&s_q[rr][l15 * 8 + 4]) = make_float4(q[4], q[5], q[6], q[7]);
     }
     __syncthreads();
     for (int rr = 0; rr < 32; ++rr) {
-      float dv[8], qv[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { dv[i] = s_dh[rr][c0 + i]; qv[i] = s_q[rr][k0 + i]; }
+      const float4 d0 = *reinterpret_cast<const float4*>(&s_dh[rr][c0]), d1 = *reinterpret_cast<const float4*>(&s_dh[rr][c0 + 4]);
+      const float4 q0 = *reinterpret_cast<const float4*>(&s_q[rr][k0]), q1 = *reinterpret_cast<const float4*>(&s_q[rr][k0 + 4]);
+      const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -262,20 +291,28 @@ __global__ __launch_bounds__(256) void pi_backward_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[(c0 + i) * 128 + k0 + j] = accW[i][j];
-  // cross-wave reduction of the per-channel vectors
-  s_red[wave][0][lane] = a_db1[0]; s_red[wave][0][lane + 64] = a_db1[1];
-  s_red[wave][1][lane] = a_dg[0];  s_red[wave][1][lane + 64] = a_dg[1];
-  s_red[wave][2][lane] = a_dbe[0]; s_red[wave][2][lane + 64] = a_dbe[1];
-  s_red[wave][3][lane] = a_dw2[0]; s_red[wave][3][lane + 64] = a_dw2[1];
-  __shared__ float s_db2[4];
-  if (lane == 0) s_db2[wave] = a_db2;
+    for (int j = 0; j < 8; ++j) out[(c0 + i) * 128 + k0 + j] = accW[i][j];   // (the 16897-float stride is not 16-byte aligned)
+  // reduction of the per-channel vectors over the 16 (wave, row-slot) groups
+  const int grp = wave * 4 + rsub;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s_red[grp][0][l15 * 8 + i] = a_db1[i]; s_red[grp][1][l15 * 8 + i] = a_dg[i];
+    s_red[grp][2][l15 * 8 + i] = a_dbe[i]; s_red[grp][3][l15 * 8 + i] = a_dw2[i];
+  }
+  if (l15 == 0) s_db2[grp] = a_db2;
   __syncthreads();
   for (int i = tid; i < 512; i += 256) {
     const int v = i >> 7, c = i & 127;
-    out[16384 + v * 128 + c] = s_red[0][v][c] + s_red[1][v][c] + s_red[2][v][c] + s_red[3][v][c];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += s_red[k][v][c];
+    out[16384 + v * 128 + c] = t;
   }
-  if (tid == 0) out[16384 + 512] = s_db2[0] + s_db2[1] + s_db2[2] + s_db2[3];
+  if (tid == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += s_db2[k];
+    out[16384 + 512] = t;
+  }
 }
 
 // flat[i] = sum_wg partial[wg][i]; stats[0] = sum S_b, stats[1] = sum cnt_b  (deterministic order)
@@ -284,9 +321,14 @@ __global__ void loss_reduce_kernel(const float* __restrict__ partial, int nwg, f
                                    double* __restrict__ stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < RIFT_PI_NPARAM) {
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * RIFT_PI_NPARAM + i];
-    flat[i] = s;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight loads in flight per thread; fixed summation order
+    int w = 0;
+    for (; w + 8 <= nwg; w += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += partial[(size_t)(w + u) * RIFT_PI_NPARAM + i];
+    }
+    for (; w < nwg; ++w) s[0] += partial[(size_t)w * RIFT_PI_NPARAM + i];
+    flat[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     double a = 0.0, c = 0.0;
