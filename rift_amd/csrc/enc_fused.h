@@ -92,8 +92,11 @@ __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
 #define RIFT_ENC_NPAR 1664   // per-layer vectors kept in LDS: ln1 g,b | ln2 g,b | bqkv 384 | bo 128 | b1 512 | b2 128
 #define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * 136 * 2 * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 128 + RIFT_ENC_NPAR * 4)
 
-__global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
   constexpr int ROWS = 96, MT = 6, C = 128;
+  constexpr int NTH = 64 * NW, NTQ = 12 / NW + (12 % NW ? 1 : 0), NTC = 8 / NW;   // n-tiles per wave: qkv chunk (12), 128-wide output (8)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int XS = 132, XN = 136, CB = 200, VS = 104, NKT = 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* xs = reinterpret_cast<float*>(smem_raw);
@@ -114,11 +117,12 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
 
   // Per-layer vectors are fetched into registers one layer ahead and dropped into LDS at the top of the layer, so
   // that no epilogue / LayerNorm starts with a dependent global load (each costs ~4k cycles at 1 workgroup per CU).
-  float pre[7];
+  constexpr int NPRE = (RIFT_ENC_NPAR + NTH - 1) / NTH;
+  float pre[NPRE];
   auto par_fetch = [&](const EncBlockW& w) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int e = tid + 256 * i;
+    for (int i = 0; i < NPRE; ++i) {
+      const int e = tid + NTH * i;
       const float* src = e < 128 ? w.ln1_g + e : e < 256 ? w.ln1_b + (e - 128) : e < 384 ? w.ln2_g + (e - 256)
                        : e < 512 ? w.ln2_b + (e - 384) : e < 896 ? w.bqkv + (e - 512) : e < 1024 ? w.bo + (e - 896)
                        : e < 1536 ? w.b1 + (e - 1024) : w.b2 + (e - 1536);
@@ -127,21 +131,21 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
   };
   auto par_commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) { const int e = tid + 256 * i; if (e < RIFT_ENC_NPAR) par[e] = pre[i]; }
+    for (int i = 0; i < NPRE; ++i) { const int e = tid + NTH * i; if (e < RIFT_ENC_NPAR) par[e] = pre[i]; }
   };
   par_fetch(p.blk[0]);
-  EFrags<4, 3> Bqkv;
-  EFrags<4, 2> Bw;       // out_proj / fc1 chunk (128 output columns, K = 128)
-  EFrags<4, 2> B2;       // fc2 partial (128 output columns, K = 128-wide hidden chunk)
-  e_load_b(Bqkv, p.blk[0].wqkv, C, 0, 0, wave, l15, l4);
+  EFrags<4, NTQ> Bqkv;
+  EFrags<4, NTC> Bw;     // out_proj / fc1 chunk (128 output columns, K = 128)
+  EFrags<4, NTC> B2;     // fc2 partial (128 output columns, K = 128-wide hidden chunk)
+  e_load_b(Bqkv, p.blk[0].wqkv, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
 
-  for (int i = tid; i < ROWS * 32; i += 256) {
+  for (int i = tid; i < ROWS * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < N) v = *reinterpret_cast<const float4*>(p.X + (grow0 + r) * C + c4);
     *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
   }
-  for (int i = tid; i < ROWS; i += 256) smask[i] = (i >= N) || p.kpm[grow0 + i];
+  for (int i = tid; i < ROWS; i += NTH) smask[i] = (i >= N) || p.kpm[grow0 + i];
   __syncthreads();
   TS();
 
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
     const int lr = lane & 31, rsub = lane >> 5;
     const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(be + lr * 4);
 #pragma unroll 2
-    for (int r = wave * 2 + rsub; r < ROWS; r += 8) {
+    for (int r = wave * 2 + rsub; r < ROWS; r += 2 * NW) {
       const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
       float s = (v.x + v.y) + (v.z + v.w);
       s = group_sum<32>(s);
@@ -178,17 +182,17 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
     TS();
     for (int ch = 0; ch < 2; ++ch) {
       {
-        f32x4 acc[MT][3];
+        f32x4 acc[MT][NTQ];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        e_mma<MT, 4, 3, 1>(acc, xn, XN, Bqkv, l15, l4);     // q|k tiles swapped (row-major stores), V tile plain (transposed stores)
-        if (ch == 0) e_load_b(Bqkv, w.wqkv, C, 192, 0, wave, l15, l4);
-        else e_load_b(Bw, w.wo, C, 0, 0, wave, l15, l4);
+          for (int j = 0; j < NTQ; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        e_mma<MT, 4, NTQ, 1>(acc, xn, XN, Bqkv, l15, l4);   // q|k tiles swapped (row-major stores), V tile (last j) plain (transposed stores)
+        if (ch == 0) e_load_b(Bqkv, w.wqkv, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
+        else e_load_b(Bw, w.wo, C, 0, 0, wave, l15, l4, EWaves<NW>());
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {       // n-tiles 0..7: q|k of the two heads -> cb[row][col..col+3]
-          const int nt = j * 4 + wave;
+        for (int j = 0; j < NTQ - 1; ++j) { // n-tiles 0..7: q|k of the two heads -> cb[row][col..col+3]
+          const int nt = j * NW + wave;
           const int col = nt * 16 + l4 * 4;
           const float4 b4 = *reinterpret_cast<const float4*>(par + P_BQKV + ch * 192 + col);
           const float sc = ((nt & 3) < 2) ? 0.17677669529663687f : 1.0f;   // q pre-scaled by 32^-0.5
@@ -197,20 +201,20 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
             *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
                 pack_bf16x4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
         }
-        {                                   // n-tiles 8..11: V -> vt[head][d][key..key+3]
+        if (wave < 4) {                     // n-tiles 8..11: V -> vt[head][d][key..key+3]
           const int nt = 8 + wave;
           const int hh = (nt - 8) >> 1, d = ((nt - 8) & 1) * 16 + l15;
           const float bias = par[P_BQKV + ch * 192 + nt * 16 + l15];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + mt * 16 + l4 * 4) =
-                pack_bf16x4(acc[mt][2][0] + bias, acc[mt][2][1] + bias, acc[mt][2][2] + bias, acc[mt][2][3] + bias);
+                pack_bf16x4(acc[mt][NTQ - 1][0] + bias, acc[mt][NTQ - 1][1] + bias, acc[mt][NTQ - 1][2] + bias, acc[mt][NTQ - 1][3] + bias);
         }
       }
       __syncthreads();
       TS();
       // ---- MFMA attention: 2 heads x 6 query tiles = 12 (head, tile) pairs, 3 per wave (see mha_mfma_kernel)
-      for (int pr = wave; pr < 12; pr += 4) {
+      for (int pr = wave; pr < 12; pr += NW) {
         const int hh = pr / 6, qt = pr - hh * 6;
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + (qt * 16 + l15) * CB + hh * 64 + l4 * 8);
         f32x4 s[NKT];
@@ -266,16 +270,16 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
     }
     // ---- out_proj + residual
     {
-      f32x4 acc[MT][2];
+      f32x4 acc[MT][NTC];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      e_mma<MT, 4, 2>(acc, ao, XN, Bw, l15, l4);
-      e_load_b(Bw, w.w1, C, 0, 0, wave, l15, l4);             // fc1 weights of hidden chunk 0
+        for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, NTC>(acc, ao, XN, Bw, l15, l4);
+      e_load_b(Bw, w.w1, C, 0, 0, wave, l15, l4, EWaves<NW>());             // fc1 weights of hidden chunk 0
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = (j * 4 + wave) * 16 + l4 * 4;
+      for (int j = 0; j < NTC; ++j) {
+        const int col = (j * NW + wave) * 16 + l4 * 4;
         const float4 b4 = *reinterpret_cast<const float4*>(par + P_BO + col);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -295,24 +299,24 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
     __syncthreads();
     TS();
     {
-      f32x4 acc2[MT][2];
+      f32x4 acc2[MT][NTC];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc2[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTC; ++j) acc2[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int hc = 0; hc < 4; ++hc) {
         {
-          f32x4 acc[MT][2];
+          f32x4 acc[MT][NTC];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          e_mma<MT, 4, 2>(acc, xn, XN, Bw, l15, l4);
-          e_load_b(B2, w.w2, 512, 0, hc * 128, wave, l15, l4);
+            for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
+          e_load_b(B2, w.w2, 512, 0, hc * 128, wave, l15, l4, EWaves<NW>());
           if (hc > 0) __syncthreads();   // previous chunk's fc2 reads of cb are complete
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int col = (j * 4 + wave) * 16 + l4 * 4;
+          for (int j = 0; j < NTC; ++j) {
+            const int col = (j * NW + wave) * 16 + l4 * 4;
             const float4 b4 = *reinterpret_cast<const float4*>(par + P_B1 + hc * 128 + col);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -321,16 +325,16 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
                               gelu_fast(acc[mt][j][3] + b4.w));
           }
         }
-        if (hc + 1 < 4) e_load_b(Bw, w.w1, C, (hc + 1) * 128, 0, wave, l15, l4);
-        else if (bi + 1 < 4) e_load_b(Bqkv, p.blk[bi + 1].wqkv, C, 0, 0, wave, l15, l4);
+        if (hc + 1 < 4) e_load_b(Bw, w.w1, C, (hc + 1) * 128, 0, wave, l15, l4, EWaves<NW>());
+        else if (bi + 1 < 4) e_load_b(Bqkv, p.blk[bi + 1].wqkv, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
         __syncthreads();
         TS();
-        e_mma<MT, 4, 2>(acc2, cb, CB, B2, l15, l4);
+        e_mma<MT, 4, NTC>(acc2, cb, CB, B2, l15, l4);
         TS();
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = (j * 4 + wave) * 16 + l4 * 4;
+      for (int j = 0; j < NTC; ++j) {
+        const int col = (j * NW + wave) * 16 + l4 * 4;
         const float4 b4 = *reinterpret_cast<const float4*>(par + P_B2 + col);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncFusedP p) {
   {
     const int lr = lane & 31, rsub = lane >> 5;
     const float4 g4 = *reinterpret_cast<const float4*>(p.norm_g + lr * 4), b4 = *reinterpret_cast<const float4*>(p.norm_b + lr * 4);
-    for (int r = wave * 2 + rsub; r < ROWS; r += 8) {
+    for (int r = wave * 2 + rsub; r < ROWS; r += 2 * NW) {
       const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
       float s = (v.x + v.y) + (v.z + v.w);
       s = group_sum<32>(s);

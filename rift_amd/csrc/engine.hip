@@ -26,6 +26,7 @@
 // fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
 // workgroups share a CU; 8 waves give a single resident workgroup two waves per SIMD)
 #define DEC_NW 8
+#define ENC_NW 8
 #define NAT_L0_NW 8
 #define NAT_L0_CW 192
 #define NAT_L1_NW 8
@@ -342,7 +343,7 @@ int set_lds_attrs(RiftCtx* c) {
   const int big = 160 * 1024;
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
   SETATTR(rollout_kernel);
-  SETATTR(enc_fused_kernel);
+  SETATTR(enc_fused_kernel<ENC_NW>);
   SETATTR(dec_fused_kernel<DEC_NW>);
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
@@ -774,7 +775,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias");
     if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
-    launch(c, "enc_fused_kernel", enc_fused_kernel, dim3(bs), dim3(256), (size_t)RIFT_ENC_LDS_BYTES, ep);
+    launch(c, "enc_fused_kernel", enc_fused_kernel<ENC_NW>, dim3(bs), dim3(64 * ENC_NW), (size_t)RIFT_ENC_LDS_BYTES, ep);
   } else {
   float* QKV = A_alloc<float>(c, (size_t)nT * 384);
   float* AO = A_alloc<float>(c, (size_t)nT * 128);
