@@ -33,7 +33,7 @@
 #define NAT_L1_CW 192
 #define NAT_L2_NW 8
 #define NAT_L2_CW 192
-#define NAT_L0 (rift::nat_level_kernel<32, 2, 20, 3, NAT_L0_NW, NAT_L0_CW>)
+#define NAT_L0 (rift::nat_level_kernel<32, 2, 20, 3, NAT_L0_NW, NAT_L0_CW, 4>)
 #define NAT_L1 (rift::nat_level_kernel<64, 4, 10, 3, NAT_L1_NW, NAT_L1_CW>)
 #define NAT_L2 (rift::nat_level_kernel<128, 8, 5, 5, NAT_L2_NW, NAT_L2_CW>)
 
@@ -81,7 +81,7 @@ struct RiftCtx {
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
   int* dec_idx = nullptr; bool dec_fused = true;
-  bool pe_fused = true; bool fo_fused = true;
+  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -635,7 +635,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         p.ds_g = fptr(c, dn + ".norm.weight"); p.ds_b = fptr(c, dn + ".norm.bias");
       }
       { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == lv + 1) { p.ts = A_alloc<long long>(c, 256); tap(c, "nat_ts", (float*)p.ts, 512); } }
-      const dim3 grid(cdiv(rows, 80));
+      // persistent workgroups (one per CU at 8 waves), each looping over row tiles with the next tile prefetched
+      const dim3 grid(std::min(cdiv(rows, 80), lv == 0 ? c->nat_grid0 : c->nat_grid));   // level 0 fits two workgroups per CU
       (void)H;
       c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (lv == 0 ? 2.0 * rows * 27 * 32 : 0.0) + (lv < 2 ? (rows / 2) * 2.0 * 3 * C * 2 * C : 0.0);
       if (lv == 0) launch(c, "nat_level_kernel_L0", NAT_L0, grid, dim3(64 * NAT_L0_NW), nat_lds_bytes(32, 2, 3, NAT_L0_CW), p);
@@ -1019,6 +1020,8 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_DEC_UNFUSED"); c->dec_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_UNFUSED"); c->pe_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
+  { const char* ev = getenv("RIFT_NAT_GRID0"); if (ev && atoi(ev) > 0) c->nat_grid0 = atoi(ev); }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }

@@ -117,8 +117,9 @@ constexpr size_t nat_lds_bytes(int C, int NHEAD, int KSZ, int CWMAX) {
 }
 
 // NW waves per workgroup (n-tiles and rows are dealt round-robin to the waves); CWMAX = widest qkv / hidden chunk
-template <int C, int NHEAD, int L, int KSZ, int NW = 4, int CWMAX = 192>
-__global__ __launch_bounds__(64 * NW) void nat_level_kernel(NatLevelP p) {
+// WPE = waves per SIMD the register allocation must leave room for (2 = one 8-wave workgroup per CU, 4 = two)
+template <int C, int NHEAD, int L, int KSZ, int NW = 4, int CWMAX = 192, int WPE = 1>
+__global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
   constexpr int ROWS = 80, MT = 5;
   constexpr int C3 = 3 * C;
   constexpr int NTH = 64 * NW;
@@ -148,10 +149,11 @@ __global__ __launch_bounds__(64 * NW) void nat_level_kernel(NatLevelP p) {
   float* par2 = par + 2 * NPAR;                             // fn_g C | fn_b C | ds_g 2C | ds_b 2C
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int row0 = blockIdx.x * ROWS;
   const int total_rows = p.nseq * L;
+  const int ntiles = (total_rows + ROWS - 1) / ROWS;
+  int row0 = blockIdx.x * ROWS;          // persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ...
   int tsn = 0;
-#define NTS() do { if (p.ts && blockIdx.x == 0 && tid == 0) p.ts[tsn++] = clock64(); } while (0)
+#define NTS() do { if (p.ts && blockIdx.x == 0 && tid == 0 && tsn < 250) p.ts[tsn++] = clock64(); } while (0)
   NTS();
 
   BFrags<KS1, NTW_CH> Bq;      // qkv / fc1 weights of the current chunk
@@ -190,63 +192,73 @@ __global__ __launch_bounds__(64 * NW) void nat_level_kernel(NatLevelP p) {
     for (int u = 0; u < NP2; ++u) { const int i = tid + u * NTH; if (i < 6 * C) par2[i] = pv[u]; }
   }
 
-  bool tokenized = false;
-  if constexpr (C == 32) tokenized = p.F9 != nullptr;
-  if constexpr (C == 32) if (tokenized) {
-    // ---- ConvTokenizer prologue: xs = conv1d(F9, k=3, pad 1) + b as one K=32 MFMA step over the 3x9 window
-    BFrags<1, NTW_C> Wt;
-    load_b(Wt, p.w_tok, 32, 0, 0, NT_C, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
-    float fv[ROWS * 32 / NTH];
+  constexpr bool tokenized = (C == 32);   // level 0 always starts from the agent features (p.F9) through the ConvTokenizer
+  // The tile's input is fetched into registers one tile ahead (issued in the middle of the previous tile's second block),
+  // so that no tile starts with an exposed HBM round trip.
+  constexpr int NFV = ROWS * 32 / NTH;                          // ConvTokenizer window values per thread (level 0)
+  constexpr int NV = (ROWS * (C / 4) + NTH - 1) / NTH;          // float4 of the residual tile per thread
+  float fv[tokenized ? NFV : 1];
+  float4 tv[tokenized ? 1 : NV];
+  BFrags<1, NTW_C> Wt;
+  if constexpr (tokenized) { load_b(Wt, p.w_tok, 32, 0, 0, NT_C, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>()); }
+  auto fetch_tile = [&](int r0) {
+    if constexpr (tokenized) {
 #pragma unroll
-    for (int u = 0; u < ROWS * 32 / NTH; ++u) {
-      const int i = tid + u * NTH;
-      const int r = i >> 5, kk = i & 31;
-      const int tap = kk / 9, cin = kk - tap * 9;
-      const int t = r % L, tt = t - 1 + tap;
-      fv[u] = 0.f;
-      if (kk < 27 && tt >= 0 && tt < L && row0 + r < total_rows) fv[u] = p.F9[(size_t)(row0 + r - t + tt) * 9 + cin];
+      for (int u = 0; u < NFV; ++u) {
+        const int i = tid + u * NTH;
+        const int r = i >> 5, kk = i & 31;
+        const int tap = kk / 9, cin = kk - tap * 9;
+        const int t = r % L, tt = t - 1 + tap;
+        fv[u] = 0.f;
+        if (kk < 27 && tt >= 0 && tt < L && r0 + r < total_rows) fv[u] = p.F9[(size_t)(r0 + r - t + tt) * 9 + cin];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int i = tid + u * NTH;
+        const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+        tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < ROWS * (C / 4) && r0 + r < total_rows) tv[u] = *reinterpret_cast<const float4*>(p.X + (size_t)(r0 + r) * C + c4);
+      }
     }
+  };
+  auto commit_tile = [&]() {       // registers -> xs (through the ConvTokenizer MFMA step on level 0); ends with a barrier
+    if constexpr (tokenized) {
+      {
+        // ---- ConvTokenizer prologue: xs = conv1d(F9, k=3, pad 1) + b as one K=32 MFMA step over the 3x9 window
 #pragma unroll
-    for (int u = 0; u < ROWS * 32 / NTH; ++u) { const int i = tid + u * NTH; xn[(i >> 5) * XN + (i & 31)] = f2bf(fv[u]); }
-    __syncthreads();
-    f32x4 acc[MT][NTW_C];
+        for (int u = 0; u < NFV; ++u) { const int i = tid + u * NTH; xn[(i >> 5) * XN + (i & 31)] = f2bf(fv[u]); }
+        __syncthreads();
+        f32x4 acc[MT][NTW_C];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < NTW_C; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mma80<1, NTW_C>(acc, xn, XN, Wt, l15, l4);
+          for (int j = 0; j < NTW_C; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma80<1, NTW_C>(acc, xn, XN, Wt, l15, l4);
 #pragma unroll
-    for (int j = 0; j < NTW_C; ++j) {
-      const int nt = j * NW + wave;
-      if (nt >= NT_C) continue;
-      const int col = nt * 16 + l4 * 4;
-      const float4 b4 = *reinterpret_cast<const float4*>(p.b_tok + col);
+        for (int j = 0; j < NTW_C; ++j) {
+          const int nt = j * NW + wave;
+          if (nt >= NT_C) continue;
+          const int col = nt * 16 + l4 * 4;
+          const float4 b4 = *reinterpret_cast<const float4*>(p.b_tok + col);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        *reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col) =
-            make_float4(acc[mt][j][0] + b4.x, acc[mt][j][1] + b4.y, acc[mt][j][2] + b4.z, acc[mt][j][3] + b4.w);
+          for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col) =
+                make_float4(acc[mt][j][0] + b4.x, acc[mt][j][1] + b4.y, acc[mt][j][2] + b4.z, acc[mt][j][3] + b4.w);
+        }
+        __syncthreads();
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int i = tid + u * NTH;
+        const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+        if (i < ROWS * (C / 4)) *reinterpret_cast<float4*>(xs + r * XS + c4) = tv[u];
+      }
+      __syncthreads();
     }
-  }
-  if (!tokenized) {
-    // ---- load the residual stream tile
-    constexpr int NV = (ROWS * (C / 4) + NTH - 1) / NTH;
-    float4 tv[NV];
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int i = tid + u * NTH;
-      const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-      tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < ROWS * (C / 4) && row0 + r < total_rows) tv[u] = *reinterpret_cast<const float4*>(p.X + (size_t)(row0 + r) * C + c4);
-    }
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int i = tid + u * NTH;
-      const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
-      if (i < ROWS * (C / 4)) *reinterpret_cast<float4*>(xs + r * XS + c4) = tv[u];
-    }
-  }
-  __syncthreads();
-  NTS();
+  };
+  fetch_tile(row0);
 
   // LayerNorm xs -> xn (bf16): C/4 lanes per row (16-byte LDS reads), xor-shuffle statistics
   auto layer_norm = [&](const float* g, const float* b) {
@@ -268,6 +280,10 @@ __global__ __launch_bounds__(64 * NW) void nat_level_kernel(NatLevelP p) {
     }
   };
 
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  row0 = tile * ROWS;
+  commit_tile();
+  NTS();
   for (int bi = 0; bi < 2; ++bi) {
     const NatBlockW& w = p.blk[bi];
     const float* pb = par + bi * NPAR;
@@ -391,6 +407,7 @@ __global__ __launch_bounds__(64 * NW) void nat_level_kernel(NatLevelP p) {
     NTS();
     // ======== MLP half ========
     if (!(p.dbg & 1)) layer_norm(pb + P_LN2G, pb + P_LN2B);
+    if (bi == 1 && tile + (int)gridDim.x < ntiles) fetch_tile((tile + (int)gridDim.x) * ROWS);
     __syncthreads();
     NTS();
     {
@@ -427,7 +444,7 @@ __global__ __launch_bounds__(64 * NW) void nat_level_kernel(NatLevelP p) {
         }
         // weights needed after this fc2: next hidden chunk's fc1, or the next block's qkv chunk 0
         if (ch + 1 < NCH) load_b(Bq, w.w1, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
-        else if (bi == 0) load_b(Bq, p.blk[1].wqkv, C, 0, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
+        else load_b(Bq, p.blk[1 - bi].wqkv, C, 0, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());   // next block, or block 0 of the next tile
         __syncthreads();
         NTS();
         // ---- fc2 partial: acc2 += cb[80][CWK] . W2[:, ch*CWK..]^T
@@ -543,6 +560,8 @@ __global__ __launch_bounds__(64 * NW) void nat_level_kernel(NatLevelP p) {
               make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
       }
     }
+  }
+  __syncthreads();   // xs / cb are re-used by the next tile
   }
   NTS();
 #undef NTS
