@@ -216,7 +216,7 @@ def main():
                                    "RIFT loss, pi_head trainable",
                        "per_gpu_batch": BATCH, "global_batch": BATCH * world, "replay_scenes_per_gpu": per_rank,
                        "parallelism": f"dp{world}", "train_mode": "dropout+droppath+state-dropout, BN batch stats",
-                       "outputs": "probability+hidden (trajectory heads are dead work for the RIFT loss)"},
+                       "outputs": "probability (the trajectory / prediction / hidden heads are dead outputs for the RIFT loss; see all_outputs)"},
             "whole_step_mfma_frac": scenes_per_sec / world * FLOPS_PER_SCENE / (PEAK_BF16_TFLOPS * 1e12),
             "all_outputs": {"ms_per_step": dt_all / args.steps * 1e3, "value": args.steps / dt_all * BATCH * world,
                             "note": "this rank's rate x N with the dead trajectory/prediction/ref-free heads also computed"},

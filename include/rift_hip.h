@@ -229,6 +229,30 @@ int rift_collate(RiftCtx* ctx, const RiftReplayArena* arena, const int32_t* scen
                  int R_out, const RiftFeatureBatch* out_batch /*caller-allocated*/, float* out_old_logits,
                  float* out_ref_logits, double* out_advantage, uint8_t* out_valid_mask, void* stream);
 
+/* ---- PPO critic (CriticPPO, rift/gym_carla/utils/net.py:420-431 with CriticBase :355-371; built with dims [256, 256],
+ * state_dim 128 by PPOPlutoModel, ppo_pluto.py:37 and planning/config/ppo_pluto.yaml:43-45).  All pointers are device fp32
+ * views onto the caller's parameters: net.{0,2,4}.{weight,bias}, state_avg / state_std (128), value_avg / value_std (1). */
+typedef struct RiftCritic {
+  const float *w0, *b0, *w1, *b1, *w2, *b2;
+  const float *state_avg, *state_std, *value_avg, *value_std;
+} RiftCritic;
+#define RIFT_CRITIC_NPARAM_C 99331   /* w0 256x128 | b0 256 | w1 256x256 | b1 256 | w2 256 | b2 1 | state_avg 128 | state_std 128 | value_avg 1 | value_std 1 */
+
+/* value[i] = value_net(state[i]) -- ppo_datamodule.py:137,149 (buffer sweeps) and ppo_trainer.py:175 */
+int rift_critic_forward(RiftCtx* ctx, const RiftCritic* w, const float* state /*(n,128)*/, int n, float* value /*(n)*/, void* stream);
+
+/* The value-loss half of get_ppo_loss (ppo_trainer.py:175-176,183): SmoothL1(value_net(state), reward_sum), mean reduction.
+ * Call after rift_loss_backward(kind = PPO) on the same stats: stats[0] -= sum_i SmoothL1_i (so that loss = -stats[0]/stats[1]
+ * is value_loss + actor_loss) and flat_grad_sum[RIFT_CRITIC_NPARAM_C] = -sum_i d SmoothL1_i / d theta (all-reduce-able sums). */
+int rift_critic_loss_backward(RiftCtx* ctx, const RiftCritic* w, const float* state /*(n,128)*/, const float* reward_sum /*(n)*/,
+                              int n, double* stats /*[2]*/, float* flat_grad_sum, void* stream);
+
+/* grads = -flat_grad_sum / stats[1] into the ten caller-owned .grad tensors (NULL = skip).  The four normalisation constants are
+ * included because the reference's freeze_parameters (ppo_trainer.py:84-96) makes every parameter of value_net trainable. */
+int rift_critic_finalize(RiftCtx* ctx, const float* flat_grad_sum, const double* stats, float* g_w0, float* g_b0, float* g_w1,
+                         float* g_b1, float* g_w2, float* g_b2, float* g_state_avg, float* g_state_std, float* g_value_avg,
+                         float* g_value_std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,10 @@ class RiftLossOut(C.Structure):
                                   "grad_w2", "grad_b2", "argmax_rm")]
 
 
+class RiftCritic(C.Structure):
+    _fields_ = [(n, vp) for n in ("w0", "b0", "w1", "b1", "w2", "b2", "state_avg", "state_std", "value_avg", "value_std")]
+
+
 class RiftReplayArena(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_scenes", "A", "Mp", "Rcap", "S", "T", "cs_ld")] + \
                [("scenes", RiftFeatureBatch)] + \
@@ -73,7 +77,11 @@ EXPORTS = [
     "rift_loss_finalize", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
+    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize",
 ]
+CRITIC_NPARAM = 99331
+CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
+               "state_avg", "state_std", "value_avg", "value_std")
 
 _lib = None
 
@@ -101,6 +109,9 @@ def load_library() -> C.CDLL:
     lib.rift_loss_backward.argtypes = [vp, C.c_int, C.POINTER(RiftLossIn), C.POINTER(RiftLossOut), vp]
     lib.rift_loss_finalize.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, vp]
     lib.rift_tap.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), vp]
+    lib.rift_critic_forward.argtypes = [vp, C.POINTER(RiftCritic), vp, C.c_int, vp, vp]
+    lib.rift_critic_loss_backward.argtypes = [vp, C.POINTER(RiftCritic), vp, vp, C.c_int, vp, vp, vp]
+    lib.rift_critic_finalize.argtypes = [vp] * 14
     lib.rift_op_linear.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     lib.rift_gae.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp]
     lib.rift_discounted_return.argtypes = [vp, vp, vp, C.c_double, C.c_int, vp, vp]
@@ -422,6 +433,40 @@ class Engine:
         self._check(self.lib.rift_rollout(self.ctx, C.byref(io), _stream()), "rift_rollout")
         self._keep_ro = (traj, cs)
         return out
+
+    # ---- PPO critic ----------------------------------------------------------------------------
+    @staticmethod
+    def critic_desc(sd: Dict[str, torch.Tensor]) -> "RiftCritic":
+        """Views onto a CriticPPO state_dict (net.{0,2,4}.{weight,bias}, state_avg/std, value_avg/std; device fp32)."""
+        w = RiftCritic()
+        keep = []
+        for f, k in (("w0", "net.0.weight"), ("b0", "net.0.bias"), ("w1", "net.2.weight"), ("b1", "net.2.bias"), ("w2", "net.4.weight"),
+                     ("b2", "net.4.bias"), ("state_avg", "state_avg"), ("state_std", "state_std"), ("value_avg", "value_avg"),
+                     ("value_std", "value_std")):
+            t = sd[k]
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise RuntimeError(f"critic parameter {k} must be a contiguous fp32 device tensor")
+            setattr(w, f, t.data_ptr())
+            keep.append(t)
+        w._keep = keep
+        return w
+
+    def critic_forward(self, sd: Dict[str, torch.Tensor], state: torch.Tensor) -> torch.Tensor:
+        st = _dev(state, torch.float32, self.device)
+        out = torch.empty(st.shape[0], dtype=torch.float32, device=self.device)
+        w = self.critic_desc(sd)
+        self._check(self.lib.rift_critic_forward(self.ctx, C.byref(w), _ptr(st), st.shape[0], _ptr(out), _stream()), "rift_critic_forward")
+        return out
+
+    def critic_loss_backward_raw(self, w: "RiftCritic", state: torch.Tensor, reward_sum: torch.Tensor, stats: torch.Tensor, flat: torch.Tensor):
+        rc = self.lib.rift_critic_loss_backward(self.ctx, C.byref(w), _ptr(state), _ptr(reward_sum), state.shape[0], _ptr(stats), _ptr(flat), _stream())
+        if rc != 0:
+            self._check(rc, "rift_critic_loss_backward")
+
+    def critic_finalize_raw(self, flat: torch.Tensor, stats: torch.Tensor, grads):
+        rc = self.lib.rift_critic_finalize(self.ctx, _ptr(flat), _ptr(stats), *[_ptr(g) for g in grads], _stream())
+        if rc != 0:
+            self._check(rc, "rift_critic_finalize")
 
     def gae(self, rewards, undones, values, next_values, unterminated, gamma=0.98, lambda_=0.98):
         dev = self.device

@@ -21,6 +21,7 @@
 #include "dec_fused.h"
 #include "pe_fused.h"
 #include "fourier_fused.h"
+#include "critic.h"
 #include "rollout.h"
 
 // fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
@@ -81,6 +82,7 @@ struct RiftCtx {
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
   int* dec_idx = nullptr; bool dec_fused = true;
+  float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
   bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
@@ -1043,6 +1045,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->ego_b) (void)hipFree(c->ego_b);
   if (c->enc_idx) (void)hipFree(c->enc_idx);
   if (c->dec_idx) (void)hipFree(c->dec_idx);
+  if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
   for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
@@ -1274,6 +1277,78 @@ int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void*
   launch(c, "loss_finalize_kernel", loss_finalize_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)out->flat_grad_sum,
          (const double*)out->stats, out->grad_w1, out->grad_b1, out->grad_ln_w, out->grad_ln_b, out->grad_w2, out->grad_b2,
          out->loss, accumulate);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+// ---- PPO critic ------------------------------------------------------------------------------------
+static int critic_scratch(RiftCtx* c, int n) {
+  const size_t need = (size_t)((n + 15) / 16 * 16) * (128 + 4 * 256 + 1 + 2 * 128 + 2);
+  if (need > c->cr_cap) {
+    if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
+    HIPCHK(c, hipMalloc((void**)&c->cr_buf, need * 4));
+    HIPCHK(c, hipMalloc((void**)&c->cr_part, (size_t)((n + 15) / 16) * 8));
+    c->cr_cap = need;
+  }
+  return RIFT_OK;
+}
+
+static CriticW critic_w(const RiftCritic* w) {
+  CriticW q;
+  q.w0 = w->w0; q.b0 = w->b0; q.w1 = w->w1; q.b1 = w->b1; q.w2 = w->w2; q.b2 = w->b2;
+  q.savg = w->state_avg; q.sstd = w->state_std; q.vavg = w->value_avg; q.vstd = w->value_std;
+  return q;
+}
+
+int rift_critic_forward(RiftCtx* c, const RiftCritic* w, const float* state, int n, float* value, void* stream) {
+  if (!c || !w || !state || !value || n < 0) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream; c->dry = false;
+  if (n == 0) return RIFT_OK;
+  CriticRowsP p; memset(&p, 0, sizeof(p));
+  p.w = critic_w(w); p.state = state; p.n = n; p.value = value;
+  launch(c, "critic_rows_kernel", critic_rows_kernel, dim3(cdiv(n, 16)), dim3(256), 0, p);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_critic_loss_backward(RiftCtx* c, const RiftCritic* w, const float* state, const float* reward_sum, int n, double* stats,
+                              float* flat, void* stream) {
+  if (!c || !w || !state || !reward_sum || !stats || !flat || n <= 0) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream; c->dry = false;
+  TRY(critic_scratch(c, n));
+  const int np = (n + 15) / 16 * 16, nwg = cdiv(n, 16);
+  CriticRowsP p; memset(&p, 0, sizeof(p));
+  p.w = critic_w(w); p.state = state; p.target = reward_sum; p.n = n;
+  p.sn = c->cr_buf; p.h1 = p.sn + (size_t)np * 128; p.h2 = p.h1 + (size_t)np * 256; p.dh1 = p.h2 + (size_t)np * 256;
+  p.dh2 = p.dh1 + (size_t)np * 256; p.dout = p.dh2 + (size_t)np * 256; p.sl1_part = c->cr_part;
+  p.gsa = p.dout + np; p.gss = p.gsa + (size_t)np * 128; p.gva = p.gss + (size_t)np * 128; p.gvs = p.gva + np;
+  launch(c, "critic_rows_kernel", critic_rows_kernel, dim3(nwg), dim3(256), 0, p);
+  // flat = -sum_rows d SmoothL1 / d theta: one thread per parameter, rows summed in order
+  launch(c, "critic_outer_sum_kernel", critic_outer_sum_kernel, dim3(cdiv(256 * 128, 256)), dim3(256), 0, (const float*)p.dh1, 256, (const float*)p.sn, 128, n, -1.f, flat);
+  launch(c, "critic_col_sum_kernel", critic_col_sum_kernel, dim3(1), dim3(256), 0, (const float*)p.dh1, 256, n, -1.f, flat + RIFT_CRITIC_OFF_B0);
+  launch(c, "critic_outer_sum_kernel", critic_outer_sum_kernel, dim3(cdiv(256 * 256, 256)), dim3(256), 0, (const float*)p.dh2, 256, (const float*)p.h1, 256, n, -1.f, flat + RIFT_CRITIC_OFF_W1);
+  launch(c, "critic_col_sum_kernel", critic_col_sum_kernel, dim3(1), dim3(256), 0, (const float*)p.dh2, 256, n, -1.f, flat + RIFT_CRITIC_OFF_B1);
+  launch(c, "critic_outer_sum_kernel", critic_outer_sum_kernel, dim3(1), dim3(256), 0, (const float*)p.dout, 1, (const float*)p.h2, 256, n, -1.f, flat + RIFT_CRITIC_OFF_W2);
+  launch(c, "critic_col_sum_kernel", critic_col_sum_kernel, dim3(1), dim3(64), 0, (const float*)p.dout, 1, n, -1.f, flat + RIFT_CRITIC_OFF_B2);
+  launch(c, "critic_col_sum_kernel", critic_col_sum_kernel, dim3(1), dim3(128), 0, (const float*)p.gsa, 128, n, -1.f, flat + RIFT_CRITIC_OFF_SAVG);
+  launch(c, "critic_col_sum_kernel", critic_col_sum_kernel, dim3(1), dim3(128), 0, (const float*)p.gss, 128, n, -1.f, flat + RIFT_CRITIC_OFF_SSTD);
+  launch(c, "critic_col_sum_kernel", critic_col_sum_kernel, dim3(1), dim3(64), 0, (const float*)p.gva, 1, n, -1.f, flat + RIFT_CRITIC_OFF_VAVG);
+  launch(c, "critic_col_sum_kernel", critic_col_sum_kernel, dim3(1), dim3(64), 0, (const float*)p.gvs, 1, n, -1.f, flat + RIFT_CRITIC_OFF_VSTD);
+  launch(c, "critic_stats_kernel", critic_stats_kernel, dim3(1), dim3(64), 0, (const double*)c->cr_part, nwg, stats);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_critic_finalize(RiftCtx* c, const float* flat, const double* stats, float* g_w0, float* g_b0, float* g_w1, float* g_b1,
+                         float* g_w2, float* g_b2, float* g_savg, float* g_sstd, float* g_vavg, float* g_vstd, void* stream) {
+  if (!c || !flat || !stats) return RIFT_ERR_ARG;
+  c->stream = (hipStream_t)stream; c->dry = false;
+  launch(c, "critic_finalize_kernel", critic_finalize_kernel, dim3(cdiv(RIFT_CRITIC_NPARAM, 256)), dim3(256), 0, flat, stats, g_w0, g_b0,
+         g_w1, g_b1, g_w2, g_b2, g_savg, g_sstd, g_vavg, g_vstd);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }

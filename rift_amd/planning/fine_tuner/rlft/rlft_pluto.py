@@ -204,7 +204,8 @@ class RLFTPluto(CBVBasePolicy):
         self.train_model.need_traj = False
         trainer = RLFTTrainer(self.train_model, kind=self.kind, lr=lr, cl_lr_decay=cfg["cl_lr_decay"],
                               weight_decay=cfg["weight_decay"], epochs=cfg["epochs"], warmup_epochs=cfg["warmup_epochs"],
-                              trainable_layers=tuple(cfg["trainable_layers"]), gradient_clip_val=cfg["gradient_clip_val"])
+                              trainable_layers=tuple(cfg["trainable_layers"]), gradient_clip_val=cfg["gradient_clip_val"],
+                              clip_epsilon=getattr(self, "clip_epsilon", 0.2), lambda_entropy=getattr(self, "lambda_entropy", 0.01))
         eng = trainer.engine
         replay = DeviceReplay(buffer_to_scenes(self.buffer), self.device)
         extras = self.preprocess_buffer(trainer, replay)
@@ -271,14 +272,69 @@ class ReinforcePluto(RLFTPluto):   # fine_tuner/rlft/reinforce_pluto/reinforce_p
         return {"returns": ret.float()}
 
 
-class PPOPluto(RLFTPluto):         # fine_tuner/rlft/ppo_pluto/ppo_pluto.py:43
+class PPOPluto(RLFTPluto):         # fine_tuner/rlft/ppo_pluto/ppo_pluto.py:40-120
     name, type, kind = 'ppo_pluto', 'learnable', 'ppo'
 
+    def __init__(self, config, logger):
+        super().__init__(config, logger)
+        ppo = dict(config.get('ppo', {}))
+        self.hidden_dim = list(ppo.get('hidden_dim', [256, 256]))      # planning/config/ppo_pluto.yaml:42-48
+        self.state_dim, self.action_dim = ppo.get('state_dim', 128), ppo.get('action_dim', 3)
+        self.clip_epsilon, self.lambda_entropy = ppo.get('clip_epsilon', 0.2), ppo.get('lambda_entropy', 0.01)
+        self.cfg["trainable_layers"] = ["planning_decoder.pi_head", "value_net"]   # ppo_training.yaml:26-28
+
+    def set_mode(self, mode):
+        self.mode = mode
+        if mode == 'train':
+            from rift_amd.planning.fine_tuner.rlft.ppo_pluto.ppo_pluto import PPOPlutoModel
+            self.train_model = PPOPlutoModel(radius=self.radius, state_dim=self.state_dim, action_dim=self.action_dim,
+                                             hidden_dim=self.hidden_dim, clip_epsilon=self.clip_epsilon,
+                                             lambda_entropy=self.lambda_entropy).to(self.device)
+            self.train_model.train()
+            self.pluto_model.eval()
+        elif mode == 'eval':
+            self.pluto_model.eval()
+        else:
+            raise ValueError(f'Unknown mode {mode}')
+
+    def _sweep(self, trainer, replay: DeviceReplay, seed0: int):
+        """hidden (n,128) and value (n) of every scene of `replay`, in chunks of the train batch size, model in train mode under
+        no_grad as in ppo_datamodule.py:127-150."""
+        eng, bs = trainer.engine, self.cfg["train_batch_size"]
+        hidden, value = [], []
+        for s in range(0, replay.n, bs):
+            idx = torch.arange(s, min(s + bs, replay.n), dtype=torch.int32, device=self.device)
+            fb, _ = replay.collate(eng, idx, int(replay.r_count_cpu[s:s + bs].max()))
+            h = trainer.forward_hidden(fb, seed0 + s // bs)
+            hidden.append(h.clone())
+            value.append(self.train_model.value_net(h))
+        return torch.cat(hidden), torch.cat(value)
+
     def preprocess_buffer(self, trainer, replay):
-        raise NotImplementedError(
-            "PPO actor loss / GAE scan / advantage normalisation run on the HIP engine (rift_loss_backward kind=PPO, rift_gae, "
-            "rift_normalize_advantage), but the CriticPPO value network (gym_carla/utils/net.py:420-431) and its two full-buffer "
-            "sweeps (ppo_datamodule.py:117-174) are not wired into this driver yet")
+        """ppo_datamodule.py:117-174: two full-buffer sweeps (current / next observation) -> GAE (gamma = lambda = 0.98) ->
+        reward_sum = advantage + value -> buffer-wide normalisation; all on the device."""
+        buf, eng = self.buffer, trainer.engine
+        rewards = torch.as_tensor(np.stack(buf.get_key_data('CBVs_reward'), axis=0)).double().view(-1)
+        undones = 1.0 - torch.as_tensor(np.stack(buf.get_key_data('CBVs_done'), axis=0)).float().view(-1)
+        unterm = 1.0 - torch.as_tensor(np.stack(buf.get_key_data('CBVs_terminated'), axis=0)).float().view(-1)
+        old_log_prob = torch.as_tensor(np.stack(buf.get_key_data('CBVs_actions_old_log_prob'), axis=0)).float().view(-1)
+        action_mode = torch.as_tensor(np.stack(buf.get_key_data('CBVs_actions_mode'), axis=0)).long().view(-1, 2)
+        state, value = self._sweep(trainer, replay, 1 << 20)
+        next_scenes = [{"feature": o['raw_pluto_feature'].data, "extras": replay_dummy_extras(o['raw_pluto_feature'].data)}
+                       for o in buf.get_key_data('CBVs_next_obs')]
+        _, next_value = self._sweep(trainer, DeviceReplay(next_scenes, self.device), 1 << 21)
+        adv = eng.gae(rewards, undones, value, next_value, unterm, self.cfg["gamma"], self.cfg["lambda_gae_adv"])
+        reward_sum = adv + value
+        adv = eng.normalize_advantage_(adv.clone())
+        dev = self.device
+        return {"state": state, "advantage": adv, "reward_sum": reward_sum, "old_log_prob": old_log_prob.to(dev),
+                "action_mode": action_mode.to(dev)}
+
+
+def replay_dummy_extras(feature):
+    R = feature["reference_line"]["position"].shape[0]
+    return {"group_advantage": torch.zeros(R, 12, dtype=torch.float64), "group_advantage_mask": torch.ones(R, 12, dtype=torch.bool),
+            "old_group_logits": torch.zeros(R, 12), "old_group_logits_mask": torch.ones(R, 12, dtype=torch.bool)}
 
 
 CBV_POLICY_LIST = {   # rift/cbv/planning/__init__.py:21-34 (RLFT entries)

@@ -110,10 +110,11 @@ class RLFTTrainer:
                  clip_epsilon=0.2, lambda_entropy=0.01):
         if kind not in _ffi.LOSS_KINDS:
             raise ValueError(kind)
-        if tuple(trainable_layers) != (PI_HEAD,):
+        want = (PI_HEAD, "value_net") if kind == "ppo" else (PI_HEAD,)
+        if tuple(trainable_layers) != want:
             raise NotImplementedError(
-                "the HIP backward covers the reference's configured trainable set "
-                "['planning_decoder.pi_head'] (rift_training.yaml:26-27); other layers are not implemented")
+                "the HIP backward covers the reference's configured trainable sets: ['planning_decoder.pi_head'] "
+                "(rift_training.yaml:26-27) and, for PPO, ['planning_decoder.pi_head', 'value_net'] (ppo_training.yaml:26-28)")
         self.model, self.kind, self.kind_id = model, kind, _ffi.LOSS_KINDS[kind]
         self.lr, self.epochs, self.warmup_epochs = lr, epochs, warmup_epochs
         self.gradient_clip_val = gradient_clip_val
@@ -130,6 +131,17 @@ class RLFTTrainer:
         for p in self.params.values():
             p.grad = torch.zeros_like(p)
         self.train_params = list(self.params.values())
+        # PPO: the critic (every parameter of value_net is trainable in the reference, normalisation constants included)
+        self.critic = None
+        if kind == "ppo":
+            vn = dict(model.named_modules())["value_net"]
+            self.critic = {k: dict(vn.named_parameters())[k] for k in _ffi.CRITIC_KEYS}
+            for p in self.critic.values():
+                p.grad = torch.zeros_like(p)
+            self.train_params += list(self.critic.values())
+            self.flat_c = torch.zeros(_ffi.CRITIC_NPARAM, dtype=torch.float32, device=dev)
+            self.critic_desc = self.engine.critic_desc(self.critic)
+            vn.bind(self.engine)
         # exchange buffers of the DP path (see dp_all_reduce)
         self.flat = torch.zeros(_ffi.PI_NPARAM, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -157,7 +169,9 @@ class RLFTTrainer:
             self._prob = torch.empty(bs, R, 12, device=dev)
             self._hidden = torch.empty(bs, 128, device=dev)
             self._argmax = torch.zeros(bs, 2, dtype=torch.int64, device=dev)
-            self.out.probability, self.out.hidden = self._prob.data_ptr(), self._hidden.data_ptr()
+            # `hidden` (pluto_model.py:173-176) feeds only PPO's critic; the other objectives never read it
+            self.out.probability = self._prob.data_ptr()
+            self.out.hidden = self._hidden.data_ptr() if (self.kind == "ppo" or getattr(self.model, "need_traj", False)) else None
             self.lo.argmax_rm = self._argmax.data_ptr()
             self._traj = None
         if getattr(self.model, "need_traj", False) and self._traj is None:
@@ -193,15 +207,30 @@ class RLFTTrainer:
         eng.forward_raw(fb, self.out, flags, self.step_count)
         self.set_loss_inputs(extras)
         eng.loss_backward_raw(self.kind_id, self.li, self.lo)
+        if self.critic is not None:   # value loss half of get_ppo_loss (ppo_trainer.py:175-176,183)
+            eng.critic_loss_backward_raw(self.critic_desc, extras["state"], extras["reward_sum"], self.stats, self.flat_c)
         if self.pg is not None and self.world > 1:
             dp_all_reduce(self.flat, self.stats, self.pg)
+            if self.critic is not None:
+                torch.distributed.all_reduce(self.flat_c, group=self.pg)
         if backward:
             eng.loss_finalize_raw(self.lo, 0)
+            if self.critic is not None:
+                eng.critic_finalize_raw(self.flat_c, self.stats, [p.grad for p in self.critic.values()])
         else:   # validation: loss only, the .grad buffers are left untouched
             lv = _ffi.RiftLossOut()
             lv.loss, lv.stats, lv.flat_grad_sum = self.lo.loss, self.lo.stats, self.lo.flat_grad_sum
             eng.loss_finalize_raw(lv, 0)
         return self.loss
+
+    def forward_hidden(self, fb: "_ffi.RiftFeatureBatch", seed: int) -> torch.Tensor:
+        """Train-mode forward for the PPO buffer sweeps: returns the `hidden` output (bs, 128) (pluto_model.py:173-176)."""
+        self._A = fb.A
+        self._outputs(fb.bs, fb.R)
+        flags = _ffi.F_TRAIN | (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | \
+                (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0)
+        self.engine.forward_raw(fb, self.out, flags, seed)
+        return self._hidden[:fb.bs]
 
     def training_step(self, fb, extras):
         """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step)."""

@@ -261,7 +261,7 @@ class PlanningModel(TorchModuleWrapper):
     # ---- engine binding -----------------------------------------------------------------------
     def _tensor_version(self):
         return tuple((p.data_ptr(), p._version) for n, p in list(self.named_parameters()) + list(self.named_buffers())
-                     if not n.startswith("planning_decoder.pi_head."))
+                     if not n.startswith("planning_decoder.pi_head.") and not n.startswith("value_net."))
 
     def engine(self):
         """Bind (or re-bind after load_state_dict / .to()) the parameter storage to the HIP context.
@@ -275,7 +275,7 @@ class PlanningModel(TorchModuleWrapper):
             self._bound_version = None
         ver = self._tensor_version()
         if ver != self._bound_version:
-            sd = {k: v for k, v in self.state_dict(keep_vars=True).items()}
+            sd = {k: v for k, v in self.state_dict(keep_vars=True).items() if not k.startswith("value_net.")}
             self._engine.load_state_dict({k: v.data for k, v in sd.items()})
             self._bound_version = self._tensor_version()
         return self._engine

@@ -278,10 +278,52 @@ def gen_rollout():
     print("rollout ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB")
 
 
+# ------------------------------------------------------------------------------------------
+# PPO critic fixture: the reference's CriticPPO (gym_carla/utils/net.py:420-431) and its full get_ppo_loss
+# (ppo_trainer.py:161-183: SmoothL1 value loss + clipped actor loss + entropy) with autograd gradients of value_net
+# ------------------------------------------------------------------------------------------
+def gen_critic():
+    import types
+    import torch.nn as nn
+    from tests.helpers import critic_inputs, critic_weights
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_net", os.path.join(ref_loader.REF_ROOT, "rift/gym_carla/utils/net.py"))
+    net = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(net)
+    critic = net.CriticPPO(dims=[256, 256], state_dim=128, action_dim=3)    # ppo_pluto.yaml:43-45
+    critic.load_state_dict(critic_weights(), strict=True)
+    for p_ in critic.parameters():      # what freeze_parameters(["planning_decoder.pi_head", "value_net"]) does (ppo_trainer.py:84-96):
+        p_.requires_grad = True         # EVERY parameter of value_net becomes trainable, state_avg/std and value_avg/std included
+    inp = critic_inputs()
+    out = {}
+    with torch.no_grad():
+        out["value"] = critic(inp["state"]).numpy()
+    ns = types.SimpleNamespace(clip_epsilon=0.2, lambda_entropy=0.01, value_criterion=nn.SmoothL1Loss(),
+                               model=types.SimpleNamespace(value_net=critic))
+    prob = inp["probability"].clone().requires_grad_(True)
+    pm = prob.masked_fill(inp["r_pad"].unsqueeze(-1), -1e8)                 # ppo_trainer.py:133
+    b = {"state_torch": inp["state"], "advantage_torch": inp["advantage"], "reward_sum_torch": inp["reward_sum"],
+         "old_log_prob_torch": inp["old_log_prob"]}
+    loss = _load_ppo_loss_fn()(ns, pm, inp["action_mode"], b)
+    loss.backward()
+    out["loss"] = loss.detach().double().numpy()
+    out["value_loss"] = nn.SmoothL1Loss()(critic(inp["state"]), inp["reward_sum"]).detach().double().numpy()
+    out["dprobability"] = prob.grad.numpy()
+    for n_, p_ in critic.named_parameters():
+        if p_.grad is not None:
+            out["grad." + n_] = p_.grad.numpy()
+    path = os.path.join(HERE, "ppo_critic.npz")
+    np.savez_compressed(path, **out)
+    print("ppo critic ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", float(out["loss"]), float(out["value_loss"]))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rollout":
         gen_rollout()
+    elif len(sys.argv) > 1 and sys.argv[1] == "critic":
+        gen_critic()
     else:
         main()
         gen_advantage()
         gen_rollout()
+        gen_critic()

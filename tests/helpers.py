@@ -107,3 +107,30 @@ def rollout_inputs(seed=777, R=3, M=12, T=80):
         ref_ang.append(ang.float().contiguous())
     state = {"pos": (10.0, -5.0), "heading": 0.3, "speed": 6.0, "width": 2.0, "length": 4.6}
     return traj, ref_pos, ref_ang, state
+
+
+# ---- PPO critic fixture inputs (tests/golden/ppo_critic.npz was generated from these by gen_golden.gen_critic) ----
+def critic_inputs(n=48, R=3, M=12, seed=515):
+    """Seeded PPO minibatch: logits (n,R,M) with the last reference line of odd scenes padded, critic state (n,128)."""
+    g = torch.Generator().manual_seed(seed)
+    prob = torch.randn(n, R, M, generator=g)
+    r_pad = torch.zeros(n, R, dtype=torch.bool)
+    r_pad[1::2, R - 1] = True
+    state = torch.randn(n, 128, generator=g)
+    return {"probability": prob, "r_pad": r_pad, "state": state,
+            "advantage": torch.randn(n, generator=g), "reward_sum": torch.randn(n, generator=g) * 2.0,
+            "old_log_prob": -3.0 + 0.3 * torch.randn(n, generator=g),
+            "action_mode": torch.stack([torch.randint(0, R - 1, (n,), generator=g), torch.randint(0, M, (n,), generator=g)], 1)}
+
+
+def critic_weights(seed=77):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i, (o, k) in zip((0, 2, 4), ((256, 128), (256, 256), (1, 256))):
+        sd[f"net.{i}.weight"] = torch.randn(o, k, generator=g) / k ** 0.5
+        sd[f"net.{i}.bias"] = 0.1 * torch.randn(o, generator=g)
+    sd["state_avg"] = 0.2 * torch.randn(128, generator=g)
+    sd["state_std"] = 0.5 + torch.rand(128, generator=g)
+    sd["value_avg"] = torch.tensor([0.3])
+    sd["value_std"] = torch.tensor([1.7])
+    return sd

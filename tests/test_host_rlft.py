@@ -75,6 +75,25 @@ def test_policy_registry_and_lr_schedule():
         sch.step()
 
 
+PPO_KEYS = ['CBVs_obs', 'CBVs_next_obs', 'CBVs_reward', 'CBVs_done', 'CBVs_terminated', 'CBVs_actions_old_log_prob', 'CBVs_actions_mode']
+
+
+def _filled_ppo_buffer(n):
+    buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': n, 'data_keys': PPO_KEYS})
+    t = 0
+    while not buf.buffer_full:
+        for k in range(8):
+            s, s2 = (syn.make_scene(t + j, num_agents=12, num_polygons=8, r_min=1, r_max=3) for j in (0, 1))
+            ex = s["extras"]
+            d = {'CBV_ids': [[3]], 'CBVs_obs': [{3: {'raw_pluto_feature': PlutoFeature(data=s["feature"])}}],
+                 'CBVs_next_obs': [{3: {'raw_pluto_feature': PlutoFeature(data=s2["feature"])}}],
+                 'CBVs_reward': [{3: float(ex["return"])}], 'CBVs_done': [{3: k == 7}], 'CBVs_terminated': [{3: k == 7 and t % 16 == 7}],
+                 'CBVs_actions_old_log_prob': [{3: np.float32(ex["old_log_prob"])}], 'CBVs_actions_mode': [{3: ex["action_mode"].numpy()}]}
+            buf.store(d)
+            t += 1
+    return buf
+
+
 def _filled_buffer(n, with_ref):
     keys = [k for k in KEYS if with_ref or k != 'CBVs_actions_ref_group_logits']
     buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': n, 'data_keys': keys})
@@ -94,6 +113,39 @@ def _filled_buffer(n, with_ref):
             buf.store(d)
             t += 1
     return buf
+
+
+@pytest.mark.gpu
+def test_ppo_train_updates_pi_head_and_critic(tmp_path):
+    """PPOPluto.train(e_i): two buffer sweeps + GAE + normalisation on the device, then epochs of actor + critic steps;
+    the checkpoint carries value_net.*, the inference model ignores it (pluto.py:130-133)."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    cfg = {'num_scenario': 1, 'ROOT_DIR': str(tmp_path), 'model_path': 'ckpt', 'device': 'cuda:0',
+           'rlft': {'epochs': 2, 'warmup_epochs': 1, 'train_batch_size': 16, 'val_batch_size': 16, 'lr': 1e-3}}
+    pol = CBV_POLICY_LIST['ppo_pluto'](cfg, None)
+    pol.load_model(resume=True)
+    pol.set_mode('train')
+    torch.manual_seed(0)
+    with torch.no_grad():
+        for p in pol.train_model.parameters():
+            if p.dim() > 1:
+                p.normal_(0, 0.05)
+    pol.pluto_model.load_state_dict({k: v for k, v in pol.train_model.state_dict().items() if not k.startswith("value_net")})
+    before = {k: v.detach().clone() for k, v in pol.train_model.state_dict().items()}
+    pol.set_buffer(_filled_ppo_buffer(48))
+    fit = pol.train(3)
+    assert len(fit["history"]) == 2 and all(np.isfinite(h["train_loss"]) and np.isfinite(h["val_loss"]) for h in fit["history"])
+    sd = torch.load(fit["checkpoint"], weights_only=False)["state_dict"]
+    assert any(k.startswith("model.value_net.net.0") for k in sd) and "model.value_net.state_avg" in sd
+    after = pol.train_model.state_dict()
+    changed = {k for k in before if not torch.equal(before[k].cpu(), after[k].cpu()) and "num_batches_tracked" not in k}
+    assert any(k.startswith("planning_decoder.pi_head") for k in changed)
+    for k in ("value_net.net.0.weight", "value_net.net.4.bias", "value_net.state_std", "value_net.value_avg"):
+        assert k in changed, k           # every value_net parameter trains (the reference's freeze_parameters quirk)
+    for k in changed:
+        assert k.startswith("planning_decoder.pi_head") or k.startswith("value_net.") or "running_" in k, k
+    assert not any(k.startswith("value_net") for k in pol.pluto_model.state_dict())
 
 
 @pytest.mark.gpu
