@@ -22,6 +22,7 @@
 #include "pe_fused.h"
 #include "fourier_fused.h"
 #include "critic.h"
+#include "fpn_fused.h"
 #include "rollout.h"
 
 // fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
@@ -83,7 +84,7 @@ struct RiftCtx {
   float* dec_bqkv[4][2] = {};
   int* dec_idx = nullptr; bool dec_fused = true;
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
-  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30;
+  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -365,6 +366,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR_N(pe_out_kernel<20>, PE_OUT_LDS);
   SETATTR_N(pe_out_kernel<120>, PE_OUT_LDS);
   SETATTR_N(fourier_fused_kernel, FO_LDS);
+  SETATTR_N(fpn_tail_kernel, FPN_LDS);
 #undef SETATTR_N
   return RIFT_OK;
 }
@@ -685,19 +687,31 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
                1e-5f, 0);
   }
   // FPN restricted to what out[:, :, -1] depends on
-  float* lat[3];
-  for (int i = 0; i < 3; ++i) {
-    lat[i] = A_alloc<float>(c, (size_t)nA * 2 * 128);
-    const std::string lc = HE + ".lateral_convs." + std::to_string(i);
-    GemmP g = mk(Oc[i], Cl[i], nA * 2, c->pw[lc], lat[i], 128);
-    g.amode = AMODE_CONV3; g.cv_C = Cl[i]; g.cv_Lin = 3; g.cv_nout = 2; g.cv_t0 = 1; g.cv_stride = 1;
-    gemm(c, g, c->pw[lc], f.fp32);
-  }
-  float* Z = A_alloc<float>(c, (size_t)nA * 256);
-  launch(c, "fpn_merge_kernel", fpn_merge_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)lat[0], (const float*)lat[1],
-         (const float*)lat[2], nA, Z);
   float* nat_out = A_alloc<float>(c, (size_t)nA * 128);
-  gemm(c, mk(Z, 256, nA, c->pw[HE + ".fpn_conv.last"], nat_out, 128), c->pw[HE + ".fpn_conv.last"], f.fp32);
+  if (fused && c->fpn_fused) {
+    FpnP q; memset(&q, 0, sizeof(q));
+    for (int i = 0; i < 3; ++i) {
+      const PW& w = c->pw[HE + ".lateral_convs." + std::to_string(i)];
+      q.oc[i] = Oc[i]; q.wl[i] = (const unsigned short*)w.bf; q.bl[i] = w.bias;
+    }
+    q.wf = (const unsigned short*)c->pw[HE + ".fpn_conv.last"].bf; q.bf_ = c->pw[HE + ".fpn_conv.last"].bias;
+    q.out = nat_out; q.nA = nA;
+    c->prof_flops = 2.0 * nA * (2.0 * 128 * (96 + 192 + 384) + 256.0 * 128);
+    launch(c, "fpn_tail_kernel", fpn_tail_kernel, dim3(cdiv(nA, FPN_AG)), dim3(512), (size_t)FPN_LDS, q);
+  } else {
+    float* lat[3];
+    for (int i = 0; i < 3; ++i) {
+      lat[i] = A_alloc<float>(c, (size_t)nA * 2 * 128);
+      const std::string lc = HE + ".lateral_convs." + std::to_string(i);
+      GemmP g = mk(Oc[i], Cl[i], nA * 2, c->pw[lc], lat[i], 128);
+      g.amode = AMODE_CONV3; g.cv_C = Cl[i]; g.cv_Lin = 3; g.cv_nout = 2; g.cv_t0 = 1; g.cv_stride = 1;
+      gemm(c, g, c->pw[lc], f.fp32);
+    }
+    float* Z = A_alloc<float>(c, (size_t)nA * 256);
+    launch(c, "fpn_merge_kernel", fpn_merge_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)lat[0], (const float*)lat[1],
+           (const float*)lat[2], nA, Z);
+    gemm(c, mk(Z, 256, nA, c->pw[HE + ".fpn_conv.last"], nat_out, 128), c->pw[HE + ".fpn_conv.last"], f.fp32);
+  }
   tap(c, "nat_out", nat_out, (int64_t)nA * 128);
 
   // ego state token (StateAttentionEncoder, agent_encoder.py:99-140)
@@ -1022,6 +1036,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_DEC_UNFUSED"); c->dec_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_UNFUSED"); c->pe_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_FPN_UNFUSED"); c->fpn_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_GRID0"); if (ev && atoi(ev) > 0) c->nat_grid0 = atoi(ev); }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
