@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256) void fourier_fused_kernel(FourierP p) {
     const float* pd = par + d * 640;
     for (int i = tid; i < FO_ROWS * 64; i += 256) {
       const int r = i >> 6, fq = i & 63;
-      const float arg = xs[r * 4 + d] * p.freqs[d * 64 + fq] * 2.f * RIFT_PI;   // same association as the reference expression
-      float sn, cs;
-      sincosf(arg, &sn, &cs);
+      // cos / sin(2 pi f x): the hardware v_sin / v_cos take their argument in revolutions, so only fract(f x) is needed
+      // (|error| ~ 1e-6, far below the bf16 rounding the features get as MFMA operands)
+      const float rev = __builtin_amdgcn_fractf(xs[r * 4 + d] * p.freqs[d * 64 + fq]);
+      const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
       feat[r * FO_FS + fq] = f2bf(cs);
       feat[r * FO_FS + 64 + fq] = f2bf(sn);
     }
