@@ -5,7 +5,8 @@ Tolerances (written here, per the parity contract):
   fp32 mode  (v_mfma_f32_16x16x4_f32, exact fp32 fma chains): logits / activations 1e-4 abs, losses 1e-5,
              pi_head grads 1e-5 + 1e-4 rel; integer indices bit-exact.
   bf16 mode  (v_mfma_f32_16x16x32_bf16, fp32 accumulate; the benchmarked precision): logits 5e-2 abs,
-             losses 5e-3 abs on these 2-6 scene batches (see test_gpu_update_step for the 256-scene bound);
+             losses 5e-3 abs on these 2-8 scene batches, 1e-4 (the north_star bar) on the 256-scene benchmark batch
+             (test_benchmark_batch_rift_loss_within_1e4_in_bf16);
              the loss/backward kernels themselves are fp32/fp64 and are held to 1e-5 against the oracle
              evaluated on the SAME (HIP) pi_head input.
 """
@@ -15,6 +16,7 @@ import numpy as np
 import pytest
 import torch
 
+from rift_amd import synthetic as syn
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
@@ -134,6 +136,30 @@ def test_loss_kernels_bf16_trunk(ffi, kind):
     assert abs(float(loss.item()) - float(ol)) < 1e-5
     for k in grads:
         assert err(grads[k], og[k]) < 1e-5 + 1e-4 * float(og[k].abs().max()), k
+    eng.close()
+
+
+def test_benchmark_batch_rift_loss_within_1e4_in_bf16(ffi):
+    """north_star's bar on the BENCHMARKED precision at the BENCHMARKED batch: the RIFT loss of a 256-scene minibatch
+    (train-mode BatchNorm, drops disabled), bf16 MFMA trunk + loss kernel through the C-ABI, within 1e-4 of the CPU oracle
+    (measured 3e-5; the fp32 mode is at 1e-9; 8-scene fixtures sit at 3e-4 in bf16, hence their looser bound above)."""
+    sd = H.weights()
+    scenes = [syn.make_scene(1000 + i) for i in range(256)]
+    batch = syn.collate_scenes(scenes)
+    data = batch["cur_pluto_feature_torch"]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    out_o, _, _ = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=False, want_taps=True)
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    want = float(losses.rift_loss(out_o["probability"], r_pad, batch["old_group_logits_torch"], batch["group_advantage_torch"],
+                                  batch["group_advantage_mask_torch"]))
+    eng = ffi.Engine("cuda:0")
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    for fp32, tol in ((False, 1e-4), (True, 1e-6)):
+        eng.forward(data, train=True, no_drop=True, fp32=fp32, bn_update=False)
+        stats, flat, _ = eng.loss_backward("rift", H.clone_tree(batch))
+        grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
+        loss = float(eng.loss_finalize(stats, flat, grads).item())
+        assert abs(loss - want) < tol, (fp32, loss, want)
     eng.close()
 
 

@@ -1,0 +1,71 @@
+"""Shape / mask edge cases of the HIP forward against the CPU oracle (fp32 mode 1e-4 abs on logits, bf16 5e-2):
+the dense-traffic configuration of BASELINE.json (128 agents, 40 polygons, 8-16 reference lines: beyond the fused
+kernels' LDS tiles, so the layer-wise paths carry it), a single-scene batch with one reference line, and degenerate masks
+(no valid neighbour agent, an all-invalid polygon, an all-invalid reference line between valid ones)."""
+import pytest
+import torch
+
+from oracle import losses, pluto_ref
+from rift_amd import synthetic as syn
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    from rift_amd import _ffi
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    _ffi.load_library()
+    return _ffi
+
+
+def _check(ffi, scenes, train):
+    sd = H.weights()
+    batch = syn.collate_scenes(scenes)
+    data = batch["cur_pluto_feature_torch"]
+    want, _, _ = pluto_ref.planning_model_forward(sd, data, train_bn=train, need_traj=True, want_taps=True)
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    eng = ffi.Engine("cuda:0")
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    for fp32, tol in ((True, 1e-4), (False, 5e-2)):
+        out = eng.forward(data, train=train, no_drop=True, need_traj=True, fp32=fp32, bn_update=False)
+        got = out["probability"].cpu()
+        assert torch.isfinite(got).all()
+        assert (got[r_pad] == -1e6).all()                                   # pluto_model.py:203
+        assert float((got - want["probability"])[~r_pad].abs().max()) < tol, (fp32, train)
+        tw = want["trajectory"][~r_pad]
+        tg = out["trajectory"].cpu()[~r_pad]
+        assert float((tg - tw).abs().max()) < (2e-3 if fp32 else 0.5) * max(1.0, float(tw.abs().max()))
+        stats, flat, _ = eng.loss_backward("rift", H.clone_tree(batch))
+        grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
+        loss = float(eng.loss_finalize(stats, flat, grads).item())
+        ref = float(losses.rift_loss(want["probability"], r_pad, batch["old_group_logits_torch"], batch["group_advantage_torch"],
+                                     batch["group_advantage_mask_torch"]))
+        assert abs(loss - ref) < (1e-5 if fp32 else 5e-3)
+    eng.close()
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_dense_traffic_configuration(ffi, train):
+    scenes = [syn.make_scene(300 + i, num_agents=128, num_polygons=40, r_min=8, r_max=16) for i in range(3)]
+    assert max(s["feature"]["reference_line"]["position"].shape[0] for s in scenes) > 6
+    _check(ffi, scenes, train)
+
+
+def test_single_scene_single_reference_line(ffi):
+    _check(ffi, [syn.make_scene(77, r_min=1, r_max=1)], train=False)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_degenerate_masks(ffi, train):
+    scenes = [syn.make_scene(500 + i, r_min=3, r_max=5) for i in range(4)]
+    f0, f1, f2 = scenes[0]["feature"], scenes[1]["feature"], scenes[2]["feature"]
+    f0["agent"]["valid_mask"][1:] = False                      # no valid neighbour agent (the ego stays)
+    f1["map"]["valid_mask"][3] = False                         # an all-invalid polygon
+    f1["map"]["valid_mask"][7, 5:] = False                     # a partially valid one
+    f2["reference_line"]["valid_mask"][1] = False              # an all-invalid reference line between valid ones
+    ex = scenes[2]["extras"]
+    ex["group_advantage_mask"][1] = False
+    _check(ffi, scenes, train)
