@@ -229,6 +229,11 @@ int rift_collate(RiftCtx* ctx, const RiftReplayArena* arena, const int32_t* scen
                  int R_out, const RiftFeatureBatch* out_batch /*caller-allocated*/, float* out_old_logits,
                  float* out_ref_logits, double* out_advantage, uint8_t* out_valid_mask, void* stream);
 
+/* Gradient-norm clipping over caller-owned .grad tensors (Lightning's gradient_clip_val = 0.5, custom_lightning.yaml:40-41 ->
+ * torch.nn.utils.clip_grad_norm_(params, max_norm), norm_type 2): in place, total norm written to total_norm (device, may be NULL). */
+int rift_clip_grad_norm(RiftCtx* ctx, float* const* grads /*host array of device pointers*/, const int64_t* numels /*host*/,
+                        int n_tensors /*<= 16*/, float max_norm, float* total_norm, void* stream);
+
 /* ---- PPO critic (CriticPPO, rift/gym_carla/utils/net.py:420-431 with CriticBase :355-371; built with dims [256, 256],
  * state_dim 128 by PPOPlutoModel, ppo_pluto.py:37 and planning/config/ppo_pluto.yaml:43-45).  All pointers are device fp32
  * views onto the caller's parameters: net.{0,2,4}.{weight,bias}, state_avg / state_std (128), value_avg / value_std (1). */

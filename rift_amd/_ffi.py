@@ -77,7 +77,7 @@ EXPORTS = [
     "rift_loss_finalize", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
-    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize",
+    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.rift_critic_forward.argtypes = [vp, C.POINTER(RiftCritic), vp, C.c_int, vp, vp]
     lib.rift_critic_loss_backward.argtypes = [vp, C.POINTER(RiftCritic), vp, vp, C.c_int, vp, vp, vp]
     lib.rift_critic_finalize.argtypes = [vp] * 14
+    lib.rift_clip_grad_norm.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), C.c_int, C.c_float, vp, vp]
     lib.rift_op_linear.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     lib.rift_gae.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp]
     lib.rift_discounted_return.argtypes = [vp, vp, vp, C.c_double, C.c_int, vp, vp]
@@ -433,6 +434,19 @@ class Engine:
         self._check(self.lib.rift_rollout(self.ctx, C.byref(io), _stream()), "rift_rollout")
         self._keep_ro = (traj, cs)
         return out
+
+    def make_clip_list(self, grads):
+        """Pre-build the (pointer, numel) arrays of a fixed list of .grad tensors for clip_grad_norm_raw."""
+        n = len(grads)
+        ptrs = (vp * n)(*[g.data_ptr() for g in grads])
+        nums = (C.c_int64 * n)(*[g.numel() for g in grads])
+        return (ptrs, nums, n, list(grads))
+
+    def clip_grad_norm_raw(self, clip_list, max_norm: float, total_norm: Optional[torch.Tensor] = None):
+        ptrs, nums, n, _ = clip_list
+        rc = self.lib.rift_clip_grad_norm(self.ctx, ptrs, nums, n, max_norm, _ptr(total_norm), _stream())
+        if rc != 0:
+            self._check(rc, "rift_clip_grad_norm")
 
     # ---- PPO critic ----------------------------------------------------------------------------
     @staticmethod

@@ -83,6 +83,7 @@ struct RiftCtx {
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
   int* dec_idx = nullptr; bool dec_fused = true;
+  double* clip_part = nullptr;
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
   bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true;
   bool loaded = false;
@@ -1061,6 +1062,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->enc_idx) (void)hipFree(c->enc_idx);
   if (c->dec_idx) (void)hipFree(c->dec_idx);
   if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
+  if (c->clip_part) (void)hipFree(c->clip_part);
   for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
@@ -1296,11 +1298,29 @@ int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void*
   return RIFT_OK;
 }
 
+int rift_clip_grad_norm(RiftCtx* c, float* const* grads, const int64_t* numels, int n, float max_norm, float* total_norm, void* stream) {
+  if (!c || !grads || !numels || n <= 0 || n > 16) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream; c->dry = false;
+  ClipList L; memset(&L, 0, sizeof(L));
+  long long tot = 0;
+  for (int i = 0; i < n; ++i) { L.g[i] = grads[i]; L.n[i] = numels[i]; tot += numels[i]; }
+  L.count = n;
+  const int nb = (int)std::min<long long>(64, (tot + 2047) / 2048);
+  if (!c->clip_part) HIPCHK(c, hipMalloc((void**)&c->clip_part, 64 * 8));
+  launch(c, "clip_norm_partial_kernel", clip_norm_partial_kernel, dim3(nb), dim3(256), 0, L, c->clip_part);
+  launch(c, "clip_scale_kernel", clip_scale_kernel, dim3(nb), dim3(256), 0, L, (const double*)c->clip_part, nb, max_norm, total_norm);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
 // ---- PPO critic ------------------------------------------------------------------------------------
 static int critic_scratch(RiftCtx* c, int n) {
   const size_t need = (size_t)((n + 15) / 16 * 16) * (128 + 4 * 256 + 1 + 2 * 128 + 2);
   if (need > c->cr_cap) {
     if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
+  if (c->clip_part) (void)hipFree(c->clip_part);
     HIPCHK(c, hipMalloc((void**)&c->cr_buf, need * 4));
     HIPCHK(c, hipMalloc((void**)&c->cr_part, (size_t)((n + 15) / 16) * 8));
     c->cr_cap = need;

@@ -359,4 +359,31 @@ __global__ void loss_finalize_kernel(const float* __restrict__ flat, const doubl
   dst[o] = accumulate ? dst[o] + v : v;
 }
 
+// ---- gradient-norm clipping over a list of tensors (torch.nn.utils.clip_grad_norm_, norm_type 2, as Lightning's
+// gradient_clip_val applies it, custom_lightning.yaml:40-41): total = sqrt(sum_t ||g_t||^2), g *= min(1, max_norm / (total + 1e-6))
+struct ClipList { float* g[16]; long long n[16]; int count; };
+
+__global__ __launch_bounds__(256) void clip_norm_partial_kernel(ClipList L, double* __restrict__ part /*[gridDim.x]*/) {
+  double s = 0.0;
+  for (int t = 0; t < L.count; ++t)
+    for (long long i = blockIdx.x * 256 + threadIdx.x; i < L.n[t]; i += (long long)gridDim.x * 256) { const double v = L.g[t][i]; s += v * v; }
+  s = wave_sum_d(s);
+  __shared__ double ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(256) void clip_scale_kernel(ClipList L, const double* __restrict__ part, int nparts, float max_norm,
+                                                         float* __restrict__ total_norm) {
+  double s = 0.0;
+  for (int i = 0; i < nparts; ++i) s += part[i];          // every thread: same order, same value
+  const float total = (float)sqrt(s);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && total_norm) *total_norm = total;
+  float coef = max_norm / (total + 1e-6f);
+  if (coef >= 1.0f) return;
+  for (int t = 0; t < L.count; ++t)
+    for (long long i = blockIdx.x * 256 + threadIdx.x; i < L.n[t]; i += (long long)gridDim.x * 256) L.g[t][i] *= coef;
+}
+
 }  // namespace rift

@@ -81,7 +81,9 @@ def configure_optimizer(model: nn.Module, lr: float, weight_decay: float):
     assert not (decay & no_decay) and not (pd.keys() - (decay | no_decay))
     groups = [{"params": [pd[n] for n in sorted(decay)], "weight_decay": weight_decay},
               {"params": [pd[n] for n in sorted(no_decay)], "weight_decay": 0.0}]
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+    # fused=True: the same AdamW update as one multi-tensor kernel per group (the host side of the default foreach path costs
+    # 0.7 ms per step for six small tensors -- a third of the whole update step)
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=pd and next(iter(pd.values())).is_cuda)
 
 
 def dp_all_reduce(flat: torch.Tensor, stats: torch.Tensor, group=None):
@@ -161,6 +163,9 @@ class RLFTTrainer:
         self._traj, self._A = None, 0
         self.step_count = 0
         self.training = True
+        self._clip_list = None
+        self._fast_groups = None
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------------------------
     def _outputs(self, bs, R):
@@ -235,10 +240,40 @@ class RLFTTrainer:
     def training_step(self, fb, extras):
         """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step)."""
         loss = self.forward_loss(fb, extras, train=True)
-        if self.gradient_clip_val:
-            torch.nn.utils.clip_grad_norm_(self.train_params, self.gradient_clip_val)
-        self.optimizer.step()
+        if self.gradient_clip_val:   # clip_grad_norm_(params, 0.5) on the device, no host round trip
+            if self._clip_list is None:
+                self._clip_list = self.engine.make_clip_list([p.grad for p in self.train_params])
+            self.engine.clip_grad_norm_raw(self._clip_list, float(self.gradient_clip_val), self.grad_norm)
+        self._optimizer_step()
         return loss
+
+    def _optimizer_step(self):
+        """torch.optim.AdamW's fused update, issued without the Python wrapper stack of Optimizer.step (which costs ~0.5 ms of
+        host time per step for six small tensors).  The first step goes through optimizer.step() so that torch creates the state;
+        afterwards the same torch kernel (torch._fused_adamw_) runs on the optimizer's own state tensors, so optimizer.state_dict()
+        and the scheduler's param_groups['lr'] keep their meaning.  Falls back to optimizer.step() if the entry point is missing."""
+        opt = self.optimizer
+        if self._fast_groups is None:
+            opt.step()
+            fast = hasattr(torch, "_fused_adamw_") and all(g.get("fused") for g in opt.param_groups)
+            groups = []
+            for g in opt.param_groups:
+                ps = [p for p in g["params"] if p.grad is not None]
+                st = [opt.state[p] for p in ps]
+                if not ps or any("exp_avg" not in s or not torch.is_tensor(s["step"]) or not s["step"].is_cuda for s in st):
+                    fast = False
+                    break
+                groups.append((g, ps, [p.grad for p in ps], [s["exp_avg"] for s in st], [s["exp_avg_sq"] for s in st], [s["step"] for s in st]))
+            self._fast_groups = groups if fast else False
+            return
+        if self._fast_groups is False:
+            opt.step()
+            return
+        with torch.no_grad():
+            for g, ps, grads, m, v, steps in self._fast_groups:
+                torch._foreach_add_(steps, 1)
+                torch._fused_adamw_(ps, grads, m, v, [], steps, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1],
+                                    weight_decay=g["weight_decay"], eps=g["eps"], amsgrad=False, maximize=False)
 
     def validation_step(self, fb, extras):
         return self.forward_loss(fb, extras, train=False, backward=False)

@@ -440,3 +440,23 @@ def test_ppo_critic_forward_and_value_loss_backward(ffi):
     for k, g in zip(ffi.CRITIC_KEYS, grads):
         assert err(g, gold["grad." + k]) < 1e-5, k
     eng.close()
+
+
+@pytest.mark.parametrize("scale", [10.0, 1e-3])
+def test_native_clip_grad_norm_matches_torch(ffi, scale):
+    """rift_clip_grad_norm against torch.nn.utils.clip_grad_norm_(params, 0.5) (Lightning's gradient_clip_val): clipping and
+    pass-through cases, total norm reported."""
+    eng = ffi.Engine("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 128), (128,), (128,), (128,), (1, 128), (1,), (256, 256)]
+    params = [torch.nn.Parameter(torch.zeros(s, device="cuda")) for s in shapes]
+    for p_ in params:
+        p_.grad = (torch.randn(p_.shape, generator=g) * scale).cuda()
+    mine = [p_.grad.clone() for p_ in params]
+    want_norm = torch.nn.utils.clip_grad_norm_(params, 0.5)
+    tn = torch.zeros(1, device="cuda")
+    eng.clip_grad_norm_raw(eng.make_clip_list(mine), 0.5, tn)
+    assert abs(float(tn) - float(want_norm)) < 1e-5 * max(1.0, float(want_norm))
+    for a, p_ in zip(mine, params):
+        assert err(a, p_.grad) < 1e-6 * max(1.0, float(p_.grad.abs().max()))
+    eng.close()
