@@ -20,6 +20,12 @@ def main(path, steps=None):
     span = rows[-1][2] - rows[0][1]
     gaps = sum(max(0, rows[i + 1][1] - rows[i][2]) for i in range(len(rows) - 1))
     print(f"kernels: {len(rows)} dispatches, busy {tot / 1e6:.3f} ms, span {span / 1e6:.3f} ms, gaps {gaps / 1e6:.3f} ms")
+    small = [max(0, rows[i + 1][1] - rows[i][2]) for i in range(len(rows) - 1)]
+    small = [g for g in small if g < 200_000]     # inter-kernel gaps inside steps (host pauses between phases excluded)
+    if small:
+        small.sort()
+        print(f"inter-kernel gaps < 0.2 ms: n {len(small)}, sum {sum(small) / 1e6:.3f} ms, median {small[len(small) // 2] / 1e3:.2f} us, "
+              f"p90 {small[int(len(small) * 0.9)] / 1e3:.2f} us")
     print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>9} {'%':>6}  name")
     for name, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         short = name if len(name) < 110 else name[:107] + "..."
