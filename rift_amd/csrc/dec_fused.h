@@ -31,9 +31,12 @@ struct DecFusedP {
   const uint8_t* r_kpm;         // (bs*R) reference-line padding
   int bs, N, R;
   int kv_ld;                    // row stride of the kv matrices (1024 when the four layers share one GEMM)
+  const unsigned short* KT;     // optional (bs, 4, 96, 128) bf16 K and (bs, 4, 128, 96) bf16 V^T written by the encoder kernel's tail;
+  const unsigned short* VT;     // when set they replace blk[].kv (no fp32 round trip, no conversion, no transposing stores)
   DecBlockW blk[4];
   float dropout;                // 0.1 in train mode
   uint32_t seed, stream;
+  long long* ts;                // optional phase timestamps of workgroup 0 (diagnostic)
 };
 
 #define RIFT_DEC_NPAR 2944   // ln1..4 g,b (1024) | b_r2r 384 | b_r2ro 128 | b_m2m 384 | b_m2mo 128 | b_cq 128 | b_co 128 | b_f1 512 | b_f2 128
@@ -63,6 +66,9 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
   const size_t qrow0 = (size_t)b * NQ;
   const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
+  int tsn = 0;
+#define DTS() do { if (p.ts && b == 0 && tid == 0 && tsn < 250) p.ts[tsn++] = clock64(); } while (0)
+  DTS();
 
   constexpr int NPRE = (RIFT_DEC_NPAR + NTH - 1) / NTH;
   float pre[NPRE];
@@ -232,17 +238,17 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     const DecBlockW& w = p.blk[li];
     const uint32_t st = p.stream + 16 * li;
     par_commit();
-    __syncthreads();
+    __syncthreads(); DTS();
     // ================= r2r =================
     layer_norm(par + P_LN + 0, par + P_LN + 128);
-    __syncthreads();
+    __syncthreads(); DTS();
     for (int ch = 0; ch < 2; ++ch) {
       qkv_chunk(ch, par + P_BR2R, nullptr);
       if (ch == 0) e_load_b(Bqkv, w.w_r2r, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
       else e_load_b(Bw, w.w_r2ro, C, 0, 0, wave, l15, l4, EWaves<NW>());
-      __syncthreads();
+      __syncthreads(); DTS();
       small_attention(ch, false, st + 0);
-      __syncthreads();
+      __syncthreads(); DTS();
     }
     {
       f32x4 acc[MT][NTC];
@@ -254,17 +260,17 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       e_load_b(Bqkv, w.w_m2m, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
       residual_epilogue(acc, par + P_BR2RO, st + 1, false);
     }
-    __syncthreads();
+    __syncthreads(); DTS();
     // ================= m2m =================
     layer_norm(par + P_LN + 256, par + P_LN + 384);
-    __syncthreads();
+    __syncthreads(); DTS();
     for (int ch = 0; ch < 2; ++ch) {
       qkv_chunk(ch, par + P_BM2M, w.mp);
       if (ch == 0) e_load_b(Bqkv, w.w_m2m, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
       else e_load_b(Bw, w.w_m2mo, C, 0, 0, wave, l15, l4, EWaves<NW>());
-      __syncthreads();
+      __syncthreads(); DTS();
       small_attention(ch, true, st + 2);
-      __syncthreads();
+      __syncthreads(); DTS();
     }
     {
       f32x4 acc[MT][NTC];
@@ -276,10 +282,10 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       e_load_b(Bw, w.w_cq, C, 0, 0, wave, l15, l4, EWaves<NW>());
       residual_epilogue(acc, par + P_BM2MO, st + 3, true);
     }
-    __syncthreads();
+    __syncthreads(); DTS();
     // ================= cross attention =================
     layer_norm(par + P_LN + 512, par + P_LN + 640);
-    __syncthreads();
+    __syncthreads(); DTS();
     {
       f32x4 acc[MT][NTC];
 #pragma unroll
@@ -300,21 +306,22 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       }
     }
     for (int ch = 0; ch < 2; ++ch) {
-      __syncthreads();          // previous chunk's reads of kc / vtc (and the q writes) are complete
+      __syncthreads(); DTS();          // previous chunk's reads of kc / vtc (and the q writes) are complete
       // stream K (row-major) and V (transposed) of heads 2ch, 2ch+1 into LDS as bf16
-      for (int i = tid; i < 96 * 16; i += NTH) {
-        const int key = i >> 4, c4 = (i & 15) * 4;
-        float4 kq = make_float4(0.f, 0.f, 0.f, 0.f), vq = kq;
-        if (key < N) {
-          const float* src = w.kv + ((size_t)b * N + key) * p.kv_ld + ch * 64 + c4;
-          kq = *reinterpret_cast<const float4*>(src);
-          vq = *reinterpret_cast<const float4*>(src + 128);
+      if (p.KT) {
+        const unsigned short* kt = p.KT + ((size_t)b * 4 + li) * 96 * 128 + ch * 64;
+        const unsigned short* vt = p.VT + (((size_t)b * 4 + li) * 128 + ch * 64) * 96;
+        for (int i = tid; i < 96 * 8 + 64 * 12; i += NTH) {
+          if (i < 96 * 8) {
+            const int key = i >> 3, c8 = (i & 7) * 8;
+            *reinterpret_cast<uint4*>(kc + key * KC + c8) = *reinterpret_cast<const uint4*>(kt + key * 128 + c8);
+          } else {
+            const int j = i - 96 * 8, d = j / 12, k8 = (j - d * 12) * 8;
+            *reinterpret_cast<uint4*>(vtc + d * VS + k8) = *reinterpret_cast<const uint4*>(vt + d * 96 + k8);
+          }
         }
-        *reinterpret_cast<uint2*>(kc + key * KC + c4) = pack_bf16x4(kq.x, kq.y, kq.z, kq.w);
-        vtc[(c4 + 0) * VS + key] = f2bf(vq.x); vtc[(c4 + 1) * VS + key] = f2bf(vq.y);
-        vtc[(c4 + 2) * VS + key] = f2bf(vq.z); vtc[(c4 + 3) * VS + key] = f2bf(vq.w);
-      }
-      __syncthreads();
+      } else
+      __syncthreads(); DTS();
       for (int pr = wave; pr < 2 * MT; pr += NW) {           // (head, query tile) pairs
         const int hh = pr / MT, qt = pr - hh * MT;
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + (qt * 16 + l15) * CB + (ch * 2 + hh) * 32 + l4 * 8);
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
       }
     }
-    __syncthreads();
+    __syncthreads(); DTS();
     {
       f32x4 acc[MT][NTC];
 #pragma unroll
@@ -383,11 +390,11 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       e_load_b(Bw, w.w_f1, C, 0, 0, wave, l15, l4, EWaves<NW>());
       residual_epilogue(acc, par + P_BCO, st + 5, false);
     }
-    __syncthreads();
+    __syncthreads(); DTS();
     // ================= FFN =================
     layer_norm(par + P_LN + 768, par + P_LN + 896);
     if (li + 1 < 4) par_fetch(p.blk[li + 1]);
-    __syncthreads();
+    __syncthreads(); DTS();
     {
       f32x4 acc2[MT][NTC];
 #pragma unroll
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
             for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
           e_load_b(B2, w.w_f2, 512, 0, hc * 128, wave, l15, l4, EWaves<NW>());
-          if (hc > 0) __syncthreads();
+          if (hc > 0) __syncthreads(); DTS();
 #pragma unroll
           for (int j = 0; j < NTC; ++j) {
             const int col = (j * NW + wave) * 16 + l4 * 4;
@@ -424,17 +431,19 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         }
         if (hc + 1 < 4) e_load_b(Bw, w.w_f1, C, (hc + 1) * 128, 0, wave, l15, l4, EWaves<NW>());
         else if (li + 1 < 4) e_load_b(Bqkv, p.blk[li + 1].w_r2r, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
-        __syncthreads();
+        __syncthreads(); DTS();
         e_mma<MT, 4, NTC>(acc2, cb, CB, B2, l15, l4);
       }
       residual_epilogue(acc2, par + P_BF2, st + 7, false);
     }
-    __syncthreads();
+    __syncthreads(); DTS();
   }
   for (int i = tid; i < ROWS * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     if (r < NQ) *reinterpret_cast<float4*>(p.Q + (qrow0 + r) * C + c4) = *reinterpret_cast<const float4*>(xs + r * XS + c4);
   }
+  DTS();
+#undef DTS
 }
 
 }  // namespace rift

@@ -32,6 +32,12 @@ struct EncFusedP {
   const float* norm_g; const float* norm_b;
   uint32_t seed, stream;
   long long* ts;                // optional phase timestamps of workgroup 0 (diagnostic)
+  // ---- optional tail: the planning decoder's cross-attention K | V projections of this scene's encoder output, all four layers
+  // (planning_decoder.py:74-79, nn.MultiheadAttention in_proj rows 128:384), written as bf16 operands of the decoder kernel
+  const unsigned short* wkv;    // fragment-major bf16 [4 * 256][128]: per layer (k 128 rows | v 128 rows)
+  const float* bkv;             // [4 * 256]
+  unsigned short* KT;           // (bs, 4, 96, 128) bf16: K rows per key (keys >= N undefined, masked by the decoder)
+  unsigned short* VT;           // (bs, 4, 128, 96) bf16: V transposed (dim-major)
 };
 
 // row-gather weight packer: dst[r][k] = bf16(src[idx[r]][k]); bias_out[r] = bias[idx[r]]
@@ -362,9 +368,45 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       q = group_sum<32>(q);
       const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
-      if (r < N)
-        *reinterpret_cast<float4*>(p.Y + (grow0 + r) * C + lr * 4) =
-            make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
+      const float4 o = make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
+      if (r < N) *reinterpret_cast<float4*>(p.Y + (grow0 + r) * C + lr * 4) = o;
+      if (p.KT) *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) = pack_bf16x4(o.x, o.y, o.z, o.w);
+    }
+  }
+  if (p.KT) {
+    // ---- decoder K | V projections of the four layers from the bf16 encoder output still in LDS.  n-tiles 0..7 (K) are issued
+    // swapped (a lane holds 4 consecutive channels of one key -> row stores), n-tiles 8..15 (V) plain (4 consecutive keys of one
+    // channel -> transposed stores): exactly the two operand layouts the decoder's MFMA cross attention reads.
+    EFrags<4, 2> Wk;
+    e_load_b(Wk, p.wkv, C, 0, 0, wave, l15, l4, EWaves<NW>());
+    __syncthreads();
+    static_assert(NW == 8, "the K|V tail deals 16 n-tiles to 8 waves");
+    for (int l = 0; l < 4; ++l) {
+      f32x4 acc[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      e_mma<MT, 4, 2, 1>(acc, xn, XN, Wk, l15, l4);
+      if (l + 1 < 4) e_load_b(Wk, p.wkv, C, (l + 1) * 256, 0, wave, l15, l4, EWaves<NW>());
+      {   // K: channels wave*16 + 4*l4 .. +3 of key mt*16 + l15
+        const int col = wave * 16 + l4 * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bkv + l * 256 + col);
+        unsigned short* kt = p.KT + ((size_t)b * 4 + l) * 96 * 128;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          *reinterpret_cast<uint2*>(kt + (mt * 16 + l15) * 128 + col) =
+              pack_bf16x4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
+      }
+      {   // V^T: channel wave*16 + l15, keys mt*16 + 4*l4 .. +3
+        const int d = wave * 16 + l15;
+        const float bias = p.bkv[l * 256 + 128 + d];
+        unsigned short* vt = p.VT + (((size_t)b * 4 + l) * 128 + d) * 96;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          *reinterpret_cast<uint2*>(vt + mt * 16 + l4 * 4) =
+              pack_bf16x4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
+      }
     }
   }
 }

@@ -776,6 +776,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // ================= encoder blocks (transformer.py:73-94) =================
   static const float edpr[4] = {0.f, 0.2f / 3.f, 0.4f / 3.f, 0.2f};   // linspace(0, 0.2, 4), pluto_model.py:80-83
   float* ENC = A_alloc<float>(c, (size_t)nT * 128);
+  unsigned short *enc_KT = nullptr, *enc_VT = nullptr;
   if (c->enc_fused && !f.fp32 && N <= 96) {
     EncFusedP ep; memset(&ep, 0, sizeof(ep));
     ep.X = X; ep.Y = ENC; ep.kpm = kpm; ep.bs = bs; ep.N = N; ep.seed = f.seed; ep.stream = f.next_stream(); f.stream_id += 8;
@@ -793,6 +794,13 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias");
     if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
+    if (c->dec_fused && R * 12 <= 80 && ENC_NW == 8) {   // the decoder kernel will run: emit its cross-attention K | V operands here
+      enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 96 * 128);
+      enc_VT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 128 * 96);
+      ep.wkv = (const unsigned short*)c->pw["planning_decoder.kv_all"].bf; ep.bkv = c->pw["planning_decoder.kv_all"].bias;
+      ep.KT = enc_KT; ep.VT = enc_VT;
+      c->prof_flops += 2.0 * bs * N * 128.0 * 1024;
+    }
     launch(c, "enc_fused_kernel", enc_fused_kernel<ENC_NW>, dim3(bs), dim3(64 * ENC_NW), (size_t)RIFT_ENC_LDS_BYTES, ep);
   } else {
   float* QKV = A_alloc<float>(c, (size_t)nT * 384);
@@ -868,8 +876,12 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
     dq.stream = f.next_stream(); f.stream_id += 64;
     // the cross-attention K | V projections of all four layers read the same encoder output: one N = 1024 GEMM
-    float* KVall = A_alloc<float>(c, (size_t)nT * 1024);
-    gemm(c, mk(ENC, 128, nT, c->pw[PD + ".kv_all"], KVall, 1024), c->pw[PD + ".kv_all"], f.fp32);
+    float* KVall = nullptr;
+    if (enc_KT) { dq.KT = enc_KT; dq.VT = enc_VT; }     // written by the encoder kernel's tail
+    else {
+      KVall = A_alloc<float>(c, (size_t)nT * 1024);
+      gemm(c, mk(ENC, 128, nT, c->pw[PD + ".kv_all"], KVall, 1024), c->pw[PD + ".kv_all"], f.fp32);
+    }
     dq.kv_ld = 1024;
     for (int i = 0; i < 4; ++i) {
       const std::string p = PD + ".decoder_blocks." + std::to_string(i);
@@ -891,8 +903,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       bool fill_mp;
       float* MPl = wconst_get(c, p + ".mp", (size_t)M * 384, f.fp32, &fill_mp);
       if (fill_mp) gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MPl, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
-      w.mp = MPl; w.kv = KVall + i * 256;
+      w.mp = MPl; w.kv = KVall ? KVall + i * 256 : nullptr;
     }
+    if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
     // algorithmic FLOPs of the 4 layers on the padded (R x 12) query block, as the reference computes them
     c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
     launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
