@@ -108,7 +108,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("RIFT_BENCH_FORCE_PG") == "1":   # (the env switch exercises the RCCL path on a single GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)

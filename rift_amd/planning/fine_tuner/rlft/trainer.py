@@ -9,6 +9,7 @@ PyTorch-ROCm, as the reference's optimizer does (rift_trainer.py:279-362).
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -165,6 +166,7 @@ class RLFTTrainer:
         self.training = True
         self._clip_list = None
         self._fast_groups = None
+        self.force_exchange = os.environ.get("RIFT_BENCH_FORCE_PG") == "1"   # run the all-reduce even with one rank (path check)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------------------------
@@ -214,7 +216,7 @@ class RLFTTrainer:
         eng.loss_backward_raw(self.kind_id, self.li, self.lo)
         if self.critic is not None:   # value loss half of get_ppo_loss (ppo_trainer.py:175-176,183)
             eng.critic_loss_backward_raw(self.critic_desc, extras["state"], extras["reward_sum"], self.stats, self.flat_c)
-        if self.pg is not None and self.world > 1:
+        if self.pg is not None and (self.world > 1 or self.force_exchange):
             dp_all_reduce(self.flat, self.stats, self.pg)
             if self.critic is not None:
                 torch.distributed.all_reduce(self.flat_c, group=self.pg)
