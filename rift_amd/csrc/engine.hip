@@ -23,6 +23,7 @@
 #include "fourier_fused.h"
 #include "critic.h"
 #include "fpn_fused.h"
+#include "ego_fused.h"
 #include "rollout.h"
 
 // fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
@@ -85,7 +86,7 @@ struct RiftCtx {
   int* dec_idx = nullptr; bool dec_fused = true;
   double* clip_part = nullptr;
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
-  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true;
+  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true; bool ego_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -717,14 +718,24 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 
   // ego state token (StateAttentionEncoder, agent_encoder.py:99-140)
   const std::string EG = "agent_encoder.ego_state_emb";
+  bool fill_eq;
+  float* eq = wconst_get(c, "ego_q", 128, f.fp32, &fill_eq);
+  if (fill_eq) gemm(c, mk(fptr(c, EG + ".query"), 128, 1, c->pw[EG + ".attn.q"], eq, 128), c->pw[EG + ".attn.q"], f.fp32);
+  float* x_ego = A_alloc<float>(c, (size_t)bs * 128);
+  if (!f.fp32 && c->ego_fused) {
+    EgoP q; memset(&q, 0, sizeof(q));
+    q.cs = B->current_state; q.cs_ld = B->cs_ld; q.lw = c->ego_w; q.lb = c->ego_b; q.pos = fptr(c, EG + ".pos_embed");
+    q.wkv = (const unsigned short*)c->pw[EG + ".attn.kv"].bf; q.bkv = c->pw[EG + ".attn.kv"].bias; q.q = eq;
+    q.wo = (const unsigned short*)c->pw[EG + ".attn.out_proj"].bf; q.bo = c->pw[EG + ".attn.out_proj"].bias;
+    q.out = x_ego; q.bs = bs; q.drop_p = f.drop ? 0.75f : 0.f; q.seed = f.seed; q.stream = f.drop ? f.next_stream() : 0;
+    c->prof_flops = 2.0 * bs * (6.0 * 128 * 256 + 128.0 * 128);
+    launch(c, "ego_fused_kernel", ego_fused_kernel, dim3(bs), dim3(256), 0, q);
+  } else {
   float* E = A_alloc<float>(c, (size_t)bs * 6 * 128);
   launch(c, "ego_token_kernel", ego_token_kernel, dim3(cdiv((long long)bs * 6 * 128, 256)), dim3(256), 0, B->current_state, B->cs_ld,
          (const float*)c->ego_w, (const float*)c->ego_b, fptr(c, EG + ".pos_embed"), bs, E);
   float* EKV = A_alloc<float>(c, (size_t)bs * 6 * 256);
   gemm(c, mk(E, 128, bs * 6, c->pw[EG + ".attn.kv"], EKV, 256), c->pw[EG + ".attn.kv"], f.fp32);
-  bool fill_eq;
-  float* eq = wconst_get(c, "ego_q", 128, f.fp32, &fill_eq);
-  if (fill_eq) gemm(c, mk(fptr(c, EG + ".query"), 128, 1, c->pw[EG + ".attn.q"], eq, 128), c->pw[EG + ".attn.q"], f.fp32);
   uint8_t* edrop = nullptr;
   if (f.drop) {
     edrop = A_alloc<uint8_t>(c, (size_t)bs * 6);
@@ -739,8 +750,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     p.o_outer = 1; p.o_inner = 0; p.o_stride = 0; p.mask = edrop; p.mask_quirk = 0; p.mask_mod = 1;
     run_mha(c, p, f.fp32);
   }
-  float* x_ego = A_alloc<float>(c, (size_t)bs * 128);
   gemm(c, mk(EAO, 128, bs, c->pw[EG + ".attn.out_proj"], x_ego, 128), c->pw[EG + ".attn.out_proj"], f.fp32);
+  }
+  tap(c, "x_ego", x_ego, (int64_t)bs * 128);
 
   // ================= tokens =================
   float* X = A_alloc<float>(c, (size_t)nT * 128);
@@ -1051,6 +1063,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_UNFUSED"); c->pe_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_FPN_UNFUSED"); c->fpn_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_EGO_UNFUSED"); c->ego_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_GRID0"); if (ev && atoi(ev) > 0) c->nat_grid0 = atoi(ev); }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }

@@ -327,6 +327,27 @@ def test_fused_fourier_embedding_matches_layerwise_path(ffi, monkeypatch):
     assert err(outs["fused"][1], outs["layerwise"][1]) < 3e-2 * max(1.0, float(outs["layerwise"][1].abs().max()))
 
 
+def test_fused_ego_token_matches_layerwise_path(ffi, monkeypatch):
+    """The one-launch StateAttentionEncoder (tokens, K|V MFMA, 4-head attention of the learned query over 6 tokens, out_proj)
+    against the five-launch path and the exact-fp32 path."""
+    gold, batch, sd = H.load_case("full")
+    data = batch["cur_pluto_feature_torch"]
+    outs = {}
+    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+        monkeypatch.setenv("RIFT_EGO_UNFUSED", env)
+        eng = ffi.Engine("cuda:0")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        eng.prof_enable(True)
+        eng.forward(data, fp32=fp32)
+        assert ("ego_fused_kernel" in eng.prof_report()) == (name == "fused")
+        eng.prof_enable(False)
+        outs[name] = eng.tap("x_ego").cpu().clone()
+        eng.close()
+    scale = max(1.0, float(outs["fp32"].abs().max()))
+    assert err(outs["fused"], outs["fp32"]) < 2e-2 * scale
+    assert err(outs["fused"], outs["layerwise"]) < 2e-2 * scale
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_fused_points_encoder_matches_layerwise_path(ffi, monkeypatch, train):
     """The three-pass fused PointsEncoder (map polygons, reference lines; BatchNorm batch statistics in train mode,
