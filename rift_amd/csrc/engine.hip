@@ -363,10 +363,8 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR((gemm_rows_kernel<false, 4, 4, 1, 4>));
 #undef SETATTR
 #define SETATTR_N(K, N) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(N)))
-  SETATTR_N(pe_mid_kernel<20>, PE_MID_LDS);   // these kernels also hold a few hundred bytes of static LDS
-  SETATTR_N(pe_mid_kernel<120>, PE_MID_LDS);
-  SETATTR_N(pe_out_kernel<20>, PE_OUT_LDS);
-  SETATTR_N(pe_out_kernel<120>, PE_OUT_LDS);
+  SETATTR_N(pe_mid_kernel, PE_MID_LDS);   // these kernels also hold a few hundred bytes of static LDS
+  SETATTR_N(pe_out_kernel, PE_OUT_LDS);
   SETATTR_N(fourier_fused_kernel, FO_LDS);
   SETATTR_N(fpn_tail_kernel, FPN_LDS);
 #undef SETATTR_N
@@ -448,55 +446,64 @@ void batchnorm_affine(Fwd& f, const float* X, int rows, int C, const uint8_t* va
          f.bn_update ? 1 : 0, 1e-5f, *scale, *shift);
 }
 
-// PointsEncoder, fused three-pass form (pe_fused.h); bf16 mode, n in {20, 120}
-float* points_encoder_fused(Fwd& f, const float* F, int Cin, int groups, int n, const uint8_t* valid, const std::string& p) {
+// The two PointsEncoders (map polygons 10 -> 128 with 20 points, reference lines 6 -> 128 with 120 points) in the fused
+// three-pass form (pe_fused.h), side by side: five launches for both (statistics, BN finalize, mid, BN finalize, out).
+static void pe_fill(Fwd& f, PeP& q, const float* F, int Cin, int groups, int n, const uint8_t* valid, const std::string& p) {
   RiftCtx* c = f.c;
+  memset(&q, 0, sizeof(q));
   const int rows = groups * n;
-  const int ntiles = cdiv(rows, 120);
-  PeP q; memset(&q, 0, sizeof(q));
-  q.F = F; q.Cin = Cin; q.valid = valid; q.rows = rows; q.ntiles = ntiles;
+  q.F = F; q.Cin = Cin; q.valid = valid; q.rows = rows; q.ntiles = cdiv(rows, 120);
   const PW &w1 = c->pw[p + ".first_mlp.0"], &w2 = c->pw[p + ".first_mlp.3"], &w3a = c->pw[p + ".second_mlp.0.feat"],
            &w3b = c->pw[p + ".second_mlp.0.pool"], &w4 = c->pw[p + ".second_mlp.3"];
   q.w1 = (const unsigned short*)w1.bf; q.w2 = (const unsigned short*)w2.bf; q.w3a = (const unsigned short*)w3a.bf;
   q.w3b = (const unsigned short*)w3b.bf; q.w4 = (const unsigned short*)w4.bf;
   q.b1 = w1.bias; q.b2 = w2.bias; q.b3 = w3a.bias; q.b4 = w4.bias;
-  float* s1 = A_alloc<float>(c, 128); float* t1 = A_alloc<float>(c, 128);
-  float* s2 = A_alloc<float>(c, 256); float* t2 = A_alloc<float>(c, 256);
-  q.s1 = s1; q.t1 = t1; q.s2 = s2; q.t2 = t2;
-  q.part1 = A_alloc<float>(c, (size_t)2 * 128 * ntiles);
-  q.part2 = A_alloc<float>(c, (size_t)2 * 256 * ntiles);
-  q.cnt = A_alloc<int>(c, ntiles);
+  q.s1 = A_alloc<float>(c, 128); q.t1 = A_alloc<float>(c, 128); q.s2 = A_alloc<float>(c, 256); q.t2 = A_alloc<float>(c, 256);
+  q.part1 = A_alloc<float>(c, (size_t)2 * 128 * q.ntiles);
+  q.part2 = A_alloc<float>(c, (size_t)2 * 256 * q.ntiles);
+  q.cnt = A_alloc<int>(c, q.ntiles);
   q.Fmid = A_alloc<unsigned short>(c, (size_t)rows * 256);
   q.gp = A_alloc<float>(c, (size_t)groups * 256);
   q.out = A_alloc<float>(c, (size_t)groups * 128);
   q.do_stats = f.train ? 1 : 0;
   { const char* ev = getenv("RIFT_PE_TS"); if (ev && atoi(ev) == n) { q.ts = A_alloc<long long>(c, 64); q.ts_tile = 0; tap(c, "pe_ts", (float*)q.ts, 128); } }
-  auto finalize = [&](const std::string& name, int C, const float* part, float* sc, float* sh) {
-    const Param* nb = find(c, name + ".num_batches_tracked");
-    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(cdiv(C, 4)), dim3(256), 0, part, (const int*)q.cnt, ntiles, C,
-           fptr(c, name + ".weight"), fptr(c, name + ".bias"), (float*)fptr(c, name + ".running_mean"),
-           (float*)fptr(c, name + ".running_var"), nb ? (long long*)nb->data : (long long*)nullptr, f.train ? 1 : 0,
-           f.bn_update ? 1 : 0, 1e-5f, sc, sh);
-  };
+}
+
+static BnFinP bn_fin(RiftCtx* c, const PeP& q, const std::string& name, int C, const float* part, const float* sc, const float* sh) {
+  BnFinP b; memset(&b, 0, sizeof(b));
+  const Param* nb = find(c, name + ".num_batches_tracked");
+  b.part = part; b.cnt = q.cnt; b.nblk = q.ntiles; b.C = C; b.gamma = fptr(c, name + ".weight"); b.beta = fptr(c, name + ".bias");
+  b.running_mean = (float*)fptr(c, name + ".running_mean"); b.running_var = (float*)fptr(c, name + ".running_var");
+  b.num_batches = nb ? (long long*)nb->data : nullptr; b.scale = (float*)sc; b.shift = (float*)sh;
+  return b;
+}
+
+void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, const std::string& pm, const float* Fr, int gr,
+                         const uint8_t* vr, const std::string& pr, float** out_m, float** out_r) {
+  RiftCtx* c = f.c;
+  PeP2 q;
+  pe_fill(f, q.a, Fm, 10, gm, 20, vm, pm);
+  pe_fill(f, q.b, Fr, 6, gr, 120, vr, pr);
+  const int nt = q.a.ntiles + q.b.ntiles;
+  const double rows = (double)q.a.rows + q.b.rows, groups = (double)gm + gr;
   if (f.train) {
-    c->prof_flops = 2.0 * rows * 128.0 * Cin;
-    launch(c, "pe_stats1_kernel", pe_stats1_kernel, dim3(ntiles), dim3(256), 0, q);
+    c->prof_flops = 2.0 * 128.0 * (q.a.rows * 10.0 + q.b.rows * 6.0);
+    launch(c, "pe_stats1_kernel", pe_stats1_kernel, dim3(nt), dim3(256), 0, q);
   }
-  finalize(p + ".first_mlp.1", 128, q.part1, s1, t1);
-  c->prof_flops = 2.0 * rows * (128.0 * Cin + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;
-  if (n == 20) launch(c, "pe_mid_kernel", pe_mid_kernel<20>, dim3(ntiles), dim3(512), (size_t)PE_MID_LDS, q);
-  else launch(c, "pe_mid_kernel", pe_mid_kernel<120>, dim3(ntiles), dim3(512), (size_t)PE_MID_LDS, q);
-  finalize(p + ".second_mlp.1", 256, q.part2, s2, t2);
+  launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(64), dim3(256), 0, bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1),
+         bn_fin(c, q.b, pr + ".first_mlp.1", 128, q.b.part1, q.b.s1, q.b.t1), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+  c->prof_flops = 2.0 * rows * (128.0 * 8 + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;
+  launch(c, "pe_mid_kernel", pe_mid_kernel, dim3(nt), dim3(512), (size_t)PE_MID_LDS, q);
+  launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(128), dim3(256), 0, bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2),
+         bn_fin(c, q.b, pr + ".second_mlp.1", 256, q.b.part2, q.b.s2, q.b.t2), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
   c->prof_flops = 2.0 * rows * (256.0 * 256 + 256.0 * 128);
-  if (n == 20) launch(c, "pe_out_kernel", pe_out_kernel<20>, dim3(ntiles), dim3(512), (size_t)PE_OUT_LDS, q);
-  else launch(c, "pe_out_kernel", pe_out_kernel<120>, dim3(ntiles), dim3(512), (size_t)PE_OUT_LDS, q);
-  return q.out;
+  launch(c, "pe_out_kernel", pe_out_kernel, dim3(nt), dim3(512), (size_t)PE_OUT_LDS, q);
+  *out_m = q.a.out; *out_r = q.b.out;
 }
 
 // PointsEncoder (embedding.py:271-296): F (groups*n, Cin) -> (groups, 128)
 float* points_encoder(Fwd& f, const float* F, int Cin, int groups, int n, const uint8_t* valid, const std::string& p) {
   RiftCtx* c = f.c;
-  if (!f.fp32 && c->pe_fused && (n == 20 || n == 120) && Cin <= 32) return points_encoder_fused(f, F, Cin, groups, n, valid, p);
   const int rows = groups * n;
   float* H1 = A_alloc<float>(c, (size_t)rows * 128);
   gemm(c, mk(F, Cin, rows, c->pw[p + ".first_mlp.0"], H1, 128), c->pw[p + ".first_mlp.0"], f.fp32);
@@ -763,7 +770,15 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* F10 = A_alloc<float>(c, (size_t)nP * 20 * 10);
   launch(c, "map_feature_kernel", map_feature_kernel, dim3(cdiv((long long)nP * 20, 256)), dim3(256), 0, B->map_point_position, B->map_point_vector,
          B->map_point_orientation, B->map_polygon_center, nP, F10);
-  float* poly = points_encoder(f, F10, 10, nP, 20, B->map_valid_mask, "map_encoder.polygon_encoder");
+  // reference-line features are input-only too: both PointsEncoders run side by side (fused path)
+  const std::string PD = "planning_decoder";
+  float* F6 = A_alloc<float>(c, (size_t)nL * 120 * 6);
+  launch(c, "ref_feature_kernel", ref_feature_kernel, dim3(cdiv((long long)nL * 120, 256)), dim3(256), 0, B->ref_position, B->ref_vector,
+         B->ref_orientation, nL, F6);
+  float *poly = nullptr, *r_emb = nullptr;
+  const bool pe_pair = !f.fp32 && c->pe_fused;
+  if (pe_pair) points_encoder_pair(f, F10, nP, B->map_valid_mask, "map_encoder.polygon_encoder", F6, nL, B->ref_valid_mask, PD + ".r_encoder", &poly, &r_emb);
+  else poly = points_encoder(f, F10, 10, nP, 20, B->map_valid_mask, "map_encoder.polygon_encoder");
   tap(c, "poly_pe", poly, (int64_t)nP * 128);
   float* speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
   launch(c, "polygon_token_kernel", polygon_token_kernel, dim3(cdiv((long long)nP * 128, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
@@ -862,13 +877,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   }
 
   // ================= planning decoder (planning_decoder.py:135-188) =================
-  const std::string PD = "planning_decoder";
-  float* F6 = A_alloc<float>(c, (size_t)nL * 120 * 6);
-  launch(c, "ref_feature_kernel", ref_feature_kernel, dim3(cdiv((long long)nL * 120, 256)), dim3(256), 0, B->ref_position, B->ref_vector,
-         B->ref_orientation, nL, F6);
   uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
   launch(c, "refline_mask_kernel", refline_mask_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_valid_mask, nL, r_kpm);
-  float* r_emb = points_encoder(f, F6, 6, nL, 120, B->ref_valid_mask, PD + ".r_encoder");
+  if (!pe_pair) r_emb = points_encoder(f, F6, 6, nL, 120, B->ref_valid_mask, PD + ".r_encoder");
   tap(c, "r_pe", r_emb, (int64_t)nL * 128);
   float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
   launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);

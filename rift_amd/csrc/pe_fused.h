@@ -139,12 +139,11 @@ __device__ __forceinline__ void pe_tile_stats(const f32x4 (&acc)[MT][NTW], const
 // ---------------------------------------------------------------------------------------------------------------
 // pass A: BatchNorm-1 statistics of h1 = x W1^T + b1 (bf16 MFMA, exactly the values pass B recomputes)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pe_stats1_kernel(PeP p) {
+__device__ __forceinline__ void pe_stats1_body(const PeP& p, const int tile) {
   __shared__ __attribute__((aligned(16))) unsigned short xin[PE_ROWS * PE_XS];
   __shared__ unsigned char sval[PE_ROWS];
   __shared__ __attribute__((aligned(16))) float b1s[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int tile = blockIdx.x;
   PFrags<1, 2> W1;
   p_load_w<4, 1, 2>(W1, p.w1, 32, 0, wave, l15, l4);
   if (tid < 128) b1s[tid] = p.b1[tid];
@@ -160,13 +159,21 @@ __global__ __launch_bounds__(256) void pe_stats1_kernel(PeP p) {
   pe_tile_stats<8, 2, 4>(acc, sval, [&](int, int c) { return *reinterpret_cast<const float4*>(b1s + c); }, p.part1, 128, p.ntiles, tile, wave, l15, l4);
 }
 
+// two encoders (map polygons: 20 points per polyline, reference lines: 120) in one launch: tiles [0, a.ntiles) belong to `a`
+struct PeP2 { PeP a, b; };
+
+__global__ __launch_bounds__(256) void pe_stats1_kernel(PeP2 q) {
+  if ((int)blockIdx.x < q.a.ntiles) pe_stats1_body(q.a, blockIdx.x);
+  else pe_stats1_body(q.b, blockIdx.x - q.a.ntiles);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pass B
 // ---------------------------------------------------------------------------------------------------------------
 #define PE_MID_LDS (PE_ROWS * PE_XS * 2 + PE_ROWS * PE_HS * 2 + PE_ROWS * PE_FS * 2 + 16 * PE_FS * 2 + 8 * 256 * 4 + 1024 * 4 + PE_ROWS)
 
 template <int NPTS>
-__global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
+__device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
   constexpr int MT = 8, GPT = PE_USED / NPTS, NW = 8;
   constexpr int SPL = GPT >= 4 ? 1 : 4;            // row splits per polyline for the max-pool (units = GPT * SPL >= 4)
   constexpr int UNITS = GPT * SPL, RPU = NPTS / SPL;
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
   unsigned char* sval = reinterpret_cast<unsigned char*>(par + 1024);
   constexpr int P_B1 = 0, P_S1 = 128, P_T1 = 256, P_B2 = 384, P_B3 = 640;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int tile = blockIdx.x, row0 = tile * PE_USED;
+  const int row0 = tile * PE_USED;
   int tsn = 0;
 #define PTS() do { if (p.ts && tile == p.ts_tile && tid == 0) p.ts[tsn++] = clock64(); } while (0)
   PTS();
@@ -315,13 +322,18 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP p) {
 #undef PTS
 }
 
+__global__ __launch_bounds__(512) void pe_mid_kernel(PeP2 q) {
+  if ((int)blockIdx.x < q.a.ntiles) pe_mid_body<20>(q.a, blockIdx.x);
+  else pe_mid_body<120>(q.b, blockIdx.x - q.a.ntiles);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pass C
 // ---------------------------------------------------------------------------------------------------------------
 #define PE_OUT_LDS (PE_ROWS * PE_FS * 2 + 8 * 256 * 4 + 640 * 4 + PE_ROWS)
 
 template <int NPTS>
-__global__ __launch_bounds__(512) void pe_out_kernel(PeP p) {
+__device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
   constexpr int MT = 8, GPT = PE_USED / NPTS, NW = 8, OS = 132;
   constexpr int SPL = GPT >= 4 ? 1 : 4;
   constexpr int UNITS = GPT * SPL, RPU = NPTS / SPL;
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(512) void pe_out_kernel(PeP p) {
   unsigned char* sval = reinterpret_cast<unsigned char*>(par + 640);
   constexpr int P_S2 = 0, P_T2 = 256, P_B4 = 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int tile = blockIdx.x, row0 = tile * PE_USED;
+  const int row0 = tile * PE_USED;
 
   PFrags<4, 2> Wa, Wb;
   p_load_w<NW, 4, 2>(Wa, p.w3a, 256, 0, wave, l15, l4);
@@ -441,13 +453,24 @@ __global__ __launch_bounds__(512) void pe_out_kernel(PeP p) {
   }
 }
 
+__global__ __launch_bounds__(512) void pe_out_kernel(PeP2 q) {
+  if ((int)blockIdx.x < q.a.ntiles) pe_out_body<20>(q.a, blockIdx.x);
+  else pe_out_body<120>(q.b, blockIdx.x - q.a.ntiles);
+}
+
 // BatchNorm finalize over tile partials laid out [2][C][nblk] (fp32 tile sums, fp64 accumulation; one wave per channel,
 // coalesced over the tiles).  Same semantics as bn_finalize_kernel.
-__global__ void bn_finalize_t_kernel(const float* __restrict__ part, const int* __restrict__ cnt, int nblk, int C,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-                                     float* running_var, long long* num_batches, int train, int update_running, float eps,
-                                     float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+struct BnFinP {
+  const float* part; const int* cnt; int nblk, C;
+  const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches;
+  float* scale; float* shift;
+};
+
+__device__ __forceinline__ void bn_finalize_t_body(const float* __restrict__ part, const int* __restrict__ cnt, int nblk, int C,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                                   float* running_var, long long* num_batches, int train, int update_running, float eps,
+                                                   float* __restrict__ scale, float* __restrict__ shift, int blk) {
+  const int c = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (c >= C) return;
   float mean, var;
@@ -474,6 +497,17 @@ __global__ void bn_finalize_t_kernel(const float* __restrict__ part, const int* 
     scale[c] = sc;
     shift[c] = beta[c] - mean * sc;
   }
+}
+
+// the BatchNorm layers of the two encoders (same position in their pipelines) in one launch; 256 threads = 4 channels per block
+__global__ void bn_finalize_t_kernel(BnFinP a, BnFinP b, int train, int update_running, float eps) {
+  const int na = (a.C + 3) / 4;
+  if ((int)blockIdx.x < na)
+    bn_finalize_t_body(a.part, a.cnt, a.nblk, a.C, a.gamma, a.beta, a.running_mean, a.running_var, a.num_batches, train, update_running, eps,
+                       a.scale, a.shift, blockIdx.x);
+  else
+    bn_finalize_t_body(b.part, b.cnt, b.nblk, b.C, b.gamma, b.beta, b.running_mean, b.running_var, b.num_batches, train, update_running, eps,
+                       b.scale, b.shift, blockIdx.x - na);
 }
 
 }  // namespace rift
