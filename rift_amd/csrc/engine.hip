@@ -383,26 +383,34 @@ void layernorm(Fwd& f, const float* X, int ldx, float* Y, int ldy, int rows, int
 }
 
 // FourierEmbedding (fourier_embedding.py:45-55): in (rows, D) -> out (rows, 128)
+FourierP fourier_desc(Fwd& f, const float* in, int in_ld, int rows, int D, const std::string& p, int wrap_dim, float* add_to) {
+  RiftCtx* c = f.c;
+  FourierP q; memset(&q, 0, sizeof(q));
+  q.in = in; q.in_ld = in_ld; q.rows = rows; q.D = D; q.wrap_dim = wrap_dim; q.freqs = fptr(c, p + ".freqs.weight");
+  for (int d = 0; d < D; ++d) {
+    const std::string m = p + ".mlps." + std::to_string(d);
+    const PW &lo = c->pw[m + ".0.lo"], &last = c->pw[m + ".0.last"], &w3 = c->pw[m + ".3"];
+    q.w0[d] = (const unsigned short*)lo.bf; q.b0[d] = lo.bias; q.wl[d] = last.f32; q.wl_ld = last.Kp;
+    q.lng[d] = fptr(c, m + ".1.weight"); q.lnb[d] = fptr(c, m + ".1.bias");
+    q.w3[d] = (const unsigned short*)w3.bf; q.b3[d] = w3.bias;
+  }
+  q.og = fptr(c, p + ".to_out.0.weight"); q.ob = fptr(c, p + ".to_out.0.bias");
+  q.wo = (const unsigned short*)c->pw[p + ".to_out.2"].bf; q.bo = c->pw[p + ".to_out.2"].bias;
+  q.Y = add_to ? add_to : A_alloc<float>(c, (size_t)rows * 128);
+  q.accumulate = add_to ? 1 : 0;
+  return q;
+}
+
 // add_to != nullptr: the embedding is added into that (rows, 128) buffer, which is returned
 float* fourier(Fwd& f, const float* in, int in_ld, int rows, int D, const std::string& p, int wrap_dim, float* add_to = nullptr) {
   RiftCtx* c = f.c;
   if (!f.fp32 && c->fo_fused && D <= 3) {
-    FourierP q; memset(&q, 0, sizeof(q));
-    q.in = in; q.in_ld = in_ld; q.rows = rows; q.D = D; q.wrap_dim = wrap_dim; q.freqs = fptr(c, p + ".freqs.weight");
-    for (int d = 0; d < D; ++d) {
-      const std::string m = p + ".mlps." + std::to_string(d);
-      const PW &lo = c->pw[m + ".0.lo"], &last = c->pw[m + ".0.last"], &w3 = c->pw[m + ".3"];
-      q.w0[d] = (const unsigned short*)lo.bf; q.b0[d] = lo.bias; q.wl[d] = last.f32; q.wl_ld = last.Kp;
-      q.lng[d] = fptr(c, m + ".1.weight"); q.lnb[d] = fptr(c, m + ".1.bias");
-      q.w3[d] = (const unsigned short*)w3.bf; q.b3[d] = w3.bias;
-    }
-    q.og = fptr(c, p + ".to_out.0.weight"); q.ob = fptr(c, p + ".to_out.0.bias");
-    q.wo = (const unsigned short*)c->pw[p + ".to_out.2"].bf; q.bo = c->pw[p + ".to_out.2"].bias;
-    q.Y = add_to ? add_to : A_alloc<float>(c, (size_t)rows * 128);
-    q.accumulate = add_to ? 1 : 0;
+    FourierP3 q3; memset(&q3, 0, sizeof(q3));
+    q3.e[0] = fourier_desc(f, in, in_ld, rows, D, p, wrap_dim, add_to);
+    q3.nblk[0] = cdiv(rows, FO_ROWS); q3.count = 1;
     c->prof_flops = 2.0 * rows * 128.0 * (D * (129.0 + 128.0) + 128.0);
-    launch(c, "fourier_fused_kernel", fourier_fused_kernel, dim3(cdiv(rows, FO_ROWS)), dim3(256), (size_t)FO_LDS, q);
-    return q.Y;
+    launch(c, "fourier_fused_kernel", fourier_fused_kernel, dim3(q3.nblk[0]), dim3(256), (size_t)FO_LDS, q3);
+    return q3.e[0].Y;
   }
   float* FF = A_alloc<float>(c, (size_t)D * rows * 129);
   launch(c, "fourier_feature_kernel", fourier_feature_kernel, dim3(cdiv((long long)D * rows * 65, 256)), dim3(256), 0, in, in_ld, rows, D,
@@ -763,9 +771,6 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 
   // ================= tokens =================
   float* X = A_alloc<float>(c, (size_t)nT * 128);
-  launch(c, "agent_token_kernel", agent_token_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)nat_out, (const float*)x_ego,
-         (const uint8_t*)valid_agent, B->agent_category, fptr(c, "agent_encoder.type_emb.weight"), bs, A, N, X);
-
   // map encoder (map_encoder.py:31-93)
   float* F10 = A_alloc<float>(c, (size_t)nP * 20 * 10);
   launch(c, "map_feature_kernel", map_feature_kernel, dim3(cdiv((long long)nP * 20, 256)), dim3(256), 0, B->map_point_position, B->map_point_vector,
@@ -780,24 +785,44 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (pe_pair) points_encoder_pair(f, F10, nP, B->map_valid_mask, "map_encoder.polygon_encoder", F6, nL, B->ref_valid_mask, PD + ".r_encoder", &poly, &r_emb);
   else poly = points_encoder(f, F10, 10, nP, 20, B->map_valid_mask, "map_encoder.polygon_encoder");
   tap(c, "poly_pe", poly, (int64_t)nP * 128);
-  float* speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
-  launch(c, "polygon_token_kernel", polygon_token_kernel, dim3(cdiv((long long)nP * 128, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
-         B->map_polygon_on_route, B->map_polygon_tl_status, B->map_polygon_has_speed_limit, (const float*)speed_emb,
-         fptr(c, "map_encoder.type_emb.weight"), fptr(c, "map_encoder.on_route_emb.weight"),
-         fptr(c, "map_encoder.traffic_light_emb.weight"), fptr(c, "map_encoder.unknown_speed_emb.weight"), bs, A, Mp, N, X);
-  if (S > 0) {
-    float* semb = fourier(f, B->static_shape, 2, bs * S, 2, "static_objects_encoder.obj_encoder", -1);
-    launch(c, "static_token_kernel", static_token_kernel, dim3(cdiv((long long)bs * S * 128, 256)), dim3(256), 0, (const float*)semb, B->static_category,
-           B->static_valid_mask, fptr(c, "static_objects_encoder.type_emb.weight"), bs, A, Mp, S, N, X);
-  }
-  tap(c, "x_tokens_nopos", X, (int64_t)nT * 128);
   uint8_t* kpm = A_alloc<uint8_t>(c, nT);
   launch(c, "token_mask_kernel", token_mask_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, (const uint8_t*)valid_agent, B->map_valid_mask,
          B->static_valid_mask, bs, A, Mp, S, kpm);
   float* pos = A_alloc<float>(c, (size_t)nT * 3);
   launch(c, "token_pos_kernel", token_pos_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, B->agent_position, B->agent_heading, T, B->map_polygon_center,
          B->static_position, B->static_heading, bs, A, Mp, S, pos);
-  fourier(f, pos, 3, nT, 3, "pos_emb", 2, X);
+  // the three Fourier embeddings (token positions, speed limits, reference-line positions) depend on inputs only: with both
+  // PointsEncoders done they run as ONE launch, and the token kernels add the positional embedding on the way
+  const bool fo3 = pe_pair && !f.fp32 && c->fo_fused && S == 0;
+  float *speed_emb = nullptr, *PEtok = nullptr;
+  bool rpe_done = false;
+  if (fo3) {
+    float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
+    launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
+    tap(c, "r_pe", r_emb, (int64_t)nL * 128);
+    FourierP3 q3; memset(&q3, 0, sizeof(q3));
+    q3.e[0] = fourier_desc(f, pos, 3, nT, 3, "pos_emb", 2, nullptr);
+    q3.e[1] = fourier_desc(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1, nullptr);
+    q3.e[2] = fourier_desc(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1, r_emb);
+    q3.nblk[0] = cdiv(nT, FO_ROWS); q3.nblk[1] = cdiv(nP, FO_ROWS); q3.nblk[2] = cdiv(nL, FO_ROWS); q3.count = 3;
+    c->prof_flops = 2.0 * 128.0 * ((nT + nL) * (3 * 257.0 + 128.0) + nP * (257.0 + 128.0));
+    launch(c, "fourier_fused_kernel", fourier_fused_kernel, dim3(q3.nblk[0] + q3.nblk[1] + q3.nblk[2]), dim3(256), (size_t)FO_LDS, q3);
+    PEtok = q3.e[0].Y; speed_emb = q3.e[1].Y; rpe_done = true;
+  } else {
+    speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
+  }
+  launch(c, "agent_token_kernel", agent_token_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)nat_out, (const float*)x_ego,
+         (const uint8_t*)valid_agent, B->agent_category, fptr(c, "agent_encoder.type_emb.weight"), bs, A, N, X, (const float*)PEtok);
+  launch(c, "polygon_token_kernel", polygon_token_kernel, dim3(cdiv((long long)nP * 128, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
+         B->map_polygon_on_route, B->map_polygon_tl_status, B->map_polygon_has_speed_limit, (const float*)speed_emb,
+         fptr(c, "map_encoder.type_emb.weight"), fptr(c, "map_encoder.on_route_emb.weight"),
+         fptr(c, "map_encoder.traffic_light_emb.weight"), fptr(c, "map_encoder.unknown_speed_emb.weight"), bs, A, Mp, N, X, (const float*)PEtok);
+  if (S > 0) {
+    float* semb = fourier(f, B->static_shape, 2, bs * S, 2, "static_objects_encoder.obj_encoder", -1);
+    launch(c, "static_token_kernel", static_token_kernel, dim3(cdiv((long long)bs * S * 128, 256)), dim3(256), 0, (const float*)semb, B->static_category,
+           B->static_valid_mask, fptr(c, "static_objects_encoder.type_emb.weight"), bs, A, Mp, S, N, X);
+  }
+  if (!fo3) fourier(f, pos, 3, nT, 3, "pos_emb", 2, X);
   tap(c, "x_tokens", X, (int64_t)nT * 128);
 
   // ================= encoder blocks (transformer.py:73-94) =================
@@ -880,10 +905,12 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
   launch(c, "refline_mask_kernel", refline_mask_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_valid_mask, nL, r_kpm);
   if (!pe_pair) r_emb = points_encoder(f, F6, 6, nL, 120, B->ref_valid_mask, PD + ".r_encoder");
-  tap(c, "r_pe", r_emb, (int64_t)nL * 128);
-  float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
-  launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
-  fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1, r_emb);
+  if (!rpe_done) {
+    tap(c, "r_pe", r_emb, (int64_t)nL * 128);
+    float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
+    launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
+    fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1, r_emb);
+  }
   tap(c, "r_emb", r_emb, (int64_t)nL * 128);
   float* Ra = A_alloc<float>(c, (size_t)nL * 128);
   gemm(c, mk(r_emb, 128, nL, c->pw[PD + ".q_proj.r"], Ra, 128), c->pw[PD + ".q_proj.r"], f.fp32);

@@ -29,7 +29,7 @@ struct FourierP {
 #define FO_NPAR (3 * 5 * 128 + 3 * 128)
 #define FO_LDS (FO_ROWS * FO_FS * 2 * 2 + FO_ROWS * FO_HS * 4 + FO_ROWS * 4 * 4 + FO_NPAR * 4)
 
-__global__ __launch_bounds__(256) void fourier_fused_kernel(FourierP p) {
+__device__ __forceinline__ void fourier_fused_body(const FourierP& p, const int blk) {
   constexpr int MT = 4, NW = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* feat = reinterpret_cast<unsigned short*>(smem_raw);
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void fourier_fused_kernel(FourierP p) {
   float* xs = hf + FO_ROWS * FO_HS;            // [64][4]
   float* par = xs + FO_ROWS * 4;               // per dim: b0 | lng | lnb | wl | b3 (640), then og | ob | bo
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int row0 = blockIdx.x * FO_ROWS;
+  const int row0 = blk * FO_ROWS;
   const int D = p.D;
 
   PFrags<4, 2> W0, W3;
@@ -160,6 +160,18 @@ __global__ __launch_bounds__(256) void fourier_fused_kernel(FourierP p) {
       }
     }
   }
+}
+
+// up to three embeddings (token positions, speed limits, reference-line positions) in one launch: blocks are dealt in order
+struct FourierP3 { FourierP e[3]; int nblk[3]; int count; };
+
+__global__ __launch_bounds__(256) void fourier_fused_kernel(FourierP3 q) {
+  int blk = blockIdx.x;
+  if (blk < q.nblk[0]) { fourier_fused_body(q.e[0], blk); return; }
+  blk -= q.nblk[0];
+  if (q.count > 1 && blk < q.nblk[1]) { fourier_fused_body(q.e[1], blk); return; }
+  blk -= q.nblk[1];
+  if (q.count > 2) fourier_fused_body(q.e[2], blk);
 }
 
 }  // namespace rift

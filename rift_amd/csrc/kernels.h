@@ -537,14 +537,16 @@ __global__ void ego_dropmask_kernel(int bs, float p, uint32_t seed, uint32_t str
 // agent tokens: x[b][a] = (a == 0 ? x_ego[b] : valid ? nat[b*A+a] : 0) + type_emb[cat] ; written into token row (b*N + a)
 __global__ void agent_token_kernel(const float* __restrict__ nat, const float* __restrict__ x_ego,
                                    const uint8_t* __restrict__ valid_agent, const int8_t* __restrict__ category,
-                                   const float* __restrict__ type_emb, int bs, int A, int N, float* __restrict__ X) {
+                                   const float* __restrict__ type_emb, int bs, int A, int N, float* __restrict__ X,
+                                   const float* __restrict__ pe /*optional (bs*N,128) positional embedding added on the way*/) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= bs * A * 128) return;
   const int c = idx & 127, a = (idx >> 7) % A, b = idx / (A * 128);
   const int ag = b * A + a;
   float v = (a == 0) ? x_ego[(size_t)b * 128 + c] : (valid_agent[ag] ? nat[(size_t)ag * 128 + c] : 0.f);
   v += type_emb[(int)category[ag] * 128 + c];
-  X[((size_t)b * N + a) * 128 + c] = v;
+  const size_t o = ((size_t)b * N + a) * 128 + c;
+  X[o] = pe ? v + pe[o] : v;
 }
 
 // polygon tokens (map_encoder.py:82-91): x = pooled + type + on_route + tl + (has ? speed_emb : unknown)
@@ -553,7 +555,7 @@ __global__ void polygon_token_kernel(const float* __restrict__ pooled, const int
                                      const uint8_t* __restrict__ has_sl, const float* __restrict__ speed_emb,
                                      const float* __restrict__ type_emb, const float* __restrict__ route_emb,
                                      const float* __restrict__ tl_emb, const float* __restrict__ unk_emb, int bs,
-                                     int A, int Mp, int N, float* __restrict__ X) {
+                                     int A, int Mp, int N, float* __restrict__ X, const float* __restrict__ pe) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= bs * Mp * 128) return;
   const int c = idx & 127, m = (idx >> 7) % Mp, b = idx / (Mp * 128);
@@ -561,7 +563,8 @@ __global__ void polygon_token_kernel(const float* __restrict__ pooled, const int
   float v = pooled[(size_t)pg * 128 + c] + type_emb[(int)ptype[pg] * 128 + c] +
             route_emb[(on_route[pg] ? 1 : 0) * 128 + c] + tl_emb[(int)tl[pg] * 128 + c];
   v += has_sl[pg] ? speed_emb[(size_t)pg * 128 + c] : unk_emb[c];
-  X[((size_t)b * N + A + m) * 128 + c] = v;
+  const size_t o = ((size_t)b * N + A + m) * 128 + c;
+  X[o] = pe ? v + pe[o] : v;
 }
 
 // static-object tokens (static_objects_encoder.py:24-26): valid ? fourier(shape) + type_emb : 0
