@@ -620,10 +620,31 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   const std::string HE = "agent_encoder.history_encoder";
 
   // ================= agent encoder (agent_encoder.py:54-96, embedding.py:62-87) =================
+  // ---- input-only preparation: one launch (prep_kernel) for the seven feature / mask / position builders
   float* F9 = A_alloc<float>(c, (size_t)nA * 20 * 9);
   uint8_t* valid_agent = A_alloc<uint8_t>(c, nA);
-  launch(c, "agent_feature_kernel", agent_feature_kernel, dim3(cdiv((long long)nA * 20, 256)), dim3(256), 0, B->agent_position, B->agent_heading,
-         B->agent_velocity, B->agent_shape, B->agent_valid_mask, nA, T, F9, valid_agent);
+  float* F10 = A_alloc<float>(c, (size_t)nP * 20 * 10);
+  float* F6 = A_alloc<float>(c, (size_t)nL * 120 * 6);
+  uint8_t* kpm = A_alloc<uint8_t>(c, nT);
+  float* pos = A_alloc<float>(c, (size_t)nT * 3);
+  float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
+  uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
+  {
+    PrepP q; memset(&q, 0, sizeof(q));
+    q.agent_pos = B->agent_position; q.agent_head = B->agent_heading; q.agent_vel = B->agent_velocity; q.agent_shape = B->agent_shape;
+    q.agent_valid = B->agent_valid_mask; q.nA = nA; q.Tfull = T; q.F9 = F9; q.valid_agent = valid_agent;
+    q.map_pp = B->map_point_position; q.map_pv = B->map_point_vector; q.map_po = B->map_point_orientation; q.map_center = B->map_polygon_center;
+    q.nPoly = nP; q.F10 = F10;
+    q.ref_pos = B->ref_position; q.ref_vec = B->ref_vector; q.ref_ori = B->ref_orientation; q.ref_valid = B->ref_valid_mask; q.nLine = nL;
+    q.F6 = F6; q.r_pos = r_pos; q.r_kpm = r_kpm;
+    q.map_valid = B->map_valid_mask; q.static_valid = B->static_valid_mask; q.st_pos = B->static_position; q.st_head = B->static_heading;
+    q.bs = bs; q.A = A; q.Mp = Mp; q.S = S; q.kpm = kpm; q.pos = pos;
+    q.nb[0] = cdiv((long long)nA * 20, 256); q.nb[1] = cdiv((long long)nP * 20, 256); q.nb[2] = cdiv((long long)nL * 120, 256);
+    q.nb[3] = cdiv(nL, 256); q.nb[4] = cdiv(nL, 256); q.nb[5] = cdiv(nT, 256); q.nb[6] = cdiv(nT, 256);
+    int tot = 0;
+    for (int i = 0; i < 7; ++i) tot += q.nb[i];
+    launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
+  }
   static const float dpr[6] = {0.f, 0.04f, 0.08f, 0.12f, 0.16f, 0.2f};   // linspace(0, 0.2, 6), embedding.py:30
   const bool fused = c->nat_fused && !f.fp32;
   static const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128}, Hl[3] = {2, 4, 8}, Kl[3] = {3, 3, 5};
@@ -772,33 +793,19 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // ================= tokens =================
   float* X = A_alloc<float>(c, (size_t)nT * 128);
   // map encoder (map_encoder.py:31-93)
-  float* F10 = A_alloc<float>(c, (size_t)nP * 20 * 10);
-  launch(c, "map_feature_kernel", map_feature_kernel, dim3(cdiv((long long)nP * 20, 256)), dim3(256), 0, B->map_point_position, B->map_point_vector,
-         B->map_point_orientation, B->map_polygon_center, nP, F10);
   // reference-line features are input-only too: both PointsEncoders run side by side (fused path)
   const std::string PD = "planning_decoder";
-  float* F6 = A_alloc<float>(c, (size_t)nL * 120 * 6);
-  launch(c, "ref_feature_kernel", ref_feature_kernel, dim3(cdiv((long long)nL * 120, 256)), dim3(256), 0, B->ref_position, B->ref_vector,
-         B->ref_orientation, nL, F6);
   float *poly = nullptr, *r_emb = nullptr;
   const bool pe_pair = !f.fp32 && c->pe_fused;
   if (pe_pair) points_encoder_pair(f, F10, nP, B->map_valid_mask, "map_encoder.polygon_encoder", F6, nL, B->ref_valid_mask, PD + ".r_encoder", &poly, &r_emb);
   else poly = points_encoder(f, F10, 10, nP, 20, B->map_valid_mask, "map_encoder.polygon_encoder");
   tap(c, "poly_pe", poly, (int64_t)nP * 128);
-  uint8_t* kpm = A_alloc<uint8_t>(c, nT);
-  launch(c, "token_mask_kernel", token_mask_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, (const uint8_t*)valid_agent, B->map_valid_mask,
-         B->static_valid_mask, bs, A, Mp, S, kpm);
-  float* pos = A_alloc<float>(c, (size_t)nT * 3);
-  launch(c, "token_pos_kernel", token_pos_kernel, dim3(cdiv(nT, 256)), dim3(256), 0, B->agent_position, B->agent_heading, T, B->map_polygon_center,
-         B->static_position, B->static_heading, bs, A, Mp, S, pos);
   // the three Fourier embeddings (token positions, speed limits, reference-line positions) depend on inputs only: with both
   // PointsEncoders done they run as ONE launch, and the token kernels add the positional embedding on the way
   const bool fo3 = pe_pair && !f.fp32 && c->fo_fused && S == 0;
   float *speed_emb = nullptr, *PEtok = nullptr;
   bool rpe_done = false;
   if (fo3) {
-    float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
-    launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
     tap(c, "r_pe", r_emb, (int64_t)nL * 128);
     FourierP3 q3; memset(&q3, 0, sizeof(q3));
     q3.e[0] = fourier_desc(f, pos, 3, nT, 3, "pos_emb", 2, nullptr);
@@ -902,13 +909,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   }
 
   // ================= planning decoder (planning_decoder.py:135-188) =================
-  uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
-  launch(c, "refline_mask_kernel", refline_mask_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_valid_mask, nL, r_kpm);
   if (!pe_pair) r_emb = points_encoder(f, F6, 6, nL, 120, B->ref_valid_mask, PD + ".r_encoder");
   if (!rpe_done) {
     tap(c, "r_pe", r_emb, (int64_t)nL * 128);
-    float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
-    launch(c, "refline_pos_kernel", refline_pos_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, B->ref_position, B->ref_orientation, nL, r_pos);
     fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1, r_emb);
   }
   tap(c, "r_emb", r_emb, (int64_t)nL * 128);

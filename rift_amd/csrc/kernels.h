@@ -38,11 +38,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* dst, int
 // ---------------------------------------------------------------------------
 // agent 9-channel difference features (agent_encoder.py:54-75) -> F[(b*A+a)*20 + t][9]
 // also valid_agent[b*A+a] = any(valid[:21])
-__global__ void agent_feature_kernel(const float* __restrict__ pos, const float* __restrict__ head,
+__device__ __forceinline__ void agent_feature_body(const float* __restrict__ pos, const float* __restrict__ head,
                                      const float* __restrict__ vel, const float* __restrict__ shp,
                                      const uint8_t* __restrict__ valid, int nA, int Tfull,
-                                     float* __restrict__ F, uint8_t* __restrict__ valid_agent) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (agent, t) t in [0,20)
+                                     float* __restrict__ F, uint8_t* __restrict__ valid_agent, const int vblk) {
+  const int idx = vblk * (int)blockDim.x + (int)threadIdx.x;   // (agent, t) t in [0,20)
   if (idx >= nA * 20) return;
   const int a = idx / 20, t = idx - a * 20;
   const size_t b1 = (size_t)a * Tfull + t + 1, b0 = b1 - 1;
@@ -64,12 +64,18 @@ __global__ void agent_feature_kernel(const float* __restrict__ pos, const float*
     valid_agent[a] = any ? 1 : 0;
   }
 }
+__global__ void agent_feature_kernel(const float* __restrict__ pos, const float* __restrict__ head,
+                                     const float* __restrict__ vel, const float* __restrict__ shp,
+                                     const uint8_t* __restrict__ valid, int nA, int Tfull,
+                                     float* __restrict__ F, uint8_t* __restrict__ valid_agent) {
+  agent_feature_body(pos, head, vel, shp, valid, nA, Tfull, F, valid_agent, blockIdx.x);
+}
 
 // map 10-channel point features (map_encoder.py:43-59) -> F[(b*Mp+m)*20 + p][10]
-__global__ void map_feature_kernel(const float* __restrict__ pp, const float* __restrict__ pv,
+__device__ __forceinline__ void map_feature_body(const float* __restrict__ pp, const float* __restrict__ pv,
                                    const float* __restrict__ po, const float* __restrict__ center,
-                                   int nPoly, float* __restrict__ F) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (poly, p)
+                                   int nPoly, float* __restrict__ F, const int vblk) {
+  const int idx = vblk * (int)blockDim.x + (int)threadIdx.x;   // (poly, p)
   if (idx >= nPoly * 20) return;
   const int m = idx / 20, p = idx - m * 20;
   const float* P0 = pp + ((size_t)(m * 3 + 0) * 20 + p) * 2;
@@ -85,11 +91,16 @@ __global__ void map_feature_kernel(const float* __restrict__ pp, const float* __
   o[6] = P1[0] - P0[0]; o[7] = P1[1] - P0[1];
   o[8] = P2[0] - P0[0]; o[9] = P2[1] - P0[1];
 }
+__global__ void map_feature_kernel(const float* __restrict__ pp, const float* __restrict__ pv,
+                                   const float* __restrict__ po, const float* __restrict__ center,
+                                   int nPoly, float* __restrict__ F) {
+  map_feature_body(pp, pv, po, center, nPoly, F, blockIdx.x);
+}
 
 // reference-line 6-channel features (planning_decoder.py:145-153) -> F[(b*R+r)*120 + p][6]
-__global__ void ref_feature_kernel(const float* __restrict__ rp, const float* __restrict__ rv,
-                                   const float* __restrict__ ro, int nLine, float* __restrict__ F) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ref_feature_body(const float* __restrict__ rp, const float* __restrict__ rv,
+                                   const float* __restrict__ ro, int nLine, float* __restrict__ F, const int vblk) {
+  const int idx = vblk * (int)blockDim.x + (int)threadIdx.x;
   if (idx >= nLine * 120) return;
   const int l = idx / 120;
   const float* p0 = rp + (size_t)l * 120 * 2;
@@ -99,6 +110,10 @@ __global__ void ref_feature_kernel(const float* __restrict__ rp, const float* __
   o[2] = rv[(size_t)idx * 2]; o[3] = rv[(size_t)idx * 2 + 1];
   const float a = ro[idx];
   o[4] = cosf(a); o[5] = sinf(a);
+}
+__global__ void ref_feature_kernel(const float* __restrict__ rp, const float* __restrict__ rv,
+                                   const float* __restrict__ ro, int nLine, float* __restrict__ F) {
+  ref_feature_body(rp, rv, ro, nLine, F, blockIdx.x);
 }
 
 // Fourier features (fourier_embedding.py:49-50): row r, input dim d -> F[d][r][129] = [cos(2pi f x), sin(..), x]
@@ -449,15 +464,23 @@ __global__ void masked_maxpool_kernel(const float* __restrict__ X, int ld, int g
 // small assembly kernels
 // ---------------------------------------------------------------------------
 // key padding masks: kpm[b][tok] for tok in agents | polygons | static (True = padded)
-__global__ void token_mask_kernel(const uint8_t* __restrict__ valid_agent, const uint8_t* __restrict__ map_valid,
+__device__ __forceinline__ void token_mask_body(const uint8_t* __restrict__ valid_agent, const uint8_t* __restrict__ map_valid,
                                   const uint8_t* __restrict__ static_valid, int bs, int A, int Mp, int S,
-                                  uint8_t* __restrict__ kpm) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+                                  uint8_t* __restrict__ kpm, const int vblk, const uint8_t* __restrict__ agent_valid_raw = nullptr,
+                                  int Tfull = 0) {
+  const int idx = vblk * (int)blockDim.x + (int)threadIdx.x;
   const int N = A + Mp + S;
   if (idx >= bs * N) return;
   const int b = idx / N, t = idx - b * N;
   uint8_t pad;
-  if (t < A) pad = !valid_agent[b * A + t];
+  if (t < A) {
+    if (valid_agent) pad = !valid_agent[b * A + t];
+    else {   // straight from the (agent, time) validity (same rule as agent_feature_body's valid_agent)
+      bool any = false;
+      for (int i = 0; i < 21; ++i) any |= (agent_valid_raw[(size_t)(b * A + t) * Tfull + i] != 0);
+      pad = !any;
+    }
+  }
   else if (t < A + Mp) {
     bool any = false;
     const uint8_t* v = map_valid + ((size_t)b * Mp + (t - A)) * 20;
@@ -466,21 +489,29 @@ __global__ void token_mask_kernel(const uint8_t* __restrict__ valid_agent, const
   } else pad = !static_valid[b * S + (t - A - Mp)];
   kpm[idx] = pad;
 }
+__global__ void token_mask_kernel(const uint8_t* __restrict__ valid_agent, const uint8_t* __restrict__ map_valid,
+                                  const uint8_t* __restrict__ static_valid, int bs, int A, int Mp, int S,
+                                  uint8_t* __restrict__ kpm) {
+  token_mask_body(valid_agent, map_valid, static_valid, bs, A, Mp, S, kpm, blockIdx.x);
+}
 
 // ref-line key padding: r_kpm[b*R + r] = !any(valid[b,r,:120])
-__global__ void refline_mask_kernel(const uint8_t* __restrict__ rvalid, int nLine, uint8_t* __restrict__ r_kpm) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void refline_mask_body(const uint8_t* __restrict__ rvalid, int nLine, uint8_t* __restrict__ r_kpm, const int vblk) {
+  const int l = vblk * (int)blockDim.x + (int)threadIdx.x;
   if (l >= nLine) return;
   bool any = false;
   for (int i = 0; i < 120; ++i) any |= (rvalid[(size_t)l * 120 + i] != 0);
   r_kpm[l] = !any;
 }
+__global__ void refline_mask_kernel(const uint8_t* __restrict__ rvalid, int nLine, uint8_t* __restrict__ r_kpm) {
+  refline_mask_body(rvalid, nLine, r_kpm, blockIdx.x);
+}
 
 // token positions for pos_emb: pos[b][tok][3] = (x, y, angle) (pluto_model.py:131-146; wrap applied in fourier kernel)
-__global__ void token_pos_kernel(const float* __restrict__ agent_pos, const float* __restrict__ agent_head, int Tfull,
+__device__ __forceinline__ void token_pos_body(const float* __restrict__ agent_pos, const float* __restrict__ agent_head, int Tfull,
                                  const float* __restrict__ center, const float* __restrict__ st_pos,
-                                 const float* __restrict__ st_head, int bs, int A, int Mp, int S, float* __restrict__ pos) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+                                 const float* __restrict__ st_head, int bs, int A, int Mp, int S, float* __restrict__ pos, const int vblk) {
+  const int idx = vblk * (int)blockDim.x + (int)threadIdx.x;
   const int N = A + Mp + S;
   if (idx >= bs * N) return;
   const int b = idx / N, t = idx - b * N;
@@ -496,6 +527,11 @@ __global__ void token_pos_kernel(const float* __restrict__ agent_pos, const floa
     x = st_pos[o * 2]; y = st_pos[o * 2 + 1]; a = st_head[o];
   }
   pos[(size_t)idx * 3] = x; pos[(size_t)idx * 3 + 1] = y; pos[(size_t)idx * 3 + 2] = a;
+}
+__global__ void token_pos_kernel(const float* __restrict__ agent_pos, const float* __restrict__ agent_head, int Tfull,
+                                 const float* __restrict__ center, const float* __restrict__ st_pos,
+                                 const float* __restrict__ st_head, int bs, int A, int Mp, int S, float* __restrict__ pos) {
+  token_pos_body(agent_pos, agent_head, Tfull, center, st_pos, st_head, bs, A, Mp, S, pos, blockIdx.x);
 }
 
 // FPN top-down merge restricted to the positions the last output step depends on
@@ -594,11 +630,15 @@ __global__ void build_q0_kernel(const float* __restrict__ Ra, const float* __res
 }
 
 // r_pos[(b,r)] = (position[b,r,0,:], orientation[b,r,0])  (planning_decoder.py:159)
-__global__ void refline_pos_kernel(const float* __restrict__ rp, const float* __restrict__ ro, int nLine,
-                                   float* __restrict__ pos) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void refline_pos_body(const float* __restrict__ rp, const float* __restrict__ ro, int nLine,
+                                   float* __restrict__ pos, const int vblk) {
+  const int l = vblk * (int)blockDim.x + (int)threadIdx.x;
   if (l >= nLine) return;
   pos[l * 3] = rp[(size_t)l * 240]; pos[l * 3 + 1] = rp[(size_t)l * 240 + 1]; pos[l * 3 + 2] = ro[(size_t)l * 120];
+}
+__global__ void refline_pos_kernel(const float* __restrict__ rp, const float* __restrict__ ro, int nLine,
+                                   float* __restrict__ pos) {
+  refline_pos_body(rp, ro, nLine, pos, blockIdx.x);
 }
 
 // gather rows: Y[i] = X[rowidx(i)] with rowidx = (i / per) * stride_rows + off  (token 0 of each scene etc.)
@@ -609,6 +649,36 @@ __global__ void gather_rows_kernel(const float* __restrict__ X, int ldx, float* 
   const int c = idx % C, r = idx / C;
   const size_t src = (size_t)(r / per) * stride_rows + off + (r % per);
   Y[(size_t)r * ldy + c] = X[src * ldx + c];
+}
+
+// ---------------------------------------------------------------------------
+// All input-only preparation of a forward in ONE launch: agent difference features + agent validity, map / reference-line point
+// features, token key-padding masks and positions, reference-line masks and positions.  Seven ~6 us dispatches become one.
+// ---------------------------------------------------------------------------
+struct PrepP {
+  const float *agent_pos, *agent_head, *agent_vel, *agent_shape; const uint8_t* agent_valid; int nA, Tfull;
+  float* F9; uint8_t* valid_agent;
+  const float *map_pp, *map_pv, *map_po, *map_center; int nPoly; float* F10;
+  const float *ref_pos, *ref_vec, *ref_ori; const uint8_t* ref_valid; int nLine; float* F6; float* r_pos; uint8_t* r_kpm;
+  const uint8_t *map_valid, *static_valid; const float *st_pos, *st_head; int bs, A, Mp, S; uint8_t* kpm; float* pos;
+  int nb[7];
+};
+
+__global__ __launch_bounds__(256) void prep_kernel(PrepP q) {
+  int blk = blockIdx.x;
+  if (blk < q.nb[0]) { agent_feature_body(q.agent_pos, q.agent_head, q.agent_vel, q.agent_shape, q.agent_valid, q.nA, q.Tfull, q.F9, q.valid_agent, blk); return; }
+  blk -= q.nb[0];
+  if (blk < q.nb[1]) { map_feature_body(q.map_pp, q.map_pv, q.map_po, q.map_center, q.nPoly, q.F10, blk); return; }
+  blk -= q.nb[1];
+  if (blk < q.nb[2]) { ref_feature_body(q.ref_pos, q.ref_vec, q.ref_ori, q.nLine, q.F6, blk); return; }
+  blk -= q.nb[2];
+  if (blk < q.nb[3]) { refline_pos_body(q.ref_pos, q.ref_ori, q.nLine, q.r_pos, blk); return; }
+  blk -= q.nb[3];
+  if (blk < q.nb[4]) { refline_mask_body(q.ref_valid, q.nLine, q.r_kpm, blk); return; }
+  blk -= q.nb[4];
+  if (blk < q.nb[5]) { token_mask_body(nullptr, q.map_valid, q.static_valid, q.bs, q.A, q.Mp, q.S, q.kpm, blk, q.agent_valid, q.Tfull); return; }
+  blk -= q.nb[5];
+  token_pos_body(q.agent_pos, q.agent_head, q.Tfull, q.map_center, q.st_pos, q.st_head, q.bs, q.A, q.Mp, q.S, q.pos, blk);
 }
 
 }  // namespace rift
