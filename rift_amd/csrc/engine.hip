@@ -36,7 +36,11 @@
 #define NAT_L1_CW 192
 #define NAT_L2_NW 8
 #define NAT_L2_CW 192
-#define NAT_L0 (rift::nat_level_kernel<32, 2, 20, 3, NAT_L0_NW, NAT_L0_CW, 4>)
+#ifndef NAT_L0_ROWS
+#define NAT_L0_ROWS 80
+#endif
+#define NAT_L0_WPE (NAT_L0_ROWS > 80 ? 2 : 4)
+#define NAT_L0 (rift::nat_level_kernel<32, 2, 20, 3, NAT_L0_NW, NAT_L0_CW, NAT_L0_WPE, NAT_L0_ROWS>)
 #define NAT_L1 (rift::nat_level_kernel<64, 4, 10, 3, NAT_L1_NW, NAT_L1_CW>)
 #define NAT_L2 (rift::nat_level_kernel<128, 8, 5, 5, NAT_L2_NW, NAT_L2_CW>)
 
@@ -678,10 +682,11 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       }
       { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == lv + 1) { p.ts = A_alloc<long long>(c, 256); tap(c, "nat_ts", (float*)p.ts, 512); } }
       // persistent workgroups (one per CU at 8 waves), each looping over row tiles with the next tile prefetched
-      const dim3 grid(std::min(cdiv(rows, 80), lv == 0 ? c->nat_grid0 : c->nat_grid));   // level 0 fits two workgroups per CU
+      const int trows = lv == 0 ? NAT_L0_ROWS : 80;
+      const dim3 grid(std::min(cdiv(rows, trows), lv == 0 ? (NAT_L0_ROWS > 80 ? c->nat_grid : c->nat_grid0) : c->nat_grid));   // level 0 fits two workgroups per CU
       (void)H;
       c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (lv == 0 ? 2.0 * rows * 27 * 32 : 0.0) + (lv < 2 ? (rows / 2) * 2.0 * 3 * C * 2 * C : 0.0);
-      if (lv == 0) launch(c, "nat_level_kernel_L0", NAT_L0, grid, dim3(64 * NAT_L0_NW), nat_lds_bytes(32, 2, 3, NAT_L0_CW), p);
+      if (lv == 0) launch(c, "nat_level_kernel_L0", NAT_L0, grid, dim3(64 * NAT_L0_NW), nat_lds_bytes(32, 2, 3, NAT_L0_CW, NAT_L0_ROWS), p);
       else if (lv == 1) launch(c, "nat_level_kernel_L1", NAT_L1, grid, dim3(64 * NAT_L1_NW), nat_lds_bytes(64, 4, 3, NAT_L1_CW), p);
       else launch(c, "nat_level_kernel_L2", NAT_L2, grid, dim3(64 * NAT_L2_NW), nat_lds_bytes(128, 8, 5, NAT_L2_CW), p);
     }

@@ -109,18 +109,21 @@ __device__ __forceinline__ void mma_rows(f32x4 (&acc)[MTN][NTW], const unsigned 
 }
 
 // dynamic LDS bytes of nat_level_kernel<C, NHEAD, L, KSZ, NW, CWMAX>
-constexpr size_t nat_lds_bytes(int C, int NHEAD, int KSZ, int CWMAX) {
+constexpr size_t nat_lds_bytes(int C, int NHEAD, int KSZ, int CWMAX, int ROWS = 80) {
+  const int DSR = (ROWS / 2 + 15) / 16 * 16;
   const int C3 = 3 * C, CWK = C3 < CWMAX ? C3 : CWMAX, CB = CWK + 8, DSB = C3 + 8;
-  const int cbsz = (C <= 64 && 48 * DSB > 80 * CB) ? 48 * DSB : 80 * CB;
+  const int cbsz = (C <= 64 && DSR * DSB > ROWS * CB) ? DSR * DSB : ROWS * CB;
   const int nrpb = NHEAD * (2 * KSZ - 1);
-  return (size_t)80 * (C + 4) * 4 + (size_t)80 * (C + 8) * 2 * 2 + (size_t)cbsz * 2 + (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4 + (size_t)6 * C * 4;
+  return (size_t)ROWS * (C + 4) * 4 + (size_t)ROWS * (C + 8) * 2 * 2 + (size_t)cbsz * 2 + (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4 + (size_t)6 * C * 4;
 }
 
 // NW waves per workgroup (n-tiles and rows are dealt round-robin to the waves); CWMAX = widest qkv / hidden chunk
 // WPE = waves per SIMD the register allocation must leave room for (2 = one 8-wave workgroup per CU, 4 = two)
-template <int C, int NHEAD, int L, int KSZ, int NW = 4, int CWMAX = 192, int WPE = 1>
+// ROWS_ = rows per tile (a multiple of 16 and of L): small-C levels take larger tiles so that a phase carries enough work
+template <int C, int NHEAD, int L, int KSZ, int NW = 4, int CWMAX = 192, int WPE = 1, int ROWS_ = 80>
 __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
-  constexpr int ROWS = 80, MT = 5;
+  constexpr int ROWS = ROWS_, MT = ROWS / 16;
+  static_assert(ROWS % 16 == 0 && ROWS % L == 0 && (ROWS / 2) % (L / 2 > 0 ? L / 2 : 1) == 0, "tile = whole sequences, whole MFMA tiles");
   constexpr int C3 = 3 * C;
   constexpr int NTH = 64 * NW;
   constexpr int CWK = C3 < CWMAX ? C3 : CWMAX;        // chunk width (columns of qkv / hidden processed at once)
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
   unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
   unsigned short* cb = xn + ROWS * XN;
   constexpr int DSB = C3 + 8;                     // row stride of the downsample conv's A tile (staged in cb)
-  constexpr int CBSZ = (C <= 64 && 48 * DSB > ROWS * CB) ? 48 * DSB : ROWS * CB;
+  constexpr int DSR = (ROWS / 2 + 15) / 16 * 16;   // rows of the downsample conv's A tile
+  constexpr int CBSZ = (C <= 64 && DSR * DSB > ROWS * CB) ? DSR * DSB : ROWS * CB;
   unsigned short* ao = cb + CBSZ;
   // both layers' bias / LayerNorm / rpb vectors live in LDS (fetched once at kernel start): no epilogue or
   // LayerNorm begins with a dependent global load
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int j = 0; j < NTW_C; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mma80<1, NTW_C>(acc, xn, XN, Wt, l15, l4);
+        mma_rows<MT, 1, NTW_C>(acc, xn, XN, Wt, l15, l4);
 #pragma unroll
         for (int j = 0; j < NTW_C; ++j) {
           const int nt = j * NW + wave;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int j = 0; j < NTW_CH; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!(p.dbg & 8)) mma80<KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
+        if (!(p.dbg & 8)) mma_rows<MT, KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
         // prefetch the next phase's weights (next qkv chunk, or proj)
         if (ch + 1 < NCH) load_b(Bq, w.wqkv, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
         else load_b(Bp, w.wproj, C, 0, 0, NT_C, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NTW_C; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      mma80<KS1, NTW_C>(acc, ao, XN, Bp, l15, l4);
+      mma_rows<MT, KS1, NTW_C>(acc, ao, XN, Bp, l15, l4);
       load_b(Bq, w.w1, C, 0, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());     // fc1 weights of hidden chunk 0
       float dps[MT];
 #pragma unroll
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < NTW_CH; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (!(p.dbg & 8)) mma80<KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
+          if (!(p.dbg & 8)) mma_rows<MT, KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
           load_b(B2, w.w2, C3, 0, ch * CWK, NT_C, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());          // fc2 weights of this hidden chunk
           if (ch > 0) __syncthreads();   // the previous chunk's fc2 reads of cb are complete
 #pragma unroll
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         __syncthreads();
         NTS();
         // ---- fc2 partial: acc2 += cb[80][CWK] . W2[:, ch*CWK..]^T
-        if (!(p.dbg & 8)) mma80<KSC, NTW_C>(acc2, cb, CB, B2, l15, l4);
+        if (!(p.dbg & 8)) mma_rows<MT, KSC, NTW_C>(acc2, cb, CB, B2, l15, l4);
         NTS();
       }
       float dps[MT];
@@ -508,12 +512,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
   }
   if constexpr (C <= 64) {
     if (p.Xnext) {
-      constexpr int MD = 3, RD = ROWS / 2, L2 = L / 2, C2 = 2 * C;       // 40 output rows in 3 m-tiles
+      constexpr int RD = ROWS / 2, MD = DSR / 16, L2 = L / 2, C2 = 2 * C;   // ROWS / 2 output rows
       constexpr int NT2 = C2 / 16, NTW2 = (NT2 + NW - 1) / NW, DS = C2 + 4;
       static_assert(C > 64 || RD * DS <= ROWS * XS, "downsample output tile must fit the residual tile");
       BFrags<C3 / 32, NTW2> Wd;
       load_b(Wd, p.w_ds, C3, 0, 0, NT2, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
-      for (int i = tid; i < 48 * (C3 / 4); i += NTH) {
+      for (int i = tid; i < DSR * (C3 / 4); i += NTH) {
         const int m = i / (C3 / 4), k4 = (i - m * (C3 / 4)) * 4;
         const int tap = k4 / C, cin = k4 - tap * C;
         const int a = m / L2, j = m - a * L2;
