@@ -19,3 +19,8 @@ med = steps[len(steps) // 4]     # a fast (steady-state) step
 print(f"a steady-state step: span {med[0] / 1e3:.1f} us, busy {med[1] / 1e3:.1f} us, {med[2]} kernels, idle {(med[0] - med[1]) / 1e3:.1f} us")
 for g, a, b in sorted(med[3], key=lambda t: -t[0])[:12]:
     print(f"  gap {g / 1e3:7.2f} us  after {a[:60]:60s} before {b[:50]}")
+print("kernels of that step, in order:")
+a = starts[len(starts) // 2]
+b = starts[len(starts) // 2 + 1]
+for n, s_, e_ in rows[a:b]:
+    print(f"  {(e_ - s_) / 1e3:8.2f} us  {n[:110]}")
