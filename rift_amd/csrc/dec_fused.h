@@ -153,17 +153,20 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     }
   };
 
-  // fp32 VALU self-attention over <= 12 keys of a (row, head) work item; q|k|v of head hh at cb[row][hh*96 + {0,32,64}]
+  // fp32 VALU self-attention over <= 12 keys of a (row, head) work item, two adjacent lanes per item (16 of the 32 head dims
+  // each; the score halves meet through a DPP lane swap); q|k|v of head hh at cb[row][hh*96 + {0,32,64}]
   auto small_attention = [&](int ch, bool over_modes, uint32_t stream) {
-    for (int it = tid; it < NQ * 2; it += NTH) {
-      const int hh = it & 1, row = it >> 1;
+    for (int it = tid; it < ((NQ * 4 + 63) & ~63); it += NTH) {      // whole waves: the DPP swap needs both lanes of a pair active
+      const bool live = it < NQ * 4;
+      const int half = it & 1, item = live ? it >> 1 : 0;
+      const int hh = item & 1, row = item >> 1;
       const int r = row / M, m = row - r * M;
       const int nkeys = over_modes ? M : R;
-      float q[32], o[32];
+      float q[16], o[16];
       {
-        const unsigned short* qp = cb + row * CB + hh * 96;
+        const unsigned short* qp = cb + row * CB + hh * 96 + half * 16;
 #pragma unroll
-        for (int c8 = 0; c8 < 4; ++c8) {
+        for (int c8 = 0; c8 < 2; ++c8) {
           const bf16x8 t = *reinterpret_cast<const bf16x8*>(qp + c8 * 8);
 #pragma unroll
           for (int d = 0; d < 8; ++d) { q[c8 * 8 + d] = bf2f((unsigned short)t[d]); o[c8 * 8 + d] = 0.f; }
@@ -171,33 +174,35 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       }
       float mx = -INFINITY, l = 0.f;
       for (int j = 0; j < nkeys; ++j) {
-        if (!over_modes && qmask[m * 8 + j]) continue;
+        if (!over_modes && qmask[m * 8 + j]) continue;            // uniform within the lane pair
         const int krow = over_modes ? r * M + j : j * M + m;
-        const unsigned short* kp = cb + krow * CB + hh * 96 + 32;
-        float s = 0.f;
+        const unsigned short* kp = cb + krow * CB + hh * 96 + 32 + half * 16;
+        float sp = 0.f;
 #pragma unroll
-        for (int c8 = 0; c8 < 4; ++c8) {
+        for (int c8 = 0; c8 < 2; ++c8) {
           const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + c8 * 8);
 #pragma unroll
-          for (int d = 0; d < 8; ++d) s += q[c8 * 8 + d] * bf2f((unsigned short)t[d]);
+          for (int d = 0; d < 8; ++d) sp += q[c8 * 8 + d] * bf2f((unsigned short)t[d]);
         }
-        const float mn = fmaxf(mx, s);
-        const float corr = __expf(mx - mn), pj = __expf(s - mn);
+        const float sc = sp + dpp_f<0xB1>(sp);                      // + the partner lane's 16 dims
+        const float mn = fmaxf(mx, sc);
+        const float corr = __expf(mx - mn), pj = __expf(sc - mn);
         l = l * corr + pj;
         float wj = pj;
         if (dp > 0.f) wj = (uniform01(p.seed, stream, (uint32_t)(((b * ROWS + row) * 4 + ch * 2 + hh) * 16 + j)) < dp) ? 0.f : pj * dpk;
 #pragma unroll
-        for (int c8 = 0; c8 < 4; ++c8) {
+        for (int c8 = 0; c8 < 2; ++c8) {
           const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + 32 + c8 * 8);
 #pragma unroll
           for (int d = 0; d < 8; ++d) o[c8 * 8 + d] = o[c8 * 8 + d] * corr + wj * bf2f((unsigned short)t[d]);
         }
         mx = mn;
       }
+      if (!live) continue;
       const float inv = 1.0f / l;
-      unsigned short* op = ao + row * XN + (ch * 2 + hh) * 32;
+      unsigned short* op = ao + row * XN + (ch * 2 + hh) * 32 + half * 16;
 #pragma unroll
-      for (int c8 = 0; c8 < 4; ++c8) {
+      for (int c8 = 0; c8 < 2; ++c8) {
         uint4 u;
         u.x = pack_bf16x2(o[c8 * 8 + 0] * inv, o[c8 * 8 + 1] * inv); u.y = pack_bf16x2(o[c8 * 8 + 2] * inv, o[c8 * 8 + 3] * inv);
         u.z = pack_bf16x2(o[c8 * 8 + 4] * inv, o[c8 * 8 + 5] * inv); u.w = pack_bf16x2(o[c8 * 8 + 6] * inv, o[c8 * 8 + 7] * inv);
