@@ -24,6 +24,7 @@
 #include "critic.h"
 #include "fpn_fused.h"
 #include "ego_fused.h"
+#include "heads_fused.h"
 #include "rollout.h"
 
 // fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
@@ -90,7 +91,7 @@ struct RiftCtx {
   int* dec_idx = nullptr; bool dec_fused = true;
   double* clip_part = nullptr;
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
-  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true; bool ego_fused = true;
+  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -371,6 +372,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR_N(pe_out_kernel, PE_OUT_LDS);
   SETATTR_N(fourier_fused_kernel, FO_LDS);
   SETATTR_N(fpn_tail_kernel, FPN_LDS);
+  SETATTR_N(heads3_fused_kernel, HD_LDS);
 #undef SETATTR_N
   return RIFT_OK;
 }
@@ -593,6 +595,20 @@ void nat_layer(Fwd& f, float* X, int rows, int C, int H, int ksz, int L, const s
 }
 
 // MLPLayer (mlp_layer.py:8-16): X (rows,128) -> out (rows, Nout) with hidden width Hd
+// three MLPLayer(128, 256, 160) heads -> interleaved (rows, 80, 6), one launch (heads_fused.h); bf16 mode
+void heads3_fused(Fwd& f, const float* X, int ldx, int rows, int g_per, int g_stride, int g_off, const std::string names[3], float* out) {
+  RiftCtx* c = f.c;
+  Heads3P q; memset(&q, 0, sizeof(q));
+  q.X = X; q.ldx = ldx; q.rows = rows; q.gather_per = g_per; q.gather_stride = g_stride; q.gather_off = g_off; q.out = out;
+  for (int i = 0; i < 3; ++i) {
+    const PW &w1 = c->pw[names[i] + ".mlp.0"], &w2 = c->pw[names[i] + ".mlp.3"];
+    q.w1[i] = (const unsigned short*)w1.bf; q.b1[i] = w1.bias; q.w2[i] = (const unsigned short*)w2.bf; q.b2[i] = w2.bias;
+    q.lng[i] = fptr(c, names[i] + ".mlp.1.weight"); q.lnb[i] = fptr(c, names[i] + ".mlp.1.bias");
+  }
+  c->prof_flops = 3.0 * 2.0 * rows * (128.0 * 256 + 256.0 * 160);
+  launch(c, "heads3_fused_kernel", heads3_fused_kernel, dim3(3 * cdiv(rows, HD_ROWS)), dim3(512), (size_t)HD_LDS, q);
+}
+
 void mlp_layer(Fwd& f, const float* X, int ldx, int rows, const std::string& p, float* out, int ldo, bool fp32) {
   RiftCtx* c = f.c;
   const PW& w0 = c->pw[p + ".mlp.0"];
@@ -900,6 +916,10 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // ================= agent predictor (agent_predictor.py:17-29) =================
   if (f.need_traj && out->prediction && A > 1) {
     const int rows = bs * (A - 1);
+    if (!f.fp32 && c->heads_fused) {
+      const std::string nm3[3] = {"agent_predictor.loc_predictor", "agent_predictor.yaw_predictor", "agent_predictor.vel_predictor"};
+      heads3_fused(f, ENC, 128, rows, A - 1, N, 1, nm3, out->prediction);
+    } else {
     float* Xa = A_alloc<float>(c, (size_t)rows * 128);
     launch(c, "gather_rows_kernel", gather_rows_kernel, dim3(cdiv((long long)rows * 128, 256)), dim3(256), 0, (const float*)ENC, 128, Xa, 128, rows, 128,
            A - 1, N, 1);
@@ -911,6 +931,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     }
     launch(c, "interleave_traj_kernel", interleave_traj_kernel, dim3(cdiv((long long)rows * 480, 256)), dim3(256), 0, (const float*)o3[0], (const float*)o3[1],
            (const float*)o3[2], rows, out->prediction);
+    }
   }
 
   // ================= planning decoder (planning_decoder.py:135-188) =================
@@ -1065,7 +1086,10 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   launch(c, "pi_tail_kernel", pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
          fptr(c, PD + ".pi_head.mlp.1.bias"), fptr(c, PD + ".pi_head.mlp.3.weight"), fptr(c, PD + ".pi_head.mlp.3.bias"),
          (const uint8_t*)r_kpm, 1e-5f, prob);
-  if (f.need_traj && out->trajectory) {
+  if (f.need_traj && out->trajectory && !f.fp32 && c->heads_fused) {
+    const std::string nm3[3] = {PD + ".loc_head", PD + ".yaw_head", PD + ".vel_head"};
+    heads3_fused(f, QF, 128, nQ, 0, 0, 0, nm3, out->trajectory);
+  } else if (f.need_traj && out->trajectory) {
     float* o3[3];
     const char* nm[3] = {"loc_head", "yaw_head", "vel_head"};
     for (int i = 0; i < 3; ++i) {
@@ -1110,6 +1134,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_PE_UNFUSED"); c->pe_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_FPN_UNFUSED"); c->fpn_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_EGO_UNFUSED"); c->ego_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_HEADS_UNFUSED"); c->heads_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_GRID0"); if (ev && atoi(ev) > 0) c->nat_grid0 = atoi(ev); }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }

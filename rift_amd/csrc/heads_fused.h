@@ -1,0 +1,144 @@
+// Fused trajectory heads for gfx950: the three MLPLayer(128, 256, 160) heads (Linear -> LayerNorm -> ReLU -> Linear; mlp_layer.py:8-16)
+// of the planning decoder (loc / yaw / vel, planning_decoder.py:178-183) or of the agent predictor (agent_predictor.py:17-29) on a tile
+// of 128 rows, writing the interleaved (rows, 80, 6) = [x, y, cos, sin, vx, vy] layout directly.  The 256-wide hidden layer never
+// leaves the CU: its LayerNorm statistics are reduced across the 8 waves through a 4 KB LDS table, the normalised values go to LDS
+// as bf16 MFMA operands.  Replaces 6 GEMM launches, an interleave kernel and ~0.4 GB of HBM traffic per call.
+#pragma once
+#include "common.h"
+#include "pe_fused.h"
+
+namespace rift {
+
+struct Heads3P {
+  const float* X; int ldx;            // (rows, 128) fp32 input rows at stride ldx; row r of scene-structured inputs: see gather
+  int rows;
+  int gather_per, gather_stride, gather_off;   // gather_per > 0: input row r lives at X[((r / per) * stride + off + r % per) * ldx]
+  const unsigned short* w1[3]; const float* b1[3]; const float* lng[3]; const float* lnb[3];
+  const unsigned short* w2[3]; const float* b2[3];   // fragment-major bf16 [256][128] and [160][256]
+  float* out;                         // (rows, 80, 6)
+};
+
+#define HD_ROWS 128
+#define HD_XS 136
+#define HD_HS 264
+#define HD_LDS (HD_ROWS * HD_XS * 2 + HD_ROWS * HD_HS * 2 + 8 * HD_ROWS * 2 * 4 + 3 * 768 * 4 + 3 * 160 * 4)
+
+__global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
+  constexpr int MT = 8, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* xb = reinterpret_cast<unsigned short*>(smem_raw);          // [128][HD_XS] bf16 input tile
+  unsigned short* hn = xb + HD_ROWS * HD_XS;                                 // [128][HD_HS] bf16 relu(LN(hidden))
+  float* wpart = reinterpret_cast<float*>(hn + HD_ROWS * HD_HS);             // [8 waves][128 rows][2]: per-wave row sums (x, x^2)
+  float* par = wpart + 8 * HD_ROWS * 2;                                      // per head: b1 256 | ln g 256 | ln b 256, then b2 160 x 3
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  // one (row tile, head) pair per workgroup: 144 + 126 row tiles alone would leave half of the 256 CUs idle
+  const int row0 = (blockIdx.x / 3) * HD_ROWS, h0 = blockIdx.x % 3;
+  PFrags<4, 2> W1;
+  p_load_w<NW, 4, 2>(W1, p.w1[h0], 128, 0, wave, l15, l4);
+  {
+    float4 xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * 512, r = i >> 5, c4 = (i & 31) * 4;
+      xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gr = row0 + r;
+      if (gr < p.rows) {
+        const size_t src = p.gather_per > 0 ? (size_t)(gr / p.gather_per) * p.gather_stride + p.gather_off + gr % p.gather_per : (size_t)gr;
+        xv[u] = *reinterpret_cast<const float4*>(p.X + src * p.ldx + c4);
+      }
+    }
+    float pv[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int e = tid + u * 512;
+      pv[u] = 0.f;
+      if (e < 3 * 768) { const int h = e / 768, k = e - h * 768; pv[u] = k < 256 ? p.b1[h][k] : k < 512 ? p.lng[h][k - 256] : p.lnb[h][k - 512]; }
+      else if (e < 3 * 768 + 480) { const int k = e - 3 * 768; pv[u] = p.b2[k / 160][k % 160]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = tid + u * 512; *reinterpret_cast<uint2*>(xb + (i >> 5) * HD_XS + (i & 31) * 4) = pack_bf16x4(xv[u].x, xv[u].y, xv[u].z, xv[u].w); }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) { const int e = tid + u * 512; if (e < 3 * 768 + 480) par[e] = pv[u]; }
+  }
+  __syncthreads();
+  for (int h = h0; h < h0 + 1; ++h) {
+    const float* ph = par + h * 768;
+    // ---- hidden = x W1^T + b1 (256 columns: n-tiles wave, wave + 8), LayerNorm statistics across the waves, ReLU -> hn
+    f32x4 acc[MT][2];
+    p_zero(acc);
+    p_mma<MT, 4, 2>(acc, xb, HD_XS, 0, W1, l15, l4);
+    PFrags<4, 2> W2a, W2b;                              // second layer: 160 outputs = n-tiles 0..9, K = 256 in two halves
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                  // n-tiles >= 10 do not exist in the 160-row image
+        const bool ok = j * NW + wave < 10;
+        W2a.f[ks][j] = ok ? fm_load(p.w2[h], 256, (j * NW + wave) * 16, ks * 32, l4 * 16 + l15) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        W2b.f[ks][j] = ok ? fm_load(p.w2[h], 256, (j * NW + wave) * 16, 128 + ks * 32, l4 * 16 + l15) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    float bsum[MT], bsq[MT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (j * NW + wave) * 16 + l4 * 4;
+      const float4 b4 = *reinterpret_cast<const float4*>(ph + col);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][j][0] += b4.x; acc[mt][j][1] += b4.y; acc[mt][j][2] += b4.z; acc[mt][j][3] += b4.w;
+        const float s = (acc[mt][j][0] + acc[mt][j][1]) + (acc[mt][j][2] + acc[mt][j][3]);
+        const float q = (acc[mt][j][0] * acc[mt][j][0] + acc[mt][j][1] * acc[mt][j][1]) + (acc[mt][j][2] * acc[mt][j][2] + acc[mt][j][3] * acc[mt][j][3]);
+        if (j == 0) { bsum[mt] = s; bsq[mt] = q; } else { bsum[mt] += s; bsq[mt] += q; }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {                   // the four l4 groups hold different columns of the same row
+      float s = bsum[mt], q = bsq[mt];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (l4 == 0) { wpart[(wave * HD_ROWS + mt * 16 + l15) * 2] = s; wpart[(wave * HD_ROWS + mt * 16 + l15) * 2 + 1] = q; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 16 + l15;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { s += wpart[(w * HD_ROWS + row) * 2]; q += wpart[(w * HD_ROWS + row) * 2 + 1]; }
+      const float mean = s * (1.0f / 256.0f);
+      const float rstd = rsqrtf(fmaxf(q * (1.0f / 256.0f) - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (j * NW + wave) * 16 + l4 * 4;
+        const float4 g4 = *reinterpret_cast<const float4*>(ph + 256 + col), e4 = *reinterpret_cast<const float4*>(ph + 512 + col);
+        *reinterpret_cast<uint2*>(hn + row * HD_HS + col) =
+            pack_bf16x4(fmaxf((acc[mt][j][0] - mean) * rstd * g4.x + e4.x, 0.f), fmaxf((acc[mt][j][1] - mean) * rstd * g4.y + e4.y, 0.f),
+                        fmaxf((acc[mt][j][2] - mean) * rstd * g4.z + e4.z, 0.f), fmaxf((acc[mt][j][3] - mean) * rstd * g4.w + e4.w, 0.f));
+      }
+    }
+    __syncthreads();
+    // ---- out = hn W2^T + b2: 10 n-tiles (waves 0, 1 own two, the others one), scattered into (row, step, component)
+    {
+      f32x4 o[MT][2];
+      p_zero(o);
+      p_mma<MT, 4, 2>(o, hn, HD_HS, 0, W2a, l15, l4);
+      p_mma<MT, 4, 2>(o, hn, HD_HS, 128, W2b, l15, l4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nt = j * NW + wave;
+        if (nt >= 10) continue;
+        const int col = nt * 16 + l4 * 4;              // head output column: step col / 2, component col % 2
+        const float4 b4 = *reinterpret_cast<const float4*>(par + 3 * 768 + h * 160 + col);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int gr = row0 + mt * 16 + l15;
+          if (gr >= p.rows) continue;
+          float* dst = p.out + (size_t)gr * 480 + (col >> 1) * 6 + h * 2;
+          *reinterpret_cast<float2*>(dst) = make_float2(o[mt][j][0] + b4.x, o[mt][j][1] + b4.y);
+          *reinterpret_cast<float2*>(dst + 6) = make_float2(o[mt][j][2] + b4.z, o[mt][j][3] + b4.w);
+        }
+      }
+    }
+    __syncthreads();     // hn / wpart are rewritten by the next head
+  }
+}
+
+}  // namespace rift

@@ -327,6 +327,29 @@ def test_fused_fourier_embedding_matches_layerwise_path(ffi, monkeypatch):
     assert err(outs["fused"][1], outs["layerwise"][1]) < 3e-2 * max(1.0, float(outs["layerwise"][1].abs().max()))
 
 
+def test_fused_trajectory_heads_match_layerwise_path(ffi, monkeypatch):
+    """The one-launch three-head MLPLayer kernel (planning trajectory and agent prediction, interleaved (.., 80, 6) output)
+    against the GEMM + interleave path and the exact-fp32 path."""
+    gold, batch, sd = H.load_case("full")
+    data = batch["cur_pluto_feature_torch"]
+    rv = data["reference_line"]["valid_mask"].any(-1)
+    outs = {}
+    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+        monkeypatch.setenv("RIFT_HEADS_UNFUSED", env)
+        eng = ffi.Engine("cuda:0")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        eng.prof_enable(True)
+        o = eng.forward(data, need_traj=True, fp32=fp32)
+        assert ("heads3_fused_kernel" in eng.prof_report()) == (name == "fused")
+        eng.prof_enable(False)
+        outs[name] = (o["trajectory"].cpu()[rv], o["prediction"].cpu())
+        eng.close()
+    for i in (0, 1):
+        scale = max(1.0, float(outs["fp32"][i].abs().max()))
+        assert err(outs["fused"][i], outs["fp32"][i]) < 3e-2 * scale
+        assert err(outs["fused"][i], outs["layerwise"][i]) < 3e-2 * scale
+
+
 def test_fused_ego_token_matches_layerwise_path(ffi, monkeypatch):
     """The one-launch StateAttentionEncoder (tokens, K|V MFMA, 4-head attention of the learned query over 6 tokens, out_proj)
     against the five-launch path and the exact-fp32 path."""
