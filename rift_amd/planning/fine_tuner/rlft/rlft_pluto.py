@@ -150,7 +150,20 @@ class RLFTPluto(CBVBasePolicy):
             raise ValueError(f'Unknown mode {mode}')
 
     def get_action(self, CBVs_obs_list, infos, deterministic=False):
-        raise NotImplementedError("rollout-side inference needs CARLA actors (SURVEY.md section 8(f) row 1)")
+        raise NotImplementedError("the CARLA-bound wrapper (CarlaDataProvider actors, render data) is not part of this package; the "
+                                  "model step, candidate trimming and PID control it calls are rift_amd.planning.pluto.inference.PlutoInference")
+
+    def reset_render_data(self):   # rlft_pluto.py:64-77 (render buffers live on the CARLA side)
+        self._render_data = [{} for _ in range(self.num_scenario)]
+
+    def get_render_data(self, env_id):
+        return self._render_data[env_id] if self._render_data else {}
+
+    def save_model(self, episode):  # checkpoints are written by train(); rlft_pluto.py:295-296
+        pass
+
+    def finish(self):
+        pass
 
     @staticmethod
     def load_infer_checkpoint(checkpoint: str, device_name) -> Dict[str, torch.Tensor]:

@@ -317,8 +317,45 @@ def gen_critic():
     print("ppo critic ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", float(out["loss"]), float(out["value_loss"]))
 
 
+# ------------------------------------------------------------------------------------------
+# rollout-side inference helpers: _trim_candidates / _global_to_local (pluto.py:196-279) and PIDController.control_pid
+# (controller/pid_controller.py:39-100), run on seeded inputs
+# ------------------------------------------------------------------------------------------
+def gen_inference():
+    import types
+    import importlib.util
+    from scipy.special import softmax
+    from tests.helpers import inference_inputs
+    inp = inference_inputs()
+    import numpy.typing as npt
+    ns = {"softmax": softmax, "npt": npt, "CarlaAgentState": object, "Tuple": tuple}
+    trim = _ref_function("rift/cbv/planning/pluto/pluto.py", "_trim_candidates", ns)
+    g2l = _ref_function("rift/cbv/planning/pluto/pluto.py", "_global_to_local", ns)
+    spec = importlib.util.spec_from_file_location("ref_pid", os.path.join(ref_loader.REF_ROOT, "rift/cbv/planning/pluto/controller/pid_controller.py"))
+    pid = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pid)
+    state = types.SimpleNamespace(rear_axle=types.SimpleNamespace(array=inp["origin"], heading=inp["angle"]))
+    fake_self = types.SimpleNamespace(_topk=10)
+    out = {}
+    traj, score, orig, n_ref, n_mode = trim(fake_self, inp["candidates"].copy(), inp["probability"].copy(), state, inp["ref_free"].copy())
+    out["trim.traj"], out["trim.score"], out["trim.orig"] = traj, score, orig.astype(np.int64)
+    best = int(score.argmax())
+    local = g2l(fake_self, traj[best, 1:], state)
+    out["local"] = local
+    ctrl = pid.PIDController()
+    acts = []
+    for k in range(6):      # consecutive ticks: the PID windows carry state
+        acts.append([float(v) for v in ctrl.control_pid(local[:, :2] * (1.0 + 0.05 * k), 3.0 + 0.5 * k)])
+    out["actions"] = np.array(acts)
+    path = os.path.join(HERE, "inference.npz")
+    np.savez_compressed(path, **out)
+    print("inference ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", out["trim.orig"].tolist(), out["actions"][0])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "rollout":
+    if len(sys.argv) > 1 and sys.argv[1] == "inference":
+        gen_inference()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rollout":
         gen_rollout()
     elif len(sys.argv) > 1 and sys.argv[1] == "critic":
         gen_critic()
@@ -327,3 +364,4 @@ if __name__ == "__main__":
         gen_advantage()
         gen_rollout()
         gen_critic()
+        gen_inference()

@@ -134,3 +134,16 @@ def critic_weights(seed=77):
     sd["value_avg"] = torch.tensor([0.3])
     sd["value_std"] = torch.tensor([1.7])
     return sd
+
+
+def inference_inputs(seed=909, R=4, M=12, T=80):
+    """Seeded candidate set of one CBV for the rollout-side helpers (tests/golden/inference.npz)."""
+    g = np.random.default_rng(seed)
+    t = np.arange(1, T + 1)[None, None, :] * 0.1
+    speed = g.uniform(2.0, 9.0, size=(R, M, 1))
+    curv = g.uniform(-0.05, 0.05, size=(R, M, 1))
+    heading = curv * speed * t
+    cand = np.stack([speed * t * np.cos(heading * 0.5), speed * t * np.sin(heading * 0.5), heading], axis=-1)
+    return {"candidates": cand.astype(np.float64), "probability": g.normal(size=(R, M)).astype(np.float32),
+            "ref_free": np.stack([5.0 * t[0, 0], 0.02 * t[0, 0] ** 2, 0.008 * t[0, 0]], axis=-1).astype(np.float64),
+            "origin": np.array([12.5, -3.25]), "angle": 0.6}

@@ -192,3 +192,33 @@ def test_rlft_train_updates_only_pi_head_and_checkpoints(policy, tmp_path):
     pol2 = CBV_POLICY_LIST[policy](cfg, None)
     pol2.load_model(resume=True)
     assert pol2.continue_episode == 8 and pol2.current_epoch == 2
+
+
+@pytest.mark.gpu
+def test_rollout_side_inference_step():
+    """PlutoInference: eval-mode HIP forward with every output, then top-k candidate trimming (integer flat indices identical to
+    those from the oracle's logits in exact-fp32 mode), frame transforms and the waypoint PID."""
+    from oracle import pluto_ref
+    from rift_amd.planning.pluto.inference import PlutoInference, trim_candidates
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel, finish_outputs
+    from tests import helpers as H
+    torch.cuda.set_device(0)
+    sd = H.weights()
+    model = PlanningModel(radius=120)
+    model.load_state_dict(sd)
+    model = model.to("cuda:0")
+    model.compute_precision = "fp32"
+    scenes = [syn.make_scene(40 + i, num_agents=16, num_polygons=10, r_min=2, r_max=4) for i in range(3)]
+    data = syn.collate_features([s["feature"] for s in scenes])
+    pi = PlutoInference(model)
+    out = pi.forward({k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in data.items()})
+    want_raw, _, _ = pluto_ref.planning_model_forward(sd, data, train_bn=False, need_traj=True, want_taps=True)
+    want = finish_outputs({k: v for k, v in want_raw.items()}, data, 21, True)
+    origin, angle = np.array([3.0, -7.0]), 0.35
+    for i in range(3):
+        (thr, steer, brake), traj, cands, score, orig = pi.act(out, i, cbv_id=100 + i, origin=origin, angle=angle, speed=4.0)
+        assert traj.shape[1] == 3 and np.isfinite(traj).all() and -1.0 <= steer <= 1.0 and 0.0 <= thr <= 1.0
+        w_c, w_s, w_o, _, _ = trim_candidates(want["candidate_trajectories"][i].numpy().astype(np.float64), want["probability"][i].numpy(),
+                                              origin, angle, want["output_ref_free_trajectory"][i].numpy().astype(np.float64), 10)
+        assert np.array_equal(orig, w_o)
+        assert np.abs(cands - w_c).max() < 1e-3 and np.abs(score - w_s).max() < 1e-4
