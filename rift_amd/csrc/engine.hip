@@ -1582,9 +1582,11 @@ int rift_op_linear_bench(RiftCtx* c, const float* X, int M, int K, const float* 
   return RIFT_OK;
 }
 
+// An empty buffer is a valid (no-op) input of the three scans below, as it is for the reference's loops.
 int rift_gae(RiftCtx* c, const double* rewards, const float* undones, const float* values, const float* next_values,
              const float* unterminated, float gamma, float lambda_, int n, float* advantages, void* stream) {
-  if (!c || n <= 0) return RIFT_ERR_ARG;
+  if (!c || n < 0) return RIFT_ERR_ARG;
+  if (n == 0) return RIFT_OK;
   GaeCoef k{rewards, undones, values, next_values, unterminated, gamma, lambda_};
   hipLaunchKernelGGL((affine_scan_reverse_kernel<GaeCoef, float>), dim3(1), dim3(64), 0, (hipStream_t)stream, k, n, advantages);
   HIPCHK(c, hipGetLastError());
@@ -1593,7 +1595,8 @@ int rift_gae(RiftCtx* c, const double* rewards, const float* undones, const floa
 
 int rift_discounted_return(RiftCtx* c, const double* rewards, const float* dones, double gamma, int n, double* returns,
                            void* stream) {
-  if (!c || n <= 0) return RIFT_ERR_ARG;
+  if (!c || n < 0) return RIFT_ERR_ARG;
+  if (n == 0) return RIFT_OK;
   ReturnCoef k{rewards, dones, gamma};
   hipLaunchKernelGGL((affine_scan_reverse_kernel<ReturnCoef, double>), dim3(1), dim3(64), 0, (hipStream_t)stream, k, n, returns);
   HIPCHK(c, hipGetLastError());
@@ -1601,7 +1604,8 @@ int rift_discounted_return(RiftCtx* c, const double* rewards, const float* dones
 }
 
 int rift_normalize_advantage(RiftCtx* c, float* x, int n, void* stream) {
-  if (!c || n <= 0) return RIFT_ERR_ARG;
+  if (!c || n < 0) return RIFT_ERR_ARG;
+  if (n == 0) return RIFT_OK;
   hipLaunchKernelGGL(normalize_unbiased_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;

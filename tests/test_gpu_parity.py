@@ -233,6 +233,35 @@ def test_advantage_kernels(ffi):
     eng.close()
 
 
+def test_advantage_kernel_edge_cases(ffi):
+    """Empty and single-element buffers, a buffer that is one unbroken trajectory and one where every step ends an episode, the
+    largest group (R = 16 -> G = 192) and a degenerate group whose returns are all equal (z-score 0 through the +1e-5 guard)."""
+    eng = ffi.Engine("cuda:0")
+    z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt)  # noqa: E731
+    assert eng.gae(z(0, torch.float64), z(0), z(0), z(0), z(0)).numel() == 0
+    assert eng.discounted_return(z(0, torch.float64), z(0)).numel() == 0
+    one = eng.gae(torch.tensor([2.0], dtype=torch.float64), torch.tensor([1.0]), torch.tensor([0.5]), torch.tensor([0.25]), torch.tensor([1.0]))
+    assert abs(float(one[0]) - (2.0 + 0.98 * 0.25 - 0.5)) < 1e-6
+    g = torch.Generator().manual_seed(11)
+    n = 4096
+    r = torch.randn(n, generator=g, dtype=torch.float64)
+    v, nv = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    for undone in (torch.ones(n), torch.zeros(n)):          # never done / always done
+        for unterm in (torch.ones(n), torch.zeros(n)):
+            got = eng.gae(r, undone, v, nv, unterm)
+            want = oadv.get_advantages_gae(r, undone, v, nv, unterm, 0.98, 0.98)
+            assert err(got, want) < 1e-5
+    done = torch.zeros(n)
+    assert err(eng.discounted_return(r, done), oadv.compute_return(r, done, 0.98)) < 1e-9
+    for G in (12, 192):
+        ret = torch.randn(5, G, generator=g, dtype=torch.float64)
+        want = (ret - ret.mean(1, keepdim=True)) / (ret.std(1, unbiased=False, keepdim=True) + 1e-5)
+        assert err(eng.group_advantage(ret), want) < 1e-9
+    flat = torch.full((2, 48), 3.25, dtype=torch.float64)
+    assert float(eng.group_advantage(flat).abs().max()) == 0.0
+    eng.close()
+
+
 def test_device_collation_matches_pad_sequence(ffi):
     """rift_collate (HBM arena gather) == PlutoFeature.collate / RIFTCollate semantics, bit-exact."""
     from rift_amd import synthetic as syn
