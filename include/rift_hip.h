@@ -123,6 +123,8 @@ typedef struct RiftLossOut {
   float*  grad_ln_w; float* grad_ln_b;   /* mlp.1.weight (128), mlp.1.bias (128) */
   float*  grad_w2;  float* grad_b2;      /* mlp.3.weight (1,128), mlp.3.bias (1) */
   int64_t* argmax_rm;      /* (bs,2) int64 chosen (r,m) -- REINFORCE, bit-exact integer output */
+  double* exchange;        /* optional device [16899] f64: flat_grad_sum (as f64) followed by stats -- ONE buffer to all-reduce for DP;
+                              when set, rift_loss_finalize reads the sums and the stats from here */
 } RiftLossOut;
 
 int  rift_ctx_create(int device, RiftCtx** ctx);

@@ -51,7 +51,7 @@ class RiftLossIn(C.Structure):
 
 class RiftLossOut(C.Structure):
     _fields_ = [(n, vp) for n in ("loss", "stats", "flat_grad_sum", "grad_w1", "grad_b1", "grad_ln_w", "grad_ln_b",
-                                  "grad_w2", "grad_b2", "argmax_rm")]
+                                  "grad_w2", "grad_b2", "argmax_rm", "exchange")]
 
 
 class RiftCritic(C.Structure):

@@ -1380,7 +1380,7 @@ int rift_loss_backward(RiftCtx* c, int kind, const RiftLossIn* in, const RiftLos
          (const float*)c->l_dz, rows, fptr(c, PH + "1.weight"), fptr(c, PH + "1.bias"), fptr(c, PH + "3.weight"), 1e-5f,
          c->l_partial);
   launch(c, "loss_reduce_kernel", loss_reduce_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)c->l_partial, nwg,
-         out->flat_grad_sum, (const double*)c->l_S, (const double*)c->l_cnt, bs, out->stats);
+         out->flat_grad_sum, (const double*)c->l_S, (const double*)c->l_cnt, bs, out->stats, out->exchange);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }
@@ -1390,7 +1390,7 @@ int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void*
   c->stream = (hipStream_t)stream; c->dry = false;
   launch(c, "loss_finalize_kernel", loss_finalize_kernel, dim3(cdiv(RIFT_PI_NPARAM, 256)), dim3(256), 0, (const float*)out->flat_grad_sum,
          (const double*)out->stats, out->grad_w1, out->grad_b1, out->grad_ln_w, out->grad_ln_b, out->grad_w2, out->grad_b2,
-         out->loss, accumulate);
+         out->loss, accumulate, (const double*)out->exchange, out->stats);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void pi_backward_kernel(
 // flat[i] = sum_wg partial[wg][i]; stats[0] = sum S_b, stats[1] = sum cnt_b  (deterministic order)
 __global__ void loss_reduce_kernel(const float* __restrict__ partial, int nwg, float* __restrict__ flat,
                                    const double* __restrict__ S, const double* __restrict__ cnt, int bs,
-                                   double* __restrict__ stats) {
+                                   double* __restrict__ stats, double* __restrict__ xchg /*optional [NPARAM + 2]*/) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < RIFT_PI_NPARAM) {
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight loads in flight per thread; fixed summation order
@@ -328,21 +328,26 @@ __global__ void loss_reduce_kernel(const float* __restrict__ partial, int nwg, f
       for (int u = 0; u < 8; ++u) s[u] += partial[(size_t)(w + u) * RIFT_PI_NPARAM + i];
     }
     for (; w < nwg; ++w) s[0] += partial[(size_t)w * RIFT_PI_NPARAM + i];
-    flat[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    flat[i] = tot;
+    if (xchg) xchg[i] = (double)tot;
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     double a = 0.0, c = 0.0;
     for (int b = threadIdx.x; b < bs; b += 64) { a += S[b]; c += cnt[b]; }
     a = wave_sum_d(a); c = wave_sum_d(c);
-    if (threadIdx.x == 0) { stats[0] = a; stats[1] = c; }
+    if (threadIdx.x == 0) { stats[0] = a; stats[1] = c; if (xchg) { xchg[RIFT_PI_NPARAM] = a; xchg[RIFT_PI_NPARAM + 1] = c; } }
   }
 }
 
 // loss = -S/cnt ; grads = -flat/cnt scattered into the six caller-owned .grad tensors (accumulate or overwrite)
-__global__ void loss_finalize_kernel(const float* __restrict__ flat, const double* __restrict__ stats,
+__global__ void loss_finalize_kernel(const float* __restrict__ flat, const double* __restrict__ stats_in,
                                      float* gW1, float* gb1, float* gg, float* gbe, float* gw2, float* gb2,
-                                     double* __restrict__ loss_out, int accumulate) {
+                                     double* __restrict__ loss_out, int accumulate, const double* __restrict__ xchg,
+                                     double* __restrict__ stats_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double* stats = xchg ? xchg + RIFT_PI_NPARAM : stats_in;     // the (all-reduced) exchange buffer wins when present
+  if (xchg && i == 0 && stats_out) { stats_out[0] = stats[0]; stats_out[1] = stats[1]; }
   const double cnt = stats[1];
   const float sc = cnt > 0.0 ? (float)(-1.0 / cnt) : 0.f;
   if (i == 0 && loss_out) loss_out[0] = cnt > 0.0 ? -stats[0] / cnt : 0.0;
@@ -355,7 +360,7 @@ __global__ void loss_finalize_kernel(const float* __restrict__ flat, const doubl
   else if (i < 16384 + 512) { dst = gw2; o = i - 16384 - 384; }
   else { dst = gb2; o = 0; }
   if (!dst) return;
-  const float v = flat[i] * sc;
+  const float v = (xchg ? (float)xchg[i] : flat[i]) * sc;
   dst[o] = accumulate ? dst[o] + v : v;
 }
 

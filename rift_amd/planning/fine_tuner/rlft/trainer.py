@@ -87,6 +87,12 @@ def configure_optimizer(model: nn.Module, lr: float, weight_decay: float):
     return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=pd and next(iter(pd.values())).is_cuda)
 
 
+def dp_all_reduce_exchange(xchg: torch.Tensor, group=None):
+    """The same exchange as ONE collective: `xchg` = f64 [16897 unnormalised gradient sums | objective sum | valid count], written by
+    rift_loss_backward and read back by rift_loss_finalize (RiftLossOut.exchange).  135 KB, latency-bound on xGMI."""
+    torch.distributed.all_reduce(xchg, op=torch.distributed.ReduceOp.SUM, group=group)
+
+
 def dp_all_reduce(flat: torch.Tensor, stats: torch.Tensor, group=None):
     """The only exchange step of the data-parallel path.  Every rank holds UNNORMALISED sums over its scene shard:
     `flat` = sum of d(objective)/d(pi_head params) (16,897 f32), `stats` = (objective sum, valid-entry count) in f64.
@@ -151,6 +157,10 @@ class RLFTTrainer:
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.lo = _ffi.RiftLossOut()
         self.lo.loss, self.lo.stats, self.lo.flat_grad_sum = self.loss.data_ptr(), self.stats.data_ptr(), self.flat.data_ptr()
+        self.xchg = None
+        if process_group is not None:     # DP: one f64 exchange buffer, one all-reduce per step
+            self.xchg = torch.zeros(_ffi.PI_NPARAM + 2, dtype=torch.float64, device=dev)
+            self.lo.exchange = self.xchg.data_ptr()
         g = self.params
         self.lo.grad_w1, self.lo.grad_b1 = g["mlp.0.weight"].grad.data_ptr(), g["mlp.0.bias"].grad.data_ptr()
         self.lo.grad_ln_w, self.lo.grad_ln_b = g["mlp.1.weight"].grad.data_ptr(), g["mlp.1.bias"].grad.data_ptr()
@@ -216,8 +226,10 @@ class RLFTTrainer:
         eng.loss_backward_raw(self.kind_id, self.li, self.lo)
         if self.critic is not None:   # value loss half of get_ppo_loss (ppo_trainer.py:175-176,183)
             eng.critic_loss_backward_raw(self.critic_desc, extras["state"], extras["reward_sum"], self.stats, self.flat_c)
+        if self.critic is not None and self.xchg is not None:
+            self.xchg[_ffi.PI_NPARAM:].copy_(self.stats)   # the value-loss term joined stats after the exchange buffer was filled
         if self.pg is not None and (self.world > 1 or self.force_exchange):
-            dp_all_reduce(self.flat, self.stats, self.pg)
+            dp_all_reduce_exchange(self.xchg, self.pg)
             if self.critic is not None:
                 torch.distributed.all_reduce(self.flat_c, group=self.pg)
         if backward:
@@ -226,7 +238,7 @@ class RLFTTrainer:
                 eng.critic_finalize_raw(self.flat_c, self.stats, [p.grad for p in self.critic.values()])
         else:   # validation: loss only, the .grad buffers are left untouched
             lv = _ffi.RiftLossOut()
-            lv.loss, lv.stats, lv.flat_grad_sum = self.lo.loss, self.lo.stats, self.lo.flat_grad_sum
+            lv.loss, lv.stats, lv.flat_grad_sum, lv.exchange = self.lo.loss, self.lo.stats, self.lo.flat_grad_sum, self.lo.exchange
             eng.loss_finalize_raw(lv, 0)
         return self.loss
 

@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import losses
-from rift_amd.planning.fine_tuner.rlft.trainer import dp_all_reduce, shard_scene_ids
+from rift_amd.planning.fine_tuner.rlft.trainer import dp_all_reduce, dp_all_reduce_exchange, shard_scene_ids
 from tests import helpers as H
 
 KINDS = ["rift", "grpo"]
@@ -45,9 +45,13 @@ def _worker(rank, world, port, kind, out_dir):
     n = q.shape[0]
     ids = shard_scene_ids(rank, world, n // world)
     flat, stats = _rank_sums(kind, sd, q, r_pad, batch, ids.start, ids.stop)
-    dp_all_reduce(flat, stats)
-    loss = -stats[0] / stats[1]
-    grad = -flat.double() / stats[1]
+    xchg = torch.cat([flat.double(), stats])               # the one-collective form (RiftLossOut.exchange)
+    dp_all_reduce_exchange(xchg)
+    dp_all_reduce(flat, stats)                             # the two-collective form must agree with it
+    assert abs(float(xchg[-2] - stats[0])) < 1e-9 and float(xchg[-1]) == float(stats[1])
+    assert float((xchg[:-2] - flat.double()).abs().max()) < 1e-4 * max(1.0, float(flat.abs().max()))
+    loss = -xchg[-2] / xchg[-1]
+    grad = -xchg[:-2] / xchg[-1]
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), loss=loss.numpy(), grad=grad.numpy())
     dist.destroy_process_group()
 

@@ -44,11 +44,11 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_sizes():
     from rift_amd import _ffi
-    # 6 int32 + 26 pointers + 1 int32 (padded) ; 5 pointers ; 8 pointers + 2 floats ; 10 pointers
+    # 6 int32 + 26 pointers + 1 int32 (padded) ; 5 pointers ; 8 pointers + 2 floats ; 11 pointers
     assert ctypes.sizeof(_ffi.RiftFeatureBatch) == 24 + 26 * 8 + 8
     assert ctypes.sizeof(_ffi.RiftOutputs) == 40
     assert ctypes.sizeof(_ffi.RiftLossIn) == 72
-    assert ctypes.sizeof(_ffi.RiftLossOut) == 80
+    assert ctypes.sizeof(_ffi.RiftLossOut) == 88   # 11 pointers (incl. the optional f64 exchange buffer)
     assert ctypes.sizeof(_ffi.RiftTensorDesc) == 8 + 8 + 8 + 8 + 32
 
 
