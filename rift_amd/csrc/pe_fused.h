@@ -8,15 +8,15 @@
 //   pass A  pe_stats1_kernel : h1 = x W1^T + b1                         -> per-tile sum / sum of squares (BN1)
 //   pass B  pe_mid_kernel    : h1 -> BN1 -> ReLU -> f = . W2^T + b2 (invalid rows 0) -> pooled = max over points
 //                              gp = pooled W3b^T + b3 ;  g = f W3a^T + gp   -> per-tile sum / sum of squares (BN2)
-//                              writes f (bf16) and gp (fp32, one row per polyline)
-//   pass C  pe_out_kernel    : g recomputed from f, gp -> BN2 -> ReLU -> o = . W4^T + b4 (invalid rows 0)
-//                              -> max over points -> out
-// `g` (rows x 256 fp32, the largest intermediate) never exists in memory: recomputing its K=256 contraction on the
-// MFMA pipe is cheaper than one HBM round trip.  Storing f as bf16 loses nothing: its only consumers are bf16 MFMA
-// operands and a max-pool (rounding is monotonic, so max(round(f)) = round(max(f))).
+//                              writes g as fp16 (the only intermediate that crosses HBM, 512 B per point)
+//   pass C  pe_out_kernel    : g -> BN2 -> ReLU -> o = . W4^T + b4 (invalid rows 0) -> max over points -> out
+// g is handed over in fp16, not bf16: BatchNorm subtracts the channel mean next, so the absolute rounding error of g is what
+// counts; 11 significand bits keep it at the level of the bf16 rounding the normalised value gets anyway as an MFMA operand
+// (|g| stays far inside the fp16 range).  The statistics are taken from the fp32 accumulators before rounding.
 // All contractions are issued with the weight fragment as the MFMA A operand (see enc_fused.h): a lane holds four
 // consecutive output channels of one point row.
 #pragma once
+#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace rift {
@@ -31,7 +31,7 @@ struct PeP {
   float* part1;                         // [2][128][ntiles] tile sums of h1, h1^2 over valid rows
   float* part2;                         // [2][256][ntiles] tile sums of g, g^2
   int* cnt;                             // [ntiles] valid rows per tile
-  unsigned short* Fmid;                 // (rows, 256) bf16
+  unsigned short* Fmid;                 // (rows, 256) fp16 bits: g = second_mlp.0 pre-activation
   float* gp;                            // (rows / NPTS, 256)
   float* out;                           // (rows / NPTS, 128)
   int do_stats;
@@ -255,11 +255,7 @@ __device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
   __syncthreads();
   PTS();
 
-  // ---- f -> HBM (bf16, 16 B per lane), and the per-polyline max over its points
-  for (int i = tid; i < PE_USED * 32; i += 512) {
-    const int r = i >> 5, c8 = (i & 31) * 8;
-    if (row0 + r < p.rows) *reinterpret_cast<uint4*>(p.Fmid + (size_t)(row0 + r) * 256 + c8) = *reinterpret_cast<const uint4*>(fl + r * PE_FS + c8);
-  }
+  // ---- the per-polyline max over its points
   {
     const int cp = (tid & 127) * 2, sub = tid >> 7;
     for (int u = sub; u < UNITS; u += 4) {
@@ -309,14 +305,33 @@ __device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
   __syncthreads();
   PTS();
 
-  // ---- g = f W3a^T + gp: only its statistics are needed here
-  if (p.do_stats) {
+  // ---- g = f W3a^T + gp: BatchNorm-2 statistics from the fp32 accumulators, the values to HBM as fp16
+  {
     f32x4 acc[MT][2];
     p_zero(acc);
     p_mma<MT, 4, 2>(acc, fl, PE_FS, 0, Wa, l15, l4);
     p_mma<MT, 4, 2>(acc, fl, PE_FS, 128, Wb, l15, l4);
-    pe_tile_stats<MT, 2, NW>(acc, sval, [&](int row, int c) { return *reinterpret_cast<const float4*>(gpl + (GPT == 1 ? 0 : row / NPTS) * 256 + c); },
-                             p.part2, 256, p.ntiles, tile, wave, l15, l4);
+    auto addend = [&](int row, int c) { return *reinterpret_cast<const float4*>(gpl + (GPT == 1 ? 0 : row / NPTS) * 256 + c); };
+    if (p.do_stats) pe_tile_stats<MT, 2, NW>(acc, sval, addend, p.part2, 256, p.ntiles, tile, wave, l15, l4);
+    __syncthreads();                       // every wave is done reading f: its tile becomes the fp16 staging area of g
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (j * NW + wave) * 16 + l4 * 4;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + l15;
+        const float4 a = addend(row < PE_USED ? row : 0, col);
+        const __half2 lo = __floats2half2_rn(acc[mt][j][0] + a.x, acc[mt][j][1] + a.y), hi = __floats2half2_rn(acc[mt][j][2] + a.z, acc[mt][j][3] + a.w);
+        uint2 u;
+        u.x = *reinterpret_cast<const unsigned int*>(&lo); u.y = *reinterpret_cast<const unsigned int*>(&hi);
+        *reinterpret_cast<uint2*>(fl + row * PE_FS + col) = u;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < PE_USED * 32; i += 512) {       // 16 B per lane, whole rows
+    const int r = i >> 5, c8 = (i & 31) * 8;
+    if (row0 + r < p.rows) *reinterpret_cast<uint4*>(p.Fmid + (size_t)(row0 + r) * 256 + c8) = *reinterpret_cast<const uint4*>(fl + r * PE_FS + c8);
   }
   PTS();
 #undef PTS
@@ -330,35 +345,30 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP2 q) {
 // ---------------------------------------------------------------------------------------------------------------
 // pass C
 // ---------------------------------------------------------------------------------------------------------------
-#define PE_OUT_LDS (PE_ROWS * PE_FS * 2 + 8 * 256 * 4 + 640 * 4 + PE_ROWS)
+#define PE_OUT_LDS (PE_ROWS * PE_FS * 2 + 4 * 128 * 4 + 640 * 4 + PE_ROWS)
 
 template <int NPTS>
 __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
   constexpr int MT = 8, GPT = PE_USED / NPTS, NW = 8, OS = 132;
   constexpr int SPL = GPT >= 4 ? 1 : 4;
   constexpr int UNITS = GPT * SPL, RPU = NPTS / SPL;
-  static_assert(PE_ROWS * OS * 4 <= PE_ROWS * PE_FS * 2, "o tile must fit the f tile");
+  static_assert(PE_ROWS * OS * 4 <= PE_ROWS * PE_FS * 2, "o tile must fit the activation tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned short* fl = reinterpret_cast<unsigned short*>(smem_raw);      // f, then relu(bn2(g)) in place, then o (fp32)
+  unsigned short* fl = reinterpret_cast<unsigned short*>(smem_raw);      // relu(bn2(g)) as bf16, then o (fp32) over the same bytes
   float* ol = reinterpret_cast<float*>(smem_raw);
-  float* gpl = reinterpret_cast<float*>(fl + PE_ROWS * PE_FS);           // [8][256]
-  float* par = gpl + 8 * 256;                                            // s2 256 | t2 256 | b4 128
+  float* pm = reinterpret_cast<float*>(fl + PE_ROWS * PE_FS);            // [4][128] max-pool partials
+  float* par = pm + 4 * 128;                                             // s2 256 | t2 256 | b4 128
   unsigned char* sval = reinterpret_cast<unsigned char*>(par + 640);
   constexpr int P_S2 = 0, P_T2 = 256, P_B4 = 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int row0 = tile * PE_USED;
 
-  PFrags<4, 2> Wa, Wb;
-  p_load_w<NW, 4, 2>(Wa, p.w3a, 256, 0, wave, l15, l4);
-  p_load_w<NW, 4, 2>(Wb, p.w3a, 256, 128, wave, l15, l4);
-  int nvalid = 0;
-  for (int r = tid; r < PE_ROWS; r += 512) {
-    unsigned char f = 0;
-    if (r < PE_USED && row0 + r < p.rows) f = p.valid[row0 + r] ? 1 : 2;
-    sval[r] = f;
-    nvalid += f == 1;
-  }
-  const int nv = __syncthreads_count(nvalid);
+  PFrags<4, 1> Wc, Wd;
+  p_load_w<NW, 4, 1>(Wc, p.w4, 256, 0, wave, l15, l4);
+  p_load_w<NW, 4, 1>(Wd, p.w4, 256, 128, wave, l15, l4);
+  unsigned char fv = 0;
+  if (tid < PE_ROWS && tid < PE_USED && row0 + tid < p.rows) fv = p.valid[row0 + tid] ? 1 : 2;
+  const int nv = __syncthreads_count(fv == 1);
   if (nv == 0) {   // every row zero -> the max is zero
     for (int i = tid; i < GPT * 128; i += 512) {
       const int grp = tile * GPT + i / 128;
@@ -366,46 +376,42 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
     }
     return;
   }
-  for (int e = tid; e < 640; e += 512) par[e] = e < 256 ? p.s2[e] : e < 512 ? p.t2[e - 256] : p.b4[e - 512];
-  for (int i = tid; i < PE_ROWS * 32; i += 512) {
-    const int r = i >> 5, c8 = (i & 31) * 8;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (r < PE_USED && row0 + r < p.rows) v = *reinterpret_cast<const uint4*>(p.Fmid + (size_t)(row0 + r) * 256 + c8);
-    *reinterpret_cast<uint4*>(fl + r * PE_FS + c8) = v;
-  }
-  for (int i = tid; i < 8 * 64; i += 512) {
-    const int g = i >> 6, c4 = (i & 63) * 4;
-    const int grp = tile * GPT + g;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g < GPT && (size_t)grp * NPTS < (size_t)p.rows) v = *reinterpret_cast<const float4*>(p.gp + (size_t)grp * 256 + c4);
-    *reinterpret_cast<float4*>(gpl + g * 256 + c4) = v;
-  }
-  __syncthreads();
-
-  // ---- g = f W3a^T + gp -> relu(bn2(g)) written over f
+  // ---- g (fp16) -> relu(bn2(g)) as the bf16 MFMA operand tile; all loads first
   {
-    f32x4 acc[MT][2];
-    p_zero(acc);
-    p_mma<MT, 4, 2>(acc, fl, PE_FS, 0, Wa, l15, l4);
-    p_mma<MT, 4, 2>(acc, fl, PE_FS, 128, Wb, l15, l4);
-    __syncthreads();    // every wave has read all of f
+    uint4 gv[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = (j * NW + wave) * 16 + l4 * 4;
-      const float4 s = *reinterpret_cast<const float4*>(par + P_S2 + col), t = *reinterpret_cast<const float4*>(par + P_T2 + col);
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * 512, r = i >> 5, c8 = (i & 31) * 8;
+      gv[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (r < PE_USED && row0 + r < p.rows) gv[u] = *reinterpret_cast<const uint4*>(p.Fmid + (size_t)(row0 + r) * 256 + c8);
+    }
+    float pv[2];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int row = mt * 16 + l15;
-        const float4 gv = *reinterpret_cast<const float4*>(gpl + (row / NPTS < GPT ? row / NPTS : 0) * 256 + col);
-        *reinterpret_cast<uint2*>(fl + row * PE_FS + col) =
-            pack_bf16x4(fmaxf((acc[mt][j][0] + gv.x) * s.x + t.x, 0.f), fmaxf((acc[mt][j][1] + gv.y) * s.y + t.y, 0.f),
-                        fmaxf((acc[mt][j][2] + gv.z) * s.z + t.z, 0.f), fmaxf((acc[mt][j][3] + gv.w) * s.w + t.w, 0.f));
+    for (int u = 0; u < 2; ++u) { const int e = tid + u * 512; pv[u] = e < 256 ? p.s2[e] : e < 512 ? p.t2[e - 256] : e < 640 ? p.b4[e - 512] : 0.f; }
+    if (tid < PE_ROWS) sval[tid] = fv;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int e = tid + u * 512; if (e < 640) par[e] = pv[u]; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * 512, r = i >> 5, c8 = (i & 31) * 8;
+      const unsigned int w[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 f2 = __half22float2(*reinterpret_cast<const __half2*>(&w[k]));
+        x[2 * k] = f2.x; x[2 * k + 1] = f2.y;
       }
+      const float4 s0 = *reinterpret_cast<const float4*>(par + P_S2 + c8), s1 = *reinterpret_cast<const float4*>(par + P_S2 + c8 + 4);
+      const float4 t0 = *reinterpret_cast<const float4*>(par + P_T2 + c8), t1 = *reinterpret_cast<const float4*>(par + P_T2 + c8 + 4);
+      uint4 o;
+      o.x = pack_bf16x2(fmaxf(x[0] * s0.x + t0.x, 0.f), fmaxf(x[1] * s0.y + t0.y, 0.f));
+      o.y = pack_bf16x2(fmaxf(x[2] * s0.z + t0.z, 0.f), fmaxf(x[3] * s0.w + t0.w, 0.f));
+      o.z = pack_bf16x2(fmaxf(x[4] * s1.x + t1.x, 0.f), fmaxf(x[5] * s1.y + t1.y, 0.f));
+      o.w = pack_bf16x2(fmaxf(x[6] * s1.z + t1.z, 0.f), fmaxf(x[7] * s1.w + t1.w, 0.f));
+      *reinterpret_cast<uint4*>(fl + r * PE_FS + c8) = o;     // (rows that do not exist carry relu(t2): masked below)
     }
   }
-  PFrags<4, 1> Wc, Wd;
-  p_load_w<NW, 4, 1>(Wc, p.w4, 256, 0, wave, l15, l4);
-  p_load_w<NW, 4, 1>(Wd, p.w4, 256, 128, wave, l15, l4);
   __syncthreads();
 
   // ---- o = . W4^T + b4, invalid rows zero (fp32 tile over the same LDS), then the max over each polyline
@@ -435,7 +441,7 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
       if (SPL == 1) {
         const int grp = tile * GPT + g;
         if ((size_t)grp * NPTS < (size_t)p.rows) p.out[(size_t)grp * 128 + c] = m;
-      } else gpl[u * 128 + c] = m;
+      } else pm[u * 128 + c] = m;
     }
   }
   if (SPL > 1) {
@@ -443,9 +449,9 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
     if (tid < 128) {
 #pragma unroll
       for (int g = 0; g < GPT; ++g) {
-        float m = gpl[g * SPL * 128 + tid];
+        float m = pm[g * SPL * 128 + tid];
 #pragma unroll
-        for (int s = 1; s < SPL; ++s) m = fmaxf(m, gpl[(g * SPL + s) * 128 + tid]);
+        for (int s = 1; s < SPL; ++s) m = fmaxf(m, pm[(g * SPL + s) * 128 + tid]);
         const int grp = tile * GPT + g;
         if ((size_t)grp * NPTS < (size_t)p.rows) p.out[(size_t)grp * 128 + tid] = m;
       }
