@@ -25,6 +25,7 @@
 #include "fpn_fused.h"
 #include "ego_fused.h"
 #include "heads_fused.h"
+#include "pi_fused.h"
 #include "rollout.h"
 
 // fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
@@ -91,7 +92,7 @@ struct RiftCtx {
   int* dec_idx = nullptr; bool dec_fused = true;
   double* clip_part = nullptr;
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
-  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true;
+  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -373,6 +374,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR_N(fourier_fused_kernel, FO_LDS);
   SETATTR_N(fpn_tail_kernel, FPN_LDS);
   SETATTR_N(heads3_fused_kernel, HD_LDS);
+  SETATTR_N(pi_forward_kernel, PI_LDS);
 #undef SETATTR_N
   return RIFT_OK;
 }
@@ -1069,23 +1071,32 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* x0p = A_alloc<float>(c, (size_t)bs * 128);
   gemm(c, mk(ENC, N * 128, bs, c->pw[PD + ".cat_x_proj.x"], x0p, 128), c->pw[PD + ".cat_x_proj.x"], f.fp32);
   float* QF = A_alloc<float>(c, (size_t)nQ * 128);
-  {
+  float* Hpi = A_alloc<float>(c, (size_t)nQ * 128);
+  float* prob = out->probability ? out->probability : A_alloc<float>(c, nQ);
+  if (!f.fp32 && c->pi_fused) {
+    // cat_x_proj (bf16) -> pi_head first Linear (exact fp32, live parameters) -> LayerNorm -> ReLU -> Linear -> masked logits: one launch
+    PiFwdP q; memset(&q, 0, sizeof(q));
+    q.Q = Q; q.rows = nQ; q.rows_per_scene = R * M;
+    q.wq = (const unsigned short*)c->pw[PD + ".cat_x_proj.q"].bf; q.bq = c->pw[PD + ".cat_x_proj.q"].bias; q.x0p = x0p;
+    q.w1 = fptr(c, PD + ".pi_head.mlp.0.weight"); q.b1 = fptr(c, PD + ".pi_head.mlp.0.bias");
+    q.lng = fptr(c, PD + ".pi_head.mlp.1.weight"); q.lnb = fptr(c, PD + ".pi_head.mlp.1.bias");
+    q.w2 = fptr(c, PD + ".pi_head.mlp.3.weight"); q.b2 = fptr(c, PD + ".pi_head.mlp.3.bias");
+    q.r_kpm = r_kpm; q.M = M; q.eps = 1e-5f; q.QF = QF; q.Hpi = Hpi; q.prob = prob;
+    c->prof_flops = 2.0 * nQ * (2.0 * 128 * 128 + 128);
+    launch(c, "pi_forward_kernel", pi_forward_kernel, dim3(cdiv(nQ, PI_ROWS)), dim3(512), (size_t)PI_LDS, q);
+  } else {
     GemmP g = mk(Q, 128, nQ, c->pw[PD + ".cat_x_proj.q"], QF, 128);
     g.gbias = x0p; g.gb_div = R * M; g.gb_mod = 0;
     gemm(c, g, c->pw[PD + ".cat_x_proj.q"], f.fp32);
-  }
-  tap(c, "q_final", QF, (int64_t)nQ * 128);
-  // pi head: first Linear straight from the live (trainable) fp32 parameters, exact-fp32 MFMA
-  float* Hpi = A_alloc<float>(c, (size_t)nQ * 128);
-  {
+    // pi head: first Linear straight from the live (trainable) fp32 parameters, exact-fp32 MFMA
     PW w; w.N = 128; w.K = 128; w.Kp = 128; w.Npad = 128;
     w.f32 = (float*)fptr(c, PD + ".pi_head.mlp.0.weight"); w.bias = fptr(c, PD + ".pi_head.mlp.0.bias");
     gemm(c, mk(QF, 128, nQ, w, Hpi, 128), w, true);
+    launch(c, "pi_tail_kernel", pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
+           fptr(c, PD + ".pi_head.mlp.1.bias"), fptr(c, PD + ".pi_head.mlp.3.weight"), fptr(c, PD + ".pi_head.mlp.3.bias"),
+           (const uint8_t*)r_kpm, 1e-5f, prob);
   }
-  float* prob = out->probability ? out->probability : A_alloc<float>(c, nQ);
-  launch(c, "pi_tail_kernel", pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
-         fptr(c, PD + ".pi_head.mlp.1.bias"), fptr(c, PD + ".pi_head.mlp.3.weight"), fptr(c, PD + ".pi_head.mlp.3.bias"),
-         (const uint8_t*)r_kpm, 1e-5f, prob);
+  tap(c, "q_final", QF, (int64_t)nQ * 128);
   if (f.need_traj && out->trajectory && !f.fp32 && c->heads_fused) {
     const std::string nm3[3] = {PD + ".loc_head", PD + ".yaw_head", PD + ".vel_head"};
     heads3_fused(f, QF, 128, nQ, 0, 0, 0, nm3, out->trajectory);
@@ -1135,6 +1146,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_FPN_UNFUSED"); c->fpn_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_EGO_UNFUSED"); c->ego_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_HEADS_UNFUSED"); c->heads_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_PI_UNFUSED"); c->pi_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_GRID0"); if (ev && atoi(ev) > 0) c->nat_grid0 = atoi(ev); }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
