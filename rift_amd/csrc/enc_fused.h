@@ -38,6 +38,8 @@ struct EncFusedP {
   const float* bkv;             // [4 * 256]
   unsigned short* KT;           // (bs, 4, 96, 128) bf16: K rows per key (keys >= N undefined, masked by the decoder)
   unsigned short* VT;           // (bs, 4, 128, 96) bf16: V transposed (dim-major)
+  const unsigned short* wx0;    // cat_x_proj columns 128:256 (planning_decoder.py:177-179), applied to the scene's ego token (row 0)
+  float* x0p;                   // (bs, 128)
 };
 
 // row-gather weight packer: dst[r][k] = bf16(src[idx[r]][k]); bias_out[r] = bias[idx[r]]
@@ -372,6 +374,15 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       if (r < N) *reinterpret_cast<float4*>(p.Y + (grow0 + r) * C + lr * 4) = o;
       if (p.KT) *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) = pack_bf16x4(o.x, o.y, o.z, o.w);
     }
+  }
+  if (p.KT && p.x0p) {   // the ego-token half of the decoder's cat_x_proj: one row per scene
+    EFrags<4, 1> Wx;
+    e_load_b(Wx, p.wx0, C, 0, 0, wave, l15, l4, EWaves<NW>());
+    __syncthreads();
+    f32x4 ax[1][1];
+    ax[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    e_mma<1, 4, 1>(ax, xn, XN, Wx, l15, l4);
+    if (l15 == 0) *reinterpret_cast<float4*>(p.x0p + (size_t)b * C + wave * 16 + l4 * 4) = make_float4(ax[0][0][0], ax[0][0][1], ax[0][0][2], ax[0][0][3]);
   }
   if (p.KT) {
     // ---- decoder K | V projections of the four layers from the bf16 encoder output still in LDS.  n-tiles 0..7 (K) are issued

@@ -859,6 +859,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   static const float edpr[4] = {0.f, 0.2f / 3.f, 0.4f / 3.f, 0.2f};   // linspace(0, 0.2, 4), pluto_model.py:80-83
   float* ENC = A_alloc<float>(c, (size_t)nT * 128);
   unsigned short *enc_KT = nullptr, *enc_VT = nullptr;
+  float* enc_x0p = nullptr;   // cat_x_proj's ego-token half, written by the encoder kernel's tail
   if (c->enc_fused && !f.fp32 && N <= 96) {
     EncFusedP ep; memset(&ep, 0, sizeof(ep));
     ep.X = X; ep.Y = ENC; ep.kpm = kpm; ep.bs = bs; ep.N = N; ep.seed = f.seed; ep.stream = f.next_stream(); f.stream_id += 8;
@@ -881,6 +882,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       enc_VT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 128 * 96);
       ep.wkv = (const unsigned short*)c->pw["planning_decoder.kv_all"].bf; ep.bkv = c->pw["planning_decoder.kv_all"].bias;
       ep.KT = enc_KT; ep.VT = enc_VT;
+      enc_x0p = A_alloc<float>(c, (size_t)bs * 128);
+      ep.wx0 = (const unsigned short*)c->pw["planning_decoder.cat_x_proj.x"].bf; ep.x0p = enc_x0p;
       c->prof_flops += 2.0 * bs * N * 128.0 * 1024;
     }
     launch(c, "enc_fused_kernel", enc_fused_kernel<ENC_NW>, dim3(bs), dim3(64 * ENC_NW), (size_t)RIFT_ENC_LDS_BYTES, ep);
@@ -943,13 +946,22 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1, r_emb);
   }
   tap(c, "r_emb", r_emb, (int64_t)nL * 128);
-  float* Ra = A_alloc<float>(c, (size_t)nL * 128);
-  gemm(c, mk(r_emb, 128, nL, c->pw[PD + ".q_proj.r"], Ra, 128), c->pw[PD + ".q_proj.r"], f.fp32);
   bool fill;
   float* Mb = wconst_get(c, "Mb", (size_t)M * 128, f.fp32, &fill);
   if (fill) gemm(c, mk(fptr(c, PD + ".m_emb"), 128, M, c->pw[PD + ".q_proj.m"], Mb, 128), c->pw[PD + ".q_proj.m"], f.fp32);
   float* Q = A_alloc<float>(c, (size_t)nQ * 128);
-  launch(c, "build_q0_kernel", build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
+  if (!f.fp32 && c->pi_fused) {
+    Q0P q; memset(&q, 0, sizeof(q));
+    q.r_emb = r_emb; q.nL = nL; q.M = M; q.wr = (const unsigned short*)c->pw[PD + ".q_proj.r"].bf; q.br = c->pw[PD + ".q_proj.r"].bias;
+    q.Mb = Mb; q.Q = Q;
+    c->prof_flops = 2.0 * nL * 128.0 * 128;
+    launch(c, "q0_fused_kernel", q0_fused_kernel, dim3(cdiv(nL, 16)), dim3(256), 0, q);
+  } else {
+    float* Ra = A_alloc<float>(c, (size_t)nL * 128);
+    gemm(c, mk(r_emb, 128, nL, c->pw[PD + ".q_proj.r"], Ra, 128), c->pw[PD + ".q_proj.r"], f.fp32);
+    launch(c, "build_q0_kernel", build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
+  }
+  tap(c, "q0", Q, (int64_t)nQ * 128);
 
   const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
   if (c->dec_fused && !f.fp32 && R * M <= 80 && N <= 96) {
@@ -1068,8 +1080,11 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   }
   tap(c, "dec3", Q, (int64_t)nQ * 128);
   // cat_x_proj(cat[q, enc_emb[:, 0]]) (planning_decoder.py:177-179): ego-token part is a per-scene bias
-  float* x0p = A_alloc<float>(c, (size_t)bs * 128);
-  gemm(c, mk(ENC, N * 128, bs, c->pw[PD + ".cat_x_proj.x"], x0p, 128), c->pw[PD + ".cat_x_proj.x"], f.fp32);
+  float* x0p = enc_x0p;
+  if (!x0p) {
+    x0p = A_alloc<float>(c, (size_t)bs * 128);
+    gemm(c, mk(ENC, N * 128, bs, c->pw[PD + ".cat_x_proj.x"], x0p, 128), c->pw[PD + ".cat_x_proj.x"], f.fp32);
+  }
   float* QF = A_alloc<float>(c, (size_t)nQ * 128);
   float* Hpi = A_alloc<float>(c, (size_t)nQ * 128);
   float* prob = out->probability ? out->probability : A_alloc<float>(c, nQ);

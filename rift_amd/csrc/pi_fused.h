@@ -138,4 +138,42 @@ __global__ __launch_bounds__(512) void pi_forward_kernel(PiFwdP p) {
   }
 }
 
+// Decoder query init (planning_decoder.py:160-165): q0[(b, r, m)] = q_proj(cat[r_emb[b, r], m_emb[m]]) = r_emb Wr^T + b + (m_emb Wm^T)[m];
+// the mode half is weight-only (cached), the reference-line half is one K = 128 MFMA contraction for 16 lines per workgroup, expanded
+// over the 12 modes on the way out.  Replaces a GEMM launch and the expansion kernel.
+struct Q0P { const float* r_emb; int nL, M; const unsigned short* wr; const float* br; const float* Mb; float* Q; };
+
+__global__ __launch_bounds__(256) void q0_fused_kernel(Q0P p) {
+  __shared__ __attribute__((aligned(16))) unsigned short xb[16 * 136];
+  __shared__ __attribute__((aligned(16))) float ra[16 * 132];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int l0 = blockIdx.x * 16;
+  PFrags<4, 2> W;
+  p_load_w<4, 4, 2>(W, p.wr, 128, 0, wave, l15, l4);
+  {
+    const int r = tid >> 4, c8 = (tid & 15) * 8;         // 16 rows x 16 lanes x 8 floats
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (l0 + r < p.nL) { v0 = *reinterpret_cast<const float4*>(p.r_emb + (size_t)(l0 + r) * 128 + c8); v1 = *reinterpret_cast<const float4*>(p.r_emb + (size_t)(l0 + r) * 128 + c8 + 4); }
+    uint4 o; o.x = pack_bf16x2(v0.x, v0.y); o.y = pack_bf16x2(v0.z, v0.w); o.z = pack_bf16x2(v1.x, v1.y); o.w = pack_bf16x2(v1.z, v1.w);
+    *reinterpret_cast<uint4*>(xb + r * 136 + c8) = o;
+  }
+  __syncthreads();
+  f32x4 acc[1][2];
+  p_zero(acc);
+  p_mma<1, 4, 2>(acc, xb, 136, 0, W, l15, l4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = (j * 4 + wave) * 16 + l4 * 4;
+    const float4 b4 = *reinterpret_cast<const float4*>(p.br + col);
+    *reinterpret_cast<float4*>(ra + l15 * 132 + col) = make_float4(acc[0][j][0] + b4.x, acc[0][j][1] + b4.y, acc[0][j][2] + b4.z, acc[0][j][3] + b4.w);
+  }
+  __syncthreads();
+  for (int i = tid; i < 16 * p.M * 32; i += 256) {        // (line, mode, 4 channels): 512 B rows, coalesced
+    const int c4 = (i & 31) * 4, rm = i >> 5, m = rm % p.M, r = rm / p.M;
+    if (l0 + r >= p.nL) continue;
+    const float4 a = *reinterpret_cast<const float4*>(ra + r * 132 + c4), mb = *reinterpret_cast<const float4*>(p.Mb + (size_t)m * 128 + c4);
+    *reinterpret_cast<float4*>(p.Q + ((size_t)(l0 + r) * p.M + m) * 128 + c4) = make_float4(a.x + mb.x, a.y + mb.y, a.z + mb.z, a.w + mb.w);
+  }
+}
+
 }  // namespace rift
