@@ -54,14 +54,19 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t stream, uint3
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 resolution):
-// one exp + one rcp instead of libm erff's ~60 instructions.  bf16 paths only; fp32 mode keeps erff.
+// erf-form GELU (nn.GELU default) for the bf16 paths, erf from Abramowitz-Stegun 7.1.25: erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) e^{-z^2},
+// t = 1 / (1 + 0.47047 z), |error| <= 2.5e-5 -- two orders below the bf16 rounding the result gets as an MFMA operand.  12 VALU
+// instructions with hardware v_rcp_f32 / v_exp_f32 (the 7.1.26 form with an IEEE division was 28, and the LDS-resident encoder /
+// NAT kernels are VALU-bound exactly in their GELU epilogues).  0.5 x (1 + sign(x) erf(|x|/sqrt2)) = 0.5 (x + |x| erf(|x|/sqrt2)).
+// fp32 mode keeps erff (gelu_erf).
 __device__ __forceinline__ float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erfz = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(erfz, x));
+  const float ax = fabsf(x);
+  const float z = ax * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  const float erfz = fmaf(-poly, e, 1.0f);
+  return 0.5f * fmaf(ax, erfz, x);
 }
 
 // Cross-lane sums.  __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100 cycles of dependent
