@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         mx = mn;
       }
       if (!live) continue;
-      const float inv = 1.0f / l;
+      const float inv = __builtin_amdgcn_rcpf(l);
       unsigned short* op = ao + row * XN + (ch * 2 + hh) * 32 + half * 16;
 #pragma unroll
       for (int c8 = 0; c8 < 2; ++c8) {
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
           o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, pf, o0, 0, 0, 0);
           o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, pf, o1, 0, 0, 0);
         }
-        const float inv = 1.0f / lsum;
+        const float inv = __builtin_amdgcn_rcpf(lsum);
         unsigned short* op = ao + (qt * 16 + l15) * XN + (ch * 2 + hh) * 32 + l4 * 4;
         *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
         *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);

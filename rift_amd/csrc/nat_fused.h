@@ -353,8 +353,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         }
         float den = 0.f;
 #pragma unroll
-        for (int j = 0; j < KSZ; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
-        const float inv = 1.0f / den;
+        for (int j = 0; j < KSZ; ++j) { sc[j] = __expf(sc[j] - mx); den += sc[j]; }
+        const float inv = __builtin_amdgcn_rcpf(den);
         float o[16];
 #pragma unroll
         for (int d = 0; d < 16; ++d) o[d] = 0.f;
