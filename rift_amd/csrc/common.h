@@ -49,6 +49,24 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t stream, uint3
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
 }
+// Element-wise dropout decisions: ONE lowbias32 round per counter and two 16-bit uniforms out of every hash (probability resolution
+// 2^-16); the decision is an integer compare against thr16 = p * 65536.  Four times cheaper per element than uniform01, which the
+// decoder kernel's dropout epilogues (attention weights, residual branches, FFN hidden layer) were paying 70 us a step for.
+__device__ __forceinline__ uint32_t hash1(uint32_t seed, uint32_t stream, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u + (seed ^ (stream * 0x85EBCA6Bu));
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 65536.0f); }
+// keep / drop four consecutive elements whose first flat index is idx4 (a multiple of 4): scales v[] in place
+__device__ __forceinline__ void dropout4(float (&v)[4], uint32_t seed, uint32_t stream, uint32_t idx4, uint32_t thr16, float keep_scale) {
+  const uint32_t h0 = hash1(seed, stream, idx4 >> 1), h1 = hash1(seed, stream, (idx4 >> 1) + 1);
+  v[0] = ((h0 & 0xffffu) < thr16) ? 0.f : v[0] * keep_scale;
+  v[1] = ((h0 >> 16) < thr16) ? 0.f : v[1] * keep_scale;
+  v[2] = ((h1 & 0xffffu) < thr16) ? 0.f : v[2] * keep_scale;
+  v[3] = ((h1 >> 16) < thr16) ? 0.f : v[3] * keep_scale;
+}
+
 __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t stream, uint32_t idx) {
   return (float)(hash32(seed, stream, idx) >> 8) * (1.0f / 16777216.0f);
 }

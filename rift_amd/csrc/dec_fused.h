@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
   const size_t qrow0 = (size_t)b * NQ;
   const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
+  const uint32_t thr16 = drop_thr16(dp);
   int tsn = 0;
 #define DTS() do { if (p.ts && b == 0 && tid == 0 && tsn < 250) p.ts[tsn++] = clock64(); } while (0)
   DTS();
@@ -139,11 +140,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
         float v[4] = {acc[mt][j][0] + b4.x, acc[mt][j][1] + b4.y, acc[mt][j][2] + b4.z, acc[mt][j][3] + b4.w};
-        if (dp > 0.f) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = (uniform01(p.seed, stream, (uint32_t)((b * ROWS + row) * C + col + e)) < dp) ? 0.f : v[e] * dpk;
-        }
+        if (dp > 0.f) dropout4(v, p.seed, stream, (uint32_t)((b * ROWS + row) * C + col), thr16, dpk);
         float4* xp = reinterpret_cast<float4*>(xs + row * XS + col);
         float4 x = *xp;
         x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
@@ -189,7 +186,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         const float corr = __expf(mx - mn), pj = __expf(sc - mn);
         l = l * corr + pj;
         float wj = pj;
-        if (dp > 0.f) wj = (uniform01(p.seed, stream, (uint32_t)(((b * ROWS + row) * 4 + ch * 2 + hh) * 16 + j)) < dp) ? 0.f : pj * dpk;
+        if (dp > 0.f) wj = ((hash1(p.seed, stream, (uint32_t)(((b * ROWS + row) * 4 + ch * 2 + hh) * 16 + j)) & 0xffffu) < thr16) ? 0.f : pj * dpk;
 #pragma unroll
         for (int c8 = 0; c8 < 2; ++c8) {
           const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + 32 + c8 * 8);
@@ -346,16 +343,15 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float lsum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+          float ev[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = __expf(s[kt][r] - m);
-            lsum += e;
-            float wv = e;
-            if (dp > 0.f)
-              wv = (uniform01(p.seed, st + 4, (uint32_t)((((b * ROWS + qt * 16 + l15) * 4 + ch * 2 + hh) * 96) + kt * 16 + l4 * 4 + r)) < dp) ? 0.f : e * dpk;
-            s[kt][r] = wv;
-          }
+          for (int r = 0; r < 4; ++r) { ev[r] = __expf(s[kt][r] - m); lsum += ev[r]; }
+          if (dp > 0.f)
+            dropout4(ev, p.seed, st + 4, (uint32_t)((((b * ROWS + qt * 16 + l15) * 4 + ch * 2 + hh) * 96) + kt * 16 + l4 * 4), thr16, dpk);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[kt][r] = ev[r];
+        }
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
@@ -425,11 +421,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
               const int row = mt * 16 + l15;
               float v[4] = {fmaxf(acc[mt][j][0] + b4.x, 0.f), fmaxf(acc[mt][j][1] + b4.y, 0.f), fmaxf(acc[mt][j][2] + b4.z, 0.f),
                             fmaxf(acc[mt][j][3] + b4.w, 0.f)};
-              if (dp > 0.f) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  v[e] = (uniform01(p.seed, st + 6, (uint32_t)((b * ROWS + row) * 512 + hc * 128 + col + e)) < dp) ? 0.f : v[e] * dpk;
-              }
+              if (dp > 0.f) dropout4(v, p.seed, st + 6, (uint32_t)((b * ROWS + row) * 512 + hc * 128 + col), thr16, dpk);
               *reinterpret_cast<uint2*>(cb + row * CB + col) = pack_bf16x4(v[0], v[1], v[2], v[3]);
             }
           }
