@@ -8,20 +8,17 @@ namespace rift {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA 16x16x32 A/B operand)
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // MFMA 16x16 accumulator
 
-__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even fp32 -> bf16
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
-
 // two fp32 -> packed bf16x2 (round-to-nearest-even) in ONE instruction (gfx950 v_cvt_pk_bf16_f32; no builtin)
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
   unsigned int r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even fp32 -> bf16: the same instruction, one lane used
+  return (unsigned short)(pack_bf16x2(f, 0.f) & 0xffffu);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
 __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
   uint2 u; u.x = pack_bf16x2(a, b); u.y = pack_bf16x2(c, d); return u;
 }
