@@ -117,4 +117,24 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// LayerNorm of one 128-wide fp32 row held by 16 lanes (8 columns each, l15 = lane & 15): the two reductions are DPP row sums (no
+// ds_bpermute), the result goes out as 8 bf16 (one 16-byte LDS store).  g / be: the 8 scale / shift values of this lane's columns.
+__device__ __forceinline__ void ln128_row16(const float* __restrict__ src, unsigned short* __restrict__ dst, const float4& g0, const float4& g1,
+                                            const float4& b0, const float4& b1, int l15, bool relu = false) {
+  const float4 v0 = *reinterpret_cast<const float4*>(src + l15 * 8), v1 = *reinterpret_cast<const float4*>(src + l15 * 8 + 4);
+  const float mean = sum16(((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) * (1.0f / 128.0f);
+  const float d0 = v0.x - mean, d1 = v0.y - mean, d2 = v0.z - mean, d3 = v0.w - mean;
+  const float d4 = v1.x - mean, d5 = v1.y - mean, d6 = v1.z - mean, d7 = v1.w - mean;
+  const float rstd = rsqrtf(sum16(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / 128.0f) + 1e-5f);
+  float y[8] = {d0 * rstd * g0.x + b0.x, d1 * rstd * g0.y + b0.y, d2 * rstd * g0.z + b0.z, d3 * rstd * g0.w + b0.w,
+                d4 * rstd * g1.x + b1.x, d5 * rstd * g1.y + b1.y, d6 * rstd * g1.z + b1.z, d7 * rstd * g1.w + b1.w};
+  if (relu) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = fmaxf(y[i], 0.f);
+  }
+  uint4 o;
+  o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]); o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);
+  *reinterpret_cast<uint4*>(dst + l15 * 8) = o;
+}
+
 }  // namespace rift

@@ -266,6 +266,13 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
 
   // LayerNorm xs -> xn (bf16): C/4 lanes per row (16-byte LDS reads), xor-shuffle statistics
   auto layer_norm = [&](const float* g, const float* b) {
+    if constexpr (C == 128) {                             // 16 lanes x 8 columns: DPP-only reductions (no ds_bpermute)
+      const float4 g0 = *reinterpret_cast<const float4*>(g + l15 * 8), g1 = *reinterpret_cast<const float4*>(g + l15 * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(b + l15 * 8), b1 = *reinterpret_cast<const float4*>(b + l15 * 8 + 4);
+#pragma unroll
+      for (int r = wave * 4 + l4; r < ROWS; r += 4 * NW) ln128_row16(xs + r * XS, xn + r * XN, g0, g1, b0, b1, l15);
+      return;
+    }
     constexpr int LPR = C / 4, RPS = 64 / LPR;            // lanes per row, rows per wave step
     const int lr = lane % LPR, rsub = lane / LPR;
     const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(b + lr * 4);
