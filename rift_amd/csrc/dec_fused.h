@@ -114,20 +114,11 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   if (tid < 8) rz[tid] = (tid >= R) || p.r_kpm[(size_t)b * R + tid];
   __syncthreads();
 
-  auto layer_norm = [&](const float* g, const float* be) {   // xs -> xn (bf16); 32 lanes per row; g/be in LDS
-    const int lr = lane & 31, rsub = lane >> 5;
-    const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(be + lr * 4);
-#pragma unroll 2
-    for (int r = wave * 2 + rsub; r < ROWS; r += 2 * NW) {
-      const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
-      float s = group_sum<32>((v.x + v.y) + (v.z + v.w));
-      const float mean = s * (1.0f / C);
-      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-      const float q = group_sum<32>((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-      const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
-      *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) =
-          pack_bf16x4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
-    }
+  auto layer_norm = [&](const float* g, const float* be) {   // xs -> xn (bf16); 16 lanes per row; g/be in LDS
+    const float4 g0 = *reinterpret_cast<const float4*>(g + l15 * 8), g1 = *reinterpret_cast<const float4*>(g + l15 * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(be + l15 * 8), b1 = *reinterpret_cast<const float4*>(be + l15 * 8 + 4);
+#pragma unroll 1
+    for (int r = wave * 4 + l4; r < ROWS; r += 4 * NW) ln128_row16(xs + r * XS, xn + r * XN, g0, g1, b0, b1, l15);
   };
 
   // x += dropout(acc + bias) for a 128-column projection held as acc[MT][2]; optional row zeroing (m2m)
