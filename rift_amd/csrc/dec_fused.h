@@ -313,8 +313,21 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
             *reinterpret_cast<uint4*>(vtc + d * VS + k8) = *reinterpret_cast<const uint4*>(vt + d * 96 + k8);
           }
         }
-      } else
-      __syncthreads(); DTS();
+      } else {                             // fp32 K|V rows from the projection GEMM (encoder kernel not fused)
+        for (int i = tid; i < 96 * 16; i += NTH) {
+          const int key = i >> 4, c4 = (i & 15) * 4;
+          float4 kq = make_float4(0.f, 0.f, 0.f, 0.f), vq = kq;
+          if (key < N) {
+            const float* src = w.kv + ((size_t)b * N + key) * p.kv_ld + ch * 64 + c4;
+            kq = *reinterpret_cast<const float4*>(src);
+            vq = *reinterpret_cast<const float4*>(src + 128);
+          }
+          *reinterpret_cast<uint2*>(kc + key * KC + c4) = pack_bf16x4(kq.x, kq.y, kq.z, kq.w);
+          vtc[(c4 + 0) * VS + key] = f2bf(vq.x); vtc[(c4 + 1) * VS + key] = f2bf(vq.y);
+          vtc[(c4 + 2) * VS + key] = f2bf(vq.z); vtc[(c4 + 3) * VS + key] = f2bf(vq.w);
+        }
+      }
+      __syncthreads(); DTS();          // K / V^T chunk visible to every wave
       for (int pr = wave; pr < 2 * MT; pr += NW) {           // (head, query tile) pairs
         const int hh = pr / MT, qt = pr - hh * MT;
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + (qt * 16 + l15) * CB + (ch * 2 + hh) * 32 + l4 * 8);

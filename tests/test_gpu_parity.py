@@ -318,17 +318,24 @@ def test_fused_encoder_matches_layerwise_path(ffi, monkeypatch):
     bs, A = data["agent"]["position"].shape[:2]
     va = data["agent"]["valid_mask"].any(-1)
     kpm = torch.cat([~va, ~data["map"]["valid_mask"].any(-1)], dim=-1)
-    outs = {}
+    rv = data["reference_line"]["valid_mask"].any(-1)
+    outs, dec = {}, {}
     for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
         monkeypatch.setenv("RIFT_ENC_UNFUSED", env)
         eng = ffi.Engine("cuda:0")
         eng.load_state_dict({k: v.clone() for k, v in sd.items()})
         eng.forward(data, fp32=fp32)
         outs[name] = eng.tap("enc_out").view(bs, -1, 128).cpu().clone()[~kpm]
+        dec[name] = eng.tap("dec3").view(rv.shape[0], rv.shape[1], 12, 128).cpu().clone()[rv]
         eng.close()
     assert err(outs["fused"], outs["fp32"]) < 5e-2
     assert err(outs["fused"], outs["layerwise"]) < 5e-2
     assert not torch.equal(outs["fused"], outs["layerwise"])
+    # downstream: the fused decoder fed by the encoder kernel's bf16 K | V^T images ("fused") and by the fp32 K|V
+    # projection GEMM ("layerwise" encoder) must both match the exact-fp32 decoder output
+    scale = max(1.0, float(dec["fp32"].abs().max()))
+    assert err(dec["fused"], dec["fp32"]) < 4e-2 * scale
+    assert err(dec["layerwise"], dec["fp32"]) < 4e-2 * scale
 
 
 def test_fused_fourier_embedding_matches_layerwise_path(ffi, monkeypatch):
