@@ -12,15 +12,15 @@
 namespace rift {
 
 struct DecBlockW {
-  const float* ln_g[4]; const float* ln_b[4];
-  const unsigned short* w_r2r;  const float* b_r2r;    // bf16 [384][128], per 2-head chunk rows (q|k|v of head a, q|k|v of head b)
-  const unsigned short* w_r2ro; const float* b_r2ro;   // out_proj [128][128]
-  const unsigned short* w_m2m;  const float* b_m2m;
-  const unsigned short* w_m2mo; const float* b_m2mo;
-  const unsigned short* w_cq;   const float* b_cq;     // cross_attn in_proj rows 0:128
-  const unsigned short* w_co;   const float* b_co;
-  const unsigned short* w_f1;   const float* b_f1;     // ffn.0 [512][128]
-  const unsigned short* w_f2;   const float* b_f2;     // ffn.3 [128][512]
+  const float* par;             // RIFT_DEC_NPAR packed fp32 LayerNorm parameters and biases of this layer (layout below)
+  const unsigned short* w_r2r;  // bf16 [384][128], per 2-head chunk rows (q|k|v of head a, q|k|v of head b)
+  const unsigned short* w_r2ro; // out_proj [128][128]
+  const unsigned short* w_m2m;
+  const unsigned short* w_m2mo;
+  const unsigned short* w_cq;   // cross_attn in_proj rows 0:128
+  const unsigned short* w_co;
+  const unsigned short* w_f1;   // ffn.0 [512][128]
+  const unsigned short* w_f2;   // ffn.3 [128][512]
   const float* mp;                                     // (12, 384) fp32: m_pos . Wqk^T in ORIGINAL column order (v part zero)
   const float* kv;                                     // (bs*N, kv_ld) fp32: cross-attention K | V projections of the encoder tokens (256 columns of this layer)
 };
@@ -40,7 +40,8 @@ struct DecFusedP {
 };
 
 #define RIFT_DEC_NPAR 2944   // ln1..4 g,b (1024) | b_r2r 384 | b_r2ro 128 | b_m2m 384 | b_m2mo 128 | b_cq 128 | b_co 128 | b_f1 512 | b_f2 128
-#define RIFT_DEC_LDS_BYTES (80 * 132 * 4 + 80 * 136 * 2 * 2 + 80 * 200 * 2 + 96 * 72 * 2 + 64 * 104 * 2 + RIFT_DEC_NPAR * 4 + 96 + 96 + 16)
+#define RIFT_DEC_NFFB 640    // the FFN biases (tail of the block) stay live to the end of a layer: double-buffered by layer parity
+#define RIFT_DEC_LDS_BYTES (80 * 132 * 4 + 80 * 136 * 2 * 2 + 80 * 200 * 2 + 96 * 72 * 2 + 64 * 104 * 2 + (RIFT_DEC_NPAR + RIFT_DEC_NFFB) * 4 + 96 + 96 + 16)
 
 // NW waves per workgroup: one scene is one workgroup on one CU, so the wave count is the only occupancy lever
 template <int NW>
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   unsigned short* kc = ao + ROWS * XN;             // [96][KC]  cross K of two heads (row-major, 64 dims + pad)
   unsigned short* vtc = kc + 96 * KC;              // [64][VS]  cross V^T of two heads
   float* par = reinterpret_cast<float*>(vtc + 64 * VS);
-  unsigned char* smask = reinterpret_cast<unsigned char*>(par + RIFT_DEC_NPAR);   // [96] encoder key mask
+  unsigned char* smask = reinterpret_cast<unsigned char*>(par + RIFT_DEC_NPAR + RIFT_DEC_NFFB);   // [96] encoder key mask
   unsigned char* qmask = smask + 96;               // [12][8] r2r quirk mask rows
   unsigned char* rz = qmask + 96;                  // [8] padded reference lines of this scene
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,30 +72,22 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
 #define DTS() do { if (p.ts && b == 0 && tid == 0 && tsn < 250) p.ts[tsn++] = clock64(); } while (0)
   DTS();
 
+  // layer parameters: one coalesced read of the host-packed block; everything before the FFN biases is dead once LN4
+  // has run, so the next layer's block is fetched right after that barrier and committed behind the first FFN MFMAs
   constexpr int NPRE = (RIFT_DEC_NPAR + NTH - 1) / NTH;
   float pre[NPRE];
-  auto par_fetch = [&](const DecBlockW& w) {
+  auto par_fetch = [&](const float* src) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) { const int e = tid + NTH * i; pre[i] = e < RIFT_DEC_NPAR ? src[e] : 0.f; }
+  };
+  auto par_commit = [&](int parity) {                     // FFN biases of odd layers live RIFT_DEC_NFFB further
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int e = tid + NTH * i;
-      const float* src;
-      if (e < 1024) { const int k = e >> 7, c = e & 127; src = ((k & 1) ? w.ln_b[k >> 1] : w.ln_g[k >> 1]) + c; }
-      else if (e < P_BR2RO) src = w.b_r2r + (e - P_BR2R);
-      else if (e < P_BM2M) src = w.b_r2ro + (e - P_BR2RO);
-      else if (e < P_BM2MO) src = w.b_m2m + (e - P_BM2M);
-      else if (e < P_BCQ) src = w.b_m2mo + (e - P_BM2MO);
-      else if (e < P_BCO) src = w.b_cq + (e - P_BCQ);
-      else if (e < P_BF1) src = w.b_co + (e - P_BCO);
-      else if (e < P_BF2) src = w.b_f1 + (e - P_BF1);
-      else src = w.b_f2 + (e - P_BF2);
-      pre[i] = e < RIFT_DEC_NPAR ? *src : 0.f;
+      if (e < RIFT_DEC_NPAR) par[e + ((e >= P_BF1 && parity) ? RIFT_DEC_NFFB : 0)] = pre[i];
     }
   };
-  auto par_commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) { const int e = tid + NTH * i; if (e < RIFT_DEC_NPAR) par[e] = pre[i]; }
-  };
-  par_fetch(p.blk[0]);
+  par_fetch(p.blk[0].par);
   EFrags<4, NTQ> Bqkv;       // 192-column qkv chunk
   EFrags<4, NTC> Bw;         // 128-column projections / ffn.0 chunk
   EFrags<4, NTC> B2;         // ffn.3 partial
@@ -230,7 +223,9 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   for (int li = 0; li < 4; ++li) {
     const DecBlockW& w = p.blk[li];
     const uint32_t st = p.stream + 16 * li;
-    par_commit();
+    const float* bf1 = par + P_BF1 + (li & 1) * RIFT_DEC_NFFB;
+    const float* bf2 = par + P_BF2 + (li & 1) * RIFT_DEC_NFFB;
+    if (li == 0) par_commit(0);
     __syncthreads(); DTS();
     // ================= r2r =================
     layer_norm(par + P_LN + 0, par + P_LN + 128);
@@ -398,8 +393,8 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     __syncthreads(); DTS();
     // ================= FFN =================
     layer_norm(par + P_LN + 768, par + P_LN + 896);
-    if (li + 1 < 4) par_fetch(p.blk[li + 1]);
     __syncthreads(); DTS();
+    if (li + 1 < 4) par_fetch(p.blk[li + 1].par);
     {
       f32x4 acc2[MT][NTC];
 #pragma unroll
@@ -415,11 +410,12 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
             for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
           e_load_b(B2, w.w_f2, 512, 0, hc * 128, wave, l15, l4, EWaves<NW>());
+          if (hc == 0 && li + 1 < 4) par_commit((li + 1) & 1);
           if (hc > 0) __syncthreads(); DTS();
 #pragma unroll
           for (int j = 0; j < NTC; ++j) {
             const int col = (j * NW + wave) * 16 + l4 * 4;
-            const float4 b4 = *reinterpret_cast<const float4*>(par + P_BF1 + hc * 128 + col);
+            const float4 b4 = *reinterpret_cast<const float4*>(bf1 + hc * 128 + col);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const int row = mt * 16 + l15;
@@ -435,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         __syncthreads(); DTS();
         e_mma<MT, 4, NTC>(acc2, cb, CB, B2, l15, l4);
       }
-      residual_epilogue(acc2, par + P_BF2, st + 7, false);
+      residual_epilogue(acc2, bf2, st + 7, false);
     }
     __syncthreads(); DTS();
   }

@@ -89,6 +89,7 @@ struct RiftCtx {
   int* enc_idx = nullptr; bool enc_fused = true;
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
+  float* dec_par = nullptr;              // [4][RIFT_DEC_NPAR] packed LayerNorm parameters / biases of the fused decoder kernel
   int* dec_idx = nullptr; bool dec_fused = true;
   double* clip_part = nullptr;
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
@@ -979,19 +980,12 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     for (int i = 0; i < 4; ++i) {
       const std::string p = PD + ".decoder_blocks." + std::to_string(i);
       DecBlockW& w = dq.blk[i];
-      for (int k = 0; k < 4; ++k) {
-        w.ln_g[k] = fptr(c, p + ".norm" + std::to_string(k + 1) + ".weight");
-        w.ln_b[k] = fptr(c, p + ".norm" + std::to_string(k + 1) + ".bias");
-      }
-      w.w_r2r = c->dec_wqkv[i][0]; w.b_r2r = c->dec_bqkv[i][0];
-      w.w_m2m = c->dec_wqkv[i][1]; w.b_m2m = c->dec_bqkv[i][1];
+      w.par = c->dec_par + (size_t)i * RIFT_DEC_NPAR;
+      w.w_r2r = c->dec_wqkv[i][0]; w.w_m2m = c->dec_wqkv[i][1];
       auto bf = [&](const std::string& k) { return (const unsigned short*)c->pw[k].bf; };
-      w.w_r2ro = bf(p + ".r2r_attn.out_proj"); w.b_r2ro = c->pw[p + ".r2r_attn.out_proj"].bias;
-      w.w_m2mo = bf(p + ".m2m_attn.out_proj"); w.b_m2mo = c->pw[p + ".m2m_attn.out_proj"].bias;
-      w.w_cq = bf(p + ".cross_attn.q"); w.b_cq = c->pw[p + ".cross_attn.q"].bias;
-      w.w_co = bf(p + ".cross_attn.out_proj"); w.b_co = c->pw[p + ".cross_attn.out_proj"].bias;
-      w.w_f1 = bf(p + ".ffn.0"); w.b_f1 = c->pw[p + ".ffn.0"].bias;
-      w.w_f2 = bf(p + ".ffn.3"); w.b_f2 = c->pw[p + ".ffn.3"].bias;
+      w.w_r2ro = bf(p + ".r2r_attn.out_proj"); w.w_m2mo = bf(p + ".m2m_attn.out_proj");
+      w.w_cq = bf(p + ".cross_attn.q"); w.w_co = bf(p + ".cross_attn.out_proj");
+      w.w_f1 = bf(p + ".ffn.0"); w.w_f2 = bf(p + ".ffn.3");
       // per-layer operands produced by the generic GEMM: m_pos.Wqk^T (12x384) and the K|V projections of the encoder tokens
       bool fill_mp;
       float* MPl = wconst_get(c, p + ".mp", (size_t)M * 384, f.fp32, &fill_mp);
@@ -1187,6 +1181,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->dec_idx) (void)hipFree(c->dec_idx);
   if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
   if (c->clip_part) (void)hipFree(c->clip_part);
+  if (c->dec_par) (void)hipFree(c->dec_par);
   for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
@@ -1321,6 +1316,28 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
         hipLaunchKernelGGL(pack_rows_indexed_kernel, dim3(cdiv(384 * 128, 256)), dim3(256), 0, c->stream, w, bsrc, (const int*)c->dec_idx,
                            384, 128, c->dec_wqkv[i][k], c->dec_bqkv[i][k]);
       }
+  }
+  {  // per-layer parameter block of the fused decoder kernel (layout: RIFT_DEC_NPAR in dec_fused.h)
+    if (!c->dec_par) HIPCHK(c, hipMalloc((void**)&c->dec_par, (size_t)4 * RIFT_DEC_NPAR * 4));
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = PD + ".decoder_blocks." + std::to_string(i);
+      float* dst = c->dec_par + (size_t)i * RIFT_DEC_NPAR;
+      auto put = [&](const float* src, int n) -> int {
+        if (!src) return RIFT_ERR_ARG;
+        HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+        dst += n;
+        return RIFT_OK;
+      };
+      for (int k = 0; k < 4; ++k) {
+        TRY(put(fptr(c, p + ".norm" + std::to_string(k + 1) + ".weight"), 128));
+        TRY(put(fptr(c, p + ".norm" + std::to_string(k + 1) + ".bias"), 128));
+      }
+      TRY(put(c->dec_bqkv[i][0], 384)); TRY(put(c->pw[p + ".r2r_attn.out_proj"].bias, 128));
+      TRY(put(c->dec_bqkv[i][1], 384)); TRY(put(c->pw[p + ".m2m_attn.out_proj"].bias, 128));
+      TRY(put(c->pw[p + ".cross_attn.q"].bias, 128)); TRY(put(c->pw[p + ".cross_attn.out_proj"].bias, 128));
+      TRY(put(c->pw[p + ".ffn.0"].bias, 512)); TRY(put(c->pw[p + ".ffn.3"].bias, 128));
+      if (dst != c->dec_par + (size_t)(i + 1) * RIFT_DEC_NPAR) return RIFT_ERR_STATE;
+    }
   }
   TRY(pack_cols(c, PD + ".cat_x_proj.q", PD + ".cat_x_proj", 0, 128, true));
   TRY(pack_cols(c, PD + ".cat_x_proj.x", PD + ".cat_x_proj", 128, 128, false));
