@@ -21,7 +21,7 @@ struct DecBlockW {
   const unsigned short* w_co;
   const unsigned short* w_f1;   // ffn.0 [512][128]
   const unsigned short* w_f2;   // ffn.3 [128][512]
-  const float* mp;                                     // (12, 384) fp32: m_pos . Wqk^T in ORIGINAL column order (v part zero)
+  const unsigned short* mpx;    // [2 chunks][8 q|k tiles] 32x16 bf16 weight fragments: rows 0..11 hi(m_pos . Wqk^T), 12..23 lo(...), rest 0
   const float* kv;                                     // (bs*N, kv_ld) fp32: cross-attention K | V projections of the encoder tokens (256 columns of this layer)
 };
 
@@ -38,6 +38,24 @@ struct DecFusedP {
   uint32_t seed, stream;
   long long* ts;                // optional phase timestamps of workgroup 0 (diagnostic)
 };
+
+// mpx image of one decoder layer: per (chunk, q|k tile) one 16 x 32 weight fragment in lane order (lane = 16*(k/8) + n, 8 k each);
+// k slots 0..11 = bf16 hi part of mp[mode][column], 12..23 = bf16(mp - hi), 24..31 = 0.  mp: (12, 384) fp32 in the ORIGINAL in_proj
+// column order, idx: image row -> original row of the chunked in_proj image (q_a k_a q_b k_b v_a v_b per chunk).
+__global__ void pack_mpx_kernel(const float* __restrict__ mp, const int* __restrict__ idx, unsigned short* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * 8 * 512) return;
+  const int i = e & 7, lane = (e >> 3) & 63, tile = e >> 9;          // tile = ch * 8 + nt
+  const int ch = tile >> 3, nt = tile & 7;
+  const int n = lane & 15, k = (lane >> 4) * 8 + i;
+  unsigned short v = 0;
+  if (k < 24) {
+    const float x = mp[(k % 12) * 384 + idx[ch * 192 + nt * 16 + n]];
+    const unsigned short hi = f2bf(x);
+    v = k < 12 ? hi : f2bf(x - bf2f(hi));
+  }
+  out[e] = v;
+}
 
 #define RIFT_DEC_NPAR 2944   // ln1..4 g,b (1024) | b_r2r 384 | b_r2ro 128 | b_m2m 384 | b_m2mo 128 | b_cq 128 | b_co 128 | b_f1 512 | b_f2 128
 #define RIFT_DEC_NFFB 640    // the FFN biases (tail of the block) stay live to the end of a layer: double-buffered by layer parity
@@ -134,89 +152,108 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     }
   };
 
-  // fp32 VALU self-attention over <= 12 keys of a (row, head) work item, two adjacent lanes per item (16 of the 32 head dims
-  // each; the score halves meet through a DPP lane swap); q|k|v of head hh at cb[row][hh*96 + {0,32,64}]
-  auto small_attention = [&](int ch, bool over_modes, uint32_t stream) {
-    for (int it = tid; it < ((NQ * 4 + 63) & ~63); it += NTH) {      // whole waves: the DPP swap needs both lanes of a pair active
-      const bool live = it < NQ * 4;
-      const int half = it & 1, item = live ? it >> 1 : 0;
-      const int hh = item & 1, row = item >> 1;
-      const int r = row / M, m = row - r * M;
-      const int nkeys = over_modes ? M : R;
-      float q[16], o[16];
-      {
-        const unsigned short* qp = cb + row * CB + hh * 96 + half * 16;
+  // MFMA self-attention over the <= 16 keys of a (group, head) tile.  m2m (over_modes): group = reference line g, queries = keys =
+  // its 12 modes (rows g*12 + i).  r2r: group = mode g, queries = keys = the R <= 8 reference lines (rows i*12 + g), with the quirk
+  // mask row of mode g.  S^T = K . Q^T puts 4 keys of ONE query in each lane (query = lane&15), O^T = V^T . P^T puts 4 output dims
+  // of that query in the lane: per-lane denominators, 8-byte stores.  q|k of head hh at cb[row][hh*64 + {0, 32}] (q pre-scaled),
+  // V^T of head hh at vtc[hh*32 + d][row].
+  auto self_attention = [&](int ch, bool over_modes, uint32_t stream) {
+    const int ngroups = over_modes ? R : M, nk = over_modes ? M : R;
+    for (int pr = wave; pr < ngroups * 2; pr += NW) {
+      const int hh = pr & 1, g = pr >> 1;
+      const bool rowok = l15 < nk;
+      const int row = rowok ? (over_modes ? g * M + l15 : l15 * M + g) : g;      // this lane's query row (and key row as an A operand)
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + row * CB + hh * 64 + l4 * 8);
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cb + row * CB + hh * 64 + 32 + l4 * 8);
+      f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      // V^T fragments: keys l4*4 .. +3 of dims l15 (+16); zero beyond the valid keys (stale LDS there)
+      unsigned short vv[2][4];
 #pragma unroll
-        for (int c8 = 0; c8 < 2; ++c8) {
-          const bf16x8 t = *reinterpret_cast<const bf16x8*>(qp + c8 * 8);
-#pragma unroll
-          for (int d = 0; d < 8; ++d) { q[c8 * 8 + d] = bf2f((unsigned short)t[d]); o[c8 * 8 + d] = 0.f; }
-        }
+      for (int i = 0; i < 4; ++i) {
+        const int key = l4 * 4 + i;
+        const bool kok = key < nk;
+        const int krow = kok ? (over_modes ? g * M + key : key * M + g) : 0;
+        const unsigned short a0 = vtc[(hh * 32 + l15) * VS + krow], a1 = vtc[(hh * 32 + 16 + l15) * VS + krow];
+        vv[0][i] = kok ? a0 : (unsigned short)0; vv[1][i] = kok ? a1 : (unsigned short)0;
+        const bool masked = !kok || (!over_modes && qmask[g * 8 + (key & 7)]);
+        if (masked) s[i] = -INFINITY;
       }
-      float mx = -INFINITY, l = 0.f;
-      for (int j = 0; j < nkeys; ++j) {
-        if (!over_modes && qmask[m * 8 + j]) continue;            // uniform within the lane pair
-        const int krow = over_modes ? r * M + j : j * M + m;
-        const unsigned short* kp = cb + krow * CB + hh * 96 + 32 + half * 16;
-        float sp = 0.f;
+      float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float ev[4];
+      float lsum = 0.f;
 #pragma unroll
-        for (int c8 = 0; c8 < 2; ++c8) {
-          const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + c8 * 8);
+      for (int i = 0; i < 4; ++i) { ev[i] = __expf(s[i] - m); lsum += ev[i]; }
+      lsum += __shfl_xor(lsum, 16, 64);
+      lsum += __shfl_xor(lsum, 32, 64);
+      if (dp > 0.f) dropout4(ev, p.seed, stream, (uint32_t)((((b * ROWS + row) * 4 + ch * 2 + hh) * 16) + l4 * 4), thr16, dpk);
+      const unsigned int p0 = pack_bf16x2(ev[0], ev[1]), p1 = pack_bf16x2(ev[2], ev[3]);
+      bf16x8 pf, b0, b1;
+      pf[0] = (short)(p0 & 0xffff); pf[1] = (short)(p0 >> 16); pf[2] = (short)(p1 & 0xffff); pf[3] = (short)(p1 >> 16);
+      pf[4] = 0; pf[5] = 0; pf[6] = 0; pf[7] = 0;
 #pragma unroll
-          for (int d = 0; d < 8; ++d) sp += q[c8 * 8 + d] * bf2f((unsigned short)t[d]);
-        }
-        const float sc = sp + dpp_f<0xB1>(sp);                      // + the partner lane's 16 dims
-        const float mn = fmaxf(mx, sc);
-        const float corr = __expf(mx - mn), pj = __expf(sc - mn);
-        l = l * corr + pj;
-        float wj = pj;
-        if (dp > 0.f) wj = ((hash1(p.seed, stream, (uint32_t)(((b * ROWS + row) * 4 + ch * 2 + hh) * 16 + j)) & 0xffffu) < thr16) ? 0.f : pj * dpk;
-#pragma unroll
-        for (int c8 = 0; c8 < 2; ++c8) {
-          const bf16x8 t = *reinterpret_cast<const bf16x8*>(kp + 32 + c8 * 8);
-#pragma unroll
-          for (int d = 0; d < 8; ++d) o[c8 * 8 + d] = o[c8 * 8 + d] * corr + wj * bf2f((unsigned short)t[d]);
-        }
-        mx = mn;
-      }
-      if (!live) continue;
-      const float inv = __builtin_amdgcn_rcpf(l);
-      unsigned short* op = ao + row * XN + (ch * 2 + hh) * 32 + half * 16;
-#pragma unroll
-      for (int c8 = 0; c8 < 2; ++c8) {
-        uint4 u;
-        u.x = pack_bf16x2(o[c8 * 8 + 0] * inv, o[c8 * 8 + 1] * inv); u.y = pack_bf16x2(o[c8 * 8 + 2] * inv, o[c8 * 8 + 3] * inv);
-        u.z = pack_bf16x2(o[c8 * 8 + 4] * inv, o[c8 * 8 + 5] * inv); u.w = pack_bf16x2(o[c8 * 8 + 6] * inv, o[c8 * 8 + 7] * inv);
-        *reinterpret_cast<uint4*>(op + c8 * 8) = u;
+      for (int i = 0; i < 4; ++i) { b0[i] = (short)vv[0][i]; b1[i] = (short)vv[1][i]; b0[4 + i] = 0; b1[4 + i] = 0; }
+      const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, pf, z4, 0, 0, 0);
+      const f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, pf, z4, 0, 0, 0);
+      if (rowok) {
+        const float inv = __builtin_amdgcn_rcpf(lsum);
+        unsigned short* op = ao + row * XN + (ch * 2 + hh) * 32 + l4 * 4;
+        *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+        *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
       }
     }
   };
 
-  // qkv chunk GEMM of a self-attention: cb[row][hh*96 + part*32 + d]; q pre-scaled; optional per-mode bias (m2m)
-  auto qkv_chunk = [&](int ch, const float* bias, const float* mp) {
+  // qkv chunk GEMM of a self-attention (2 heads): n-tiles 0..7 = q_a q_a k_a k_a q_b q_b k_b k_b -> cb[row][nt*16 ..] (q pre-scaled),
+  // n-tiles 8..11 = v_a v_a v_b v_b in the plain MFMA order -> V^T rows.  m2m adds m_pos to q and k (planning_decoder.py:62-64):
+  // (LN(x) + m_pos) Wqk^T = LN(x) Wqk^T + onehot(mode) . [hi(m_pos Wqk^T); lo(...)], one extra K = 32 MFMA step per q|k tile
+  // whose weight fragment `mpx` is the hi/lo bf16 split of the fp32 product (exact to 2^-17) -- no global reads in the epilogue.
+  auto qkv_chunk = [&](int ch, const float* bias, const unsigned short* mpx) {
+    static_assert(NW == 8, "tile ownership below assumes 8 waves: one q|k tile each, V tiles on waves 0..3");
+    bf16x8 mf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (mpx) mf = *reinterpret_cast<const bf16x8*>(mpx + ((size_t)(ch * 8 + wave) * 64 + lane) * 8);
     f32x4 acc[MT][NTQ];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < NTQ; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    e_mma<MT, 4, NTQ>(acc, xn, XN, Bqkv, l15, l4);
-#pragma unroll
-    for (int j = 0; j < NTQ; ++j) {
-      const int nt = j * NW + wave;                         // 12 n-tiles: head (nt/6), part ((nt%6)/2), half (nt&1)
-      if (nt >= 12) continue;
-      const int hh = nt / 6, part = (nt % 6) >> 1, half = nt & 1;
-      const int col = nt * 16 + l4 * 4;
-      const float4 b4 = *reinterpret_cast<const float4*>(bias + ch * 192 + col);
-      const float sc = part == 0 ? 0.17677669529663687f : 1.0f;
-      const int ocol = part * 128 + (ch * 2 + hh) * 32 + half * 16 + l4 * 4;   // column in the ORIGINAL (q|k|v) order
+    e_mma<MT, 4, NTQ, 1>(acc, xn, XN, Bqkv, l15, l4);
+    if (mpx) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mp && part < 2) m4 = *reinterpret_cast<const float4*>(mp + ((mt * 16 + l15) % M) * 384 + ocol);
-        *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
-            pack_bf16x4((acc[mt][j][0] + b4.x + m4.x) * sc, (acc[mt][j][1] + b4.y + m4.y) * sc,
-                        (acc[mt][j][2] + b4.z + m4.z) * sc, (acc[mt][j][3] + b4.w + m4.w) * sc);
+        const int m = (mt * 16 + l15) % M;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                        // k slots m (hi part) and 12 + m (lo part)
+          const int i = m + 12 * t - l4 * 8;
+          const uint32_t one = ((unsigned)i < 8u) ? (0x3F80u << ((i & 1) * 16)) : 0u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q] |= ((i >> 1) == q) ? one : 0u;
+        }
+        bf16x8 oh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { oh[2 * q] = (short)(w[q] & 0xffff); oh[2 * q + 1] = (short)(w[q] >> 16); }
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf, oh, acc[mt][0], 0, 0, 0);
       }
+    }
+    {
+      const int col = wave * 16 + l4 * 4;
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + ch * 192 + col);
+      const float sc = ((wave & 3) < 2) ? 0.17677669529663687f : 1.0f;   // q pre-scaled by 32^-0.5
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+            pack_bf16x4((acc[mt][0][0] + b4.x) * sc, (acc[mt][0][1] + b4.y) * sc, (acc[mt][0][2] + b4.z) * sc, (acc[mt][0][3] + b4.w) * sc);
+    }
+    if (wave < 4) {                         // V tile (plain order: 4 consecutive ROWS of dim l15) -> vtc[head][d][row .. row+3]
+      const int hh = wave >> 1, d = (wave & 1) * 16 + l15;
+      const float bv = bias[ch * 192 + 128 + wave * 16 + l15];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<uint2*>(vtc + (hh * 32 + d) * VS + mt * 16 + l4 * 4) =
+            pack_bf16x4(acc[mt][1][0] + bv, acc[mt][1][1] + bv, acc[mt][1][2] + bv, acc[mt][1][3] + bv);
     }
   };
 
@@ -235,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       if (ch == 0) e_load_b(Bqkv, w.w_r2r, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
       else e_load_b(Bw, w.w_r2ro, C, 0, 0, wave, l15, l4, EWaves<NW>());
       __syncthreads(); DTS();
-      small_attention(ch, false, st + 0);
+      self_attention(ch, false, st + 0);
       __syncthreads(); DTS();
     }
     {
@@ -253,11 +290,11 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     layer_norm(par + P_LN + 256, par + P_LN + 384);
     __syncthreads(); DTS();
     for (int ch = 0; ch < 2; ++ch) {
-      qkv_chunk(ch, par + P_BM2M, w.mp);
+      qkv_chunk(ch, par + P_BM2M, w.mpx);
       if (ch == 0) e_load_b(Bqkv, w.w_m2m, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
       else e_load_b(Bw, w.w_m2mo, C, 0, 0, wave, l15, l4, EWaves<NW>());
       __syncthreads(); DTS();
-      small_attention(ch, true, st + 2);
+      self_attention(ch, true, st + 2);
       __syncthreads(); DTS();
     }
     {

@@ -90,7 +90,7 @@ struct RiftCtx {
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
   float* dec_par = nullptr;              // [4][RIFT_DEC_NPAR] packed LayerNorm parameters / biases of the fused decoder kernel
-  int* dec_idx = nullptr; bool dec_fused = true;
+  bool dec_fused = true;
   double* clip_part = nullptr;
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
   bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
@@ -986,11 +986,13 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       w.w_r2ro = bf(p + ".r2r_attn.out_proj"); w.w_m2mo = bf(p + ".m2m_attn.out_proj");
       w.w_cq = bf(p + ".cross_attn.q"); w.w_co = bf(p + ".cross_attn.out_proj");
       w.w_f1 = bf(p + ".ffn.0"); w.w_f2 = bf(p + ".ffn.3");
-      // per-layer operands produced by the generic GEMM: m_pos.Wqk^T (12x384) and the K|V projections of the encoder tokens
-      bool fill_mp;
+      // m_pos . Wqk^T (12 x 384, weights only: cached) and its hi/lo bf16 fragment image for the kernel's extra MFMA k-step
+      bool fill_mp, fill_mpx;
       float* MPl = wconst_get(c, p + ".mp", (size_t)M * 384, f.fp32, &fill_mp);
       if (fill_mp) gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MPl, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
-      w.mp = MPl; w.kv = KVall ? KVall + i * 256 : nullptr;
+      unsigned short* MPX = (unsigned short*)wconst_get(c, p + ".mpx", (size_t)2 * 8 * 512 / 2, f.fp32, &fill_mpx);
+      if (fill_mpx) launch(c, "pack_mpx_kernel", pack_mpx_kernel, dim3(cdiv(2 * 8 * 512, 256)), dim3(256), 0, (const float*)MPl, (const int*)c->enc_idx, MPX);
+      w.mpx = MPX; w.kv = KVall ? KVall + i * 256 : nullptr;
     }
     if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
     // algorithmic FLOPs of the 4 layers on the padded (R x 12) query block, as the reference computes them
@@ -1178,7 +1180,6 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->ego_w) (void)hipFree(c->ego_w);
   if (c->ego_b) (void)hipFree(c->ego_b);
   if (c->enc_idx) (void)hipFree(c->enc_idx);
-  if (c->dec_idx) (void)hipFree(c->dec_idx);
   if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
   if (c->clip_part) (void)hipFree(c->clip_part);
   if (c->dec_par) (void)hipFree(c->dec_par);
@@ -1297,15 +1298,7 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     }
     TRY(pack_stacked_rows(c, PD + ".kv_all", wn, bn, 128, 256));
   }
-  {  // chunk-ordered in_proj images of the two decoder self-attentions: per 2-head chunk (q|k|v of head a, q|k|v of head b)
-    int idx[384];
-    for (int ch = 0; ch < 2; ++ch)
-      for (int hh = 0; hh < 2; ++hh)
-        for (int part = 0; part < 3; ++part)
-          for (int d = 0; d < 32; ++d) idx[ch * 192 + hh * 96 + part * 32 + d] = part * 128 + (2 * ch + hh) * 32 + d;
-    if (!c->dec_idx) HIPCHK(c, hipMalloc((void**)&c->dec_idx, sizeof(idx)));
-    HIPCHK(c, hipMemcpyAsync(c->dec_idx, idx, sizeof(idx), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+  {  // chunked in_proj images of the two decoder self-attentions, in the encoder kernel's order (q_a k_a q_b k_b v_a v_b per chunk)
     const char* nm[2] = {".r2r_attn", ".m2m_attn"};
     for (int i = 0; i < 4; ++i)
       for (int k = 0; k < 2; ++k) {
@@ -1313,7 +1306,7 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
         const float* w = fptr(c, p + ".in_proj_weight"); const float* bsrc = fptr(c, p + ".in_proj_bias");
         if (!w || !bsrc) return RIFT_ERR_ARG;
         if (!c->dec_wqkv[i][k]) { HIPCHK(c, hipMalloc((void**)&c->dec_wqkv[i][k], 384 * 128 * 2)); HIPCHK(c, hipMalloc((void**)&c->dec_bqkv[i][k], 384 * 4)); }
-        hipLaunchKernelGGL(pack_rows_indexed_kernel, dim3(cdiv(384 * 128, 256)), dim3(256), 0, c->stream, w, bsrc, (const int*)c->dec_idx,
+        hipLaunchKernelGGL(pack_rows_indexed_kernel, dim3(cdiv(384 * 128, 256)), dim3(256), 0, c->stream, w, bsrc, (const int*)c->enc_idx,
                            384, 128, c->dec_wqkv[i][k], c->dec_bqkv[i][k]);
       }
   }

@@ -455,13 +455,17 @@ def test_fused_decoder_matches_layerwise_path(ffi, monkeypatch, case):
         monkeypatch.setenv("RIFT_DEC_UNFUSED", env)
         eng = ffi.Engine("cuda:0")
         eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        eng.prof_enable(True)
         eng.forward(data, fp32=fp32)
+        # the fused kernel rounds to bf16 at the same points as the layer-wise MFMA path (most rows agree bit for bit), so
+        # "it ran" is checked on the launch record, not on a difference in the output
+        assert ("dec_fused_kernel" in eng.prof_report()) == (name == "fused")
+        eng.prof_enable(False)
         outs[name] = eng.tap("dec3").view(rv.shape[0], rv.shape[1], 12, 128).cpu().clone()[rv]
         eng.close()
     scale = max(1.0, float(outs["fp32"].abs().max()))
     assert err(outs["fused"], outs["fp32"]) < 4e-2 * scale
     assert err(outs["fused"], outs["layerwise"]) < 4e-2 * scale
-    assert not torch.equal(outs["fused"], outs["layerwise"])
 
 
 def test_candidate_rollout_and_ref_line_info(ffi):
