@@ -25,7 +25,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sources()
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -amdgpu-spill-sgpr-to-vgpr=0: the decoder kernel sits at the 256-VGPR limit; with SGPR spills parked in VGPR lanes (the
+    # default) AND VGPR spills in the same kernel, ROCm 7.2's backend produced wrong results whenever the SGPR spill count
+    # rose (reproduced three times; identical source is correct with SGPR spills sent to scratch).  Cost: < 2 % on that kernel.
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0",
            os.path.join(CSRC, "engine.hip"), "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

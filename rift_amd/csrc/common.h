@@ -94,7 +94,29 @@ __device__ __forceinline__ float dpp_f(float v) {
 __device__ __forceinline__ float sum4(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); return v; }
 __device__ __forceinline__ float sum8(float v) { v = sum4(v); v += dpp_f<0x141>(v); return v; }
 __device__ __forceinline__ float sum16(float v) { v = sum8(v); v += dpp_f<0x140>(v); return v; }
-__device__ __forceinline__ float sum32(float v) { v = sum16(v); v += __shfl_xor(v, 16, 64); return v; }
+// Across the four 16-lane rows gfx950 has half-exchange instructions: v_permlane16_swap (odd rows of vdst <-> even rows of src)
+// and v_permlane32_swap (upper half of vdst <-> lower half of src).  With vdst = src = v the two results hold v[lane] and
+// v[lane ^ 16] (resp. v[lane ^ 32]) in some order in every lane, so a commutative combine of them is the xor exchange -- one
+// VALU-rate instruction instead of a ds_bpermute round trip.
+__device__ __forceinline__ float xadd16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xadd32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xmax16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xmax32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) { return xadd32(xadd16(v)); }   // over the 4 lanes {l, l^16, l^32, l^48}
+__device__ __forceinline__ float rows_max(float v) { return xmax32(xmax16(v)); }
+__device__ __forceinline__ float sum32(float v) { v = sum16(v); return xadd16(v); }
 // sum over groups of LPR consecutive lanes (LPR = 8, 16, 32, 64), result in every lane of the group
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
@@ -102,7 +124,7 @@ __device__ __forceinline__ float group_sum(float v) {
   if (LPR == 8) return sum8(v);
   if (LPR == 16) return sum16(v);
   v = sum32(v);
-  if (LPR == 64) v += __shfl_xor(v, 32, 64);
+  if (LPR == 64) v = xadd32(v);
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }

@@ -179,14 +179,12 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         if (masked) s[i] = -INFINITY;
       }
       float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = rows_max(m);
       float ev[4];
       float lsum = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { ev[i] = __expf(s[i] - m); lsum += ev[i]; }
-      lsum += __shfl_xor(lsum, 16, 64);
-      lsum += __shfl_xor(lsum, 32, 64);
+      lsum = rows_sum(lsum);
       if (dp > 0.f) dropout4(ev, p.seed, stream, (uint32_t)((((b * ROWS + row) * 4 + ch * 2 + hh) * 16) + l4 * 4), thr16, dpk);
       const unsigned int p0 = pack_bf16x2(ev[0], ev[1]), p1 = pack_bf16x2(ev[2], ev[3]);
       bf16x8 pf, b0, b1;
@@ -375,8 +373,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
             m = fmaxf(m, s[kt][r]);
           }
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows_max(m);
         float lsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -388,8 +385,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[kt][r] = ev[r];
         }
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = rows_sum(lsum);
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
         for (int pt = 0; pt < NKT / 2; ++pt) {

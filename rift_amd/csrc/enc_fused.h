@@ -226,15 +226,13 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
             m = fmaxf(m, s[kt][r]);
           }
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows_max(m);
         float lsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float e = __expf(s[kt][r] - m); lsum += e; s[kt][r] = e; }
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = rows_sum(lsum);
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
         for (int pt = 0; pt < NKT / 2; ++pt) {

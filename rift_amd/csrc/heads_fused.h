@@ -92,8 +92,8 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {                   // the four l4 groups hold different columns of the same row
       float s = bsum[mt], q = bsq[mt];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      s = rows_sum(s);
+      q = rows_sum(q);
       if (l4 == 0) { wpart[(wave * HD_ROWS + mt * 16 + l15) * 2] = s; wpart[(wave * HD_ROWS + mt * 16 + l15) * 2 + 1] = q; }
     }
     __syncthreads();

@@ -335,8 +335,7 @@ __global__ void mha_mfma_kernel(MhaP p) {
         m = fmaxf(m, s[kt][r]);
       }
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = rows_max(m);
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -351,8 +350,7 @@ __global__ void mha_mfma_kernel(MhaP p) {
         }
         s[kt][r] = w;
       }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
+    lsum = rows_sum(lsum);
     f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
     for (int pt = 0; pt < NKT / 2; ++pt) {

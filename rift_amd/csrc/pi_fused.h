@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void pi_forward_kernel(PiFwdP p) {
     h[mt][0] += b14.x; h[mt][1] += b14.y; h[mt][2] += b14.z; h[mt][3] += b14.w;
     if (gr < p.rows) *reinterpret_cast<float4*>(p.Hpi + (size_t)gr * 128 + col) = make_float4(h[mt][0], h[mt][1], h[mt][2], h[mt][3]);
     float s = (h[mt][0] + h[mt][1]) + (h[mt][2] + h[mt][3]);
-    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    s = rows_sum(s);
     if (l4 == 0) wpart[(wave * PI_ROWS + row) * 2] = s;
   }
   __syncthreads();
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void pi_forward_kernel(PiFwdP p) {
     mean[mt] = s * (1.0f / 128.0f);
     const float d0 = h[mt][0] - mean[mt], d1 = h[mt][1] - mean[mt], d2 = h[mt][2] - mean[mt], d3 = h[mt][3] - mean[mt];
     float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    q = rows_sum(q);
     if (l4 == 0) wpart[(wave * PI_ROWS + row) * 2 + 1] = q;
   }
   __syncthreads();
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void pi_forward_kernel(PiFwdP p) {
     const float rstd = rsqrtf(q * (1.0f / 128.0f) + p.eps);
     float z = fmaxf((h[mt][0] - mean[mt]) * rstd * g4.x + e4.x, 0.f) * w24.x + fmaxf((h[mt][1] - mean[mt]) * rstd * g4.y + e4.y, 0.f) * w24.y +
               fmaxf((h[mt][2] - mean[mt]) * rstd * g4.z + e4.z, 0.f) * w24.z + fmaxf((h[mt][3] - mean[mt]) * rstd * g4.w + e4.w, 0.f) * w24.w;
-    z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
+    z = rows_sum(z);
     if (l4 == 0) zpart[wave * PI_ROWS + row] = z;
   }
   __syncthreads();
