@@ -69,19 +69,49 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t stream, uint3
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// erf-form GELU (nn.GELU default) for the bf16 paths, erf from Abramowitz-Stegun 7.1.25: erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) e^{-z^2},
-// t = 1 / (1 + 0.47047 z), |error| <= 2.5e-5 -- two orders below the bf16 rounding the result gets as an MFMA operand.  12 VALU
-// instructions with hardware v_rcp_f32 / v_exp_f32 (the 7.1.26 form with an IEEE division was 28, and the LDS-resident encoder /
-// NAT kernels are VALU-bound exactly in their GELU epilogues).  0.5 x (1 + sign(x) erf(|x|/sqrt2)) = 0.5 (x + |x| erf(|x|/sqrt2)).
+// erf-form GELU (nn.GELU default) for the bf16 paths: erf(z) = z P(z^2) / Q(z^2) with z clamped to +-3.3 (a (3,3) rational minimax
+// fit, |erf error| <= 2.9e-6, |gelu error| <= 7.2e-6 measured over [-10, 10] -- two orders below the bf16 rounding the result gets
+// as an MFMA operand).  One transcendental (v_rcp_f32); every other step is a mul / fma that packs two elements per instruction
+// (v_pk_mul_f32 / v_pk_fma_f32) in gelu_fast2: 39 cycles per element against 49 for the rcp + exp2 Abramowitz-Stegun 7.1.25 form
+// and 2.6e-5 error (tools/ubench/gelu_rate.hip).  The LDS-resident encoder / NAT kernels are VALU-bound exactly in these epilogues.
 // fp32 mode keeps erff (gelu_erf).
+#define RIFT_GELU_P0 1.12838531f
+#define RIFT_GELU_P1 0.153424003f
+#define RIFT_GELU_P2 0.0432474986f
+#define RIFT_GELU_P3 0.000753648848f
+#define RIFT_GELU_Q1 0.469360935f
+#define RIFT_GELU_Q2 0.0945981576f
+#define RIFT_GELU_Q3 0.00932609519f
 __device__ __forceinline__ float gelu_fast(float x) {
-  const float ax = fabsf(x);
-  const float z = ax * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f, z, 1.0f));
-  const float poly = t * fmaf(t, fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
-  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-  const float erfz = fmaf(-poly, e, 1.0f);
-  return 0.5f * fmaf(ax, erfz, x);
+  const float z = __builtin_amdgcn_fmed3f(x * 0.70710678118654752440f, -3.3f, 3.3f);
+  const float t = z * z;
+  const float pn = fmaf(t, fmaf(t, fmaf(t, RIFT_GELU_P3, RIFT_GELU_P2), RIFT_GELU_P1), RIFT_GELU_P0);
+  const float qd = fmaf(t, fmaf(t, fmaf(t, RIFT_GELU_Q3, RIFT_GELU_Q2), RIFT_GELU_Q1), 1.0f);
+  const float e = z * pn * __builtin_amdgcn_rcpf(qd);
+  const float hx = 0.5f * x;
+  return fmaf(hx, e, hx);
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
+  typedef f32x2_t V;
+  V z = x * 0.70710678118654752440f;
+  z.x = __builtin_amdgcn_fmed3f(z.x, -3.3f, 3.3f); z.y = __builtin_amdgcn_fmed3f(z.y, -3.3f, 3.3f);
+  const V t = z * z;
+  const V pn = __builtin_elementwise_fma(t, __builtin_elementwise_fma(t, __builtin_elementwise_fma(t, (V)RIFT_GELU_P3, (V)RIFT_GELU_P2), (V)RIFT_GELU_P1), (V)RIFT_GELU_P0);
+  const V qd = __builtin_elementwise_fma(t, __builtin_elementwise_fma(t, __builtin_elementwise_fma(t, (V)RIFT_GELU_Q3, (V)RIFT_GELU_Q2), (V)RIFT_GELU_Q1), (V)1.0f);
+  V r; r.x = __builtin_amdgcn_rcpf(qd.x); r.y = __builtin_amdgcn_rcpf(qd.y);
+  const V e = z * pn * r;
+  const V hx = x * 0.5f;
+  return __builtin_elementwise_fma(hx, e, hx);
+}
+
+// bias + GELU + bf16 pack of one MFMA accumulator fragment (4 consecutive output columns), two packed pairs
+__device__ __forceinline__ uint2 gelu4_pack(const f32x4 a, const float4 b) {
+  f32x2_t lo, hi, bl, bh;
+  lo.x = a[0]; lo.y = a[1]; hi.x = a[2]; hi.y = a[3];
+  bl.x = b.x; bl.y = b.y; bh.x = b.z; bh.y = b.w;
+  lo = gelu_fast2(lo + bl); hi = gelu_fast2(hi + bh);
+  return pack_bf16x4(lo.x, lo.y, hi.x, hi.y);
 }
 
 // Cross-lane sums.  __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100 cycles of dependent

@@ -316,8 +316,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
               *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
-                  pack_bf16x4(gelu_fast(acc[mt][j][0] + b4.x), gelu_fast(acc[mt][j][1] + b4.y), gelu_fast(acc[mt][j][2] + b4.z),
-                              gelu_fast(acc[mt][j][3] + b4.w));
+                  gelu4_pack(acc[mt][j], b4);
           }
         }
         if (hc + 1 < 4) e_load_b(Bw, w.w1, C, (hc + 1) * 128, 0, wave, l15, l4, EWaves<NW>());

@@ -446,10 +446,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
             const float4 b4 = *reinterpret_cast<const float4*>(pb + P_B1 + ch * CWK + col);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              float v0 = acc[mt][j][0] + b4.x, v1 = acc[mt][j][1] + b4.y, v2 = acc[mt][j][2] + b4.z, v3 = acc[mt][j][3] + b4.w;
-              if (p.dbg & 4) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-              else { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
-              *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) = pack_bf16x4(v0, v1, v2, v3);
+              *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) = gelu4_pack(acc[mt][j], b4);
             }
           }
         }
