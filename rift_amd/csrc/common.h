@@ -105,6 +105,16 @@ __device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
   return __builtin_elementwise_fma(hx, e, hx);
 }
 
+// fp32 += dot of two packed bf16 pairs (v_dot2c_f32_bf16): a 2-element q.k step without unpacking either operand
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16(unsigned int a, unsigned int b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+// the two bf16 values of a packed dword as fp32
+__device__ __forceinline__ f32x2_t unpack_bf16x2(unsigned int u) {
+  f32x2_t r; r.x = __uint_as_float(u << 16); r.y = __uint_as_float(u & 0xffff0000u); return r;
+}
+
 // bias + GELU + bf16 pack of one MFMA accumulator fragment (4 consecutive output columns), two packed pairs
 __device__ __forceinline__ uint2 gelu4_pack(const f32x4 a, const float4 b) {
   f32x2_t lo, hi, bl, bh;

@@ -334,13 +334,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         const int hh = it % HPC, row = it / HPC;
         const int a0 = (row / L) * L, i = row - a0;
         const int head = ch * HPC + hh;
-        float q[16];
-        {
-          const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(cb + row * CB + hh * 48);
-          const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(cb + row * CB + hh * 48 + 8);
-#pragma unroll
-          for (int d = 0; d < 8; ++d) { q[d] = bf2f((unsigned short)q0[d]); q[8 + d] = bf2f((unsigned short)q1[d]); }
-        }
+        // q.k through v_dot2c_f32_bf16 on the packed operands (no unpacking), P.V as packed fp32 FMAs on unpacked pairs
+        const uint4 q0 = *reinterpret_cast<const uint4*>(cb + row * CB + hh * 48), q1 = *reinterpret_cast<const uint4*>(cb + row * CB + hh * 48 + 8);
         int start = i - KSZ / 2;
         start = start < 0 ? 0 : start;
         start = start > L - KSZ ? L - KSZ : start;
@@ -350,32 +345,33 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         for (int j = 0; j < KSZ; ++j) {
           const int nb = start + j;
           const unsigned short* kp = cb + (a0 + nb) * CB + hh * 48 + 16;
-          const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp), k1 = *reinterpret_cast<const bf16x8*>(kp + 8);
-          float s = 0.f;
-#pragma unroll
-          for (int d = 0; d < 8; ++d) s += q[d] * bf2f((unsigned short)k0[d]) + q[8 + d] * bf2f((unsigned short)k1[d]);
-          s += pb[P_RPB + head * (2 * KSZ - 1) + (nb - i) + KSZ - 1];
-          sc[j] = s;
-          mx = fmaxf(mx, s);
+          const uint4 k0 = *reinterpret_cast<const uint4*>(kp), k1 = *reinterpret_cast<const uint4*>(kp + 8);
+          float s0 = pb[P_RPB + head * (2 * KSZ - 1) + (nb - i) + KSZ - 1], s1 = 0.f;
+          s0 = dot2_bf16(q0.x, k0.x, s0); s1 = dot2_bf16(q0.y, k0.y, s1); s0 = dot2_bf16(q0.z, k0.z, s0); s1 = dot2_bf16(q0.w, k0.w, s1);
+          s0 = dot2_bf16(q1.x, k1.x, s0); s1 = dot2_bf16(q1.y, k1.y, s1); s0 = dot2_bf16(q1.z, k1.z, s0); s1 = dot2_bf16(q1.w, k1.w, s1);
+          sc[j] = s0 + s1;
+          mx = fmaxf(mx, sc[j]);
         }
         float den = 0.f;
 #pragma unroll
         for (int j = 0; j < KSZ; ++j) { sc[j] = __expf(sc[j] - mx); den += sc[j]; }
         const float inv = __builtin_amdgcn_rcpf(den);
-        float o[16];
+        f32x2_t o[8];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] = 0.f;
+        for (int d = 0; d < 8; ++d) o[d] = (f32x2_t)0.f;
 #pragma unroll
         for (int j = 0; j < KSZ; ++j) {
           const unsigned short* vp = cb + (a0 + start + j) * CB + hh * 48 + 32;
-          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vp), v1 = *reinterpret_cast<const bf16x8*>(vp + 8);
-          const float wj = sc[j] * inv;
-#pragma unroll
-          for (int d = 0; d < 8; ++d) { o[d] += wj * bf2f((unsigned short)v0[d]); o[8 + d] += wj * bf2f((unsigned short)v1[d]); }
+          const uint4 v0 = *reinterpret_cast<const uint4*>(vp), v1 = *reinterpret_cast<const uint4*>(vp + 8);
+          const f32x2_t wj = (f32x2_t)(sc[j] * inv);
+          o[0] = __builtin_elementwise_fma(wj, unpack_bf16x2(v0.x), o[0]); o[1] = __builtin_elementwise_fma(wj, unpack_bf16x2(v0.y), o[1]);
+          o[2] = __builtin_elementwise_fma(wj, unpack_bf16x2(v0.z), o[2]); o[3] = __builtin_elementwise_fma(wj, unpack_bf16x2(v0.w), o[3]);
+          o[4] = __builtin_elementwise_fma(wj, unpack_bf16x2(v1.x), o[4]); o[5] = __builtin_elementwise_fma(wj, unpack_bf16x2(v1.y), o[5]);
+          o[6] = __builtin_elementwise_fma(wj, unpack_bf16x2(v1.z), o[6]); o[7] = __builtin_elementwise_fma(wj, unpack_bf16x2(v1.w), o[7]);
         }
         uint4 o0, o1;
-        o0.x = pack_bf16x2(o[0], o[1]); o0.y = pack_bf16x2(o[2], o[3]); o0.z = pack_bf16x2(o[4], o[5]); o0.w = pack_bf16x2(o[6], o[7]);
-        o1.x = pack_bf16x2(o[8], o[9]); o1.y = pack_bf16x2(o[10], o[11]); o1.z = pack_bf16x2(o[12], o[13]); o1.w = pack_bf16x2(o[14], o[15]);
+        o0.x = pack_bf16x2(o[0].x, o[0].y); o0.y = pack_bf16x2(o[1].x, o[1].y); o0.z = pack_bf16x2(o[2].x, o[2].y); o0.w = pack_bf16x2(o[3].x, o[3].y);
+        o1.x = pack_bf16x2(o[4].x, o[4].y); o1.y = pack_bf16x2(o[5].x, o[5].y); o1.z = pack_bf16x2(o[6].x, o[6].y); o1.w = pack_bf16x2(o[7].x, o[7].y);
         *reinterpret_cast<uint4*>(ao + row * XN + head * 16) = o0;
         *reinterpret_cast<uint4*>(ao + row * XN + head * 16 + 8) = o1;
       }
