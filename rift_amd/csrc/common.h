@@ -179,24 +179,39 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// LayerNorm of one 128-wide fp32 row held by 16 lanes (8 columns each, l15 = lane & 15): the two reductions are DPP row sums (no
-// ds_bpermute), the result goes out as 8 bf16 (one 16-byte LDS store).  g / be: the 8 scale / shift values of this lane's columns.
-__device__ __forceinline__ void ln128_row16(const float* __restrict__ src, unsigned short* __restrict__ dst, const float4& g0, const float4& g1,
-                                            const float4& b0, const float4& b1, int l15, bool relu = false) {
-  const float4 v0 = *reinterpret_cast<const float4*>(src + l15 * 8), v1 = *reinterpret_cast<const float4*>(src + l15 * 8 + 4);
-  const float mean = sum16(((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) * (1.0f / 128.0f);
-  const float d0 = v0.x - mean, d1 = v0.y - mean, d2 = v0.z - mean, d3 = v0.w - mean;
-  const float d4 = v1.x - mean, d5 = v1.y - mean, d6 = v1.z - mean, d7 = v1.w - mean;
-  const float rstd = rsqrtf(sum16(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / 128.0f) + 1e-5f);
-  float y[8] = {d0 * rstd * g0.x + b0.x, d1 * rstd * g0.y + b0.y, d2 * rstd * g0.z + b0.z, d3 * rstd * g0.w + b0.w,
-                d4 * rstd * g1.x + b1.x, d5 * rstd * g1.y + b1.y, d6 * rstd * g1.z + b1.z, d7 * rstd * g1.w + b1.w};
+// LayerNorm of one fp32 row of C = 8 * LPR columns held by LPR adjacent lanes (8 columns each, lr = lane % LPR; LPR = 4, 8, 16):
+// the two reductions are DPP row sums (no ds_bpermute), the element-wise math is packed fp32 (two columns per instruction), the
+// result goes out as 8 bf16 in one 16-byte LDS store.  g / be: the 8 scale / shift values of this lane's columns.
+template <int LPR>
+__device__ __forceinline__ void ln_row8(const float* __restrict__ src, unsigned short* __restrict__ dst, const float4& g0, const float4& g1,
+                                        const float4& b0, const float4& b1, int lr, bool relu = false) {
+  typedef f32x2_t V;
+  constexpr float invC = 1.0f / (8 * LPR);
+  const float4 v0 = *reinterpret_cast<const float4*>(src + lr * 8), v1 = *reinterpret_cast<const float4*>(src + lr * 8 + 4);
+  V a, b, c, d;
+  a.x = v0.x; a.y = v0.y; b.x = v0.z; b.y = v0.w; c.x = v1.x; c.y = v1.y; d.x = v1.z; d.y = v1.w;
+  const V s2 = (a + b) + (c + d);
+  const V m2 = (V)(group_sum<LPR>(s2.x + s2.y) * invC);
+  a -= m2; b -= m2; c -= m2; d -= m2;
+  V q2 = a * a;
+  q2 = __builtin_elementwise_fma(b, b, q2); q2 = __builtin_elementwise_fma(c, c, q2); q2 = __builtin_elementwise_fma(d, d, q2);
+  const V r2 = (V)rsqrtf(group_sum<LPR>(q2.x + q2.y) * invC + 1e-5f);
+  V ga, gb, gc, gd, ba, bb, bc, bd;
+  ga.x = g0.x; ga.y = g0.y; gb.x = g0.z; gb.y = g0.w; gc.x = g1.x; gc.y = g1.y; gd.x = g1.z; gd.y = g1.w;
+  ba.x = b0.x; ba.y = b0.y; bb.x = b0.z; bb.y = b0.w; bc.x = b1.x; bc.y = b1.y; bd.x = b1.z; bd.y = b1.w;
+  a = __builtin_elementwise_fma(a * r2, ga, ba); b = __builtin_elementwise_fma(b * r2, gb, bb);
+  c = __builtin_elementwise_fma(c * r2, gc, bc); d = __builtin_elementwise_fma(d * r2, gd, bd);
   if (relu) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = fmaxf(y[i], 0.f);
+    const V z = (V)0.f;
+    a = __builtin_elementwise_max(a, z); b = __builtin_elementwise_max(b, z); c = __builtin_elementwise_max(c, z); d = __builtin_elementwise_max(d, z);
   }
   uint4 o;
-  o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]); o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);
-  *reinterpret_cast<uint4*>(dst + l15 * 8) = o;
+  o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(b.x, b.y); o.z = pack_bf16x2(c.x, c.y); o.w = pack_bf16x2(d.x, d.y);
+  *reinterpret_cast<uint4*>(dst + lr * 8) = o;
+}
+__device__ __forceinline__ void ln128_row16(const float* __restrict__ src, unsigned short* __restrict__ dst, const float4& g0, const float4& g1,
+                                            const float4& b0, const float4& b1, int l15, bool relu = false) {
+  ln_row8<16>(src, dst, g0, g1, b0, b1, l15, relu);
 }
 
 }  // namespace rift

@@ -264,31 +264,14 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
   };
   fetch_tile(row0);
 
-  // LayerNorm xs -> xn (bf16): C/4 lanes per row (16-byte LDS reads), xor-shuffle statistics
+  // LayerNorm xs -> xn (bf16): C/8 lanes per row, 8 columns each (two 16-byte LDS reads, DPP statistics, packed fp32 math)
   auto layer_norm = [&](const float* g, const float* b) {
-    if constexpr (C == 128) {                             // 16 lanes x 8 columns: DPP-only reductions (no ds_bpermute)
-      const float4 g0 = *reinterpret_cast<const float4*>(g + l15 * 8), g1 = *reinterpret_cast<const float4*>(g + l15 * 8 + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(b + l15 * 8), b1 = *reinterpret_cast<const float4*>(b + l15 * 8 + 4);
-#pragma unroll
-      for (int r = wave * 4 + l4; r < ROWS; r += 4 * NW) ln128_row16(xs + r * XS, xn + r * XN, g0, g1, b0, b1, l15);
-      return;
-    }
-    constexpr int LPR = C / 4, RPS = 64 / LPR;            // lanes per row, rows per wave step
+    constexpr int LPR = C / 8, RPS = 64 / LPR;            // lanes per row, rows per wave step
     const int lr = lane % LPR, rsub = lane / LPR;
-    const float4 g4 = *reinterpret_cast<const float4*>(g + lr * 4), b4 = *reinterpret_cast<const float4*>(b + lr * 4);
-#pragma unroll 2
-    for (int r = wave * RPS + rsub; r < ROWS; r += NW * RPS) {
-      const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
-      float s = (v.x + v.y) + (v.z + v.w);
-      s = group_sum<LPR>(s);
-      const float mean = s * (1.0f / C);
-      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-      float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      q = group_sum<LPR>(q);
-      const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
-      *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) =
-          pack_bf16x4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
-    }
+    const float4 g0 = *reinterpret_cast<const float4*>(g + lr * 8), g1 = *reinterpret_cast<const float4*>(g + lr * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + lr * 8), b1 = *reinterpret_cast<const float4*>(b + lr * 8 + 4);
+#pragma unroll
+    for (int r = wave * RPS + rsub; r < ROWS; r += NW * RPS) ln_row8<LPR>(xs + r * XS, xn + r * XN, g0, g1, b0, b1, lr);
   };
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
