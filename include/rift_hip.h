@@ -146,6 +146,10 @@ int rift_forward(RiftCtx* ctx, const RiftFeatureBatch* batch, const RiftOutputs*
  *   rift_loss_finalize : loss = -S/count, grads = -flat/count into the .grad buffers        */
 int rift_loss_backward(RiftCtx* ctx, int kind, const RiftLossIn* in, const RiftLossOut* out, void* stream);
 int rift_loss_finalize(RiftCtx* ctx, const RiftLossOut* out, int accumulate, void* stream);
+/* rift_loss_finalize followed by clip_grad_norm_(the six pi_head .grad tensors, max_norm) in one launch -- the tail of
+ * LightningTrainer.training_step when pi_head is the only trainable module (rift_trainer.py:78-90; gradient_clip_val 0.5,
+ * custom_lightning.yaml:40-41).  total_norm: device float, may be NULL.  Not for PPO (the critic's gradients join the norm). */
+int rift_loss_finalize_clip(RiftCtx* ctx, const RiftLossOut* out, int accumulate, float max_norm, float* total_norm, void* stream);
 
 /* Per-launch HIP-event profiling of the forward/loss kernels on the caller's stream (bench roofline leg).
  * rift_prof_report synchronises and writes a JSON object {label: {count, ms, flops}} into buf. */

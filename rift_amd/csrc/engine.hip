@@ -1432,6 +1432,17 @@ int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void*
   return RIFT_OK;
 }
 
+int rift_loss_finalize_clip(RiftCtx* c, const RiftLossOut* out, int accumulate, float max_norm, float* total_norm, void* stream) {
+  if (!c || !out || !out->stats || !out->flat_grad_sum || !(max_norm > 0.f)) return RIFT_ERR_ARG;
+  if (!out->grad_w1 || !out->grad_b1 || !out->grad_ln_w || !out->grad_ln_b || !out->grad_w2 || !out->grad_b2) return RIFT_ERR_ARG;
+  c->stream = (hipStream_t)stream; c->dry = false;
+  launch(c, "loss_finalize_clip_kernel", loss_finalize_clip_kernel, dim3(1), dim3(1024), 0, (const float*)out->flat_grad_sum,
+         (const double*)out->stats, out->grad_w1, out->grad_b1, out->grad_ln_w, out->grad_ln_b, out->grad_w2, out->grad_b2,
+         out->loss, accumulate, (const double*)out->exchange, out->stats, max_norm, total_norm);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
 int rift_clip_grad_norm(RiftCtx* c, float* const* grads, const int64_t* numels, int n, float max_norm, float* total_norm, void* stream) {
   if (!c || !grads || !numels || n <= 0 || n > 16) return RIFT_ERR_ARG;
   c->err.clear();

@@ -364,6 +364,56 @@ __global__ void loss_finalize_kernel(const float* __restrict__ flat, const doubl
   dst[o] = accumulate ? dst[o] + v : v;
 }
 
+// loss_finalize + clip_grad_norm_ over exactly the six pi_head gradients in ONE single-workgroup launch (the update's tail is a
+// chain of latency-bound launches; these were three).  Same arithmetic: grads = -sum/count (+ existing .grad when accumulating),
+// total = sqrt(sum of squares in f64), grads *= min(1, max_norm / (total + 1e-6)).
+__global__ __launch_bounds__(1024) void loss_finalize_clip_kernel(const float* __restrict__ flat, const double* __restrict__ stats_in,
+                                                                  float* gW1, float* gb1, float* gg, float* gbe, float* gw2, float* gb2,
+                                                                  double* __restrict__ loss_out, int accumulate, const double* __restrict__ xchg,
+                                                                  double* __restrict__ stats_out, float max_norm, float* __restrict__ total_norm) {
+  constexpr int NU = (RIFT_PI_NPARAM + 1023) / 1024;
+  const int tid = threadIdx.x;
+  const double* stats = xchg ? xchg + RIFT_PI_NPARAM : stats_in;
+  const double s0 = stats[0], cnt = stats[1];
+  const float sc = cnt > 0.0 ? (float)(-1.0 / cnt) : 0.f;
+  float v[NU]; float* dp[NU];
+  double ss = 0.0;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = tid + u * 1024;
+    float* dst = nullptr; int o = 0;
+    if (i < 16384) { dst = gW1; o = i; }
+    else if (i < 16384 + 128) { dst = gb1; o = i - 16384; }
+    else if (i < 16384 + 256) { dst = gg; o = i - 16384 - 128; }
+    else if (i < 16384 + 384) { dst = gbe; o = i - 16384 - 256; }
+    else if (i < 16384 + 512) { dst = gw2; o = i - 16384 - 384; }
+    else if (i < RIFT_PI_NPARAM) { dst = gb2; o = 0; }
+    dp[u] = dst ? dst + o : nullptr;
+    v[u] = 0.f;
+    if (dp[u]) {
+      v[u] = (xchg ? (float)xchg[i] : flat[i]) * sc;
+      if (accumulate) v[u] += *dp[u];
+      ss += (double)v[u] * (double)v[u];
+    }
+  }
+  ss = wave_sum_d(ss);
+  __shared__ double ws[16];
+  if ((tid & 63) == 0) ws[tid >> 6] = ss;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += ws[w];                 // every thread: same order, same value
+  const float total = (float)sqrt(tot);
+  const float coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+  if (tid == 0) {
+    if (total_norm) *total_norm = total;
+    if (loss_out) loss_out[0] = cnt > 0.0 ? -s0 / cnt : 0.0;
+    if (xchg && stats_out) { stats_out[0] = s0; stats_out[1] = cnt; }
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) if (dp[u]) *dp[u] = v[u] * coef;
+}
+
 // ---- gradient-norm clipping over a list of tensors (torch.nn.utils.clip_grad_norm_, norm_type 2, as Lightning's
 // gradient_clip_val applies it, custom_lightning.yaml:40-41): total = sqrt(sum_t ||g_t||^2), g *= min(1, max_norm / (total + 1e-6))
 struct ClipList { float* g[16]; long long n[16]; int count; };

@@ -212,8 +212,9 @@ class RLFTTrainer:
         self.li.returns = p(b.get("returns"))
 
     def forward_loss(self, fb: "_ffi.RiftFeatureBatch", extras: Dict[str, torch.Tensor], train: bool = True,
-                     backward: bool = True, flags_extra: int = 0):
-        """forward + objective (+ pi_head backward into .grad).  Returns the device f64 loss scalar."""
+                     backward: bool = True, flags_extra: int = 0, clip_val: Optional[float] = None):
+        """forward + objective (+ pi_head backward into .grad).  Returns the device f64 loss scalar.  With `clip_val` (and no
+        critic, i.e. pi_head is the only trainable module) the gradient-norm clip rides in the finalize launch."""
         eng = self.engine
         self._A = fb.A
         self._outputs(fb.bs, fb.R)
@@ -233,7 +234,10 @@ class RLFTTrainer:
             if self.critic is not None:
                 torch.distributed.all_reduce(self.flat_c, group=self.pg)
         if backward:
-            eng.loss_finalize_raw(self.lo, 0)
+            if clip_val and self.critic is None:
+                eng.loss_finalize_clip_raw(self.lo, 0, float(clip_val), self.grad_norm)
+            else:
+                eng.loss_finalize_raw(self.lo, 0)
             if self.critic is not None:
                 eng.critic_finalize_raw(self.flat_c, self.stats, [p.grad for p in self.critic.values()])
         else:   # validation: loss only, the .grad buffers are left untouched
@@ -253,8 +257,9 @@ class RLFTTrainer:
 
     def training_step(self, fb, extras):
         """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step)."""
-        loss = self.forward_loss(fb, extras, train=True)
-        if self.gradient_clip_val:   # clip_grad_norm_(params, 0.5) on the device, no host round trip
+        fused_clip = bool(self.gradient_clip_val) and self.critic is None
+        loss = self.forward_loss(fb, extras, train=True, clip_val=self.gradient_clip_val if fused_clip else None)
+        if self.gradient_clip_val and not fused_clip:   # PPO: clip_grad_norm_(pi_head + critic params, 0.5) on the device
             if self._clip_list is None:
                 self._clip_list = self.engine.make_clip_list([p.grad for p in self.train_params])
             self.engine.clip_grad_norm_raw(self._clip_list, float(self.gradient_clip_val), self.grad_norm)

@@ -544,3 +544,45 @@ def test_native_clip_grad_norm_matches_torch(ffi, scale):
     for a, p_ in zip(mine, params):
         assert err(a, p_.grad) < 1e-6 * max(1.0, float(p_.grad.abs().max()))
     eng.close()
+
+
+@pytest.mark.parametrize("scale,accumulate,use_xchg", [(1e-3, 0, False), (40.0, 0, True), (40.0, 1, False)])
+def test_fused_finalize_clip_matches_finalize_then_torch_clip(ffi, scale, accumulate, use_xchg):
+    """rift_loss_finalize_clip (one launch) against rift_loss_finalize followed by torch.nn.utils.clip_grad_norm_(pi_head, 0.5):
+    pass-through and clipping cases, .grad accumulation, sums read from the f64 exchange buffer; loss and total norm reported."""
+    eng = ffi.Engine("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    shapes = [(128, 128), (128,), (128,), (128,), (1, 128), (1,)]
+    flat = (torch.randn(ffi.PI_NPARAM, generator=g) * scale).cuda()
+    stats = torch.tensor([-37.25, 4242.0], dtype=torch.float64, device="cuda")
+    xchg = torch.cat([flat.double() * 2.0, stats * 2.0]) if use_xchg else None     # as after a 2-rank all-reduce of equal shards
+    prev = [torch.randn(s, generator=g).cuda() * 0.01 for s in shapes]
+
+    def run(fused):
+        grads = [p.clone() for p in prev]
+        lo = ffi.RiftLossOut()
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+        st = stats.clone()
+        lo.loss, lo.stats, lo.flat_grad_sum = ffi._ptr(loss), ffi._ptr(st), ffi._ptr(flat)
+        lo.exchange = ffi._ptr(xchg)
+        lo.grad_w1, lo.grad_b1, lo.grad_ln_w, lo.grad_ln_b, lo.grad_w2, lo.grad_b2 = (ffi._ptr(t) for t in grads)
+        tn = torch.zeros(1, device="cuda")
+        if fused:
+            eng.loss_finalize_clip_raw(lo, accumulate, 0.5, tn)
+        else:
+            eng.loss_finalize_raw(lo, accumulate)
+            params = [torch.nn.Parameter(torch.zeros_like(t)) for t in grads]
+            for p_, t in zip(params, grads):
+                p_.grad = t
+            tn = torch.nn.utils.clip_grad_norm_(params, 0.5).reshape(1)
+        torch.cuda.synchronize()
+        return grads, float(loss), float(tn), st.cpu()
+
+    g1, l1, n1, s1 = run(True)
+    g0, l0, n0, s0 = run(False)
+    assert l1 == l0 and torch.equal(s1, s0)
+    assert abs(n1 - n0) < 1e-5 * max(1.0, n0)
+    assert (n0 > 0.5) == (scale > 1.0)                      # the two regimes really are clip / pass-through
+    for a, b in zip(g1, g0):
+        assert err(a, b) < 1e-6 * max(1.0, float(b.abs().max()))
+    eng.close()

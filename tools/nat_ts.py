@@ -30,5 +30,10 @@ for b in range(2):
         names += [f"fc1_{ch}", f"fc2_{ch}"]
     names += ["fc2epi"]
 names += ["tail"]
-for n, v in zip(names, d):
-    print(f"{n:8s} {v}")
+per = len(names)
+ntile = len(d) // per
+import numpy as np
+T = np.array(d[:ntile * per]).reshape(ntile, per)
+print("tiles recorded", ntile, "per-tile totals", T.sum(1).tolist())
+for i, n in enumerate(names):
+    print(f"{n:8s} {T[:, i].tolist()}")
