@@ -507,11 +507,11 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
     c->prof_flops = 2.0 * 128.0 * (q.a.rows * 10.0 + q.b.rows * 6.0);
     launch(c, "pe_stats1_kernel", pe_stats1_kernel, dim3(nt), dim3(256), 0, q);
   }
-  launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(64), dim3(256), 0, bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1),
+  launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(256), dim3(256), 0, bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1),
          bn_fin(c, q.b, pr + ".first_mlp.1", 128, q.b.part1, q.b.s1, q.b.t1), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
   c->prof_flops = 2.0 * rows * (128.0 * 8 + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;
   launch(c, "pe_mid_kernel", pe_mid_kernel, dim3(nt), dim3(512), (size_t)PE_MID_LDS, q);
-  launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(128), dim3(256), 0, bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2),
+  launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(512), dim3(256), 0, bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2),
          bn_fin(c, q.b, pr + ".second_mlp.1", 256, q.b.part2, q.b.s2, q.b.t2), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
   c->prof_flops = 2.0 * rows * (256.0 * 256 + 256.0 * 128);
   launch(c, "pe_out_kernel", pe_out_kernel, dim3(nt), dim3(512), (size_t)PE_OUT_LDS, q);

@@ -464,56 +464,65 @@ __global__ __launch_bounds__(512) void pe_out_kernel(PeP2 q) {
   else pe_out_body<120>(q.b, blockIdx.x - q.a.ntiles);
 }
 
-// BatchNorm finalize over tile partials laid out [2][C][nblk] (fp32 tile sums, fp64 accumulation; one wave per channel,
-// coalesced over the tiles).  Same semantics as bn_finalize_kernel.
+// BatchNorm finalize over tile partials laid out [2][C][nblk] (fp32 tile sums, fp64 accumulation).  One 256-thread workgroup per
+// channel, coalesced over the tiles with every load of a thread issued before the first add (the kernel is a pure latency chain:
+// one wave per channel walking 24 dependent rounds cost 11 us per launch).  Same semantics as bn_finalize_kernel.
 struct BnFinP {
   const float* part; const int* cnt; int nblk, C;
   const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches;
   float* scale; float* shift;
 };
 
-__device__ __forceinline__ void bn_finalize_t_body(const float* __restrict__ part, const int* __restrict__ cnt, int nblk, int C,
-                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-                                                   float* running_var, long long* num_batches, int train, int update_running, float eps,
-                                                   float* __restrict__ scale, float* __restrict__ shift, int blk) {
-  const int c = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
+__device__ __forceinline__ void bn_finalize_t_body(const BnFinP& p, int train, int update_running, float eps, int c) {
+  constexpr int NT = 256, MAXU = 8;                      // up to 2048 tiles in one unrolled round; more take further rounds
+  const int tid = threadIdx.x;
   float mean, var;
   if (train) {
     double s = 0.0, q = 0.0;
     long long n = 0;
-    for (int b = lane; b < nblk; b += 64) { s += (double)part[(size_t)c * nblk + b]; q += (double)part[(size_t)(C + c) * nblk + b]; n += cnt[b]; }
-    s = wave_sum_d(s); q = wave_sum_d(q);
+    for (int b0 = 0; b0 < p.nblk; b0 += NT * MAXU) {
+      float sv[MAXU], qv[MAXU]; int nv[MAXU];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-    const double mu = s / (double)n;
-    double v = q / (double)n - mu * mu;
+      for (int u = 0; u < MAXU; ++u) {
+        const int b = b0 + tid + u * NT;
+        const bool ok = b < p.nblk;
+        sv[u] = ok ? p.part[(size_t)c * p.nblk + b] : 0.f;
+        qv[u] = ok ? p.part[(size_t)(p.C + c) * p.nblk + b] : 0.f;
+        nv[u] = ok ? p.cnt[b] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < MAXU; ++u) { s += (double)sv[u]; q += (double)qv[u]; n += nv[u]; }
+    }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    double nd = wave_sum_d((double)n);                    // counts stay far below 2^53: exact
+    __shared__ double red[3][4];
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; red[2][tid >> 6] = nd; }
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    nd = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const double mu = s / nd;
+    double v = q / nd - mu * mu;
     v = v < 0.0 ? 0.0 : v;
     mean = (float)mu; var = (float)v;
-    if (update_running && lane == 0) {
-      const double unb = n > 1 ? v * (double)n / (double)(n - 1) : v;
-      running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean;
-      running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unb;
-      if (c == 0 && num_batches) *num_batches += 1;
+    if (update_running && tid == 0) {
+      const double unb = nd > 1.0 ? v * nd / (nd - 1.0) : v;
+      p.running_mean[c] = 0.9f * p.running_mean[c] + 0.1f * mean;
+      p.running_var[c] = 0.9f * p.running_var[c] + 0.1f * (float)unb;
+      if (c == 0 && p.num_batches) *p.num_batches += 1;
     }
-  } else { mean = running_mean[c]; var = running_var[c]; }
-  if (lane == 0) {
-    const float sc = gamma[c] * rsqrtf(var + eps);
-    scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
+  } else { mean = p.running_mean[c]; var = p.running_var[c]; }
+  if (tid == 0) {
+    const float sc = p.gamma[c] * rsqrtf(var + eps);
+    p.scale[c] = sc;
+    p.shift[c] = p.beta[c] - mean * sc;
   }
 }
 
-// the BatchNorm layers of the two encoders (same position in their pipelines) in one launch; 256 threads = 4 channels per block
-__global__ void bn_finalize_t_kernel(BnFinP a, BnFinP b, int train, int update_running, float eps) {
-  const int na = (a.C + 3) / 4;
-  if ((int)blockIdx.x < na)
-    bn_finalize_t_body(a.part, a.cnt, a.nblk, a.C, a.gamma, a.beta, a.running_mean, a.running_var, a.num_batches, train, update_running, eps,
-                       a.scale, a.shift, blockIdx.x);
-  else
-    bn_finalize_t_body(b.part, b.cnt, b.nblk, b.C, b.gamma, b.beta, b.running_mean, b.running_var, b.num_batches, train, update_running, eps,
-                       b.scale, b.shift, blockIdx.x - na);
+// the BatchNorm layers of the two encoders (same position in their pipelines) in one launch: blocks [0, a.C) are a's channels
+__global__ __launch_bounds__(256) void bn_finalize_t_kernel(BnFinP a, BnFinP b, int train, int update_running, float eps) {
+  if ((int)blockIdx.x < a.C) bn_finalize_t_body(a, train, update_running, eps, blockIdx.x);
+  else bn_finalize_t_body(b, train, update_running, eps, blockIdx.x - a.C);
 }
 
 }  // namespace rift
