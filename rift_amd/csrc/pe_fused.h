@@ -110,20 +110,24 @@ __device__ __forceinline__ int pe_stage_x(const PeP& p, int tile, unsigned short
 template <int MT, int NTW, int NW, class F>
 __device__ __forceinline__ void pe_tile_stats(const f32x4 (&acc)[MT][NTW], const unsigned char* sval, F&& addend, float* part, int C,
                                               int ntiles, int tile, int wave, int l15, int l4) {
-  bool ok[MT];
+  f32x2_t okf[MT];                                   // 1 / 0 row mask, applied with packed multiplies (two columns per instruction)
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) ok[mt] = sval[mt * 16 + l15] == 1;
+  for (int mt = 0; mt < MT; ++mt) okf[mt] = (f32x2_t)(sval[mt * 16 + l15] == 1 ? 1.0f : 0.0f);
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int col = (j * NW + wave) * 16 + l4 * 4;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2_t s01 = (f32x2_t)0.f, s23 = s01, q01 = s01, q23 = s01;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const float4 a = addend(mt * 16 + l15, col);
-      const float v0 = ok[mt] ? acc[mt][j][0] + a.x : 0.f, v1 = ok[mt] ? acc[mt][j][1] + a.y : 0.f;
-      const float v2 = ok[mt] ? acc[mt][j][2] + a.z : 0.f, v3 = ok[mt] ? acc[mt][j][3] + a.w : 0.f;
-      s[0] += v0; q[0] += v0 * v0; s[1] += v1; q[1] += v1 * v1; s[2] += v2; q[2] += v2 * v2; s[3] += v3; q[3] += v3 * v3;
+      f32x2_t v01, v23, a01, a23;
+      v01.x = acc[mt][j][0]; v01.y = acc[mt][j][1]; v23.x = acc[mt][j][2]; v23.y = acc[mt][j][3];
+      a01.x = a.x; a01.y = a.y; a23.x = a.z; a23.y = a.w;
+      v01 = (v01 + a01) * okf[mt]; v23 = (v23 + a23) * okf[mt];
+      s01 += v01; s23 += v23;
+      q01 = __builtin_elementwise_fma(v01, v01, q01); q23 = __builtin_elementwise_fma(v23, v23, q23);
     }
+    float s[4] = {s01.x, s01.y, s23.x, s23.y}, q[4] = {q01.x, q01.y, q23.x, q23.y};
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s[r] = sum16(s[r]); q[r] = sum16(q[r]); }
     if (l15 == 0) {
