@@ -240,6 +240,15 @@ int rift_collate(RiftCtx* ctx, const RiftReplayArena* arena, const int32_t* scen
 int rift_clip_grad_norm(RiftCtx* ctx, float* const* grads /*host array of device pointers*/, const int64_t* numels /*host*/,
                         int n_tensors /*<= 16*/, float max_norm, float* total_norm, void* stream);
 
+/* torch.optim.AdamW's update (amsgrad False, maximize False; configure_optimizers, rift_trainer.py:279-362) for up to 16 tensors of
+ * any parameter groups in one launch, in place on the caller's parameters and on torch's optimizer state (exp_avg, exp_avg_sq and the
+ * float32 device step counter of every tensor, as created by AdamW(fused=True)).  lr / weight_decay: per tensor (host arrays);
+ * step_new: the step count of THIS update (written to the counters).  Host arrays of device pointers to fp32 tensors; the scalars
+ * are doubles because torch forms 1 - beta, the bias corrections and lr / (1 - beta1^t) in double before rounding to fp32. */
+int rift_adamw_step(RiftCtx* ctx, int n_tensors /*<= 16*/, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, float* const* steps, const int64_t* numels /*host*/, const double* lr /*host*/,
+                    const double* weight_decay /*host*/, double step_new, double beta1, double beta2, double eps, void* stream);
+
 /* ---- PPO critic (CriticPPO, rift/gym_carla/utils/net.py:420-431 with CriticBase :355-371; built with dims [256, 256],
  * state_dim 128 by PPOPlutoModel, ppo_pluto.py:37 and planning/config/ppo_pluto.yaml:43-45).  All pointers are device fp32
  * views onto the caller's parameters: net.{0,2,4}.{weight,bias}, state_avg / state_std (128), value_avg / value_std (1). */

@@ -77,7 +77,7 @@ EXPORTS = [
     "rift_loss_finalize", "rift_loss_finalize_clip", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
-    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm",
+    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -114,6 +114,9 @@ def load_library() -> C.CDLL:
     lib.rift_critic_loss_backward.argtypes = [vp, C.POINTER(RiftCritic), vp, vp, C.c_int, vp, vp, vp]
     lib.rift_critic_finalize.argtypes = [vp] * 14
     lib.rift_clip_grad_norm.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), C.c_int, C.c_float, vp, vp]
+    lib.rift_adamw_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
+                                    C.c_double, C.c_double, vp]
     lib.rift_op_linear.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     lib.rift_gae.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp]
     lib.rift_discounted_return.argtypes = [vp, vp, vp, C.c_double, C.c_int, vp, vp]
@@ -297,6 +300,21 @@ class Engine:
                                               _ptr(total_norm) if total_norm is not None else None, _stream())
         if rc != 0:
             self._check(rc, "rift_loss_finalize_clip")
+
+    def make_adam_list(self, params, grads, exp_avg, exp_avg_sq, steps):
+        """Host-side argument arrays of rift_adamw_step for a fixed list of tensors (built once, reused every step)."""
+        n = len(params)
+        arr = lambda ts: (vp * n)(*[t.data_ptr() for t in ts])
+        return {"n": n, "p": arr(params), "g": arr(grads), "m": arr(exp_avg), "v": arr(exp_avg_sq), "s": arr(steps),
+                "numel": (C.c_int64 * n)(*[t.numel() for t in params]), "keep": (params, grads, exp_avg, exp_avg_sq, steps)}
+
+    def adamw_step_raw(self, al, lrs, wds, step_new: float, beta1: float, beta2: float, eps: float):
+        n = al["n"]
+        rc = self.lib.rift_adamw_step(self.ctx, n, al["p"], al["g"], al["m"], al["v"], al["s"], al["numel"],
+                                      (C.c_double * n)(*lrs), (C.c_double * n)(*wds), float(step_new), float(beta1), float(beta2),
+                                      float(eps), _stream())
+        if rc != 0:
+            self._check(rc, "rift_adamw_step")
 
     def prof_enable(self, on: bool):
         self._check(self.lib.rift_prof_enable(self.ctx, 1 if on else 0), "rift_prof_enable")

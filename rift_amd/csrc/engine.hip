@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <set>
+#include <cmath>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -1456,6 +1457,31 @@ int rift_clip_grad_norm(RiftCtx* c, float* const* grads, const int64_t* numels, 
   if (!c->clip_part) HIPCHK(c, hipMalloc((void**)&c->clip_part, 64 * 8));
   launch(c, "clip_norm_partial_kernel", clip_norm_partial_kernel, dim3(nb), dim3(256), 0, L, c->clip_part);
   launch(c, "clip_scale_kernel", clip_scale_kernel, dim3(nb), dim3(256), 0, L, (const double*)c->clip_part, nb, max_norm, total_norm);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_adamw_step(RiftCtx* c, int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    float* const* steps, const int64_t* numels, const double* lr, const double* weight_decay, double step_new,
+                    double beta1, double beta2, double eps, void* stream) {
+  if (!c || n <= 0 || n > 16 || !params || !grads || !exp_avg || !exp_avg_sq || !steps || !numels || !lr || !weight_decay) return RIFT_ERR_ARG;
+  if (!(step_new >= 1.0)) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream; c->dry = false;
+  AdamList L; memset(&L, 0, sizeof(L));
+  const double bc1 = 1.0 - std::pow(beta1, step_new), bc2 = 1.0 - std::pow(beta2, step_new);
+  long long tot = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || !steps[i] || numels[i] <= 0) return RIFT_ERR_ARG;
+    L.p[i] = params[i]; L.g[i] = grads[i]; L.m[i] = exp_avg[i]; L.v[i] = exp_avg_sq[i]; L.step[i] = steps[i];
+    L.n[i] = numels[i]; L.step_size[i] = (float)(lr[i] / bc1); L.decay[i] = (float)(1.0 - lr[i] * weight_decay[i]); L.step_new[i] = (float)step_new;
+    tot += numels[i];
+  }
+  L.count = n; L.beta1 = (float)beta1; L.beta2 = (float)beta2; L.omb1 = (float)(1.0 - beta1); L.omb2 = (float)(1.0 - beta2);
+  L.bc2_sqrt = (float)std::sqrt(bc2); L.eps = (float)eps;
+  const int nb = (int)std::min<long long>(256, (tot + 255) / 256);
+  launch(c, "adamw_kernel", adamw_kernel, dim3(nb), dim3(256), 0, L);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }

@@ -267,32 +267,45 @@ class RLFTTrainer:
         return loss
 
     def _optimizer_step(self):
-        """torch.optim.AdamW's fused update, issued without the Python wrapper stack of Optimizer.step (which costs ~0.5 ms of
-        host time per step for six small tensors).  The first step goes through optimizer.step() so that torch creates the state;
-        afterwards the same torch kernel (torch._fused_adamw_) runs on the optimizer's own state tensors, so optimizer.state_dict()
-        and the scheduler's param_groups['lr'] keep their meaning.  Falls back to optimizer.step() if the entry point is missing."""
+        """AdamW on the optimizer's own state tensors in ONE native launch (rift_adamw_step) for every parameter group.  The first
+        step goes through optimizer.step() so that torch creates the state (exp_avg, exp_avg_sq, device step counters); afterwards
+        the native kernel updates exactly those tensors, so optimizer.state_dict() and the scheduler's param_groups['lr'] keep their
+        meaning.  torch's own route for six small tensors is four launches per step (two groups x (_foreach_add_ + _fused_adamw_))
+        under ~0.5 ms of Optimizer.step Python; it remains the fallback (state layout not as expected, RIFT_TORCH_ADAMW=1)."""
         opt = self.optimizer
         if self._fast_groups is None:
             opt.step()
-            fast = hasattr(torch, "_fused_adamw_") and all(g.get("fused") for g in opt.param_groups)
+            fast = all(g.get("fused") for g in opt.param_groups) and os.environ.get("RIFT_TORCH_ADAMW", "0") != "1"
             groups = []
             for g in opt.param_groups:
                 ps = [p for p in g["params"] if p.grad is not None]
                 st = [opt.state[p] for p in ps]
-                if not ps or any("exp_avg" not in s or not torch.is_tensor(s["step"]) or not s["step"].is_cuda for s in st):
+                if not ps or g.get("amsgrad") or g.get("maximize") or \
+                        any("exp_avg" not in s_ or not torch.is_tensor(s_["step"]) or not s_["step"].is_cuda
+                            or s_["step"].dtype != torch.float32 or p.dtype != torch.float32 for s_, p in zip(st, ps)):
                     fast = False
                     break
-                groups.append((g, ps, [p.grad for p in ps], [s["exp_avg"] for s in st], [s["exp_avg_sq"] for s in st], [s["step"] for s in st]))
+                groups.append((g, ps, st))
+            g0 = opt.param_groups[0]
+            if fast and (any(g["betas"] != g0["betas"] or g["eps"] != g0["eps"] for g in opt.param_groups)
+                         or sum(len(ps) for _, ps, _ in groups) > 16):
+                fast = False
+            if fast:
+                ps = [p for _, gp, _ in groups for p in gp]
+                st = [s_ for _, _, gs in groups for s_ in gs]
+                self._adam_list = self.engine.make_adam_list(ps, [p.grad for p in ps], [s_["exp_avg"] for s_ in st],
+                                                             [s_["exp_avg_sq"] for s_ in st], [s_["step"] for s_ in st])
+                self._adam_owner = [g for g, gp, _ in groups for _ in gp]       # the param group of every listed tensor
+                self._adam_step = int(st[0]["step"].item())                      # one host read, at setup
             self._fast_groups = groups if fast else False
             return
         if self._fast_groups is False:
             opt.step()
             return
-        with torch.no_grad():
-            for g, ps, grads, m, v, steps in self._fast_groups:
-                torch._foreach_add_(steps, 1)
-                torch._fused_adamw_(ps, grads, m, v, [], steps, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1],
-                                    weight_decay=g["weight_decay"], eps=g["eps"], amsgrad=False, maximize=False)
+        self._adam_step += 1
+        g0 = opt.param_groups[0]
+        self.engine.adamw_step_raw(self._adam_list, [g["lr"] for g in self._adam_owner], [g["weight_decay"] for g in self._adam_owner],
+                                   float(self._adam_step), g0["betas"][0], g0["betas"][1], g0["eps"])
 
     def validation_step(self, fb, extras):
         return self.forward_loss(fb, extras, train=False, backward=False)

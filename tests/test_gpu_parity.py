@@ -586,3 +586,50 @@ def test_fused_finalize_clip_matches_finalize_then_torch_clip(ffi, scale, accumu
     for a, b in zip(g1, g0):
         assert err(a, b) < 1e-6 * max(1.0, float(b.abs().max()))
     eng.close()
+
+
+def test_native_adamw_matches_torch_adamw(ffi):
+    """rift_adamw_step (one launch over both parameter groups, on torch's own optimizer state) against torch.optim.AdamW for the
+    pi_head shapes: weight-decay group (1e-5) and no-decay group, lr changing between steps (WarmupCosLR), step counters advanced."""
+    eng = ffi.Engine("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(128, 128), (1, 128), (128,), (128,), (128,), (1,)]
+    init = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    wds = [1e-5, 1e-5, 0.0, 0.0, 0.0, 0.0]
+
+    def make():
+        ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        opt = torch.optim.AdamW([{"params": ps[:2], "weight_decay": 1e-5}, {"params": ps[2:], "weight_decay": 0.0}],
+                                lr=1e-4, fused=True)
+        return ps, opt
+
+    ref_p, ref_opt = make()
+    my_p, my_opt = make()
+    grads = [[torch.randn(s, generator=g).cuda() * (0.01 if k % 2 else 3.0) for s in shapes] for k in range(6)]
+    lrs = [1e-4 / 3, 2e-4 / 3, 1e-4, 9.7e-5, 9.1e-5, 9e-5]
+    al = None
+    for k in range(6):
+        for grp in list(ref_opt.param_groups) + list(my_opt.param_groups):
+            grp["lr"] = lrs[k]
+        for p_, p2, gr in zip(ref_p, my_p, grads[k]):
+            p_.grad = gr.clone(); p2.grad = gr.clone()
+        ref_opt.step()
+        if k == 0:
+            my_opt.step()                       # torch creates the state; the native kernel takes over from step 2
+            st = [my_opt.state[p_] for p_ in my_p]
+            assert all(s_["step"].is_cuda and s_["step"].dtype == torch.float32 for s_ in st)
+        else:
+            st = [my_opt.state[p_] for p_ in my_p]
+            al = eng.make_adam_list(my_p, [p_.grad for p_ in my_p], [s_["exp_avg"] for s_ in st], [s_["exp_avg_sq"] for s_ in st],
+                                    [s_["step"] for s_ in st])
+            with torch.no_grad():
+                eng.adamw_step_raw(al, [lrs[k]] * 6, wds, float(k + 1), 0.9, 0.999, 1e-8)
+    torch.cuda.synchronize()
+    # tolerances: a few fp32 ulps of the largest entry (measured: <= 2 ulps; the two kernels order the same fp32 operations differently)
+    for a, b in zip(my_p, ref_p):
+        sa, sb = my_opt.state[a], ref_opt.state[b]
+        assert err(a.detach(), b.detach()) < 1e-6 * max(1.0, float(b.detach().abs().max()))
+        assert float(sa["step"]) == float(sb["step"]) == 6.0
+        assert err(sa["exp_avg"], sb["exp_avg"]) < 1e-6 * max(1.0, float(sb["exp_avg"].abs().max()))
+        assert err(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 1e-6 * max(1.0, float(sb["exp_avg_sq"].abs().max()))
+    eng.close()
