@@ -140,6 +140,12 @@ int rift_model_load(RiftCtx* ctx, const RiftTensorDesc* params, int n, void* str
 int rift_forward(RiftCtx* ctx, const RiftFeatureBatch* batch, const RiftOutputs* out, int flags,
                  uint32_t seed, void* stream);
 
+/* Optional: `event` (a hipEvent_t, NULL to clear) marks the point after which the trainable parameters (planning_decoder.pi_head.*,
+ * read live by rift_forward) are up to date.  rift_forward then waits for it on ITS stream right before the first kernel that reads
+ * pi_head, so a host may run the previous step's exchange + clip + optimizer on a second stream while the frozen trunk of the next
+ * step already executes (only pi_head is trainable: rift_trainer.py:78-90).  The event is re-read at every rift_forward. */
+int rift_set_param_event(RiftCtx* ctx, void* event);
+
 /* Objective + analytic backward into pi_head, using the activations of the last rift_forward.
  * Two phases so that a data-parallel host can all-reduce (flat_grad_sum, stats) in between:
  *   rift_loss_backward : fills stats, flat_grad_sum (and argmax_rm)

@@ -74,7 +74,7 @@ class RiftRolloutIO(C.Structure):
 
 EXPORTS = [
     "rift_ctx_create", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_loss_backward",
-    "rift_loss_finalize", "rift_loss_finalize_clip", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
+    "rift_loss_finalize", "rift_loss_finalize_clip", "rift_set_param_event", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
     "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step",
@@ -108,6 +108,7 @@ def load_library() -> C.CDLL:
     lib.rift_forward.argtypes = [vp, C.POINTER(RiftFeatureBatch), C.POINTER(RiftOutputs), C.c_int, C.c_uint32, vp]
     lib.rift_loss_backward.argtypes = [vp, C.c_int, C.POINTER(RiftLossIn), C.POINTER(RiftLossOut), vp]
     lib.rift_loss_finalize.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, vp]
+    lib.rift_set_param_event.argtypes = [vp, vp]
     lib.rift_loss_finalize_clip.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, C.c_float, vp, vp]
     lib.rift_tap.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), vp]
     lib.rift_critic_forward.argtypes = [vp, C.POINTER(RiftCritic), vp, C.c_int, vp, vp]
@@ -293,6 +294,12 @@ class Engine:
         rc = self.lib.rift_loss_finalize(self.ctx, C.byref(lo), accumulate, _stream())
         if rc != 0:
             self._check(rc, "rift_loss_finalize")
+
+    def set_param_event(self, event: Optional["torch.cuda.Event"]):
+        """rift_set_param_event: forwards wait for `event` (recorded after the optimizer step) right before they read pi_head."""
+        self._param_event = event                                   # keep the handle alive
+        self._check(self.lib.rift_set_param_event(self.ctx, C.c_void_p(event.cuda_event) if event is not None else None),
+                    "rift_set_param_event")
 
     def loss_finalize_clip_raw(self, lo: RiftLossOut, accumulate: int, max_norm: float, total_norm: Optional[torch.Tensor]):
         """rift_loss_finalize + clip_grad_norm_ over the six pi_head gradients, one launch."""

@@ -90,6 +90,7 @@ struct RiftCtx {
   int* enc_idx = nullptr; bool enc_fused = true;
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
+  hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   float* dec_par = nullptr;              // [4][RIFT_DEC_NPAR] packed LayerNorm parameters / biases of the fused decoder kernel
   bool dec_fused = true;
   double* clip_part = nullptr;
@@ -1085,6 +1086,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* QF = A_alloc<float>(c, (size_t)nQ * 128);
   float* Hpi = A_alloc<float>(c, (size_t)nQ * 128);
   float* prob = out->probability ? out->probability : A_alloc<float>(c, nQ);
+  // Everything above reads frozen, load-time-packed weights only; pi_head.* is read LIVE from here on.  A host that updates pi_head on
+  // another stream (all-reduce + clip + AdamW of the previous step) hands over the event that marks the update's end.
+  if (c->param_event && !c->dry) HIPCHK(c, hipStreamWaitEvent(c->stream, c->param_event, 0));
   if (!f.fp32 && c->pi_fused) {
     // cat_x_proj (bf16) -> pi_head first Linear (exact fp32, live parameters) -> LayerNorm -> ReLU -> Linear -> masked logits: one launch
     PiFwdP q; memset(&q, 0, sizeof(q));
@@ -1370,6 +1374,9 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     c->arena_cap = cap;
   }
   c->dry = false; c->arena_off = 0; c->taps.clear();
+  // diagnostic: RIFT_POISON_ARENA=<byte> fills the scratch arena before every forward (0xFF = NaN pattern), so that a kernel reading
+  // scratch it never wrote shows up as NaN / as run-to-run differences instead of depending on what the memory held before
+  { const char* pe = getenv("RIFT_POISON_ARENA"); if (pe && c->arena) HIPCHK(c, hipMemsetAsync(c->arena, (int)strtol(pe, nullptr, 0) & 0xff, c->arena_cap, c->stream)); }
   rc = forward_impl(c, B, out, flags, seed);
   if (rc != RIFT_OK) return rc;
   if (!c->err.empty()) return RIFT_ERR_ARG;
@@ -1430,6 +1437,12 @@ int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void*
          (const double*)out->stats, out->grad_w1, out->grad_b1, out->grad_ln_w, out->grad_ln_b, out->grad_w2, out->grad_b2,
          out->loss, accumulate, (const double*)out->exchange, out->stats);
   HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_set_param_event(RiftCtx* c, void* event) {
+  if (!c) return RIFT_ERR_ARG;
+  c->param_event = (hipEvent_t)event;
   return RIFT_OK;
 }
 

@@ -315,7 +315,8 @@ __device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
     p_zero(acc);
     p_mma<MT, 4, 2>(acc, fl, PE_FS, 0, Wa, l15, l4);
     p_mma<MT, 4, 2>(acc, fl, PE_FS, 128, Wb, l15, l4);
-    auto addend = [&](int row, int c) { return *reinterpret_cast<const float4*>(gpl + (GPT == 1 ? 0 : row / NPTS) * 256 + c); };
+    // rows 120..127 of the MFMA tile belong to no polyline: they read polyline 0's term (their statistics weight is zero and their g is never stored)
+    auto addend = [&](int row, int c) { return *reinterpret_cast<const float4*>(gpl + (GPT == 1 || row >= PE_USED ? 0 : row / NPTS) * 256 + c); };
     if (p.do_stats) pe_tile_stats<MT, 2, NW>(acc, sval, addend, p.part2, 256, p.ntiles, tile, wave, l15, l4);
     __syncthreads();                       // every wave is done reading f: its tile becomes the fp16 staging area of g
 #pragma unroll
@@ -324,7 +325,7 @@ __device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
-        const float4 a = addend(row < PE_USED ? row : 0, col);
+        const float4 a = addend(row, col);
         const __half2 lo = __floats2half2_rn(acc[mt][j][0] + a.x, acc[mt][j][1] + a.y), hi = __floats2half2_rn(acc[mt][j][2] + a.z, acc[mt][j][3] + a.w);
         uint2 u;
         u.x = *reinterpret_cast<const unsigned int*>(&lo); u.y = *reinterpret_cast<const unsigned int*>(&hi);

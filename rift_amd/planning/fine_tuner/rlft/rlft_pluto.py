@@ -246,11 +246,13 @@ class RLFTPluto(CBVBasePolicy):
             return trainer.training_step(fb, b) if train else trainer.validation_step(fb, b)
 
         for epoch in range(cfg["epochs"]):
-            tl = [float(run(i, True).item()) for i in batches(train_idx, cfg["train_batch_size"], cfg["shuffle"])]
+            for i in batches(train_idx, cfg["train_batch_size"], cfg["shuffle"]):
+                run(i, True)
+            train_loss = trainer.pop_mean_loss()    # mean of the step losses; also joins the update stream (parameters are final)
             vl = [float(run(i, False).item()) for i in batches(val_idx, cfg["val_batch_size"], False)]
             trainer.on_epoch_end()
-            val_loss = float(np.mean(vl)) if vl else float(np.mean(tl))
-            history.append({"epoch": epoch, "train_loss": float(np.mean(tl)), "val_loss": val_loss,
+            val_loss = float(np.mean(vl)) if vl else train_loss
+            history.append({"epoch": epoch, "train_loss": train_loss, "val_loss": val_loss,
                             "lr": trainer.optimizer.param_groups[0]["lr"]})
             if best is None or val_loss < best:                    # ModelCheckpoint(save_top_k=1, monitor loss/val_loss)
                 if best_path is not None and best_path.exists():

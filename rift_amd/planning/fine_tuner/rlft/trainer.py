@@ -178,6 +178,18 @@ class RLFTTrainer:
         self._fast_groups = None
         self.force_exchange = os.environ.get("RIFT_BENCH_FORCE_PG") == "1"   # run the all-reduce even with one rank (path check)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        # Only pi_head is trainable, so the frozen trunk of step k+1 does not depend on the update of step k: exchange + finalize +
+        # clip + AdamW run on a second stream, and the engine waits for their end right before it reads pi_head (rift_set_param_event).
+        # Hides the all-reduce latency under the next forward (DP) and the latency-bound update tail (any world size).
+        self.overlap_update = (self.critic is None and dev.type == "cuda" and os.environ.get("RIFT_NO_OVERLAP", "0") != "1")
+        self.loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)      # sum of training losses since pop_mean_loss()
+        self.loss_n = 0
+        if self.overlap_update:
+            self._side = torch.cuda.Stream(device=dev)
+            self._ev_loss = torch.cuda.Event()
+            self._ev_param = torch.cuda.Event()
+            self._ev_param.record(torch.cuda.current_stream(dev))            # creates the handle; a passed event is a no-op wait
+            self.engine.set_param_event(self._ev_param)
 
     # ------------------------------------------------------------------------------------
     def _outputs(self, bs, R):
@@ -212,7 +224,7 @@ class RLFTTrainer:
         self.li.returns = p(b.get("returns"))
 
     def forward_loss(self, fb: "_ffi.RiftFeatureBatch", extras: Dict[str, torch.Tensor], train: bool = True,
-                     backward: bool = True, flags_extra: int = 0, clip_val: Optional[float] = None):
+                     backward: bool = True, flags_extra: int = 0, clip_val: Optional[float] = None, defer_update: bool = False):
         """forward + objective (+ pi_head backward into .grad).  Returns the device f64 loss scalar.  With `clip_val` (and no
         critic, i.e. pi_head is the only trainable module) the gradient-norm clip rides in the finalize launch."""
         eng = self.engine
@@ -229,6 +241,13 @@ class RLFTTrainer:
             eng.critic_loss_backward_raw(self.critic_desc, extras["state"], extras["reward_sum"], self.stats, self.flat_c)
         if self.critic is not None and self.xchg is not None:
             self.xchg[_ffi.PI_NPARAM:].copy_(self.stats)   # the value-loss term joined stats after the exchange buffer was filled
+        if defer_update:     # the caller runs exchange / finalize / clip / optimizer (on the update stream)
+            return self.loss
+        self._exchange_and_finalize(backward, clip_val)
+        return self.loss
+
+    def _exchange_and_finalize(self, backward: bool, clip_val: Optional[float]):
+        eng = self.engine
         if self.pg is not None and (self.world > 1 or self.force_exchange):
             dp_all_reduce_exchange(self.xchg, self.pg)
             if self.critic is not None:
@@ -244,7 +263,6 @@ class RLFTTrainer:
             lv = _ffi.RiftLossOut()
             lv.loss, lv.stats, lv.flat_grad_sum, lv.exchange = self.lo.loss, self.lo.stats, self.lo.flat_grad_sum, self.lo.exchange
             eng.loss_finalize_raw(lv, 0)
-        return self.loss
 
     def forward_hidden(self, fb: "_ffi.RiftFeatureBatch", seed: int) -> torch.Tensor:
         """Train-mode forward for the PPO buffer sweeps: returns the `hidden` output (bs, 128) (pluto_model.py:173-176)."""
@@ -256,15 +274,43 @@ class RLFTTrainer:
         return self._hidden[:fb.bs]
 
     def training_step(self, fb, extras):
-        """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step)."""
+        """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step).  Returns the device f64 loss
+        scalar; with overlap_update it is written on the update stream -- read it through pop_mean_loss() / wait_update()."""
         fused_clip = bool(self.gradient_clip_val) and self.critic is None
+        if self.overlap_update:
+            self.forward_loss(fb, extras, train=True, defer_update=True)
+            main = torch.cuda.current_stream()
+            self._ev_loss.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ev_loss)
+                self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
+                self._optimizer_step()
+                self.loss_acc.add_(self.loss)
+                self._ev_param.record(self._side)
+            self.loss_n += 1
+            return self.loss
         loss = self.forward_loss(fb, extras, train=True, clip_val=self.gradient_clip_val if fused_clip else None)
         if self.gradient_clip_val and not fused_clip:   # PPO: clip_grad_norm_(pi_head + critic params, 0.5) on the device
             if self._clip_list is None:
                 self._clip_list = self.engine.make_clip_list([p.grad for p in self.train_params])
             self.engine.clip_grad_norm_raw(self._clip_list, float(self.gradient_clip_val), self.grad_norm)
         self._optimizer_step()
+        self.loss_acc.add_(loss)
+        self.loss_n += 1
         return loss
+
+    def wait_update(self):
+        """Make the current stream wait for the last parameter update (needed before reading loss / parameters / .grad on it)."""
+        if self.overlap_update:
+            torch.cuda.current_stream().wait_event(self._ev_param)
+
+    def pop_mean_loss(self) -> float:
+        """Mean training loss since the last call (one host read per epoch instead of one per step)."""
+        self.wait_update()
+        n, self.loss_n = self.loss_n, 0
+        v = float(self.loss_acc.item()) / max(n, 1)
+        self.loss_acc.zero_()
+        return v
 
     def _optimizer_step(self):
         """AdamW on the optimizer's own state tensors in ONE native launch (rift_adamw_step) for every parameter group.  The first

@@ -69,3 +69,33 @@ def test_degenerate_masks(ffi, train):
     ex = scenes[2]["extras"]
     ex["group_advantage_mask"][1] = False
     _check(ffi, scenes, train)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
+def test_forward_does_not_depend_on_scratch_contents(monkeypatch, train):
+    """RIFT_POISON_ARENA fills the engine's scratch arena before every forward: with a NaN pattern (0xFF), with 0x3F bytes and with
+    zeros the outputs must be bit-identical and finite -- no kernel may read scratch that the same forward did not write (ragged
+    shapes: 12 agents, 8 polygons, 1-3 reference lines, a partial last PointsEncoder tile)."""
+    from rift_amd import _ffi as ffi, synthetic as syn
+    from tests import helpers as H
+    sd = H.weights()
+    scenes = [syn.make_scene(300 + i, num_agents=12, num_polygons=8, r_min=1, r_max=3) for i in range(5)]
+    data = syn.collate_features([s["feature"] for s in scenes])
+    data = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in data.items()}
+    outs = []
+    for byte in ("0xFF", "0x3F", "0x00"):
+        monkeypatch.setenv("RIFT_POISON_ARENA", byte)
+        eng = ffi.Engine("cuda:0")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        for _ in range(2):                                   # second forward: the weights-only products are cached by then
+            out = eng.forward(data, train=train, seed=5, bn_update=False, need_traj=True)
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().clone() for k, v in out.items() if torch.is_tensor(v)})
+        eng.close()
+    rv = data["reference_line"]["valid_mask"].any(-1).cpu()
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k]).all() or k in ("probability",), k
+        for o in outs[1:]:
+            assert torch.equal(outs[0][k], o[k]), k
+    assert torch.isfinite(outs[0]["probability"][rv]).all()

@@ -222,3 +222,36 @@ def test_rollout_side_inference_step():
                                               origin, angle, want["output_ref_free_trajectory"][i].numpy().astype(np.float64), 10)
         assert np.array_equal(orig, w_o)
         assert np.abs(cands - w_c).max() < 1e-3 and np.abs(score - w_s).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_update_on_second_stream_equals_serial_update(tmp_path, monkeypatch):
+    """RLFTTrainer.overlap_update (exchange + finalize + clip + AdamW of step k on a second stream while the frozen trunk of step k+1
+    runs; the engine waits for the update's event before reading pi_head) gives bit-identical parameters, history and checkpoint
+    losses to the serial order (RIFT_NO_OVERLAP=1): same kernels, same seeds, only the stream placement differs."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RIFT_NO_OVERLAP", mode)
+        root = tmp_path / mode
+        cfg = {'num_scenario': 1, 'ROOT_DIR': str(root), 'model_path': 'ckpt', 'device': 'cuda:0',
+               'rlft': {'epochs': 3, 'warmup_epochs': 1, 'train_batch_size': 8, 'val_batch_size': 8, 'lr': 1e-3}}
+        torch.manual_seed(0)                       # before the policy is built: its constructor draws the 1-D parameters
+        pol = CBV_POLICY_LIST["rift_pluto"](cfg, None)
+        with torch.no_grad():
+            for p in pol.pluto_model.parameters():
+                if p.dim() > 1:
+                    p.normal_(0, 0.05)
+        pol.load_model(resume=True)
+        pol.set_mode('train')
+        pol.set_buffer(_filled_buffer(48, with_ref=False))
+        fit = pol.train(1)
+        torch.cuda.synchronize()
+        results[mode] = (fit["history"], {k: v.detach().cpu().clone() for k, v in pol.pluto_model.state_dict().items()
+                                          if k.startswith("planning_decoder.pi_head")})
+    h0, p0 = results["0"]
+    h1, p1 = results["1"]
+    assert [(h["train_loss"], h["val_loss"]) for h in h0] == [(h["train_loss"], h["val_loss"]) for h in h1]
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
