@@ -164,38 +164,6 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
   BFrags<KS1, NTW_C> Bp;       // proj weights
   BFrags<KSC, NTW_C> B2;       // fc2 weights of the current hidden chunk
   load_b(Bq, p.blk[0].wqkv, C, 0, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
-  // all parameter vectors and the activation tile are requested up front (independent loads into registers, one
-  // wait), never as load -> LDS-store pairs: at one wave per SIMD each exposed global round trip costs microseconds
-  {
-    constexpr int NPV = (2 * NPAR + NTH - 1) / NTH;
-    float pv[NPV];
-#pragma unroll
-    for (int u = 0; u < NPV; ++u) {
-      const int i = tid + u * NTH;
-      const NatBlockW& w = p.blk[i >= NPAR ? 1 : 0];
-      const int e = i >= NPAR ? i - NPAR : i;
-      const float* src = e < C ? w.ln1_g + e : e < 2 * C ? w.ln1_b + (e - C) : e < 3 * C ? w.ln2_g + (e - 2 * C)
-                       : e < 4 * C ? w.ln2_b + (e - 3 * C) : e < 7 * C ? w.bqkv + (e - 4 * C) : e < 8 * C ? w.bproj + (e - 7 * C)
-                       : e < 11 * C ? w.b1 + (e - 8 * C) : e < 12 * C ? w.b2 + (e - 11 * C) : w.rpb + (e - 12 * C);
-      pv[u] = (i < 2 * NPAR && e < 12 * C + NRPB) ? *src : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < NPV; ++u) { const int i = tid + u * NTH; if (i < 2 * NPAR) par[i] = pv[u]; }
-  }
-  {
-    constexpr int NP2 = (6 * C + NTH - 1) / NTH;
-    float pv[NP2];
-#pragma unroll
-    for (int u = 0; u < NP2; ++u) {
-      const int i = tid + u * NTH;
-      pv[u] = 0.f;
-      if (i < 2 * C) { if (p.Oc) pv[u] = i < C ? p.fn_g[i] : p.fn_b[i - C]; }
-      else if (i < 6 * C && p.Xnext) pv[u] = i < 4 * C ? p.ds_g[i - 2 * C] : p.ds_b[i - 4 * C];
-    }
-#pragma unroll
-    for (int u = 0; u < NP2; ++u) { const int i = tid + u * NTH; if (i < 6 * C) par2[i] = pv[u]; }
-  }
-
   constexpr bool tokenized = (C == 32);   // level 0 always starts from the agent features (p.F9) through the ConvTokenizer
   // The tile's input is fetched into registers one tile ahead (issued in the middle of the previous tile's second block),
   // so that no tile starts with an exposed HBM round trip.
@@ -226,6 +194,37 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
       }
     }
   };
+  // every global load of the prologue -- the first tile, both layers' parameter vectors, the level-tail vectors -- is issued before
+  // the first LDS store: one exposed round trip per workgroup instead of three (level 0 runs one tile per workgroup, so its prologue
+  // is a quarter of its run time)
+  fetch_tile(row0);
+  {
+    constexpr int NPV = (2 * NPAR + NTH - 1) / NTH;
+    constexpr int NP2 = (6 * C + NTH - 1) / NTH;
+    float pv[NPV], pv2[NP2];
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) {
+      const int i = tid + u * NTH;
+      const NatBlockW& w = p.blk[i >= NPAR ? 1 : 0];
+      const int e = i >= NPAR ? i - NPAR : i;
+      const float* src = e < C ? w.ln1_g + e : e < 2 * C ? w.ln1_b + (e - C) : e < 3 * C ? w.ln2_g + (e - 2 * C)
+                       : e < 4 * C ? w.ln2_b + (e - 3 * C) : e < 7 * C ? w.bqkv + (e - 4 * C) : e < 8 * C ? w.bproj + (e - 7 * C)
+                       : e < 11 * C ? w.b1 + (e - 8 * C) : e < 12 * C ? w.b2 + (e - 11 * C) : w.rpb + (e - 12 * C);
+      pv[u] = (i < 2 * NPAR && e < 12 * C + NRPB) ? *src : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NP2; ++u) {
+      const int i = tid + u * NTH;
+      pv2[u] = 0.f;
+      if (i < 2 * C) { if (p.Oc) pv2[u] = i < C ? p.fn_g[i] : p.fn_b[i - C]; }
+      else if (i < 6 * C && p.Xnext) pv2[u] = i < 4 * C ? p.ds_g[i - 2 * C] : p.ds_b[i - 4 * C];
+    }
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) { const int i = tid + u * NTH; if (i < 2 * NPAR) par[i] = pv[u]; }
+#pragma unroll
+    for (int u = 0; u < NP2; ++u) { const int i = tid + u * NTH; if (i < 6 * C) par2[i] = pv2[u]; }
+  }
+
   auto commit_tile = [&]() {       // registers -> xs (through the ConvTokenizer MFMA step on level 0); ends with a barrier
     if constexpr (tokenized) {
       {
@@ -262,7 +261,6 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
       __syncthreads();
     }
   };
-  fetch_tile(row0);
 
   // LayerNorm xs -> xn (bf16): C/8 lanes per row, 8 columns each (two 16-byte LDS reads, DPP statistics, packed fp32 math)
   auto layer_norm = [&](const float* g, const float* b) {
