@@ -80,8 +80,8 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   unsigned char* smask = reinterpret_cast<unsigned char*>(par + RIFT_DEC_NPAR + RIFT_DEC_NFFB);   // [96] encoder key mask
   unsigned char* qmask = smask + 96;               // [12][8] r2r quirk mask rows
   unsigned char* rz = qmask + 96;                  // [8] padded reference lines of this scene
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
+  const int tid0 = threadIdx.x, wave = tid0 >> 6;
+  int tid = tid0, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;   // re-derived through an opaque zero every layer (see the loop)
   const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
   const size_t qrow0 = (size_t)b * NQ;
   const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
@@ -256,6 +256,12 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   };
 
   for (int li = 0; li < 4; ++li) {
+    {   // the per-lane indices pass through an opaque zero once per layer: otherwise every LDS address of the ~30 phases is hoisted out
+        // of this loop as a loop invariant, and the kernel (already at 256 VGPRs) spills them around the loop
+      int zr;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(zr));
+      tid = tid0 + zr; lane = tid & 63; l15 = lane & 15; l4 = lane >> 4;
+    }
     const DecBlockW& w = p.blk[li];
     const uint32_t st = p.stream + 16 * li;
     const float* bf1 = par + P_BF1 + (li & 1) * RIFT_DEC_NFFB;
