@@ -124,6 +124,14 @@ __device__ __forceinline__ uint2 gelu4_pack(const f32x4 a, const float4 b) {
   return pack_bf16x4(lo.x, lo.y, hi.x, hi.y);
 }
 
+// Workgroup barrier for phases that hand data over through LDS only.  __syncthreads() makes hipcc drain EVERY outstanding memory
+// operation first (s_waitcnt vmcnt(0) lgkmcnt(0)), which ends the flight of the weight / parameter / next-tile loads these kernels
+// issue a phase ahead; here only the LDS counter is drained, so global loads stay in flight across the barrier until their first use.
+// Not for phases that exchange data through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Cross-lane sums.  __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100 cycles of dependent
 // latency per step); within a 16-lane row the same exchange is a DPP modifier on a VALU op (a few cycles):
 // quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror.

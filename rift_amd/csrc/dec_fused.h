@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     qmask[i] = (r >= R) || p.r_kpm[(size_t)((b * M + m) % p.bs) * R + r];
   }
   if (tid < 8) rz[tid] = (tid >= R) || p.r_kpm[(size_t)b * R + tid];
-  __syncthreads();
+  lds_barrier();
 
   auto layer_norm = [&](const float* g, const float* be) {   // xs -> xn (bf16); 16 lanes per row; g/be in LDS
     const float4 g0 = *reinterpret_cast<const float4*>(g + l15 * 8), g1 = *reinterpret_cast<const float4*>(g + l15 * 8 + 4);
@@ -267,17 +267,17 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     const float* bf1 = par + P_BF1 + (li & 1) * RIFT_DEC_NFFB;
     const float* bf2 = par + P_BF2 + (li & 1) * RIFT_DEC_NFFB;
     if (li == 0) par_commit(0);
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     // ================= r2r =================
     layer_norm(par + P_LN + 0, par + P_LN + 128);
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     for (int ch = 0; ch < 2; ++ch) {
       qkv_chunk(ch, par + P_BR2R, nullptr);
       if (ch == 0) e_load_b(Bqkv, w.w_r2r, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
       else e_load_b(Bw, w.w_r2ro, C, 0, 0, wave, l15, l4, EWaves<NW>());
-      __syncthreads(); DTS();
+      lds_barrier(); DTS();
       self_attention(ch, false, st + 0);
-      __syncthreads(); DTS();
+      lds_barrier(); DTS();
     }
     {
       f32x4 acc[MT][NTC];
@@ -289,17 +289,17 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       e_load_b(Bqkv, w.w_m2m, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
       residual_epilogue(acc, par + P_BR2RO, st + 1, false);
     }
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     // ================= m2m =================
     layer_norm(par + P_LN + 256, par + P_LN + 384);
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     for (int ch = 0; ch < 2; ++ch) {
       qkv_chunk(ch, par + P_BM2M, w.mpx);
       if (ch == 0) e_load_b(Bqkv, w.w_m2m, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
       else e_load_b(Bw, w.w_m2mo, C, 0, 0, wave, l15, l4, EWaves<NW>());
-      __syncthreads(); DTS();
+      lds_barrier(); DTS();
       self_attention(ch, true, st + 2);
-      __syncthreads(); DTS();
+      lds_barrier(); DTS();
     }
     {
       f32x4 acc[MT][NTC];
@@ -311,10 +311,10 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       e_load_b(Bw, w.w_cq, C, 0, 0, wave, l15, l4, EWaves<NW>());
       residual_epilogue(acc, par + P_BM2MO, st + 3, true);
     }
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     // ================= cross attention =================
     layer_norm(par + P_LN + 512, par + P_LN + 640);
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     {
       f32x4 acc[MT][NTC];
 #pragma unroll
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       }
     }
     for (int ch = 0; ch < 2; ++ch) {
-      __syncthreads(); DTS();          // previous chunk's reads of kc / vtc (and the q writes) are complete
+      lds_barrier(); DTS();          // previous chunk's reads of kc / vtc (and the q writes) are complete
       // stream K (row-major) and V (transposed) of heads 2ch, 2ch+1 into LDS as bf16
       if (p.KT) {
         const unsigned short* kt = p.KT + ((size_t)b * 4 + li) * 96 * 128 + ch * 64;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
           vtc[(c4 + 2) * VS + key] = f2bf(vq.z); vtc[(c4 + 3) * VS + key] = f2bf(vq.w);
         }
       }
-      __syncthreads(); DTS();          // K / V^T chunk visible to every wave
+      lds_barrier(); DTS();          // K / V^T chunk visible to every wave
       for (int pr = wave; pr < 2 * MT; pr += NW) {           // (head, query tile) pairs
         const int hh = pr / MT, qt = pr - hh * MT;
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + (qt * 16 + l15) * CB + (ch * 2 + hh) * 32 + l4 * 8);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
       }
     }
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     {
       f32x4 acc[MT][NTC];
 #pragma unroll
@@ -429,10 +429,10 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       e_load_b(Bw, w.w_f1, C, 0, 0, wave, l15, l4, EWaves<NW>());
       residual_epilogue(acc, par + P_BCO, st + 5, false);
     }
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     // ================= FFN =================
     layer_norm(par + P_LN + 768, par + P_LN + 896);
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
     if (li + 1 < 4) par_fetch(p.blk[li + 1].par);
     {
       f32x4 acc2[MT][NTC];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
           e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
           e_load_b(B2, w.w_f2, 512, 0, hc * 128, wave, l15, l4, EWaves<NW>());
           if (hc == 0 && li + 1 < 4) par_commit((li + 1) & 1);
-          if (hc > 0) __syncthreads(); DTS();
+          if (hc > 0) lds_barrier(); DTS();
 #pragma unroll
           for (int j = 0; j < NTC; ++j) {
             const int col = (j * NW + wave) * 16 + l4 * 4;
@@ -467,12 +467,12 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
         }
         if (hc + 1 < 4) e_load_b(Bw, w.w_f1, C, (hc + 1) * 128, 0, wave, l15, l4, EWaves<NW>());
         else if (li + 1 < 4) e_load_b(Bqkv, p.blk[li + 1].w_r2r, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
-        __syncthreads(); DTS();
+        lds_barrier(); DTS();
         e_mma<MT, 4, NTC>(acc2, cb, CB, B2, l15, l4);
       }
       residual_epilogue(acc2, bf2, st + 7, false);
     }
-    __syncthreads(); DTS();
+    lds_barrier(); DTS();
   }
   for (int i = tid; i < ROWS * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
