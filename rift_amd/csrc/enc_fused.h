@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
     *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
   }
   for (int i = tid; i < ROWS; i += NTH) smask[i] = (i >= N) || p.kpm[grow0 + i];
-  __syncthreads();
+  lds_barrier();
   TS();
 
   auto layer_norm = [&](const float* g, const float* be) {   // xs -> xn (bf16); 16 lanes per row (DPP reductions only); g/be in LDS
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       dpscale2 = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)b) < w.droppath) ? 0.f : 1.0f / (1.0f - w.droppath);
     }
     par_commit();
-    __syncthreads();
+    lds_barrier();
     // ======== self attention ========
     layer_norm(par + P_LN1G, par + P_LN1B);
-    __syncthreads();
+    lds_barrier();
     TS();
     for (int ch = 0; ch < 2; ++ch) {
       {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
                 pack_bf16x4(acc[mt][NTQ - 1][0] + bias, acc[mt][NTQ - 1][1] + bias, acc[mt][NTQ - 1][2] + bias, acc[mt][NTQ - 1][3] + bias);
         }
       }
-      __syncthreads();
+      lds_barrier();
       TS();
       // ---- MFMA attention: 2 heads x 6 query tiles = 12 (head, tile) pairs, 3 per wave (see mha_mfma_kernel)
       for (int pr = wave; pr < 12; pr += NW) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
         *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
       }
-      __syncthreads();
+      lds_barrier();
       TS();
     }
     // ---- out_proj + residual
@@ -286,12 +286,12 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     TS();
     // ======== MLP ========
     layer_norm(par + P_LN2G, par + P_LN2B);
     if (bi + 1 < 4) par_fetch(p.blk[bi + 1]);
-    __syncthreads();
+    lds_barrier();
     TS();
     {
       f32x4 acc2[MT][NTC];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
             for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
           e_load_b(B2, w.w2, 512, 0, hc * 128, wave, l15, l4, EWaves<NW>());
-          if (hc > 0) __syncthreads();   // previous chunk's fc2 reads of cb are complete
+          if (hc > 0) lds_barrier();   // previous chunk's fc2 reads of cb are complete
 #pragma unroll
           for (int j = 0; j < NTC; ++j) {
             const int col = (j * NW + wave) * 16 + l4 * 4;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         }
         if (hc + 1 < 4) e_load_b(Bw, w.w1, C, (hc + 1) * 128, 0, wave, l15, l4, EWaves<NW>());
         else if (bi + 1 < 4) e_load_b(Bqkv, p.blk[bi + 1].wqkv, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
-        __syncthreads();
+        lds_barrier();
         TS();
         e_mma<MT, 4, NTC>(acc2, cb, CB, B2, l15, l4);
         TS();
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     TS();
   }
   // ---- final LayerNorm (fp32 out) -> global
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
   if (p.KT && p.x0p) {   // the ego-token half of the decoder's cat_x_proj: one row per scene
     EFrags<4, 1> Wx;
     e_load_b(Wx, p.wx0, C, 0, 0, wave, l15, l4, EWaves<NW>());
-    __syncthreads();
+    lds_barrier();
     f32x4 ax[1][1];
     ax[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     e_mma<1, 4, 1>(ax, xn, XN, Wx, l15, l4);
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
     // channel -> transposed stores): exactly the two operand layouts the decoder's MFMA cross attention reads.
     EFrags<4, 2> Wk;
     e_load_b(Wk, p.wkv, C, 0, 0, wave, l15, l4, EWaves<NW>());
-    __syncthreads();
+    lds_barrier();
     static_assert(NW == 8, "the K|V tail deals 16 n-tiles to 8 waves");
     for (int l = 0; l < 4; ++l) {
       f32x4 acc[MT][2];

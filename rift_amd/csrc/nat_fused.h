@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         // ---- ConvTokenizer prologue: xs = conv1d(F9, k=3, pad 1) + b as one K=32 MFMA step over the 3x9 window
 #pragma unroll
         for (int u = 0; u < NFV; ++u) { const int i = tid + u * NTH; xn[(i >> 5) * XN + (i & 31)] = f2bf(fv[u]); }
-        __syncthreads();
+        lds_barrier();
         f32x4 acc[MT][NTW_C];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
             *reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col) =
                 make_float4(acc[mt][j][0] + b4.x, acc[mt][j][1] + b4.y, acc[mt][j][2] + b4.z, acc[mt][j][3] + b4.w);
         }
-        __syncthreads();
+        lds_barrier();
       }
     } else {
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
         if (i < ROWS * (C / 4)) *reinterpret_cast<float4*>(xs + r * XS + c4) = tv[u];
       }
-      __syncthreads();
+      lds_barrier();
     }
   };
 
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
     const float* pb = par + bi * NPAR;
     // ======== attention half ========
     if (!(p.dbg & 1)) layer_norm(pb + P_LN1G, pb + P_LN1B);
-    __syncthreads();
+    lds_barrier();
     NTS();
     for (int ch = 0; ch < NCH; ++ch) {
       // ---- qkv chunk GEMM: cb[80][CWK] = xn[80][C] . Wqkv[ch*CWK .. +CWK][C]^T + b ; q pre-scaled by 16^-0.5
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
                 pack_bf16x4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
         }
       }
-      __syncthreads();
+      lds_barrier();
       NTS();
       // ---- neighbourhood attention of the chunk's heads (VALU, fp32 softmax); one (row, head) per work item
       for (int it = tid; it < ((p.dbg & 2) ? 0 : ROWS * HPC); it += NTH) {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         *reinterpret_cast<uint4*>(ao + row * XN + head * 16) = o0;
         *reinterpret_cast<uint4*>(ao + row * XN + head * 16 + 8) = o1;
       }
-      __syncthreads();
+      lds_barrier();
       NTS();
     }
     // ---- proj GEMM + residual: xs += droppath( ao . Wproj^T + b )
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     NTS();
     // ======== MLP half ========
     if (!(p.dbg & 1)) layer_norm(pb + P_LN2G, pb + P_LN2B);
     if (bi == 1 && tile + (int)gridDim.x < ntiles) fetch_tile((tile + (int)gridDim.x) * ROWS);
-    __syncthreads();
+    lds_barrier();
     NTS();
     {
       f32x4 acc2[MT][NTW_C];
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
             for (int j = 0; j < NTW_CH; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (!(p.dbg & 8)) mma_rows<MT, KS1, NTW_CH>(acc, xn, XN, Bq, l15, l4);
           load_b(B2, w.w2, C3, 0, ch * CWK, NT_C, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());          // fc2 weights of this hidden chunk
-          if (ch > 0) __syncthreads();   // the previous chunk's fc2 reads of cb are complete
+          if (ch > 0) lds_barrier();   // the previous chunk's fc2 reads of cb are complete
 #pragma unroll
           for (int j = 0; j < NTW_CH; ++j) {
             const int nt = j * NW + wave;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         // weights needed after this fc2: next hidden chunk's fc1, or the next block's qkv chunk 0
         if (ch + 1 < NCH) load_b(Bq, w.w1, C, (ch + 1) * CWK, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());
         else load_b(Bq, p.blk[1 - bi].wqkv, C, 0, 0, NT_CH, wave, l15, l4, (p.dbg & 32) != 0, NWaves<NW>());   // next block, or block 0 of the next tile
-        __syncthreads();
+        lds_barrier();
         NTS();
         // ---- fc2 partial: acc2 += cb[80][CWK] . W2[:, ch*CWK..]^T
         if (!(p.dbg & 8)) mma_rows<MT, KSC, NTW_C>(acc2, cb, CB, B2, l15, l4);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     NTS();
   }
   // ---- level output: what the FPN reads (normalised last 3 steps), the next level's input (downsample + LN), and X itself
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
         if (m < RD && t >= 0 && t < L) v = *reinterpret_cast<const float4*>(xs + (a * L + t) * XS + cin);
         *reinterpret_cast<uint2*>(cb + m * DSB + k4) = pack_bf16x4(v.x, v.y, v.z, v.w);
       }
-      __syncthreads();
+      lds_barrier();
       f32x4 acc[MD][NTW2];
 #pragma unroll
       for (int mt = 0; mt < MD; ++mt)
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
           if (m < RD) *reinterpret_cast<float4*>(ds + m * DS + col) = make_float4(acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]);
         }
       }
-      __syncthreads();
+      lds_barrier();
       constexpr int LPR = C2 / 4, RPS = 64 / LPR;
       const int lr = lane % LPR, rsub = lane / LPR;
       const float4 g4 = *reinterpret_cast<const float4*>(par2 + 2 * C + lr * 4), b4 = *reinterpret_cast<const float4*>(par2 + 4 * C + lr * 4);
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
       }
     }
   }
-  __syncthreads();   // xs / cb are re-used by the next tile
+  lds_barrier();   // xs / cb are re-used by the next tile
   }
   NTS();
 #undef NTS
