@@ -7,6 +7,7 @@
 // generic GEMM (one per layer) and streamed into LDS per 2-head chunk.  All GEMMs are bf16 MFMA with swapped
 // operands (row-contiguous epilogues); the two tiny self-attentions are fp32 VALU over LDS.
 #pragma once
+#include <type_traits>
 #include "enc_fused.h"
 
 namespace rift {
@@ -152,54 +153,72 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     }
   };
 
-  // MFMA self-attention over the <= 16 keys of a (group, head) tile.  m2m (over_modes): group = reference line g, queries = keys =
-  // its 12 modes (rows g*12 + i).  r2r: group = mode g, queries = keys = the R <= 8 reference lines (rows i*12 + g), with the quirk
-  // mask row of mode g.  S^T = K . Q^T puts 4 keys of ONE query in each lane (query = lane&15), O^T = V^T . P^T puts 4 output dims
-  // of that query in the lane: per-lane denominators, 8-byte stores.  q|k of head hh at cb[row][hh*64 + {0, 32}] (q pre-scaled),
-  // V^T of head hh at vtc[hh*32 + d][row].
-  auto self_attention = [&](int ch, bool over_modes, uint32_t stream) {
-    const int ngroups = over_modes ? R : M, nk = over_modes ? M : R;
-    for (int pr = wave; pr < ngroups * 2; pr += NW) {
-      const int hh = pr & 1, g = pr >> 1;
-      const bool rowok = l15 < nk;
-      const int row = rowok ? (over_modes ? g * M + l15 : l15 * M + g) : g;      // this lane's query row (and key row as an A operand)
-      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + row * CB + hh * 64 + l4 * 8);
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cb + row * CB + hh * 64 + 32 + l4 * 8);
-      f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      // V^T fragments: keys l4*4 .. +3 of dims l15 (+16); zero beyond the valid keys (stale LDS there)
-      unsigned short vv[2][4];
+  // MFMA self-attention, one 16 x 16 score tile per (group, head).  m2m (over_modes): group = reference line g, queries = keys = its
+  // 12 modes (rows g*12 + i).  r2r: group = the mode PAIR (2g, 2g+1): tile slots 0..7 / 8..15 are the R <= 8 reference lines of the
+  // two modes (rows r*12 + mode), cross-mode scores masked, keys masked by the quirk row of their mode.  S^T = K . Q^T puts 4 keys of
+  // ONE query in each lane (query = lane&15), O^T = V^T . P^T puts 4 output dims of that query in the lane: per-lane denominators,
+  // 8-byte stores.  q|k of head hh at cb[row][hh*64 + {0, 32}] (q pre-scaled), V^T of head hh at vtc[hh*32 + d][row].  Each wave
+  // carries TWO tiles through the (latency-bound) chain at once.
+  auto self_attention = [&](int ch, auto over_modes_t, uint32_t stream) {
+    constexpr bool over_modes = decltype(over_modes_t)::value;
+    const int ntile = (over_modes ? R : M / 2) * 2;
+    const int qslot = over_modes ? l15 : (l15 & 7), qsub = over_modes ? 0 : (l15 >> 3);
+    const bool rowok = over_modes ? (l15 < M) : (qslot < R);
+    constexpr int U = 1;                  // tiles in flight per wave
+    for (int pr0 = wave; pr0 < ntile; pr0 += U * NW) {
+      f32x4 s[U];
+      unsigned short vv[U][2][4];
+      int row[U];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int key = l4 * 4 + i;
-        const bool kok = key < nk;
-        const int krow = kok ? (over_modes ? g * M + key : key * M + g) : 0;
-        const unsigned short a0 = vtc[(hh * 32 + l15) * VS + krow], a1 = vtc[(hh * 32 + 16 + l15) * VS + krow];
-        vv[0][i] = kok ? a0 : (unsigned short)0; vv[1][i] = kok ? a1 : (unsigned short)0;
-        const bool masked = !kok || (!over_modes && qmask[g * 8 + (key & 7)]);
-        if (masked) s[i] = -INFINITY;
+      for (int u = 0; u < U; ++u) {
+        const int pr = pr0 + u * NW;
+        if (pr >= ntile) { row[u] = 0; continue; }
+        const int hh = pr & 1, g = pr >> 1;
+        row[u] = rowok ? (over_modes ? g * M + qslot : qslot * M + 2 * g + qsub) : 0;
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + row[u] * CB + hh * 64 + l4 * 8);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cb + row[u] * CB + hh * 64 + 32 + l4 * 8);
+        s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // V^T fragments: keys l4*4 .. +3 of dims l15 (+16); zero beyond the valid keys (stale LDS there)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = l4 * 4 + i;
+          const int kslot = over_modes ? key : (key & 7), ksub = over_modes ? 0 : (key >> 3);
+          const bool kok = over_modes ? (key < M) : (kslot < R);
+          const int krow = kok ? (over_modes ? g * M + kslot : kslot * M + 2 * g + ksub) : 0;
+          const unsigned short a0 = vtc[(hh * 32 + l15) * VS + krow], a1 = vtc[(hh * 32 + 16 + l15) * VS + krow];
+          vv[u][0][i] = kok ? a0 : (unsigned short)0; vv[u][1][i] = kok ? a1 : (unsigned short)0;
+          const bool masked = !kok || (!over_modes && (ksub != qsub || qmask[(2 * g + ksub) * 8 + kslot]));
+          if (masked) s[u][i] = -INFINITY;
+        }
       }
-      float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-      m = rows_max(m);
-      float ev[4];
-      float lsum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { ev[i] = __expf(s[i] - m); lsum += ev[i]; }
-      lsum = rows_sum(lsum);
-      if (dp > 0.f) dropout4(ev, p.seed, stream, (uint32_t)((((b * ROWS + row) * 4 + ch * 2 + hh) * 16) + l4 * 4), thr16, dpk);
-      const unsigned int p0 = pack_bf16x2(ev[0], ev[1]), p1 = pack_bf16x2(ev[2], ev[3]);
-      bf16x8 pf, b0, b1;
-      pf[0] = (short)(p0 & 0xffff); pf[1] = (short)(p0 >> 16); pf[2] = (short)(p1 & 0xffff); pf[3] = (short)(p1 >> 16);
-      pf[4] = 0; pf[5] = 0; pf[6] = 0; pf[7] = 0;
+      for (int u = 0; u < U; ++u) {
+        const int pr = pr0 + u * NW;
+        if (pr >= ntile) continue;
+        const int hh = pr & 1;
+        float m = fmaxf(fmaxf(s[u][0], s[u][1]), fmaxf(s[u][2], s[u][3]));
+        m = rows_max(m);
+        float ev[4];
+        float lsum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { b0[i] = (short)vv[0][i]; b1[i] = (short)vv[1][i]; b0[4 + i] = 0; b1[4 + i] = 0; }
-      const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const f32x4 o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, pf, z4, 0, 0, 0);
-      const f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, pf, z4, 0, 0, 0);
-      if (rowok) {
-        const float inv = __builtin_amdgcn_rcpf(lsum);
-        unsigned short* op = ao + row * XN + (ch * 2 + hh) * 32 + l4 * 4;
-        *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
-        *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+        for (int i = 0; i < 4; ++i) { ev[i] = __expf(s[u][i] - m); lsum += ev[i]; }
+        lsum = rows_sum(lsum);
+        if (dp > 0.f) dropout4(ev, p.seed, stream, (uint32_t)((((b * ROWS + row[u]) * 4 + ch * 2 + hh) * 16) + l4 * 4), thr16, dpk);
+        const unsigned int p0 = pack_bf16x2(ev[0], ev[1]), p1 = pack_bf16x2(ev[2], ev[3]);
+        bf16x8 pf, b0, b1;
+        pf[0] = (short)(p0 & 0xffff); pf[1] = (short)(p0 >> 16); pf[2] = (short)(p1 & 0xffff); pf[3] = (short)(p1 >> 16);
+        pf[4] = 0; pf[5] = 0; pf[6] = 0; pf[7] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { b0[i] = (short)vv[u][0][i]; b1[i] = (short)vv[u][1][i]; b0[4 + i] = 0; b1[4 + i] = 0; }
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, pf, z4, 0, 0, 0);
+        const f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, pf, z4, 0, 0, 0);
+        if (rowok) {
+          const float inv = __builtin_amdgcn_rcpf(lsum);
+          unsigned short* op = ao + row[u] * XN + (ch * 2 + hh) * 32 + l4 * 4;
+          *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+          *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+        }
       }
     }
   };
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       if (ch == 0) e_load_b(Bqkv, w.w_r2r, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
       else e_load_b(Bw, w.w_r2ro, C, 0, 0, wave, l15, l4, EWaves<NW>());
       lds_barrier(); DTS();
-      self_attention(ch, false, st + 0);
+      self_attention(ch, std::false_type{}, st + 0);
       lds_barrier(); DTS();
     }
     {
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
       if (ch == 0) e_load_b(Bqkv, w.w_m2m, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
       else e_load_b(Bw, w.w_m2mo, C, 0, 0, wave, l15, l4, EWaves<NW>());
       lds_barrier(); DTS();
-      self_attention(ch, true, st + 2);
+      self_attention(ch, std::true_type{}, st + 2);
       lds_barrier(); DTS();
     }
     {
