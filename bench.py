@@ -101,6 +101,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (rank 0's JSON): libraries that print banners to fd 1 (RCCL prints its version block at communicator
+    # creation) are sent to stderr for the whole run; the saved descriptor is restored for the final print.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -226,7 +232,10 @@ def main():
             line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scenes, sd_cpu)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
