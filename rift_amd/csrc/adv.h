@@ -8,9 +8,10 @@
 namespace rift {
 
 // ---------------------------------------------------------------------------
-// Reverse affine scan  x_t = b_t + a_t * x_{t+1},  x_n = 0, in fp64, by ONE wave:
-// lane l owns the contiguous chunk [l*ch, (l+1)*ch); pass 1 composes the chunk map,
-// a shuffle scan (right to left) yields each chunk's incoming x, pass 2 replays the chunk.
+// Reverse affine scan  x_t = b_t + a_t * x_{t+1},  x_n = 0, in fp64, by ONE workgroup of 16 waves:
+// thread i owns the contiguous chunk [i*ch, (i+1)*ch); pass 1 composes the chunk's map x_hi -> x_lo, a DPP/shuffle scan from the
+// right composes the maps inside each wave, the 16 wave composites are chained through LDS, pass 2 replays the chunk from its
+// incoming value.  A 4096-step PPO buffer is 4 steps per thread (the reference walks it as a 4096-iteration Python loop).
 // ---------------------------------------------------------------------------
 struct GaeCoef {    // get_advantages_GAE, ppo_datamodule.py:22-37 (dtype promotion mirrored: fp64 rewards, fp32 rest)
   const double* rewards; const float* undones; const float* values; const float* next_values; const float* unterminated;
@@ -29,22 +30,29 @@ struct ReturnCoef { // compute_return, reinforce_datamodule.py:19-38
   }
 };
 
+#define RIFT_SCAN_THREADS 1024
 template <class Coef, class OutT>
-__global__ __launch_bounds__(64) void affine_scan_reverse_kernel(Coef c, int n, OutT* __restrict__ out) {
-  const int lane = threadIdx.x;
-  const int ch = (n + 63) / 64;
-  const int lo = lane * ch, hi = min(n, lo + ch);
-  // chunk composite: x_lo = B + A * x_hi
+__global__ __launch_bounds__(RIFT_SCAN_THREADS) void affine_scan_reverse_kernel(Coef c, int n, OutT* __restrict__ out) {
+  constexpr int NWV = RIFT_SCAN_THREADS / 64;
+  __shared__ double sA[NWV], sB[NWV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ch = (n + RIFT_SCAN_THREADS - 1) / RIFT_SCAN_THREADS;
+  const int lo = min(n, tid * ch), hi = min(n, lo + ch);
+  // chunk composite: x_lo = B + A * x_hi   (identity for an empty chunk)
   double A = 1.0, B = 0.0;
   for (int t = hi - 1; t >= lo; --t) { double a, b; c.get(t, a, b); B = b + a * B; A = a * A; }
-  // inclusive scan from the right: after it, (A,B) maps x_n(=0) to x at this lane's chunk start
+  // inclusive scan from the right inside the wave: (A,B) then maps x at the wave's right end to x at this lane's chunk start
   for (int o = 1; o < 64; o <<= 1) {
     const double Ar = __shfl_down(A, o, 64), Br = __shfl_down(B, o, 64);
     if (lane + o < 64) { B = B + A * Br; A = A * Ar; }
   }
-  // incoming value for this chunk = x at the start of the next lane's chunk
-  double x = __shfl_down(B, 1, 64);
-  if (lane == 63) x = 0.0;
+  if (lane == 0) { sA[wave] = A; sB[wave] = B; }
+  __syncthreads();
+  double xw = 0.0;                                   // x at this wave's right end: the later waves' maps applied to x_n = 0
+  for (int w = NWV - 1; w > wave; --w) xw = sB[w] + sA[w] * xw;
+  // incoming value of this chunk = x at the start of the next lane's chunk
+  const double An = __shfl_down(A, 1, 64), Bn = __shfl_down(B, 1, 64);
+  double x = lane == 63 ? xw : Bn + An * xw;
   for (int t = hi - 1; t >= lo; --t) { double a, b; c.get(t, a, b); x = b + a * x; out[t] = (OutT)x; }
 }
 
@@ -101,27 +109,35 @@ __device__ __forceinline__ double dense_reward(float dd_abs, float da_abs, float
   return r_collision + r_offroad + r_comfort + r_l_align + r_l_center + r_velocity + r_timestep;
 }
 
-// get_rollout_return (traj_evaluator.py:333-370): one thread per candidate, sequential over Ts,
-// stop after the first colliding step (inclusive).
-__global__ void rollout_return_kernel(const float* __restrict__ delta_dis, const float* __restrict__ delta_angle,
+// get_rollout_return (traj_evaluator.py:333-370): one WAVE per candidate, lane j = time step j (Ts <= 64): the 7-term dense reward
+// and gamma^j of every step in parallel, the first colliding step from a ballot (steps after it are dropped, the colliding step
+// itself counts), one wave sum in fp64.  (One lane per candidate walking 40 steps with a double pow each took 39 us per group.)
+__global__ __launch_bounds__(256) void rollout_return_kernel(const float* __restrict__ delta_dis, const float* __restrict__ delta_angle,
                                       const float* __restrict__ speed, const float* __restrict__ acc,
                                       const float* __restrict__ ang_vel, const float* __restrict__ ang_acc,
                                       const uint8_t* __restrict__ collision, int col_ld,
                                       const uint8_t* __restrict__ off_road, int off_ld, int G, int Ts, double gamma,
                                       double* __restrict__ ret) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= G) return;
   (void)ang_vel;
   double r = 0.0;
-  for (int j = 0; j < Ts; ++j) {
-    const size_t o = (size_t)i * Ts + j;
-    const int col = collision[(size_t)i * col_ld + j] ? 1 : 0;
-    const int off = off_road[(size_t)i * off_ld + j] ? 1 : 0;
-    r += dense_reward(fabsf(delta_dis[o]), fabsf(delta_angle[o]), speed[o], acc[o], ang_acc[o], col, off) *
-         pow(gamma, (double)j);
-    if (col) break;
+  for (int j0 = 0; j0 < Ts; j0 += 64) {                     // one round for Ts <= 64
+    const int j = j0 + lane;
+    const bool live = j < Ts;
+    const size_t o = (size_t)i * Ts + (live ? j : 0);
+    const int col = (live && collision[(size_t)i * col_ld + j]) ? 1 : 0;
+    const int off = (live && off_road[(size_t)i * off_ld + j]) ? 1 : 0;
+    const unsigned long long hit = __ballot(col);
+    const int first = hit ? __ffsll((long long)hit) - 1 : 64;          // lane of the first collision of this round
+    double term = 0.0;
+    if (live && lane <= first)
+      term = dense_reward(fabsf(delta_dis[o]), fabsf(delta_angle[o]), speed[o], acc[o], ang_acc[o], col, off) * pow(gamma, (double)j);
+    r += wave_sum_d(term);
+    if (hit) break;
   }
-  ret[i] = r;
+  if (lane == 0) ret[i] = r;
 }
 
 // ---------------------------------------------------------------------------

@@ -1675,7 +1675,7 @@ int rift_gae(RiftCtx* c, const double* rewards, const float* undones, const floa
   if (!c || n < 0) return RIFT_ERR_ARG;
   if (n == 0) return RIFT_OK;
   GaeCoef k{rewards, undones, values, next_values, unterminated, gamma, lambda_};
-  hipLaunchKernelGGL((affine_scan_reverse_kernel<GaeCoef, float>), dim3(1), dim3(64), 0, (hipStream_t)stream, k, n, advantages);
+  hipLaunchKernelGGL((affine_scan_reverse_kernel<GaeCoef, float>), dim3(1), dim3(RIFT_SCAN_THREADS), 0, (hipStream_t)stream, k, n, advantages);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }
@@ -1685,7 +1685,7 @@ int rift_discounted_return(RiftCtx* c, const double* rewards, const float* dones
   if (!c || n < 0) return RIFT_ERR_ARG;
   if (n == 0) return RIFT_OK;
   ReturnCoef k{rewards, dones, gamma};
-  hipLaunchKernelGGL((affine_scan_reverse_kernel<ReturnCoef, double>), dim3(1), dim3(64), 0, (hipStream_t)stream, k, n, returns);
+  hipLaunchKernelGGL((affine_scan_reverse_kernel<ReturnCoef, double>), dim3(1), dim3(RIFT_SCAN_THREADS), 0, (hipStream_t)stream, k, n, returns);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }
@@ -1709,7 +1709,7 @@ int rift_rollout_return(RiftCtx* c, const float* delta_dis, const float* delta_a
                         const float* ang_vel, const float* ang_acc, const uint8_t* collision, int collision_ld,
                         const uint8_t* off_road, int off_road_ld, int G, int Ts, double gamma, double* returns, void* stream) {
   if (!c || G <= 0 || Ts <= 0) return RIFT_ERR_ARG;
-  hipLaunchKernelGGL(rollout_return_kernel, dim3(cdiv(G, 64)), dim3(64), 0, (hipStream_t)stream, delta_dis, delta_angle, speed,
+  hipLaunchKernelGGL(rollout_return_kernel, dim3(cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, delta_dis, delta_angle, speed,
                      acc, ang_vel, ang_acc, collision, collision_ld, off_road, off_road_ld, G, Ts, gamma, returns);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
