@@ -187,15 +187,17 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// LayerNorm of one fp32 row of C = 8 * LPR columns held by LPR adjacent lanes (8 columns each, lr = lane % LPR; LPR = 4, 8, 16):
+// LayerNorm of one fp32 row of C = 8 * LPR columns held by LPR adjacent lanes (lr = lane % LPR; LPR = 4, 8, 16).  A lane owns columns
+// [4 lr, 4 lr + 4) and [C/2 + 4 lr, C/2 + 4 lr + 4): both 16-byte reads are then contiguous across the lanes of the row (a lane-stride of
+// 32 bytes would hit every LDS bank twice).  g0/b0 and g1/b1 are the scale / shift values of those two column groups:
 // the two reductions are DPP row sums (no ds_bpermute), the element-wise math is packed fp32 (two columns per instruction), the
-// result goes out as 8 bf16 in one 16-byte LDS store.  g / be: the 8 scale / shift values of this lane's columns.
+// result goes out as 2 x 4 bf16.
 template <int LPR>
 __device__ __forceinline__ void ln_row8(const float* __restrict__ src, unsigned short* __restrict__ dst, const float4& g0, const float4& g1,
                                         const float4& b0, const float4& b1, int lr, bool relu = false) {
   typedef f32x2_t V;
   constexpr float invC = 1.0f / (8 * LPR);
-  const float4 v0 = *reinterpret_cast<const float4*>(src + lr * 8), v1 = *reinterpret_cast<const float4*>(src + lr * 8 + 4);
+  const float4 v0 = *reinterpret_cast<const float4*>(src + lr * 4), v1 = *reinterpret_cast<const float4*>(src + 4 * LPR + lr * 4);
   V a, b, c, d;
   a.x = v0.x; a.y = v0.y; b.x = v0.z; b.y = v0.w; c.x = v1.x; c.y = v1.y; d.x = v1.z; d.y = v1.w;
   const V s2 = (a + b) + (c + d);
@@ -213,9 +215,8 @@ __device__ __forceinline__ void ln_row8(const float* __restrict__ src, unsigned 
     const V z = (V)0.f;
     a = __builtin_elementwise_max(a, z); b = __builtin_elementwise_max(b, z); c = __builtin_elementwise_max(c, z); d = __builtin_elementwise_max(d, z);
   }
-  uint4 o;
-  o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(b.x, b.y); o.z = pack_bf16x2(c.x, c.y); o.w = pack_bf16x2(d.x, d.y);
-  *reinterpret_cast<uint4*>(dst + lr * 8) = o;
+  *reinterpret_cast<uint2*>(dst + lr * 4) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(b.x, b.y));
+  *reinterpret_cast<uint2*>(dst + 4 * LPR + lr * 4) = make_uint2(pack_bf16x2(c.x, c.y), pack_bf16x2(d.x, d.y));
 }
 __device__ __forceinline__ void ln128_row16(const float* __restrict__ src, unsigned short* __restrict__ dst, const float4& g0, const float4& g1,
                                             const float4& b0, const float4& b1, int l15, bool relu = false) {

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
   TS();
 
   auto layer_norm = [&](const float* g, const float* be) {   // xs -> xn (bf16); 16 lanes per row (DPP reductions only); g/be in LDS
-    const float4 g0 = *reinterpret_cast<const float4*>(g + l15 * 8), g1 = *reinterpret_cast<const float4*>(g + l15 * 8 + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(be + l15 * 8), b1 = *reinterpret_cast<const float4*>(be + l15 * 8 + 4);
+    const float4 g0 = *reinterpret_cast<const float4*>(g + l15 * 4), g1 = *reinterpret_cast<const float4*>(g + 64 + l15 * 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(be + l15 * 4), b1 = *reinterpret_cast<const float4*>(be + 64 + l15 * 4);
 #pragma unroll
     for (int r = wave * 4 + l4; r < ROWS; r += 4 * NW) ln128_row16(xs + r * XS, xn + r * XN, g0, g1, b0, b1, l15);
   };

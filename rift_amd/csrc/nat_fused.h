@@ -266,8 +266,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
   auto layer_norm = [&](const float* g, const float* b) {
     constexpr int LPR = C / 8, RPS = 64 / LPR;            // lanes per row, rows per wave step
     const int lr = lane % LPR, rsub = lane / LPR;
-    const float4 g0 = *reinterpret_cast<const float4*>(g + lr * 8), g1 = *reinterpret_cast<const float4*>(g + lr * 8 + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(b + lr * 8), b1 = *reinterpret_cast<const float4*>(b + lr * 8 + 4);
+    const float4 g0 = *reinterpret_cast<const float4*>(g + lr * 4), g1 = *reinterpret_cast<const float4*>(g + C / 2 + lr * 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + lr * 4), b1 = *reinterpret_cast<const float4*>(b + C / 2 + lr * 4);
 #pragma unroll
     for (int r = wave * RPS + rsub; r < ROWS; r += NW * RPS) ln_row8<LPR>(xs + r * XS, xn + r * XN, g0, g1, b0, b1, lr);
   };
