@@ -90,6 +90,7 @@ struct RiftCtx {
   int* enc_idx = nullptr; bool enc_fused = true;
   unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
   float* dec_bqkv[4][2] = {};
+  int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   float* dec_par = nullptr;              // [4][RIFT_DEC_NPAR] packed LayerNorm parameters / biases of the fused decoder kernel
   bool dec_fused = true;
@@ -138,9 +139,23 @@ void tap(RiftCtx* c, const char* name, float* p, int64_t numel) {
   if (!c->dry) c->taps[name] = Tap{p, numel};
 }
 
+// diagnostic (RIFT_POISON_LDS=<byte>): LDS keeps its contents between kernels, so a kernel that reads LDS it never wrote sees whatever
+// the previous kernel on that CU left there.  With the switch set every launch is preceded by a kernel that fills all 160 KB of every
+// CU's LDS with the byte (0xFF = NaN pattern): such a read then shows up in the parity tests instead of depending on history.
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned int pattern) {
+  extern __shared__ unsigned int lds_all[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) lds_all[i] = pattern;
+  __syncthreads();
+  if (lds_all[threadIdx.x] != pattern) asm volatile("s_nop 0");      // keep the stores
+}
+
 template <class... KArgs, class... Args>
 void launch(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
   if (c->dry || grid.x == 0 || grid.y == 0) return;
+  if (c->poison_lds >= 0) {
+    const unsigned int b = (unsigned int)c->poison_lds & 0xffu;
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, c->stream, b | (b << 8) | (b << 16) | (b << 24));
+  }
   if (c->prof_on) {
     hipEvent_t e0, e1;
     prof_events(c, &e0, &e1);
@@ -372,6 +387,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR((gemm_rows_kernel<false, 4, 4, 1, 4>));
 #undef SETATTR
 #define SETATTR_N(K, N) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(N)))
+  SETATTR_N(lds_poison_kernel, 160 * 1024);
   SETATTR_N(pe_mid_kernel, PE_MID_LDS);   // these kernels also hold a few hundred bytes of static LDS
   SETATTR_N(pe_out_kernel, PE_OUT_LDS);
   SETATTR_N(fourier_fused_kernel, FO_LDS);
@@ -1164,6 +1180,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_HEADS_UNFUSED"); c->heads_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PI_UNFUSED"); c->pi_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
+  { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_NAT_GRID0"); if (ev && atoi(ev) > 0) c->nat_grid0 = atoi(ev); }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }

@@ -74,8 +74,9 @@ def test_degenerate_masks(ffi, train):
 @pytest.mark.gpu
 @pytest.mark.parametrize("train", [False, True])
 def test_forward_does_not_depend_on_scratch_contents(monkeypatch, train):
-    """RIFT_POISON_ARENA fills the engine's scratch arena before every forward: with a NaN pattern (0xFF), with 0x3F bytes and with
-    zeros the outputs must be bit-identical and finite -- no kernel may read scratch that the same forward did not write (ragged
+    """RIFT_POISON_ARENA fills the engine's scratch arena before every forward and RIFT_POISON_LDS every CU's LDS before every launch:
+    with a NaN pattern (0xFF), with other bytes and with zeros the outputs must be bit-identical and finite -- no kernel may read
+    scratch or LDS that it (or the same forward) did not write (ragged
     shapes: 12 agents, 8 polygons, 1-3 reference lines, a partial last PointsEncoder tile)."""
     from rift_amd import _ffi as ffi, synthetic as syn
     from tests import helpers as H
@@ -84,8 +85,14 @@ def test_forward_does_not_depend_on_scratch_contents(monkeypatch, train):
     data = syn.collate_features([s["feature"] for s in scenes])
     data = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in data.items()}
     outs = []
-    for byte in ("0xFF", "0x3F", "0x00"):
+    # (arena byte, LDS byte): the LDS switch refills every CU's 160 KB of LDS before each launch (LDS keeps the previous kernel's
+    # contents otherwise), so a kernel reading LDS it did not write is caught the same way
+    for byte, lds in (("0xFF", "0xFF"), ("0x3F", "0x00"), ("0x00", None)):
         monkeypatch.setenv("RIFT_POISON_ARENA", byte)
+        if lds is None:
+            monkeypatch.delenv("RIFT_POISON_LDS", raising=False)
+        else:
+            monkeypatch.setenv("RIFT_POISON_LDS", lds)
         eng = ffi.Engine("cuda:0")
         eng.load_state_dict({k: v.clone() for k, v in sd.items()})
         for _ in range(2):                                   # second forward: the weights-only products are cached by then
