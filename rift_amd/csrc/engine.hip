@@ -96,7 +96,7 @@ struct RiftCtx {
   bool dec_fused = true;
   double* clip_part = nullptr;
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
-  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1 << 30; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
+  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1024; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
