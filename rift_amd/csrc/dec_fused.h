@@ -82,7 +82,6 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   unsigned char* qmask = smask + 96;               // [12][8] r2r quirk mask rows
   unsigned char* rz = qmask + 96;                  // [8] padded reference lines of this scene
   const int tid0 = threadIdx.x, wave = tid0 >> 6;
-  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every issue arbitration otherwise (MI355X_MICROARCH.md)
   int tid = tid0, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;   // re-derived through an opaque zero every layer (see the loop)
   const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
   const size_t qrow0 = (size_t)b * NQ;
