@@ -192,6 +192,20 @@ int rift_normalize_advantage(RiftCtx* ctx, float* x, int n, void* stream);
  * adv = (ret - mean) / (std_ddof0 + 1e-5). */
 int rift_group_advantage(RiftCtx* ctx, const double* returns, int n_groups, int G, double* advantage, void* stream);
 
+/* TrajEvaluator.get_collision_matrix (traj_eval/traj_evaluator.py:241-275).  The reference queries an STRtree of the other vehicles'
+ * footprints with the candidate's footprint and NO predicate, i.e. an envelope test: collision[g][j] = 1 iff the axis-aligned bounding
+ * box of center_vertices[g][j] intersects (touching included) that of other_vertices[n][j] for some n.  center_vertices: (G,Tc,4,2) f32
+ * (rift_rollout's `vertices`), other_vertices: (N,Ts,4,2) f64 (get_other_vehicle_rollout, :160-239; N may be 0), collision: (G,Ts) u8. */
+int rift_collision_matrix(RiftCtx* ctx, const float* center_vertices, int G, int Tc, const double* other_vertices, int N, int Ts,
+                          uint8_t* collision, void* stream);
+
+/* TrajEvaluator.get_off_road_matrix, the lookup (traj_evaluator.py:299-318): pixel = round(((p - origin) . R(heading)) / resolution_hw
+ * + offset) in fp64 with round-half-even; off_road = inside the (H,W) raster and off_road_mask[py][px] == 1.  The mask itself (1 =
+ * not drivable; cv2.fillPoly of the HD-map drivable polygons, :284-297) is the caller's.  rollout_center: (n_points,2) f32. */
+int rift_off_road_matrix(RiftCtx* ctx, const float* rollout_center, int n_points, const uint8_t* off_road_mask, int H, int W,
+                         double origin_x, double origin_y, double heading, double res_x, double res_y, double off_x, double off_y,
+                         uint8_t* off_road, void* stream);
+
 /* Discounted dense-reward return of candidate rollouts (traj_evaluator.py:333-370 with
  * gym_carla/reward/reward_model.py:34-50): inputs (G,Ts) f32, flags (G,*) bool with row strides. */
 int rift_rollout_return(RiftCtx* ctx, const float* delta_dis, const float* delta_angle, const float* speed,

@@ -77,7 +77,7 @@ EXPORTS = [
     "rift_loss_finalize", "rift_loss_finalize_clip", "rift_set_param_event", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
-    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step",
+    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -118,6 +118,8 @@ def load_library() -> C.CDLL:
     lib.rift_adamw_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                     C.c_double, C.c_double, vp]
+    lib.rift_collision_matrix.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    lib.rift_off_road_matrix.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int] + [C.c_double] * 7 + [vp, vp]
     lib.rift_op_linear.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     lib.rift_gae.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp]
     lib.rift_discounted_return.argtypes = [vp, vp, vp, C.c_double, C.c_int, vp, vp]
@@ -467,6 +469,34 @@ class Engine:
         self._check(self.lib.rift_rollout(self.ctx, C.byref(io), _stream()), "rift_rollout")
         self._keep_ro = (traj, cs)
         return out
+
+    def collision_matrix(self, center_vertices, other_vertices, Ts: int = 40):
+        """get_collision_matrix: envelope overlap of candidate footprints (G,Tc,4,2) with forecast neighbours (N,Ts,4,2) -> (G,Ts) bool."""
+        dev = self.device
+        cv = _dev(center_vertices, torch.float32, dev)
+        G, Tc = cv.shape[:2]
+        ov = _dev(torch.as_tensor(other_vertices), torch.float64, dev)
+        N = ov.shape[0]
+        assert N == 0 or (ov.shape[1] >= Ts and tuple(ov.shape[2:]) == (4, 2))
+        if N and ov.shape[1] != Ts:
+            ov = ov[:, :Ts].contiguous()
+        out = torch.empty(G, Ts, dtype=torch.uint8, device=dev)
+        self._check(self.lib.rift_collision_matrix(self.ctx, _ptr(cv), G, Tc, _ptr(ov) if N else None, N, Ts, _ptr(out), _stream()),
+                    "rift_collision_matrix")
+        return out.bool()
+
+    def off_road_matrix(self, rollout_center, off_road_mask, origin, heading: float, resolution_hw=(0.5, -0.5), offset=(200.0, 200.0)):
+        """get_off_road_matrix lookup: rollout_center (G,T,2), off_road_mask (H,W) uint8 with 1 = not drivable -> (G,T) bool."""
+        dev = self.device
+        rc = _dev(rollout_center, torch.float32, dev)
+        G, T = rc.shape[:2]
+        m = _dev(torch.as_tensor(off_road_mask), torch.uint8, dev)
+        H, W = m.shape
+        out = torch.empty(G, T, dtype=torch.uint8, device=dev)
+        self._check(self.lib.rift_off_road_matrix(self.ctx, _ptr(rc), G * T, _ptr(m), H, W, float(origin[0]), float(origin[1]), float(heading),
+                                                  float(resolution_hw[0]), float(resolution_hw[1]), float(offset[0]), float(offset[1]),
+                                                  _ptr(out), _stream()), "rift_off_road_matrix")
+        return out.bool()
 
     def make_clip_list(self, grads):
         """Pre-build the (pointer, numel) arrays of a fixed list of .grad tensors for clip_grad_norm_raw."""

@@ -140,6 +140,47 @@ __global__ __launch_bounds__(256) void rollout_return_kernel(const float* __rest
   if (lane == 0) ret[i] = r;
 }
 
+// get_collision_matrix (traj_evaluator.py:241-275): the reference builds an STRtree of the other vehicles' footprints per step and
+// calls tree.query(ego_polygon) WITHOUT a predicate, which returns the geometries whose ENVELOPES intersect the candidate's
+// envelope (closed intervals: touching counts) -- so collision[g][j] = any_n AABB(center[g][j]) overlaps AABB(other[n][j]).
+// One thread per (candidate, step); candidate vertices fp32 (exact in fp64), other vertices fp64 as numpy holds them.
+__global__ __launch_bounds__(256) void collision_matrix_kernel(const float* __restrict__ cv /*(G,Tc,4,2)*/, int G, int Tc,
+                                                               const double* __restrict__ ov /*(N,Ts,4,2)*/, int N, int Ts,
+                                                               uint8_t* __restrict__ out /*(G,Ts)*/) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= G * Ts) return;
+  const int g = i / Ts, j = i - g * Ts;
+  const float* e = cv + ((size_t)g * Tc + j) * 8;
+  double ex0 = e[0], ex1 = e[0], ey0 = e[1], ey1 = e[1];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) { ex0 = fmin(ex0, (double)e[2 * k]); ex1 = fmax(ex1, (double)e[2 * k]); ey0 = fmin(ey0, (double)e[2 * k + 1]); ey1 = fmax(ey1, (double)e[2 * k + 1]); }
+  uint8_t hit = 0;
+  for (int n = 0; n < N; ++n) {
+    const double* o = ov + ((size_t)n * Ts + j) * 8;
+    double ox0 = o[0], ox1 = o[0], oy0 = o[1], oy1 = o[1];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { ox0 = fmin(ox0, o[2 * k]); ox1 = fmax(ox1, o[2 * k]); oy0 = fmin(oy0, o[2 * k + 1]); oy1 = fmax(oy1, o[2 * k + 1]); }
+    if (!(ox0 > ex1 || ox1 < ex0 || oy0 > ey1 || oy1 < ey0)) { hit = 1; break; }
+  }
+  out[i] = hit;
+}
+
+// get_off_road_matrix, lookup part (traj_evaluator.py:299-318): pixel = round(((p - origin) . rot) / resolution_hw + offset) in fp64
+// (np.round = half to even = rint), inside the raster and mask == 1 -> off road.  rot = [[c, -s], [s, c]] of the centre heading.
+__global__ __launch_bounds__(256) void off_road_kernel(const float* __restrict__ pts /*(n,2)*/, int n, const uint8_t* __restrict__ mask, int H,
+                                                       int W, double ox, double oy, double c, double s, double res_x, double res_y,
+                                                       double off_x, double off_y, uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double dx = (double)pts[2 * i] - ox, dy = (double)pts[2 * i + 1] - oy;
+  const double lx = __dadd_rn(__dmul_rn(dx, c), __dmul_rn(dy, s));        // (d . rot)[0] = dx*c + dy*s   (no fused multiply-add, as numpy)
+  const double ly = __dadd_rn(__dmul_rn(dx, -s), __dmul_rn(dy, c));       // (d . rot)[1] = -dx*s + dy*c
+  const double px = rint(lx / res_x + off_x), py = rint(ly / res_y + off_y);
+  uint8_t off = 0;
+  if (px >= 0.0 && px < (double)W && py >= 0.0 && py < (double)H) off = mask[(size_t)(int)py * W + (int)px] == 1;
+  out[i] = off;
+}
+
 // ---------------------------------------------------------------------------
 // Replay-arena gather (collation): for tensor k, scene b:
 //   dst_k[b*dst_bytes .. +dst_bytes) = src_k[idx[b]*src_bytes .. +dst_bytes)

@@ -1457,6 +1457,29 @@ int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void*
   return RIFT_OK;
 }
 
+int rift_collision_matrix(RiftCtx* c, const float* center_vertices, int G, int Tc, const double* other_vertices, int N, int Ts,
+                          uint8_t* collision, void* stream) {
+  if (!c || G <= 0 || Ts <= 0 || Tc < Ts || N < 0 || !center_vertices || !collision || (N > 0 && !other_vertices)) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(collision_matrix_kernel, dim3(cdiv((long long)G * Ts, 256)), dim3(256), 0, (hipStream_t)stream, center_vertices, G, Tc,
+                     other_vertices, N, Ts, collision);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_off_road_matrix(RiftCtx* c, const float* rollout_center, int n_points, const uint8_t* off_road_mask, int H, int W,
+                         double origin_x, double origin_y, double heading, double res_x, double res_y, double off_x, double off_y,
+                         uint8_t* off_road, void* stream) {
+  if (!c || n_points <= 0 || H <= 0 || W <= 0 || !rollout_center || !off_road_mask || !off_road || res_x == 0.0 || res_y == 0.0) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(off_road_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, (hipStream_t)stream, rollout_center, n_points, off_road_mask,
+                     H, W, origin_x, origin_y, std::cos(heading), std::sin(heading), res_x, res_y, off_x, off_y, off_road);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
 int rift_set_param_event(RiftCtx* c, void* event) {
   if (!c) return RIFT_ERR_ARG;
   c->param_event = (hipEvent_t)event;

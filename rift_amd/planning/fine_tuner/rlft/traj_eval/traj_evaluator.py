@@ -5,8 +5,11 @@
     (rift_rollout, persistent PID state as in the reference) -> discounted dense-reward return
     (rift_rollout_return) -> group z-score (rift_group_advantage, ddof 0, +1e-5).
 
-The collision / off-road flags (shapely envelope test against forecast neighbours, HD-map raster lookup;
-traj_evaluator.py:160-331) need CARLA actors and map data: they are inputs here.
+The collision / off-road flags (traj_evaluator.py:160-331) come either from the caller (the reference's own shapely / raster code)
+or from the device: `other_vehicle_vertices` (N, 40, 4, 2) -- the forecast footprints of get_other_vehicle_rollout, which needs CARLA
+actors -- gives the collision matrix through rift_collision_matrix (the reference's STRtree query is an envelope test), and
+`off_road_mask` + `center_pose` -- the raster the reference draws from the HD map with cv2.fillPoly -- gives the off-road matrix
+through rift_off_road_matrix.
 """
 from typing import Dict, List, Optional
 
@@ -22,10 +25,13 @@ class TrajEvaluator:
         self.last_rollout: Optional[Dict[str, torch.Tensor]] = None
 
     def get_grpo_advantage(self, center_state, trajectories: torch.Tensor, ref_line_pos: List[torch.Tensor],
-                           ref_line_angle: List[torch.Tensor], collision_matrix, off_road_matrix, gamma: float = 0.98):
+                           ref_line_angle: List[torch.Tensor], collision_matrix=None, off_road_matrix=None, gamma: float = 0.98,
+                           other_vehicle_vertices=None, off_road_mask=None, center_pose=None):
         """center_state: (x, y, heading, speed, width, length) of the CBV rear axle / footprint.
         trajectories: (R, M, 80, 6) raw model output of the valid reference lines.
-        collision_matrix (G, >=40) / off_road_matrix (G, >=40): bool flags per candidate and frame."""
+        collision_matrix (G, >=40) / off_road_matrix (G, >=40): bool flags per candidate and frame, OR
+        other_vehicle_vertices (N, >=40, 4, 2) float64 and off_road_mask (H, W) uint8 + center_pose (x, y, heading of the footprint
+        centre, get_off_road_matrix's origin / angle) to have them computed on the device from this call's rollout."""
         eng = self.engine
         R, M = trajectories.shape[:2]
         G = R * M
@@ -34,6 +40,14 @@ class TrajEvaluator:
         ro = eng.rollout(trajectories.reshape(G, trajectories.shape[2], 6), cs, self.pid_state)
         self.last_rollout = ro
         T = self.num_frames
+        if collision_matrix is None:
+            if other_vehicle_vertices is None:
+                raise ValueError("pass collision_matrix or other_vehicle_vertices")
+            collision_matrix = eng.collision_matrix(ro["vertices"], other_vehicle_vertices, Ts=T)
+        if off_road_matrix is None:
+            if off_road_mask is None or center_pose is None:
+                raise ValueError("pass off_road_matrix or off_road_mask + center_pose")
+            off_road_matrix = eng.off_road_matrix(ro["center"], off_road_mask, center_pose[:2], float(center_pose[2]))
         ret = eng.rollout_return(dd, da, ro["speed"][:, :T].contiguous(), ro["acc"][:, :T].contiguous(),
                                  ro["ang_vel"][:, :T].contiguous(), ro["ang_acc"][:, :T].contiguous(),
                                  torch.as_tensor(collision_matrix), torch.as_tensor(off_road_matrix), gamma)

@@ -633,3 +633,95 @@ def test_native_adamw_matches_torch_adamw(ffi):
         assert err(sa["exp_avg"], sb["exp_avg"]) < 1e-6 * max(1.0, float(sb["exp_avg"].abs().max()))
         assert err(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 1e-6 * max(1.0, float(sb["exp_avg_sq"].abs().max()))
     eng.close()
+
+
+def test_collision_and_off_road_flags_match_oracle(ffi):
+    """rift_collision_matrix / rift_off_road_matrix against oracle/traj_flags.py (the reference's STRtree envelope query and raster
+    lookup): boolean outputs bit-exact, including footprints that only touch, no neighbours at all, points outside the raster and
+    pixel coordinates exactly on a .5 tie (round half to even)."""
+    from oracle import traj_flags as otf
+    eng = ffi.Engine("cuda:0")
+    rng = np.random.default_rng(7)
+    G, Tc, Ts, N = 48, 80, 40, 9
+
+    def boxes(n, t, spread):
+        c = rng.normal(0, spread, (n, t, 1, 2))
+        half = rng.uniform(0.8, 2.6, (n, t, 1, 2))
+        ang = rng.uniform(-np.pi, np.pi, (n, t))
+        corners = np.array([[1, 1], [-1, 1], [-1, -1], [1, -1]], dtype=np.float64)[None, None] * half
+        rot = np.stack([np.cos(ang), -np.sin(ang), np.sin(ang), np.cos(ang)], -1).reshape(n, t, 2, 2)
+        return c + np.einsum("ntkj,ntij->ntki", corners, rot)
+
+    center = boxes(G, Tc, 12.0).astype(np.float32)
+    other = boxes(N, Ts, 12.0)
+    # exact touch: neighbour 0's envelope starts where candidate 0's ends at step 3; and a hair apart at step 4
+    e = center[0, 3].astype(np.float64)
+    other[0, 3] = np.array([[e[:, 0].max() + 2.0, 0], [e[:, 0].max(), 0], [e[:, 0].max(), 1], [e[:, 0].max() + 2.0, 1]]) + [0, e[:, 1].min()]
+    e = center[0, 4].astype(np.float64)
+    other[:, 4] += 1e3
+    other[0, 4] = np.array([[np.nextafter(e[:, 0].max(), np.inf) + 2.0, 0], [np.nextafter(e[:, 0].max(), np.inf), 0],
+                            [np.nextafter(e[:, 0].max(), np.inf), 1], [np.nextafter(e[:, 0].max(), np.inf) + 2.0, 1]]) + [0, e[:, 1].min()]
+    want = otf.get_collision_matrix(center, other)
+    got = eng.collision_matrix(torch.from_numpy(center), torch.from_numpy(other), Ts=Ts).cpu().numpy()
+    assert want[0, 3] and not want[0, 4]
+    assert 0.02 < want.mean() < 0.9
+    assert np.array_equal(got, want)
+    none = eng.collision_matrix(torch.from_numpy(center), torch.zeros(0, Ts, 4, 2, dtype=torch.float64), Ts=Ts).cpu().numpy()
+    assert not none.any() and none.shape == (G, Ts)
+
+    mask = (rng.random((400, 400)) > 0.6).astype(np.uint8)
+    origin, angle = np.array([13.25, -7.5]), 0.7
+    pts = rng.normal(0, 60.0, (G, Tc, 2)).astype(np.float32)            # +-100 m raster: some points fall outside
+    # a pixel tie: local x chosen so that x / 0.5 + 200 = 10.5 exactly -> rounds to 10 (even); and 11.5 -> 12
+    c, s_ = np.cos(angle), np.sin(angle)
+    for k, lx in enumerate((-94.75, -94.25)):
+        loc = np.array([lx, 3.0])
+        pts[1, k] = (np.array([[c, -s_], [s_, c]]) @ loc + origin).astype(np.float32)
+    want_o = otf.get_off_road_matrix(pts, mask, origin, angle)
+    got_o = eng.off_road_matrix(torch.from_numpy(pts), torch.from_numpy(mask), origin, angle).cpu().numpy()
+    assert 0.05 < want_o.mean() < 0.6
+    assert np.array_equal(got_o, want_o)
+    eng.close()
+
+
+def test_traj_evaluator_grpo_advantage_with_device_flags(ffi):
+    """TrajEvaluator.get_grpo_advantage end to end on the device -- ref-line deviation, closed-loop rollout, collision flags from the
+    neighbours' forecast footprints, off-road flags from the raster, discounted return, group z-score -- against the oracle chain.
+    The flags are computed from each side's OWN rollout (device vs CPU libm differ in the last ulp after 79 closed-loop steps), so
+    they are compared through the advantage: 1e-3 abs on the z-scored returns unless a flag differs, which the test rules out first."""
+    from oracle import advantage as oadv, rollout as orl, traj_flags as otf
+    from rift_amd.planning.fine_tuner.rlft.traj_eval.traj_evaluator import TrajEvaluator
+    eng = ffi.Engine("cuda:0")
+    traj, ref_pos, ref_ang, st = H.rollout_inputs(991)
+    R, M = traj.shape[:2]
+    rng = np.random.default_rng(3)
+    # neighbours: boxes drifting along the candidates' corridor (N, 40, 4, 2) float64; raster: a drivable band around the start pose
+    N = 5
+    t = np.arange(40)[None, :, None]
+    ctr = np.array(st["pos"])[None, None] + rng.normal(0, 6.0, (N, 1, 2)) + t * rng.normal(0.4, 0.2, (N, 1, 2))
+    corners = np.array([[2.4, 1.1], [-2.4, 1.1], [-2.4, -1.1], [2.4, -1.1]])[None, None]
+    other = ctr[:, :, None, :] + corners
+    mask = np.ones((400, 400), dtype=np.uint8)
+    mask[170:232, :260] = 0                                            # drivable: a +-15 m band, up to 30 m ahead of the start pose
+    pose = (st["pos"][0], st["pos"][1], st["heading"])
+    te = TrajEvaluator(eng)
+    got = te.get_grpo_advantage((st["pos"][0], st["pos"][1], st["heading"], st["speed"], st["width"], st["length"]), traj, ref_pos, ref_ang,
+                                other_vehicle_vertices=other, off_road_mask=mask, center_pose=pose)
+    ro_dev = te.last_rollout
+    # oracle chain
+    t40 = traj[:, :, :40, :]
+    dd, da, _ = orl.ref_line_info(t40, ref_pos, ref_ang)
+    gpos, ghead = orl.to_global(t40, torch.tensor(st["pos"]), torch.tensor(st["heading"]))
+    ref = orl.Rollout().propagate(gpos, ghead, st["speed"], st["width"], st["length"])
+    col = otf.get_collision_matrix(ref["vertices"].numpy(), other)
+    off = otf.get_off_road_matrix(ref["center"].numpy(), mask, pose[:2], pose[2])
+    col_dev = eng.collision_matrix(ro_dev["vertices"], other, Ts=40).cpu().numpy()
+    off_dev = eng.off_road_matrix(ro_dev["center"], mask, pose[:2], pose[2]).cpu().numpy()
+    assert col.any() and not col.all() and off.any() and not off.all()          # both kinds of flags are exercised
+    assert np.array_equal(col_dev, col) and np.array_equal(off_dev, off)        # no candidate sits within an ulp of a box / pixel edge
+    ret = oadv.rollout_return(dd.numpy(), da.numpy(), ref["speed"][:, :40].numpy(), ref["acc"][:, :40].numpy(),
+                              ref["ang_vel"][:, :40].numpy(), ref["ang_acc"][:, :40].numpy(), col, off)
+    want = oadv.group_zscore(ret).reshape(R, M)
+    assert got["valid_mask"].all() and got["advantage"].shape == (R, M)
+    assert err(torch.from_numpy(got["advantage"]), torch.from_numpy(want)) < 1e-3
+    eng.close()

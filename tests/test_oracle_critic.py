@@ -22,3 +22,26 @@ def test_critic_and_ppo_loss_match_reference_fixture():
     assert np.abs(dprob.numpy() - gold["dprobability"]).max() < 1e-7
     for k in ocr.CRITIC_KEYS:
         assert np.abs(grads[k].numpy() - gold["grad." + k]).max() < 1e-6, k
+
+
+def test_traj_flag_oracle_envelope_and_raster_semantics():
+    """oracle/traj_flags.py (unpinned restatement of the STRtree envelope query and the raster lookup): touching envelopes collide,
+    an empty neighbour list gives zeros with the candidate's step count, pixels round half to even and points off the raster are
+    not off-road."""
+    from oracle import traj_flags as otf
+    sq = lambda x0, y0, w: np.array([[x0 + w, y0 + w], [x0, y0 + w], [x0, y0], [x0 + w, y0]], dtype=np.float64)
+    center = np.stack([sq(0, 0, 2), sq(10, 10, 2)])[:, None].repeat(3, 1).astype(np.float32)          # (2, 3, 4, 2)
+    other = np.stack([np.stack([sq(2, 0, 1), sq(2.0001, 0, 1), sq(-5, -5, 1)])])                       # (1, 3, 4, 2)
+    col = otf.get_collision_matrix(center, other)
+    assert col.tolist() == [[True, False, False], [False, False, False]]
+    assert otf.get_collision_matrix(center, np.zeros((0, 3, 4, 2))).shape == (2, 3)
+    # a diagonal footprint whose envelope overlaps although the polygons do not: still a "collision" (envelope query)
+    diag = np.array([[[3.0, 0.0], [0.0, 3.0], [-0.1, 2.9], [2.9, -0.1]]])[None]                          # thin diagonal sliver
+    corner = sq(0, 0, 0.5)[None, None].astype(np.float32)
+    assert otf.get_collision_matrix(corner, diag)[0, 0]
+    mask = np.zeros((400, 400), dtype=np.uint8)
+    mask[200, 10] = 1
+    mask[200, 12] = 1
+    pts = np.array([[[-94.75, 0.0], [-94.25, 0.0], [-94.5, 0.0], [1e4, 0.0]]], dtype=np.float32)   # pixels 10.5 -> 10, 11.5 -> 12, 11, outside
+    off = otf.get_off_road_matrix(pts, mask, origin=(0.0, 0.0), angle=0.0)
+    assert off.tolist() == [[True, True, False, False]]
