@@ -58,6 +58,15 @@ def main():
         off = (torch.rand(G, 80, generator=g) > 0.97).to(dev)
         rec(f"rollout_return G={G}", timeit(lambda: eng.rollout_return(f[0], f[1], f[2], f[3], f[4], f[5], col, off)),
             G * (80 * 4 + 5 * Ts * 4 + 40 + 80 + 8), "dense reward + discounted sum with collision break")
+    for G, N in ((48, 10), (192, 30), (4096 * 72, 10)):
+        cv = torch.randn(G, 80, 4, 2, generator=g).to(dev)
+        ov = torch.randn(N, 40, 4, 2, generator=g, dtype=torch.float64).to(dev)
+        rec(f"collision_matrix G={G} N={N}", timeit(lambda: eng.collision_matrix(cv, ov, Ts=40)), G * 40 * 32 + N * 40 * 64 + G * 40,
+            "envelope overlap of candidate footprints with forecast neighbours (traj_evaluator.py:241-275)")
+        rc = (torch.randn(G, 80, 2, generator=g) * 60).to(dev)
+        mask = (torch.rand(400, 400, generator=g) > 0.5).to(torch.uint8).to(dev)
+        rec(f"off_road_matrix G={G}", timeit(lambda: eng.off_road_matrix(rc, mask, (1.0, 2.0), 0.3)), G * 80 * 9,
+            "raster lookup (traj_evaluator.py:299-318)")
     scenes = [syn.make_scene(i) for i in range(512)]
     replay = DeviceReplay(scenes, dev, rcap=6)
     idx = torch.randperm(512, generator=g)[:256].to(torch.int32).to(dev)
