@@ -192,6 +192,16 @@ int rift_normalize_advantage(RiftCtx* ctx, float* x, int n, void* stream);
  * adv = (ret - mean) / (std_ddof0 + 1e-5). */
 int rift_group_advantage(RiftCtx* ctx, const double* returns, int n_groups, int G, double* advantage, void* stream);
 
+/* TrajEvaluator.get_other_vehicle_rollout (traj_eval/traj_evaluator.py:160-239): the nearby actors' footprints over T future frames under
+ * their last control -- KinematicBicycleModel.forecast_other_vehicles (rift/ego/pdm_lite/kinematic_bicycle_model.py:33-62), the speed- and
+ * horizon-dependent extent inflation (GlobalConfig, rift/ego/pdm_lite/config.py:186-199) times bbox_inflation_ratio, corners FL RL RR FR in
+ * the right-handed global frame.  Inputs are what the reference reads off the CARLA actors, as device fp64 arrays: actions (N,3) = steer,
+ * throttle, brake; speed (N) = |velocity|; location (N,3) and yaw_deg (N) in CARLA's left-handed frame; extent (N,2) = bounding-box half
+ * extents (x, y).  vertices: (N,T,4,2) f64 -- the `other_vertices` of rift_collision_matrix. */
+int rift_other_vehicle_rollout(RiftCtx* ctx, const double* actions, const double* speed, const double* location, const double* yaw_deg,
+                               const double* extent, int N, int T, int near_lane_change, double bbox_inflation_ratio, double* vertices,
+                               void* stream);
+
 /* TrajEvaluator.get_collision_matrix (traj_eval/traj_evaluator.py:241-275).  The reference queries an STRtree of the other vehicles'
  * footprints with the candidate's footprint and NO predicate, i.e. an envelope test: collision[g][j] = 1 iff the axis-aligned bounding
  * box of center_vertices[g][j] intersects (touching included) that of other_vertices[n][j] for some n.  center_vertices: (G,Tc,4,2) f32

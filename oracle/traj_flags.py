@@ -2,7 +2,9 @@
 
 R/ = rift/cbv/planning/fine_tuner/rlft/traj_eval/traj_evaluator.py
 
-PARITY UNPINNED: the reference computes these with third-party code that is not importable here -- Shapely==2.0.6
+PARITY: the other-vehicle forecast (get_other_vehicle_rollout and callees) IS pinned -- tests/golden/other_vehicles.npz holds the output of
+the reference's own code on seeded actor readings (tests/golden/gen_golden.py other_vehicles) and the restatement matches it bit for bit.
+UNPINNED: the two flag matrices -- the reference computes these with third-party code that is not importable here -- Shapely==2.0.6
 (requirements.txt:34; call sites R/:15-16,259-271) and opencv_python==4.10.0.84 (requirements.txt:21; call site R/:323-325) -- and it has
 no tests or fixtures for them.  What is restated is the published behaviour of the calls the reference makes:
   * `STRtree.query(geometry)` with no predicate (shapely 2.0 API): "the integer indices of all geometries in the tree whose extents
@@ -55,3 +57,73 @@ def get_off_road_matrix(rollout_center: np.ndarray, off_road_mask: np.ndarray, o
     flags = np.zeros(all_points.shape[0], dtype=np.bool_)
     flags[valid] = off_road_mask[pixel_indices[valid, 1], pixel_indices[valid, 0]] == 1
     return flags.reshape(G, T)
+
+
+# GlobalConfig constants used by the forecast (rift/ego/pdm_lite/config.py:186-199,336-347), checked against the fixture's `config` row
+CFG = dict(time_step=0.1, front_wheel_base=-0.090769015, rear_wheel_base=1.4178275, steering_gain=0.36848336,
+           brake_acceleration=-4.952399, throttle_acceleration=0.5633837, slow_speed_extent_factor_ego=1.0,
+           extent_other_vehicles_bbs_speed_threshold=1.0, high_speed_min_extent_y_other_vehicle=1.0,
+           high_speed_extent_y_factor_other_vehicle=1.3, high_speed_min_extent_x_other_vehicle=1.2,
+           high_speed_min_extent_x_other_vehicle_lane_change=2.0)
+
+
+def forecast_other_vehicles(locations, headings, speeds, actions):
+    """rift/ego/pdm_lite/kinematic_bicycle_model.py:33-62 (float64 numpy)."""
+    c = CFG
+    steers, throttles, brakes = actions[:, 0], actions[:, 1], actions[:, 2].astype(np.uint8)
+    wheel_angles = c["steering_gain"] * steers
+    slip_angles = np.arctan(c["rear_wheel_base"] / (c["front_wheel_base"] + c["rear_wheel_base"]) * np.tan(wheel_angles))
+    next_x = locations[:, 0] + speeds * np.cos(headings + slip_angles) * c["time_step"]
+    next_y = locations[:, 1] + speeds * np.sin(headings + slip_angles) * c["time_step"]
+    next_headings = headings + speeds / c["rear_wheel_base"] * np.sin(slip_angles) * c["time_step"]
+    next_speeds = speeds + c["time_step"] * np.where(brakes, c["brake_acceleration"], throttles * c["throttle_acceleration"])
+    next_speeds = np.maximum(0.0, next_speeds)
+    return np.column_stack([next_x, next_y, locations[:, 2]]), next_headings, next_speeds
+
+
+def compute_agents_vertices(center, angle, shape):
+    """R/:33-79: corners FL, RL, RR, FR of boxes (N, T) with shape (N, T, 2) = [width, length]."""
+    N, T = center.shape[:2]
+    center = center.reshape(N * T, 2)
+    angle = angle.reshape(N * T)
+    shape = (shape / 2).reshape(N * T, 2)
+    half_w, half_l = shape[:, 0], shape[:, 1]
+    cos_a, sin_a = np.cos(angle)[:, None], np.sin(angle)[:, None]
+    rot = np.stack([cos_a, sin_a, -sin_a, cos_a], axis=-1).reshape(N * T, 2, 2)
+    ow = np.stack([half_w, half_w, -half_w, -half_w], axis=-1)
+    ol = np.stack([half_l, -half_l, -half_l, half_l], axis=-1)
+    v = np.matmul(np.stack([ol, ow], axis=-1), rot) + center[:, None]
+    return v.reshape(N, T, 4, 2)
+
+
+def get_other_vehicle_rollout(steer, throttle, brake, speed, location, yaw_deg, extent, num_future_frames=40, near_lane_change=True,
+                              bbox_inflation_ratio=1.1):
+    """R/:160-239 with the CARLA actor accessors replaced by arrays: last control (steer, throttle, brake), speed = |velocity|,
+    location (N, 3) and yaw (degrees) in CARLA's left-handed frame, bounding-box half extents (N, 2) = (x, y).  -> (N, T, 4, 2) f64
+    in the right-handed global frame."""
+    c = CFG
+    N = len(steer)
+    if N == 0:
+        return np.zeros((0, num_future_frames, 4, 2), dtype=np.float32)
+    actions = np.stack([steer, throttle, brake], -1).astype(np.float64)
+    velocities = np.asarray(speed, dtype=np.float64)
+    locations = np.asarray(location, dtype=np.float64)
+    headings = np.deg2rad(np.asarray(yaw_deg, dtype=np.float64))
+    fl = np.empty((num_future_frames, N, 3)); fh = np.empty((num_future_frames, N)); fv = np.empty((num_future_frames, N))
+    for i in range(num_future_frames):
+        locations, headings, velocities = forecast_other_vehicles(locations, headings, velocities, actions)
+        fl[i], fv[i], fh[i] = locations.copy(), velocities.copy(), headings.copy()
+    shape = np.empty((num_future_frames, N, 2))
+    s = c["high_speed_min_extent_x_other_vehicle_lane_change"] if near_lane_change else c["high_speed_min_extent_x_other_vehicle"]
+    for a in range(N):
+        for i in range(num_future_frames):
+            ex, ey = float(extent[a][0]), float(extent[a][1])
+            slow = fv[i, a] < c["extent_other_vehicles_bbs_speed_threshold"]
+            ex *= c["slow_speed_extent_factor_ego"] if slow else max(s, c["high_speed_min_extent_x_other_vehicle"] * float(i) / float(num_future_frames))
+            ey *= c["slow_speed_extent_factor_ego"] if slow else max(c["high_speed_min_extent_y_other_vehicle"],
+                                                                     c["high_speed_extent_y_factor_other_vehicle"] * float(i) / float(num_future_frames))
+            ex *= bbox_inflation_ratio
+            ey *= bbox_inflation_ratio
+            shape[i, a] = np.array([ey * 2, ex * 2])
+    return compute_agents_vertices(center=fl.transpose(1, 0, 2)[..., :2] * np.array([1, -1]), angle=-fh.transpose(1, 0),
+                                   shape=shape.transpose(1, 0, 2))

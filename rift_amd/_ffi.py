@@ -7,6 +7,7 @@ import ctypes as C
 import os
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -77,7 +78,7 @@ EXPORTS = [
     "rift_loss_finalize", "rift_loss_finalize_clip", "rift_set_param_event", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
-    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix",
+    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -118,6 +119,7 @@ def load_library() -> C.CDLL:
     lib.rift_adamw_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                     C.c_double, C.c_double, vp]
+    lib.rift_other_vehicle_rollout.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]
     lib.rift_collision_matrix.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     lib.rift_off_road_matrix.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int] + [C.c_double] * 7 + [vp, vp]
     lib.rift_op_linear.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
@@ -468,6 +470,21 @@ class Engine:
             setattr(io, k, v.data_ptr())
         self._check(self.lib.rift_rollout(self.ctx, C.byref(io), _stream()), "rift_rollout")
         self._keep_ro = (traj, cs)
+        return out
+
+    def other_vehicle_rollout(self, steer, throttle, brake, speed, location, yaw_deg, extent, num_future_frames: int = 40,
+                              near_lane_change: bool = True, bbox_inflation_ratio: float = 1.1):
+        """get_other_vehicle_rollout on the device: per-actor arrays (see rift_hip.h) -> (N, T, 4, 2) float64 device tensor."""
+        dev = self.device
+        f64 = lambda a: _dev(torch.as_tensor(np.asarray(a, dtype=np.float64)), torch.float64, dev)
+        act = f64(np.stack([np.asarray(steer, dtype=np.float64), np.asarray(throttle, dtype=np.float64), np.asarray(brake, dtype=np.float64)], -1))
+        N = act.shape[0]
+        out = torch.empty(N, num_future_frames, 4, 2, dtype=torch.float64, device=dev)
+        if N:
+            sp, loc, yaw, ext = f64(speed), f64(location), f64(yaw_deg), f64(extent)
+            self._check(self.lib.rift_other_vehicle_rollout(self.ctx, _ptr(act), _ptr(sp), _ptr(loc), _ptr(yaw), _ptr(ext), N, num_future_frames,
+                                                            1 if near_lane_change else 0, float(bbox_inflation_ratio), _ptr(out), _stream()),
+                        "rift_other_vehicle_rollout")
         return out
 
     def collision_matrix(self, center_vertices, other_vertices, Ts: int = 40):

@@ -140,6 +140,48 @@ __global__ __launch_bounds__(256) void rollout_return_kernel(const float* __rest
   if (lane == 0) ret[i] = r;
 }
 
+// get_other_vehicle_rollout (traj_evaluator.py:160-239): constant-control kinematic-bicycle forecast of the nearby actors
+// (KinematicBicycleModel.forecast_other_vehicles, rift/ego/pdm_lite/kinematic_bicycle_model.py:33-62, constants from
+// rift/ego/pdm_lite/config.py:186-199,336-347), speed-dependent footprint inflation, corners FL RL RR FR in the right-handed frame
+// (compute_agents_vertices, traj_evaluator.py:33-79).  One thread per actor, T sequential steps, all in fp64 as numpy computes it.
+__global__ __launch_bounds__(64) void other_vehicle_rollout_kernel(const double* __restrict__ actions /*(N,3) steer throttle brake*/,
+                                                                   const double* __restrict__ speed, const double* __restrict__ location /*(N,3)*/,
+                                                                   const double* __restrict__ yaw_deg, const double* __restrict__ extent /*(N,2)*/,
+                                                                   int N, int T, int near_lane_change, double inflation,
+                                                                   double* __restrict__ vertices /*(N,T,4,2)*/) {
+  const int a = blockIdx.x * 64 + threadIdx.x;
+  if (a >= N) return;
+  const double dt = 0.1, Lf = -0.090769015, Lr = 1.4178275, gain = 0.36848336, brake_acc = -4.952399, thr_acc = 0.5633837;
+  const double slow_f = 1.0, v_thr = 1.0, min_y = 1.0, fac_y = 1.3, min_x = 1.2, min_x_lc = 2.0;
+  const double steer = actions[3 * a], throttle = actions[3 * a + 1];
+  const bool brake = ((unsigned char)actions[3 * a + 2]) != 0;                 // .astype(np.uint8): truncation
+  const double slip = atan(Lr / (Lf + Lr) * tan(gain * steer));
+  double x = location[3 * a], y = location[3 * a + 1], h = yaw_deg[a] * (3.14159265358979323846 / 180.0), v = speed[a];
+  const double s = near_lane_change ? min_x_lc : min_x;
+  const double acc = brake ? brake_acc : __dmul_rn(throttle, thr_acc);
+  for (int i = 0; i < T; ++i) {
+    const double nx = __dadd_rn(x, __dmul_rn(__dmul_rn(v, cos(h + slip)), dt));
+    const double ny = __dadd_rn(y, __dmul_rn(__dmul_rn(v, sin(h + slip)), dt));
+    const double nh = __dadd_rn(h, __dmul_rn(__dmul_rn(v / Lr, sin(slip)), dt));
+    const double nv = fmax(0.0, __dadd_rn(v, __dmul_rn(dt, acc)));
+    x = nx; y = ny; h = nh; v = nv;
+    const bool slow = v < v_thr;
+    const double fr = (double)i / (double)T;
+    double ex = extent[2 * a] * (slow ? slow_f : fmax(s, min_x * fr));
+    double ey = extent[2 * a + 1] * (slow ? slow_f : fmax(min_y, fac_y * fr));
+    ex *= inflation; ey *= inflation;
+    const double hw = (ey * 2) / 2, hl = (ex * 2) / 2;
+    const double cx = x, cy = -y, c = cos(-h), sn = sin(-h);
+    const double ol[4] = {hl, -hl, -hl, hl}, ow[4] = {hw, hw, -hw, -hw};
+    double* o = vertices + ((size_t)a * T + i) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[2 * k] = __dadd_rn(__dadd_rn(__dmul_rn(ol[k], c), __dmul_rn(ow[k], -sn)), cx);
+      o[2 * k + 1] = __dadd_rn(__dadd_rn(__dmul_rn(ol[k], sn), __dmul_rn(ow[k], c)), cy);
+    }
+  }
+}
+
 // get_collision_matrix (traj_evaluator.py:241-275): the reference builds an STRtree of the other vehicles' footprints per step and
 // calls tree.query(ego_polygon) WITHOUT a predicate, which returns the geometries whose ENVELOPES intersect the candidate's
 // envelope (closed intervals: touching counts) -- so collision[g][j] = any_n AABB(center[g][j]) overlaps AABB(other[n][j]).

@@ -1457,6 +1457,20 @@ int rift_loss_finalize(RiftCtx* c, const RiftLossOut* out, int accumulate, void*
   return RIFT_OK;
 }
 
+int rift_other_vehicle_rollout(RiftCtx* c, const double* actions, const double* speed, const double* location, const double* yaw_deg,
+                               const double* extent, int N, int T, int near_lane_change, double bbox_inflation_ratio, double* vertices,
+                               void* stream) {
+  if (!c || N < 0 || T <= 0) return RIFT_ERR_ARG;
+  if (N == 0) return RIFT_OK;
+  if (!actions || !speed || !location || !yaw_deg || !extent || !vertices) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(other_vehicle_rollout_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, actions, speed, location, yaw_deg, extent,
+                     N, T, near_lane_change, bbox_inflation_ratio, vertices);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
 int rift_collision_matrix(RiftCtx* c, const float* center_vertices, int G, int Tc, const double* other_vertices, int N, int Ts,
                           uint8_t* collision, void* stream) {
   if (!c || G <= 0 || Ts <= 0 || Tc < Ts || N < 0 || !center_vertices || !collision || (N > 0 && !other_vertices)) return RIFT_ERR_ARG;

@@ -7,7 +7,8 @@
 
 The collision / off-road flags (traj_evaluator.py:160-331) come either from the caller (the reference's own shapely / raster code)
 or from the device: `other_vehicle_vertices` (N, 40, 4, 2) -- the forecast footprints of get_other_vehicle_rollout, which needs CARLA
-actors -- gives the collision matrix through rift_collision_matrix (the reference's STRtree query is an envelope test), and
+actors (or `nearby_actor_states`, the raw actor readings, forecast by rift_other_vehicle_rollout) -- gives the collision matrix
+through rift_collision_matrix (the reference's STRtree query is an envelope test), and
 `off_road_mask` + `center_pose` -- the raster the reference draws from the HD map with cv2.fillPoly -- gives the off-road matrix
 through rift_off_road_matrix.
 """
@@ -26,12 +27,14 @@ class TrajEvaluator:
 
     def get_grpo_advantage(self, center_state, trajectories: torch.Tensor, ref_line_pos: List[torch.Tensor],
                            ref_line_angle: List[torch.Tensor], collision_matrix=None, off_road_matrix=None, gamma: float = 0.98,
-                           other_vehicle_vertices=None, off_road_mask=None, center_pose=None):
+                           other_vehicle_vertices=None, off_road_mask=None, center_pose=None, nearby_actor_states=None):
         """center_state: (x, y, heading, speed, width, length) of the CBV rear axle / footprint.
         trajectories: (R, M, 80, 6) raw model output of the valid reference lines.
         collision_matrix (G, >=40) / off_road_matrix (G, >=40): bool flags per candidate and frame, OR
         other_vehicle_vertices (N, >=40, 4, 2) float64 and off_road_mask (H, W) uint8 + center_pose (x, y, heading of the footprint
-        centre, get_off_road_matrix's origin / angle) to have them computed on the device from this call's rollout."""
+        centre, get_off_road_matrix's origin / angle) to have them computed on the device from this call's rollout; OR, instead of
+        other_vehicle_vertices, nearby_actor_states = dict(steer, throttle, brake, speed, location (N,3), yaw_deg, extent (N,2)) read
+        off the CARLA actors, forecast on the device (get_other_vehicle_rollout)."""
         eng = self.engine
         R, M = trajectories.shape[:2]
         G = R * M
@@ -41,8 +44,10 @@ class TrajEvaluator:
         self.last_rollout = ro
         T = self.num_frames
         if collision_matrix is None:
+            if other_vehicle_vertices is None and nearby_actor_states is not None:
+                other_vehicle_vertices = eng.other_vehicle_rollout(num_future_frames=T, **nearby_actor_states)
             if other_vehicle_vertices is None:
-                raise ValueError("pass collision_matrix or other_vehicle_vertices")
+                raise ValueError("pass collision_matrix, other_vehicle_vertices or nearby_actor_states")
             collision_matrix = eng.collision_matrix(ro["vertices"], other_vehicle_vertices, Ts=T)
         if off_road_matrix is None:
             if off_road_mask is None or center_pose is None:

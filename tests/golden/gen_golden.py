@@ -352,8 +352,71 @@ def gen_inference():
     print("inference ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", out["trim.orig"].tolist(), out["actions"][0])
 
 
+def gen_other_vehicles():
+    """TrajEvaluator.get_other_vehicle_rollout (traj_evaluator.py:160-239) run as the reference wrote it: the method and
+    compute_agents_vertices are compiled in memory from the reference file, KinematicBicycleModel and GlobalConfig are imported from
+    rift/ego/pdm_lite (numpy only; `carla` is a permissive stand-in because GlobalConfig's class body names CARLA enums)."""
+    import importlib.util
+    import types
+    from tests.helpers import other_vehicle_inputs
+
+    class _Any:
+        def __getattr__(self, k):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    class Vector3D:
+        def __init__(self, x=0.0, y=0.0, z=0.0):
+            self.x, self.y, self.z = x, y, z
+
+        def length(self):
+            return float(np.sqrt(self.x ** 2 + self.y ** 2 + self.z ** 2))
+
+    carla = types.ModuleType("carla")
+    carla.__getattr__ = lambda k: _Any()
+    carla.Vector3D = Vector3D
+    sys.modules["carla"] = carla
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref_loader.REF_ROOT, rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    cfg = load("ref_pdm_config", "rift/ego/pdm_lite/config.py").GlobalConfig()
+    kbm = load("ref_kbm", "rift/ego/pdm_lite/kinematic_bicycle_model.py").KinematicBicycleModel(cfg)
+    TE = "rift/cbv/planning/fine_tuner/rlft/traj_eval/traj_evaluator.py"
+    cav = _ref_function(TE, "compute_agents_vertices")
+    rollout = _ref_function(TE, "get_other_vehicle_rollout", {"carla": carla, "compute_agents_vertices": cav})
+    inp = other_vehicle_inputs()
+    N = len(inp["steer"])
+
+    def actor(i):
+        ctl = types.SimpleNamespace(steer=float(inp["steer"][i]), throttle=float(inp["throttle"][i]), brake=float(inp["brake"][i]))
+        loc = types.SimpleNamespace(x=float(inp["location"][i, 0]), y=float(inp["location"][i, 1]), z=float(inp["location"][i, 2]))
+        return types.SimpleNamespace(get_control=lambda: ctl, get_velocity=lambda: Vector3D(float(inp["speed"][i]), 0.0, 0.0),
+                                     get_location=lambda: loc,
+                                     get_transform=lambda: types.SimpleNamespace(rotation=types.SimpleNamespace(yaw=float(inp["yaw_deg"][i]))),
+                                     bounding_box=types.SimpleNamespace(extent=Vector3D(float(inp["extent"][i, 0]), float(inp["extent"][i, 1]), 0.8)))
+
+    fake_self = types.SimpleNamespace(config=cfg, other_vehicle_model=kbm, bbox_inflation_ratio=1.1)
+    out = {"vertices": rollout(fake_self, [actor(i) for i in range(N)], num_future_frames=40),
+           "vertices_empty_shape": np.array(rollout(fake_self, [], num_future_frames=40).shape),
+           "config": np.array([cfg.time_step, cfg.front_wheel_base, cfg.rear_wheel_base, cfg.steering_gain, cfg.brake_acceleration,
+                               cfg.throttle_acceleration, cfg.slow_speed_extent_factor_ego, cfg.extent_other_vehicles_bbs_speed_threshold,
+                               cfg.high_speed_min_extent_y_other_vehicle, cfg.high_speed_extent_y_factor_other_vehicle,
+                               cfg.high_speed_min_extent_x_other_vehicle, cfg.high_speed_min_extent_x_other_vehicle_lane_change])}
+    path = os.path.join(HERE, "other_vehicles.npz")
+    np.savez_compressed(path, **out)
+    print("other vehicles ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", out["vertices"].shape, out["vertices"].dtype, out["config"])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "inference":
+    if len(sys.argv) > 1 and sys.argv[1] == "other_vehicles":
+        gen_other_vehicles()
+    elif len(sys.argv) > 1 and sys.argv[1] == "inference":
         gen_inference()
     elif len(sys.argv) > 1 and sys.argv[1] == "rollout":
         gen_rollout()
@@ -365,3 +428,4 @@ if __name__ == "__main__":
         gen_rollout()
         gen_critic()
         gen_inference()
+        gen_other_vehicles()

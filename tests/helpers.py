@@ -147,3 +147,14 @@ def inference_inputs(seed=909, R=4, M=12, T=80):
     return {"candidates": cand.astype(np.float64), "probability": g.normal(size=(R, M)).astype(np.float32),
             "ref_free": np.stack([5.0 * t[0, 0], 0.02 * t[0, 0] ** 2, 0.008 * t[0, 0]], axis=-1).astype(np.float64),
             "origin": np.array([12.5, -3.25]), "angle": 0.6}
+
+
+def other_vehicle_inputs(seed=4242, N=7):
+    """Seeded nearby-actor states for get_other_vehicle_rollout (tests/golden/other_vehicles.npz): steer / throttle / brake of the
+    last control, speed (m/s), CARLA location (x, y, z; left-handed), yaw in degrees, bounding-box half extents (x = length/2, y)."""
+    g = np.random.default_rng(seed)
+    brake = (g.random(N) < 0.3).astype(np.float64)
+    return {"steer": g.uniform(-0.6, 0.6, N), "throttle": g.uniform(0.0, 0.9, N) * (1 - brake), "brake": brake,
+            "speed": np.concatenate([[0.2, 0.9], g.uniform(1.5, 14.0, N - 2)]),        # two actors below the 1 m/s extent threshold
+            "location": np.stack([g.normal(20, 15, N), g.normal(-5, 15, N), g.uniform(0, 0.3, N)], -1),
+            "yaw_deg": g.uniform(-180, 180, N), "extent": np.stack([g.uniform(1.8, 2.6, N), g.uniform(0.8, 1.1, N)], -1)}

@@ -725,3 +725,26 @@ def test_traj_evaluator_grpo_advantage_with_device_flags(ffi):
     assert got["valid_mask"].all() and got["advantage"].shape == (R, M)
     assert err(torch.from_numpy(got["advantage"]), torch.from_numpy(want)) < 1e-3
     eng.close()
+
+
+def test_other_vehicle_rollout_matches_reference_fixture(ffi):
+    """rift_other_vehicle_rollout against tests/golden/other_vehicles.npz (the reference's get_other_vehicle_rollout run on the seeded
+    actors): fp64 corner coordinates within 1e-9 (device libm vs numpy's in the last ulps over 40 recursive steps); and the chain
+    forecast -> collision matrix on the device equals the oracle's collision matrix on the reference vertices."""
+    import os
+    from oracle import traj_flags as otf
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "other_vehicles.npz"))
+    inp = H.other_vehicle_inputs()
+    eng = ffi.Engine("cuda:0")
+    got = eng.other_vehicle_rollout(**inp)
+    assert got.shape == (7, 40, 4, 2) and got.dtype == torch.float64
+    assert err(got, torch.from_numpy(gold["vertices"])) < 1e-9
+    assert eng.other_vehicle_rollout(*[np.zeros((0,))] * 4, np.zeros((0, 3)), np.zeros((0,)), np.zeros((0, 2))).shape == (0, 40, 4, 2)
+    rng = np.random.default_rng(5)
+    ctr = gold["vertices"][rng.integers(0, 7, 48)].mean(2, keepdims=True) + rng.normal(0, 3.0, (48, 40, 1, 2))     # candidates near the actors
+    cand = (ctr + np.array([[2.3, 1.0], [-2.3, 1.0], [-2.3, -1.0], [2.3, -1.0]])[None, None]).astype(np.float32)
+    cand80 = np.concatenate([cand, cand], 1)
+    want = otf.get_collision_matrix(cand80, gold["vertices"])
+    have = eng.collision_matrix(torch.from_numpy(cand80), got, Ts=40).cpu().numpy()
+    assert 0.05 < want.mean() < 0.95 and (have != want).mean() < 2e-3         # an ulp-level edge case may flip a single flag
+    eng.close()

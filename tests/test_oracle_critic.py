@@ -45,3 +45,20 @@ def test_traj_flag_oracle_envelope_and_raster_semantics():
     pts = np.array([[[-94.75, 0.0], [-94.25, 0.0], [-94.5, 0.0], [1e4, 0.0]]], dtype=np.float32)   # pixels 10.5 -> 10, 11.5 -> 12, 11, outside
     off = otf.get_off_road_matrix(pts, mask, origin=(0.0, 0.0), angle=0.0)
     assert off.tolist() == [[True, True, False, False]]
+
+
+def test_other_vehicle_rollout_oracle_matches_reference_fixture():
+    """oracle/traj_flags.get_other_vehicle_rollout against tests/golden/other_vehicles.npz, produced by running the reference's own
+    TrajEvaluator.get_other_vehicle_rollout + KinematicBicycleModel + GlobalConfig on the seeded actors of H.other_vehicle_inputs."""
+    from oracle import traj_flags as otf
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "other_vehicles.npz"))
+    assert np.allclose(gold["config"], [otf.CFG[k] for k in (
+        "time_step", "front_wheel_base", "rear_wheel_base", "steering_gain", "brake_acceleration", "throttle_acceleration",
+        "slow_speed_extent_factor_ego", "extent_other_vehicles_bbs_speed_threshold", "high_speed_min_extent_y_other_vehicle",
+        "high_speed_extent_y_factor_other_vehicle", "high_speed_min_extent_x_other_vehicle",
+        "high_speed_min_extent_x_other_vehicle_lane_change")], rtol=0, atol=0)
+    inp = H.other_vehicle_inputs()
+    got = otf.get_other_vehicle_rollout(**inp)
+    assert got.shape == gold["vertices"].shape == (7, 40, 4, 2) and got.dtype == np.float64
+    assert np.array_equal(got, gold["vertices"])                                  # same numpy operations in the same order: bit-exact
+    assert otf.get_other_vehicle_rollout(*[np.zeros((0,))] * 4, np.zeros((0, 3)), np.zeros((0,)), np.zeros((0, 2))).shape == tuple(gold["vertices_empty_shape"])
