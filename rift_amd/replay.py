@@ -142,3 +142,48 @@ class DeviceReplay:
                 data[grp][key] = b[name]
         data["current_state"] = b["current_state"]
         return data
+
+
+# ---- on-disk scene dump ---------------------------------------------------------------------------
+# The reference keeps rollout scenes only as Python objects inside CBVRolloutBuffer (cbv_rollout_buffer.py:16-138); BASELINE config 0
+# speaks of "pre-dumped CARLA rollout scenes", so the dump format is defined here: ONE .npz per replay, every per-scene tensor of the
+# Appendix-A schema stored under "<scene index>/<group>/<key>" ("<i>/current_state", "<i>/extras/<key>" for the RLFT extras), dtypes
+# as PlutoFeature holds them (fp32 / fp64 features, bool masks, int8 categories).  `buffer_to_scenes` output goes in, the same list
+# comes out, so a replay dumped next to CARLA can be trained on without it.
+DUMP_VERSION = 1
+
+
+def save_scenes(path: str, scenes: List[Dict]) -> None:
+    import numpy as np
+    out = {"__rift_scene_dump__": np.array([DUMP_VERSION, len(scenes)], dtype=np.int64)}
+    for i, s in enumerate(scenes):
+        for grp, v in s["feature"].items():
+            if isinstance(v, dict):
+                for k, t in v.items():
+                    out[f"{i}/{grp}/{k}"] = torch.as_tensor(t).cpu().numpy()
+            else:
+                out[f"{i}/{grp}"] = torch.as_tensor(v).cpu().numpy()
+        for k, t in s.get("extras", {}).items():
+            out[f"{i}/extras/{k}"] = torch.as_tensor(t).cpu().numpy()
+    np.savez_compressed(path, **out)
+
+
+def load_scenes(path: str) -> List[Dict]:
+    import numpy as np
+    z = np.load(path)
+    if "__rift_scene_dump__" not in z.files or int(z["__rift_scene_dump__"][0]) != DUMP_VERSION:
+        raise ValueError(f"{path}: not a rift_amd scene dump of version {DUMP_VERSION}")
+    n = int(z["__rift_scene_dump__"][1])
+    scenes: List[Dict] = [{"feature": {}, "extras": {}} for _ in range(n)]
+    for name in z.files:
+        if name.startswith("__"):
+            continue
+        parts = name.split("/")
+        i, t = int(parts[0]), torch.from_numpy(z[name])
+        if parts[1] == "extras":
+            scenes[i]["extras"][parts[2]] = t
+        elif len(parts) == 2:
+            scenes[i]["feature"][parts[1]] = t
+        else:
+            scenes[i]["feature"].setdefault(parts[1], {})[parts[2]] = t
+    return scenes

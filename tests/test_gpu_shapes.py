@@ -106,3 +106,34 @@ def test_forward_does_not_depend_on_scratch_contents(monkeypatch, train):
         for o in outs[1:]:
             assert torch.equal(outs[0][k], o[k]), k
     assert torch.isfinite(outs[0]["probability"][rv]).all()
+
+
+@pytest.mark.gpu
+def test_config0_grpo_step_on_dumped_carla_shaped_scenes(tmp_path):
+    """BASELINE configs[0]: one GRPO update step on 8 pre-dumped rollout scenes with CARLA-like shapes (A <= 49 agents, ~60 map
+    polygons, R <= 6 reference lines, all ragged) -- scenes written with rift_amd.replay.save_scenes, read back, collated; the CPU
+    oracle step (forward in train mode with the drops off, GRPO objective, pi_head gradients) against the HIP step in fp32:
+    loss 1e-5, gradients 1e-4 relative."""
+    from rift_amd import _ffi as ffi
+    from rift_amd.replay import load_scenes, save_scenes
+    sd = H.weights()
+    scenes = [syn.make_scene(5000 + i, num_agents=30 + 3 * (i % 7), num_polygons=52 + 2 * (i % 5), r_min=1, r_max=6) for i in range(8)]
+    path = str(tmp_path / "carla_rollout_dump.npz")
+    save_scenes(path, scenes)
+    batch = syn.collate_scenes(load_scenes(path))
+    data = batch["cur_pluto_feature_torch"]
+    assert data["agent"]["position"].shape[1] <= 49 and data["map"]["point_position"].shape[1] >= 52
+    out_o, _, taps = pluto_ref.planning_model_forward(sd, H.clone_tree(data), train_bn=True, need_traj=False, want_taps=True)
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    loss_o, grads_o, _ = losses.pi_head_loss_and_grads(sd, taps["q_final"], "grpo", batch, r_pad)
+    eng = ffi.Engine("cuda:0")
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    eng.forward(data, train=True, no_drop=True, fp32=True, bn_update=False)
+    stats, flat, _ = eng.loss_backward("grpo", H.clone_tree(batch))
+    grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
+    loss = float(eng.loss_finalize(stats, flat, grads).item())
+    assert abs(loss - float(loss_o)) < 1e-5
+    for k in grads:
+        ref = grads_o[k]
+        assert float((grads[k].cpu() - ref).abs().max()) < 1e-5 + 1e-4 * float(ref.abs().max()), k
+    eng.close()

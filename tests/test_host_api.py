@@ -62,3 +62,35 @@ def test_product_package_never_touches_the_oracle():
         if "import oracle" in txt or "from oracle" in txt or "oracle/" in txt:
             offenders.append(str(f))
     assert not offenders, offenders
+
+
+def test_scene_dump_round_trip(tmp_path):
+    """save_scenes / load_scenes (the dump format BASELINE config 0's "pre-dumped rollout scenes" needs): 8 ragged scenes come back with
+    identical keys, dtypes, shapes and values, and collate to the same padded batch."""
+    from rift_amd import synthetic as syn
+    from rift_amd.replay import load_scenes, save_scenes
+    scenes = [syn.make_scene(900 + i, num_agents=10 + i, num_polygons=6 + (i % 3), r_min=1, r_max=4) for i in range(8)]
+    path = str(tmp_path / "replay.npz")
+    save_scenes(path, scenes)
+    back = load_scenes(path)
+    assert len(back) == 8
+
+    def same(a, b, where):
+        if isinstance(a, dict):
+            assert set(a) == set(b), where
+            for k in a:
+                same(a[k], b[k], f"{where}/{k}")
+        else:
+            a, b = torch.as_tensor(a), torch.as_tensor(b)
+            assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), where
+
+    for i, (s, t) in enumerate(zip(scenes, back)):
+        same(s["feature"], t["feature"], f"scene {i} feature")
+        same(s["extras"], t["extras"], f"scene {i} extras")
+    b0 = syn.collate_features([s["feature"] for s in scenes])
+    b1 = syn.collate_features([s["feature"] for s in back])
+    same(b0, b1, "collated batch")
+    with pytest.raises(ValueError):
+        import numpy as np
+        np.savez(str(tmp_path / "other.npz"), x=np.zeros(3))
+        load_scenes(str(tmp_path / "other.npz"))
