@@ -38,7 +38,8 @@ enum {
 };
 
 /* loss kinds */
-enum { RIFT_LOSS_RIFT = 0, RIFT_LOSS_GRPO = 1, RIFT_LOSS_PPO = 2, RIFT_LOSS_REINFORCE = 3 };
+enum { RIFT_LOSS_RIFT = 0, RIFT_LOSS_GRPO = 1, RIFT_LOSS_PPO = 2, RIFT_LOSS_REINFORCE = 3,
+       RIFT_LOSS_SFT = 4 /* teacher cross entropy, sft_trainer.py:123-184: in->action_mode[b][1] = teacher mode (rift_sft_teacher_mode) */ };
 
 /* A named view onto one tensor of PlanningModel.state_dict()
  * (rift/cbv/planning/pluto/model/pluto_model.py:22-120; names as in SURVEY.md Appendix B). */
@@ -139,6 +140,14 @@ int rift_model_load(RiftCtx* ctx, const RiftTensorDesc* params, int n, void* str
 /* PlanningModel.forward (pluto_model.py:122-225). */
 int rift_forward(RiftCtx* ctx, const RiftFeatureBatch* batch, const RiftOutputs* out, int flags,
                  uint32_t seed, void* stream);
+
+/* SFTTrainer.generate_target_label's teacher side (fine_tuner/sft/sft_trainer.py:186-199): per scene, the (r, m) index of the candidate
+ * whose PID target speed (mean spacing of the trajectory sub-sampled every `frame_rate` frames, in the teacher's local frame;
+ * sft/utils.py:10-32, pluto/controller/pid_controller.py:108-125) is closest to teacher_infos[b][0].  trajectory: the (bs,R,M,T,6) output
+ * of rift_forward; teacher_infos: (bs,5) f32 = target speed, origin x, y, heading, speed; mode_rm: (bs,2) int64.  Only column 1 (the
+ * mode) enters the label: RIFT_LOSS_SFT combines it with the policy's own best reference line. */
+int rift_sft_teacher_mode(RiftCtx* ctx, const float* trajectory, const float* teacher_infos, int bs, int R, int M, int T, int frame_rate,
+                          int64_t* mode_rm, void* stream);
 
 /* Optional: `event` (a hipEvent_t, NULL to clear) marks the point after which the trainable parameters (planning_decoder.pi_head.*,
  * read live by rift_forward) are up to date.  rift_forward then waits for it on ITS stream right before the first kernel that reads

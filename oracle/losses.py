@@ -101,7 +101,54 @@ def pi_head_loss_and_grads(sd_flat: Dict[str, torch.Tensor], q_final, kind: str,
                               batch["old_log_prob_torch"])
     elif kind == "reinforce":
         loss, _, _ = reinforce_loss(prob, r_pad, batch["return_torch"])
+    elif kind == "sft":
+        loss, _, _ = sft_loss(prob, r_pad, batch["trajectory_torch"], batch["teacher_infos_torch"])
     else:
         raise ValueError(kind)
     loss.backward()
     return loss.detach(), {k: v.grad.detach().clone() for k, v in params.items()}, prob.detach()
+
+
+# ---- SFT teacher objective (rift/cbv/planning/fine_tuner/sft/sft_trainer.py:123-199) -------------------------------------------------
+def sft_global_to_local(candidate_trajectories, origin, heading, step_interval=10):
+    """sft/utils.py:10-32."""
+    bs, R, M, T, _ = candidate_trajectories.shape
+    if T < step_interval:
+        local_traj = candidate_trajectories[:, :, :, -1:, :2]
+    else:
+        local_traj = candidate_trajectories[:, :, :, step_interval - 1::step_interval, :2]
+    origin = origin.view(bs, 1, 1, 1, 2)
+    rot_mat = torch.stack([torch.stack([torch.cos(heading), -torch.sin(heading)], dim=1),
+                           torch.stack([torch.sin(heading), torch.cos(heading)], dim=1)], dim=1).view(bs, 1, 1, 1, 2, 2)
+    return torch.einsum('brmtc,brmtcd->brmtd', local_traj - origin, rot_mat)
+
+
+def sft_target_speed(local_traj):
+    """PIDController.batch_control_pid, the target-speed half (pluto/controller/pid_controller.py:108-125)."""
+    if local_traj.shape[3] == 1:
+        return local_traj[..., 0, :].norm(dim=-1, p=2)
+    diff = local_traj[..., 1:, :] - local_traj[..., :-1, :]
+    return diff.norm(dim=-1, p=2).mean(dim=-1)
+
+
+def sft_teacher_mode(candidate_trajectories, teacher_infos, frame_rate=10):
+    """generate_target_label :186-196: (r, m) of the candidate closest in target speed to the teacher (padded lines included)."""
+    bs, R, M = candidate_trajectories.shape[:3]
+    local = sft_global_to_local(candidate_trajectories, teacher_infos[:, 1:3], teacher_infos[:, 3], frame_rate)
+    speed = sft_target_speed(local)
+    idx = torch.argmin((speed - teacher_infos[:, 0][:, None, None]).abs().view(bs, -1), dim=1)
+    return idx // M, idx % M
+
+
+def sft_loss(probability, r_pad, candidate_trajectories, teacher_infos, frame_rate=10):
+    """_compute_objectives + get_teacher_loss (:123-184): mask -1e8, argmax -> best_r, one-hot label at (best_r, teacher m), F.cross_entropy
+    with a float one-hot target (mean over the batch).  Returns (loss, best_r, teacher_m)."""
+    bs, R, M = probability.shape
+    prob = probability.masked_fill(r_pad.unsqueeze(-1), -1e8)
+    max_idx = torch.argmax(prob.reshape(bs, -1), dim=1)
+    best_r = max_idx // M
+    _, m_idx = sft_teacher_mode(candidate_trajectories, teacher_infos, frame_rate)
+    target = torch.zeros_like(prob)
+    target[torch.arange(bs), best_r, m_idx] = 1
+    loss = torch.nn.functional.cross_entropy(prob.reshape(bs, -1), target.reshape(bs, -1).detach())
+    return loss, best_r, m_idx

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librift_hip.so")
 
 # forward flags / loss kinds (include/rift_hip.h)
 F_TRAIN, F_NEED_TRAJ, F_FP32, F_NO_DROP, F_NO_BN_UPDATE = 1, 2, 4, 8, 16
-LOSS_KINDS = {"rift": 0, "grpo": 1, "ppo": 2, "reinforce": 3}
+LOSS_KINDS = {"rift": 0, "grpo": 1, "ppo": 2, "reinforce": 3, "sft": 4}
 PI_NPARAM = 16897
 
 vp = C.c_void_p
@@ -78,7 +78,7 @@ EXPORTS = [
     "rift_loss_finalize", "rift_loss_finalize_clip", "rift_set_param_event", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
-    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout",
+    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout", "rift_sft_teacher_mode",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -119,6 +119,7 @@ def load_library() -> C.CDLL:
     lib.rift_adamw_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                     C.c_double, C.c_double, vp]
+    lib.rift_sft_teacher_mode.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.rift_other_vehicle_rollout.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]
     lib.rift_collision_matrix.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     lib.rift_off_road_matrix.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int] + [C.c_double] * 7 + [vp, vp]
@@ -371,7 +372,7 @@ class Engine:
         flat = torch.zeros(PI_NPARAM, dtype=torch.float32, device=dev)
         lo.stats, lo.flat_grad_sum = stats.data_ptr(), flat.data_ptr()
         argmax = None
-        if kind == "reinforce":
+        if kind in ("reinforce", "sft"):          # chosen (r, m): REINFORCE's argmax / SFT's target label
             argmax = torch.zeros(self._bs, 2, dtype=torch.int64, device=dev)
             lo.argmax_rm = argmax.data_ptr()
         self._check(self.lib.rift_loss_backward(self.ctx, LOSS_KINDS[kind], C.byref(li), C.byref(lo), _stream()),
@@ -485,6 +486,18 @@ class Engine:
             self._check(self.lib.rift_other_vehicle_rollout(self.ctx, _ptr(act), _ptr(sp), _ptr(loc), _ptr(yaw), _ptr(ext), N, num_future_frames,
                                                             1 if near_lane_change else 0, float(bbox_inflation_ratio), _ptr(out), _stream()),
                         "rift_other_vehicle_rollout")
+        return out
+
+    def sft_teacher_mode(self, trajectory, teacher_infos, frame_rate: int = 10):
+        """generate_target_label's teacher side: trajectory (bs,R,M,T,6), teacher_infos (bs,5) -> (bs,2) int64 (r, m) of the candidate
+        whose PID target speed is closest to the teacher's; feed it as `action_mode_torch` to loss_backward("sft")."""
+        dev = self.device
+        tr = _dev(trajectory, torch.float32, dev)
+        ti = _dev(teacher_infos, torch.float32, dev)
+        bs, R, M, T, _ = tr.shape
+        out = torch.empty(bs, 2, dtype=torch.int64, device=dev)
+        self._check(self.lib.rift_sft_teacher_mode(self.ctx, _ptr(tr), _ptr(ti), bs, R, M, T, frame_rate, _ptr(out), _stream()),
+                    "rift_sft_teacher_mode")
         return out
 
     def collision_matrix(self, center_vertices, other_vertices, Ts: int = 40):

@@ -1433,6 +1433,7 @@ int rift_loss_backward(RiftCtx* c, int kind, const RiftLossIn* in, const RiftLos
   if (kind == RIFT_LOSS_GRPO && !p.ref_logits) { c->err = "missing ref logits"; return RIFT_ERR_ARG; }
   if (kind == RIFT_LOSS_PPO && (!p.action_mode || !p.scal_a || !p.old_log_prob)) { c->err = "missing ppo inputs"; return RIFT_ERR_ARG; }
   if (kind == RIFT_LOSS_REINFORCE && !p.scal_a) { c->err = "missing returns"; return RIFT_ERR_ARG; }
+  if (kind == RIFT_LOSS_SFT && !p.action_mode) { c->err = "missing teacher mode (action_mode)"; return RIFT_ERR_ARG; }
   const dim3 lgrid(cdiv(bs, 4)), lblock(256);
   if (G <= 64 * 2) launch(c, "loss_kernel", loss_kernel<2>, lgrid, lblock, 0, p);
   else if (G <= 64 * 4) launch(c, "loss_kernel", loss_kernel<4>, lgrid, lblock, 0, p);
@@ -1490,6 +1491,17 @@ int rift_off_road_matrix(RiftCtx* c, const float* rollout_center, int n_points, 
   HIPCHK(c, hipSetDevice(c->device));
   hipLaunchKernelGGL(off_road_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, (hipStream_t)stream, rollout_center, n_points, off_road_mask,
                      H, W, origin_x, origin_y, std::cos(heading), std::sin(heading), res_x, res_y, off_x, off_y, off_road);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_sft_teacher_mode(RiftCtx* c, const float* trajectory, const float* teacher_infos, int bs, int R, int M, int T, int frame_rate,
+                          int64_t* mode_rm, void* stream) {
+  if (!c || !trajectory || !teacher_infos || !mode_rm || bs <= 0 || R <= 0 || M <= 0 || T <= 0 || frame_rate <= 0) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(sft_teacher_mode_kernel, dim3(bs), dim3(64), 0, (hipStream_t)stream, trajectory, teacher_infos, bs, R * M, M, T, frame_rate,
+                     (long long*)mode_rm);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }

@@ -7,7 +7,7 @@
 
 namespace rift {
 
-enum { LOSS_RIFT = 0, LOSS_GRPO = 1, LOSS_PPO = 2, LOSS_REINFORCE = 3 };
+enum { LOSS_RIFT = 0, LOSS_GRPO = 1, LOSS_PPO = 2, LOSS_REINFORCE = 3, LOSS_SFT = 4 };
 
 // pi_head tail (mlp_layer.py:8-13 after the first Linear): per row  LN(128) -> ReLU -> dot(w2) + b2.
 // One wave per row.  Writes raw logits and the -1e6-masked `probability` (pluto_model.py:203).
@@ -157,7 +157,7 @@ __global__ void loss_kernel(LossP p) {
       // dH/dlp_j routed through dlogit below: dH/dz_j = -p_j (lp_j + H); expressed as gi on lp: g_j = -(p_j (lp_j + 1))
       gi[i] = -p.lambda_entropy * expf(lp[i]) * (lp[i] + 1.f) + (j == chosen ? gsel : 0.f);
     }
-  } else {   // REINFORCE, reinforce_trainer.py:125-170
+  } else {   // REINFORCE, reinforce_trainer.py:125-170; SFT shares the argmax
     // argmax over the masked logits, first index on ties (torch.argmax)
     float bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
@@ -170,11 +170,15 @@ __global__ void loss_kernel(LossP p) {
       const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
+    // SFT (sft_trainer.py:123-184): the target keeps the policy's own best reference line and takes the MODE of the teacher
+    // (generate_target_label :193-199); cross entropy against that one-hot label = -log p[target], mean over the batch
+    float ret = 1.0f;
+    if (p.kind == LOSS_SFT) bi = (bi / p.M) * p.M + (int)p.action_mode[(size_t)b * 2 + 1];
+    else ret = p.scal_a[b];
     float cur = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXPL; ++i) if (lane + i * 64 == bi) cur = lp[i];
     cur = wave_sum(cur);
-    const float ret = p.scal_a[b];
     S = (double)(cur * ret); cnt = 1.0;
 #pragma unroll
     for (int i = 0; i < MAXPL; ++i) if (lane + i * 64 == bi) gi[i] = ret;
@@ -193,6 +197,40 @@ __global__ void loss_kernel(LossP p) {
   }
   if (p.kind == LOSS_RIFT || p.kind == LOSS_GRPO) { S = wave_sum_d(S); cnt = wave_sum_d(cnt); }
   if (lane == 0) { p.S[b] = S; p.cnt[b] = cnt; }
+}
+
+// SFT teacher label, the mode index (sft_trainer.py:186-199 with sft/utils.py:10-32 and pid_controller.py:108-125): every candidate's
+// trajectory is sub-sampled every `fr` frames, moved to the teacher's local frame (fp32, as the reference's einsum does), its target
+// speed is the mean distance between consecutive sub-sampled points, and the label takes the mode index of the candidate -- padded
+// reference lines included, as in the reference -- whose target speed is closest to the teacher's (first minimum).  One wave per scene.
+__global__ __launch_bounds__(64) void sft_teacher_mode_kernel(const float* __restrict__ traj /*(bs,G,T,6)*/, const float* __restrict__ teacher /*(bs,5)*/,
+                                                              int bs, int G, int M, int T, int fr, long long* __restrict__ mode_out /*(bs,2)*/) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= bs) return;
+  const float tsp = teacher[b * 5], ox = teacher[b * 5 + 1], oy = teacher[b * 5 + 2], hd = teacher[b * 5 + 3];
+  const float c = cosf(hd), s = sinf(hd);
+  const int np_ = T < fr ? 1 : T / fr;
+  float best = INFINITY; int bi = 0x7fffffff;
+  for (int g = lane; g < G; g += 64) {
+    const float* q = traj + ((size_t)b * G + g) * T * 6;
+    float px = 0.f, py = 0.f, acc = 0.f, speed;
+    for (int k = 0; k < np_; ++k) {
+      const int t = T < fr ? T - 1 : fr - 1 + k * fr;
+      const float dx = q[t * 6] - ox, dy = q[t * 6 + 1] - oy;
+      const float lx = dx * c + dy * s, ly = dx * (-s) + dy * c;          // (p - origin) . [[cos, -sin], [sin, cos]]
+      if (k > 0) acc += sqrtf((lx - px) * (lx - px) + (ly - py) * (ly - py));
+      px = lx; py = ly;
+    }
+    speed = np_ == 1 ? sqrtf(px * px + py * py) : acc / (float)(np_ - 1);
+    const float d = fabsf(speed - tsp);
+    if (d < best) { best = d; bi = g; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { mode_out[(size_t)b * 2] = bi / M; mode_out[(size_t)b * 2 + 1] = bi % M; }
 }
 
 // Backward through pi_head for a chunk of rows.  partial layout per workgroup (floats):

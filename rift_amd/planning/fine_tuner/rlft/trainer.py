@@ -125,6 +125,8 @@ class RLFTTrainer:
                 "the HIP backward covers the reference's configured trainable sets: ['planning_decoder.pi_head'] "
                 "(rift_training.yaml:26-27) and, for PPO, ['planning_decoder.pi_head', 'value_net'] (ppo_training.yaml:26-28)")
         self.model, self.kind, self.kind_id = model, kind, _ffi.LOSS_KINDS[kind]
+        if kind == "sft":      # the teacher label is read off the candidate trajectories (sft_trainer.py:186-199): the heads must run
+            model.need_traj = True
         self.lr, self.epochs, self.warmup_epochs = lr, epochs, warmup_epochs
         self.gradient_clip_val = gradient_clip_val
         self.pg = process_group
@@ -238,6 +240,9 @@ class RLFTTrainer:
                 (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0) | flags_extra
         self.step_count += 1
         eng.forward_raw(fb, self.out, flags, self.step_count)
+        if self.kind == "sft":   # label = (the policy's best line, the teacher's mode); extras["teacher_infos"]: (bs, 5) as SFTDataModule yields
+            extras = dict(extras)
+            extras["action_mode"] = eng.sft_teacher_mode(self._traj[0][:fb.bs], extras["teacher_infos"])
         self.set_loss_inputs(extras)
         eng.loss_backward_raw(self.kind_id, self.li, self.lo)
         if self.critic is not None:   # value loss half of get_ppo_loss (ppo_trainer.py:175-176,183)

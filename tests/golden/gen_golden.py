@@ -413,8 +413,48 @@ def gen_other_vehicles():
     print("other vehicles ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", out["vertices"].shape, out["vertices"].dtype, out["config"])
 
 
+def gen_sft():
+    """SFT teacher objective as the reference computes it: LightningTrainer._compute_objectives / get_teacher_loss / generate_target_label
+    (fine_tuner/sft/sft_trainer.py:123-199) compiled in memory, sft/utils.global_to_local and PIDController imported from the reference."""
+    import importlib.util
+    import types
+    import torch.nn.functional as F
+    from tests.helpers import sft_inputs
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref_loader.REF_ROOT, rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    g2l = load("ref_sft_utils", "rift/cbv/planning/fine_tuner/sft/utils.py").global_to_local
+    pid = load("ref_pid2", "rift/cbv/planning/pluto/controller/pid_controller.py").PIDController()
+    T_ = "rift/cbv/planning/fine_tuner/sft/sft_trainer.py"
+    ns = {"F": F, "global_to_local": g2l, "Dict": dict}
+    objectives = _ref_function(T_, "_compute_objectives", ns)
+    fake = types.SimpleNamespace(controller=pid, frame_rate=10)
+    fake.generate_target_label = types.MethodType(_ref_function(T_, "generate_target_label", ns), fake)
+    fake.get_teacher_loss = types.MethodType(_ref_function(T_, "get_teacher_loss", ns), fake)
+    inp = sft_inputs()
+    prob = inp["probability"].clone().requires_grad_(True)
+    cur_res = {"trajectory": inp["trajectory"].clone(), "probability": prob * 1.0}
+    cur_data = {"reference_line": {"valid_mask": inp["ref_valid_mask"]}}
+    out = objectives(fake, cur_res, cur_data, {"teacher_infos": inp["teacher_infos"]})
+    out["loss"].backward()
+    target, _ = fake.generate_target_label(inp["trajectory"], cur_res["probability"].detach(), inp["teacher_infos"],
+                                           torch.argmax(cur_res["probability"].detach().view(prob.shape[0], -1), 1) // 12,
+                                           torch.argmax(cur_res["probability"].detach().view(prob.shape[0], -1), 1) % 12)
+    tgt = target.view(prob.shape).nonzero()
+    res = {"loss": np.array(float(out["loss"])), "dloss_dprob": prob.grad.numpy(), "target_r": tgt[:, 1].numpy(), "target_m": tgt[:, 2].numpy()}
+    path = os.path.join(HERE, "sft.npz")
+    np.savez_compressed(path, **res)
+    print("sft ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", float(out["loss"]), res["target_r"].tolist(), res["target_m"].tolist())
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "other_vehicles":
+    if len(sys.argv) > 1 and sys.argv[1] == "sft":
+        gen_sft()
+    elif len(sys.argv) > 1 and sys.argv[1] == "other_vehicles":
         gen_other_vehicles()
     elif len(sys.argv) > 1 and sys.argv[1] == "inference":
         gen_inference()
@@ -429,3 +469,4 @@ if __name__ == "__main__":
         gen_critic()
         gen_inference()
         gen_other_vehicles()
+        gen_sft()

@@ -158,3 +158,24 @@ def other_vehicle_inputs(seed=4242, N=7):
             "speed": np.concatenate([[0.2, 0.9], g.uniform(1.5, 14.0, N - 2)]),        # two actors below the 1 m/s extent threshold
             "location": np.stack([g.normal(20, 15, N), g.normal(-5, 15, N), g.uniform(0, 0.3, N)], -1),
             "yaw_deg": g.uniform(-180, 180, N), "extent": np.stack([g.uniform(1.8, 2.6, N), g.uniform(0.8, 1.1, N)], -1)}
+
+
+def sft_inputs(seed=31337, bs=6, R=4, M=12, T=80):
+    """Seeded inputs of the SFT teacher objective (tests/golden/sft.npz): policy logits with the model's -1e6 on padded reference lines,
+    candidate trajectories (padded lines hold values too, as the model emits them), ragged valid lines, teacher_infos (bs, 5) =
+    target speed, origin x, y, heading, speed."""
+    g = torch.Generator().manual_seed(seed)
+    rcount = torch.tensor([1, 4, 2, 3, 4, 1])[:bs]
+    rvalid = torch.arange(R)[None, :] < rcount[:, None]
+    prob = torch.randn(bs, R, M, generator=g)
+    prob = prob.masked_fill(~rvalid[..., None], -1e6)
+    v = 1.0 + 11.0 * torch.rand(bs, R, M, generator=g)
+    kappa = torch.randn(bs, R, M, generator=g) * 0.02
+    t = torch.arange(1, T + 1, dtype=torch.float32) * 0.1
+    th = kappa[..., None] * v[..., None] * t + torch.randn(bs, R, M, 1, generator=g) * 0.1
+    pos = torch.cumsum(torch.stack([th.cos(), th.sin()], -1) * (v[..., None, None] * 0.1), dim=3) + torch.randn(bs, 1, 1, 1, 2, generator=g) * 20
+    traj = torch.cat([pos, th.cos()[..., None], th.sin()[..., None], torch.zeros(bs, R, M, T, 2)], -1).float().contiguous()
+    teacher = torch.stack([1.0 + 10.0 * torch.rand(bs, generator=g), pos[:, 0, 0, 0, 0], pos[:, 0, 0, 0, 1],
+                           torch.rand(bs, generator=g) * 2 - 1, 3.0 + 5.0 * torch.rand(bs, generator=g)], -1).float()
+    return {"probability": prob, "trajectory": traj, "ref_valid_mask": rvalid[..., None].expand(bs, R, 120).contiguous(),
+            "r_pad": ~rvalid, "teacher_infos": teacher}

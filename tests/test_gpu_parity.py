@@ -748,3 +748,40 @@ def test_other_vehicle_rollout_matches_reference_fixture(ffi):
     have = eng.collision_matrix(torch.from_numpy(cand80), got, Ts=40).cpu().numpy()
     assert 0.05 < want.mean() < 0.95 and (have != want).mean() < 2e-3         # an ulp-level edge case may flip a single flag
     eng.close()
+
+
+def test_sft_teacher_loss_and_pi_head_grads(ffi):
+    """§8(f) rank 3, the SFT objective on the device: rift_sft_teacher_mode (integer label, bit-exact against the reference fixture)
+    and loss kind "sft" (cross entropy against (the policy's best reference line, the teacher's mode), analytic pi_head backward)
+    against the oracle on the HIP forward's own fp32 outputs: loss 1e-5, gradients 1e-4 relative."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sft.npz"))
+    eng = ffi.Engine("cuda:0")
+    inp = H.sft_inputs()
+    rm = eng.sft_teacher_mode(inp["trajectory"], inp["teacher_infos"]).cpu().numpy()
+    assert np.array_equal(rm[:, 1], gold["target_m"])                      # the mode index is what enters the label
+    # end to end on the model: forward with the trajectory head, label from the device, loss + backward
+    g_, batch, sd, data, eng2, out = _run_case(ffi, "small", True)
+    bs = out["probability"].shape[0]
+    gen = torch.Generator().manual_seed(17)
+    traj = out["trajectory"].detach().cpu()
+    teacher = torch.stack([2.0 + 8.0 * torch.rand(bs, generator=gen), torch.zeros(bs), torch.zeros(bs), torch.rand(bs, generator=gen) - 0.5,
+                           4.0 + torch.rand(bs, generator=gen)], -1)
+    ref, _, taps = pluto_ref.planning_model_forward(sd, H.clone_tree(data), need_traj=True, want_taps=True)
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    b = H.clone_tree(batch)
+    b["trajectory_torch"], b["teacher_infos_torch"] = ref["trajectory"], teacher
+    loss_o, grads_o, _ = losses.pi_head_loss_and_grads(sd, taps["q_final"], "sft", b, r_pad)
+    _, best_r_o, m_o = losses.sft_loss(ref["probability"], r_pad, ref["trajectory"], teacher)
+    mode = eng2.sft_teacher_mode(out["trajectory"], teacher)
+    assert np.array_equal(mode[:, 1].cpu().numpy(), m_o.numpy())
+    b["action_mode_torch"] = mode
+    stats, flat, chosen = eng2.loss_backward("sft", b)
+    grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
+    loss = float(eng2.loss_finalize(stats, flat, grads).item())
+    assert np.array_equal(chosen[:, 0].cpu().numpy(), best_r_o.numpy()) and np.array_equal(chosen[:, 1].cpu().numpy(), m_o.numpy())
+    assert abs(loss - float(loss_o)) < 1e-5
+    for k in grads:
+        refg = grads_o[k]
+        assert err(grads[k], refg) < 1e-5 + 1e-4 * float(refg.abs().max()), k
+    eng.close(); eng2.close()

@@ -256,3 +256,39 @@ def test_update_on_second_stream_equals_serial_update(tmp_path, monkeypatch):
     assert [(h["train_loss"], h["val_loss"]) for h in h0] == [(h["train_loss"], h["val_loss"]) for h in h1]
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+
+
+@pytest.mark.gpu
+def test_sft_kind_trains_pi_head_towards_the_teacher_mode():
+    """RLFTTrainer(kind="sft"): the teacher cross entropy with the label built on the device falls over a few
+    steps on a fixed minibatch and only pi_head moves."""
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+    from rift_amd.replay import DeviceReplay
+    from tests import helpers as H
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    scenes = [syn.make_scene(700 + i, num_agents=12, num_polygons=8, r_min=1, r_max=3) for i in range(16)]
+    replay = DeviceReplay(scenes, dev, rcap=3)
+    model = PlanningModel(radius=120)
+    model.load_state_dict(H.weights())
+    model = model.to(dev)
+    model.train()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tr = RLFTTrainer(model, kind="sft", lr=3e-3, gradient_clip_val=0.5)
+    idx = torch.arange(16, dtype=torch.int32, device=dev)
+    g = torch.Generator().manual_seed(2)
+    teacher = torch.stack([2.0 + 6.0 * torch.rand(16, generator=g), torch.zeros(16), torch.zeros(16), torch.zeros(16), 5.0 * torch.ones(16)], -1).to(dev)
+    losses_ = []
+    model._no_drop = True
+    for _ in range(12):
+        fb, b = replay.collate(tr.engine, idx)
+        b = dict(b)
+        b["teacher_infos"] = teacher
+        tr.training_step(fb, b)
+        tr.wait_update()
+        losses_.append(float(tr.loss.item()))
+    assert all(np.isfinite(losses_)) and losses_[-1] < losses_[0] - 0.05, losses_
+    after = model.state_dict()
+    moved = [k for k in before if not torch.equal(before[k], after[k]) and "num_batches_tracked" not in k and "running_" not in k]
+    assert moved and all(k.startswith("planning_decoder.pi_head") for k in moved), moved

@@ -62,3 +62,18 @@ def test_other_vehicle_rollout_oracle_matches_reference_fixture():
     assert got.shape == gold["vertices"].shape == (7, 40, 4, 2) and got.dtype == np.float64
     assert np.array_equal(got, gold["vertices"])                                  # same numpy operations in the same order: bit-exact
     assert otf.get_other_vehicle_rollout(*[np.zeros((0,))] * 4, np.zeros((0, 3)), np.zeros((0,)), np.zeros((0, 2))).shape == tuple(gold["vertices_empty_shape"])
+
+
+def test_sft_teacher_objective_oracle_matches_reference_fixture():
+    """oracle/losses.sft_loss against tests/golden/sft.npz, the output of the reference's own _compute_objectives / get_teacher_loss /
+    generate_target_label + sft/utils.global_to_local + PIDController.batch_control_pid on H.sft_inputs: loss, d loss / d logits and the
+    integer target label (best reference line of the policy, mode of the teacher) bit-exact."""
+    from oracle import losses
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sft.npz"))
+    inp = H.sft_inputs()
+    prob = inp["probability"].clone().requires_grad_(True)
+    loss, best_r, m_idx = losses.sft_loss(prob * 1.0, inp["r_pad"], inp["trajectory"], inp["teacher_infos"])
+    loss.backward()
+    assert np.array_equal(best_r.numpy(), gold["target_r"]) and np.array_equal(m_idx.numpy(), gold["target_m"])
+    assert abs(float(loss) - float(gold["loss"])) < 1e-6
+    assert np.abs(prob.grad.numpy() - gold["dloss_dprob"]).max() < 1e-7
