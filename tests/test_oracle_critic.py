@@ -75,5 +75,5 @@ def test_sft_teacher_objective_oracle_matches_reference_fixture():
     loss, best_r, m_idx = losses.sft_loss(prob * 1.0, inp["r_pad"], inp["trajectory"], inp["teacher_infos"])
     loss.backward()
     assert np.array_equal(best_r.numpy(), gold["target_r"]) and np.array_equal(m_idx.numpy(), gold["target_m"])
-    assert abs(float(loss) - float(gold["loss"])) < 1e-6
+    assert abs(float(loss.detach()) - float(gold["loss"])) < 1e-6
     assert np.abs(prob.grad.numpy() - gold["dloss_dprob"]).max() < 1e-7
