@@ -860,9 +860,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   } else {
     speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
   }
-  launch(c, "agent_token_kernel", agent_token_kernel, dim3(cdiv((long long)nA * 128, 256)), dim3(256), 0, (const float*)nat_out, (const float*)x_ego,
+  launch(c, "agent_token_kernel", agent_token_kernel, dim3(cdiv((long long)nA * 32, 256)), dim3(256), 0, (const float*)nat_out, (const float*)x_ego,
          (const uint8_t*)valid_agent, B->agent_category, fptr(c, "agent_encoder.type_emb.weight"), bs, A, N, X, (const float*)PEtok);
-  launch(c, "polygon_token_kernel", polygon_token_kernel, dim3(cdiv((long long)nP * 128, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
+  launch(c, "polygon_token_kernel", polygon_token_kernel, dim3(cdiv((long long)nP * 32, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
          B->map_polygon_on_route, B->map_polygon_tl_status, B->map_polygon_has_speed_limit, (const float*)speed_emb,
          fptr(c, "map_encoder.type_emb.weight"), fptr(c, "map_encoder.on_route_emb.weight"),
          fptr(c, "map_encoder.traffic_light_emb.weight"), fptr(c, "map_encoder.unknown_speed_emb.weight"), bs, A, Mp, N, X, (const float*)PEtok);

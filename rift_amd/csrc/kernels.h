@@ -573,14 +573,18 @@ __global__ void agent_token_kernel(const float* __restrict__ nat, const float* _
                                    const uint8_t* __restrict__ valid_agent, const int8_t* __restrict__ category,
                                    const float* __restrict__ type_emb, int bs, int A, int N, float* __restrict__ X,
                                    const float* __restrict__ pe /*optional (bs*N,128) positional embedding added on the way*/) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= bs * A * 128) return;
-  const int c = idx & 127, a = (idx >> 7) % A, b = idx / (A * 128);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // one thread = 4 channels of one agent token (16-byte accesses)
+  if (idx >= bs * A * 32) return;
+  const int c = (idx & 31) * 4, a = (idx >> 5) % A, b = idx / (A * 32);
   const int ag = b * A + a;
-  float v = (a == 0) ? x_ego[(size_t)b * 128 + c] : (valid_agent[ag] ? nat[(size_t)ag * 128 + c] : 0.f);
-  v += type_emb[(int)category[ag] * 128 + c];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a == 0) v = *reinterpret_cast<const float4*>(x_ego + (size_t)b * 128 + c);
+  else if (valid_agent[ag]) v = *reinterpret_cast<const float4*>(nat + (size_t)ag * 128 + c);
+  const float4 t = *reinterpret_cast<const float4*>(type_emb + (int)category[ag] * 128 + c);
+  v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
   const size_t o = ((size_t)b * N + a) * 128 + c;
-  X[o] = pe ? v + pe[o] : v;
+  if (pe) { const float4 q = *reinterpret_cast<const float4*>(pe + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+  *reinterpret_cast<float4*>(X + o) = v;
 }
 
 // polygon tokens (map_encoder.py:82-91): x = pooled + type + on_route + tl + (has ? speed_emb : unknown)
@@ -590,15 +594,19 @@ __global__ void polygon_token_kernel(const float* __restrict__ pooled, const int
                                      const float* __restrict__ type_emb, const float* __restrict__ route_emb,
                                      const float* __restrict__ tl_emb, const float* __restrict__ unk_emb, int bs,
                                      int A, int Mp, int N, float* __restrict__ X, const float* __restrict__ pe) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= bs * Mp * 128) return;
-  const int c = idx & 127, m = (idx >> 7) % Mp, b = idx / (Mp * 128);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // one thread = 4 channels of one polygon token
+  if (idx >= bs * Mp * 32) return;
+  const int c = (idx & 31) * 4, m = (idx >> 5) % Mp, b = idx / (Mp * 32);
   const int pg = b * Mp + m;
-  float v = pooled[(size_t)pg * 128 + c] + type_emb[(int)ptype[pg] * 128 + c] +
-            route_emb[(on_route[pg] ? 1 : 0) * 128 + c] + tl_emb[(int)tl[pg] * 128 + c];
-  v += has_sl[pg] ? speed_emb[(size_t)pg * 128 + c] : unk_emb[c];
+  auto ld = [&](const float* p) { return *reinterpret_cast<const float4*>(p + c); };
+  const float4 a0 = ld(pooled + (size_t)pg * 128), a1 = ld(type_emb + (int)ptype[pg] * 128), a2 = ld(route_emb + (on_route[pg] ? 1 : 0) * 128),
+               a3 = ld(tl_emb + (int)tl[pg] * 128), a4 = has_sl[pg] ? ld(speed_emb + (size_t)pg * 128) : ld(unk_emb);
+  // same association as the scalar form: ((pooled + type) + route) + tl, then + speed
+  float4 v = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w);
+  v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
   const size_t o = ((size_t)b * N + A + m) * 128 + c;
-  X[o] = pe ? v + pe[o] : v;
+  if (pe) { const float4 q = *reinterpret_cast<const float4*>(pe + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+  *reinterpret_cast<float4*>(X + o) = v;
 }
 
 // static-object tokens (static_objects_encoder.py:24-26): valid ? fourier(shape) + type_emb : 0
