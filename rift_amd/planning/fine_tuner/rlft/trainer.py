@@ -117,15 +117,18 @@ class RLFTTrainer:
     def __init__(self, model, kind: str = "rift", lr=1e-4, cl_lr_decay=0.9, weight_decay=1e-5, epochs=16,
                  warmup_epochs=3, trainable_layers=(PI_HEAD,), gradient_clip_val=0.5, process_group=None,
                  clip_epsilon=0.2, lambda_entropy=0.01):
-        if kind not in _ffi.LOSS_KINDS:
+        if kind not in _ffi.LOSS_KINDS and kind != "rtr":
             raise ValueError(kind)
-        want = (PI_HEAD, "value_net") if kind == "ppo" else (PI_HEAD,)
+        want = (PI_HEAD, "value_net") if kind in ("ppo", "rtr") else (PI_HEAD,)
         if tuple(trainable_layers) != want:
             raise NotImplementedError(
                 "the HIP backward covers the reference's configured trainable sets: ['planning_decoder.pi_head'] "
                 "(rift_training.yaml:26-27) and, for PPO, ['planning_decoder.pi_head', 'value_net'] (ppo_training.yaml:26-28)")
-        self.model, self.kind, self.kind_id = model, kind, _ffi.LOSS_KINDS[kind]
-        if kind == "sft":      # the teacher label is read off the candidate trajectories (sft_trainer.py:186-199): the heads must run
+        # "rtr" (fine_tuner/sft/rtr_pluto/rtr_trainer.py:131-171) = lambda_rl * PPO objective + teacher cross entropy: two passes of the
+        # loss kernels over the same forward, the second accumulated into .grad
+        self.model, self.kind, self.kind_id = model, kind, _ffi.LOSS_KINDS["ppo" if kind == "rtr" else kind]
+        self.lambda_rl = 5.0                                     # rtr_trainer.py:153
+        if kind in ("sft", "rtr"):      # the teacher label is read off the candidate trajectories (sft_trainer.py:186-199): the heads must run
             model.need_traj = True
         self.lr, self.epochs, self.warmup_epochs = lr, epochs, warmup_epochs
         self.gradient_clip_val = gradient_clip_val
@@ -144,7 +147,7 @@ class RLFTTrainer:
         self.train_params = list(self.params.values())
         # PPO: the critic (every parameter of value_net is trainable in the reference, normalisation constants included)
         self.critic = None
-        if kind == "ppo":
+        if kind in ("ppo", "rtr"):
             vn = dict(model.named_modules())["value_net"]
             self.critic = {k: dict(vn.named_parameters())[k] for k in _ffi.CRITIC_KEYS}
             for p in self.critic.values():
@@ -205,7 +208,7 @@ class RLFTTrainer:
             self._argmax = torch.zeros(bs, 2, dtype=torch.int64, device=dev)
             # `hidden` (pluto_model.py:173-176) feeds only PPO's critic; the other objectives never read it
             self.out.probability = self._prob.data_ptr()
-            self.out.hidden = self._hidden.data_ptr() if (self.kind == "ppo" or getattr(self.model, "need_traj", False)) else None
+            self.out.hidden = self._hidden.data_ptr() if (self.kind in ("ppo", "rtr") or getattr(self.model, "need_traj", False)) else None
             self.lo.argmax_rm = self._argmax.data_ptr()
             self._traj = None
         if getattr(self.model, "need_traj", False) and self._traj is None:
@@ -251,21 +254,37 @@ class RLFTTrainer:
             self.xchg[_ffi.PI_NPARAM:].copy_(self.stats)   # the value-loss term joined stats after the exchange buffer was filled
         if defer_update:     # the caller runs exchange / finalize / clip / optimizer (on the update stream)
             return self.loss
+        if self.kind == "rtr":
+            # weight the PPO pass by lambda_rl: loss = -S/cnt and grad = -flat/cnt, so dividing the count does it for the actor, the
+            # critic and the reported loss alike (after the exchange: the count is summed over ranks first)
+            self._exchange_and_finalize(backward, None, count_scale=1.0 / self.lambda_rl)
+            loss_rl = self.loss.clone()
+            ex2 = dict(extras)
+            ex2["action_mode"] = eng.sft_teacher_mode(self._traj[0][:fb.bs], extras["teacher_infos"])
+            self.set_loss_inputs(ex2)
+            eng.loss_backward_raw(_ffi.LOSS_KINDS["sft"], self.li, self.lo)
+            self._exchange_and_finalize(backward, None, accumulate=1, with_critic=False)
+            self.loss.add_(loss_rl)
+            return self.loss
         self._exchange_and_finalize(backward, clip_val)
         return self.loss
 
-    def _exchange_and_finalize(self, backward: bool, clip_val: Optional[float]):
+    def _exchange_and_finalize(self, backward: bool, clip_val: Optional[float], accumulate: int = 0, with_critic: bool = True,
+                               count_scale: float = 1.0):
         eng = self.engine
+        with_critic = with_critic and self.critic is not None
         if self.pg is not None and (self.world > 1 or self.force_exchange):
             dp_all_reduce_exchange(self.xchg, self.pg)
-            if self.critic is not None:
+            if with_critic:
                 torch.distributed.all_reduce(self.flat_c, group=self.pg)
+        if count_scale != 1.0:
+            (self.xchg[_ffi.PI_NPARAM + 1:] if (self.xchg is not None and self.lo.exchange) else self.stats[1:]).mul_(count_scale)
         if backward:
             if clip_val and self.critic is None:
-                eng.loss_finalize_clip_raw(self.lo, 0, float(clip_val), self.grad_norm)
+                eng.loss_finalize_clip_raw(self.lo, accumulate, float(clip_val), self.grad_norm)
             else:
-                eng.loss_finalize_raw(self.lo, 0)
-            if self.critic is not None:
+                eng.loss_finalize_raw(self.lo, accumulate)
+            if with_critic:
                 eng.critic_finalize_raw(self.flat_c, self.stats, [p.grad for p in self.critic.values()])
         else:   # validation: loss only, the .grad buffers are left untouched
             lv = _ffi.RiftLossOut()

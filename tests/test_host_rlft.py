@@ -292,3 +292,52 @@ def test_sft_kind_trains_pi_head_towards_the_teacher_mode():
     after = model.state_dict()
     moved = [k for k in before if not torch.equal(before[k], after[k]) and "num_batches_tracked" not in k and "running_" not in k]
     assert moved and all(k.startswith("planning_decoder.pi_head") for k in moved), moved
+
+
+@pytest.mark.gpu
+def test_rtr_objective_is_five_ppo_plus_teacher():
+    """RLFTTrainer(kind="rtr") (rtr_trainer.py:131-171: loss = 5 * PPO objective + teacher cross entropy, pi_head and value_net trainable):
+    on one fixed minibatch in fp32 with the drops off, its loss and gradients equal 5 x those of kind="ppo" plus those of kind="sft"
+    (each of which is checked against the oracle on its own), the critic's gradients 5 x PPO's."""
+    from rift_amd.planning.fine_tuner.rlft.ppo_pluto.ppo_pluto import PPOPlutoModel
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.replay import DeviceReplay
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    scenes = [syn.make_scene(800 + i, num_agents=12, num_polygons=8, r_min=1, r_max=3) for i in range(8)]
+    replay = DeviceReplay(scenes, dev, rcap=3)
+    idx = torch.arange(8, dtype=torch.int32, device=dev)
+    g = torch.Generator().manual_seed(4)
+    extras = {"teacher_infos": torch.stack([2.0 + 6.0 * torch.rand(8, generator=g), torch.zeros(8), torch.zeros(8), torch.zeros(8), 5.0 * torch.ones(8)], -1).to(dev),
+              "action_mode": torch.stack([s["extras"]["action_mode"] for s in scenes]).to(dev),
+              "advantage": torch.randn(8, generator=g).to(dev), "old_log_prob": (-2.0 - torch.rand(8, generator=g)).to(dev),
+              "state": torch.randn(8, 128, generator=g).to(dev), "reward_sum": torch.randn(8, generator=g).to(dev)}
+    torch.manual_seed(11)
+    base = PPOPlutoModel(radius=120)
+    sd0 = {k: v.clone() for k, v in base.state_dict().items()}
+    res = {}
+    for kind in ("ppo", "sft", "rtr"):
+        model = PPOPlutoModel(radius=120)
+        model.load_state_dict(sd0)
+        model = model.to(dev)
+        model.train()
+        model.compute_precision, model._no_drop = "fp32", True
+        layers = ("planning_decoder.pi_head",) if kind == "sft" else ("planning_decoder.pi_head", "value_net")
+        tr = RLFTTrainer(model, kind=kind, trainable_layers=layers)
+        fb, b = replay.collate(tr.engine, idx)
+        b = dict(b)
+        b.update(extras)
+        loss = tr.forward_loss(fb, b, train=True)
+        torch.cuda.synchronize()
+        res[kind] = (float(loss.item()), {k: p.grad.detach().cpu().clone() for k, p in tr.params.items()},
+                     {k: p.grad.detach().cpu().clone() for k, p in tr.critic.items()} if tr.critic else None)
+        tr.engine.close()
+    lp, gp, cp = res["ppo"]
+    ls, gs, _ = res["sft"]
+    lr_, gr, cr = res["rtr"]
+    assert abs(lr_ - (5.0 * lp + ls)) < 1e-5 * max(1.0, abs(lr_))
+    for k in gr:
+        want = 5.0 * gp[k] + gs[k]
+        assert float((gr[k] - want).abs().max()) < 1e-6 + 1e-5 * float(want.abs().max()), k
+    for k in cr:
+        assert float((cr[k] - 5.0 * cp[k]).abs().max()) < 1e-6 + 1e-5 * float(cp[k].abs().max()) * 5.0, k
