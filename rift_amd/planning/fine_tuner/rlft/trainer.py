@@ -186,9 +186,10 @@ class RLFTTrainer:
         # Only pi_head is trainable, so the frozen trunk of step k+1 does not depend on the update of step k: exchange + finalize +
         # clip + AdamW run on a second stream, and the engine waits for their end right before it reads pi_head (rift_set_param_event).
         # Hides the all-reduce latency under the next forward (DP) and the latency-bound update tail (any world size).
-        # On by default only when there IS a collective to hide (world > 1): on one GPU the two-stream order measured 0.3-2 % slower
-        # (the single-workgroup update kernels share CUs with the next step's first kernels).  RIFT_OVERLAP=1 / RIFT_NO_OVERLAP=1 force it.
-        want = (self.pg is not None and self.world > 1) or os.environ.get("RIFT_OVERLAP", "0") == "1"
+        # Opt-in (RIFT_OVERLAP=1): on one GPU there is no collective to hide and the two-stream order measured 0.3-2 % slower (the
+        # single-workgroup update kernels share CUs with the next step's first kernels); with several ranks it hides the all-reduce,
+        # but that could not be measured on the single-GPU boxes of this round, so the serial order stays the default everywhere.
+        want = os.environ.get("RIFT_OVERLAP", "0") == "1"
         self.overlap_update = (want and self.critic is None and dev.type == "cuda" and os.environ.get("RIFT_NO_OVERLAP", "0") != "1")
         self.loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)      # sum of training losses since pop_mean_loss()
         self.loss_n = 0

@@ -232,7 +232,7 @@ def test_update_on_second_stream_equals_serial_update(tmp_path, monkeypatch):
     from rift_amd.planning import CBV_POLICY_LIST
     torch.cuda.set_device(0)
     results = {}
-    monkeypatch.setenv("RIFT_OVERLAP", "1")               # the two-stream order is the default only with world > 1
+    monkeypatch.setenv("RIFT_OVERLAP", "1")               # the two-stream order is opt-in
     for mode in ("0", "1"):
         monkeypatch.setenv("RIFT_NO_OVERLAP", mode)
         root = tmp_path / mode
