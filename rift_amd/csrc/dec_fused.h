@@ -3,9 +3,10 @@
 // buffers) across   r2r self-attention over the R reference lines (with the reference's
 // `tgt_key_padding_mask.repeat(M, 1)` mask quirk, :56-60)  ->  m2m self-attention over the 12 modes (+m_pos on
 // q/k, padded lines zeroed, :62-72)  ->  cross attention against the scene's encoder tokens (MFMA, :74-79)  ->
-// FFN (:81-83).  The cross-attention K/V projections of the encoder tokens are produced beforehand by the
-// generic GEMM (one per layer) and streamed into LDS per 2-head chunk.  All GEMMs are bf16 MFMA with swapped
-// operands (row-contiguous epilogues); the two tiny self-attentions are fp32 VALU over LDS.
+// FFN (:81-83).  The cross-attention K | V^T operands of the encoder tokens come as bf16 images written by the encoder kernel's tail
+// (or as fp32 rows from the projection GEMM when that kernel is not fused) and are streamed into LDS per 2-head chunk.  All GEMMs are
+// bf16 MFMA with swapped operands (row-contiguous epilogues); the r2r / m2m self-attentions are MFMA too (one 16x16 score tile per
+// group and head, see self_attention).
 #pragma once
 #include <type_traits>
 #include "enc_fused.h"
