@@ -117,6 +117,8 @@ class RLFTTrainer:
     def __init__(self, model, kind: str = "rift", lr=1e-4, cl_lr_decay=0.9, weight_decay=1e-5, epochs=16,
                  warmup_epochs=3, trainable_layers=(PI_HEAD,), gradient_clip_val=0.5, process_group=None,
                  clip_epsilon=0.2, lambda_entropy=0.01):
+        if kind == "rs":     # RS's objective (fine_tuner/sft/rs_pluto/rs_trainer.py:120-170) is REINFORCE's, line for line
+            kind = "reinforce"
         if kind not in _ffi.LOSS_KINDS and kind != "rtr":
             raise ValueError(kind)
         want = (PI_HEAD, "value_net") if kind in ("ppo", "rtr") else (PI_HEAD,)
