@@ -137,3 +137,22 @@ def test_config0_grpo_step_on_dumped_carla_shaped_scenes(tmp_path):
         ref = grads_o[k]
         assert float((grads[k].cpu() - ref).abs().max()) < 1e-5 + 1e-4 * float(ref.abs().max()), k
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agents,polygons,rmax", [(76, 20, 6), (77, 20, 6), (64, 20, 7)])
+def test_fused_kernel_size_limits(ffi, agents, polygons, rmax):
+    """At and just beyond what the one-scene-per-workgroup kernels hold: N = 96 tokens exactly fills the encoder / decoder-key tiles
+    (76 agents + 20 polygons), N = 97 and R = 7 (84 queries > 80) must take the layer-wise route -- all three against the oracle,
+    bf16 and fp32, eval and the loss."""
+    scenes = [syn.make_scene(6000 + i, num_agents=agents, num_polygons=polygons, r_min=rmax, r_max=rmax) for i in range(3)]
+    eng = ffi.Engine("cuda:0")
+    eng.load_state_dict({k: v.clone() for k, v in H.weights().items()})
+    eng.prof_enable(True)
+    eng.forward(syn.collate_scenes(scenes)["cur_pluto_feature_torch"], fp32=False)
+    rep = eng.prof_report()
+    eng.prof_enable(False)
+    eng.close()
+    assert ("enc_fused_kernel" in rep) == (agents + polygons <= 96)
+    assert ("dec_fused_kernel" in rep) == (agents + polygons <= 96 and rmax * 12 <= 80)
+    _check(ffi, scenes, train=False)
