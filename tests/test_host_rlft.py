@@ -341,3 +341,38 @@ def test_rtr_objective_is_five_ppo_plus_teacher():
         assert float((gr[k] - want).abs().max()) < 1e-6 + 1e-5 * float(want.abs().max()), k
     for k in cr:
         assert float((cr[k] - 5.0 * cp[k]).abs().max()) < 1e-6 + 1e-5 * float(cp[k].abs().max()) * 5.0, k
+
+
+@pytest.mark.gpu
+def test_training_steps_are_bit_deterministic():
+    """The same seeded update steps (train mode: dropout, DropPath, BatchNorm batch statistics, ragged batches of 8, 3 and 5 scenes) on two
+    fresh engines give bit-identical losses and parameters: no atomics, no uninitialised reads, no order-dependent reductions."""
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+    from rift_amd.replay import DeviceReplay
+    from tests import helpers as H
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    scenes = [syn.make_scene(i, num_agents=12, num_polygons=8, r_min=1, r_max=3) for i in range(24)]
+    runs = []
+    for _ in range(2):
+        replay = DeviceReplay(scenes, dev, rcap=3)
+        model = PlanningModel(radius=120)
+        model.load_state_dict(H.weights())
+        model = model.to(dev)
+        model.train()
+        tr = RLFTTrainer(model, kind="rift")
+        g = torch.Generator().manual_seed(3)
+        ls = []
+        for bs in (8, 3, 5, 8):
+            idx = torch.randperm(24, generator=g)[:bs].to(torch.int32).to(dev)
+            fb, b = replay.collate(tr.engine, idx, int(replay.r_count_cpu[idx.cpu().long()].max()))
+            tr.training_step(fb, b)
+            tr.wait_update()
+            ls.append(float(tr.loss.item()))
+        torch.cuda.synchronize()
+        runs.append((ls, {k: v.detach().cpu().clone() for k, v in tr.params.items()}))
+        tr.engine.close()
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
