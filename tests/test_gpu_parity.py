@@ -142,7 +142,7 @@ def test_loss_kernels_bf16_trunk(ffi, kind):
 def test_benchmark_batch_rift_loss_within_1e4_in_bf16(ffi):
     """north_star's bar on the BENCHMARKED precision at the BENCHMARKED batch: the RIFT loss of a 256-scene minibatch
     (train-mode BatchNorm, drops disabled), bf16 MFMA trunk + loss kernel through the C-ABI, within 1e-4 of the CPU oracle
-    (measured 3e-5; the fp32 mode is at 1e-9; 8-scene fixtures sit at 3e-4 in bf16, hence their looser bound above)."""
+    (measured 6e-5; the fp32 mode is at 1e-9; 8-scene fixtures sit at 2e-4 in bf16, hence their looser bound above)."""
     sd = H.weights()
     scenes = [syn.make_scene(1000 + i) for i in range(256)]
     batch = syn.collate_scenes(scenes)
