@@ -9,7 +9,7 @@ import traceback
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 
 from oracle import advantage as oadv, losses, pluto_ref  # noqa: E402

@@ -1,7 +1,7 @@
 """RIFT loss of the HIP path (bf16 and fp32 modes, train-mode BatchNorm, drops disabled) against the CPU oracle on batches of
 growing size: how far the bf16 trunk moves the loss (north_star bar: 1e-4)."""
 import os, sys, time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 import torch
 from oracle import losses, pluto_ref
