@@ -1,93 +1,134 @@
-"""CBVRolloutBuffer -- host mirror of rift/gym_carla/buffer/cbv_rollout_buffer.py:16-138 (+ base_buffer.py).
+"""On-policy replay for the CBV update, built around the HBM replay arena.
 
-Same interface and semantics (per-key deque(maxlen=capacity), per-CBV trajectory staging until `CBVs_done`,
-trajectories of <= 5 steps dropped, full at `buffer_capacity`), pure Python: the buffer is filled by the CARLA
-rollout loop.  The policy update uploads it once into the HBM replay arena (rift_amd.replay.DeviceReplay)."""
-from collections import defaultdict, deque
+Interface of the reference's `CBVRolloutBuffer` (rift/gym_carla/buffer/cbv_rollout_buffer.py:16-138: `store`, `sample`,
+`add_extra_data`, `get_key_data`, `get_all_np_data`, `reset_buffer`, `buffer_full`, `buffer_pos`, `buffer_data`), different
+construction: transitions are kept ROW-major.  Every CBV owns an open episode (a list of transition rows); a finished episode is
+committed as a block of rows into one flat row store, and the per-key columns that the reference keeps in deques are views built
+from the rows on demand.  A committed row is exactly the unit `rift_amd.replay.DeviceReplay` uploads into the arena (`rows()` /
+`rift_amd.planning.fine_tuner.rlft.rlft_pluto.buffer_to_scenes`), so the update never walks per-key containers.
+
+Semantics kept from the reference (they decide which transitions reach the update):
+  * a transition of CBV `c` in environment `i` is `{key: data_dict[key][i][c]}` for the configured `data_keys`;
+  * an episode is committed when `CBVs_done[i][c]` is true;
+  * the episodes finished by ONE `store()` call are committed together, and dropped together when they hold <= 5 transitions in total
+    (cbv_rollout_buffer.py:80);
+  * committing stops at `buffer_capacity`; the buffer counts as full as soon as a commit reaches or would pass it (:81-90).
+"""
+from typing import Dict, Hashable, Iterable, List, Sequence
 
 import numpy as np
 
+MIN_COMMIT = 6     # a store() call must finish at least this many transitions for them to be kept
 
-class BaseBuffer:
-    name = 'base'
 
-    def __init__(self, num_scenario, mode, logger):
-        self.num_scenario, self.mode, self.logger = num_scenario, mode, logger
-        self.buffer_capacity = 2000
-        self.buffer_pos = 0
-        self.buffer_full = False
-        self.buffer_data = None
-        self.temp_buffer = None
+class _Column(Sequence):
+    """Read-only per-key view over the committed rows (what the reference exposes as a deque per key)."""
+
+    def __init__(self, rows: List[dict], key: str):
+        self._rows, self._key = rows, key
 
     def __len__(self):
-        return self.buffer_pos
+        return len(self._rows)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [r[self._key] for r in self._rows[i]]
+        return self._rows[i][self._key]
+
+    def __iter__(self):
+        k = self._key
+        return (r[k] for r in self._rows)
 
 
-class CBVRolloutBuffer(BaseBuffer):
+class _Columns(dict):
+    """`buffer_data`: key -> column.  Configured keys are views over the rows; `add_extra_data` attaches whole extra columns."""
+
+    def __init__(self, rows: List[dict], keys: Iterable[str]):
+        super().__init__((k, _Column(rows, k)) for k in keys)
+
+
+class CBVRolloutBuffer:
     name = 'CBVRolloutBuffer'
 
     def __init__(self, num_scenario, mode, cbv_config, logger=None):
-        super().__init__(num_scenario, mode, logger)
-        assert self.mode == 'train_cbv', f'Only initialize {self.name} when training the rl-based onpolicy cbv agent'
-        self.buffer_capacity = cbv_config['buffer_capacity']
-        self.data_keys = cbv_config['data_keys']
+        if mode != 'train_cbv':
+            raise AssertionError(f'Only initialize {self.name} when training the rl-based onpolicy cbv agent')
+        self.num_scenario, self.mode, self.logger = num_scenario, mode, logger
+        self.buffer_capacity = int(cbv_config['buffer_capacity'])
+        self.data_keys = list(cbv_config['data_keys'])
         self.reset_buffer()
 
+    # ---- state ------------------------------------------------------------------------------------------------------
     def reset_buffer(self):
-        self.buffer_pos = 0
+        self._rows: List[dict] = []
+        self._open: Dict[Hashable, List[dict]] = {}
         self.buffer_full = False
-        self.buffer_data = {key: deque(maxlen=self.buffer_capacity) for key in self.data_keys}
-        self.temp_buffer = {key: defaultdict(list) for key in self.buffer_data}
+        self.buffer_data = _Columns(self._rows, self.data_keys)
 
-    def process_data_dict(self, data_dict):
-        processed = {key: [] for key in self.buffer_data.keys()}
-        lengths = set(len(data) for key, data in data_dict.items() if key in self.buffer_data.keys())
-        assert len(lengths) == 1, 'all the data in the data dict should have same length'
-        n = lengths.pop()
-        ids_list = [ids for ids in data_dict['CBV_ids']]
-        for i in range(n):
-            for cbv_id in ids_list[i]:
-                for key, value in self.temp_buffer.items():
-                    value[cbv_id].append(data_dict[key][i][cbv_id])
-                if data_dict['CBVs_done'][i][cbv_id]:
-                    for key, value in processed.items():
-                        value.extend(self.temp_buffer[key].pop(cbv_id))
-        dl = set(len(d) for d in processed.values())
-        assert len(dl) == 1, 'the data in the processed data dict should have same length'
-        return processed, dl.pop()
+    @property
+    def buffer_pos(self) -> int:
+        return len(self._rows)
+
+    def __len__(self):
+        return len(self._rows)
+
+    def rows(self) -> List[dict]:
+        """The committed transitions, oldest first (one dict per transition, keys = data_keys)."""
+        return self._rows
+
+    # ---- writing ----------------------------------------------------------------------------------------------------
+    def _finished_rows(self, data_dict) -> List[dict]:
+        keys = self.data_keys
+        n_env = {len(data_dict[k]) for k in keys if k in data_dict}
+        if len(n_env) != 1:
+            raise AssertionError('all the data in the data dict should have same length')
+        done_rows: List[dict] = []
+        for i, ids in enumerate(data_dict['CBV_ids']):
+            for c in ids:
+                episode = self._open.setdefault(c, [])
+                episode.append({k: data_dict[k][i][c] for k in keys})
+                if data_dict['CBVs_done'][i][c]:
+                    done_rows += self._open.pop(c)
+        return done_rows
 
     def store(self, data_dict):
-        processed, n = self.process_data_dict(data_dict)
-        if n > 5:
-            if self.buffer_pos + n >= self.buffer_capacity:
-                for i in range(n):
-                    if self.buffer_pos < self.buffer_capacity:
-                        for key, data in self.buffer_data.items():
-                            data.append(processed[key][i])
-                        self.buffer_pos += 1
-                    else:
-                        break
-                self.buffer_full = True
-            else:
-                for key, data in self.buffer_data.items():
-                    data.extend(processed[key])
-                self.buffer_pos += n
-
-    def get_all_np_data(self):
-        assert self.buffer_pos == self.buffer_capacity, 'only get the data when the buffer is full'
-        return {key: np.stack(d).reshape(self.buffer_capacity, -1) for key, d in self.buffer_data.items()}
+        block = self._finished_rows(data_dict)
+        if len(block) < MIN_COMMIT:
+            return
+        room = self.buffer_capacity - len(self._rows)
+        if len(block) >= room:
+            block = block[:max(room, 0)]
+            self.buffer_full = True
+        self._rows += block
 
     def add_extra_data(self, data_dict: dict):
-        assert self.buffer_full, 'only add data when the buffer is full'
-        assert all(len(v) == self.buffer_capacity for v in data_dict.values())
+        """Attach whole extra columns (PPO / REINFORCE preprocessing results), one entry per committed transition."""
+        self._require_full('only add data when the buffer is full')
+        if any(len(v) != self.buffer_capacity for v in data_dict.values()):
+            raise AssertionError('extra columns must have one entry per buffer slot')
         self.buffer_data.update(data_dict)
 
+    # ---- reading ----------------------------------------------------------------------------------------------------
+    def _require_full(self, msg):
+        if not self.buffer_full:
+            raise AssertionError(msg)
+
     def get_key_data(self, key: str):
-        assert self.buffer_full, 'only get the data when the buffer is full'
+        self._require_full('only get the data when the buffer is full')
         return self.buffer_data[key]
 
+    def get_all_np_data(self):
+        if len(self._rows) != self.buffer_capacity:
+            raise AssertionError('only get the data when the buffer is full')
+        return {k: np.stack(list(col)).reshape(self.buffer_capacity, -1) for k, col in self.buffer_data.items()}
+
     def sample(self, idx):
-        assert self.buffer_full, 'only sample the data when the buffer is full'
-        indices = idx if isinstance(idx, (list, tuple)) else [idx]
-        assert all(0 <= i < self.buffer_capacity for i in indices)
-        return {key: [d[i] for i in indices] if len(indices) > 1 else d[indices[0]] for key, d in self.buffer_data.items()}
+        """One transition (int index -> {key: value}) or several (list / tuple -> {key: [values]})."""
+        self._require_full('only sample the data when the buffer is full')
+        many = isinstance(idx, (list, tuple))
+        picks = list(idx) if many else [idx]
+        if not all(0 <= i < self.buffer_capacity for i in picks):
+            raise AssertionError('sample index out of range')
+        if many and len(picks) > 1:
+            return {k: [col[i] for i in picks] for k, col in self.buffer_data.items()}
+        return {k: col[picks[0]] for k, col in self.buffer_data.items()}
