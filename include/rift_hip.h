@@ -141,6 +141,36 @@ int rift_model_load(RiftCtx* ctx, const RiftTensorDesc* params, int n, void* str
 int rift_forward(RiftCtx* ctx, const RiftFeatureBatch* batch, const RiftOutputs* out, int flags,
                  uint32_t seed, void* stream);
 
+/* ---- data parallelism (absent in the reference: one device, custom_lightning.yaml:26,43) ----
+ * A minibatch of `global_bs` scenes is split contiguously over the ranks; this rank's rift_forward receives scenes
+ * [scene_offset, scene_offset + batch->bs).  Two things in PlanningModel.forward couple the scenes of a minibatch, and both are made
+ * to see the GLOBAL minibatch so that the sharded update equals the single-process one:
+ *   - train-mode BatchNorm1d batch statistics of the two PointsEncoders (layers/embedding.py:260,266): per-channel (sum, sum of
+ *     squares, count) are all-reduced before normalisation (two exchanges per forward on the fused path), running statistics are
+ *     updated from the global sums, identically on every rank;
+ *   - the r2r attention's `tgt_key_padding_mask.repeat(M, 1)` (modules/planning_decoder.py:56-60): row b*12+m is masked with the
+ *     padding row of scene (b*12+m) % bs, of the global minibatch: the padding rows are gathered with the first exchange (in an eval
+ *     forward: in an exchange of their own).
+ * The library owns no communicator: at each exchange point it fills xchg[offset, offset+count) (device f64, caller-owned) on `stream`
+ * and calls `exchange`, which must enqueue an in-place SUM all-reduce of that range over the ranks on `stream` (RCCL through
+ * torch.distributed in the host layer; any transport works) and return 0.  Every rank must call rift_forward with the same R and flags.
+ * xchg_len >= global_bs * R + 1026.  The loss exchange (RiftLossOut.exchange) stays with the host between rift_loss_backward and
+ * rift_loss_finalize.  dp == NULL (or global_bs <= 0) switches data parallelism off. */
+typedef int (*RiftExchangeFn)(void* user, int64_t offset, int64_t count, void* stream);
+typedef struct RiftDp {
+  int32_t scene_offset, global_bs;
+  double* xchg; int64_t xchg_len;
+  RiftExchangeFn exchange; void* user;
+} RiftDp;
+int rift_set_dp(RiftCtx* ctx, const RiftDp* dp);
+
+/* The reference asserts torch.isfinite(q).all() on the decoder queries after every decoder layer (planning_decoder.py:175).  Here the
+ * policy-head kernels of rift_forward raise a device flag when the decoder output holds a NaN / Inf (either propagates through the
+ * residual stream to the last layer); rift_forward itself stays asynchronous.  rift_check_finite is the sync point: it waits for
+ * `stream`, returns RIFT_ERR_NONFINITE (and clears the flag) if any forward since the last check raised it, RIFT_OK otherwise.
+ * The host layer calls it wherever it reads results back (once per epoch in the update loop, once per get_action). */
+int rift_check_finite(RiftCtx* ctx, void* stream);
+
 /* SFTTrainer.generate_target_label's teacher side (fine_tuner/sft/sft_trainer.py:186-199): per scene, the (r, m) index of the candidate
  * whose PID target speed (mean spacing of the trajectory sub-sampled every `frame_rate` frames, in the teacher's local frame;
  * sft/utils.py:10-32, pluto/controller/pid_controller.py:108-125) is closest to teacher_infos[b][0].  trajectory: the (bs,R,M,T,6) output

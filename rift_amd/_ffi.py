@@ -66,6 +66,14 @@ class RiftReplayArena(C.Structure):
                                   "group_valid_mask")]
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
+
+
+class RiftDp(C.Structure):
+    _fields_ = [("scene_offset", C.c_int32), ("global_bs", C.c_int32), ("xchg", vp), ("xchg_len", C.c_int64),
+                ("exchange", EXCHANGE_FN), ("user", vp)]
+
+
 class RiftRolloutIO(C.Structure):
     _fields_ = [("trajectories", vp), ("G", C.c_int32), ("Tfull", C.c_int32), ("G_per_group", C.c_int32), ("center_state", vp),
                 ("turn_buf", vp), ("turn_ptr", vp), ("turn_len", vp), ("speed_buf", vp), ("speed_ptr", vp), ("speed_len", vp),
@@ -79,6 +87,7 @@ EXPORTS = [
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
     "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout", "rift_sft_teacher_mode",
+    "rift_check_finite", "rift_set_dp",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -110,6 +119,8 @@ def load_library() -> C.CDLL:
     lib.rift_loss_backward.argtypes = [vp, C.c_int, C.POINTER(RiftLossIn), C.POINTER(RiftLossOut), vp]
     lib.rift_loss_finalize.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, vp]
     lib.rift_set_param_event.argtypes = [vp, vp]
+    lib.rift_check_finite.argtypes = [vp, vp]
+    lib.rift_set_dp.argtypes = [vp, C.POINTER(RiftDp)]
     lib.rift_loss_finalize_clip.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, C.c_float, vp, vp]
     lib.rift_tap.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), vp]
     lib.rift_critic_forward.argtypes = [vp, C.POINTER(RiftCritic), vp, C.c_int, vp, vp]
@@ -232,6 +243,9 @@ class Engine:
             pass
 
     def _check(self, rc, what):
+        if rc != 0 and getattr(self, "_dp_error", None) is not None:
+            e, self._dp_error = self._dp_error, None
+            raise RuntimeError(f"{what}: the data-parallel exchange raised") from e
         if rc != 0:
             msg = self.lib.rift_last_error(self.ctx)
             raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
@@ -299,6 +313,35 @@ class Engine:
         rc = self.lib.rift_loss_finalize(self.ctx, C.byref(lo), accumulate, _stream())
         if rc != 0:
             self._check(rc, "rift_loss_finalize")
+
+    def check_finite(self):
+        """Sync point of the reference's `assert torch.isfinite(q).all()` (planning_decoder.py:175): waits for the current stream and
+        raises if any forward since the last check produced non-finite decoder queries."""
+        self._check(self.lib.rift_check_finite(self.ctx, _stream()), "rift_forward (decoder finiteness check)")
+
+    def set_dp(self, scene_offset: int, global_bs: int, xchg: torch.Tensor, exchange):
+        """rift_set_dp: this rank's forwards process scenes [scene_offset, scene_offset + bs) of a `global_bs`-scene minibatch.
+        `xchg`: caller-owned device f64 buffer; `exchange(t)`: in-place SUM all-reduce of a slice of it over the ranks, enqueued on the
+        current stream.  The BatchNorm statistics and the r2r quirk masks of rift_forward then cover the global minibatch."""
+        assert xchg.dtype == torch.float64 and xchg.is_cuda and xchg.is_contiguous()
+        if getattr(self, "_dp_key", None) != (xchg.data_ptr(), id(exchange)):
+            def _cb(user, offset, count, stream):
+                try:
+                    exchange(xchg[offset:offset + count])
+                    return 0
+                except BaseException as e:          # an exception must not unwind through the C frames
+                    self._dp_error = e
+                    return -1
+            self._dp_cb = EXCHANGE_FN(_cb)
+            self._dp_key = (xchg.data_ptr(), id(exchange))
+            self._dp_keep = (xchg, exchange)
+        d = RiftDp()
+        d.scene_offset, d.global_bs, d.xchg, d.xchg_len, d.exchange, d.user = scene_offset, global_bs, xchg.data_ptr(), xchg.numel(), self._dp_cb, None
+        self._check(self.lib.rift_set_dp(self.ctx, C.byref(d)), "rift_set_dp")
+
+    def clear_dp(self):
+        self._check(self.lib.rift_set_dp(self.ctx, None), "rift_set_dp")
+        self._dp_key = self._dp_cb = self._dp_keep = None
 
     def set_param_event(self, event: Optional["torch.cuda.Event"]):
         """rift_set_param_event: forwards wait for `event` (recorded after the optimizer step) right before they read pi_head."""

@@ -31,6 +31,8 @@ struct DecFusedP {
   float* Q;                     // (bs*R*12, 128) fp32 decoder queries, updated in place
   const uint8_t* kpm;           // (bs*N) encoder key padding
   const uint8_t* r_kpm;         // (bs*R) reference-line padding
+  const uint8_t* q_kpm;         // (q_bs*R) padding rows the r2r quirk indexes: r_kpm, or the gathered masks of the global (data-parallel) minibatch
+  int q_bs, q_off;              // scenes of that minibatch and this shard's first scene in it
   int bs, N, R;
   int kv_ld;                    // row stride of the kv matrices (1024 when the four layers share one GEMM)
   const unsigned short* KT;     // optional (bs, 4, 96, 128) bf16 K and (bs, 4, 128, 96) bf16 V^T written by the encoder kernel's tail;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   for (int i = tid; i < 96; i += NTH) smask[i] = (i >= N) || p.kpm[(size_t)b * N + i];
   for (int i = tid; i < 96; i += NTH) {            // quirk: mode m of scene b uses the padding row of scene (b*12+m) % bs
     const int m = i >> 3, r = i & 7;
-    qmask[i] = (r >= R) || p.r_kpm[(size_t)((b * M + m) % p.bs) * R + r];
+    qmask[i] = (r >= R) || p.q_kpm[(size_t)(((p.q_off + b) * M + m) % p.q_bs) * R + r];
   }
   if (tid < 8) rz[tid] = (tid >= R) || p.r_kpm[(size_t)b * R + tid];
   lds_barrier();

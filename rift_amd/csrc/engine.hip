@@ -95,6 +95,8 @@ struct RiftCtx {
   float* dec_par = nullptr;              // [4][RIFT_DEC_NPAR] packed LayerNorm parameters / biases of the fused decoder kernel
   bool dec_fused = true;
   double* clip_part = nullptr;
+  struct Dp { bool on = false; int off = 0, gbs = 0; double* xchg = nullptr; long long len = 0; RiftExchangeFn fn = nullptr; void* user = nullptr; } dp;   // rift_set_dp
+  int* nonfinite = nullptr;              // device flag set by the policy-head kernels when the decoder output is not finite
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
   bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1024; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
   bool loaded = false;
@@ -401,7 +403,22 @@ int set_lds_attrs(RiftCtx* c) {
 struct Fwd {   // per-forward context
   RiftCtx* c; bool train, drop, fp32, need_traj, bn_update; uint32_t seed; uint32_t stream_id = 1;
   uint32_t next_stream() { return stream_id++; }
+  // data parallel (rift_set_dp): xchg[0, kb) = quirk-mask slots of the global minibatch, xchg[kb, ...) = BatchNorm sums of the current point
+  bool dp = false, kpm_pending = false; int kb = 0; uint8_t* g_rkpm = nullptr;
 };
+
+// All-reduce xchg[kb, kb + n) over the ranks (BatchNorm sums); the first exchange of a forward also carries the mask slots [0, kb)
+// and is followed by their conversion into the gathered padding mask.  Dry (arena sizing) passes exchange nothing.
+void dp_exchange(Fwd& f, long long n) {
+  RiftCtx* c = f.c;
+  if (!f.dp) return;
+  const bool with_kpm = f.kpm_pending;
+  f.kpm_pending = false;
+  if (c->dry) return;
+  const long long off = with_kpm ? 0 : f.kb, cnt = with_kpm ? f.kb + n : n;
+  if (cnt > 0 && c->dp.fn(c->dp.user, off, cnt, (void*)c->stream) != 0 && c->err.empty()) c->err = "data-parallel exchange callback failed";
+  if (with_kpm) launch(c, "dp_kpm_read_kernel", dp_kpm_read_kernel, dim3(cdiv(f.kb, 256)), dim3(256), 0, (const double*)c->dp.xchg, f.kb, f.g_rkpm);
+}
 
 void layernorm(Fwd& f, const float* X, int ldx, float* Y, int ldy, int rows, int C, const std::string& name, int relu = 0) {
   RiftCtx* c = f.c;
@@ -475,10 +492,15 @@ void batchnorm_affine(Fwd& f, const float* X, int rows, int C, const uint8_t* va
   int* cnt = A_alloc<int>(c, nblk);
   if (f.train) launch(c, "bn_partial_kernel", bn_partial_kernel, dim3(nblk), dim3(C), 0, X, C, rows, C, valid, part, cnt, rows_per_blk);
   const Param* nb = find(c, name + ".num_batches_tracked");
-  launch(c, "bn_finalize_kernel", bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (const double*)part, (const int*)cnt, nblk, C,
-         fptr(c, name + ".weight"), fptr(c, name + ".bias"), (float*)fptr(c, name + ".running_mean"),
-         (float*)fptr(c, name + ".running_var"), nb ? (long long*)nb->data : (long long*)nullptr, f.train ? 1 : 0,
-         f.bn_update ? 1 : 0, 1e-5f, *scale, *shift);
+  const bool dpx = f.dp && f.train;      // data parallel: batch statistics over the GLOBAL minibatch (sums all-reduced between two launches)
+  double* sums = dpx ? c->dp.xchg + f.kb : nullptr;
+  for (int mode = dpx ? 1 : 0; mode <= (dpx ? 2 : 0); ++mode) {
+    launch(c, "bn_finalize_kernel", bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (const double*)part, (const int*)cnt, nblk, C,
+           fptr(c, name + ".weight"), fptr(c, name + ".bias"), (float*)fptr(c, name + ".running_mean"),
+           (float*)fptr(c, name + ".running_var"), nb ? (long long*)nb->data : (long long*)nullptr, f.train ? 1 : 0,
+           f.bn_update ? 1 : 0, 1e-5f, *scale, *shift, sums, mode);
+    if (mode == 1) dp_exchange(f, 2 * C + 1);
+  }
 }
 
 // The two PointsEncoders (map polygons 10 -> 128 with 20 points, reference lines 6 -> 128 with 120 points) in the fused
@@ -504,8 +526,10 @@ static void pe_fill(Fwd& f, PeP& q, const float* F, int Cin, int groups, int n, 
   { const char* ev = getenv("RIFT_PE_TS"); if (ev && atoi(ev) == n) { q.ts = A_alloc<long long>(c, 64); q.ts_tile = 0; tap(c, "pe_ts", (float*)q.ts, 128); } }
 }
 
-static BnFinP bn_fin(RiftCtx* c, const PeP& q, const std::string& name, int C, const float* part, const float* sc, const float* sh) {
+static BnFinP bn_fin(RiftCtx* c, const PeP& q, const std::string& name, int C, const float* part, const float* sc, const float* sh,
+                     double* sums = nullptr, int sums_mode = 0) {
   BnFinP b; memset(&b, 0, sizeof(b));
+  b.sums = sums; b.sums_mode = sums_mode;
   const Param* nb = find(c, name + ".num_batches_tracked");
   b.part = part; b.cnt = q.cnt; b.nblk = q.ntiles; b.C = C; b.gamma = fptr(c, name + ".weight"); b.beta = fptr(c, name + ".bias");
   b.running_mean = (float*)fptr(c, name + ".running_mean"); b.running_var = (float*)fptr(c, name + ".running_var");
@@ -525,12 +549,20 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
     c->prof_flops = 2.0 * 128.0 * (q.a.rows * 10.0 + q.b.rows * 6.0);
     launch(c, "pe_stats1_kernel", pe_stats1_kernel, dim3(nt), dim3(256), 0, q);
   }
-  launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(256), dim3(256), 0, bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1),
-         bn_fin(c, q.b, pr + ".first_mlp.1", 128, q.b.part1, q.b.s1, q.b.t1), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+  const bool dpx = f.dp && f.train;      // data parallel: the four BatchNorms see the statistics of the GLOBAL minibatch
+  double* xs = dpx ? c->dp.xchg + f.kb : nullptr;
+  for (int mode = dpx ? 1 : 0; mode <= (dpx ? 2 : 0); ++mode) {
+    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(256), dim3(256), 0, bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1, xs, mode),
+           bn_fin(c, q.b, pr + ".first_mlp.1", 128, q.b.part1, q.b.s1, q.b.t1, xs ? xs + 257 : nullptr, mode), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+    if (mode == 1) dp_exchange(f, 2 * 257);
+  }
   c->prof_flops = 2.0 * rows * (128.0 * 8 + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;
   launch(c, "pe_mid_kernel", pe_mid_kernel, dim3(nt), dim3(512), (size_t)PE_MID_LDS, q);
-  launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(512), dim3(256), 0, bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2),
-         bn_fin(c, q.b, pr + ".second_mlp.1", 256, q.b.part2, q.b.s2, q.b.t2), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+  for (int mode = dpx ? 1 : 0; mode <= (dpx ? 2 : 0); ++mode) {
+    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(512), dim3(256), 0, bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2, xs, mode),
+           bn_fin(c, q.b, pr + ".second_mlp.1", 256, q.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, mode), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+    if (mode == 1) dp_exchange(f, 2 * 513);
+  }
   c->prof_flops = 2.0 * rows * (256.0 * 256 + 256.0 * 128);
   launch(c, "pe_out_kernel", pe_out_kernel, dim3(nt), dim3(512), (size_t)PE_OUT_LDS, q);
   *out_m = q.a.out; *out_r = q.b.out;
@@ -685,6 +717,16 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     int tot = 0;
     for (int i = 0; i < 7; ++i) tot += q.nb[i];
     launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
+  }
+  // data parallel: the r2r mask quirk indexes padding rows of the GLOBAL minibatch -> gather them (slots in the exchange buffer; the
+  // first BatchNorm exchange carries them, an eval forward exchanges them on their own before the decoder)
+  const uint8_t* q_kpm = r_kpm; int q_bs = bs, q_off = 0;
+  if (c->dp.on) {
+    f.dp = true; f.kb = c->dp.gbs * R; f.kpm_pending = true;
+    f.g_rkpm = A_alloc<uint8_t>(c, (size_t)f.kb);
+    if ((long long)f.kb + 2 * 513 > c->dp.len || c->dp.off < 0 || c->dp.off + bs > c->dp.gbs) { c->err = "rift_set_dp: exchange buffer too small or shard outside the global minibatch"; return RIFT_ERR_ARG; }
+    launch(c, "dp_kpm_fill_kernel", dp_kpm_fill_kernel, dim3(cdiv(f.kb, 256)), dim3(256), 0, (const uint8_t*)r_kpm, nL, c->dp.off * R, f.kb, c->dp.xchg);
+    q_kpm = f.g_rkpm; q_bs = c->dp.gbs; q_off = c->dp.off;
   }
   static const float dpr[6] = {0.f, 0.04f, 0.08f, 0.12f, 0.16f, 0.2f};   // linspace(0, 0.2, 6), embedding.py:30
   const bool fused = c->nat_fused && !f.fp32;
@@ -982,10 +1024,11 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   }
   tap(c, "q0", Q, (int64_t)nQ * 128);
 
+  dp_exchange(f, 0);                      // (eval forward under data parallelism: the mask slots have not travelled yet)
   const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
   if (c->dec_fused && !f.fp32 && R * M <= 80 && N <= 96) {
     DecFusedP dq; memset(&dq, 0, sizeof(dq));
-    dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
+    dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
     dq.stream = f.next_stream(); f.stream_id += 64;
     // the cross-attention K | V projections of all four layers read the same encoder output: one N = 1024 GEMM
     float* KVall = nullptr;
@@ -1035,7 +1078,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       m.nb_outer = bs; m.nb_inner = M; m.H = 4; m.Lq = R; m.Lk = R;
       m.q_outer = R * M; m.q_inner = 1; m.q_stride = M; m.kv_outer = R * M; m.kv_inner = 1; m.kv_stride = M;
       m.o_outer = R * M; m.o_inner = 1; m.o_stride = M;
-      m.mask = r_kpm; m.mask_quirk = 1; m.mask_mod = bs;   // tgt_key_padding_mask.repeat(M, 1), planning_decoder.py:56-60
+      m.mask = q_kpm; m.mask_quirk = 1; m.mask_mod = q_bs; m.mask_off = q_off * M;   // tgt_key_padding_mask.repeat(M, 1), planning_decoder.py:56-60
       if (dp > 0.f) { m.dropout_p = dp; m.seed = f.seed; m.stream = f.next_stream(); }
       run_mha(c, m, f.fp32);
     }
@@ -1113,7 +1156,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     q.w1 = fptr(c, PD + ".pi_head.mlp.0.weight"); q.b1 = fptr(c, PD + ".pi_head.mlp.0.bias");
     q.lng = fptr(c, PD + ".pi_head.mlp.1.weight"); q.lnb = fptr(c, PD + ".pi_head.mlp.1.bias");
     q.w2 = fptr(c, PD + ".pi_head.mlp.3.weight"); q.b2 = fptr(c, PD + ".pi_head.mlp.3.bias");
-    q.r_kpm = r_kpm; q.M = M; q.eps = 1e-5f; q.QF = QF; q.Hpi = Hpi; q.prob = prob;
+    q.r_kpm = r_kpm; q.M = M; q.eps = 1e-5f; q.QF = QF; q.Hpi = Hpi; q.prob = prob; q.nonfinite = c->nonfinite;
     c->prof_flops = 2.0 * nQ * (2.0 * 128 * 128 + 128);
     launch(c, "pi_forward_kernel", pi_forward_kernel, dim3(cdiv(nQ, PI_ROWS)), dim3(512), (size_t)PI_LDS, q);
   } else {
@@ -1126,7 +1169,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     gemm(c, mk(QF, 128, nQ, w, Hpi, 128), w, true);
     launch(c, "pi_tail_kernel", pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
            fptr(c, PD + ".pi_head.mlp.1.bias"), fptr(c, PD + ".pi_head.mlp.3.weight"), fptr(c, PD + ".pi_head.mlp.3.bias"),
-           (const uint8_t*)r_kpm, 1e-5f, prob);
+           (const uint8_t*)r_kpm, 1e-5f, prob, c->nonfinite);
   }
   tap(c, "q_final", QF, (int64_t)nQ * 128);
   if (f.need_traj && out->trajectory && !f.fp32 && c->heads_fused) {
@@ -1185,6 +1228,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
+  if (hipMalloc((void**)&c->nonfinite, sizeof(int)) != hipSuccess || hipMemset(c->nonfinite, 0, sizeof(int)) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   int rc = set_lds_attrs(c);
   if (rc != RIFT_OK) { fprintf(stderr, "rift_ctx_create: %s\n", c->err.c_str()); delete c; return rc; }
   *ctx = c;
@@ -1204,6 +1248,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->enc_idx) (void)hipFree(c->enc_idx);
   if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
   if (c->clip_part) (void)hipFree(c->clip_part);
+  if (c->nonfinite) (void)hipFree(c->nonfinite);
   if (c->dec_par) (void)hipFree(c->dec_par);
   for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
@@ -1506,6 +1551,27 @@ int rift_sft_teacher_mode(RiftCtx* c, const float* trajectory, const float* teac
   return RIFT_OK;
 }
 
+int rift_set_dp(RiftCtx* c, const RiftDp* dp) {
+  if (!c) return RIFT_ERR_ARG;
+  if (!dp || dp->global_bs <= 0) { c->dp = RiftCtx::Dp(); return RIFT_OK; }
+  if (!dp->xchg || !dp->exchange || dp->scene_offset < 0 || dp->xchg_len <= 0) { c->err = "rift_set_dp: bad descriptor"; return RIFT_ERR_ARG; }
+  c->dp.on = true; c->dp.off = dp->scene_offset; c->dp.gbs = dp->global_bs; c->dp.xchg = dp->xchg; c->dp.len = dp->xchg_len;
+  c->dp.fn = dp->exchange; c->dp.user = dp->user;
+  return RIFT_OK;
+}
+
+int rift_check_finite(RiftCtx* c, void* stream) {
+  if (!c) return RIFT_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int flag = 0;
+  HIPCHK(c, hipMemcpyAsync(&flag, c->nonfinite, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+  if (!flag) return RIFT_OK;
+  HIPCHK(c, hipMemsetAsync(c->nonfinite, 0, sizeof(int), (hipStream_t)stream));
+  c->err = "non-finite decoder queries (the reference asserts torch.isfinite(q).all(), planning_decoder.py:175)";
+  return RIFT_ERR_NONFINITE;
+}
+
 int rift_set_param_event(RiftCtx* c, void* event) {
   if (!c) return RIFT_ERR_ARG;
   c->param_event = (hipEvent_t)event;
@@ -1570,7 +1636,6 @@ static int critic_scratch(RiftCtx* c, int n) {
   const size_t need = (size_t)((n + 15) / 16 * 16) * (128 + 4 * 256 + 1 + 2 * 128 + 2);
   if (need > c->cr_cap) {
     if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
-  if (c->clip_part) (void)hipFree(c->clip_part);
     HIPCHK(c, hipMalloc((void**)&c->cr_buf, need * 4));
     HIPCHK(c, hipMalloc((void**)&c->cr_part, (size_t)((n + 15) / 16) * 8));
     c->cr_cap = need;

@@ -219,7 +219,7 @@ struct MhaP {
   int q_outer, q_inner, q_stride;      // in rows
   int kv_outer, kv_inner, kv_stride;
   int o_outer, o_inner, o_stride;
-  const uint8_t* mask; int mask_quirk, mask_mod;
+  const uint8_t* mask; int mask_quirk, mask_mod, mask_off;   // mask_off: data-parallel shard offset of the quirk row (rows of the global batch)
   float dropout_p; uint32_t seed, stream;
 };
 
@@ -238,7 +238,7 @@ __global__ void mha_kernel(MhaP p) {
 #pragma unroll
   for (int d = 0; d < 32; ++d) { q[d] = qp[d] * scale; acc[d] = 0.f; }
   const size_t kv0 = (size_t)bo * p.kv_outer + (size_t)bi * p.kv_inner;
-  const int mb = p.mask ? (p.mask_quirk ? (bo * p.nb_inner + bi) % p.mask_mod : bo) : 0;
+  const int mb = p.mask ? (p.mask_quirk ? (bo * p.nb_inner + bi + p.mask_off) % p.mask_mod : bo) : 0;
   float m = -INFINITY, l = 0.f;
   for (int j = 0; j < p.Lk; ++j) {
     if (p.mask && p.mask[(size_t)mb * p.Lk + j]) continue;
@@ -290,7 +290,7 @@ __global__ void mha_mfma_kernel(MhaP p) {
   const int bi = (blockIdx.x / p.H) % p.nb_inner;
   const int bo = blockIdx.x / (p.H * p.nb_inner);
   const size_t kv0 = (size_t)bo * p.kv_outer + (size_t)bi * p.kv_inner;
-  const int mb = p.mask ? (p.mask_quirk ? (bo * p.nb_inner + bi) % p.mask_mod : bo) : 0;
+  const int mb = p.mask ? (p.mask_quirk ? (bo * p.nb_inner + bi + p.mask_off) % p.mask_mod : bo) : 0;
   // ---- stage K (row-major) and V (transposed) as bf16; keys >= Lk are zero and masked
   for (int i = tid; i < LKP * 8; i += blockDim.x) {
     const int key = i >> 3, d4 = (i & 7) * 4;
@@ -411,7 +411,8 @@ __global__ void bn_partial_kernel(const float* __restrict__ X, int ld, int rows,
 __global__ void bn_finalize_kernel(const double* __restrict__ part, const int* __restrict__ cnt, int nblk, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long long* num_batches, int train,
-                                   int update_running, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+                                   int update_running, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                   double* sums /*[2C+1] (sum, sum of squares per channel, count)*/, int sums_mode /*0 local, 1 emit, 2 consume*/) {
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (c >= C) return;
@@ -419,10 +420,17 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, const int* _
   if (train) {
     double s = 0.0, q = 0.0;
     long long n = 0;
-    for (int b = lane; b < nblk; b += 64) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; n += cnt[b]; }
+    if (sums_mode != 2) for (int b = lane; b < nblk; b += 64) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; n += cnt[b]; }
+    if (sums_mode != 2) {
     s = wave_sum_d(s); q = wave_sum_d(q);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    }
+    if (sums_mode == 1) {        // data parallel: this rank's sums go to the exchange buffer; a second launch consumes the reduced ones
+      if (lane == 0) { sums[c] = s; sums[C + c] = q; if (c == 0) sums[2 * C] = (double)n; }
+      return;
+    }
+    if (sums_mode == 2) { s = sums[c]; q = sums[C + c]; n = (long long)sums[2 * C]; }
     const double mu = s / (double)n;
     double v = q / (double)n - mu * mu;
     v = v < 0.0 ? 0.0 : v;
@@ -439,6 +447,20 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, const int* _
     scale[c] = sc;
     shift[c] = beta[c] - mean * sc;
   }
+}
+
+// Data-parallel r2r quirk: `tgt_key_padding_mask.repeat(M, 1)` (planning_decoder.py:56-60) makes row b*12+m of the batch use the
+// reference-line padding of scene (b*12+m) % bs -- of the GLOBAL minibatch when it is sharded over ranks.  Every rank writes its
+// scenes' masks into its slots of the exchange buffer (zeros elsewhere); the SUM all-reduce that carries the BatchNorm sums gathers them.
+__global__ void dp_kpm_fill_kernel(const uint8_t* __restrict__ r_kpm, int n_local, int slot0, int n_global, double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_global) return;
+  const int l = i - slot0;
+  x[i] = (l >= 0 && l < n_local && r_kpm[l]) ? 1.0 : 0.0;
+}
+__global__ void dp_kpm_read_kernel(const double* __restrict__ x, int n_global, uint8_t* __restrict__ g_kpm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_global) g_kpm[i] = x[i] != 0.0;
 }
 
 // masked max-pool over the n points of each group (PointsEncoder: invalid points are all-zero rows)

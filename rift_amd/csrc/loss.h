@@ -15,7 +15,7 @@ __global__ void pi_tail_kernel(const float* __restrict__ Hpi /*[rows][128]*/, in
                                const float* __restrict__ g, const float* __restrict__ be,
                                const float* __restrict__ w2, const float* __restrict__ b2,
                                const uint8_t* __restrict__ r_kpm /*[rows/M]*/, float eps,
-                               float* __restrict__ prob /*[rows]*/) {
+                               float* __restrict__ prob /*[rows]*/, int* __restrict__ nonfinite) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -26,7 +26,11 @@ __global__ void pi_tail_kernel(const float* __restrict__ Hpi /*[rows][128]*/, in
   const float a0 = fmaxf(d0 * rstd * g[lane] + be[lane], 0.f);
   const float a1 = fmaxf(d1 * rstd * g[lane + 64] + be[lane + 64], 0.f);
   const float z = wave_sum(a0 * w2[lane] + a1 * w2[lane + 64]) + b2[0];
-  if (lane == 0) prob[row] = r_kpm[row / M] ? -1e6f : z;
+  if (lane == 0) {
+    prob[row] = r_kpm[row / M] ? -1e6f : z;
+    // a NaN / Inf in the decoder queries (the reference's assert, planning_decoder.py:175) reaches the hidden row and its logit
+    if (nonfinite && z * 0.f != 0.f) atomicOr(nonfinite, 1);
+  }
 }
 
 struct LossP {

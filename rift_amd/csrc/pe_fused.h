@@ -476,6 +476,7 @@ struct BnFinP {
   const float* part; const int* cnt; int nblk, C;
   const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches;
   float* scale; float* shift;
+  double* sums; int sums_mode;     // data parallel: [2C+1] (sum, sum of squares, count); 0 local, 1 emit this rank's sums, 2 consume reduced sums
 };
 
 __device__ __forceinline__ void bn_finalize_t_body(const BnFinP& p, int train, int update_running, float eps, int c) {
@@ -485,7 +486,7 @@ __device__ __forceinline__ void bn_finalize_t_body(const BnFinP& p, int train, i
   if (train) {
     double s = 0.0, q = 0.0;
     long long n = 0;
-    for (int b0 = 0; b0 < p.nblk; b0 += NT * MAXU) {
+    for (int b0 = 0; b0 < (p.sums_mode == 2 ? 0 : p.nblk); b0 += NT * MAXU) {
       float sv[MAXU], qv[MAXU]; int nv[MAXU];
 #pragma unroll
       for (int u = 0; u < MAXU; ++u) {
@@ -506,6 +507,11 @@ __device__ __forceinline__ void bn_finalize_t_body(const BnFinP& p, int train, i
     s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     nd = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    if (p.sums_mode == 1) {
+      if (tid == 0) { p.sums[c] = s; p.sums[p.C + c] = q; if (c == 0) p.sums[2 * p.C] = nd; }
+      return;
+    }
+    if (p.sums_mode == 2) { s = p.sums[c]; q = p.sums[p.C + c]; nd = p.sums[2 * p.C]; }
     const double mu = s / nd;
     double v = q / nd - mu * mu;
     v = v < 0.0 ? 0.0 : v;

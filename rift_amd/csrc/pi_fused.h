@@ -20,6 +20,7 @@ struct PiFwdP {
   const uint8_t* r_kpm; int M;                   // (rows / M) padded reference lines
   float eps;
   float* QF; float* Hpi; float* prob;            // (rows,128) (rows,128) (rows)
+  int* nonfinite;                                // device flag: set when the decoder output holds a NaN / Inf (planning_decoder.py:175)
 };
 
 #define PI_ROWS 128
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(512) void pi_forward_kernel(PiFwdP p) {
   const float4 g4 = *reinterpret_cast<const float4*>(p.lng + col), e4 = *reinterpret_cast<const float4*>(p.lnb + col);
   const float4 w24 = *reinterpret_cast<const float4*>(p.w2 + col);
   const float b2 = p.b2[0];
+  bool bad = false;
   {
     float4 qv[8];
 #pragma unroll
@@ -72,9 +74,14 @@ __global__ __launch_bounds__(512) void pi_forward_kernel(PiFwdP p) {
       if (gr < p.rows) x0 = *reinterpret_cast<const float4*>(p.x0p + (size_t)(gr / p.rows_per_scene) * 128 + col);
       const float4 v = make_float4(acc[mt][0][0] + bq4.x + x0.x, acc[mt][0][1] + bq4.y + x0.y, acc[mt][0][2] + bq4.z + x0.z, acc[mt][0][3] + bq4.w + x0.w);
       *reinterpret_cast<float4*>(qf + row * PI_FS + col) = v;
-      if (gr < p.rows) *reinterpret_cast<float4*>(p.QF + (size_t)gr * 128 + col) = v;
+      if (gr < p.rows) {
+        *reinterpret_cast<float4*>(p.QF + (size_t)gr * 128 + col) = v;
+        bad |= (v.x * 0.f + v.y * 0.f) + (v.z * 0.f + v.w * 0.f) != 0.f;     // x * 0 is NaN for NaN and +-Inf, 0 otherwise
+      }
     }
   }
+  // the reference asserts torch.isfinite(q).all() on the decoder queries (planning_decoder.py:175); a NaN / Inf there reaches q_final
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0 && p.nonfinite) atomicOr(p.nonfinite, 1);
   __syncthreads();
   // ---- h = q_final W1^T + b1, exact fp32: D^T[n][m] = sum_k W1[n][k] q_final[m][k]; a lane ends with 4 consecutive n of row m = l15
   f32x4 h[MT];

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
-from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer, split_minibatch
 from rift_amd.planning.pluto.model.pluto_model import PlanningModel
 from rift_amd.replay import DeviceReplay
 
@@ -187,7 +187,11 @@ class RLFTPluto(CBVBasePolicy):
                     f.unlink()
             self.checkpoint = self.config.get('ckpt_path')
             self.continue_episode, self.current_epoch = 0, 0
-        if self.checkpoint and Path(self.checkpoint).exists():
+        # the reference always loads (rlft_pluto.py:293) and fails loudly on a bad path; only a policy configured WITHOUT any checkpoint
+        # (ckpt_path unset: synthetic benchmarks, tests) keeps its seeded initialisation
+        if self.checkpoint:
+            if not Path(self.checkpoint).exists():
+                raise FileNotFoundError(f"{self.name}: checkpoint {self.checkpoint} does not exist")
             self.pluto_model.load_state_dict(self.load_infer_checkpoint(self.checkpoint, self.device))
 
     def update_training_ckpt(self):
@@ -203,13 +207,22 @@ class RLFTPluto(CBVBasePolicy):
         """No-op for RIFT / GRPO (rift_datamodule.py:97-98)."""
         return {}
 
-    def train(self, e_i):
+    def train(self, e_i, process_group=None):
+        """One policy update = RLFTPluto.train (rlft_pluto.py:206-247): 16 epochs over a 90/10 split of the full buffer, batch 256,
+        clip 0.5, per-epoch WarmupCosLR, top-1 checkpoint by validation loss, inference-model refresh, buffer reset.
+
+        `process_group` (torch.distributed, nccl = RCCL): data-parallel update.  Every rank holds the same replay and
+        draws the same minibatch order; each 256-scene minibatch is split contiguously over the ranks (32 scenes per GPU at 8 GPUs) and
+        the exchanges of RLFTTrainer make the sharded step equal the single-process one -- same losses, gradients, BatchNorm running
+        statistics and therefore the same checkpoint on every rank; rank 0 writes it."""
         assert self.buffer is not None and self.buffer.buffer_full, 'The buffer should be full before training'
         if self.train_model is None:
             self.set_mode('train')
         cfg = self.cfg
         lr = max(self.initial_lr * (cfg["cl_lr_decay"] ** self.current_epoch), cfg["min_lr"])   # rlft_pluto.py:212
-        if self.checkpoint and Path(self.checkpoint).exists():
+        if self.checkpoint:
+            if not Path(self.checkpoint).exists():
+                raise FileNotFoundError(f"{self.name}: checkpoint {self.checkpoint} does not exist")
             sd = torch.load(self.checkpoint, map_location=self.device, weights_only=False)["state_dict"]
             self.train_model.load_state_dict({k.replace("model.", "", 1): v for k, v in sd.items()}, strict=False)
         else:
@@ -218,12 +231,14 @@ class RLFTPluto(CBVBasePolicy):
         trainer = RLFTTrainer(self.train_model, kind=self.kind, lr=lr, cl_lr_decay=cfg["cl_lr_decay"],
                               weight_decay=cfg["weight_decay"], epochs=cfg["epochs"], warmup_epochs=cfg["warmup_epochs"],
                               trainable_layers=tuple(cfg["trainable_layers"]), gradient_clip_val=cfg["gradient_clip_val"],
-                              clip_epsilon=getattr(self, "clip_epsilon", 0.2), lambda_entropy=getattr(self, "lambda_entropy", 0.01))
+                              clip_epsilon=getattr(self, "clip_epsilon", 0.2), lambda_entropy=getattr(self, "lambda_entropy", 0.01),
+                              process_group=process_group, seed=int(e_i) + 1)
+        rank, world = trainer.rank, trainer.world
         eng = trainer.engine
         replay = DeviceReplay(buffer_to_scenes(self.buffer), self.device)
         extras = self.preprocess_buffer(trainer, replay)
         n = replay.n
-        g = torch.Generator().manual_seed(int(e_i) + 1234)
+        g = torch.Generator().manual_seed(int(e_i) + 1234)          # same split and order on every rank
         perm = torch.randperm(n, generator=g)                      # random_split(dataset, [0.9, 0.1]), rift_datamodule.py:93
         n_train = int(math.floor(n * cfg["train_ratio"]))
         train_idx, val_idx = perm[:n_train], perm[n_train:]
@@ -231,36 +246,45 @@ class RLFTPluto(CBVBasePolicy):
         save_dir.mkdir(parents=True, exist_ok=True)
         best, best_path, history = None, None, []
 
-        def batches(idx, bs, shuffle):
+        def minibatches(idx, bs, shuffle):
+            """(device index slice of this rank, R of the whole minibatch, shard descriptor) per minibatch; one upload per pass."""
             if shuffle:
                 idx = idx[torch.randperm(idx.numel(), generator=g)]
+            idx_dev = idx.to(torch.int32).to(self.device)
             for s in range(0, idx.numel(), bs):
-                yield idx[s:s + bs].to(torch.int32).to(self.device)
+                m = min(bs, idx.numel() - s)
+                lo, hi = split_minibatch(m, rank, world) if world > 1 else (0, m)
+                yield idx_dev[s + lo:s + hi], int(replay.r_count_cpu[idx[s:s + m]].max()), ((lo, m) if world > 1 else None)
 
-        def run(idx_dev, train):
-            R_out = int(replay.r_count_cpu[idx_dev.cpu().long()].max())
+        def run(batch, train):
+            idx_dev, R_out, shard = batch
             fb, b = replay.collate(eng, idx_dev, R_out)
-            b = dict(b)
-            for k, v in extras.items():
-                b[k] = v[idx_dev.long()].contiguous()
-            return trainer.training_step(fb, b) if train else trainer.validation_step(fb, b)
+            if extras:
+                b = dict(b)
+                for k, v in extras.items():
+                    b[k] = v[idx_dev.long()].contiguous()
+            return trainer.training_step(fb, b, shard=shard) if train else trainer.validation_step(fb, b, shard=shard)
 
         for epoch in range(cfg["epochs"]):
-            for i in batches(train_idx, cfg["train_batch_size"], cfg["shuffle"]):
-                run(i, True)
+            for mb in minibatches(train_idx, cfg["train_batch_size"], cfg["shuffle"]):
+                run(mb, True)
             train_loss = trainer.pop_mean_loss()    # mean of the step losses; also joins the update stream (parameters are final)
-            vl = [float(run(i, False).item()) for i in batches(val_idx, cfg["val_batch_size"], False)]
+            vl = [run(mb, False).clone() for mb in minibatches(val_idx, cfg["val_batch_size"], False)]
             trainer.on_epoch_end()
-            val_loss = float(np.mean(vl)) if vl else train_loss
+            val_loss = float(torch.stack(vl).mean().item()) if vl else train_loss
             history.append({"epoch": epoch, "train_loss": train_loss, "val_loss": val_loss,
                             "lr": trainer.optimizer.param_groups[0]["lr"]})
             if best is None or val_loss < best:                    # ModelCheckpoint(save_top_k=1, monitor loss/val_loss)
-                if best_path is not None and best_path.exists():
+                if rank == 0 and best_path is not None and best_path.exists():
                     best_path.unlink()
                 best = val_loss
-                best_path = save_dir / f"carla_episode={e_i}-epoch={epoch:02d}-val_loss={val_loss:.4f}.ckpt"
-                torch.save({"state_dict": {"model." + k: v.detach().cpu() for k, v in self.train_model.state_dict().items()},
-                            "epoch": epoch, "carla_episode": e_i}, best_path)
+                best_path = save_dir / f"carla_episode={e_i}-epoch={epoch}-val_loss={val_loss:.3f}.ckpt"   # training_builder.py:133
+                if rank == 0:
+                    torch.save({"state_dict": {"model." + k: v.detach().cpu() for k, v in self.train_model.state_dict().items()},
+                                "epoch": epoch, "carla_episode": e_i}, best_path)
+        trainer.close()
+        if process_group is not None:
+            torch.distributed.barrier(group=process_group)         # the checkpoint of rank 0 is on disk before anyone reloads
         self.last_fit = {"history": history, "best_val_loss": best, "checkpoint": best_path.as_posix(), "lr": lr}
         self.update_training_ckpt()
         self.pluto_model.load_state_dict(self.load_infer_checkpoint(self.checkpoint, self.device))

@@ -93,6 +93,16 @@ def dp_all_reduce_exchange(xchg: torch.Tensor, group=None):
     torch.distributed.all_reduce(xchg, op=torch.distributed.ReduceOp.SUM, group=group)
 
 
+def split_minibatch(n: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of an n-scene minibatch for `rank` (256 scenes -> 32 per GPU at 8 GPUs; a remainder
+    goes to the first ranks).  Every rank needs at least one scene (it has to join the exchanges of the forward)."""
+    if n < world:
+        raise ValueError(f"a {n}-scene minibatch cannot be split over {world} ranks")
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
 def dp_all_reduce(flat: torch.Tensor, stats: torch.Tensor, group=None):
     """The only exchange step of the data-parallel path.  Every rank holds UNNORMALISED sums over its scene shard:
     `flat` = sum of d(objective)/d(pi_head params) (16,897 f32), `stats` = (objective sum, valid-entry count) in f64.
@@ -111,12 +121,16 @@ def shard_scene_ids(rank: int, world: int, per_rank: int):
 class RLFTTrainer:
     """Update-step driver for kind in {'rift','grpo','ppo','reinforce'}.
 
-    `process_group` (torch.distributed, backend nccl = RCCL on ROCm) enables data parallelism:
-    scenes are sharded across ranks, the exchange step is one all-reduce per optimizer step."""
+    `process_group` (torch.distributed, backend nccl = RCCL on ROCm) enables data parallelism: every minibatch is sharded across the
+    ranks and three SUM all-reduces per step make the sharded update equal the single-process update on the whole minibatch
+    (SURVEY.md 8(e)): two inside the forward (BatchNorm sums of the PointsEncoders + the padding rows the r2r mask quirk reads, then
+    the second BatchNorm; rift_set_dp) and one between backward and finalize (gradient sums, objective sum, valid count).
+    `exchange` (callable(tensor) -> in-place sum over ranks) with `dp_rank` / `dp_world` replaces the process group's all-reduce
+    (tests drive several emulated ranks through one GPU with it)."""
 
     def __init__(self, model, kind: str = "rift", lr=1e-4, cl_lr_decay=0.9, weight_decay=1e-5, epochs=16,
                  warmup_epochs=3, trainable_layers=(PI_HEAD,), gradient_clip_val=0.5, process_group=None,
-                 clip_epsilon=0.2, lambda_entropy=0.01):
+                 clip_epsilon=0.2, lambda_entropy=0.01, seed: int = 0, exchange=None, dp_rank=None, dp_world=None):
         if kind == "rs":     # RS's objective (fine_tuner/sft/rs_pluto/rs_trainer.py:120-170) is REINFORCE's, line for line
             kind = "reinforce"
         if kind not in _ffi.LOSS_KINDS and kind != "rtr":
@@ -135,7 +149,12 @@ class RLFTTrainer:
         self.lr, self.epochs, self.warmup_epochs = lr, epochs, warmup_epochs
         self.gradient_clip_val = gradient_clip_val
         self.pg = process_group
-        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else (dp_world or 1)
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else (dp_rank or 0)
+        if exchange is None and process_group is not None:
+            exchange = lambda t: torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=process_group)  # noqa: E731
+        self.exchange = exchange             # None = single process
+        self.dp_buf = None                   # exchange buffer of the forward (rift_set_dp), sized at the first step
         freeze_parameters(model, list(trainable_layers))
         self.optimizer = configure_optimizer(model, lr, weight_decay)
         self.scheduler = WarmupCosLR(self.optimizer, lr=lr, min_lr=lr * cl_lr_decay, warmup_epochs=warmup_epochs,
@@ -165,7 +184,7 @@ class RLFTTrainer:
         self.lo = _ffi.RiftLossOut()
         self.lo.loss, self.lo.stats, self.lo.flat_grad_sum = self.loss.data_ptr(), self.stats.data_ptr(), self.flat.data_ptr()
         self.xchg = None
-        if process_group is not None:     # DP: one f64 exchange buffer, one all-reduce per step
+        if self.exchange is not None:     # DP: one f64 exchange buffer, one all-reduce per step
             self.xchg = torch.zeros(_ffi.PI_NPARAM + 2, dtype=torch.float64, device=dev)
             self.lo.exchange = self.xchg.data_ptr()
         g = self.params
@@ -178,8 +197,12 @@ class RLFTTrainer:
         self._prob = None
         self._hidden = None
         self._argmax = None
-        self._traj, self._A = None, 0
+        self._traj, self._A, self._traj_A = None, 0, 0
         self.step_count = 0
+        # dropout / DropPath / state-dropout stream: a fresh stream per fit (the caller mixes carla_episode into `seed`) and per DP rank,
+        # as the reference draws fresh torch RNG per fit and per process; the step counter is added on top (forward_loss)
+        rank = self.rank
+        self.seed_base = (int(seed) * 0x9E3779B1 + rank * 0x85EBCA77) & 0x7FFFFFFF
         self.training = True
         self._clip_list = None
         self._fast_groups = None
@@ -204,7 +227,7 @@ class RLFTTrainer:
 
     # ------------------------------------------------------------------------------------
     def _outputs(self, bs, R):
-        if self._prob is None or self._prob.shape[:2] != (bs, R):
+        if self._prob is None or self._prob.shape[:2] != (bs, R) or (self._traj is not None and self._traj_A != self._A):
             dev = self.engine.device
             self._prob = torch.empty(bs, R, 12, device=dev)
             self._hidden = torch.empty(bs, 128, device=dev)
@@ -219,6 +242,7 @@ class RLFTTrainer:
             dev, A = self.engine.device, self._A
             self._traj = (torch.empty(bs, R, 12, 80, 6, device=dev), torch.empty(bs, max(A - 1, 0), 80, 6, device=dev),
                           torch.empty(bs, 80, 4, device=dev))
+            self._traj_A = A                       # the prediction buffer is sized by the agent count: part of the cache key
             self.out.trajectory, self.out.prediction, self.out.ref_free_trajectory = (t.data_ptr() for t in self._traj)
         return self._prob
 
@@ -234,18 +258,40 @@ class RLFTTrainer:
         self.li.old_log_prob = p(b.get("old_log_prob"))
         self.li.returns = p(b.get("returns"))
 
+    def _set_shard(self, fb, shard):
+        """Tell the engine which scenes of the global minibatch this forward holds (None: equal shards in rank order)."""
+        if self.exchange is None or not (self.world > 1 or self.force_exchange):
+            return
+        if shard == "replicated":      # every rank runs the same whole batch (PPO's buffer sweeps): nothing to exchange
+            if self.dp_buf is not None:
+                self.engine.clear_dp()
+            return
+        lo, gbs = shard if shard is not None else (self.rank * fb.bs, self.world * fb.bs)
+        need = gbs * fb.R + 1026
+        if self.dp_buf is None or self.dp_buf.numel() < need:
+            self.dp_buf = torch.zeros(max(need, 4096), dtype=torch.float64, device=self.engine.device)
+        self.engine.set_dp(lo, gbs, self.dp_buf, self.exchange)
+
+    def close(self):
+        """Detach the data-parallel hooks from the (model-owned) engine."""
+        if self.dp_buf is not None:
+            self.engine.clear_dp()
+            self.dp_buf = None
+
     def forward_loss(self, fb: "_ffi.RiftFeatureBatch", extras: Dict[str, torch.Tensor], train: bool = True,
-                     backward: bool = True, flags_extra: int = 0, clip_val: Optional[float] = None, defer_update: bool = False):
+                     backward: bool = True, flags_extra: int = 0, clip_val: Optional[float] = None, defer_update: bool = False,
+                     shard=None):
         """forward + objective (+ pi_head backward into .grad).  Returns the device f64 loss scalar.  With `clip_val` (and no
         critic, i.e. pi_head is the only trainable module) the gradient-norm clip rides in the finalize launch."""
         eng = self.engine
         self._A = fb.A
         self._outputs(fb.bs, fb.R)
+        self._set_shard(fb, shard)
         flags = (_ffi.F_TRAIN if train else 0) | (_ffi.F_NEED_TRAJ if getattr(self.model, "need_traj", False) else 0) | \
                  (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | \
                 (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0) | flags_extra
         self.step_count += 1
-        eng.forward_raw(fb, self.out, flags, self.step_count)
+        eng.forward_raw(fb, self.out, flags, (self.seed_base + self.step_count) & 0xFFFFFFFF)
         if self.kind == "sft":   # label = (the policy's best line, the teacher's mode); extras["teacher_infos"]: (bs, 5) as SFTDataModule yields
             extras = dict(extras)
             extras["action_mode"] = eng.sft_teacher_mode(self._traj[0][:fb.bs], extras["teacher_infos"])
@@ -276,10 +322,10 @@ class RLFTTrainer:
                                count_scale: float = 1.0):
         eng = self.engine
         with_critic = with_critic and self.critic is not None
-        if self.pg is not None and (self.world > 1 or self.force_exchange):
-            dp_all_reduce_exchange(self.xchg, self.pg)
+        if self.exchange is not None and (self.world > 1 or self.force_exchange):
+            self.exchange(self.xchg)
             if with_critic:
-                torch.distributed.all_reduce(self.flat_c, group=self.pg)
+                self.exchange(self.flat_c)
         if count_scale != 1.0:
             (self.xchg[_ffi.PI_NPARAM + 1:] if (self.xchg is not None and self.lo.exchange) else self.stats[1:]).mul_(count_scale)
         if backward:
@@ -294,21 +340,22 @@ class RLFTTrainer:
             lv.loss, lv.stats, lv.flat_grad_sum, lv.exchange = self.lo.loss, self.lo.stats, self.lo.flat_grad_sum, self.lo.exchange
             eng.loss_finalize_raw(lv, 0)
 
-    def forward_hidden(self, fb: "_ffi.RiftFeatureBatch", seed: int) -> torch.Tensor:
+    def forward_hidden(self, fb: "_ffi.RiftFeatureBatch", seed: int, shard="replicated") -> torch.Tensor:
         """Train-mode forward for the PPO buffer sweeps: returns the `hidden` output (bs, 128) (pluto_model.py:173-176)."""
         self._A = fb.A
         self._outputs(fb.bs, fb.R)
+        self._set_shard(fb, shard)
         flags = _ffi.F_TRAIN | (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | \
                 (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0)
         self.engine.forward_raw(fb, self.out, flags, seed)
         return self._hidden[:fb.bs]
 
-    def training_step(self, fb, extras):
+    def training_step(self, fb, extras, shard=None):
         """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step).  Returns the device f64 loss
         scalar; with overlap_update it is written on the update stream -- read it through pop_mean_loss() / wait_update()."""
         fused_clip = bool(self.gradient_clip_val) and self.critic is None
         if self.overlap_update:
-            self.forward_loss(fb, extras, train=True, defer_update=True)
+            self.forward_loss(fb, extras, train=True, defer_update=True, shard=shard)
             main = torch.cuda.current_stream()
             self._ev_loss.record(main)
             with torch.cuda.stream(self._side):
@@ -319,7 +366,7 @@ class RLFTTrainer:
                 self._ev_param.record(self._side)
             self.loss_n += 1
             return self.loss
-        loss = self.forward_loss(fb, extras, train=True, clip_val=self.gradient_clip_val if fused_clip else None)
+        loss = self.forward_loss(fb, extras, train=True, clip_val=self.gradient_clip_val if fused_clip else None, shard=shard)
         if self.gradient_clip_val and not fused_clip:   # PPO: clip_grad_norm_(pi_head + critic params, 0.5) on the device
             if self._clip_list is None:
                 self._clip_list = self.engine.make_clip_list([p.grad for p in self.train_params])
@@ -338,6 +385,7 @@ class RLFTTrainer:
         """Mean training loss since the last call (one host read per epoch instead of one per step)."""
         self.wait_update()
         n, self.loss_n = self.loss_n, 0
+        self.engine.check_finite()          # the reference's isfinite assert on the decoder queries, at the epoch's one host read
         v = float(self.loss_acc.item()) / max(n, 1)
         self.loss_acc.zero_()
         return v
@@ -383,8 +431,8 @@ class RLFTTrainer:
         self.engine.adamw_step_raw(self._adam_list, [g["lr"] for g in self._adam_owner], [g["weight_decay"] for g in self._adam_owner],
                                    float(self._adam_step), g0["betas"][0], g0["betas"][1], g0["eps"])
 
-    def validation_step(self, fb, extras):
-        return self.forward_loss(fb, extras, train=False, backward=False)
+    def validation_step(self, fb, extras, shard=None):
+        return self.forward_loss(fb, extras, train=False, backward=False, shard=shard)
 
     def on_epoch_end(self):
         self.scheduler.step()

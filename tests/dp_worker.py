@@ -1,0 +1,63 @@
+"""torchrun worker of tests/test_gpu_dp.py::test_two_rccl_ranks_equal_single_process: every rank runs (a) three single-process
+optimizer steps on the whole 16-scene minibatch and (b) three data-parallel steps on its half over RCCL; pi_head must agree."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", device_id=dev)
+    from rift_amd import synthetic as syn
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer, split_minibatch
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+    from rift_amd.replay import DeviceReplay
+    from tests import helpers as H
+
+    def model():
+        m = PlanningModel(radius=120, drop_path=0.0, dropout=0.0, state_dropout=0.0)
+        m.load_state_dict(H.weights())
+        m = m.to(dev)
+        m.compute_precision, m.need_traj = "fp32", False
+        m.train()
+        return m
+
+    n = 16
+    replay = DeviceReplay([syn.make_scene(900 + i) for i in range(n)], dev)
+    idx = torch.arange(n, dtype=torch.int32, device=dev)
+    single = RLFTTrainer(model(), kind="rift")
+    for _ in range(3):
+        fb, b = replay.collate(single.engine, idx)
+        single.training_step(fb, b)
+    dp = RLFTTrainer(model(), kind="rift", process_group=dist.group.WORLD)
+    lo, hi = split_minibatch(n, rank, world)
+    for _ in range(3):
+        fb, b = replay.collate(dp.engine, idx[lo:hi])
+        dp.training_step(fb, b, shard=(lo, n))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k in single.params:
+        worst = max(worst, float((single.params[k] - dp.params[k]).abs().max()))
+    sd1, sd2 = single.model.state_dict(), dp.model.state_dict()
+    for k in sd1:
+        if "running_" in k:
+            worst = max(worst, float((sd1[k] - sd2[k]).abs().max() / (1e-6 + sd1[k].abs().max())))
+    t = torch.tensor([worst], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dp.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    assert float(t) < 1e-5, float(t)
+    if rank == 0:
+        print("DP_WORKER_OK", float(t), flush=True)
+
+
+if __name__ == "__main__":
+    main()

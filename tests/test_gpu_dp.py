@@ -1,0 +1,182 @@
+"""Data-parallel update on the HIP path: a minibatch sharded over ranks, with the exchanges of rift_set_dp
+(BatchNorm sums + r2r quirk masks inside the forward) and of the loss (gradient sums, objective sum, count), must equal the
+single-process update on the whole minibatch -- loss, pi_head gradients and BatchNorm running statistics.
+
+One GPU is enough to prove it: the ranks are run one after the other through the same C-ABI with a loop-back exchange that replays,
+at exchange call k, the sum over ranks of what they contributed at call k (one extra pass per exchange call, since a later exchange
+depends on the earlier ones being the reduced values).  The RCCL transport itself is exercised with one rank in-process and, when
+the box has two GPUs, with two torchrun ranks.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from rift_amd import synthetic as syn
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BN_STATS = [f"{p}.{m}.1.{s}" for p in ("map_encoder.polygon_encoder", "planning_decoder.r_encoder")
+            for m in ("first_mlp", "second_mlp") for s in ("running_mean", "running_var")]
+
+
+def _model(precision):
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+    m = PlanningModel(radius=120, drop_path=0.0, dropout=0.0, state_dropout=0.0)       # drops off: the RNG streams are per rank
+    m.load_state_dict(H.weights())
+    m = m.to("cuda:0")
+    m.compute_precision = precision
+    m.need_traj = False
+    m.train()
+    return m
+
+
+class Loopback:
+    """Sequential emulation of `world` ranks: exchange call k of every rank yields sum_r(contribution of rank r at call k)."""
+
+    def __init__(self, world):
+        self.world, self.total, self.pending = world, [], {}
+        self.k = [0] * world
+
+    def start_pass(self):
+        self.k = [0] * self.world
+        self.pending = {}
+
+    def fn(self, r):
+        def exchange(t):
+            k = self.k[r]
+            self.k[r] += 1
+            if k < len(self.total):
+                t.copy_(self.total[k])
+            elif k == len(self.total):
+                self.pending[r] = t.clone()
+        return exchange
+
+    def end_pass(self):
+        """True when every exchange call of the pass was a replay (the results of this pass are final)."""
+        if len(self.pending) == self.world:
+            self.total.append(sum(self.pending.values()))
+            return False
+        assert not self.pending
+        return True
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("sizes", [(6, 6), (5, 4, 3)])
+def test_sharded_step_equals_single_process_step(precision, sizes):
+    from rift_amd import _ffi
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.replay import DeviceReplay
+    n, world = sum(sizes), len(sizes)
+    scenes = [syn.make_scene(300 + i) for i in range(n)]            # heterogeneous reference-line counts: the r2r quirk couples scenes
+    replay = DeviceReplay(scenes, "cuda:0")
+    assert len(set(replay.r_count_cpu.tolist())) > 1
+    R = replay.Rcap
+    idx = torch.arange(n, dtype=torch.int32, device="cuda:0")
+
+    single = RLFTTrainer(_model(precision), kind="rift")
+    fb, b = replay.collate(single.engine, idx, R)
+    want_loss = float(single.forward_loss(fb, b, train=True).item())
+    want_grads = {k: p.grad.clone() for k, p in single.params.items()}
+    want_stats = {k: v.clone() for k, v in single.model.state_dict().items() if k in BN_STATS}
+
+    lb = Loopback(world)
+    ranks = [RLFTTrainer(_model(precision), kind="rift", exchange=lb.fn(r), dp_rank=r, dp_world=world) for r in range(world)]
+    lo = [sum(sizes[:r]) for r in range(world)]
+    for _ in range(8):
+        lb.start_pass()
+        for r, tr in enumerate(ranks):
+            fbr, br = replay.collate(tr.engine, idx[lo[r]:lo[r] + sizes[r]], R)
+            tr.forward_loss(fbr, dict(br), train=True, flags_extra=_ffi.F_NO_BN_UPDATE, shard=(lo[r], n))
+        if lb.end_pass():
+            break
+    else:
+        raise AssertionError("the loop-back exchange did not converge")
+    n_calls = len(lb.total)
+    assert n_calls == (3 if precision == "bf16" else 5)            # fused: 2 BatchNorm points + loss; layer-wise fp32: 4 + loss
+    # final pass once more WITH the running-statistics update (every exchange replays the reduced values)
+    lb.start_pass()
+    for r, tr in enumerate(ranks):
+        fbr, br = replay.collate(tr.engine, idx[lo[r]:lo[r] + sizes[r]], R)
+        tr.forward_loss(fbr, dict(br), train=True, shard=(lo[r], n))
+    assert lb.end_pass()
+    torch.cuda.synchronize()
+    tol = 1e-6 if precision == "fp32" else 2e-6      # same arithmetic per scene; only the fp32 partial-sum order of the reductions differs
+    for r, tr in enumerate(ranks):
+        assert abs(float(tr.loss.item()) - want_loss) < tol, (r, float(tr.loss.item()), want_loss)
+        for k, p in tr.params.items():
+            ref = want_grads[k]
+            assert float((p.grad - ref).abs().max()) < 1e-6 + 1e-4 * float(ref.abs().max()), (r, k)
+        sd = tr.model.state_dict()
+        for k, ref in want_stats.items():
+            assert float((sd[k] - ref).abs().max()) < 1e-6 + 1e-5 * float(ref.abs().max()), (r, k)
+        tr.close()
+
+
+def test_sharded_eval_forward_uses_global_quirk_masks():
+    """Validation step under data parallelism: no BatchNorm exchange, but the r2r quirk still reads the global padding rows."""
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.replay import DeviceReplay
+    sizes, n = (4, 5), 9
+    scenes = [syn.make_scene(700 + i) for i in range(n)]
+    replay = DeviceReplay(scenes, "cuda:0")
+    R = replay.Rcap
+    idx = torch.arange(n, dtype=torch.int32, device="cuda:0")
+    single = RLFTTrainer(_model("fp32"), kind="rift")
+    fb, b = replay.collate(single.engine, idx, R)
+    want = float(single.validation_step(fb, b).item())
+    lb = Loopback(2)
+    ranks = [RLFTTrainer(_model("fp32"), kind="rift", exchange=lb.fn(r), dp_rank=r, dp_world=2) for r in range(2)]
+    lo = [0, sizes[0]]
+    for _ in range(4):
+        lb.start_pass()
+        for r, tr in enumerate(ranks):
+            fbr, br = replay.collate(tr.engine, idx[lo[r]:lo[r] + sizes[r]], R)
+            tr.validation_step(fbr, dict(br), shard=(lo[r], n))
+        if lb.end_pass():
+            break
+    assert len(lb.total) == 2                      # quirk masks, loss sums
+    for tr in ranks:
+        assert abs(float(tr.loss.item()) - want) < 1e-6
+        tr.close()
+
+
+def test_rccl_transport_with_one_rank():
+    """The product path with a real RCCL process group (world size 1, exchanges forced): same step as without a group."""
+    import torch.distributed as dist
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.replay import DeviceReplay
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29613")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        replay = DeviceReplay([syn.make_scene(40 + i) for i in range(16)], "cuda:0")
+        idx = torch.arange(16, dtype=torch.int32, device="cuda:0")
+        plain = RLFTTrainer(_model("bf16"), kind="rift")
+        fb, b = replay.collate(plain.engine, idx)
+        l0 = float(plain.training_step(fb, b).item())
+        dp = RLFTTrainer(_model("bf16"), kind="rift", process_group=dist.group.WORLD)
+        dp.force_exchange = True
+        fb, b = replay.collate(dp.engine, idx)
+        l1 = float(dp.training_step(fb, b).item())
+        torch.cuda.synchronize()
+        assert abs(l0 - l1) < 1e-9
+        for k in plain.params:
+            assert torch.equal(plain.params[k], dp.params[k]), k
+        dp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on the box")
+def test_two_rccl_ranks_equal_single_process():
+    """Two torchrun ranks over RCCL: the sharded update (3 optimizer steps) leaves the same pi_head on both ranks as one process."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29617", os.path.join(REPO, "tests", "dp_worker.py")], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DP_WORKER_OK" in out.stdout
