@@ -7,9 +7,12 @@
 One *step* = one policy-update step of the reference's RIFT trainer on a 256-scene minibatch per GPU:
 device-side collation of 256 scenes from the HBM-resident replay arena -> train-mode PlanningModel
 forward (dropout / DropPath / state-dropout on, BatchNorm batch statistics) -> RIFT dual-clip loss ->
-analytic pi_head backward -> [RCCL all-reduce] -> clip_grad_norm_(0.5) -> AdamW.
+analytic pi_head backward -> clip_grad_norm_(0.5) -> AdamW.  With N > 1 ranks three RCCL all-reduces per step
+(two inside the forward: BatchNorm sums + the r2r quirk's padding rows; one after the backward: gradient sums,
+objective sum, valid count) make the sharded step equal the single-process step on the global minibatch.
 Workload = BASELINE.json configs[2]/[3]: 4096-scene synthetic replay, 64 agents x 20 polygons x R~U{1..6}
-reference lines x 12 modes, sharded across the N ranks (weak scaling: 256 scenes / GPU / step).
+reference lines x 12 modes.  --scaling weak (default): the replay is sharded, 256 scenes / GPU / step;
+--scaling strong: the reference's 256-scene minibatch is split over the ranks.
 """
 import argparse
 import json
@@ -22,60 +25,88 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-FLOPS_PER_SCENE = 1.335e9        # reference-equivalent forward FLOPs/scene at (A=64, Mp=20, R=4)
+FLOPS_PER_SCENE = 1.335e9        # reference-equivalent forward FLOPs/scene at (A=64, Mp=20, R=4), every output computed
+FLOPS_PER_SCENE_LOSS = 1.285e9   # the loss-necessary subset (no trajectory / prediction / ref-free heads) -- what the headline step executes
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 BATCH = 256
 
 
-def cpu_baseline(scenes, sd, steps=6):
-    """The reference update step restated on the host cores (oracle = PyTorch-CPU fp32 port of the
-    reference algorithm): CPU collate (pad_sequence) -> forward (BatchNorm batch stats, drop p=0) ->
-    RIFT loss -> autograd pi_head backward -> clip 0.5 -> AdamW.  Bounded sample (~20 s).
-    Threads: 32 (measured fastest on the 256-core GPU box: 4 -> 76, 8 -> 117, 16 -> 131, 32 -> 145, 64 -> 71
-    scenes/s forward; the reference's own default is 4, scripts/run.py:133,164)."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(scenes, sd):
+    """The reference update step restated on the host cores (oracle = PyTorch-CPU fp32 port of the reference algorithm): CPU collate
+    (pad_sequence) -> forward (BatchNorm batch stats, drop p=0) -> RIFT loss -> autograd pi_head backward -> clip 0.5 -> AdamW.
+    Bounded sample (~25 s): 5 steps at 32 threads (the fastest count measured on the 256-core GPU box: 4 -> 76, 8 -> 117, 16 -> 131,
+    32 -> 145, 64 -> 71 scenes/s forward) and 2 steps at the reference's own default of 4 threads (scripts/run.py:133,164)."""
     from oracle import losses, pluto_ref
     from rift_amd import synthetic as syn
-    threads = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     prefix = "planning_decoder.pi_head."
-    params = {k: sd[prefix + k].clone().requires_grad_(True) for k in losses.PI_KEYS}
-    opt = torch.optim.AdamW(list(params.values()), lr=1e-4, weight_decay=1e-5)
 
-    def one_step(chunk):
-        batch = syn.collate_scenes(chunk)
-        data = batch["cur_pluto_feature_torch"]
-        _, _, taps = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=True, want_taps=True)
-        r_pad = ~data["reference_line"]["valid_mask"].any(-1)
-        live = dict(sd)
-        live.update({prefix + k: v for k, v in params.items()})
-        pi = pluto_ref.mlp_layer(taps["q_final"], pluto_ref.SD(live, prefix)).squeeze(-1)
-        prob = pi.masked_fill(r_pad.unsqueeze(-1), -1e6)
-        loss = losses.rift_loss(prob, r_pad, batch["old_group_logits_torch"], batch["group_advantage_torch"],
-                                batch["group_advantage_mask_torch"])
-        opt.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(list(params.values()), 0.5)
-        opt.step()
+    def run(threads, steps):
+        torch.set_num_threads(threads)
+        params = {k: sd[prefix + k].clone().requires_grad_(True) for k in losses.PI_KEYS}
+        opt = torch.optim.AdamW(list(params.values()), lr=1e-4, weight_decay=1e-5)
 
-    one_step(scenes[:32])          # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    n = 0
-    for s in range(steps):
-        chunk = scenes[s * BATCH:(s + 1) * BATCH]
-        if len(chunk) < BATCH:
-            break
-        one_step(chunk)
-        n += 1
-    dt = time.perf_counter() - t0
+        def one_step(chunk):
+            batch = syn.collate_scenes(chunk)
+            data = batch["cur_pluto_feature_torch"]
+            _, _, taps = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=True, want_taps=True)
+            r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+            live = dict(sd)
+            live.update({prefix + k: v for k, v in params.items()})
+            pi = pluto_ref.mlp_layer(taps["q_final"], pluto_ref.SD(live, prefix)).squeeze(-1)
+            prob = pi.masked_fill(r_pad.unsqueeze(-1), -1e6)
+            loss = losses.rift_loss(prob, r_pad, batch["old_group_logits_torch"], batch["group_advantage_torch"],
+                                    batch["group_advantage_mask_torch"])
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(list(params.values()), 0.5)
+            opt.step()
+
+        one_step(scenes[:32])          # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        n = 0
+        for s in range(steps):
+            chunk = scenes[s * BATCH:(s + 1) * BATCH]
+            if len(chunk) < BATCH:
+                break
+            one_step(chunk)
+            n += 1
+        dt = time.perf_counter() - t0
+        return n, dt
+
+    hw = os.cpu_count() or 1
+    threads = min(32, hw)
+    n, dt = run(threads, 5)
+    n4, dt4 = run(min(4, hw), 2)
     return {"value": n * BATCH / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
-            "sample": f"{n} update steps x {BATCH} scenes (collate+fwd+RIFT loss+bwd+clip+AdamW), PyTorch-CPU fp32 oracle, "
-                      f"{dt:.1f}s", "steps_per_sec": n / dt}
+            "sample": f"{n} update steps x {BATCH} scenes (collate+fwd all outputs+RIFT loss+bwd+clip+AdamW), PyTorch-CPU fp32 oracle, "
+                      f"{dt:.1f}s at {threads} threads; {n4} steps, {dt4:.1f}s at 4 threads", "steps_per_sec": n / dt,
+            "reference_default_4_threads": {"value": n4 * BATCH / dt4, "unit": "scenes/s", "cores": min(4, hw), "steps_per_sec": n4 / dt4},
+            "cpu_model": cpu_model_name(), "logical_cpus": hw}
+
+
+def pmc_traffic_file():
+    """The newest committed per-kernel HBM-traffic table (profiles/rNN_pmc_traffic.json, written by tools/profile_round.sh from separate
+    rocprofv3 --pmc passes of this bench).  Counters cannot be collected from inside the process, so `roofline.traffic` is the
+    committed measurement of the same command; null when no table is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    return files[-1] if files else None
 
 
 def pmc_traffic(label):
     """HBM bytes per launch of the kernel behind an engine profiler label, from the committed PMC passes (None if absent)."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    path = pmc_traffic_file()
+    if path is None:
         return None
     kern = json.load(open(path))["kernels"]
     nat = {"nat_level_kernel_L0": "nat_level_kernel<32,", "nat_level_kernel_L1": "nat_level_kernel<64,", "nat_level_kernel_L2": "nat_level_kernel<128,"}
@@ -93,12 +124,16 @@ def pmc_traffic(label):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--replay", type=int, default=4096, help="total replay scenes (sharded across ranks)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 256 scenes per GPU per step (global minibatch 256 x N); strong: the reference's 256-scene minibatch split over "
+                         "the N GPUs (SURVEY.md 8(e): 32 scenes per GPU at N = 8)")
+    ap.add_argument("--no-full-update", action="store_true")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (rank 0's JSON): libraries that print banners to fd 1 (RCCL prints its version block at communicator
@@ -125,10 +160,18 @@ def main():
     from rift_amd.planning.pluto.model.pluto_model import PlanningModel
     from rift_amd.replay import DeviceReplay
 
-    # ---- replay shard of this rank (seeded per scene index, so the union over ranks is the same 4096 scenes)
-    per_rank = max(BATCH, args.replay // world)
+    # ---- replay of this rank.  weak scaling: disjoint shards of the 4096 scenes (seeded per scene index), 256 scenes per GPU per step,
+    # global minibatch 256 x N.  strong scaling: every rank holds the whole replay, all ranks draw the same 256-scene
+    # minibatch and each takes its contiguous 256 / N slice.  Either way the three exchanges of RLFTTrainer make the step equal the
+    # single-process step on the global minibatch.
+    strong = args.scaling == "strong" and world > 1
+    if strong and BATCH % world:
+        raise SystemExit(f"--scaling strong needs {BATCH} % N == 0")
+    local_bs = BATCH // world if strong else BATCH
+    global_bs = BATCH if strong else BATCH * world
+    per_rank = args.replay if strong else max(BATCH, args.replay // world)
     t_gen = time.perf_counter()
-    scenes = [syn.make_scene(i) for i in shard_scene_ids(rank, world, per_rank)]
+    scenes = [syn.make_scene(i) for i in (range(per_rank) if strong else shard_scene_ids(rank, world, per_rank))]
     replay = DeviceReplay(scenes, dev, rcap=6)
     t_gen = time.perf_counter() - t_gen
 
@@ -141,57 +184,85 @@ def main():
     model.compute_precision = args.precision
     model.need_traj = False
     model.train()
-    trainer = RLFTTrainer(model, kind="rift", process_group=pg)
+    trainer = RLFTTrainer(model, kind="rift", process_group=pg, seed=1)
     eng = trainer.engine
 
-    g = torch.Generator().manual_seed(1000 + rank)
+    g = torch.Generator().manual_seed(1000 if strong else 1000 + rank)
     nsteps = args.warmup + args.steps + 8
-    idx = [torch.randperm(per_rank, generator=g)[:BATCH].to(torch.int32).to(dev) for _ in range(nsteps)]
+    lo = rank * local_bs if strong else 0
+    idx = [torch.randperm(per_rank, generator=g)[:BATCH][lo:lo + local_bs].to(torch.int32).to(dev) for _ in range(nsteps)]
+    shard = (rank * local_bs, global_bs)
 
     def step(i):
         fb, b = replay.collate(eng, idx[i])
-        return trainer.training_step(fb, b)
+        return trainer.training_step(fb, b, shard=shard)
+
+    def timed(first, count):
+        """`count` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        if pg is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(first, first + count):
+            last = step(i)
+        torch.cuda.synchronize()
+        if pg is not None:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        if pg is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, last
 
     for i in range(args.warmup):
         step(i)
-    if pg is not None:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        loss = step(i)
-    torch.cuda.synchronize()
-    if pg is not None:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if pg is not None:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, loss = timed(args.warmup, args.steps)
     final_loss = float(loss.item())
+    eng.check_finite()
 
     # ---- companion figure: the same K steps with EVERY output of PlanningModel.forward computed (trajectory / prediction /
     # ref-free heads -- outputs the RLFT losses never read; the reference's training_step computes them, SURVEY.md 8 a6/a7)
     model.need_traj = True
     for i in range(2):
         step(i)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    dt_all = time.perf_counter() - t1
+    dt_all, _ = timed(args.warmup, args.steps)
     model.need_traj = False
 
+    # ---- companion figure: one full policy update as SURVEY.md 8(d) words it -- 16 epochs x (15 training steps + 2 validation steps
+    # on the 90 / 10 split of the 4096-scene replay) with the per-epoch host read and scheduler step (single GPU only)
+    full_update = None
+    if world == 1 and not args.no_full_update:
+        n_val = per_rank - int(0.9 * per_rank)
+        val_idx = [torch.arange(s, min(s + BATCH, n_val), dtype=torch.int32, device=dev) for s in range(0, n_val, BATCH)]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        k = 0
+        for epoch in range(16):
+            for _ in range(15):
+                step(k % nsteps)
+                k += 1
+            trainer.pop_mean_loss()
+            for vi in val_idx:
+                fb, b = replay.collate(eng, vi)
+                trainer.validation_step(fb, b)
+            trainer.on_epoch_end()
+        torch.cuda.synchronize()
+        t_full = time.perf_counter() - t2
+        full_update = {"seconds": t_full, "train_steps": 240, "val_steps": 16 * len(val_idx), "updates_per_sec": 1.0 / t_full,
+                       "note": "16 epochs x (15 x 256-scene training steps + validation of the 10 % split), epoch-end host read included"}
+
     # ---- roofline leg: per-launch HIP events on the launch stream (separate short pass, rank 0)
+    # (every rank runs the profiled steps -- they contain the exchanges -- and rank 0 reports)
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         eng.prof_enable(True)
         nprof = 4
         for i in range(nprof):
             step(args.warmup + args.steps + i)
         rep = eng.prof_report()
         eng.prof_enable(False)
+    if rank == 0 and not args.no_roofline:
         tot_ms = sum(v["ms"] for v in rep.values())
         dom = max(rep.items(), key=lambda kv: kv[1]["ms"])
         gemm_ms = sum(v["ms"] for k, v in rep.items() if k.startswith("gemm_"))
@@ -199,8 +270,9 @@ def main():
         ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12 if dom[1]["ms"] > 0 else 0.0
         roof = {"bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom[0]),
-                "traffic_source": "profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from separate rocprofv3 --pmc "
-                                  "passes of this bench (tools/profile_round.sh)",
+                "traffic_source": (os.path.relpath(pmc_traffic_file(), REPO) if pmc_traffic_file() else "none") +
+                                  ": (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from separate rocprofv3 --pmc passes of this bench "
+                                  "(tools/profile_round.sh); committed measurement, not collected in this run",
                 "avg_launch_us": dom[1]["ms"] * 1e3 / dom[1]["count"], "launches_per_step": dom[1]["count"] / nprof,
                 "kernel_share_of_gpu_time": dom[1]["ms"] / tot_ms,
                 "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
@@ -210,24 +282,31 @@ def main():
 
     if rank == 0:
         steps_per_sec = args.steps / dt
-        scenes_per_sec = steps_per_sec * BATCH * world
+        scenes_per_sec = steps_per_sec * global_bs
         line = {
             "metric": "policy-update scenes/sec (256-scene RIFT update steps on a 4096-scene replay)",
             "value": scenes_per_sec, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "steps_per_sec": steps_per_sec,
             "config": {"workload": "BASELINE configs[2]/[3]: full rift_pluto CBV policy, 4096-scene synthetic replay "
                                    "(64 agents x 21 steps, 20 polygons x 3 x 20 pts, R~U{1..6} x 120 ref pts, 12 modes), "
                                    "RIFT loss, pi_head trainable",
-                       "per_gpu_batch": BATCH, "global_batch": BATCH * world, "replay_scenes_per_gpu": per_rank,
-                       "parallelism": f"dp{world}", "train_mode": "dropout+droppath+state-dropout, BN batch stats",
-                       "outputs": "probability (the trajectory / prediction / hidden heads are dead outputs for the RIFT loss; see all_outputs)"},
-            "whole_step_mfma_frac": scenes_per_sec / world * FLOPS_PER_SCENE / (PEAK_BF16_TFLOPS * 1e12),
-            "all_outputs": {"ms_per_step": dt_all / args.steps * 1e3, "value": args.steps / dt_all * BATCH * world,
-                            "note": "this rank's rate x N with the dead trajectory/prediction/ref-free heads also computed"},
+                       "per_gpu_batch": local_bs, "global_batch": global_bs, "replay_scenes_per_gpu": per_rank,
+                       "parallelism": f"dp{world}", "train_mode": "dropout+droppath+state-dropout, BN batch stats"
+                                                                + (" over the global minibatch (3 all-reduces per step)" if world > 1 else ""),
+                       "outputs": "probability (the trajectory / prediction / ref-free heads feed no RLFT loss and are skipped; "
+                                  "all_outputs = the same steps with every output of PlanningModel.forward computed)"},
+            # whole-step fraction of the dense bf16 MFMA peak, priced at the algorithmic FLOPs of what each variant executes
+            "whole_step_mfma_frac": scenes_per_sec / world * FLOPS_PER_SCENE_LOSS / (PEAK_BF16_TFLOPS * 1e12),
+            "all_outputs": {"ms_per_step": dt_all / args.steps * 1e3, "value": args.steps / dt_all * global_bs,
+                            "steps_per_sec": args.steps / dt_all,
+                            "whole_step_mfma_frac": args.steps / dt_all * global_bs / world * FLOPS_PER_SCENE / (PEAK_BF16_TFLOPS * 1e12),
+                            "note": "trajectory / prediction / ref-free heads computed as the reference's training_step does (1.335 GFLOP per scene)"},
             "final_loss": final_loss, "replay_gen_s": round(t_gen, 2), "replay_hbm_mb": round(replay.nbytes() / 1e6, 1),
         }
+        if full_update is not None:
+            line["full_update"] = full_update
         if roof is not None:
             line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:

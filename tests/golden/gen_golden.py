@@ -451,8 +451,46 @@ def gen_sft():
     print("sft ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", float(out["loss"]), res["target_r"].tolist(), res["target_m"].tolist())
 
 
+def gen_collate():
+    """Collation as the reference does it: PlutoFeature.collate (pluto/feature_builder/pluto_feature.py:25-96) inside RIFTCollate.__call__
+    (fine_tuner/rlft/rift_pluto/rift_datamodule.py:20-51), imported from the reference and run on ragged seeded scenes (agent, polygon
+    and reference-line counts all differ per scene).  The fixture holds every tensor of the padded batch."""
+    import types
+    from tests.helpers import collate_scenes_ragged
+    ref_loader.install()
+    for pkg in ("rift.gym_carla", "rift.gym_carla.buffer", "rift.util"):      # package shells: their __init__ import carla / pygame
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(ref_loader.REF_ROOT, *pkg.split("."))]
+            sys.modules[pkg] = m
+    dm = importlib.import_module("rift.cbv.planning.fine_tuner.rlft.rift_pluto.rift_datamodule")
+    pf = importlib.import_module("rift.cbv.planning.pluto.feature_builder.pluto_feature")
+    scenes = collate_scenes_ragged()
+    batch_in = [{"CBVs_obs": {"raw_pluto_feature": pf.PlutoFeature(data=s["feature"])},
+                 "CBVs_group_advantage": {"advantage": s["extras"]["group_advantage"].numpy(),
+                                          "valid_mask": s["extras"]["group_advantage_mask"].numpy()},
+                 "CBVs_actions_old_group_logits": {"logits": s["extras"]["old_group_logits"].numpy(),
+                                                   "valid_mask": s["extras"]["old_group_logits_mask"].numpy()}} for s in scenes]
+    res = dm.RIFTCollate()(batch_in)
+    out = {}
+    for grp, v in res["cur_pluto_feature_torch"].data.items():
+        if isinstance(v, dict):
+            for k, t in v.items():
+                out[f"feature/{grp}/{k}"] = to_np(t)
+        else:
+            out[f"feature/{grp}"] = to_np(v)
+    for k in ("group_advantage_torch", "group_advantage_mask_torch", "old_group_logits_torch", "old_group_logits_mask_torch"):
+        out[k] = to_np(res[k])
+    out["input_digest"] = syn.digest({f"{i}/{k}": v for i, s in enumerate(scenes) for k, v in syn.flatten_dict(s["feature"]).items()})
+    path = os.path.join(HERE, "collate.npz")
+    np.savez_compressed(path, **out)
+    print("collate ->", path, f"{os.path.getsize(path) / 1e3:.1f} KB", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and k.startswith("feature/agent")})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "sft":
+    if len(sys.argv) > 1 and sys.argv[1] == "collate":
+        gen_collate()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sft":
         gen_sft()
     elif len(sys.argv) > 1 and sys.argv[1] == "other_vehicles":
         gen_other_vehicles()

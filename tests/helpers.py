@@ -179,3 +179,13 @@ def sft_inputs(seed=31337, bs=6, R=4, M=12, T=80):
                            torch.rand(bs, generator=g) * 2 - 1, 3.0 + 5.0 * torch.rand(bs, generator=g)], -1).float()
     return {"probability": prob, "trajectory": traj, "ref_valid_mask": rvalid[..., None].expand(bs, R, 120).contiguous(),
             "r_pad": ~rvalid, "teacher_infos": teacher}
+
+
+def collate_scenes_ragged():
+    """Seeded scenes with ragged agent / polygon / reference-line counts (tests/golden/collate.npz = the reference's RIFTCollate on them)."""
+    dims = [(9, 5, 2), (16, 10, 4), (3, 7, 1), (12, 2, 3), (16, 9, 4), (5, 10, 2), (1, 1, 1)]
+    scenes = []
+    for i, (A, Mp, R) in enumerate(dims):
+        s = syn.make_scene(5000 + i, A, Mp, R, R)
+        scenes.append({"feature": s["feature"], "extras": s["extras"]})
+    return scenes

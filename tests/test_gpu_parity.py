@@ -290,6 +290,43 @@ def test_device_collation_matches_pad_sequence(ffi):
     eng.close()
 
 
+def test_device_collation_matches_the_reference_generated_fixture(ffi):
+    """rift_collate against tests/golden/collate.npz -- the output of the REFERENCE's RIFTCollate.__call__ / PlutoFeature.collate
+    (rift_datamodule.py:20-51, pluto_feature.py:25-96) on ragged seeded scenes (agent, polygon and reference-line counts differ per
+    scene): every tensor the engine consumes, bit-exact, in the order and with a repeated index as a DataLoader batch could hold."""
+    import os
+    from rift_amd.replay import DeviceReplay
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "collate.npz")))
+    scenes = H.collate_scenes_ragged()
+    assert syn.digest({f"{i}/{k}": v for i, s in enumerate(scenes) for k, v in syn.flatten_dict(s["feature"]).items()}) == str(gold["input_digest"])
+    eng = ffi.Engine("cuda:0")
+    rp = DeviceReplay(scenes, "cuda:0")
+    idx = torch.arange(len(scenes), dtype=torch.int32, device="cuda:0")
+    fb, b = rp.collate(eng, idx, int(rp.r_count_cpu.max()))
+    torch.cuda.synchronize()
+    flat = syn.flatten_dict(rp.batch_dict(b))
+    n = 0
+    for k, v in flat.items():
+        ref = gold["feature/" + k.replace(".", "/")]
+        got = v.cpu().numpy()
+        assert got.shape == ref.shape and got.dtype == ref.dtype, (k, got.shape, got.dtype, ref.shape, ref.dtype)
+        assert np.array_equal(got, ref), k
+        n += 1
+    assert n >= 21
+    for mine, theirs in (("old_group_logits", "old_group_logits_torch"), ("group_advantage", "group_advantage_torch"),
+                         ("group_valid_mask", "group_advantage_mask_torch")):
+        got = b[mine].cpu().numpy()
+        assert got.dtype == gold[theirs].dtype and np.array_equal(got, gold[theirs]), mine
+    # a permuted pick with a repeat: rows of the fixture in that order (reference-line padding is to the fixture's batch maximum)
+    pick = [4, 0, 6, 4, 2]
+    fb, b = rp.collate(eng, torch.tensor(pick, dtype=torch.int32, device="cuda:0"), int(rp.r_count_cpu.max()))
+    torch.cuda.synchronize()
+    for k, v in syn.flatten_dict(rp.batch_dict(b)).items():
+        assert np.array_equal(v.cpu().numpy(), gold["feature/" + k.replace(".", "/")][pick]), k
+    assert np.array_equal(b["group_advantage"].cpu().numpy(), gold["group_advantage_torch"][pick])
+    eng.close()
+
+
 def test_fused_nat_level_matches_layerwise_path(ffi, monkeypatch):
     """The fused NAT level kernel (80 rows resident in LDS) against the layer-by-layer GEMM path and
     against the exact-fp32 path, on the history-encoder output of every agent."""
@@ -470,9 +507,11 @@ def test_fused_decoder_matches_layerwise_path(ffi, monkeypatch, case):
 
 def test_candidate_rollout_and_ref_line_info(ffi):
     """rift_ref_line_info / rift_rollout against the oracle (bit-exact with the reference on CPU) on two
-    consecutive calls (persistent PID state).  Integer outputs (closest reference indices, PID aim indices):
-    bit-exact; trajectories / kinematics: 1e-3 abs (GPU libm differs from the host's in the last ulp and the
-    79-step loop is iterative)."""
+    consecutive calls (persistent PID state).  Integer outputs (closest reference indices, PID aim indices): bit-exact.
+    Floats: the device's sinf / cosf / atan2f and torch-CPU's (SLEEF, 1 ulp) differ in the last bit, and the 79-step closed loop
+    integrates that: tolerances are ~3x the worst error measured over 8 seeded calls (tests/diagnostics/a11_errors.py on MI355X:
+    delta_dis 1.9e-6, delta_angle 2.4e-7, center 3.1e-4 m after 8 s, angle 7.2e-6, speed 1.4e-4, acc 7.6e-4, ang_vel 6.6e-6,
+    ang_acc 4.2e-5; discounted return 9.3e-5 on values of O(10), group advantage 3.2e-6 -- north_star's bar for advantages is 1e-4)."""
     from oracle import rollout as orl
     eng = ffi.Engine("cuda:0")
     ro = orl.Rollout()
@@ -483,7 +522,7 @@ def test_candidate_rollout_and_ref_line_info(ffi):
         dd, da, ci = orl.ref_line_info(t40, ref_pos, ref_ang)
         hdd, hda, hci = eng.ref_line_info(traj, ref_pos, ref_ang, Ts=40)
         assert np.array_equal(hci.cpu().numpy(), ci.numpy().astype(np.int32))          # bit-exact integer indices
-        assert err(hdd, dd) < 1e-4 and err(hda, da) < 1e-4
+        assert err(hdd, dd) < 1e-5 and err(hda, da) < 2e-6
         gpos, ghead = orl.to_global(t40, torch.tensor(st["pos"]), torch.tensor(st["heading"]))
         ref = ro.propagate(gpos, ghead, st["speed"], st["width"], st["length"])
         cs = torch.tensor([[st["pos"][0], st["pos"][1], st["heading"], st["speed"], st["width"], st["length"]]])
@@ -491,7 +530,7 @@ def test_candidate_rollout_and_ref_line_info(ffi):
         torch.cuda.synchronize()
         assert np.array_equal(out["closest_index"].cpu().numpy(), ref["closest_index"].numpy().astype(np.int32)), call
         assert np.array_equal(out["aim_idx"].cpu().numpy(), ref["aim_idx"].numpy().astype(np.int32)), call
-        for k, tol in (("center", 1e-3), ("angle", 1e-4), ("speed", 1e-3), ("acc", 2e-2), ("ang_vel", 2e-3), ("ang_acc", 5e-2),
+        for k, tol in (("center", 1e-3), ("angle", 2e-5), ("speed", 5e-4), ("acc", 2.5e-3), ("ang_vel", 2e-5), ("ang_acc", 1.5e-4),
                        ("vertices", 1e-3)):
             assert err(out[k], ref[k]) < tol, (call, k, err(out[k], ref[k]))
     eng.close()
@@ -688,7 +727,8 @@ def test_traj_evaluator_grpo_advantage_with_device_flags(ffi):
     """TrajEvaluator.get_grpo_advantage end to end on the device -- ref-line deviation, closed-loop rollout, collision flags from the
     neighbours' forecast footprints, off-road flags from the raster, discounted return, group z-score -- against the oracle chain.
     The flags are computed from each side's OWN rollout (device vs CPU libm differ in the last ulp after 79 closed-loop steps), so
-    they are compared through the advantage: 1e-3 abs on the z-scored returns unless a flag differs, which the test rules out first."""
+    they are compared through the advantage: north_star's 1e-4 abs on the z-scored returns (measured 3.2e-6 worst over 8 seeded calls,
+    tests/diagnostics/a11_errors.py; held to 2e-5 here) unless a flag differs, which the test rules out first."""
     from oracle import advantage as oadv, rollout as orl, traj_flags as otf
     from rift_amd.planning.fine_tuner.rlft.traj_eval.traj_evaluator import TrajEvaluator
     eng = ffi.Engine("cuda:0")
@@ -723,7 +763,7 @@ def test_traj_evaluator_grpo_advantage_with_device_flags(ffi):
                               ref["ang_vel"][:, :40].numpy(), ref["ang_acc"][:, :40].numpy(), col, off)
     want = oadv.group_zscore(ret).reshape(R, M)
     assert got["valid_mask"].all() and got["advantage"].shape == (R, M)
-    assert err(torch.from_numpy(got["advantage"]), torch.from_numpy(want)) < 1e-3
+    assert err(torch.from_numpy(got["advantage"]), torch.from_numpy(want)) < 2e-5
     eng.close()
 
 

@@ -7,6 +7,7 @@ import torch
 from rift_amd import synthetic as syn
 from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
 from rift_amd.planning.pluto.feature_builder.pluto_feature import PlutoFeature
+from tests import helpers as H
 
 KEYS = ['CBVs_obs', 'CBVs_reward', 'CBVs_done', 'CBVs_actions_old_group_logits', 'CBVs_group_advantage',
         'CBVs_actions_ref_group_logits']
@@ -59,6 +60,34 @@ def test_pluto_feature_collate_matches_reference_semantics():
     assert pf.data["agent"]["position"].shape[:2] == (3, 8)
     rt = PlutoFeature.deserialize(pf.serialize())
     assert torch.equal(rt.data["map"]["point_position"], pf.data["map"]["point_position"])
+
+
+def _collate_fixture():
+    import os
+    import numpy as np
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "collate.npz")))
+    scenes = H.collate_scenes_ragged()
+    assert syn.digest({f"{i}/{k}": v for i, s in enumerate(scenes) for k, v in syn.flatten_dict(s["feature"]).items()}) == str(gold["input_digest"])
+    return gold, scenes
+
+
+def test_collation_matches_the_reference_generated_fixture():
+    """tests/golden/collate.npz = the reference's own RIFTCollate.__call__ / PlutoFeature.collate (rift_datamodule.py:20-51,
+    pluto_feature.py:25-96) run on ragged seeded scenes.  The host mirror and the helper every other parity test builds its batches
+    with (rift_amd.synthetic.collate_scenes) must reproduce it bit for bit: every key, shape, dtype and value."""
+    import numpy as np
+    gold, scenes = _collate_fixture()
+    mirror = PlutoFeature.collate([PlutoFeature(data=s["feature"]) for s in scenes]).data
+    helper = syn.collate_scenes(scenes)
+    want_keys = {k[len("feature/"):].replace("/", ".") for k in gold if k.startswith("feature/")}
+    for name, got in (("mirror", syn.flatten_dict(mirror)), ("helper", syn.flatten_dict(helper["cur_pluto_feature_torch"]))):
+        assert set(got) == want_keys, (name, set(got) ^ want_keys)
+        for k, v in got.items():
+            ref = gold["feature/" + k.replace(".", "/")]
+            assert tuple(v.shape) == ref.shape and v.numpy().dtype == ref.dtype, (name, k, v.shape, v.dtype, ref.shape, ref.dtype)
+            assert np.array_equal(v.numpy(), ref), (name, k)
+    for k in ("group_advantage_torch", "group_advantage_mask_torch", "old_group_logits_torch", "old_group_logits_mask_torch"):
+        assert helper[k].numpy().dtype == gold[k].dtype and np.array_equal(helper[k].numpy(), gold[k]), k
 
 
 def test_policy_registry_and_lr_schedule():
