@@ -152,7 +152,8 @@ def main():
     if world > 1 or os.environ.get("RIFT_BENCH_FORCE_PG") == "1":   # (the env switch exercises the RCCL path on a single GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
 
     from rift_amd import synthetic as syn
