@@ -4,11 +4,17 @@ golden fixtures.  Needs a real MI355X: `pytest -m gpu`.
 Tolerances (written here, per the parity contract):
   fp32 mode  (v_mfma_f32_16x16x4_f32, exact fp32 fma chains): logits / activations 1e-4 abs, losses 1e-5,
              pi_head grads 1e-5 + 1e-4 rel; integer indices bit-exact.
-  bf16 mode  (v_mfma_f32_16x16x32_bf16, fp32 accumulate; the benchmarked precision): logits 5e-2 abs,
-             losses 5e-3 abs on these 2-8 scene batches, 1e-4 (the north_star bar) on the 256-scene benchmark batch
-             (test_benchmark_batch_rift_loss_within_1e4_in_bf16);
-             the loss/backward kernels themselves are fp32/fp64 and are held to 1e-5 against the oracle
-             evaluated on the SAME (HIP) pi_head input.
+  bf16 mode  (v_mfma_f32_16x16x32_bf16, fp32 accumulate; the benchmarked precision).  Every MFMA operand of ~50 chained contractions
+             is rounded to 8 mantissa bits, which puts ~1.5e-2 on the logits whatever the kernel does
+             (tests/diagnostics/precision_study.py reproduces it on the CPU from operand rounding alone: bf16 2.3e-2 / 1.8e-2 on
+             small / full, fp16 2.7e-3, three-pass bf16 3e-5).  Bars are ~2.5x what MI355X measures:
+               logits 4e-2 abs (measured 1.5e-2 small, 1.1e-2 full);
+               losses of the 6-scene fixture: RIFT 2.5e-4 (8.9e-5), GRPO / REINFORCE / PPO 3.5e-3 (1.0e-3 / 4.4e-4 / 1.4e-3);
+               RIFT loss of the 256-scene benchmark minibatch 1e-4, north_star's bar (5.8e-5: per-scene errors average out);
+               pi_head gradient of that minibatch against the fp32 oracle: ||dg|| / ||g|| 0.16, cosine 0.988
+               (test_benchmark_batch_bf16_gradients_against_the_fp32_oracle).
+             The loss / backward kernels themselves are fp32 / fp64 and are held to 1e-5 against the oracle evaluated on the SAME
+             (HIP) pi_head input.  A caller that needs 1e-4 per small batch or 1e-4-relative gradients sets compute_precision = "fp32".
 """
 import os
 
@@ -77,7 +83,8 @@ def _run_case(ffi, case, fp32):
 def test_forward_eval(ffi, case, fp32):
     gold, batch, sd, data, eng, out = _run_case(ffi, case, fp32)
     ref, _, taps = pluto_ref.planning_model_forward(sd, H.clone_tree(data), want_taps=True)
-    tol = 1e-4 if fp32 else 5e-2
+    tol = 1e-4 if fp32 else 4e-2
+    print(f"forward_eval[{case}, {'fp32' if fp32 else 'bf16'}]: max |logit - reference| = {err(out['probability'], gold['eval.probability']):.3e}")
     bs, A = data["agent"]["position"].shape[:2]
     va = data["agent"]["valid_mask"].any(-1)
     kpm = torch.cat([~va, ~data["map"]["valid_mask"].any(-1)], dim=-1)
@@ -129,7 +136,8 @@ def test_loss_kernels_bf16_trunk(ffi, kind):
     grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
     loss = eng.loss_finalize(stats, flat, grads)
     torch.cuda.synchronize()
-    assert abs(float(loss.item()) - float(gold[f"{kind}.loss"])) < 5e-3
+    print(f"bf16 trunk, small fixture, {kind}: |loss - reference| = {abs(float(loss.item()) - float(gold[f'{kind}.loss'])):.3e}")
+    assert abs(float(loss.item()) - float(gold[f"{kind}.loss"])) < (2.5e-4 if kind == "rift" else 3.5e-3)
     rv = data["reference_line"]["valid_mask"].any(-1)
     qf = eng.tap("q_final").view(rv.shape[0], rv.shape[1], 12, 128).cpu()
     ol, og, _ = losses.pi_head_loss_and_grads(sd, qf, kind, H.clone_tree(b), ~rv)
@@ -161,6 +169,56 @@ def test_benchmark_batch_rift_loss_within_1e4_in_bf16(ffi):
         loss = float(eng.loss_finalize(stats, flat, grads).item())
         assert abs(loss - want) < tol, (fp32, loss, want)
     eng.close()
+
+
+def test_benchmark_batch_bf16_gradients_against_the_fp32_oracle(ffi):
+    """The gradient that drives AdamW in the benchmarked mode -- bf16 trunk, 256-scene minibatch, train-mode BatchNorm -- against the
+    fp32 ORACLE's gradient end to end (not the oracle fed with HIP's q_final).
+
+    Two comparisons, because the RIFT objective is only piecewise smooth: clamp(ratio, 0.8, 1.2), min / max and the dual clip at 3A
+    switch an entry's gradient on or off at a boundary, so an entry within the trunk's logit error of a boundary contributes its FULL
+    gradient to the difference (an fp32-vs-fp32 perturbation of q_final by 1e-5 already moves this gradient by 0.7 %, measured with
+    the oracle alone).  (a) the raw gradients; (b) the same with every entry whose oracle ratio lies within 5 % of a boundary removed
+    from the objective on both sides.  Measured on MI355X: (a) ||dg|| / ||g|| = 0.158, cosine 0.988; (b) 0.191, 0.982 -- the smooth
+    part carries the error, i.e. it is the bf16 rounding of q_final (~5e-2), not boundary flips.  Bars ~2.5x the measurement.
+    tests/diagnostics/precision_study.py derives the same numbers on the CPU from operand rounding alone (bf16 0.157) and shows that a
+    1e-4 relative bar needs 16 mantissa bits in EVERY contraction of the trunk (three bf16 MFMAs per product): no tail-only or
+    weight-only refinement gets below 5e-2.  compute_precision = "fp32" is the mode that meets it (test_losses_and_pi_head_grads)."""
+    import torch.nn.functional as F
+    sd = H.weights()
+    batch = syn.collate_scenes([syn.make_scene(1000 + i) for i in range(256)])
+    data = batch["cur_pluto_feature_torch"]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    out_o, _, taps = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=False, want_taps=True)
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    bs = r_pad.shape[0]
+    lp = F.log_softmax(out_o["probability"].masked_fill(r_pad.unsqueeze(-1), -1e8).view(bs, -1), 1)
+    lpo = F.log_softmax(batch["old_group_logits_torch"].masked_fill(r_pad.unsqueeze(-1), -1e8).view(bs, -1), 1)
+    ratio = (lp - lpo).exp().view_as(out_o["probability"])
+    near = ((ratio - 0.8).abs() < 0.04) | ((ratio - 1.2).abs() < 0.06) | ((ratio - 3.0).abs() < 0.15)
+    eng = ffi.Engine("cuda:0")
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    res = {}
+    for name, mask in (("raw", batch["group_advantage_mask_torch"]), ("interior", batch["group_advantage_mask_torch"] & ~near)):
+        b = H.clone_tree(batch)
+        b["group_advantage_mask_torch"] = mask
+        lo, go, _ = losses.pi_head_loss_and_grads(sd, taps["q_final"], "rift", H.clone_tree(b), r_pad)
+        eng.forward(data, train=True, no_drop=True, fp32=False, bn_update=False)
+        stats, flat, _ = eng.loss_backward("rift", b)
+        grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
+        lh = float(eng.loss_finalize(stats, flat, grads).item())
+        gmax = max(float(v.abs().max()) for v in go.values())
+        rel = max(float((grads[k].cpu() - go[k]).abs().max()) for k in go) / gmax
+        num = sum(float(((grads[k].cpu() - go[k]).double() ** 2).sum()) for k in go) ** 0.5
+        den = sum(float((go[k].double() ** 2).sum()) for k in go) ** 0.5
+        cos = sum(float((grads[k].cpu().double() * go[k].double()).sum()) for k in go) / den / sum(float((grads[k].cpu().double() ** 2).sum()) for k in go) ** 0.5
+        res[name] = (abs(lh - float(lo)), rel, num / den, cos)
+        print(f"bf16 vs fp32 oracle, 256 scenes [{name}]: loss err {res[name][0]:.2e}, max grad err / max|grad| {rel:.3e}, ||dg||/||g|| {num / den:.3e}, cosine {cos:.5f}"
+              f" ({int(mask.sum())} entries)")
+    eng.close()
+    assert res["raw"][0] < 1e-4 and res["interior"][0] < 1e-4                      # north_star's bar on the loss, at the benchmarked batch
+    assert res["raw"][2] < 0.4 and res["raw"][3] > 0.95
+    assert res["interior"][2] < 0.45 and res["interior"][3] > 0.95
 
 
 @pytest.mark.parametrize("case", ["small", "full"])
