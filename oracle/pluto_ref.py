@@ -195,15 +195,25 @@ def agent_encoder(data, sd: SD, taps=None, state_drop_mask=None):
 # --------------------------------------------------------------------------
 # PointsEncoder / Fourier / map encoder
 # --------------------------------------------------------------------------
+DP = None   # data-parallel restatement (tests only): {"bn_sync": f(sum, sumsq, n) -> reduced triple, "quirk_kpm": (global_bs, R) bool, "offset": int}
+
+
 def batch_norm(x, sd: SD, name: str, train: bool, new_stats: Optional[dict] = None):
     """nn.BatchNorm1d on (rows, C). train=True: batch statistics (biased var) and
-    running-stat update with unbiased var, momentum 0.1 (embedding.py:260,266)."""
+    running-stat update with unbiased var, momentum 0.1 (embedding.py:260,266).
+    With the module-level DP hook set, the statistics are those of the GLOBAL minibatch: per-channel (sum, sum of squares, count) go
+    through DP["bn_sync"] (an all-reduce) first -- SURVEY.md 8(e); the reference itself is single-device."""
     w, b = sd[name + ".weight"], sd[name + ".bias"]
     if train:
-        mean = x.mean(0)
-        var = x.var(0, unbiased=False)
+        n = x.shape[0]
+        if DP is not None:
+            s, q, n = DP["bn_sync"](x.double().sum(0), (x.double() ** 2).sum(0), float(n))
+            mean = (s / n).float()
+            var = (q / n - (s / n) ** 2).clamp_min(0).float()
+        else:
+            mean = x.mean(0)
+            var = x.var(0, unbiased=False)
         if new_stats is not None:
-            n = x.shape[0]
             key = sd.prefix + name
             new_stats[key + ".running_mean"] = 0.9 * sd[name + ".running_mean"] + 0.1 * mean
             new_stats[key + ".running_var"] = 0.9 * sd[name + ".running_var"] + 0.1 * var * n / max(n - 1, 1)
@@ -301,7 +311,11 @@ def decoder_layer(tgt, memory, sd: SD, tgt_kpm, mem_kpm, m_pos):
     bs, R, M, D = tgt.shape
     tgt = tgt.transpose(1, 2).reshape(bs * M, R, D)
     h = layer_norm(tgt, sd, "norm1")
-    tgt = tgt + mha(h, h, h, sd.sub("r2r_attn"), 4, tgt_kpm.repeat(M, 1))
+    quirk = tgt_kpm.repeat(M, 1)          # row b*M + m gets the padding row of scene (b*M + m) % bs
+    if DP is not None:                    # sharded minibatch: of the GLOBAL minibatch (rows of this shard start at offset * M)
+        g = DP["quirk_kpm"]
+        quirk = g[(DP["offset"] * M + torch.arange(bs * M)) % g.shape[0]]
+    tgt = tgt + mha(h, h, h, sd.sub("r2r_attn"), 4, quirk)
     tmp = tgt.reshape(bs, M, R, D).transpose(1, 2).reshape(bs * R, M, D)
     valid = ~tgt_kpm.reshape(-1)
     tv = tmp[valid]

@@ -81,6 +81,91 @@ def test_two_rank_exchange_equals_full_batch(kind, tmp_path):
     assert np.abs(outs[0]["grad"] - full.numpy()).max() < 1e-6
 
 
+# ---- the whole sharded step: forward with BatchNorm statistics and r2r quirk masks of the global minibatch + the loss exchange ----------
+def _dp_inputs():
+    from rift_amd import synthetic as syn
+    scenes = [syn.make_scene(640 + i, 10, 6, 1, 4) for i in range(7)]       # uneven split 4 + 3, heterogeneous reference-line counts
+    return H.weights(), scenes
+
+
+def _dp_worker(rank, world, port, out_dir):
+    from oracle import pluto_ref
+    from rift_amd import synthetic as syn
+    from rift_amd.planning.fine_tuner.rlft.trainer import split_minibatch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sd, scenes = _dp_inputs()
+    n = len(scenes)
+    lo, hi = split_minibatch(n, rank, world)
+    full = syn.collate_scenes(scenes)                                        # only to learn the global R (the host knows r_count of the replay)
+    R = full["cur_pluto_feature_torch"]["reference_line"]["position"].shape[1]
+    batch = syn.collate_scenes(scenes[lo:hi])
+    data = batch["cur_pluto_feature_torch"]
+
+    def pad_r(t):                                                            # every rank pads its reference lines to the global R
+        if t.shape[1] == R:
+            return t
+        return torch.cat([t, torch.zeros((t.shape[0], R - t.shape[1]) + tuple(t.shape[2:]), dtype=t.dtype)], dim=1)
+    data["reference_line"] = {k: pad_r(v) for k, v in data["reference_line"].items()}
+    for k in ("group_advantage_torch", "group_advantage_mask_torch", "old_group_logits_torch", "old_group_logits_mask_torch"):
+        batch[k] = pad_r(batch[k])
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    slots = torch.zeros(n, R, dtype=torch.float64)                           # rift_set_dp: mask slots gathered by a SUM all-reduce
+    slots[lo:hi] = r_pad.double()
+    dist.all_reduce(slots)
+
+    def bn_sync(s, q, cnt):
+        t = torch.cat([s, q, torch.tensor([cnt], dtype=torch.float64)])
+        dist.all_reduce(t)
+        c = s.numel()
+        return t[:c], t[c:2 * c], float(t[-1])
+    pluto_ref.DP = {"bn_sync": bn_sync, "quirk_kpm": slots != 0, "offset": lo}
+    out, stats, taps = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=False, want_taps=True)
+    pluto_ref.DP = None
+    loss, grads, _ = losses.pi_head_loss_and_grads(sd, taps["q_final"], "rift", batch, r_pad)
+    cnt = float(batch["group_advantage_mask_torch"].sum())
+    xchg = torch.cat([torch.cat([grads[k].reshape(-1) for k in losses.PI_KEYS]).double() * (-cnt),
+                      torch.tensor([-float(loss) * cnt, cnt], dtype=torch.float64)])
+    dp_all_reduce_exchange(xchg)
+    np.savez(os.path.join(out_dir, f"dp{rank}.npz"), loss=(-xchg[-2] / xchg[-1]).numpy(), grad=(-xchg[:-2] / xchg[-1]).numpy(),
+             prob=out["probability"].numpy(), lo=lo, hi=hi,
+             **{"stat." + k: v.numpy() for k, v in stats.items() if "running" in k})
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_equals_the_single_process_step(tmp_path):
+    """SURVEY.md 8(e) at the algorithm level, over real gloo collectives: two ranks hold 4 + 3 scenes of a 7-scene minibatch, exchange the
+    BatchNorm sums (4 points), the r2r quirk's padding rows and the loss sums, and reproduce the single-process oracle on the whole
+    minibatch: logits of their own scenes, loss, pi_head gradients and BatchNorm running statistics.  (The HIP engine implements the
+    same protocol behind rift_set_dp; tests/test_gpu_dp.py checks it against the HIP single-process step.)"""
+    from oracle import pluto_ref
+    from rift_amd import synthetic as syn
+    sd, scenes = _dp_inputs()
+    port = _free_port()
+    mp.start_processes(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    batch = syn.collate_scenes(scenes)
+    data = batch["cur_pluto_feature_torch"]
+    out, stats, taps = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=False, want_taps=True)
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    loss, grads, _ = losses.pi_head_loss_and_grads(sd, taps["q_final"], "rift", batch, r_pad)
+    full = torch.cat([grads[k].reshape(-1) for k in losses.PI_KEYS]).double().numpy()
+    outs = [np.load(tmp_path / f"dp{r}.npz") for r in range(2)]
+    assert np.array_equal(outs[0]["grad"], outs[1]["grad"]) and outs[0]["loss"] == outs[1]["loss"]
+    assert abs(float(outs[0]["loss"]) - float(loss)) < 1e-6
+    assert np.abs(outs[0]["grad"] - full).max() < 1e-6 + 1e-4 * np.abs(full).max()
+    for o in outs:
+        lo, hi = int(o["lo"]), int(o["hi"])
+        assert np.abs(o["prob"] - out["probability"][lo:hi].numpy()).max() < 2e-5
+        for k, v in stats.items():
+            if "running" in k:
+                assert np.abs(o["stat." + k] - v.numpy()).max() < 1e-6 + 1e-5 * float(v.abs().max()), k
+    # and without the exchanges the shards do NOT reproduce it (the test would be vacuous otherwise)
+    alone, _, _ = pluto_ref.planning_model_forward(sd, syn.collate_scenes(scenes[:4])["cur_pluto_feature_torch"], train_bn=True, need_traj=False)
+    R4 = alone["probability"].shape[1]
+    assert float((alone["probability"] - out["probability"][:4, :R4]).abs().max()) > 1e-3
+
+
 def test_shards_are_disjoint_and_cover():
     ids = [set(shard_scene_ids(r, 4, 1024)) for r in range(4)]
     assert set.union(*ids) == set(range(4096)) and sum(len(i) for i in ids) == 4096
