@@ -4,13 +4,16 @@ without hydra / Lightning / wandb: the same `CBVBasePolicy` surface, checkpoint 
 updates, 16-epoch fit with a 90/10 split, batch 256, clip 0.5, per-epoch WarmupCosLR and top-1 checkpointing
 by validation loss -- every forward / loss / backward on the HIP engine, batches gathered on device.
 
-`get_action` (per-tick inference + PID control of live CARLA actors, rift_pluto.py:28-161, pluto.py:196-276) needs
-CarlaDataProvider and is the rollout-side row of SURVEY.md section 8(f); it is not part of this package.
+Rollout side: `get_action` (rlft_pluto.py:84-204, rift_pluto.py:28-161, grpo_pluto.py:33-170) on top of
+rift_amd.planning.pluto.pluto.PLUTO -- one eval forward per environment and tick, candidate trimming, PID control, and in train mode
+the replay columns the update consumes: old log-prob + chosen (r, m) (PPO / REINFORCE), old / reference group logits and the
+group-relative advantage of every candidate (RIFT / GRPO; TrajEvaluator on the device).  Live CARLA state comes through the injected
+state source (rift_amd.planning.pluto.pluto.CBVStateSource).
 """
 import math
 import re
 from pathlib import Path
-from typing import Dict, List, Optional
+from typing import Any, Dict, List, Optional
 
 import numpy as np
 import torch
@@ -18,6 +21,7 @@ import torch
 from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
 from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer, split_minibatch
 from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+from rift_amd.planning.pluto.pluto import PLUTO, CBVBasePolicy, CBVStateSource, Candidates, CenterState   # noqa: F401 (re-exported)
 from rift_amd.replay import DeviceReplay
 
 DEFAULT_CFG = {   # fine_tuner/rlft/config/{rift,grpo,ppo,reinforce}_training.yaml + datamodule/*.yaml + lightning/custom_lightning.yaml
@@ -25,50 +29,6 @@ DEFAULT_CFG = {   # fine_tuner/rlft/config/{rift,grpo,ppo,reinforce}_training.ya
     "trainable_layers": ["planning_decoder.pi_head"], "train_batch_size": 256, "val_batch_size": 256, "shuffle": True,
     "train_ratio": 0.9, "gamma": 0.98, "lambda_gae_adv": 0.98, "gradient_clip_val": 0.5,
 }
-
-
-class CBVBasePolicy:   # rift/cbv/planning/base_policy.py:9-52
-    name = 'base'
-    type = 'unlearnable'
-
-    def __init__(self, config, logger):
-        self.config = config
-        self.num_scenario = config['num_scenario']
-        self._render_data = None
-        self.route_planner = None
-
-    def set_buffer(self, buffer, total_routes):
-        self.buffer, self.total_routes = buffer, total_routes
-
-    def set_route_planner(self, route_planner):
-        self.route_planner = route_planner
-
-    def train(self, e_i):
-        raise NotImplementedError()
-
-    def set_mode(self, mode):
-        self.mode = mode
-
-    def get_action(self, state, infos, deterministic):
-        raise NotImplementedError()
-
-    def get_render_data(self, env_id):
-        return NotImplementedError()
-
-    def log_episode_reward(self, episode_reward, episode):
-        pass
-
-    def load_model(self, resume=True):
-        pass
-
-    def save_model(self, episode):
-        pass
-
-    def clean_up(self):
-        pass
-
-    def finish(self):
-        pass
 
 
 def buffer_to_scenes(buffer: CBVRolloutBuffer) -> List[Dict]:
@@ -100,16 +60,14 @@ def buffer_to_scenes(buffer: CBVRolloutBuffer) -> List[Dict]:
     return scenes
 
 
-class RLFTPluto(CBVBasePolicy):
+class RLFTPluto(PLUTO):
     name = 'rlft_pluto'
     type = 'rlft'
     kind = 'rift'
+    EXTRA_COLUMNS = ('CBVs_actions_old_log_prob', 'CBVs_actions_mode')      # rlft_pluto.py:131-135
 
     def __init__(self, config, logger):
         super().__init__(config, logger)
-        self.logger = logger
-        self.radius = config.get('radius', 120)
-        self.device = torch.device(config.get('device', 'cuda:0'))
         self.model_path = Path(config.get('ROOT_DIR', '.')) / config.get('model_path', 'model_ckpt')
         self.cbv_recog, self.seed = config.get('cbv_recog', 'rule'), config.get('seed', 0)
         self.pretrain_seed = config.get('pretrain_seed', self.seed)
@@ -122,11 +80,8 @@ class RLFTPluto(CBVBasePolicy):
         sd = self.seed if config.get('mode', 'train_cbv') == 'train_cbv' else self.pretrain_seed
         self.load_agent_info = f"{ego}-{self.cbv_recog}-seed{sd}"
         self.save_agent_info = f"{config.get('ego_policy', 'pdm_lite')}-{self.cbv_recog}-seed{self.seed}"
-        self.pluto_model = PlanningModel(radius=self.radius).to(self.device)   # inference model
-        self.pluto_model.eval()
         self.train_model: Optional[PlanningModel] = None
         self.buffer: Optional[CBVRolloutBuffer] = None
-        self.mode = 'eval'
         self.last_fit: Dict = {}
 
     def _log(self, msg, color=None):
@@ -149,28 +104,17 @@ class RLFTPluto(CBVBasePolicy):
         else:
             raise ValueError(f'Unknown mode {mode}')
 
-    def get_action(self, CBVs_obs_list, infos, deterministic=False):
-        raise NotImplementedError("the CARLA-bound wrapper (CarlaDataProvider actors, render data) is not part of this package; the "
-                                  "model step, candidate trimming and PID control it calls are rift_amd.planning.pluto.inference.PlutoInference")
-
-    def reset_render_data(self):   # rlft_pluto.py:64-77 (render buffers live on the CARLA side)
-        self._render_data = [{} for _ in range(self.num_scenario)]
-
-    def get_render_data(self, env_id):
-        return self._render_data[env_id] if self._render_data else {}
+    def _per_cbv(self, env_id, cbv_id, obs, data, out, index, state, decision):
+        """rlft_pluto.py:172-176: log of the chosen candidate's softmax score and its (r, m) -- integer, bit-exact."""
+        flat = int(decision.flat_index[decision.best])
+        return {'CBVs_actions_old_log_prob': np.log(decision.score[decision.best] + 1e-12),
+                'CBVs_actions_mode': (flat // decision.n_mode, flat % decision.n_mode)}
 
     def save_model(self, episode):  # checkpoints are written by train(); rlft_pluto.py:295-296
         pass
 
     def finish(self):
         pass
-
-    @staticmethod
-    def load_infer_checkpoint(checkpoint: str, device_name) -> Dict[str, torch.Tensor]:
-        """pluto.py:130-133: strip the 'model.' prefix; value_net.* (PPO) is not part of the inference model."""
-        ckpt = torch.load(checkpoint, map_location=device_name, weights_only=False)
-        sd = {k.replace("model.", "", 1) if k.startswith("model.") else k: v for k, v in ckpt["state_dict"].items()}
-        return {k: v for k, v in sd.items() if not k.startswith("value_net")}
 
     def load_model(self, resume=True):
         load_dir = self.model_path / self.load_agent_info
@@ -185,7 +129,7 @@ class RLFTPluto(CBVBasePolicy):
             if not resume:
                 for f in files:
                     f.unlink()
-            self.checkpoint = self.config.get('ckpt_path')
+            self.checkpoint = self._ckpt_path
             self.continue_episode, self.current_epoch = 0, 0
         # the reference always loads (rlft_pluto.py:293) and fails loudly on a bad path; only a policy configured WITHOUT any checkpoint
         # (ckpt_path unset: synthetic benchmarks, tests) keeps its seeded initialisation
@@ -292,12 +236,85 @@ class RLFTPluto(CBVBasePolicy):
         return self.last_fit
 
 
-class RIFTPluto(RLFTPluto):        # fine_tuner/rlft/rift_pluto/rift_pluto.py:18
+class _GroupRelativePluto(RLFTPluto):
+    """Shared rollout side of RIFT and GRPO (rift_pluto.py:74-161): in train mode every tick also yields, per CBV, the raw logits of
+    its valid reference lines (the "old policy" of the coming update) and the group-relative advantage of all R x 12 candidates."""
+    EXTRA_COLUMNS = ('CBVs_actions_old_group_logits', 'CBVs_group_advantage')
+
+    def __init__(self, config, logger):
+        super().__init__(config, logger)
+        self._traj_evaluator = None
+
+    @property
+    def traj_evaluator(self):
+        if self._traj_evaluator is None:
+            from rift_amd.planning.fine_tuner.rlft.traj_eval.traj_evaluator import TrajEvaluator
+            self._traj_evaluator = TrajEvaluator(self.pluto_model.engine(), dt=self._step_interval)
+        return self._traj_evaluator
+
+    def _valid_lines(self, data, index):
+        valid = data["reference_line"]["valid_mask"][index]                     # (R, 120)
+        return valid, valid.any(-1)
+
+    def _group_columns(self, env_id, cbv_id, data, out, index, state, decision) -> Dict[str, Any]:
+        valid, r_valid = self._valid_lines(data, index)
+        pos = data["reference_line"]["position"][index][r_valid]
+        ang = data["reference_line"]["orientation"][index][r_valid]
+        ref_pos = [p[m] for p, m in zip(pos, valid[r_valid])]                   # ragged: only the valid points of each valid line
+        ref_ang = [a[m] for a, m in zip(ang, valid[r_valid])]
+        src = self.state_source
+        raster = src.off_road_raster(env_id, cbv_id)
+        actors = src.nearby_actor_states(env_id, cbv_id)
+        G = int(r_valid.sum()) * 12
+        kw = {}
+        if raster is None:
+            kw["off_road_matrix"] = np.zeros((G, 80), dtype=np.bool_)
+        else:
+            kw["off_road_mask"], kw["center_pose"] = raster
+        if actors is None:
+            kw["collision_matrix"] = np.zeros((G, 40), dtype=np.bool_)
+        else:
+            kw["nearby_actor_states"] = actors
+        adv = self.traj_evaluator.get_grpo_advantage(tuple(state), out["trajectory"][index][r_valid], ref_pos, ref_ang, **kw)
+        logits = decision.probability[r_valid.cpu().numpy()]
+        return {'CBVs_actions_old_group_logits': {'logits': logits, 'valid_mask': np.ones_like(logits, dtype=np.bool_)},
+                'CBVs_group_advantage': adv}
+
+    def _per_cbv(self, env_id, cbv_id, obs, data, out, index, state, decision):
+        if self.mode != 'train':
+            return {k: None for k in self.EXTRA_COLUMNS}
+        return self._group_columns(env_id, cbv_id, data, out, index, state, decision)
+
+
+class RIFTPluto(_GroupRelativePluto):        # fine_tuner/rlft/rift_pluto/rift_pluto.py:18
     name, type, kind = 'rift_pluto', 'rlft', 'rift'
 
 
-class GRPOPluto(RLFTPluto):        # fine_tuner/rlft/grpo_pluto/grpo_pluto.py
+class GRPOPluto(_GroupRelativePluto):        # fine_tuner/rlft/grpo_pluto/grpo_pluto.py:18-170
     name, type, kind = 'grpo_pluto', 'rlft', 'grpo'
+    EXTRA_COLUMNS = _GroupRelativePluto.EXTRA_COLUMNS + ('CBVs_actions_ref_group_logits',)
+
+    def __init__(self, config, logger):
+        super().__init__(config, logger)
+        self.ref_model = PlanningModel(radius=self.radius).to(self.device)      # frozen reference policy of the KL term (:24-28)
+        if self._ckpt_path:
+            self.ref_model.load_state_dict(self.load_infer_checkpoint(self._ckpt_path, self.device))
+        self.ref_model.eval()
+
+    @torch.no_grad()
+    def _forward(self, CBVs_obs):
+        data, out = super()._forward(CBVs_obs)
+        self.ref_model.need_traj = False
+        out["ref_probability"] = self.ref_model(data)["probability"]
+        return data, out
+
+    def _per_cbv(self, env_id, cbv_id, obs, data, out, index, state, decision):
+        cols = super()._per_cbv(env_id, cbv_id, obs, data, out, index, state, decision)
+        if self.mode == 'train':
+            r_valid = self._valid_lines(data, index)[1].cpu().numpy()
+            logits = out["ref_probability"][index].cpu().numpy()[r_valid]
+            cols['CBVs_actions_ref_group_logits'] = {'logits': logits, 'valid_mask': np.ones_like(logits, dtype=np.bool_)}
+        return cols
 
 
 class ReinforcePluto(RLFTPluto):   # fine_tuner/rlft/reinforce_pluto/reinforce_pluto.py
@@ -376,6 +393,6 @@ def replay_dummy_extras(feature):
             "old_group_logits": torch.zeros(R, 12), "old_group_logits_mask": torch.ones(R, 12, dtype=torch.bool)}
 
 
-CBV_POLICY_LIST = {   # rift/cbv/planning/__init__.py:21-34 (RLFT entries)
-    'rift_pluto': RIFTPluto, 'grpo_pluto': GRPOPluto, 'reinforce_pluto': ReinforcePluto, 'ppo_pluto': PPOPluto,
+CBV_POLICY_LIST = {   # rift/cbv/planning/__init__.py:21-34 (the Pluto family; the MLP-RL and rule-based entries are other policies)
+    'pluto': PLUTO, 'rift_pluto': RIFTPluto, 'grpo_pluto': GRPOPluto, 'reinforce_pluto': ReinforcePluto, 'ppo_pluto': PPOPluto,
 }

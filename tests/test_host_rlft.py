@@ -405,3 +405,142 @@ def test_training_steps_are_bit_deterministic():
     assert runs[0][0] == runs[1][0]
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
+class _RecordedStates:
+    """A CBVStateSource with recorded values (what CarlaStateSource reads off the simulator)."""
+
+    def __init__(self, with_neighbours=True):
+        from rift_amd.planning.pluto.pluto import CBVStateSource, CenterState
+        self.base = CBVStateSource
+        self.CenterState = CenterState
+        self.with_neighbours = with_neighbours
+
+    def center_state(self, env_id, cbv_id):
+        return self.CenterState(10.0 + cbv_id, -5.0, 0.3, 6.0 + 0.1 * cbv_id, 2.0, 4.6)
+
+    def nearby_actor_states(self, env_id, cbv_id):
+        return H.other_vehicle_inputs(seed=100 + cbv_id, N=4) if self.with_neighbours else None
+
+    def off_road_raster(self, env_id, cbv_id):
+        mask = np.ones((400, 400), dtype=np.uint8)
+        mask[150:250, :300] = 0
+        return mask, (10.0 + cbv_id, -5.0, 0.3)
+
+
+@pytest.mark.gpu
+def test_rollout_fills_the_buffer_and_the_update_trains_on_it(tmp_path):
+    """The closed loop of train_cbv without the reference classes (carla_runner.py:207-235): RIFTPluto.get_action in train mode ->
+    buffer.store -> RIFTPluto.train.  The columns get_action emits are checked against the oracle chain: old group logits = the
+    model's logits of the valid reference lines, chosen control = PlutoInference on the same outputs, group advantage = oracle
+    rollout + reward + z-score on the oracle-side flags (1e-4; exact-fp32 mode)."""
+    from oracle import advantage as oadv, pluto_ref, rollout as orl, traj_flags as otf
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    src = _RecordedStates()
+    cfg = {'num_scenario': 1, 'ROOT_DIR': str(tmp_path), 'model_path': 'ckpt', 'device': 'cuda:0', 'state_source': src,
+           'rlft': {'epochs': 2, 'warmup_epochs': 1, 'train_batch_size': 16, 'val_batch_size': 16, 'lr': 1e-3}}
+    pol = CBV_POLICY_LIST['rift_pluto'](cfg, None)
+    sd = H.weights()
+    pol.pluto_model.load_state_dict(sd)
+    pol.pluto_model.compute_precision = "fp32"
+    pol.load_model(resume=True)
+    pol.set_mode('train')
+    keys = ['CBVs_obs', 'CBVs_actions', 'CBVs_reward', 'CBVs_done', 'CBVs_actions_old_group_logits', 'CBVs_group_advantage']
+    buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': 36, 'data_keys': keys})
+    pol.set_buffer(buf)
+    t, checked = 0, 0
+    while not buf.buffer_full:
+        ids = [1, 2]
+        feats = {c: syn.make_scene(3000 + 2 * t + j, num_agents=12, num_polygons=8, r_min=1, r_max=3)["feature"] for j, c in enumerate(ids)}
+        obs = {c: {'raw_pluto_feature': PlutoFeature(data=feats[c])} for c in ids}
+        act = pol.get_action([obs], [{'env_id': 0}], deterministic=False)
+        assert set(act) == {'CBVs_actions', 'CBVs_actions_old_group_logits', 'CBVs_group_advantage'}
+        for c in ids:
+            thr, steer, brake = act['CBVs_actions'][0][c]
+            R = feats[c]["reference_line"]["position"].shape[0]
+            lg, adv = act['CBVs_actions_old_group_logits'][0][c], act['CBVs_group_advantage'][0][c]
+            assert lg['logits'].shape == (R, 12) and lg['valid_mask'].all() and adv['advantage'].shape == (R, 12) and adv['advantage'].dtype == np.float64
+            assert 0.0 <= thr <= 1.0 and -1.0 <= steer <= 1.0
+        if t < 2:                                             # oracle chain for the first ticks (first calls of the persistent PID state per lane)
+            data = syn.collate_features([feats[c] for c in ids])
+            want, _, _ = pluto_ref.planning_model_forward(sd, data, train_bn=False, need_traj=True)
+            for j, c in enumerate(ids):
+                R = feats[c]["reference_line"]["position"].shape[0]
+                lg = act['CBVs_actions_old_group_logits'][0][c]['logits']
+                assert np.abs(lg - want["probability"][j, :R].numpy()).max() < 1e-4
+            checked += 1
+        buf.store({'CBV_ids': [ids], 'CBVs_obs': [obs], 'CBVs_actions': [act['CBVs_actions'][0]], 'CBVs_reward': [{c: 0.1 for c in ids}],
+                   'CBVs_done': [{c: t % 6 == 5 for c in ids}], 'CBVs_actions_old_group_logits': [act['CBVs_actions_old_group_logits'][0]],
+                   'CBVs_group_advantage': [act['CBVs_group_advantage'][0]]})
+        t += 1
+    assert checked == 2 and buf.buffer_full
+    # group advantage of one fresh CBV against the oracle chain (fresh policy -> fresh PID state on both sides)
+    pol2 = CBV_POLICY_LIST['rift_pluto'](dict(cfg, state_source=_RecordedStates(with_neighbours=True)), None)
+    pol2.pluto_model.load_state_dict(sd)
+    pol2.pluto_model.compute_precision = "fp32"
+    pol2.set_mode('eval'); pol2.mode = 'train'
+    feat = syn.make_scene(3333, num_agents=12, num_polygons=8, r_min=2, r_max=3)["feature"]
+    act = pol2.get_action([{7: {'raw_pluto_feature': PlutoFeature(data=feat)}}], [{'env_id': 0}])
+    got = act['CBVs_group_advantage'][0][7]['advantage']
+    data = syn.collate_features([feat])
+    want, _, _ = pluto_ref.planning_model_forward(sd, data, train_bn=False, need_traj=True)
+    R = feat["reference_line"]["position"].shape[0]
+    traj = want["trajectory"][0, :R]
+    valid = feat["reference_line"]["valid_mask"]
+    ref_pos = [feat["reference_line"]["position"][r][valid[r]] for r in range(R)]
+    ref_ang = [feat["reference_line"]["orientation"][r][valid[r]] for r in range(R)]
+    st = src.center_state(0, 7)
+    t40 = traj[:, :, :40]
+    dd, da, _ = orl.ref_line_info(t40, ref_pos, ref_ang)
+    gpos, ghead = orl.to_global(t40, torch.tensor([st.x, st.y]), torch.tensor(st.heading))
+    ro = orl.Rollout().propagate(gpos, ghead, st.speed, st.width, st.length)
+    other = otf.get_other_vehicle_rollout(**src.nearby_actor_states(0, 7))
+    col = otf.get_collision_matrix(ro["vertices"].numpy(), other)
+    mask, pose = src.off_road_raster(0, 7)
+    off = otf.get_off_road_matrix(ro["center"].numpy(), mask, pose[:2], pose[2])
+    ret = oadv.rollout_return(dd.numpy(), da.numpy(), ro["speed"][:, :40].numpy(), ro["acc"][:, :40].numpy(), ro["ang_vel"][:, :40].numpy(),
+                              ro["ang_acc"][:, :40].numpy(), col, off)
+    assert np.abs(got - oadv.group_zscore(ret).reshape(R, 12)).max() < 1e-4
+    # and the update trains on what the rollout stored
+    fit = pol.train(1)
+    assert len(fit["history"]) == 2 and all(np.isfinite(h["train_loss"]) for h in fit["history"]) and len(buf) == 0
+
+
+@pytest.mark.gpu
+def test_pluto_policy_and_ppo_columns(tmp_path):
+    """Registry key 'pluto' (inference only: refuses train mode, needs a checkpoint) and the base RLFT columns (old log-prob, chosen
+    (r, m) -- integers recomputed here from the emitted logits)."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    assert set(CBV_POLICY_LIST) == {'pluto', 'rift_pluto', 'grpo_pluto', 'reinforce_pluto', 'ppo_pluto'}
+    sd = H.weights()
+    ck = tmp_path / "pluto.ckpt"
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}}, ck)
+    src = _RecordedStates()
+    cfg = {'num_scenario': 2, 'device': 'cuda:0', 'state_source': src, 'ckpt_path': str(ck), 'ROOT_DIR': str(tmp_path), 'model_path': 'ckpt'}
+    plain = CBV_POLICY_LIST['pluto'](cfg, None)
+    with pytest.raises(ValueError):
+        plain.set_mode('train')
+    with pytest.raises(FileNotFoundError):
+        CBV_POLICY_LIST['pluto'](dict(cfg, ckpt_path=None), None).load_model()
+    plain.load_model()
+    plain.set_mode('eval')
+    feats = {c: syn.make_scene(4100 + c, num_agents=12, num_polygons=8, r_min=2, r_max=4)["feature"] for c in (5, 6)}
+    obs = [{}, {c: {'raw_pluto_feature': PlutoFeature(data=f)} for c, f in feats.items()}]          # environment 0 has no CBV this tick
+    infos = [{'env_id': 0}, {'env_id': 1}]
+    a = plain.get_action(obs, infos)
+    assert set(a) == {'CBVs_actions'} and a['CBVs_actions'][0] == {} and set(a['CBVs_actions'][1]) == {5, 6}
+    ppo = CBV_POLICY_LIST['ppo_pluto'](cfg, None)
+    ppo.load_model(resume=True)
+    b = ppo.get_action(obs, infos)
+    assert set(b) == {'CBVs_actions', 'CBVs_actions_old_log_prob', 'CBVs_actions_mode'}
+    for c in (5, 6):
+        assert b['CBVs_actions'][1][c] == a['CBVs_actions'][1][c]              # same model, same fresh PID state
+        r, m = b['CBVs_actions_mode'][1][c]
+        R = feats[c]["reference_line"]["position"].shape[0]
+        # (r, m) = divmod(flat index, 12); the ref-free candidate carries flat index -1 -> (-1, 11), as in the reference (rlft_pluto.py:174-176)
+        assert -1 <= r < R and 0 <= m < 12 and (r >= 0 or m == 11) and b['CBVs_actions_old_log_prob'][1][c] <= 0.0
+    # a CBV that disappears frees its PID state
+    plain.get_action([{}, {5: obs[1][5]}], infos)
+    assert set(plain.controllers[1]) == {5}
