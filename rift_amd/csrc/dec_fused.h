@@ -66,9 +66,10 @@ __global__ void pack_mpx_kernel(const float* __restrict__ mp, const int* __restr
 #define RIFT_DEC_LDS_BYTES (80 * 132 * 4 + 80 * 136 * 2 * 2 + 80 * 200 * 2 + 96 * 72 * 2 + 64 * 104 * 2 + (RIFT_DEC_NPAR + RIFT_DEC_NFFB) * 4 + 96 + 96 + 16)
 
 // NW waves per workgroup: one scene is one workgroup on one CU, so the wave count is the only occupancy lever
-template <int NW>
+template <int NW, int MTT = 5>
 __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
-  constexpr int ROWS = 80, MT = 5, C = 128, M = 12;
+  constexpr int ROWS = 80, MT = MTT, C = 128, M = 12;   // ROWS: LDS row allocation; MT: 16-row tiles actually processed (R * 12 <= 16 * MT)
+  constexpr int RUSE = 16 * MT;
   constexpr int NTH = 64 * NW, NTQ = (12 + NW - 1) / NW, NTC = 8 / NW;   // n-tiles per wave: 192-column chunk, 128-column output
   constexpr int XS = 132, XN = 136, CB = 200, KC = 72, VS = 104, NKT = 6;
   constexpr int P_LN = 0, P_BR2R = 1024, P_BR2RO = 1408, P_BM2M = 1536, P_BM2MO = 1920, P_BCQ = 2048, P_BCO = 2176,
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   EFrags<4, NTC> B2;         // ffn.3 partial
   e_load_b(Bqkv, p.blk[0].w_r2r, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
 
-  for (int i = tid; i < ROWS * 32; i += NTH) {
+  for (int i = tid; i < RUSE * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < NQ) v = *reinterpret_cast<const float4*>(p.Q + (qrow0 + r) * C + c4);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     const float4 g0 = *reinterpret_cast<const float4*>(g + l15 * 4), g1 = *reinterpret_cast<const float4*>(g + 64 + l15 * 4);
     const float4 b0 = *reinterpret_cast<const float4*>(be + l15 * 4), b1 = *reinterpret_cast<const float4*>(be + 64 + l15 * 4);
 #pragma unroll 1
-    for (int r = wave * 4 + l4; r < ROWS; r += 4 * NW) ln128_row16(xs + r * XS, xn + r * XN, g0, g1, b0, b1, l15);
+    for (int r = wave * 4 + l4; r < RUSE; r += 4 * NW) ln128_row16(xs + r * XS, xn + r * XN, g0, g1, b0, b1, l15);
   };
 
   // x += dropout(acc + bias) for a 128-column projection held as acc[MT][2]; optional row zeroing (m2m)
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
     }
     lds_barrier(); DTS();
   }
-  for (int i = tid; i < ROWS * 32; i += NTH) {
+  for (int i = tid; i < RUSE * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     if (r < NQ) *reinterpret_cast<float4*>(p.Q + (qrow0 + r) * C + c4) = *reinterpret_cast<const float4*>(xs + r * XS + c4);
   }

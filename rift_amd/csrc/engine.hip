@@ -376,6 +376,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR(rollout_kernel);
   SETATTR(enc_fused_kernel<ENC_NW>);
   SETATTR(dec_fused_kernel<DEC_NW>);
+  SETATTR((dec_fused_kernel<DEC_NW, 1>)); SETATTR((dec_fused_kernel<DEC_NW, 2>)); SETATTR((dec_fused_kernel<DEC_NW, 3>)); SETATTR((dec_fused_kernel<DEC_NW, 4>));
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
   SETATTR(NAT_L2);
@@ -1058,7 +1059,19 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
     // algorithmic FLOPs of the 4 layers on the padded (R x 12) query block, as the reference computes them
     c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
-    launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
+    {
+      // the variant that processes just the 16-row query tiles this batch has (R * 12 <= 16 * MT): a batch whose padded R is below 6 skips
+      // whole tiles of MFMA / LayerNorm / epilogue work (measured 90 / 99 / 119 / 136 / 163 us for MT = 1..5, tools/dec_mt.py: 72 us of
+      // per-phase latency + ~18 us per tile).  RIFT_DEC_MT overrides (diagnostic).
+      const char* ev = getenv("RIFT_DEC_MT");
+      const int mt = ev ? atoi(ev) : std::min(5, (R * M + 15) / 16);
+      if (mt < 5 && R * M > 16 * mt) { c->err = "RIFT_DEC_MT too small for this batch"; return RIFT_ERR_ARG; }
+      if (mt == 1) launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW, 1>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
+      else if (mt == 2) launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW, 2>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
+      else if (mt == 3) launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW, 3>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
+      else if (mt == 4) launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW, 4>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
+      else launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
+    }
   } else {
   float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
   float* DAO = A_alloc<float>(c, (size_t)nQ * 128);

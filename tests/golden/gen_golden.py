@@ -487,8 +487,32 @@ def gen_collate():
     print("collate ->", path, f"{os.path.getsize(path) / 1e3:.1f} KB", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and k.startswith("feature/agent")})
 
 
+def gen_normalize():
+    """PlutoFeature.normalize / to_feature_tensor as the reference runs them (pluto_feature.py:98-126,166-263) on a seeded raw feature dict:
+    first call (map crop, origin / angle) and a later call (first_time=False) on a fresh copy."""
+    from tests.helpers import raw_feature_inputs
+    ref_loader.install()
+    pf = importlib.import_module("rift.cbv.planning.pluto.feature_builder.pluto_feature")
+    out = {}
+    for tag, first in (("first", True), ("later", False)):
+        res = pf.PlutoFeature.normalize(raw_feature_inputs(), first_time=first, radius=120, hist_steps=21)
+        ten = res.to_feature_tensor()
+        for src, name in ((res.data, "np"), (ten.data, "tensor")):
+            for grp, v in src.items():
+                if isinstance(v, dict):
+                    for k, t in v.items():
+                        out[f"{tag}/{name}/{grp}/{k}"] = to_np(t) if torch.is_tensor(t) else np.asarray(t)
+                else:
+                    out[f"{tag}/{name}/{grp}"] = to_np(v) if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, "normalize.npz")
+    np.savez_compressed(path, **out)
+    print("normalize ->", path, f"{os.path.getsize(path) / 1e3:.1f} KB", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "collate":
+    if len(sys.argv) > 1 and sys.argv[1] == "normalize":
+        gen_normalize()
+    elif len(sys.argv) > 1 and sys.argv[1] == "collate":
         gen_collate()
     elif len(sys.argv) > 1 and sys.argv[1] == "sft":
         gen_sft()

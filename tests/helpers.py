@@ -189,3 +189,32 @@ def collate_scenes_ragged():
         s = syn.make_scene(5000 + i, A, Mp, R, R)
         scenes.append({"feature": s["feature"], "extras": s["extras"]})
     return scenes
+
+
+def raw_feature_inputs(seed=2718, A=9, Mp=14, R=3, T=26, S=2):
+    """A raw feature dict as PlutoFeatureBuilder hands it to PlutoFeature.normalize: numpy float64 in the GLOBAL frame, 21 history + 5
+    future agent steps, polygons partly beyond the +-radius crop, static objects, a route (tests/golden/normalize.npz)."""
+    g = np.random.default_rng(seed)
+    cx, cy, th = 312.5, -48.25, 0.83
+    state = np.array([cx, cy, th, 4.2, 0.1, -0.03, 0.002], dtype=np.float64)
+    far = g.random(Mp) < 0.3
+    centre = np.stack([cx + g.normal(0, 40, Mp) + far * 400.0, cy + g.normal(0, 40, Mp)], -1)
+    pts = centre[:, None, None, :] + g.normal(0, 6, (Mp, 3, 20, 2))
+    return {
+        "current_state": state,
+        "agent": {"position": np.stack([cx, cy]) + g.normal(0, 30, (A, T, 2)), "heading": g.uniform(-3.14, 3.14, (A, T)),
+                  "velocity": g.normal(0, 5, (A, T, 2)), "shape": g.uniform(1, 4, (A, T, 2)), "category": g.integers(0, 4, A).astype(np.int8),
+                  "valid_mask": g.random((A, T)) < 0.85},
+        "map": {"point_position": pts, "point_vector": g.normal(0, 1, (Mp, 3, 20, 2)), "point_orientation": g.uniform(-3.14, 3.14, (Mp, 3, 20)),
+                "point_side": np.tile(np.arange(3, dtype=np.int8), (Mp, 1)), "polygon_center": np.concatenate([centre, g.uniform(-3.14, 3.14, (Mp, 1))], -1),
+                "polygon_position": centre + g.normal(0, 1, (Mp, 2)), "polygon_orientation": g.uniform(-3.14, 3.14, Mp),
+                "polygon_type": g.integers(0, 3, Mp).astype(np.int8), "polygon_on_route": g.random(Mp) < 0.5,
+                "polygon_tl_status": g.integers(0, 4, Mp).astype(np.int8), "polygon_has_speed_limit": g.random(Mp) < 0.7,
+                "polygon_speed_limit": g.uniform(0, 15, Mp), "polygon_road_block_id": g.integers(0, 99, Mp).astype(np.int32)},
+        "static_objects": {"position": np.stack([cx, cy]) + g.normal(0, 20, (S, 2)), "heading": g.uniform(-3.14, 3.14, S),
+                           "shape": g.uniform(0.5, 2, (S, 2)), "category": g.integers(0, 4, S).astype(np.int8), "valid_mask": np.ones(S, dtype=bool)},
+        "route": {"position": np.stack([cx, cy]) + g.normal(0, 50, (30, 2))},
+        "reference_line": {"position": np.stack([cx, cy]) + g.normal(0, 25, (R, 120, 2)), "vector": g.normal(0, 1, (R, 120, 2)),
+                           "orientation": g.uniform(-3.14, 3.14, (R, 120)), "valid_mask": g.random((R, 120)) < 0.9,
+                           "future_projection": g.normal(0, 1, (R, 8, 2))},
+    }

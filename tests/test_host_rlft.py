@@ -544,3 +544,28 @@ def test_pluto_policy_and_ppo_columns(tmp_path):
     # a CBV that disappears frees its PID state
     plain.get_action([{}, {5: obs[1][5]}], infos)
     assert set(plain.controllers[1]) == {5}
+
+
+def test_normalize_and_tensorisation_match_the_reference_generated_fixture():
+    """tests/golden/normalize.npz = the reference's PlutoFeature.normalize + to_feature_tensor (pluto_feature.py:98-126,166-263) on a seeded
+    raw global-frame feature dict -- first call (map crop to +-radius, origin / angle recorded) and a later call.  The mirror must give the
+    same keys, shapes, dtypes (float64 -> float32 only in the tensor form) and values, bit for bit."""
+    import os
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "normalize.npz")))
+    for tag, first in (("first", True), ("later", False)):
+        res = PlutoFeature.normalize(H.raw_feature_inputs(), first_time=first, radius=120, hist_steps=21)
+        assert res.is_valid
+        for name, src in (("np", res.data), ("tensor", res.to_feature_tensor().data)):
+            flat = {}
+            for grp, v in src.items():
+                for k, t in (v.items() if isinstance(v, dict) else [(None, v)]):
+                    flat[f"{tag}/{name}/{grp}" + (f"/{k}" if k else "")] = t.numpy() if torch.is_tensor(t) else np.asarray(t)
+            want = {k for k in gold if k.startswith(f"{tag}/{name}/")}
+            assert set(flat) == want, set(flat) ^ want
+            for k, v in flat.items():
+                assert v.shape == gold[k].shape and v.dtype == gold[k].dtype, (k, v.shape, v.dtype, gold[k].shape, gold[k].dtype)
+                assert np.array_equal(v, gold[k]), k
+    assert gold["first/np/map/point_position"].shape[0] < H.raw_feature_inputs()["map"]["point_position"].shape[0]     # the crop removed polygons
+    # round trip through numpy
+    back = PlutoFeature.normalize(H.raw_feature_inputs(), first_time=True, radius=120).to_feature_tensor().to_numpy()
+    assert isinstance(back.data["agent"]["position"], np.ndarray) and back.data["agent"]["position"].dtype == np.float32
