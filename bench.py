@@ -134,7 +134,10 @@ def main():
                     help="weak: 256 scenes per GPU per step (global minibatch 256 x N); strong: the reference's 256-scene minibatch split over "
                          "the N GPUs (SURVEY.md 8(e): 32 scenes per GPU at N = 8)")
     ap.add_argument("--no-full-update", action="store_true")
+    ap.add_argument("--batch", type=int, default=256, help="scenes per minibatch (diagnostic: 32 = what one of 8 ranks runs under --scaling strong)")
     args = ap.parse_args()
+    global BATCH
+    BATCH = args.batch
 
     # stdout carries exactly ONE line (rank 0's JSON): libraries that print banners to fd 1 (RCCL prints its version block at communicator
     # creation) are sent to stderr for the whole run; the saved descriptor is restored for the final print.
@@ -285,7 +288,7 @@ def main():
         steps_per_sec = args.steps / dt
         scenes_per_sec = steps_per_sec * global_bs
         line = {
-            "metric": "policy-update scenes/sec (256-scene RIFT update steps on a 4096-scene replay)",
+            "metric": f"policy-update scenes/sec ({BATCH}-scene RIFT update steps on a 4096-scene replay)",
             "value": scenes_per_sec, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",

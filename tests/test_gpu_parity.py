@@ -348,6 +348,26 @@ def test_device_collation_matches_pad_sequence(ffi):
     eng.close()
 
 
+@pytest.mark.parametrize("fp32", [False, True])
+def test_non_finite_decoder_queries_are_reported(ffi, fp32):
+    """The reference asserts torch.isfinite(q).all() on the decoder queries (planning_decoder.py:175).  Here: a device flag raised by the
+    policy-head kernels, surfaced as RIFT_ERR_NONFINITE by rift_check_finite (the host's sync point) -- and cleared by it."""
+    gold, batch, sd = H.load_case("small")
+    data = batch["cur_pluto_feature_torch"]
+    eng = ffi.Engine("cuda:0")
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad["planning_decoder.decoder_blocks.2.ffn.3.bias"][5] = float("inf")          # one Inf in the residual stream of layer 2
+    eng.load_state_dict(bad)
+    eng.forward(data, fp32=fp32)
+    with pytest.raises(RuntimeError, match="non-finite decoder queries"):
+        eng.check_finite()
+    eng.check_finite()                                                             # the flag was cleared by the failing check
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    eng.forward(data, fp32=fp32)
+    eng.check_finite()
+    eng.close()
+
+
 def test_device_collation_matches_the_reference_generated_fixture(ffi):
     """rift_collate against tests/golden/collate.npz -- the output of the REFERENCE's RIFTCollate.__call__ / PlutoFeature.collate
     (rift_datamodule.py:20-51, pluto_feature.py:25-96) on ragged seeded scenes (agent, polygon and reference-line counts differ per
