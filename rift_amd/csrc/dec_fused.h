@@ -63,7 +63,11 @@ __global__ void pack_mpx_kernel(const float* __restrict__ mp, const int* __restr
 
 #define RIFT_DEC_NPAR 2944   // ln1..4 g,b (1024) | b_r2r 384 | b_r2ro 128 | b_m2m 384 | b_m2mo 128 | b_cq 128 | b_co 128 | b_f1 512 | b_f2 128
 #define RIFT_DEC_NFFB 640    // the FFN biases (tail of the block) stay live to the end of a layer: double-buffered by layer parity
-#define RIFT_DEC_LDS_BYTES (80 * 132 * 4 + 80 * 136 * 2 * 2 + 80 * 200 * 2 + 96 * 72 * 2 + 64 * 104 * 2 + (RIFT_DEC_NPAR + RIFT_DEC_NFFB) * 4 + 96 + 96 + 16)
+// LDS row strides (elements): bf16 operand tiles use strides = 16 (mod 32), i.e. 8 (mod 16) dwords -- the 16 (row, k-chunk) lanes of every
+// ds_read_b128 lane group then fall on 16 distinct 4-bank windows (4 LDS cycles per fragment read; 136 / 200 cost 8: tools/lds_conflicts.py)
+#define RIFT_DEC_XN 144
+#define RIFT_DEC_CB 208
+#define RIFT_DEC_LDS_BYTES (80 * 132 * 4 + 80 * RIFT_DEC_XN * 2 * 2 + 80 * RIFT_DEC_CB * 2 + 96 * 72 * 2 + 64 * 104 * 2 + (RIFT_DEC_NPAR + RIFT_DEC_NFFB) * 4 + 96 + 96 + 16)
 
 // NW waves per workgroup: one scene is one workgroup on one CU, so the wave count is the only occupancy lever
 template <int NW, int MTT = 5>
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(64 * NW) void dec_fused_kernel(DecFusedP p) {
   constexpr int ROWS = 80, MT = MTT, C = 128, M = 12;   // ROWS: LDS row allocation; MT: 16-row tiles actually processed (R * 12 <= 16 * MT)
   constexpr int RUSE = 16 * MT;
   constexpr int NTH = 64 * NW, NTQ = (12 + NW - 1) / NW, NTC = 8 / NW;   // n-tiles per wave: 192-column chunk, 128-column output
-  constexpr int XS = 132, XN = 136, CB = 200, KC = 72, VS = 104, NKT = 6;
+  constexpr int XS = 132, XN = RIFT_DEC_XN, CB = RIFT_DEC_CB, KC = 72, VS = 104, NKT = 6;
   constexpr int P_LN = 0, P_BR2R = 1024, P_BR2RO = 1408, P_BM2M = 1536, P_BM2MO = 1920, P_BCQ = 2048, P_BCO = 2176,
                 P_BF1 = 2304, P_BF2 = 2816;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

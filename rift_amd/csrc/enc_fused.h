@@ -98,20 +98,24 @@ __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
 }
 
 #define RIFT_ENC_NPAR 1664   // per-layer vectors kept in LDS: ln1 g,b | ln2 g,b | bqkv 384 | bo 128 | b1 512 | b2 128
-#define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * 136 * 2 * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 128 + RIFT_ENC_NPAR * 4)
+// LDS row strides (bf16 elements).  xn -- the operand of six of the eleven GEMM phases of a layer -- uses 144 = 16 (mod 32): its ds_read_b128
+// fragment reads are bank-conflict free (4 LDS cycles; 136 costs 8, tools/lds_conflicts.py).  ao / cb keep 136 / 200: the 160 KB are full.
+#define RIFT_ENC_XN 144
+#define RIFT_ENC_XA 136
+#define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * (RIFT_ENC_XN + RIFT_ENC_XA) * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 128 + RIFT_ENC_NPAR * 4)
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
   constexpr int ROWS = 96, MT = 6, C = 128;
   constexpr int NTH = 64 * NW, NTQ = 12 / NW + (12 % NW ? 1 : 0), NTC = 8 / NW;   // n-tiles per wave: qkv chunk (12), 128-wide output (8)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  constexpr int XS = 132, XN = 136, CB = 200, VS = 104, NKT = 6;
+  constexpr int XS = 132, XN = RIFT_ENC_XN, XA = RIFT_ENC_XA, CB = 200, VS = 104, NKT = 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* xs = reinterpret_cast<float*>(smem_raw);
   unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
   unsigned short* cb = xn + ROWS * XN;
   unsigned short* ao = cb + ROWS * CB;
-  unsigned short* vt = ao + ROWS * XN;            // [2][32][VS]
+  unsigned short* vt = ao + ROWS * XA;            // [2][32][VS]
   unsigned char* smask = reinterpret_cast<unsigned char*>(vt + 2 * 32 * VS);
   float* par = reinterpret_cast<float*>(smask + 128);   // [RIFT_ENC_NPAR] this layer's bias / LayerNorm vectors
   constexpr int P_LN1G = 0, P_LN1B = 128, P_LN2G = 256, P_LN2B = 384, P_BQKV = 512, P_BO = 896, P_B1 = 1024, P_B2 = 1536;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         }
         const int head = ch * 2 + hh;
         const float inv = __builtin_amdgcn_rcpf(lsum);
-        unsigned short* op = ao + (qt * 16 + l15) * XN + head * 32 + l4 * 4;
+        unsigned short* op = ao + (qt * 16 + l15) * XA + head * 32 + l4 * 4;
         *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
         *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
       }
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      e_mma<MT, 4, NTC>(acc, ao, XN, Bw, l15, l4);
+      e_mma<MT, 4, NTC>(acc, ao, XA, Bw, l15, l4);
       e_load_b(Bw, w.w1, C, 0, 0, wave, l15, l4, EWaves<NW>());             // fc1 weights of hidden chunk 0
 #pragma unroll
       for (int j = 0; j < NTC; ++j) {

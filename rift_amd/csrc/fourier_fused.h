@@ -24,7 +24,7 @@ struct FourierP {
 };
 
 #define FO_ROWS 64
-#define FO_FS 136
+#define FO_FS 144
 #define FO_HS 132
 #define FO_NPAR (3 * 5 * 128 + 3 * 128)
 #define FO_LDS (FO_ROWS * FO_FS * 2 * 2 + FO_ROWS * FO_HS * 4 + FO_ROWS * 4 * 4 + FO_NPAR * 4)

@@ -22,7 +22,7 @@ struct FpnP {
 };
 
 #define FPN_AG 64
-#define FPN_LDA 392
+#define FPN_LDA 400
 #define FPN_LDS (128 * FPN_LDA * 2)
 
 template <int C, int KS>
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void fpn_tail_kernel(FpnP p) {
                b0 = *reinterpret_cast<const float4*>(p.bl[0] + col);
   const float bb2[4] = {b2.x, b2.y, b2.z, b2.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w}, bb0[4] = {b0.x, b0.y, b0.z, b0.w};
   // top-down merge (see fpn_merge_kernel): positions a = even row, b = odd row of the same agent
-  unsigned short* Zt = At;                        // [64][264] bf16: [Z0 | Z1] per agent (the A tile is dead)
+  unsigned short* Zt = At;                        // [64][272] bf16: [Z0 | Z1] per agent (the A tile is dead)
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     float z[4];
@@ -83,12 +83,12 @@ __global__ __launch_bounds__(512) void fpn_tail_kernel(FpnP p) {
       z[r] = odd ? l0 + l1b : l0 + (0.25f * l1a + 0.75f * l1b);
     }
     const int agent = (mt * 16 + l15) >> 1;
-    *reinterpret_cast<uint2*>(Zt + agent * 264 + (odd ? 128 : 0) + col) = pack_bf16x4(z[0], z[1], z[2], z[3]);
+    *reinterpret_cast<uint2*>(Zt + agent * 272 + (odd ? 128 : 0) + col) = pack_bf16x4(z[0], z[1], z[2], z[3]);
   }
   __syncthreads();
   f32x4 acc[4][1];
   p_zero(acc);
-  p_mma<4, 8, 1>(acc, Zt, 264, 0, Wf, l15, l4);
+  p_mma<4, 8, 1>(acc, Zt, 272, 0, Wf, l15, l4);
   const float4 bf4 = *reinterpret_cast<const float4*>(p.bf_ + col);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {

@@ -19,8 +19,8 @@ struct Heads3P {
 };
 
 #define HD_ROWS 128
-#define HD_XS 136
-#define HD_HS 264
+#define HD_XS 144
+#define HD_HS 272
 #define HD_LDS (HD_ROWS * HD_XS * 2 + HD_ROWS * HD_HS * 2 + 8 * HD_ROWS * 2 * 4 + 3 * 768 * 4 + 3 * 160 * 4)
 
 __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {

@@ -26,10 +26,12 @@ __global__ void pi_tail_kernel(const float* __restrict__ Hpi /*[rows][128]*/, in
   const float a0 = fmaxf(d0 * rstd * g[lane] + be[lane], 0.f);
   const float a1 = fmaxf(d1 * rstd * g[lane + 64] + be[lane + 64], 0.f);
   const float z = wave_sum(a0 * w2[lane] + a1 * w2[lane + 64]) + b2[0];
+  // a NaN / Inf in the decoder queries (the reference's assert, planning_decoder.py:175) reaches this hidden row; test the row itself
+  // (x * 0 is NaN for NaN and +-Inf) -- the ReLU's fmaxf would swallow a NaN before it reached the logit
+  const float bad = wave_sum(h0 * 0.f + h1 * 0.f);
   if (lane == 0) {
     prob[row] = r_kpm[row / M] ? -1e6f : z;
-    // a NaN / Inf in the decoder queries (the reference's assert, planning_decoder.py:175) reaches the hidden row and its logit
-    if (nonfinite && z * 0.f != 0.f) atomicOr(nonfinite, 1);
+    if (nonfinite && bad != 0.f) atomicOr(nonfinite, 1);
   }
 }
 

@@ -111,10 +111,10 @@ __device__ __forceinline__ void mma_rows(f32x4 (&acc)[MTN][NTW], const unsigned 
 // dynamic LDS bytes of nat_level_kernel<C, NHEAD, L, KSZ, NW, CWMAX>
 constexpr size_t nat_lds_bytes(int C, int NHEAD, int KSZ, int CWMAX, int ROWS = 80) {
   const int DSR = (ROWS / 2 + 15) / 16 * 16;
-  const int C3 = 3 * C, CWK = C3 < CWMAX ? C3 : CWMAX, CB = CWK + 8, DSB = C3 + 8;
+  const int C3 = 3 * C, CWK = C3 < CWMAX ? C3 : CWMAX, CB = CWK + 16, DSB = C3 + 16;
   const int cbsz = (C <= 64 && DSR * DSB > ROWS * CB) ? DSR * DSB : ROWS * CB;
   const int nrpb = NHEAD * (2 * KSZ - 1);
-  return (size_t)ROWS * (C + 4) * 4 + (size_t)ROWS * (C + 8) * 2 * 2 + (size_t)cbsz * 2 + (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4 + (size_t)6 * C * 4;
+  return (size_t)ROWS * (C + 4) * 4 + (size_t)ROWS * (C + 16) * 2 * 2 + (size_t)cbsz * 2 + (size_t)2 * (12 * C + ((nrpb + 3) & ~3)) * 4 + (size_t)6 * C * 4;
 }
 
 // NW waves per workgroup (n-tiles and rows are dealt round-robin to the waves); CWMAX = widest qkv / hidden chunk
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
   constexpr int CWK = C3 < CWMAX ? C3 : CWMAX;        // chunk width (columns of qkv / hidden processed at once)
   constexpr int NCH = C3 / CWK;                   // 1, 1, 2
   constexpr int HPC = CWK / 48;                   // heads per qkv chunk
-  constexpr int XS = C + 4, XN = C + 8, CB = CWK + 8;
+  // bf16 operand tiles: row strides = 16 (mod 32) elements -> conflict-free ds_read_b128 fragment reads (tools/lds_conflicts.py)
+  constexpr int XS = C + 4, XN = C + 16, CB = CWK + 16;
   constexpr int KS1 = C / 32;                     // k-steps with K = C
   constexpr int KSC = CWK / 32;                   // k-steps with K = chunk
   constexpr int NT_CH = CWK / 16;                 // n-tiles of a chunk (6 or 12)
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void nat_level_kernel(NatLevelP p) {
   float* xs = reinterpret_cast<float*>(smem_raw);
   unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
   unsigned short* cb = xn + ROWS * XN;
-  constexpr int DSB = C3 + 8;                     // row stride of the downsample conv's A tile (staged in cb)
+  constexpr int DSB = C3 + 16;                    // row stride of the downsample conv's A tile (staged in cb)
   constexpr int DSR = (ROWS / 2 + 15) / 16 * 16;   // rows of the downsample conv's A tile
   constexpr int CBSZ = (C <= 64 && DSR * DSB > ROWS * CB) ? DSR * DSB : ROWS * CB;
   unsigned short* ao = cb + CBSZ;

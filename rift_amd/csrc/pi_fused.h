@@ -24,7 +24,7 @@ struct PiFwdP {
 };
 
 #define PI_ROWS 128
-#define PI_QS 136
+#define PI_QS 144
 #define PI_FS 132
 #define PI_LDS (PI_ROWS * PI_QS * 2 + PI_ROWS * PI_FS * 4 + 8 * PI_ROWS * 2 * 4 + 8 * PI_ROWS * 4)
 
