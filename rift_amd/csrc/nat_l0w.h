@@ -1,0 +1,395 @@
+// Level 0 of the NAT-FPN history encoder (embedding.py:57-99,196-202: ConvTokenizer -> 2 NATLayers (dim 32, 2 heads, kernel 3) ->
+// {LayerNorm of the last 3 steps for the FPN, downsample conv + LayerNorm -> level 1}) as WAVE-PRIVATE, REGISTER-RESIDENT tiles.
+//
+// Why a second design for this level.  nat_level_kernel keeps an 80-row tile in LDS and splits every GEMM's n-tiles over the 8 waves
+// of a workgroup, with a workgroup barrier between phases.  At C = 32 a phase is 2..6 MFMA n-tiles and 80 x 32 values of VALU work:
+// most waves idle, and the level's ~30 phases per tile are pure barrier latency (137 us for 13.7 GFLOP).  Here one WAVE owns a tile of
+// 4 agents x 20 steps = 80 rows for the whole level and nothing is ever exchanged between waves:
+//   * row (agent a, step t) lives in MFMA row tile mt = t / 4, lane row l15 = 4 a + t % 4 -- the 4 lanes of a DPP quad are 4
+//     consecutive steps of one agent, so the kernel-3 neighbourhood attention reads its neighbours with quad_perm DPP moves (plus the
+//     quad edge from the adjacent row tile's register);
+//   * the fp32 residual stream is the MFMA C/D layout itself: x[mt][nt] holds, per lane, 4 consecutive channels of one row
+//     (40 VGPRs for 80 x 32).  A GEMM output in that layout IS the next GEMM's B operand: the contraction order is free, so the
+//     weights are packed with the K order "lane l4 holds channels {4 l4 .. +3} of n-tile 0 and of n-tile 1" -- no LDS round trip,
+//     no transposition between LayerNorm -> qkv, attention -> proj, LayerNorm -> fc1 -> GELU -> fc2;
+//   * q, k, v stay fp32 (VALU attention); only MFMA operands are bf16;
+//   * weights (54 fragments of 1 KiB) and parameters sit in LDS, read as conflict-free 16-byte-per-lane fragment loads; the only other
+//     LDS use is a per-wave bf16 staging tile for the stride-2 downsample conv (rows change lanes there).
+// No workgroup barrier after the prologue.
+#pragma once
+#include "common.h"
+
+namespace rift {
+
+#define L0W_NFRAG 54
+#define L0W_F_TOK 0                       // 2 n-tiles, K = 27 window values (tap-major: tap * 9 + cin)
+#define L0W_F_BLK(b) (2 + 20 * (b))      // + 0..5 qkv (q_h0 q_h1 k_h0 k_h1 v_h0 v_h1; q pre-scaled) | + 6..7 proj | + 8..13 fc1 | + 14 + 2 ks + nt fc2
+#define L0W_F_DS 42                       // + 4 tap + nt: downsample conv, K = 32 channels of one tap (natural order)
+// parameter block (fp32): b_tok 32 | per block: ln1_g 32, ln1_b 32, bqkv 96 (q part pre-scaled), rpb 16 (2 x 5 used), bproj 32, ln2_g 32, ln2_b 32,
+// b1 96, b2 32 | fn_g 32, fn_b 32 | ds_g 64, ds_b 64
+#define L0W_P_BLK(b) (32 + 400 * (b))
+#define L0W_PB_LN1G 0
+#define L0W_PB_LN1B 32
+#define L0W_PB_BQKV 64
+#define L0W_PB_RPB 160
+#define L0W_PB_BP 176
+#define L0W_PB_LN2G 208
+#define L0W_PB_LN2B 240
+#define L0W_PB_B1 272
+#define L0W_PB_B2 368
+#define L0W_P_FN 832
+#define L0W_P_DS 896
+#define L0W_NPAR 1024
+#define L0W_ST 40                         // staging tile row stride (bf16): 80 B rows, 16-byte aligned fragments
+#ifndef L0W_NWV
+#define L0W_NWV 8                        // waves per workgroup (= per CU: the LDS image allows one workgroup); 12 -> 168 VGPRs per wave
+#endif
+#define L0W_LDS (L0W_NFRAG * 1024 + L0W_NPAR * 4 + L0W_NWV * 80 * L0W_ST * 2)
+
+struct NatL0WSrc {    // raw fp32 parameters (views onto the state_dict) for pack_l0w_kernel
+  const float* w_tok; const float* b_tok;                                   // embed.proj (32, 9, 3), (32)
+  struct Blk { const float *ln1_g, *ln1_b, *wqkv, *bqkv, *rpb, *wproj, *bproj, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2; } blk[2];
+  const float* fn_g; const float* fn_b;                                     // norm0
+  const float* w_ds; const float* ds_g; const float* ds_b;                  // levels.0.downsample.reduction (64, 32, 3), norm (64)
+};
+
+// channel a lane's k-slot j (0..7) of chunk l4 stands for when the operand is a GEMM output kept in the C/D layout (two n-tiles)
+__host__ __device__ __forceinline__ int l0w_chan(int l4, int j, int nt_lo) { return (j < 4 ? nt_lo : nt_lo + 1) * 16 + l4 * 4 + (j & 3); }
+
+__global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, float* __restrict__ par) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < L0W_NFRAG * 512) {
+    const int f = e >> 9, lane = (e >> 3) & 63, j = e & 7, l15 = lane & 15, l4 = lane >> 4;
+    float v = 0.f;
+    if (f < 2) {                                   // tokenizer: window index = tap * 9 + cin
+      const int w = l4 * 8 + j, n = f * 16 + l15;
+      if (w < 27) v = s.w_tok[(n * 9 + (w % 9)) * 3 + (w / 9)];
+    } else if (f < L0W_F_DS) {
+      const int b = (f - 2) / 20, g = (f - 2) % 20;
+      const NatL0WSrc::Blk& k = s.blk[b];
+      if (g < 6) v = k.wqkv[(g * 16 + l15) * 32 + l0w_chan(l4, j, 0)] * (g < 2 ? 0.25f : 1.0f);        // q scaled by head_dim^-0.5
+      else if (g < 8) v = k.wproj[((g - 6) * 16 + l15) * 32 + l0w_chan(l4, j, 0)];
+      else if (g < 14) v = k.w1[((g - 8) * 16 + l15) * 32 + l0w_chan(l4, j, 0)];
+      else { const int ks = (g - 14) >> 1, nt = (g - 14) & 1; v = k.w2[(nt * 16 + l15) * 96 + l0w_chan(l4, j, 2 * ks)]; }
+    } else {
+      const int tap = (f - L0W_F_DS) >> 2, nt = (f - L0W_F_DS) & 3;
+      v = s.w_ds[((nt * 16 + l15) * 32 + l4 * 8 + j) * 3 + tap];
+    }
+    img[e] = f2bf(v);
+  }
+  if (e < L0W_NPAR) {
+    float v = 0.f;
+    if (e < 32) v = s.b_tok[e];
+    else if (e < L0W_P_FN) {
+      const int b = (e - 32) / 400, o = (e - 32) % 400;
+      const NatL0WSrc::Blk& k = s.blk[b];
+      if (o < 32) v = k.ln1_g[o];
+      else if (o < 64) v = k.ln1_b[o - 32];
+      else if (o < 160) v = k.bqkv[o - 64] * (o - 64 < 32 ? 0.25f : 1.0f);
+      else if (o < 176) v = (o - 160 < 10) ? k.rpb[o - 160] : 0.f;
+      else if (o < 208) v = k.bproj[o - 176];
+      else if (o < 240) v = k.ln2_g[o - 208];
+      else if (o < 272) v = k.ln2_b[o - 240];
+      else if (o < 368) v = k.b1[o - 272];
+      else v = k.b2[o - 368];
+    } else if (e < L0W_P_DS) v = (e - L0W_P_FN < 32) ? s.fn_g[e - L0W_P_FN] : s.fn_b[e - L0W_P_FN - 32];
+    else v = (e - L0W_P_DS < 64) ? s.ds_g[e - L0W_P_DS] : s.ds_b[e - L0W_P_DS - 64];
+    par[e] = v;
+  }
+}
+
+struct NatL0WP {
+  const float* F9; int nseq;               // (nseq * 20, 9) agent features
+  const unsigned short* img; const float* par;
+  float* Oc;                               // (nseq * 3, 32)  LayerNorm(norm0) of steps 17..19
+  float* Xnext;                            // (nseq * 10, 64) downsample conv + LayerNorm
+  float droppath[2]; uint32_t seed, stream;
+  long long* ts;                           // optional section timestamps of wave 0 of workgroup 0 (diagnostic, RIFT_NAT_TS=1)
+};
+
+__device__ __forceinline__ bf16x8 l0w_pack8(const f32x4 a, const f32x4 b) {
+  bf16x8 r;
+  const unsigned int p0 = pack_bf16x2(a[0], a[1]), p1 = pack_bf16x2(a[2], a[3]), p2 = pack_bf16x2(b[0], b[1]), p3 = pack_bf16x2(b[2], b[3]);
+  r[0] = (short)(p0 & 0xffff); r[1] = (short)(p0 >> 16); r[2] = (short)(p1 & 0xffff); r[3] = (short)(p1 >> 16);
+  r[4] = (short)(p2 & 0xffff); r[5] = (short)(p2 >> 16); r[6] = (short)(p3 & 0xffff); r[7] = (short)(p3 >> 16);
+  return r;
+}
+__device__ __forceinline__ bf16x8 l0w_from_u2(const uint2 a, const uint2 b) {
+  bf16x8 r;
+  r[0] = (short)(a.x & 0xffff); r[1] = (short)(a.x >> 16); r[2] = (short)(a.y & 0xffff); r[3] = (short)(a.y >> 16);
+  r[4] = (short)(b.x & 0xffff); r[5] = (short)(b.x >> 16); r[6] = (short)(b.y & 0xffff); r[7] = (short)(b.y >> 16);
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ f32x4 l0w_dpp4(const f32x4 v) {
+  return (f32x4){dpp_f<CTRL>(v[0]), dpp_f<CTRL>(v[1]), dpp_f<CTRL>(v[2]), dpp_f<CTRL>(v[3])};
+}
+__device__ __forceinline__ f32x4 l0w_sel(bool c, const f32x4 a, const f32x4 b) {
+  return (f32x4){c ? a[0] : b[0], c ? a[1] : b[1], c ? a[2] : b[2], c ? a[3] : b[3]};
+}
+
+// LayerNorm over the 32 channels of every row of x (8 per lane, 4 lanes per row) -> bf16 B operands (two-pass statistics, as torch)
+__device__ __forceinline__ void l0w_layer_norm(const f32x4 (&x)[5][2], bf16x8 (&xn)[5], const float* g, const float* b, int l4) {
+  const float4 g0 = *reinterpret_cast<const float4*>(g + l4 * 4), g1 = *reinterpret_cast<const float4*>(g + 16 + l4 * 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(b + l4 * 4), b1 = *reinterpret_cast<const float4*>(b + 16 + l4 * 4);
+#pragma unroll
+  for (int mt = 0; mt < 5; ++mt) {
+    const f32x4 u = x[mt][0], w = x[mt][1];
+    const float mean = rows_sum(((u[0] + u[1]) + (u[2] + u[3])) + ((w[0] + w[1]) + (w[2] + w[3]))) * (1.0f / 32.0f);
+    const f32x4 du = u - mean, dw = w - mean;
+    const float var = rows_sum(((du[0] * du[0] + du[1] * du[1]) + (du[2] * du[2] + du[3] * du[3])) +
+                               ((dw[0] * dw[0] + dw[1] * dw[1]) + (dw[2] * dw[2] + dw[3] * dw[3]))) * (1.0f / 32.0f);
+    const float r = rsqrtf(var + 1e-5f);
+    const f32x4 yu = {du[0] * r * g0.x + b0.x, du[1] * r * g0.y + b0.y, du[2] * r * g0.z + b0.z, du[3] * r * g0.w + b0.w};
+    const f32x4 yw = {dw[0] * r * g1.x + b1.x, dw[1] * r * g1.y + b1.y, dw[2] * r * g1.z + b1.z, dw[3] * r * g1.w + b1.w};
+    xn[mt] = l0w_pack8(yu, yw);
+  }
+}
+
+__global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
+  constexpr int NTHR = 64 * L0W_NWV;
+  constexpr int L = 20;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* wl = reinterpret_cast<unsigned short*>(smem_raw);            // [54][64][8] weight fragments
+  float* par = reinterpret_cast<float*>(wl + L0W_NFRAG * 512);
+  unsigned short* stg = reinterpret_cast<unsigned short*>(par + L0W_NPAR);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  for (int i = tid; i < L0W_NFRAG * 64; i += NTHR) reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(p.img)[i];
+  for (int i = tid; i < L0W_NPAR / 4; i += NTHR) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
+  __syncthreads();
+  unsigned short* st = stg + wave * 80 * L0W_ST;
+  auto W = [&](int f) { return *reinterpret_cast<const bf16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
+  const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
+  const int a = l15 >> 2, s = l15 & 3;
+  const int ntiles = (p.nseq + 3) >> 2;
+  int tsn = 0;
+#define L0TS() do { if (p.ts && blockIdx.x == 0 && tid == 0 && tsn < 60) p.ts[tsn++] = clock64(); } while (0)
+  L0TS();
+
+  for (int tile = blockIdx.x * L0W_NWV + wave; tile < ntiles; tile += gridDim.x * L0W_NWV) {
+    const int seq = tile * 4 + a;
+    const bool seq_ok = seq < p.nseq;
+    f32x4 x[5][2];
+    L0TS();
+    // ---- ConvTokenizer: one K = 32 MFMA step over the 3 x 9 window, read straight from the feature rows (27 contiguous floats)
+    {
+      const bf16x8 w0 = W(L0W_F_TOK), w1 = W(L0W_F_TOK + 1);
+      const float4 b0 = *reinterpret_cast<const float4*>(par + l4 * 4), b1 = *reinterpret_cast<const float4*>(par + 16 + l4 * 4);
+      // the window of step t = feature rows t-1, t, t+1 = 27 contiguous floats; lane l4 takes values 8 l4 .. +7 with two UNCONDITIONAL
+      // 16-byte loads (4-byte aligned; the engine pads the feature buffer in front) and masks what lies outside the sequence afterwards
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+      const int sq = seq_ok ? seq : p.nseq - 1;
+      unsigned m_all = 0u, m_tap0 = 0u, m_tap2 = 0u;          // bit j: window value 8 l4 + j exists / belongs to tap 0 / to tap 2
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int w = l4 * 8 + j;
+        m_all |= (w < 27 ? 1u : 0u) << j; m_tap0 |= (w < 9 ? 1u : 0u) << j; m_tap2 |= (w >= 18 ? 1u : 0u) << j;
+      }
+      if (!seq_ok) m_all = 0u;
+#pragma unroll
+      for (int mt = 0; mt < 5; ++mt) {
+        const int t = mt * 4 + s;
+        const float* src = p.F9 + ((long long)sq * L + t - 1) * 9 + l4 * 8;
+        const f4u lo = *reinterpret_cast<const f4u*>(src), hi = *reinterpret_cast<const f4u*>(src + 4);
+        unsigned m = m_all;
+        if (mt == 0) m &= (s == 0) ? ~m_tap0 : ~0u;           // t = 0: no step -1
+        if (mt == 4) m &= (s == 3) ? ~m_tap2 : ~0u;           // t = 19: no step 20
+        const f32x4 va = {(m & 1u) ? lo[0] : 0.f, (m & 2u) ? lo[1] : 0.f, (m & 4u) ? lo[2] : 0.f, (m & 8u) ? lo[3] : 0.f};
+        const f32x4 vb = {(m & 16u) ? hi[0] : 0.f, (m & 32u) ? hi[1] : 0.f, (m & 64u) ? hi[2] : 0.f, (m & 128u) ? hi[3] : 0.f};
+        const bf16x8 bop = l0w_pack8(va, vb);
+        x[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, bop, Z, 0, 0, 0);
+        x[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, bop, Z, 0, 0, 0);
+        x[mt][0] += (f32x4){b0.x, b0.y, b0.z, b0.w};
+        x[mt][1] += (f32x4){b1.x, b1.y, b1.z, b1.w};
+      }
+    }
+    L0TS();
+#pragma unroll 1
+    for (int bi = 0; bi < 2; ++bi) {
+      const float* pb = par + L0W_P_BLK(bi);
+      const int fb = L0W_F_BLK(bi);
+      bf16x8 xn[5];
+      // ================= attention half =================
+      l0w_layer_norm(x, xn, pb + L0W_PB_LN1G, pb + L0W_PB_LN1B, l4);
+      // one head at a time (rolled loop: the live set is the residual, the LayerNorm operands and ONE head's k / v): its proj contribution
+      // goes straight into the residual -- proj(concat(o_0, o_1)) = W[:, head 0] o_0 + W[:, head 1] o_1, each as a K = 32 step whose
+      // other half is zero
+      float dps = 1.f;
+      if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+      const bf16x8 wp0 = W(fb + 6), wp1 = W(fb + 7);
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        f32x4 k[5], v[5];
+        const bf16x8 wq = W(fb + h);
+        const float4 bq = *reinterpret_cast<const float4*>(pb + L0W_PB_BQKV + h * 16 + l4 * 4);
+        {
+          const bf16x8 wk = W(fb + 2 + h), wv = W(fb + 4 + h);
+          const float4 bk = *reinterpret_cast<const float4*>(pb + L0W_PB_BQKV + 32 + h * 16 + l4 * 4);
+          const float4 bv = *reinterpret_cast<const float4*>(pb + L0W_PB_BQKV + 64 + h * 16 + l4 * 4);
+#pragma unroll
+          for (int mt = 0; mt < 5; ++mt) {
+            k[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk, xn[mt], Z, 0, 0, 0) + (f32x4){bk.x, bk.y, bk.z, bk.w};
+            v[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xn[mt], Z, 0, 0, 0) + (f32x4){bv.x, bv.y, bv.z, bv.w};
+          }
+        }
+        // 1-D neighbourhood attention, kernel 3, window start clamp(t - 1, 0, L - 3); keys of step t: (t-1, t, t+1), (0, 1, 2) at t = 0,
+        // (17, 18, 19) at t = 19.  The quad (4 lanes) holds steps 4 mt .. 4 mt + 3 of one agent: neighbours come through quad_perm DPP,
+        // the quad edges from the adjacent row tile's register.  Lane l4 holds 4 of the 16 head dims: partial dots summed over the 4 l4 lanes.
+        const float* rp = pb + L0W_PB_RPB + h * 5;
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+          const f32x4 qq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, xn[mt], Z, 0, 0, 0) + (f32x4){bq.x, bq.y, bq.z, bq.w};
+          // neighbours at t - 1 and t + 1 (generic case)
+          f32x4 km = l0w_dpp4<0x90>(k[mt]), kp = l0w_dpp4<0xF9>(k[mt]);            // quad_perm [0,0,1,2] / [1,2,3,3]
+          f32x4 vm = l0w_dpp4<0x90>(v[mt]), vp = l0w_dpp4<0xF9>(v[mt]);
+          if (mt > 0) { km = l0w_sel(s == 0, l0w_dpp4<0xFF>(k[mt - 1]), km); vm = l0w_sel(s == 0, l0w_dpp4<0xFF>(v[mt - 1]), vm); }
+          if (mt < 4) { kp = l0w_sel(s == 3, l0w_dpp4<0x00>(k[mt + 1]), kp); vp = l0w_sel(s == 3, l0w_dpp4<0x00>(v[mt + 1]), vp); }
+          f32x4 k0 = km, k1 = k[mt], k2 = kp, v0 = vm, v1 = v[mt], v2 = vp;
+          int shift = 0;                                                          // rpb index of key j: j + 1 + shift
+          if (mt == 0) {        // t = 0 (lane s = 0): keys (0, 1, 2) = (own, +1, +2)
+            const f32x4 kpp = l0w_dpp4<0xFE>(k[0]), vpp = l0w_dpp4<0xFE>(v[0]);   // quad_perm [2,3,3,3]
+            const bool e = s == 0;
+            k0 = l0w_sel(e, k[0], km); k1 = l0w_sel(e, kp, k[0]); k2 = l0w_sel(e, kpp, kp);
+            v0 = l0w_sel(e, v[0], vm); v1 = l0w_sel(e, vp, v[0]); v2 = l0w_sel(e, vpp, vp);
+            shift = e ? 1 : 0;
+          }
+          if (mt == 4) {        // t = 19 (lane s = 3): keys (17, 18, 19) = (-2, -1, own)
+            const f32x4 kmm = l0w_dpp4<0x40>(k[4]), vmm = l0w_dpp4<0x40>(v[4]);   // quad_perm [0,0,0,1]
+            const bool e = s == 3;
+            k0 = l0w_sel(e, kmm, km); k1 = l0w_sel(e, km, k[4]); k2 = l0w_sel(e, k[4], kp);
+            v0 = l0w_sel(e, vmm, vm); v1 = l0w_sel(e, vm, v[4]); v2 = l0w_sel(e, v[4], vp);
+            shift = e ? -1 : 0;
+          }
+          float s0 = (qq[0] * k0[0] + qq[1] * k0[1]) + (qq[2] * k0[2] + qq[3] * k0[3]);
+          float s1 = (qq[0] * k1[0] + qq[1] * k1[1]) + (qq[2] * k1[2] + qq[3] * k1[3]);
+          float s2 = (qq[0] * k2[0] + qq[1] * k2[1]) + (qq[2] * k2[2] + qq[3] * k2[3]);
+          s0 = rows_sum(s0) + rp[1 + shift]; s1 = rows_sum(s1) + rp[2 + shift]; s2 = rows_sum(s2) + rp[3 + shift];
+          const float mx = fmaxf(fmaxf(s0, s1), s2);
+          const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx), e2 = __expf(s2 - mx);
+          const float inv = __builtin_amdgcn_rcpf((e0 + e1) + e2);
+          const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+          const f32x4 oh = {p0 * v0[0] + p1 * v1[0] + p2 * v2[0], p0 * v0[1] + p1 * v1[1] + p2 * v2[1],
+                            p0 * v0[2] + p1 * v1[2] + p2 * v2[2], p0 * v0[3] + p1 * v1[3] + p2 * v2[3]};
+          const bf16x8 ao = h == 0 ? l0w_pack8(oh, Z) : l0w_pack8(Z, oh);
+          x[mt][0] += __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp0, ao, Z, 0, 0, 0) * dps;
+          x[mt][1] += __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp1, ao, Z, 0, 0, 0) * dps;
+        }
+      }
+      {   // proj bias
+        const float4 b0 = *reinterpret_cast<const float4*>(pb + L0W_PB_BP + l4 * 4), b1 = *reinterpret_cast<const float4*>(pb + L0W_PB_BP + 16 + l4 * 4);
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+          x[mt][0] += (f32x4){b0.x, b0.y, b0.z, b0.w} * dps; x[mt][1] += (f32x4){b1.x, b1.y, b1.z, b1.w} * dps;
+        }
+      }
+      L0TS();
+      // ================= MLP half: fc1 (32 -> 96) -> GELU -> fc2 (96 -> 32), the hidden layer 32 channels (one k-step) at a time =================
+      l0w_layer_norm(x, xn, pb + L0W_PB_LN2G, pb + L0W_PB_LN2B, l4);
+      {
+        f32x4 acc2[5][2];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) { acc2[mt][0] = Z; acc2[mt][1] = Z; }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const bf16x8 wa = W(fb + 8 + 2 * ks), wb = W(fb + 9 + 2 * ks), u0 = W(fb + 14 + 2 * ks), u1 = W(fb + 15 + 2 * ks);
+          const float4 ba = *reinterpret_cast<const float4*>(pb + L0W_PB_B1 + (2 * ks) * 16 + l4 * 4);
+          const float4 bb = *reinterpret_cast<const float4*>(pb + L0W_PB_B1 + (2 * ks + 1) * 16 + l4 * 4);
+#pragma unroll
+          for (int mt = 0; mt < 5; ++mt) {
+            const f32x4 ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xn[mt], Z, 0, 0, 0);
+            const f32x4 hb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xn[mt], Z, 0, 0, 0);
+            const bf16x8 hop = l0w_from_u2(gelu4_pack(ha, ba), gelu4_pack(hb, bb));
+            acc2[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, hop, acc2[mt][0], 0, 0, 0);
+            acc2[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, hop, acc2[mt][1], 0, 0, 0);
+          }
+        }
+        const float4 b0 = *reinterpret_cast<const float4*>(pb + L0W_PB_B2 + l4 * 4), b1 = *reinterpret_cast<const float4*>(pb + L0W_PB_B2 + 16 + l4 * 4);
+        float dps = 1.f;
+        if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+          x[mt][0] += (acc2[mt][0] + (f32x4){b0.x, b0.y, b0.z, b0.w}) * dps;
+          x[mt][1] += (acc2[mt][1] + (f32x4){b1.x, b1.y, b1.z, b1.w}) * dps;
+        }
+      }
+      L0TS();
+    }
+    L0TS();
+    // ---- what the FPN reads of this level: LayerNorm(norm0) of steps 17, 18, 19 (row tile 4, quad lanes 1..3)
+    {
+      const float* g = par + L0W_P_FN;
+      const float4 g0 = *reinterpret_cast<const float4*>(g + l4 * 4), g1 = *reinterpret_cast<const float4*>(g + 16 + l4 * 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(g + 32 + l4 * 4), b1 = *reinterpret_cast<const float4*>(g + 48 + l4 * 4);
+      const f32x4 u = x[4][0], w = x[4][1];
+      const float mean = rows_sum(((u[0] + u[1]) + (u[2] + u[3])) + ((w[0] + w[1]) + (w[2] + w[3]))) * (1.0f / 32.0f);
+      const f32x4 du = u - mean, dw = w - mean;
+      const float var = rows_sum(((du[0] * du[0] + du[1] * du[1]) + (du[2] * du[2] + du[3] * du[3])) +
+                                 ((dw[0] * dw[0] + dw[1] * dw[1]) + (dw[2] * dw[2] + dw[3] * dw[3]))) * (1.0f / 32.0f);
+      const float r = rsqrtf(var + 1e-5f);
+      if (seq_ok && s >= 1) {
+        float* dst = p.Oc + ((size_t)seq * 3 + (s - 1)) * 32;
+        *reinterpret_cast<float4*>(dst + l4 * 4) = make_float4(du[0] * r * g0.x + b0.x, du[1] * r * g0.y + b0.y, du[2] * r * g0.z + b0.z, du[3] * r * g0.w + b0.w);
+        *reinterpret_cast<float4*>(dst + 16 + l4 * 4) = make_float4(dw[0] * r * g1.x + b1.x, dw[1] * r * g1.y + b1.y, dw[2] * r * g1.z + b1.z, dw[3] * r * g1.w + b1.w);
+      }
+    }
+    // ---- next level's input: Conv1d(32 -> 64, k = 3, stride 2, pad 1, no bias) + LayerNorm(64).  Output row (a, t') reads steps
+    // 2 t' - 1 .. 2 t' + 1 of its agent: rows change lanes, so the tile goes through a per-wave bf16 staging buffer (natural channel order)
+    {
+#pragma unroll
+      for (int mt = 0; mt < 5; ++mt) {
+        const int row = a * L + mt * 4 + s;
+        *reinterpret_cast<uint2*>(st + row * L0W_ST + l4 * 4) = pack_bf16x4(x[mt][0][0], x[mt][0][1], x[mt][0][2], x[mt][0][3]);
+        *reinterpret_cast<uint2*>(st + row * L0W_ST + 16 + l4 * 4) = pack_bf16x4(x[mt][1][0], x[mt][1][1], x[mt][1][2], x[mt][1][3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS hand-off: DS operations of a wave execute in order
+      f32x4 d[3][4];
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) d[mt][nt] = Z;
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        bf16x8 wd[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wd[nt] = W(L0W_F_DS + 4 * tap + nt);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+          const int m = mt * 16 + l15, oa = m / 10, t = 2 * (m - oa * 10) - 1 + tap;
+          bf16x8 bop = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          if (m < 40 && t >= 0 && t < L) bop = *reinterpret_cast<const bf16x8*>(st + (oa * L + t) * L0W_ST + l4 * 8);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) d[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[nt], bop, d[mt][nt], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staging tile is rewritten by this wave's next tile
+      L0TS();
+      const float* g = par + L0W_P_DS;
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        float sm = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) sm += (d[mt][nt][0] + d[mt][nt][1]) + (d[mt][nt][2] + d[mt][nt][3]);
+        const float mean = rows_sum(sm) * (1.0f / 64.0f);
+        float qs = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          d[mt][nt] = d[mt][nt] - mean;
+          qs += (d[mt][nt][0] * d[mt][nt][0] + d[mt][nt][1] * d[mt][nt][1]) + (d[mt][nt][2] * d[mt][nt][2] + d[mt][nt][3] * d[mt][nt][3]);
+        }
+        const float r = rsqrtf(rows_sum(qs) * (1.0f / 64.0f) + 1e-5f);
+        const int m = mt * 16 + l15, oa = m / 10;
+        if (m < 40 && tile * 4 + oa < p.nseq) {
+          float* dst = p.Xnext + ((size_t)tile * 40 + m) * 64;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 64 + nt * 16 + l4 * 4);
+            *reinterpret_cast<float4*>(dst + nt * 16 + l4 * 4) =
+                make_float4(d[mt][nt][0] * r * gg.x + bb.x, d[mt][nt][1] * r * gg.y + bb.y, d[mt][nt][2] * r * gg.z + bb.z, d[mt][nt][3] * r * gg.w + bb.w);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace rift
