@@ -19,6 +19,7 @@
 #include "loss.h"
 #include "nat_fused.h"
 #include "nat_l0w.h"
+#include "nat_l1w.h"
 #include "enc_fused.h"
 #include "dec_fused.h"
 #include "pe_fused.h"
@@ -86,7 +87,8 @@ struct RiftCtx {
   unsigned short* nat_wqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // head-major bf16 qkv weights
   float* nat_bqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool nat_fused = true; int nat_dbg = 0; int gemm_dbg = 0;
-  bool nat_l0w = true; unsigned short* l0w_img = nullptr; float* l0w_par = nullptr;   // wave-private level-0 NAT kernel (nat_l0w.h)
+  bool nat_l0w = true; unsigned short* l0w_img = nullptr; float* l0w_par = nullptr;
+  bool nat_l1w = true; unsigned short* l1w_img = nullptr; float* l1w_par = nullptr;   // wave-private level-1 NAT kernel (nat_l1w.h)   // wave-private level-0 NAT kernel (nat_l0w.h)
   unsigned short* enc_wqkv[4] = {nullptr, nullptr, nullptr, nullptr};   // chunked (q|k|q|k|v|v) bf16 in_proj images
   float* enc_bqkv[4] = {nullptr, nullptr, nullptr, nullptr};
   int* enc_idx = nullptr; bool enc_fused = true;
@@ -400,6 +402,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR_N(heads3_fused_kernel, HD_LDS);
   SETATTR_N(pi_forward_kernel, PI_LDS);
   SETATTR_N(nat_l0w_kernel, L0W_LDS);
+  SETATTR_N(nat_l1w_kernel, L1W_LDS);
 #undef SETATTR_N
   return RIFT_OK;
 }
@@ -750,6 +753,14 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         q.droppath[0] = f.drop ? dpr[0] : 0.f; q.droppath[1] = f.drop ? dpr[1] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + 2.0 * rows * 27 * 32 + (rows / 2) * 2.0 * 3 * C * 2 * C;
         launch(c, "nat_level_kernel_L0", nat_l0w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid)), dim3(64 * L0W_NWV), (size_t)L0W_LDS, q);
+        continue;
+      }
+      if (lv == 1 && c->nat_l1w) {   // level 1 likewise (weights swapped through LDS between the two layers): nat_l1w.h
+        NatL1WP q; memset(&q, 0, sizeof(q));
+        q.X = Xin[1]; q.nseq = nA; q.img = c->l1w_img; q.par = c->l1w_par; q.Oc = Oc[1]; q.Xnext = Xin[2];
+        q.droppath[0] = f.drop ? dpr[2] : 0.f; q.droppath[1] = f.drop ? dpr[3] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
+        c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (rows / 2) * 2.0 * 3 * C * 2 * C;
+        launch(c, "nat_level_kernel_L1", nat_l1w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid)), dim3(512), (size_t)L1W_LDS, q);
         continue;
       }
       NatLevelP p; memset(&p, 0, sizeof(p));
@@ -1254,6 +1265,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("RIFT_NAT_L0W"); c->nat_l0w = !(ev && ev[0] == '0'); }
+  { const char* ev = getenv("RIFT_NAT_L1W"); c->nat_l1w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   if (hipMalloc((void**)&c->nonfinite, sizeof(int)) != hipSuccess || hipMemset(c->nonfinite, 0, sizeof(int)) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   int rc = set_lds_attrs(c);
@@ -1277,6 +1289,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->clip_part) (void)hipFree(c->clip_part);
   if (c->nonfinite) (void)hipFree(c->nonfinite);
   if (c->l0w_img) { (void)hipFree(c->l0w_img); (void)hipFree(c->l0w_par); }
+  if (c->l1w_img) { (void)hipFree(c->l1w_img); (void)hipFree(c->l1w_par); }
   if (c->dec_par) (void)hipFree(c->dec_par);
   for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
@@ -1337,6 +1350,22 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     if (!c->err.empty()) return RIFT_ERR_ARG;
     if (!c->l0w_img) { HIPCHK(c, hipMalloc((void**)&c->l0w_img, (size_t)L0W_NFRAG * 1024)); HIPCHK(c, hipMalloc((void**)&c->l0w_par, (size_t)L0W_NPAR * 4)); }
     hipLaunchKernelGGL(pack_l0w_kernel, dim3(cdiv(L0W_NFRAG * 512, 256)), dim3(256), 0, c->stream, q, c->l0w_img, c->l0w_par);
+  }
+  {  // wave-private level-1 kernel (nat_l1w.h)
+    NatL1WSrc q; memset(&q, 0, sizeof(q));
+    for (int b = 0; b < 2; ++b) {
+      const std::string p = HE + ".levels.1.blocks." + std::to_string(b);
+      NatL1WSrc::Blk& k = q.blk[b];
+      k.ln1_g = fptr(c, p + ".norm1.weight"); k.ln1_b = fptr(c, p + ".norm1.bias"); k.wqkv = fptr(c, p + ".attn.qkv.weight"); k.bqkv = fptr(c, p + ".attn.qkv.bias");
+      k.rpb = fptr(c, p + ".attn.rpb"); k.wproj = fptr(c, p + ".attn.proj.weight"); k.bproj = fptr(c, p + ".attn.proj.bias");
+      k.ln2_g = fptr(c, p + ".norm2.weight"); k.ln2_b = fptr(c, p + ".norm2.bias"); k.w1 = fptr(c, p + ".mlp.fc1.weight"); k.b1 = fptr(c, p + ".mlp.fc1.bias");
+      k.w2 = fptr(c, p + ".mlp.fc2.weight"); k.b2 = fptr(c, p + ".mlp.fc2.bias");
+    }
+    q.fn_g = fptr(c, HE + ".norm1.weight"); q.fn_b = fptr(c, HE + ".norm1.bias");
+    q.w_ds = fptr(c, HE + ".levels.1.downsample.reduction.weight"); q.ds_g = fptr(c, HE + ".levels.1.downsample.norm.weight"); q.ds_b = fptr(c, HE + ".levels.1.downsample.norm.bias");
+    if (!c->err.empty()) return RIFT_ERR_ARG;
+    if (!c->l1w_img) { HIPCHK(c, hipMalloc((void**)&c->l1w_img, (size_t)L1W_NFRAG * 1024)); HIPCHK(c, hipMalloc((void**)&c->l1w_par, (size_t)L1W_NPAR * 4)); }
+    hipLaunchKernelGGL(pack_l1w_kernel, dim3(cdiv(L1W_NFRAG * 512, 256)), dim3(256), 0, c->stream, q, c->l1w_img, c->l1w_par);
   }
   {  // fpn_conv at the last step: taps 0,1 only -> [128][256]
     const Param* w = find(c, HE + ".fpn_conv.weight");

@@ -1,0 +1,363 @@
+// Level 1 of the NAT-FPN history encoder (dim 64, 4 heads, kernel 3, L = 10; embedding.py:93-99,196-202) in the wave-private,
+// register-resident form of nat_l0w.h: one wave owns 4 agents x 10 steps (3 row tiles of 16: row (a, t) -> tile t / 4, lane row
+// 4 a + t % 4; the last two steps' quads are half empty) for both NATLayers, the residual stream is the MFMA C/D layout (48 VGPRs),
+// GEMM outputs chain as the next GEMM's operand through K-permuted weight images, neighbourhood attention reads its neighbours with
+// quad_perm DPP.  The level's weights (80 KiB per NATLayer + 48 KiB for the downsample conv) do not fit LDS together: the 8 waves of a
+// workgroup walk their tiles in step and swap the weight image between the layers (three swaps = six barriers per 32 agents, against
+// ~30 barriers per 8 agents in nat_level_kernel).
+#pragma once
+#include "common.h"
+#include "nat_l0w.h"
+
+namespace rift {
+
+#define L1W_BLK_FRAGS 80        // per NATLayer: qkv (nt 0..11) x 2 k-steps | proj 4 x 2 | fc1 12 x 2 | fc2 6 k-steps x 4 n-tiles
+#define L1W_F_QKV(nt, ks) ((nt) * 2 + (ks))
+#define L1W_F_PROJ(nt, ks) (24 + (nt) * 2 + (ks))
+#define L1W_F_FC1(nt, ks) (32 + (nt) * 2 + (ks))
+#define L1W_F_FC2(ks, nt) (56 + (ks) * 4 + (nt))
+#define L1W_DS_FRAGS 48         // downsample conv: (tap, k-step of 32 channels, n-tile 0..7)
+#define L1W_F_DS(tap, ks, nt) (((tap) * 2 + (ks)) * 8 + (nt))
+#define L1W_NFRAG (2 * L1W_BLK_FRAGS + L1W_DS_FRAGS)
+// parameters (fp32): per block 800: ln1_g 64, ln1_b 64, bqkv 192 (q pre-scaled), rpb 32 (4 x 5 used), bproj 64, ln2_g 64, ln2_b 64, b1 192, b2 64 |
+// fn_g 64, fn_b 64 | ds_g 128, ds_b 128
+#define L1W_P_BLK(b) (800 * (b))
+#define L1W_PB_LN1G 0
+#define L1W_PB_LN1B 64
+#define L1W_PB_BQKV 128
+#define L1W_PB_RPB 320
+#define L1W_PB_BP 352
+#define L1W_PB_LN2G 416
+#define L1W_PB_LN2B 480
+#define L1W_PB_B1 544
+#define L1W_PB_B2 736
+#define L1W_P_FN 1600
+#define L1W_P_DS 1728
+#define L1W_NPAR 2048
+#define L1W_ST 72               // staging row stride (bf16): 144 B
+#define L1W_LDS (L1W_BLK_FRAGS * 1024 + L1W_NPAR * 4 + 8 * 40 * L1W_ST * 2)
+
+struct NatL1WSrc {
+  struct Blk { const float *ln1_g, *ln1_b, *wqkv, *bqkv, *rpb, *wproj, *bproj, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2; } blk[2];
+  const float* fn_g; const float* fn_b;                                     // norm1
+  const float* w_ds; const float* ds_g; const float* ds_b;                  // levels.1.downsample.reduction (128, 64, 3), norm (128)
+};
+
+__global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, float* __restrict__ par) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < L1W_NFRAG * 512) {
+    const int f = e >> 9, lane = (e >> 3) & 63, j = e & 7, l15 = lane & 15, l4 = lane >> 4;
+    float v;
+    if (f < 2 * L1W_BLK_FRAGS) {
+      const int b = f / L1W_BLK_FRAGS, g = f % L1W_BLK_FRAGS;
+      const NatL1WSrc::Blk& k = s.blk[b];
+      if (g < 24) { const int nt = g >> 1, ks = g & 1; v = k.wqkv[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)] * (nt < 4 ? 0.25f : 1.0f); }
+      else if (g < 32) { const int nt = (g - 24) >> 1, ks = (g - 24) & 1; v = k.wproj[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)]; }
+      else if (g < 56) { const int nt = (g - 32) >> 1, ks = (g - 32) & 1; v = k.w1[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)]; }
+      else { const int ks = (g - 56) >> 2, nt = (g - 56) & 3; v = k.w2[(nt * 16 + l15) * 192 + l0w_chan(l4, j, 2 * ks)]; }
+    } else {
+      const int g = f - 2 * L1W_BLK_FRAGS, nt = g & 7, ks = (g >> 3) & 1, tap = g >> 4;
+      v = s.w_ds[((nt * 16 + l15) * 64 + ks * 32 + l4 * 8 + j) * 3 + tap];
+    }
+    img[e] = f2bf(v);
+  }
+  if (e < L1W_NPAR) {
+    float v = 0.f;
+    if (e < 1600) {
+      const int b = e / 800, o = e % 800;
+      const NatL1WSrc::Blk& k = s.blk[b];
+      if (o < 64) v = k.ln1_g[o];
+      else if (o < 128) v = k.ln1_b[o - 64];
+      else if (o < 320) v = k.bqkv[o - 128] * (o - 128 < 64 ? 0.25f : 1.0f);
+      else if (o < 352) v = (o - 320 < 20) ? k.rpb[o - 320] : 0.f;
+      else if (o < 416) v = k.bproj[o - 352];
+      else if (o < 480) v = k.ln2_g[o - 416];
+      else if (o < 544) v = k.ln2_b[o - 480];
+      else if (o < 736) v = k.b1[o - 544];
+      else v = k.b2[o - 736];
+    } else if (e < L1W_P_DS) v = (e - L1W_P_FN < 64) ? s.fn_g[e - L1W_P_FN] : s.fn_b[e - L1W_P_FN - 64];
+    else if (e < L1W_P_DS + 256) v = (e - L1W_P_DS < 128) ? s.ds_g[e - L1W_P_DS] : s.ds_b[e - L1W_P_DS - 128];
+    par[e] = v;
+  }
+}
+
+struct NatL1WP {
+  const float* X; int nseq;                // (nseq * 10, 64) level input (level 0's downsample output)
+  const unsigned short* img; const float* par;
+  float* Oc;                               // (nseq * 3, 64)  LayerNorm(norm1) of steps 7..9
+  float* Xnext;                            // (nseq * 5, 128) downsample conv + LayerNorm
+  float droppath[2]; uint32_t seed, stream;
+};
+
+// LayerNorm over the 64 channels of every row (16 per lane, 4 lanes per row) -> bf16 operands of the two k-steps
+__device__ __forceinline__ void l1w_layer_norm(const f32x4 (&x)[3][4], bf16x8 (&xn)[3][2], const float* g, const float* b, int l4) {
+  float4 gg[4], bb[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) { gg[nt] = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4); bb[nt] = *reinterpret_cast<const float4*>(b + nt * 16 + l4 * 4); }
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) {
+    float sm = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) sm += (x[mt][nt][0] + x[mt][nt][1]) + (x[mt][nt][2] + x[mt][nt][3]);
+    const float mean = rows_sum(sm) * (1.0f / 64.0f);
+    f32x4 d[4];
+    float qs = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      d[nt] = x[mt][nt] - mean;
+      qs += (d[nt][0] * d[nt][0] + d[nt][1] * d[nt][1]) + (d[nt][2] * d[nt][2] + d[nt][3] * d[nt][3]);
+    }
+    const float r = rsqrtf(rows_sum(qs) * (1.0f / 64.0f) + 1e-5f);
+    f32x4 y[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      y[nt] = (f32x4){d[nt][0] * r * gg[nt].x + bb[nt].x, d[nt][1] * r * gg[nt].y + bb[nt].y, d[nt][2] * r * gg[nt].z + bb[nt].z, d[nt][3] * r * gg[nt].w + bb[nt].w};
+    xn[mt][0] = l0w_pack8(y[0], y[1]);
+    xn[mt][1] = l0w_pack8(y[2], y[3]);
+  }
+}
+
+__global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
+  constexpr int L = 10;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* wl = reinterpret_cast<unsigned short*>(smem_raw);            // [80][64][8] weight fragments of the current phase
+  float* par = reinterpret_cast<float*>(wl + L1W_BLK_FRAGS * 512);
+  unsigned short* stg = reinterpret_cast<unsigned short*>(par + L1W_NPAR);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  for (int i = tid; i < L1W_NPAR / 4; i += 512) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
+  unsigned short* st = stg + wave * 40 * L1W_ST;
+  auto W = [&](int f) { return *reinterpret_cast<const bf16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
+  auto load_weights = [&](int frag0, int nfrag) {       // workgroup-wide swap of the weight image (all waves are between phases)
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(p.img + (size_t)frag0 * 512);
+    for (int i = tid; i < nfrag * 64; i += 512) reinterpret_cast<uint4*>(wl)[i] = src[i];
+    __syncthreads();
+  };
+  const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
+  const int a = l15 >> 2, s = l15 & 3;
+  const int ntiles = (p.nseq + 3) >> 2;
+  const int ngroups = (ntiles + 7) >> 3;
+
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int tile = grp * 8 + wave;
+    const int seq = tile * 4 + a;
+    const bool seq_ok = seq < p.nseq;
+    f32x4 x[3][4];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      const int t = mt * 4 + s;
+      const bool ok = seq_ok && t < L;
+      const float* src = p.X + ((size_t)(ok ? seq : 0) * L + (ok ? t : 0)) * 64 + l4 * 4;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float4 v = *reinterpret_cast<const float4*>(src + nt * 16);
+        x[mt][nt] = ok ? (f32x4){v.x, v.y, v.z, v.w} : Z;
+      }
+    }
+#pragma unroll 1
+    for (int bi = 0; bi < 2; ++bi) {
+      load_weights(bi * L1W_BLK_FRAGS, L1W_BLK_FRAGS);
+      const float* pb = par + L1W_P_BLK(bi);
+      bf16x8 xn[3][2];
+      // ================= attention half =================
+      l1w_layer_norm(x, xn, pb + L1W_PB_LN1G, pb + L1W_PB_LN1B, l4);
+      float dps = 1.f;
+      if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+#pragma unroll 1
+      for (int h = 0; h < 4; ++h) {
+        f32x4 k[3], v[3];
+        {
+          const bf16x8 wk0 = W(L1W_F_QKV(4 + h, 0)), wk1 = W(L1W_F_QKV(4 + h, 1)), wv0 = W(L1W_F_QKV(8 + h, 0)), wv1 = W(L1W_F_QKV(8 + h, 1));
+          const float4 bk = *reinterpret_cast<const float4*>(pb + L1W_PB_BQKV + 64 + h * 16 + l4 * 4);
+          const float4 bv = *reinterpret_cast<const float4*>(pb + L1W_PB_BQKV + 128 + h * 16 + l4 * 4);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) {
+            k[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk0, xn[mt][0], Z, 0, 0, 0);
+            k[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk1, xn[mt][1], k[mt], 0, 0, 0) + (f32x4){bk.x, bk.y, bk.z, bk.w};
+            v[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv0, xn[mt][0], Z, 0, 0, 0);
+            v[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv1, xn[mt][1], v[mt], 0, 0, 0) + (f32x4){bv.x, bv.y, bv.z, bv.w};
+          }
+        }
+        const bf16x8 wq0 = W(L1W_F_QKV(h, 0)), wq1 = W(L1W_F_QKV(h, 1));
+        const float4 bq = *reinterpret_cast<const float4*>(pb + L1W_PB_BQKV + h * 16 + l4 * 4);
+        const int pks = h >> 1;                                    // proj k-step that holds this head's 16 channels (its lower / upper half)
+        bf16x8 wp[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wp[nt] = W(L1W_F_PROJ(nt, pks));
+        const float* rp = pb + L1W_PB_RPB + h * 5;
+        // neighbourhood attention, kernel 3: keys of step t are (t-1, t, t+1), (0, 1, 2) at t = 0, (7, 8, 9) at t = 9 = (tile 2, quad lane 1)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+          f32x4 qq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq0, xn[mt][0], Z, 0, 0, 0);
+          qq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq1, xn[mt][1], qq, 0, 0, 0) + (f32x4){bq.x, bq.y, bq.z, bq.w};
+          f32x4 km = l0w_dpp4<0x90>(k[mt]), kp = l0w_dpp4<0xF9>(k[mt]);
+          f32x4 vm = l0w_dpp4<0x90>(v[mt]), vp = l0w_dpp4<0xF9>(v[mt]);
+          if (mt > 0) { km = l0w_sel(s == 0, l0w_dpp4<0xFF>(k[mt - 1]), km); vm = l0w_sel(s == 0, l0w_dpp4<0xFF>(v[mt - 1]), vm); }
+          if (mt < 2) { kp = l0w_sel(s == 3, l0w_dpp4<0x00>(k[mt + 1]), kp); vp = l0w_sel(s == 3, l0w_dpp4<0x00>(v[mt + 1]), vp); }
+          f32x4 k0 = km, k1 = k[mt], k2 = kp, v0 = vm, v1 = v[mt], v2 = vp;
+          int shift = 0;
+          if (mt == 0) {        // t = 0: keys (own, +1, +2)
+            const f32x4 kpp = l0w_dpp4<0xFE>(k[0]), vpp = l0w_dpp4<0xFE>(v[0]);
+            const bool e = s == 0;
+            k0 = l0w_sel(e, k[0], km); k1 = l0w_sel(e, kp, k[0]); k2 = l0w_sel(e, kpp, kp);
+            v0 = l0w_sel(e, v[0], vm); v1 = l0w_sel(e, vp, v[0]); v2 = l0w_sel(e, vpp, vp);
+            shift = e ? 1 : 0;
+          }
+          if (mt == 2) {        // t = 9 (quad lane 1): keys (7, 8, 9) = (previous tile's lane 3, this quad's lane 0, own)
+            const f32x4 k7 = l0w_dpp4<0xFF>(k[1]), v7 = l0w_dpp4<0xFF>(v[1]);
+            const bool e = s == 1;
+            k0 = l0w_sel(e, k7, km); k1 = l0w_sel(e, km, k[2]); k2 = l0w_sel(e, k[2], kp);
+            v0 = l0w_sel(e, v7, vm); v1 = l0w_sel(e, vm, v[2]); v2 = l0w_sel(e, v[2], vp);
+            shift = e ? -1 : 0;
+          }
+          float s0 = (qq[0] * k0[0] + qq[1] * k0[1]) + (qq[2] * k0[2] + qq[3] * k0[3]);
+          float s1 = (qq[0] * k1[0] + qq[1] * k1[1]) + (qq[2] * k1[2] + qq[3] * k1[3]);
+          float s2 = (qq[0] * k2[0] + qq[1] * k2[1]) + (qq[2] * k2[2] + qq[3] * k2[3]);
+          s0 = rows_sum(s0) + rp[1 + shift]; s1 = rows_sum(s1) + rp[2 + shift]; s2 = rows_sum(s2) + rp[3 + shift];
+          const float mx = fmaxf(fmaxf(s0, s1), s2);
+          const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx), e2 = __expf(s2 - mx);
+          const float inv = __builtin_amdgcn_rcpf((e0 + e1) + e2);
+          const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+          const f32x4 oh = {p0 * v0[0] + p1 * v1[0] + p2 * v2[0], p0 * v0[1] + p1 * v1[1] + p2 * v2[1],
+                            p0 * v0[2] + p1 * v1[2] + p2 * v2[2], p0 * v0[3] + p1 * v1[3] + p2 * v2[3]};
+          const bf16x8 ao = (h & 1) ? l0w_pack8(Z, oh) : l0w_pack8(oh, Z);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) x[mt][nt] += __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[nt], ao, Z, 0, 0, 0) * dps;
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(pb + L1W_PB_BP + nt * 16 + l4 * 4);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) x[mt][nt] += (f32x4){b4.x, b4.y, b4.z, b4.w} * dps;
+      }
+      // ================= MLP half: fc1 (64 -> 192) -> GELU -> fc2 (192 -> 64), 32 hidden channels (one fc2 k-step) at a time =================
+      l1w_layer_norm(x, xn, pb + L1W_PB_LN2G, pb + L1W_PB_LN2B, l4);
+      {
+        f32x4 acc2[3][4];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = Z;
+#pragma unroll 1
+        for (int ks = 0; ks < 6; ++ks) {
+          const bf16x8 wa0 = W(L1W_F_FC1(2 * ks, 0)), wa1 = W(L1W_F_FC1(2 * ks, 1)), wb0 = W(L1W_F_FC1(2 * ks + 1, 0)), wb1 = W(L1W_F_FC1(2 * ks + 1, 1));
+          bf16x8 u[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) u[nt] = W(L1W_F_FC2(ks, nt));
+          const float4 ba = *reinterpret_cast<const float4*>(pb + L1W_PB_B1 + (2 * ks) * 16 + l4 * 4);
+          const float4 bb = *reinterpret_cast<const float4*>(pb + L1W_PB_B1 + (2 * ks + 1) * 16 + l4 * 4);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) {
+            f32x4 ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa0, xn[mt][0], Z, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1, xn[mt][1], ha, 0, 0, 0);
+            f32x4 hb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0, xn[mt][0], Z, 0, 0, 0);
+            hb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1, xn[mt][1], hb, 0, 0, 0);
+            const bf16x8 hop = l0w_from_u2(gelu4_pack(ha, ba), gelu4_pack(hb, bb));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[nt], hop, acc2[mt][nt], 0, 0, 0);
+          }
+        }
+        float dp2 = 1.f;
+        if (p.droppath[bi] > 0.f) dp2 = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float4 b4 = *reinterpret_cast<const float4*>(pb + L1W_PB_B2 + nt * 16 + l4 * 4);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) x[mt][nt] += (acc2[mt][nt] + (f32x4){b4.x, b4.y, b4.z, b4.w}) * dp2;
+        }
+      }
+    }
+    // ---- what the FPN reads: LayerNorm(norm1) of steps 7 (tile 1, lane 3), 8, 9 (tile 2, lanes 0, 1)
+    {
+      const float* g = par + L1W_P_FN;
+#pragma unroll
+      for (int mt = 1; mt < 3; ++mt) {
+        float sm = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) sm += (x[mt][nt][0] + x[mt][nt][1]) + (x[mt][nt][2] + x[mt][nt][3]);
+        const float mean = rows_sum(sm) * (1.0f / 64.0f);
+        f32x4 d[4];
+        float qs = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          d[nt] = x[mt][nt] - mean;
+          qs += (d[nt][0] * d[nt][0] + d[nt][1] * d[nt][1]) + (d[nt][2] * d[nt][2] + d[nt][3] * d[nt][3]);
+        }
+        const float r = rsqrtf(rows_sum(qs) * (1.0f / 64.0f) + 1e-5f);
+        const int t = mt * 4 + s;
+        if (seq_ok && t >= 7 && t < L) {
+          float* dst = p.Oc + ((size_t)seq * 3 + (t - 7)) * 64;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 64 + nt * 16 + l4 * 4);
+            *reinterpret_cast<float4*>(dst + nt * 16 + l4 * 4) =
+                make_float4(d[nt][0] * r * gg.x + bb.x, d[nt][1] * r * gg.y + bb.y, d[nt][2] * r * gg.z + bb.z, d[nt][3] * r * gg.w + bb.w);
+          }
+        }
+      }
+    }
+    // ---- next level's input: Conv1d(64 -> 128, k = 3, stride 2, pad 1, no bias) + LayerNorm(128) through the per-wave staging tile
+    load_weights(2 * L1W_BLK_FRAGS, L1W_DS_FRAGS);
+    {
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        const int t = mt * 4 + s;
+        if (t < L) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            *reinterpret_cast<uint2*>(st + (a * L + t) * L1W_ST + nt * 16 + l4 * 4) = pack_bf16x4(x[mt][nt][0], x[mt][nt][1], x[mt][nt][2], x[mt][nt][3]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      f32x4 d[2][8];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) d[mt][nt] = Z;
+#pragma unroll 1
+      for (int tk = 0; tk < 6; ++tk) {                       // (tap, k-step)
+        const int tap = tk >> 1, ks = tk & 1;
+        bf16x8 wd[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) wd[nt] = W(tk * 8 + nt);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int m = mt * 16 + l15, oa = m / 5, t = 2 * (m - oa * 5) - 1 + tap;
+          bf16x8 bop = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          if (m < 20 && t >= 0 && t < L) bop = *reinterpret_cast<const bf16x8*>(st + (oa * L + t) * L1W_ST + ks * 32 + l4 * 8);
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) d[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[nt], bop, d[mt][nt], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const float* g = par + L1W_P_DS;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float sm = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) sm += (d[mt][nt][0] + d[mt][nt][1]) + (d[mt][nt][2] + d[mt][nt][3]);
+        const float mean = rows_sum(sm) * (1.0f / 128.0f);
+        float qs = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+          d[mt][nt] = d[mt][nt] - mean;
+          qs += (d[mt][nt][0] * d[mt][nt][0] + d[mt][nt][1] * d[mt][nt][1]) + (d[mt][nt][2] * d[mt][nt][2] + d[mt][nt][3] * d[mt][nt][3]);
+        }
+        const float r = rsqrtf(rows_sum(qs) * (1.0f / 128.0f) + 1e-5f);
+        const int m = mt * 16 + l15, oa = m / 5;
+        if (m < 20 && tile * 4 + oa < p.nseq) {
+          float* dst = p.Xnext + ((size_t)tile * 20 + m) * 128;
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 128 + nt * 16 + l4 * 4);
+            *reinterpret_cast<float4*>(dst + nt * 16 + l4 * 4) =
+                make_float4(d[mt][nt][0] * r * gg.x + bb.x, d[mt][nt][1] * r * gg.y + bb.y, d[mt][nt][2] * r * gg.z + bb.z, d[mt][nt][3] * r * gg.w + bb.w);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace rift
