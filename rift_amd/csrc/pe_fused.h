@@ -80,7 +80,8 @@ __device__ __forceinline__ void p_zero(f32x4 (&acc)[MT][NTW]) {
 #define PE_USED 120
 #define PE_XS 40
 #define PE_HS 136
-#define PE_FS 264
+#define PE_FS 264     // pass B's f / g tile: written twice per element by row-strided epilogues -> the +8 padding (tools/lds_conflicts.py)
+#define PE_GS 272     // pass C's normalised-g tile: read as MFMA operand only -> conflict-free +16 padding
 
 // stage the tile's point features as bf16 [128][PE_XS] (k >= Cin and unused rows zero) and the row flags
 // (0 = not a row of this tile, 1 = valid point, 2 = invalid point: an all-zero row that still takes part in the max)
@@ -350,18 +351,18 @@ __global__ __launch_bounds__(512) void pe_mid_kernel(PeP2 q) {
 // ---------------------------------------------------------------------------------------------------------------
 // pass C
 // ---------------------------------------------------------------------------------------------------------------
-#define PE_OUT_LDS (PE_ROWS * PE_FS * 2 + 4 * 128 * 4 + 640 * 4 + PE_ROWS)
+#define PE_OUT_LDS (PE_ROWS * PE_GS * 2 + 4 * 128 * 4 + 640 * 4 + PE_ROWS)
 
 template <int NPTS>
 __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
   constexpr int MT = 8, GPT = PE_USED / NPTS, NW = 8, OS = 132;
   constexpr int SPL = GPT >= 4 ? 1 : 4;
   constexpr int UNITS = GPT * SPL, RPU = NPTS / SPL;
-  static_assert(PE_ROWS * OS * 4 <= PE_ROWS * PE_FS * 2, "o tile must fit the activation tile");
+  static_assert(PE_ROWS * OS * 4 <= PE_ROWS * PE_GS * 2, "o tile must fit the activation tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* fl = reinterpret_cast<unsigned short*>(smem_raw);      // relu(bn2(g)) as bf16, then o (fp32) over the same bytes
   float* ol = reinterpret_cast<float*>(smem_raw);
-  float* pm = reinterpret_cast<float*>(fl + PE_ROWS * PE_FS);            // [4][128] max-pool partials
+  float* pm = reinterpret_cast<float*>(fl + PE_ROWS * PE_GS);            // [4][128] max-pool partials
   float* par = pm + 4 * 128;                                             // s2 256 | t2 256 | b4 128
   unsigned char* sval = reinterpret_cast<unsigned char*>(par + 640);
   constexpr int P_S2 = 0, P_T2 = 256, P_B4 = 512;
@@ -414,7 +415,7 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
       o.y = pack_bf16x2(fmaxf(x[2] * s0.z + t0.z, 0.f), fmaxf(x[3] * s0.w + t0.w, 0.f));
       o.z = pack_bf16x2(fmaxf(x[4] * s1.x + t1.x, 0.f), fmaxf(x[5] * s1.y + t1.y, 0.f));
       o.w = pack_bf16x2(fmaxf(x[6] * s1.z + t1.z, 0.f), fmaxf(x[7] * s1.w + t1.w, 0.f));
-      *reinterpret_cast<uint4*>(fl + r * PE_FS + c8) = o;     // (rows that do not exist carry relu(t2): masked below)
+      *reinterpret_cast<uint4*>(fl + r * PE_GS + c8) = o;     // (rows that do not exist carry relu(t2): masked below)
     }
   }
   __syncthreads();
@@ -423,8 +424,8 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
   {
     f32x4 acc[MT][1];
     p_zero(acc);
-    p_mma<MT, 4, 1>(acc, fl, PE_FS, 0, Wc, l15, l4);
-    p_mma<MT, 4, 1>(acc, fl, PE_FS, 128, Wd, l15, l4);
+    p_mma<MT, 4, 1>(acc, fl, PE_GS, 0, Wc, l15, l4);
+    p_mma<MT, 4, 1>(acc, fl, PE_GS, 128, Wd, l15, l4);
     __syncthreads();
     const int col = wave * 16 + l4 * 4;
     const float4 b = *reinterpret_cast<const float4*>(par + P_B4 + col);
