@@ -28,11 +28,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # -amdgpu-spill-sgpr-to-vgpr=0: the decoder kernel sits at the 256-VGPR limit; with SGPR spills parked in VGPR lanes (the
     # default) AND VGPR spills in the same kernel, ROCm 7.2's backend produced wrong results whenever the SGPR spill count
     # rose (reproduced three times; identical source is correct with SGPR spills sent to scratch).  Cost: < 2 % on that kernel.
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0",
-           os.path.join(CSRC, "engine.hip"), "-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    # dec_w.hip (the wave-private decoder kernel) is its own translation unit WITHOUT that flag: its LDS-DMA weight stream must not meet the
+    # `s_waitcnt vmcnt(0)` of a scratch reload at every group boundary, and it has no VGPR spills for the SGPR lanes to collide with.
+    common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    obj = os.path.join(HERE, "_obj")
+    os.makedirs(obj, exist_ok=True)
+    steps = [common + ["-c", "-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0", os.path.join(CSRC, "engine.hip"), "-o", os.path.join(obj, "engine.o")],
+             common + ["-c", os.path.join(CSRC, "dec_w.hip"), "-o", os.path.join(obj, "dec_w.o")],
+             common + ["-shared", os.path.join(obj, "engine.o"), os.path.join(obj, "dec_w.o"), "-o", LIB]]
+    for cmd in steps:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

@@ -1,0 +1,642 @@
+// Wave-private planning decoder kernel (see dec_w.h) as its own translation unit: engine.hip is compiled with SGPR spills sent to scratch
+// (a ROCm 7.2 backend workaround for dec_fused_kernel, rift_amd/build.py); here that would put a scratch reload -- and its
+// `s_waitcnt vmcnt(0)`, which drains the LDS-DMA prefetch -- on most group boundaries, so this file is compiled with the default
+// (SGPR spills in VGPR lanes).
+#include "common.h"
+#include "dec_w.h"
+
+namespace rift {
+
+// Weight image: [layer][group][fragment f = ks * 8 + nt][lane][8]: element = W[out = nt*16 + lane&15][in = chan(ks, lane>>4, j)] with the
+// K permutation of nat_l0w.h (an n-tile PAIR of one GEMM's C/D output is the next GEMM's k-step).  Softmax scales are folded into q.
+__global__ void pack_decw_kernel(DecWSrc s, unsigned short* __restrict__ img, float* __restrict__ par) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const float SC = 0.17677669529663687f * 1.4426950408889634f;   // head_dim^-0.5 (head_dim = 32) x log2 e: the softmaxes run on v_exp_f32 = 2^x
+  if (e < 4 * DECW_LAYER_FRAGS * 512) {
+    const int j = e & 7, lane = (e >> 3) & 63, fr = e >> 9, li = fr / DECW_LAYER_FRAGS, g = (fr % DECW_LAYER_FRAGS) >> 5, f = fr & 31;
+    const int ks = f >> 3, nt = f & 7, l15 = lane & 15, l4 = lane >> 4;
+    const int ch = l0w_chan(l4, j, 2 * ks), o = nt * 16 + l15;
+    const DecWSrc::L& L = s.l[li];
+    float v;
+    if (g < 3) v = L.r2r_w[(g * 128 + o) * 128 + ch] * (g == 0 ? SC : 1.0f);
+    else if (g == 3) v = L.r2ro_w[o * 128 + ch];
+    else if (g < 7) v = L.m2m_w[((g - 4) * 128 + o) * 128 + ch] * (g == 4 ? SC : 1.0f);
+    else if (g == 7) v = L.m2mo_w[o * 128 + ch];
+    else if (g == 8) v = L.c_w[o * 128 + ch] * SC;
+    else if (g == 9) v = L.co_w[o * 128 + ch];
+    else {
+      const int hc = (g - 10) >> 1;
+      v = ((g - 10) & 1) ? L.f2_w[o * 512 + hc * 128 + ch] : L.f1_w[(hc * 128 + o) * 128 + ch];
+    }
+    img[e] = f2bf(v);
+  }
+  if (e < 4 * DECW_PAR_LAYER) {
+    const int li = e / DECW_PAR_LAYER, o = e % DECW_PAR_LAYER;
+    const DecWSrc::L& L = s.l[li];
+    float v = 0.f;
+    if (o < DECW_E_N) {
+      if (o < 256) v = L.ln[o >> 7][o & 127];
+      else if (o < 640) v = L.r2r_b[o - 256] * (o - 256 < 128 ? SC : 1.0f);
+      else if (o < 768) v = L.r2ro_b[o - 640];
+      else if (o < 1024) v = L.ln[2 + ((o - 768) >> 7)][o & 127];
+      else if (o < DECW_E_BM2MV) {
+        const int m = (o - 1024) / DECW_PBS, c = (o - 1024) % DECW_PBS;
+        if (c < 256) {
+          float acc = 0.f;
+          for (int k = 0; k < 128; ++k) acc += s.m_pos[m * 128 + k] * L.m2m_w[c * 128 + k];
+          v = (acc + L.m2m_b[c]) * (c < 128 ? SC : 1.0f);
+        }
+      } else if (o < DECW_E_BM2MO) v = L.m2m_b[256 + o - DECW_E_BM2MV];
+      else if (o < DECW_E_BM2MO + 128) v = L.m2mo_b[o - DECW_E_BM2MO];
+    } else {
+      const int q = o - DECW_E_N;
+      if (q < 256) v = L.ln[4 + (q >> 7)][q & 127];
+      else if (q < 384) v = L.c_b[q - 256] * SC;
+      else if (q < 512) v = L.co_b[q - 384];
+      else if (q < 768) v = L.ln[6 + ((q - 512) >> 7)][q & 127];
+      else if (q < 1280) v = L.f1_b[q - 768];
+      else if (q < 1408) v = L.f2_b[q - 1280];
+    }
+    par[e] = v;
+  }
+}
+
+// Dropout decisions of this kernel: a per-lane xorshift32 stream (6 full-rate integer instructions per 32 random bits = two 16-bit
+// uniforms), seeded once per lane from the counter hash.  The counter hash of common.h costs three quarter-rate 32-bit multiplies per two
+// elements; at 384 dropout elements per lane and layer it was more than half of this kernel's VALU time.  Same Bernoulli(p) decisions at
+// 2^-16 resolution and the same 1/(1-p) scaling; the mask is a deterministic function of (seed, stream, scene, lane, draw order).
+struct DecWRng { uint32_t x; };
+__device__ __forceinline__ uint32_t decw_rand(DecWRng& g) {
+  uint32_t x = g.x;
+  x ^= x << 13; x ^= x >> 17; x ^= x << 5;      // xorshift32 (Marsaglia 2003), full period 2^32 - 1
+  g.x = x;
+  return x;
+}
+// one 1 KiB fragment, global -> LDS, no staging registers: lane i's 16 bytes land at lds_dst + 16 i.  `src` and `lds_dst` are wave-uniform.
+__device__ __forceinline__ void decw_glds(const void* src, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+}
+
+// One group GEMM (16 rows x K = 128 against the 32 fragments at LDS address `addr` + 1024 f) as a hand-scheduled stream: the 8 fragments of
+// k-step ks + 1 are requested under the 8 MFMAs of k-step ks (lgkmcnt(8) = the fragment 8 requests back has landed), so an MFMA never waits a
+// full LDS round trip; hipcc's own schedule of the same loop kept 1-2 reads in flight.  PLAIN = activations as the A operand (V^T tiles).
+template <bool PLAIN>
+__device__ __forceinline__ void decw_gemm(uint32_t addr, const bf16x8 (&x)[4], f32x4 (&c)[8]) {
+  bf16x8 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;
+  if (PLAIN) {
+    asm volatile(
+        "ds_read_b128 %[w0], %[a] offset:0\n\t"
+        "ds_read_b128 %[w1], %[a] offset:1024\n\t"
+        "ds_read_b128 %[w2], %[a] offset:2048\n\t"
+        "ds_read_b128 %[w3], %[a] offset:3072\n\t"
+        "ds_read_b128 %[w4], %[a] offset:4096\n\t"
+        "ds_read_b128 %[w5], %[a] offset:5120\n\t"
+        "ds_read_b128 %[w6], %[a] offset:6144\n\t"
+        "ds_read_b128 %[w7], %[a] offset:7168\n\t"
+        "ds_read_b128 %[w8], %[a] offset:8192\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c0], %[x0], %[w0], %[c0]\n\t"
+        "ds_read_b128 %[w9], %[a] offset:9216\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c1], %[x0], %[w1], %[c1]\n\t"
+        "ds_read_b128 %[w10], %[a] offset:10240\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c2], %[x0], %[w2], %[c2]\n\t"
+        "ds_read_b128 %[w11], %[a] offset:11264\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c3], %[x0], %[w3], %[c3]\n\t"
+        "ds_read_b128 %[w12], %[a] offset:12288\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c4], %[x0], %[w4], %[c4]\n\t"
+        "ds_read_b128 %[w13], %[a] offset:13312\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c5], %[x0], %[w5], %[c5]\n\t"
+        "ds_read_b128 %[w14], %[a] offset:14336\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c6], %[x0], %[w6], %[c6]\n\t"
+        "ds_read_b128 %[w15], %[a] offset:15360\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c7], %[x0], %[w7], %[c7]\n\t"
+        "ds_read_b128 %[w0], %[a] offset:16384\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c0], %[x1], %[w8], %[c0]\n\t"
+        "ds_read_b128 %[w1], %[a] offset:17408\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c1], %[x1], %[w9], %[c1]\n\t"
+        "ds_read_b128 %[w2], %[a] offset:18432\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c2], %[x1], %[w10], %[c2]\n\t"
+        "ds_read_b128 %[w3], %[a] offset:19456\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c3], %[x1], %[w11], %[c3]\n\t"
+        "ds_read_b128 %[w4], %[a] offset:20480\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c4], %[x1], %[w12], %[c4]\n\t"
+        "ds_read_b128 %[w5], %[a] offset:21504\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c5], %[x1], %[w13], %[c5]\n\t"
+        "ds_read_b128 %[w6], %[a] offset:22528\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c6], %[x1], %[w14], %[c6]\n\t"
+        "ds_read_b128 %[w7], %[a] offset:23552\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c7], %[x1], %[w15], %[c7]\n\t"
+        "ds_read_b128 %[w8], %[a] offset:24576\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c0], %[x2], %[w0], %[c0]\n\t"
+        "ds_read_b128 %[w9], %[a] offset:25600\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c1], %[x2], %[w1], %[c1]\n\t"
+        "ds_read_b128 %[w10], %[a] offset:26624\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c2], %[x2], %[w2], %[c2]\n\t"
+        "ds_read_b128 %[w11], %[a] offset:27648\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c3], %[x2], %[w3], %[c3]\n\t"
+        "ds_read_b128 %[w12], %[a] offset:28672\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c4], %[x2], %[w4], %[c4]\n\t"
+        "ds_read_b128 %[w13], %[a] offset:29696\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c5], %[x2], %[w5], %[c5]\n\t"
+        "ds_read_b128 %[w14], %[a] offset:30720\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c6], %[x2], %[w6], %[c6]\n\t"
+        "ds_read_b128 %[w15], %[a] offset:31744\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c7], %[x2], %[w7], %[c7]\n\t"
+        "s_waitcnt lgkmcnt(7)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c0], %[x3], %[w8], %[c0]\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c1], %[x3], %[w9], %[c1]\n\t"
+        "s_waitcnt lgkmcnt(5)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c2], %[x3], %[w10], %[c2]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c3], %[x3], %[w11], %[c3]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c4], %[x3], %[w12], %[c4]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c5], %[x3], %[w13], %[c5]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c6], %[x3], %[w14], %[c6]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c7], %[x3], %[w15], %[c7]\n\t"
+        "s_nop 15\n\t"
+        : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [w5] "=&v"(w5), [w6] "=&v"(w6), [w7] "=&v"(w7), [w8] "=&v"(w8), [w9] "=&v"(w9), [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [w14] "=&v"(w14), [w15] "=&v"(w15)
+        : [a] "v"(addr), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3])
+        : "memory");
+  }
+  if (!PLAIN) {
+    asm volatile(
+        "ds_read_b128 %[w0], %[a] offset:0\n\t"
+        "ds_read_b128 %[w1], %[a] offset:1024\n\t"
+        "ds_read_b128 %[w2], %[a] offset:2048\n\t"
+        "ds_read_b128 %[w3], %[a] offset:3072\n\t"
+        "ds_read_b128 %[w4], %[a] offset:4096\n\t"
+        "ds_read_b128 %[w5], %[a] offset:5120\n\t"
+        "ds_read_b128 %[w6], %[a] offset:6144\n\t"
+        "ds_read_b128 %[w7], %[a] offset:7168\n\t"
+        "ds_read_b128 %[w8], %[a] offset:8192\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c0], %[w0], %[x0], %[c0]\n\t"
+        "ds_read_b128 %[w9], %[a] offset:9216\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c1], %[w1], %[x0], %[c1]\n\t"
+        "ds_read_b128 %[w10], %[a] offset:10240\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c2], %[w2], %[x0], %[c2]\n\t"
+        "ds_read_b128 %[w11], %[a] offset:11264\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c3], %[w3], %[x0], %[c3]\n\t"
+        "ds_read_b128 %[w12], %[a] offset:12288\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c4], %[w4], %[x0], %[c4]\n\t"
+        "ds_read_b128 %[w13], %[a] offset:13312\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c5], %[w5], %[x0], %[c5]\n\t"
+        "ds_read_b128 %[w14], %[a] offset:14336\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c6], %[w6], %[x0], %[c6]\n\t"
+        "ds_read_b128 %[w15], %[a] offset:15360\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c7], %[w7], %[x0], %[c7]\n\t"
+        "ds_read_b128 %[w0], %[a] offset:16384\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c0], %[w8], %[x1], %[c0]\n\t"
+        "ds_read_b128 %[w1], %[a] offset:17408\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c1], %[w9], %[x1], %[c1]\n\t"
+        "ds_read_b128 %[w2], %[a] offset:18432\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c2], %[w10], %[x1], %[c2]\n\t"
+        "ds_read_b128 %[w3], %[a] offset:19456\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c3], %[w11], %[x1], %[c3]\n\t"
+        "ds_read_b128 %[w4], %[a] offset:20480\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c4], %[w12], %[x1], %[c4]\n\t"
+        "ds_read_b128 %[w5], %[a] offset:21504\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c5], %[w13], %[x1], %[c5]\n\t"
+        "ds_read_b128 %[w6], %[a] offset:22528\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c6], %[w14], %[x1], %[c6]\n\t"
+        "ds_read_b128 %[w7], %[a] offset:23552\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c7], %[w15], %[x1], %[c7]\n\t"
+        "ds_read_b128 %[w8], %[a] offset:24576\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c0], %[w0], %[x2], %[c0]\n\t"
+        "ds_read_b128 %[w9], %[a] offset:25600\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c1], %[w1], %[x2], %[c1]\n\t"
+        "ds_read_b128 %[w10], %[a] offset:26624\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c2], %[w2], %[x2], %[c2]\n\t"
+        "ds_read_b128 %[w11], %[a] offset:27648\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c3], %[w3], %[x2], %[c3]\n\t"
+        "ds_read_b128 %[w12], %[a] offset:28672\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c4], %[w4], %[x2], %[c4]\n\t"
+        "ds_read_b128 %[w13], %[a] offset:29696\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c5], %[w5], %[x2], %[c5]\n\t"
+        "ds_read_b128 %[w14], %[a] offset:30720\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c6], %[w6], %[x2], %[c6]\n\t"
+        "ds_read_b128 %[w15], %[a] offset:31744\n\t"
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c7], %[w7], %[x2], %[c7]\n\t"
+        "s_waitcnt lgkmcnt(7)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c0], %[w8], %[x3], %[c0]\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c1], %[w9], %[x3], %[c1]\n\t"
+        "s_waitcnt lgkmcnt(5)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c2], %[w10], %[x3], %[c2]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c3], %[w11], %[x3], %[c3]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c4], %[w12], %[x3], %[c4]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c5], %[w13], %[x3], %[c5]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c6], %[w14], %[x3], %[c6]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[c7], %[w15], %[x3], %[c7]\n\t"
+        "s_nop 15\n\t"
+        : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [w5] "=&v"(w5), [w6] "=&v"(w6), [w7] "=&v"(w7), [w8] "=&v"(w8), [w9] "=&v"(w9), [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [w14] "=&v"(w14), [w15] "=&v"(w15)
+        : [a] "v"(addr), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3])
+        : "memory");
+  }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dec_w_kernel(DecWP p) {
+  constexpr int M = 12, XS = DECW_XS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* ring = smem_raw;
+  float* xs = reinterpret_cast<float*>(smem_raw + 2 * 32768);
+  float* parE = xs + 96 * XS;
+  float* parL = parE + DECW_E_N;
+  float* smaskf = parL + DECW_L_N;                                             // [96] encoder key mask as 0 / -inf
+  float* qmaskf = smaskf + 96;                                                 // [12][8] r2r quirk rows as 0 / -inf
+  unsigned char* rz = reinterpret_cast<unsigned char*>(qmaskf + 96);           // [8] padded reference lines of this scene
+  const int tid = threadIdx.x;
+  int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;            // re-derived through an opaque zero every layer (see the loop)
+  const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wv = wv0;
+  const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
+  const size_t qrow0 = (size_t)b * NQ;
+  const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
+  const uint32_t thr16 = drop_thr16(dp);
+  const uint32_t lds00 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw);
+  uint32_t lds0 = lds00;
+  uint32_t voff = (uint32_t)lane * 16u;
+  const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
+  DecWRng rng;
+  rng.x = hash32(p.seed, p.stream, (uint32_t)(b * 512 + tid)) | 1u;
+  int tsn = 0;
+#define DTS() do { if (p.ts && b == 0 && tid == 0 && tsn < 120) p.ts[tsn++] = clock64(); } while (0)
+
+  // fragments wv, wv + 8, ... of a contiguous source -> LDS byte offset dst
+  auto dma = [&](const void* src, uint32_t dst, int nfrag) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int f = wv + 8 * i;
+      if (p.dbg & 4) f = (f + b * 5) & 31;                      // experiment: per-workgroup rotation of the request order
+      const int nf = (p.dbg & 2) ? nfrag / 2 : nfrag;           // experiment: half the bytes per group (stream-only runs)
+      if (f < nf) decw_glds(reinterpret_cast<const unsigned char*>(src) + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
+    }
+  };
+  // group boundary: my share of the next group has landed; after the barrier everybody's has, and nobody reads the other slot any more
+  auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); DTS(); };
+  auto W = [&](int slot, int f) { return *reinterpret_cast<const bf16x8*>(ring + slot * 32768 + f * 1024 + lane * 16); };
+
+  const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.img);
+  const unsigned char* kvimg = reinterpret_cast<const unsigned char*>(p.KV) + (size_t)b * 4 * DECW_KV_FRAGS * 1024;
+  const uint32_t OFF_E = 2 * 32768 + 96 * XS * 4, OFF_L = OFF_E + DECW_E_N * 4;
+  // prologue: first group + both parameter regions of layer 0 in flight, then the queries and masks
+  dma(wimg, 0, 32);
+  {
+    const unsigned char* ps = reinterpret_cast<const unsigned char*>(p.par);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int f = wv + 8 * i; if (f < 18) decw_glds(ps + (size_t)f * 1024, voff, lds0 + OFF_E + (uint32_t)f * 1024u); }
+    if (wv < 6) decw_glds(ps + (size_t)DECW_E_N * 4 + (size_t)wv * 1024, voff, lds0 + OFF_L + (uint32_t)wv * 1024u);
+  }
+  for (int i = tid; i < 96 * 32; i += 512) {
+    const int r = i >> 5, c4 = (i & 31) * 4;
+    if (r < NQ) *reinterpret_cast<float4*>(xs + r * XS + c4) = *reinterpret_cast<const float4*>(p.Q + (qrow0 + r) * 128 + c4);
+  }
+  if (tid < 96) smaskf[tid] = ((tid >= N) || p.kpm[(size_t)b * N + tid]) ? -INFINITY : 0.f;
+  else if (tid < 192) {            // quirk: mode m of scene b uses the padding row of scene (b*12+m) % bs (planning_decoder.py:56-60)
+    const int i = tid - 96, m = i >> 3, r = i & 7;
+    qmaskf[i] = ((r >= R) || p.q_kpm[(size_t)(((p.q_off + b) * M + m) % p.q_bs) * R + r]) ? -INFINITY : 0.f;
+  } else if (tid < 200) rz[tid - 192] = (tid - 192 >= R) || p.r_kpm[(size_t)b * R + tid - 192];
+
+  bool actA, actB, a_ok, b_ok;
+  int a_sub, a_row, b_row;
+  // tiling A (mode pair wv): slot l15 = sub * 8 + r;  tiling B (reference line wv): slot l15 = mode
+  auto derive = [&](int zv, int zs) {
+    lane = (tid & 63) + zv; l15 = lane & 15; l4 = lane >> 4; voff = (uint32_t)lane * 16u;
+    wv = wv0 + zs; lds0 = lds00 + (uint32_t)zs;
+    actA = wv < 6 && !p.dbg; actB = wv < R && !p.dbg;
+    a_sub = l15 >> 3;
+    const int a_r = l15 & 7;
+    a_ok = a_r < R; b_ok = l15 < M;
+    a_row = a_ok ? a_r * M + 2 * wv + a_sub : 0; b_row = b_ok ? wv * M + l15 : 0;
+  };
+  derive(0, 0);
+
+  auto init8 = [&](f32x4 (&a)[8], const float* bias) {        // accumulators start from the bias row (4 channels per n-tile of this lane)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) { const float4 v = *reinterpret_cast<const float4*>(bias + nt * 16 + l4 * 4); a[nt] = (f32x4){v.x, v.y, v.z, v.w}; }
+  };
+  auto zero8 = [&](f32x4 (&a)[8]) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) a[nt] = Z;
+  };
+  auto read_xs = [&](f32x4 (&res)[8], int row, bool ok) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const float4 v = *reinterpret_cast<const float4*>(xs + row * XS + nt * 16 + l4 * 4);
+      res[nt] = ok ? (f32x4){v.x, v.y, v.z, v.w} : Z;
+    }
+  };
+  auto write_xs = [&](const f32x4 (&res)[8], int row, bool ok) {
+    if (ok) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<float4*>(xs + row * XS + nt * 16 + l4 * 4) = make_float4(res[nt][0], res[nt][1], res[nt][2], res[nt][3]);
+    }
+  };
+  // res -> xb (bf16 operands of the four k-steps); g: gamma 128 | beta 128 in LDS.  Two-pass statistics as torch; vector (packed fp32) math.
+  auto layer_norm = [&](const f32x4 (&res)[8], bf16x8 (&xb)[4], const float* g) {
+    f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
+    s4 += (res[4] + res[5]) + (res[6] + res[7]);
+    const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
+    f32x4 d[8];
+    f32x4 q4 = Z;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) { d[nt] = res[nt] - mean; q4 += d[nt] * d[nt]; }
+    const float r = rsqrtf(rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f32x4 y[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int nt = 2 * ks + u;
+        const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 128 + nt * 16 + l4 * 4);
+        y[u] = d[nt] * ((f32x4){gg.x, gg.y, gg.z, gg.w} * r) + (f32x4){bb.x, bb.y, bb.z, bb.w};
+      }
+      xb[ks] = l0w_pack8(y[0], y[1]);
+    }
+  };
+  // 16 rows x K=128 -> 128 output channels against the 32 fragments of a ring slot (swapped operands: lane = 4 channels of its row)
+  auto gemm = [&](int slot, const bf16x8 (&x)[4], f32x4 (&acc)[8]) {
+    decw_gemm<false>((uint32_t)(uintptr_t)ring + (uint32_t)slot * 32768u + voff, x, acc);
+  };
+  // q / k of the four heads as attention operands: n-tile pair (2h, 2h+1) -> one bf16 fragment (the bias came in through the accumulator)
+  auto to_heads = [&](const f32x4 (&acc)[8], bf16x8 (&out)[4]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) out[h] = l0w_pack8(acc[2 * h], acc[2 * h + 1]);
+  };
+  // V of the tile in the plain operand order (A = activations): lane = 4 consecutive KEYS (rows 4*l4..) of dim nt*16 + l15 = the V^T operand
+  auto gemm_v = [&](int slot, const bf16x8 (&xb)[4], bf16x8 (&vf)[8], const float* bias) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) { const float bv = bias[nt * 16 + l15]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
+    decw_gemm<true>((uint32_t)(uintptr_t)ring + (uint32_t)slot * 32768u + voff, xb, acc);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_bf16x4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]), make_uint2(0u, 0u));   // k slots 4..7 unused
+  };
+  // dropout multipliers of four consecutive draws: 1/(1-p) or 0
+  auto keep4 = [&]() -> f32x4 {
+    const uint32_t h0 = decw_rand(rng), h1 = decw_rand(rng);
+    return (f32x4){((h0 & 0xffffu) < thr16) ? 0.f : dpk, ((h0 >> 16) < thr16) ? 0.f : dpk, ((h1 & 0xffffu) < thr16) ? 0.f : dpk, ((h1 >> 16) < thr16) ? 0.f : dpk};
+  };
+  // 16 x 16 self-attention of the tile, per head, entirely in registers: S^T = K Q^T (lane: 4 keys of query l15), O^T = V^T P^T.
+  // `mask4`: 0 / -inf of this lane's four keys, entering as the accumulator of the score MFMA; scores are in log2 units (q carries log2 e).
+  auto self_attention = [&](const f32x4 mask4, const bf16x8 (&qf)[4], const bf16x8 (&kf)[4], const bf16x8 (&vf)[8], bf16x8 (&ao)[4]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[h], qf[h], mask4, 0, 0, 0);
+      const float m = rows_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+      f32x4 ev = {__builtin_amdgcn_exp2f(s[0] - m), __builtin_amdgcn_exp2f(s[1] - m), __builtin_amdgcn_exp2f(s[2] - m), __builtin_amdgcn_exp2f(s[3] - m)};
+      const float lsum = rows_sum((ev[0] + ev[1]) + (ev[2] + ev[3]));
+      if (dp > 0.f) ev *= keep4();
+      const bf16x8 pf = l0w_from_u2(pack_bf16x4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
+      const f32x4 o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2 * h], pf, Z, 0, 0, 0);
+      const f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2 * h + 1], pf, Z, 0, 0, 0);
+      const float inv = __builtin_amdgcn_rcpf(lsum);
+      ao[h] = l0w_pack8(o0 * inv, o1 * inv);
+    }
+  };
+  // x += dropout(acc)   (acc already holds the bias)
+  auto residual = [&](f32x4 (&res)[8], const f32x4 (&acc)[8]) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      if (dp > 0.f) res[nt] += acc[nt] * keep4();
+      else res[nt] += acc[nt];
+    }
+  };
+  // cross attention of heads 2c, 2c+1 against the K | V^T fragments in a ring slot (96 keys); the key-padding mask is the score accumulator
+  auto cross_half = [&](int slot, int c, const bf16x8 (&qf)[4], bf16x8 (&ao)[4]) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int h = 2 * c + hh;
+      f32x4 s[6];
+#pragma unroll
+      for (int kt = 0; kt < 6; ++kt) {
+        const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, kt * 2 + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+      }
+      float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+      for (int kt = 1; kt < 6; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+      m = rows_max(m);
+      f32x4 l4s = Z;
+#pragma unroll
+      for (int kt = 0; kt < 6; ++kt) {
+        s[kt] = (f32x4){__builtin_amdgcn_exp2f(s[kt][0] - m), __builtin_amdgcn_exp2f(s[kt][1] - m), __builtin_amdgcn_exp2f(s[kt][2] - m), __builtin_amdgcn_exp2f(s[kt][3] - m)};
+        l4s += s[kt];
+        if (dp > 0.f) s[kt] *= keep4();
+      }
+      const float lsum = rows_sum((l4s[0] + l4s[1]) + (l4s[2] + l4s[3]));
+      f32x4 o0 = Z, o1 = Z;
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt) {
+        const bf16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 12 + (hh * 2 + 0) * 3 + pt), pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 12 + (hh * 2 + 1) * 3 + pt), pf, o1, 0, 0, 0);
+      }
+      const float inv = __builtin_amdgcn_rcpf(lsum);
+      ao[h] = l0w_pack8(o0 * inv, o1 * inv);
+    }
+  };
+
+  // after the barrier that opens group k of layer li: request group k + 1 into the other ring slot, plus the parameter region that rides on
+  // this boundary.  Stream order: 0 r2r q | 1 r2r k | 2 r2r v | 3 r2r out | 4 m2m q | 5 m2m k | 6 m2m v | 7 m2m out | 8 cross q |
+  // 9 scene K|V^T heads {0,1} | 10 scene K|V^T heads {2,3} | 11 cross out | 12 + 2 hc ffn.0 chunk hc | 13 + 2 hc ffn.3 chunk hc
+  auto issue = [&](int li, int k) {
+    const unsigned char* wl = wimg + (size_t)li * DECW_LAYER_FRAGS * 1024;
+    const unsigned char* kvl = kvimg + (size_t)li * DECW_KV_FRAGS * 1024;
+    const int g = k + 1;
+    const uint32_t dst = (uint32_t)(g & 1) * 32768u;
+    if (g == 9) dma(kvl, dst, 24);
+    else if (g == 10) dma(kvl + 24 * 1024, dst, 24);
+    else if (g < 20) dma(wl + (size_t)(g < 9 ? g : g - 2) * 32768, dst, 32);
+    else if (li + 1 < 4) dma(wl + (size_t)DECW_LAYER_FRAGS * 1024, dst, 32);
+    if (k == 0 && li > 0 && wv < 6)      // region L of this layer: the previous layer's FFN epilogue is over for every wave
+      decw_glds(reinterpret_cast<const unsigned char*>(p.par + (size_t)li * DECW_PAR_LAYER + DECW_E_N) + (size_t)wv * 1024, voff, lds0 + OFF_L + (uint32_t)wv * 1024u);
+    if (k == 12 && li + 1 < 4) {         // region E of the next layer: r2r / m2m are over for every wave
+      const unsigned char* ps = reinterpret_cast<const unsigned char*>(p.par + (size_t)(li + 1) * DECW_PAR_LAYER);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const int f = wv + 8 * i; if (f < 18) decw_glds(ps + (size_t)f * 1024, voff, lds0 + OFF_E + (uint32_t)f * 1024u); }
+    }
+  };
+
+#pragma unroll 1
+  for (int li = 0; li < 4; ++li) {
+    {   // the lane / wave indices pass through opaque zeros once per layer: otherwise every LDS and DMA address of the 20 groups is
+        // hoisted out of this loop as a loop invariant and spilled around it
+      int zv, zs;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+      derive(zv, zs);
+    }
+
+    // Waves without a tile in a tiling run the same boundaries (barrier + their share of the stream) and nothing else; the working waves'
+    // code is straight-line between the boundaries of a tiling, so that register liveness follows the phases.
+    // ================= tiling A: r2r over the reference lines of a mode pair =================
+    if (actA) {
+      f32x4 res[8], acc[8];
+      bf16x8 xb[4], qf[4], kf[4], ao[4];
+      bf16x8 vf[8];
+      sync(); issue(li, 0);                                   // ---- group 0: r2r q
+      read_xs(res, a_row, a_ok);
+      layer_norm(res, xb, parE + DECW_E_LN1);
+      init8(acc, parE + DECW_E_BR2R); gemm(0, xb, acc);
+      to_heads(acc, qf);
+      sync(); issue(li, 1);                                   // ---- group 1: r2r k
+      init8(acc, parE + DECW_E_BR2R + 128); gemm(1, xb, acc);
+      to_heads(acc, kf);
+      sync(); issue(li, 2);                                   // ---- group 2: r2r v + attention
+      gemm_v(0, xb, vf, parE + DECW_E_BR2R + 256);
+      {   // keys 4 l4 .. + 3 = reference lines (l4 & 1) * 4 .. of mode 2 wv + (l4 >> 1): other-mode keys and the quirk's padded lines are masked
+        const float4 mk = *reinterpret_cast<const float4*>(qmaskf + (2 * wv + (l4 >> 1)) * 8 + (l4 & 1) * 4);
+        const bool cross = (l4 >> 1) != a_sub;
+        const float ninf = -INFINITY;
+        self_attention((f32x4){cross ? ninf : mk.x, cross ? ninf : mk.y, cross ? ninf : mk.z, cross ? ninf : mk.w}, qf, kf, vf, ao);
+      }
+      sync(); issue(li, 3);                                   // ---- group 3: r2r out_proj, residual, hand-over to the reference-line tiling
+      init8(acc, parE + DECW_E_BR2RO); gemm(1, ao, acc);
+      residual(res, acc);
+      write_xs(res, a_row, a_ok);
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) { sync(); issue(li, k); }
+    }
+    // ================= tiling B: m2m, cross attention, FFN of one reference line =================
+    if (actB) {
+      f32x4 res[8], acc[8];
+      bf16x8 xb[4], qf[4], kf[4], ao[4];
+      bf16x8 vf[8];
+      sync(); issue(li, 4);                                   // ---- group 4: m2m q (+ m_pos)
+      read_xs(res, b_row, b_ok);
+      layer_norm(res, xb, parE + DECW_E_LN2);
+      init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS); gemm(0, xb, acc);
+      to_heads(acc, qf);
+      sync(); issue(li, 5);                                   // ---- group 5: m2m k (+ m_pos)
+      init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS + 128); gemm(1, xb, acc);
+      to_heads(acc, kf);
+      sync(); issue(li, 6);                                   // ---- group 6: m2m v + attention over the modes
+      gemm_v(0, xb, vf, parE + DECW_E_BM2MV);
+      { const float mk = l4 == 3 ? -INFINITY : 0.f; self_attention((f32x4){mk, mk, mk, mk}, qf, kf, vf, ao); }   // keys 12..15 are padding slots
+      sync(); issue(li, 7);                                   // ---- group 7: m2m out_proj, residual, padded lines zeroed (:70-72), LayerNorm
+      init8(acc, parE + DECW_E_BM2MO); gemm(1, ao, acc);
+      residual(res, acc);
+      if (rz[wv]) zero8(res);
+      layer_norm(res, xb, parL + DECW_L_LN3);
+      sync(); issue(li, 8);                                   // ---- group 8: cross q
+      init8(acc, parL + DECW_L_BCQ); gemm(0, xb, acc);
+      to_heads(acc, qf);
+      sync(); issue(li, 9);                                   // ---- groups 9, 10: the scene's K | V^T, heads {0,1} then {2,3}
+      cross_half(1, 0, qf, ao);
+      sync(); issue(li, 10);
+      cross_half(0, 1, qf, ao);
+      sync(); issue(li, 11);                                  // ---- group 11: cross out_proj, residual, LayerNorm for the FFN
+      init8(acc, parL + DECW_L_BCO); gemm(1, ao, acc);
+      residual(res, acc);
+      layer_norm(res, xb, parL + DECW_L_LN4);
+      f32x4 acc2[8];
+      init8(acc2, parL + DECW_L_BF2);
+#pragma unroll
+      for (int hc = 0; hc < 4; ++hc) {                        // ---- groups 12..19: ffn.0 chunk -> ReLU, dropout -> ffn.3 partial
+        sync(); issue(li, 12 + 2 * hc);
+        init8(acc, parL + DECW_L_BF1 + hc * 128); gemm(0, xb, acc);
+        bf16x8 hb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          f32x4 v[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x4 a = acc[2 * ks + q];
+            v[q] = (f32x4){fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)};
+            if (dp > 0.f) v[q] *= keep4();
+          }
+          hb[ks] = l0w_pack8(v[0], v[1]);
+        }
+        sync(); issue(li, 13 + 2 * hc);
+        gemm(1, hb, acc2);
+      }
+      residual(res, acc2);
+      if (li + 1 < 4) write_xs(res, b_row, b_ok);
+      else if (b_ok) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+          *reinterpret_cast<float4*>(p.Q + (qrow0 + b_row) * 128 + nt * 16 + l4 * 4) = make_float4(res[nt][0], res[nt][1], res[nt][2], res[nt][3]);
+      }
+    } else {
+#pragma unroll 1
+      for (int k = 4; k < 20; ++k) { sync(); issue(li, k); }
+    }
+  }
+
+  DTS();
+#undef DTS
+}
+
+
+int decw_set_attributes() {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
+}
+void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t stream) {
+  const int n = 4 * DECW_LAYER_FRAGS * 512;
+  hipLaunchKernelGGL(pack_decw_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, img, par);
+}
+void decw_launch(const DecWP& p, hipStream_t stream) {
+  hipLaunchKernelGGL(dec_w_kernel, dim3(p.bs), dim3(512), (size_t)DECW_LDS_BYTES, stream, p);
+}
+
+}  // namespace rift

@@ -22,6 +22,7 @@
 #include "nat_l1w.h"
 #include "enc_fused.h"
 #include "dec_fused.h"
+#include "dec_w.h"
 #include "pe_fused.h"
 #include "fourier_fused.h"
 #include "critic.h"
@@ -98,6 +99,7 @@ struct RiftCtx {
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   float* dec_par = nullptr;              // [4][RIFT_DEC_NPAR] packed LayerNorm parameters / biases of the fused decoder kernel
   bool dec_fused = true;
+  bool dec_w = true; unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // wave-private decoder kernel (dec_w.h)
   double* clip_part = nullptr;
   struct Dp { bool on = false; int off = 0, gbs = 0; double* xchg = nullptr; long long len = 0; RiftExchangeFn fn = nullptr; void* user = nullptr; } dp;   // rift_set_dp
   int* nonfinite = nullptr;              // device flag set by the policy-head kernels when the decoder output is not finite
@@ -173,6 +175,27 @@ void launch(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 grid, di
     return;
   }
   hipLaunchKernelGGL(kern, grid, block, shmem, c->stream, static_cast<KArgs>(args)...);
+}
+
+// same bookkeeping for a kernel that lives in another translation unit (its launch is the callable)
+template <class F>
+void launch_call(RiftCtx* c, const char* label, F&& f) {
+  if (c->dry) return;
+  if (c->poison_lds >= 0) {
+    const unsigned int b = (unsigned int)c->poison_lds & 0xffu;
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, c->stream, b | (b << 8) | (b << 16) | (b << 24));
+  }
+  if (c->prof_on) {
+    hipEvent_t e0, e1;
+    prof_events(c, &e0, &e1);
+    (void)hipEventRecord(e0, c->stream);
+    f();
+    (void)hipEventRecord(e1, c->stream);
+    prof_push(c, label, e0, e1, c->prof_flops);
+    c->prof_flops = 0.0;
+    return;
+  }
+  f();
 }
 
 template <class... KArgs>
@@ -380,6 +403,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR(rollout_kernel);
   SETATTR(enc_fused_kernel<ENC_NW>);
   SETATTR(dec_fused_kernel<DEC_NW>);
+  HIPCHK(c, (hipError_t)decw_set_attributes());
   SETATTR((dec_fused_kernel<DEC_NW, 1>)); SETATTR((dec_fused_kernel<DEC_NW, 2>)); SETATTR((dec_fused_kernel<DEC_NW, 3>)); SETATTR((dec_fused_kernel<DEC_NW, 4>));
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
@@ -963,9 +987,11 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias");
     if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
-    if (c->dec_fused && R * 12 <= 80 && ENC_NW == 8) {   // the decoder kernel will run: emit its cross-attention K | V operands here
-      enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 96 * 128);
-      enc_VT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 128 * 96);
+    const bool decw = c->dec_w && R <= 8;
+    if (c->dec_fused && (decw || R * 12 <= 80) && ENC_NW == 8) {   // the decoder kernel will run: emit its cross-attention K | V operands here
+      enc_KT = A_alloc<unsigned short>(c, decw ? (size_t)bs * 4 * DECW_KV_FRAGS * 512 : (size_t)bs * 4 * 96 * 128);
+      enc_VT = decw ? nullptr : A_alloc<unsigned short>(c, (size_t)bs * 4 * 128 * 96);
+      ep.kv_frag = decw ? 1 : 0;
       ep.wkv = (const unsigned short*)c->pw["planning_decoder.kv_all"].bf; ep.bkv = c->pw["planning_decoder.kv_all"].bias;
       ep.KT = enc_KT; ep.VT = enc_VT;
       enc_x0p = A_alloc<float>(c, (size_t)bs * 128);
@@ -1051,7 +1077,16 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 
   dp_exchange(f, 0);                      // (eval forward under data parallelism: the mask slots have not travelled yet)
   const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
-  if (c->dec_fused && !f.fp32 && R * M <= 80 && N <= 96) {
+  if (c->dec_fused && c->dec_w && !f.fp32 && R <= 8 && N <= 96 && enc_KT) {
+    DecWP dq; memset(&dq, 0, sizeof(dq));
+    dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
+    dq.stream = f.next_stream(); f.stream_id += 64;
+    dq.KV = enc_KT; dq.img = c->decw_img; dq.par = c->decw_par;
+    if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
+    { const char* ev = getenv("RIFT_DEC_DBG"); dq.dbg = ev ? atoi(ev) : 0; }
+    c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
+    launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
+  } else if (c->dec_fused && !f.fp32 && R * M <= 80 && N <= 96 && !(c->dec_w && R <= 8 && enc_KT)) {
     DecFusedP dq; memset(&dq, 0, sizeof(dq));
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
     dq.stream = f.next_stream(); f.stream_id += 64;
@@ -1253,6 +1288,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   if (hipSetDevice(device) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   { const char* ev = getenv("RIFT_NAT_UNFUSED"); c->nat_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_DEC_UNFUSED"); c->dec_fused = !(ev && ev[0] == '1'); }
+  { const char* ev = getenv("RIFT_DEC_W"); c->dec_w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_UNFUSED"); c->pe_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_FPN_UNFUSED"); c->fpn_fused = !(ev && ev[0] == '1'); }
@@ -1291,6 +1327,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->l0w_img) { (void)hipFree(c->l0w_img); (void)hipFree(c->l0w_par); }
   if (c->l1w_img) { (void)hipFree(c->l1w_img); (void)hipFree(c->l1w_par); }
   if (c->dec_par) (void)hipFree(c->dec_par);
+  if (c->decw_img) { (void)hipFree(c->decw_img); (void)hipFree(c->decw_par); }
   for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
@@ -1472,6 +1509,25 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
       TRY(put(c->pw[p + ".ffn.0"].bias, 512)); TRY(put(c->pw[p + ".ffn.3"].bias, 128));
       if (dst != c->dec_par + (size_t)(i + 1) * RIFT_DEC_NPAR) return RIFT_ERR_STATE;
     }
+  }
+  {  // wave-private decoder kernel (dec_w.h): the layers' weight stream and parameter blocks
+    DecWSrc q; memset(&q, 0, sizeof(q));
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = PD + ".decoder_blocks." + std::to_string(i);
+      DecWSrc::L& k = q.l[i];
+      for (int n = 0; n < 4; ++n) { k.ln[2 * n] = fptr(c, p + ".norm" + std::to_string(n + 1) + ".weight"); k.ln[2 * n + 1] = fptr(c, p + ".norm" + std::to_string(n + 1) + ".bias"); }
+      k.r2r_w = fptr(c, p + ".r2r_attn.in_proj_weight"); k.r2r_b = fptr(c, p + ".r2r_attn.in_proj_bias");
+      k.r2ro_w = fptr(c, p + ".r2r_attn.out_proj.weight"); k.r2ro_b = fptr(c, p + ".r2r_attn.out_proj.bias");
+      k.m2m_w = fptr(c, p + ".m2m_attn.in_proj_weight"); k.m2m_b = fptr(c, p + ".m2m_attn.in_proj_bias");
+      k.m2mo_w = fptr(c, p + ".m2m_attn.out_proj.weight"); k.m2mo_b = fptr(c, p + ".m2m_attn.out_proj.bias");
+      k.c_w = fptr(c, p + ".cross_attn.in_proj_weight"); k.c_b = fptr(c, p + ".cross_attn.in_proj_bias");
+      k.co_w = fptr(c, p + ".cross_attn.out_proj.weight"); k.co_b = fptr(c, p + ".cross_attn.out_proj.bias");
+      k.f1_w = fptr(c, p + ".ffn.0.weight"); k.f1_b = fptr(c, p + ".ffn.0.bias"); k.f2_w = fptr(c, p + ".ffn.3.weight"); k.f2_b = fptr(c, p + ".ffn.3.bias");
+    }
+    q.m_pos = fptr(c, PD + ".m_pos");
+    if (!c->err.empty()) return RIFT_ERR_ARG;
+    if (!c->decw_img) { HIPCHK(c, hipMalloc((void**)&c->decw_img, (size_t)4 * DECW_LAYER_FRAGS * 1024)); HIPCHK(c, hipMalloc((void**)&c->decw_par, (size_t)4 * DECW_PAR_LAYER * 4)); }
+    decw_pack(q, c->decw_img, c->decw_par, c->stream);
   }
   TRY(pack_cols(c, PD + ".cat_x_proj.q", PD + ".cat_x_proj", 0, 128, true));
   TRY(pack_cols(c, PD + ".cat_x_proj.x", PD + ".cat_x_proj", 128, 128, false));

@@ -53,8 +53,6 @@ struct NatL0WSrc {    // raw fp32 parameters (views onto the state_dict) for pac
   const float* w_ds; const float* ds_g; const float* ds_b;                  // levels.0.downsample.reduction (64, 32, 3), norm (64)
 };
 
-// channel a lane's k-slot j (0..7) of chunk l4 stands for when the operand is a GEMM output kept in the C/D layout (two n-tiles)
-__host__ __device__ __forceinline__ int l0w_chan(int l4, int j, int nt_lo) { return (j < 4 ? nt_lo : nt_lo + 1) * 16 + l4 * 4 + (j & 3); }
 
 __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, float* __restrict__ par) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,19 +105,6 @@ struct NatL0WP {
   long long* ts;                           // optional section timestamps of wave 0 of workgroup 0 (diagnostic, RIFT_NAT_TS=1)
 };
 
-__device__ __forceinline__ bf16x8 l0w_pack8(const f32x4 a, const f32x4 b) {
-  bf16x8 r;
-  const unsigned int p0 = pack_bf16x2(a[0], a[1]), p1 = pack_bf16x2(a[2], a[3]), p2 = pack_bf16x2(b[0], b[1]), p3 = pack_bf16x2(b[2], b[3]);
-  r[0] = (short)(p0 & 0xffff); r[1] = (short)(p0 >> 16); r[2] = (short)(p1 & 0xffff); r[3] = (short)(p1 >> 16);
-  r[4] = (short)(p2 & 0xffff); r[5] = (short)(p2 >> 16); r[6] = (short)(p3 & 0xffff); r[7] = (short)(p3 >> 16);
-  return r;
-}
-__device__ __forceinline__ bf16x8 l0w_from_u2(const uint2 a, const uint2 b) {
-  bf16x8 r;
-  r[0] = (short)(a.x & 0xffff); r[1] = (short)(a.x >> 16); r[2] = (short)(a.y & 0xffff); r[3] = (short)(a.y >> 16);
-  r[4] = (short)(b.x & 0xffff); r[5] = (short)(b.x >> 16); r[6] = (short)(b.y & 0xffff); r[7] = (short)(b.y >> 16);
-  return r;
-}
 template <int CTRL>
 __device__ __forceinline__ f32x4 l0w_dpp4(const f32x4 v) {
   return (f32x4){dpp_f<CTRL>(v[0]), dpp_f<CTRL>(v[1]), dpp_f<CTRL>(v[2]), dpp_f<CTRL>(v[3])};
