@@ -8,10 +8,13 @@ namespace rift {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA 16x16x32 A/B operand)
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // MFMA 16x16 accumulator
 
-// two fp32 -> packed bf16x2 (round-to-nearest-even) in ONE instruction (gfx950 v_cvt_pk_bf16_f32; no builtin)
+// two fp32 -> packed bf16x2 (round-to-nearest-even) in ONE instruction (gfx950 v_cvt_pk_bf16_f32).  The `s_nop 0` is part of the contract:
+// an MFMA that reads a VALU-written VGPR as an operand needs TWO wait states behind the write (tools/ubench/cvt_mfma_hazard.hip on MI355X:
+// 0 or 1 states -> the MFMA reads the register's previous content in 95-100 % of the issues, 2 -> never), and behind an asm statement hipcc
+// pads only one.  Without the nop every "convert, then multiply" site was a latent stale-operand read.
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
   unsigned int r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
 __device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even fp32 -> bf16: the same instruction, one lane used

@@ -61,22 +61,29 @@ __global__ void pack_decw_kernel(DecWSrc s, unsigned short* __restrict__ img, fl
   }
 }
 
-// Dropout decisions of this kernel: a per-lane xorshift32 stream (6 full-rate integer instructions per 32 random bits = two 16-bit
+// Dropout decisions of this kernel: per-lane xorshift32 streams (6 full-rate integer instructions per 32 random bits = two 16-bit
 // uniforms), seeded once per lane from the counter hash.  The counter hash of common.h costs three quarter-rate 32-bit multiplies per two
 // elements; at 384 dropout elements per lane and layer it was more than half of this kernel's VALU time.  Same Bernoulli(p) decisions at
 // 2^-16 resolution and the same 1/(1-p) scaling; the mask is a deterministic function of (seed, stream, scene, lane, draw order).
-struct DecWRng { uint32_t x; };
-__device__ __forceinline__ uint32_t decw_rand(DecWRng& g) {
-  uint32_t x = g.x;
+// Four independent xorshift32 states per lane, used round-robin (one state's six operations are a serial chain).
+struct DecWRng { uint32_t x[4]; };
+__device__ __forceinline__ uint32_t decw_step(uint32_t x) {
   x ^= x << 13; x ^= x >> 17; x ^= x << 5;      // xorshift32 (Marsaglia 2003), full period 2^32 - 1
-  g.x = x;
   return x;
 }
 // one 1 KiB fragment, global -> LDS, no staging registers: lane i's 16 bytes land at lds_dst + 16 i.  `src` and `lds_dst` are wave-uniform.
 __device__ __forceinline__ void decw_glds(const void* src, uint32_t voff, uint32_t lds_dst) {
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+  // the scalar operands are pinned to SGPRs by hand: an "s" constraint on a value hipcc's divergence analysis does not prove uniform
+  // is NOT legalised with a readfirstlane, it reaches the assembler as a VGPR
+  const uint64_t a = reinterpret_cast<uint64_t>(src);
+  const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t sd = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);
+  // `s_nop 4` first: the SGPR operands may come straight out of v_readfirstlane, and a VALU-written SGPR needs five wait states before a
+  // VMEM instruction reads it as its base -- hipcc pads its own instructions, not the inside of an asm statement (seen: a build whose
+  // readfirstlane sat four instructions ahead of the load streamed garbage into half the scenes)
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sa), "s"(sd) : "memory");
 }
 
 // One group GEMM (16 rows x K = 128 against the 32 fragments at LDS address `addr` + 1024 f) as a hand-scheduled stream: the 8 fragments of
@@ -293,6 +300,9 @@ __device__ __forceinline__ void decw_gemm(uint32_t addr, const bf16x8 (&x)[4], f
   }
 }
 
+// DROP: train mode (dropout 0.1 at eight sites of every layer) -- a template parameter, so that the per-site tests are not sixteen uniform
+// branches per epilogue
+template <bool DROP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dec_w_kernel(DecWP p) {
   constexpr int M = 12, XS = DECW_XS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -308,6 +318,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6);
   int wv = wv0;
   const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
+  const bool six = N > 80;
   const size_t qrow0 = (size_t)b * NQ;
   const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
   const uint32_t thr16 = drop_thr16(dp);
@@ -316,19 +327,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   uint32_t voff = (uint32_t)lane * 16u;
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
   DecWRng rng;
-  rng.x = hash32(p.seed, p.stream, (uint32_t)(b * 512 + tid)) | 1u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rng.x[i] = hash32(p.seed, p.stream + i, (uint32_t)(b * 512 + tid)) | 1u;
   int tsn = 0;
 #define DTS() do { if (p.ts && b == 0 && tid == 0 && tsn < 120) p.ts[tsn++] = clock64(); } while (0)
 
-  // fragments wv, wv + 8, ... of a contiguous source -> LDS byte offset dst
+  // a contiguous source of nfrag fragments -> LDS byte offset dst.  Who loads: with R <= 6 waves 6 and 7 own no tile in either tiling, and
+  // waves 2 and 3 are alone on their SIMDs among the working waves (6 tiles on 4 SIMDs): those four carry the stream, the waves of the
+  // doubly loaded SIMDs 0 and 1 go from the barrier straight to their MFMAs.  Otherwise all eight waves share it.
+  const bool ld_few = R <= 6;
   auto dma = [&](const void* src, uint32_t dst, int nfrag) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int f = wv + 8 * i;
-      if (p.dbg & 4) f = (f + b * 5) & 31;                      // experiment: per-workgroup rotation of the request order
-      const int nf = (p.dbg & 2) ? nfrag / 2 : nfrag;           // experiment: half the bytes per group (stream-only runs)
-      if (f < nf) decw_glds(reinterpret_cast<const unsigned char*>(src) + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
-    }
+    if ((ld_few && !(wv & 2)) || (p.dbg & 8)) return;            // (dbg 8: no stream at all -- compute on whatever LDS holds, timing only)
+    const int lw = ld_few ? (wv & 1) + ((wv >> 2) << 1) : wv, ln = ld_few ? 4 : 8;
+#pragma unroll 1
+    for (int f = lw; f < nfrag; f += ln)       // (rolled: every boundary site carries this loop; unrolled it was 40 KB of a 105 KB kernel)
+      decw_glds(reinterpret_cast<const unsigned char*>(src) + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
   };
   // group boundary: my share of the next group has landed; after the barrier everybody's has, and nobody reads the other slot any more
   auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); DTS(); };
@@ -339,12 +352,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const uint32_t OFF_E = 2 * 32768 + 96 * XS * 4, OFF_L = OFF_E + DECW_E_N * 4;
   // prologue: first group + both parameter regions of layer 0 in flight, then the queries and masks
   dma(wimg, 0, 32);
-  {
-    const unsigned char* ps = reinterpret_cast<const unsigned char*>(p.par);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { const int f = wv + 8 * i; if (f < 18) decw_glds(ps + (size_t)f * 1024, voff, lds0 + OFF_E + (uint32_t)f * 1024u); }
-    if (wv < 6) decw_glds(ps + (size_t)DECW_E_N * 4 + (size_t)wv * 1024, voff, lds0 + OFF_L + (uint32_t)wv * 1024u);
-  }
+  dma(p.par, OFF_E, 18);
+  dma(p.par + DECW_E_N, OFF_L, 6);
   for (int i = tid; i < 96 * 32; i += 512) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     if (r < NQ) *reinterpret_cast<float4*>(xs + r * XS + c4) = *reinterpret_cast<const float4*>(p.Q + (qrow0 + r) * 128 + c4);
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto derive = [&](int zv, int zs) {
     lane = (tid & 63) + zv; l15 = lane & 15; l4 = lane >> 4; voff = (uint32_t)lane * 16u;
     wv = wv0 + zs; lds0 = lds00 + (uint32_t)zs;
-    actA = wv < 6 && !p.dbg; actB = wv < R && !p.dbg;
+    actA = wv < 6 && !(p.dbg & 1); actB = wv < R && !(p.dbg & 1);
     a_sub = l15 >> 3;
     const int a_r = l15 & 7;
     a_ok = a_r < R; b_ok = l15 < M;
@@ -431,9 +440,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_bf16x4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]), make_uint2(0u, 0u));   // k slots 4..7 unused
   };
   // dropout multipliers of four consecutive draws: 1/(1-p) or 0
-  auto keep4 = [&]() -> f32x4 {
-    const uint32_t h0 = decw_rand(rng), h1 = decw_rand(rng);
-    return (f32x4){((h0 & 0xffffu) < thr16) ? 0.f : dpk, ((h0 >> 16) < thr16) ? 0.f : dpk, ((h1 & 0xffffu) < thr16) ? 0.f : dpk, ((h1 >> 16) < thr16) ? 0.f : dpk};
+  auto keep4 = [&](int site) -> f32x4 {        // site: compile-time call index (selects the state pair)
+    const int i0 = (2 * site) & 3, i1 = (2 * site + 1) & 3;
+    const uint32_t h0 = rng.x[i0] = decw_step(rng.x[i0]), h1 = rng.x[i1] = decw_step(rng.x[i1]);
+    const unsigned short t = (unsigned short)thr16;         // 16-bit compares on the register halves: no extraction instructions
+    return (f32x4){((unsigned short)h0 < t) ? 0.f : dpk, ((unsigned short)(h0 >> 16) < t) ? 0.f : dpk, ((unsigned short)h1 < t) ? 0.f : dpk, ((unsigned short)(h1 >> 16) < t) ? 0.f : dpk};
   };
   // 16 x 16 self-attention of the tile, per head, entirely in registers: S^T = K Q^T (lane: 4 keys of query l15), O^T = V^T P^T.
   // `mask4`: 0 / -inf of this lane's four keys, entering as the accumulator of the score MFMA; scores are in log2 units (q carries log2 e).
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float m = rows_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
       f32x4 ev = {__builtin_amdgcn_exp2f(s[0] - m), __builtin_amdgcn_exp2f(s[1] - m), __builtin_amdgcn_exp2f(s[2] - m), __builtin_amdgcn_exp2f(s[3] - m)};
       const float lsum = rows_sum((ev[0] + ev[1]) + (ev[2] + ev[3]));
-      if (dp > 0.f) ev *= keep4();
+      if (DROP) ev *= keep4(h);
       const bf16x8 pf = l0w_from_u2(pack_bf16x4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
       const f32x4 o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2 * h], pf, Z, 0, 0, 0);
       const f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2 * h + 1], pf, Z, 0, 0, 0);
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto residual = [&](f32x4 (&res)[8], const f32x4 (&acc)[8]) {
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      if (dp > 0.f) res[nt] += acc[nt] * keep4();
+      if (DROP) res[nt] += acc[nt] * keep4(nt);
       else res[nt] += acc[nt];
     }
   };
@@ -467,21 +478,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int h = 2 * c + hh;
       f32x4 s[6];
 #pragma unroll
-      for (int kt = 0; kt < 6; ++kt) {
+      for (int kt = 0; kt < 5; ++kt) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, kt * 2 + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
       }
       float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-      for (int kt = 1; kt < 6; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+      for (int kt = 1; kt < 5; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+      if (six) {                                  // keys 80..95 exist only in batches with more than 80 tokens
+        const float4 mk = *reinterpret_cast<const float4*>(smaskf + 80 + l4 * 4);
+        s[5] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 10 + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+        m = fmaxf(fmaxf(m, fmaxf(s[5][0], s[5][1])), fmaxf(s[5][2], s[5][3]));
+      }
       m = rows_max(m);
       f32x4 l4s = Z;
 #pragma unroll
-      for (int kt = 0; kt < 6; ++kt) {
+      for (int kt = 0; kt < 5; ++kt) {
         s[kt] = (f32x4){__builtin_amdgcn_exp2f(s[kt][0] - m), __builtin_amdgcn_exp2f(s[kt][1] - m), __builtin_amdgcn_exp2f(s[kt][2] - m), __builtin_amdgcn_exp2f(s[kt][3] - m)};
         l4s += s[kt];
-        if (dp > 0.f) s[kt] *= keep4();
+        if (DROP) s[kt] *= keep4(kt);
       }
+      if (six) {
+        s[5] = (f32x4){__builtin_amdgcn_exp2f(s[5][0] - m), __builtin_amdgcn_exp2f(s[5][1] - m), __builtin_amdgcn_exp2f(s[5][2] - m), __builtin_amdgcn_exp2f(s[5][3] - m)};
+        l4s += s[5];
+        if (DROP) s[5] *= keep4(5);
+      } else s[5] = Z;
       const float lsum = rows_sum((l4s[0] + l4s[1]) + (l4s[2] + l4s[3]));
       f32x4 o0 = Z, o1 = Z;
 #pragma unroll
@@ -507,13 +528,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else if (g == 10) dma(kvl + 24 * 1024, dst, 24);
     else if (g < 20) dma(wl + (size_t)(g < 9 ? g : g - 2) * 32768, dst, 32);
     else if (li + 1 < 4) dma(wl + (size_t)DECW_LAYER_FRAGS * 1024, dst, 32);
-    if (k == 0 && li > 0 && wv < 6)      // region L of this layer: the previous layer's FFN epilogue is over for every wave
-      decw_glds(reinterpret_cast<const unsigned char*>(p.par + (size_t)li * DECW_PAR_LAYER + DECW_E_N) + (size_t)wv * 1024, voff, lds0 + OFF_L + (uint32_t)wv * 1024u);
-    if (k == 12 && li + 1 < 4) {         // region E of the next layer: r2r / m2m are over for every wave
-      const unsigned char* ps = reinterpret_cast<const unsigned char*>(p.par + (size_t)(li + 1) * DECW_PAR_LAYER);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { const int f = wv + 8 * i; if (f < 18) decw_glds(ps + (size_t)f * 1024, voff, lds0 + OFF_E + (uint32_t)f * 1024u); }
-    }
+    if (k == 0 && li > 0) dma(p.par + (size_t)li * DECW_PAR_LAYER + DECW_E_N, OFF_L, 6);      // region L of this layer: the previous FFN epilogue is over
+    if (k == 12 && li + 1 < 4) dma(p.par + (size_t)(li + 1) * DECW_PAR_LAYER, OFF_E, 18);      // region E of the next layer: r2r / m2m are over
   };
 
 #pragma unroll 1
@@ -538,8 +554,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       layer_norm(res, xb, parE + DECW_E_LN1);
       init8(acc, parE + DECW_E_BR2R); gemm(0, xb, acc);
       to_heads(acc, qf);
+      init8(acc, parE + DECW_E_BR2R + 128);                   // (bias rows are requested ahead of the barrier that hides their latency)
       sync(); issue(li, 1);                                   // ---- group 1: r2r k
-      init8(acc, parE + DECW_E_BR2R + 128); gemm(1, xb, acc);
+      gemm(1, xb, acc);
       to_heads(acc, kf);
       sync(); issue(li, 2);                                   // ---- group 2: r2r v + attention
       gemm_v(0, xb, vf, parE + DECW_E_BR2R + 256);
@@ -549,8 +566,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float ninf = -INFINITY;
         self_attention((f32x4){cross ? ninf : mk.x, cross ? ninf : mk.y, cross ? ninf : mk.z, cross ? ninf : mk.w}, qf, kf, vf, ao);
       }
+      init8(acc, parE + DECW_E_BR2RO);
       sync(); issue(li, 3);                                   // ---- group 3: r2r out_proj, residual, hand-over to the reference-line tiling
-      init8(acc, parE + DECW_E_BR2RO); gemm(1, ao, acc);
+      gemm(1, ao, acc);
       residual(res, acc);
       write_xs(res, a_row, a_ok);
     } else {
@@ -567,34 +585,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       layer_norm(res, xb, parE + DECW_E_LN2);
       init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS); gemm(0, xb, acc);
       to_heads(acc, qf);
+      init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS + 128);
       sync(); issue(li, 5);                                   // ---- group 5: m2m k (+ m_pos)
-      init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS + 128); gemm(1, xb, acc);
+      gemm(1, xb, acc);
       to_heads(acc, kf);
       sync(); issue(li, 6);                                   // ---- group 6: m2m v + attention over the modes
       gemm_v(0, xb, vf, parE + DECW_E_BM2MV);
       { const float mk = l4 == 3 ? -INFINITY : 0.f; self_attention((f32x4){mk, mk, mk, mk}, qf, kf, vf, ao); }   // keys 12..15 are padding slots
+      init8(acc, parE + DECW_E_BM2MO);
       sync(); issue(li, 7);                                   // ---- group 7: m2m out_proj, residual, padded lines zeroed (:70-72), LayerNorm
-      init8(acc, parE + DECW_E_BM2MO); gemm(1, ao, acc);
+      gemm(1, ao, acc);
       residual(res, acc);
       if (rz[wv]) zero8(res);
       layer_norm(res, xb, parL + DECW_L_LN3);
+      init8(acc, parL + DECW_L_BCQ);
       sync(); issue(li, 8);                                   // ---- group 8: cross q
-      init8(acc, parL + DECW_L_BCQ); gemm(0, xb, acc);
+      gemm(0, xb, acc);
       to_heads(acc, qf);
       sync(); issue(li, 9);                                   // ---- groups 9, 10: the scene's K | V^T, heads {0,1} then {2,3}
       cross_half(1, 0, qf, ao);
       sync(); issue(li, 10);
       cross_half(0, 1, qf, ao);
+      init8(acc, parL + DECW_L_BCO);
       sync(); issue(li, 11);                                  // ---- group 11: cross out_proj, residual, LayerNorm for the FFN
-      init8(acc, parL + DECW_L_BCO); gemm(1, ao, acc);
+      gemm(1, ao, acc);
       residual(res, acc);
       layer_norm(res, xb, parL + DECW_L_LN4);
       f32x4 acc2[8];
       init8(acc2, parL + DECW_L_BF2);
-#pragma unroll
+#pragma unroll 1
       for (int hc = 0; hc < 4; ++hc) {                        // ---- groups 12..19: ffn.0 chunk -> ReLU, dropout -> ffn.3 partial
+        init8(acc, parL + DECW_L_BF1 + hc * 128);
         sync(); issue(li, 12 + 2 * hc);
-        init8(acc, parL + DECW_L_BF1 + hc * 128); gemm(0, xb, acc);
+        gemm(0, xb, acc);
         bf16x8 hb[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -603,7 +626,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int q = 0; q < 2; ++q) {
             const f32x4 a = acc[2 * ks + q];
             v[q] = (f32x4){fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)};
-            if (dp > 0.f) v[q] *= keep4();
+            if (DROP) v[q] *= keep4(2 * ks + q);
           }
           hb[ks] = l0w_pack8(v[0], v[1]);
         }
@@ -629,14 +652,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 
 int decw_set_attributes() {
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
+  const int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
+  return e ? e : (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
 }
 void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t stream) {
   const int n = 4 * DECW_LAYER_FRAGS * 512;
   hipLaunchKernelGGL(pack_decw_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, img, par);
 }
 void decw_launch(const DecWP& p, hipStream_t stream) {
-  hipLaunchKernelGGL(dec_w_kernel, dim3(p.bs), dim3(512), (size_t)DECW_LDS_BYTES, stream, p);
+  if (p.dropout > 0.f) hipLaunchKernelGGL(dec_w_kernel<true>, dim3(p.bs), dim3(512), (size_t)DECW_LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL(dec_w_kernel<false>, dim3(p.bs), dim3(512), (size_t)DECW_LDS_BYTES, stream, p);
 }
 
 }  // namespace rift
