@@ -36,7 +36,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     steps = [common + ["-c", "-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0", os.path.join(CSRC, "engine.hip"), "-o", os.path.join(obj, "engine.o")],
              # no IEEE-mode canonicalisation (`v_max_f32 x, x, x` in front of every fmaxf on an MFMA result): this kernel tests no NaN
              common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "dec_w.hip"), "-o", os.path.join(obj, "dec_w.o")],
-             common + ["-shared", os.path.join(obj, "engine.o"), os.path.join(obj, "dec_w.o"), "-o", LIB]]
+             common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "nat_l2w.hip"), "-o", os.path.join(obj, "nat_l2w.o")],
+             common + ["-shared", os.path.join(obj, "engine.o"), os.path.join(obj, "dec_w.o"), os.path.join(obj, "nat_l2w.o"), "-o", LIB]]
     for cmd in steps:
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -23,6 +23,7 @@
 #include "enc_fused.h"
 #include "dec_fused.h"
 #include "dec_w.h"
+#include "nat_l2w.h"
 #include "pe_fused.h"
 #include "fourier_fused.h"
 #include "critic.h"
@@ -89,6 +90,7 @@ struct RiftCtx {
   float* nat_bqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool nat_fused = true; int nat_dbg = 0; int gemm_dbg = 0;
   bool nat_l0w = true; unsigned short* l0w_img = nullptr; float* l0w_par = nullptr;
+  bool nat_l2w = true; unsigned short* l2w_img = nullptr; float* l2w_par = nullptr;   // wave-private, weight-streaming level-2 NAT kernel (nat_l2w.h)
   bool nat_l1w = true; unsigned short* l1w_img = nullptr; float* l1w_par = nullptr;   // wave-private level-1 NAT kernel (nat_l1w.h)   // wave-private level-0 NAT kernel (nat_l0w.h)
   unsigned short* enc_wqkv[4] = {nullptr, nullptr, nullptr, nullptr};   // chunked (q|k|q|k|v|v) bf16 in_proj images
   float* enc_bqkv[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -404,6 +406,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR(enc_fused_kernel<ENC_NW>);
   SETATTR(dec_fused_kernel<DEC_NW>);
   HIPCHK(c, (hipError_t)decw_set_attributes());
+  HIPCHK(c, (hipError_t)l2w_set_attributes());
   SETATTR((dec_fused_kernel<DEC_NW, 1>)); SETATTR((dec_fused_kernel<DEC_NW, 2>)); SETATTR((dec_fused_kernel<DEC_NW, 3>)); SETATTR((dec_fused_kernel<DEC_NW, 4>));
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
@@ -785,6 +788,16 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         q.droppath[0] = f.drop ? dpr[2] : 0.f; q.droppath[1] = f.drop ? dpr[3] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (rows / 2) * 2.0 * 3 * C * 2 * C;
         launch(c, "nat_level_kernel_L1", nat_l1w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid)), dim3(512), (size_t)L1W_LDS, q);
+        continue;
+      }
+      if (lv == 2 && c->nat_l2w) {   // level 2: wave-private tiles of 3 agents, the two layers' weights streamed through LDS (nat_l2w.h)
+        NatL2WP q; memset(&q, 0, sizeof(q));
+        q.X = Xin[2]; q.nseq = nA; q.img = c->l2w_img; q.par = c->l2w_par; q.Oc = Oc[2];
+        q.droppath[0] = f.drop ? dpr[4] : 0.f; q.droppath[1] = f.drop ? dpr[5] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
+        { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 3) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
+        c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C);
+        const int l2grid = std::min(cdiv(cdiv(nA, 3), 8), c->nat_grid);
+        launch_call(c, "nat_level_kernel_L2", [&] { l2w_launch(q, l2grid, c->stream); });
         continue;
       }
       NatLevelP p; memset(&p, 0, sizeof(p));
@@ -1302,6 +1315,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("RIFT_NAT_L0W"); c->nat_l0w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_NAT_L1W"); c->nat_l1w = !(ev && ev[0] == '0'); }
+  { const char* ev = getenv("RIFT_NAT_L2W"); c->nat_l2w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   if (hipMalloc((void**)&c->nonfinite, sizeof(int)) != hipSuccess || hipMemset(c->nonfinite, 0, sizeof(int)) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   int rc = set_lds_attrs(c);
@@ -1326,6 +1340,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->nonfinite) (void)hipFree(c->nonfinite);
   if (c->l0w_img) { (void)hipFree(c->l0w_img); (void)hipFree(c->l0w_par); }
   if (c->l1w_img) { (void)hipFree(c->l1w_img); (void)hipFree(c->l1w_par); }
+  if (c->l2w_img) { (void)hipFree(c->l2w_img); (void)hipFree(c->l2w_par); }
   if (c->dec_par) (void)hipFree(c->dec_par);
   if (c->decw_img) { (void)hipFree(c->decw_img); (void)hipFree(c->decw_par); }
   for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
@@ -1403,6 +1418,21 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     if (!c->err.empty()) return RIFT_ERR_ARG;
     if (!c->l1w_img) { HIPCHK(c, hipMalloc((void**)&c->l1w_img, (size_t)L1W_NFRAG * 1024)); HIPCHK(c, hipMalloc((void**)&c->l1w_par, (size_t)L1W_NPAR * 4)); }
     hipLaunchKernelGGL(pack_l1w_kernel, dim3(cdiv(L1W_NFRAG * 512, 256)), dim3(256), 0, c->stream, q, c->l1w_img, c->l1w_par);
+  }
+  {  // wave-private level-2 kernel (nat_l2w.h)
+    NatL2WSrc q; memset(&q, 0, sizeof(q));
+    for (int b = 0; b < 2; ++b) {
+      const std::string p = HE + ".levels.2.blocks." + std::to_string(b);
+      NatL2WSrc::Blk& k = q.blk[b];
+      k.ln1_g = fptr(c, p + ".norm1.weight"); k.ln1_b = fptr(c, p + ".norm1.bias"); k.wqkv = fptr(c, p + ".attn.qkv.weight"); k.bqkv = fptr(c, p + ".attn.qkv.bias");
+      k.rpb = fptr(c, p + ".attn.rpb"); k.wproj = fptr(c, p + ".attn.proj.weight"); k.bproj = fptr(c, p + ".attn.proj.bias");
+      k.ln2_g = fptr(c, p + ".norm2.weight"); k.ln2_b = fptr(c, p + ".norm2.bias"); k.w1 = fptr(c, p + ".mlp.fc1.weight"); k.b1 = fptr(c, p + ".mlp.fc1.bias");
+      k.w2 = fptr(c, p + ".mlp.fc2.weight"); k.b2 = fptr(c, p + ".mlp.fc2.bias");
+    }
+    q.fn_g = fptr(c, HE + ".norm2.weight"); q.fn_b = fptr(c, HE + ".norm2.bias");
+    if (!c->err.empty()) return RIFT_ERR_ARG;
+    if (!c->l2w_img) { HIPCHK(c, hipMalloc((void**)&c->l2w_img, (size_t)2 * L2W_BLK_FRAGS * 1024)); HIPCHK(c, hipMalloc((void**)&c->l2w_par, (size_t)L2W_NPAR * 4)); }
+    l2w_pack(q, c->l2w_img, c->l2w_par, c->stream);
   }
   {  // fpn_conv at the last step: taps 0,1 only -> [128][256]
     const Param* w = find(c, HE + ".fpn_conv.weight");

@@ -1,0 +1,258 @@
+// Wave-private level-2 NAT kernel (see nat_l2w.h); its own translation unit for the reasons given in dec_w.hip.
+#include "common.h"
+#include "nat_l2w.h"
+#include "wp_stream.h"
+
+namespace rift {
+
+// Weight image: [block][group][fragment f = ks * 8 + nt][lane][8] with the K permutation of nat_l0w.h.  natten's qkv rows are (3, H, 16):
+// q of head h = rows h*16.., k = 128 + ..., v = 256 + ...; q carries head_dim^-0.5 log2 e.
+__global__ void pack_l2w_kernel(NatL2WSrc s, unsigned short* __restrict__ img, float* __restrict__ par) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const float SC = 0.25f * 1.4426950408889634f;
+  if (e < 2 * L2W_BLK_FRAGS * 512) {
+    const int j = e & 7, lane = (e >> 3) & 63, fr = e >> 9, bi = fr / L2W_BLK_FRAGS, g = (fr % L2W_BLK_FRAGS) >> 5, f = fr & 31;
+    const int ks = f >> 3, nt = f & 7, l15 = lane & 15, l4 = lane >> 4;
+    const int ch = l0w_chan(l4, j, 2 * ks), o = nt * 16 + l15;
+    const NatL2WSrc::Blk& k = s.blk[bi];
+    float v;
+    if (g < 3) v = k.wqkv[(g * 128 + o) * 128 + ch] * (g == 0 ? SC : 1.0f);
+    else if (g == 3) v = k.wproj[o * 128 + ch];
+    else {
+      const int c = (g - 4) >> 1;
+      v = ((g - 4) & 1) ? k.w2[o * 384 + c * 128 + ch] : k.w1[(c * 128 + o) * 128 + ch];
+    }
+    img[e] = f2bf(v);
+  }
+  if (e < L2W_NPAR) {
+    float v = 0.f;
+    if (e < 2 * 1664) {
+      const int bi = e / 1664, o = e % 1664;
+      const NatL2WSrc::Blk& k = s.blk[bi];
+      if (o < 128) v = k.ln1_g[o];
+      else if (o < 256) v = k.ln1_b[o - 128];
+      else if (o < 640) v = k.bqkv[o - 256] * (o - 256 < 128 ? SC : 1.0f);
+      else if (o < 768) v = (o - 640 < 72) ? k.rpb[o - 640] * 1.4426950408889634f : 0.f;
+      else if (o < 896) v = k.bproj[o - 768];
+      else if (o < 1024) v = k.ln2_g[o - 896];
+      else if (o < 1152) v = k.ln2_b[o - 1024];
+      else if (o < 1536) v = k.b1[o - 1152];
+      else v = k.b2[o - 1536];
+    } else if (e < L2W_P_FN + 256) v = (e - L2W_P_FN < 128) ? s.fn_g[e - L2W_P_FN] : s.fn_b[e - L2W_P_FN - 128];
+    par[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nat_l2w_kernel(NatL2WP p) {
+  constexpr int L = 5;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* ring = smem_raw;
+  float* par = reinterpret_cast<float*>(smem_raw + L2W_SLOTS * 32768);
+  const int tid = threadIdx.x;
+  int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wv = wv0;
+  const uint32_t lds00 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw);
+  uint32_t lds0 = lds00, voff = (uint32_t)lane * 16u;
+  const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (p.nseq + 2) / 3, nrounds = (ntiles + 7) >> 3;
+  const int my_rounds = blockIdx.x < nrounds ? (nrounds - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int total = 20 * my_rounds;                      // groups this workgroup consumes
+  int tsn = 0;
+#define L2TS() do { if (p.ts && blockIdx.x == 0 && tid == 0 && tsn < 60) p.ts[tsn++] = clock64(); } while (0)
+
+  // ---- operand stream: group s of this workgroup = group s % 20 of the two-layer sequence; ring slot s % 3; a boundary requests s + 2
+  const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.img);
+  auto request = [&](int s) {
+    if (s >= total) return;
+    const unsigned char* src = wimg + (size_t)(s % 20) * 32768;
+    const uint32_t dst = (uint32_t)(s % 3) * 32768u;
+#pragma unroll 1
+    for (int f = wv; f < 32; f += 8) decw_glds(src + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
+  };
+  // boundary that opens group s: my four requests of it have landed (at most the four of group s + 1 may still fly behind them), then
+  // the barrier: everybody's have, and nobody reads slot (s - 1) % 3 any more
+  auto boundary = [&](int s) {
+    if (s + 1 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    L2TS();
+    request(s + 2);
+  };
+  auto slot_off = [&](int s) -> uint32_t { return (uint32_t)(s % 3) * 32768u; };
+  auto gemm = [&](uint32_t so, const bf16x8 (&x)[4], f32x4 (&acc)[8]) { decw_gemm<false>((uint32_t)(uintptr_t)ring + so + voff, x, acc); };
+
+  for (int i = tid; i < L2W_NPAR / 4; i += 512) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
+  request(0);
+  request(1);
+
+  auto init8 = [&](f32x4 (&a)[8], const float* bias) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) { const float4 v = *reinterpret_cast<const float4*>(bias + nt * 16 + l4 * 4); a[nt] = (f32x4){v.x, v.y, v.z, v.w}; }
+  };
+  auto layer_norm = [&](const f32x4 (&res)[8], bf16x8 (&xb)[4], const float* g) {
+    f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
+    s4 += (res[4] + res[5]) + (res[6] + res[7]);
+    const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
+    f32x4 d[8];
+    f32x4 q4 = Z;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) { d[nt] = res[nt] - mean; q4 += d[nt] * d[nt]; }
+    const float r = rsqrtf(rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f32x4 y[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int nt = 2 * ks + u;
+        const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 128 + nt * 16 + l4 * 4);
+        y[u] = d[nt] * ((f32x4){gg.x, gg.y, gg.z, gg.w} * r) + (f32x4){bb.x, bb.y, bb.z, bb.w};
+      }
+      xb[ks] = l0w_pack8(y[0], y[1]);
+    }
+  };
+
+  int s = 0;                                             // sequence number of the next group to open
+#pragma unroll 1
+  for (int round = blockIdx.x; round < nrounds; round += gridDim.x) {
+    {   // opaque zeros (see dec_w.hip): keep the addresses of the 20 groups from being hoisted out of the loop
+      int zv, zs;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+      lane = (tid & 63) + zv; l15 = lane & 15; l4 = lane >> 4; voff = (uint32_t)lane * 16u; wv = wv0 + zs; lds0 = lds00 + (uint32_t)zs;
+    }
+    const int tile = round * 8 + wv;
+    const int qa = l15 / L, qt = l15 - qa * L;           // this lane row: agent qa (3 = the idle row 15), step qt
+    const int seq = tile * 3 + qa;
+    const bool row_ok = qa < 3 && seq < p.nseq;
+    f32x4 res[8];
+    {
+      const float* src = p.X + ((size_t)(row_ok ? seq : 0) * L + (row_ok ? qt : 0)) * 128 + l4 * 4;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const float4 v = *reinterpret_cast<const float4*>(src + nt * 16);
+        res[nt] = row_ok ? (f32x4){v.x, v.y, v.z, v.w} : Z;
+      }
+    }
+    // score accumulator pattern of this lane: keys 4 l4 + i -> same agent ? rpb[key step - query step + 4] : -inf.  The idle row 15 is its
+    // own "agent 3" and sees itself: a row without any key would turn NaN, and a NaN KEY row poisons every query through the score MFMA
+    int ridx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = l4 * 4 + i, ka = key / L, kt = key - ka * L;
+      ridx[i] = (ka == qa) ? kt - qt + 4 : -1;
+    }
+#pragma unroll 1
+    for (int bi = 0; bi < 2; ++bi) {
+      const float* pb = par + L2W_P_BLK(bi);
+      f32x4 acc[8];
+      bf16x8 xb[4], qf[4], kp[4], ao[4], vf[8];
+      float dps = 1.f, dp2 = 1.f;
+      if (p.droppath[bi] > 0.f) {
+        dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+        dp2 = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+      }
+      // ---- group 0: q
+      layer_norm(res, xb, pb + L2W_PB_LN1);
+      init8(acc, pb + L2W_PB_BQKV);
+      boundary(s); gemm(slot_off(s), xb, acc); ++s;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qf[j] = l0w_pack8(acc[2 * j], acc[2 * j + 1]);
+      init8(acc, pb + L2W_PB_BQKV + 128);
+      // ---- group 1: k
+      boundary(s); gemm(slot_off(s), xb, acc); ++s;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kp[j] = l0w_pack8(acc[2 * j], acc[2 * j + 1]);
+      // ---- group 2: v (plain order: lane = 4 keys of dim l15 of head nt) + attention
+      {
+        f32x4 av[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) { const float bv = pb[L2W_PB_BQKV + 256 + nt * 16 + l15]; av[nt] = (f32x4){bv, bv, bv, bv}; }
+        boundary(s); decw_gemm<true>((uint32_t)(uintptr_t)ring + slot_off(s) + voff, xb, av); ++s;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_bf16x4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]), make_uint2(0u, 0u));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 o[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int h = 2 * j + u;
+          f32x4 mb;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mb[i] = ridx[i] >= 0 ? pb[L2W_PB_RPB + h * 9 + ridx[i]] : -INFINITY;
+          // head h's 16 dims are one half of the k-step: the other half of the K operand is zero
+          bf16x8 kh = kp[j];
+          if (u == 0) { kh[4] = 0; kh[5] = 0; kh[6] = 0; kh[7] = 0; } else { kh[0] = 0; kh[1] = 0; kh[2] = 0; kh[3] = 0; }
+          const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qf[j], mb, 0, 0, 0);
+          const float m = rows_max(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+          const f32x4 ev = {__builtin_amdgcn_exp2f(sc[0] - m), __builtin_amdgcn_exp2f(sc[1] - m), __builtin_amdgcn_exp2f(sc[2] - m), __builtin_amdgcn_exp2f(sc[3] - m)};
+          const float inv = __builtin_amdgcn_rcpf(rows_sum((ev[0] + ev[1]) + (ev[2] + ev[3])));
+          const bf16x8 pf = l0w_from_u2(pack_bf16x4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
+          o[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[h], pf, Z, 0, 0, 0) * inv;
+        }
+        ao[j] = l0w_pack8(o[0], o[1]);
+      }
+      init8(acc, pb + L2W_PB_BP);
+      // ---- group 3: proj, DropPath, residual
+      boundary(s); gemm(slot_off(s), ao, acc); ++s;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) res[nt] += acc[nt] * dps;
+      // ---- groups 4..9: fc1 chunk -> GELU -> fc2 partial
+      layer_norm(res, xb, pb + L2W_PB_LN2);
+      f32x4 acc2[8];
+      init8(acc2, pb + L2W_PB_B2);
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) {
+        boundary(s);
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[nt] = Z;
+        gemm(slot_off(s), xb, acc); ++s;
+        bf16x8 hb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const float4 ba = *reinterpret_cast<const float4*>(pb + L2W_PB_B1 + c * 128 + (2 * ks) * 16 + l4 * 4);
+          const float4 bb = *reinterpret_cast<const float4*>(pb + L2W_PB_B1 + c * 128 + (2 * ks + 1) * 16 + l4 * 4);
+          hb[ks] = l0w_from_u2(gelu4_pack(acc[2 * ks], ba), gelu4_pack(acc[2 * ks + 1], bb));
+        }
+        boundary(s); gemm(slot_off(s), hb, acc2); ++s;
+      }
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) res[nt] += acc2[nt] * dp2;
+    }
+    // ---- what the FPN reads: LayerNorm(norm2) of steps 2, 3, 4
+    {
+      const float* g = par + L2W_P_FN;
+      f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
+      s4 += (res[4] + res[5]) + (res[6] + res[7]);
+      const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
+      f32x4 d[8];
+      f32x4 q4 = Z;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) { d[nt] = res[nt] - mean; q4 += d[nt] * d[nt]; }
+      const float r = rsqrtf(rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + 1e-5f);
+      if (row_ok && qt >= 2) {
+        float* dst = p.Oc + ((size_t)seq * 3 + (qt - 2)) * 128;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+          const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 128 + nt * 16 + l4 * 4);
+          *reinterpret_cast<float4*>(dst + nt * 16 + l4 * 4) =
+              make_float4(d[nt][0] * r * gg.x + bb.x, d[nt][1] * r * gg.y + bb.y, d[nt][2] * r * gg.z + bb.z, d[nt][3] * r * gg.w + bb.w);
+        }
+      }
+    }
+  }
+#undef L2TS
+}
+
+int l2w_set_attributes() {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&nat_l2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L2W_LDS);
+}
+void l2w_pack(const NatL2WSrc& src, unsigned short* img, float* par, hipStream_t stream) {
+  const int n = 2 * L2W_BLK_FRAGS * 512;
+  hipLaunchKernelGGL(pack_l2w_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, img, par);
+}
+void l2w_launch(const NatL2WP& p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(nat_l2w_kernel, dim3(grid), dim3(512), (size_t)L2W_LDS, stream, p);
+}
+
+}  // namespace rift
