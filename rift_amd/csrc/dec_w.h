@@ -67,7 +67,7 @@ struct DecWP {
   long long* ts;                // optional: clock of wave 0 of workgroup 0 at every group boundary (diagnostic, RIFT_DEC_TS)
 };
 
-// host entry points of the dec_w.hip translation unit (built without -amdgpu-spill-sgpr-to-vgpr=0, see build.py)
+// host entry points of the dec_w.hip translation unit (see build.py)
 int decw_set_attributes();
 void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t stream);
 void decw_launch(const DecWP& p, hipStream_t stream);

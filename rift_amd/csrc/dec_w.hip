@@ -1,7 +1,4 @@
-// Wave-private planning decoder kernel (see dec_w.h) as its own translation unit: engine.hip is compiled with SGPR spills sent to scratch
-// (a ROCm 7.2 backend workaround for dec_fused_kernel, rift_amd/build.py); here that would put a scratch reload -- and its
-// `s_waitcnt vmcnt(0)`, which drains the LDS-DMA prefetch -- on most group boundaries, so this file is compiled with the default
-// (SGPR spills in VGPR lanes).
+// Wave-private planning decoder kernel (see dec_w.h).  Its own translation unit: built with `-fno-honor-nans -mno-amdgpu-ieee` (rift_amd/build.py).
 #include "common.h"
 #include "dec_w.h"
 #include "wp_stream.h"

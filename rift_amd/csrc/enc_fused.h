@@ -36,9 +36,8 @@ struct EncFusedP {
   // (planning_decoder.py:74-79, nn.MultiheadAttention in_proj rows 128:384), written as bf16 operands of the decoder kernel
   const unsigned short* wkv;    // fragment-major bf16 [4 * 256][128]: per layer (k 128 rows | v 128 rows)
   const float* bkv;             // [4 * 256]
-  unsigned short* KT;           // (bs, 4, 96, 128) bf16: K rows per key (keys >= N undefined, masked by the decoder)
-  unsigned short* VT;           // (bs, 4, 128, 96) bf16: V transposed (dim-major)
-  int kv_frag;                  // 1: KT is the (bs, 4, 48, 512) fragment image of dec_w.h (K | V^T MFMA operand fragments per head pair), VT unused
+  unsigned short* KT;           // (bs, 4, 48, 512) bf16: per layer the 48 K | V^T MFMA operand fragments of dec_w.h (per head pair: 12 K, 12 V^T;
+                                // keys >= N undefined, masked by the decoder)
   const unsigned short* wx0;    // cat_x_proj columns 128:256 (planning_decoder.py:177-179), applied to the scene's ego token (row 0)
   float* x0p;                   // (bs, 128)
 };
@@ -395,23 +394,20 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         const int col = wave * 16 + l4 * 4;
         const float4 b4 = *reinterpret_cast<const float4*>(p.bkv + l * 256 + col);
         // fragment image: head h = wave >> 1 holds dims 32 h + 16 (j / 4) + 4 l4 + j % 4 in k slot j: this wave supplies j / 4 = wave & 1
-        unsigned short* kt = p.kv_frag ? p.KT + (((size_t)b * 4 + l) * 48 + (wave >> 2) * 24 + ((wave >> 1) & 1)) * 512 + lane * 8 + (wave & 1) * 4
-                                       : p.KT + ((size_t)b * 4 + l) * 96 * 128 + l15 * 128 + col;
-        const int kstep = p.kv_frag ? 2 * 512 : 16 * 128;
+        unsigned short* kt = p.KT + (((size_t)b * 4 + l) * 48 + (wave >> 2) * 24 + ((wave >> 1) & 1)) * 512 + lane * 8 + (wave & 1) * 4;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          *reinterpret_cast<uint2*>(kt + mt * kstep) =
+          *reinterpret_cast<uint2*>(kt + mt * 2 * 512) =
               pack_bf16x4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
       }
       {   // V^T: channel wave*16 + l15, keys mt*16 + 4*l4 .. +3
         const int d = wave * 16 + l15;
         const float bias = p.bkv[l * 256 + 128 + d];
         // fragment image: (head pair, head, dim tile wave & 1, key pair pt = mt >> 1), k slot j <-> key 32 pt + 16 (j / 4) + 4 l4 + j % 4
-        unsigned short* vt = p.kv_frag ? p.KT + (((size_t)b * 4 + l) * 48 + (wave >> 2) * 24 + 12 + (((wave >> 1) & 1) * 2 + (wave & 1)) * 3) * 512 + lane * 8
-                                       : p.VT + (((size_t)b * 4 + l) * 128 + d) * 96 + l4 * 4;
+        unsigned short* vt = p.KT + (((size_t)b * 4 + l) * 48 + (wave >> 2) * 24 + 12 + (((wave >> 1) & 1) * 2 + (wave & 1)) * 3) * 512 + lane * 8;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          *reinterpret_cast<uint2*>(vt + (p.kv_frag ? (mt >> 1) * 512 + (mt & 1) * 4 : mt * 16)) =
+          *reinterpret_cast<uint2*>(vt + (mt >> 1) * 512 + (mt & 1) * 4) =
               pack_bf16x4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
       }
     }

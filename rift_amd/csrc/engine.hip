@@ -21,7 +21,7 @@
 #include "nat_l0w.h"
 #include "nat_l1w.h"
 #include "enc_fused.h"
-#include "dec_fused.h"
+#include "enc_fused.h"
 #include "dec_w.h"
 #include "nat_l2w.h"
 #include "pe_fused.h"
@@ -35,7 +35,6 @@
 
 // fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
 // workgroups share a CU; 8 waves give a single resident workgroup two waves per SIMD)
-#define DEC_NW 8
 #define ENC_NW 8
 #define NAT_L0_NW 8
 #define NAT_L0_CW 192
@@ -95,13 +94,10 @@ struct RiftCtx {
   unsigned short* enc_wqkv[4] = {nullptr, nullptr, nullptr, nullptr};   // chunked (q|k|q|k|v|v) bf16 in_proj images
   float* enc_bqkv[4] = {nullptr, nullptr, nullptr, nullptr};
   int* enc_idx = nullptr; bool enc_fused = true;
-  unsigned short* dec_wqkv[4][2] = {};   // [layer][r2r, m2m] chunk-ordered in_proj images
-  float* dec_bqkv[4][2] = {};
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
-  float* dec_par = nullptr;              // [4][RIFT_DEC_NPAR] packed LayerNorm parameters / biases of the fused decoder kernel
   bool dec_fused = true;
-  bool dec_w = true; unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // wave-private decoder kernel (dec_w.h)
+  unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // weight stream / parameter blocks of the decoder kernel (dec_w.h)
   double* clip_part = nullptr;
   struct Dp { bool on = false; int off = 0, gbs = 0; double* xchg = nullptr; long long len = 0; RiftExchangeFn fn = nullptr; void* user = nullptr; } dp;   // rift_set_dp
   int* nonfinite = nullptr;              // device flag set by the policy-head kernels when the decoder output is not finite
@@ -404,10 +400,8 @@ int set_lds_attrs(RiftCtx* c) {
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
   SETATTR(rollout_kernel);
   SETATTR(enc_fused_kernel<ENC_NW>);
-  SETATTR(dec_fused_kernel<DEC_NW>);
   HIPCHK(c, (hipError_t)decw_set_attributes());
   HIPCHK(c, (hipError_t)l2w_set_attributes());
-  SETATTR((dec_fused_kernel<DEC_NW, 1>)); SETATTR((dec_fused_kernel<DEC_NW, 2>)); SETATTR((dec_fused_kernel<DEC_NW, 3>)); SETATTR((dec_fused_kernel<DEC_NW, 4>));
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
   SETATTR(NAT_L2);
@@ -981,7 +975,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // ================= encoder blocks (transformer.py:73-94) =================
   static const float edpr[4] = {0.f, 0.2f / 3.f, 0.4f / 3.f, 0.2f};   // linspace(0, 0.2, 4), pluto_model.py:80-83
   float* ENC = A_alloc<float>(c, (size_t)nT * 128);
-  unsigned short *enc_KT = nullptr, *enc_VT = nullptr;
+  unsigned short* enc_KT = nullptr;   // the decoder's cross-attention K | V^T operand fragments, written by the encoder kernel's tail
   float* enc_x0p = nullptr;   // cat_x_proj's ego-token half, written by the encoder kernel's tail
   if (c->enc_fused && !f.fp32 && N <= 96) {
     EncFusedP ep; memset(&ep, 0, sizeof(ep));
@@ -1000,13 +994,10 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias");
     if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
-    const bool decw = c->dec_w && R <= 8;
-    if (c->dec_fused && (decw || R * 12 <= 80) && ENC_NW == 8) {   // the decoder kernel will run: emit its cross-attention K | V operands here
-      enc_KT = A_alloc<unsigned short>(c, decw ? (size_t)bs * 4 * DECW_KV_FRAGS * 512 : (size_t)bs * 4 * 96 * 128);
-      enc_VT = decw ? nullptr : A_alloc<unsigned short>(c, (size_t)bs * 4 * 128 * 96);
-      ep.kv_frag = decw ? 1 : 0;
+    if (c->dec_fused && R <= 8 && ENC_NW == 8) {   // the decoder kernel will run: emit its cross-attention K | V operand fragments here
+      enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * DECW_KV_FRAGS * 512);
       ep.wkv = (const unsigned short*)c->pw["planning_decoder.kv_all"].bf; ep.bkv = c->pw["planning_decoder.kv_all"].bias;
-      ep.KT = enc_KT; ep.VT = enc_VT;
+      ep.KT = enc_KT;
       enc_x0p = A_alloc<float>(c, (size_t)bs * 128);
       ep.wx0 = (const unsigned short*)c->pw["planning_decoder.cat_x_proj.x"].bf; ep.x0p = enc_x0p;
       c->prof_flops += 2.0 * bs * N * 128.0 * 1024;
@@ -1090,7 +1081,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 
   dp_exchange(f, 0);                      // (eval forward under data parallelism: the mask slots have not travelled yet)
   const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
-  if (c->dec_fused && c->dec_w && !f.fp32 && R <= 8 && N <= 96 && enc_KT) {
+  if (c->dec_fused && !f.fp32 && R <= 8 && N <= 96 && enc_KT) {
     DecWP dq; memset(&dq, 0, sizeof(dq));
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
     dq.stream = f.next_stream(); f.stream_id += 64;
@@ -1099,51 +1090,6 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     { const char* ev = getenv("RIFT_DEC_DBG"); dq.dbg = ev ? atoi(ev) : 0; }
     c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
     launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
-  } else if (c->dec_fused && !f.fp32 && R * M <= 80 && N <= 96 && !(c->dec_w && R <= 8 && enc_KT)) {
-    DecFusedP dq; memset(&dq, 0, sizeof(dq));
-    dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
-    dq.stream = f.next_stream(); f.stream_id += 64;
-    // the cross-attention K | V projections of all four layers read the same encoder output: one N = 1024 GEMM
-    float* KVall = nullptr;
-    if (enc_KT) { dq.KT = enc_KT; dq.VT = enc_VT; }     // written by the encoder kernel's tail
-    else {
-      KVall = A_alloc<float>(c, (size_t)nT * 1024);
-      gemm(c, mk(ENC, 128, nT, c->pw[PD + ".kv_all"], KVall, 1024), c->pw[PD + ".kv_all"], f.fp32);
-    }
-    dq.kv_ld = 1024;
-    for (int i = 0; i < 4; ++i) {
-      const std::string p = PD + ".decoder_blocks." + std::to_string(i);
-      DecBlockW& w = dq.blk[i];
-      w.par = c->dec_par + (size_t)i * RIFT_DEC_NPAR;
-      w.w_r2r = c->dec_wqkv[i][0]; w.w_m2m = c->dec_wqkv[i][1];
-      auto bf = [&](const std::string& k) { return (const unsigned short*)c->pw[k].bf; };
-      w.w_r2ro = bf(p + ".r2r_attn.out_proj"); w.w_m2mo = bf(p + ".m2m_attn.out_proj");
-      w.w_cq = bf(p + ".cross_attn.q"); w.w_co = bf(p + ".cross_attn.out_proj");
-      w.w_f1 = bf(p + ".ffn.0"); w.w_f2 = bf(p + ".ffn.3");
-      // m_pos . Wqk^T (12 x 384, weights only: cached) and its hi/lo bf16 fragment image for the kernel's extra MFMA k-step
-      bool fill_mp, fill_mpx;
-      float* MPl = wconst_get(c, p + ".mp", (size_t)M * 384, f.fp32, &fill_mp);
-      if (fill_mp) gemm(c, mk(fptr(c, PD + ".m_pos"), 128, M, c->pw[p + ".m2m_attn.qk0"], MPl, 384), c->pw[p + ".m2m_attn.qk0"], f.fp32);
-      unsigned short* MPX = (unsigned short*)wconst_get(c, p + ".mpx", (size_t)2 * 8 * 512 / 2, f.fp32, &fill_mpx);
-      if (fill_mpx) launch(c, "pack_mpx_kernel", pack_mpx_kernel, dim3(cdiv(2 * 8 * 512, 256)), dim3(256), 0, (const float*)MPl, (const int*)c->enc_idx, MPX);
-      w.mpx = MPX; w.kv = KVall ? KVall + i * 256 : nullptr;
-    }
-    if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
-    // algorithmic FLOPs of the 4 layers on the padded (R x 12) query block, as the reference computes them
-    c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
-    {
-      // the variant that processes just the 16-row query tiles this batch has (R * 12 <= 16 * MT): a batch whose padded R is below 6 skips
-      // whole tiles of MFMA / LayerNorm / epilogue work (measured 90 / 99 / 119 / 136 / 163 us for MT = 1..5, tools/dec_mt.py: 72 us of
-      // per-phase latency + ~18 us per tile).  RIFT_DEC_MT overrides (diagnostic).
-      const char* ev = getenv("RIFT_DEC_MT");
-      const int mt = ev ? atoi(ev) : std::min(5, (R * M + 15) / 16);
-      if (mt < 5 && R * M > 16 * mt) { c->err = "RIFT_DEC_MT too small for this batch"; return RIFT_ERR_ARG; }
-      if (mt == 1) launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW, 1>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
-      else if (mt == 2) launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW, 2>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
-      else if (mt == 3) launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW, 3>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
-      else if (mt == 4) launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW, 4>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
-      else launch(c, "dec_fused_kernel", dec_fused_kernel<DEC_NW>, dim3(bs), dim3(64 * DEC_NW), (size_t)RIFT_DEC_LDS_BYTES, dq);
-    }
   } else {
   float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
   float* DAO = A_alloc<float>(c, (size_t)nQ * 128);
@@ -1301,7 +1247,6 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   if (hipSetDevice(device) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   { const char* ev = getenv("RIFT_NAT_UNFUSED"); c->nat_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_DEC_UNFUSED"); c->dec_fused = !(ev && ev[0] == '1'); }
-  { const char* ev = getenv("RIFT_DEC_W"); c->dec_w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_ENC_UNFUSED"); c->enc_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_UNFUSED"); c->pe_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_FPN_UNFUSED"); c->fpn_fused = !(ev && ev[0] == '1'); }
@@ -1341,9 +1286,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->l0w_img) { (void)hipFree(c->l0w_img); (void)hipFree(c->l0w_par); }
   if (c->l1w_img) { (void)hipFree(c->l1w_img); (void)hipFree(c->l1w_par); }
   if (c->l2w_img) { (void)hipFree(c->l2w_img); (void)hipFree(c->l2w_par); }
-  if (c->dec_par) (void)hipFree(c->dec_par);
   if (c->decw_img) { (void)hipFree(c->decw_img); (void)hipFree(c->decw_par); }
-  for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) { if (c->dec_wqkv[i][k]) (void)hipFree(c->dec_wqkv[i][k]); if (c->dec_bqkv[i][k]) (void)hipFree(c->dec_bqkv[i][k]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
   delete c;
@@ -1505,40 +1448,6 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
       bn.push_back(PD + ".decoder_blocks." + std::to_string(i) + ".cross_attn.in_proj_bias");
     }
     TRY(pack_stacked_rows(c, PD + ".kv_all", wn, bn, 128, 256));
-  }
-  {  // chunked in_proj images of the two decoder self-attentions, in the encoder kernel's order (q_a k_a q_b k_b v_a v_b per chunk)
-    const char* nm[2] = {".r2r_attn", ".m2m_attn"};
-    for (int i = 0; i < 4; ++i)
-      for (int k = 0; k < 2; ++k) {
-        const std::string p = PD + ".decoder_blocks." + std::to_string(i) + nm[k];
-        const float* w = fptr(c, p + ".in_proj_weight"); const float* bsrc = fptr(c, p + ".in_proj_bias");
-        if (!w || !bsrc) return RIFT_ERR_ARG;
-        if (!c->dec_wqkv[i][k]) { HIPCHK(c, hipMalloc((void**)&c->dec_wqkv[i][k], 384 * 128 * 2)); HIPCHK(c, hipMalloc((void**)&c->dec_bqkv[i][k], 384 * 4)); }
-        hipLaunchKernelGGL(pack_rows_indexed_kernel, dim3(cdiv(384 * 128, 256)), dim3(256), 0, c->stream, w, bsrc, (const int*)c->enc_idx,
-                           384, 128, c->dec_wqkv[i][k], c->dec_bqkv[i][k]);
-      }
-  }
-  {  // per-layer parameter block of the fused decoder kernel (layout: RIFT_DEC_NPAR in dec_fused.h)
-    if (!c->dec_par) HIPCHK(c, hipMalloc((void**)&c->dec_par, (size_t)4 * RIFT_DEC_NPAR * 4));
-    for (int i = 0; i < 4; ++i) {
-      const std::string p = PD + ".decoder_blocks." + std::to_string(i);
-      float* dst = c->dec_par + (size_t)i * RIFT_DEC_NPAR;
-      auto put = [&](const float* src, int n) -> int {
-        if (!src) return RIFT_ERR_ARG;
-        HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
-        dst += n;
-        return RIFT_OK;
-      };
-      for (int k = 0; k < 4; ++k) {
-        TRY(put(fptr(c, p + ".norm" + std::to_string(k + 1) + ".weight"), 128));
-        TRY(put(fptr(c, p + ".norm" + std::to_string(k + 1) + ".bias"), 128));
-      }
-      TRY(put(c->dec_bqkv[i][0], 384)); TRY(put(c->pw[p + ".r2r_attn.out_proj"].bias, 128));
-      TRY(put(c->dec_bqkv[i][1], 384)); TRY(put(c->pw[p + ".m2m_attn.out_proj"].bias, 128));
-      TRY(put(c->pw[p + ".cross_attn.q"].bias, 128)); TRY(put(c->pw[p + ".cross_attn.out_proj"].bias, 128));
-      TRY(put(c->pw[p + ".ffn.0"].bias, 512)); TRY(put(c->pw[p + ".ffn.3"].bias, 128));
-      if (dst != c->dec_par + (size_t)(i + 1) * RIFT_DEC_NPAR) return RIFT_ERR_STATE;
-    }
   }
   {  // wave-private decoder kernel (dec_w.h): the layers' weight stream and parameter blocks
     DecWSrc q; memset(&q, 0, sizeof(q));

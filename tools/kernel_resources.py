@@ -5,9 +5,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from rift_amd import build as b
 
-cmd = [b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0",
-       "-Rpass-analysis=kernel-resource-usage", os.path.join(b.CSRC, "engine.hip"), "-o", "/tmp/_kr.so"] + sys.argv[2:]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+out = ""
+for tu, extra in (("engine.hip", []), ("dec_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l2w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
+    cmd = [b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage"] + extra + \
+          [os.path.join(b.CSRC, tu), "-o", "/tmp/_kr.o"] + sys.argv[2:]
+    out += subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
     m = re.search(r"remark: (.*?) \[-Rpass", line)

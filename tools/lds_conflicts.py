@@ -41,7 +41,7 @@ def report(name, kind, f):
 
 
 def decoder_patterns(XS=132, XN=136, CB=200, KC=72, VS=104, verbose=True):
-    """Representative wave-instructions of dec_fused_kernel / enc_fused_kernel (element strides; xs fp32, the rest bf16)."""
+    """Representative wave-instructions of the LDS-resident kernels (enc_fused_kernel; the round-1 decoder kernel had the same tiles) (element strides; xs fp32, the rest bf16)."""
     pats = [
         ("MFMA operand fragment from xn / ao (row l15, k l4*8)", "read_b128", lambda l15, l4, l: (l15 * XN + l4 * 8) * 2),
         ("MFMA operand fragment from cb (q | k, FFN hidden)", "read_b128", lambda l15, l4, l: (l15 * CB + l4 * 8) * 2),
