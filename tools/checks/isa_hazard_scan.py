@@ -1,0 +1,81 @@
+"""Scan the gfx950 ISA of the three translation units for operand hazards that hipcc does not pad INSIDE or right behind inline asm:
+  * a VALU write of a VGPR followed within fewer than 2 wait states by an MFMA reading it as A / B / C, by v_permlane*_swap or by a DPP
+    instruction reading it (tools/ubench/cvt_mfma_hazard.hip: the MFMA case measured on MI355X -- 0 or 1 states read the OLD register);
+  * v_readfirstlane writing an SGPR followed within fewer than 5 wait states by global_load_lds / buffer / global instructions using it.
+The round-2 kernels hide `v_cvt_pk_bf16_f32`, the LDS-DMA and the group GEMM in asm statements; this scan is how their padding is checked.
+    python tools/checks/isa_hazard_scan.py            # compiles (no GPU needed) and scans; exit status 1 on a finding"""
+import os, re, subprocess, sys, tempfile
+from collections import Counter
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from rift_amd import build as b
+
+
+def regs(tok, kind="v"):
+    tok = tok.rstrip(",")
+    m = re.match(kind + r"\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(kind + r"(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def states(l):
+    return int(l.split()[1]) + 1 if l.startswith("s_nop") else 1
+
+
+def scan(path):
+    ins = [l.strip() for l in open(path).read().split("\n")
+           if l.startswith("\t") and l.strip() and not l.strip().startswith(";") and not l.strip().startswith(".")]
+    bad = []
+    for k, l in enumerate(ins):
+        toks = l.split()
+        op = toks[0]
+        if op.startswith("v_readfirstlane") and len(toks) > 1:
+            dst, st = regs(toks[1], "s"), 0
+            for d in range(1, 7):
+                if k + d >= len(ins) or st >= 5:
+                    break
+                l2 = ins[k + d]
+                if l2.split()[0].startswith(("global_", "buffer_", "scratch_")) and dst & set().union(*[regs(t, "s") for t in l2.split()[1:]]):
+                    bad.append(("sgpr->vmem", st, l, l2))
+                st += states(l2)
+            continue
+        if not op.startswith("v_") or op.startswith(("v_mfma", "v_cmp")) or len(toks) < 2:
+            continue
+        dst = regs(toks[1])
+        if not dst:
+            continue
+        st = 0
+        for d in range(1, 4):
+            if k + d >= len(ins) or st >= 2:
+                break
+            l2 = ins[k + d]
+            op2, t2 = l2.split()[0], l2.split()[1:]
+            if op2.startswith("v_mfma") and dst & set().union(*[regs(t) for t in t2[1:4]]):
+                bad.append(("valu->mfma", st, l, l2))
+            if "permlane" in op2 and dst & set().union(*[regs(t) for t in t2[0:2]]):
+                bad.append(("valu->permlane", st, l, l2))
+            if ("quad_perm" in l2 or "row_" in l2 or "_dpp" in op2) and dst & set().union(*[regs(t) for t in t2[1:3]]):
+                bad.append(("valu->dpp", st, l, l2))
+            st += states(l2)
+    return bad
+
+
+def main():
+    total = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for tu, extra in (("engine.hip", []), ("dec_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l2w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
+            out = os.path.join(tmp, tu + ".s")
+            subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w"] + extra +
+                                  [os.path.join(b.CSRC, tu), "-o", out])
+            bad = scan(out)
+            print(f"{tu}: {sum(1 for _ in open(out))} lines, findings {dict(Counter(x[0] for x in bad))}")
+            for x in bad[:10]:
+                print("   ", x)
+            total += len(bad)
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
