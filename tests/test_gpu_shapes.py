@@ -180,3 +180,35 @@ def test_decoder_on_few_and_many_reference_lines(ffi, r_max):
     assert float((fused - exact).abs().cpu()[rv].max()) < 4e-2
     assert torch.equal(fused, again)
     eng.close()
+
+
+@pytest.mark.parametrize("agents,nscenes", [(5, 1), (7, 3), (64, 2), (33, 5)])
+def test_agent_counts_off_the_tile_grid(ffi, agents, nscenes):
+    """The NAT kernels tile agents in fours (levels 0, 1) and threes (level 2, 8 tiles per round): agent counts that leave partial tiles, a
+    partial last round and idle waves -- against the oracle, eval and BatchNorm batch statistics."""
+    scenes = [syn.make_scene(9100 + i, num_agents=agents, num_polygons=7, r_min=1, r_max=3) for i in range(nscenes)]
+    _check(ffi, scenes, train=False)
+    _check(ffi, scenes, train=True)
+
+
+def test_train_mode_forward_is_bit_reproducible(ffi):
+    """Two launches with the same seed give the same bits (train mode: dropout, DropPath, BatchNorm batch statistics).  The wave-private
+    kernels keep operands in registers between a conversion and the MFMA that reads it; a missing wait state there shows up as
+    launch-to-launch differences of whole tiles (the VALU -> MFMA operand hazard)."""
+    sd = H.weights()
+    data = syn.collate_scenes([syn.make_scene(9300 + i) for i in range(48)])["cur_pluto_feature_torch"]
+    eng = ffi.Engine("cuda:0")
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    first = None
+    for _ in range(6):
+        out = eng.forward(data, train=True, seed=11, bn_update=False)
+        cur = (out["probability"].clone(), eng.tap("enc_out").clone(), eng.tap("dec3").clone())
+        torch.cuda.synchronize()
+        if first is None:
+            first = cur
+        else:
+            for a, b in zip(first, cur):
+                assert torch.equal(a, b)
+    other = eng.forward(data, train=True, seed=12, bn_update=False)["probability"]
+    assert not torch.equal(other, first[0])
+    eng.close()
