@@ -40,6 +40,7 @@ namespace rift {
 #define DECW_PAR_LAYER (DECW_E_N + DECW_L_N)
 #define DECW_XS 132
 #define DECW_LDS_BYTES (2 * 32768 + 96 * DECW_XS * 4 + DECW_PAR_LAYER * 4 + 96 * 4 + 96 * 4 + 16)
+#define DECW_LDS_DENSE_BYTES (2 * 32768 + 2 * DECW_PAR_LAYER * 4 + 192 * 4 + 12 * 16 * 4 + 16)
 #define DECW_ROWS 96                            // dropout counter stride per scene
 
 struct DecWSrc {
@@ -58,8 +59,9 @@ struct DecWP {
   const uint8_t* r_kpm;         // (bs*R) reference-line padding
   const uint8_t* q_kpm;         // (q_bs*R) padding rows the r2r quirk indexes (see DecFusedP)
   int q_bs, q_off;
-  int bs, N, R;                 // N <= 96 tokens, R <= 8 reference lines
-  const unsigned short* KV;     // (bs, 4, DECW_KV_FRAGS, 512) bf16 fragment images from the encoder kernel's tail
+  int bs, N, R;                 // N <= 96 tokens and R <= 8 reference lines: the standard kernel; up to N <= 192, R <= 16: the dense-traffic variant
+  const unsigned short* KV;     // (bs, 4, DECW_KV_FRAGS, 512) bf16 fragment images from the encoder kernel's tail; dense variant: (bs, 4, 96, 512)
+                                // from dec_kv_frag_kernel (per head: 12 K fragments, then V^T (dim tile, key pair))
   const unsigned short* img;    // pack_decw_kernel
   const float* par;
   float dropout; uint32_t seed, stream;

@@ -2,6 +2,7 @@
 #include "common.h"
 #include "dec_w.h"
 #include "wp_stream.h"
+#include <type_traits>
 
 namespace rift {
 
@@ -71,23 +72,36 @@ __device__ __forceinline__ uint32_t decw_step(uint32_t x) {
 }
 // DROP: train mode (dropout 0.1 at eight sites of every layer) -- a template parameter, so that the per-site tests are not sixteen uniform
 // branches per epilogue
-template <bool DROP>
+// DENSE: the dense-traffic shapes (BASELINE configs[4]: up to 16 reference lines, up to 192 tokens).  r2r tiles hold ONE mode x 16 lines
+// (12 tiles), m2m / cross / FFN tiles one line each (up to 16): both tilings run in rounds of eight tiles, the sub-block's groups are streamed
+// once per round; the residual changes tiling through the query array in global memory (release / acquire fences around the group barrier)
+// instead of the 96-row LDS buffer, the parameter blocks of two layers are resident (double-buffered by layer parity), and the scene's
+// K | V^T operands come as four per-head groups of 12 key tiles (dec_kv.h writes them).
+template <bool DROP, bool DENSE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dec_w_kernel(DecWP p) {
   constexpr int M = 12, XS = DECW_XS;
+  constexpr int NS = DENSE ? 16 : 8;             // reference-line slots of an r2r tile
+  constexpr int NKT = DENSE ? 12 : 6;            // key tiles of the cross attention
+  constexpr int NTA = DENSE ? 12 : 6;            // r2r tiles: one mode each / one mode pair each
+  constexpr int RA = DENSE ? 2 : 1;              // rounds of eight tiles in the r2r tiling
+  constexpr int GB = DENSE ? 18 : 16;            // groups of the reference-line tiling: m2m 4 | cross q | K|V^T 4 or 2 | cross out | FFN 8
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* ring = smem_raw;
-  float* xs = reinterpret_cast<float*>(smem_raw + 2 * 32768);
-  float* parE = xs + 96 * XS;
+  float* xs = reinterpret_cast<float*>(smem_raw + 2 * 32768);                  // (not DENSE) [96][XS] residual hand-over
+  float* parbase = DENSE ? xs : xs + 96 * XS;                                   // DENSE: [2][DECW_PAR_LAYER] by layer parity
+  float* parE = parbase;
   float* parL = parE + DECW_E_N;
-  float* smaskf = parL + DECW_L_N;                                             // [96] encoder key mask as 0 / -inf
-  float* qmaskf = smaskf + 96;                                                 // [12][8] r2r quirk rows as 0 / -inf
-  unsigned char* rz = reinterpret_cast<unsigned char*>(qmaskf + 96);           // [8] padded reference lines of this scene
+  float* smaskf = parbase + (DENSE ? 2 : 1) * DECW_PAR_LAYER;                  // [16 NKT] encoder key mask as 0 / -inf
+  float* qmaskf = smaskf + 16 * NKT;                                           // [12][NS] r2r quirk rows as 0 / -inf
+  unsigned char* rz = reinterpret_cast<unsigned char*>(qmaskf + 12 * NS);      // [NS] padded reference lines of this scene
   const int tid = threadIdx.x;
   int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;            // re-derived through an opaque zero every layer (see the loop)
   const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6);
   int wv = wv0;
   const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
   const bool six = N > 80;
+  const int RB = DENSE ? (R > 8 ? 2 : 1) : 1;    // rounds of eight tiles in the reference-line tiling
+  const int GL = 4 * RA + GB * RB;               // groups of a layer (even)
   const size_t qrow0 = (size_t)b * NQ;
   const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
   const uint32_t thr16 = drop_thr16(dp);
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // a contiguous source of nfrag fragments -> LDS byte offset dst.  Who loads: with R <= 6 waves 6 and 7 own no tile in either tiling, and
   // waves 2 and 3 are alone on their SIMDs among the working waves (6 tiles on 4 SIMDs): those four carry the stream, the waves of the
   // doubly loaded SIMDs 0 and 1 go from the barrier straight to their MFMAs.  Otherwise all eight waves share it.
-  const bool ld_few = R <= 6;
+  const bool ld_few = !DENSE && R <= 6;
   auto dma = [&](const void* src, uint32_t dst, int nfrag) {
     if ((ld_few && !(wv & 2)) || (p.dbg & 8)) return;            // (dbg 8: no stream at all -- compute on whatever LDS holds, timing only)
     const int lw = ld_few ? (wv & 1) + ((wv >> 2) << 1) : wv, ln = ld_few ? 4 : 8;
@@ -117,35 +131,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto W = [&](int slot, int f) { return *reinterpret_cast<const bf16x8*>(ring + slot * 32768 + f * 1024 + lane * 16); };
 
   const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.img);
-  const unsigned char* kvimg = reinterpret_cast<const unsigned char*>(p.KV) + (size_t)b * 4 * DECW_KV_FRAGS * 1024;
-  const uint32_t OFF_E = 2 * 32768 + 96 * XS * 4, OFF_L = OFF_E + DECW_E_N * 4;
-  // prologue: first group + both parameter regions of layer 0 in flight, then the queries and masks
+  constexpr int KVF = DENSE ? 96 : DECW_KV_FRAGS;                              // K | V^T fragments per (scene, layer)
+  const unsigned char* kvimg = reinterpret_cast<const unsigned char*>(p.KV) + (size_t)b * 4 * KVF * 1024;
+  const uint32_t OFF_P = 2 * 32768 + (DENSE ? 0 : 96 * XS * 4), OFF_E = OFF_P, OFF_L = OFF_E + DECW_E_N * 4;
+  // prologue: first group + the parameter block of layer 0 in flight, then the queries and masks
   dma(wimg, 0, 32);
   dma(p.par, OFF_E, 18);
   dma(p.par + DECW_E_N, OFF_L, 6);
-  for (int i = tid; i < 96 * 32; i += 512) {
-    const int r = i >> 5, c4 = (i & 31) * 4;
-    if (r < NQ) *reinterpret_cast<float4*>(xs + r * XS + c4) = *reinterpret_cast<const float4*>(p.Q + (qrow0 + r) * 128 + c4);
+  if (!DENSE) {
+    for (int i = tid; i < 96 * 32; i += 512) {
+      const int r = i >> 5, c4 = (i & 31) * 4;
+      if (r < NQ) *reinterpret_cast<float4*>(xs + r * XS + c4) = *reinterpret_cast<const float4*>(p.Q + (qrow0 + r) * 128 + c4);
+    }
   }
-  if (tid < 96) smaskf[tid] = ((tid >= N) || p.kpm[(size_t)b * N + tid]) ? -INFINITY : 0.f;
-  else if (tid < 192) {            // quirk: mode m of scene b uses the padding row of scene (b*12+m) % bs (planning_decoder.py:56-60)
-    const int i = tid - 96, m = i >> 3, r = i & 7;
+  for (int i = tid; i < 16 * NKT; i += 512) smaskf[i] = ((i >= N) || p.kpm[(size_t)b * N + i]) ? -INFINITY : 0.f;
+  for (int i = tid; i < 12 * NS; i += 512) {   // quirk: mode m of scene b uses the padding row of scene (b*12+m) % bs (planning_decoder.py:56-60)
+    const int m = i / NS, r = i - m * NS;
     qmaskf[i] = ((r >= R) || p.q_kpm[(size_t)(((p.q_off + b) * M + m) % p.q_bs) * R + r]) ? -INFINITY : 0.f;
-  } else if (tid < 200) rz[tid - 192] = (tid - 192 >= R) || p.r_kpm[(size_t)b * R + tid - 192];
+  }
+  if (tid < NS) rz[tid] = (tid >= R) || p.r_kpm[(size_t)b * R + tid];
 
   bool actA, actB, a_ok, b_ok;
-  int a_sub, a_row, b_row;
-  // tiling A (mode pair wv): slot l15 = sub * 8 + r;  tiling B (reference line wv): slot l15 = mode
+  int a_sub, a_row, b_row, tileA, tileB;
+  // tiling A: slot l15 = sub * 8 + r of mode pair tileA (DENSE: slot l15 = r of mode tileA);  tiling B (reference line tileB): slot l15 = mode
   auto derive = [&](int zv, int zs) {
     lane = (tid & 63) + zv; l15 = lane & 15; l4 = lane >> 4; voff = (uint32_t)lane * 16u;
     wv = wv0 + zs; lds0 = lds00 + (uint32_t)zs;
-    actA = wv < 6 && !(p.dbg & 1); actB = wv < R && !(p.dbg & 1);
-    a_sub = l15 >> 3;
-    const int a_r = l15 & 7;
+  };
+  auto set_tiles = [&](int ra, int rb) {
+    tileA = ra * 8 + wv; tileB = rb * 8 + wv;
+    actA = tileA < NTA && !(p.dbg & 1); actB = tileB < R && !(p.dbg & 1);
+    a_sub = DENSE ? 0 : (l15 >> 3);
+    const int a_r = DENSE ? l15 : (l15 & 7);
     a_ok = a_r < R; b_ok = l15 < M;
-    a_row = a_ok ? a_r * M + 2 * wv + a_sub : 0; b_row = b_ok ? wv * M + l15 : 0;
+    a_row = a_ok ? a_r * M + (DENSE ? tileA : 2 * tileA + a_sub) : 0; b_row = b_ok ? tileB * M + l15 : 0;
   };
   derive(0, 0);
+  set_tiles(0, 0);
 
   auto init8 = [&](f32x4 (&a)[8], const float* bias) {        // accumulators start from the bias row (4 channels per n-tile of this lane)
 #pragma unroll
@@ -155,19 +177,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) a[nt] = Z;
   };
+  // residual hand-over between the tilings: the LDS buffer xs, or (DENSE) the query array itself -- written with a release fence ahead of
+  // the group barrier, read behind an acquire fence (the vector L1 of this CU may hold the rows from the previous layer)
   auto read_xs = [&](f32x4 (&res)[8], int row, bool ok) {
+    const float* src = DENSE ? p.Q + (qrow0 + row) * 128 + l4 * 4 : xs + row * XS + l4 * 4;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      const float4 v = *reinterpret_cast<const float4*>(xs + row * XS + nt * 16 + l4 * 4);
+      const float4 v = *reinterpret_cast<const float4*>(src + nt * 16);
       res[nt] = ok ? (f32x4){v.x, v.y, v.z, v.w} : Z;
     }
   };
   auto write_xs = [&](const f32x4 (&res)[8], int row, bool ok) {
     if (ok) {
+      float* dst = DENSE ? p.Q + (qrow0 + row) * 128 + l4 * 4 : xs + row * XS + l4 * 4;
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<float4*>(xs + row * XS + nt * 16 + l4 * 4) = make_float4(res[nt][0], res[nt][1], res[nt][2], res[nt][3]);
+      for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<float4*>(dst + nt * 16) = make_float4(res[nt][0], res[nt][1], res[nt][2], res[nt][3]);
     }
   };
+  auto publish = [&]() { if (DENSE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); };     // after the last write_xs of a tiling, before its barrier
+  auto acquire = [&]() { if (DENSE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); };     // after that barrier, before the first read_xs
   // res -> xb (bf16 operands of the four k-steps); g: gamma 128 | beta 128 in LDS.  Two-pass statistics as torch; vector (packed fp32) math.
   auto layer_norm = [&](const f32x4 (&res)[8], bf16x8 (&xb)[4], const float* g) {
     f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
@@ -240,65 +268,84 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       else res[nt] += acc[nt];
     }
   };
-  // cross attention of heads 2c, 2c+1 against the K | V^T fragments in a ring slot (96 keys); the key-padding mask is the score accumulator
-  auto cross_half = [&](int slot, int c, const bf16x8 (&qf)[4], bf16x8 (&ao)[4]) {
+  // cross attention of `nh` heads starting at h0 against the K | V^T fragments in a ring slot (16 NKT keys); the key-padding mask is the score
+  // accumulator.  Fragment order of the slot: K (kt, hh) at kt * nh + hh, V^T (hh, dim tile d, key pair pt) behind them.
+  auto cross_heads = [&](int slot, int h0, auto nh_t, const bf16x8 (&qf)[4], bf16x8 (&ao)[4]) {
+    constexpr int nh = decltype(nh_t)::value;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * c + hh;
-      f32x4 s[6];
+    for (int hh = 0; hh < nh; ++hh) {
+      const int h = h0 + hh;
+      f32x4 s[NKT];
+      constexpr int NK0 = DENSE ? NKT : 5;         // (not DENSE: keys 80..95 exist only in batches with more than 80 tokens)
 #pragma unroll
-      for (int kt = 0; kt < 5; ++kt) {
+      for (int kt = 0; kt < NK0; ++kt) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, kt * 2 + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, kt * nh + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
       }
       float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-      for (int kt = 1; kt < 5; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-      if (six) {                                  // keys 80..95 exist only in batches with more than 80 tokens
+      for (int kt = 1; kt < NK0; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+      if (!DENSE && six) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + 80 + l4 * 4);
-        s[5] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 10 + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
-        m = fmaxf(fmaxf(m, fmaxf(s[5][0], s[5][1])), fmaxf(s[5][2], s[5][3]));
+        s[NKT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 5 * nh + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+        m = fmaxf(fmaxf(m, fmaxf(s[NKT - 1][0], s[NKT - 1][1])), fmaxf(s[NKT - 1][2], s[NKT - 1][3]));
       }
       m = rows_max(m);
       f32x4 l4s = Z;
 #pragma unroll
-      for (int kt = 0; kt < 5; ++kt) {
+      for (int kt = 0; kt < NK0; ++kt) {
         s[kt] = (f32x4){__builtin_amdgcn_exp2f(s[kt][0] - m), __builtin_amdgcn_exp2f(s[kt][1] - m), __builtin_amdgcn_exp2f(s[kt][2] - m), __builtin_amdgcn_exp2f(s[kt][3] - m)};
         l4s += s[kt];
         if (DROP) s[kt] *= keep4(kt);
       }
-      if (six) {
-        s[5] = (f32x4){__builtin_amdgcn_exp2f(s[5][0] - m), __builtin_amdgcn_exp2f(s[5][1] - m), __builtin_amdgcn_exp2f(s[5][2] - m), __builtin_amdgcn_exp2f(s[5][3] - m)};
-        l4s += s[5];
-        if (DROP) s[5] *= keep4(5);
-      } else s[5] = Z;
+      if (!DENSE) {
+        if (six) {
+          s[5] = (f32x4){__builtin_amdgcn_exp2f(s[5][0] - m), __builtin_amdgcn_exp2f(s[5][1] - m), __builtin_amdgcn_exp2f(s[5][2] - m), __builtin_amdgcn_exp2f(s[5][3] - m)};
+          l4s += s[5];
+          if (DROP) s[5] *= keep4(5);
+        } else s[5] = Z;
+      }
       const float lsum = rows_sum((l4s[0] + l4s[1]) + (l4s[2] + l4s[3]));
       f32x4 o0 = Z, o1 = Z;
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt) {
+      for (int pt = 0; pt < NKT / 2; ++pt) {
         const bf16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
-        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 12 + (hh * 2 + 0) * 3 + pt), pf, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 12 + (hh * 2 + 1) * 3 + pt), pf, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, NKT * nh + (hh * 2 + 0) * (NKT / 2) + pt), pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, NKT * nh + (hh * 2 + 1) * (NKT / 2) + pt), pf, o1, 0, 0, 0);
       }
       const float inv = __builtin_amdgcn_rcpf(lsum);
       ao[h] = l0w_pack8(o0 * inv, o1 * inv);
     }
   };
 
-  // after the barrier that opens group k of layer li: request group k + 1 into the other ring slot, plus the parameter region that rides on
-  // this boundary.  Stream order: 0 r2r q | 1 r2r k | 2 r2r v | 3 r2r out | 4 m2m q | 5 m2m k | 6 m2m v | 7 m2m out | 8 cross q |
-  // 9 scene K|V^T heads {0,1} | 10 scene K|V^T heads {2,3} | 11 cross out | 12 + 2 hc ffn.0 chunk hc | 13 + 2 hc ffn.3 chunk hc
-  auto issue = [&](int li, int k) {
+  // ---- the operand stream of a layer: RA rounds of the r2r groups [r2r q | k | v | out], then RB rounds of the reference-line groups
+  // [m2m q | k | v | out | cross q | scene K|V^T (two head pairs; DENSE: four heads) | cross out | (ffn.0 chunk c, ffn.3 chunk c) x 4];
+  // position `pos` of layer li has sequence number li * GL + pos and lands in ring slot (pos & 1) (GL is even).
+  auto request = [&](int li, int pos) {          // the group at (li, pos); pos == GL means the first group of the next layer
+    if (pos >= GL) { pos = 0; ++li; }
+    if (li >= 4) return;
     const unsigned char* wl = wimg + (size_t)li * DECW_LAYER_FRAGS * 1024;
-    const unsigned char* kvl = kvimg + (size_t)li * DECW_KV_FRAGS * 1024;
-    const int g = k + 1;
-    const uint32_t dst = (uint32_t)(g & 1) * 32768u;
-    if (g == 9) dma(kvl, dst, 24);
-    else if (g == 10) dma(kvl + 24 * 1024, dst, 24);
-    else if (g < 20) dma(wl + (size_t)(g < 9 ? g : g - 2) * 32768, dst, 32);
-    else if (li + 1 < 4) dma(wl + (size_t)DECW_LAYER_FRAGS * 1024, dst, 32);
-    if (k == 0 && li > 0) dma(p.par + (size_t)li * DECW_PAR_LAYER + DECW_E_N, OFF_L, 6);      // region L of this layer: the previous FFN epilogue is over
-    if (k == 12 && li + 1 < 4) dma(p.par + (size_t)(li + 1) * DECW_PAR_LAYER, OFF_E, 18);      // region E of the next layer: r2r / m2m are over
+    const unsigned char* kvl = kvimg + (size_t)li * KVF * 1024;
+    const uint32_t dst = (uint32_t)(pos & 1) * 32768u;
+    if (pos < 4 * RA) { dma(wl + (size_t)(pos & 3) * 32768, dst, 32); return; }
+    const int q = (pos - 4 * RA) % GB;
+    constexpr int NKV = DENSE ? 4 : 2;           // K | V^T groups, 24 fragments each
+    if (q < 5) dma(wl + (size_t)(4 + q) * 32768, dst, 32);
+    else if (q < 5 + NKV) dma(kvl + (size_t)(q - 5) * 24 * 1024, dst, 24);
+    else dma(wl + (size_t)(9 + q - 5 - NKV) * 32768, dst, 32);
+  };
+  // group boundary that opens position `pos` of layer li: my share of the group has landed; after the barrier everybody's has, and nobody
+  // reads the other slot any more: the group after it goes there.  The parameter blocks ride on fixed boundaries.  (`pos` is a literal at
+  // the call sites of the standard kernel, so the stream addresses fold; the dense variant adds its round offsets at run time.)
+  auto bnd = [&](int li, int pos) {
+    sync();
+    request(li, pos + 1);
+    if (DENSE) {             // both regions of the NEXT layer into the other parity block, any time during this layer
+      if (pos == 0 && li + 1 < 4) dma(p.par + (size_t)(li + 1) * DECW_PAR_LAYER, OFF_P + (uint32_t)((li + 1) & 1) * DECW_PAR_LAYER * 4, 24);
+    } else {
+      if (pos == 0 && li > 0) dma(p.par + (size_t)li * DECW_PAR_LAYER + DECW_E_N, OFF_L, 6);        // region L of this layer: the previous FFN epilogue is over
+      if (pos == 12 && li + 1 < 4) dma(p.par + (size_t)(li + 1) * DECW_PAR_LAYER, OFF_E, 18);       // region E of the next layer: r2r / m2m are over
+    }
   };
 
 #pragma unroll 1
@@ -310,127 +357,157 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
       derive(zv, zs);
     }
-
+    if (DENSE) { parE = parbase + (li & 1) * DECW_PAR_LAYER; parL = parE + DECW_E_N; }
     // Waves without a tile in a tiling run the same boundaries (barrier + their share of the stream) and nothing else; the working waves'
-    // code is straight-line between the boundaries of a tiling, so that register liveness follows the phases.
-    // ================= tiling A: r2r over the reference lines of a mode pair =================
-    if (actA) {
-      f32x4 res[8], acc[8];
-      bf16x8 xb[4], qf[4], kf[4], ao[4];
-      bf16x8 vf[8];
-      sync(); issue(li, 0);                                   // ---- group 0: r2r q
-      read_xs(res, a_row, a_ok);
-      layer_norm(res, xb, parE + DECW_E_LN1);
-      init8(acc, parE + DECW_E_BR2R); gemm(0, xb, acc);
-      to_heads(acc, qf);
-      init8(acc, parE + DECW_E_BR2R + 128);                   // (bias rows are requested ahead of the barrier that hides their latency)
-      sync(); issue(li, 1);                                   // ---- group 1: r2r k
-      gemm(1, xb, acc);
-      to_heads(acc, kf);
-      sync(); issue(li, 2);                                   // ---- group 2: r2r v + attention
-      gemm_v(0, xb, vf, parE + DECW_E_BR2R + 256);
-      {   // keys 4 l4 .. + 3 = reference lines (l4 & 1) * 4 .. of mode 2 wv + (l4 >> 1): other-mode keys and the quirk's padded lines are masked
-        const float4 mk = *reinterpret_cast<const float4*>(qmaskf + (2 * wv + (l4 >> 1)) * 8 + (l4 & 1) * 4);
-        const bool cross = (l4 >> 1) != a_sub;
-        const float ninf = -INFINITY;
-        self_attention((f32x4){cross ? ninf : mk.x, cross ? ninf : mk.y, cross ? ninf : mk.z, cross ? ninf : mk.w}, qf, kf, vf, ao);
-      }
-      init8(acc, parE + DECW_E_BR2RO);
-      sync(); issue(li, 3);                                   // ---- group 3: r2r out_proj, residual, hand-over to the reference-line tiling
-      gemm(1, ao, acc);
-      residual(res, acc);
-      write_xs(res, a_row, a_ok);
-    } else {
+    // code is straight-line between the boundaries of a tiling, so that register liveness follows the phases.  A group at round-relative
+    // position k sits in ring slot k & 1 (the rounds start at even positions).
+    // ================= tiling A: r2r over the reference lines of a mode pair (DENSE: of one mode) =================
 #pragma unroll 1
-      for (int k = 0; k < 4; ++k) { sync(); issue(li, k); }
-    }
-    // ================= tiling B: m2m, cross attention, FFN of one reference line =================
-    if (actB) {
-      f32x4 res[8], acc[8];
-      bf16x8 xb[4], qf[4], kf[4], ao[4];
-      bf16x8 vf[8];
-      sync(); issue(li, 4);                                   // ---- group 4: m2m q (+ m_pos)
-      read_xs(res, b_row, b_ok);
-      layer_norm(res, xb, parE + DECW_E_LN2);
-      init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS); gemm(0, xb, acc);
-      to_heads(acc, qf);
-      init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS + 128);
-      sync(); issue(li, 5);                                   // ---- group 5: m2m k (+ m_pos)
-      gemm(1, xb, acc);
-      to_heads(acc, kf);
-      sync(); issue(li, 6);                                   // ---- group 6: m2m v + attention over the modes
-      gemm_v(0, xb, vf, parE + DECW_E_BM2MV);
-      { const float mk = l4 == 3 ? -INFINITY : 0.f; self_attention((f32x4){mk, mk, mk, mk}, qf, kf, vf, ao); }   // keys 12..15 are padding slots
-      init8(acc, parE + DECW_E_BM2MO);
-      sync(); issue(li, 7);                                   // ---- group 7: m2m out_proj, residual, padded lines zeroed (:70-72), LayerNorm
-      gemm(1, ao, acc);
-      residual(res, acc);
-      if (rz[wv]) zero8(res);
-      layer_norm(res, xb, parL + DECW_L_LN3);
-      init8(acc, parL + DECW_L_BCQ);
-      sync(); issue(li, 8);                                   // ---- group 8: cross q
-      gemm(0, xb, acc);
-      to_heads(acc, qf);
-      sync(); issue(li, 9);                                   // ---- groups 9, 10: the scene's K | V^T, heads {0,1} then {2,3}
-      cross_half(1, 0, qf, ao);
-      sync(); issue(li, 10);
-      cross_half(0, 1, qf, ao);
-      init8(acc, parL + DECW_L_BCO);
-      sync(); issue(li, 11);                                  // ---- group 11: cross out_proj, residual, LayerNorm for the FFN
-      gemm(1, ao, acc);
-      residual(res, acc);
-      layer_norm(res, xb, parL + DECW_L_LN4);
-      f32x4 acc2[8];
-      init8(acc2, parL + DECW_L_BF2);
-#pragma unroll 1
-      for (int hc = 0; hc < 4; ++hc) {                        // ---- groups 12..19: ffn.0 chunk -> ReLU, dropout -> ffn.3 partial
-        init8(acc, parL + DECW_L_BF1 + hc * 128);
-        sync(); issue(li, 12 + 2 * hc);
-        gemm(0, xb, acc);
-        bf16x8 hb[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          f32x4 v[2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const f32x4 a = acc[2 * ks + q];
-            v[q] = (f32x4){fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)};
-            if (DROP) v[q] *= keep4(2 * ks + q);
-          }
-          hb[ks] = l0w_pack8(v[0], v[1]);
+    for (int ra = 0; ra < RA; ++ra) {
+      set_tiles(ra, 0);
+      const int pa = DENSE ? 4 * ra : 0;                          // first position of this round
+      if (actA) {
+        f32x4 res[8], acc[8];
+        bf16x8 xb[4], qf[4], kf[4], ao[4];
+        bf16x8 vf[8];
+        bnd(li, pa + 0);                                        // ---- r2r q
+        if (ra == 0) acquire();
+        read_xs(res, a_row, a_ok);
+        layer_norm(res, xb, parE + DECW_E_LN1);
+        init8(acc, parE + DECW_E_BR2R); gemm(0, xb, acc);
+        to_heads(acc, qf);
+        init8(acc, parE + DECW_E_BR2R + 128);                   // (bias rows are requested ahead of the barrier that hides their latency)
+        bnd(li, pa + 1);                                        // ---- r2r k
+        gemm(1, xb, acc);
+        to_heads(acc, kf);
+        bnd(li, pa + 2);                                        // ---- r2r v + attention
+        gemm_v(0, xb, vf, parE + DECW_E_BR2R + 256);
+        if (DENSE) {     // keys 4 l4 .. + 3 = reference lines of mode tileA: the quirk's padded lines are masked
+          const float4 mk = *reinterpret_cast<const float4*>(qmaskf + tileA * NS + l4 * 4);
+          self_attention((f32x4){mk.x, mk.y, mk.z, mk.w}, qf, kf, vf, ao);
+        } else {         // keys 4 l4 .. + 3 = reference lines (l4 & 1) * 4 .. of mode 2 tileA + (l4 >> 1): other-mode keys are masked as well
+          const float4 mk = *reinterpret_cast<const float4*>(qmaskf + (2 * tileA + (l4 >> 1)) * NS + (l4 & 1) * 4);
+          const bool cross = (l4 >> 1) != a_sub;
+          const float ninf = -INFINITY;
+          self_attention((f32x4){cross ? ninf : mk.x, cross ? ninf : mk.y, cross ? ninf : mk.z, cross ? ninf : mk.w}, qf, kf, vf, ao);
         }
-        sync(); issue(li, 13 + 2 * hc);
-        gemm(1, hb, acc2);
-      }
-      residual(res, acc2);
-      if (li + 1 < 4) write_xs(res, b_row, b_ok);
-      else if (b_ok) {
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
-          *reinterpret_cast<float4*>(p.Q + (qrow0 + b_row) * 128 + nt * 16 + l4 * 4) = make_float4(res[nt][0], res[nt][1], res[nt][2], res[nt][3]);
-      }
-    } else {
+        init8(acc, parE + DECW_E_BR2RO);
+        bnd(li, pa + 3);                                        // ---- r2r out_proj, residual, hand-over to the reference-line tiling
+        gemm(1, ao, acc);
+        residual(res, acc);
+        write_xs(res, a_row, a_ok);
+      } else {
 #pragma unroll 1
-      for (int k = 4; k < 20; ++k) { sync(); issue(li, k); }
+        for (int k = 0; k < 4; ++k) bnd(li, pa + k);
+      }
     }
+    publish();
+    // ================= tiling B: m2m, cross attention, FFN of one reference line =================
+#pragma unroll 1
+    for (int rb = 0; rb < RB; ++rb) {
+      set_tiles(0, rb);
+      const int pb = DENSE ? 4 * RA + GB * rb : 4;                // first position of this round
+      constexpr int KO = DENSE ? 9 : 7;                           // round-relative position of cross out_proj (behind the K | V^T groups)
+      if (actB) {
+        f32x4 res[8], acc[8];
+        bf16x8 xb[4], qf[4], kf[4], ao[4];
+        bf16x8 vf[8];
+        bnd(li, pb + 0);                                        // ---- m2m q (+ m_pos)
+        if (rb == 0) acquire();
+        read_xs(res, b_row, b_ok);
+        layer_norm(res, xb, parE + DECW_E_LN2);
+        init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS); gemm(0, xb, acc);
+        to_heads(acc, qf);
+        init8(acc, parE + DECW_E_PB + (b_ok ? l15 : 0) * DECW_PBS + 128);
+        bnd(li, pb + 1);                                        // ---- m2m k (+ m_pos)
+        gemm(1, xb, acc);
+        to_heads(acc, kf);
+        bnd(li, pb + 2);                                        // ---- m2m v + attention over the modes
+        gemm_v(0, xb, vf, parE + DECW_E_BM2MV);
+        { const float mk = l4 == 3 ? -INFINITY : 0.f; self_attention((f32x4){mk, mk, mk, mk}, qf, kf, vf, ao); }   // keys 12..15 are padding slots
+        init8(acc, parE + DECW_E_BM2MO);
+        bnd(li, pb + 3);                                        // ---- m2m out_proj, residual, padded lines zeroed (:70-72), LayerNorm
+        gemm(1, ao, acc);
+        residual(res, acc);
+        if (rz[tileB]) zero8(res);
+        layer_norm(res, xb, parL + DECW_L_LN3);
+        init8(acc, parL + DECW_L_BCQ);
+        bnd(li, pb + 4);                                        // ---- cross q
+        gemm(0, xb, acc);
+        to_heads(acc, qf);
+        if (DENSE) {                                            // ---- the scene's K | V^T: one group per head (DENSE) / per head pair
+#pragma unroll
+          for (int h = 0; h < 4; ++h) { bnd(li, pb + 5 + h); cross_heads((5 + h) & 1, h, std::integral_constant<int, 1>{}, qf, ao); }
+        } else {
+          bnd(li, pb + 5); cross_heads(1, 0, std::integral_constant<int, 2>{}, qf, ao);
+          bnd(li, pb + 6); cross_heads(0, 2, std::integral_constant<int, 2>{}, qf, ao);
+        }
+        init8(acc, parL + DECW_L_BCO);
+        bnd(li, pb + KO);                                       // ---- cross out_proj, residual, LayerNorm for the FFN
+        gemm(KO & 1, ao, acc);
+        residual(res, acc);
+        layer_norm(res, xb, parL + DECW_L_LN4);
+        f32x4 acc2[8];
+        init8(acc2, parL + DECW_L_BF2);
+#pragma unroll 1
+        for (int hc = 0; hc < 4; ++hc) {                        // ---- ffn.0 chunk -> ReLU, dropout -> ffn.3 partial
+          init8(acc, parL + DECW_L_BF1 + hc * 128);
+          bnd(li, pb + KO + 1 + 2 * hc);
+          gemm((KO + 1) & 1, xb, acc);
+          bf16x8 hb[4];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            f32x4 v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 a = acc[2 * ks + q];
+              v[q] = (f32x4){fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)};
+              if (DROP) v[q] *= keep4(2 * ks + q);
+            }
+            hb[ks] = l0w_pack8(v[0], v[1]);
+          }
+          bnd(li, pb + KO + 2 + 2 * hc);
+          gemm(KO & 1, hb, acc2);
+        }
+        residual(res, acc2);
+        if (DENSE || li + 1 < 4) write_xs(res, b_row, b_ok);
+        else if (b_ok) {
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt)
+            *reinterpret_cast<float4*>(p.Q + (qrow0 + b_row) * 128 + nt * 16 + l4 * 4) = make_float4(res[nt][0], res[nt][1], res[nt][2], res[nt][3]);
+        }
+      } else {
+#pragma unroll 1
+        for (int k = 0; k < GB; ++k) bnd(li, pb + k);
+      }
+    }
+    publish();
   }
-
   DTS();
 #undef DTS
 }
 
 
 int decw_set_attributes() {
-  const int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
-  return e ? e : (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
+  int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
+  if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
+  if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
+  if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
+  return e;
 }
 void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t stream) {
   const int n = 4 * DECW_LAYER_FRAGS * 512;
   hipLaunchKernelGGL(pack_decw_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, img, par);
 }
 void decw_launch(const DecWP& p, hipStream_t stream) {
-  if (p.dropout > 0.f) hipLaunchKernelGGL(dec_w_kernel<true>, dim3(p.bs), dim3(512), (size_t)DECW_LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL(dec_w_kernel<false>, dim3(p.bs), dim3(512), (size_t)DECW_LDS_BYTES, stream, p);
+  const bool dense = p.R > 8 || p.N > 96;        // the dense-traffic variant: rounds of eight tiles, hand-over through the query array
+  if (dense) {
+    if (p.dropout > 0.f) hipLaunchKernelGGL((dec_w_kernel<true, true>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_DENSE_BYTES, stream, p);
+    else hipLaunchKernelGGL((dec_w_kernel<false, true>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_DENSE_BYTES, stream, p);
+  } else {
+    if (p.dropout > 0.f) hipLaunchKernelGGL((dec_w_kernel<true, false>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((dec_w_kernel<false, false>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_BYTES, stream, p);
+  }
 }
 
 }  // namespace rift

@@ -23,6 +23,7 @@
 #include "enc_fused.h"
 #include "enc_fused.h"
 #include "dec_w.h"
+#include "dec_kv.h"
 #include "nat_l2w.h"
 #include "pe_fused.h"
 #include "fourier_fused.h"
@@ -416,6 +417,7 @@ int set_lds_attrs(RiftCtx* c) {
 #undef SETATTR
 #define SETATTR_N(K, N) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(N)))
   SETATTR_N(lds_poison_kernel, 160 * 1024);
+  SETATTR_N(dec_kv_frag_kernel, DEC_KV_LDS);
   SETATTR_N(pe_mid_kernel, PE_MID_LDS);   // these kernels also hold a few hundred bytes of static LDS
   SETATTR_N(pe_out_kernel, PE_OUT_LDS);
   SETATTR_N(fourier_fused_kernel, FO_LDS);
@@ -1081,7 +1083,15 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 
   dp_exchange(f, 0);                      // (eval forward under data parallelism: the mask slots have not travelled yet)
   const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
-  if (c->dec_fused && !f.fp32 && R <= 8 && N <= 96 && enc_KT) {
+  const bool dec_dense = (R > 8 || N > 96) && R <= 16 && N <= 192;      // dense-traffic shapes: the kernel's round-of-eight-tiles variant
+  if (c->dec_fused && !f.fp32 && dec_dense) {   // its K | V^T operand fragments from the (layer-wise) encoder's output
+    enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 96 * 512);
+    DecKvP kq; memset(&kq, 0, sizeof(kq));
+    kq.ENC = ENC; kq.bs = bs; kq.N = N; kq.wkv = (const unsigned short*)c->pw[PD + ".kv_all"].bf; kq.bkv = c->pw[PD + ".kv_all"].bias; kq.KV = enc_KT;
+    c->prof_flops = 2.0 * bs * N * 128.0 * 1024;
+    launch(c, "dec_kv_frag_kernel", dec_kv_frag_kernel, dim3(bs), dim3(512), (size_t)DEC_KV_LDS, kq);
+  }
+  if (c->dec_fused && !f.fp32 && ((R <= 8 && N <= 96) || dec_dense) && enc_KT) {
     DecWP dq; memset(&dq, 0, sizeof(dq));
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
     dq.stream = f.next_stream(); f.stream_id += 64;

@@ -142,9 +142,9 @@ def test_config0_grpo_step_on_dumped_carla_shaped_scenes(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("agents,polygons,rmax", [(76, 20, 6), (77, 20, 6), (64, 20, 7)])
 def test_fused_kernel_size_limits(ffi, agents, polygons, rmax):
-    """At and just beyond what the one-scene-per-workgroup kernels hold: N = 96 tokens exactly fills the encoder / decoder-key tiles
-    (76 agents + 20 polygons), N = 97 must take the layer-wise route, R = 7 runs fused (the wave-private decoder holds R <= 8) -- all three against the oracle,
-    bf16 and fp32, eval and the loss."""
+    """At and just beyond what the standard one-scene-per-workgroup kernels hold: N = 96 tokens exactly fills the encoder / decoder-key
+    tiles (76 agents + 20 polygons); at N = 97 the encoder takes the layer-wise route and the decoder its dense-traffic variant (K | V^T
+    operands from dec_kv_frag_kernel); R = 7 runs the standard decoder (R <= 8) -- all three against the oracle, bf16 and fp32, eval and the loss."""
     scenes = [syn.make_scene(6000 + i, num_agents=agents, num_polygons=polygons, r_min=rmax, r_max=rmax) for i in range(3)]
     eng = ffi.Engine("cuda:0")
     eng.load_state_dict({k: v.clone() for k, v in H.weights().items()})
@@ -154,7 +154,8 @@ def test_fused_kernel_size_limits(ffi, agents, polygons, rmax):
     eng.prof_enable(False)
     eng.close()
     assert ("enc_fused_kernel" in rep) == (agents + polygons <= 96)
-    assert ("dec_w_kernel" in rep) == (agents + polygons <= 96 and rmax <= 8)
+    assert "dec_w_kernel" in rep
+    assert ("dec_kv_frag_kernel" in rep) == (agents + polygons > 96)
     _check(ffi, scenes, train=False)
 
 
