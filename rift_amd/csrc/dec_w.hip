@@ -178,7 +178,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int nt = 0; nt < 8; ++nt) a[nt] = Z;
   };
   // residual hand-over between the tilings: the LDS buffer xs, or (DENSE) the query array itself -- written with a release fence ahead of
-  // the group barrier, read behind an acquire fence (the vector L1 of this CU may hold the rows from the previous layer)
+  // the group barrier, read behind an acquire fence.  WORKGROUP scope: writer and reader waves sit on one CU and share its write-through
+  // vector L1, so the fences are waits, not cache maintenance (agent scope writes back / invalidates the XCD's whole L2: measured 40-60 us
+  // per hand-over)
   auto read_xs = [&](f32x4 (&res)[8], int row, bool ok) {
     const float* src = DENSE ? p.Q + (qrow0 + row) * 128 + l4 * 4 : xs + row * XS + l4 * 4;
 #pragma unroll
@@ -194,8 +196,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<float4*>(dst + nt * 16) = make_float4(res[nt][0], res[nt][1], res[nt][2], res[nt][3]);
     }
   };
-  auto publish = [&]() { if (DENSE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); };     // after the last write_xs of a tiling, before its barrier
-  auto acquire = [&]() { if (DENSE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); };     // after that barrier, before the first read_xs
+  auto publish = [&]() { if (DENSE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); };     // after the last write_xs of a tiling, before its barrier
+  auto acquire = [&]() { if (DENSE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };     // after that barrier, before the first read_xs
   // res -> xb (bf16 operands of the four k-steps); g: gamma 128 | beta 128 in LDS.  Two-pass statistics as torch; vector (packed fp32) math.
   auto layer_norm = [&](const f32x4 (&res)[8], bf16x8 (&xb)[4], const float* g) {
     f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
