@@ -25,6 +25,7 @@
 #include "dec_w.h"
 #include "dec_kv.h"
 #include "nat_l2w.h"
+#include "enc_w.h"
 #include "pe_fused.h"
 #include "fourier_fused.h"
 #include "critic.h"
@@ -90,6 +91,7 @@ struct RiftCtx {
   float* nat_bqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool nat_fused = true; int nat_dbg = 0; int gemm_dbg = 0;
   bool nat_l0w = true; unsigned short* l0w_img = nullptr; float* l0w_par = nullptr;
+  unsigned short* encw_img = nullptr; float* encw_par = nullptr;   // weight stream / parameters of the dense-traffic scene encoder (enc_w.h)
   bool nat_l2w = true; unsigned short* l2w_img = nullptr; float* l2w_par = nullptr;   // wave-private, weight-streaming level-2 NAT kernel (nat_l2w.h)
   bool nat_l1w = true; unsigned short* l1w_img = nullptr; float* l1w_par = nullptr;   // wave-private level-1 NAT kernel (nat_l1w.h)   // wave-private level-0 NAT kernel (nat_l0w.h)
   unsigned short* enc_wqkv[4] = {nullptr, nullptr, nullptr, nullptr};   // chunked (q|k|q|k|v|v) bf16 in_proj images
@@ -403,6 +405,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR(enc_fused_kernel<ENC_NW>);
   HIPCHK(c, (hipError_t)decw_set_attributes());
   HIPCHK(c, (hipError_t)l2w_set_attributes());
+  HIPCHK(c, (hipError_t)encw_set_attributes());
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
   SETATTR(NAT_L2);
@@ -1005,6 +1008,15 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       c->prof_flops += 2.0 * bs * N * 128.0 * 1024;
     }
     launch(c, "enc_fused_kernel", enc_fused_kernel<ENC_NW>, dim3(bs), dim3(64 * ENC_NW), (size_t)RIFT_ENC_LDS_BYTES, ep);
+  } else if (c->enc_fused && !f.fp32 && N <= 192) {   // dense-traffic shapes: the wave-private, weight-streaming encoder (two passes per layer)
+    EncWP eq; memset(&eq, 0, sizeof(eq));
+    eq.X = X; eq.Y = ENC; eq.kpm = kpm; eq.bs = bs; eq.N = N; eq.seed = f.seed; eq.stream = f.next_stream(); f.stream_id += 8;
+    eq.KVs = A_alloc<unsigned short>(c, (size_t)bs * 96 * 512);
+    eq.img = c->encw_img; eq.par = c->encw_par;
+    if (c->dec_fused && R <= 16) { enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 96 * 512); eq.DKV = enc_KT; }   // the decoder's (dense-variant) operands
+    for (int i = 0; i < 4; ++i) eq.droppath[i] = f.drop ? edpr[i] : 0.f;
+    c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
+    launch_call(c, "enc_w_kernel", [&] { encw_launch(eq, c->stream); });
   } else {
   float* QKV = A_alloc<float>(c, (size_t)nT * 384);
   float* AO = A_alloc<float>(c, (size_t)nT * 128);
@@ -1084,7 +1096,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   dp_exchange(f, 0);                      // (eval forward under data parallelism: the mask slots have not travelled yet)
   const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
   const bool dec_dense = (R > 8 || N > 96) && R <= 16 && N <= 192;      // dense-traffic shapes: the kernel's round-of-eight-tiles variant
-  if (c->dec_fused && !f.fp32 && dec_dense) {   // its K | V^T operand fragments from the (layer-wise) encoder's output
+  if (c->dec_fused && !f.fp32 && dec_dense && !enc_KT) {   // its K | V^T operand fragments from the (layer-wise) encoder's output
     enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 96 * 512);
     DecKvP kq; memset(&kq, 0, sizeof(kq));
     kq.ENC = ENC; kq.bs = bs; kq.N = N; kq.wkv = (const unsigned short*)c->pw[PD + ".kv_all"].bf; kq.bkv = c->pw[PD + ".kv_all"].bias; kq.KV = enc_KT;
@@ -1296,6 +1308,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->l0w_img) { (void)hipFree(c->l0w_img); (void)hipFree(c->l0w_par); }
   if (c->l1w_img) { (void)hipFree(c->l1w_img); (void)hipFree(c->l1w_par); }
   if (c->l2w_img) { (void)hipFree(c->l2w_img); (void)hipFree(c->l2w_par); }
+  if (c->encw_img) { (void)hipFree(c->encw_img); (void)hipFree(c->encw_par); }
   if (c->decw_img) { (void)hipFree(c->decw_img); (void)hipFree(c->decw_par); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
@@ -1458,6 +1471,26 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
       bn.push_back(PD + ".decoder_blocks." + std::to_string(i) + ".cross_attn.in_proj_bias");
     }
     TRY(pack_stacked_rows(c, PD + ".kv_all", wn, bn, 128, 256));
+  }
+  {  // dense-traffic scene encoder (enc_w.h)
+    EncWSrc q; memset(&q, 0, sizeof(q));
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = "encoder_blocks." + std::to_string(i);
+      EncWSrc::L& k = q.l[i];
+      k.ln1_g = fptr(c, p + ".norm1.weight"); k.ln1_b = fptr(c, p + ".norm1.bias"); k.ln2_g = fptr(c, p + ".norm2.weight"); k.ln2_b = fptr(c, p + ".norm2.bias");
+      k.w_in = fptr(c, p + ".attn.in_proj_weight"); k.b_in = fptr(c, p + ".attn.in_proj_bias");
+      k.wo = fptr(c, p + ".attn.out_proj.weight"); k.bo = fptr(c, p + ".attn.out_proj.bias");
+      k.w1 = fptr(c, p + ".mlp.fc1.weight"); k.b1 = fptr(c, p + ".mlp.fc1.bias"); k.w2 = fptr(c, p + ".mlp.fc2.weight"); k.b2 = fptr(c, p + ".mlp.fc2.bias");
+    }
+    q.fn_g = fptr(c, "norm.weight"); q.fn_b = fptr(c, "norm.bias");
+    if (!c->err.empty()) return RIFT_ERR_ARG;
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = PD + ".decoder_blocks." + std::to_string(i) + ".cross_attn";
+      q.dkv_w[i] = fptr(c, p + ".in_proj_weight"); q.dkv_b[i] = fptr(c, p + ".in_proj_bias");
+    }
+    if (!c->err.empty()) return RIFT_ERR_ARG;
+    if (!c->encw_img) { HIPCHK(c, hipMalloc((void**)&c->encw_img, (size_t)(4 * ENCW_LAYER_FRAGS + ENCW_TAIL_FRAGS) * 1024)); HIPCHK(c, hipMalloc((void**)&c->encw_par, (size_t)ENCW_NPAR * 4)); }
+    encw_pack(q, c->encw_img, c->encw_par, c->stream);
   }
   {  // wave-private decoder kernel (dec_w.h): the layers' weight stream and parameter blocks
     DecWSrc q; memset(&q, 0, sizeof(q));

@@ -1,6 +1,6 @@
 """Shape / mask edge cases of the HIP forward against the CPU oracle (fp32 mode 1e-4 abs on logits, bf16 5e-2):
-the dense-traffic configuration of BASELINE.json (128 agents, 40 polygons, 8-16 reference lines: beyond the fused
-kernels' LDS tiles, so the layer-wise paths carry it), a single-scene batch with one reference line, and degenerate masks
+the dense-traffic configuration of BASELINE.json (128 agents, 40 polygons, 8-16 reference lines: the round-of-eight-tiles variants of the
+wave-private encoder / decoder kernels carry it), a single-scene batch with one reference line, and degenerate masks
 (no valid neighbour agent, an all-invalid polygon, an all-invalid reference line between valid ones)."""
 import pytest
 import torch
@@ -143,8 +143,7 @@ def test_config0_grpo_step_on_dumped_carla_shaped_scenes(tmp_path):
 @pytest.mark.parametrize("agents,polygons,rmax", [(76, 20, 6), (77, 20, 6), (64, 20, 7)])
 def test_fused_kernel_size_limits(ffi, agents, polygons, rmax):
     """At and just beyond what the standard one-scene-per-workgroup kernels hold: N = 96 tokens exactly fills the encoder / decoder-key
-    tiles (76 agents + 20 polygons); at N = 97 the encoder takes the layer-wise route and the decoder its dense-traffic variant (K | V^T
-    operands from dec_kv_frag_kernel); R = 7 runs the standard decoder (R <= 8) -- all three against the oracle, bf16 and fp32, eval and the loss."""
+    tiles (76 agents + 20 polygons); at N = 97 encoder and decoder run their dense-traffic variants (enc_w_kernel, dec_w_kernel<., true>); R = 7 runs the standard decoder (R <= 8) -- all three against the oracle, bf16 and fp32, eval and the loss."""
     scenes = [syn.make_scene(6000 + i, num_agents=agents, num_polygons=polygons, r_min=rmax, r_max=rmax) for i in range(3)]
     eng = ffi.Engine("cuda:0")
     eng.load_state_dict({k: v.clone() for k, v in H.weights().items()})
@@ -155,7 +154,7 @@ def test_fused_kernel_size_limits(ffi, agents, polygons, rmax):
     eng.close()
     assert ("enc_fused_kernel" in rep) == (agents + polygons <= 96)
     assert "dec_w_kernel" in rep
-    assert ("dec_kv_frag_kernel" in rep) == (agents + polygons > 96)
+    assert ("enc_w_kernel" in rep) == (agents + polygons > 96)        # the dense-traffic encoder, which also writes the decoder's K | V^T operands
     _check(ffi, scenes, train=False)
 
 

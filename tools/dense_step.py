@@ -1,5 +1,6 @@
 """Step time of the dense-traffic configuration (BASELINE configs[4] shapes: 128 agents, 40 polygons, 8-16 reference lines) on one GPU.
-The fused encoder / decoder kernels do not cover N = 168 tokens / 192 queries; those layers run on the layer-wise GEMM path."""
+N = 168 tokens and up to 16 reference lines run on the dense-traffic variants of the wave-private kernels (enc_w_kernel: two passes per layer
+over rounds of eight token tiles; dec_w_kernel<., true>: rounds of eight query tiles, hand-over through the query array)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
