@@ -102,7 +102,7 @@ __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
 // fragment reads are bank-conflict free (4 LDS cycles; 136 costs 8, tools/lds_conflicts.py).  ao / cb keep 136 / 200: the 160 KB are full.
 #define RIFT_ENC_XN 144
 #define RIFT_ENC_XA 136
-#define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * (RIFT_ENC_XN + RIFT_ENC_XA) * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 128 + RIFT_ENC_NPAR * 4)
+#define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * (RIFT_ENC_XN + RIFT_ENC_XA) * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 96 * 4 + RIFT_ENC_NPAR * 4)
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
   unsigned short* cb = xn + ROWS * XN;
   unsigned short* ao = cb + ROWS * CB;
   unsigned short* vt = ao + ROWS * XA;            // [2][32][VS]
-  unsigned char* smask = reinterpret_cast<unsigned char*>(vt + 2 * 32 * VS);
-  float* par = reinterpret_cast<float*>(smask + 128);   // [RIFT_ENC_NPAR] this layer's bias / LayerNorm vectors
+  float* smaskf = reinterpret_cast<float*>(vt + 2 * 32 * VS);   // [96] key-padding mask as 0 / -inf: it enters the scores as the MFMA accumulator
+  float* par = smaskf + 96;                             // [RIFT_ENC_NPAR] this layer's bias / LayerNorm vectors
   constexpr int P_LN1G = 0, P_LN1B = 128, P_LN2G = 256, P_LN2B = 384, P_BQKV = 512, P_BO = 896, P_B1 = 1024, P_B2 = 1536;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
     if (r < N) v = *reinterpret_cast<const float4*>(p.X + (grow0 + r) * C + c4);
     *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
   }
-  for (int i = tid; i < ROWS; i += NTH) smask[i] = (i >= N) || p.kpm[grow0 + i];
+  for (int i = tid; i < ROWS; i += NTH) smaskf[i] = ((i >= N) || p.kpm[grow0 + i]) ? -INFINITY : 0.f;
   lds_barrier();
   TS();
 
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
           const int nt = j * NW + wave;
           const int col = nt * 16 + l4 * 4;
           const float4 b4 = *reinterpret_cast<const float4*>(par + P_BQKV + ch * 192 + col);
-          const float sc = ((nt & 3) < 2) ? 0.17677669529663687f : 1.0f;   // q pre-scaled by 32^-0.5
+          const float sc = ((nt & 3) < 2) ? 0.17677669529663687f * 1.4426950408889634f : 1.0f;   // q pre-scaled by 32^-0.5 log2 e: the softmax runs on v_exp_f32 = 2^x
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
@@ -223,19 +223,16 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cb + (kt * 16 + l15) * CB + hh * 64 + 32 + l4 * 8);
-          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (smask[kt * 16 + l4 * 4 + r]) s[kt][r] = -INFINITY;
-            m = fmaxf(m, s[kt][r]);
-          }
+          const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+          m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
         }
         m = rows_max(m);
         float lsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float e = __expf(s[kt][r] - m); lsum += e; s[kt][r] = e; }
+          for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - m); lsum += e; s[kt][r] = e; }
         lsum = rows_sum(lsum);
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
