@@ -26,6 +26,7 @@
 #include "dec_kv.h"
 #include "nat_l2w.h"
 #include "enc_w.h"
+#include "pe_w.h"
 #include "pe_fused.h"
 #include "fourier_fused.h"
 #include "critic.h"
@@ -100,6 +101,7 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
+  bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
   unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // weight stream / parameter blocks of the decoder kernel (dec_w.h)
   double* clip_part = nullptr;
   struct Dp { bool on = false; int off = 0, gbs = 0; double* xchg = nullptr; long long len = 0; RiftExchangeFn fn = nullptr; void* user = nullptr; } dp;   // rift_set_dp
@@ -406,6 +408,7 @@ int set_lds_attrs(RiftCtx* c) {
   HIPCHK(c, (hipError_t)decw_set_attributes());
   HIPCHK(c, (hipError_t)l2w_set_attributes());
   HIPCHK(c, (hipError_t)encw_set_attributes());
+  HIPCHK(c, (hipError_t)pew_set_attributes());
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
   SETATTR(NAT_L2);
@@ -590,10 +593,35 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
     if (mode == 1) dp_exchange(f, 2 * 257);
   }
   c->prof_flops = 2.0 * rows * (128.0 * 8 + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;
-  launch(c, "pe_mid_kernel", pe_mid_kernel, dim3(nt), dim3(512), (size_t)PE_MID_LDS, q);
+  BnFinP fa, fb;
+  if (c->pe_w) {     // wave-private pass B: rounds of 240 rows, one statistics partial per round
+    PeWP w; memset(&w, 0, sizeof(w));
+    const PeP* src[2] = {&q.a, &q.b};
+    PeWSide* dst[2] = {&w.a, &w.b};
+    const int npts[2] = {20, 120};
+    for (int i = 0; i < 2; ++i) {
+      const PeP& o = *src[i]; PeWSide& d = *dst[i];
+      d.F = o.F; d.Cin = o.Cin; d.valid = o.valid; d.rows = o.rows; d.npts = npts[i]; d.nrounds = cdiv(o.rows, PEW_ROUND_ROWS);
+      d.img = c->pew_img[i]; d.w3b = o.w3b; d.b1 = o.b1; d.b2 = o.b2; d.b3 = o.b3; d.s1 = o.s1; d.t1 = o.t1;
+      d.cnt = f.train ? o.cnt : nullptr;
+      d.part2 = A_alloc<float>(c, (size_t)2 * 256 * d.nrounds); d.cnt2 = A_alloc<int>(c, d.nrounds);
+      d.Fmid = o.Fmid;
+    }
+    w.do_stats = f.train ? 1 : 0;
+    { const char* ev = getenv("RIFT_PEW_DBG"); w.dbg = ev ? atoi(ev) : 0; }
+    { const char* ev = getenv("RIFT_PEW_TS"); if (ev && ev[0] == '1') { w.ts = A_alloc<long long>(c, 128); tap(c, "pew_ts", (float*)w.ts, 256); } }
+    const int grid = std::min(w.a.nrounds + w.b.nrounds, c->nat_grid);
+    launch_call(c, "pe_w_kernel", [&] { pew_launch(w, grid, c->stream); });
+    fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, w.a.part2, q.a.s2, q.a.t2, xs, 0); fa.cnt = w.a.cnt2; fa.nblk = w.a.nrounds;
+    fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, w.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0); fb.cnt = w.b.cnt2; fb.nblk = w.b.nrounds;
+  } else {
+    launch(c, "pe_mid_kernel", pe_mid_kernel, dim3(nt), dim3(512), (size_t)PE_MID_LDS, q);
+    fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2, xs, 0);
+    fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, q.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0);
+  }
   for (int mode = dpx ? 1 : 0; mode <= (dpx ? 2 : 0); ++mode) {
-    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(512), dim3(256), 0, bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2, xs, mode),
-           bn_fin(c, q.b, pr + ".second_mlp.1", 256, q.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, mode), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+    fa.sums_mode = mode; fb.sums_mode = mode;
+    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(512), dim3(256), 0, fa, fb, f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
     if (mode == 1) dp_exchange(f, 2 * 513);
   }
   c->prof_flops = 2.0 * rows * (256.0 * 256 + 256.0 * 128);
@@ -1283,6 +1311,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_L0W"); c->nat_l0w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_NAT_L1W"); c->nat_l1w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_NAT_L2W"); c->nat_l2w = !(ev && ev[0] == '0'); }
+  { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   if (hipMalloc((void**)&c->nonfinite, sizeof(int)) != hipSuccess || hipMemset(c->nonfinite, 0, sizeof(int)) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   int rc = set_lds_attrs(c);
@@ -1310,6 +1339,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->l2w_img) { (void)hipFree(c->l2w_img); (void)hipFree(c->l2w_par); }
   if (c->encw_img) { (void)hipFree(c->encw_img); (void)hipFree(c->encw_par); }
   if (c->decw_img) { (void)hipFree(c->decw_img); (void)hipFree(c->decw_par); }
+  for (int i = 0; i < 2; ++i) if (c->pew_img[i]) (void)hipFree(c->pew_img[i]);
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
   delete c;
@@ -1491,6 +1521,17 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     if (!c->err.empty()) return RIFT_ERR_ARG;
     if (!c->encw_img) { HIPCHK(c, hipMalloc((void**)&c->encw_img, (size_t)(4 * ENCW_LAYER_FRAGS + ENCW_TAIL_FRAGS) * 1024)); HIPCHK(c, hipMalloc((void**)&c->encw_par, (size_t)ENCW_NPAR * 4)); }
     encw_pack(q, c->encw_img, c->encw_par, c->stream);
+  }
+  {  // wave-private PointsEncoder pass B (pe_w.h): W1 | W2 | W3a streams of the two encoders
+    const std::string enc[2] = {"map_encoder.polygon_encoder", PD + ".r_encoder"};
+    const int cin[2] = {10, 6};
+    for (int i = 0; i < 2; ++i) {
+      PeWSrc q; q.Cin = cin[i];
+      q.w1 = fptr(c, enc[i] + ".first_mlp.0.weight"); q.w2 = fptr(c, enc[i] + ".first_mlp.3.weight"); q.w3 = fptr(c, enc[i] + ".second_mlp.0.weight");
+      if (!c->err.empty()) return RIFT_ERR_ARG;
+      if (!c->pew_img[i]) HIPCHK(c, hipMalloc((void**)&c->pew_img[i], (size_t)PEW_FRAGS * 1024));
+      pew_pack(q, c->pew_img[i], c->stream);
+    }
   }
   {  // wave-private decoder kernel (dec_w.h): the layers' weight stream and parameter blocks
     DecWSrc q; memset(&q, 0, sizeof(q));

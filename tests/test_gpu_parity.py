@@ -536,14 +536,16 @@ def test_fused_points_encoder_matches_layerwise_path(ffi, monkeypatch, train):
     outs = {}
     bn_keys = [k for k in sd if ("polygon_encoder" in k or "r_encoder" in k) and "running_" in k]
     assert len(bn_keys) == 8
-    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+    for name, env, fp32 in (("fused", "0", False), ("mid", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
         monkeypatch.setenv("RIFT_PE_UNFUSED", env)
+        monkeypatch.setenv("RIFT_PE_W", "0" if name == "mid" else "1")     # "mid": pass B as the LDS-resident pe_mid_kernel instead of pe_w_kernel
         eng = ffi.Engine("cuda:0")
         live = {k: v.clone().cuda() for k, v in sd.items()}
         eng.load_state_dict(live)
         eng.prof_enable(True)
         eng.forward(data, train=train, no_drop=True, fp32=fp32)
-        assert ("pe_mid_kernel" in eng.prof_report()) == (name == "fused")
+        rep = eng.prof_report()
+        assert ("pe_w_kernel" in rep) == (name == "fused") and ("pe_mid_kernel" in rep) == (name == "mid")
         eng.prof_enable(False)
         outs[name] = (eng.tap("poly_pe").cpu().clone(), eng.tap("r_pe").cpu().clone(),
                       {k: live[k].cpu().clone() for k in bn_keys})
@@ -551,10 +553,13 @@ def test_fused_points_encoder_matches_layerwise_path(ffi, monkeypatch, train):
     for i in (0, 1):
         scale = max(1.0, float(outs["fp32"][i].abs().max()))
         assert err(outs["fused"][i], outs["fp32"][i]) < 3e-2 * scale
-        assert err(outs["fused"][i], outs["layerwise"][i]) < 3e-2 * scale   # (eval mode: same rounding points, bit-identical)
+        assert err(outs["fused"][i], outs["layerwise"][i]) < 3e-2 * scale
+        assert err(outs["mid"][i], outs["fp32"][i]) < 3e-2 * scale
+        assert err(outs["fused"][i], outs["mid"][i]) < 3e-2 * scale
     for k in bn_keys:   # running statistics: unchanged in eval mode, momentum-0.1 update of the same batch statistics in train mode
         tol = 2e-2 * max(1.0, float(outs["fp32"][2][k].abs().max()))
         assert err(outs["fused"][2][k], outs["fp32"][2][k]) < tol, k
+        assert err(outs["mid"][2][k], outs["fp32"][2][k]) < tol, k
         if not train:
             assert torch.equal(outs["fused"][2][k], sd[k]), k
         else:
