@@ -594,26 +594,29 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
   }
   c->prof_flops = 2.0 * rows * (128.0 * 8 + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;
   BnFinP fa, fb;
-  if (c->pe_w) {     // wave-private pass B: rounds of 240 rows, one statistics partial per round
+  if (c->pe_w) {     // wave-private pass B: rounds of 240 rows, one statistics partial per workgroup
     PeWP w; memset(&w, 0, sizeof(w));
     const PeP* src[2] = {&q.a, &q.b};
     PeWSide* dst[2] = {&w.a, &w.b};
     const int npts[2] = {20, 120};
+    int grid = c->nat_grid, ga = 0;
+    pew_split(cdiv(q.a.rows, PEW_ROUND_ROWS), cdiv(q.b.rows, PEW_ROUND_ROWS), &grid, &ga);
+    const int nwg[2] = {ga, grid - ga};
     for (int i = 0; i < 2; ++i) {
       const PeP& o = *src[i]; PeWSide& d = *dst[i];
       d.F = o.F; d.Cin = o.Cin; d.valid = o.valid; d.rows = o.rows; d.npts = npts[i]; d.nrounds = cdiv(o.rows, PEW_ROUND_ROWS);
       d.img = c->pew_img[i]; d.w3b = o.w3b; d.b1 = o.b1; d.b2 = o.b2; d.b3 = o.b3; d.s1 = o.s1; d.t1 = o.t1;
       d.cnt = f.train ? o.cnt : nullptr;
-      d.part2 = A_alloc<float>(c, (size_t)2 * 256 * d.nrounds); d.cnt2 = A_alloc<int>(c, d.nrounds);
+      d.part2 = A_alloc<float>(c, (size_t)2 * 256 * std::max(nwg[i], 1)); d.cnt2 = A_alloc<int>(c, std::max(nwg[i], 1));
       d.Fmid = o.Fmid;
     }
+    w.ga = ga;
     w.do_stats = f.train ? 1 : 0;
     { const char* ev = getenv("RIFT_PEW_DBG"); w.dbg = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("RIFT_PEW_TS"); if (ev && ev[0] == '1') { w.ts = A_alloc<long long>(c, 128); tap(c, "pew_ts", (float*)w.ts, 256); } }
-    const int grid = std::min(w.a.nrounds + w.b.nrounds, c->nat_grid);
     launch_call(c, "pe_w_kernel", [&] { pew_launch(w, grid, c->stream); });
-    fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, w.a.part2, q.a.s2, q.a.t2, xs, 0); fa.cnt = w.a.cnt2; fa.nblk = w.a.nrounds;
-    fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, w.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0); fb.cnt = w.b.cnt2; fb.nblk = w.b.nrounds;
+    fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, w.a.part2, q.a.s2, q.a.t2, xs, 0); fa.cnt = w.a.cnt2; fa.nblk = nwg[0];
+    fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, w.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0); fb.cnt = w.b.cnt2; fb.nblk = nwg[1];
   } else {
     launch(c, "pe_mid_kernel", pe_mid_kernel, dim3(nt), dim3(512), (size_t)PE_MID_LDS, q);
     fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2, xs, 0);

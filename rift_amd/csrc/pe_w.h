@@ -10,7 +10,7 @@
 //     workgroup combines them into the 16 x 256 pooled operand; gp = pooled W3b^T + b3 takes its 16 fragments per wave straight from L2
 //     into registers (streaming W3b's 128 KiB through the ring for 16 MFMAs per wave would be 40 % of the stream);
 //   * g goes to HBM as fp16 in 32-byte pieces per lane (W3a's image permutes the output channels so that a lane's 4 n-tiles x 4 values
-//     are 16 consecutive channels); BatchNorm-2 statistics from the fp32 accumulators, one partial per round;
+//     are 16 consecutive channels); BatchNorm-2 statistics from the fp32 accumulators, one partial per workgroup;
 //   * persistent workgroups (one per CU) walk the rounds with the stream running across round boundaries; rounds whose two 120-row tiles
 //     hold no valid point (pass A's counts) are skipped.
 // Replaces: pe_mid_kernel (kept for RIFT_PE_W=0 and as the parity reference of tests/test_gpu_parity.py).
@@ -34,8 +34,8 @@ struct PeWSide {
   const unsigned short* w3b;              // second_mlp.0 pool half, fragment-major bf16 image [256][256] (engine pack_cols)
   const float *b1, *b2, *b3, *s1, *t1;    // biases; BatchNorm-1 folded to y = x s1 + t1
   const int* cnt;                         // valid points per 120-row tile (pass A), or null: no round is skipped
-  float* part2;                           // [2][256][nrounds] sums of g, g^2 over the valid rows of a round
-  int* cnt2;                              // [nrounds] valid rows per round
+  float* part2;                           // [2][256][nwg] sums of g, g^2 over the valid rows of a workgroup's rounds (nwg = its share of the grid)
+  int* cnt2;                              // [nwg] valid rows of a workgroup's rounds
   unsigned short* Fmid;                   // (rows, 256) fp16 bits of g
 };
 
@@ -49,6 +49,7 @@ struct PeWP {
 
 int pew_set_attributes();
 void pew_pack(const PeWSrc& src, unsigned short* img, hipStream_t stream);
-void pew_launch(PeWP p, int grid, hipStream_t stream);   // grid = persistent workgroups (one per CU), split over the encoders by their round counts
+void pew_split(int ra, int rb, int* grid, int* ga);        // grid = persistent workgroups (<= *grid, one per CU): [0, ga) for a's rounds, the rest for b's
+void pew_launch(const PeWP& p, int grid, hipStream_t stream);
 
 }  // namespace rift

@@ -115,11 +115,8 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     if (2 * ri + 1 < nt120) n += s.cnt[2 * ri + 1];
     return n == 0;
   };
-  auto next_round = [&](int ri) {            // first round >= ri of this workgroup with a valid point; skipped rounds get zero statistics
-    while (ri < R && empty(ri)) {
-      if (p.do_stats) { s.part2[(size_t)tid * R + ri] = 0.f; if (tid == 0) s.cnt2[ri] = 0; }
-      ri += G;
-    }
+  auto next_round = [&](int ri) {            // first round >= ri of this workgroup with a valid point
+    while (ri < R && empty(ri)) ri += G;
     return ri;
   };
   auto dma = [&](const unsigned char* src, uint32_t dst, int nfrag) {
@@ -128,19 +125,16 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     for (int f = wv; f < nfrag; f += 8) decw_glds(src + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
   };
   auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); PWTS(); };
-  // statistics of a finished round: the eight waves' partials -> part2 (called behind a barrier that follows the round's last group)
-  auto finish_stats = [&](int ri) {
-    if (!p.do_stats || (p.dbg & 4)) return;    // (diagnostic 4: no statistics write-out)
-    float a = 0.f;
+  // statistics of a finished round: the eight waves' partials are added to this thread's running sum (thread = kind * 256 + channel); the
+  // workgroup writes ONE partial at its end (fp32 over its <= ~6 rounds x 240 rows; bn_finalize_t_kernel adds the partials in fp64).
+  // Called behind a barrier that follows the round's last group.
+  float stat_acc = 0.f;
+  int cnt_acc = 0;
+  auto finish_stats = [&]() {
+    if (!p.do_stats || (p.dbg & 4)) return;    // (diagnostic 4: no statistics)
 #pragma unroll
-    for (int w = 0; w < 8; ++w) a += *reinterpret_cast<const float*>(smem_raw + OFF_SCR + w * SCR_W + tid * 4);
-    s.part2[(size_t)tid * R + ri] = a;
-    if (tid == 0) {
-      int n = 0;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) n += *reinterpret_cast<const int*>(smem_raw + OFF_SCR + w * SCR_W + 2048);
-      s.cnt2[ri] = n;
-    }
+    for (int w = 0; w < 8; ++w) stat_acc += *reinterpret_cast<const float*>(smem_raw + OFF_SCR + w * SCR_W + tid * 4);
+    if (tid < 8) cnt_acc += *reinterpret_cast<const int*>(smem_raw + OFF_SCR + tid * SCR_W + 2048);
   };
   // the point rows of this wave's two tiles T = 2 wv + mt in round ri: validity byte (0xff = no such row) and features, raw
   auto load_rows = [&](int ri, unsigned (&vb)[2], float (&xv)[2][3]) {
@@ -162,7 +156,10 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
 
   int gc = 0;                                 // groups consumed so far: group gc sits in ring slot gc & 1
   int ri = next_round(wg);
-  if (ri >= R) return;
+  if (ri >= R) {
+    if (p.do_stats) { s.part2[(size_t)tid * G + wg] = 0.f; if (tid == 0) s.cnt2[wg] = 0; }
+    return;
+  }
   dma(img, 0, 8);
   for (int i = tid; i < 768; i += 512) {      // parameter block (published by the first group barrier)
     float v;
@@ -243,19 +240,21 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     // partial maxima -> pooled operand; gp = pooled W3b^T + b3 of the round's polylines -> gpt (every wave: 32 of the 256 columns)
     auto pooled_gp = [&](const bf16x8 (&wb)[16]) {
       const int npoly = pdiv(nex);                                   // polylines of this round that exist (whole ones)
-#pragma unroll 1
-      for (int u = 0; u < 4; ++u) {                                // 16 polylines x 128 channel pairs; a wave's 64 items share their polyline
-        const int i = tid + u * 512, pl = i >> 7, cp = i & 127;
-        float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                                // wave wv: polylines 2 wv, 2 wv + 1 (uniform tile loop); a lane: channel pairs lane, lane + 64
+        const int pl = 2 * wv + u;
+        float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
         if (pl < npoly) {
-          a = -INFINITY; b = -INFINITY;
-          const int r0 = pl * NPTS, T0 = r0 >> 4, T1 = (r0 + NPTS - 1) >> 4;
-          for (int T = T0; T <= T1; ++T) {                         // a tile that starts ahead of the polyline holds it as its second segment
-            const uint32_t wd = pmax[(T * 2 + (16 * T < r0 ? 1 : 0)) * 128 + cp];
-            a = fmaxf(a, bf_lo(wd)); b = fmaxf(b, bf_hi(wd));
+          a0 = b0 = a1 = b1 = -INFINITY;
+          const int r0 = pl * NPTS, T1 = (r0 + NPTS - 1) >> 4;
+          for (int T = r0 >> 4; T <= T1; ++T) {                    // a tile that starts ahead of the polyline holds it as its second segment
+            const uint32_t* src = pmax + (T * 2 + (16 * T < r0 ? 1 : 0)) * 128;
+            const uint32_t w0 = src[lane], w1 = src[lane + 64];
+            a0 = fmaxf(a0, bf_lo(w0)); b0 = fmaxf(b0, bf_hi(w0)); a1 = fmaxf(a1, bf_lo(w1)); b1 = fmaxf(b1, bf_hi(w1));
           }
         }
-        reinterpret_cast<uint32_t*>(pool)[pl * (PLS / 2) + cp] = bf_pair(a, b);
+        reinterpret_cast<uint32_t*>(pool)[pl * (PLS / 2) + lane] = bf_pair(a0, b0);
+        reinterpret_cast<uint32_t*>(pool)[pl * (PLS / 2) + lane + 64] = bf_pair(a1, b1);
       }
       lds_barrier();                   // (not __syncthreads: that would also wait for the group just requested)
       f32x4 ga[2];
@@ -299,10 +298,9 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
 
     if (wact) {
       // ---- group 0: h1 = relu(bn1(x W1^T + b1)) as the k-steps of W2
-      boundary(0, nothing);
-      if (pend) { store_hold(3); pend = false; }
+      boundary(0, [&] { if (prev_ri >= 0) finish_stats(); });
       PWTS();
-      if (prev_ri >= 0) finish_stats(prev_ri);
+      if (pend) { store_hold(3); pend = false; }
       PWTS();
       bf16x8 hb[2][4];
       {
@@ -431,9 +429,8 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     } else {
       // ---- no valid point among this wave's rows: it keeps the barriers, carries its share of the stream and of gp, and its
       // existing rows are zero rows (they take part in the max with 0; their g is never read)
-      boundary(0, nothing);
+      boundary(0, [&] { if (prev_ri >= 0) finish_stats(); });
       if (pend) { store_hold(3); pend = false; }
-      if (prev_ri >= 0) finish_stats(prev_ri);
       ++gc;
       boundary(1, nothing);
 #pragma unroll
@@ -473,7 +470,13 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   }
   __syncthreads();
   if (pend) store_hold(3);
-  if (prev_ri >= 0) finish_stats(prev_ri);
+  if (prev_ri >= 0) finish_stats();
+  if (p.do_stats) {
+    s.part2[(size_t)tid * G + wg] = stat_acc;
+    int n = cnt_acc;                           // lanes 0..7 of wave 0 hold the eight waves' counts, every other lane 0
+    n += __shfl_xor(n, 1, 64); n += __shfl_xor(n, 2, 64); n += __shfl_xor(n, 4, 64);
+    if (tid == 0) s.cnt2[wg] = n;
+  }
 #undef PWTS
 #undef s
 }
@@ -492,16 +495,18 @@ void pew_pack(const PeWSrc& src, unsigned short* img, hipStream_t stream) {
   hipLaunchKernelGGL(pack_pew_kernel, dim3((PEW_FRAGS * 512 + 255) / 256), dim3(256), 0, stream, src, img);
 }
 
-void pew_launch(PeWP p, int grid, hipStream_t stream) {
-  const int ra = p.a.nrounds, rb = p.b.nrounds;
-  if (ra + rb == 0) return;
-  grid = grid < ra + rb ? grid : ra + rb;
-  int ga = (int)(((long long)grid * ra + (ra + rb) / 2) / (ra + rb));
-  if (ra > 0 && ga < 1) ga = 1;
-  if (rb > 0 && ga > grid - 1) ga = grid - 1;
-  if (rb == 0) ga = grid;
-  if (ga > ra) ga = ra;
-  p.ga = ga;
+void pew_split(int ra, int rb, int* grid, int* ga) {
+  int g = *grid < ra + rb ? *grid : ra + rb;
+  int a = ra + rb > 0 ? (int)(((long long)g * ra + (ra + rb) / 2) / (ra + rb)) : 0;
+  if (ra > 0 && a < 1) a = 1;
+  if (rb > 0 && a > g - 1) a = g - 1;
+  if (rb == 0) a = g;
+  if (a > ra) a = ra;
+  *grid = g; *ga = a;
+}
+
+void pew_launch(const PeWP& p, int grid, hipStream_t stream) {
+  if (grid <= 0) return;
   hipLaunchKernelGGL(pe_w_kernel, dim3(grid), dim3(512), PEW_LDS_BYTES, stream, p);
 }
 
