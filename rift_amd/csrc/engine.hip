@@ -994,12 +994,16 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   } else {
     speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
   }
-  launch(c, "agent_token_kernel", agent_token_kernel, dim3(cdiv((long long)nA * 32, 256)), dim3(256), 0, (const float*)nat_out, (const float*)x_ego,
-         (const uint8_t*)valid_agent, B->agent_category, fptr(c, "agent_encoder.type_emb.weight"), bs, A, N, X, (const float*)PEtok);
-  launch(c, "polygon_token_kernel", polygon_token_kernel, dim3(cdiv((long long)nP * 32, 256)), dim3(256), 0, (const float*)poly, B->map_polygon_type,
-         B->map_polygon_on_route, B->map_polygon_tl_status, B->map_polygon_has_speed_limit, (const float*)speed_emb,
-         fptr(c, "map_encoder.type_emb.weight"), fptr(c, "map_encoder.on_route_emb.weight"),
-         fptr(c, "map_encoder.traffic_light_emb.weight"), fptr(c, "map_encoder.unknown_speed_emb.weight"), bs, A, Mp, N, X, (const float*)PEtok);
+  {
+    TokenP q;
+    q.nat = nat_out; q.x_ego = x_ego; q.valid_agent = (const uint8_t*)valid_agent; q.category = B->agent_category; q.a_type_emb = fptr(c, "agent_encoder.type_emb.weight");
+    q.pooled = poly; q.ptype = B->map_polygon_type; q.on_route = B->map_polygon_on_route; q.tl = B->map_polygon_tl_status; q.has_sl = B->map_polygon_has_speed_limit;
+    q.speed_emb = speed_emb; q.p_type_emb = fptr(c, "map_encoder.type_emb.weight"); q.route_emb = fptr(c, "map_encoder.on_route_emb.weight");
+    q.tl_emb = fptr(c, "map_encoder.traffic_light_emb.weight"); q.unk_emb = fptr(c, "map_encoder.unknown_speed_emb.weight");
+    q.bs = bs; q.A = A; q.Mp = Mp; q.N = N; q.X = X; q.pe = PEtok;
+    q.nblk_a = cdiv((long long)nA * 32, 256);
+    launch(c, "token_kernel", token_kernel, dim3(q.nblk_a + cdiv((long long)nP * 32, 256)), dim3(256), 0, q);
+  }
   if (S > 0) {
     float* semb = fourier(f, B->static_shape, 2, bs * S, 2, "static_objects_encoder.obj_encoder", -1);
     launch(c, "static_token_kernel", static_token_kernel, dim3(cdiv((long long)bs * S * 128, 256)), dim3(256), 0, (const float*)semb, B->static_category,

@@ -591,12 +591,11 @@ __global__ void ego_dropmask_kernel(int bs, float p, uint32_t seed, uint32_t str
 }
 
 // agent tokens: x[b][a] = (a == 0 ? x_ego[b] : valid ? nat[b*A+a] : 0) + type_emb[cat] ; written into token row (b*N + a)
-__global__ void agent_token_kernel(const float* __restrict__ nat, const float* __restrict__ x_ego,
-                                   const uint8_t* __restrict__ valid_agent, const int8_t* __restrict__ category,
-                                   const float* __restrict__ type_emb, int bs, int A, int N, float* __restrict__ X,
-                                   const float* __restrict__ pe /*optional (bs*N,128) positional embedding added on the way*/) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // one thread = 4 channels of one agent token (16-byte accesses)
-  if (idx >= bs * A * 32) return;
+__device__ __forceinline__ void agent_token_body(const int idx, const float* __restrict__ nat, const float* __restrict__ x_ego,
+                                                 const uint8_t* __restrict__ valid_agent, const int8_t* __restrict__ category,
+                                                 const float* __restrict__ type_emb, int bs, int A, int N, float* __restrict__ X,
+                                                 const float* __restrict__ pe /*optional (bs*N,128) positional embedding added on the way*/) {
+  if (idx >= bs * A * 32) return;                                 // one thread = 4 channels of one agent token (16-byte accesses)
   const int c = (idx & 31) * 4, a = (idx >> 5) % A, b = idx / (A * 32);
   const int ag = b * A + a;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -610,14 +609,13 @@ __global__ void agent_token_kernel(const float* __restrict__ nat, const float* _
 }
 
 // polygon tokens (map_encoder.py:82-91): x = pooled + type + on_route + tl + (has ? speed_emb : unknown)
-__global__ void polygon_token_kernel(const float* __restrict__ pooled, const int8_t* __restrict__ ptype,
-                                     const uint8_t* __restrict__ on_route, const int8_t* __restrict__ tl,
-                                     const uint8_t* __restrict__ has_sl, const float* __restrict__ speed_emb,
-                                     const float* __restrict__ type_emb, const float* __restrict__ route_emb,
-                                     const float* __restrict__ tl_emb, const float* __restrict__ unk_emb, int bs,
-                                     int A, int Mp, int N, float* __restrict__ X, const float* __restrict__ pe) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // one thread = 4 channels of one polygon token
-  if (idx >= bs * Mp * 32) return;
+__device__ __forceinline__ void polygon_token_body(const int idx, const float* __restrict__ pooled, const int8_t* __restrict__ ptype,
+                                                   const uint8_t* __restrict__ on_route, const int8_t* __restrict__ tl,
+                                                   const uint8_t* __restrict__ has_sl, const float* __restrict__ speed_emb,
+                                                   const float* __restrict__ type_emb, const float* __restrict__ route_emb,
+                                                   const float* __restrict__ tl_emb, const float* __restrict__ unk_emb, int bs,
+                                                   int A, int Mp, int N, float* __restrict__ X, const float* __restrict__ pe) {
+  if (idx >= bs * Mp * 32) return;                                // one thread = 4 channels of one polygon token
   const int c = (idx & 31) * 4, m = (idx >> 5) % Mp, b = idx / (Mp * 32);
   const int pg = b * Mp + m;
   auto ld = [&](const float* p) { return *reinterpret_cast<const float4*>(p + c); };
@@ -629,6 +627,22 @@ __global__ void polygon_token_kernel(const float* __restrict__ pooled, const int
   const size_t o = ((size_t)b * N + A + m) * 128 + c;
   if (pe) { const float4 q = *reinterpret_cast<const float4*>(pe + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
   *reinterpret_cast<float4*>(X + o) = v;
+}
+
+// agent and polygon tokens of the scene encoder in one launch (blocks [0, nblk_a) build agent tokens): two ~5 us launches in a row cost their
+// fixed part twice
+struct TokenP {
+  const float *nat, *x_ego; const uint8_t* valid_agent; const int8_t* category; const float* a_type_emb;
+  const float* pooled; const int8_t* ptype; const uint8_t* on_route; const int8_t* tl; const uint8_t* has_sl;
+  const float *speed_emb, *p_type_emb, *route_emb, *tl_emb, *unk_emb;
+  int bs, A, Mp, N, nblk_a; float* X; const float* pe;
+};
+__global__ void token_kernel(TokenP p) {
+  if ((int)blockIdx.x < p.nblk_a)
+    agent_token_body(blockIdx.x * blockDim.x + threadIdx.x, p.nat, p.x_ego, p.valid_agent, p.category, p.a_type_emb, p.bs, p.A, p.N, p.X, p.pe);
+  else
+    polygon_token_body((blockIdx.x - p.nblk_a) * blockDim.x + threadIdx.x, p.pooled, p.ptype, p.on_route, p.tl, p.has_sl, p.speed_emb, p.p_type_emb,
+                       p.route_emb, p.tl_emb, p.unk_emb, p.bs, p.A, p.Mp, p.N, p.X, p.pe);
 }
 
 // static-object tokens (static_objects_encoder.py:24-26): valid ? fourier(shape) + type_emb : 0

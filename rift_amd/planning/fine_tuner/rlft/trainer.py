@@ -180,7 +180,11 @@ class RLFTTrainer:
         # exchange buffers of the DP path (see dp_all_reduce)
         self.flat = torch.zeros(_ffi.PI_NPARAM, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
-        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        # the finalize kernel writes a training step's loss into its own slot of `loss_hist` (summed once per pop_mean_loss()): no
+        # accumulate launch per step; validation writes the separate `loss_val`
+        self.loss_hist = torch.zeros(self.LOSS_SLOTS, dtype=torch.float64, device=dev)
+        self.loss_val = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.loss = self.loss_val
         self.lo = _ffi.RiftLossOut()
         self.lo.loss, self.lo.stats, self.lo.flat_grad_sum = self.loss.data_ptr(), self.stats.data_ptr(), self.flat.data_ptr()
         self.xchg = None
@@ -350,9 +354,21 @@ class RLFTTrainer:
         self.engine.forward_raw(fb, self.out, flags, seed)
         return self._hidden[:fb.bs]
 
+    LOSS_SLOTS = 1024
+
+    def _loss_slot(self, k=None):
+        """Point the loss output at slot k of loss_hist (training step k since the last pop / fold), or at loss_val (k None)."""
+        self.loss = self.loss_val if k is None else self.loss_hist[k:k + 1]
+        self.lo.loss = self.loss.data_ptr()
+
     def training_step(self, fb, extras, shard=None):
         """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step).  Returns the device f64 loss
         scalar; with overlap_update it is written on the update stream -- read it through pop_mean_loss() / wait_update()."""
+        k = self.loss_n % self.LOSS_SLOTS
+        if k == 0 and self.loss_n:          # every slot used: fold them into the accumulator (once per LOSS_SLOTS steps)
+            self.wait_update()
+            self.loss_acc.add_(self.loss_hist.sum())
+        self._loss_slot(k)
         fused_clip = bool(self.gradient_clip_val) and self.critic is None
         if self.overlap_update:
             self.forward_loss(fb, extras, train=True, defer_update=True, shard=shard)
@@ -362,7 +378,6 @@ class RLFTTrainer:
                 self._side.wait_event(self._ev_loss)
                 self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
                 self._optimizer_step()
-                self.loss_acc.add_(self.loss)
                 self._ev_param.record(self._side)
             self.loss_n += 1
             return self.loss
@@ -372,7 +387,6 @@ class RLFTTrainer:
                 self._clip_list = self.engine.make_clip_list([p.grad for p in self.train_params])
             self.engine.clip_grad_norm_raw(self._clip_list, float(self.gradient_clip_val), self.grad_norm)
         self._optimizer_step()
-        self.loss_acc.add_(loss)
         self.loss_n += 1
         return loss
 
@@ -386,7 +400,9 @@ class RLFTTrainer:
         self.wait_update()
         n, self.loss_n = self.loss_n, 0
         self.engine.check_finite()          # the reference's isfinite assert on the decoder queries, at the epoch's one host read
-        v = float(self.loss_acc.item()) / max(n, 1)
+        used = n % self.LOSS_SLOTS or (self.LOSS_SLOTS if n else 0)      # slots written since the last fold
+        # (summed on the host: one small device-to-host copy, no reduction kernel whose first use would load a module mid-epoch)
+        v = (float(self.loss_acc.item()) + float(self.loss_hist[:used].cpu().sum())) / max(n, 1)
         self.loss_acc.zero_()
         return v
 
@@ -432,6 +448,7 @@ class RLFTTrainer:
                                    float(self._adam_step), g0["betas"][0], g0["betas"][1], g0["eps"])
 
     def validation_step(self, fb, extras, shard=None):
+        self._loss_slot(None)
         return self.forward_loss(fb, extras, train=False, backward=False, shard=shard)
 
     def on_epoch_end(self):

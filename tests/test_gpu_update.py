@@ -103,7 +103,8 @@ def test_thirty_step_update_trajectory(oracle_run, precision):
             idx = torch.tensor(pick, dtype=torch.int32, device="cuda:0")
             fb, b = replay.collate(tr.engine, idx, int(replay.r_count_cpu[pick].max()))
             got_losses.append(float(tr.training_step(fb, b).item()))
-        tr.pop_mean_loss()
+        mean = tr.pop_mean_loss()           # the epoch's mean of the per-step device losses (one host read; slots of loss_hist)
+        assert abs(mean - sum(got_losses[-STEPS_PER_EPOCH:]) / STEPS_PER_EPOCH) < 1e-12
         tr.on_epoch_end()
     torch.cuda.synchronize()
     from oracle import pluto_ref
@@ -140,3 +141,34 @@ def test_thirty_step_update_trajectory(oracle_run, precision):
         assert loss_err < 1e-5 and well < 1e-5 and mid < 1e-4 and policy_err < 2e-4 and cosine > 0.9995
     else:
         assert loss_err < 2e-3 and well < 6e-4 and mid < 2e-3 and policy_err < 8e-2 and cosine > 0.97
+
+
+@pytest.mark.gpu
+def test_mean_loss_accounting_across_slot_folds(monkeypatch):
+    """pop_mean_loss() = mean of the step losses also when the steps outnumber the loss slots (they are folded into the accumulator
+    every LOSS_SLOTS steps) and with validation steps in between (validation writes its own scalar)."""
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+    from rift_amd.replay import DeviceReplay
+    from rift_amd import synthetic as syn
+    from tests import helpers as H
+    monkeypatch.setattr(RLFTTrainer, "LOSS_SLOTS", 4)
+    model = PlanningModel(radius=120, drop_path=0.0, dropout=0.0, state_dropout=0.0)
+    model.load_state_dict(H.weights())
+    model = model.to("cuda:0")
+    model.compute_precision, model.need_traj = "bf16", False
+    model.train()
+    tr = RLFTTrainer(model, kind="rift", lr=1e-4, cl_lr_decay=0.9, weight_decay=1e-5, epochs=4, warmup_epochs=1)
+    scenes = [syn.make_scene(40 + i, r_min=3, r_max=5) for i in range(8)]
+    replay = DeviceReplay(scenes, "cuda:0")
+    idx = torch.arange(8, dtype=torch.int32, device="cuda:0")
+    for n in (3, 4, 9, 1):
+        losses = []
+        for i in range(n):
+            fb, b = replay.collate(tr.engine, idx)
+            losses.append(float(tr.training_step(fb, b).item()))
+            if i % 2 == 0:
+                fb, b = replay.collate(tr.engine, idx)
+                tr.validation_step(fb, b)
+        assert abs(tr.pop_mean_loss() - sum(losses) / n) < 1e-12
+    assert tr.pop_mean_loss() == 0.0
