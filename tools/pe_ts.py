@@ -1,7 +1,9 @@
-"""Phase timestamps of pe_mid_kernel (tile 0): RIFT_PE_TS=<20|120>."""
+"""Phase timestamps of pe_mid_kernel (tile 0), the LDS-resident pass B kept behind RIFT_PE_W=0: RIFT_PE_TS=<20|120>.
+(The default pass B is pe_w_kernel: tools/pew_ts.py.)"""
 import os, sys
 n = sys.argv[1] if len(sys.argv) > 1 else "20"
 os.environ["RIFT_PE_TS"] = n
+os.environ["RIFT_PE_W"] = "0"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch
