@@ -122,9 +122,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto dma = [&](const void* src, uint32_t dst, int nfrag) {
     if ((ld_few && !(wv & 2)) || (p.dbg & 8)) return;            // (dbg 8: no stream at all -- compute on whatever LDS holds, timing only)
     const int lw = ld_few ? (wv & 1) + ((wv >> 2) << 1) : wv, ln = ld_few ? 4 : 8;
-#pragma unroll 1
-    for (int f = lw; f < nfrag; f += ln)       // (rolled: every boundary site carries this loop; unrolled it was 40 KB of a 105 KB kernel)
-      decw_glds(reinterpret_cast<const unsigned char*>(src) + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
+    decw_dma_share(reinterpret_cast<const unsigned char*>(src), voff, lds0 + dst, nfrag, lw, ln);   // (one rolled loop: every boundary site carries it)
   };
   // group boundary: my share of the next group has landed; after the barrier everybody's has, and nobody reads the other slot any more
   auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); DTS(); };

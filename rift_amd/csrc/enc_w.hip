@@ -73,8 +73,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned short* kvs = p.KVs + (size_t)b * 96 * 512;
 
   auto dma = [&](const void* src, uint32_t dst, int nfrag) {
-#pragma unroll 1
-    for (int f = wv; f < nfrag; f += 8) decw_glds(reinterpret_cast<const unsigned char*>(src) + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
+    decw_dma_share(reinterpret_cast<const unsigned char*>(src), voff, lds0 + dst, nfrag, wv, 8);
   };
   auto request = [&](int li, int pos) {
     if (pos >= (li == 3 ? 2 * RR + Q3 * RR : GL)) { pos = 0; ++li; }

@@ -67,8 +67,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (s >= total) return;
     const unsigned char* src = wimg + (size_t)(s % 20) * 32768;
     const uint32_t dst = (uint32_t)(s % 3) * 32768u;
-#pragma unroll 1
-    for (int f = wv; f < 32; f += 8) decw_glds(src + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
+    decw_dma_share(src, voff, lds0 + dst, 32, wv, 8);
   };
   // boundary that opens group s: my four requests of it have landed (at most the four of group s + 1 may still fly behind them), then
   // the barrier: everybody's have, and nobody reads slot (s - 1) % 3 any more

@@ -121,8 +121,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   };
   auto dma = [&](const unsigned char* src, uint32_t dst, int nfrag) {
     if (p.dbg & 2) return;                     // (diagnostic: no weight stream -- compute on whatever the ring holds)
-#pragma unroll 1
-    for (int f = wv; f < nfrag; f += 8) decw_glds(src + (size_t)f * 1024, voff, lds0 + dst + (uint32_t)f * 1024u);
+    decw_dma_share(src, voff, lds0 + dst, nfrag, wv, 8);
   };
   auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); PWTS(); };
   // statistics of a finished round: the eight waves' partials are added to this thread's running sum (thread = kind * 256 + channel); the

@@ -20,6 +20,31 @@ __device__ __forceinline__ void decw_glds(const void* src, uint32_t voff, uint32
                : "=&s"(keep) : "v"(voff), "s"(sa), "s"(sd) : "memory");
 }
 
+// four CONSECUTIVE fragments behind one M0 write: the instruction offset moves the global and the LDS address alike (checked byte for byte
+// in tools/ubench/lds_dma_rate.hip).  Writing M0 ahead of every fragment holds a wave at ~210 cycles per request; this form reaches
+// 58 B/cycle/CU with two groups in flight against 39.
+__device__ __forceinline__ void decw_glds4(const void* src, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  const uint64_t a = reinterpret_cast<uint64_t>(src);
+  const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t sd = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sa), "s"(sd) : "memory");
+}
+// This loader's share of an nfrag-fragment group (nfrag >= 4), loader lw of ln: consecutive fragments in runs of four; a run that would
+// pass the end of the group starts at nfrag - 4 instead (re-requesting a neighbour's fragments is harmless and keeps this to one loop).
+__device__ __forceinline__ void decw_dma_share(const unsigned char* src, uint32_t voff, uint32_t lds_dst, int nfrag, int lw, int ln) {
+  const int per = max(4, (nfrag + ln - 1) / ln);
+  const int f1 = min(lw * per + per, nfrag);
+#pragma unroll 1
+  for (int f = lw * per; f < f1; f += 4) {
+    const int ff = min(f, nfrag - 4);
+    decw_glds4(src + (size_t)ff * 1024, voff, lds_dst + (uint32_t)ff * 1024u);
+  }
+}
+
 // One group GEMM (16 rows x K = 128 against the 32 fragments at LDS address `addr` + 1024 f) as a hand-scheduled stream: the 8 fragments of
 // k-step ks + 1 are requested under the 8 MFMAs of k-step ks (lgkmcnt(8) = the fragment 8 requests back has landed), so an MFMA never waits a
 // full LDS round trip; hipcc's own schedule of the same loop kept 1-2 reads in flight.  PLAIN = activations as the A operand (V^T tiles).
