@@ -65,7 +65,7 @@ struct DecWP {
   const unsigned short* img;    // pack_decw_kernel
   const float* par;
   float dropout; uint32_t seed, stream;
-  int dbg;                      // diagnostic: 1 = skip all compute (weight stream + barriers only)
+  int dbg;                      // diagnostic: 1 = skip all compute (weight stream + barriers only), 8 = no stream, 16 = all eight waves carry the stream
   long long* ts;                // optional: clock of wave 0 of workgroup 0 at every group boundary (diagnostic, RIFT_DEC_TS)
 };
 

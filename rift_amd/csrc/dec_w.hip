@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // a contiguous source of nfrag fragments -> LDS byte offset dst.  Who loads: with R <= 6 waves 6 and 7 own no tile in either tiling, and
   // waves 2 and 3 are alone on their SIMDs among the working waves (6 tiles on 4 SIMDs): those four carry the stream, the waves of the
   // doubly loaded SIMDs 0 and 1 go from the barrier straight to their MFMAs.  Otherwise all eight waves share it.
-  const bool ld_few = !DENSE && R <= 6;
+  const bool ld_few = !DENSE && R <= 6 && !(p.dbg & 16);     // (dbg 16: all eight waves carry the stream)
   auto dma = [&](const void* src, uint32_t dst, int nfrag) {
     if ((ld_few && !(wv & 2)) || (p.dbg & 8)) return;            // (dbg 8: no stream at all -- compute on whatever LDS holds, timing only)
     const int lw = ld_few ? (wv & 1) + ((wv >> 2) << 1) : wv, ln = ld_few ? 4 : 8;
