@@ -297,9 +297,8 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
 
     if (wact) {
       // ---- group 0: h1 = relu(bn1(x W1^T + b1)) as the k-steps of W2
-      boundary(0, [&] { if (prev_ri >= 0) finish_stats(); });
+      boundary(0, [&] { if (prev_ri >= 0) finish_stats(); if (pend) { store_hold(3); pend = false; } });
       PWTS();
-      if (pend) { store_hold(3); pend = false; }
       PWTS();
       bf16x8 hb[2][4];
       {
@@ -376,9 +375,9 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       float nxv[2][3];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        boundary(3 + q, [&] { if (q == 1 && nri < R) { to_operand(nxv, xb); vb[0] = nvb[0]; vb[1] = nvb[1]; } });
+        // (the held stores go out AHEAD of the request: behind it they queue in the texture path after the group's 32 requests)
+        boundary(3 + q, [&] { if (q == 1 && nri < R) { to_operand(nxv, xb); vb[0] = nvb[0]; vb[1] = nvb[1]; } if (q > 0) store_hold(q - 1); });
         if (q == 0) { hex[0] = fl[0] != 0; hex[1] = fl[1] != 0; hrow0 = row0; pooled_gp(wb); }
-        else store_hold(q - 1);
         if (q == 0 && nri < R) load_rows(nri, nvb, nxv);      // the next round's rows: in flight under this group
         f32x4 c0[4], c1[4];
 #pragma unroll
