@@ -8,6 +8,7 @@
 #pragma once
 #include "common.h"
 #include "nat_l0w.h"
+#include "wp_stream.h"
 
 namespace rift {
 
@@ -127,11 +128,14 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
   for (int i = tid; i < L1W_NPAR / 4; i += 512) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
   unsigned short* st = stg + wave * 40 * L1W_ST;
   auto W = [&](int f) { return *reinterpret_cast<const bf16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
-  auto load_weights = [&](int frag0, int nfrag) {       // workgroup-wide swap of the weight image (all waves are between phases)
+  // workgroup-wide swap of the weight image (all waves are between phases), by LDS-DMA in runs of four fragments (wp_stream.h): the
+  // copy through registers (512 threads x uint4 per pass, a global and an LDS round trip each) cost 18 us of this kernel's 118
+  const uint32_t wl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw);
+  auto load_weights = [&](int frag0, int nfrag) {
     __syncthreads();
-    const uint4* src = reinterpret_cast<const uint4*>(p.img + (size_t)frag0 * 512);
-    for (int i = tid; i < nfrag * 64; i += 512) reinterpret_cast<uint4*>(wl)[i] = src[i];
-    __syncthreads();
+    decw_dma_share(reinterpret_cast<const unsigned char*>(p.img) + (size_t)frag0 * 1024, (uint32_t)lane * 16u, wl_lds, nfrag,
+                   __builtin_amdgcn_readfirstlane(wave), 8);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
   const int a = l15 >> 2, s = l15 & 3;
