@@ -25,7 +25,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sources()
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
-    # engine.hip, dec_w.hip, nat_l2w.hip, enc_w.hip and pe_w.hip are separate translation units; the wave-private streaming kernels are built with
+    # engine.hip, dec_w.hip, nat_l2w.hip, enc_w.hip, pe_w.hip and fo_w.hip are separate translation units; the wave-private streaming kernels are built with
     # `-fno-honor-nans -mno-amdgpu-ieee`: no IEEE-mode canonicalisation (`v_max_f32 x, x, x` in front of every fmaxf on an MFMA result); they test no NaN.
     common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
     obj = os.path.join(HERE, "_obj")
@@ -35,7 +35,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
              common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "nat_l2w.hip"), "-o", os.path.join(obj, "nat_l2w.o")],
              common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "enc_w.hip"), "-o", os.path.join(obj, "enc_w.o")],
              common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "pe_w.hip"), "-o", os.path.join(obj, "pe_w.o")],
-             common + ["-shared", os.path.join(obj, "engine.o"), os.path.join(obj, "dec_w.o"), os.path.join(obj, "nat_l2w.o"), os.path.join(obj, "enc_w.o"), os.path.join(obj, "pe_w.o"), "-o", LIB]]
+             common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "fo_w.hip"), "-o", os.path.join(obj, "fo_w.o")],
+             common + ["-shared", os.path.join(obj, "engine.o"), os.path.join(obj, "dec_w.o"), os.path.join(obj, "nat_l2w.o"), os.path.join(obj, "enc_w.o"), os.path.join(obj, "pe_w.o"), os.path.join(obj, "fo_w.o"), "-o", LIB]]
     for cmd in steps:
         if verbose:
             print(" ".join(cmd), flush=True)

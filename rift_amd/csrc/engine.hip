@@ -27,6 +27,7 @@
 #include "nat_l2w.h"
 #include "enc_w.h"
 #include "pe_w.h"
+#include "fo_w.h"
 #include "pe_fused.h"
 #include "fourier_fused.h"
 #include "critic.h"
@@ -101,6 +102,7 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
+  bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
   unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // weight stream / parameter blocks of the decoder kernel (dec_w.h)
   double* clip_part = nullptr;
@@ -409,6 +411,7 @@ int set_lds_attrs(RiftCtx* c) {
   HIPCHK(c, (hipError_t)l2w_set_attributes());
   HIPCHK(c, (hipError_t)encw_set_attributes());
   HIPCHK(c, (hipError_t)pew_set_attributes());
+  HIPCHK(c, (hipError_t)fow_set_attributes());
   SETATTR(NAT_L0);
   SETATTR(NAT_L1);
   SETATTR(NAT_L2);
@@ -989,6 +992,16 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     q3.e[2] = fourier_desc(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1, r_emb);
     q3.nblk[0] = cdiv(nT, FO_ROWS); q3.nblk[1] = cdiv(nP, FO_ROWS); q3.nblk[2] = cdiv(nL, FO_ROWS); q3.count = 3;
     c->prof_flops = 2.0 * 128.0 * ((nT + nL) * (3 * 257.0 + 128.0) + nP * (257.0 + 128.0));
+    if (c->fo_w) {          // wave-private form: one 16-row tile per wave, 8 tiles per pass, the one-dimensional embedding two passes per workgroup
+      FoWP w; memset(&w, 0, sizeof(w));
+      w.count = 3;
+      for (int i = 0; i < 3; ++i) {
+        const FourierP& o = q3.e[i]; FoWSide& d = w.e[i];
+        d.in = o.in; d.in_ld = o.in_ld; d.rows = o.rows; d.D = o.D; d.wrap_dim = o.wrap_dim; d.img = c->fow_img[i]; d.par = c->fow_par[i];
+        d.Y = o.Y; d.accumulate = o.accumulate; d.rep = o.D == 1 ? 2 : 1; d.nwg = cdiv(cdiv(o.rows, 16), 8 * d.rep);
+      }
+      launch_call(c, "fourier_fused_kernel", [&] { fow_launch(w, c->stream); });
+    } else
     launch(c, "fourier_fused_kernel", fourier_fused_kernel, dim3(q3.nblk[0] + q3.nblk[1] + q3.nblk[2]), dim3(256), (size_t)FO_LDS, q3);
     PEtok = q3.e[0].Y; speed_emb = q3.e[1].Y; rpe_done = true;
   } else {
@@ -1319,6 +1332,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_L1W"); c->nat_l1w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_NAT_L2W"); c->nat_l2w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }
+  { const char* ev = getenv("RIFT_FO_W"); c->fo_w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   if (hipMalloc((void**)&c->nonfinite, sizeof(int)) != hipSuccess || hipMemset(c->nonfinite, 0, sizeof(int)) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   int rc = set_lds_attrs(c);
@@ -1347,6 +1361,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->encw_img) { (void)hipFree(c->encw_img); (void)hipFree(c->encw_par); }
   if (c->decw_img) { (void)hipFree(c->decw_img); (void)hipFree(c->decw_par); }
   for (int i = 0; i < 2; ++i) if (c->pew_img[i]) (void)hipFree(c->pew_img[i]);
+  for (int i = 0; i < 3; ++i) if (c->fow_img[i]) { (void)hipFree(c->fow_img[i]); (void)hipFree(c->fow_par[i]); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
   delete c;
@@ -1528,6 +1543,24 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     if (!c->err.empty()) return RIFT_ERR_ARG;
     if (!c->encw_img) { HIPCHK(c, hipMalloc((void**)&c->encw_img, (size_t)(4 * ENCW_LAYER_FRAGS + ENCW_TAIL_FRAGS) * 1024)); HIPCHK(c, hipMalloc((void**)&c->encw_par, (size_t)ENCW_NPAR * 4)); }
     encw_pack(q, c->encw_img, c->encw_par, c->stream);
+  }
+  {  // wave-private Fourier embeddings (fo_w.h): weight streams + parameter blocks of the three embeddings of the fused launch
+    const std::string emb[3] = {"pos_emb", "map_encoder.speed_limit_emb", PD + ".r_pos_emb"};
+    const int dims[3] = {3, 1, 3};
+    for (int i = 0; i < 3; ++i) {
+      FoWSrc q; memset(&q, 0, sizeof(q));
+      q.D = dims[i];
+      for (int d = 0; d < q.D; ++d) {
+        const std::string m = emb[i] + ".mlps." + std::to_string(d);
+        q.w0[d] = fptr(c, m + ".0.weight"); q.b0[d] = fptr(c, m + ".0.bias"); q.lng[d] = fptr(c, m + ".1.weight"); q.lnb[d] = fptr(c, m + ".1.bias");
+        q.w3[d] = fptr(c, m + ".3.weight"); q.b3[d] = fptr(c, m + ".3.bias");
+      }
+      q.og = fptr(c, emb[i] + ".to_out.0.weight"); q.ob = fptr(c, emb[i] + ".to_out.0.bias");
+      q.wo = fptr(c, emb[i] + ".to_out.2.weight"); q.bo = fptr(c, emb[i] + ".to_out.2.bias"); q.freqs = fptr(c, emb[i] + ".freqs.weight");
+      if (!c->err.empty()) return RIFT_ERR_ARG;
+      if (!c->fow_img[i]) { HIPCHK(c, hipMalloc((void**)&c->fow_img[i], (size_t)7 * 32 * 1024)); HIPCHK(c, hipMalloc((void**)&c->fow_par[i], (size_t)FOW_NPAR * 4)); }
+      fow_pack(q, c->fow_img[i], c->fow_par[i], c->stream);
+    }
   }
   {  // wave-private PointsEncoder pass B (pe_w.h): W1 | W2 | W3a streams of the two encoders
     const std::string enc[2] = {"map_encoder.polygon_encoder", PD + ".r_encoder"};

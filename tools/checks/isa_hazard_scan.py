@@ -67,7 +67,8 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         for tu, extra in (("engine.hip", []), ("dec_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l2w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
                           ("enc_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
-                          ("pe_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
+                          ("pe_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
+                          ("fo_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
             out = os.path.join(tmp, tu + ".s")
             subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w"] + extra +
                                   [os.path.join(b.CSRC, tu), "-o", out])
