@@ -1000,7 +1000,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         d.in = o.in; d.in_ld = o.in_ld; d.rows = o.rows; d.D = o.D; d.wrap_dim = o.wrap_dim; d.img = c->fow_img[i]; d.par = c->fow_par[i];
         d.Y = o.Y; d.accumulate = o.accumulate; d.rep = o.D == 1 ? 2 : 1; d.nwg = cdiv(cdiv(o.rows, 16), 8 * d.rep);
       }
-      launch_call(c, "fourier_fused_kernel", [&] { fow_launch(w, c->stream); });
+      launch_call(c, "fo_w_kernel", [&] { fow_launch(w, c->stream); });
     } else
     launch(c, "fourier_fused_kernel", fourier_fused_kernel, dim3(q3.nblk[0] + q3.nblk[1] + q3.nblk[2]), dim3(256), (size_t)FO_LDS, q3);
     PEtok = q3.e[0].Y; speed_emb = q3.e[1].Y; rpe_done = true;

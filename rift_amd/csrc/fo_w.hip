@@ -33,7 +33,7 @@ __global__ void pack_fow_kernel(FoWSrc s, unsigned short* __restrict__ img, floa
     } else if (e < FOW_PAR_B3SUM) {
       const int k = e - FOW_PAR_FREQ;
       if (k < s.D * 64) v = s.freqs[k];
-    } else {
+    } else if (e < FOW_PAR_B3SUM + 128) {
       for (int d = 0; d < s.D; ++d) v += s.b3[d][e - FOW_PAR_B3SUM];
     }
     par[e] = v;
@@ -91,7 +91,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 
   dma(0, 0);
-  for (int i = tid; i < FOW_NPAR; i += 512) par[i] = p.par[i];      // (published by the first group barrier)
+  {                                            // the parameter block: every load issued before the first LDS store (published by the first group barrier)
+    float4 t[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) t[u] = tid + u * 512 < FOW_NPAR / 4 ? reinterpret_cast<const float4*>(p.par)[tid + u * 512] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (tid + u * 512 < FOW_NPAR / 4) reinterpret_cast<float4*>(par)[tid + u * 512] = t[u];
+  }
 
 #pragma unroll 1
   for (int r = 0; r < p.rep; ++r) {

@@ -465,13 +465,15 @@ def test_fused_fourier_embedding_matches_layerwise_path(ffi, monkeypatch):
     gold, batch, sd = H.load_case("full")
     data = batch["cur_pluto_feature_torch"]
     outs = {}
-    for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
+    for name, env, fp32 in (("fused", "0", False), ("lds", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
         monkeypatch.setenv("RIFT_FOURIER_UNFUSED", env)
+        monkeypatch.setenv("RIFT_FO_W", "0" if name == "lds" else "1")     # "lds": the LDS-resident fourier_fused_kernel instead of fo_w_kernel
         eng = ffi.Engine("cuda:0")
         eng.load_state_dict({k: v.clone() for k, v in sd.items()})
         eng.prof_enable(True)
         eng.forward(data, fp32=fp32)
-        assert ("fourier_fused_kernel" in eng.prof_report()) == (name == "fused")
+        rep = eng.prof_report()
+        assert ("fo_w_kernel" in rep) == (name == "fused") and ("fourier_fused_kernel" in rep) == (name == "lds")
         eng.prof_enable(False)
         # x_tokens is only meaningful where the (fused) encoder leaves its input untouched, i.e. in the two bf16 runs
         outs[name] = (eng.tap("r_emb").cpu().clone(), eng.tap("x_tokens").cpu().clone())
@@ -479,7 +481,9 @@ def test_fused_fourier_embedding_matches_layerwise_path(ffi, monkeypatch):
     scale = max(1.0, float(outs["fp32"][0].abs().max()))
     assert err(outs["fused"][0], outs["fp32"][0]) < 3e-2 * scale
     assert err(outs["fused"][0], outs["layerwise"][0]) < 3e-2 * scale
-    assert err(outs["fused"][1], outs["layerwise"][1]) < 3e-2 * max(1.0, float(outs["layerwise"][1].abs().max()))
+    assert err(outs["lds"][0], outs["fp32"][0]) < 3e-2 * scale
+    for k in ("fused", "lds"):
+        assert err(outs[k][1], outs["layerwise"][1]) < 3e-2 * max(1.0, float(outs["layerwise"][1].abs().max()))
 
 
 def test_fused_trajectory_heads_match_layerwise_path(ffi, monkeypatch):
