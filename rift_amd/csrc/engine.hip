@@ -801,6 +801,10 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   static const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128}, Hl[3] = {2, 4, 8}, Kl[3] = {3, 3, 5};
   float* Oc[3];   // LayerNorm(norm_i) of the last 3 steps of level i: all that out[:, :, -1] of the FPN depends on
   for (int i = 0; i < 3; ++i) Oc[i] = A_alloc<float>(c, (size_t)nA * 3 * Cl[i]);
+  // the wave-private level kernels hand these rows to fpn_tail_kernel as bf16 (it rounds them to bf16 first thing anyway): same values, half the bytes
+  const bool oc_bf16 = fused && c->fpn_fused && c->nat_l0w && c->nat_l1w && c->nat_l2w;
+  unsigned short* Ocb[3] = {nullptr, nullptr, nullptr};
+  if (oc_bf16) for (int i = 0; i < 3; ++i) Ocb[i] = A_alloc<unsigned short>(c, (size_t)nA * 3 * Cl[i]);
   if (fused) {
     // one launch per level: [ConvTokenizer ->] 2 NAT blocks -> {FPN LayerNorm of the last 3 steps, downsample conv + LN}
     float* Xin[3] = {nullptr, A_alloc<float>(c, (size_t)nA * 10 * 64), A_alloc<float>(c, (size_t)nA * 5 * 128)};
@@ -808,7 +812,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       const int C = Cl[lv], H = Hl[lv], ksz = Kl[lv], L = Ll[lv], rows = nA * L;
       if (lv == 0 && c->nat_l0w) {   // level 0 as wave-private, register-resident tiles (no workgroup barriers): nat_l0w.h
         NatL0WP q; memset(&q, 0, sizeof(q));
-        q.F9 = F9; q.nseq = nA; q.img = c->l0w_img; q.par = c->l0w_par; q.Oc = Oc[0]; q.Xnext = Xin[1];
+        q.F9 = F9; q.nseq = nA; q.img = c->l0w_img; q.par = c->l0w_par; q.Oc = Oc[0]; q.Ocb = Ocb[0]; q.Xnext = Xin[1];
         { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 1) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         q.droppath[0] = f.drop ? dpr[0] : 0.f; q.droppath[1] = f.drop ? dpr[1] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + 2.0 * rows * 27 * 32 + (rows / 2) * 2.0 * 3 * C * 2 * C;
@@ -817,7 +821,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       }
       if (lv == 1 && c->nat_l1w) {   // level 1 likewise (weights swapped through LDS between the two layers): nat_l1w.h
         NatL1WP q; memset(&q, 0, sizeof(q));
-        q.X = Xin[1]; q.nseq = nA; q.img = c->l1w_img; q.par = c->l1w_par; q.Oc = Oc[1]; q.Xnext = Xin[2];
+        q.X = Xin[1]; q.nseq = nA; q.img = c->l1w_img; q.par = c->l1w_par; q.Oc = Oc[1]; q.Ocb = Ocb[1]; q.Xnext = Xin[2];
         q.droppath[0] = f.drop ? dpr[2] : 0.f; q.droppath[1] = f.drop ? dpr[3] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (rows / 2) * 2.0 * 3 * C * 2 * C;
         launch(c, "nat_level_kernel_L1", nat_l1w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid)), dim3(512), (size_t)L1W_LDS, q);
@@ -825,7 +829,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       }
       if (lv == 2 && c->nat_l2w) {   // level 2: wave-private tiles of 3 agents, the two layers' weights streamed through LDS (nat_l2w.h)
         NatL2WP q; memset(&q, 0, sizeof(q));
-        q.X = Xin[2]; q.nseq = nA; q.img = c->l2w_img; q.par = c->l2w_par; q.Oc = Oc[2];
+        q.X = Xin[2]; q.nseq = nA; q.img = c->l2w_img; q.par = c->l2w_par; q.Oc = Oc[2]; q.Ocb = Ocb[2];
         q.droppath[0] = f.drop ? dpr[4] : 0.f; q.droppath[1] = f.drop ? dpr[5] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 3) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C);
@@ -909,7 +913,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     FpnP q; memset(&q, 0, sizeof(q));
     for (int i = 0; i < 3; ++i) {
       const PW& w = c->pw[HE + ".lateral_convs." + std::to_string(i)];
-      q.oc[i] = Oc[i]; q.wl[i] = (const unsigned short*)w.bf; q.bl[i] = w.bias;
+      q.oc[i] = Oc[i]; q.ocb[i] = Ocb[i]; q.wl[i] = (const unsigned short*)w.bf; q.bl[i] = w.bias;
     }
     q.wf = (const unsigned short*)c->pw[HE + ".fpn_conv.last"].bf; q.bf_ = c->pw[HE + ".fpn_conv.last"].bias;
     q.out = nat_out; q.nA = nA;

@@ -13,6 +13,7 @@ namespace rift {
 
 struct FpnP {
   const float* oc[3];            // level i: (nA, 3, C_i) normalised last three steps, C = 32, 64, 128
+  const unsigned short* ocb[3];  // if set: the same rows already rounded to bf16 by the NAT kernel that wrote them
   const unsigned short* wl[3];   // lateral conv weights, fragment-major bf16 [128][3 C_i] tap-major
   const float* bl[3];
   const unsigned short* wf;      // fpn conv at the last step, taps 0 and 1: [128][256]
@@ -35,9 +36,11 @@ __device__ __forceinline__ void fpn_lateral(const FpnP& p, int lv, int a0, unsig
   for (int i = tid; i < V; i += 512) {
     const int a = i / (3 * (C / 4)), rem = i - a * (3 * (C / 4));
     const int pz = rem / (C / 4), c4 = (rem - pz * (C / 4)) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a0 + a < p.nA) v = *reinterpret_cast<const float4*>(p.oc[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4);
-    const uint2 u = pack_bf16x4(v.x, v.y, v.z, v.w);
+    uint2 u = make_uint2(0u, 0u);
+    if (a0 + a < p.nA) {
+      if (p.ocb[lv]) u = *reinterpret_cast<const uint2*>(p.ocb[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4);
+      else { const float4 v = *reinterpret_cast<const float4*>(p.oc[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4); u = pack_bf16x4(v.x, v.y, v.z, v.w); }
+    }
     *reinterpret_cast<uint2*>(At + (a * 2) * FPN_LDA + pz * C + c4) = u;
     if (pz >= 1) *reinterpret_cast<uint2*>(At + (a * 2 + 1) * FPN_LDA + (pz - 1) * C + c4) = u;
   }

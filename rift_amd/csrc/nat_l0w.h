@@ -100,6 +100,7 @@ struct NatL0WP {
   const float* F9; int nseq;               // (nseq * 20, 9) agent features
   const unsigned short* img; const float* par;
   float* Oc;                               // (nseq * 3, 32)  LayerNorm(norm0) of steps 17..19
+  unsigned short* Ocb;                     // if set: the same rows as bf16 instead (what fpn_tail_kernel rounds them to anyway: half the bytes both ways)
   float* Xnext;                            // (nseq * 10, 64) downsample conv + LayerNorm
   float droppath[2]; uint32_t seed, stream;
   long long* ts;                           // optional section timestamps of wave 0 of workgroup 0 (diagnostic, RIFT_NAT_TS=1)
@@ -312,9 +313,16 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
                                  ((dw[0] * dw[0] + dw[1] * dw[1]) + (dw[2] * dw[2] + dw[3] * dw[3]))) * (1.0f / 32.0f);
       const float r = rsqrtf(var + 1e-5f);
       if (seq_ok && s >= 1) {
-        float* dst = p.Oc + ((size_t)seq * 3 + (s - 1)) * 32;
-        *reinterpret_cast<float4*>(dst + l4 * 4) = make_float4(du[0] * r * g0.x + b0.x, du[1] * r * g0.y + b0.y, du[2] * r * g0.z + b0.z, du[3] * r * g0.w + b0.w);
-        *reinterpret_cast<float4*>(dst + 16 + l4 * 4) = make_float4(dw[0] * r * g1.x + b1.x, dw[1] * r * g1.y + b1.y, dw[2] * r * g1.z + b1.z, dw[3] * r * g1.w + b1.w);
+        const float4 o0 = make_float4(du[0] * r * g0.x + b0.x, du[1] * r * g0.y + b0.y, du[2] * r * g0.z + b0.z, du[3] * r * g0.w + b0.w);
+        const float4 o1 = make_float4(dw[0] * r * g1.x + b1.x, dw[1] * r * g1.y + b1.y, dw[2] * r * g1.z + b1.z, dw[3] * r * g1.w + b1.w);
+        const size_t orow = ((size_t)seq * 3 + (s - 1)) * 32;
+        if (p.Ocb) {
+          *reinterpret_cast<uint2*>(p.Ocb + orow + l4 * 4) = pack_bf16x4(o0.x, o0.y, o0.z, o0.w);
+          *reinterpret_cast<uint2*>(p.Ocb + orow + 16 + l4 * 4) = pack_bf16x4(o1.x, o1.y, o1.z, o1.w);
+        } else {
+          *reinterpret_cast<float4*>(p.Oc + orow + l4 * 4) = o0;
+          *reinterpret_cast<float4*>(p.Oc + orow + 16 + l4 * 4) = o1;
+        }
       }
     }
     // ---- next level's input: Conv1d(32 -> 64, k = 3, stride 2, pad 1, no bias) + LayerNorm(64).  Output row (a, t') reads steps

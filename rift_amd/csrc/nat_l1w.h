@@ -86,6 +86,7 @@ struct NatL1WP {
   const float* X; int nseq;                // (nseq * 10, 64) level input (level 0's downsample output)
   const unsigned short* img; const float* par;
   float* Oc;                               // (nseq * 3, 64)  LayerNorm(norm1) of steps 7..9
+  unsigned short* Ocb;                     // if set: the same rows as bf16 instead (what fpn_tail_kernel rounds them to anyway: half the bytes both ways)
   float* Xnext;                            // (nseq * 5, 128) downsample conv + LayerNorm
   float droppath[2]; uint32_t seed, stream;
 };
@@ -291,12 +292,13 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
         const float r = rsqrtf(rows_sum(qs) * (1.0f / 64.0f) + 1e-5f);
         const int t = mt * 4 + s;
         if (seq_ok && t >= 7 && t < L) {
-          float* dst = p.Oc + ((size_t)seq * 3 + (t - 7)) * 64;
+          const size_t orow = ((size_t)seq * 3 + (t - 7)) * 64;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
             const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 64 + nt * 16 + l4 * 4);
-            *reinterpret_cast<float4*>(dst + nt * 16 + l4 * 4) =
-                make_float4(d[nt][0] * r * gg.x + bb.x, d[nt][1] * r * gg.y + bb.y, d[nt][2] * r * gg.z + bb.z, d[nt][3] * r * gg.w + bb.w);
+            const float4 o = make_float4(d[nt][0] * r * gg.x + bb.x, d[nt][1] * r * gg.y + bb.y, d[nt][2] * r * gg.z + bb.z, d[nt][3] * r * gg.w + bb.w);
+            if (p.Ocb) *reinterpret_cast<uint2*>(p.Ocb + orow + nt * 16 + l4 * 4) = pack_bf16x4(o.x, o.y, o.z, o.w);
+            else *reinterpret_cast<float4*>(p.Oc + orow + nt * 16 + l4 * 4) = o;
           }
         }
       }

@@ -34,6 +34,7 @@ struct NatL2WP {
   const float* X; int nseq;                // (nseq * 5, 128) level input (level 1's downsample output)
   const unsigned short* img; const float* par;
   float* Oc;                               // (nseq * 3, 128) LayerNorm(norm2) of steps 2..4
+  unsigned short* Ocb;                     // if set: the same rows as bf16 instead (what fpn_tail_kernel rounds them to anyway: half the bytes both ways)
   float droppath[2]; uint32_t seed, stream;
   long long* ts;                           // optional: clock of wave 0 of workgroup 0 at every group boundary (diagnostic)
 };

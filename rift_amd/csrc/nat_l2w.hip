@@ -230,12 +230,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int nt = 0; nt < 8; ++nt) { d[nt] = res[nt] - mean; q4 += d[nt] * d[nt]; }
       const float r = rsqrtf(rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f) + 1e-5f);
       if (row_ok && qt >= 2) {
-        float* dst = p.Oc + ((size_t)seq * 3 + (qt - 2)) * 128;
+        const size_t orow = ((size_t)seq * 3 + (qt - 2)) * 128;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
           const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 128 + nt * 16 + l4 * 4);
-          *reinterpret_cast<float4*>(dst + nt * 16 + l4 * 4) =
-              make_float4(d[nt][0] * r * gg.x + bb.x, d[nt][1] * r * gg.y + bb.y, d[nt][2] * r * gg.z + bb.z, d[nt][3] * r * gg.w + bb.w);
+          const float4 o = make_float4(d[nt][0] * r * gg.x + bb.x, d[nt][1] * r * gg.y + bb.y, d[nt][2] * r * gg.z + bb.z, d[nt][3] * r * gg.w + bb.w);
+          if (p.Ocb) *reinterpret_cast<uint2*>(p.Ocb + orow + nt * 16 + l4 * 4) = pack_bf16x4(o.x, o.y, o.z, o.w);
+          else *reinterpret_cast<float4*>(p.Oc + orow + nt * 16 + l4 * 4) = o;
         }
       }
     }
