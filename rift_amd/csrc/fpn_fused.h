@@ -26,23 +26,45 @@ struct FpnP {
 #define FPN_LDA 400
 #define FPN_LDS (128 * FPN_LDA * 2)
 
+// the rows of level lv that this thread stages (issued for all three levels before the first one is used: one global round trip instead of three)
+template <int C>
+struct FpnRows { uint2 u[(FPN_AG * 3 * (C / 4) + 511) / 512]; };
+
+template <int C>
+__device__ __forceinline__ void fpn_load(const FpnP& p, int lv, int a0, FpnRows<C>& R, int tid) {
+  constexpr int V = FPN_AG * 3 * (C / 4), N = (V + 511) / 512;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int i = tid + k * 512;
+    uint2 u = make_uint2(0u, 0u);
+    if (i < V) {
+      const int a = i / (3 * (C / 4)), rem = i - a * (3 * (C / 4));
+      const int pz = rem / (C / 4), c4 = (rem - pz * (C / 4)) * 4;
+      if (a0 + a < p.nA) {
+        if (p.ocb[lv]) u = *reinterpret_cast<const uint2*>(p.ocb[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4);
+        else { const float4 v = *reinterpret_cast<const float4*>(p.oc[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4); u = pack_bf16x4(v.x, v.y, v.z, v.w); }
+      }
+    }
+    R.u[k] = u;
+  }
+}
+
 template <int C, int KS>
-__device__ __forceinline__ void fpn_lateral(const FpnP& p, int lv, int a0, unsigned short* At, f32x4 (&acc)[8][1], int tid, int wave,
+__device__ __forceinline__ void fpn_lateral(const FpnP& p, int lv, const FpnRows<C>& R, unsigned short* At, f32x4 (&acc)[8][1], int tid, int wave,
                                             int l15, int l4) {
   PFrags<KS, 1> W;
   p_load_w<8, KS, 1>(W, p.wl[lv], 3 * C, 0, wave, l15, l4);
   // A tile: row (a, j) = [x[a][j], x[a][j+1], x[a][j+2] or 0], x = oc[lv][a] (3 x C)
-  constexpr int V = FPN_AG * 3 * (C / 4);
-  for (int i = tid; i < V; i += 512) {
-    const int a = i / (3 * (C / 4)), rem = i - a * (3 * (C / 4));
-    const int pz = rem / (C / 4), c4 = (rem - pz * (C / 4)) * 4;
-    uint2 u = make_uint2(0u, 0u);
-    if (a0 + a < p.nA) {
-      if (p.ocb[lv]) u = *reinterpret_cast<const uint2*>(p.ocb[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4);
-      else { const float4 v = *reinterpret_cast<const float4*>(p.oc[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4); u = pack_bf16x4(v.x, v.y, v.z, v.w); }
+  constexpr int V = FPN_AG * 3 * (C / 4), N = (V + 511) / 512;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int i = tid + k * 512;
+    if (i < V) {
+      const int a = i / (3 * (C / 4)), rem = i - a * (3 * (C / 4));
+      const int pz = rem / (C / 4), c4 = (rem - pz * (C / 4)) * 4;
+      *reinterpret_cast<uint2*>(At + (a * 2) * FPN_LDA + pz * C + c4) = R.u[k];
+      if (pz >= 1) *reinterpret_cast<uint2*>(At + (a * 2 + 1) * FPN_LDA + (pz - 1) * C + c4) = R.u[k];
     }
-    *reinterpret_cast<uint2*>(At + (a * 2) * FPN_LDA + pz * C + c4) = u;
-    if (pz >= 1) *reinterpret_cast<uint2*>(At + (a * 2 + 1) * FPN_LDA + (pz - 1) * C + c4) = u;
   }
   for (int i = tid; i < FPN_AG * (C / 4); i += 512) {      // the third tap of position 1 looks past the sequence end
     const int a = i / (C / 4), c4 = (i - a * (C / 4)) * 4;
@@ -64,9 +86,11 @@ __global__ __launch_bounds__(512) void fpn_tail_kernel(FpnP p) {
   PFrags<8, 1> Wf;
   p_load_w<8, 8, 1>(Wf, p.wf, 256, 0, wave, l15, l4);
   f32x4 a2[8][1], a1[8][1], a0c[8][1];
-  fpn_lateral<128, 12>(p, 2, a0, At, a2, tid, wave, l15, l4);
-  fpn_lateral<64, 6>(p, 1, a0, At, a1, tid, wave, l15, l4);
-  fpn_lateral<32, 3>(p, 0, a0, At, a0c, tid, wave, l15, l4);
+  FpnRows<128> r2; FpnRows<64> r1; FpnRows<32> r0;
+  fpn_load<128>(p, 2, a0, r2, tid); fpn_load<64>(p, 1, a0, r1, tid); fpn_load<32>(p, 0, a0, r0, tid);
+  fpn_lateral<128, 12>(p, 2, r2, At, a2, tid, wave, l15, l4);
+  fpn_lateral<64, 6>(p, 1, r1, At, a1, tid, wave, l15, l4);
+  fpn_lateral<32, 3>(p, 0, r0, At, a0c, tid, wave, l15, l4);
   const float4 b2 = *reinterpret_cast<const float4*>(p.bl[2] + col), b1 = *reinterpret_cast<const float4*>(p.bl[1] + col),
                b0 = *reinterpret_cast<const float4*>(p.bl[0] + col);
   const float bb2[4] = {b2.x, b2.y, b2.z, b2.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w}, bb0[4] = {b0.x, b0.y, b0.z, b0.w};
