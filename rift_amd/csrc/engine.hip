@@ -584,15 +584,30 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
   pe_fill(f, q.b, Fr, 6, gr, 120, vr, pr);
   const int nt = q.a.ntiles + q.b.ntiles;
   const double rows = (double)q.a.rows + q.b.rows, groups = (double)gm + gr;
-  if (f.train) {
+  const bool stats_p = f.train && c->pe_w;          // persistent pass A: one partial per workgroup (pe_fused.h)
+  if (stats_p) {
+    int g = std::min(nt, 4 * c->nat_grid);          // four 256-thread workgroups per CU
+    int ga = (int)(((long long)g * q.a.ntiles + nt / 2) / nt);
+    if (q.a.ntiles > 0 && ga < 1) ga = 1;
+    if (q.b.ntiles > 0 && ga > g - 1) ga = g - 1;
+    if (q.b.ntiles == 0) ga = g;
+    ga = std::min(ga, q.a.ntiles);
+    q.a.nwg1 = ga; q.b.nwg1 = std::min(g - ga, q.b.ntiles);
+    PeP* sd[2] = {&q.a, &q.b};
+    for (int i = 0; i < 2; ++i) { sd[i]->part1w = A_alloc<float>(c, (size_t)2 * 128 * std::max(sd[i]->nwg1, 1)); sd[i]->cnt1w = A_alloc<int>(c, std::max(sd[i]->nwg1, 1)); }
+    c->prof_flops = 2.0 * 128.0 * (q.a.rows * 10.0 + q.b.rows * 6.0);
+    launch(c, "pe_stats1_kernel", pe_stats1p_kernel, dim3(q.a.nwg1 + q.b.nwg1), dim3(256), 0, q);
+  } else if (f.train) {
     c->prof_flops = 2.0 * 128.0 * (q.a.rows * 10.0 + q.b.rows * 6.0);
     launch(c, "pe_stats1_kernel", pe_stats1_kernel, dim3(nt), dim3(256), 0, q);
   }
   const bool dpx = f.dp && f.train;      // data parallel: the four BatchNorms see the statistics of the GLOBAL minibatch
   double* xs = dpx ? c->dp.xchg + f.kb : nullptr;
   for (int mode = dpx ? 1 : 0; mode <= (dpx ? 2 : 0); ++mode) {
-    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(256), dim3(256), 0, bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1, xs, mode),
-           bn_fin(c, q.b, pr + ".first_mlp.1", 128, q.b.part1, q.b.s1, q.b.t1, xs ? xs + 257 : nullptr, mode), f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+    BnFinP f1a = bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1, xs, mode);
+    BnFinP f1b = bn_fin(c, q.b, pr + ".first_mlp.1", 128, q.b.part1, q.b.s1, q.b.t1, xs ? xs + 257 : nullptr, mode);
+    if (stats_p) { f1a.part = q.a.part1w; f1a.cnt = q.a.cnt1w; f1a.nblk = q.a.nwg1; f1b.part = q.b.part1w; f1b.cnt = q.b.cnt1w; f1b.nblk = q.b.nwg1; }
+    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(256), dim3(256), 0, f1a, f1b, f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
     if (mode == 1) dp_exchange(f, 2 * 257);
   }
   c->prof_flops = 2.0 * rows * (128.0 * 8 + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;

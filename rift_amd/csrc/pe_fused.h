@@ -31,6 +31,7 @@ struct PeP {
   float* part1;                         // [2][128][ntiles] tile sums of h1, h1^2 over valid rows
   float* part2;                         // [2][256][ntiles] tile sums of g, g^2
   int* cnt;                             // [ntiles] valid rows per tile
+  float* part1w; int* cnt1w; int nwg1;  // persistent pass A (pe_stats1p_kernel): [2][128][nwg1] sums over a workgroup's tiles, [nwg1] valid rows
   unsigned short* Fmid;                 // (rows, 256) fp16 bits: g = second_mlp.0 pre-activation
   float* gp;                            // (rows / NPTS, 256)
   float* out;                           // (rows / NPTS, 128)
@@ -166,6 +167,98 @@ __device__ __forceinline__ void pe_stats1_body(const PeP& p, const int tile) {
 
 // two encoders (map polygons: 20 points per polyline, reference lines: 120) in one launch: tiles [0, a.ntiles) belong to `a`
 struct PeP2 { PeP a, b; };
+
+// Pass A, persistent: a workgroup walks the tiles wg, wg + G, ... of one encoder with the per-lane partial sums of h1, h1^2 in registers and
+// reduces / stores them ONCE (the one-tile-per-workgroup form below pays a 256-float scattered store, a cross-lane reduction and the launch
+// floor of 2900 workgroups for 16 MFMAs of work each).  Still writes the per-tile valid counts (pass B skips empty rounds by them).
+__device__ __forceinline__ void pe_stats1p_body(const PeP& p, const int wg, const int G) {
+  __shared__ __attribute__((aligned(16))) unsigned short xin[PE_ROWS * PE_XS];
+  __shared__ unsigned char sval[PE_ROWS];
+  __shared__ __attribute__((aligned(16))) float b1s[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  PFrags<1, 2> W1;
+  p_load_w<4, 1, 2>(W1, p.w1, 32, 0, wave, l15, l4);
+  if (tid < 128) b1s[tid] = p.b1[tid];
+  f32x2_t s01[2], s23[2], q01[2], q23[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { s01[j] = (f32x2_t)0.f; s23[j] = s01[j]; q01[j] = s01[j]; q23[j] = s01[j]; }
+  int nvw = 0;
+  // The tile's features are one contiguous run of 120 Cin floats: fetched linearly (five coalesced loads per thread; the [row][32]-shaped
+  // gather of pe_stage_x is 16 mostly masked loads per thread, and those load instructions were what this pass took its 20 us for), the
+  // next tile's before this tile's MFMAs.  Columns k >= Cin of the operand tile are zeroed once.
+  constexpr int NXL = (PE_USED * 10 + 255) / 256;                  // Cin <= 10
+  const int Cin = p.Cin;
+  const float rcin = 1.0f / (float)Cin;
+  float xv[NXL];
+  unsigned char fl = 0;
+  auto request = [&](int tile) {
+    const int row0 = tile * PE_USED;
+    const int nfl = tile < p.ntiles ? min(PE_USED, p.rows - row0) * Cin : 0;
+    fl = 0;
+    if (tile < p.ntiles && tid < PE_USED && row0 + tid < p.rows) fl = p.valid[row0 + tid] ? 1 : 2;
+#pragma unroll
+    for (int u = 0; u < NXL; ++u) { const int i = tid + u * 256; xv[u] = i < nfl ? p.F[(size_t)row0 * Cin + i] : 0.f; }
+  };
+  for (int i = tid; i < PE_ROWS * PE_XS / 2; i += 256) reinterpret_cast<unsigned int*>(xin)[i] = 0u;
+  request(wg);
+  __syncthreads();
+  for (int tile = wg; tile < p.ntiles; tile += G) {
+    if (tid < PE_ROWS) sval[tid] = fl;
+#pragma unroll
+    for (int u = 0; u < NXL; ++u) {
+      const int i = tid + u * 256;
+      if (i < PE_USED * Cin) {
+        const int r = (int)(((float)i + 0.5f) * rcin), k = i - r * Cin;
+        xin[r * PE_XS + k] = f2bf(xv[u]);
+      }
+    }
+    const int nv = __syncthreads_count(fl == 1);                  // (the barrier also publishes b1s the first time)
+    request(tile + G);
+    if (tid == 0) p.cnt[tile] = nv;
+    nvw += nv;
+    if (nv) {
+      f32x4 acc[8][2];
+      p_zero(acc);
+      p_mma<8, 1, 2>(acc, xin, PE_XS, 0, W1, l15, l4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(b1s + (j * 4 + wave) * 16 + l4 * 4);
+        f32x2_t b01, b23;
+        b01.x = b.x; b01.y = b.y; b23.x = b.z; b23.y = b.w;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          const f32x2_t ok = (f32x2_t)(sval[mt * 16 + l15] == 1 ? 1.0f : 0.0f);
+          f32x2_t v01, v23;
+          v01.x = acc[mt][j][0]; v01.y = acc[mt][j][1]; v23.x = acc[mt][j][2]; v23.y = acc[mt][j][3];
+          v01 = (v01 + b01) * ok; v23 = (v23 + b23) * ok;
+          s01[j] += v01; s23[j] += v23;
+          q01[j] = __builtin_elementwise_fma(v01, v01, q01[j]); q23[j] = __builtin_elementwise_fma(v23, v23, q23[j]);
+        }
+      }
+    }
+    __syncthreads();                                               // the tile buffers are free again
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = (j * 4 + wave) * 16 + l4 * 4;
+    float sv[4] = {s01[j].x, s01[j].y, s23[j].x, s23[j].y}, qv[4] = {q01[j].x, q01[j].y, q23[j].x, q23[j].y};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sv[r] = sum16(sv[r]); qv[r] = sum16(qv[r]); }
+    if (l15 == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p.part1w[(size_t)(col + r) * G + wg] = sv[r];
+        p.part1w[(size_t)(128 + col + r) * G + wg] = qv[r];
+      }
+    }
+  }
+  if (tid == 0) p.cnt1w[wg] = nvw;
+}
+
+__global__ __launch_bounds__(256) void pe_stats1p_kernel(PeP2 q) {
+  if ((int)blockIdx.x < q.a.nwg1) pe_stats1p_body(q.a, blockIdx.x, q.a.nwg1);
+  else pe_stats1p_body(q.b, blockIdx.x - q.a.nwg1, q.b.nwg1);
+}
 
 __global__ __launch_bounds__(256) void pe_stats1_kernel(PeP2 q) {
   if ((int)blockIdx.x < q.a.ntiles) pe_stats1_body(q.a, blockIdx.x);
