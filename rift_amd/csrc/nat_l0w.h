@@ -18,6 +18,7 @@
 // No workgroup barrier after the prologue.
 #pragma once
 #include "common.h"
+#include "wp_stream.h"
 
 namespace rift {
 
@@ -140,9 +141,11 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
   float* par = reinterpret_cast<float*>(wl + L0W_NFRAG * 512);
   unsigned short* stg = reinterpret_cast<unsigned short*>(par + L0W_NPAR);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  for (int i = tid; i < L0W_NFRAG * 64; i += NTHR) reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(p.img)[i];
+  // the weight image by LDS-DMA in runs of four fragments (wp_stream.h; lands under the parameter copy below, waited for at the barrier)
+  decw_dma_share(reinterpret_cast<const unsigned char*>(p.img), (uint32_t)lane * 16u, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw), L0W_NFRAG,
+                 __builtin_amdgcn_readfirstlane(wave), L0W_NWV);
   for (int i = tid; i < L0W_NPAR / 4; i += NTHR) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   unsigned short* st = stg + wave * 80 * L0W_ST;
   auto W = [&](int f) { return *reinterpret_cast<const bf16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
