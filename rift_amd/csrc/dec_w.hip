@@ -136,10 +136,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   dma(wimg, 0, 32);
   dma(p.par, OFF_E, 18);
   dma(p.par + DECW_E_N, OFF_L, 6);
-  if (!DENSE) {
-    for (int i = tid; i < 96 * 32; i += 512) {
-      const int r = i >> 5, c4 = (i & 31) * 4;
-      if (r < NQ) *reinterpret_cast<float4*>(xs + r * XS + c4) = *reinterpret_cast<const float4*>(p.Q + (qrow0 + r) * 128 + c4);
+  if (!DENSE) {                                 // every query row requested before the first LDS store (as a rolled loop this was six dependent global round trips)
+    float4 qv[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = tid + u * 512, r = i >> 5, c4 = (i & 31) * 4;
+      qv[u] = *reinterpret_cast<const float4*>(p.Q + (qrow0 + (r < NQ ? r : 0)) * 128 + c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = tid + u * 512, r = i >> 5, c4 = (i & 31) * 4;
+      if (r < NQ) *reinterpret_cast<float4*>(xs + r * XS + c4) = qv[u];
     }
   }
   for (int i = tid; i < 16 * NKT; i += 512) smaskf[i] = ((i >= N) || p.kpm[(size_t)b * N + i]) ? -INFINITY : 0.f;
