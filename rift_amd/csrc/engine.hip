@@ -102,6 +102,7 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
+  bool two_streams = true; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
   bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
   unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // weight stream / parameter blocks of the decoder kernel (dec_w.h)
@@ -813,6 +814,16 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   }
   static const float dpr[6] = {0.f, 0.04f, 0.08f, 0.12f, 0.16f, 0.2f};   // linspace(0, 0.2, 6), embedding.py:30
   const bool fused = c->nat_fused && !f.fp32;
+  // fork: the agent-history chain depends on prep_kernel only and joins at the token assembly; on its own stream it fills the CUs the
+  // map / reference-line chain leaves idle (partial last rounds, 238-workgroup launches) and vice versa.  Off while profiling per kernel.
+  hipStream_t main_stream = c->stream;
+  const bool forked = c->two_streams && fused && !c->prof_on && !c->dry;
+  if (forked) {
+    if (!c->side) { HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
+    HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    c->stream = c->side;
+  }
   static const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128}, Hl[3] = {2, 4, 8}, Kl[3] = {3, 3, 5};
   float* Oc[3];   // LayerNorm(norm_i) of the last 3 steps of level i: all that out[:, :, -1] of the FPN depends on
   for (int i = 0; i < 3; ++i) Oc[i] = A_alloc<float>(c, (size_t)nA * 3 * Cl[i]);
@@ -948,6 +959,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
            (const float*)lat[2], nA, Z);
     gemm(c, mk(Z, 256, nA, c->pw[HE + ".fpn_conv.last"], nat_out, 128), c->pw[HE + ".fpn_conv.last"], f.fp32);
   }
+  if (forked) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
   tap(c, "nat_out", nat_out, (int64_t)nA * 128);
 
   // ego state token (StateAttentionEncoder, agent_encoder.py:99-140)
@@ -1026,6 +1038,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   } else {
     speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
   }
+  if (forked) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));      // join: the agent tokens need the history encoder's output
   {
     TokenP q;
     q.nat = nat_out; q.x_ego = x_ego; q.valid_agent = (const uint8_t*)valid_agent; q.category = B->agent_category; q.a_type_emb = fptr(c, "agent_encoder.type_emb.weight");
@@ -1352,6 +1365,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_L2W"); c->nat_l2w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_FO_W"); c->fo_w = !(ev && ev[0] == '0'); }
+  { const char* ev = getenv("RIFT_TWO_STREAMS"); c->two_streams = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   if (hipMalloc((void**)&c->nonfinite, sizeof(int)) != hipSuccess || hipMemset(c->nonfinite, 0, sizeof(int)) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   int rc = set_lds_attrs(c);
@@ -1381,6 +1395,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->decw_img) { (void)hipFree(c->decw_img); (void)hipFree(c->decw_par); }
   for (int i = 0; i < 2; ++i) if (c->pew_img[i]) (void)hipFree(c->pew_img[i]);
   for (int i = 0; i < 3; ++i) if (c->fow_img[i]) { (void)hipFree(c->fow_img[i]); (void)hipFree(c->fow_par[i]); }
+  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
   delete c;
@@ -1637,6 +1652,7 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // pass 1 (dry): size the activation arena; pass 2: launch
   c->dry = true; c->arena_off = 0;
   int rc = forward_impl(c, B, out, flags, seed);
+  c->stream = (hipStream_t)stream;              // (forward_impl forks onto its side stream; an early error return leaves it selected)
   if (rc != RIFT_OK) { c->dry = false; return rc; }
   const size_t need = c->arena_off;
   if (need > c->arena_cap) {
@@ -1652,6 +1668,7 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // scratch it never wrote shows up as NaN / as run-to-run differences instead of depending on what the memory held before
   { const char* pe = getenv("RIFT_POISON_ARENA"); if (pe && c->arena) HIPCHK(c, hipMemsetAsync(c->arena, (int)strtol(pe, nullptr, 0) & 0xff, c->arena_cap, c->stream)); }
   rc = forward_impl(c, B, out, flags, seed);
+  c->stream = (hipStream_t)stream;
   if (rc != RIFT_OK) return rc;
   if (!c->err.empty()) return RIFT_ERR_ARG;
   HIPCHK(c, hipGetLastError());
