@@ -12,6 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-30}
 python $REPO/bench.py --steps $STEPS --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.err
+# (the kernel trace and the counter passes run with the two chains of the forward on ONE stream: per-kernel times and counters of serial launches)
+export RIFT_TWO_STREAMS=0
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $REPO/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-full-update > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 DB=$(find /tmp/kt -name '*.db' | head -1)
 python $REPO/tools/rocpd_summary.py "$DB" > $OUT/kt_summary.txt 2>&1
