@@ -1038,6 +1038,28 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   } else {
     speed_emb = fourier(f, B->map_polygon_speed_limit, 1, nP, 1, "map_encoder.speed_limit_emb", -1);
   }
+  // decoder queries q0 = q_proj(cat[r_emb, m_emb]) (planning_decoder.py:149-154): they depend on the reference-line embedding only, so with the fused
+  // embeddings done they are launched here, ahead of the join, and run beside the tail of the agent-history chain instead of between encoder and decoder
+  float* Q = nullptr;
+  auto build_q0 = [&]() -> int {
+  bool fill;
+  float* Mb = wconst_get(c, "Mb", (size_t)M * 128, f.fp32, &fill);
+  if (fill) gemm(c, mk(fptr(c, PD + ".m_emb"), 128, M, c->pw[PD + ".q_proj.m"], Mb, 128), c->pw[PD + ".q_proj.m"], f.fp32);
+  Q = A_alloc<float>(c, (size_t)nQ * 128);
+  if (!f.fp32 && c->pi_fused) {
+    Q0P q; memset(&q, 0, sizeof(q));
+    q.r_emb = r_emb; q.nL = nL; q.M = M; q.wr = (const unsigned short*)c->pw[PD + ".q_proj.r"].bf; q.br = c->pw[PD + ".q_proj.r"].bias;
+    q.Mb = Mb; q.Q = Q;
+    c->prof_flops = 2.0 * nL * 128.0 * 128;
+    launch(c, "q0_fused_kernel", q0_fused_kernel, dim3(cdiv(nL, 16)), dim3(256), 0, q);
+  } else {
+    float* Ra = A_alloc<float>(c, (size_t)nL * 128);
+    gemm(c, mk(r_emb, 128, nL, c->pw[PD + ".q_proj.r"], Ra, 128), c->pw[PD + ".q_proj.r"], f.fp32);
+    launch(c, "build_q0_kernel", build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
+  }
+    return RIFT_OK;
+  };
+  if (forked && rpe_done) { const int rc0 = build_q0(); if (rc0 != RIFT_OK) return rc0; }
   if (forked) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));      // join: the agent tokens need the history encoder's output
   {
     TokenP q;
@@ -1156,21 +1178,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     fourier(f, r_pos, 3, nL, 3, PD + ".r_pos_emb", -1, r_emb);
   }
   tap(c, "r_emb", r_emb, (int64_t)nL * 128);
-  bool fill;
-  float* Mb = wconst_get(c, "Mb", (size_t)M * 128, f.fp32, &fill);
-  if (fill) gemm(c, mk(fptr(c, PD + ".m_emb"), 128, M, c->pw[PD + ".q_proj.m"], Mb, 128), c->pw[PD + ".q_proj.m"], f.fp32);
-  float* Q = A_alloc<float>(c, (size_t)nQ * 128);
-  if (!f.fp32 && c->pi_fused) {
-    Q0P q; memset(&q, 0, sizeof(q));
-    q.r_emb = r_emb; q.nL = nL; q.M = M; q.wr = (const unsigned short*)c->pw[PD + ".q_proj.r"].bf; q.br = c->pw[PD + ".q_proj.r"].bias;
-    q.Mb = Mb; q.Q = Q;
-    c->prof_flops = 2.0 * nL * 128.0 * 128;
-    launch(c, "q0_fused_kernel", q0_fused_kernel, dim3(cdiv(nL, 16)), dim3(256), 0, q);
-  } else {
-    float* Ra = A_alloc<float>(c, (size_t)nL * 128);
-    gemm(c, mk(r_emb, 128, nL, c->pw[PD + ".q_proj.r"], Ra, 128), c->pw[PD + ".q_proj.r"], f.fp32);
-    launch(c, "build_q0_kernel", build_q0_kernel, dim3(cdiv((long long)nQ * 128, 256)), dim3(256), 0, (const float*)Ra, (const float*)Mb, nL, M, Q);
-  }
+  if (!Q) { const int rc0 = build_q0(); if (rc0 != RIFT_OK) return rc0; }
   tap(c, "q0", Q, (int64_t)nQ * 128);
 
   dp_exchange(f, 0);                      // (eval forward under data parallelism: the mask slots have not travelled yet)
