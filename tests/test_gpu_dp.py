@@ -165,11 +165,13 @@ def test_rccl_transport_with_one_rank():
         idx = torch.arange(16, dtype=torch.int32, device="cuda:0")
         plain = RLFTTrainer(_model("bf16"), kind="rift")
         fb, b = replay.collate(plain.engine, idx)
-        l0 = float(plain.training_step(fb, b).item())
+        plain.training_step(fb, b)
+        l0 = plain.step_loss()              # (the loss is written on the update stream: read behind wait_update())
         dp = RLFTTrainer(_model("bf16"), kind="rift", process_group=dist.group.WORLD)
         dp.force_exchange = True
         fb, b = replay.collate(dp.engine, idx)
-        l1 = float(dp.training_step(fb, b).item())
+        dp.training_step(fb, b)
+        l1 = dp.step_loss()
         torch.cuda.synchronize()
         assert abs(l0 - l1) < 1e-9
         for k in plain.params:

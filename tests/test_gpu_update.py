@@ -102,7 +102,8 @@ def test_thirty_step_update_trajectory(oracle_run, precision):
             pick = order[epoch * STEPS_PER_EPOCH + s]
             idx = torch.tensor(pick, dtype=torch.int32, device="cuda:0")
             fb, b = replay.collate(tr.engine, idx, int(replay.r_count_cpu[pick].max()))
-            got_losses.append(float(tr.training_step(fb, b).item()))
+            tr.training_step(fb, b)
+            got_losses.append(tr.step_loss())           # (written on the update stream: read behind wait_update())
         mean = tr.pop_mean_loss()           # the epoch's mean of the per-step device losses (one host read; slots of loss_hist)
         assert abs(mean - sum(got_losses[-STEPS_PER_EPOCH:]) / STEPS_PER_EPOCH) < 1e-12
         tr.on_epoch_end()
@@ -166,7 +167,8 @@ def test_mean_loss_accounting_across_slot_folds(monkeypatch):
         losses = []
         for i in range(n):
             fb, b = replay.collate(tr.engine, idx)
-            losses.append(float(tr.training_step(fb, b).item()))
+            tr.training_step(fb, b)
+            losses.append(tr.step_loss())
             if i % 2 == 0:
                 fb, b = replay.collate(tr.engine, idx)
                 tr.validation_step(fb, b)
