@@ -20,7 +20,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime initialises (rift_amd/__init__.py explains; an explicit setting wins)
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
