@@ -212,3 +212,31 @@ def test_train_mode_forward_is_bit_reproducible(ffi):
     other = eng.forward(data, train=True, seed=12, bn_update=False)["probability"]
     assert not torch.equal(other, first[0])
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
+def test_two_stream_forward_equals_the_serial_forward(monkeypatch, train):
+    """The forward runs the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain and joins
+    them at the token assembly (RIFT_TWO_STREAMS, on by default): outputs bit-identical to the one-stream order, repeatedly (a missing
+    dependency between the chains would show as run-to-run differences)."""
+    from rift_amd import _ffi
+    torch.cuda.set_device(0)
+    _ffi.load_library()
+    scenes = [syn.make_scene(700 + i, r_min=2, r_max=6) for i in range(64)]
+    data = syn.collate_scenes(scenes)["cur_pluto_feature_torch"]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RIFT_TWO_STREAMS", mode)
+        eng = _ffi.Engine("cuda:0")
+        eng.load_state_dict({k: v.clone() for k, v in H.weights().items()})
+        runs = []
+        for _ in range(4):
+            out = eng.forward(data, train=train, seed=11, need_traj=True, bn_update=False)
+            runs.append((out["probability"].cpu().clone(), out["trajectory"].cpu().clone()))
+        for p, t in runs[1:]:
+            assert torch.equal(p, runs[0][0]) and torch.equal(t, runs[0][1])
+        outs[mode] = runs[0]
+        eng.close()
+    assert torch.isfinite(outs["1"][0][outs["1"][0] > -1e5]).all()
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
