@@ -32,7 +32,7 @@ enum { RIFT_OK = 0, RIFT_ERR_ARG = -1, RIFT_ERR_HIP = -2, RIFT_ERR_STATE = -3, R
 enum {
   RIFT_F_TRAIN      = 1,   /* Lightning .train(): dropout / DropPath / state-dropout on, BatchNorm batch statistics */
   RIFT_F_NEED_TRAJ  = 2,   /* also produce trajectory / prediction / ref_free_trajectory (unused by the RLFT losses) */
-  RIFT_F_FP32       = 4,   /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of bf16 MFMA for the trunk GEMMs */
+  RIFT_F_FP32       = 4,   /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), layer by layer, instead of the fused 16-bit-operand kernels */
   RIFT_F_NO_DROP    = 8,   /* with TRAIN: every drop probability 0 (BatchNorm batch statistics only) */
   RIFT_F_NO_BN_UPDATE = 16 /* with TRAIN: do not update BatchNorm running statistics */
 };
@@ -128,7 +128,15 @@ typedef struct RiftLossOut {
                               when set, rift_loss_finalize reads the sums and the stats from here */
 } RiftLossOut;
 
-int  rift_ctx_create(int device, RiftCtx** ctx);
+/* The 16-bit MFMA operand format of a context's fused kernels (RIFT_F_FP32 forwards do not use it).  The reference trains at
+ * `precision: 32` (fine_tuner/rlft/config/lightning/custom_lightning.yaml:28); BASELINE's benchmark is quoted on bf16 MFMA.
+ *   BF16: 8 significand bits  -- the benchmarked default
+ *   FP16: 11 significand bits -- same instruction rate and bytes; holds the 1e-4 loss / advantage tolerance on small batches too */
+enum { RIFT_OPERANDS_BF16 = 0, RIFT_OPERANDS_FP16 = 1 };
+
+int  rift_ctx_create(int device, RiftCtx** ctx);     /* operands: bf16, or fp16 when the environment has RIFT_OPERANDS=fp16 */
+int  rift_ctx_create_ex(int device, int operand_format, RiftCtx** ctx);
+int  rift_ctx_operand_format(RiftCtx* ctx);          /* RIFT_OPERANDS_* of the context */
 void rift_ctx_destroy(RiftCtx* ctx);
 const char* rift_last_error(RiftCtx* ctx);
 

@@ -81,8 +81,9 @@ class RiftRolloutIO(C.Structure):
                 ("closest_index", vp), ("aim_idx", vp)]
 
 
+OPERANDS = {"bf16": 0, "fp16": 1}       # RIFT_OPERANDS_* of include/rift_hip.h: the 16-bit MFMA operand format of a context's fused kernels
 EXPORTS = [
-    "rift_ctx_create", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_loss_backward",
+    "rift_ctx_create", "rift_ctx_create_ex", "rift_ctx_operand_format", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_loss_backward",
     "rift_loss_finalize", "rift_loss_finalize_clip", "rift_set_param_event", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
@@ -110,6 +111,8 @@ def load_library() -> C.CDLL:
         if not hasattr(lib, name):
             raise RuntimeError(f"librift_hip.so does not export {name}")
     lib.rift_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.rift_ctx_create_ex.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    lib.rift_ctx_operand_format.argtypes = [vp]
     lib.rift_ctx_destroy.argtypes = [vp]
     lib.rift_ctx_destroy.restype = None
     lib.rift_last_error.argtypes = [vp]
@@ -217,16 +220,20 @@ def feature_batch(data: Dict, device) -> (RiftFeatureBatch, list):
 class Engine:
     """One RiftCtx bound to one device + the torch tensors it borrows."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, operands: str = "bf16"):
+        """operands: "bf16" | "fp16" -- the MFMA operand format of the fused kernels (forward(fp32=True) ignores it)."""
+        if operands not in OPERANDS:
+            raise ValueError(f"operands must be one of {sorted(OPERANDS)}, got {operands!r}")
         if not torch.cuda.is_available():
             raise RuntimeError("rift_amd.Engine needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
         self.lib = load_library()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.ctx = vp()
-        rc = self.lib.rift_ctx_create(self.device.index or 0, C.byref(self.ctx))
+        self.operands = operands
+        rc = self.lib.rift_ctx_create_ex(self.device.index or 0, OPERANDS[operands], C.byref(self.ctx))
         if rc != 0:
-            raise RuntimeError(f"rift_ctx_create failed ({rc})")
+            raise RuntimeError(f"rift_ctx_create_ex failed ({rc})")
         self._params = None
         self._names = None
         self._keep = []

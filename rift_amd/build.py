@@ -1,12 +1,33 @@
-"""Build librift_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build librift_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library holds TWO builds of the engine -- bf16 and fp16 MFMA operands (csrc/opfmt.h: -DRIFT_OP_F16=0/1, kernels in namespace
+rift_bf / rift_hf) -- behind one set of exported `rift_*` symbols (csrc/abi.cpp, generated from include/rift_hip.h by
+tools/gen/abi_trampolines.py): a context is created for one format and every call is routed to the build that owns it.
+"""
 import glob
 import os
+import re
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librift_hip.so")
+OBJ = os.path.join(HERE, "_obj")
+
+# Translation units of one engine build.  The wave-private streaming kernels are built with `-fno-honor-nans -mno-amdgpu-ieee`: no
+# IEEE-mode canonicalisation (`v_max_f32 x, x, x` in front of every fmaxf on an MFMA result); they test no NaN themselves -- a NaN / Inf
+# in the residual stream is caught by the bit-pattern test of the policy-head kernels (rift_check_finite).
+# Spill rule (check_resources): a kernel with VGPR spills whose SGPR spills the backend parks in VGPR lanes was miscompiled by ROCm 7.2
+# (round 1, DESIGN.md "A compiler hazard").  No kernel may be in that state: either kind of spill alone is fine (pe_w_kernel: SGPR spills
+# only since its body became a template on the polyline length; dec_kv_frag_kernel: VGPR spills only), both at once fail the build --
+# remove the spills or build that unit with SPILL_SAFE (SGPR spills to scratch memory: correct, and measured 45 % slower on pe_w_kernel).
+FAST = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
+SPILL_SAFE = ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"]
+UNITS = [("engine", []), ("dec_w", FAST), ("nat_l2w", FAST), ("enc_w", FAST), ("pe_w", FAST), ("fo_w", FAST)]
+FORMATS = [("bf", 0), ("hf", 1)]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def hipcc() -> str:
@@ -17,30 +38,65 @@ def hipcc() -> str:
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))
-                  + [os.path.join(os.path.dirname(HERE), "include", "rift_hip.h")])
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cpp"))
+                  + [os.path.join(os.path.dirname(HERE), "include", "rift_hip.h"), os.path.abspath(__file__)])
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def compile_commands(extra=()):
+    """[(object path, command)] of every translation unit of the library; `extra` is appended to each hipcc command."""
+    cmds = []
+    for tag, f16 in FORMATS:
+        for unit, flags in UNITS:
+            o = os.path.join(OBJ, f"{unit}_{tag}.o")
+            cmds.append((o, [hipcc()] + COMMON + [f"-DRIFT_OP_F16={f16}", "-c"] + flags + [os.path.join(CSRC, unit + ".hip"), "-o", o] + list(extra)))
+    o = os.path.join(OBJ, "abi.o")
+    cmds.append((o, [hipcc()] + COMMON + ["-x", "hip", "-c", os.path.join(CSRC, "abi.cpp"), "-o", o] + list(extra)))
+    return cmds
+
+
+def check_resources(remarks: str, spill_safe: bool):
+    """Raise when a kernel of a translation unit built WITHOUT SPILL_SAFE has VGPR spills and SGPR spills at once (spill rule above)."""
+    bad, cur = [], {}
+    for line in remarks.splitlines():
+        m = re.search(r"remark: (.*?) \[-Rpass", line)
+        if not m:
+            continue
+        t = m.group(1).strip()
+        if t.startswith("Function Name:"):
+            cur = {"name": t.split(":", 1)[1].strip()}
+        elif ":" in t:
+            k, v = t.split(":", 1)
+            cur[k.strip()] = v.strip()
+            if k.strip().startswith("LDS Size"):      # last remark of a kernel
+                ss, vs = int(cur.get("SGPRs Spill", "0") or 0), int(cur.get("VGPRs Spill", "0") or 0)
+                if ss > 0 and vs > 0 and not spill_safe:
+                    bad.append(f"{cur['name']}: {vs} VGPR spills and {ss} SGPR spills parked in VGPR lanes")
+    if bad:
+        raise RuntimeError("kernel resource check failed (build the unit with SPILL_SAFE or remove the spills):\n  " + "\n  ".join(bad))
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
     srcs = sources()
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
-    # engine.hip, dec_w.hip, nat_l2w.hip, enc_w.hip, pe_w.hip and fo_w.hip are separate translation units; the wave-private streaming kernels are built with
-    # `-fno-honor-nans -mno-amdgpu-ieee`: no IEEE-mode canonicalisation (`v_max_f32 x, x, x` in front of every fmaxf on an MFMA result); they test no NaN.
-    common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-    obj = os.path.join(HERE, "_obj")
-    os.makedirs(obj, exist_ok=True)
-    steps = [common + ["-c", os.path.join(CSRC, "engine.hip"), "-o", os.path.join(obj, "engine.o")],
-             common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "dec_w.hip"), "-o", os.path.join(obj, "dec_w.o")],
-             common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "nat_l2w.hip"), "-o", os.path.join(obj, "nat_l2w.o")],
-             common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "enc_w.hip"), "-o", os.path.join(obj, "enc_w.o")],
-             common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "pe_w.hip"), "-o", os.path.join(obj, "pe_w.o")],
-             common + ["-c", "-fno-honor-nans", "-mno-amdgpu-ieee", os.path.join(CSRC, "fo_w.hip"), "-o", os.path.join(obj, "fo_w.o")],
-             common + ["-shared", os.path.join(obj, "engine.o"), os.path.join(obj, "dec_w.o"), os.path.join(obj, "nat_l2w.o"), os.path.join(obj, "enc_w.o"), os.path.join(obj, "pe_w.o"), os.path.join(obj, "fo_w.o"), "-o", LIB]]
-    for cmd in steps:
+    os.makedirs(OBJ, exist_ok=True)
+    cmds = compile_commands(extra=["-Rpass-analysis=kernel-resource-usage"])
+
+    def run(item):
+        o, cmd = item
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd)}\n{r.stderr}")
+        check_resources(r.stderr, "-amdgpu-spill-sgpr-to-vgpr=0" in cmd)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(cmds), os.cpu_count() or 4)) as ex:
+        list(ex.map(run, cmds))
+    link = [hipcc(), "--offload-arch=gfx950", "-shared"] + [o for o, _ in cmds] + ["-o", LIB]
+    if verbose:
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return LIB
 
 

@@ -5,7 +5,7 @@
 #pragma once
 #include "common.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 // ---------------------------------------------------------------------------
 // Reverse affine scan  x_t = b_t + a_t * x_{t+1},  x_n = 0, in fp64, by ONE workgroup of 16 waves:
@@ -256,4 +256,4 @@ __global__ void collate_kernel(CollateP p, const int32_t* __restrict__ scene_idx
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

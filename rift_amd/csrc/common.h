@@ -3,27 +3,73 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace rift {
+#include "opfmt.h"
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA 16x16x32 A/B operand)
+namespace RIFT_NS {
+
+typedef __attribute__((ext_vector_type(8))) short h16x8;    // 8 operand words = 4 VGPRs (MFMA 16x16x32 A/B operand)
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // MFMA 16x16 accumulator
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// two fp32 -> packed bf16x2 (round-to-nearest-even) in ONE instruction (gfx950 v_cvt_pk_bf16_f32).  The `s_nop 0` is part of the contract:
-// an MFMA that reads a VALU-written VGPR as an operand needs TWO wait states behind the write (tools/ubench/cvt_mfma_hazard.hip on MI355X:
-// 0 or 1 states -> the MFMA reads the register's previous content in 95-100 % of the issues, 2 -> never), and behind an asm statement hipcc
-// pads only one.  Without the nop every "convert, then multiply" site was a latent stale-operand read.
-__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+__device__ __forceinline__ f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c, int, int, int) {
+#if RIFT_OP_F16
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+#else
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+#endif
+}
+
+// two fp32 -> packed operand pair (round-to-nearest-even) in ONE instruction (gfx950 v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).  The `s_nop 0`
+// is part of the contract: an MFMA that reads a VALU-written VGPR as an operand needs TWO wait states behind the write
+// (tools/ubench/cvt_mfma_hazard.hip on MI355X: 0 or 1 states -> the MFMA reads the register's previous content in 95-100 % of the issues,
+// 2 -> never), and behind an asm statement hipcc pads only one.  Without the nop every "convert, then multiply" site was a latent
+// stale-operand read.
+__device__ __forceinline__ unsigned int pack_h2(float lo, float hi) {
   unsigned int r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(lo), "v"(hi));
+  asm(RIFT_CVT_PK_H_ASM " %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
-__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even fp32 -> bf16: the same instruction, one lane used
-  return (unsigned short)(pack_bf16x2(f, 0.f) & 0xffffu);
+__device__ __forceinline__ unsigned short f2h(float f) {   // round-to-nearest-even fp32 -> operand word: the same instruction, one lane used
+  return (unsigned short)(pack_h2(f, 0.f) & 0xffffu);
 }
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+// operand word(s) -> fp32: a shift / mask for bf16, v_cvt_f32_f16 (SDWA picks the upper half) for fp16 -- one VALU instruction either way
+// (plain C++ so that hipcc, not an opaque asm statement, owns the SDWA hazards)
+#if RIFT_OP_F16
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+#endif
+__device__ __forceinline__ float h_lo(unsigned int u) {
+#if RIFT_OP_F16
+  return (float)__builtin_bit_cast(f16x2_t, u)[0];
+#else
+  return __uint_as_float(u << 16);
+#endif
+}
+__device__ __forceinline__ float h_hi(unsigned int u) {
+#if RIFT_OP_F16
+  return (float)__builtin_bit_cast(f16x2_t, u)[1];
+#else
+  return __uint_as_float(u & 0xffff0000u);
+#endif
+}
+__device__ __forceinline__ float h2f(unsigned short h) { return h_lo((unsigned int)h); }
+// re-pack two fp32 values that ARE operand-format values (results of max / select over unpacked words): exact, no rounding involved
+__device__ __forceinline__ unsigned int h_pair_exact(float lo, float hi) {
+#if RIFT_OP_F16
+  return pack_h2(lo, hi);
+#else
+  return (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16);
+#endif
+}
+#if RIFT_OP_F16
+#define RIFT_H_NEG_INF2 0xfc00fc00u      // a packed pair of -inf
+#else
+#define RIFT_H_NEG_INF2 0xff80ff80u
+#endif
 
-__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
-  uint2 u; u.x = pack_bf16x2(a, b); u.y = pack_bf16x2(c, d); return u;
+__device__ __forceinline__ uint2 pack_h4(float a, float b, float c, float d) {
+  uint2 u; u.x = pack_h2(a, b); u.y = pack_h2(c, d); return u;
 }
 
 // ---- bf16 weight images are stored FRAGMENT-MAJOR ---------------------------------------------------------------------
@@ -36,8 +82,8 @@ __host__ __device__ __forceinline__ size_t fm_index(int n, int k, int Kp) {
   return ((size_t)((n >> 4) * (Kp >> 5) + (k >> 5)) * 64 + (size_t)(((k >> 3) & 3) * 16 + (n & 15))) * 8 + (k & 7);
 }
 // fragment (rows n0.., columns k0..) of a fragment-major image with row length Kp; n0 % 16 == 0, k0 % 32 == 0
-__device__ __forceinline__ bf16x8 fm_load(const unsigned short* W, int Kp, int n0, int k0, int lane) {
-  return *reinterpret_cast<const bf16x8*>(W + ((size_t)((n0 >> 4) * (Kp >> 5) + (k0 >> 5)) * 64 + lane) * 8);
+__device__ __forceinline__ h16x8 fm_load(const unsigned short* W, int Kp, int n0, int k0, int lane) {
+  return *reinterpret_cast<const h16x8*>(W + ((size_t)((n0 >> 4) * (Kp >> 5) + (k0 >> 5)) * 64 + lane) * 8);
 }
 
 // counter-based RNG for dropout / drop-path / state-dropout: one 32-bit hash per element
@@ -94,7 +140,6 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float hx = 0.5f * x;
   return fmaf(hx, e, hx);
 }
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
   typedef f32x2_t V;
   V z = x * 0.70710678118654752440f;
@@ -108,14 +153,18 @@ __device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
   return __builtin_elementwise_fma(hx, e, hx);
 }
 
-// fp32 += dot of two packed bf16 pairs (v_dot2c_f32_bf16): a 2-element q.k step without unpacking either operand
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float dot2_bf16(unsigned int a, unsigned int b, float c) {
+// fp32 += dot of two packed operand pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16): a 2-element q.k step without unpacking either operand
+__device__ __forceinline__ float dot2_h(unsigned int a, unsigned int b, float c) {
+#if RIFT_OP_F16
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
+#else
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+#endif
 }
-// the two bf16 values of a packed dword as fp32
-__device__ __forceinline__ f32x2_t unpack_bf16x2(unsigned int u) {
-  f32x2_t r; r.x = __uint_as_float(u << 16); r.y = __uint_as_float(u & 0xffff0000u); return r;
+// the two values of a packed operand dword as fp32
+__device__ __forceinline__ f32x2_t unpack_h2(unsigned int u) {
+  f32x2_t r; r.x = h_lo(u); r.y = h_hi(u); return r;
 }
 
 // bias + GELU + bf16 pack of one MFMA accumulator fragment (4 consecutive output columns), two packed pairs
@@ -124,7 +173,7 @@ __device__ __forceinline__ uint2 gelu4_pack(const f32x4 a, const float4 b) {
   lo.x = a[0]; lo.y = a[1]; hi.x = a[2]; hi.y = a[3];
   bl.x = b.x; bl.y = b.y; bh.x = b.z; bh.y = b.w;
   lo = gelu_fast2(lo + bl); hi = gelu_fast2(hi + bh);
-  return pack_bf16x4(lo.x, lo.y, hi.x, hi.y);
+  return pack_h4(lo.x, lo.y, hi.x, hi.y);
 }
 
 // Workgroup barrier for phases that hand data over through LDS only.  __syncthreads() makes hipcc drain EVERY outstanding memory
@@ -218,8 +267,8 @@ __device__ __forceinline__ void ln_row8(const float* __restrict__ src, unsigned 
     const V z = (V)0.f;
     a = __builtin_elementwise_max(a, z); b = __builtin_elementwise_max(b, z); c = __builtin_elementwise_max(c, z); d = __builtin_elementwise_max(d, z);
   }
-  *reinterpret_cast<uint2*>(dst + lr * 4) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(b.x, b.y));
-  *reinterpret_cast<uint2*>(dst + 4 * LPR + lr * 4) = make_uint2(pack_bf16x2(c.x, c.y), pack_bf16x2(d.x, d.y));
+  *reinterpret_cast<uint2*>(dst + lr * 4) = make_uint2(pack_h2(a.x, a.y), pack_h2(b.x, b.y));
+  *reinterpret_cast<uint2*>(dst + 4 * LPR + lr * 4) = make_uint2(pack_h2(c.x, c.y), pack_h2(d.x, d.y));
 }
 __device__ __forceinline__ void ln128_row16(const float* __restrict__ src, unsigned short* __restrict__ dst, const float4& g0, const float4& g1,
                                             const float4& b0, const float4& b1, int l15, bool relu = false) {
@@ -229,18 +278,18 @@ __device__ __forceinline__ void ln128_row16(const float* __restrict__ src, unsig
 // ---- register-resident (wave-private) kernels: nat_l0w.h, nat_l1w.h, dec_w.hip ----
 // channel a lane's k-slot j (0..7) of chunk l4 stands for when the operand is a GEMM output kept in the C/D layout (two n-tiles)
 __host__ __device__ __forceinline__ int l0w_chan(int l4, int j, int nt_lo) { return (j < 4 ? nt_lo : nt_lo + 1) * 16 + l4 * 4 + (j & 3); }
-__device__ __forceinline__ bf16x8 l0w_pack8(const f32x4 a, const f32x4 b) {
-  bf16x8 r;
-  const unsigned int p0 = pack_bf16x2(a[0], a[1]), p1 = pack_bf16x2(a[2], a[3]), p2 = pack_bf16x2(b[0], b[1]), p3 = pack_bf16x2(b[2], b[3]);
+__device__ __forceinline__ h16x8 l0w_pack8(const f32x4 a, const f32x4 b) {
+  h16x8 r;
+  const unsigned int p0 = pack_h2(a[0], a[1]), p1 = pack_h2(a[2], a[3]), p2 = pack_h2(b[0], b[1]), p3 = pack_h2(b[2], b[3]);
   r[0] = (short)(p0 & 0xffff); r[1] = (short)(p0 >> 16); r[2] = (short)(p1 & 0xffff); r[3] = (short)(p1 >> 16);
   r[4] = (short)(p2 & 0xffff); r[5] = (short)(p2 >> 16); r[6] = (short)(p3 & 0xffff); r[7] = (short)(p3 >> 16);
   return r;
 }
-__device__ __forceinline__ bf16x8 l0w_from_u2(const uint2 a, const uint2 b) {
-  bf16x8 r;
+__device__ __forceinline__ h16x8 l0w_from_u2(const uint2 a, const uint2 b) {
+  h16x8 r;
   r[0] = (short)(a.x & 0xffff); r[1] = (short)(a.x >> 16); r[2] = (short)(a.y & 0xffff); r[3] = (short)(a.y >> 16);
   r[4] = (short)(b.x & 0xffff); r[5] = (short)(b.x >> 16); r[6] = (short)(b.y & 0xffff); r[7] = (short)(b.y >> 16);
   return r;
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -7,7 +7,7 @@
 #pragma once
 #include "common.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 #define RIFT_CRITIC_IN 128
 #define RIFT_CRITIC_H 256
@@ -242,4 +242,4 @@ __global__ void critic_finalize_kernel(const float* __restrict__ flat, const dou
   if (dst) dst[o] = flat[i] * sc;
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -7,7 +7,7 @@
 #pragma once
 #include "enc_fused.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 struct DecKvP {
   const float* ENC;             // (bs*N, 128) encoder output
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512) void dec_kv_frag_kernel(DecKvP p) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // keys beyond N: zero rows (masked by the decoder; finite operands)
     if (r < N) v = *reinterpret_cast<const float4*>(p.ENC + ((size_t)b * N + r) * 128 + c4);
-    *reinterpret_cast<uint2*>(xn + r * XN + c4) = pack_bf16x4(v.x, v.y, v.z, v.w);
+    *reinterpret_cast<uint2*>(xn + r * XN + c4) = pack_h4(v.x, v.y, v.z, v.w);
   }
   __syncthreads();
   for (int l = 0; l < 4; ++l) {
@@ -49,16 +49,16 @@ __global__ __launch_bounds__(512) void dec_kv_frag_kernel(DecKvP p) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         *reinterpret_cast<uint2*>(base + mt * 512 + (wave & 1) * 4) =
-            pack_bf16x4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
+            pack_h4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
     }
     {   // V^T: channel wave * 16 + l15 (dim tile d = wave & 1), keys mt * 16 + 4 l4 .. + 3 = k slots (mt & 1) * 4 .. of fragment (d, pt = mt >> 1)
       const float bias = p.bkv[l * 256 + 128 + wave * 16 + l15];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         *reinterpret_cast<uint2*>(base + (12 + (wave & 1) * 6 + (mt >> 1)) * 512 + (mt & 1) * 4) =
-            pack_bf16x4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
+            pack_h4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
     }
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -15,7 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace rift {
+#include "opfmt.h"
+
+namespace RIFT_NS {
 
 #define DECW_WGROUPS 18                         // weight groups per layer, 32 fragments each (consumption order, see the kernel)
 #define DECW_LAYER_FRAGS (DECW_WGROUPS * 32)
@@ -74,4 +76,4 @@ int decw_set_attributes();
 void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t stream);
 void decw_launch(const DecWP& p, hipStream_t stream);
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -4,7 +4,7 @@
 #include "wp_stream.h"
 #include <type_traits>
 
-namespace rift {
+namespace RIFT_NS {
 
 // Weight image: [layer][group][fragment f = ks * 8 + nt][lane][8]: element = W[out = nt*16 + lane&15][in = chan(ks, lane>>4, j)] with the
 // K permutation of nat_l0w.h (an n-tile PAIR of one GEMM's C/D output is the next GEMM's k-step).  Softmax scales are folded into q.
@@ -27,7 +27,7 @@ __global__ void pack_decw_kernel(DecWSrc s, unsigned short* __restrict__ img, fl
       const int hc = (g - 10) >> 1;
       v = ((g - 10) & 1) ? L.f2_w[o * 512 + hc * 128 + ch] : L.f1_w[(hc * 128 + o) * 128 + ch];
     }
-    img[e] = f2bf(v);
+    img[e] = f2h(v);
   }
   if (e < 4 * DECW_PAR_LAYER) {
     const int li = e / DECW_PAR_LAYER, o = e % DECW_PAR_LAYER;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   // group boundary: my share of the next group has landed; after the barrier everybody's has, and nobody reads the other slot any more
   auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); DTS(); };
-  auto W = [&](int slot, int f) { return *reinterpret_cast<const bf16x8*>(ring + slot * 32768 + f * 1024 + lane * 16); };
+  auto W = [&](int slot, int f) { return *reinterpret_cast<const h16x8*>(ring + slot * 32768 + f * 1024 + lane * 16); };
 
   const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.img);
   constexpr int KVF = DENSE ? 96 : DECW_KV_FRAGS;                              // K | V^T fragments per (scene, layer)
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto publish = [&]() { if (DENSE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); };     // after the last write_xs of a tiling, before its barrier
   auto acquire = [&]() { if (DENSE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };     // after that barrier, before the first read_xs
   // res -> xb (bf16 operands of the four k-steps); g: gamma 128 | beta 128 in LDS.  Two-pass statistics as torch; vector (packed fp32) math.
-  auto layer_norm = [&](const f32x4 (&res)[8], bf16x8 (&xb)[4], const float* g) {
+  auto layer_norm = [&](const f32x4 (&res)[8], h16x8 (&xb)[4], const float* g) {
     f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
     s4 += (res[4] + res[5]) + (res[6] + res[7]);
     const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
@@ -226,22 +226,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   // 16 rows x K=128 -> 128 output channels against the 32 fragments of a ring slot (swapped operands: lane = 4 channels of its row)
-  auto gemm = [&](int slot, const bf16x8 (&x)[4], f32x4 (&acc)[8]) {
+  auto gemm = [&](int slot, const h16x8 (&x)[4], f32x4 (&acc)[8]) {
     decw_gemm<false>((uint32_t)(uintptr_t)ring + (uint32_t)slot * 32768u + voff, x, acc);
   };
   // q / k of the four heads as attention operands: n-tile pair (2h, 2h+1) -> one bf16 fragment (the bias came in through the accumulator)
-  auto to_heads = [&](const f32x4 (&acc)[8], bf16x8 (&out)[4]) {
+  auto to_heads = [&](const f32x4 (&acc)[8], h16x8 (&out)[4]) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) out[h] = l0w_pack8(acc[2 * h], acc[2 * h + 1]);
   };
   // V of the tile in the plain operand order (A = activations): lane = 4 consecutive KEYS (rows 4*l4..) of dim nt*16 + l15 = the V^T operand
-  auto gemm_v = [&](int slot, const bf16x8 (&xb)[4], bf16x8 (&vf)[8], const float* bias) {
+  auto gemm_v = [&](int slot, const h16x8 (&xb)[4], h16x8 (&vf)[8], const float* bias) {
     f32x4 acc[8];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) { const float bv = bias[nt * 16 + l15]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
     decw_gemm<true>((uint32_t)(uintptr_t)ring + (uint32_t)slot * 32768u + voff, xb, acc);
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_bf16x4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]), make_uint2(0u, 0u));   // k slots 4..7 unused
+    for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_h4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]), make_uint2(0u, 0u));   // k slots 4..7 unused
   };
   // dropout multipliers of four consecutive draws: 1/(1-p) or 0
   auto keep4 = [&](int site) -> f32x4 {        // site: compile-time call index (selects the state pair)
@@ -252,17 +252,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   // 16 x 16 self-attention of the tile, per head, entirely in registers: S^T = K Q^T (lane: 4 keys of query l15), O^T = V^T P^T.
   // `mask4`: 0 / -inf of this lane's four keys, entering as the accumulator of the score MFMA; scores are in log2 units (q carries log2 e).
-  auto self_attention = [&](const f32x4 mask4, const bf16x8 (&qf)[4], const bf16x8 (&kf)[4], const bf16x8 (&vf)[8], bf16x8 (&ao)[4]) {
+  auto self_attention = [&](const f32x4 mask4, const h16x8 (&qf)[4], const h16x8 (&kf)[4], const h16x8 (&vf)[8], h16x8 (&ao)[4]) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[h], qf[h], mask4, 0, 0, 0);
+      const f32x4 s = mfma_h(kf[h], qf[h], mask4, 0, 0, 0);
       const float m = rows_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
       f32x4 ev = {__builtin_amdgcn_exp2f(s[0] - m), __builtin_amdgcn_exp2f(s[1] - m), __builtin_amdgcn_exp2f(s[2] - m), __builtin_amdgcn_exp2f(s[3] - m)};
       const float lsum = rows_sum((ev[0] + ev[1]) + (ev[2] + ev[3]));
       if (DROP) ev *= keep4(h);
-      const bf16x8 pf = l0w_from_u2(pack_bf16x4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
-      const f32x4 o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2 * h], pf, Z, 0, 0, 0);
-      const f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2 * h + 1], pf, Z, 0, 0, 0);
+      const h16x8 pf = l0w_from_u2(pack_h4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
+      const f32x4 o0 = mfma_h(vf[2 * h], pf, Z, 0, 0, 0);
+      const f32x4 o1 = mfma_h(vf[2 * h + 1], pf, Z, 0, 0, 0);
       const float inv = __builtin_amdgcn_rcpf(lsum);
       ao[h] = l0w_pack8(o0 * inv, o1 * inv);
     }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   // cross attention of `nh` heads starting at h0 against the K | V^T fragments in a ring slot (16 NKT keys); the key-padding mask is the score
   // accumulator.  Fragment order of the slot: K (kt, hh) at kt * nh + hh, V^T (hh, dim tile d, key pair pt) behind them.
-  auto cross_heads = [&](int slot, int h0, auto nh_t, const bf16x8 (&qf)[4], bf16x8 (&ao)[4]) {
+  auto cross_heads = [&](int slot, int h0, auto nh_t, const h16x8 (&qf)[4], h16x8 (&ao)[4]) {
     constexpr int nh = decltype(nh_t)::value;
 #pragma unroll
     for (int hh = 0; hh < nh; ++hh) {
@@ -287,14 +287,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int kt = 0; kt < NK0; ++kt) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, kt * nh + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+        s[kt] = mfma_h(W(slot, kt * nh + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
       }
       float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
       for (int kt = 1; kt < NK0; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
       if (!DENSE && six) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + 80 + l4 * 4);
-        s[NKT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 5 * nh + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+        s[NKT - 1] = mfma_h(W(slot, 5 * nh + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
         m = fmaxf(fmaxf(m, fmaxf(s[NKT - 1][0], s[NKT - 1][1])), fmaxf(s[NKT - 1][2], s[NKT - 1][3]));
       }
       m = rows_max(m);
@@ -316,9 +316,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       f32x4 o0 = Z, o1 = Z;
 #pragma unroll
       for (int pt = 0; pt < NKT / 2; ++pt) {
-        const bf16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
-        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, NKT * nh + (hh * 2 + 0) * (NKT / 2) + pt), pf, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, NKT * nh + (hh * 2 + 1) * (NKT / 2) + pt), pf, o1, 0, 0, 0);
+        const h16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
+        o0 = mfma_h(W(slot, NKT * nh + (hh * 2 + 0) * (NKT / 2) + pt), pf, o0, 0, 0, 0);
+        o1 = mfma_h(W(slot, NKT * nh + (hh * 2 + 1) * (NKT / 2) + pt), pf, o1, 0, 0, 0);
       }
       const float inv = __builtin_amdgcn_rcpf(lsum);
       ao[h] = l0w_pack8(o0 * inv, o1 * inv);
@@ -375,8 +375,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int pa = DENSE ? 4 * ra : 0;                          // first position of this round
       if (actA) {
         f32x4 res[8], acc[8];
-        bf16x8 xb[4], qf[4], kf[4], ao[4];
-        bf16x8 vf[8];
+        h16x8 xb[4], qf[4], kf[4], ao[4];
+        h16x8 vf[8];
         bnd(li, pa + 0);                                        // ---- r2r q
         if (ra == 0) acquire();
         read_xs(res, a_row, a_ok);
@@ -417,8 +417,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr int KO = DENSE ? 9 : 7;                           // round-relative position of cross out_proj (behind the K | V^T groups)
       if (actB) {
         f32x4 res[8], acc[8];
-        bf16x8 xb[4], qf[4], kf[4], ao[4];
-        bf16x8 vf[8];
+        h16x8 xb[4], qf[4], kf[4], ao[4];
+        h16x8 vf[8];
         bnd(li, pb + 0);                                        // ---- m2m q (+ m_pos)
         if (rb == 0) acquire();
         read_xs(res, b_row, b_ok);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           init8(acc, parL + DECW_L_BF1 + hc * 128);
           bnd(li, pb + KO + 1 + 2 * hc);
           gemm((KO + 1) & 1, xb, acc);
-          bf16x8 hb[4];
+          h16x8 hb[4];
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             f32x4 v[2];
@@ -517,4 +517,4 @@ void decw_launch(const DecWP& p, hipStream_t stream) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

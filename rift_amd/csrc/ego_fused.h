@@ -4,7 +4,7 @@
 #pragma once
 #include "enc_fused.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 struct EgoP {
   const float* cs; int cs_ld;        // (bs, cs_ld) current_state, first 6 entries used
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void ego_fused_kernel(EgoP p) {
   }
   const float qv = p.q[(wave * 32 + (lane & 31))];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { const int i = tid + k * 256; e[(i >> 7) * ES + (i & 127)] = f2bf(tv[k]); }
+  for (int k = 0; k < 3; ++k) { const int i = tid + k * 256; e[(i >> 7) * ES + (i & 127)] = f2h(tv[k]); }
   for (int i = tid; i < 10 * 128; i += 256) e[(6 + (i >> 7)) * ES + (i & 127)] = 0;
   for (int i = tid; i < 16 * 128; i += 256) ao[(i >> 7) * ES + (i & 127)] = 0;
   if (tid < 6) msk[tid] = (p.drop_p > 0.f && tid >= 3 && uniform01(p.seed, p.stream, (uint32_t)(b * 6 + tid)) < p.drop_p) ? 1 : 0;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ego_fused_kernel(EgoP p) {
     float den = 0.f, o = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { const float w = __expf(s[j] - mx); den += w; o += w * kvs[j * KS_ + 128 + d]; }
-    if (lane < 32) ao[d] = f2bf(o / den);
+    if (lane < 32) ao[d] = f2h(o / den);
   }
   __syncthreads();
   {
@@ -89,4 +89,4 @@ __global__ __launch_bounds__(256) void ego_fused_kernel(EgoP p) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

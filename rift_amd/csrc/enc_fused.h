@@ -8,7 +8,7 @@
 #pragma once
 #include "common.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 struct EncBlockW {
   const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
@@ -49,12 +49,12 @@ __global__ void pack_rows_indexed_kernel(const float* __restrict__ src, const fl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrows * K) return;
   const int r = i / K, k = i - r * K;
-  dst[fm_index(r, k, K)] = f2bf(src[(size_t)idx[r] * K + k]);   // fragment-major image
+  dst[fm_index(r, k, K)] = f2h(src[(size_t)idx[r] * K + k]);   // fragment-major image
   if (k == 0 && bias) bias_out[r] = bias[idx[r]];
 }
 
 template <int KS, int NTW>
-struct EFrags { bf16x8 f[KS][NTW]; };
+struct EFrags { h16x8 f[KS][NTW]; };
 
 template <int NWV> struct EWaves {};
 // this wave's n-tiles are (j * NW + wave), j < NTW; tiles at or beyond `ntiles` are skipped (zero fragments)
@@ -66,7 +66,7 @@ __device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned shor
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       B.f[ks][j] = (j * NW + wave < ntiles) ? fm_load(W, ldw, n0 + (j * NW + wave) * 16, k0 + ks * 32, l4 * 16 + l15)
-                                            : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                                            : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
 }
 template <int KS, int NTW>
 __device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned short* W, int ldw, int n0, int k0, int wave,
@@ -85,15 +85,15 @@ __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
                                       int l15, int l4) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    bf16x8 a[MT];
+    h16x8 a[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + l15) * lda + ks * 32 + l4 * 8);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const h16x8*>(A + (mt * 16 + l15) * lda + ks * 32 + l4 * 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
-        acc[mt][j] = (j >= NTW - NPLAIN) ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0)
-                                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+        acc[mt][j] = (j >= NTW - NPLAIN) ? mfma_h(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0)
+                                         : mfma_h(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
   }
 }
 
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
-                pack_bf16x4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
+                pack_h4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
         }
         if (wave < 4) {                     // n-tiles 8..11: V -> vt[head][d][key..key+3]
           const int nt = 8 + wave;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + mt * 16 + l4 * 4) =
-                pack_bf16x4(acc[mt][NTQ - 1][0] + bias, acc[mt][NTQ - 1][1] + bias, acc[mt][NTQ - 1][2] + bias, acc[mt][NTQ - 1][3] + bias);
+                pack_h4(acc[mt][NTQ - 1][0] + bias, acc[mt][NTQ - 1][1] + bias, acc[mt][NTQ - 1][2] + bias, acc[mt][NTQ - 1][3] + bias);
         }
       }
       lds_barrier();
@@ -217,14 +217,14 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       // ---- MFMA attention: 2 heads x 6 query tiles = 12 (head, tile) pairs, 3 per wave (see mha_mfma_kernel)
       for (int pr = wave; pr < 12; pr += NW) {
         const int hh = pr / 6, qt = pr - hh * 6;
-        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cb + (qt * 16 + l15) * CB + hh * 64 + l4 * 8);
+        const h16x8 qf = *reinterpret_cast<const h16x8*>(cb + (qt * 16 + l15) * CB + hh * 64 + l4 * 8);
         f32x4 s[NKT];
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cb + (kt * 16 + l15) * CB + hh * 64 + 32 + l4 * 8);
+          const h16x8 kf = *reinterpret_cast<const h16x8*>(cb + (kt * 16 + l15) * CB + hh * 64 + 32 + l4 * 8);
           const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
-          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+          s[kt] = mfma_h(kf, qf, (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
           m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
         }
         m = rows_max(m);
@@ -237,29 +237,29 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
         for (int pt = 0; pt < NKT / 2; ++pt) {
-          bf16x8 pf;
-          const unsigned int p0 = pack_bf16x2(s[2 * pt][0], s[2 * pt][1]), p1 = pack_bf16x2(s[2 * pt][2], s[2 * pt][3]);
-          const unsigned int p2 = pack_bf16x2(s[2 * pt + 1][0], s[2 * pt + 1][1]), p3 = pack_bf16x2(s[2 * pt + 1][2], s[2 * pt + 1][3]);
+          h16x8 pf;
+          const unsigned int p0 = pack_h2(s[2 * pt][0], s[2 * pt][1]), p1 = pack_h2(s[2 * pt][2], s[2 * pt][3]);
+          const unsigned int p2 = pack_h2(s[2 * pt + 1][0], s[2 * pt + 1][1]), p3 = pack_h2(s[2 * pt + 1][2], s[2 * pt + 1][3]);
           pf[0] = (short)(p0 & 0xffff); pf[1] = (short)(p0 >> 16); pf[2] = (short)(p1 & 0xffff); pf[3] = (short)(p1 >> 16);
           pf[4] = (short)(p2 & 0xffff); pf[5] = (short)(p2 >> 16); pf[6] = (short)(p3 & 0xffff); pf[7] = (short)(p3 >> 16);
           const unsigned short* v0 = vt + (hh * 32 + l15) * VS + pt * 32 + l4 * 4;
           const unsigned short* v1 = vt + (hh * 32 + 16 + l15) * VS + pt * 32 + l4 * 4;
           const uint2 x0 = *reinterpret_cast<const uint2*>(v0), x1 = *reinterpret_cast<const uint2*>(v0 + 16);
           const uint2 y0 = *reinterpret_cast<const uint2*>(v1), y1 = *reinterpret_cast<const uint2*>(v1 + 16);
-          bf16x8 b0, b1;
+          h16x8 b0, b1;
           b0[0] = (short)(x0.x & 0xffff); b0[1] = (short)(x0.x >> 16); b0[2] = (short)(x0.y & 0xffff); b0[3] = (short)(x0.y >> 16);
           b0[4] = (short)(x1.x & 0xffff); b0[5] = (short)(x1.x >> 16); b0[6] = (short)(x1.y & 0xffff); b0[7] = (short)(x1.y >> 16);
           b1[0] = (short)(y0.x & 0xffff); b1[1] = (short)(y0.x >> 16); b1[2] = (short)(y0.y & 0xffff); b1[3] = (short)(y0.y >> 16);
           b1[4] = (short)(y1.x & 0xffff); b1[5] = (short)(y1.x >> 16); b1[6] = (short)(y1.y & 0xffff); b1[7] = (short)(y1.y >> 16);
           // O^T = V^T . P^T : lane holds out dims 4*(lane>>4)..+3 (+16) of ITS query (lane&15) -> 8-byte stores, own denominator
-          o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, pf, o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, pf, o1, 0, 0, 0);
+          o0 = mfma_h(b0, pf, o0, 0, 0, 0);
+          o1 = mfma_h(b1, pf, o1, 0, 0, 0);
         }
         const int head = ch * 2 + hh;
         const float inv = __builtin_amdgcn_rcpf(lsum);
         unsigned short* op = ao + (qt * 16 + l15) * XA + head * 32 + l4 * 4;
-        *reinterpret_cast<uint2*>(op) = pack_bf16x4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
-        *reinterpret_cast<uint2*>(op + 16) = pack_bf16x4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+        *reinterpret_cast<uint2*>(op) = pack_h4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+        *reinterpret_cast<uint2*>(op + 16) = pack_h4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
       }
       lds_barrier();
       TS();
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
       const float4 o = make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
       if (r < N) *reinterpret_cast<float4*>(p.Y + (grow0 + r) * C + lr * 4) = o;
-      if (p.KT) *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) = pack_bf16x4(o.x, o.y, o.z, o.w);
+      if (p.KT) *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) = pack_h4(o.x, o.y, o.z, o.w);
     }
   }
   if (p.KT && p.x0p) {   // the ego-token half of the decoder's cat_x_proj: one row per scene
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           *reinterpret_cast<uint2*>(kt + mt * 2 * 512) =
-              pack_bf16x4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
+              pack_h4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
       }
       {   // V^T: channel wave*16 + l15, keys mt*16 + 4*l4 .. +3
         const int d = wave * 16 + l15;
@@ -405,10 +405,10 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           *reinterpret_cast<uint2*>(vt + (mt >> 1) * 512 + (mt & 1) * 4) =
-              pack_bf16x4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
+              pack_h4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
       }
     }
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -12,7 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace rift {
+#include "opfmt.h"
+
+namespace RIFT_NS {
 
 #define ENCW_WGROUPS 12                          // weight groups per layer: k | v | q | out | (fc1 chunk c, fc2 chunk c) x 4
 #define ENCW_LAYER_FRAGS (ENCW_WGROUPS * 32)
@@ -54,4 +56,4 @@ int encw_set_attributes();
 void encw_pack(const EncWSrc& src, unsigned short* img, float* par, hipStream_t stream);
 void encw_launch(const EncWP& p, hipStream_t stream);
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -3,7 +3,7 @@
 #include "enc_w.h"
 #include "wp_stream.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 __global__ void pack_encw_kernel(EncWSrc s, unsigned short* __restrict__ img, float* __restrict__ par) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -12,7 +12,7 @@ __global__ void pack_encw_kernel(EncWSrc s, unsigned short* __restrict__ img, fl
     const int t = e - 4 * ENCW_LAYER_FRAGS * 512;
     const int j = t & 7, lane = (t >> 3) & 63, fr = t >> 9, g = fr >> 5, f = fr & 31;
     const int ks = f >> 3, nt = f & 7, l15 = lane & 15, l4 = lane >> 4;
-    img[e] = f2bf(s.dkv_w[g >> 1][((size_t)(128 + (g & 1) * 128 + nt * 16 + l15)) * 128 + l0w_chan(l4, j, 2 * ks)]);
+    img[e] = f2h(s.dkv_w[g >> 1][((size_t)(128 + (g & 1) * 128 + nt * 16 + l15)) * 128 + l0w_chan(l4, j, 2 * ks)]);
   }
   if (e < 4 * ENCW_LAYER_FRAGS * 512) {
     const int j = e & 7, lane = (e >> 3) & 63, fr = e >> 9, li = fr / ENCW_LAYER_FRAGS, g = (fr % ENCW_LAYER_FRAGS) >> 5, f = fr & 31;
@@ -28,7 +28,7 @@ __global__ void pack_encw_kernel(EncWSrc s, unsigned short* __restrict__ img, fl
       const int c = (g - 4) >> 1;
       v = ((g - 4) & 1) ? L.w2[o * 512 + c * 128 + ch] : L.w1[(c * 128 + o) * 128 + ch];
     }
-    img[e] = f2bf(v);
+    img[e] = f2h(v);
   }
   if (e < ENCW_NPAR) {
     float v;
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     request(li, pos + 1);
   };
-  auto W = [&](int slot, int f) { return *reinterpret_cast<const bf16x8*>(ring + slot * 32768 + f * 1024 + lane * 16); };
-  auto gemm = [&](int slot, const bf16x8 (&x)[4], f32x4 (&acc)[8]) { decw_gemm<false>((uint32_t)(uintptr_t)ring + (uint32_t)slot * 32768u + voff, x, acc); };
+  auto W = [&](int slot, int f) { return *reinterpret_cast<const h16x8*>(ring + slot * 32768 + f * 1024 + lane * 16); };
+  auto gemm = [&](int slot, const h16x8 (&x)[4], f32x4 (&acc)[8]) { decw_gemm<false>((uint32_t)(uintptr_t)ring + (uint32_t)slot * 32768u + voff, x, acc); };
 
   for (int i = tid; i < ENCW_NPAR / 4; i += 512) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
   for (int i = tid; i < 192; i += 512) smaskf[i] = ((i >= N) || p.kpm[row0 + i]) ? -INFINITY : 0.f;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int nt = 0; nt < 8; ++nt) { const float4 v = *reinterpret_cast<const float4*>(bias + nt * 16 + l4 * 4); a[nt] = (f32x4){v.x, v.y, v.z, v.w}; }
   };
   // LayerNorm of the tile's rows in the C/D layout; OUT = false: bf16 operands of the four k-steps, OUT = true: fp32 values back into res
-  auto layer_norm = [&](f32x4 (&res)[8], bf16x8 (&xb)[4], const float* g, bool out) {
+  auto layer_norm = [&](f32x4 (&res)[8], h16x8 (&xb)[4], const float* g, bool out) {
     f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
     s4 += (res[4] + res[5]) + (res[6] + res[7]);
     const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
@@ -146,12 +146,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   // attention of head h over all 16 NKT keys against the K | V^T fragments of a ring slot (K (kt) at kt, V^T (d, pt) at 12 + 6 d + pt)
-  auto attend = [&](int slot, const bf16x8 qh, bf16x8& aoh) {
+  auto attend = [&](int slot, const h16x8 qh, h16x8& aoh) {
     f32x4 s[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
-      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, kt), qh, (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+      s[kt] = mfma_h(W(slot, kt), qh, (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
     }
     float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 o0 = Z, o1 = Z;
 #pragma unroll
     for (int pt = 0; pt < NKT / 2; ++pt) {
-      const bf16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
-      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 12 + pt), pf, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W(slot, 18 + pt), pf, o1, 0, 0, 0);
+      const h16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
+      o0 = mfma_h(W(slot, 12 + pt), pf, o0, 0, 0, 0);
+      o1 = mfma_h(W(slot, 18 + pt), pf, o1, 0, 0, 0);
     }
     aoh = l0w_pack8(o0 * inv, o1 * inv);
   };
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int p1 = 2 * rr;
       if (act) {
         f32x4 res[8], acc[8];
-        bf16x8 xb[4];
+        h16x8 xb[4];
         bnd(li, p1 + 0);                                        // ---- k
         if (rr == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         load_rows(res, rows_in);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         init8(acc, pl + ENCW_P_BK); gemm(0, xb, acc);
 #pragma unroll
         for (int h = 0; h < 4; ++h)                             // K fragment (head h, key tile `tile`): this lane's 16 bytes
-          *reinterpret_cast<bf16x8*>(kvs + ((size_t)(h * 24 + tile) * 64 + lane) * 8) = l0w_pack8(acc[2 * h], acc[2 * h + 1]);
+          *reinterpret_cast<h16x8*>(kvs + ((size_t)(h * 24 + tile) * 64 + lane) * 8) = l0w_pack8(acc[2 * h], acc[2 * h + 1]);
         bnd(li, p1 + 1);                                        // ---- v (plain order: lane = 4 keys of dim nt * 16 + l15)
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) { const float bv = pl[ENCW_P_BV + nt * 16 + l15]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)                          // V^T fragment (head nt / 2, dim tile nt & 1, key pair tile / 2): k slots (tile & 1) * 4 ..
           *reinterpret_cast<uint2*>(kvs + ((size_t)((nt >> 1) * 24 + 12 + (nt & 1) * 6 + (tile >> 1)) * 64 + lane) * 8 + (tile & 1) * 4) =
-              pack_bf16x4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+              pack_h4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
       } else {
         // a round's missing tiles: their K rows must still be finite (masked keys multiply V^T by zero) -- tiles >= ntiles of a 12-tile image
         bnd(li, p1 + 0);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int p2 = 2 * RR + (li == 3 ? Q3 : 14) * rr;
       if (act) {
         f32x4 res[8], acc[8];
-        bf16x8 xb[4], qf[4], ao[4];
+        h16x8 xb[4], qf[4], ao[4];
         bnd(li, p2 + 0);                                        // ---- q
         if (rr == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         load_rows(res, rows_in);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt) acc[nt] = Z;
           gemm(0, xb, acc);
-          bf16x8 hb[4];
+          h16x8 hb[4];
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             const float4 ba = *reinterpret_cast<const float4*>(pl + ENCW_P_B1 + c * 128 + (2 * ks) * 16 + l4 * 4);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bnd(li, p2 + 14 + 2 * l);
             gemm(0, xb, acc);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) *reinterpret_cast<bf16x8*>(dk + ((size_t)(h * 24 + tile) * 64 + lane) * 8) = l0w_pack8(acc[2 * h], acc[2 * h + 1]);
+            for (int h = 0; h < 4; ++h) *reinterpret_cast<h16x8*>(dk + ((size_t)(h * 24 + tile) * 64 + lane) * 8) = l0w_pack8(acc[2 * h], acc[2 * h + 1]);
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) { const float bv = bk[128 + nt * 16 + l15]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
             bnd(li, p2 + 15 + 2 * l);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt)
               *reinterpret_cast<uint2*>(dk + ((size_t)((nt >> 1) * 24 + 12 + (nt & 1) * 6 + (tile >> 1)) * 64 + lane) * 8 + (tile & 1) * 4) =
-                  pack_bf16x4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+                  pack_h4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
           }
         }
       } else {
@@ -325,4 +325,4 @@ void encw_launch(const EncWP& p, hipStream_t stream) {
   hipLaunchKernelGGL(enc_w_kernel, dim3(p.bs), dim3(512), (size_t)ENCW_LDS, stream, p);
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

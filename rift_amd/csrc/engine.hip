@@ -17,7 +17,6 @@
 #include "gemm.h"
 #include "kernels.h"
 #include "loss.h"
-#include "nat_fused.h"
 #include "nat_l0w.h"
 #include "nat_l1w.h"
 #include "enc_fused.h"
@@ -37,24 +36,9 @@
 #include "pi_fused.h"
 #include "rollout.h"
 
-// fused NAT level variants: waves per workgroup and chunk width are occupancy choices (LDS per workgroup decides how many
-// workgroups share a CU; 8 waves give a single resident workgroup two waves per SIMD)
 #define ENC_NW 8
-#define NAT_L0_NW 8
-#define NAT_L0_CW 192
-#define NAT_L1_NW 8
-#define NAT_L1_CW 192
-#define NAT_L2_NW 8
-#define NAT_L2_CW 192
-#ifndef NAT_L0_ROWS
-#define NAT_L0_ROWS 80
-#endif
-#define NAT_L0_WPE (NAT_L0_ROWS > 80 ? 2 : 4)
-#define NAT_L0 (rift::nat_level_kernel<32, 2, 20, 3, NAT_L0_NW, NAT_L0_CW, NAT_L0_WPE, NAT_L0_ROWS>)
-#define NAT_L1 (rift::nat_level_kernel<64, 4, 10, 3, NAT_L1_NW, NAT_L1_CW>)
-#define NAT_L2 (rift::nat_level_kernel<128, 8, 5, 5, NAT_L2_NW, NAT_L2_CW>)
 
-using namespace rift;
+using namespace RIFT_NS;
 
 namespace {
 
@@ -70,6 +54,7 @@ struct Tap { float* p; int64_t numel; };
 }  // namespace
 
 struct RiftCtx {
+  int opfmt = 0;                         // FIRST member (set by rift_ctx_create of the build): abi.cpp reads it to route a call to the build (bf16 / fp16 operands) that owns the context
   int device = 0;
   std::string err;
   std::unordered_map<std::string, Param> params;
@@ -89,13 +74,11 @@ struct RiftCtx {
   double* l_S = nullptr; double* l_cnt = nullptr; float* l_dz = nullptr; float* l_partial = nullptr;
   size_t l_cap_bs = 0, l_cap_rows = 0, l_cap_wg = 0;
   float* ego_w = nullptr; float* ego_b = nullptr;   // packed (6,128) linears of StateAttentionEncoder
-  unsigned short* nat_wqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // head-major bf16 qkv weights
-  float* nat_bqkv[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  bool nat_fused = true; int nat_dbg = 0; int gemm_dbg = 0;
-  bool nat_l0w = true; unsigned short* l0w_img = nullptr; float* l0w_par = nullptr;
+  bool nat_fused = true; int gemm_dbg = 0;
+  unsigned short* l0w_img = nullptr; float* l0w_par = nullptr;   // wave-private level-0 NAT kernel (nat_l0w.h)
   unsigned short* encw_img = nullptr; float* encw_par = nullptr;   // weight stream / parameters of the dense-traffic scene encoder (enc_w.h)
-  bool nat_l2w = true; unsigned short* l2w_img = nullptr; float* l2w_par = nullptr;   // wave-private, weight-streaming level-2 NAT kernel (nat_l2w.h)
-  bool nat_l1w = true; unsigned short* l1w_img = nullptr; float* l1w_par = nullptr;   // wave-private level-1 NAT kernel (nat_l1w.h)   // wave-private level-0 NAT kernel (nat_l0w.h)
+  unsigned short* l2w_img = nullptr; float* l2w_par = nullptr;   // wave-private, weight-streaming level-2 NAT kernel (nat_l2w.h)
+  unsigned short* l1w_img = nullptr; float* l1w_par = nullptr;   // wave-private level-1 NAT kernel (nat_l1w.h)
   unsigned short* enc_wqkv[4] = {nullptr, nullptr, nullptr, nullptr};   // chunked (q|k|q|k|v|v) bf16 in_proj images
   float* enc_bqkv[4] = {nullptr, nullptr, nullptr, nullptr};
   int* enc_idx = nullptr; bool enc_fused = true;
@@ -110,7 +93,7 @@ struct RiftCtx {
   struct Dp { bool on = false; int off = 0, gbs = 0; double* xchg = nullptr; long long len = 0; RiftExchangeFn fn = nullptr; void* user = nullptr; } dp;   // rift_set_dp
   int* nonfinite = nullptr;              // device flag set by the policy-head kernels when the decoder output is not finite
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
-  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256, nat_grid0 = 1024; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
+  bool pe_fused = true; bool fo_fused = true; int nat_grid = 256; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
   bool loaded = false;
   // optional per-launch HIP-event profiling (bench roofline leg; off on the timed path)
   bool prof_on = false; double prof_flops = 0.0; bool prof_shapes = false;
@@ -413,9 +396,6 @@ int set_lds_attrs(RiftCtx* c) {
   HIPCHK(c, (hipError_t)encw_set_attributes());
   HIPCHK(c, (hipError_t)pew_set_attributes());
   HIPCHK(c, (hipError_t)fow_set_attributes());
-  SETATTR(NAT_L0);
-  SETATTR(NAT_L1);
-  SETATTR(NAT_L2);
   SETATTR((gemm_rows_kernel<true, 1, 8, 4, 1>));
   SETATTR((gemm_rows_kernel<true, 4, 2, 1, 4>));
   SETATTR((gemm_rows_kernel<false, 4, 2, 1, 4>));
@@ -828,7 +808,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* Oc[3];   // LayerNorm(norm_i) of the last 3 steps of level i: all that out[:, :, -1] of the FPN depends on
   for (int i = 0; i < 3; ++i) Oc[i] = A_alloc<float>(c, (size_t)nA * 3 * Cl[i]);
   // the wave-private level kernels hand these rows to fpn_tail_kernel as bf16 (it rounds them to bf16 first thing anyway): same values, half the bytes
-  const bool oc_bf16 = fused && c->fpn_fused && c->nat_l0w && c->nat_l1w && c->nat_l2w;
+  const bool oc_bf16 = fused && c->fpn_fused;
   unsigned short* Ocb[3] = {nullptr, nullptr, nullptr};
   if (oc_bf16) for (int i = 0; i < 3; ++i) Ocb[i] = A_alloc<unsigned short>(c, (size_t)nA * 3 * Cl[i]);
   if (fused) {
@@ -836,63 +816,33 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     float* Xin[3] = {nullptr, A_alloc<float>(c, (size_t)nA * 10 * 64), A_alloc<float>(c, (size_t)nA * 5 * 128)};
     for (int lv = 0; lv < 3; ++lv) {
       const int C = Cl[lv], H = Hl[lv], ksz = Kl[lv], L = Ll[lv], rows = nA * L;
-      if (lv == 0 && c->nat_l0w) {   // level 0 as wave-private, register-resident tiles (no workgroup barriers): nat_l0w.h
+      if (lv == 0) {   // level 0 as wave-private, register-resident tiles (no workgroup barriers): nat_l0w.h
         NatL0WP q; memset(&q, 0, sizeof(q));
         q.F9 = F9; q.nseq = nA; q.img = c->l0w_img; q.par = c->l0w_par; q.Oc = Oc[0]; q.Ocb = Ocb[0]; q.Xnext = Xin[1];
         { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 1) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         q.droppath[0] = f.drop ? dpr[0] : 0.f; q.droppath[1] = f.drop ? dpr[1] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + 2.0 * rows * 27 * 32 + (rows / 2) * 2.0 * 3 * C * 2 * C;
-        launch(c, "nat_level_kernel_L0", nat_l0w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid)), dim3(64 * L0W_NWV), (size_t)L0W_LDS, q);
+        launch(c, "nat_l0w_kernel", nat_l0w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid)), dim3(64 * L0W_NWV), (size_t)L0W_LDS, q);
         continue;
       }
-      if (lv == 1 && c->nat_l1w) {   // level 1 likewise (weights swapped through LDS between the two layers): nat_l1w.h
+      if (lv == 1) {   // level 1 likewise (weights swapped through LDS between the two layers): nat_l1w.h
         NatL1WP q; memset(&q, 0, sizeof(q));
         q.X = Xin[1]; q.nseq = nA; q.img = c->l1w_img; q.par = c->l1w_par; q.Oc = Oc[1]; q.Ocb = Ocb[1]; q.Xnext = Xin[2];
         q.droppath[0] = f.drop ? dpr[2] : 0.f; q.droppath[1] = f.drop ? dpr[3] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (rows / 2) * 2.0 * 3 * C * 2 * C;
-        launch(c, "nat_level_kernel_L1", nat_l1w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid)), dim3(512), (size_t)L1W_LDS, q);
+        launch(c, "nat_l1w_kernel", nat_l1w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid)), dim3(512), (size_t)L1W_LDS, q);
         continue;
       }
-      if (lv == 2 && c->nat_l2w) {   // level 2: wave-private tiles of 3 agents, the two layers' weights streamed through LDS (nat_l2w.h)
+      {   // level 2: wave-private tiles of 3 agents, the two layers' weights streamed through LDS (nat_l2w.h)
         NatL2WP q; memset(&q, 0, sizeof(q));
         q.X = Xin[2]; q.nseq = nA; q.img = c->l2w_img; q.par = c->l2w_par; q.Oc = Oc[2]; q.Ocb = Ocb[2];
         q.droppath[0] = f.drop ? dpr[4] : 0.f; q.droppath[1] = f.drop ? dpr[5] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 3) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C);
         const int l2grid = std::min(cdiv(cdiv(nA, 3), 8), c->nat_grid);
-        launch_call(c, "nat_level_kernel_L2", [&] { l2w_launch(q, l2grid, c->stream); });
+        launch_call(c, "nat_l2w_kernel", [&] { l2w_launch(q, l2grid, c->stream); });
         continue;
       }
-      NatLevelP p; memset(&p, 0, sizeof(p));
-      p.dbg = c->nat_dbg;
-      p.X = Xin[lv]; p.nseq = nA; p.seed = f.seed; p.stream = f.next_stream(); f.stream_id += 4;
-      for (int b = 0; b < 2; ++b) {
-        const std::string bp = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b);
-        NatBlockW& w = p.blk[b];
-        w.ln1_g = fptr(c, bp + ".norm1.weight"); w.ln1_b = fptr(c, bp + ".norm1.bias");
-        w.ln2_g = fptr(c, bp + ".norm2.weight"); w.ln2_b = fptr(c, bp + ".norm2.bias");
-        w.wqkv = c->nat_wqkv[lv][b]; w.bqkv = c->nat_bqkv[lv][b]; w.rpb = fptr(c, bp + ".attn.rpb");
-        w.wproj = (const unsigned short*)c->pw[bp + ".attn.proj"].bf; w.bproj = c->pw[bp + ".attn.proj"].bias;
-        w.w1 = (const unsigned short*)c->pw[bp + ".mlp.fc1"].bf; w.b1 = c->pw[bp + ".mlp.fc1"].bias;
-        w.w2 = (const unsigned short*)c->pw[bp + ".mlp.fc2"].bf; w.b2 = c->pw[bp + ".mlp.fc2"].bias;
-        w.droppath = f.drop ? dpr[2 * lv + b] : 0.f;
-      }
-      if (lv == 0) { p.F9 = F9; p.w_tok = (const unsigned short*)c->pw[HE + ".embed.proj"].bf; p.b_tok = c->pw[HE + ".embed.proj"].bias; }
-      p.Oc = Oc[lv]; p.fn_g = fptr(c, HE + ".norm" + std::to_string(lv) + ".weight"); p.fn_b = fptr(c, HE + ".norm" + std::to_string(lv) + ".bias");
-      if (lv < 2) {
-        const std::string dn = HE + ".levels." + std::to_string(lv) + ".downsample";
-        p.Xnext = Xin[lv + 1]; p.w_ds = (const unsigned short*)c->pw[dn + ".reduction"].bf;
-        p.ds_g = fptr(c, dn + ".norm.weight"); p.ds_b = fptr(c, dn + ".norm.bias");
-      }
-      { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == lv + 1) { p.ts = A_alloc<long long>(c, 256); tap(c, "nat_ts", (float*)p.ts, 512); } }
-      // persistent workgroups (one per CU at 8 waves), each looping over row tiles with the next tile prefetched
-      const int trows = lv == 0 ? NAT_L0_ROWS : 80;
-      const dim3 grid(std::min(cdiv(rows, trows), lv == 0 ? (NAT_L0_ROWS > 80 ? c->nat_grid : c->nat_grid0) : c->nat_grid));   // level 0 fits two workgroups per CU
-      (void)H;
-      c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (lv == 0 ? 2.0 * rows * 27 * 32 : 0.0) + (lv < 2 ? (rows / 2) * 2.0 * 3 * C * 2 * C : 0.0);
-      if (lv == 0) launch(c, "nat_level_kernel_L0", NAT_L0, grid, dim3(64 * NAT_L0_NW), nat_lds_bytes(32, 2, 3, NAT_L0_CW, NAT_L0_ROWS), p);
-      else if (lv == 1) launch(c, "nat_level_kernel_L1", NAT_L1, grid, dim3(64 * NAT_L1_NW), nat_lds_bytes(64, 4, 3, NAT_L1_CW), p);
-      else launch(c, "nat_level_kernel_L2", NAT_L2, grid, dim3(64 * NAT_L2_NW), nat_lds_bytes(128, 8, 5, NAT_L2_CW), p);
     }
   } else {
     float* X0 = A_alloc<float>(c, (size_t)nA * 20 * 32);
@@ -1346,13 +1296,15 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 }  // namespace
 
 // ============================================================================================
-// C-ABI
+// C-ABI of this build (one per operand format).  The exported `rift_*` symbols of include/rift_hip.h are trampolines (abi.cpp, generated
+// from the header) that route a call through the table at the end of this file to the build that owns the context.
 // ============================================================================================
-extern "C" {
+namespace RIFT_NS { namespace abi {
 
 int rift_ctx_create(int device, RiftCtx** ctx) {
   if (!ctx) return RIFT_ERR_ARG;
   RiftCtx* c = new RiftCtx();
+  c->opfmt = RIFT_OP_F16;
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
   { const char* ev = getenv("RIFT_NAT_UNFUSED"); c->nat_fused = !(ev && ev[0] == '1'); }
@@ -1365,12 +1317,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_PI_UNFUSED"); c->pi_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
-  { const char* ev = getenv("RIFT_NAT_GRID0"); if (ev && atoi(ev) > 0) c->nat_grid0 = atoi(ev); }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
-  { const char* ev = getenv("RIFT_NAT_DBG"); c->nat_dbg = ev ? atoi(ev) : 0; }
-  { const char* ev = getenv("RIFT_NAT_L0W"); c->nat_l0w = !(ev && ev[0] == '0'); }
-  { const char* ev = getenv("RIFT_NAT_L1W"); c->nat_l1w = !(ev && ev[0] == '0'); }
-  { const char* ev = getenv("RIFT_NAT_L2W"); c->nat_l2w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_FO_W"); c->fo_w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_TWO_STREAMS"); c->two_streams = !(ev && ev[0] == '0'); }
@@ -1405,7 +1352,6 @@ void rift_ctx_destroy(RiftCtx* c) {
   for (int i = 0; i < 3; ++i) if (c->fow_img[i]) { (void)hipFree(c->fow_img[i]); (void)hipFree(c->fow_par[i]); }
   if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
-  for (int lv = 0; lv < 3; ++lv) for (int b = 0; b < 2; ++b) { if (c->nat_wqkv[lv][b]) (void)hipFree(c->nat_wqkv[lv][b]); if (c->nat_bqkv[lv][b]) (void)hipFree(c->nat_bqkv[lv][b]); }
   delete c;
 }
 
@@ -1430,18 +1376,6 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
       const std::string p = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b);
       TRY(pack_linear(c, p + ".attn.qkv")); TRY(pack_linear(c, p + ".attn.proj"));
       TRY(pack_linear(c, p + ".mlp.fc1")); TRY(pack_linear(c, p + ".mlp.fc2"));
-    }
-    for (int b = 0; b < 2; ++b) {   // head-major bf16 qkv image for the fused level kernel
-      const std::string p = HE + ".levels." + std::to_string(lv) + ".blocks." + std::to_string(b) + ".attn.qkv";
-      const int C = 32 << lv, H = 2 << lv;
-      const float* w = fptr(c, p + ".weight"); const float* bsrc = fptr(c, p + ".bias");
-      if (!w || !bsrc) return RIFT_ERR_ARG;
-      if (!c->nat_wqkv[lv][b]) {
-        HIPCHK(c, hipMalloc((void**)&c->nat_wqkv[lv][b], (size_t)3 * C * C * 2));
-        HIPCHK(c, hipMalloc((void**)&c->nat_bqkv[lv][b], (size_t)3 * C * 4));
-      }
-      hipLaunchKernelGGL(pack_qkv_headmajor_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, c->stream, w, bsrc, C, H,
-                         c->nat_wqkv[lv][b], c->nat_bqkv[lv][b]);
     }
     if (lv < 2) TRY(pack_conv(c, HE + ".levels." + std::to_string(lv) + ".downsample.reduction"));
     TRY(pack_conv(c, HE + ".lateral_convs." + std::to_string(lv)));
@@ -2139,4 +2073,18 @@ int rift_collate(RiftCtx* c, const RiftReplayArena* ar, const int32_t* scene_idx
   return RIFT_OK;
 }
 
-}  // extern "C"
+}}  // namespace RIFT_NS::abi
+
+#include "abi_table.h"
+#if RIFT_OP_F16
+#define RIFT_VT_SYM rift_vtable_fp16
+#else
+#define RIFT_VT_SYM rift_vtable_bf16
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)      // host data: the device pass of this file must not see pointers to host functions
+extern "C" const RiftVTable RIFT_VT_SYM = {
+#define RIFT_FN(name) &RIFT_NS::abi::name,
+#include "abi_list.h"
+#undef RIFT_FN
+};
+#endif

@@ -11,7 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace rift {
+#include "opfmt.h"
+
+namespace RIFT_NS {
 
 #define FOW_PAR_DIM 640                          // per dim: b0 | ln gamma | ln beta | w0[:, 128] | b3
 #define FOW_PAR_OUT 1920                         // to_out: ln gamma | ln beta | bias
@@ -43,4 +45,4 @@ int fow_set_attributes();
 void fow_pack(const FoWSrc& src, unsigned short* img, float* par, hipStream_t stream);
 void fow_launch(const FoWP& p, hipStream_t stream);
 
-}  // namespace rift
+}  // namespace RIFT_NS

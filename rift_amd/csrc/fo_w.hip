@@ -3,7 +3,7 @@
 #include "fo_w.h"
 #include "wp_stream.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 #ifndef RIFT_PI
 #define RIFT_PI 3.14159265358979323846f
@@ -20,7 +20,7 @@ __global__ void pack_fow_kernel(FoWSrc s, unsigned short* __restrict__ img, floa
     if (g == 2 * s.D) v = s.wo[o * 128 + ch];
     else if (g & 1) v = s.w3[g >> 1][o * 128 + ch];
     else v = s.w0[g >> 1][o * 129 + 32 * ks + 8 * l4 + j];
-    img[e] = f2bf(v);
+    img[e] = f2h(v);
   }
   if (e < FOW_NPAR) {
     float v = 0.f;
@@ -63,11 +63,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sync();
     if (gc + 1 < total) dma((gc + 1) % NG, (uint32_t)((gc + 1) & 1));
   };
-  auto gemm = [&](const bf16x8 (&x)[4], f32x4 (&c)[8]) {
+  auto gemm = [&](const h16x8 (&x)[4], f32x4 (&c)[8]) {
     decw_gemm<false>((uint32_t)(uintptr_t)ring + (uint32_t)(gc & 1) * 32768u + voff, x, c);
   };
   // LayerNorm over the 128 channels of a row (32 per lane, four lanes per row) + ReLU -> bf16 operands of the four k-steps
-  auto ln_relu = [&](const f32x4 (&v)[8], bf16x8 (&xb)[4], const float* g, const float* b) {
+  auto ln_relu = [&](const f32x4 (&v)[8], h16x8 (&xb)[4], const float* g, const float* b) {
     f32x4 s4 = (v[0] + v[1]) + (v[2] + v[3]);
     s4 += (v[4] + v[5]) + (v[6] + v[7]);
     const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) { const float4 b = *reinterpret_cast<const float4*>(par + FOW_PAR_B3SUM + nt * 16 + l4 * 4); sum[nt] = (f32x4){b.x, b.y, b.z, b.w}; }
       }
-      bf16x8 fk[4];
+      h16x8 fk[4];
       {
         // cos / sin(2 pi f x): v_sin / v_cos take revolutions, so only fract(f x) is needed; lane quarter l4 holds frequencies 8 l4 + j and 32 + 8 l4 + j
         float cs[16], sn[16];
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          fk[h] = l0w_from_u2(make_uint2(pack_bf16x2(cs[8 * h], cs[8 * h + 1]), pack_bf16x2(cs[8 * h + 2], cs[8 * h + 3])),
-                              make_uint2(pack_bf16x2(cs[8 * h + 4], cs[8 * h + 5]), pack_bf16x2(cs[8 * h + 6], cs[8 * h + 7])));
-          fk[2 + h] = l0w_from_u2(make_uint2(pack_bf16x2(sn[8 * h], sn[8 * h + 1]), pack_bf16x2(sn[8 * h + 2], sn[8 * h + 3])),
-                                  make_uint2(pack_bf16x2(sn[8 * h + 4], sn[8 * h + 5]), pack_bf16x2(sn[8 * h + 6], sn[8 * h + 7])));
+          fk[h] = l0w_from_u2(make_uint2(pack_h2(cs[8 * h], cs[8 * h + 1]), pack_h2(cs[8 * h + 2], cs[8 * h + 3])),
+                              make_uint2(pack_h2(cs[8 * h + 4], cs[8 * h + 5]), pack_h2(cs[8 * h + 6], cs[8 * h + 7])));
+          fk[2 + h] = l0w_from_u2(make_uint2(pack_h2(sn[8 * h], sn[8 * h + 1]), pack_h2(sn[8 * h + 2], sn[8 * h + 3])),
+                                  make_uint2(pack_h2(sn[8 * h + 4], sn[8 * h + 5]), pack_h2(sn[8 * h + 6], sn[8 * h + 7])));
         }
       }
       f32x4 acc[8];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         acc[nt] = (f32x4){b.x + w.x * xd, b.y + w.y * xd, b.z + w.z * xd, b.w + w.w * xd};
       }
       gemm(fk, acc);
-      bf16x8 hb[4];
+      h16x8 hb[4];
       ln_relu(acc, hb, pd + 128, pd + 256);
       ++gc;
       boundary();                                                  // ---- mlps.d.3, summed over the dims
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ++gc;
     }
     boundary();                                                    // ---- to_out: LayerNorm, ReLU, Linear
-    bf16x8 ob[4];
+    h16x8 ob[4];
     ln_relu(sum, ob, par + FOW_PAR_OUT, par + FOW_PAR_OUT + 128);
     f32x4 acc[8];
 #pragma unroll
@@ -194,4 +194,4 @@ void fow_launch(const FoWP& p, hipStream_t stream) {
   if (grid > 0) hipLaunchKernelGGL(fo_w_kernel, dim3(grid), dim3(512), FOW_LDS_BYTES, stream, p);
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -9,7 +9,7 @@
 #include "common.h"
 #include "pe_fused.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 struct FourierP {
   const float* in; int in_ld, rows, D, wrap_dim;
@@ -77,10 +77,10 @@ __device__ __forceinline__ void fourier_fused_body(const FourierP& p, const int 
       q = sum16(q);
       const float rstd = rsqrtf(q * (1.0f / 128.0f) + 1e-5f);
       uint4 o;
-      o.x = pack_bf16x2(fmaxf(d0 * rstd * g0.x + b0.x, 0.f), fmaxf(d1 * rstd * g0.y + b0.y, 0.f));
-      o.y = pack_bf16x2(fmaxf(d2 * rstd * g0.z + b0.z, 0.f), fmaxf(d3 * rstd * g0.w + b0.w, 0.f));
-      o.z = pack_bf16x2(fmaxf(d4 * rstd * g1.x + b1.x, 0.f), fmaxf(d5 * rstd * g1.y + b1.y, 0.f));
-      o.w = pack_bf16x2(fmaxf(d6 * rstd * g1.z + b1.z, 0.f), fmaxf(d7 * rstd * g1.w + b1.w, 0.f));
+      o.x = pack_h2(fmaxf(d0 * rstd * g0.x + b0.x, 0.f), fmaxf(d1 * rstd * g0.y + b0.y, 0.f));
+      o.y = pack_h2(fmaxf(d2 * rstd * g0.z + b0.z, 0.f), fmaxf(d3 * rstd * g0.w + b0.w, 0.f));
+      o.z = pack_h2(fmaxf(d4 * rstd * g1.x + b1.x, 0.f), fmaxf(d5 * rstd * g1.y + b1.y, 0.f));
+      o.w = pack_h2(fmaxf(d6 * rstd * g1.z + b1.z, 0.f), fmaxf(d7 * rstd * g1.w + b1.w, 0.f));
       *reinterpret_cast<uint4*>(hn + r * FO_FS + l15 * 8) = o;
     }
   };
@@ -95,8 +95,8 @@ __device__ __forceinline__ void fourier_fused_body(const FourierP& p, const int 
       // (|error| ~ 1e-6, far below the bf16 rounding the features get as MFMA operands)
       const float rev = __builtin_amdgcn_fractf(xs[r * 4 + d] * p.freqs[d * 64 + fq]);
       const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
-      feat[r * FO_FS + fq] = f2bf(cs);
-      feat[r * FO_FS + 64 + fq] = f2bf(sn);
+      feat[r * FO_FS + fq] = f2h(cs);
+      feat[r * FO_FS + 64 + fq] = f2h(sn);
     }
     __syncthreads();
     {
@@ -174,4 +174,4 @@ __global__ __launch_bounds__(256) void fourier_fused_kernel(FourierP3 q) {
   if (q.count > 2) fourier_fused_body(q.e[2], blk);
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -9,7 +9,7 @@
 #include "common.h"
 #include "pe_fused.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 struct FpnP {
   const float* oc[3];            // level i: (nA, 3, C_i) normalised last three steps, C = 32, 64, 128
@@ -42,7 +42,7 @@ __device__ __forceinline__ void fpn_load(const FpnP& p, int lv, int a0, FpnRows<
       const int pz = rem / (C / 4), c4 = (rem - pz * (C / 4)) * 4;
       if (a0 + a < p.nA) {
         if (p.ocb[lv]) u = *reinterpret_cast<const uint2*>(p.ocb[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4);
-        else { const float4 v = *reinterpret_cast<const float4*>(p.oc[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4); u = pack_bf16x4(v.x, v.y, v.z, v.w); }
+        else { const float4 v = *reinterpret_cast<const float4*>(p.oc[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4); u = pack_h4(v.x, v.y, v.z, v.w); }
       }
     }
     R.u[k] = u;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512) void fpn_tail_kernel(FpnP p) {
       z[r] = odd ? l0 + l1b : l0 + (0.25f * l1a + 0.75f * l1b);
     }
     const int agent = (mt * 16 + l15) >> 1;
-    *reinterpret_cast<uint2*>(Zt + agent * 272 + (odd ? 128 : 0) + col) = pack_bf16x4(z[0], z[1], z[2], z[3]);
+    *reinterpret_cast<uint2*>(Zt + agent * 272 + (odd ? 128 : 0) + col) = pack_h4(z[0], z[1], z[2], z[3]);
   }
   __syncthreads();
   f32x4 acc[4][1];
@@ -126,4 +126,4 @@ __global__ __launch_bounds__(512) void fpn_tail_kernel(FpnP p) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -12,7 +12,7 @@
 #pragma once
 #include "common.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 enum { PRO_NONE = 0, PRO_LN = 1, PRO_AFFINE = 2 };
@@ -46,7 +46,7 @@ template <bool BF16> struct Prec;
 template <> struct Prec<true> {
   typedef unsigned short lds_t;
   static constexpr int PAD = 8;
-  __device__ static __forceinline__ lds_t cvt(float f) { return f2bf(f); }
+  __device__ static __forceinline__ lds_t cvt(float f) { return f2h(f); }
 };
 template <> struct Prec<false> {
   typedef float lds_t;
@@ -79,8 +79,8 @@ __device__ __forceinline__ RowDesc row_desc(const GemmP& p, int row) {
 
 __device__ __forceinline__ void lds_store4(unsigned short* dst, float4 v) {
   uint2 u;
-  u.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-  u.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+  u.x = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16);
+  u.y = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
   *reinterpret_cast<uint2*>(dst) = u;
 }
 __device__ __forceinline__ void lds_store4(float* dst, float4 v) { *reinterpret_cast<float4*>(dst) = v; }
@@ -258,21 +258,21 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmP p) {
     if constexpr (BF16) {
       const unsigned short* W = reinterpret_cast<const unsigned short*>(p.W);
       for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 b[NT], a[MT];
+        h16x8 b[NT], a[MT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int nb = ncol0 + nt * 16;
           if (nb < Npad) b[nt] = fm_load(W, p.Kp, nb, ks * 32, l4 * 16 + l15);   // fragment-major weight image (common.h)
-          else b[nt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          else b[nt] = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          a[mt] = *reinterpret_cast<const bf16x8*>(As + ((wm * MT + mt) * 16 + l15) * lda + ks * 32 + l4 * 8);
+          a[mt] = *reinterpret_cast<const h16x8*>(As + ((wm * MT + mt) * 16 + l15) * lda + ks * 32 + l4 * 8);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = mfma_h(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
       }
     } else {
       const float* W = reinterpret_cast<const float*>(p.W);
@@ -388,4 +388,4 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmP p) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -7,7 +7,7 @@
 #include "common.h"
 #include "pe_fused.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 struct Heads3P {
   const float* X; int ldx;            // (rows, 128) fp32 input rows at stride ldx; row r of scene-structured inputs: see gather
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
       else if (e < 3 * 768 + 480) { const int k = e - 3 * 768; pv[u] = p.b2[k / 160][k % 160]; }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int i = tid + u * 512; *reinterpret_cast<uint2*>(xb + (i >> 5) * HD_XS + (i & 31) * 4) = pack_bf16x4(xv[u].x, xv[u].y, xv[u].z, xv[u].w); }
+    for (int u = 0; u < 8; ++u) { const int i = tid + u * 512; *reinterpret_cast<uint2*>(xb + (i >> 5) * HD_XS + (i & 31) * 4) = pack_h4(xv[u].x, xv[u].y, xv[u].z, xv[u].w); }
 #pragma unroll
     for (int u = 0; u < 6; ++u) { const int e = tid + u * 512; if (e < 3 * 768 + 480) par[e] = pv[u]; }
   }
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {                  // n-tiles >= 10 do not exist in the 160-row image
         const bool ok = j * NW + wave < 10;
-        W2a.f[ks][j] = ok ? fm_load(p.w2[h], 256, (j * NW + wave) * 16, ks * 32, l4 * 16 + l15) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        W2b.f[ks][j] = ok ? fm_load(p.w2[h], 256, (j * NW + wave) * 16, 128 + ks * 32, l4 * 16 + l15) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        W2a.f[ks][j] = ok ? fm_load(p.w2[h], 256, (j * NW + wave) * 16, ks * 32, l4 * 16 + l15) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        W2b.f[ks][j] = ok ? fm_load(p.w2[h], 256, (j * NW + wave) * 16, 128 + ks * 32, l4 * 16 + l15) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
       }
     float bsum[MT], bsq[MT];
 #pragma unroll
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
         const int col = (j * NW + wave) * 16 + l4 * 4;
         const float4 g4 = *reinterpret_cast<const float4*>(ph + 256 + col), e4 = *reinterpret_cast<const float4*>(ph + 512 + col);
         *reinterpret_cast<uint2*>(hn + row * HD_HS + col) =
-            pack_bf16x4(fmaxf((acc[mt][j][0] - mean) * rstd * g4.x + e4.x, 0.f), fmaxf((acc[mt][j][1] - mean) * rstd * g4.y + e4.y, 0.f),
+            pack_h4(fmaxf((acc[mt][j][0] - mean) * rstd * g4.x + e4.x, 0.f), fmaxf((acc[mt][j][1] - mean) * rstd * g4.y + e4.y, 0.f),
                         fmaxf((acc[mt][j][2] - mean) * rstd * g4.z + e4.z, 0.f), fmaxf((acc[mt][j][3] - mean) * rstd * g4.w + e4.w, 0.f));
       }
     }
@@ -141,4 +141,4 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

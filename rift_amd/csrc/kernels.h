@@ -5,7 +5,7 @@
 #pragma once
 #include "common.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 #define RIFT_PI 3.14159265358979323846f
 
@@ -29,7 +29,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* dst, int
       v = src[(size_t)(n + src_row_off) * src_ld + k];
     }
   }
-  if (BF16) reinterpret_cast<unsigned short*>(dst)[fm_index(n, k, Kp)] = f2bf(v);   // fragment-major (common.h)
+  if (BF16) reinterpret_cast<unsigned short*>(dst)[fm_index(n, k, Kp)] = f2h(v);   // fragment-major (common.h)
   else reinterpret_cast<float*>(dst)[idx] = v;
 }
 
@@ -301,11 +301,11 @@ __global__ void mha_mfma_kernel(MhaP p) {
       vv = *reinterpret_cast<const float4*>(p.V + row * p.ldkv + h * 32 + d4);
     }
     uint2 u;
-    u.x = (unsigned)f2bf(kv.x) | ((unsigned)f2bf(kv.y) << 16);
-    u.y = (unsigned)f2bf(kv.z) | ((unsigned)f2bf(kv.w) << 16);
+    u.x = (unsigned)f2h(kv.x) | ((unsigned)f2h(kv.y) << 16);
+    u.y = (unsigned)f2h(kv.z) | ((unsigned)f2h(kv.w) << 16);
     *reinterpret_cast<uint2*>(Ks + key * KS + d4) = u;
-    Vt[(d4 + 0) * VS + key] = f2bf(vv.x); Vt[(d4 + 1) * VS + key] = f2bf(vv.y);
-    Vt[(d4 + 2) * VS + key] = f2bf(vv.z); Vt[(d4 + 3) * VS + key] = f2bf(vv.w);
+    Vt[(d4 + 0) * VS + key] = f2h(vv.x); Vt[(d4 + 1) * VS + key] = f2h(vv.y);
+    Vt[(d4 + 2) * VS + key] = f2h(vv.z); Vt[(d4 + 3) * VS + key] = f2h(vv.w);
   }
   for (int i = tid; i < LKP; i += blockDim.x)
     smask[i] = (i >= p.Lk) || (p.mask && p.mask[(size_t)mb * p.Lk + i]);
@@ -316,19 +316,19 @@ __global__ void mha_mfma_kernel(MhaP p) {
   const int nqt = (p.Lq + 15) >> 4;
   for (int qt = wave; qt < nqt; qt += nwave) {
     const int q = qt * 16 + l15;
-    bf16x8 qf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    h16x8 qf = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
     if (q < p.Lq) {
       const float* qp = p.Q + ((size_t)bo * p.q_outer + (size_t)bi * p.q_inner + (size_t)q * p.q_stride) * p.ldq + h * 32 + l4 * 8;
       const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
-      qf[0] = (short)f2bf(a.x * scale); qf[1] = (short)f2bf(a.y * scale); qf[2] = (short)f2bf(a.z * scale); qf[3] = (short)f2bf(a.w * scale);
-      qf[4] = (short)f2bf(b.x * scale); qf[5] = (short)f2bf(b.y * scale); qf[6] = (short)f2bf(b.z * scale); qf[7] = (short)f2bf(b.w * scale);
+      qf[0] = (short)f2h(a.x * scale); qf[1] = (short)f2h(a.y * scale); qf[2] = (short)f2h(a.z * scale); qf[3] = (short)f2h(a.w * scale);
+      qf[4] = (short)f2h(b.x * scale); qf[5] = (short)f2h(b.y * scale); qf[6] = (short)f2h(b.z * scale); qf[7] = (short)f2h(b.w * scale);
     }
     f32x4 s[NKT];
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + l15) * KS + l4 * 8);
-      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const h16x8 kf = *reinterpret_cast<const h16x8*>(Ks + (kt * 16 + l15) * KS + l4 * 8);
+      s[kt] = mfma_h(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (smask[kt * 16 + l4 * 4 + r]) s[kt][r] = -INFINITY;
@@ -354,20 +354,20 @@ __global__ void mha_mfma_kernel(MhaP p) {
     f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
     for (int pt = 0; pt < NKT / 2; ++pt) {
-      bf16x8 pf;
+      h16x8 pf;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { pf[j] = (short)f2bf(s[2 * pt][j]); pf[4 + j] = (short)f2bf(s[2 * pt + 1][j]); }
+      for (int j = 0; j < 4; ++j) { pf[j] = (short)f2h(s[2 * pt][j]); pf[4 + j] = (short)f2h(s[2 * pt + 1][j]); }
       const unsigned short* v0 = Vt + l15 * VS + pt * 32 + l4 * 4;
       const unsigned short* v1 = Vt + (16 + l15) * VS + pt * 32 + l4 * 4;
-      bf16x8 b0, b1;
+      h16x8 b0, b1;
       const uint2 x0 = *reinterpret_cast<const uint2*>(v0), x1 = *reinterpret_cast<const uint2*>(v0 + 16);
       const uint2 y0 = *reinterpret_cast<const uint2*>(v1), y1 = *reinterpret_cast<const uint2*>(v1 + 16);
       b0[0] = (short)(x0.x & 0xffff); b0[1] = (short)(x0.x >> 16); b0[2] = (short)(x0.y & 0xffff); b0[3] = (short)(x0.y >> 16);
       b0[4] = (short)(x1.x & 0xffff); b0[5] = (short)(x1.x >> 16); b0[6] = (short)(x1.y & 0xffff); b0[7] = (short)(x1.y >> 16);
       b1[0] = (short)(y0.x & 0xffff); b1[1] = (short)(y0.x >> 16); b1[2] = (short)(y0.y & 0xffff); b1[3] = (short)(y0.y >> 16);
       b1[4] = (short)(y1.x & 0xffff); b1[5] = (short)(y1.x >> 16); b1[6] = (short)(y1.y & 0xffff); b1[7] = (short)(y1.y >> 16);
-      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b0, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b1, o1, 0, 0, 0);
+      o0 = mfma_h(pf, b0, o0, 0, 0, 0);
+      o1 = mfma_h(pf, b1, o1, 0, 0, 0);
     }
     // O[q = 4*l4 + r][d = l15 (+16)] ; the softmax denominator of query qq lives in lane qq
 #pragma unroll
@@ -723,4 +723,4 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepP q) {
   token_pos_body(q.agent_pos, q.agent_head, q.Tfull, q.map_center, q.st_pos, q.st_head, q.bs, q.A, q.Mp, q.S, q.pos, blk);
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

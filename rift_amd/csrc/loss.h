@@ -5,7 +5,7 @@
 #pragma once
 #include "common.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 enum { LOSS_RIFT = 0, LOSS_GRPO = 1, LOSS_PPO = 2, LOSS_REINFORCE = 3, LOSS_SFT = 4 };
 
@@ -511,4 +511,4 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamList L) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -20,7 +20,7 @@
 #include "common.h"
 #include "wp_stream.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 #define L0W_NFRAG 54
 #define L0W_F_TOK 0                       // 2 n-tiles, K = 27 window values (tap-major: tap * 9 + cin)
@@ -74,7 +74,7 @@ __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, f
       const int tap = (f - L0W_F_DS) >> 2, nt = (f - L0W_F_DS) & 3;
       v = s.w_ds[((nt * 16 + l15) * 32 + l4 * 8 + j) * 3 + tap];
     }
-    img[e] = f2bf(v);
+    img[e] = f2h(v);
   }
   if (e < L0W_NPAR) {
     float v = 0.f;
@@ -116,7 +116,7 @@ __device__ __forceinline__ f32x4 l0w_sel(bool c, const f32x4 a, const f32x4 b) {
 }
 
 // LayerNorm over the 32 channels of every row of x (8 per lane, 4 lanes per row) -> bf16 B operands (two-pass statistics, as torch)
-__device__ __forceinline__ void l0w_layer_norm(const f32x4 (&x)[5][2], bf16x8 (&xn)[5], const float* g, const float* b, int l4) {
+__device__ __forceinline__ void l0w_layer_norm(const f32x4 (&x)[5][2], h16x8 (&xn)[5], const float* g, const float* b, int l4) {
   const float4 g0 = *reinterpret_cast<const float4*>(g + l4 * 4), g1 = *reinterpret_cast<const float4*>(g + 16 + l4 * 4);
   const float4 b0 = *reinterpret_cast<const float4*>(b + l4 * 4), b1 = *reinterpret_cast<const float4*>(b + 16 + l4 * 4);
 #pragma unroll
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
   for (int i = tid; i < L0W_NPAR / 4; i += NTHR) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   unsigned short* st = stg + wave * 80 * L0W_ST;
-  auto W = [&](int f) { return *reinterpret_cast<const bf16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
+  auto W = [&](int f) { return *reinterpret_cast<const h16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
   const int a = l15 >> 2, s = l15 & 3;
   const int ntiles = (p.nseq + 3) >> 2;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
     L0TS();
     // ---- ConvTokenizer: one K = 32 MFMA step over the 3 x 9 window, read straight from the feature rows (27 contiguous floats)
     {
-      const bf16x8 w0 = W(L0W_F_TOK), w1 = W(L0W_F_TOK + 1);
+      const h16x8 w0 = W(L0W_F_TOK), w1 = W(L0W_F_TOK + 1);
       const float4 b0 = *reinterpret_cast<const float4*>(par + l4 * 4), b1 = *reinterpret_cast<const float4*>(par + 16 + l4 * 4);
       // the window of step t = feature rows t-1, t, t+1 = 27 contiguous floats; lane l4 takes values 8 l4 .. +7 with two UNCONDITIONAL
       // 16-byte loads (4-byte aligned; the engine pads the feature buffer in front) and masks what lies outside the sequence afterwards
@@ -185,9 +185,9 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
         if (mt == 4) m &= (s == 3) ? ~m_tap2 : ~0u;           // t = 19: no step 20
         const f32x4 va = {(m & 1u) ? lo[0] : 0.f, (m & 2u) ? lo[1] : 0.f, (m & 4u) ? lo[2] : 0.f, (m & 8u) ? lo[3] : 0.f};
         const f32x4 vb = {(m & 16u) ? hi[0] : 0.f, (m & 32u) ? hi[1] : 0.f, (m & 64u) ? hi[2] : 0.f, (m & 128u) ? hi[3] : 0.f};
-        const bf16x8 bop = l0w_pack8(va, vb);
-        x[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, bop, Z, 0, 0, 0);
-        x[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, bop, Z, 0, 0, 0);
+        const h16x8 bop = l0w_pack8(va, vb);
+        x[mt][0] = mfma_h(w0, bop, Z, 0, 0, 0);
+        x[mt][1] = mfma_h(w1, bop, Z, 0, 0, 0);
         x[mt][0] += (f32x4){b0.x, b0.y, b0.z, b0.w};
         x[mt][1] += (f32x4){b1.x, b1.y, b1.z, b1.w};
       }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
     for (int bi = 0; bi < 2; ++bi) {
       const float* pb = par + L0W_P_BLK(bi);
       const int fb = L0W_F_BLK(bi);
-      bf16x8 xn[5];
+      h16x8 xn[5];
       // ================= attention half =================
       l0w_layer_norm(x, xn, pb + L0W_PB_LN1G, pb + L0W_PB_LN1B, l4);
       // one head at a time (rolled loop: the live set is the residual, the LayerNorm operands and ONE head's k / v): its proj contribution
@@ -205,20 +205,20 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
       // other half is zero
       float dps = 1.f;
       if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
-      const bf16x8 wp0 = W(fb + 6), wp1 = W(fb + 7);
+      const h16x8 wp0 = W(fb + 6), wp1 = W(fb + 7);
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
         f32x4 k[5], v[5];
-        const bf16x8 wq = W(fb + h);
+        const h16x8 wq = W(fb + h);
         const float4 bq = *reinterpret_cast<const float4*>(pb + L0W_PB_BQKV + h * 16 + l4 * 4);
         {
-          const bf16x8 wk = W(fb + 2 + h), wv = W(fb + 4 + h);
+          const h16x8 wk = W(fb + 2 + h), wv = W(fb + 4 + h);
           const float4 bk = *reinterpret_cast<const float4*>(pb + L0W_PB_BQKV + 32 + h * 16 + l4 * 4);
           const float4 bv = *reinterpret_cast<const float4*>(pb + L0W_PB_BQKV + 64 + h * 16 + l4 * 4);
 #pragma unroll
           for (int mt = 0; mt < 5; ++mt) {
-            k[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk, xn[mt], Z, 0, 0, 0) + (f32x4){bk.x, bk.y, bk.z, bk.w};
-            v[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xn[mt], Z, 0, 0, 0) + (f32x4){bv.x, bv.y, bv.z, bv.w};
+            k[mt] = mfma_h(wk, xn[mt], Z, 0, 0, 0) + (f32x4){bk.x, bk.y, bk.z, bk.w};
+            v[mt] = mfma_h(wv, xn[mt], Z, 0, 0, 0) + (f32x4){bv.x, bv.y, bv.z, bv.w};
           }
         }
         // 1-D neighbourhood attention, kernel 3, window start clamp(t - 1, 0, L - 3); keys of step t: (t-1, t, t+1), (0, 1, 2) at t = 0,
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
         const float* rp = pb + L0W_PB_RPB + h * 5;
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
-          const f32x4 qq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, xn[mt], Z, 0, 0, 0) + (f32x4){bq.x, bq.y, bq.z, bq.w};
+          const f32x4 qq = mfma_h(wq, xn[mt], Z, 0, 0, 0) + (f32x4){bq.x, bq.y, bq.z, bq.w};
           // neighbours at t - 1 and t + 1 (generic case)
           f32x4 km = l0w_dpp4<0x90>(k[mt]), kp = l0w_dpp4<0xF9>(k[mt]);            // quad_perm [0,0,1,2] / [1,2,3,3]
           f32x4 vm = l0w_dpp4<0x90>(v[mt]), vp = l0w_dpp4<0xF9>(v[mt]);
@@ -259,9 +259,9 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
           const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
           const f32x4 oh = {p0 * v0[0] + p1 * v1[0] + p2 * v2[0], p0 * v0[1] + p1 * v1[1] + p2 * v2[1],
                             p0 * v0[2] + p1 * v1[2] + p2 * v2[2], p0 * v0[3] + p1 * v1[3] + p2 * v2[3]};
-          const bf16x8 ao = h == 0 ? l0w_pack8(oh, Z) : l0w_pack8(Z, oh);
-          x[mt][0] += __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp0, ao, Z, 0, 0, 0) * dps;
-          x[mt][1] += __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp1, ao, Z, 0, 0, 0) * dps;
+          const h16x8 ao = h == 0 ? l0w_pack8(oh, Z) : l0w_pack8(Z, oh);
+          x[mt][0] += mfma_h(wp0, ao, Z, 0, 0, 0) * dps;
+          x[mt][1] += mfma_h(wp1, ao, Z, 0, 0, 0) * dps;
         }
       }
       {   // proj bias
@@ -280,16 +280,16 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
         for (int mt = 0; mt < 5; ++mt) { acc2[mt][0] = Z; acc2[mt][1] = Z; }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-          const bf16x8 wa = W(fb + 8 + 2 * ks), wb = W(fb + 9 + 2 * ks), u0 = W(fb + 14 + 2 * ks), u1 = W(fb + 15 + 2 * ks);
+          const h16x8 wa = W(fb + 8 + 2 * ks), wb = W(fb + 9 + 2 * ks), u0 = W(fb + 14 + 2 * ks), u1 = W(fb + 15 + 2 * ks);
           const float4 ba = *reinterpret_cast<const float4*>(pb + L0W_PB_B1 + (2 * ks) * 16 + l4 * 4);
           const float4 bb = *reinterpret_cast<const float4*>(pb + L0W_PB_B1 + (2 * ks + 1) * 16 + l4 * 4);
 #pragma unroll
           for (int mt = 0; mt < 5; ++mt) {
-            const f32x4 ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xn[mt], Z, 0, 0, 0);
-            const f32x4 hb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xn[mt], Z, 0, 0, 0);
-            const bf16x8 hop = l0w_from_u2(gelu4_pack(ha, ba), gelu4_pack(hb, bb));
-            acc2[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u0, hop, acc2[mt][0], 0, 0, 0);
-            acc2[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u1, hop, acc2[mt][1], 0, 0, 0);
+            const f32x4 ha = mfma_h(wa, xn[mt], Z, 0, 0, 0);
+            const f32x4 hb = mfma_h(wb, xn[mt], Z, 0, 0, 0);
+            const h16x8 hop = l0w_from_u2(gelu4_pack(ha, ba), gelu4_pack(hb, bb));
+            acc2[mt][0] = mfma_h(u0, hop, acc2[mt][0], 0, 0, 0);
+            acc2[mt][1] = mfma_h(u1, hop, acc2[mt][1], 0, 0, 0);
           }
         }
         const float4 b0 = *reinterpret_cast<const float4*>(pb + L0W_PB_B2 + l4 * 4), b1 = *reinterpret_cast<const float4*>(pb + L0W_PB_B2 + 16 + l4 * 4);
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
         const float4 o1 = make_float4(dw[0] * r * g1.x + b1.x, dw[1] * r * g1.y + b1.y, dw[2] * r * g1.z + b1.z, dw[3] * r * g1.w + b1.w);
         const size_t orow = ((size_t)seq * 3 + (s - 1)) * 32;
         if (p.Ocb) {
-          *reinterpret_cast<uint2*>(p.Ocb + orow + l4 * 4) = pack_bf16x4(o0.x, o0.y, o0.z, o0.w);
-          *reinterpret_cast<uint2*>(p.Ocb + orow + 16 + l4 * 4) = pack_bf16x4(o1.x, o1.y, o1.z, o1.w);
+          *reinterpret_cast<uint2*>(p.Ocb + orow + l4 * 4) = pack_h4(o0.x, o0.y, o0.z, o0.w);
+          *reinterpret_cast<uint2*>(p.Ocb + orow + 16 + l4 * 4) = pack_h4(o1.x, o1.y, o1.z, o1.w);
         } else {
           *reinterpret_cast<float4*>(p.Oc + orow + l4 * 4) = o0;
           *reinterpret_cast<float4*>(p.Oc + orow + 16 + l4 * 4) = o1;
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
 #pragma unroll
       for (int mt = 0; mt < 5; ++mt) {
         const int row = a * L + mt * 4 + s;
-        *reinterpret_cast<uint2*>(st + row * L0W_ST + l4 * 4) = pack_bf16x4(x[mt][0][0], x[mt][0][1], x[mt][0][2], x[mt][0][3]);
-        *reinterpret_cast<uint2*>(st + row * L0W_ST + 16 + l4 * 4) = pack_bf16x4(x[mt][1][0], x[mt][1][1], x[mt][1][2], x[mt][1][3]);
+        *reinterpret_cast<uint2*>(st + row * L0W_ST + l4 * 4) = pack_h4(x[mt][0][0], x[mt][0][1], x[mt][0][2], x[mt][0][3]);
+        *reinterpret_cast<uint2*>(st + row * L0W_ST + 16 + l4 * 4) = pack_h4(x[mt][1][0], x[mt][1][1], x[mt][1][2], x[mt][1][3]);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS hand-off: DS operations of a wave execute in order
       f32x4 d[3][4];
@@ -345,16 +345,16 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
         for (int nt = 0; nt < 4; ++nt) d[mt][nt] = Z;
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) {
-        bf16x8 wd[4];
+        h16x8 wd[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wd[nt] = W(L0W_F_DS + 4 * tap + nt);
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
           const int m = mt * 16 + l15, oa = m / 10, t = 2 * (m - oa * 10) - 1 + tap;
-          bf16x8 bop = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-          if (m < 40 && t >= 0 && t < L) bop = *reinterpret_cast<const bf16x8*>(st + (oa * L + t) * L0W_ST + l4 * 8);
+          h16x8 bop = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          if (m < 40 && t >= 0 && t < L) bop = *reinterpret_cast<const h16x8*>(st + (oa * L + t) * L0W_ST + l4 * 8);
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) d[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[nt], bop, d[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < 4; ++nt) d[mt][nt] = mfma_h(wd[nt], bop, d[mt][nt], 0, 0, 0);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staging tile is rewritten by this wave's next tile
@@ -388,4 +388,4 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

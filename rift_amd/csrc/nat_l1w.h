@@ -10,7 +10,7 @@
 #include "nat_l0w.h"
 #include "wp_stream.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 #define L1W_BLK_FRAGS 80        // per NATLayer: qkv (nt 0..11) x 2 k-steps | proj 4 x 2 | fc1 12 x 2 | fc2 6 k-steps x 4 n-tiles
 #define L1W_F_QKV(nt, ks) ((nt) * 2 + (ks))
@@ -60,7 +60,7 @@ __global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, f
       const int g = f - 2 * L1W_BLK_FRAGS, nt = g & 7, ks = (g >> 3) & 1, tap = g >> 4;
       v = s.w_ds[((nt * 16 + l15) * 64 + ks * 32 + l4 * 8 + j) * 3 + tap];
     }
-    img[e] = f2bf(v);
+    img[e] = f2h(v);
   }
   if (e < L1W_NPAR) {
     float v = 0.f;
@@ -92,7 +92,7 @@ struct NatL1WP {
 };
 
 // LayerNorm over the 64 channels of every row (16 per lane, 4 lanes per row) -> bf16 operands of the two k-steps
-__device__ __forceinline__ void l1w_layer_norm(const f32x4 (&x)[3][4], bf16x8 (&xn)[3][2], const float* g, const float* b, int l4) {
+__device__ __forceinline__ void l1w_layer_norm(const f32x4 (&x)[3][4], h16x8 (&xn)[3][2], const float* g, const float* b, int l4) {
   float4 gg[4], bb[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) { gg[nt] = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4); bb[nt] = *reinterpret_cast<const float4*>(b + nt * 16 + l4 * 4); }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   for (int i = tid; i < L1W_NPAR / 4; i += 512) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
   unsigned short* st = stg + wave * 40 * L1W_ST;
-  auto W = [&](int f) { return *reinterpret_cast<const bf16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
+  auto W = [&](int f) { return *reinterpret_cast<const h16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
   // workgroup-wide swap of the weight image (all waves are between phases), by LDS-DMA in runs of four fragments (wp_stream.h): the
   // copy through registers (512 threads x uint4 per pass, a global and an LDS round trip each) cost 18 us of this kernel's 118
   const uint32_t wl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
     for (int bi = 0; bi < 2; ++bi) {
       load_weights(bi * L1W_BLK_FRAGS, L1W_BLK_FRAGS);
       const float* pb = par + L1W_P_BLK(bi);
-      bf16x8 xn[3][2];
+      h16x8 xn[3][2];
       // ================= attention half =================
       l1w_layer_norm(x, xn, pb + L1W_PB_LN1G, pb + L1W_PB_LN1B, l4);
       float dps = 1.f;
@@ -172,29 +172,29 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
       for (int h = 0; h < 4; ++h) {
         f32x4 k[3], v[3];
         {
-          const bf16x8 wk0 = W(L1W_F_QKV(4 + h, 0)), wk1 = W(L1W_F_QKV(4 + h, 1)), wv0 = W(L1W_F_QKV(8 + h, 0)), wv1 = W(L1W_F_QKV(8 + h, 1));
+          const h16x8 wk0 = W(L1W_F_QKV(4 + h, 0)), wk1 = W(L1W_F_QKV(4 + h, 1)), wv0 = W(L1W_F_QKV(8 + h, 0)), wv1 = W(L1W_F_QKV(8 + h, 1));
           const float4 bk = *reinterpret_cast<const float4*>(pb + L1W_PB_BQKV + 64 + h * 16 + l4 * 4);
           const float4 bv = *reinterpret_cast<const float4*>(pb + L1W_PB_BQKV + 128 + h * 16 + l4 * 4);
 #pragma unroll
           for (int mt = 0; mt < 3; ++mt) {
-            k[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk0, xn[mt][0], Z, 0, 0, 0);
-            k[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk1, xn[mt][1], k[mt], 0, 0, 0) + (f32x4){bk.x, bk.y, bk.z, bk.w};
-            v[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv0, xn[mt][0], Z, 0, 0, 0);
-            v[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv1, xn[mt][1], v[mt], 0, 0, 0) + (f32x4){bv.x, bv.y, bv.z, bv.w};
+            k[mt] = mfma_h(wk0, xn[mt][0], Z, 0, 0, 0);
+            k[mt] = mfma_h(wk1, xn[mt][1], k[mt], 0, 0, 0) + (f32x4){bk.x, bk.y, bk.z, bk.w};
+            v[mt] = mfma_h(wv0, xn[mt][0], Z, 0, 0, 0);
+            v[mt] = mfma_h(wv1, xn[mt][1], v[mt], 0, 0, 0) + (f32x4){bv.x, bv.y, bv.z, bv.w};
           }
         }
-        const bf16x8 wq0 = W(L1W_F_QKV(h, 0)), wq1 = W(L1W_F_QKV(h, 1));
+        const h16x8 wq0 = W(L1W_F_QKV(h, 0)), wq1 = W(L1W_F_QKV(h, 1));
         const float4 bq = *reinterpret_cast<const float4*>(pb + L1W_PB_BQKV + h * 16 + l4 * 4);
         const int pks = h >> 1;                                    // proj k-step that holds this head's 16 channels (its lower / upper half)
-        bf16x8 wp[4];
+        h16x8 wp[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wp[nt] = W(L1W_F_PROJ(nt, pks));
         const float* rp = pb + L1W_PB_RPB + h * 5;
         // neighbourhood attention, kernel 3: keys of step t are (t-1, t, t+1), (0, 1, 2) at t = 0, (7, 8, 9) at t = 9 = (tile 2, quad lane 1)
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
-          f32x4 qq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq0, xn[mt][0], Z, 0, 0, 0);
-          qq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq1, xn[mt][1], qq, 0, 0, 0) + (f32x4){bq.x, bq.y, bq.z, bq.w};
+          f32x4 qq = mfma_h(wq0, xn[mt][0], Z, 0, 0, 0);
+          qq = mfma_h(wq1, xn[mt][1], qq, 0, 0, 0) + (f32x4){bq.x, bq.y, bq.z, bq.w};
           f32x4 km = l0w_dpp4<0x90>(k[mt]), kp = l0w_dpp4<0xF9>(k[mt]);
           f32x4 vm = l0w_dpp4<0x90>(v[mt]), vp = l0w_dpp4<0xF9>(v[mt]);
           if (mt > 0) { km = l0w_sel(s == 0, l0w_dpp4<0xFF>(k[mt - 1]), km); vm = l0w_sel(s == 0, l0w_dpp4<0xFF>(v[mt - 1]), vm); }
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
           const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
           const f32x4 oh = {p0 * v0[0] + p1 * v1[0] + p2 * v2[0], p0 * v0[1] + p1 * v1[1] + p2 * v2[1],
                             p0 * v0[2] + p1 * v1[2] + p2 * v2[2], p0 * v0[3] + p1 * v1[3] + p2 * v2[3]};
-          const bf16x8 ao = (h & 1) ? l0w_pack8(Z, oh) : l0w_pack8(oh, Z);
+          const h16x8 ao = (h & 1) ? l0w_pack8(Z, oh) : l0w_pack8(oh, Z);
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) x[mt][nt] += __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[nt], ao, Z, 0, 0, 0) * dps;
+          for (int nt = 0; nt < 4; ++nt) x[mt][nt] += mfma_h(wp[nt], ao, Z, 0, 0, 0) * dps;
         }
       }
 #pragma unroll
@@ -246,21 +246,21 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
           for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = Z;
 #pragma unroll 1
         for (int ks = 0; ks < 6; ++ks) {
-          const bf16x8 wa0 = W(L1W_F_FC1(2 * ks, 0)), wa1 = W(L1W_F_FC1(2 * ks, 1)), wb0 = W(L1W_F_FC1(2 * ks + 1, 0)), wb1 = W(L1W_F_FC1(2 * ks + 1, 1));
-          bf16x8 u[4];
+          const h16x8 wa0 = W(L1W_F_FC1(2 * ks, 0)), wa1 = W(L1W_F_FC1(2 * ks, 1)), wb0 = W(L1W_F_FC1(2 * ks + 1, 0)), wb1 = W(L1W_F_FC1(2 * ks + 1, 1));
+          h16x8 u[4];
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) u[nt] = W(L1W_F_FC2(ks, nt));
           const float4 ba = *reinterpret_cast<const float4*>(pb + L1W_PB_B1 + (2 * ks) * 16 + l4 * 4);
           const float4 bb = *reinterpret_cast<const float4*>(pb + L1W_PB_B1 + (2 * ks + 1) * 16 + l4 * 4);
 #pragma unroll
           for (int mt = 0; mt < 3; ++mt) {
-            f32x4 ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa0, xn[mt][0], Z, 0, 0, 0);
-            ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1, xn[mt][1], ha, 0, 0, 0);
-            f32x4 hb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0, xn[mt][0], Z, 0, 0, 0);
-            hb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1, xn[mt][1], hb, 0, 0, 0);
-            const bf16x8 hop = l0w_from_u2(gelu4_pack(ha, ba), gelu4_pack(hb, bb));
+            f32x4 ha = mfma_h(wa0, xn[mt][0], Z, 0, 0, 0);
+            ha = mfma_h(wa1, xn[mt][1], ha, 0, 0, 0);
+            f32x4 hb = mfma_h(wb0, xn[mt][0], Z, 0, 0, 0);
+            hb = mfma_h(wb1, xn[mt][1], hb, 0, 0, 0);
+            const h16x8 hop = l0w_from_u2(gelu4_pack(ha, ba), gelu4_pack(hb, bb));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[nt], hop, acc2[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = mfma_h(u[nt], hop, acc2[mt][nt], 0, 0, 0);
           }
         }
         float dp2 = 1.f;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
           for (int nt = 0; nt < 4; ++nt) {
             const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 64 + nt * 16 + l4 * 4);
             const float4 o = make_float4(d[nt][0] * r * gg.x + bb.x, d[nt][1] * r * gg.y + bb.y, d[nt][2] * r * gg.z + bb.z, d[nt][3] * r * gg.w + bb.w);
-            if (p.Ocb) *reinterpret_cast<uint2*>(p.Ocb + orow + nt * 16 + l4 * 4) = pack_bf16x4(o.x, o.y, o.z, o.w);
+            if (p.Ocb) *reinterpret_cast<uint2*>(p.Ocb + orow + nt * 16 + l4 * 4) = pack_h4(o.x, o.y, o.z, o.w);
             else *reinterpret_cast<float4*>(p.Oc + orow + nt * 16 + l4 * 4) = o;
           }
         }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
         if (t < L) {
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
-            *reinterpret_cast<uint2*>(st + (a * L + t) * L1W_ST + nt * 16 + l4 * 4) = pack_bf16x4(x[mt][nt][0], x[mt][nt][1], x[mt][nt][2], x[mt][nt][3]);
+            *reinterpret_cast<uint2*>(st + (a * L + t) * L1W_ST + nt * 16 + l4 * 4) = pack_h4(x[mt][nt][0], x[mt][nt][1], x[mt][nt][2], x[mt][nt][3]);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -324,16 +324,16 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
 #pragma unroll 1
       for (int tk = 0; tk < 6; ++tk) {                       // (tap, k-step)
         const int tap = tk >> 1, ks = tk & 1;
-        bf16x8 wd[8];
+        h16x8 wd[8];
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) wd[nt] = W(tk * 8 + nt);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const int m = mt * 16 + l15, oa = m / 5, t = 2 * (m - oa * 5) - 1 + tap;
-          bf16x8 bop = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-          if (m < 20 && t >= 0 && t < L) bop = *reinterpret_cast<const bf16x8*>(st + (oa * L + t) * L1W_ST + ks * 32 + l4 * 8);
+          h16x8 bop = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          if (m < 20 && t >= 0 && t < L) bop = *reinterpret_cast<const h16x8*>(st + (oa * L + t) * L1W_ST + ks * 32 + l4 * 8);
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt) d[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[nt], bop, d[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < 8; ++nt) d[mt][nt] = mfma_h(wd[nt], bop, d[mt][nt], 0, 0, 0);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -366,4 +366,4 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace rift {
+#include "opfmt.h"
+
+namespace RIFT_NS {
 
 #define L2W_GROUPS 10                           // per NATLayer: q | k | v | proj | (fc1 chunk c, fc2 k-range c) x 3
 #define L2W_BLK_FRAGS (L2W_GROUPS * 32)
@@ -43,4 +45,4 @@ int l2w_set_attributes();
 void l2w_pack(const NatL2WSrc& src, unsigned short* img, float* par, hipStream_t stream);
 void l2w_launch(const NatL2WP& p, int grid, hipStream_t stream);
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -3,7 +3,7 @@
 #include "nat_l2w.h"
 #include "wp_stream.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 // Weight image: [block][group][fragment f = ks * 8 + nt][lane][8] with the K permutation of nat_l0w.h.  natten's qkv rows are (3, H, 16):
 // q of head h = rows h*16.., k = 128 + ..., v = 256 + ...; q carries head_dim^-0.5 log2 e.
@@ -22,7 +22,7 @@ __global__ void pack_l2w_kernel(NatL2WSrc s, unsigned short* __restrict__ img, f
       const int c = (g - 4) >> 1;
       v = ((g - 4) & 1) ? k.w2[o * 384 + c * 128 + ch] : k.w1[(c * 128 + o) * 128 + ch];
     }
-    img[e] = f2bf(v);
+    img[e] = f2h(v);
   }
   if (e < L2W_NPAR) {
     float v = 0.f;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     request(s + 2);
   };
   auto slot_off = [&](int s) -> uint32_t { return (uint32_t)(s % 3) * 32768u; };
-  auto gemm = [&](uint32_t so, const bf16x8 (&x)[4], f32x4 (&acc)[8]) { decw_gemm<false>((uint32_t)(uintptr_t)ring + so + voff, x, acc); };
+  auto gemm = [&](uint32_t so, const h16x8 (&x)[4], f32x4 (&acc)[8]) { decw_gemm<false>((uint32_t)(uintptr_t)ring + so + voff, x, acc); };
 
   for (int i = tid; i < L2W_NPAR / 4; i += 512) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
   request(0);
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) { const float4 v = *reinterpret_cast<const float4*>(bias + nt * 16 + l4 * 4); a[nt] = (f32x4){v.x, v.y, v.z, v.w}; }
   };
-  auto layer_norm = [&](const f32x4 (&res)[8], bf16x8 (&xb)[4], const float* g) {
+  auto layer_norm = [&](const f32x4 (&res)[8], h16x8 (&xb)[4], const float* g) {
     f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
     s4 += (res[4] + res[5]) + (res[6] + res[7]);
     const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int bi = 0; bi < 2; ++bi) {
       const float* pb = par + L2W_P_BLK(bi);
       f32x4 acc[8];
-      bf16x8 xb[4], qf[4], kp[4], ao[4], vf[8];
+      h16x8 xb[4], qf[4], kp[4], ao[4], vf[8];
       float dps = 1.f, dp2 = 1.f;
       if (p.droppath[bi] > 0.f) {
         dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int nt = 0; nt < 8; ++nt) { const float bv = pb[L2W_PB_BQKV + 256 + nt * 16 + l15]; av[nt] = (f32x4){bv, bv, bv, bv}; }
         boundary(s); decw_gemm<true>((uint32_t)(uintptr_t)ring + slot_off(s) + voff, xb, av); ++s;
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_bf16x4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]), make_uint2(0u, 0u));
+        for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_h4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]), make_uint2(0u, 0u));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -180,14 +180,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int i = 0; i < 4; ++i) mb[i] = ridx[i] >= 0 ? pb[L2W_PB_RPB + h * 9 + ridx[i]] : -INFINITY;
           // head h's 16 dims are one half of the k-step: the other half of the K operand is zero
-          bf16x8 kh = kp[j];
+          h16x8 kh = kp[j];
           if (u == 0) { kh[4] = 0; kh[5] = 0; kh[6] = 0; kh[7] = 0; } else { kh[0] = 0; kh[1] = 0; kh[2] = 0; kh[3] = 0; }
-          const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qf[j], mb, 0, 0, 0);
+          const f32x4 sc = mfma_h(kh, qf[j], mb, 0, 0, 0);
           const float m = rows_max(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
           const f32x4 ev = {__builtin_amdgcn_exp2f(sc[0] - m), __builtin_amdgcn_exp2f(sc[1] - m), __builtin_amdgcn_exp2f(sc[2] - m), __builtin_amdgcn_exp2f(sc[3] - m)};
           const float inv = __builtin_amdgcn_rcpf(rows_sum((ev[0] + ev[1]) + (ev[2] + ev[3])));
-          const bf16x8 pf = l0w_from_u2(pack_bf16x4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
-          o[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[h], pf, Z, 0, 0, 0) * inv;
+          const h16x8 pf = l0w_from_u2(pack_h4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
+          o[u] = mfma_h(vf[h], pf, Z, 0, 0, 0) * inv;
         }
         ao[j] = l0w_pack8(o[0], o[1]);
       }
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) acc[nt] = Z;
         gemm(slot_off(s), xb, acc); ++s;
-        bf16x8 hb[4];
+        h16x8 hb[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const float4 ba = *reinterpret_cast<const float4*>(pb + L2W_PB_B1 + c * 128 + (2 * ks) * 16 + l4 * 4);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int nt = 0; nt < 8; ++nt) {
           const float4 gg = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4), bb = *reinterpret_cast<const float4*>(g + 128 + nt * 16 + l4 * 4);
           const float4 o = make_float4(d[nt][0] * r * gg.x + bb.x, d[nt][1] * r * gg.y + bb.y, d[nt][2] * r * gg.z + bb.z, d[nt][3] * r * gg.w + bb.w);
-          if (p.Ocb) *reinterpret_cast<uint2*>(p.Ocb + orow + nt * 16 + l4 * 4) = pack_bf16x4(o.x, o.y, o.z, o.w);
+          if (p.Ocb) *reinterpret_cast<uint2*>(p.Ocb + orow + nt * 16 + l4 * 4) = pack_h4(o.x, o.y, o.z, o.w);
           else *reinterpret_cast<float4*>(p.Oc + orow + nt * 16 + l4 * 4) = o;
         }
       }
@@ -255,4 +255,4 @@ void l2w_launch(const NatL2WP& p, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(nat_l2w_kernel, dim3(grid), dim3(512), (size_t)L2W_LDS, stream, p);
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -1,0 +1,24 @@
+// Build parameter of the engine: the 16-bit MFMA operand format and the namespace its kernels live in.
+#pragma once
+
+// ---- the 16-bit MFMA operand format is a BUILD parameter ------------------------------------------------------------------
+// Every fused kernel multiplies 16-bit operands with fp32 accumulation (v_mfma_f32_16x16x32_{bf16,f16}: same rate, same bytes).  The
+// library carries two builds of the whole engine, one per format, and a context selects one at creation (abi.cpp):
+//   RIFT_OP_F16 = 0 : bf16 operands (8 significand bits)  -- BASELINE's "bf16 MFMA", the benchmarked default
+//   RIFT_OP_F16 = 1 : fp16 operands (11 significand bits) -- the mode that holds north_star's 1e-4 on losses / advantages with the same
+//                     instruction count; range 6e-8 .. 65504 is enough for what the operands are here (post-LayerNorm / post-BatchNorm
+//                     activations, attention probabilities, metre-scale geometry, |weights| < 10); an overflow becomes inf and is
+//                     reported by the non-finite flag (rift_check_finite).
+// "h16" below means "the build's 16-bit operand format"; weight images, LDS tiles and hand-over buffers hold it as raw 16-bit words.
+#ifndef RIFT_OP_F16
+#define RIFT_OP_F16 0
+#endif
+#if RIFT_OP_F16
+#define RIFT_NS rift_hf
+#define RIFT_MFMA_H_ASM "v_mfma_f32_16x16x32_f16"
+#define RIFT_CVT_PK_H_ASM "v_cvt_pk_f16_f32"
+#else
+#define RIFT_NS rift_bf
+#define RIFT_MFMA_H_ASM "v_mfma_f32_16x16x32_bf16"
+#define RIFT_CVT_PK_H_ASM "v_cvt_pk_bf16_f32"
+#endif

@@ -19,7 +19,7 @@
 #include <hip/hip_fp16.h>
 #include "common.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 struct PeP {
   const float* F; int Cin;              // (rows, Cin) fp32 point features, Cin <= 32
@@ -41,7 +41,7 @@ struct PeP {
 };
 
 template <int KS, int NTW>
-struct PFrags { bf16x8 f[KS][NTW]; };
+struct PFrags { h16x8 f[KS][NTW]; };
 
 // weight fragments of n-tiles (j * NW + wave), j < NTW, k in [k0, k0 + 32 KS)
 template <int NW, int KS, int NTW>
@@ -59,13 +59,13 @@ __device__ __forceinline__ void p_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
                                       int l15, int l4) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    bf16x8 a[MT];
+    h16x8 a[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + l15) * lda + k0 + ks * 32 + l4 * 8);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const h16x8*>(A + (mt * 16 + l15) * lda + k0 + ks * 32 + l4 * 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+      for (int j = 0; j < NTW; ++j) acc[mt][j] = mfma_h(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
   }
 }
 
@@ -103,7 +103,7 @@ __device__ __forceinline__ int pe_stage_x(const PeP& p, int tile, unsigned short
   }
   if (tid < PE_ROWS) sval[tid] = fl;
 #pragma unroll
-  for (int u = 0; u < NX; ++u) { const int i = tid + u * NT; xin[(i >> 5) * PE_XS + (i & 31)] = f2bf(xv[u]); }
+  for (int u = 0; u < NX; ++u) { const int i = tid + u * NT; xin[(i >> 5) * PE_XS + (i & 31)] = f2h(xv[u]); }
   return __syncthreads_count(fl == 1);   // also the barrier after staging
 }
 
@@ -209,7 +209,7 @@ __device__ __forceinline__ void pe_stats1p_body(const PeP& p, const int wg, cons
       const int i = tid + u * 256;
       if (i < PE_USED * Cin) {
         const int r = (int)(((float)i + 0.5f) * rcin), k = i - r * Cin;
-        xin[r * PE_XS + k] = f2bf(xv[u]);
+        xin[r * PE_XS + k] = f2h(xv[u]);
       }
     }
     const int nv = __syncthreads_count(fl == 1);                  // (the barrier also publishes b1s the first time)
@@ -324,7 +324,7 @@ __device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       *reinterpret_cast<uint2*>(h1 + (mt * 16 + l15) * PE_HS + col) =
-          pack_bf16x4(fmaxf((acc[mt][0][0] + b.x) * s.x + t.x, 0.f), fmaxf((acc[mt][0][1] + b.y) * s.y + t.y, 0.f),
+          pack_h4(fmaxf((acc[mt][0][0] + b.x) * s.x + t.x, 0.f), fmaxf((acc[mt][0][1] + b.y) * s.y + t.y, 0.f),
                       fmaxf((acc[mt][0][2] + b.z) * s.z + t.z, 0.f), fmaxf((acc[mt][0][3] + b.w) * s.w + t.w, 0.f));
   }
   __syncthreads();
@@ -346,7 +346,7 @@ __device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
         const int row = mt * 16 + l15;
         const bool ok = sval[row] == 1;
         *reinterpret_cast<uint2*>(fl + row * PE_FS + col) =
-            ok ? pack_bf16x4(acc[mt][j][0] + b.x, acc[mt][j][1] + b.y, acc[mt][j][2] + b.z, acc[mt][j][3] + b.w) : make_uint2(0u, 0u);
+            ok ? pack_h4(acc[mt][j][0] + b.x, acc[mt][j][1] + b.y, acc[mt][j][2] + b.z, acc[mt][j][3] + b.w) : make_uint2(0u, 0u);
       }
     }
   }
@@ -361,8 +361,8 @@ __device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
       float m0 = -INFINITY, m1 = -INFINITY;
       for (int r = r0; r < r0 + RPU; ++r) {
         const unsigned int v = *reinterpret_cast<const unsigned int*>(fl + r * PE_FS + cp);
-        m0 = fmaxf(m0, __uint_as_float(v << 16));
-        m1 = fmaxf(m1, __uint_as_float(v & 0xffff0000u));
+        m0 = fmaxf(m0, h_lo(v));
+        m1 = fmaxf(m1, h_hi(v));
       }
       gpl[u * 256 + cp] = m0; gpl[u * 256 + cp + 1] = m1;
     }
@@ -374,7 +374,7 @@ __device__ __forceinline__ void pe_mid_body(const PeP& p, const int tile) {
       float m = gpl[g * SPL * 256 + tid];
 #pragma unroll
       for (int s = 1; s < SPL; ++s) m = fmaxf(m, gpl[(g * SPL + s) * 256 + tid]);
-      pool[g * PE_FS + tid] = (unsigned short)(__float_as_uint(m) >> 16);   // already a bf16 value
+      pool[g * PE_FS + tid] = (unsigned short)(h_pair_exact(m, 0.f) & 0xffffu);   // already an operand-format value
     }
   }
   __syncthreads();
@@ -504,10 +504,10 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
       const float4 s0 = *reinterpret_cast<const float4*>(par + P_S2 + c8), s1 = *reinterpret_cast<const float4*>(par + P_S2 + c8 + 4);
       const float4 t0 = *reinterpret_cast<const float4*>(par + P_T2 + c8), t1 = *reinterpret_cast<const float4*>(par + P_T2 + c8 + 4);
       uint4 o;
-      o.x = pack_bf16x2(fmaxf(x[0] * s0.x + t0.x, 0.f), fmaxf(x[1] * s0.y + t0.y, 0.f));
-      o.y = pack_bf16x2(fmaxf(x[2] * s0.z + t0.z, 0.f), fmaxf(x[3] * s0.w + t0.w, 0.f));
-      o.z = pack_bf16x2(fmaxf(x[4] * s1.x + t1.x, 0.f), fmaxf(x[5] * s1.y + t1.y, 0.f));
-      o.w = pack_bf16x2(fmaxf(x[6] * s1.z + t1.z, 0.f), fmaxf(x[7] * s1.w + t1.w, 0.f));
+      o.x = pack_h2(fmaxf(x[0] * s0.x + t0.x, 0.f), fmaxf(x[1] * s0.y + t0.y, 0.f));
+      o.y = pack_h2(fmaxf(x[2] * s0.z + t0.z, 0.f), fmaxf(x[3] * s0.w + t0.w, 0.f));
+      o.z = pack_h2(fmaxf(x[4] * s1.x + t1.x, 0.f), fmaxf(x[5] * s1.y + t1.y, 0.f));
+      o.w = pack_h2(fmaxf(x[6] * s1.z + t1.z, 0.f), fmaxf(x[7] * s1.w + t1.w, 0.f));
       *reinterpret_cast<uint4*>(fl + r * PE_GS + c8) = o;     // (rows that do not exist carry relu(t2): masked below)
     }
   }
@@ -630,4 +630,4 @@ __global__ __launch_bounds__(256) void bn_finalize_t_kernel(BnFinP a, BnFinP b, 
   else bn_finalize_t_body(b, train, update_running, eps, blockIdx.x - a.C);
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -18,7 +18,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace rift {
+#include "opfmt.h"
+
+namespace RIFT_NS {
 
 #define PEW_FRAGS 200                     // per encoder: W1 8 | W2 2 x 32 | W3a 4 x 32 fragments, consumption order
 #define PEW_ROUND_ROWS 240
@@ -52,4 +54,4 @@ void pew_pack(const PeWSrc& src, unsigned short* img, hipStream_t stream);
 void pew_split(int ra, int rb, int* grid, int* ga);        // grid = persistent workgroups (<= *grid, one per CU): [0, ga) for a's rounds, the rest for b's
 void pew_launch(const PeWP& p, int grid, hipStream_t stream);
 
-}  // namespace rift
+}  // namespace RIFT_NS

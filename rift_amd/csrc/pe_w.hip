@@ -6,7 +6,7 @@
 #include "pe_w_gemm.h"
 #include <type_traits>
 
-namespace rift {
+namespace RIFT_NS {
 
 // Weight image: PEW_FRAGS one-KiB fragments [lane][8] in consumption order.
 //   W1  (fragments 0..7):   n-tile fr; element j of lane quarter l4 = feature k = 4 j + l4 (j < 3, k < Cin <= 12; the rest zero), so that
@@ -30,12 +30,9 @@ __global__ void pack_pew_kernel(PeWSrc s, unsigned short* __restrict__ img) {
     const int o = 64 * q + 16 * (l15 >> 2) + 4 * jn + (l15 & 3);
     v = s.w3[o * 512 + l0w_chan(l4, j, 2 * ks)];
   }
-  img[e] = f2bf(v);
+  img[e] = f2h(v);
 }
 
-__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint32_t bf_pair(float lo, float hi) { return (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16); }   // exact bf16 values in
 
 // sum over the 16 lanes of a row of eight values at once: one fused v_add_f32_dpp per value and step (hipcc's own lowering of the same
 // reduction was v_mov_b32_dpp + v_pk_add_f32: 1.5 instructions per value and step).  The four steps of a value are 8 instructions apart
@@ -80,6 +77,7 @@ __device__ __forceinline__ void pew_sum16x8(float (&v)[8]) {
 }
 
 // One encoder's rounds ri = wg, wg + G, ...
+template <bool map20>   // 20 points per polyline (map polygons) or 120 (reference lines)
 __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, const int wg, const int G) {
   const PeWSide* sp = &s0;
 #define s (*sp)
@@ -101,13 +99,20 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   // transposition read-back: dword `lane` of a scratch row = elements 2 (lane & 3), +1 of the operand fragment (pair lane >> 4, quarter (lane >> 2) & 3)
   const int pch = ((2 * (lane >> 4) + ((lane & 3) >> 1)) * 16 + 4 * ((lane >> 2) & 3) + 2 * (lane & 1)) >> 1;     // its channel pair within the half
   const int R = s.nrounds, Cin = s.Cin, nt120 = (s.rows + 119) / 120;
-  const bool map20 = s.npts == 20;            // 20 points per polyline (map polygons) or 120 (reference lines)
-  const int NPTS = map20 ? 20 : 120;
-  auto pdiv = [&](int x) { return map20 ? x / 20 : x / 120; };
+  constexpr int NPTS = map20 ? 20 : 120;
+  auto pdiv = [&](int x) { return x / NPTS; };
   const unsigned char* img = reinterpret_cast<const unsigned char*>(s.img);
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
+#if RIFT_PEW_DIAG
   int tsn = 0;
+#endif
+#if RIFT_PEW_DIAG
 #define PWTS() do { if (p.ts && blockIdx.x == 0 && tid == 0 && tsn < 120) p.ts[tsn++] = clock64(); } while (0)
+#define PWDBG(bit) (p.dbg & (bit))
+#else
+#define PWTS() do { } while (0)
+#define PWDBG(bit) 0
+#endif
 
   auto empty = [&](int ri) -> bool {
     if (!s.cnt) return false;
@@ -120,7 +125,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     return ri;
   };
   auto dma = [&](const unsigned char* src, uint32_t dst, int nfrag) {
-    if (p.dbg & 2) return;                     // (diagnostic: no weight stream -- compute on whatever the ring holds)
+    if (PWDBG(2)) return;                     // (diagnostic: no weight stream -- compute on whatever the ring holds)
     decw_dma_share(src, voff, lds0 + dst, nfrag, wv, 8);
   };
   auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); PWTS(); };
@@ -130,7 +135,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   float stat_acc = 0.f;
   int cnt_acc = 0;
   auto finish_stats = [&]() {
-    if (!p.do_stats || (p.dbg & 4)) return;    // (diagnostic 4: no statistics)
+    if (!p.do_stats || PWDBG(4)) return;    // (diagnostic 4: no statistics)
 #pragma unroll
     for (int w = 0; w < 8; ++w) stat_acc += *reinterpret_cast<const float*>(smem_raw + OFF_SCR + w * SCR_W + tid * 4);
     if (tid < 8) cnt_acc += *reinterpret_cast<const int*>(smem_raw + OFF_SCR + tid * SCR_W + 2048);
@@ -168,13 +173,13 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     else v = s.b3[i - 512];
     par[i] = v;
   }
-  auto to_operand = [&](const float (&xv)[2][3], bf16x8 (&xb)[2]) {
+  auto to_operand = [&](const float (&xv)[2][3], h16x8 (&xb)[2]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
-      xb[mt] = l0w_from_u2(make_uint2(pack_bf16x2(xv[mt][0], xv[mt][1]), pack_bf16x2(xv[mt][2], 0.f)), make_uint2(0u, 0u));
+      xb[mt] = l0w_from_u2(make_uint2(pack_h2(xv[mt][0], xv[mt][1]), pack_h2(xv[mt][2], 0.f)), make_uint2(0u, 0u));
   };
   unsigned vb[2];
-  bf16x8 xb[2];
+  h16x8 xb[2];
   {
     float xv[2][3];
     load_rows(ri, vb, xv);
@@ -186,7 +191,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   bool hex[2] = {false, false};               // rows of the held tiles exist
   int hrow0 = 0;
   auto store_hold = [&](int q) {
-    if (p.dbg & 1) return;                     // (diagnostic: no g stores)
+    if (PWDBG(1)) return;                     // (diagnostic: no g stores)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       if (hex[mt]) {
@@ -229,7 +234,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       if (k < 6) dma(img + (8 + 32 * k) * 1024, ((gc + 1) & 1) * 32768u, 32);
       else if (nri < R) dma(img, ((gc + 1) & 1) * 32768u, 8);
     };
-    auto load_wb = [&](bf16x8 (&wb)[16], int k0, int k1) {       // W3b fragments of this wave's gp columns (n-tiles 2 wv, 2 wv + 1), straight from L2
+    auto load_wb = [&](h16x8 (&wb)[16], int k0, int k1) {       // W3b fragments of this wave's gp columns (n-tiles 2 wv, 2 wv + 1), straight from L2
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -237,7 +242,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
           if (ks >= k0 && ks < k1) wb[u * 8 + ks] = fm_load(s.w3b, 256, (2 * wv + u) * 16, ks * 32, lane);
     };
     // partial maxima -> pooled operand; gp = pooled W3b^T + b3 of the round's polylines -> gpt (every wave: 32 of the 256 columns)
-    auto pooled_gp = [&](const bf16x8 (&wb)[16]) {
+    auto pooled_gp = [&](const h16x8 (&wb)[16]) {
       const int npoly = pdiv(nex);                                   // polylines of this round that exist (whole ones)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {                                // wave wv: polylines 2 wv, 2 wv + 1 (uniform tile loop); a lane: channel pairs lane, lane + 64
@@ -249,11 +254,11 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
           for (int T = r0 >> 4; T <= T1; ++T) {                    // a tile that starts ahead of the polyline holds it as its second segment
             const uint32_t* src = pmax + (T * 2 + (16 * T < r0 ? 1 : 0)) * 128;
             const uint32_t w0 = src[lane], w1 = src[lane + 64];
-            a0 = fmaxf(a0, bf_lo(w0)); b0 = fmaxf(b0, bf_hi(w0)); a1 = fmaxf(a1, bf_lo(w1)); b1 = fmaxf(b1, bf_hi(w1));
+            a0 = fmaxf(a0, h_lo(w0)); b0 = fmaxf(b0, h_hi(w0)); a1 = fmaxf(a1, h_lo(w1)); b1 = fmaxf(b1, h_hi(w1));
           }
         }
-        reinterpret_cast<uint32_t*>(pool)[pl * (PLS / 2) + lane] = bf_pair(a0, b0);
-        reinterpret_cast<uint32_t*>(pool)[pl * (PLS / 2) + lane + 64] = bf_pair(a1, b1);
+        reinterpret_cast<uint32_t*>(pool)[pl * (PLS / 2) + lane] = h_pair_exact(a0, b0);
+        reinterpret_cast<uint32_t*>(pool)[pl * (PLS / 2) + lane + 64] = h_pair_exact(a1, b1);
       }
       lds_barrier();                   // (not __syncthreads: that would also wait for the group just requested)
       f32x4 ga[2];
@@ -264,9 +269,9 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 pb = *reinterpret_cast<const bf16x8*>(pool + l15 * PLS + ks * 32 + l4 * 8);
+        const h16x8 pb = *reinterpret_cast<const h16x8*>(pool + l15 * PLS + ks * 32 + l4 * 8);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) ga[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u * 8 + ks], pb, ga[u], 0, 0, 0);
+        for (int u = 0; u < 2; ++u) ga[u] = mfma_h(wb[u * 8 + ks], pb, ga[u], 0, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(gpt + l15 * GPS + (2 * wv + u) * 16 + l4 * 4) = make_float4(ga[u][0], ga[u][1], ga[u][2], ga[u][3]);
@@ -282,8 +287,8 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       float ba[4], bb[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        ba[k] = fmaxf(fmaxf(bf_lo(w[4 * k]), bf_lo(w[4 * k + 1])), fmaxf(bf_lo(w[4 * k + 2]), bf_lo(w[4 * k + 3])));
-        bb[k] = fmaxf(fmaxf(bf_hi(w[4 * k]), bf_hi(w[4 * k + 1])), fmaxf(bf_hi(w[4 * k + 2]), bf_hi(w[4 * k + 3])));
+        ba[k] = fmaxf(fmaxf(h_lo(w[4 * k]), h_lo(w[4 * k + 1])), fmaxf(h_lo(w[4 * k + 2]), h_lo(w[4 * k + 3])));
+        bb[k] = fmaxf(fmaxf(h_hi(w[4 * k]), h_hi(w[4 * k + 1])), fmaxf(h_hi(w[4 * k + 2]), h_hi(w[4 * k + 3])));
       }
       float m0a = ba[0], m0b = bb[0], m1a = -INFINITY, m1b = -INFINITY;
 #pragma unroll
@@ -291,8 +296,8 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
         if (4 * k < B) { m0a = fmaxf(m0a, ba[k]); m0b = fmaxf(m0b, bb[k]); }
         else { m1a = fmaxf(m1a, ba[k]); m1b = fmaxf(m1b, bb[k]); }
       }
-      pmax[(T * 2 + 0) * 128 + 64 * h + pch] = bf_pair(m0a, m0b);
-      pmax[(T * 2 + 1) * 128 + 64 * h + pch] = bf_pair(m1a, m1b);
+      pmax[(T * 2 + 0) * 128 + 64 * h + pch] = h_pair_exact(m0a, m0b);
+      pmax[(T * 2 + 1) * 128 + 64 * h + pch] = h_pair_exact(m1a, m1b);
     };
 
     if (wact) {
@@ -300,14 +305,14 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       boundary(0, [&] { if (prev_ri >= 0) finish_stats(); if (pend) { store_hold(3); pend = false; } });
       PWTS();
       PWTS();
-      bf16x8 hb[2][4];
+      h16x8 hb[2][4];
       {
         f32x4 acc[2][8];
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
-          const bf16x8 w = *reinterpret_cast<const bf16x8*>(ring + (gc & 1) * 32768 + nt * 1024 + lane * 16);
+          const h16x8 w = *reinterpret_cast<const h16x8*>(ring + (gc & 1) * 32768 + nt * 1024 + lane * 16);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb[mt], Z, 0, 0, 0);
+          for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma_h(w, xb[mt], Z, 0, 0, 0);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -333,8 +338,8 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       ++gc;
 
       // ---- groups 1, 2: f = h1 W2^T + b2 (invalid rows zero) as the k-steps of W3a; per-(tile, segment) maxima of the bf16 values
-      bf16x8 fb[2][8];
-      bf16x8 wb[16];
+      h16x8 fb[2][8];
+      h16x8 wb[16];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         boundary(1 + h, nothing);
@@ -352,7 +357,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const f32x4 a = mt ? c1[2 * q] : c0[2 * q], b = mt ? c1[2 * q + 1] : c0[2 * q + 1];
-              uint2 w0 = pack_bf16x4(a[0], a[1], a[2], a[3]), w1 = pack_bf16x4(b[0], b[1], b[2], b[3]);
+              uint2 w0 = pack_h4(a[0], a[1], a[2], a[3]), w1 = pack_h4(b[0], b[1], b[2], b[3]);
               if (!ok) { w0 = make_uint2(0u, 0u); w1 = w0; }
               fb[mt][4 * h + q] = l0w_from_u2(w0, w1);
             }
@@ -363,7 +368,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)          // n-tiles 2 q (elements 0..3) and 2 q + 1 (elements 4..7) of this half, row l15
-            *reinterpret_cast<bf16x8*>(scr + l15 * TRS + q * 64 + l4 * 16) = fb[mt][4 * h + q];
+            *reinterpret_cast<h16x8*>(scr + l15 * TRS + q * 64 + l4 * 16) = fb[mt][4 * h + q];
           // rows in-lane: lane t owns two channels of the 16 rows just written (same wave: LDS operations stay in order)
           tile_max(2 * wv + mt, h);
         }
@@ -437,13 +442,13 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
         const int ext = max(0, min(16, nex - 16 * T)), B = min(16, (pdiv(16 * T) + 1) * NPTS - 16 * T);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          pmax[(T * 2 + 0) * 128 + 64 * u + lane] = ext > 0 ? 0u : 0xff80ff80u;
-          pmax[(T * 2 + 1) * 128 + 64 * u + lane] = ext > B ? 0u : 0xff80ff80u;
+          pmax[(T * 2 + 0) * 128 + 64 * u + lane] = ext > 0 ? 0u : RIFT_H_NEG_INF2;
+          pmax[(T * 2 + 1) * 128 + 64 * u + lane] = ext > B ? 0u : RIFT_H_NEG_INF2;
         }
       }
       ++gc;
       boundary(2, nothing);
-      bf16x8 wb[16];
+      h16x8 wb[16];
       load_wb(wb, 0, 8);
       ++gc;
       boundary(3, nothing);
@@ -476,13 +481,14 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     if (tid == 0) s.cnt2[wg] = n;
   }
 #undef PWTS
+#undef PWDBG
 #undef s
 }
 
 // workgroups [0, ga) walk the map encoder's rounds, the others the reference-line encoder's
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pe_w_kernel(PeWP p) {
-  const bool sa = (int)blockIdx.x < p.ga;
-  pe_w_body(sa ? p.a : p.b, p, sa ? blockIdx.x : blockIdx.x - p.ga, sa ? p.ga : gridDim.x - p.ga);
+  if ((int)blockIdx.x < p.ga) pe_w_body<true>(p.a, p, blockIdx.x, p.ga);
+  else pe_w_body<false>(p.b, p, blockIdx.x - p.ga, gridDim.x - p.ga);
 }
 
 int pew_set_attributes() {
@@ -508,4 +514,4 @@ void pew_launch(const PeWP& p, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(pe_w_kernel, dim3(grid), dim3(512), PEW_LDS_BYTES, stream, p);
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

@@ -9,7 +9,7 @@
 #include "common.h"
 #include "pe_fused.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 struct PiFwdP {
   const float* Q; int rows, rows_per_scene;      // (rows, 128) decoder output
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void pi_forward_kernel(PiFwdP p) {
       if (row0 + r < p.rows) qv[u] = *reinterpret_cast<const float4*>(p.Q + (size_t)(row0 + r) * 128 + c4);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int i = tid + u * 512; *reinterpret_cast<uint2*>(qb + (i >> 5) * PI_QS + (i & 31) * 4) = pack_bf16x4(qv[u].x, qv[u].y, qv[u].z, qv[u].w); }
+    for (int u = 0; u < 8; ++u) { const int i = tid + u * 512; *reinterpret_cast<uint2*>(qb + (i >> 5) * PI_QS + (i & 31) * 4) = pack_h4(qv[u].x, qv[u].y, qv[u].z, qv[u].w); }
   }
   __syncthreads();
   {   // ---- q_final = q Wq^T + b + x0p[scene]
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void q0_fused_kernel(Q0P p) {
     const int r = tid >> 4, c8 = (tid & 15) * 8;         // 16 rows x 16 lanes x 8 floats
     float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
     if (l0 + r < p.nL) { v0 = *reinterpret_cast<const float4*>(p.r_emb + (size_t)(l0 + r) * 128 + c8); v1 = *reinterpret_cast<const float4*>(p.r_emb + (size_t)(l0 + r) * 128 + c8 + 4); }
-    uint4 o; o.x = pack_bf16x2(v0.x, v0.y); o.y = pack_bf16x2(v0.z, v0.w); o.z = pack_bf16x2(v1.x, v1.y); o.w = pack_bf16x2(v1.z, v1.w);
+    uint4 o; o.x = pack_h2(v0.x, v0.y); o.y = pack_h2(v0.z, v0.w); o.z = pack_h2(v1.x, v1.y); o.w = pack_h2(v1.z, v1.w);
     *reinterpret_cast<uint4*>(xb + r * 136 + c8) = o;
   }
   __syncthreads();
@@ -183,4 +183,4 @@ __global__ __launch_bounds__(256) void q0_fused_kernel(Q0P p) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

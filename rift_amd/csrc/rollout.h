@@ -7,7 +7,7 @@
 #pragma once
 #include "common.h"
 
-namespace rift {
+namespace RIFT_NS {
 
 // ---- reference-line deviation: one thread per (candidate, frame), ragged reference lines ----
 __global__ void ref_line_info_kernel(const float* __restrict__ traj /*(G,Tfull,6)*/, int G, int Tfull, int Ts, int M,
@@ -215,4 +215,4 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutP p) {
   }
 }
 
-}  // namespace rift
+}  // namespace RIFT_NS

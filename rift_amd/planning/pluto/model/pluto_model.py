@@ -240,7 +240,9 @@ class PlanningModel(TorchModuleWrapper):
 
         self._engine = None
         self._bound_version = None
-        self.compute_precision = "bf16"      # "bf16" (MFMA bf16, fp32 accumulate) | "fp32" (exact fp32 MFMA)
+        # "bf16" (bf16 MFMA operands, fp32 accumulate: the benchmarked default) | "fp16" (fp16 operands: same rate, 8x finer rounding --
+        # the mode that holds the 1e-4 loss tolerance on small batches) | "fp32" (exact fp32 MFMA, layer by layer: the reference's precision)
+        self.compute_precision = "bf16"
         self.need_traj = True                # trajectory heads are dead work for the RLFT losses; trainers switch it off
         self._seed = 0
 
@@ -270,8 +272,13 @@ class PlanningModel(TorchModuleWrapper):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("PlanningModel runs on a HIP device only: call .to('cuda') first (no CPU fallback)")
-        if self._engine is None or self._engine.device != dev:
-            self._engine = _ffi.Engine(dev)
+        if self.compute_precision not in ("bf16", "fp16", "fp32"):
+            raise ValueError(f"compute_precision must be 'bf16', 'fp16' or 'fp32', got {self.compute_precision!r}")
+        operands = "fp16" if self.compute_precision == "fp16" else "bf16"
+        if self._engine is None or self._engine.device != dev or (self._engine.operands != operands and self.compute_precision != "fp32"):
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = _ffi.Engine(dev, operands=operands)
             self._bound_version = None
         ver = self._tensor_version()
         if ver != self._bound_version:

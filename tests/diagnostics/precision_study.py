@@ -190,6 +190,13 @@ def main():
         ("fp16; dec*+misc bf16x2", {k: "bf16x2" for k in REG if k.startswith("dec")}, "fp16"),
         ("fp16; enc+dec* bf16x2", {k: "bf16x2" for k in REG if k.startswith("dec") or k == "enc"}, "fp16"),
     ]
+    if os.environ.get("FP16"):      # which regions carry the fp16 error: one region at a time exact, then cumulative sets
+        configs = [("all fp16", {}, "fp16")] + [(f"fp16 except {r}=fp32", {r: "fp32"}, "fp16") for r in REG]
+        configs += [("fp16; dec_misc+dec3 fp32", {"dec_misc": "fp32", "dec3": "fp32"}, "fp16"),
+                    ("fp16; dec* + misc fp32", {k: "fp32" for k in REG if k.startswith("dec")}, "fp16"),
+                    ("fp16; enc + dec* + misc fp32", {k: "fp32" for k in REG if k.startswith("dec") or k == "enc"}, "fp16"),
+                    ("fp16; nat + pe fp32", {"nat": "fp32", "pe": "fp32"}, "fp16"),
+                    ("fp16 act / fp32 weights", {}, "fp16/fp32"), ("fp32 act / fp16 weights", {}, "fp32/fp16")]
     for cname, batch in cases.items():
         data = batch["cur_pluto_feature_torch"]
         r_pad = ~data["reference_line"]["valid_mask"].any(-1)

@@ -42,6 +42,25 @@ def test_library_exports_every_declared_symbol():
     assert set(_ffi.EXPORTS) == declared
 
 
+def test_trampolines_are_generated_from_the_header():
+    """csrc/abi.cpp / abi_list.h (the exported symbols: routing onto the bf16- or fp16-operand build that owns a context) are what
+    tools/gen/abi_trampolines.py derives from include/rift_hip.h -- the header stays the single statement of the interface."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("abi_trampolines", os.path.join(repo, "tools", "gen", "abi_trampolines.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lst, cpp = mod.render()
+    assert open(mod.OUT_LIST).read() == lst and open(mod.OUT_CPP).read() == cpp, "run python tools/gen/abi_trampolines.py"
+    from rift_amd import _ffi
+    lib = _ffi.load_library()
+    for sym in ("rift_vtable_bf16", "rift_vtable_fp16"):          # one table per operand-format build
+        assert hasattr(lib, sym), sym
+    # no GPU here: creating a context for an unknown operand format is refused before any device call
+    ctx = ctypes.c_void_p()
+    assert lib.rift_ctx_create_ex(0, 7, ctypes.byref(ctx)) == -1
+
+
 def test_struct_layouts_match_header_sizes():
     from rift_amd import _ffi
     # 6 int32 + 26 pointers + 1 int32 (padded) ; 5 pointers ; 8 pointers + 2 floats ; 11 pointers

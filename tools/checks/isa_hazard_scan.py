@@ -1,8 +1,8 @@
-"""Scan the gfx950 ISA of the three translation units for operand hazards that hipcc does not pad INSIDE or right behind inline asm:
+"""Scan the gfx950 ISA of every translation unit (both operand-format builds) for operand hazards that hipcc does not pad INSIDE or right behind inline asm:
   * a VALU write of a VGPR followed within fewer than 2 wait states by an MFMA reading it as A / B / C, by v_permlane*_swap or by a DPP
     instruction reading it (tools/ubench/cvt_mfma_hazard.hip: the MFMA case measured on MI355X -- 0 or 1 states read the OLD register);
   * v_readfirstlane writing an SGPR followed within fewer than 5 wait states by global_load_lds / buffer / global instructions using it.
-The round-2 kernels hide `v_cvt_pk_bf16_f32`, the LDS-DMA and the group GEMM in asm statements; this scan is how their padding is checked.
+The wave-private kernels hide `v_cvt_pk_bf16_f32` / `v_cvt_pk_f16_f32`, the LDS-DMA and the group GEMM in asm statements; this scan is how their padding is checked.
     python tools/checks/isa_hazard_scan.py            # compiles (no GPU needed) and scans; exit status 1 on a finding"""
 import os, re, subprocess, sys, tempfile
 from collections import Counter
@@ -63,17 +63,23 @@ def scan(path):
 
 
 def main():
+    """Both builds of the engine (bf16 and fp16 MFMA operands) with the flags build.py compiles them with."""
+    from concurrent.futures import ThreadPoolExecutor
     total = 0
     with tempfile.TemporaryDirectory() as tmp:
-        for tu, extra in (("engine.hip", []), ("dec_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l2w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
-                          ("enc_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
-                          ("pe_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
-                          ("fo_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
-            out = os.path.join(tmp, tu + ".s")
-            subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w"] + extra +
-                                  [os.path.join(b.CSRC, tu), "-o", out])
+        jobs = []
+        for obj, cmd in b.compile_commands():
+            if obj.endswith("abi.o"):
+                continue
+            out = os.path.join(tmp, os.path.basename(obj)[:-2] + ".s")
+            cmd = [x for x in cmd if x != "-c" and x != "-fPIC"]
+            cmd[cmd.index("-o") + 1] = out
+            jobs.append((out, cmd + ["-S", "--cuda-device-only", "-w"]))
+        with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+            list(ex.map(lambda j: subprocess.check_call(j[1]), jobs))
+        for out, _ in jobs:
             bad = scan(out)
-            print(f"{tu}: {sum(1 for _ in open(out))} lines, findings {dict(Counter(x[0] for x in bad))}")
+            print(f"{os.path.basename(out)}: {sum(1 for _ in open(out))} lines, findings {dict(Counter(x[0] for x in bad))}")
             for x in bad[:10]:
                 print("   ", x)
             total += len(bad)
