@@ -1,8 +1,8 @@
 """RIFT policy-update benchmark on MI355X (contract: see the task brief / DESIGN.md section "Measurement").
 
-    python bench.py --gpus 1 --steps 30 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py                         # 1 GPU, 200 timed steps
+    python bench.py --gpus N ...            # N > 1 from a plain shell: re-executes itself under torch.distributed.run (one rank per GPU, RCCL)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 One *step* = one policy-update step of the reference's RIFT trainer on a 256-scene minibatch per GPU:
 device-side collation of 256 scenes from the HBM-resident replay arena -> train-mode PlanningModel
@@ -11,16 +11,24 @@ analytic pi_head backward -> clip_grad_norm_(0.5) -> AdamW.  With N > 1 ranks th
 (two inside the forward: BatchNorm sums + the r2r quirk's padding rows; one after the backward: gradient sums,
 objective sum, valid count) make the sharded step equal the single-process step on the global minibatch.
 Workload = BASELINE.json configs[2]/[3]: 4096-scene synthetic replay, 64 agents x 20 polygons x R~U{1..6}
-reference lines x 12 modes.  --scaling weak (default): the replay is sharded, 256 scenes / GPU / step;
---scaling strong: the reference's 256-scene minibatch is split over the ranks.
+reference lines x 12 modes.
+
+Scaling.  The headline line is WEAK scaling (the replay is sharded, 256 scenes / GPU / step, global minibatch 256 N); with N > 1 the
+same run also times STRONG scaling -- the reference's 256-scene minibatch split over the ranks (32 scenes per GPU at
+N = 8) -- and reports it in the `strong` object (`--scaling strong` makes it the headline instead).
+Precision.  The headline runs bf16 MFMA operands (BASELINE.json); at N = 1 the `precisions` object carries the same steps in fp16
+operands (same kernels built for v_mfma_f32_16x16x32_f16) and in exact fp32 (layer by layer, the reference's `precision: 32`).
 """
 import argparse
+import glob
 import json
 import os
+import socket
 import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime initialises (rift_amd/__init__.py explains; an explicit setting wins)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver supports dmabuf IPC only: RCCL needs it for any N > 1
 
 import torch  # noqa: E402
 
@@ -29,7 +37,7 @@ sys.path.insert(0, REPO)
 
 FLOPS_PER_SCENE = 1.335e9        # reference-equivalent forward FLOPs/scene at (A=64, Mp=20, R=4), every output computed
 FLOPS_PER_SCENE_LOSS = 1.285e9   # the loss-necessary subset (no trajectory / prediction / ref-free heads) -- what the headline step executes
-PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 BATCH = 256
 
 
@@ -91,31 +99,42 @@ def cpu_baseline(scenes, sd):
     n4, dt4 = run(min(4, hw), 2)
     return {"value": n * BATCH / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
             "sample": f"{n} update steps x {BATCH} scenes (collate+fwd all outputs+RIFT loss+bwd+clip+AdamW), PyTorch-CPU fp32 oracle, "
-                      f"{dt:.1f}s at {threads} threads; {n4} steps, {dt4:.1f}s at 4 threads", "steps_per_sec": n / dt,
+                      f"train-mode BatchNorm batch statistics with every drop probability 0 (the GPU step runs dropout / DropPath / "
+                      f"state-dropout: the oracle has no RNG work to do), {dt:.1f}s at {threads} threads; {n4} steps, {dt4:.1f}s at 4 threads",
+            "steps_per_sec": n / dt,
             "reference_default_4_threads": {"value": n4 * BATCH / dt4, "unit": "scenes/s", "cores": min(4, hw), "steps_per_sec": n4 / dt4},
             "cpu_model": cpu_model_name(), "logical_cpus": hw}
 
 
-def pmc_traffic_file():
-    """The newest committed per-kernel HBM-traffic table (profiles/rNN_pmc_traffic.json, written by tools/profile_round.sh from separate
-    rocprofv3 --pmc passes of this bench).  Counters cannot be collected from inside the process, so `roofline.traffic` is the
-    committed measurement of the same command; null when no table is present."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+# ---- committed counter tables (profiles/rNN_pmc_*): counters cannot be collected from inside the process, so the roofline object cites the
+# newest committed PMC passes of this same command (tools/profile_round.sh) and names the file
+def _newest(pattern):
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))
     return files[-1] if files else None
 
 
-def pmc_traffic(label):
+def pmc_traffic_file():
+    return _newest("r*_pmc_traffic.json")
+
+
+def kernel_of(label):
+    """Engine profiler label -> substring of the kernel's name in the rocprofv3 tables (labels ARE kernel names; GEMM labels carry the
+    tile variant and, with RIFT_PROF_SHAPES, a shape suffix)."""
+    key = label.split(":")[0]
+    gemm = {"gemm_bf16_m1n8": "gemm_rows_kernel<true, 1, 8", "gemm_bf16_m4n2": "gemm_rows_kernel<true, 4, 2", "gemm_bf16_m2n6": "gemm_rows_kernel<true, 2, 6",
+            "gemm_bf16_m4n4": "gemm_rows_kernel<true, 4, 4", "gemm_fp32_m1n8": "gemm_rows_kernel<false, 1, 8", "gemm_fp32_m4n2": "gemm_rows_kernel<false, 4, 2",
+            "gemm_fp32_m2n6": "gemm_rows_kernel<false, 2, 6", "gemm_fp32_m4n4": "gemm_rows_kernel<false, 4, 4"}
+    alias = {"pe_stats1_kernel": "pe_stats1"}          # (pe_stats1_kernel / pe_stats1p_kernel share a label)
+    return gemm.get(key, alias.get(key, key))
+
+
+def pmc_traffic(label, path=None):
     """HBM bytes per launch of the kernel behind an engine profiler label, from the committed PMC passes (None if absent)."""
-    path = pmc_traffic_file()
+    path = path or pmc_traffic_file()
     if path is None:
         return None
     kern = json.load(open(path))["kernels"]
-    nat = {"nat_level_kernel_L0": "nat_level_kernel<32,", "nat_level_kernel_L1": "nat_level_kernel<64,", "nat_level_kernel_L2": "nat_level_kernel<128,"}
-    key = nat.get(label, label.split(":")[0])
-    gemm = {"gemm_bf16_m1n8": "gemm_rows_kernel<true, 1, 8", "gemm_bf16_m4n2": "gemm_rows_kernel<true, 4, 2", "gemm_bf16_m2n6": "gemm_rows_kernel<true, 2, 6",
-            "gemm_bf16_m4n4": "gemm_rows_kernel<true, 4, 4"}
-    key = gemm.get(key, key)
+    key = kernel_of(label)
     hit = [v for k, v in kern.items() if key in k]
     if not hit:
         return None
@@ -123,23 +142,81 @@ def pmc_traffic(label):
     return sum((2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 * v["launches"] for v in hit) / max(n, 1)
 
 
+def pmc_mfma(label, path=None):
+    """(executed MFMA FLOPs per launch, MFMA-busy fraction, source) of a kernel from the committed MFMA counter pass, or None."""
+    path = path or _newest("r*_pmc_SQ_INSTS_VALU_MFMA_MOPS_BF16.txt")
+    if path is None:
+        return None
+    cols, key = None, kernel_of(label)
+    for line in open(path):
+        if line.startswith("dispatches"):
+            cols = [c.split("/")[0] for c in line.split()]
+            continue
+        if cols is None or line.startswith("#") or key not in line:
+            continue
+        vals = line.split(None, len(cols) - 1)
+        row = dict(zip(cols[:-1], vals[:-1]))
+        try:
+            mops = float(row["SQ_INSTS_VALU_MFMA_MOPS_BF16"])
+            busy = float(row["SQ_VALU_MFMA_BUSY_CYCLES"]) / (4.0 * float(row["SQ_BUSY_CU_CYCLES"]))
+        except (KeyError, ValueError, ZeroDivisionError):
+            return None
+        return mops * 512.0, busy, os.path.relpath(path, REPO)
+    return None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: re-execute under torch.distributed.run, one rank per GPU of this node."""
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, torch sees {have}; nothing was measured.\n"
+                         f"          (data-parallel correctness without the hardware: tests/test_gpu_dp.py, tests/test_dp_gloo.py)\n")
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: launching " + " ".join(cmd) + "\n")
+    os.execvpe(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--replay", type=int, default=4096, help="total replay scenes (sharded across ranks)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--replay", type=int, default=4096, help="total replay scenes (sharded across ranks under weak scaling)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"], help="precision of the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-precisions", action="store_true", help="skip the fp16 / fp32 companion legs (N = 1)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: 256 scenes per GPU per step (global minibatch 256 x N); strong: the reference's 256-scene minibatch split over "
-                         "the N GPUs (SURVEY.md 8(e): 32 scenes per GPU at N = 8)")
+                    help="which scaling mode is the headline with N > 1 (the other one is reported beside it). weak: 256 scenes per GPU per "
+                         "step (global minibatch 256 x N); strong: the reference's 256-scene minibatch split over the N GPUs (SURVEY.md 8(e))")
     ap.add_argument("--no-full-update", action="store_true")
-    ap.add_argument("--batch", type=int, default=256, help="scenes per minibatch (diagnostic: 32 = what one of 8 ranks runs under --scaling strong)")
+    ap.add_argument("--batch", type=int, default=256, help="scenes per minibatch (diagnostic: 32 = what one of 8 ranks runs under strong scaling)")
     args = ap.parse_args()
     global BATCH
     BATCH = args.batch
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; start N ranks for --gpus N "
+                         f"(or run `python bench.py --gpus N` without a launcher).\n")
+        sys.exit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.stderr.write(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, torch sees {torch.cuda.device_count()} devices).\n")
+        sys.exit(2)
+    if BATCH % world:
+        sys.stderr.write(f"bench.py: strong scaling splits the {BATCH}-scene minibatch over the ranks: {BATCH} % {world} != 0.\n")
+        sys.exit(2)
 
     # stdout carries exactly ONE line (rank 0's JSON): libraries that print banners to fd 1 (RCCL prints its version block at communicator
     # creation) are sent to stderr for the whole run; the saved descriptor is restored for the final print.
@@ -147,10 +224,6 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -162,159 +235,206 @@ def main():
         pg = dist.group.WORLD
 
     from rift_amd import synthetic as syn
-    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer, shard_scene_ids
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
     from rift_amd.planning.pluto.model.pluto_model import PlanningModel
     from rift_amd.replay import DeviceReplay
 
-    # ---- replay of this rank.  weak scaling: disjoint shards of the 4096 scenes (seeded per scene index), 256 scenes per GPU per step,
-    # global minibatch 256 x N.  strong scaling: every rank holds the whole replay, all ranks draw the same 256-scene
-    # minibatch and each takes its contiguous 256 / N slice.  Either way the three exchanges of RLFTTrainer make the step equal the
-    # single-process step on the global minibatch.
-    strong = args.scaling == "strong" and world > 1
-    if strong and BATCH % world:
-        raise SystemExit(f"--scaling strong needs {BATCH} % N == 0")
-    local_bs = BATCH // world if strong else BATCH
-    global_bs = BATCH if strong else BATCH * world
-    per_rank = args.replay if strong else max(BATCH, args.replay // world)
+    # ---- the replay: `--replay` scenes seeded per scene index.  weak scaling: rank r holds the contiguous shard [r P, (r + 1) P), P = replay / N,
+    # and draws 256 scenes per step from it (global minibatch 256 N); strong scaling: every rank holds the whole replay,
+    # all ranks draw the SAME 256-scene minibatch and each takes its contiguous 256 / N slice.  Either way the three exchanges of
+    # RLFTTrainer make the step equal the single-process step on the global minibatch.
     t_gen = time.perf_counter()
-    scenes = [syn.make_scene(i) for i in (range(per_rank) if strong else shard_scene_ids(rank, world, per_rank))]
-    replay = DeviceReplay(scenes, dev, rcap=6)
+    per_rank_weak = max(BATCH, args.replay // world)
+    ids_weak = range(rank * per_rank_weak, (rank + 1) * per_rank_weak)
+    all_ids = range(max(args.replay, per_rank_weak * world)) if world > 1 else ids_weak
+    scene_of = {i: syn.make_scene(i) for i in all_ids}
+    replays = {"weak": DeviceReplay([scene_of[i] for i in ids_weak], dev, rcap=6)}
+    if world > 1:
+        replays["strong"] = DeviceReplay([scene_of[i] for i in range(args.replay)], dev, rcap=6)
+    scenes = [scene_of[i] for i in ids_weak]
     t_gen = time.perf_counter() - t_gen
 
     torch.manual_seed(20250515)   # identical random-init policy on every rank
     model = PlanningModel(radius=120)
     # non-trivial norm/bias/BatchNorm statistics (random-init has all-zero biases)
     sd_cpu = syn.perturbed_state_dict({k: list(v.shape) for k, v in model.state_dict().items()})
-    model.load_state_dict(sd_cpu)
-    model = model.to(dev)
-    model.compute_precision = args.precision
-    model.need_traj = False
-    model.train()
-    trainer = RLFTTrainer(model, kind="rift", process_group=pg, seed=1)
-    eng = trainer.engine
-
-    g = torch.Generator().manual_seed(1000 if strong else 1000 + rank)
     nsteps = args.warmup + args.steps + 8
-    lo = rank * local_bs if strong else 0
-    idx = [torch.randperm(per_rank, generator=g)[:BATCH][lo:lo + local_bs].to(torch.int32).to(dev) for _ in range(nsteps)]
-    shard = (rank * local_bs, global_bs)
 
-    def step(i):
-        fb, b = replay.collate(eng, idx[i])
-        return trainer.training_step(fb, b, shard=shard)
+    def leg(scaling, precision, steps, want_all_outputs=False, want_full_update=False, want_roofline=False):
+        """Time `steps` update steps in one (scaling, precision) configuration on fresh parameters / optimizer state."""
+        strong = scaling == "strong" and world > 1
+        replay = replays["strong" if strong else "weak"]
+        per_rank = args.replay if strong else per_rank_weak
+        local_bs = BATCH // world if strong else BATCH
+        global_bs = BATCH if strong else BATCH * world
+        model.load_state_dict(sd_cpu)
+        model.to(dev)
+        model.compute_precision = precision
+        model.need_traj = False
+        model.train()
+        trainer = RLFTTrainer(model, kind="rift", process_group=pg, seed=1)
+        eng = trainer.engine
+        g = torch.Generator().manual_seed(1000 if strong else 1000 + rank)
+        lo = rank * local_bs if strong else 0
+        idx = [torch.randperm(per_rank, generator=g)[:BATCH][lo:lo + local_bs].to(torch.int32).to(dev) for _ in range(nsteps)]
+        shard = (rank * local_bs, global_bs)
 
-    def timed(first, count):
-        """`count` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
-        if pg is not None:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(first, first + count):
-            last = step(i)
-        torch.cuda.synchronize()
-        if pg is not None:
-            torch.distributed.barrier()
-        dt = time.perf_counter() - t0
-        if pg is not None:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tmax.item())
-        return dt, last
+        def step(i):
+            fb, b = replay.collate(eng, idx[i % nsteps])
+            return trainer.training_step(fb, b, shard=shard)
 
-    for i in range(args.warmup):
-        step(i)
-    dt, loss = timed(args.warmup, args.steps)
-    final_loss = float(loss.item())
-    eng.check_finite()
+        def timed(first, count):
+            """`count` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+            if pg is not None:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(first, first + count):
+                last = step(i)
+            torch.cuda.synchronize()
+            if pg is not None:
+                torch.distributed.barrier()
+            dt = time.perf_counter() - t0
+            if pg is not None:
+                tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+                torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+                dt = float(tmax.item())
+            return dt, last
 
-    # ---- companion figure: the same K steps with EVERY output of PlanningModel.forward computed (trajectory / prediction /
-    # ref-free heads -- outputs the RLFT losses never read; the reference's training_step computes them, SURVEY.md 8 a6/a7)
-    model.need_traj = True
-    for i in range(2):
-        step(i)
-    dt_all, _ = timed(args.warmup, args.steps)
-    model.need_traj = False
+        for i in range(args.warmup):
+            step(i)
+        dt, loss = timed(args.warmup, steps)
+        trainer.wait_update()
+        res = {"ms_per_step": dt / steps * 1e3, "value": steps / dt * global_bs, "steps_per_sec": steps / dt, "steps": steps,
+               "per_gpu_batch": local_bs, "global_batch": global_bs, "replay_scenes_per_gpu": per_rank, "final_loss": float(loss.item())}
+        eng.check_finite()
 
-    # ---- companion figure: one full policy update as SURVEY.md 8(d) words it -- 16 epochs x (15 training steps + 2 validation steps
-    # on the 90 / 10 split of the 4096-scene replay) with the per-epoch host read and scheduler step (single GPU only)
-    full_update = None
-    if world == 1 and not args.no_full_update:
-        n_val = per_rank - int(0.9 * per_rank)
-        val_idx = [torch.arange(s, min(s + BATCH, n_val), dtype=torch.int32, device=dev) for s in range(0, n_val, BATCH)]
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        k = 0
-        for epoch in range(16):
-            for _ in range(15):
-                step(k % nsteps)
-                k += 1
-            trainer.pop_mean_loss()
-            for vi in val_idx:
-                fb, b = replay.collate(eng, vi)
-                trainer.validation_step(fb, b)
-            trainer.on_epoch_end()
-        torch.cuda.synchronize()
-        t_full = time.perf_counter() - t2
-        full_update = {"seconds": t_full, "train_steps": 240, "val_steps": 16 * len(val_idx), "updates_per_sec": 1.0 / t_full,
-                       "note": "16 epochs x (15 x 256-scene training steps + validation of the 10 % split), epoch-end host read included"}
+        if want_all_outputs:
+            # companion figure: the same K steps with EVERY output of PlanningModel.forward computed (trajectory / prediction /
+            # ref-free heads -- outputs the RLFT losses never read; the reference's training_step computes them, SURVEY.md 8 a6/a7)
+            model.need_traj = True
+            for i in range(2):
+                step(i)
+            dt_all, _ = timed(args.warmup, steps)
+            model.need_traj = False
+            res["all_outputs"] = {"ms_per_step": dt_all / steps * 1e3, "value": steps / dt_all * global_bs, "steps_per_sec": steps / dt_all,
+                                  "whole_step_mfma_frac": steps / dt_all * global_bs / world * FLOPS_PER_SCENE / (PEAK_BF16_TFLOPS * 1e12),
+                                  "note": "trajectory / prediction / ref-free heads computed as the reference's training_step does (1.335 GFLOP per scene)"}
 
-    # ---- roofline leg: per-launch HIP events on the launch stream (separate short pass, rank 0)
-    # (every rank runs the profiled steps -- they contain the exchanges -- and rank 0 reports)
-    roof = None
-    if not args.no_roofline:
-        eng.prof_enable(True)
-        nprof = 4
-        for i in range(nprof):
-            step(args.warmup + args.steps + i)
-        rep = eng.prof_report()
-        eng.prof_enable(False)
-    if rank == 0 and not args.no_roofline:
-        tot_ms = sum(v["ms"] for v in rep.values())
-        dom = max(rep.items(), key=lambda kv: kv[1]["ms"])
-        gemm_ms = sum(v["ms"] for k, v in rep.items() if k.startswith("gemm_"))
-        gemm_fl = sum(v["flops"] for k, v in rep.items() if k.startswith("gemm_"))
-        ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12 if dom[1]["ms"] > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom[0]),
-                "traffic_source": (os.path.relpath(pmc_traffic_file(), REPO) if pmc_traffic_file() else "none") +
-                                  ": (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from separate rocprofv3 --pmc passes of this bench "
-                                  "(tools/profile_round.sh); committed measurement, not collected in this run",
-                "avg_launch_us": dom[1]["ms"] * 1e3 / dom[1]["count"], "launches_per_step": dom[1]["count"] / nprof,
-                "kernel_share_of_gpu_time": dom[1]["ms"] / tot_ms,
-                "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
-                "gpu_ms_per_step_sum_of_kernels": tot_ms / nprof,
-                "per_kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in
-                                           sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("RIFT_PROF_TOP", "12"))]}}
+        if want_full_update and world == 1:
+            # companion figure: one full policy update as SURVEY.md 8(d) words it -- 16 epochs x (15 training steps + 2 validation steps
+            # on the 90 / 10 split of the 4096-scene replay) with the per-epoch host read and scheduler step (single GPU only)
+            n_val = per_rank - int(0.9 * per_rank)
+            val_idx = [torch.arange(s, min(s + BATCH, n_val), dtype=torch.int32, device=dev) for s in range(0, n_val, BATCH)]
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            k = 0
+            for epoch in range(16):
+                for _ in range(15):
+                    step(k)
+                    k += 1
+                trainer.pop_mean_loss()
+                for vi in val_idx:
+                    fb, b = replay.collate(eng, vi)
+                    trainer.validation_step(fb, b)
+                trainer.on_epoch_end()
+            torch.cuda.synchronize()
+            t_full = time.perf_counter() - t2
+            res["full_update"] = {"seconds": t_full, "train_steps": 240, "val_steps": 16 * len(val_idx), "updates_per_sec": 1.0 / t_full,
+                                  "note": "16 epochs x (15 x 256-scene training steps + validation of the 10 % split), epoch-end host read included"}
+
+        if want_roofline:
+            # roofline leg: per-launch HIP events on the launch stream (separate short pass; every rank runs the profiled steps -- they
+            # contain the exchanges -- and rank 0 reports)
+            eng.prof_enable(True)
+            nprof = 4
+            for i in range(nprof):
+                step(args.warmup + steps + i)
+            rep = eng.prof_report()
+            eng.prof_enable(False)
+            if rank == 0:
+                tot_ms = sum(v["ms"] for v in rep.values())
+                dom = max(rep.items(), key=lambda kv: kv[1]["ms"])
+                gemm_ms = sum(v["ms"] for k, v in rep.items() if k.startswith("gemm_"))
+                gemm_fl = sum(v["flops"] for k, v in rep.items() if k.startswith("gemm_"))
+                ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12 if dom[1]["ms"] > 0 else 0.0
+                traffic = pmc_traffic(dom[0])
+                tfile = pmc_traffic_file()
+                roof = {"bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                        "traffic_source": (os.path.relpath(tfile, REPO) if tfile else "none") +
+                                          ": (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from separate rocprofv3 --pmc passes of this bench "
+                                          "(tools/profile_round.sh); committed measurement, not collected in this run",
+                        "avg_launch_us": dom[1]["ms"] * 1e3 / dom[1]["count"], "launches_per_step": dom[1]["count"] / nprof,
+                        "algorithmic_flops_per_launch": dom[1]["flops"] / dom[1]["count"],
+                        "kernel_share_of_gpu_time": dom[1]["ms"] / tot_ms,
+                        "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
+                        "gpu_ms_per_step_sum_of_kernels": tot_ms / nprof,
+                        "per_kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in
+                                                   sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("RIFT_PROF_TOP", "12"))]}}
+                if traffic is None:       # loud: a renamed kernel must not turn the traffic figure into a silent null
+                    roof["traffic_missing"] = f"no entry for {dom[0]!r} in {os.path.relpath(tfile, REPO) if tfile else 'profiles/ (no table)'}"
+                    sys.stderr.write(f"bench.py: WARNING: roofline.traffic is null: {roof['traffic_missing']} -- re-run tools/profile_round.sh\n")
+                mf = pmc_mfma(dom[0])
+                if mf is not None and roof["algorithmic_flops_per_launch"]:
+                    roof["executed_over_algorithmic_mops"] = mf[0] / roof["algorithmic_flops_per_launch"]
+                    roof["mfma_busy_frac"] = mf[1]
+                    roof["mfma_counters_source"] = mf[2] + ": SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 FLOP and SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) per launch (committed pass)"
+                res["roofline"] = roof
+        trainer.close()
+        return res
+
+    head_scaling = args.scaling if world > 1 else "weak"
+    head = leg(head_scaling, args.precision, args.steps, want_all_outputs=True, want_full_update=not args.no_full_update,
+               want_roofline=not args.no_roofline)
+    other = None
+    if world > 1:
+        other_scaling = "strong" if head_scaling == "weak" else "weak"
+        other = (other_scaling, leg(other_scaling, args.precision, args.steps))
+    precisions = None
+    keep = ("ms_per_step", "value", "steps_per_sec", "steps", "final_loss")
+    if world == 1 and not args.no_precisions:
+        precisions = {args.precision: {k: head[k] for k in keep}}
+        for p in ("bf16", "fp16", "fp32"):
+            if p in precisions:
+                continue
+            r = leg("weak", p, args.steps if p != "fp32" else max(5, min(args.steps, 20)))      # (the layer-by-layer fp32 step is several times longer)
+            precisions[p] = {k: r[k] for k in keep}
+        precisions["note"] = ("the same update steps per compute precision: bf16 / fp16 = the fused kernels on bf16 / fp16 MFMA operands; fp32 = exact "
+                              "v_mfma_f32_16x16x4_f32 layer by layer (the reference's `precision: 32`).  Parity per mode: tests/test_gpu_parity.py header")
 
     if rank == 0:
-        steps_per_sec = args.steps / dt
-        scenes_per_sec = steps_per_sec * global_bs
+        strong = head_scaling == "strong" and world > 1
         line = {
             "metric": f"policy-update scenes/sec ({BATCH}-scene RIFT update steps on a 4096-scene replay)",
-            "value": scenes_per_sec, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "value": head["value"], "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "steps_per_sec": steps_per_sec,
+            "steps_per_sec": head["steps_per_sec"], "rccl_ranks": world if pg is not None else 0,
             "config": {"workload": "BASELINE configs[2]/[3]: full rift_pluto CBV policy, 4096-scene synthetic replay "
                                    "(64 agents x 21 steps, 20 polygons x 3 x 20 pts, R~U{1..6} x 120 ref pts, 12 modes), "
                                    "RIFT loss, pi_head trainable",
-                       "per_gpu_batch": local_bs, "global_batch": global_bs, "replay_scenes_per_gpu": per_rank,
+                       "per_gpu_batch": head["per_gpu_batch"], "global_batch": head["global_batch"], "replay_scenes_per_gpu": head["replay_scenes_per_gpu"],
                        "parallelism": f"dp{world}", "train_mode": "dropout+droppath+state-dropout, BN batch stats"
                                                                 + (" over the global minibatch (3 all-reduces per step)" if world > 1 else ""),
                        "outputs": "probability (the trajectory / prediction / ref-free heads feed no RLFT loss and are skipped; "
                                   "all_outputs = the same steps with every output of PlanningModel.forward computed)"},
             # whole-step fraction of the dense bf16 MFMA peak, priced at the algorithmic FLOPs of what each variant executes (SURVEY.md 8(d))
-            "whole_step_mfma_frac": scenes_per_sec / world * FLOPS_PER_SCENE_LOSS / (PEAK_BF16_TFLOPS * 1e12),
-            "all_outputs": {"ms_per_step": dt_all / args.steps * 1e3, "value": args.steps / dt_all * global_bs,
-                            "steps_per_sec": args.steps / dt_all,
-                            "whole_step_mfma_frac": args.steps / dt_all * global_bs / world * FLOPS_PER_SCENE / (PEAK_BF16_TFLOPS * 1e12),
-                            "note": "trajectory / prediction / ref-free heads computed as the reference's training_step does (1.335 GFLOP per scene)"},
-            "final_loss": final_loss, "replay_gen_s": round(t_gen, 2), "replay_hbm_mb": round(replay.nbytes() / 1e6, 1),
+            "whole_step_mfma_frac": head["value"] / world * FLOPS_PER_SCENE_LOSS / (PEAK_BF16_TFLOPS * 1e12),
+            "all_outputs": head["all_outputs"],
+            "final_loss": head["final_loss"], "replay_gen_s": round(t_gen, 2), "replay_hbm_mb": round(replays["weak"].nbytes() / 1e6, 1),
         }
-        if full_update is not None:
-            line["full_update"] = full_update
-        if roof is not None:
-            line["roofline"] = roof
+        if world > 1:
+            for name, r in ((head_scaling, head), other):
+                line[name] = {k: r[k] for k in ("ms_per_step", "value", "steps_per_sec", "per_gpu_batch", "global_batch", "replay_scenes_per_gpu")}
+            line["strong"]["note"] = "SURVEY.md 8(e): the reference's 256-scene minibatch split contiguously over the ranks; steps/s is the reference's optimizer-step rate"
+            line["weak"]["note"] = "256 scenes per GPU per step: the reference's update with train_batch_size = 256 N (fewer, larger optimizer steps per epoch)"
+        if "full_update" in head:
+            line["full_update"] = head["full_update"]
+        if precisions is not None:
+            line["precisions"] = precisions
+        if "roofline" in head:
+            line["roofline"] = head["roofline"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scenes, sd_cpu)
         sys.stdout.flush()
