@@ -176,7 +176,13 @@ int rift_set_dp(RiftCtx* ctx, const RiftDp* dp);
  * policy-head kernels of rift_forward raise a device flag when the decoder output holds a NaN / Inf (either propagates through the
  * residual stream to the last layer); rift_forward itself stays asynchronous.  rift_check_finite is the sync point: it waits for
  * `stream`, returns RIFT_ERR_NONFINITE (and clears the flag) if any forward since the last check raised it, RIFT_OK otherwise.
- * The host layer calls it wherever it reads results back (once per epoch in the update loop, once per get_action). */
+ * The host layer calls it wherever it reads results back (once per epoch in the update loop, once per get_action).
+ * What it guarantees, precisely (weaker than an assert per layer): the test is an integer exponent compare on the LAST decoder output, so
+ * it sees every NaN / Inf that is in the residual stream of the encoder or decoder at some point (a residual add keeps it to the end).
+ * The wave-private kernels are built without IEEE NaN handling (-fno-honor-nans -mno-amdgpu-ieee: v_max_f32 returns the non-NaN
+ * operand), so a NaN born INSIDE a branch ahead of a ReLU / max -- Inf - Inf in an FFN hidden layer, a PointsEncoder max-pool --
+ * can be replaced by a finite value there and never reach the stream; an Inf survives either way.  The reference's assert shares
+ * the blind spot for the PointsEncoder (it looks at the decoder queries only) but not for the decoder FFN. */
 int rift_check_finite(RiftCtx* ctx, void* stream);
 
 /* SFTTrainer.generate_target_label's teacher side (fine_tuner/sft/sft_trainer.py:186-199): per scene, the (r, m) index of the candidate

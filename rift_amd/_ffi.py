@@ -334,7 +334,13 @@ class Engine:
         if getattr(self, "_dp_key", None) != (xchg.data_ptr(), id(exchange)):
             def _cb(user, offset, count, stream):
                 try:
-                    exchange(xchg[offset:offset + count])
+                    # the header's contract: the all-reduce is enqueued on the stream the engine names (it is torch's current stream
+                    # unless the caller handed rift_forward another one)
+                    if (stream or 0) != torch.cuda.current_stream(xchg.device).cuda_stream:
+                        with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0, device=xchg.device)):
+                            exchange(xchg[offset:offset + count])
+                    else:
+                        exchange(xchg[offset:offset + count])
                     return 0
                 except BaseException as e:          # an exception must not unwind through the C frames
                     self._dp_error = e

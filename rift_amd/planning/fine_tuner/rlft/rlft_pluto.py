@@ -21,7 +21,7 @@ import torch
 from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
 from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer, split_minibatch
 from rift_amd.planning.pluto.model.pluto_model import PlanningModel
-from rift_amd.planning.pluto.pluto import PLUTO, CBVBasePolicy, CBVStateSource, Candidates, CenterState   # noqa: F401 (re-exported)
+from rift_amd.planning.pluto.pluto import PLUTO, CBVBasePolicy, CBVStateSource, Candidates, CenterState, NoFlagSource   # noqa: F401 (re-exported)
 from rift_amd.replay import DeviceReplay
 
 DEFAULT_CFG = {   # fine_tuner/rlft/config/{rift,grpo,ppo,reinforce}_training.yaml + datamodule/*.yaml + lightning/custom_lightning.yaml
@@ -197,6 +197,8 @@ class RLFTPluto(PLUTO):
             idx_dev = idx.to(torch.int32).to(self.device)
             for s in range(0, idx.numel(), bs):
                 m = min(bs, idx.numel() - s)
+                if m < world:       # a tail with fewer scenes than ranks cannot give every rank a scene (each one has to join the
+                    continue        # exchanges of the forward): dropped on ALL ranks alike -- at most world - 1 scenes per pass
                 lo, hi = split_minibatch(m, rank, world) if world > 1 else (0, m)
                 yield idx_dev[s + lo:s + hi], int(replay.r_count_cpu[idx[s:s + m]].max()), ((lo, m) if world > 1 else None)
 
@@ -209,24 +211,26 @@ class RLFTPluto(PLUTO):
                     b[k] = v[idx_dev.long()].contiguous()
             return trainer.training_step(fb, b, shard=shard) if train else trainer.validation_step(fb, b, shard=shard)
 
-        for epoch in range(cfg["epochs"]):
-            for mb in minibatches(train_idx, cfg["train_batch_size"], cfg["shuffle"]):
-                run(mb, True)
-            train_loss = trainer.pop_mean_loss()    # mean of the step losses; also joins the update stream (parameters are final)
-            vl = [run(mb, False).clone() for mb in minibatches(val_idx, cfg["val_batch_size"], False)]
-            trainer.on_epoch_end()
-            val_loss = float(torch.stack(vl).mean().item()) if vl else train_loss
-            history.append({"epoch": epoch, "train_loss": train_loss, "val_loss": val_loss,
-                            "lr": trainer.optimizer.param_groups[0]["lr"]})
-            if best is None or val_loss < best:                    # ModelCheckpoint(save_top_k=1, monitor loss/val_loss)
-                if rank == 0 and best_path is not None and best_path.exists():
-                    best_path.unlink()
-                best = val_loss
-                best_path = save_dir / f"carla_episode={e_i}-epoch={epoch}-val_loss={val_loss:.3f}.ckpt"   # training_builder.py:133
-                if rank == 0:
-                    torch.save({"state_dict": {"model." + k: v.detach().cpu() for k, v in self.train_model.state_dict().items()},
-                                "epoch": epoch, "carla_episode": e_i}, best_path)
-        trainer.close()
+        try:
+            for epoch in range(cfg["epochs"]):
+                for mb in minibatches(train_idx, cfg["train_batch_size"], cfg["shuffle"]):
+                    run(mb, True)
+                train_loss = trainer.pop_mean_loss()    # mean of the step losses; also joins the update stream (parameters are final)
+                vl = [run(mb, False).clone() for mb in minibatches(val_idx, cfg["val_batch_size"], False)]
+                trainer.on_epoch_end()
+                val_loss = float(torch.stack(vl).mean().item()) if vl else train_loss
+                history.append({"epoch": epoch, "train_loss": train_loss, "val_loss": val_loss,
+                                "lr": trainer.optimizer.param_groups[0]["lr"]})
+                if best is None or val_loss < best:                    # ModelCheckpoint(save_top_k=1, monitor loss/val_loss)
+                    if rank == 0 and best_path is not None and best_path.exists():
+                        best_path.unlink()
+                    best = val_loss
+                    best_path = save_dir / f"carla_episode={e_i}-epoch={epoch}-val_loss={val_loss:.3f}.ckpt"   # training_builder.py:133
+                    if rank == 0:
+                        torch.save({"state_dict": {"model." + k: v.detach().cpu() for k, v in self.train_model.state_dict().items()},
+                                    "epoch": epoch, "carla_episode": e_i}, best_path)
+        finally:
+            trainer.close()             # the data-parallel hooks sit on the model-owned engine: detach them also when an epoch raises
         if process_group is not None:
             torch.distributed.barrier(group=process_group)         # the checkpoint of rank 0 is on disk before anyone reloads
         self.last_fit = {"history": history, "best_val_loss": best, "checkpoint": best_path.as_posix(), "lr": lr}
@@ -267,15 +271,19 @@ class _GroupRelativePluto(RLFTPluto):
         actors = src.nearby_actor_states(env_id, cbv_id)
         G = int(r_valid.sum()) * 12
         kw = {}
-        if raster is None:
+        # (a source without these inputs raises NotImplementedError: the reference's advantage always carries both penalties; zeros
+        # only when the source says so explicitly or, for collisions, when the CBV has no neighbours right now)
+        if raster is NoFlagSource.ALL_CLEAR:
             kw["off_road_matrix"] = np.zeros((G, 80), dtype=np.bool_)
+        elif raster is None:
+            raise RuntimeError(f"{type(src).__name__}.off_road_raster returned None: return (mask, pose) or NoFlagSource.ALL_CLEAR")
         else:
             kw["off_road_mask"], kw["center_pose"] = raster
-        if actors is None:
+        if actors is None or actors is NoFlagSource.ALL_CLEAR:
             kw["collision_matrix"] = np.zeros((G, 40), dtype=np.bool_)
         else:
             kw["nearby_actor_states"] = actors
-        adv = self.traj_evaluator.get_grpo_advantage(tuple(state), out["trajectory"][index][r_valid], ref_pos, ref_ang, **kw)
+        adv = self.traj_evaluator.get_grpo_advantage(state.rollout_tuple(), out["trajectory"][index][r_valid], ref_pos, ref_ang, **kw)
         logits = decision.probability[r_valid.cpu().numpy()]
         return {'CBVs_actions_old_group_logits': {'logits': logits, 'valid_mask': np.ones_like(logits, dtype=np.bool_)},
                 'CBVs_group_advantage': adv}

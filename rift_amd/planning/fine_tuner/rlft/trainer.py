@@ -404,12 +404,29 @@ class RLFTTrainer:
         """Mean training loss since the last call (one host read per epoch instead of one per step)."""
         self.wait_update()
         n, self.loss_n = self.loss_n, 0
-        self.engine.check_finite()          # the reference's isfinite assert on the decoder queries, at the epoch's one host read
+        self.check_finite()                 # the reference's isfinite assert on the decoder queries, at the epoch's one host read
         used = n % self.LOSS_SLOTS or (self.LOSS_SLOTS if n else 0)      # slots written since the last fold
         # (summed on the host: one small device-to-host copy, no reduction kernel whose first use would load a module mid-epoch)
         v = (float(self.loss_acc.item()) + float(self.loss_hist[:used].cpu().sum())) / max(n, 1)
         self.loss_acc.zero_()
         return v
+
+    def check_finite(self):
+        """The engine's non-finite flag is per shard: under data parallelism every rank learns whether ANY rank saw a non-finite
+        decoder query (one scalar exchange), so that all of them raise together instead of one raising and the others waiting in the
+        next all-reduce."""
+        err = None
+        try:
+            self.engine.check_finite()
+        except RuntimeError as e:
+            err = e
+        if self.exchange is not None and self.world > 1:
+            flag = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64, device=self.engine.device)
+            self.exchange(flag)
+            if float(flag.item()) > 0 and err is None:
+                err = RuntimeError("non-finite decoder queries on another data-parallel rank")
+        if err is not None:
+            raise err
 
     def _optimizer_step(self):
         """AdamW on the optimizer's own state tensors in ONE native launch (rift_adamw_step) for every parameter group.  The first

@@ -428,6 +428,32 @@ class _RecordedStates:
         return mask, (10.0 + cbv_id, -5.0, 0.3)
 
 
+def test_state_source_contract():
+    """The group advantage never runs on silently missing inputs: a source that does not implement the neighbour / raster readings fails
+    the train-mode tick (the reference always feeds both, rift_pluto.py:113-135); the PID gets the CENTRE speed (pluto.py:252), the
+    rollout the rear-axle speed (track_propogate.py:628); the raster helper places polygon vertices where the oracle's global_to_pixel does."""
+    from oracle import traj_flags as otf
+    from rift_amd.planning.pluto.pluto import CBVStateSource, CenterState, NoFlagSource, raster_drivable_area
+    src = CBVStateSource()
+    for call in (src.nearby_actor_states, src.off_road_raster):
+        with pytest.raises(NotImplementedError, match="group advantage needs"):
+            call(0, 1)
+    st = CenterState(1.0, 2.0, 0.3, 6.0, 2.0, 4.6, center_speed=6.4)
+    assert st.rollout_tuple() == (1.0, 2.0, 0.3, 6.0, 2.0, 4.6) and st.pid_speed() == 6.4
+    assert CenterState(1.0, 2.0, 0.3, 6.0, 2.0, 4.6).pid_speed() == 6.0
+    assert NoFlagSource.ALL_CLEAR is not None
+    rng = np.random.default_rng(5)
+    polys = [rng.normal(0, 40, size=(5, 2)) + np.array([12.0, -7.0]) for _ in range(3)]
+    seen = []
+    mask = raster_drivable_area(polys, (12.0, -7.0), 0.4, fill_polygon=lambda m, v, val: seen.append((v.copy(), val)))
+    assert mask.shape == (400, 400) and mask.dtype == np.uint8 and mask.all() and len(seen) == 3
+    rot = np.array([[np.cos(0.4), -np.sin(0.4)], [np.sin(0.4), np.cos(0.4)]])
+    for poly, (v, val) in zip(polys, seen):
+        want = np.round(otf.global_to_pixel(poly, np.array([12.0, -7.0]), rot, np.array([0.5, -0.5], dtype=np.float32),
+                                            np.array([200.0, 200.0], dtype=np.float32))).astype(np.int32)
+        assert val == 0 and v.dtype == np.int32 and np.array_equal(v, want)
+
+
 @pytest.mark.gpu
 def test_rollout_fills_the_buffer_and_the_update_trains_on_it(tmp_path):
     """The closed loop of train_cbv without the reference classes (carla_runner.py:207-235): RIFTPluto.get_action in train mode ->
