@@ -509,8 +509,97 @@ def gen_normalize():
     print("normalize ->", path, f"{os.path.getsize(path) / 1e3:.1f} KB", len(out), "arrays")
 
 
+def gen_rtr():
+    """RTR objective as the reference computes it: LightningTrainer._compute_objectives / get_ppo_loss / get_teacher_loss /
+    generate_target_label of fine_tuner/sft/rtr_pluto/rtr_trainer.py:130-255 compiled in memory, with the reference's CriticPPO
+    (gym_carla/utils/net.py), sft/utils.global_to_local and PIDController imported from where they lie."""
+    import importlib.util
+    import types
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from tests.helpers import critic_weights, rtr_inputs
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref_loader.REF_ROOT, rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    g2l = load("ref_sft_utils2", "rift/cbv/planning/fine_tuner/sft/utils.py").global_to_local
+    pid = load("ref_pid3", "rift/cbv/planning/pluto/controller/pid_controller.py").PIDController()
+    critic = load("ref_net2", "rift/gym_carla/utils/net.py").CriticPPO(dims=[256, 256], state_dim=128, action_dim=3)
+    critic.load_state_dict(critic_weights(), strict=True)
+    for p_ in critic.parameters():
+        p_.requires_grad = True                       # freeze_parameters([pi_head, value_net]) (rtr_trainer.py:84-100)
+    T_ = "rift/cbv/planning/fine_tuner/sft/rtr_pluto/rtr_trainer.py"
+    ns = {"F": F, "global_to_local": g2l, "Dict": dict}
+    fake = types.SimpleNamespace(controller=pid, frame_rate=10, clip_epsilon=0.2, lambda_entropy=0.01, value_criterion=nn.SmoothL1Loss(),
+                                 model=types.SimpleNamespace(value_net=critic))
+    for name in ("generate_target_label", "get_teacher_loss", "get_ppo_loss"):
+        setattr(fake, name, types.MethodType(_ref_function(T_, name, ns), fake))
+    objectives = _ref_function(T_, "_compute_objectives", ns)
+    inp = rtr_inputs()
+    prob = inp["probability"].clone().requires_grad_(True)
+    cur_res = {"trajectory": inp["trajectory"].clone(), "probability": prob * 1.0}
+    cur_data = {"reference_line": {"valid_mask": inp["ref_valid_mask"]}}
+    batch = {"teacher_infos": inp["teacher_infos"], "action_mode_torch": inp["action_mode"], "state_torch": inp["state"],
+             "advantage_torch": inp["advantage"], "reward_sum_torch": inp["reward_sum"], "old_log_prob_torch": inp["old_log_prob"]}
+    out = objectives(fake, cur_res, cur_data, batch)
+    out["loss"].backward()
+    res = {"loss": np.array(float(out["loss"])), "ppo_loss": np.array(out["ppo_loss"]), "teacher_loss": np.array(out["teacher_loss"]),
+           "dloss_dprob": prob.grad.numpy()}
+    for n_, p_ in critic.named_parameters():
+        if p_.grad is not None:
+            res["grad." + n_] = p_.grad.numpy()
+    path = os.path.join(HERE, "rtr.npz")
+    np.savez_compressed(path, **res)
+    print("rtr ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", float(out["loss"]), out["ppo_loss"], out["teacher_loss"])
+
+
+def gen_buffer():
+    """CBVRolloutBuffer (rift/gym_carla/buffer/cbv_rollout_buffer.py:16-138), the reference class itself: the seeded store() sequences
+    of tests.helpers.buffer_store_sequences are replayed through it; after EVERY call the fixture records buffer_pos, buffer_full and
+    the stored order (the integer codes of 'CBVs_obs'), and at the end what sample() / get_key_data() return."""
+    import types
+    from tests.helpers import BUFFER_KEYS, buffer_store_sequences
+    ref_loader.install()
+    for pkg in ("rift.gym_carla", "rift.gym_carla.buffer"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(ref_loader.REF_ROOT, *pkg.split("."))]
+        sys.modules[pkg] = m
+    from rift.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer as RefBuffer
+    pos, full, order, order_off, done_col, sample_mid = [], [], [], [0], [], []
+    seqs = buffer_store_sequences()
+    for capacity, calls in seqs:
+        buf = RefBuffer(1, 'train_cbv', {'buffer_capacity': capacity, 'data_keys': list(BUFFER_KEYS)})
+        for chunk in calls:
+            if buf.buffer_full:              # carla_runner.py:239-247 trains and resets as soon as the buffer is full; further stores would
+                break                        # rotate the deques (maxlen) -- not a state the runner produces
+            buf.store(chunk)
+            pos.append(buf.buffer_pos)
+            full.append(buf.buffer_full)
+            order.extend(int(v) for v in buf.buffer_data['CBVs_obs'])
+            order_off.append(len(order))
+        if buf.buffer_full:
+            done_col.extend(bool(v) for v in buf.get_key_data('CBVs_done'))
+            sample_mid.append(int(buf.sample(capacity // 2)['CBVs_actions']))
+        else:
+            sample_mid.append(-1)
+    out = {"buffer_pos": np.array(pos, dtype=np.int64), "buffer_full": np.array(full), "order": np.array(order, dtype=np.int64),
+           "order_off": np.array(order_off, dtype=np.int64), "done_when_full": np.array(done_col), "sample_mid": np.array(sample_mid, dtype=np.int64),
+           "n_seq": np.array(len(seqs))}
+    path = os.path.join(HERE, "buffer.npz")
+    np.savez_compressed(path, **out)
+    print("buffer ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", len(seqs), "sequences,", len(pos), "store calls,",
+          int(np.sum(full)), "calls ending full,", int(sum(1 for s in sample_mid if s >= 0)), "sequences filled")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "normalize":
+    if len(sys.argv) > 1 and sys.argv[1] == "buffer":
+        gen_buffer()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rtr":
+        gen_rtr()
+    elif len(sys.argv) > 1 and sys.argv[1] == "normalize":
         gen_normalize()
     elif len(sys.argv) > 1 and sys.argv[1] == "collate":
         gen_collate()
@@ -532,3 +621,5 @@ if __name__ == "__main__":
         gen_inference()
         gen_other_vehicles()
         gen_sft()
+        gen_buffer()
+        gen_rtr()

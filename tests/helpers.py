@@ -181,6 +181,19 @@ def sft_inputs(seed=31337, bs=6, R=4, M=12, T=80):
             "r_pad": ~rvalid, "teacher_infos": teacher}
 
 
+def rtr_inputs(seed=27183):
+    """Seeded inputs of the RTR objective (tests/golden/rtr.npz): the SFT inputs plus PPO's per-scene extras (rtr_trainer.py:173-196)."""
+    inp = sft_inputs()
+    g = torch.Generator().manual_seed(seed)
+    bs, R, M = inp["probability"].shape
+    rcount = (~inp["r_pad"]).sum(1)
+    inp.update({"state": torch.randn(bs, 128, generator=g), "advantage": torch.randn(bs, generator=g),
+                "reward_sum": torch.randn(bs, generator=g) * 2.0, "old_log_prob": -3.0 + 0.3 * torch.randn(bs, generator=g),
+                "action_mode": torch.stack([(torch.rand(bs, generator=g) * rcount).long().clamp(max=R - 1),
+                                            torch.randint(0, M, (bs,), generator=g)], 1)})
+    return inp
+
+
 def collate_scenes_ragged():
     """Seeded scenes with ragged agent / polygon / reference-line counts (tests/golden/collate.npz = the reference's RIFTCollate on them)."""
     dims = [(9, 5, 2), (16, 10, 4), (3, 7, 1), (12, 2, 3), (16, 9, 4), (5, 10, 2), (1, 1, 1)]
@@ -218,3 +231,66 @@ def raw_feature_inputs(seed=2718, A=9, Mp=14, R=3, T=26, S=2):
                            "orientation": g.uniform(-3.14, 3.14, (R, 120)), "valid_mask": g.random((R, 120)) < 0.9,
                            "future_projection": g.normal(0, 1, (R, 8, 2))},
     }
+
+
+BUFFER_KEYS = ['CBVs_obs', 'CBVs_actions', 'CBVs_actions_old_group_logits', 'CBVs_group_advantage', 'CBVs_next_obs', 'CBVs_reward',
+               'CBVs_terminated', 'CBVs_done']          # planning/config/rift_pluto.yaml:8-16
+
+
+def buffer_store_sequences(n_seq=120, seed=60221):
+    """Seeded store() call sequences for CBVRolloutBuffer (shared by gen_golden.gen_buffer and the tests; regenerated, not stored).
+    Every sequence = (capacity, [data_dict per store call]).  A data_dict is one env's rollout chunk as carla_runner.py:455-463 hands it
+    over: per key a list over the chunk's steps of {cbv_id: value}, plus 'CBV_ids'.  Values are integer codes (sequence, cbv, step of
+    that CBV) so that the stored ORDER is readable from the buffer.  The sequences cover episodes shorter than six steps (dropped),
+    chunks that end mid-episode (staged across calls), several CBVs finishing in one chunk, exact fills and overflows."""
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for q in range(n_seq):
+        capacity = int(rng.choice([16, 24, 40, 64]))
+        alive, age, calls, next_id = {}, {}, [], 1
+        fill_target = capacity + int(rng.integers(0, 30)) if q % 3 else capacity          # q % 3 == 0: aim at an exact fill
+        stored = 0
+        while stored < fill_target and len(calls) < 200:
+            steps = int(rng.integers(1, 9))
+            chunk = {k: [] for k in BUFFER_KEYS + ['CBV_ids']}
+            for _ in range(steps):
+                while len(alive) < int(rng.integers(1, 4)):
+                    alive[next_id] = int(rng.choice([2, 3, 5, 6, 7, 9, 14, 23]))         # episode length of the new CBV
+                    age[next_id] = 0
+                    next_id += 1
+                ids = sorted(alive)
+                if q % 5 == 0:
+                    ids = ids[::-1]                                                      # iteration order = order of 'CBV_ids'
+                chunk['CBV_ids'].append(list(ids))
+                row = {k: {} for k in BUFFER_KEYS}
+                for c in ids:
+                    age[c] += 1
+                    done = age[c] >= alive[c]
+                    code = (q * 1000 + c) * 100 + age[c]
+                    for k in BUFFER_KEYS:
+                        row[k][c] = done if k == 'CBVs_done' else (bool(done and c % 2) if k == 'CBVs_terminated' else code)
+                    if done:
+                        if alive[c] > 5:
+                            stored += alive[c]
+                        del alive[c], age[c]
+                for k in BUFFER_KEYS:
+                    chunk[k].append(row[k])
+            calls.append(chunk)
+        seqs.append((capacity, calls))
+    return seqs
+
+
+def traj_flag_kat():
+    """tests/golden/traj_flags_kat.json as arrays: (centre footprints (G,1,4,2) f32, list of neighbour arrays (N_g,1,4,2) f64, expected (G,)),
+    (raster mask (H,W) u8, per case (point (1,1,2) f32, origin, heading, expected))."""
+    import json
+    doc = json.load(open(os.path.join(GOLDEN, "traj_flags_kat.json")))
+    col = [(c["name"], np.asarray(c["center"], dtype=np.float32).reshape(1, 1, 4, 2),
+            np.asarray(c["others"], dtype=np.float64).reshape(-1, 1, 4, 2), bool(c["expect"])) for c in doc["collision"]]
+    r = doc["raster"]
+    mask = np.zeros((r["height"], r["width"]), dtype=np.uint8)
+    for row, c_ in r["ones_row_col"]:
+        mask[row, c_] = 1
+    off = [(c["name"], np.asarray(c["point"], dtype=np.float32).reshape(1, 1, 2), tuple(c["origin"]), float(c["heading"]), bool(c["expect"]))
+           for c in doc["off_road"]]
+    return col, mask, off

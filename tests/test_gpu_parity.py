@@ -884,6 +884,27 @@ def test_collision_and_off_road_flags_match_oracle(ffi):
     eng.close()
 
 
+def test_device_flags_against_hand_derived_known_answers(ffi):
+    """rift_collision_matrix / rift_off_road_matrix against tests/golden/traj_flags_kat.json (42 hand-derived cases: touching and
+    merely-envelope-overlapping footprints, degenerate footprints, half-pixel ties, raster edges, the flipped y axis, rotation)."""
+    col, mask, off = H.traj_flag_kat()
+    eng = ffi.Engine("cuda:0")
+    for name, center, others, want in col:
+        got = eng.collision_matrix(torch.from_numpy(center), torch.from_numpy(others), Ts=1).cpu().numpy()
+        assert got.shape == (1, 1) and bool(got[0, 0]) == want, name
+    # all collision cases at once (G candidates against each case's neighbours would mix cases: run the centre footprints as one batch
+    # against a single common neighbour to exercise G > 1 and Tc > Ts)
+    centers = np.concatenate([c[1] for c in col], axis=0).repeat(3, axis=1)                       # (G, 3, 4, 2)
+    nb = np.asarray([[[3.0, 3.0], [2.0, 3.0], [2.0, 2.0], [3.0, 2.0]]], dtype=np.float64)[:, None].repeat(2, axis=1)   # (1, 2, 4, 2): the box [2,3]^2
+    got = eng.collision_matrix(torch.from_numpy(centers), torch.from_numpy(nb), Ts=2).cpu().numpy()
+    from oracle import traj_flags as otf
+    assert np.array_equal(got, otf.get_collision_matrix(centers, nb))
+    for name, pt, origin, heading, want in off:
+        got = eng.off_road_matrix(torch.from_numpy(pt), torch.from_numpy(mask), origin, heading).cpu().numpy()
+        assert bool(got[0, 0]) == want, name
+    eng.close()
+
+
 def test_traj_evaluator_grpo_advantage_with_device_flags(ffi):
     """TrajEvaluator.get_grpo_advantage end to end on the device -- ref-line deviation, closed-loop rollout, collision flags from the
     neighbours' forecast footprints, off-road flags from the raster, discounted return, group z-score -- against the oracle chain.

@@ -49,6 +49,36 @@ def test_buffer_staging_drop_short_and_fill():
         buf.get_key_data('CBVs_obs')
 
 
+def test_buffer_matches_the_reference_class_on_seeded_store_sequences():
+    """a14 pinned: tests/golden/buffer.npz holds what the REFERENCE's CBVRolloutBuffer (cbv_rollout_buffer.py:16-138, imported by
+    gen_golden.gen_buffer) did on 120 seeded multi-CBV store sequences -- short episodes (dropped), episodes staged across calls,
+    exact fills, overflows: buffer_pos / buffer_full / stored order after EVERY store call, the done column and a sample once full."""
+    import os
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "buffer.npz")))
+    seqs = H.buffer_store_sequences()
+    assert len(seqs) == int(gold["n_seq"])
+    call, n_full = 0, 0
+    for q, (capacity, calls) in enumerate(seqs):
+        buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': capacity, 'data_keys': list(H.BUFFER_KEYS)})
+        for chunk in calls:
+            if buf.buffer_full:
+                break
+            buf.store(chunk)
+            assert len(buf) == buf.buffer_pos == int(gold["buffer_pos"][call]), (q, call)
+            assert buf.buffer_full == bool(gold["buffer_full"][call]), (q, call)
+            want = gold["order"][gold["order_off"][call]:gold["order_off"][call + 1]]
+            assert [int(v) for v in buf.buffer_data['CBVs_obs']] == want.tolist(), (q, call)
+            call += 1
+        if buf.buffer_full:
+            assert [bool(v) for v in buf.get_key_data('CBVs_done')] == gold["done_when_full"][n_full:n_full + capacity].tolist(), q
+            n_full += capacity
+            assert int(buf.sample(capacity // 2)['CBVs_actions']) == int(gold["sample_mid"][q])
+            assert buf.get_all_np_data()['CBVs_reward'].shape == (capacity, 1)
+        else:
+            assert int(gold["sample_mid"][q]) == -1
+    assert call == len(gold["buffer_pos"]) and n_full == len(gold["done_when_full"])
+
+
 def test_pluto_feature_collate_matches_reference_semantics():
     scenes = [syn.make_scene(i, num_agents=6 + i, num_polygons=4 + i) for i in range(3)]
     pf = PlutoFeature.collate([PlutoFeature(data=s["feature"]) for s in scenes])
@@ -327,7 +357,8 @@ def test_sft_kind_trains_pi_head_towards_the_teacher_mode():
 def test_rtr_objective_is_five_ppo_plus_teacher():
     """RLFTTrainer(kind="rtr") (rtr_trainer.py:131-171: loss = 5 * PPO objective + teacher cross entropy, pi_head and value_net trainable):
     on one fixed minibatch in fp32 with the drops off, its loss and gradients equal 5 x those of kind="ppo" plus those of kind="sft"
-    (each of which is checked against the oracle on its own), the critic's gradients 5 x PPO's."""
+    (each of which is checked against the oracle on its own), the critic's gradients 5 x PPO's -- and loss, pi_head and value_net
+    gradients equal the oracle chain whose objective is pinned to the reference's rtr_trainer._compute_objectives (tests/golden/rtr.npz)."""
     from rift_amd.planning.fine_tuner.rlft.ppo_pluto.ppo_pluto import PPOPlutoModel
     from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
     from rift_amd.replay import DeviceReplay
@@ -370,6 +401,31 @@ def test_rtr_objective_is_five_ppo_plus_teacher():
         assert float((gr[k] - want).abs().max()) < 1e-6 + 1e-5 * float(want.abs().max()), k
     for k in cr:
         assert float((cr[k] - 5.0 * cp[k]).abs().max()) < 1e-6 + 1e-5 * float(cp[k].abs().max()) * 5.0, k
+    # ---- and against the ORACLE chain end to end: oracle forward (train-mode BatchNorm) -> pi_head / value_net with autograd ->
+    # oracle/critic.rtr objective, which tests/test_oracle_critic.py pins to the reference's own rtr_trainer._compute_objectives (rtr.npz)
+    from oracle import critic as ocr, losses, pluto_ref
+    import torch.nn.functional as F
+    batch = syn.collate_scenes(scenes)
+    data = batch["cur_pluto_feature_torch"]
+    trunk = {k: v for k, v in sd0.items() if not k.startswith("value_net.")}
+    out_o, _, taps = pluto_ref.planning_model_forward(trunk, data, train_bn=True, need_traj=True, want_taps=True)
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    PI = "planning_decoder.pi_head."
+    pp = {k: sd0[PI + k].clone().requires_grad_(True) for k in losses.PI_KEYS}
+    cpar = {k: sd0["value_net." + k].clone().requires_grad_(True) for k in ocr.CRITIC_KEYS}
+    prob = pluto_ref.mlp_layer(taps["q_final"], pluto_ref.SD({PI + k: v for k, v in pp.items()}, PI)).squeeze(-1).masked_fill(r_pad.unsqueeze(-1), -1e6)
+    ex = {k: v.cpu() for k, v in extras.items()}
+    ppo = F.smooth_l1_loss(ocr.critic_forward(cpar, ex["state"]), ex["reward_sum"]) + \
+        losses.ppo_actor_loss(prob, r_pad, ex["action_mode"], ex["advantage"], ex["old_log_prob"])
+    teacher, _, _ = losses.sft_loss(prob, r_pad, out_o["trajectory"], ex["teacher_infos"])
+    want = 5.0 * ppo + teacher
+    want.backward()
+    print(f"rtr vs oracle chain: loss {lr_:.6f} vs {float(want):.6f}")
+    assert abs(lr_ - float(want)) < 2e-5 * max(1.0, abs(float(want)))
+    for k in gr:
+        assert float((gr[k] - pp[k].grad).abs().max()) < 1e-5 + 2e-4 * float(pp[k].grad.abs().max()), k
+    for k in cr:
+        assert float((cr[k] - cpar[k].grad).abs().max()) < 1e-5 + 2e-4 * float(cpar[k].grad.abs().max()), k
 
 
 @pytest.mark.gpu

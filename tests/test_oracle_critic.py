@@ -24,6 +24,25 @@ def test_critic_and_ppo_loss_match_reference_fixture():
         assert np.abs(grads[k].numpy() - gold["grad." + k]).max() < 1e-6, k
 
 
+def test_rtr_objective_oracle_matches_reference_fixture():
+    """oracle/critic.rtr_loss_and_grads against tests/golden/rtr.npz = the reference's own rtr_trainer._compute_objectives / get_ppo_loss /
+    get_teacher_loss / generate_target_label + CriticPPO on H.rtr_inputs: total loss, its PPO and teacher parts, d loss / d logits and the
+    critic gradients (lambda_rl = 5 on the PPO part, value loss included)."""
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "rtr.npz"))
+    sd, inp = H.critic_weights(), H.rtr_inputs()
+    loss, ppo, teacher, dprob, grads = ocr.rtr_loss_and_grads(sd, inp["probability"], inp["r_pad"], inp["trajectory"], inp["teacher_infos"],
+                                                              inp["state"], inp["action_mode"], inp["advantage"], inp["old_log_prob"],
+                                                              inp["reward_sum"])
+    assert abs(float(loss) - float(gold["loss"])) < 1e-5 and abs(float(ppo) - float(gold["ppo_loss"])) < 1e-6
+    assert abs(float(teacher) - float(gold["teacher_loss"])) < 1e-6
+    assert np.abs(dprob.numpy() - gold["dloss_dprob"]).max() < 1e-6
+    n = 0
+    for k in ocr.CRITIC_KEYS:
+        assert np.abs(grads[k].numpy() - gold["grad." + k]).max() < 1e-5, k
+        n += 1
+    assert n == 10
+
+
 def test_traj_flag_oracle_envelope_and_raster_semantics():
     """oracle/traj_flags.py (unpinned restatement of the STRtree envelope query and the raster lookup): touching envelopes collide,
     an empty neighbour list gives zeros with the candidate's step count, pixels round half to even and points off the raster are
@@ -45,6 +64,19 @@ def test_traj_flag_oracle_envelope_and_raster_semantics():
     pts = np.array([[[-94.75, 0.0], [-94.25, 0.0], [-94.5, 0.0], [1e4, 0.0]]], dtype=np.float32)   # pixels 10.5 -> 10, 11.5 -> 12, 11, outside
     off = otf.get_off_road_matrix(pts, mask, origin=(0.0, 0.0), angle=0.0)
     assert off.tolist() == [[True, True, False, False]]
+
+
+def test_traj_flag_oracle_against_hand_derived_known_answers():
+    """oracle/traj_flags.py against tests/golden/traj_flags_kat.json: 20 collision and 22 off-road cases derived by hand from the
+    documented semantics of what the reference calls (STRtree.query without predicate = inclusive envelope intersection; np.round half
+    to even; y axis flipped by the negative resolution; outside the raster = not off road) -- each case carries its reasoning."""
+    from oracle import traj_flags as otf
+    col, mask, off = H.traj_flag_kat()
+    assert len(col) >= 20 and len(off) >= 20
+    for name, center, others, want in col:
+        assert bool(otf.get_collision_matrix(center, others)[0, 0]) == want, name
+    for name, pt, origin, heading, want in off:
+        assert bool(otf.get_off_road_matrix(pt, mask, origin, heading)[0, 0]) == want, name
 
 
 def test_other_vehicle_rollout_oracle_matches_reference_fixture():
