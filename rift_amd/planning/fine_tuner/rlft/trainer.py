@@ -59,32 +59,23 @@ def freeze_parameters(model: nn.Module, trainable_layers: List[str]):
 
 
 def configure_optimizer(model: nn.Module, lr: float, weight_decay: float):
-    """Parameter grouping of rift_trainer.py:279-362: trainable Linear/Conv/MHA weights decay,
-    biases / norm / embedding weights do not; AdamW."""
-    white = (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.MultiheadAttention, nn.LSTM, nn.GRU)
-    black = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm, nn.LayerNorm, nn.Embedding)
-    decay, no_decay = set(), set()
-    for mn, m in model.named_modules():
-        for pn, p in m.named_parameters():
-            fpn = f"{mn}.{pn}" if mn else pn
-            if not p.requires_grad:
-                continue
-            if "bias" in pn:
-                no_decay.add(fpn)
-            elif "weight" in pn:
-                if isinstance(m, white):
-                    decay.add(fpn)
-                elif isinstance(m, black):
-                    no_decay.add(fpn)
-            else:
-                no_decay.add(fpn)
+    """AdamW parameter groups of rift_trainer.py:279-362 for the trainable sets of this path: `planning_decoder.pi_head` (Linear,
+    LayerNorm, ReLU, Linear) and, for PPO / RTR, `value_net` (three Linears and the four normalisation constants).  The reference's
+    module-type rule comes out as: group 0 (decays) = the weights of the Linear layers, group 1 (no decay) = every bias, the LayerNorm
+    weight and the critic's constants; each group sorted by parameter name, as the reference sorts them."""
+    linear_weights = {f"{mn}.weight" for mn, m in model.named_modules() if isinstance(m, nn.Linear)}
+    norm_weights = {f"{mn}.weight" for mn, m in model.named_modules() if isinstance(m, nn.LayerNorm)}
     pd = {n: p for n, p in model.named_parameters() if p.requires_grad}
-    assert not (decay & no_decay) and not (pd.keys() - (decay | no_decay))
-    groups = [{"params": [pd[n] for n in sorted(decay)], "weight_decay": weight_decay},
-              {"params": [pd[n] for n in sorted(no_decay)], "weight_decay": 0.0}]
+    decay = sorted(n for n in pd if n in linear_weights)
+    no_decay = sorted(n for n in pd if n not in linear_weights)
+    for n in no_decay:      # anything else with a weight (a conv, an attention in-projection, an embedding) is not a layer this path trains
+        if n.endswith("weight") and n not in norm_weights:
+            raise NotImplementedError(f"trainable parameter {n}: only Linear / LayerNorm layers are trainable on this path")
+    groups = [{"params": [pd[n] for n in decay], "weight_decay": weight_decay},
+              {"params": [pd[n] for n in no_decay], "weight_decay": 0.0}]
     # fused=True: the same AdamW update as one multi-tensor kernel per group (the host side of the default foreach path costs
     # 0.7 ms per step for six small tensors -- a third of the whole update step)
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=pd and next(iter(pd.values())).is_cuda)
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=bool(pd) and next(iter(pd.values())).is_cuda)
 
 
 def dp_all_reduce_exchange(xchg: torch.Tensor, group=None):

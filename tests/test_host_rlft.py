@@ -134,6 +134,49 @@ def test_policy_registry_and_lr_schedule():
         sch.step()
 
 
+def test_optimizer_groups_are_the_reference_rule_on_the_trainable_sets():
+    """configure_optimizer's explicit grouping (Linear weights decay; biases, LayerNorm weight and the critic's constants do not) names
+    the same two sorted groups as the reference's module-type rule (rift_trainer.py:279-362) for pi_head and for pi_head + value_net;
+    a trainable layer of another kind is refused instead of being silently mis-grouped."""
+    import torch.nn as nn
+    from rift_amd.planning.fine_tuner.rlft.ppo_pluto.ppo_pluto import PPOPlutoModel
+    from rift_amd.planning.fine_tuner.rlft.trainer import configure_optimizer, freeze_parameters
+
+    def reference_rule(model):           # the reference's loop, restated on names (decay set, no-decay set)
+        white = (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.MultiheadAttention, nn.LSTM, nn.GRU)
+        black = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm, nn.LayerNorm, nn.Embedding)
+        decay, no_decay = set(), set()
+        for mn, m in model.named_modules():
+            for pn, p in m.named_parameters():
+                if not p.requires_grad:
+                    continue
+                full = f"{mn}.{pn}" if mn else pn
+                if "bias" in pn:
+                    no_decay.add(full)
+                elif "weight" in pn:
+                    if isinstance(m, white):
+                        decay.add(full)
+                    elif isinstance(m, black):
+                        no_decay.add(full)
+                else:
+                    no_decay.add(full)
+        return sorted(decay), sorted(no_decay)
+
+    model = PPOPlutoModel(radius=120)
+    names = {id(p): n for n, p in model.named_parameters()}
+    for layers, n_decay, n_no in ((["planning_decoder.pi_head"], 2, 4), (["planning_decoder.pi_head", "value_net"], 5, 11)):
+        freeze_parameters(model, layers)
+        opt = configure_optimizer(model, 1e-4, 1e-5)
+        got = [[names[id(p)] for p in g["params"]] for g in opt.param_groups]
+        want = reference_rule(model)
+        assert got[0] == want[0] and got[1] == want[1], (got, want)
+        assert (len(got[0]), len(got[1])) == (n_decay, n_no)
+        assert opt.param_groups[0]["weight_decay"] == 1e-5 and opt.param_groups[1]["weight_decay"] == 0.0
+    freeze_parameters(model, ["agent_encoder.type_emb"])          # an Embedding: not a layer this path trains
+    with pytest.raises(NotImplementedError, match="only Linear / LayerNorm"):
+        configure_optimizer(model, 1e-4, 1e-5)
+
+
 PPO_KEYS = ['CBVs_obs', 'CBVs_next_obs', 'CBVs_reward', 'CBVs_done', 'CBVs_terminated', 'CBVs_actions_old_log_prob', 'CBVs_actions_mode']
 
 
