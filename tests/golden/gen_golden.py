@@ -509,6 +509,86 @@ def gen_normalize():
     print("normalize ->", path, f"{os.path.getsize(path) / 1e3:.1f} KB", len(out), "arrays")
 
 
+def _flatten_feature(prefix, data, out):
+    for k, v in data.items():
+        if isinstance(v, dict):
+            _flatten_feature(f"{prefix}/{k}", v, out)
+        elif isinstance(v, (np.ndarray, np.generic, float, int)):
+            out[f"{prefix}/{k}"] = np.asarray(v)
+        elif isinstance(v, list) and all(isinstance(x, (str, int, np.integer)) for x in v):
+            out[f"{prefix}/{k}"] = np.asarray([str(x) for x in v])
+
+
+def gen_feature_builder():
+    """PlutoFeatureBuilder as the reference runs it (pluto/feature_builder/pluto_feature_builder.py:30-401): its methods are compiled in
+    memory (the module's top imports CARLA), bound to an object that carries the reference's own __init__ results, and run on the recorded
+    readings of tests.helpers.feature_builder_world -- CarlaDataProvider, the map API and the route planner are the recorded objects,
+    the enums are the reference's own (nuplan_plugin), PlutoFeature.normalize and CostMapManager are the reference's own classes.
+    OpenCV is absent here: cv2.fillPoly / fillConvexPoly are tests.helpers.bbox_fill on BOTH sides (the fills are injected callables
+    in the mirror), so the fixture pins the raster geometry, the distance transform and the float16 cast, not OpenCV's scan conversion."""
+    import ast
+    import importlib
+    import types
+    import warnings
+    from tests.helpers import bbox_fill, feature_builder_world
+    ref_loader.install()
+    for name in ("geopandas", "numba", "shapely", "carla"):
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["geopandas"], "GeoDataFrame"):
+        sys.modules["geopandas"].GeoDataFrame = object          # (maps_datatypes.py:15 only aliases the type)
+    sh = sys.modules["shapely"]
+    if not hasattr(sh, "Point"):
+        class _P:                                   # query-point stand-in: the recorded map ignores it
+            def __init__(self, *xy):
+                self.xy = xy
+        sh.Point, sh.Polygon, sh.LineString = _P, object, object
+        sys.modules["shapely.geometry"] = types.ModuleType("shapely.geometry")
+        sys.modules["shapely.geometry"].Point, sys.modules["shapely.geometry"].Polygon = _P, object
+    cv2 = sys.modules["cv2"]
+    cv2.fillPoly = lambda mask, pts, value: [bbox_fill(mask, p, value) for p in pts]
+    cv2.fillConvexPoly = lambda mask, pts, value: bbox_fill(mask, pts, value)
+    from nuplan_plugin.actor_state.tracked_objects_types import TrackedObjectType
+    from nuplan_plugin.maps.maps_datatypes import SemanticMapLayer, TrafficLightStatusType
+    # the map-utils module is CARLA / geopandas bound: the cost-map manager only names its CarlaMap type
+    mu = types.ModuleType("rift.cbv.planning.pluto.utils.nuplan_map_utils")
+    mu.CarlaMap = object
+    for pkg in ("rift.cbv.planning.pluto", "rift.cbv.planning.pluto.utils"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(ref_loader.REF_ROOT, *pkg.split("."))]
+            sys.modules[pkg] = m
+    sys.modules["rift.cbv.planning.pluto.utils.nuplan_map_utils"] = mu
+    cmm = importlib.import_module("rift.cbv.planning.pluto.utils.cost_map_manager")
+    pf = importlib.import_module("rift.cbv.planning.pluto.feature_builder.pluto_feature")
+    # (rotate_round_z_axis is @numba.njit in the reference; numba is absent here: the decorator becomes the identity, the body runs as numpy)
+    rot = _ref_function("rift/cbv/planning/pluto/feature_builder/common.py", "rotate_round_z_axis",
+                        {"numba": types.SimpleNamespace(njit=lambda f: f)})
+    B_ = "rift/cbv/planning/pluto/feature_builder/pluto_feature_builder.py"
+    out = {}
+    for case in ("busy", "alone"):
+        w = feature_builder_world(case, agent_type=lambda n: TrackedObjectType[n], layer=lambda n: SemanticMapLayer[n])
+        ns = {"np": np, "TrackedObjectType": TrackedObjectType, "SemanticMapLayer": SemanticMapLayer, "TrafficLightStatusType": TrafficLightStatusType,
+              "CarlaDataProvider": w.provider, "rotate_round_z_axis": rot, "Point": sh.Point, "LineString": sh.LineString, "warnings": warnings,
+              "CostMapManager": cmm.CostMapManager, "PlutoFeature": pf.PlutoFeature, "List": list, "Set": set, "CarlaAgentState": object,
+              "CarlaMap": object, "Point2D": object, "carla": types.SimpleNamespace(Vehicle=object), "CBVRoutePlanner": object}
+        tree = ast.parse(open(os.path.join(ref_loader.REF_ROOT, B_)).read())
+        cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "PlutoFeatureBuilder")
+        exec(compile(ast.Module(body=[cls], type_ignores=[]), B_, "exec"), ns)          # the class as written, names resolved from `ns`
+        builder = ns["PlutoFeatureBuilder"](w.config, w.planner)
+        feature, route_ids, lines, elements, wp = builder.build_feature(w.center, w.nearby, mode=w.mode)
+        _flatten_feature(case, feature.data, out)
+        out[f"{case}/route_road_ids"] = np.asarray(route_ids["road_ids"])
+        out[f"{case}/n_lines"] = np.asarray(len(lines))
+    path = os.path.join(HERE, "feature_builder.npz")
+    np.savez_compressed(path, **out)
+    print("feature_builder ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", len(out), "arrays;",
+          {k: v.shape for k, v in out.items() if k.endswith(("agent/position", "map/point_position", "reference_line/position", "cost_maps"))})
+
+
 def gen_rtr():
     """RTR objective as the reference computes it: LightningTrainer._compute_objectives / get_ppo_loss / get_teacher_loss /
     generate_target_label of fine_tuner/sft/rtr_pluto/rtr_trainer.py:130-255 compiled in memory, with the reference's CriticPPO
@@ -597,6 +677,8 @@ def gen_buffer():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "buffer":
         gen_buffer()
+    elif len(sys.argv) > 1 and sys.argv[1] == "feature_builder":
+        gen_feature_builder()
     elif len(sys.argv) > 1 and sys.argv[1] == "rtr":
         gen_rtr()
     elif len(sys.argv) > 1 and sys.argv[1] == "normalize":
@@ -623,3 +705,4 @@ if __name__ == "__main__":
         gen_sft()
         gen_buffer()
         gen_rtr()
+        gen_feature_builder()

@@ -294,3 +294,106 @@ def traj_flag_kat():
     off = [(c["name"], np.asarray(c["point"], dtype=np.float32).reshape(1, 1, 2), tuple(c["origin"]), float(c["heading"]), bool(c["expect"]))
            for c in doc["off_road"]]
     return col, mask, off
+
+
+# ---- recorded CARLA readings for the feature builder (tests/golden/feature_builder.npz) ---------------------------------------------------
+def _ns(**kw):
+    import types
+    return types.SimpleNamespace(**kw)
+
+
+def _pose(x, y, heading):
+    return _ns(x=float(x), y=float(y), heading=float(heading), array=np.array([x, y], dtype=np.float64))
+
+
+def _vec(x, y):
+    return _ns(x=float(x), y=float(y), array=np.array([x, y], dtype=np.float64))
+
+
+def _ring(xy):
+    """Duck-typed shapely polygon: `.exterior.coords.xy` = (xs, ys)."""
+    xy = np.asarray(xy, dtype=np.float64)
+    return _ns(exterior=_ns(coords=_ns(xy=(xy[:, 0], xy[:, 1]))))
+
+
+def bbox_fill(mask, vertices, value):
+    """The deterministic raster fill both sides of the cost-map fixture use in place of OpenCV (absent here): the vertices' bounding box."""
+    v = np.asarray(vertices).reshape(-1, 2)
+    x0, x1 = max(int(v[:, 0].min()), 0), min(int(v[:, 0].max()), mask.shape[1] - 1)
+    y0, y1 = max(int(v[:, 1].min()), 0), min(int(v[:, 1].max()), mask.shape[0] - 1)
+    if x0 <= x1 and y0 <= y1:
+        mask[y0:y1 + 1, x0:x1 + 1] = value
+
+
+def feature_builder_world(case: str, agent_type=lambda n: n, layer=lambda n: n):
+    """Seeded recorded readings of one CBV tick, as the reference's PlutoFeatureBuilder asks CarlaDataProvider / the map API / the route
+    planner for them.  `agent_type` / `layer` turn the names 'VEHICLE', 'LANE', ... into the objects a side wants (the reference's
+    enums for gen_golden, plain strings for the mirror).  Cases:
+      'busy'  : 4 neighbours = max_agent (one pedestrian, one with a 7-step history, distances not in list order), 5 lanes + 2 lane
+                connectors + 2 crosswalks (one lane far outside the +-radius crop, one repeated on-route road), 3 reference lines of
+                61 / 500 / 9 route points, mode train_cbv (cost maps);
+      'alone' : no neighbours, 2 lanes, one reference line of 3 points (nothing valid after the every-4th subsampling), mode eval."""
+    g = np.random.default_rng({"busy": 9001, "alone": 9002}[case])
+    T, P = 21, 20
+    cx, cy, th = (212.25, -31.5, 0.7) if case == "busy" else (-40.0, 18.75, -2.1)
+
+    def agent_history(n, x0, y0, kind, width, length):
+        out = []
+        for t in range(n):
+            x, y, h = x0 + 0.4 * t + g.normal(0, 0.02), y0 + 0.1 * t + g.normal(0, 0.02), 0.3 + 0.01 * t
+            box = _ns(width=width, length=length, geometry=_ring([[x - 1, y - 2], [x + 1, y - 2], [x + 1, y + 2], [x - 1, y + 2], [x - 1, y - 2]]))
+            ag = _ns(center=_pose(x, y, h), velocity=_vec(g.normal(4, 1), g.normal(0, 0.3)), box=box, tracked_object_type=agent_type(kind))
+            out.append(_ns(agent_state=ag, center=_pose(x, y, h)))
+        return out
+
+    def center_history():
+        out = []
+        for t in range(T + 4):                         # longer than needed: the builder keeps the last 21
+            x, y, h = cx - 0.5 * (T + 3 - t), cy - 0.1 * (T + 3 - t), th + 0.004 * (t - T)
+            dyn = _ns(rear_axle_velocity_2d=_vec(g.normal(5, 0.5), g.normal(0, 0.2)), rear_axle_acceleration_2d=_vec(g.normal(0, 0.4), g.normal(0, 0.1)),
+                      angular_velocity=float(g.normal(0, 0.05)), speed=5.0, center_velocity_2d=_vec(5.0, 0.0))
+            out.append(_ns(rear_axle=_pose(x, y, h), center=_pose(x + 1.4 * np.cos(h), y + 1.4 * np.sin(h), h), dynamic_car_state=dyn,
+                           tire_steering_angle=float(g.normal(0, 0.03))))
+        return out
+
+    center = _ns(id=100, bounding_box=_ns(extent=_ns(x=2.45, y=1.05, z=0.8)))
+    hist = {100: center_history()}
+    nearby = []
+    if case == "busy":
+        for i, (dx, dy, kind, n) in enumerate([(30.0, 5.0, "VEHICLE", T + 2), (-6.0, 2.0, "PEDESTRIAN", T), (12.0, -9.0, "VEHICLE", 7), (3.0, 40.0, "BICYCLE", T)]):
+            a = _ns(id=200 + i, bounding_box=_ns(extent=_ns(x=2.0, y=0.9, z=0.7)))
+            nearby.append(a)
+            hist[a.id] = agent_history(n, cx + dx, cy + dy, kind, 1.8 + 0.1 * i, 4.2 + 0.2 * i)
+
+    def lane(token, ox, oy, road_id):
+        base = np.stack([ox + np.linspace(0, 38, P + 1), oy + 0.02 * np.linspace(0, 38, P + 1) ** 1.5], -1) + g.normal(0, 0.01, (P + 1, 2))
+        edges = np.stack([base, base + np.array([0.0, 1.75]), base - np.array([0.0, 1.75])])         # (3, P + 1, 2): centre, left, right
+        ring = np.concatenate([edges[1], edges[2][::-1], edges[1][:1]])
+        return _ns(token_id=str(token), centerline=base, edges=edges, road_id=str(road_id), polygon=_ring(ring), speed_limit_mps=None if token % 2 else 8.33)
+
+    def crosswalk(token, ox, oy):
+        base = np.stack([ox + np.zeros(P + 1), oy + np.linspace(0, 6, P + 1)], -1)
+        return _ns(token_id=str(token), edges=np.stack([base, base + np.array([1.5, 0.0]), base - np.array([1.5, 0.0])]))
+
+    if case == "busy":
+        objects = {layer("LANE"): [lane(11, cx - 20, cy - 3, 7), lane(12, cx + 10, cy + 4, 8), lane(13, cx + 500, cy, 9), lane(14, cx - 60, cy + 30, 7),
+                                   lane(15, cx - 5, cy - 40, 3)],
+                   layer("LANE_CONNECTOR"): [lane(21, cx + 15, cy - 12, 8), lane(22, cx - 90, cy - 70, 5)],
+                   layer("CROSSWALK"): [crosswalk(31, cx + 8, cy - 2), crosswalk(32, cx - 30, cy + 12)]}
+        road_ids = [7, 8]
+        lines = []
+        for n, lat in ((61, 0.0), (500, 3.5), (9, -3.5)):
+            s_ = np.arange(n) * 0.25
+            lines.append(np.stack([cx + s_ * np.cos(th) - lat * np.sin(th), cy + s_ * np.sin(th) + lat * np.cos(th), th + 0.002 * s_], -1))
+        mode = "train_cbv"
+    else:
+        objects = {layer("LANE"): [lane(41, cx - 10, cy - 1, 2), lane(42, cx + 5, cy + 6, 4)], layer("LANE_CONNECTOR"): [], layer("CROSSWALK"): []}
+        road_ids = [4]
+        lines = [np.array([[cx, cy, th], [cx + 0.2, cy, th], [cx + 0.4, cy, th]])]
+        mode = "eval"
+    map_api = _ns(map_sample_points=P, speed_limit_mps=8.33, query_proximal_map_data=lambda point, radius: objects)
+    provider = _ns(get_history_state=lambda actor: hist[actor.id], get_current_state=lambda actor: hist[actor.id][-1],
+                   get_frame_rate=lambda: 10, get_map_api=lambda: map_api)
+    planner = _ns(build_reference_line=lambda c, st, r: (lines, ["route-elements"], {"road_ids": road_ids, "lane_ids": [1, 2]}, ["interaction-wp"]))
+    config = {"obs": {"max_agent": 4, "radius": 120, "history_horizon": 2}}
+    return _ns(config=config, provider=provider, planner=planner, center=center, nearby=nearby, mode=mode)
