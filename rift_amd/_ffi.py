@@ -94,19 +94,20 @@ CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
                "state_avg", "state_std", "value_avg", "value_std")
 
-_lib = None
+_libs = {}
 
 
-def load_library() -> C.CDLL:
-    """Load librift_hip.so; raise loudly when it is absent (no fallback path exists)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(variant: str = "") -> C.CDLL:
+    """Load librift_hip.so (variant "stats": librift_hip_stats.so, the diagnostic twin with the drop-decision counters of
+    csrc/dropstats.h); raise loudly when it is absent (no fallback path exists)."""
+    if variant in _libs:
+        return _libs[variant]
+    path = LIB_PATH if not variant else LIB_PATH.replace("librift_hip.so", f"librift_hip_{variant}.so")
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). rift_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise RuntimeError(f"librift_hip.so does not export {name}")
@@ -155,7 +156,7 @@ def load_library() -> C.CDLL:
     for name in EXPORTS:
         if name not in ("rift_ctx_destroy", "rift_last_error"):
             getattr(lib, name).restype = C.c_int
-    _lib = lib
+    _libs[variant] = lib
     return lib
 
 
@@ -220,14 +221,15 @@ def feature_batch(data: Dict, device) -> (RiftFeatureBatch, list):
 class Engine:
     """One RiftCtx bound to one device + the torch tensors it borrows."""
 
-    def __init__(self, device=None, operands: str = "bf16"):
-        """operands: "bf16" | "fp16" -- the MFMA operand format of the fused kernels (forward(fp32=True) ignores it)."""
+    def __init__(self, device=None, operands: str = "bf16", variant: str = ""):
+        """operands: "bf16" | "fp16" -- the MFMA operand format of the fused kernels (forward(fp32=True) ignores it).
+        variant: "" | "stats" (the diagnostic library; bf16 operands only)."""
         if operands not in OPERANDS:
             raise ValueError(f"operands must be one of {sorted(OPERANDS)}, got {operands!r}")
         if not torch.cuda.is_available():
             raise RuntimeError("rift_amd.Engine needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
-        self.lib = load_library()
+        self.lib = load_library(variant)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.ctx = vp()
         self.operands = operands

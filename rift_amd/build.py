@@ -14,6 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librift_hip.so")
+LIB_STATS = os.path.join(HERE, "librift_hip_stats.so")     # diagnostic twin (build_stats): the bf16 build with the drop-decision counters of csrc/dropstats.h
 OBJ = os.path.join(HERE, "_obj")
 
 # Translation units of one engine build.  The wave-private streaming kernels are built with `-fno-honor-nans -mno-amdgpu-ieee`: no
@@ -42,15 +43,17 @@ def sources():
                   + [os.path.join(os.path.dirname(HERE), "include", "rift_hip.h"), os.path.abspath(__file__)])
 
 
-def compile_commands(extra=()):
-    """[(object path, command)] of every translation unit of the library; `extra` is appended to each hipcc command."""
+def compile_commands(extra=(), stats=False):
+    """[(object path, command)] of every translation unit of the library; `extra` is appended to each hipcc command.
+    stats=True: the diagnostic twin -- the bf16-operand build only, compiled with -DRIFT_DROP_STATS=1."""
     cmds = []
-    for tag, f16 in FORMATS:
+    sfx, defs = ("_st", ["-DRIFT_DROP_STATS=1"]) if stats else ("", [])
+    for tag, f16 in (FORMATS[:1] if stats else FORMATS):
         for unit, flags in UNITS:
-            o = os.path.join(OBJ, f"{unit}_{tag}.o")
-            cmds.append((o, [hipcc()] + COMMON + [f"-DRIFT_OP_F16={f16}", "-c"] + flags + [os.path.join(CSRC, unit + ".hip"), "-o", o] + list(extra)))
-    o = os.path.join(OBJ, "abi.o")
-    cmds.append((o, [hipcc()] + COMMON + ["-x", "hip", "-c", os.path.join(CSRC, "abi.cpp"), "-o", o] + list(extra)))
+            o = os.path.join(OBJ, f"{unit}_{tag}{sfx}.o")
+            cmds.append((o, [hipcc()] + COMMON + defs + [f"-DRIFT_OP_F16={f16}", "-c"] + flags + [os.path.join(CSRC, unit + ".hip"), "-o", o] + list(extra)))
+    o = os.path.join(OBJ, f"abi{sfx}.o")
+    cmds.append((o, [hipcc()] + COMMON + (["-DRIFT_ABI_BF16_ONLY=1"] if stats else []) + ["-x", "hip", "-c", os.path.join(CSRC, "abi.cpp"), "-o", o] + list(extra)))
     return cmds
 
 
@@ -75,12 +78,18 @@ def check_resources(remarks: str, spill_safe: bool):
         raise RuntimeError("kernel resource check failed (build the unit with SPILL_SAFE or remove the spills):\n  " + "\n  ".join(bad))
 
 
-def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
+def build_stats(force: bool = False, verbose: bool = True) -> str:
+    """librift_hip_stats.so: what tests/test_gpu_dropstats.py loads to check the train-mode dropout / DropPath / state-dropout decisions."""
+    return build(force, verbose, stats=True)
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int = 0, stats: bool = False) -> str:
     srcs = sources()
+    LIB = LIB_STATS if stats else globals()["LIB"]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
-    cmds = compile_commands(extra=["-Rpass-analysis=kernel-resource-usage"])
+    cmds = compile_commands(extra=["-Rpass-analysis=kernel-resource-usage"], stats=stats)
 
     def run(item):
         o, cmd = item
@@ -102,3 +111,4 @@ def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
 
 if __name__ == "__main__":
     build(force=True)
+    build_stats(force=True)

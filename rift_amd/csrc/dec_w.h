@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "opfmt.h"
+#include "dropstats.h"
 
 namespace RIFT_NS {
 
@@ -69,6 +70,7 @@ struct DecWP {
   float dropout; uint32_t seed, stream;
   int dbg;                      // diagnostic: 1 = skip all compute (weight stream + barriers only), 8 = no stream, 16 = all eight waves carry the stream
   long long* ts;                // optional: clock of wave 0 of workgroup 0 at every group boundary (diagnostic, RIFT_DEC_TS)
+  DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 
 // host entry points of the dec_w.hip translation unit (see build.py)

@@ -112,6 +112,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   DecWRng rng;
 #pragma unroll
   for (int i = 0; i < 4; ++i) rng.x[i] = hash32(p.seed, p.stream + i, (uint32_t)(b * 512 + tid)) | 1u;
+#if RIFT_DROP_STATS
+  int dsite = 0;                                 // which of the eight dropout sites of a layer the next keep4() calls belong to
+  unsigned int dkept[RIFT_DS_DEC_SITES] = {0, 0, 0, 0, 0, 0, 0, 0}, ddrawn[RIFT_DS_DEC_SITES] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DSITE(s) dsite = (s)
+#else
+#define DSITE(s)
+#endif
   int tsn = 0;
 #define DTS() do { if (p.ts && b == 0 && tid == 0 && tsn < 120) p.ts[tsn++] = clock64(); } while (0)
 
@@ -248,6 +255,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int i0 = (2 * site) & 3, i1 = (2 * site + 1) & 3;
     const uint32_t h0 = rng.x[i0] = decw_step(rng.x[i0]), h1 = rng.x[i1] = decw_step(rng.x[i1]);
     const unsigned short t = (unsigned short)thr16;         // 16-bit compares on the register halves: no extraction instructions
+#if RIFT_DROP_STATS
+    ddrawn[dsite] += 4;
+    dkept[dsite] += ((unsigned short)h0 < t ? 0 : 1) + ((unsigned short)(h0 >> 16) < t ? 0 : 1) + ((unsigned short)h1 < t ? 0 : 1) + ((unsigned short)(h1 >> 16) < t ? 0 : 1);
+#endif
     return (f32x4){((unsigned short)h0 < t) ? 0.f : dpk, ((unsigned short)(h0 >> 16) < t) ? 0.f : dpk, ((unsigned short)h1 < t) ? 0.f : dpk, ((unsigned short)(h1 >> 16) < t) ? 0.f : dpk};
   };
   // 16 x 16 self-attention of the tile, per head, entirely in registers: S^T = K Q^T (lane: 4 keys of query l15), O^T = V^T P^T.
@@ -391,16 +402,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         gemm_v(0, xb, vf, parE + DECW_E_BR2R + 256);
         if (DENSE) {     // keys 4 l4 .. + 3 = reference lines of mode tileA: the quirk's padded lines are masked
           const float4 mk = *reinterpret_cast<const float4*>(qmaskf + tileA * NS + l4 * 4);
+          DSITE(0);
           self_attention((f32x4){mk.x, mk.y, mk.z, mk.w}, qf, kf, vf, ao);
         } else {         // keys 4 l4 .. + 3 = reference lines (l4 & 1) * 4 .. of mode 2 tileA + (l4 >> 1): other-mode keys are masked as well
           const float4 mk = *reinterpret_cast<const float4*>(qmaskf + (2 * tileA + (l4 >> 1)) * NS + (l4 & 1) * 4);
           const bool cross = (l4 >> 1) != a_sub;
           const float ninf = -INFINITY;
+          DSITE(0);
           self_attention((f32x4){cross ? ninf : mk.x, cross ? ninf : mk.y, cross ? ninf : mk.z, cross ? ninf : mk.w}, qf, kf, vf, ao);
         }
         init8(acc, parE + DECW_E_BR2RO);
         bnd(li, pa + 3);                                        // ---- r2r out_proj, residual, hand-over to the reference-line tiling
         gemm(1, ao, acc);
+        DSITE(1);
         residual(res, acc);
         write_xs(res, a_row, a_ok);
       } else {
@@ -431,10 +445,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         to_heads(acc, kf);
         bnd(li, pb + 2);                                        // ---- m2m v + attention over the modes
         gemm_v(0, xb, vf, parE + DECW_E_BM2MV);
+        DSITE(2);
         { const float mk = l4 == 3 ? -INFINITY : 0.f; self_attention((f32x4){mk, mk, mk, mk}, qf, kf, vf, ao); }   // keys 12..15 are padding slots
         init8(acc, parE + DECW_E_BM2MO);
         bnd(li, pb + 3);                                        // ---- m2m out_proj, residual, padded lines zeroed (:70-72), LayerNorm
         gemm(1, ao, acc);
+        DSITE(3);
         residual(res, acc);
         if (rz[tileB]) zero8(res);
         layer_norm(res, xb, parL + DECW_L_LN3);
@@ -442,6 +458,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bnd(li, pb + 4);                                        // ---- cross q
         gemm(0, xb, acc);
         to_heads(acc, qf);
+        DSITE(4);
         if (DENSE) {                                            // ---- the scene's K | V^T: one group per head (DENSE) / per head pair
 #pragma unroll
           for (int h = 0; h < 4; ++h) { bnd(li, pb + 5 + h); cross_heads((5 + h) & 1, h, std::integral_constant<int, 1>{}, qf, ao); }
@@ -452,8 +469,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         init8(acc, parL + DECW_L_BCO);
         bnd(li, pb + KO);                                       // ---- cross out_proj, residual, LayerNorm for the FFN
         gemm(KO & 1, ao, acc);
+        DSITE(5);
         residual(res, acc);
         layer_norm(res, xb, parL + DECW_L_LN4);
+        DSITE(6);
         f32x4 acc2[8];
         init8(acc2, parL + DECW_L_BF2);
 #pragma unroll 1
@@ -476,6 +495,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           bnd(li, pb + KO + 2 + 2 * hc);
           gemm(KO & 1, hb, acc2);
         }
+        DSITE(7);
         residual(res, acc2);
         if (DENSE || li + 1 < 4) write_xs(res, b_row, b_ok);
         else if (b_ok) {
@@ -492,6 +512,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   DTS();
 #undef DTS
+#undef DSITE
+#if RIFT_DROP_STATS
+  if (DROP && p.ds.elem) {
+    for (int s = 0; s < RIFT_DS_DEC_SITES; ++s) {
+      atomicAdd(&p.ds.elem[2 * s], (unsigned long long)dkept[s]);
+      atomicAdd(&p.ds.elem[2 * s + 1], (unsigned long long)ddrawn[s]);
+    }
+    if (b == 0 && tid == 0) for (int s = 0; s < RIFT_DS_DEC_SITES; ++s) p.ds.scale[RIFT_DS_SITES + s] = dpk;
+  }
+#endif
 }
 
 

@@ -17,6 +17,7 @@ struct EgoP {
   int bs;
   float drop_p;                      // state dropout probability (0 = off): tokens 3..5 are masked with this probability
   uint32_t seed, stream;
+  DropStats ds;                      // diagnostic build only (dropstats.h)
 };
 
 __global__ __launch_bounds__(256) void ego_fused_kernel(EgoP p) {
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256) void ego_fused_kernel(EgoP p) {
   for (int i = tid; i < 10 * 128; i += 256) e[(6 + (i >> 7)) * ES + (i & 127)] = 0;
   for (int i = tid; i < 16 * 128; i += 256) ao[(i >> 7) * ES + (i & 127)] = 0;
   if (tid < 6) msk[tid] = (p.drop_p > 0.f && tid >= 3 && uniform01(p.seed, p.stream, (uint32_t)(b * 6 + tid)) < p.drop_p) ? 1 : 0;
+  if (tid < 6 && p.drop_p > 0.f) ds_sample(p.ds, RIFT_DS_EGO, b * 6 + tid, msk[tid] ? 0.f : 1.f);      // (a masked key, no rescaling: agent_encoder.py:119-129)
   __syncthreads();
   {
     f32x4 acc[1][4];

@@ -7,6 +7,7 @@
 // L2 as MFMA B fragments requested one phase ahead.  Replaces ~44 launches and ~1 GB of HBM traffic per step.
 #pragma once
 #include "common.h"
+#include "dropstats.h"
 
 namespace RIFT_NS {
 
@@ -40,6 +41,7 @@ struct EncFusedP {
                                 // keys >= N undefined, masked by the decoder)
   const unsigned short* wx0;    // cat_x_proj columns 128:256 (planning_decoder.py:177-179), applied to the scene's ego token (row 0)
   float* x0p;                   // (bs, 128)
+  DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 
 // row-gather weight packer: dst[r][k] = bf16(src[idx[r]][k]); bias_out[r] = bias[idx[r]]
@@ -174,6 +176,8 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
     if (w.droppath > 0.f) {
       dpscale = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)b) < w.droppath) ? 0.f : 1.0f / (1.0f - w.droppath);
       dpscale2 = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)b) < w.droppath) ? 0.f : 1.0f / (1.0f - w.droppath);
+      ds_sample(p.ds, RIFT_DS_ENC(bi, 0), b, dpscale);
+      ds_sample(p.ds, RIFT_DS_ENC(bi, 1), b, dpscale2);
     }
     par_commit();
     lds_barrier();

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "opfmt.h"
+#include "dropstats.h"
 
 namespace RIFT_NS {
 
@@ -50,6 +51,7 @@ struct EncWP {
                                 // dense layout), projected from the final output while it is still in registers (planning_decoder.py:74-79)
   const unsigned short* img; const float* par;
   float droppath[4]; uint32_t seed, stream;
+  DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 
 int encw_set_attributes();

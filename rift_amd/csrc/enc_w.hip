@@ -187,6 +187,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (p.droppath[li] > 0.f) {
       dp1 = (uniform01(p.seed, p.stream + 2 * li, (uint32_t)b) < p.droppath[li]) ? 0.f : 1.0f / (1.0f - p.droppath[li]);
       dp2 = (uniform01(p.seed, p.stream + 2 * li + 1, (uint32_t)b) < p.droppath[li]) ? 0.f : 1.0f / (1.0f - p.droppath[li]);
+      ds_sample(p.ds, RIFT_DS_ENC(li, 0), b, dp1);
+      ds_sample(p.ds, RIFT_DS_ENC(li, 1), b, dp2);
     }
     const float* rows_in = li == 0 ? p.X : p.Y;
     // ================= pass 1: the layer's K | V^T operand fragments of every tile =================

@@ -792,6 +792,26 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     launch(c, "dp_kpm_fill_kernel", dp_kpm_fill_kernel, dim3(cdiv(f.kb, 256)), dim3(256), 0, (const uint8_t*)r_kpm, nL, c->dp.off * R, f.kb, c->dp.xchg);
     q_kpm = f.g_rkpm; q_bs = c->dp.gbs; q_off = c->dp.off;
   }
+#if RIFT_DROP_STATS      // diagnostic build (dropstats.h): the counters of this forward's stochastic decisions, readable as taps afterwards
+  DropStats ds; memset(&ds, 0, sizeof(ds));
+  if (f.drop) {
+    ds.nmax = std::max(nA, bs * 6);
+    const size_t n = (size_t)RIFT_DS_SITES * ds.nmax;
+    ds.cnt = A_alloc<unsigned int>(c, n); ds.any = A_alloc<unsigned int>(c, n); ds.all = A_alloc<unsigned int>(c, n);
+    ds.scale = A_alloc<float>(c, RIFT_DS_SITES + RIFT_DS_DEC_SITES); ds.elem = A_alloc<unsigned long long>(c, 2 * RIFT_DS_DEC_SITES);
+    if (!c->dry) {
+      HIPCHK(c, hipMemsetAsync(ds.cnt, 0, n * 4, c->stream)); HIPCHK(c, hipMemsetAsync(ds.any, 0, n * 4, c->stream));
+      HIPCHK(c, hipMemsetAsync(ds.all, 0xff, n * 4, c->stream));
+      HIPCHK(c, hipMemsetAsync(ds.scale, 0, (RIFT_DS_SITES + RIFT_DS_DEC_SITES) * 4, c->stream));
+      HIPCHK(c, hipMemsetAsync(ds.elem, 0, 2 * RIFT_DS_DEC_SITES * 8, c->stream));
+    }
+    tap(c, "drop_cnt", (float*)ds.cnt, (int64_t)n); tap(c, "drop_any", (float*)ds.any, (int64_t)n); tap(c, "drop_all", (float*)ds.all, (int64_t)n);
+    tap(c, "drop_scale", ds.scale, RIFT_DS_SITES + RIFT_DS_DEC_SITES); tap(c, "drop_elem", (float*)ds.elem, 4 * RIFT_DS_DEC_SITES);
+  }
+#define RIFT_SET_DS(x) (x).ds = ds
+#else
+#define RIFT_SET_DS(x)
+#endif
   static const float dpr[6] = {0.f, 0.04f, 0.08f, 0.12f, 0.16f, 0.2f};   // linspace(0, 0.2, 6), embedding.py:30
   const bool fused = c->nat_fused && !f.fp32;
   // fork: the agent-history chain depends on prep_kernel only and joins at the token assembly; on its own stream it fills the CUs the
@@ -821,6 +841,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         q.F9 = F9; q.nseq = nA; q.img = c->l0w_img; q.par = c->l0w_par; q.Oc = Oc[0]; q.Ocb = Ocb[0]; q.Xnext = Xin[1];
         { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 1) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         q.droppath[0] = f.drop ? dpr[0] : 0.f; q.droppath[1] = f.drop ? dpr[1] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
+        RIFT_SET_DS(q);
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + 2.0 * rows * 27 * 32 + (rows / 2) * 2.0 * 3 * C * 2 * C;
         launch(c, "nat_l0w_kernel", nat_l0w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid)), dim3(64 * L0W_NWV), (size_t)L0W_LDS, q);
         continue;
@@ -829,6 +850,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         NatL1WP q; memset(&q, 0, sizeof(q));
         q.X = Xin[1]; q.nseq = nA; q.img = c->l1w_img; q.par = c->l1w_par; q.Oc = Oc[1]; q.Ocb = Ocb[1]; q.Xnext = Xin[2];
         q.droppath[0] = f.drop ? dpr[2] : 0.f; q.droppath[1] = f.drop ? dpr[3] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
+        RIFT_SET_DS(q);
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (rows / 2) * 2.0 * 3 * C * 2 * C;
         launch(c, "nat_l1w_kernel", nat_l1w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid)), dim3(512), (size_t)L1W_LDS, q);
         continue;
@@ -837,6 +859,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         NatL2WP q; memset(&q, 0, sizeof(q));
         q.X = Xin[2]; q.nseq = nA; q.img = c->l2w_img; q.par = c->l2w_par; q.Oc = Oc[2]; q.Ocb = Ocb[2];
         q.droppath[0] = f.drop ? dpr[4] : 0.f; q.droppath[1] = f.drop ? dpr[5] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
+        RIFT_SET_DS(q);
         { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 3) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C);
         const int l2grid = std::min(cdiv(cdiv(nA, 3), 8), c->nat_grid);
@@ -924,6 +947,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     q.wkv = (const unsigned short*)c->pw[EG + ".attn.kv"].bf; q.bkv = c->pw[EG + ".attn.kv"].bias; q.q = eq;
     q.wo = (const unsigned short*)c->pw[EG + ".attn.out_proj"].bf; q.bo = c->pw[EG + ".attn.out_proj"].bias;
     q.out = x_ego; q.bs = bs; q.drop_p = f.drop ? 0.75f : 0.f; q.seed = f.seed; q.stream = f.drop ? f.next_stream() : 0;
+    RIFT_SET_DS(q);
     c->prof_flops = 2.0 * bs * (6.0 * 128 * 256 + 128.0 * 128);
     launch(c, "ego_fused_kernel", ego_fused_kernel, dim3(bs), dim3(256), 0, q);
   } else {
@@ -1049,6 +1073,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       w.droppath = f.drop ? edpr[i] : 0.f;
     }
     ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias");
+    RIFT_SET_DS(ep);
     if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
     if (c->dec_fused && R <= 8 && ENC_NW == 8) {   // the decoder kernel will run: emit its cross-attention K | V operand fragments here
@@ -1067,6 +1092,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     eq.img = c->encw_img; eq.par = c->encw_par;
     if (c->dec_fused && R <= 16) { enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 96 * 512); eq.DKV = enc_KT; }   // the decoder's (dense-variant) operands
     for (int i = 0; i < 4; ++i) eq.droppath[i] = f.drop ? edpr[i] : 0.f;
+    RIFT_SET_DS(eq);
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
     launch_call(c, "enc_w_kernel", [&] { encw_launch(eq, c->stream); });
   } else {
@@ -1146,6 +1172,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
     dq.stream = f.next_stream(); f.stream_id += 64;
     dq.KV = enc_KT; dq.img = c->decw_img; dq.par = c->decw_par;
+    RIFT_SET_DS(dq);
     if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
     { const char* ev = getenv("RIFT_DEC_DBG"); dq.dbg = ev ? atoi(ev) : 0; }
     c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
@@ -1287,6 +1314,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (f.need_traj && out->ref_free_trajectory)
     mlp_layer(f, ENC, N * 128, bs, "ref_free_decoder", out->ref_free_trajectory, 320, f.fp32);
 
+#undef RIFT_SET_DS
   if (!c->dry) {
     c->last_qfinal = QF; c->last_hpi = Hpi; c->last_prob = prob; c->last_rkpm = r_kpm; c->last_bs = bs; c->last_R = R;
   }

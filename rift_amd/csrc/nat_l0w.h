@@ -18,6 +18,7 @@
 // No workgroup barrier after the prologue.
 #pragma once
 #include "common.h"
+#include "dropstats.h"
 #include "wp_stream.h"
 
 namespace RIFT_NS {
@@ -105,6 +106,7 @@ struct NatL0WP {
   float* Xnext;                            // (nseq * 10, 64) downsample conv + LayerNorm
   float droppath[2]; uint32_t seed, stream;
   long long* ts;                           // optional section timestamps of wave 0 of workgroup 0 (diagnostic, RIFT_NAT_TS=1)
+  DropStats ds;                            // diagnostic build only (dropstats.h)
 };
 
 template <int CTRL>
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
       // other half is zero
       float dps = 1.f;
       if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+      if (p.droppath[bi] > 0.f) ds_sample(p.ds, RIFT_DS_NAT(0, bi, 0), seq_ok ? seq : -1, dps);
       const h16x8 wp0 = W(fb + 6), wp1 = W(fb + 7);
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
         const float4 b0 = *reinterpret_cast<const float4*>(pb + L0W_PB_B2 + l4 * 4), b1 = *reinterpret_cast<const float4*>(pb + L0W_PB_B2 + 16 + l4 * 4);
         float dps = 1.f;
         if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+        if (p.droppath[bi] > 0.f) ds_sample(p.ds, RIFT_DS_NAT(0, bi, 1), seq_ok ? seq : -1, dps);
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
           x[mt][0] += (acc2[mt][0] + (f32x4){b0.x, b0.y, b0.z, b0.w}) * dps;

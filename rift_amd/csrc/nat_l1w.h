@@ -89,6 +89,7 @@ struct NatL1WP {
   unsigned short* Ocb;                     // if set: the same rows as bf16 instead (what fpn_tail_kernel rounds them to anyway: half the bytes both ways)
   float* Xnext;                            // (nseq * 5, 128) downsample conv + LayerNorm
   float droppath[2]; uint32_t seed, stream;
+  DropStats ds;                            // diagnostic build only (dropstats.h)
 };
 
 // LayerNorm over the 64 channels of every row (16 per lane, 4 lanes per row) -> bf16 operands of the two k-steps
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
       l1w_layer_norm(x, xn, pb + L1W_PB_LN1G, pb + L1W_PB_LN1B, l4);
       float dps = 1.f;
       if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+      if (p.droppath[bi] > 0.f) ds_sample(p.ds, RIFT_DS_NAT(1, bi, 0), seq_ok ? seq : -1, dps);
 #pragma unroll 1
       for (int h = 0; h < 4; ++h) {
         f32x4 k[3], v[3];
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
         }
         float dp2 = 1.f;
         if (p.droppath[bi] > 0.f) dp2 = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+        if (p.droppath[bi] > 0.f) ds_sample(p.ds, RIFT_DS_NAT(1, bi, 1), seq_ok ? seq : -1, dp2);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const float4 b4 = *reinterpret_cast<const float4*>(pb + L1W_PB_B2 + nt * 16 + l4 * 4);

@@ -149,6 +149,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (p.droppath[bi] > 0.f) {
         dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
         dp2 = (uniform01(p.seed, p.stream + 2 * bi + 1, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
+        ds_sample(p.ds, RIFT_DS_NAT(2, bi, 0), row_ok ? seq : -1, dps);
+        ds_sample(p.ds, RIFT_DS_NAT(2, bi, 1), row_ok ? seq : -1, dp2);
       }
       // ---- group 0: q
       layer_norm(res, xb, pb + L2W_PB_LN1);
