@@ -280,7 +280,7 @@ def main():
         shard = (rank * local_bs, global_bs)
 
         def step(i):
-            fb, b = replay.collate(eng, idx[i % nsteps])
+            fb, b = replay.collate(eng, idx[i % nsteps], slot=trainer.next_slot())     # (two batch-buffer sets: step k's tail runs beside step k + 1's gather + trunk)
             return trainer.training_step(fb, b, shard=shard)
 
         def timed(first, count):
@@ -335,6 +335,7 @@ def main():
                     k += 1
                 trainer.pop_mean_loss()
                 for vi in val_idx:
+                    trainer.wait_update()
                     fb, b = replay.collate(eng, vi)
                     trainer.validation_step(fb, b)
                 trainer.on_epoch_end()

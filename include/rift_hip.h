@@ -34,7 +34,12 @@ enum {
   RIFT_F_NEED_TRAJ  = 2,   /* also produce trajectory / prediction / ref_free_trajectory (unused by the RLFT losses) */
   RIFT_F_FP32       = 4,   /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), layer by layer, instead of the fused 16-bit-operand kernels */
   RIFT_F_NO_DROP    = 8,   /* with TRAIN: every drop probability 0 (BatchNorm batch statistics only) */
-  RIFT_F_NO_BN_UPDATE = 16 /* with TRAIN: do not update BatchNorm running statistics */
+  RIFT_F_NO_BN_UPDATE = 16,/* with TRAIN: do not update BatchNorm running statistics */
+  RIFT_F_DEFER_HEAD = 32   /* stop in front of the policy head: everything up to the decoder output reads frozen weights only, so the caller
+                              may run rift_forward_head + rift_loss_backward + its optimizer step on ANOTHER stream while the next
+                              rift_forward (the trunk of the next minibatch) is already under way.  Deferred forwards alternate between
+                              two activation arenas; before the forward after next the caller must know the deferred head and
+                              rift_loss_backward of this one to be finished (an event wait) */
 };
 
 /* loss kinds */
@@ -148,6 +153,10 @@ int rift_model_load(RiftCtx* ctx, const RiftTensorDesc* params, int n, void* str
 /* PlanningModel.forward (pluto_model.py:122-225). */
 int rift_forward(RiftCtx* ctx, const RiftFeatureBatch* batch, const RiftOutputs* out, int flags,
                  uint32_t seed, void* stream);
+
+/* The policy head of the last RIFT_F_DEFER_HEAD forward (cat_x_proj -> pi_head -> masked logits -> `probability`, and the trajectory heads
+ * when they were requested), launched on `stream`; the caller orders it behind that forward (event).  rift_loss_backward then refers to it. */
+int rift_forward_head(RiftCtx* ctx, void* stream);
 
 /* ---- data parallelism (absent in the reference: one device, custom_lightning.yaml:26,43) ----
  * A minibatch of `global_bs` scenes is split contiguously over the ranks; this rank's rift_forward receives scenes

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librift_hip.so")
 
 # forward flags / loss kinds (include/rift_hip.h)
-F_TRAIN, F_NEED_TRAJ, F_FP32, F_NO_DROP, F_NO_BN_UPDATE = 1, 2, 4, 8, 16
+F_TRAIN, F_NEED_TRAJ, F_FP32, F_NO_DROP, F_NO_BN_UPDATE, F_DEFER_HEAD = 1, 2, 4, 8, 16, 32
 LOSS_KINDS = {"rift": 0, "grpo": 1, "ppo": 2, "reinforce": 3, "sft": 4}
 PI_NPARAM = 16897
 
@@ -83,7 +83,7 @@ class RiftRolloutIO(C.Structure):
 
 OPERANDS = {"bf16": 0, "fp16": 1}       # RIFT_OPERANDS_* of include/rift_hip.h: the 16-bit MFMA operand format of a context's fused kernels
 EXPORTS = [
-    "rift_ctx_create", "rift_ctx_create_ex", "rift_ctx_operand_format", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_loss_backward",
+    "rift_ctx_create", "rift_ctx_create_ex", "rift_ctx_operand_format", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_forward_head", "rift_loss_backward",
     "rift_loss_finalize", "rift_loss_finalize_clip", "rift_set_param_event", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
@@ -120,6 +120,7 @@ def load_library(variant: str = "") -> C.CDLL:
     lib.rift_last_error.restype = C.c_char_p
     lib.rift_model_load.argtypes = [vp, C.POINTER(RiftTensorDesc), C.c_int, vp]
     lib.rift_forward.argtypes = [vp, C.POINTER(RiftFeatureBatch), C.POINTER(RiftOutputs), C.c_int, C.c_uint32, vp]
+    lib.rift_forward_head.argtypes = [vp, vp]
     lib.rift_loss_backward.argtypes = [vp, C.c_int, C.POINTER(RiftLossIn), C.POINTER(RiftLossOut), vp]
     lib.rift_loss_finalize.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, vp]
     lib.rift_set_param_event.argtypes = [vp, vp]
@@ -312,6 +313,12 @@ class Engine:
         if rc != 0:
             self._check(rc, "rift_forward")
         self._bs = fb.bs
+
+    def forward_head(self):
+        """The policy head of the last F_DEFER_HEAD forward, on the current stream (the caller has ordered it behind that forward)."""
+        rc = self.lib.rift_forward_head(self.ctx, _stream())
+        if rc != 0:
+            self._check(rc, "rift_forward_head")
 
     def loss_backward_raw(self, kind: int, li: RiftLossIn, lo: RiftLossOut):
         rc = self.lib.rift_loss_backward(self.ctx, kind, C.byref(li), C.byref(lo), _stream())

@@ -62,8 +62,16 @@ struct RiftCtx {
   std::vector<void*> owned;          // packed weight allocations
   struct WConst { float* p = nullptr; bool ready = false; };
   std::unordered_map<std::string, WConst> wconst;   // activations that depend on (frozen) weights only, computed once per model load
-  // activation arena (bump allocator, reset every forward)
+  // activation arena (bump allocator, reset every forward).  A forward with RIFT_F_DEFER_HEAD alternates between two arenas, so that the
+  // policy head / loss / backward of step k (rift_forward_head, rift_loss_backward on another stream) read step k's activations while the
+  // frozen trunk of step k + 1 already writes its own.
   char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
+  char* arenas[2] = {nullptr, nullptr}; size_t arena_caps[2] = {0, 0}; int parity = 0;
+  struct Head {   // what the policy head of a forward needs (pi_forward .. trajectory heads); kept per arena for the deferred form
+    bool valid = false, fp32 = false, need_traj = false;
+    float *Q = nullptr, *x0p = nullptr, *QF = nullptr, *Hpi = nullptr, *prob = nullptr, *traj = nullptr, *o3[3] = {nullptr, nullptr, nullptr}, *oT[3] = {nullptr, nullptr, nullptr};
+    uint8_t* r_kpm = nullptr; int bs = 0, R = 0, nQ = 0;
+  } head[2];
   bool dry = false;
   hipStream_t stream = nullptr;
   std::unordered_map<std::string, Tap> taps;
@@ -745,6 +753,62 @@ __global__ void interleave_traj_kernel(const float* __restrict__ loc, const floa
   out[idx] = src[(size_t)r * 160 + t * 2 + (c6 & 1)];
 }
 
+// The policy head of a forward: cat_x_proj -> pi_head (read LIVE: the only trainable parameters) -> masked logits, then the trajectory
+// heads on its q_final.  Launched on c->stream; leaves what rift_loss_backward consumes.
+int head_impl(RiftCtx* c, const RiftCtx::Head& h) {
+  const std::string PD = "planning_decoder";
+  const int nQ = h.nQ, R = h.R, M = 12;
+  Fwd f; f.c = c; f.fp32 = h.fp32; f.need_traj = h.need_traj; f.train = f.drop = f.bn_update = false; f.seed = 0;
+  // Everything before reads frozen, load-time-packed weights only; pi_head.* is read LIVE from here on.  A host that updates pi_head on
+  // another stream (all-reduce + clip + AdamW of the previous step) hands over the event that marks the update's end.
+  if (c->param_event && !c->dry) HIPCHK(c, hipStreamWaitEvent(c->stream, c->param_event, 0));
+  if (!h.fp32 && c->pi_fused) {
+    // cat_x_proj (bf16) -> pi_head first Linear (exact fp32, live parameters) -> LayerNorm -> ReLU -> Linear -> masked logits: one launch
+    PiFwdP q; memset(&q, 0, sizeof(q));
+    q.Q = h.Q; q.rows = nQ; q.rows_per_scene = R * M;
+    q.wq = (const unsigned short*)c->pw[PD + ".cat_x_proj.q"].bf; q.bq = c->pw[PD + ".cat_x_proj.q"].bias; q.x0p = h.x0p;
+    q.w1 = fptr(c, PD + ".pi_head.mlp.0.weight"); q.b1 = fptr(c, PD + ".pi_head.mlp.0.bias");
+    q.lng = fptr(c, PD + ".pi_head.mlp.1.weight"); q.lnb = fptr(c, PD + ".pi_head.mlp.1.bias");
+    q.w2 = fptr(c, PD + ".pi_head.mlp.3.weight"); q.b2 = fptr(c, PD + ".pi_head.mlp.3.bias");
+    q.r_kpm = h.r_kpm; q.M = M; q.eps = 1e-5f; q.QF = h.QF; q.Hpi = h.Hpi; q.prob = h.prob; q.nonfinite = c->nonfinite;
+    c->prof_flops = 2.0 * nQ * (2.0 * 128 * 128 + 128);
+    launch(c, "pi_forward_kernel", pi_forward_kernel, dim3(cdiv(nQ, PI_ROWS)), dim3(512), (size_t)PI_LDS, q);
+  } else {
+    GemmP g = mk(h.Q, 128, nQ, c->pw[PD + ".cat_x_proj.q"], h.QF, 128);
+    g.gbias = h.x0p; g.gb_div = R * M; g.gb_mod = 0;
+    gemm(c, g, c->pw[PD + ".cat_x_proj.q"], h.fp32);
+    // pi head: first Linear straight from the live (trainable) fp32 parameters, exact-fp32 MFMA
+    PW w; w.N = 128; w.K = 128; w.Kp = 128; w.Npad = 128;
+    w.f32 = (float*)fptr(c, PD + ".pi_head.mlp.0.weight"); w.bias = fptr(c, PD + ".pi_head.mlp.0.bias");
+    gemm(c, mk(h.QF, 128, nQ, w, h.Hpi, 128), w, true);
+    launch(c, "pi_tail_kernel", pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)h.Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
+           fptr(c, PD + ".pi_head.mlp.1.bias"), fptr(c, PD + ".pi_head.mlp.3.weight"), fptr(c, PD + ".pi_head.mlp.3.bias"),
+           (const uint8_t*)h.r_kpm, 1e-5f, h.prob, c->nonfinite);
+  }
+  tap(c, "q_final", h.QF, (int64_t)nQ * 128);
+  if (h.need_traj && !h.fp32 && c->heads_fused) {
+    const std::string nm3[3] = {PD + ".loc_head", PD + ".yaw_head", PD + ".vel_head"};
+    heads3_fused(f, h.QF, 128, nQ, 0, 0, 0, nm3, h.traj);
+  } else if (h.need_traj) {
+    const char* nm[3] = {"loc_head", "yaw_head", "vel_head"};
+    for (int i = 0; i < 3; ++i) {      // MLPLayer(128, 256, 160) as in mlp_layer(), on the buffers the trunk reserved
+      const PW& w0 = c->pw[PD + "." + nm[i] + ".mlp.0"];
+      const PW& w3 = c->pw[PD + "." + nm[i] + ".mlp.3"];
+      float* T = h.oT[i];
+      gemm(c, mk(h.QF, 128, nQ, w0, T, w0.N), w0, h.fp32);
+      GemmP g = mk(T, w0.N, nQ, w3, h.o3[i], 160);
+      g.pro = PRO_LN; g.pg = fptr(c, PD + "." + nm[i] + ".mlp.1.weight"); g.pb = fptr(c, PD + "." + nm[i] + ".mlp.1.bias"); g.pro_relu = 1;
+      gemm(c, g, w3, h.fp32);
+    }
+    launch(c, "interleave_traj_kernel", interleave_traj_kernel, dim3(cdiv((long long)nQ * 480, 256)), dim3(256), 0, (const float*)h.o3[0], (const float*)h.o3[1],
+           (const float*)h.o3[2], nQ, h.traj);
+  }
+  if (!c->dry) {
+    c->last_qfinal = h.QF; c->last_hpi = h.Hpi; c->last_prob = h.prob; c->last_rkpm = h.r_kpm; c->last_bs = h.bs; c->last_R = h.R;
+  }
+  return RIFT_OK;
+}
+
 int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, int flags, uint32_t seed) {
   Fwd f;
   f.c = c; f.train = (flags & RIFT_F_TRAIN) != 0; f.drop = f.train && !(flags & RIFT_F_NO_DROP);
@@ -1260,49 +1324,19 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     x0p = A_alloc<float>(c, (size_t)bs * 128);
     gemm(c, mk(ENC, N * 128, bs, c->pw[PD + ".cat_x_proj.x"], x0p, 128), c->pw[PD + ".cat_x_proj.x"], f.fp32);
   }
-  float* QF = A_alloc<float>(c, (size_t)nQ * 128);
-  float* Hpi = A_alloc<float>(c, (size_t)nQ * 128);
-  float* prob = out->probability ? out->probability : A_alloc<float>(c, nQ);
-  // Everything above reads frozen, load-time-packed weights only; pi_head.* is read LIVE from here on.  A host that updates pi_head on
-  // another stream (all-reduce + clip + AdamW of the previous step) hands over the event that marks the update's end.
-  if (c->param_event && !c->dry) HIPCHK(c, hipStreamWaitEvent(c->stream, c->param_event, 0));
-  if (!f.fp32 && c->pi_fused) {
-    // cat_x_proj (bf16) -> pi_head first Linear (exact fp32, live parameters) -> LayerNorm -> ReLU -> Linear -> masked logits: one launch
-    PiFwdP q; memset(&q, 0, sizeof(q));
-    q.Q = Q; q.rows = nQ; q.rows_per_scene = R * M;
-    q.wq = (const unsigned short*)c->pw[PD + ".cat_x_proj.q"].bf; q.bq = c->pw[PD + ".cat_x_proj.q"].bias; q.x0p = x0p;
-    q.w1 = fptr(c, PD + ".pi_head.mlp.0.weight"); q.b1 = fptr(c, PD + ".pi_head.mlp.0.bias");
-    q.lng = fptr(c, PD + ".pi_head.mlp.1.weight"); q.lnb = fptr(c, PD + ".pi_head.mlp.1.bias");
-    q.w2 = fptr(c, PD + ".pi_head.mlp.3.weight"); q.b2 = fptr(c, PD + ".pi_head.mlp.3.bias");
-    q.r_kpm = r_kpm; q.M = M; q.eps = 1e-5f; q.QF = QF; q.Hpi = Hpi; q.prob = prob; q.nonfinite = c->nonfinite;
-    c->prof_flops = 2.0 * nQ * (2.0 * 128 * 128 + 128);
-    launch(c, "pi_forward_kernel", pi_forward_kernel, dim3(cdiv(nQ, PI_ROWS)), dim3(512), (size_t)PI_LDS, q);
-  } else {
-    GemmP g = mk(Q, 128, nQ, c->pw[PD + ".cat_x_proj.q"], QF, 128);
-    g.gbias = x0p; g.gb_div = R * M; g.gb_mod = 0;
-    gemm(c, g, c->pw[PD + ".cat_x_proj.q"], f.fp32);
-    // pi head: first Linear straight from the live (trainable) fp32 parameters, exact-fp32 MFMA
-    PW w; w.N = 128; w.K = 128; w.Kp = 128; w.Npad = 128;
-    w.f32 = (float*)fptr(c, PD + ".pi_head.mlp.0.weight"); w.bias = fptr(c, PD + ".pi_head.mlp.0.bias");
-    gemm(c, mk(QF, 128, nQ, w, Hpi, 128), w, true);
-    launch(c, "pi_tail_kernel", pi_tail_kernel, dim3(cdiv(nQ, 4)), dim3(256), 0, (const float*)Hpi, nQ, M, fptr(c, PD + ".pi_head.mlp.1.weight"),
-           fptr(c, PD + ".pi_head.mlp.1.bias"), fptr(c, PD + ".pi_head.mlp.3.weight"), fptr(c, PD + ".pi_head.mlp.3.bias"),
-           (const uint8_t*)r_kpm, 1e-5f, prob, c->nonfinite);
-  }
-  tap(c, "q_final", QF, (int64_t)nQ * 128);
-  if (f.need_traj && out->trajectory && !f.fp32 && c->heads_fused) {
-    const std::string nm3[3] = {PD + ".loc_head", PD + ".yaw_head", PD + ".vel_head"};
-    heads3_fused(f, QF, 128, nQ, 0, 0, 0, nm3, out->trajectory);
-  } else if (f.need_traj && out->trajectory) {
-    float* o3[3];
-    const char* nm[3] = {"loc_head", "yaw_head", "vel_head"};
-    for (int i = 0; i < 3; ++i) {
-      o3[i] = A_alloc<float>(c, (size_t)nQ * 160);
-      mlp_layer(f, QF, 128, nQ, PD + "." + nm[i], o3[i], 160, f.fp32);
-    }
-    launch(c, "interleave_traj_kernel", interleave_traj_kernel, dim3(cdiv((long long)nQ * 480, 256)), dim3(256), 0, (const float*)o3[0], (const float*)o3[1],
-           (const float*)o3[2], nQ, out->trajectory);
-  }
+  // ---- the policy head (and the trajectory heads that read its q_final): right here, or -- RIFT_F_DEFER_HEAD -- later through
+  // rift_forward_head on a stream of the caller's choice, so that it (and the loss / backward / update behind it) runs beside the next
+  // forward's frozen trunk
+  RiftCtx::Head hs;
+  hs.valid = true; hs.fp32 = f.fp32; hs.need_traj = f.need_traj && out->trajectory != nullptr; hs.Q = Q; hs.x0p = x0p; hs.r_kpm = r_kpm;
+  hs.bs = bs; hs.R = R; hs.nQ = nQ; hs.traj = out->trajectory;
+  hs.QF = A_alloc<float>(c, (size_t)nQ * 128);
+  hs.Hpi = A_alloc<float>(c, (size_t)nQ * 128);
+  hs.prob = out->probability ? out->probability : A_alloc<float>(c, nQ);
+  if (hs.need_traj && (f.fp32 || !c->heads_fused))      // layer-wise trajectory heads: their buffers come out of this forward's arena
+    for (int i = 0; i < 3; ++i) { hs.oT[i] = A_alloc<float>(c, (size_t)nQ * 256); hs.o3[i] = A_alloc<float>(c, (size_t)nQ * 160); }
+  if (flags & RIFT_F_DEFER_HEAD) { if (!c->dry) c->head[c->parity] = hs; }
+  else TRY(head_impl(c, hs));
   // hidden_proj / ref_free_decoder on the ego token (pluto_model.py:173-180)
   if (out->hidden) {
     float* Th = A_alloc<float>(c, (size_t)bs * 128);
@@ -1315,9 +1349,6 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     mlp_layer(f, ENC, N * 128, bs, "ref_free_decoder", out->ref_free_trajectory, 320, f.fp32);
 
 #undef RIFT_SET_DS
-  if (!c->dry) {
-    c->last_qfinal = QF; c->last_hpi = Hpi; c->last_prob = prob; c->last_rkpm = r_kpm; c->last_bs = bs; c->last_R = R;
-  }
   return RIFT_OK;
 }
 
@@ -1360,7 +1391,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
 void rift_ctx_destroy(RiftCtx* c) {
   if (!c) return;
   for (void* p : c->owned) (void)hipFree(p);
-  if (c->arena) (void)hipFree(c->arena);
+  for (int i = 0; i < 2; ++i) if (c->arenas[i]) (void)hipFree(c->arenas[i]);
   if (c->l_S) (void)hipFree(c->l_S);
   if (c->l_cnt) (void)hipFree(c->l_cnt);
   if (c->l_dz) (void)hipFree(c->l_dz);
@@ -1619,6 +1650,10 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (B->bs <= 0 || B->A <= 0 || B->Mp <= 0 || B->R <= 0 || B->S < 0 || B->T < 21) { c->err = "bad batch dims"; return RIFT_ERR_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   c->stream = (hipStream_t)stream;
+  // deferred-head forwards alternate between the two arenas (the caller guarantees that the head / loss of the forward before last is over,
+  // i.e. that this arena is free again); every other forward runs in arena 0
+  c->parity = (flags & RIFT_F_DEFER_HEAD) ? (c->parity ^ 1) : 0;
+  c->arena = c->arenas[c->parity]; c->arena_cap = c->arena_caps[c->parity];
   // pass 1 (dry): size the activation arena; pass 2: launch
   c->dry = true; c->arena_off = 0;
   int rc = forward_impl(c, B, out, flags, seed);
@@ -1633,12 +1668,29 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     HIPCHK(c, hipMalloc((void**)&c->arena, cap));
     c->arena_cap = cap;
   }
+  c->arenas[c->parity] = c->arena; c->arena_caps[c->parity] = c->arena_cap;
   c->dry = false; c->arena_off = 0; c->taps.clear();
   // diagnostic: RIFT_POISON_ARENA=<byte> fills the scratch arena before every forward (0xFF = NaN pattern), so that a kernel reading
   // scratch it never wrote shows up as NaN / as run-to-run differences instead of depending on what the memory held before
   { const char* pe = getenv("RIFT_POISON_ARENA"); if (pe && c->arena) HIPCHK(c, hipMemsetAsync(c->arena, (int)strtol(pe, nullptr, 0) & 0xff, c->arena_cap, c->stream)); }
   rc = forward_impl(c, B, out, flags, seed);
   c->stream = (hipStream_t)stream;
+  if (rc != RIFT_OK) return rc;
+  if (!c->err.empty()) return RIFT_ERR_ARG;
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+int rift_forward_head(RiftCtx* c, void* stream) {
+  if (!c) return RIFT_ERR_ARG;
+  c->err.clear();
+  if (!c->head[c->parity].valid) { c->err = "rift_forward_head without a RIFT_F_DEFER_HEAD forward"; return RIFT_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const hipStream_t trunk_stream = c->stream;
+  c->stream = (hipStream_t)stream; c->dry = false;
+  const int rc = head_impl(c, c->head[c->parity]);
+  c->head[c->parity].valid = false;
+  c->stream = trunk_stream;
   if (rc != RIFT_OK) return rc;
   if (!c->err.empty()) return RIFT_ERR_ARG;
   HIPCHK(c, hipGetLastError());

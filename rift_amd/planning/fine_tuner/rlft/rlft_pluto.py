@@ -204,7 +204,9 @@ class RLFTPluto(PLUTO):
 
         def run(batch, train):
             idx_dev, R_out, shard = batch
-            fb, b = replay.collate(eng, idx_dev, R_out)
+            # training steps alternate between two batch-buffer sets: the tail of step k (policy head .. AdamW) runs beside the gather and
+            # trunk of step k + 1 (RLFTTrainer.next_slot); validation joins the update stream first and uses slot 0
+            fb, b = replay.collate(eng, idx_dev, R_out, slot=trainer.next_slot() if train else 0)
             if extras:
                 b = dict(b)
                 for k, v in extras.items():

@@ -219,6 +219,15 @@ class RLFTTrainer:
             self._ev_param = torch.cuda.Event()
             self._ev_param.record(torch.cuda.current_stream(dev))            # creates the handle; a passed event is a no-op wait
             self.engine.set_param_event(self._ev_param)
+        # Deferred tail (RIFT_PIPELINE=0 switches it off): with the caller taking its batch buffers by `next_slot()`, the WHOLE tail of a step
+        # -- policy head, loss, pi_head backward, exchange, finalize, clip, AdamW -- runs on the update stream beside the next step's
+        # gather and frozen trunk (rift_forward with RIFT_F_DEFER_HEAD + rift_forward_head; two activation arenas, two batch-buffer sets).
+        self.pipeline = self.overlap_update and os.environ.get("RIFT_PIPELINE", "1") == "1" and kind in ("rift", "grpo", "reinforce")
+        self._slot, self._slot_taken = 0, False
+        if self.pipeline:
+            self._ev_tail = [torch.cuda.Event(), torch.cuda.Event()]         # end of the tail that read slot / arena i
+            for e in self._ev_tail:
+                e.record(torch.cuda.current_stream(dev))
 
     # ------------------------------------------------------------------------------------
     def _outputs(self, bs, R):
@@ -313,6 +322,17 @@ class RLFTTrainer:
         self._exchange_and_finalize(backward, clip_val)
         return self.loss
 
+    def forward_trunk(self, fb: "_ffi.RiftFeatureBatch", shard=None):
+        """The frozen part of a training forward (everything up to the decoder output) on the current stream; the policy head follows through
+        Engine.forward_head() wherever the caller orders it."""
+        self._A = fb.A
+        self._outputs(fb.bs, fb.R)
+        self._set_shard(fb, shard)
+        flags = _ffi.F_TRAIN | _ffi.F_DEFER_HEAD | (_ffi.F_NEED_TRAJ if getattr(self.model, "need_traj", False) else 0) | \
+            (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0)
+        self.step_count += 1
+        self.engine.forward_raw(fb, self.out, flags, (self.seed_base + self.step_count) & 0xFFFFFFFF)
+
     def _exchange_and_finalize(self, backward: bool, clip_val: Optional[float], accumulate: int = 0, with_critic: bool = True,
                                count_scale: float = 1.0):
         eng = self.engine
@@ -352,6 +372,17 @@ class RLFTTrainer:
         self.loss = self.loss_val if k is None else self.loss_hist[k:k + 1]
         self.lo.loss = self.loss.data_ptr()
 
+    def next_slot(self) -> int:
+        """Batch-buffer slot of the NEXT training step (pass it to DeviceReplay.collate).  Calling it is what enables the deferred tail:
+        the current stream first waits until the tail that last read this slot (two steps ago) is over, then the caller may overwrite
+        the slot's buffers while the previous step's tail is still running."""
+        if not self.pipeline:
+            return 0
+        self._slot ^= 1
+        self._slot_taken = True
+        torch.cuda.current_stream().wait_event(self._ev_tail[self._slot])
+        return self._slot
+
     def training_step(self, fb, extras, shard=None):
         """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step).  Returns the device f64 loss
         scalar; with overlap_update it is written on the update stream -- read it through pop_mean_loss() / wait_update()."""
@@ -361,6 +392,29 @@ class RLFTTrainer:
             self.loss_acc.add_(self.loss_hist.sum())
         self._loss_slot(k)
         fused_clip = bool(self.gradient_clip_val) and self.critic is None
+        if self.pipeline and self._slot_taken:
+            # trunk on the current stream, everything behind it on the update stream (which is serial in itself: head k waits for AdamW k-1)
+            self._slot_taken = False
+            slot = self._slot
+            self.forward_trunk(fb, shard)
+            main = torch.cuda.current_stream()
+            self._ev_loss.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ev_loss)
+                self.engine.forward_head()
+                for t in extras.values():         # per-step tensors (buffer-wide extras indexed by the minibatch) are read on this stream:
+                    if torch.is_tensor(t) and t.is_cuda:      # keep the caching allocator from recycling them under it
+                        t.record_stream(self._side)
+                self.set_loss_inputs(extras)
+                self.engine.loss_backward_raw(self.kind_id, self.li, self.lo)
+                self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
+                self._optimizer_step()
+                self._ev_param.record(self._side)
+                self._ev_tail[slot].record(self._side)
+            self.loss_n += 1
+            return self.loss
+        if self.pipeline:                   # a step without next_slot(): the buffers are the caller's single set -- let the last tail finish first
+            self.wait_update()
         if self.overlap_update:
             self.forward_loss(fb, extras, train=True, defer_update=True, shard=shard)
             main = torch.cuda.current_stream()
@@ -461,6 +515,7 @@ class RLFTTrainer:
                                    float(self._adam_step), g0["betas"][0], g0["betas"][1], g0["eps"])
 
     def validation_step(self, fb, extras, shard=None):
+        self.wait_update()              # (a deferred tail may still be reading the activations this forward is about to overwrite)
         self._loss_slot(None)
         return self.forward_loss(fb, extras, train=False, backward=False, shard=shard)
 

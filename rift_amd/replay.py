@@ -94,8 +94,8 @@ class DeviceReplay:
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.t.values())
 
-    def _buffers(self, bs: int, R: int):
-        key = (bs, R)
+    def _buffers(self, bs: int, R: int, slot: int = 0):
+        key = (bs, R, slot)
         if key in self._out:
             return self._out[key]
         dev = self.device
@@ -119,13 +119,15 @@ class DeviceReplay:
         self._out[key] = (fb, b)
         return self._out[key]
 
-    def collate(self, engine: "_ffi.Engine", scene_idx: torch.Tensor, R_out: Optional[int] = None):
+    def collate(self, engine: "_ffi.Engine", scene_idx: torch.Tensor, R_out: Optional[int] = None, slot: int = 0):
         """Gather `scene_idx` (int32, device) into the (cached) batch buffers.
-        Returns (RiftFeatureBatch, dict of batch tensors incl. the RIFT/GRPO extras)."""
+        Returns (RiftFeatureBatch, dict of batch tensors incl. the RIFT/GRPO extras).
+        `slot`: which of the cached buffer sets to fill -- a trainer that runs the loss of step k beside the forward of step k + 1
+        (RLFTTrainer.next_slot) alternates between two, so that step k + 1's gather does not overwrite what step k's loss still reads."""
         bs = scene_idx.numel()
         if R_out is None:
             R_out = self.Rcap
-        fb, b = self._buffers(bs, R_out)
+        fb, b = self._buffers(bs, R_out, slot)
         rc = engine.lib.rift_collate(
             engine.ctx, C.byref(self.arena), C.c_void_p(scene_idx.data_ptr()), bs, R_out, C.byref(fb),
             _ffi._ptr(b["old_group_logits"]), _ffi._ptr(b["ref_group_logits"]), _ffi._ptr(b["group_advantage"]),

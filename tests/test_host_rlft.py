@@ -329,14 +329,16 @@ def test_rollout_side_inference_step():
 @pytest.mark.gpu
 def test_update_on_second_stream_equals_serial_update(tmp_path, monkeypatch):
     """RLFTTrainer.overlap_update (exchange + finalize + clip + AdamW of step k on a second stream while the frozen trunk of step k+1
-    runs; the engine waits for the update's event before reading pi_head) gives bit-identical parameters, history and checkpoint
-    losses to the serial order (RIFT_NO_OVERLAP=1): same kernels, same seeds, only the stream placement differs."""
+    runs; the engine waits for the update's event before reading pi_head) and the deferred tail on top of it (RIFT_PIPELINE: policy
+    head, loss and backward move to that stream too -- two activation arenas, two batch-buffer sets) give bit-identical parameters,
+    history and checkpoint losses to the serial order (RIFT_NO_OVERLAP=1): same kernels, same seeds, only the stream placement differs."""
     from rift_amd.planning import CBV_POLICY_LIST
     torch.cuda.set_device(0)
     results = {}
-    monkeypatch.setenv("RIFT_OVERLAP", "1")               # the two-stream order is opt-in
-    for mode in ("0", "1"):
-        monkeypatch.setenv("RIFT_NO_OVERLAP", mode)
+    monkeypatch.setenv("RIFT_OVERLAP", "1")
+    for mode, (no_overlap, pipeline) in {"0": ("0", "0"), "1": ("1", "0"), "2": ("0", "1")}.items():
+        monkeypatch.setenv("RIFT_NO_OVERLAP", no_overlap)
+        monkeypatch.setenv("RIFT_PIPELINE", pipeline)
         root = tmp_path / mode
         cfg = {'num_scenario': 1, 'ROOT_DIR': str(root), 'model_path': 'ckpt', 'device': 'cuda:0',
                'rlft': {'epochs': 3, 'warmup_epochs': 1, 'train_batch_size': 8, 'val_batch_size': 8, 'lr': 1e-3}}
@@ -354,10 +356,11 @@ def test_update_on_second_stream_equals_serial_update(tmp_path, monkeypatch):
         results[mode] = (fit["history"], {k: v.detach().cpu().clone() for k, v in pol.pluto_model.state_dict().items()
                                           if k.startswith("planning_decoder.pi_head")})
     h0, p0 = results["0"]
-    h1, p1 = results["1"]
-    assert [(h["train_loss"], h["val_loss"]) for h in h0] == [(h["train_loss"], h["val_loss"]) for h in h1]
-    for k in p0:
-        assert torch.equal(p0[k], p1[k]), k
+    for other in ("1", "2"):
+        h1, p1 = results[other]
+        assert [(h["train_loss"], h["val_loss"]) for h in h0] == [(h["train_loss"], h["val_loss"]) for h in h1], other
+        for k in p0:
+            assert torch.equal(p0[k], p1[k]), (other, k)
 
 
 @pytest.mark.gpu
