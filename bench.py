@@ -347,12 +347,15 @@ def main():
         if want_roofline:
             # roofline leg: per-launch HIP events on the launch stream (separate short pass; every rank runs the profiled steps -- they
             # contain the exchanges -- and rank 0 reports)
+            trainer.wait_update()
+            piped, trainer.pipeline = trainer.pipeline, False      # per-kernel times of serial launches: the deferred tail would run beside the next trunk
             eng.prof_enable(True)
             nprof = 4
             for i in range(nprof):
                 step(args.warmup + steps + i)
             rep = eng.prof_report()
             eng.prof_enable(False)
+            trainer.pipeline = piped
             if rank == 0:
                 tot_ms = sum(v["ms"] for v in rep.values())
                 dom = max(rep.items(), key=lambda kv: kv[1]["ms"])

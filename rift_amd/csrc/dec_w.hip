@@ -60,15 +60,18 @@ __global__ void pack_decw_kernel(DecWSrc s, unsigned short* __restrict__ img, fl
   }
 }
 
-// Dropout decisions of this kernel: per-lane xorshift32 streams (6 full-rate integer instructions per 32 random bits = two 16-bit
-// uniforms), seeded once per lane from the counter hash.  The counter hash of common.h costs three quarter-rate 32-bit multiplies per two
-// elements; at 384 dropout elements per lane and layer it was more than half of this kernel's VALU time.  Same Bernoulli(p) decisions at
-// 2^-16 resolution and the same 1/(1-p) scaling; the mask is a deterministic function of (seed, stream, scene, lane, draw order).
-// Four independent xorshift32 states per lane, used round-robin (one state's six operations are a serial chain).
+// Dropout decisions of this kernel: four per-lane 24-bit linear congruential streams, one FULL-RATE instruction per decision
+// (v_mad_u32_u24: x <- x[23:0] * A + C_i; the decision compares bits 31..16 of the result -- the middle of the 42-bit product, where
+// every state bit has mixed in -- with the 16-bit threshold p * 65536).  The round-2 form drew two decisions from one xorshift32 step (six
+// instructions, three per decision); the counter hash of common.h before it costs three quarter-rate 32-bit multiplies per two decisions.
+// At 384 decisions per lane and layer the generator was a third of this kernel's VALU work.  Same Bernoulli(p) decisions at 2^-16
+// resolution and the same 1/(1-p) scaling (tests/test_gpu_dropstats.py checks rates, scaling and independence in the kernel); the mask is a
+// deterministic function of (seed, stream, scene, lane, draw order).  A = 214013 (a = 1 mod 4: full period 2^24 with an odd increment);
+// the four states of a lane use four different odd increments, so their sequences are different affine images of the cycle, and every
+// lane starts its four at hashed positions.
 struct DecWRng { uint32_t x[4]; };
-__device__ __forceinline__ uint32_t decw_step(uint32_t x) {
-  x ^= x << 13; x ^= x >> 17; x ^= x << 5;      // xorshift32 (Marsaglia 2003), full period 2^32 - 1
-  return x;
+__device__ __forceinline__ uint32_t decw_step(uint32_t x, uint32_t c) {
+  return (x & 0xffffffu) * 214013u + c;          // both factors below 2^24: hipcc selects v_mad_u32_u24 and drops the mask (the ISA test of tools/checks counts them)
 }
 // DROP: train mode (dropout 0.1 at eight sites of every layer) -- a template parameter, so that the per-site tests are not sixteen uniform
 // branches per epilogue
@@ -251,15 +254,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_h4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]), make_uint2(0u, 0u));   // k slots 4..7 unused
   };
   // dropout multipliers of four consecutive draws: 1/(1-p) or 0
-  auto keep4 = [&](int site) -> f32x4 {        // site: compile-time call index (selects the state pair)
-    const int i0 = (2 * site) & 3, i1 = (2 * site + 1) & 3;
-    const uint32_t h0 = rng.x[i0] = decw_step(rng.x[i0]), h1 = rng.x[i1] = decw_step(rng.x[i1]);
-    const unsigned short t = (unsigned short)thr16;         // 16-bit compares on the register halves: no extraction instructions
+  auto keep4 = [&](int) -> f32x4 {
+    const uint32_t h0 = rng.x[0] = decw_step(rng.x[0], 2531011u), h1 = rng.x[1] = decw_step(rng.x[1], 1013904223u & 0xffffffu);
+    const uint32_t h2 = rng.x[2] = decw_step(rng.x[2], 12345u), h3 = rng.x[3] = decw_step(rng.x[3], 7046029u);
+    const unsigned short t = (unsigned short)thr16;         // 16-bit compares on the upper register halves: no extraction instructions
 #if RIFT_DROP_STATS
     ddrawn[dsite] += 4;
-    dkept[dsite] += ((unsigned short)h0 < t ? 0 : 1) + ((unsigned short)(h0 >> 16) < t ? 0 : 1) + ((unsigned short)h1 < t ? 0 : 1) + ((unsigned short)(h1 >> 16) < t ? 0 : 1);
+    dkept[dsite] += ((unsigned short)(h0 >> 16) < t ? 0 : 1) + ((unsigned short)(h1 >> 16) < t ? 0 : 1) + ((unsigned short)(h2 >> 16) < t ? 0 : 1) + ((unsigned short)(h3 >> 16) < t ? 0 : 1);
 #endif
-    return (f32x4){((unsigned short)h0 < t) ? 0.f : dpk, ((unsigned short)(h0 >> 16) < t) ? 0.f : dpk, ((unsigned short)h1 < t) ? 0.f : dpk, ((unsigned short)(h1 >> 16) < t) ? 0.f : dpk};
+    return (f32x4){((unsigned short)(h0 >> 16) < t) ? 0.f : dpk, ((unsigned short)(h1 >> 16) < t) ? 0.f : dpk, ((unsigned short)(h2 >> 16) < t) ? 0.f : dpk, ((unsigned short)(h3 >> 16) < t) ? 0.f : dpk};
   };
   // 16 x 16 self-attention of the tile, per head, entirely in registers: S^T = K Q^T (lane: 4 keys of query l15), O^T = V^T P^T.
   // `mask4`: 0 / -inf of this lane's four keys, entering as the accumulator of the score MFMA; scores are in log2 units (q carries log2 e).
