@@ -61,6 +61,28 @@ def test_trampolines_are_generated_from_the_header():
     assert lib.rift_ctx_create_ex(0, 7, ctypes.byref(ctx)) == -1
 
 
+def test_bench_kernel_labels_resolve_in_the_committed_counter_tables():
+    """bench.py's roofline object reads HBM traffic and MFMA counters of the dominant kernel from the newest committed PMC passes
+    (profiles/rNN_pmc_*): every kernel the newest committed bench line lists must resolve there, so that a renamed kernel shows up here
+    and not as a silent `traffic: null` at round end."""
+    import glob
+    import importlib.util
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lines = sorted(glob.glob(os.path.join(repo, "profiles", "r*_bench.json")))
+    assert lines and bench.pmc_traffic_file() is not None
+    assert os.path.basename(lines[-1])[:3] == os.path.basename(bench.pmc_traffic_file())[:3], "bench line and traffic table of different rounds"
+    roof = json.load(open(lines[-1]))["roofline"]
+    for label in roof["per_kernel_ms_per_step"]:
+        assert bench.pmc_traffic(label) is not None, f"{label}: no traffic entry in {bench.pmc_traffic_file()}"
+    big = [k for k, ms in roof["per_kernel_ms_per_step"].items() if ms > 0.05]
+    for label in big:
+        assert bench.pmc_mfma(label) is not None, f"{label}: no MFMA counters in the committed pass"
+
+
 def test_struct_layouts_match_header_sizes():
     from rift_amd import _ffi
     # 6 int32 + 26 pointers + 1 int32 (padded) ; 5 pointers ; 8 pointers + 2 floats ; 11 pointers

@@ -20,11 +20,12 @@ tr = RLFTTrainer(model, kind="rift")
 g = torch.Generator().manual_seed(0)
 idx = [torch.randperm(len(scenes), generator=g)[:bs].to(torch.int32).to(dev) for _ in range(16)]
 def step(i):
-    fb, b = replay.collate(tr.engine, idx[i]); return tr.training_step(fb, b)
+    fb, b = replay.collate(tr.engine, idx[i], slot=tr.next_slot()); return tr.training_step(fb, b)
 for i in range(4): step(i)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(4, 14): loss = step(i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+tr.wait_update(); tr.pipeline = False
 tr.engine.prof_enable(True); step(14); rep = tr.engine.prof_report(); tr.engine.prof_enable(False)
 top = sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:8]
 print(f"dense bs={bs}: {dt*1e3:.2f} ms/step, {bs/dt:.0f} scenes/s, loss {float(loss):.4f}")
