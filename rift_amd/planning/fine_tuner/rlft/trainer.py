@@ -231,23 +231,36 @@ class RLFTTrainer:
 
     # ------------------------------------------------------------------------------------
     def _outputs(self, bs, R):
-        if self._prob is None or self._prob.shape[:2] != (bs, R) or (self._traj is not None and self._traj_A != self._A):
+        """Output tensors of the forward / loss for a (bs, R) batch.  Every shape keeps ITS set for the trainer's lifetime: with the tail of
+        step k on the update stream, a tensor freed when the next minibatch has another R would go back to the caching allocator (which
+        tracks the stream it was allocated on only) and could be handed out again while that tail still reads it."""
+        cache = self.__dict__.setdefault("_out_cache", {})
+        key = (bs, R)
+        if key not in cache:
             dev = self.engine.device
-            self._prob = torch.empty(bs, R, 12, device=dev)
-            self._hidden = torch.empty(bs, 128, device=dev)
-            self._argmax = torch.zeros(bs, 2, dtype=torch.int64, device=dev)
+            cache[key] = (torch.empty(bs, R, 12, device=dev), torch.empty(bs, 128, device=dev), torch.zeros(bs, 2, dtype=torch.int64, device=dev))
+        if getattr(self, "_out_key", None) != key:
+            self._out_key = key
+            self._prob, self._hidden, self._argmax = cache[key]
             # `hidden` (pluto_model.py:173-176) feeds only PPO's critic; the other objectives never read it
             self.out.probability = self._prob.data_ptr()
-            self.out.hidden = self._hidden.data_ptr() if (self.kind in ("ppo", "rtr") or getattr(self.model, "need_traj", False)) else None
             self.lo.argmax_rm = self._argmax.data_ptr()
             self._traj = None
-        if getattr(self.model, "need_traj", False) and self._traj is None:
+        want_traj = bool(getattr(self.model, "need_traj", False))
+        self.out.hidden = self._hidden.data_ptr() if (self.kind in ("ppo", "rtr") or want_traj) else None
+        if want_traj:
             # every output of PlanningModel.forward (pluto_model.py:167-223), as the reference's training_step computes them
-            dev, A = self.engine.device, self._A
-            self._traj = (torch.empty(bs, R, 12, 80, 6, device=dev), torch.empty(bs, max(A - 1, 0), 80, 6, device=dev),
-                          torch.empty(bs, 80, 4, device=dev))
-            self._traj_A = A                       # the prediction buffer is sized by the agent count: part of the cache key
+            tkey = (bs, R, self._A)                # the prediction buffer is sized by the agent count: part of the cache key
+            tcache = self.__dict__.setdefault("_traj_cache", {})
+            if tkey not in tcache:
+                dev, A = self.engine.device, self._A
+                tcache[tkey] = (torch.empty(bs, R, 12, 80, 6, device=dev), torch.empty(bs, max(A - 1, 0), 80, 6, device=dev),
+                                torch.empty(bs, 80, 4, device=dev))
+            self._traj, self._traj_A = tcache[tkey], self._A
             self.out.trajectory, self.out.prediction, self.out.ref_free_trajectory = (t.data_ptr() for t in self._traj)
+        else:
+            self._traj = None
+            self.out.trajectory = self.out.prediction = self.out.ref_free_trajectory = None
         return self._prob
 
     def set_loss_inputs(self, b: Dict[str, torch.Tensor]):

@@ -15,9 +15,10 @@ model = PlanningModel(radius=120)
 model.load_state_dict(syn.perturbed_state_dict({k: list(v.shape) for k, v in model.state_dict().items()}))
 model = model.to(dev); model.need_traj = False; model.train()
 tr = RLFTTrainer(model, kind="rift")
-idx = [torch.randperm(512)[:256].to(torch.int32).to(dev) for _ in range(64)]
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+idx = [torch.randperm(512)[:BATCH].to(torch.int32).to(dev) for _ in range(64)]
 def step(i):
-    fb, b = replay.collate(tr.engine, idx[i % 64]); return tr.training_step(fb, b)
+    fb, b = replay.collate(tr.engine, idx[i % 64], slot=tr.next_slot()); return tr.training_step(fb, b)
 for i in range(10): step(i)
 torch.cuda.synchronize()
 import cProfile, pstats
