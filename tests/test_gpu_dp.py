@@ -65,14 +65,16 @@ class Loopback:
         return True
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("sizes", [(6, 6), (5, 4, 3)])
-def test_sharded_step_equals_single_process_step(precision, sizes):
+@pytest.mark.parametrize("precision,sizes,dense", [("fp32", (6, 6), False), ("bf16", (6, 6), False), ("fp32", (5, 4, 3), False), ("bf16", (5, 4, 3), False),
+                                                  ("fp16", (6, 6), False), ("fp16", (5, 4, 3), False),
+                                                  ("bf16", (3, 3), True), ("fp16", (2, 3, 1), True)])      # dense: BASELINE configs[4] shapes (enc_w / dec_w<., true>)
+def test_sharded_step_equals_single_process_step(precision, sizes, dense):
     from rift_amd import _ffi
     from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
     from rift_amd.replay import DeviceReplay
     n, world = sum(sizes), len(sizes)
-    scenes = [syn.make_scene(300 + i) for i in range(n)]            # heterogeneous reference-line counts: the r2r quirk couples scenes
+    # heterogeneous reference-line counts: the r2r quirk couples scenes
+    scenes = [syn.make_scene(300 + i, 128, 40, 8, 16) if dense else syn.make_scene(300 + i) for i in range(n)]
     replay = DeviceReplay(scenes, "cuda:0")
     assert len(set(replay.r_count_cpu.tolist())) > 1
     R = replay.Rcap
@@ -97,7 +99,7 @@ def test_sharded_step_equals_single_process_step(precision, sizes):
     else:
         raise AssertionError("the loop-back exchange did not converge")
     n_calls = len(lb.total)
-    assert n_calls == (3 if precision == "bf16" else 5)            # fused: 2 BatchNorm points + loss; layer-wise fp32: 4 + loss
+    assert n_calls == (5 if precision == "fp32" else 3)            # fused: 2 BatchNorm points + loss; layer-wise fp32: 4 + loss
     # final pass once more WITH the running-statistics update (every exchange replays the reduced values)
     lb.start_pass()
     for r, tr in enumerate(ranks):
@@ -111,7 +113,8 @@ def test_sharded_step_equals_single_process_step(precision, sizes):
     # operand rounding (2^-9 relative on one activation), measured 3.7e-5 on this 12-scene loss -- and a logit that moves by that much can
     # carry one of the ~500 candidates across a clip boundary of the piecewise RIFT objective, which switches its whole gradient
     # contribution (measured 9.5 % of the largest gradient entry).  Hence two bars; the aligned split stays bit-identical in both modes.
-    aligned = all((sum(sizes[:r]) * 20) % 6 == 0 for r in range(world))          # shards start on a PointsEncoder tile (6 polygons of 20)
+    n_poly = 40 if dense else 20
+    aligned = all((sum(sizes[:r]) * n_poly) % 12 == 0 for r in range(world))     # shards start on a PointsEncoder round (12 polygons of 20 points)
     tol, gtol = (1e-6, 1e-4) if (precision == "fp32" or aligned) else (2e-4, 0.25)
     for r, tr in enumerate(ranks):
         assert abs(float(tr.loss.item()) - want_loss) < tol, (r, float(tr.loss.item()), want_loss)
