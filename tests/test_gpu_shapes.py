@@ -27,24 +27,26 @@ def _check(ffi, scenes, train):
     data = batch["cur_pluto_feature_torch"]
     want, _, _ = pluto_ref.planning_model_forward(sd, data, train_bn=train, need_traj=True, want_taps=True)
     r_pad = ~data["reference_line"]["valid_mask"].any(-1)
-    eng = ffi.Engine("cuda:0")
-    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
-    for fp32, tol in ((True, 1e-4), (False, 5e-2)):
+    # exact fp32, then the fused kernels on bf16 and on fp16 MFMA operands (logit bars: 1e-4 / 5e-2 / 1e-2)
+    for mode, tol in (("fp32", 1e-4), ("bf16", 5e-2), ("fp16", 1e-2)):
+        fp32 = mode == "fp32"
+        eng = ffi.Engine("cuda:0", operands="fp16" if mode == "fp16" else "bf16")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
         out = eng.forward(data, train=train, no_drop=True, need_traj=True, fp32=fp32, bn_update=False)
         got = out["probability"].cpu()
         assert torch.isfinite(got).all()
         assert (got[r_pad] == -1e6).all()                                   # pluto_model.py:203
-        assert float((got - want["probability"])[~r_pad].abs().max()) < tol, (fp32, train)
+        assert float((got - want["probability"])[~r_pad].abs().max()) < tol, (mode, train)
         tw = want["trajectory"][~r_pad]
         tg = out["trajectory"].cpu()[~r_pad]
-        assert float((tg - tw).abs().max()) < (2e-3 if fp32 else 0.5) * max(1.0, float(tw.abs().max()))
+        assert float((tg - tw).abs().max()) < {"fp32": 2e-3, "bf16": 0.5, "fp16": 0.1}[mode] * max(1.0, float(tw.abs().max()))
         stats, flat, _ = eng.loss_backward("rift", H.clone_tree(batch))
         grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
         loss = float(eng.loss_finalize(stats, flat, grads).item())
         ref = float(losses.rift_loss(want["probability"], r_pad, batch["old_group_logits_torch"], batch["group_advantage_torch"],
                                      batch["group_advantage_mask_torch"]))
-        assert abs(loss - ref) < (1e-5 if fp32 else 5e-3)
-    eng.close()
+        assert abs(loss - ref) < {"fp32": 1e-5, "bf16": 5e-3, "fp16": 1e-3}[mode], (mode, abs(loss - ref))
+        eng.close()
 
 
 @pytest.mark.parametrize("train", [False, True])
