@@ -180,6 +180,24 @@ def test_rccl_transport_with_one_rank():
         for k in plain.params:
             assert torch.equal(plain.params[k], dp.params[k]), k
         dp.close()
+        # the deferred tail with the exchanges in flight on two streams (BatchNorm sums inside the trunk on the caller's stream, the loss
+        # sums on the update stream) over the same communicator: six steps equal six steps without a group, bit for bit
+        g = torch.Generator().manual_seed(5)
+        order = [torch.randperm(16, generator=g)[:8].to(torch.int32).to("cuda:0") for _ in range(6)]
+        res = []
+        for grp in (None, dist.group.WORLD):
+            tr = RLFTTrainer(_model("bf16"), kind="rift", process_group=grp)
+            tr.force_exchange = grp is not None
+            assert tr.pipeline
+            for ix in order:
+                fb, b = replay.collate(tr.engine, ix, slot=tr.next_slot())
+                tr.training_step(fb, b)
+            tr.wait_update()
+            torch.cuda.synchronize()
+            res.append({k: v.detach().clone() for k, v in tr.params.items()})
+            tr.close()
+        for k in res[0]:
+            assert torch.equal(res[0][k], res[1][k]), k
     finally:
         dist.destroy_process_group()
 
