@@ -292,4 +292,22 @@ __device__ __forceinline__ h16x8 l0w_from_u2(const uint2 a, const uint2 b) {
   return r;
 }
 
+// ---- sequence bookkeeping of the compacted history-encoder launch (nat_l0w.h ranks the sequences; agent_encoder.py:77-87).
+// Rank r = 3 i + c is the i-th marked agent slot of residue class c = slot % 3: a sequence keeps its position (r % 3 == slot % 3) in level 2's
+// three-agent tiles, which makes the compacted launch bit-identical to the uncompacted one (that level's P V MFMA sums a query's five keys at
+// k offset 5 (r % 3) -- an ulp-level dependence on the position, a rare bf16 flip downstream).  Ranks at or beyond their class's count are
+// holes (at most a few, at the end); cnt = the three class counts in device memory, nullptr for the plain launch over nseq sequences
+// ("SeqCount" below: sq_n = the number of ranks, sq_c0..2 = the class counts).
+// (plain ints, not a struct: hipcc kept a struct of them in scratch memory)
+#define RIFT_SEQ_COUNT(cnt, nseq)                                                                        \
+  const int sq_c0 = (cnt) ? __builtin_amdgcn_readfirstlane((cnt)[0]) : 0x7fffffff;                       \
+  const int sq_c1 = (cnt) ? __builtin_amdgcn_readfirstlane((cnt)[1]) : 0x7fffffff;                       \
+  const int sq_c2 = (cnt) ? __builtin_amdgcn_readfirstlane((cnt)[2]) : 0x7fffffff;                       \
+  const int sq_n = (cnt) ? 3 * max(sq_c0, max(sq_c1, sq_c2)) : (nseq)
+#define RIFT_SEQ_LIVE(seq) seq_live(sq_n, sq_c0, sq_c1, sq_c2, (seq))
+__device__ __forceinline__ bool seq_live(int n, int c0, int c1, int c2, int seq) {
+  const int i = seq / 3, c = seq - 3 * i;
+  return seq < n && i < (c == 0 ? c0 : c == 1 ? c1 : c2);
+}
+
 }  // namespace RIFT_NS

@@ -93,7 +93,7 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
-  bool two_streams = true; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
+  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; int side_prio = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
   bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
   unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // weight stream / parameter blocks of the decoder kernel (dec_w.h)
@@ -422,7 +422,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR_N(fpn_tail_kernel, FPN_LDS);
   SETATTR_N(heads3_fused_kernel, HD_LDS);
   SETATTR_N(pi_forward_kernel, PI_LDS);
-  SETATTR_N(nat_l0w_kernel, L0W_LDS);
+  SETATTR_N(nat_l0w_kernel, L0W_LDS + L0W_LIST_BYTES);
   SETATTR_N(nat_l1w_kernel, L1W_LDS);
 #undef SETATTR_N
   return RIFT_OK;
@@ -824,6 +824,12 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   (void)A_alloc<float>(c, 64);          // front padding: the level-0 NAT kernel's window loads start up to 9 floats before a sequence's first row
   float* F9 = A_alloc<float>(c, (size_t)nA * 20 * 9 + 64);
   uint8_t* valid_agent = A_alloc<uint8_t>(c, nA);
+  // the fused history encoder runs on the sequences its output is read of -- valid agents other than the ego (agent_encoder.py:77-87) -- in
+  // compacted order (nat_l0w.h ranks them); the layer-wise / fp32 path keeps all nA sequences
+  const bool nat_compact = c->nat_compact && c->nat_fused && !f.fp32 && c->fpn_fused;
+  uint8_t* hist_agent = nat_compact ? A_alloc<uint8_t>(c, nA) : nullptr;
+  int* nat_aidx = nat_compact ? A_alloc<int>(c, nA) : nullptr;
+  int* nat_cnt = nat_compact ? A_alloc<int>(c, 4) : nullptr;
   float* F10 = A_alloc<float>(c, (size_t)nP * 20 * 10);
   float* F6 = A_alloc<float>(c, (size_t)nL * 120 * 6);
   uint8_t* kpm = A_alloc<uint8_t>(c, nT);
@@ -833,7 +839,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   {
     PrepP q; memset(&q, 0, sizeof(q));
     q.agent_pos = B->agent_position; q.agent_head = B->agent_heading; q.agent_vel = B->agent_velocity; q.agent_shape = B->agent_shape;
-    q.agent_valid = B->agent_valid_mask; q.nA = nA; q.Tfull = T; q.F9 = F9; q.valid_agent = valid_agent;
+    q.agent_valid = B->agent_valid_mask; q.nA = nA; q.Tfull = T; q.F9 = F9; q.valid_agent = valid_agent; q.hist_agent = hist_agent;
     q.map_pp = B->map_point_position; q.map_pv = B->map_point_vector; q.map_po = B->map_point_orientation; q.map_center = B->map_polygon_center;
     q.nPoly = nP; q.F10 = F10;
     q.ref_pos = B->ref_position; q.ref_vec = B->ref_vector; q.ref_ori = B->ref_orientation; q.ref_valid = B->ref_valid_mask; q.nLine = nL;
@@ -883,10 +889,10 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   hipStream_t main_stream = c->stream;
   const bool forked = c->two_streams && fused && !c->prof_on && !c->dry;
   if (forked) {
-    if (!c->side) { HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
+    if (!c->side) { HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, c->side_prio)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
     HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    c->stream = c->side;
+    if (!c->nat_on_main) c->stream = c->side;
   }
   static const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128}, Hl[3] = {2, 4, 8}, Kl[3] = {3, 3, 5};
   float* Oc[3];   // LayerNorm(norm_i) of the last 3 steps of level i: all that out[:, :, -1] of the FPN depends on
@@ -902,16 +908,20 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       const int C = Cl[lv], H = Hl[lv], ksz = Kl[lv], L = Ll[lv], rows = nA * L;
       if (lv == 0) {   // level 0 as wave-private, register-resident tiles (no workgroup barriers): nat_l0w.h
         NatL0WP q; memset(&q, 0, sizeof(q));
+        q.hist = hist_agent; q.aidx = nat_aidx; q.cnt = nat_cnt;
         q.F9 = F9; q.nseq = nA; q.img = c->l0w_img; q.par = c->l0w_par; q.Oc = Oc[0]; q.Ocb = Ocb[0]; q.Xnext = Xin[1];
         { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 1) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         q.droppath[0] = f.drop ? dpr[0] : 0.f; q.droppath[1] = f.drop ? dpr[1] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + 2.0 * rows * 27 * 32 + (rows / 2) * 2.0 * 3 * C * 2 * C;
-        launch(c, "nat_l0w_kernel", nat_l0w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid)), dim3(64 * L0W_NWV), (size_t)L0W_LDS, q);
+        const int l0grid = std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid);
+        if (nat_compact && cdiv(cdiv(cdiv(nA, 4), L0W_NWV), l0grid) * L0W_NWV * 16 > L0W_LIST_BYTES) { c->err = "nat_l0w_kernel: too many rounds per workgroup for the compaction list"; return RIFT_ERR_ARG; }
+        launch(c, "nat_l0w_kernel", nat_l0w_kernel, dim3(l0grid), dim3(64 * L0W_NWV), (size_t)(L0W_LDS + L0W_LIST_BYTES), q);
         continue;
       }
       if (lv == 1) {   // level 1 likewise (weights swapped through LDS between the two layers): nat_l1w.h
         NatL1WP q; memset(&q, 0, sizeof(q));
+        q.cnt = nat_cnt;
         q.X = Xin[1]; q.nseq = nA; q.img = c->l1w_img; q.par = c->l1w_par; q.Oc = Oc[1]; q.Ocb = Ocb[1]; q.Xnext = Xin[2];
         q.droppath[0] = f.drop ? dpr[2] : 0.f; q.droppath[1] = f.drop ? dpr[3] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
@@ -921,6 +931,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       }
       {   // level 2: wave-private tiles of 3 agents, the two layers' weights streamed through LDS (nat_l2w.h)
         NatL2WP q; memset(&q, 0, sizeof(q));
+        q.cnt = nat_cnt;
         q.X = Xin[2]; q.nseq = nA; q.img = c->l2w_img; q.par = c->l2w_par; q.Oc = Oc[2]; q.Ocb = Ocb[2];
         q.droppath[0] = f.drop ? dpr[4] : 0.f; q.droppath[1] = f.drop ? dpr[5] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
@@ -979,7 +990,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       q.oc[i] = Oc[i]; q.ocb[i] = Ocb[i]; q.wl[i] = (const unsigned short*)w.bf; q.bl[i] = w.bias;
     }
     q.wf = (const unsigned short*)c->pw[HE + ".fpn_conv.last"].bf; q.bf_ = c->pw[HE + ".fpn_conv.last"].bias;
-    q.out = nat_out; q.nA = nA;
+    q.out = nat_out; q.nA = nA; q.cnt = fused ? nat_cnt : nullptr; q.aidx = fused ? nat_aidx : nullptr;
     c->prof_flops = 2.0 * nA * (2.0 * 128 * (96 + 192 + 384) + 256.0 * 128);
     launch(c, "fpn_tail_kernel", fpn_tail_kernel, dim3(cdiv(nA, FPN_AG)), dim3(512), (size_t)FPN_LDS, q);
   } else {
@@ -996,7 +1007,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
            (const float*)lat[2], nA, Z);
     gemm(c, mk(Z, 256, nA, c->pw[HE + ".fpn_conv.last"], nat_out, 128), c->pw[HE + ".fpn_conv.last"], f.fp32);
   }
-  if (forked) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
+  // the longer chain (agent history: ~310 of the front's ~510 us at 256 scenes) stays on the caller's queue, so neither its start nor the
+  // join pays a cross-queue hop (12-15 us each by the kernel trace); the map / reference-line chain is the one that forks
+  if (forked) { if (c->nat_on_main) c->stream = c->side; else { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; } }
   tap(c, "nat_out", nat_out, (int64_t)nA * 128);
 
   // ego state token (StateAttentionEncoder, agent_encoder.py:99-140)
@@ -1098,7 +1111,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     return RIFT_OK;
   };
   if (forked && rpe_done) { const int rc0 = build_q0(); if (rc0 != RIFT_OK) return rc0; }
-  if (forked) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));      // join: the agent tokens need the history encoder's output
+  if (forked && c->nat_on_main) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
+  if (forked) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));      // join: the agent tokens need both chains
   {
     TokenP q;
     q.nat = nat_out; q.x_ego = x_ego; q.valid_agent = (const uint8_t*)valid_agent; q.category = B->agent_category; q.a_type_emb = fptr(c, "agent_encoder.type_emb.weight");
@@ -1375,6 +1389,9 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_HEADS_UNFUSED"); c->heads_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PI_UNFUSED"); c->pi_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
+  { const char* ev = getenv("RIFT_NAT_MAIN"); if (ev) c->nat_on_main = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_NAT_COMPACT"); if (ev) c->nat_compact = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_SIDE_PRIO"); if (ev) c->side_prio = atoi(ev); }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }

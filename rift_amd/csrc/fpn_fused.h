@@ -20,6 +20,7 @@ struct FpnP {
   const float* bf_;
   float* out;                    // (nA, 128)
   int nA;
+  const int* cnt; const int* aidx;   // compacted launch (nat_l0w.h; common.h: SeqCount): live row r is agent slot aidx[r] of `out`
 };
 
 #define FPN_AG 64
@@ -31,7 +32,7 @@ template <int C>
 struct FpnRows { uint2 u[(FPN_AG * 3 * (C / 4) + 511) / 512]; };
 
 template <int C>
-__device__ __forceinline__ void fpn_load(const FpnP& p, int lv, int a0, FpnRows<C>& R, int tid) {
+__device__ __forceinline__ void fpn_load(const FpnP& p, int lv, int a0, FpnRows<C>& R, int tid, int sq_n, int sq_c0, int sq_c1, int sq_c2) {
   constexpr int V = FPN_AG * 3 * (C / 4), N = (V + 511) / 512;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -40,7 +41,7 @@ __device__ __forceinline__ void fpn_load(const FpnP& p, int lv, int a0, FpnRows<
     if (i < V) {
       const int a = i / (3 * (C / 4)), rem = i - a * (3 * (C / 4));
       const int pz = rem / (C / 4), c4 = (rem - pz * (C / 4)) * 4;
-      if (a0 + a < p.nA) {
+      if (RIFT_SEQ_LIVE(a0 + a)) {
         if (p.ocb[lv]) u = *reinterpret_cast<const uint2*>(p.ocb[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4);
         else { const float4 v = *reinterpret_cast<const float4*>(p.oc[lv] + ((size_t)(a0 + a) * 3 + pz) * C + c4); u = pack_h4(v.x, v.y, v.z, v.w); }
       }
@@ -81,13 +82,15 @@ __global__ __launch_bounds__(512) void fpn_tail_kernel(FpnP p) {
   unsigned short* At = reinterpret_cast<unsigned short*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int a0 = blockIdx.x * FPN_AG;
+  RIFT_SEQ_COUNT(p.cnt, p.nA);
+  if (a0 >= sq_n) return;
   const int col = wave * 16 + l4 * 4;
   const bool odd = l15 & 1;                       // position 1 of its agent
   PFrags<8, 1> Wf;
   p_load_w<8, 8, 1>(Wf, p.wf, 256, 0, wave, l15, l4);
   f32x4 a2[8][1], a1[8][1], a0c[8][1];
   FpnRows<128> r2; FpnRows<64> r1; FpnRows<32> r0;
-  fpn_load<128>(p, 2, a0, r2, tid); fpn_load<64>(p, 1, a0, r1, tid); fpn_load<32>(p, 0, a0, r0, tid);
+  fpn_load<128>(p, 2, a0, r2, tid, sq_n, sq_c0, sq_c1, sq_c2); fpn_load<64>(p, 1, a0, r1, tid, sq_n, sq_c0, sq_c1, sq_c2); fpn_load<32>(p, 0, a0, r0, tid, sq_n, sq_c0, sq_c1, sq_c2);
   fpn_lateral<128, 12>(p, 2, r2, At, a2, tid, wave, l15, l4);
   fpn_lateral<64, 6>(p, 1, r1, At, a1, tid, wave, l15, l4);
   fpn_lateral<32, 3>(p, 0, r0, At, a0c, tid, wave, l15, l4);
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(512) void fpn_tail_kernel(FpnP p) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int agent = a0 + mt * 16 + l15;
-    if (agent < p.nA)
-      *reinterpret_cast<float4*>(p.out + (size_t)agent * 128 + col) =
+    if (RIFT_SEQ_LIVE(agent))
+      *reinterpret_cast<float4*>(p.out + (size_t)(p.aidx ? p.aidx[agent] : agent) * 128 + col) =
           make_float4(acc[mt][0][0] + bf4.x, acc[mt][0][1] + bf4.y, acc[mt][0][2] + bf4.z, acc[mt][0][3] + bf4.w);
   }
 }

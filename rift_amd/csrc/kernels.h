@@ -37,11 +37,13 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* dst, int
 // feature builders
 // ---------------------------------------------------------------------------
 // agent 9-channel difference features (agent_encoder.py:54-75) -> F[(b*A+a)*20 + t][9]
-// also valid_agent[b*A+a] = any(valid[:21])
+// also valid_agent[b*A+a] = any(valid[:21]) and, if asked for, hist_agent[b*A+a] = valid_agent && a != 0: the sequences the history
+// encoder's output is read of (agent_encoder.py:77-87: it runs on agent_feature[valid_agent_mask], and row 0 is overwritten by the ego state token)
 __device__ __forceinline__ void agent_feature_body(const float* __restrict__ pos, const float* __restrict__ head,
                                      const float* __restrict__ vel, const float* __restrict__ shp,
                                      const uint8_t* __restrict__ valid, int nA, int Tfull,
-                                     float* __restrict__ F, uint8_t* __restrict__ valid_agent, const int vblk) {
+                                     float* __restrict__ F, uint8_t* __restrict__ valid_agent, const int vblk,
+                                     uint8_t* __restrict__ hist_agent = nullptr, const int A = 1) {
   const int idx = vblk * (int)blockDim.x + (int)threadIdx.x;   // (agent, t) t in [0,20)
   if (idx >= nA * 20) return;
   const int a = idx / 20, t = idx - a * 20;
@@ -62,6 +64,7 @@ __device__ __forceinline__ void agent_feature_body(const float* __restrict__ pos
     bool any = false;
     for (int i = 0; i < 21; ++i) any |= (valid[(size_t)a * Tfull + i] != 0);
     valid_agent[a] = any ? 1 : 0;
+    if (hist_agent) hist_agent[a] = (any && (a % A) != 0) ? 1 : 0;
   }
 }
 __global__ void agent_feature_kernel(const float* __restrict__ pos, const float* __restrict__ head,
@@ -699,7 +702,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ X, int ldx, float* 
 // ---------------------------------------------------------------------------
 struct PrepP {
   const float *agent_pos, *agent_head, *agent_vel, *agent_shape; const uint8_t* agent_valid; int nA, Tfull;
-  float* F9; uint8_t* valid_agent;
+  float* F9; uint8_t* valid_agent; uint8_t* hist_agent;
   const float *map_pp, *map_pv, *map_po, *map_center; int nPoly; float* F10;
   const float *ref_pos, *ref_vec, *ref_ori; const uint8_t* ref_valid; int nLine; float* F6; float* r_pos; uint8_t* r_kpm;
   const uint8_t *map_valid, *static_valid; const float *st_pos, *st_head; int bs, A, Mp, S; uint8_t* kpm; float* pos;
@@ -708,7 +711,7 @@ struct PrepP {
 
 __global__ __launch_bounds__(256) void prep_kernel(PrepP q) {
   int blk = blockIdx.x;
-  if (blk < q.nb[0]) { agent_feature_body(q.agent_pos, q.agent_head, q.agent_vel, q.agent_shape, q.agent_valid, q.nA, q.Tfull, q.F9, q.valid_agent, blk); return; }
+  if (blk < q.nb[0]) { agent_feature_body(q.agent_pos, q.agent_head, q.agent_vel, q.agent_shape, q.agent_valid, q.nA, q.Tfull, q.F9, q.valid_agent, blk, q.hist_agent, q.A); return; }
   blk -= q.nb[0];
   if (blk < q.nb[1]) { map_feature_body(q.map_pp, q.map_pv, q.map_po, q.map_center, q.nPoly, q.F10, blk); return; }
   blk -= q.nb[1];

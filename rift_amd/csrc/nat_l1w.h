@@ -89,6 +89,7 @@ struct NatL1WP {
   unsigned short* Ocb;                     // if set: the same rows as bf16 instead (what fpn_tail_kernel rounds them to anyway: half the bytes both ways)
   float* Xnext;                            // (nseq * 5, 128) downsample conv + LayerNorm
   float droppath[2]; uint32_t seed, stream;
+  const int* cnt;                          // if set: the three class counts of the compacted launch (nat_l0w.h; common.h: SeqCount); nseq is the bound
   DropStats ds;                            // diagnostic build only (dropstats.h)
 };
 
@@ -141,13 +142,14 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
   };
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
   const int a = l15 >> 2, s = l15 & 3;
-  const int ntiles = (p.nseq + 3) >> 2;
+  RIFT_SEQ_COUNT(p.cnt, p.nseq);
+  const int ntiles = (sq_n + 3) >> 2;
   const int ngroups = (ntiles + 7) >> 3;
 
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int tile = grp * 8 + wave;
     const int seq = tile * 4 + a;
-    const bool seq_ok = seq < p.nseq;
+    const bool seq_ok = RIFT_SEQ_LIVE(seq);
     f32x4 x[3][4];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
         }
         const float r = rsqrtf(rows_sum(qs) * (1.0f / 128.0f) + 1e-5f);
         const int m = mt * 16 + l15, oa = m / 5;
-        if (m < 20 && tile * 4 + oa < p.nseq) {
+        if (m < 20 && RIFT_SEQ_LIVE(tile * 4 + oa)) {
           float* dst = p.Xnext + ((size_t)tile * 20 + m) * 128;
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt) {

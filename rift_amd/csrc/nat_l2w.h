@@ -40,6 +40,7 @@ struct NatL2WP {
   unsigned short* Ocb;                     // if set: the same rows as bf16 instead (what fpn_tail_kernel rounds them to anyway: half the bytes both ways)
   float droppath[2]; uint32_t seed, stream;
   long long* ts;                           // optional: clock of wave 0 of workgroup 0 at every group boundary (diagnostic)
+  const int* cnt;                          // if set: the three class counts of the compacted launch (nat_l0w.h; common.h: SeqCount); nseq is the bound
   DropStats ds;                            // diagnostic build only (dropstats.h)
 };
 

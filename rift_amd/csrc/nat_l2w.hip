@@ -55,7 +55,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const uint32_t lds00 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw);
   uint32_t lds0 = lds00, voff = (uint32_t)lane * 16u;
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
-  const int ntiles = (p.nseq + 2) / 3, nrounds = (ntiles + 7) >> 3;
+  RIFT_SEQ_COUNT(p.cnt, p.nseq);
+  const int ntiles = (sq_n + 2) / 3, nrounds = (ntiles + 7) >> 3;
   const int my_rounds = blockIdx.x < nrounds ? (nrounds - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = 20 * my_rounds;                      // groups this workgroup consumes
   int tsn = 0;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tile = round * 8 + wv;
     const int qa = l15 / L, qt = l15 - qa * L;           // this lane row: agent qa (3 = the idle row 15), step qt
     const int seq = tile * 3 + qa;
-    const bool row_ok = qa < 3 && seq < p.nseq;
+    const bool row_ok = qa < 3 && RIFT_SEQ_LIVE(seq);
     f32x4 res[8];
     {
       const float* src = p.X + ((size_t)(row_ok ? seq : 0) * L + (row_ok ? qt : 0)) * 128 + l4 * 4;

@@ -29,7 +29,7 @@ def _site_enc(li, br):
 
 @pytest.fixture(scope="module")
 def stats_runs():
-    """32 seeded train-mode forwards of a 64-scene batch (4096 agent sequences) on the diagnostic library."""
+    """32 seeded train-mode forwards of a 64-scene batch (4096 agent slots, ~3600 history sequences) on the diagnostic library."""
     from rift_amd import _ffi
     torch.cuda.set_device(0)
     eng = _ffi.Engine("cuda:0", variant="stats")
@@ -38,6 +38,11 @@ def stats_runs():
     data = batch["cur_pluto_feature_torch"]
     bs, A = data["agent"]["position"].shape[:2]
     nmax = max(bs * A, bs * 6)
+    hist = data["agent"]["valid_mask"][:, :, :21].any(-1).clone()
+    hist[:, 0] = False                                                  # the history encoder runs on valid agents other than the ego, compacted:
+    slots = hist.flatten().nonzero().flatten().numpy()                  # rank 3 i + c = the i-th such slot of residue class c = slot % 3
+    n_hist = np.sort(np.concatenate([3 * np.arange((slots % 3 == c).sum()) + c for c in range(3)]))
+    assert 0 < len(n_hist) < bs * A
     runs = []
     for seed in range(1, SEEDS + 1):
         out = eng.forward(data, train=True, seed=seed, bn_update=False)
@@ -48,7 +53,7 @@ def stats_runs():
         r["elem"] = eng.tap("drop_elem").view(torch.int64).cpu().numpy().reshape(N_DEC, 2).copy()
         runs.append(r)
     eng.close()
-    return runs, bs, A
+    return runs, bs, A, n_hist
 
 
 def _rate_ok(kept, n, p_keep, what):
@@ -59,16 +64,18 @@ def _rate_ok(kept, n, p_keep, what):
 
 
 def _droppath_site(runs, site, n, p, what):
-    """One DropPath site with n samples per forward: granularity, rate, scale, independence."""
+    """One DropPath site with n samples per forward (an int: samples 0..n-1; an index array: exactly those samples): granularity, rate, scale,
+    independence."""
+    live = np.arange(n) if np.isscalar(n) else np.asarray(n)
     if p == 0.0:
         assert all(int(r["cnt"][site].sum()) == 0 for r in runs), f"{what}: rate 0 makes no decision"
         return
     masks = []
     for r in runs:
-        cnt, any_, all_ = r["cnt"][site, :n], r["any"][site, :n], r["all"][site, :n]
+        cnt, any_, all_ = r["cnt"][site, live], r["any"][site, live], r["all"][site, live]
         assert (cnt > 0).all(), f"{what}: every sample takes part"
         assert ((any_ != 0) == (all_ != 0)).all(), f"{what}: rows of one sample saw different decisions"
-        assert int(r["cnt"][site, n:].sum()) == 0
+        assert int(r["cnt"][site].sum()) == int(cnt.sum()), f"{what}: decisions outside the samples"
         masks.append(any_ != 0)
         want = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
         assert r["scale"][site] == want, f"{what}: keep multiplier {r['scale'][site]!r} vs 1 / (1 - p) = {want!r}"
@@ -83,14 +90,14 @@ def _droppath_site(runs, site, n, p, what):
 
 
 def test_nat_droppath_per_agent_sequence(stats_runs):
-    runs, bs, A = stats_runs
+    runs, bs, A, n_hist = stats_runs
     rates = np.linspace(0, 0.2, 6)
     masks = {}
     for lv in range(3):
         for bi in range(2):
             for br in range(2):
                 p = float(np.float32(rates[2 * lv + bi]))
-                masks[(lv, bi, br)] = _droppath_site(runs, _site_nat(lv, bi, br), bs * A, float(rates[2 * lv + bi]), f"NAT level {lv} block {bi} branch {br}")
+                masks[(lv, bi, br)] = _droppath_site(runs, _site_nat(lv, bi, br), n_hist, float(rates[2 * lv + bi]), f"NAT level {lv} block {bi} branch {br}")
     # the attention and the MLP branch of a block, and different blocks, decide independently
     keys = [k for k, v in masks.items() if v is not None]
     for i in range(len(keys) - 1):
@@ -100,7 +107,7 @@ def test_nat_droppath_per_agent_sequence(stats_runs):
 
 
 def test_encoder_droppath_per_scene(stats_runs):
-    runs, bs, A = stats_runs
+    runs, bs, A, n_hist = stats_runs
     rates = np.linspace(0, 0.2, 4)
     for li in range(4):
         for br in range(2):
@@ -108,7 +115,7 @@ def test_encoder_droppath_per_scene(stats_runs):
 
 
 def test_state_dropout_keeps_the_first_three_tokens(stats_runs):
-    runs, bs, A = stats_runs
+    runs, bs, A, n_hist = stats_runs
     dropped = []
     for r in runs:
         cnt, any_, all_ = r["cnt"][20, :bs * 6].reshape(bs, 6), r["any"][20, :bs * 6].reshape(bs, 6), r["all"][20, :bs * 6].reshape(bs, 6)
@@ -123,7 +130,7 @@ def test_state_dropout_keeps_the_first_three_tokens(stats_runs):
 
 
 def test_decoder_dropout_sites(stats_runs):
-    runs, bs, A = stats_runs
+    runs, bs, A, n_hist = stats_runs
     names = ["r2r weights", "r2r branch", "m2m weights", "m2m branch", "cross weights", "cross branch", "FFN hidden", "FFN branch"]
     kept = np.stack([r["elem"][:, 0] for r in runs]).astype(np.float64)       # (seeds, sites)
     drawn = np.stack([r["elem"][:, 1] for r in runs]).astype(np.float64)

@@ -479,23 +479,58 @@ def test_device_collation_matches_the_reference_generated_fixture(ffi):
 
 
 def test_fused_nat_level_matches_layerwise_path(ffi, monkeypatch):
-    """The fused NAT level kernel (80 rows resident in LDS) against the layer-by-layer GEMM path and
-    against the exact-fp32 path, on the history-encoder output of every agent."""
+    """The fused NAT level kernels against the layer-by-layer GEMM path and against the exact-fp32 path, on the history-encoder output of
+    every sequence that output is read of: valid agents other than the ego (agent_encoder.py:77-87; the fused path runs on exactly those, in
+    compacted order, the layer-wise paths on all)."""
     gold, batch, sd = H.load_case("full")
     data = batch["cur_pluto_feature_torch"]
+    hist = data["agent"]["valid_mask"][:, :, :21].any(-1).clone()
+    hist[:, 0] = False
+    hist = hist.flatten()
+    assert 0 < int(hist.sum()) < hist.numel()
     outs = {}
     for name, env, fp32 in (("fused", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
         monkeypatch.setenv("RIFT_NAT_UNFUSED", env)
         eng = ffi.Engine("cuda:0")
         eng.load_state_dict({k: v.clone() for k, v in sd.items()})
         eng.forward(data, fp32=fp32)
-        outs[name] = eng.tap("nat_out").cpu().clone()
+        outs[name] = eng.tap("nat_out").view(-1, 128).cpu().clone()[hist]
         eng.close()
     scale = float(outs["fp32"].abs().max())
     assert err(outs["fused"], outs["fp32"]) < 3e-2 * max(1.0, scale)
     assert err(outs["fused"], outs["layerwise"]) < 3e-2 * max(1.0, scale)
     # the fused kernel must not be a no-op: its bf16 rounding points differ from the layer-wise path
     assert not torch.equal(outs["fused"], outs["layerwise"])
+
+
+def test_compacted_history_encoder_equals_the_uncompacted_launch(ffi, monkeypatch):
+    """The history encoder on the compacted sequences (valid agents other than the ego, ranked inside nat_l0w_kernel) against the same kernels
+    over all bs * A sequences (RIFT_NAT_COMPACT=0): a sequence's result does not depend on which tile it rides in and the ranking keeps its
+    position in level 2's three-agent tiles (common.h: SeqCount), so everything downstream is bit-identical -- on the fixture, on a 64-scene synthetic batch (partial last tiles at every level) and on a batch whose agents are all
+    invalid but the egos (no sequence at all)."""
+    gold, batch, sd = H.load_case("full")
+    cases = [batch["cur_pluto_feature_torch"], syn.collate_scenes([syn.make_scene(5000 + i) for i in range(64)])["cur_pluto_feature_torch"]]
+    lone = syn.collate_scenes([syn.make_scene(5100 + i) for i in range(3)])["cur_pluto_feature_torch"]
+    lone["agent"]["valid_mask"][:, 1:] = False
+    cases.append(lone)
+    for ci, data in enumerate(cases):
+        hist = data["agent"]["valid_mask"][:, :, :21].any(-1).clone()
+        hist[:, 0] = False
+        hist = hist.flatten()
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RIFT_NAT_COMPACT", mode)
+            eng = ffi.Engine("cuda:0")
+            eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+            out = eng.forward(data, need_traj=True)
+            torch.cuda.synchronize()
+            got[mode] = {"nat": eng.tap("nat_out").view(-1, 128).cpu().clone()[hist], "enc": eng.tap("enc_out").cpu().clone(),
+                         "prob": out["probability"].cpu().clone(), "traj": out["trajectory"].cpu().clone()}
+            eng.close()
+        assert ci == 2 or got["1"]["nat"].shape[0] > 0
+        for k in got["1"]:
+            assert torch.equal(got["1"][k], got["0"][k]), (ci, k)
+        assert not torch.isnan(got["1"]["prob"]).any()
 
 
 def test_fused_encoder_matches_layerwise_path(ffi, monkeypatch):
