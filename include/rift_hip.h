@@ -181,6 +181,16 @@ typedef struct RiftDp {
 } RiftDp;
 int rift_set_dp(RiftCtx* ctx, const RiftDp* dp);
 
+/* Input prefetch.  Everything a forward does before its first encoder kernel depends on the batch alone: the caller's gather of the batch
+ * (rift_collate) and the forward's own input-only preparation (difference features, masks, positions: one launch).  With a prepare stream
+ * set, rift_forward launches that preparation on `prepare_stream` -- behind what the caller queued there, i.e. the gather -- and makes its
+ * own streams wait for it: a host that runs ahead of the device (the update loop does, by about a step) gets the next step's inputs built
+ * beside the current step's kernels instead of between two steps (12 + 12 us of a 0.7 ms step at 256 scenes, 7 + 6 of 0.39 at 32).  The
+ * caller orders `prepare_stream` behind whatever last read the batch buffers and the activation arena of this forward (with
+ * RIFT_F_DEFER_HEAD: the head / loss of the forward before last).  NULL (the default) keeps the preparation on the forward's stream; the
+ * data-parallel path and the per-kernel profile ignore the setting.  Results do not depend on it. */
+int rift_set_prepare_stream(RiftCtx* ctx, void* prepare_stream);
+
 /* The reference asserts torch.isfinite(q).all() on the decoder queries after every decoder layer (planning_decoder.py:175).  Here the
  * policy-head kernels of rift_forward raise a device flag when the decoder output holds a NaN / Inf (either propagates through the
  * residual stream to the last layer); rift_forward itself stays asynchronous.  rift_check_finite is the sync point: it waits for

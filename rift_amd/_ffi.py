@@ -88,7 +88,7 @@ EXPORTS = [
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
     "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout", "rift_sft_teacher_mode",
-    "rift_check_finite", "rift_set_dp",
+    "rift_check_finite", "rift_set_dp", "rift_set_prepare_stream",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -126,6 +126,7 @@ def load_library(variant: str = "") -> C.CDLL:
     lib.rift_set_param_event.argtypes = [vp, vp]
     lib.rift_check_finite.argtypes = [vp, vp]
     lib.rift_set_dp.argtypes = [vp, C.POINTER(RiftDp)]
+    lib.rift_set_prepare_stream.argtypes = [vp, vp]
     lib.rift_loss_finalize_clip.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, C.c_float, vp, vp]
     lib.rift_tap.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), vp]
     lib.rift_critic_forward.argtypes = [vp, C.POINTER(RiftCritic), vp, C.c_int, vp, vp]
@@ -313,6 +314,14 @@ class Engine:
         if rc != 0:
             self._check(rc, "rift_forward")
         self._bs = fb.bs
+
+    def set_prepare_stream(self, stream: Optional["torch.cuda.Stream"]):
+        """rift_set_prepare_stream: the input-only preparation of the following forwards runs on `stream` (behind the gather of the batch
+        the caller queued there) instead of between two steps on the forward's stream; None switches it off."""
+        self._prep_stream = stream                     # keeps the torch stream object alive while the engine holds its handle
+        rc = self.lib.rift_set_prepare_stream(self.ctx, C.c_void_p(stream.cuda_stream if stream is not None else 0))
+        if rc != 0:
+            self._check(rc, "rift_set_prepare_stream")
 
     def forward_head(self):
         """The policy head of the last F_DEFER_HEAD forward, on the current stream (the caller has ordered it behind that forward)."""

@@ -93,7 +93,9 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
-  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; int side_prio = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
+  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true;
+  hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = -1; int n_cu = 256;      // rift_set_prepare_stream
+  int side_prio = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
   bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
   unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // weight stream / parameter blocks of the decoder kernel (dec_w.h)
@@ -592,11 +594,27 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
   }
   const bool dpx = f.dp && f.train;      // data parallel: the four BatchNorms see the statistics of the GLOBAL minibatch
   double* xs = dpx ? c->dp.xchg + f.kb : nullptr;
+  // pass B's live rounds and workgroup split, from pass A's counts (pe_fused.h: PeLiveP): one extra block of the BatchNorm-1 finalize
+  PeLiveP lv; memset(&lv, 0, sizeof(lv));
+  const bool live = stats_p && c->pe_live;
+  int pew_grid = c->nat_grid, pew_ga = 0;
+  if (c->pe_w) pew_split(cdiv(q.a.rows, PEW_ROUND_ROWS), cdiv(q.b.rows, PEW_ROUND_ROWS), &pew_grid, &pew_ga);
+  if (live) {
+    const PeP* sd[2] = {&q.a, &q.b};
+    for (int i = 0; i < 2; ++i) {
+      lv.cnt[i] = sd[i]->cnt; lv.nt[i] = sd[i]->ntiles; lv.nr[i] = cdiv(sd[i]->rows, PEW_ROUND_ROWS);
+      lv.live[i] = A_alloc<int>(c, std::max(lv.nr[i], 1));
+    }
+    lv.grid = pew_grid; lv.hdr = A_alloc<int>(c, 4);
+  }
   for (int mode = dpx ? 1 : 0; mode <= (dpx ? 2 : 0); ++mode) {
     BnFinP f1a = bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1, xs, mode);
     BnFinP f1b = bn_fin(c, q.b, pr + ".first_mlp.1", 128, q.b.part1, q.b.s1, q.b.t1, xs ? xs + 257 : nullptr, mode);
     if (stats_p) { f1a.part = q.a.part1w; f1a.cnt = q.a.cnt1w; f1a.nblk = q.a.nwg1; f1b.part = q.b.part1w; f1b.cnt = q.b.cnt1w; f1b.nblk = q.b.nwg1; }
-    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(256), dim3(256), 0, f1a, f1b, f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+    const bool with_lv = live && mode == (dpx ? 2 : 0);
+    PeLiveP none; memset(&none, 0, sizeof(none));
+    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(256 + (with_lv ? 1 : 0)), dim3(256), 0, f1a, f1b, f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f,
+           with_lv ? lv : none);
     if (mode == 1) dp_exchange(f, 2 * 257);
   }
   c->prof_flops = 2.0 * rows * (128.0 * 8 + 128.0 * 256 + (f.train ? 256.0 * 256 : 0.0)) + 2.0 * groups * 256.0 * 256;
@@ -606,24 +624,23 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
     const PeP* src[2] = {&q.a, &q.b};
     PeWSide* dst[2] = {&w.a, &w.b};
     const int npts[2] = {20, 120};
-    int grid = c->nat_grid, ga = 0;
-    pew_split(cdiv(q.a.rows, PEW_ROUND_ROWS), cdiv(q.b.rows, PEW_ROUND_ROWS), &grid, &ga);
-    const int nwg[2] = {ga, grid - ga};
+    const int grid = pew_grid, ga = pew_ga;
+    const int nwg[2] = {live ? grid : ga, live ? grid : grid - ga};       // (live: the split is made on the device; room for either extreme)
     for (int i = 0; i < 2; ++i) {
       const PeP& o = *src[i]; PeWSide& d = *dst[i];
       d.F = o.F; d.Cin = o.Cin; d.valid = o.valid; d.rows = o.rows; d.npts = npts[i]; d.nrounds = cdiv(o.rows, PEW_ROUND_ROWS);
       d.img = c->pew_img[i]; d.w3b = o.w3b; d.b1 = o.b1; d.b2 = o.b2; d.b3 = o.b3; d.s1 = o.s1; d.t1 = o.t1;
-      d.cnt = f.train ? o.cnt : nullptr;
+      d.live = live ? lv.live[i] : nullptr;
       d.part2 = A_alloc<float>(c, (size_t)2 * 256 * std::max(nwg[i], 1)); d.cnt2 = A_alloc<int>(c, std::max(nwg[i], 1));
       d.Fmid = o.Fmid;
     }
-    w.ga = ga;
+    w.ga = ga; w.hdr = live ? lv.hdr : nullptr;
     w.do_stats = f.train ? 1 : 0;
     { const char* ev = getenv("RIFT_PEW_DBG"); w.dbg = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("RIFT_PEW_TS"); if (ev && ev[0] == '1') { w.ts = A_alloc<long long>(c, 128); tap(c, "pew_ts", (float*)w.ts, 256); } }
     launch_call(c, "pe_w_kernel", [&] { pew_launch(w, grid, c->stream); });
-    fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, w.a.part2, q.a.s2, q.a.t2, xs, 0); fa.cnt = w.a.cnt2; fa.nblk = nwg[0];
-    fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, w.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0); fb.cnt = w.b.cnt2; fb.nblk = nwg[1];
+    fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, w.a.part2, q.a.s2, q.a.t2, xs, 0); fa.cnt = w.a.cnt2; fa.nblk = nwg[0]; fa.nblk_dev = live ? lv.hdr + 2 : nullptr;
+    fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, w.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0); fb.cnt = w.b.cnt2; fb.nblk = nwg[1]; fb.nblk_dev = live ? lv.hdr + 3 : nullptr;
   } else {
     launch(c, "pe_mid_kernel", pe_mid_kernel, dim3(nt), dim3(512), (size_t)PE_MID_LDS, q);
     fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2, xs, 0);
@@ -631,7 +648,8 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
   }
   for (int mode = dpx ? 1 : 0; mode <= (dpx ? 2 : 0); ++mode) {
     fa.sums_mode = mode; fb.sums_mode = mode;
-    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(512), dim3(256), 0, fa, fb, f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f);
+    PeLiveP none; memset(&none, 0, sizeof(none));
+    launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(512), dim3(256), 0, fa, fb, f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f, none);
     if (mode == 1) dp_exchange(f, 2 * 513);
   }
   c->prof_flops = 2.0 * rows * (256.0 * 256 + 256.0 * 128);
@@ -836,6 +854,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* pos = A_alloc<float>(c, (size_t)nT * 3);
   float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
   uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
+  bool prefetched = false;
   {
     PrepP q; memset(&q, 0, sizeof(q));
     q.agent_pos = B->agent_position; q.agent_head = B->agent_heading; q.agent_vel = B->agent_velocity; q.agent_shape = B->agent_shape;
@@ -850,7 +869,19 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     q.nb[3] = cdiv(nL, 256); q.nb[4] = cdiv(nL, 256); q.nb[5] = cdiv(nT, 256); q.nb[6] = cdiv(nT, 256);
     int tot = 0;
     for (int i = 0; i < 7; ++i) tot += q.nb[i];
-    launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
+    // on the caller's prepare stream if there is one (rift_set_prepare_stream): behind the gather of the batch, beside the previous step
+    prefetched = c->prep_set && !c->dp.on && !c->prof_on && !c->dry && !getenv("RIFT_POISON_ARENA");
+    if (prefetched) {
+      if (!c->ev_prep) HIPCHK(c, hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
+      hipStream_t own = c->stream;
+      c->stream = c->prep_stream;
+      launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
+      c->stream = own;
+      HIPCHK(c, hipEventRecord(c->ev_prep, c->prep_stream));
+      HIPCHK(c, hipStreamWaitEvent(own, c->ev_prep, 0));
+    } else {
+      launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
+    }
   }
   // data parallel: the r2r mask quirk indexes padding rows of the GLOBAL minibatch -> gather them (slots in the exchange buffer; the
   // first BatchNorm exchange carries them, an eval forward exchanges them on their own before the decoder)
@@ -890,8 +921,16 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   const bool forked = c->two_streams && fused && !c->prof_on && !c->dry;
   if (forked) {
     if (!c->side) { HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, c->side_prio)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
-    HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
-    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    // the map chain waits for the preparation and -- when the batch fills the chip, i.e. the previous forward's one-workgroup-per-scene
+    // encoder / decoder hold every CU -- for the caller's stream to get here; a smaller batch leaves CUs free, and the map chain of step
+    // k + 1 then runs beside the encoder / decoder of step k (measured, ms per step gated / not: 32 scenes 0.374 / 0.365, 64 0.399 / 0.391,
+    // 128 0.499 / 0.454, 192 0.593 / 0.593, 256 0.699 / 0.711; RIFT_SIDE_GATE=0|1 forces it)
+    const bool gate = c->side_gate >= 0 ? c->side_gate != 0 : bs >= c->n_cu;
+    if (prefetched) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_prep, 0));
+    if (!prefetched || gate) {
+      HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+      HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
     if (!c->nat_on_main) c->stream = c->side;
   }
   static const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128}, Hl[3] = {2, 4, 8}, Kl[3] = {3, 3, 5};
@@ -1391,6 +1430,9 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_GRID"); if (ev && atoi(ev) > 0) c->nat_grid = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_MAIN"); if (ev) c->nat_on_main = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_NAT_COMPACT"); if (ev) c->nat_compact = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_PE_LIVE"); if (ev) c->pe_live = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
+  { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->n_cu = n; }
   { const char* ev = getenv("RIFT_SIDE_PRIO"); if (ev) c->side_prio = atoi(ev); }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
@@ -1426,6 +1468,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->decw_img) { (void)hipFree(c->decw_img); (void)hipFree(c->decw_par); }
   for (int i = 0; i < 2; ++i) if (c->pew_img[i]) (void)hipFree(c->pew_img[i]);
   for (int i = 0; i < 3; ++i) if (c->fow_img[i]) { (void)hipFree(c->fow_img[i]); (void)hipFree(c->fow_par[i]); }
+  if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
   if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   delete c;
@@ -1825,6 +1868,12 @@ int rift_set_dp(RiftCtx* c, const RiftDp* dp) {
   if (!dp->xchg || !dp->exchange || dp->scene_offset < 0 || dp->xchg_len <= 0) { c->err = "rift_set_dp: bad descriptor"; return RIFT_ERR_ARG; }
   c->dp.on = true; c->dp.off = dp->scene_offset; c->dp.gbs = dp->global_bs; c->dp.xchg = dp->xchg; c->dp.len = dp->xchg_len;
   c->dp.fn = dp->exchange; c->dp.user = dp->user;
+  return RIFT_OK;
+}
+
+int rift_set_prepare_stream(RiftCtx* c, void* prepare_stream) {
+  if (!c) return RIFT_ERR_ARG;
+  c->prep_stream = (hipStream_t)prepare_stream; c->prep_set = prepare_stream != nullptr;
   return RIFT_OK;
 }
 

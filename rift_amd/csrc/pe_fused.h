@@ -568,6 +568,7 @@ __global__ __launch_bounds__(512) void pe_out_kernel(PeP2 q) {
 // one wave per channel walking 24 dependent rounds cost 11 us per launch).  Same semantics as bn_finalize_kernel.
 struct BnFinP {
   const float* part; const int* cnt; int nblk, C;
+  const int* nblk_dev;             // if set: the number of partials comes from device memory (pe_w_kernel's workgroup split, PeLiveP)
   const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches;
   float* scale; float* shift;
   double* sums; int sums_mode;     // data parallel: [2C+1] (sum, sum of squares, count); 0 local, 1 emit this rank's sums, 2 consume reduced sums
@@ -576,18 +577,19 @@ struct BnFinP {
 __device__ __forceinline__ void bn_finalize_t_body(const BnFinP& p, int train, int update_running, float eps, int c) {
   constexpr int NT = 256, MAXU = 8;                      // up to 2048 tiles in one unrolled round; more take further rounds
   const int tid = threadIdx.x;
+  const int nblk = p.nblk_dev ? *p.nblk_dev : p.nblk;
   float mean, var;
   if (train) {
     double s = 0.0, q = 0.0;
     long long n = 0;
-    for (int b0 = 0; b0 < (p.sums_mode == 2 ? 0 : p.nblk); b0 += NT * MAXU) {
+    for (int b0 = 0; b0 < (p.sums_mode == 2 ? 0 : nblk); b0 += NT * MAXU) {
       float sv[MAXU], qv[MAXU]; int nv[MAXU];
 #pragma unroll
       for (int u = 0; u < MAXU; ++u) {
         const int b = b0 + tid + u * NT;
-        const bool ok = b < p.nblk;
-        sv[u] = ok ? p.part[(size_t)c * p.nblk + b] : 0.f;
-        qv[u] = ok ? p.part[(size_t)(p.C + c) * p.nblk + b] : 0.f;
+        const bool ok = b < nblk;
+        sv[u] = ok ? p.part[(size_t)c * nblk + b] : 0.f;
+        qv[u] = ok ? p.part[(size_t)(p.C + c) * nblk + b] : 0.f;
         nv[u] = ok ? p.cnt[b] : 0;
       }
 #pragma unroll
@@ -625,7 +627,53 @@ __device__ __forceinline__ void bn_finalize_t_body(const BnFinP& p, int train, i
 }
 
 // the BatchNorm layers of the two encoders (same position in their pipelines) in one launch: blocks [0, a.C) are a's channels
-__global__ __launch_bounds__(256) void bn_finalize_t_kernel(BnFinP a, BnFinP b, int train, int update_running, float eps) {
+// The rounds of pe_w_kernel (240 rows = two of pass A's 120-row tiles) that hold a valid point, per encoder, in ascending order, and the split
+// of pe_w_kernel's persistent workgroups over the two encoders in proportion to those counts: built by one extra block of the BatchNorm-1
+// finalize launch (it sits between pass A and pass B anyway).  A workgroup then walks list positions wg, wg + G, ...: every workgroup of an
+// encoder gets the same number of live rounds to within one.  (Before: the split went by ALL rounds and a workgroup skipped its empty ones,
+// so the reference-line workgroups -- a third of their rounds empty at the benchmark's ragged R -- finished at two thirds of the map
+// encoder's five rounds.)
+struct PeLiveP {
+  const int* cnt[2]; int nt[2];    // pass A's valid-point counts per 120-row tile
+  int nr[2];                       // rounds per encoder
+  int grid;                        // pe_w_kernel's workgroups
+  int* live[2];                    // out: live rounds
+  int* hdr;                        // out: n_live a, n_live b, workgroups of a, workgroups of b
+};
+__device__ __forceinline__ void pe_live_body(const PeLiveP& q) {
+  __shared__ int sc[256];
+  __shared__ int tot[2];
+  const int tid = threadIdx.x;
+  for (int e = 0; e < 2; ++e) {
+    const int R = q.nr[e], K = (R + 255) / 256, r0 = tid * K;
+    auto is_live = [&](int r) { return r < R && (q.cnt[e][2 * r] + (2 * r + 1 < q.nt[e] ? q.cnt[e][2 * r + 1] : 0)) > 0; };
+    int mine = 0;
+    for (int j = 0; j < K; ++j) mine += is_live(r0 + j) ? 1 : 0;
+    sc[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int v = tid >= d ? sc[tid - d] : 0;
+      __syncthreads();
+      sc[tid] += v;
+      __syncthreads();
+    }
+    int o = sc[tid] - mine;
+    for (int j = 0; j < K; ++j) if (is_live(r0 + j)) q.live[e][o++] = r0 + j;
+    if (tid == 255) tot[e] = sc[255];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int na = tot[0], nb = tot[1], g = q.grid;
+    int a = na + nb > 0 ? (int)(((long long)g * na + (na + nb) / 2) / (na + nb)) : 0;
+    if (na > 0 && a < 1) a = 1;
+    if (nb > 0 && a > g - 1) a = g - 1;
+    if (nb == 0) a = g;
+    q.hdr[0] = na; q.hdr[1] = nb; q.hdr[2] = a; q.hdr[3] = g - a;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_t_kernel(BnFinP a, BnFinP b, int train, int update_running, float eps, PeLiveP lv) {
+  if ((int)blockIdx.x >= a.C + b.C) { pe_live_body(lv); return; }      // (one extra block, launched only when lv is filled)
   if ((int)blockIdx.x < a.C) bn_finalize_t_body(a, train, update_running, eps, blockIdx.x);
   else bn_finalize_t_body(b, train, update_running, eps, blockIdx.x - a.C);
 }

@@ -11,8 +11,8 @@
 //     into registers (streaming W3b's 128 KiB through the ring for 16 MFMAs per wave would be 40 % of the stream);
 //   * g goes to HBM as fp16 in 32-byte pieces per lane (W3a's image permutes the output channels so that a lane's 4 n-tiles x 4 values
 //     are 16 consecutive channels); BatchNorm-2 statistics from the fp32 accumulators, one partial per workgroup;
-//   * persistent workgroups (one per CU) walk the rounds with the stream running across round boundaries; rounds whose two 120-row tiles
-//     hold no valid point (pass A's counts) are skipped.
+//   * persistent workgroups (one per CU) walk the rounds with the stream running across round boundaries; in train mode only the rounds
+//     that hold a valid point (pass A's counts -> the live lists of PeLiveP, pe_fused.h), dealt evenly: list positions wg, wg + G, ...
 // Replaces: pe_mid_kernel (kept for RIFT_PE_W=0 and as the parity reference of tests/test_gpu_parity.py).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -35,7 +35,7 @@ struct PeWSide {
   const unsigned short* img;              // pack_pew_kernel: PEW_FRAGS fragments
   const unsigned short* w3b;              // second_mlp.0 pool half, fragment-major bf16 image [256][256] (engine pack_cols)
   const float *b1, *b2, *b3, *s1, *t1;    // biases; BatchNorm-1 folded to y = x s1 + t1
-  const int* cnt;                         // valid points per 120-row tile (pass A), or null: no round is skipped
+  const int* live;                        // the rounds that hold a valid point, ascending (pe_fused.h: PeLiveP), or null: all nrounds rounds
   float* part2;                           // [2][256][nwg] sums of g, g^2 over the valid rows of a workgroup's rounds (nwg = its share of the grid)
   int* cnt2;                              // [nwg] valid rows of a workgroup's rounds
   unsigned short* Fmid;                   // (rows, 256) fp16 bits of g
@@ -44,6 +44,7 @@ struct PeWSide {
 struct PeWP {
   PeWSide a, b;                           // a: map polygons (20 points), b: reference lines (120 points)
   int ga;                                 // workgroups [0, ga) take a's rounds, the rest b's
+  const int* hdr;                         // if set (with a.live / b.live): n_live a, n_live b, ga, grid - ga from device memory (PeLiveP) instead
   int do_stats;
   int dbg;                                // diagnostics (timing only, results invalid): 1 no g stores, 2 no weight stream, 4 no statistics write-out (RIFT_PEW_DBG)
   long long* ts;                          // optional: clock of wave 0 of workgroup 0 at the group boundaries of its first round

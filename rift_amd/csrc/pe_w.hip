@@ -98,7 +98,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   const uint32_t voff = (uint32_t)lane * 16u;
   // transposition read-back: dword `lane` of a scratch row = elements 2 (lane & 3), +1 of the operand fragment (pair lane >> 4, quarter (lane >> 2) & 3)
   const int pch = ((2 * (lane >> 4) + ((lane & 3) >> 1)) * 16 + 4 * ((lane >> 2) & 3) + 2 * (lane & 1)) >> 1;     // its channel pair within the half
-  const int R = s.nrounds, Cin = s.Cin, nt120 = (s.rows + 119) / 120;
+  const int R = s.nrounds, Cin = s.Cin;
   constexpr int NPTS = map20 ? 20 : 120;
   auto pdiv = [&](int x) { return x / NPTS; };
   const unsigned char* img = reinterpret_cast<const unsigned char*>(s.img);
@@ -114,16 +114,10 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
 #define PWDBG(bit) 0
 #endif
 
-  auto empty = [&](int ri) -> bool {
-    if (!s.cnt) return false;
-    int n = s.cnt[2 * ri];
-    if (2 * ri + 1 < nt120) n += s.cnt[2 * ri + 1];
-    return n == 0;
-  };
-  auto next_round = [&](int ri) {            // first round >= ri of this workgroup with a valid point
-    while (ri < R && empty(ri)) ri += G;
-    return ri;
-  };
+  // this workgroup's rounds: positions wg, wg + G, ... of the live list (train mode) or of 0 .. R - 1
+  const int NL = s.live ? __builtin_amdgcn_readfirstlane(p.hdr[map20 ? 0 : 1]) : R;
+  auto round_at = [&](int pos) { return pos >= NL ? R : (s.live ? __builtin_amdgcn_readfirstlane(s.live[pos]) : pos); };
+  int li = wg;
   auto dma = [&](const unsigned char* src, uint32_t dst, int nfrag) {
     if (PWDBG(2)) return;                     // (diagnostic: no weight stream -- compute on whatever the ring holds)
     decw_dma_share(src, voff, lds0 + dst, nfrag, wv, 8);
@@ -159,7 +153,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   };
 
   int gc = 0;                                 // groups consumed so far: group gc sits in ring slot gc & 1
-  int ri = next_round(wg);
+  int ri = round_at(li);
   if (ri >= R) {
     if (p.do_stats) { s.part2[(size_t)tid * G + wg] = 0.f; if (tid == 0) s.cnt2[wg] = 0; }
     return;
@@ -223,7 +217,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     }
     const bool wact = __builtin_amdgcn_ballot_w64(fl[0] == 1 || fl[1] == 1) != 0;        // a valid point among this wave's 32 rows
     const int nval = __builtin_popcountll(__builtin_amdgcn_ballot_w64(fl[0] == 1 && l4 == 0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(fl[1] == 1 && l4 == 0));
-    const int nri = next_round(ri + G);
+    const int nri = round_at(li + G);
 
     // group k of the round has landed for everybody and nobody reads the other slot any more: request group k + 1 into it
     // (fragment offsets: W1 0 | W2 8, 40 | W3a 72, 104, 136, 168; behind the last group the next round's W1)
@@ -469,7 +463,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     }
     if (lane == 0) *reinterpret_cast<int*>(scr + 2048) = nval;
     prev_ri = ri;
-    ri = nri;
+    ri = nri; li += G;
   }
   __syncthreads();
   if (pend) store_hold(3);
@@ -487,8 +481,9 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
 
 // workgroups [0, ga) walk the map encoder's rounds, the others the reference-line encoder's
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pe_w_kernel(PeWP p) {
-  if ((int)blockIdx.x < p.ga) pe_w_body<true>(p.a, p, blockIdx.x, p.ga);
-  else pe_w_body<false>(p.b, p, blockIdx.x - p.ga, gridDim.x - p.ga);
+  const int ga = p.hdr ? __builtin_amdgcn_readfirstlane(p.hdr[2]) : p.ga;
+  if ((int)blockIdx.x < ga) pe_w_body<true>(p.a, p, blockIdx.x, ga);
+  else pe_w_body<false>(p.b, p, blockIdx.x - ga, gridDim.x - ga);
 }
 
 int pew_set_attributes() {

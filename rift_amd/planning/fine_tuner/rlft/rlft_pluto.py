@@ -195,18 +195,20 @@ class RLFTPluto(PLUTO):
             if shuffle:
                 idx = idx[torch.randperm(idx.numel(), generator=g)]
             idx_dev = idx.to(torch.int32).to(self.device)
+            up = torch.cuda.Event()           # the upload is queued on this stream; the prefetch stream's gathers wait for it
+            up.record()
             for s in range(0, idx.numel(), bs):
                 m = min(bs, idx.numel() - s)
                 if m < world:       # a tail with fewer scenes than ranks cannot give every rank a scene (each one has to join the
                     continue        # exchanges of the forward): dropped on ALL ranks alike -- at most world - 1 scenes per pass
                 lo, hi = split_minibatch(m, rank, world) if world > 1 else (0, m)
-                yield idx_dev[s + lo:s + hi], int(replay.r_count_cpu[idx[s:s + m]].max()), ((lo, m) if world > 1 else None)
+                yield idx_dev[s + lo:s + hi], int(replay.r_count_cpu[idx[s:s + m]].max()), ((lo, m) if world > 1 else None), up
 
         def run(batch, train):
-            idx_dev, R_out, shard = batch
-            # training steps alternate between two batch-buffer sets: the tail of step k (policy head .. AdamW) runs beside the gather and
-            # trunk of step k + 1 (RLFTTrainer.next_slot); validation joins the update stream first and uses slot 0
-            fb, b = replay.collate(eng, idx_dev, R_out, slot=trainer.next_slot() if train else 0)
+            idx_dev, R_out, shard, up = batch
+            # training steps alternate between two batch-buffer sets: the tail of step k (policy head .. AdamW) runs beside the trunk of step
+            # k + 1, whose batch is gathered on the prefetch stream (RLFTTrainer.gather); validation joins the update stream first and uses slot 0
+            fb, b = trainer.gather(replay, idx_dev, R_out, ready=up) if train else replay.collate(eng, idx_dev, R_out, slot=0)
             if extras:
                 b = dict(b)
                 for k, v in extras.items():

@@ -223,11 +223,17 @@ class RLFTTrainer:
         # -- policy head, loss, pi_head backward, exchange, finalize, clip, AdamW -- runs on the update stream beside the next step's
         # gather and frozen trunk (rift_forward with RIFT_F_DEFER_HEAD + rift_forward_head; two activation arenas, two batch-buffer sets).
         self.pipeline = self.overlap_update and os.environ.get("RIFT_PIPELINE", "1") == "1" and kind in ("rift", "grpo", "reinforce")
-        self._slot, self._slot_taken = 0, False
+        self._slot, self._slot_taken, self._slot_prefetch = 0, False, False
+        self._prefetch = None
         if self.pipeline:
             self._ev_tail = [torch.cuda.Event(), torch.cuda.Event()]         # end of the tail that read slot / arena i
             for e in self._ev_tail:
                 e.record(torch.cuda.current_stream(dev))
+            # Input prefetch (RIFT_PREFETCH=0 switches it off): the gather of the next batch (DeviceReplay.collate(stream=prefetch_stream)) and
+            # the forward's input-only preparation (rift_set_prepare_stream) run on a stream of their own, beside the current step's kernels
+            # instead of between two steps
+            if os.environ.get("RIFT_PREFETCH", "1") == "1":
+                self._prefetch = torch.cuda.Stream(device=dev)
 
     # ------------------------------------------------------------------------------------
     def _outputs(self, bs, R):
@@ -385,16 +391,39 @@ class RLFTTrainer:
         self.loss = self.loss_val if k is None else self.loss_hist[k:k + 1]
         self.lo.loss = self.loss.data_ptr()
 
-    def next_slot(self) -> int:
+    @property
+    def prefetch_stream(self):
+        """The stream the next batch is gathered on (pass it to DeviceReplay.collate(stream=)), or None: gather on the current stream.  None
+        on the data-parallel path, whose forwards exchange through one buffer in step order."""
+        if self._prefetch is None or (self.exchange is not None and (self.world > 1 or self.force_exchange)):
+            return None
+        return self._prefetch
+
+    def next_slot(self, prefetch: bool = False) -> int:
         """Batch-buffer slot of the NEXT training step (pass it to DeviceReplay.collate).  Calling it is what enables the deferred tail:
-        the current stream first waits until the tail that last read this slot (two steps ago) is over, then the caller may overwrite
-        the slot's buffers while the previous step's tail is still running."""
+        the stream the batch is gathered on first waits until the tail that last read this slot (two steps ago) is over, then the caller
+        may overwrite the slot's buffers while the previous step's tail is still running.  `prefetch`: the caller gathers on
+        `prefetch_stream` (if that is not None) -- see gather()."""
         if not self.pipeline:
+            self._slot_prefetch = False
             return 0
         self._slot ^= 1
         self._slot_taken = True
-        torch.cuda.current_stream().wait_event(self._ev_tail[self._slot])
+        self._slot_prefetch = prefetch and self.prefetch_stream is not None
+        # with prefetch it is the prefetch stream that waits for the slot's (and the activation arena's) last reader: the gather and the
+        # forward's input preparation run there (rift_set_prepare_stream), and the forward's own streams wait for the preparation
+        (self.prefetch_stream if self._slot_prefetch else torch.cuda.current_stream()).wait_event(self._ev_tail[self._slot])
         return self._slot
+
+    def gather(self, replay, scene_idx: torch.Tensor, R_out=None, ready: Optional[torch.cuda.Event] = None):
+        """The batch of the next training step: DeviceReplay.collate into the next slot, on the prefetch stream when there is one (beside the
+        previous step's kernels instead of in front of this step's).  `ready`: an event behind the kernels / copies that produce `scene_idx`,
+        if any are still queued on the caller's stream (a pageable-memory upload is); None when the index tensor is complete."""
+        slot = self.next_slot(prefetch=True)
+        st = self.prefetch_stream if self._slot_prefetch else None
+        if st is not None and ready is not None:
+            st.wait_event(ready)
+        return replay.collate(self.engine, scene_idx, R_out, slot=slot, stream=st)
 
     def training_step(self, fb, extras, shard=None):
         """One optimizer step (LightningTrainer.training_step + Lightning's clip + optimizer.step).  Returns the device f64 loss
@@ -409,7 +438,11 @@ class RLFTTrainer:
             # trunk on the current stream, everything behind it on the update stream (which is serial in itself: head k waits for AdamW k-1)
             self._slot_taken = False
             slot = self._slot
+            if self._slot_prefetch:
+                self.engine.set_prepare_stream(self.prefetch_stream)
             self.forward_trunk(fb, shard)
+            if self._slot_prefetch:
+                self.engine.set_prepare_stream(None)
             main = torch.cuda.current_stream()
             self._ev_loss.record(main)
             with torch.cuda.stream(self._side):

@@ -119,19 +119,29 @@ class DeviceReplay:
         self._out[key] = (fb, b)
         return self._out[key]
 
-    def collate(self, engine: "_ffi.Engine", scene_idx: torch.Tensor, R_out: Optional[int] = None, slot: int = 0):
+    def collate(self, engine: "_ffi.Engine", scene_idx: torch.Tensor, R_out: Optional[int] = None, slot: int = 0,
+                stream: Optional[torch.cuda.Stream] = None):
         """Gather `scene_idx` (int32, device) into the (cached) batch buffers.
         Returns (RiftFeatureBatch, dict of batch tensors incl. the RIFT/GRPO extras).
         `slot`: which of the cached buffer sets to fill -- a trainer that runs the loss of step k beside the forward of step k + 1
-        (RLFTTrainer.next_slot) alternates between two, so that step k + 1's gather does not overwrite what step k's loss still reads."""
+        (RLFTTrainer.next_slot) alternates between two, so that step k + 1's gather does not overwrite what step k's loss still reads.
+        `stream`: gather on this stream instead of the current one (RLFTTrainer.prefetch_stream: the gather then runs beside the previous
+        step's kernels; the trainer's forward waits for it).  `scene_idx` must be complete when the call is made -- an index tensor built
+        by kernels still queued on another stream needs its own event."""
         bs = scene_idx.numel()
         if R_out is None:
             R_out = self.Rcap
-        fb, b = self._buffers(bs, R_out, slot)
+        if stream is not None:
+            with torch.cuda.stream(stream):       # (a slot's buffers are allocated once, from the pool of the stream that writes them)
+                fb, b = self._buffers(bs, R_out, slot)
+        else:
+            fb, b = self._buffers(bs, R_out, slot)
         rc = engine.lib.rift_collate(
             engine.ctx, C.byref(self.arena), C.c_void_p(scene_idx.data_ptr()), bs, R_out, C.byref(fb),
             _ffi._ptr(b["old_group_logits"]), _ffi._ptr(b["ref_group_logits"]), _ffi._ptr(b["group_advantage"]),
-            _ffi._ptr(b["group_valid_mask"]), _ffi._stream())
+            _ffi._ptr(b["group_valid_mask"]), C.c_void_p(stream.cuda_stream) if stream is not None else _ffi._stream())
+        if stream is not None:
+            scene_idx.record_stream(stream)
         if rc != 0:
             engine._check(rc, "rift_collate")
         return fb, b

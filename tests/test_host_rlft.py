@@ -331,14 +331,20 @@ def test_update_on_second_stream_equals_serial_update(tmp_path, monkeypatch):
     """RLFTTrainer.overlap_update (exchange + finalize + clip + AdamW of step k on a second stream while the frozen trunk of step k+1
     runs; the engine waits for the update's event before reading pi_head) and the deferred tail on top of it (RIFT_PIPELINE: policy
     head, loss and backward move to that stream too -- two activation arenas, two batch-buffer sets) give bit-identical parameters,
-    history and checkpoint losses to the serial order (RIFT_NO_OVERLAP=1): same kernels, same seeds, only the stream placement differs."""
+    history and checkpoint losses to the serial order (RIFT_NO_OVERLAP=1): same kernels, same seeds, only the stream placement differs.
+    Likewise the input prefetch (RLFTTrainer.gather: the next batch's gather and the forward's input preparation on a third stream,
+    rift_set_prepare_stream), with the next step's map chain free to start beside the current step's encoder / decoder (small batches) or
+    gated behind them (RIFT_SIDE_GATE=1: what a batch that fills the chip gets)."""
     from rift_amd.planning import CBV_POLICY_LIST
     torch.cuda.set_device(0)
     results = {}
     monkeypatch.setenv("RIFT_OVERLAP", "1")
-    for mode, (no_overlap, pipeline) in {"0": ("0", "0"), "1": ("1", "0"), "2": ("0", "1")}.items():
+    for mode, (no_overlap, pipeline, prefetch, gate) in {"0": ("0", "0", "0", "-1"), "1": ("1", "0", "0", "-1"), "2": ("0", "1", "1", "-1"),
+                                                         "3": ("0", "1", "0", "-1"), "4": ("0", "1", "1", "1")}.items():
         monkeypatch.setenv("RIFT_NO_OVERLAP", no_overlap)
         monkeypatch.setenv("RIFT_PIPELINE", pipeline)
+        monkeypatch.setenv("RIFT_PREFETCH", prefetch)
+        monkeypatch.setenv("RIFT_SIDE_GATE", gate)
         root = tmp_path / mode
         cfg = {'num_scenario': 1, 'ROOT_DIR': str(root), 'model_path': 'ckpt', 'device': 'cuda:0',
                'rlft': {'epochs': 3, 'warmup_epochs': 1, 'train_batch_size': 8, 'val_batch_size': 8, 'lr': 1e-3}}
@@ -356,7 +362,7 @@ def test_update_on_second_stream_equals_serial_update(tmp_path, monkeypatch):
         results[mode] = (fit["history"], {k: v.detach().cpu().clone() for k, v in pol.pluto_model.state_dict().items()
                                           if k.startswith("planning_decoder.pi_head")})
     h0, p0 = results["0"]
-    for other in ("1", "2"):
+    for other in ("1", "2", "3", "4"):
         h1, p1 = results[other]
         assert [(h["train_loss"], h["val_loss"]) for h in h0] == [(h["train_loss"], h["val_loss"]) for h in h1], other
         for k in p0:

@@ -20,7 +20,7 @@ tr = RLFTTrainer(model, kind="rift")
 g = torch.Generator().manual_seed(0)
 idx = [torch.randperm(len(scenes), generator=g)[:bs].to(torch.int32).to(dev) for _ in range(16)]
 def step(i):
-    fb, b = replay.collate(tr.engine, idx[i], slot=tr.next_slot()); return tr.training_step(fb, b)
+    fb, b = tr.gather(replay, idx[i]); return tr.training_step(fb, b)
 for i in range(4): step(i)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(4, 14): loss = step(i)

@@ -18,7 +18,7 @@ tr = RLFTTrainer(model, kind="rift")
 BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 idx = [torch.randperm(512)[:BATCH].to(torch.int32).to(dev) for _ in range(64)]
 def step(i):
-    fb, b = replay.collate(tr.engine, idx[i % 64], slot=tr.next_slot()); return tr.training_step(fb, b)
+    fb, b = tr.gather(replay, idx[i % 64]); return tr.training_step(fb, b)
 for i in range(10): step(i)
 torch.cuda.synchronize()
 import cProfile, pstats
