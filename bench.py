@@ -280,7 +280,7 @@ def main():
         shard = (rank * local_bs, global_bs)
 
         def step(i):
-            fb, b = trainer.gather(replay, idx[i % nsteps])     # (two batch-buffer sets, gathered on the prefetch stream: step k's tail and step k + 1's gather run beside the trunks)
+            fb, b = trainer.gather(replay, idx[i % nsteps])     # (DEFER_SLOTS batch-buffer sets, gathered on the prefetch stream: step k's tail and step k + 1's gather run beside the trunks)
             return trainer.training_step(fb, b, shard=shard)
 
         def timed(first, count):

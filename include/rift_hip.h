@@ -37,10 +37,14 @@ enum {
   RIFT_F_NO_BN_UPDATE = 16,/* with TRAIN: do not update BatchNorm running statistics */
   RIFT_F_DEFER_HEAD = 32   /* stop in front of the policy head: everything up to the decoder output reads frozen weights only, so the caller
                               may run rift_forward_head + rift_loss_backward + its optimizer step on ANOTHER stream while the next
-                              rift_forward (the trunk of the next minibatch) is already under way.  Deferred forwards alternate between
-                              two activation arenas; before the forward after next the caller must know the deferred head and
-                              rift_loss_backward of this one to be finished (an event wait) */
+                              rift_forward (the trunk of the next minibatch) is already under way.  Deferred forwards cycle through
+                              RIFT_DEFER_SLOTS activation arenas; before the RIFT_DEFER_SLOTS-th forward after this one the caller must
+                              know the deferred head and rift_loss_backward of this one to be finished (an event wait) */
 };
+/* (four: the front of step k + 1 -- gather, preparation, history and map encoders -- can then run beside step k without waiting for the
+ *  head / loss / update of step k - 1: with two arenas that wait closes a cycle of two steps' length through tail -> front -> encoder ->
+ *  decoder -> tail, which is what bounds a small-batch step.) */
+#define RIFT_DEFER_SLOTS 4
 
 /* loss kinds */
 enum { RIFT_LOSS_RIFT = 0, RIFT_LOSS_GRPO = 1, RIFT_LOSS_PPO = 2, RIFT_LOSS_REINFORCE = 3,
@@ -187,7 +191,7 @@ int rift_set_dp(RiftCtx* ctx, const RiftDp* dp);
  * own streams wait for it: a host that runs ahead of the device (the update loop does, by about a step) gets the next step's inputs built
  * beside the current step's kernels instead of between two steps (12 + 12 us of a 0.7 ms step at 256 scenes, 7 + 6 of 0.39 at 32).  The
  * caller orders `prepare_stream` behind whatever last read the batch buffers and the activation arena of this forward (with
- * RIFT_F_DEFER_HEAD: the head / loss of the forward before last).  NULL (the default) keeps the preparation on the forward's stream; the
+ * RIFT_F_DEFER_HEAD: the head / loss of the forward RIFT_DEFER_SLOTS calls back).  NULL (the default) keeps the preparation on the forward's stream; the
  * data-parallel path and the per-kernel profile ignore the setting.  Results do not depend on it. */
 int rift_set_prepare_stream(RiftCtx* ctx, void* prepare_stream);
 

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librift_hip.so")
 
 # forward flags / loss kinds (include/rift_hip.h)
 F_TRAIN, F_NEED_TRAJ, F_FP32, F_NO_DROP, F_NO_BN_UPDATE, F_DEFER_HEAD = 1, 2, 4, 8, 16, 32
+DEFER_SLOTS = 4        # RIFT_DEFER_SLOTS: activation arenas the deferred-head forwards cycle through
 LOSS_KINDS = {"rift": 0, "grpo": 1, "ppo": 2, "reinforce": 3, "sft": 4}
 PI_NPARAM = 16897
 

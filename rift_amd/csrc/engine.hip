@@ -66,12 +66,12 @@ struct RiftCtx {
   // policy head / loss / backward of step k (rift_forward_head, rift_loss_backward on another stream) read step k's activations while the
   // frozen trunk of step k + 1 already writes its own.
   char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
-  char* arenas[2] = {nullptr, nullptr}; size_t arena_caps[2] = {0, 0}; int parity = 0;
+  char* arenas[RIFT_DEFER_SLOTS] = {}; size_t arena_caps[RIFT_DEFER_SLOTS] = {}; int parity = 0;     // (parity: the arena of the current forward)
   struct Head {   // what the policy head of a forward needs (pi_forward .. trajectory heads); kept per arena for the deferred form
     bool valid = false, fp32 = false, need_traj = false;
     float *Q = nullptr, *x0p = nullptr, *QF = nullptr, *Hpi = nullptr, *prob = nullptr, *traj = nullptr, *o3[3] = {nullptr, nullptr, nullptr}, *oT[3] = {nullptr, nullptr, nullptr};
     uint8_t* r_kpm = nullptr; int bs = 0, R = 0, nQ = 0;
-  } head[2];
+  } head[RIFT_DEFER_SLOTS];
   bool dry = false;
   hipStream_t stream = nullptr;
   std::unordered_map<std::string, Tap> taps;
@@ -94,7 +94,8 @@ struct RiftCtx {
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
   bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true;
-  hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = -1; int n_cu = 256;      // rift_set_prepare_stream
+  hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = 0;      // rift_set_prepare_stream
+  hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr; bool nat_aside = true;
   int side_prio = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
   bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
@@ -919,19 +920,30 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // map / reference-line chain leaves idle (partial last rounds, 238-workgroup launches) and vice versa.  Off while profiling per kernel.
   hipStream_t main_stream = c->stream;
   const bool forked = c->two_streams && fused && !c->prof_on && !c->dry;
+  bool nat_aside = false;
   if (forked) {
     if (!c->side) { HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, c->side_prio)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
-    // the map chain waits for the preparation and -- when the batch fills the chip, i.e. the previous forward's one-workgroup-per-scene
-    // encoder / decoder hold every CU -- for the caller's stream to get here; a smaller batch leaves CUs free, and the map chain of step
-    // k + 1 then runs beside the encoder / decoder of step k (measured, ms per step gated / not: 32 scenes 0.374 / 0.365, 64 0.399 / 0.391,
-    // 128 0.499 / 0.454, 192 0.593 / 0.593, 256 0.699 / 0.711; RIFT_SIDE_GATE=0|1 forces it)
-    const bool gate = c->side_gate >= 0 ? c->side_gate != 0 : bs >= c->n_cu;
+    // With the preparation prefetched, neither front chain of step k + 1 needs anything of step k: the map chain (side stream) waits for
+    // the preparation only, the agent-history chain follows it on the prepare stream, and the caller's queue holds token assembly ->
+    // encoder -> decoder of step k, then of step k + 1 -- the fronts run beside the previous step's one-workgroup-per-scene encoder /
+    // decoder (which leave most of the chip idle below 256 scenes, and SIMD slots at 256).  ms per step, fronts behind the caller's queue
+    // / beside it: 32 scenes 0.372 / 0.237, 64 0.394 / 0.245, 128 0.462 / 0.389, 192 0.597 / 0.524, 256 0.701 / 0.678.  What it took:
+    // RIFT_DEFER_SLOTS = 4 arenas (with two, tail k - 1 -> front k + 1 -> encoder / decoder k + 1 -> tail k + 1 is a cycle two steps long)
+    // and no further hardware queue for the history chain (on a stream of its own every cross-queue wait of the step got slower: 0.372).
+    // RIFT_SIDE_GATE=1 keeps the fronts behind the caller's queue (the event record costs that queue ~5 us), RIFT_NAT_ASIDE=0 the history
+    // chain on it.
+    const bool gate = c->side_gate > 0;
     if (prefetched) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_prep, 0));
     if (!prefetched || gate) {
       HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
       HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     }
-    if (!c->nat_on_main) c->stream = c->side;
+    nat_aside = prefetched && !gate && c->nat_aside;
+    if (nat_aside) {
+      if (!c->ev_join2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+      c->side2 = c->prep_stream;
+      c->stream = c->side2;
+    } else if (!c->nat_on_main) c->stream = c->side;
   }
   static const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128}, Hl[3] = {2, 4, 8}, Kl[3] = {3, 3, 5};
   float* Oc[3];   // LayerNorm(norm_i) of the last 3 steps of level i: all that out[:, :, -1] of the FPN depends on
@@ -1048,7 +1060,11 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   }
   // the longer chain (agent history: ~310 of the front's ~510 us at 256 scenes) stays on the caller's queue, so neither its start nor the
   // join pays a cross-queue hop (12-15 us each by the kernel trace); the map / reference-line chain is the one that forks
-  if (forked) { if (c->nat_on_main) c->stream = c->side; else { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; } }
+  if (forked) {
+    if (nat_aside) { HIPCHK(c, hipEventRecord(c->ev_join2, c->side2)); c->stream = c->side; }
+    else if (c->nat_on_main) c->stream = c->side;
+    else { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
+  }
   tap(c, "nat_out", nat_out, (int64_t)nA * 128);
 
   // ego state token (StateAttentionEncoder, agent_encoder.py:99-140)
@@ -1150,8 +1166,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     return RIFT_OK;
   };
   if (forked && rpe_done) { const int rc0 = build_q0(); if (rc0 != RIFT_OK) return rc0; }
-  if (forked && c->nat_on_main) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
+  if (forked && (c->nat_on_main || nat_aside)) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
   if (forked) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));      // join: the agent tokens need both chains
+  if (nat_aside) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join2, 0));
   {
     TokenP q;
     q.nat = nat_out; q.x_ego = x_ego; q.valid_agent = (const uint8_t*)valid_agent; q.category = B->agent_category; q.a_type_emb = fptr(c, "agent_encoder.type_emb.weight");
@@ -1432,7 +1449,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_COMPACT"); if (ev) c->nat_compact = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_PE_LIVE"); if (ev) c->pe_live = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
-  { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->n_cu = n; }
+  { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_SIDE_PRIO"); if (ev) c->side_prio = atoi(ev); }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
@@ -1450,7 +1467,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
 void rift_ctx_destroy(RiftCtx* c) {
   if (!c) return;
   for (void* p : c->owned) (void)hipFree(p);
-  for (int i = 0; i < 2; ++i) if (c->arenas[i]) (void)hipFree(c->arenas[i]);
+  for (int i = 0; i < RIFT_DEFER_SLOTS; ++i) if (c->arenas[i]) (void)hipFree(c->arenas[i]);
   if (c->l_S) (void)hipFree(c->l_S);
   if (c->l_cnt) (void)hipFree(c->l_cnt);
   if (c->l_dz) (void)hipFree(c->l_dz);
@@ -1469,6 +1486,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   for (int i = 0; i < 2; ++i) if (c->pew_img[i]) (void)hipFree(c->pew_img[i]);
   for (int i = 0; i < 3; ++i) if (c->fow_img[i]) { (void)hipFree(c->fow_img[i]); (void)hipFree(c->fow_par[i]); }
   if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   delete c;
@@ -1710,9 +1728,9 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (B->bs <= 0 || B->A <= 0 || B->Mp <= 0 || B->R <= 0 || B->S < 0 || B->T < 21) { c->err = "bad batch dims"; return RIFT_ERR_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   c->stream = (hipStream_t)stream;
-  // deferred-head forwards alternate between the two arenas (the caller guarantees that the head / loss of the forward before last is over,
-  // i.e. that this arena is free again); every other forward runs in arena 0
-  c->parity = (flags & RIFT_F_DEFER_HEAD) ? (c->parity ^ 1) : 0;
+  // deferred-head forwards cycle through the arenas (the caller guarantees that the head / loss of the forward RIFT_DEFER_SLOTS calls back is
+  // over, i.e. that this arena is free again); every other forward runs in arena 0
+  c->parity = (flags & RIFT_F_DEFER_HEAD) ? (c->parity + 1) % RIFT_DEFER_SLOTS : 0;
   c->arena = c->arenas[c->parity]; c->arena_cap = c->arena_caps[c->parity];
   // pass 1 (dry): size the activation arena; pass 2: launch
   c->dry = true; c->arena_off = 0;

@@ -206,7 +206,7 @@ class RLFTPluto(PLUTO):
 
         def run(batch, train):
             idx_dev, R_out, shard, up = batch
-            # training steps alternate between two batch-buffer sets: the tail of step k (policy head .. AdamW) runs beside the trunk of step
+            # training steps cycle through _ffi.DEFER_SLOTS batch-buffer sets: the tail of step k (policy head .. AdamW) runs beside the trunk of step
             # k + 1, whose batch is gathered on the prefetch stream (RLFTTrainer.gather); validation joins the update stream first and uses slot 0
             fb, b = trainer.gather(replay, idx_dev, R_out, ready=up) if train else replay.collate(eng, idx_dev, R_out, slot=0)
             if extras:

@@ -221,12 +221,12 @@ class RLFTTrainer:
             self.engine.set_param_event(self._ev_param)
         # Deferred tail (RIFT_PIPELINE=0 switches it off): with the caller taking its batch buffers by `next_slot()`, the WHOLE tail of a step
         # -- policy head, loss, pi_head backward, exchange, finalize, clip, AdamW -- runs on the update stream beside the next step's
-        # gather and frozen trunk (rift_forward with RIFT_F_DEFER_HEAD + rift_forward_head; two activation arenas, two batch-buffer sets).
+        # gather and frozen trunk (rift_forward with RIFT_F_DEFER_HEAD + rift_forward_head; DEFER_SLOTS activation arenas and batch-buffer sets).
         self.pipeline = self.overlap_update and os.environ.get("RIFT_PIPELINE", "1") == "1" and kind in ("rift", "grpo", "reinforce")
         self._slot, self._slot_taken, self._slot_prefetch = 0, False, False
         self._prefetch = None
         if self.pipeline:
-            self._ev_tail = [torch.cuda.Event(), torch.cuda.Event()]         # end of the tail that read slot / arena i
+            self._ev_tail = [torch.cuda.Event() for _ in range(_ffi.DEFER_SLOTS)]      # end of the tail that read slot / arena i
             for e in self._ev_tail:
                 e.record(torch.cuda.current_stream(dev))
             # Input prefetch (RIFT_PREFETCH=0 switches it off): the gather of the next batch (DeviceReplay.collate(stream=prefetch_stream)) and
@@ -401,13 +401,13 @@ class RLFTTrainer:
 
     def next_slot(self, prefetch: bool = False) -> int:
         """Batch-buffer slot of the NEXT training step (pass it to DeviceReplay.collate).  Calling it is what enables the deferred tail:
-        the stream the batch is gathered on first waits until the tail that last read this slot (two steps ago) is over, then the caller
+        the stream the batch is gathered on first waits until the tail that last read this slot (DEFER_SLOTS steps ago) is over, then the caller
         may overwrite the slot's buffers while the previous step's tail is still running.  `prefetch`: the caller gathers on
         `prefetch_stream` (if that is not None) -- see gather()."""
         if not self.pipeline:
             self._slot_prefetch = False
             return 0
-        self._slot ^= 1
+        self._slot = (self._slot + 1) % _ffi.DEFER_SLOTS
         self._slot_taken = True
         self._slot_prefetch = prefetch and self.prefetch_stream is not None
         # with prefetch it is the prefetch stream that waits for the slot's (and the activation arena's) last reader: the gather and the

@@ -124,7 +124,7 @@ class DeviceReplay:
         """Gather `scene_idx` (int32, device) into the (cached) batch buffers.
         Returns (RiftFeatureBatch, dict of batch tensors incl. the RIFT/GRPO extras).
         `slot`: which of the cached buffer sets to fill -- a trainer that runs the loss of step k beside the forward of step k + 1
-        (RLFTTrainer.next_slot) alternates between two, so that step k + 1's gather does not overwrite what step k's loss still reads.
+        (RLFTTrainer.next_slot) cycles through _ffi.DEFER_SLOTS of them, so that step k + 1's gather does not overwrite what step k's loss still reads.
         `stream`: gather on this stream instead of the current one (RLFTTrainer.prefetch_stream: the gather then runs beside the previous
         step's kernels; the trainer's forward waits for it).  `scene_idx` must be complete when the call is made -- an index tensor built
         by kernels still queued on another stream needs its own event."""

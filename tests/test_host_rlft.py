@@ -333,14 +333,14 @@ def test_update_on_second_stream_equals_serial_update(tmp_path, monkeypatch):
     head, loss and backward move to that stream too -- two activation arenas, two batch-buffer sets) give bit-identical parameters,
     history and checkpoint losses to the serial order (RIFT_NO_OVERLAP=1): same kernels, same seeds, only the stream placement differs.
     Likewise the input prefetch (RLFTTrainer.gather: the next batch's gather and the forward's input preparation on a third stream,
-    rift_set_prepare_stream), with the next step's map chain free to start beside the current step's encoder / decoder (small batches) or
-    gated behind them (RIFT_SIDE_GATE=1: what a batch that fills the chip gets)."""
+    rift_set_prepare_stream; four activation arenas / batch-buffer sets), with the next step's history and map encoders beside the current
+    step's encoder / decoder (the default) or gated behind them (RIFT_SIDE_GATE=1)."""
     from rift_amd.planning import CBV_POLICY_LIST
     torch.cuda.set_device(0)
     results = {}
     monkeypatch.setenv("RIFT_OVERLAP", "1")
-    for mode, (no_overlap, pipeline, prefetch, gate) in {"0": ("0", "0", "0", "-1"), "1": ("1", "0", "0", "-1"), "2": ("0", "1", "1", "-1"),
-                                                         "3": ("0", "1", "0", "-1"), "4": ("0", "1", "1", "1")}.items():
+    for mode, (no_overlap, pipeline, prefetch, gate) in {"0": ("0", "0", "0", "0"), "1": ("1", "0", "0", "0"), "2": ("0", "1", "1", "0"),
+                                                         "3": ("0", "1", "0", "0"), "4": ("0", "1", "1", "1")}.items():
         monkeypatch.setenv("RIFT_NO_OVERLAP", no_overlap)
         monkeypatch.setenv("RIFT_PIPELINE", pipeline)
         monkeypatch.setenv("RIFT_PREFETCH", prefetch)
