@@ -69,6 +69,24 @@ __device__ __forceinline__ void p_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
   }
 }
 
+// the same over the first K row tiles only (K a compile-time count: a run-time predicate inside the loops made hipcc index the fragments
+// dynamically -- 1 KB of scratch per lane -- or, row tile by row tile, double the registers)
+template <int K, int MT, int KS, int NTW>
+__device__ __forceinline__ void p_mma_first(f32x4 (&acc)[MT][NTW], const unsigned short* A, int lda, int k0, const PFrags<KS, NTW>& B,
+                                            int l15, int l4) {
+  static_assert(K <= MT, "row tiles");
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    h16x8 a[K];
+#pragma unroll
+    for (int mt = 0; mt < K; ++mt) a[mt] = *reinterpret_cast<const h16x8*>(A + (mt * 16 + l15) * lda + k0 + ks * 32 + l4 * 8);
+#pragma unroll
+    for (int mt = 0; mt < K; ++mt)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[mt][j] = mfma_h(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+  }
+}
+
 template <int MT, int NTW>
 __device__ __forceinline__ void p_zero(f32x4 (&acc)[MT][NTW]) {
 #pragma unroll
@@ -467,7 +485,13 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
   p_load_w<NW, 4, 1>(Wd, p.w4, 256, 128, wave, l15, l4);
   unsigned char fv = 0;
   if (tid < PE_ROWS && tid < PE_USED && row0 + tid < p.rows) fv = p.valid[row0 + tid] ? 1 : 2;
+  // the row tiles behind the last valid point hold zero rows only (a reference line's valid points are a prefix of its 120): their g is
+  // not fetched and their rows take no part in the contraction -- the o rows of invalid points are zero whatever the GEMM says
+  unsigned long long* sbal = reinterpret_cast<unsigned long long*>(pm);
+  { const unsigned long long bal = __ballot(fv == 1); if (lane == 0 && wave < 2) sbal[wave] = bal; }
   const int nv = __syncthreads_count(fv == 1);
+  const unsigned long long bal0 = sbal[0], bal1 = sbal[1];
+  const int nmt = __builtin_amdgcn_readfirstlane(((bal1 ? 128 - __builtin_clzll(bal1) : bal0 ? 64 - __builtin_clzll(bal0) : 0) + 15) >> 4);
   if (nv == 0) {   // every row zero -> the max is zero
     for (int i = tid; i < GPT * 128; i += 512) {
       const int grp = tile * GPT + i / 128;
@@ -482,7 +506,7 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
     for (int u = 0; u < 8; ++u) {
       const int i = tid + u * 512, r = i >> 5, c8 = (i & 31) * 8;
       gv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (r < PE_USED && row0 + r < p.rows) gv[u] = *reinterpret_cast<const uint4*>(p.Fmid + (size_t)(row0 + r) * 256 + c8);
+      if (r < PE_USED && row0 + r < p.rows && r < 16 * nmt) gv[u] = *reinterpret_cast<const uint4*>(p.Fmid + (size_t)(row0 + r) * 256 + c8);
     }
     float pv[2];
 #pragma unroll
@@ -508,7 +532,7 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
       o.y = pack_h2(fmaxf(x[2] * s0.z + t0.z, 0.f), fmaxf(x[3] * s0.w + t0.w, 0.f));
       o.z = pack_h2(fmaxf(x[4] * s1.x + t1.x, 0.f), fmaxf(x[5] * s1.y + t1.y, 0.f));
       o.w = pack_h2(fmaxf(x[6] * s1.z + t1.z, 0.f), fmaxf(x[7] * s1.w + t1.w, 0.f));
-      *reinterpret_cast<uint4*>(fl + r * PE_GS + c8) = o;     // (rows that do not exist carry relu(t2): masked below)
+      if (r < 16 * nmt) *reinterpret_cast<uint4*>(fl + r * PE_GS + c8) = o;     // (rows that do not exist carry relu(t2): masked below)
     }
   }
   __syncthreads();
@@ -517,8 +541,10 @@ __device__ __forceinline__ void pe_out_body(const PeP& p, const int tile) {
   {
     f32x4 acc[MT][1];
     p_zero(acc);
-    p_mma<MT, 4, 1>(acc, fl, PE_GS, 0, Wc, l15, l4);
-    p_mma<MT, 4, 1>(acc, fl, PE_GS, 128, Wd, l15, l4);
+    if (nmt <= 2) { p_mma_first<2, MT, 4, 1>(acc, fl, PE_GS, 0, Wc, l15, l4); p_mma_first<2, MT, 4, 1>(acc, fl, PE_GS, 128, Wd, l15, l4); }
+    else if (nmt <= 4) { p_mma_first<4, MT, 4, 1>(acc, fl, PE_GS, 0, Wc, l15, l4); p_mma_first<4, MT, 4, 1>(acc, fl, PE_GS, 128, Wd, l15, l4); }
+    else if (nmt <= 6) { p_mma_first<6, MT, 4, 1>(acc, fl, PE_GS, 0, Wc, l15, l4); p_mma_first<6, MT, 4, 1>(acc, fl, PE_GS, 128, Wd, l15, l4); }
+    else { p_mma<MT, 4, 1>(acc, fl, PE_GS, 0, Wc, l15, l4); p_mma<MT, 4, 1>(acc, fl, PE_GS, 128, Wd, l15, l4); }
     __syncthreads();
     const int col = wave * 16 + l4 * 4;
     const float4 b = *reinterpret_cast<const float4*>(par + P_B4 + col);

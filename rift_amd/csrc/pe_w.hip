@@ -182,7 +182,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   int prev_ri = -1;
   // g of a group leaves one boundary late (a store issued just ahead of a boundary would be waited for there: vmcnt counts stores too)
   uint32_t hold[2][8];
-  bool hex[2] = {false, false};               // rows of the held tiles exist
+  bool hex[2] = {false, false};               // rows of the held tiles are valid points
   int hrow0 = 0;
   auto store_hold = [&](int q) {
     if (PWDBG(1)) return;                     // (diagnostic: no g stores)
@@ -376,7 +376,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       for (int q = 0; q < 4; ++q) {
         // (the held stores go out AHEAD of the request: behind it they queue in the texture path after the group's 32 requests)
         boundary(3 + q, [&] { if (q == 1 && nri < R) { to_operand(nxv, xb); vb[0] = nvb[0]; vb[1] = nvb[1]; } if (q > 0) store_hold(q - 1); });
-        if (q == 0) { hex[0] = fl[0] != 0; hex[1] = fl[1] != 0; hrow0 = row0; pooled_gp(wb); }
+        if (q == 0) { hex[0] = fl[0] == 1; hex[1] = fl[1] == 1; hrow0 = row0; pooled_gp(wb); }      // (g of an invalid point is never read: pass C masks the row)
         if (q == 0 && nri < R) load_rows(nri, nvb, nxv);      // the next round's rows: in flight under this group
         f32x4 c0[4], c1[4];
 #pragma unroll
