@@ -389,8 +389,9 @@ def main():
         return res
 
     head_scaling = args.scaling if world > 1 else "weak"
-    head = leg(head_scaling, args.precision, args.steps, want_all_outputs=True, want_full_update=not args.no_full_update,
-               want_roofline=not args.no_roofline)
+    # The companion legs run FIRST: a process's first ~30 ms of device work run at ramping clocks (per-step times of one leg fall by 5-10 %
+    # over its first 25 steps and are flat in a second leg: tools/jobs/stepdeltas.py), and W = 5 warm-up steps are 4 ms -- the headline leg
+    # should not be the one that pays for the ramp.  (--no-precisions on one GPU leaves nothing in front of it.)
     other = None
     if world > 1:
         other_scaling = "strong" if head_scaling == "weak" else "weak"
@@ -398,12 +399,16 @@ def main():
     precisions = None
     keep = ("ms_per_step", "value", "steps_per_sec", "steps", "final_loss")
     if world == 1 and not args.no_precisions:
-        precisions = {args.precision: {k: head[k] for k in keep}}
-        for p in ("bf16", "fp16", "fp32"):
-            if p in precisions:
+        precisions = {}
+        for p in ("fp32", "fp16", "bf16"):
+            if p == args.precision:
                 continue
             r = leg("weak", p, args.steps if p != "fp32" else max(5, min(args.steps, 20)))      # (the layer-by-layer fp32 step is several times longer)
             precisions[p] = {k: r[k] for k in keep}
+    head = leg(head_scaling, args.precision, args.steps, want_all_outputs=True, want_full_update=not args.no_full_update,
+               want_roofline=not args.no_roofline)
+    if precisions is not None:
+        precisions[args.precision] = {k: head[k] for k in keep}
         precisions["note"] = ("the same update steps per compute precision: bf16 / fp16 = the fused kernels on bf16 / fp16 MFMA operands; fp32 = exact "
                               "v_mfma_f32_16x16x4_f32 layer by layer (the reference's `precision: 32`).  Parity per mode: tests/test_gpu_parity.py header")
 

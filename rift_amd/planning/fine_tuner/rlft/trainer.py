@@ -234,6 +234,8 @@ class RLFTTrainer:
             # instead of between two steps
             if os.environ.get("RIFT_PREFETCH", "1") == "1":
                 self._prefetch = torch.cuda.Stream(device=dev)
+                self._ev_serial = torch.cuda.Event()                          # end of the last whole step on the caller's stream (forward_loss)
+                self._ev_serial.record(torch.cuda.current_stream(dev))
 
     # ------------------------------------------------------------------------------------
     def _outputs(self, bs, R):
@@ -301,11 +303,20 @@ class RLFTTrainer:
             self.engine.clear_dp()
             self.dp_buf = None
 
-    def forward_loss(self, fb: "_ffi.RiftFeatureBatch", extras: Dict[str, torch.Tensor], train: bool = True,
-                     backward: bool = True, flags_extra: int = 0, clip_val: Optional[float] = None, defer_update: bool = False,
-                     shard=None):
-        """forward + objective (+ pi_head backward into .grad).  Returns the device f64 loss scalar.  With `clip_val` (and no
-        critic, i.e. pi_head is the only trainable module) the gradient-norm clip rides in the finalize launch."""
+    def forward_loss(self, *args, **kwargs):
+        """forward + objective (+ pi_head backward into .grad) on the current stream.  Returns the device f64 loss scalar.  With `clip_val`
+        (and no critic, i.e. pi_head is the only trainable module) the gradient-norm clip rides in the finalize launch."""
+        try:
+            return self._forward_loss(*args, **kwargs)
+        finally:
+            # a whole step on the caller's stream (validation, PPO, a step without next_slot()) runs in activation arena 0 and on batch buffers
+            # the prefetch stream knows nothing about: the next prefetched gather waits for it (next_slot)
+            if self._prefetch is not None:
+                self._ev_serial.record(torch.cuda.current_stream())
+
+    def _forward_loss(self, fb: "_ffi.RiftFeatureBatch", extras: Dict[str, torch.Tensor], train: bool = True,
+                      backward: bool = True, flags_extra: int = 0, clip_val: Optional[float] = None, defer_update: bool = False,
+                      shard=None):
         eng = self.engine
         self._A = fb.A
         self._outputs(fb.bs, fb.R)
@@ -412,7 +423,10 @@ class RLFTTrainer:
         self._slot_prefetch = prefetch and self.prefetch_stream is not None
         # with prefetch it is the prefetch stream that waits for the slot's (and the activation arena's) last reader: the gather and the
         # forward's input preparation run there (rift_set_prepare_stream), and the forward's own streams wait for the preparation
-        (self.prefetch_stream if self._slot_prefetch else torch.cuda.current_stream()).wait_event(self._ev_tail[self._slot])
+        st = self.prefetch_stream if self._slot_prefetch else torch.cuda.current_stream()
+        st.wait_event(self._ev_tail[self._slot])
+        if self._slot_prefetch:
+            st.wait_event(self._ev_serial)
         return self._slot
 
     def gather(self, replay, scene_idx: torch.Tensor, R_out=None, ready: Optional[torch.cuda.Event] = None):

@@ -176,3 +176,50 @@ def test_mean_loss_accounting_across_slot_folds(monkeypatch):
                 tr.validation_step(fb, b)
         assert abs(tr.pop_mean_loss() - sum(losses) / n) < 1e-12
     assert tr.pop_mean_loss() == 0.0
+
+
+def test_validation_between_prefetched_training_steps(monkeypatch):
+    """Training steps whose batch is gathered on the prefetch stream (RLFTTrainer.gather, four batch-buffer sets / activation arenas), with a
+    validation step on the caller's stream -- batch-buffer set 0, activation arena 0 -- after every third one, as the update loop interleaves
+    them: the host runs ahead, so the gather of the step behind a validation is issued while that validation is still running and must wait
+    for it (the trainer's serial-step event).  Losses and parameters equal the run without the prefetch stream bit for bit, and the run
+    without any second stream; 128-scene batches, so that a validation forward is long enough to be overrun."""
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+    from rift_amd.replay import DeviceReplay
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    scenes = [syn.make_scene(2000 + i) for i in range(160)]
+    sd = H.weights()
+    g = torch.Generator().manual_seed(7)
+    train_ix = [torch.randperm(160, generator=g)[:128].to(torch.int32).to(dev) for _ in range(12)]
+    val_ix = torch.arange(128, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    runs = {}
+    for mode, (pipeline, prefetch) in {"serial": ("0", "0"), "tail": ("1", "0"), "prefetch": ("1", "1")}.items():
+        monkeypatch.setenv("RIFT_PIPELINE", pipeline)
+        monkeypatch.setenv("RIFT_PREFETCH", prefetch)
+        replay = DeviceReplay(scenes, dev, rcap=6)
+        model = PlanningModel(radius=120)
+        model.load_state_dict({k: v.clone() for k, v in sd.items()})
+        model = model.to(dev)
+        model.need_traj = False
+        model.train()
+        tr = RLFTTrainer(model, kind="rift", seed=3)
+        assert (tr.prefetch_stream is not None) == (mode == "prefetch")
+        vals = []
+        for k, ix in enumerate(train_ix):
+            fb, b = tr.gather(replay, ix)
+            tr.training_step(fb, b)
+            if k % 3 == 2:
+                tr.wait_update()
+                fb, b = replay.collate(tr.engine, val_ix)
+                vals.append(tr.validation_step(fb, b).clone())
+        mean = tr.pop_mean_loss()
+        torch.cuda.synchronize()
+        runs[mode] = (mean, [float(v.item()) for v in vals], {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k.startswith(PI)})
+        tr.close()
+    for other in ("tail", "prefetch"):
+        assert runs[other][0] == runs["serial"][0] and runs[other][1] == runs["serial"][1], (other, runs[other][:2], runs["serial"][:2])
+        for k, v in runs["serial"][2].items():
+            assert torch.equal(v, runs[other][2][k]), (other, k)
