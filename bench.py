@@ -309,6 +309,15 @@ def main():
                "per_gpu_batch": local_bs, "global_batch": global_bs, "replay_scenes_per_gpu": per_rank, "final_loss": float(loss.item())}
         eng.check_finite()
 
+        if want_all_outputs and steps < 200:
+            # companion figure: 200 steps behind the same barriers.  The step pipeline is four steps deep (gather / preparation / history and
+            # map encoders of step k + 1 .. k + 3 beside encoder / decoder of step k, head / loss / update of step k behind them): a timed run
+            # of K steps pays its fill and drain once (~1 ms), which a 20-step run sees as +0.04 .. 0.05 ms per step
+            dt_long, _ = timed(args.warmup, 200)
+            trainer.wait_update()
+            res["steady_state"] = {"steps": 200, "ms_per_step": dt_long / 200 * 1e3, "value": 200 / dt_long * global_bs,
+                                   "note": "the same update steps, 200 of them in one timed region: what an epoch of the update loop runs at"}
+
         if want_all_outputs:
             # companion figure: the same K steps with EVERY output of PlanningModel.forward computed (trajectory / prediction /
             # ref-free heads -- outputs the RLFT losses never read; the reference's training_step computes them)
@@ -386,6 +395,7 @@ def main():
                     roof["mfma_counters_source"] = mf[2] + ": SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 FLOP and SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) per launch (committed pass)"
                 res["roofline"] = roof
         trainer.close()
+        eng.close()                  # (the context's side stream goes with it: a later leg's streams must not end up sharing hardware queues)
         return res
 
     head_scaling = args.scaling if world > 1 else "weak"
@@ -431,6 +441,7 @@ def main():
             # whole-step fraction of the dense bf16 MFMA peak, priced at the algorithmic FLOPs of what each variant executes
             "whole_step_mfma_frac": head["value"] / world * FLOPS_PER_SCENE_LOSS / (PEAK_BF16_TFLOPS * 1e12),
             "all_outputs": head["all_outputs"],
+            **({"steady_state": head["steady_state"]} if "steady_state" in head else {}),
             "final_loss": head["final_loss"], "replay_gen_s": round(t_gen, 2), "replay_hbm_mb": round(replays["weak"].nbytes() / 1e6, 1),
         }
         if world > 1:
