@@ -261,7 +261,13 @@ def main():
     nsteps = args.warmup + args.steps + 8
 
     def leg(scaling, precision, steps, want_all_outputs=False, want_full_update=False, want_roofline=False):
-        """Time `steps` update steps in one (scaling, precision) configuration on fresh parameters / optimizer state."""
+        """Time `steps` update steps in one (scaling, precision) configuration on fresh parameters / optimizer state.
+        A generator: the first next() builds the leg (its own model, engine context, trainer, index tensors -- host work, tens of ms), the
+        second one runs it and yields the result.  main() builds the headline leg BEFORE it runs the companion legs, so that the headline
+        leg's warm-up steps follow the last companion's device work at once: a device left idle while a leg is being built runs the next
+        ~30 ms at ramping clocks (per-step times of a leg's first 25 steps fall by 5-10 %, tools/jobs/stepdeltas.py), and W = 5 warm-up
+        steps are 4 ms."""
+        model = PlanningModel(radius=120)
         strong = scaling == "strong" and world > 1
         replay = replays["strong" if strong else "weak"]
         per_rank = args.replay if strong else per_rank_weak
@@ -301,6 +307,7 @@ def main():
                 dt = float(tmax.item())
             return dt, last
 
+        yield None
         for i in range(args.warmup):
             step(i)
         dt, loss = timed(args.warmup, steps)
@@ -395,28 +402,32 @@ def main():
                     roof["mfma_counters_source"] = mf[2] + ": SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 FLOP and SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) per launch (committed pass)"
                 res["roofline"] = roof
         trainer.close()
-        eng.close()                  # (the context's side stream goes with it: a later leg's streams must not end up sharing hardware queues)
-        return res
+        model.release_engine()       # (the context's side stream goes with it: a later leg's streams must not end up sharing hardware queues)
+        yield res
 
     head_scaling = args.scaling if world > 1 else "weak"
-    # The companion legs run FIRST: a process's first ~30 ms of device work run at ramping clocks (per-step times of one leg fall by 5-10 %
-    # over its first 25 steps and are flat in a second leg: tools/jobs/stepdeltas.py), and W = 5 warm-up steps are 4 ms -- the headline leg
-    # should not be the one that pays for the ramp.  (--no-precisions on one GPU leaves nothing in front of it.)
+    # the companion legs run first, the headline leg last, every leg built before the first one runs (see leg())
+    def built(*a, **kw):
+        g = leg(*a, **kw)
+        next(g)
+        return g
+
+    head_leg = built(head_scaling, args.precision, args.steps, want_all_outputs=True, want_full_update=not args.no_full_update,
+                     want_roofline=not args.no_roofline)
     other = None
     if world > 1:
         other_scaling = "strong" if head_scaling == "weak" else "weak"
-        other = (other_scaling, leg(other_scaling, args.precision, args.steps))
+        other = (other_scaling, next(built(other_scaling, args.precision, args.steps)))
     precisions = None
     keep = ("ms_per_step", "value", "steps_per_sec", "steps", "final_loss")
     if world == 1 and not args.no_precisions:
         precisions = {}
-        for p in ("fp32", "fp16", "bf16"):
-            if p == args.precision:
-                continue
-            r = leg("weak", p, args.steps if p != "fp32" else max(5, min(args.steps, 20)))      # (the layer-by-layer fp32 step is several times longer)
+        todo = [(p, built("weak", p, args.steps if p != "fp32" else max(5, min(args.steps, 20))))      # (the layer-by-layer fp32 step is several times longer)
+                for p in ("fp32", "fp16", "bf16") if p != args.precision]
+        for p, g in todo:
+            r = next(g)
             precisions[p] = {k: r[k] for k in keep}
-    head = leg(head_scaling, args.precision, args.steps, want_all_outputs=True, want_full_update=not args.no_full_update,
-               want_roofline=not args.no_roofline)
+    head = next(head_leg)
     if precisions is not None:
         precisions[args.precision] = {k: head[k] for k in keep}
         precisions["note"] = ("the same update steps per compute precision: bf16 / fp16 = the fused kernels on bf16 / fp16 MFMA operands; fp32 = exact "

@@ -287,6 +287,13 @@ class PlanningModel(TorchModuleWrapper):
             self._bound_version = self._tensor_version()
         return self._engine
 
+    def release_engine(self):
+        """Destroy the HIP context (its scratch arenas and side stream); the next engine() call builds a new one."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+            self._bound_version = None
+
     def forward(self, data: FeaturesType) -> TargetsType:
         eng = self.engine()
         self._seed += 1
