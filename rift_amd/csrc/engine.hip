@@ -425,7 +425,7 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR_N(fpn_tail_kernel, FPN_LDS);
   SETATTR_N(heads3_fused_kernel, HD_LDS);
   SETATTR_N(pi_forward_kernel, PI_LDS);
-  SETATTR_N(nat_l0w_kernel, L0W_LDS + L0W_LIST_BYTES);
+  SETATTR_N(nat_l0w_kernel, L0W_LDS);
   SETATTR_N(nat_l1w_kernel, L1W_LDS);
 #undef SETATTR_N
   return RIFT_OK;
@@ -877,11 +877,13 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       hipStream_t own = c->stream;
       c->stream = c->prep_stream;
       launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
+      if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(1024), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
       c->stream = own;
       HIPCHK(c, hipEventRecord(c->ev_prep, c->prep_stream));
       HIPCHK(c, hipStreamWaitEvent(own, c->ev_prep, 0));
     } else {
       launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
+      if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(1024), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
     }
   }
   // data parallel: the r2r mask quirk indexes padding rows of the GLOBAL minibatch -> gather them (slots in the exchange buffer; the
@@ -959,15 +961,13 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       const int C = Cl[lv], H = Hl[lv], ksz = Kl[lv], L = Ll[lv], rows = nA * L;
       if (lv == 0) {   // level 0 as wave-private, register-resident tiles (no workgroup barriers): nat_l0w.h
         NatL0WP q; memset(&q, 0, sizeof(q));
-        q.hist = hist_agent; q.aidx = nat_aidx; q.cnt = nat_cnt;
+        q.aidx = nat_aidx; q.cnt = nat_cnt;
         q.F9 = F9; q.nseq = nA; q.img = c->l0w_img; q.par = c->l0w_par; q.Oc = Oc[0]; q.Ocb = Ocb[0]; q.Xnext = Xin[1];
         { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 1) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         q.droppath[0] = f.drop ? dpr[0] : 0.f; q.droppath[1] = f.drop ? dpr[1] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + 2.0 * rows * 27 * 32 + (rows / 2) * 2.0 * 3 * C * 2 * C;
-        const int l0grid = std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid);
-        if (nat_compact && cdiv(cdiv(cdiv(nA, 4), L0W_NWV), l0grid) * L0W_NWV * 16 > L0W_LIST_BYTES) { c->err = "nat_l0w_kernel: too many rounds per workgroup for the compaction list"; return RIFT_ERR_ARG; }
-        launch(c, "nat_l0w_kernel", nat_l0w_kernel, dim3(l0grid), dim3(64 * L0W_NWV), (size_t)(L0W_LDS + L0W_LIST_BYTES), q);
+        launch(c, "nat_l0w_kernel", nat_l0w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid)), dim3(64 * L0W_NWV), (size_t)L0W_LDS, q);
         continue;
       }
       if (lv == 1) {   // level 1 likewise (weights swapped through LDS between the two layers): nat_l1w.h

@@ -47,7 +47,6 @@ namespace RIFT_NS {
 #define L0W_NWV 8                        // waves per workgroup (= per CU: the LDS image allows one workgroup); 12 -> 168 VGPRs per wave
 #endif
 #define L0W_LDS (L0W_NFRAG * 1024 + L0W_NPAR * 4 + L0W_NWV * 80 * L0W_ST * 2)
-#define L0W_LIST_BYTES 4096              // compacted launch: the agent slots of this workgroup's tiles (4 per tile, <= 32 rounds x 8 waves)
 
 struct NatL0WSrc {    // raw fp32 parameters (views onto the state_dict) for pack_l0w_kernel
   const float* w_tok; const float* b_tok;                                   // embed.proj (32, 9, 3), (32)
@@ -107,12 +106,10 @@ struct NatL0WP {
   float* Xnext;                            // (nseq * 10, 64) downsample conv + LayerNorm
   float droppath[2]; uint32_t seed, stream;
   long long* ts;                           // optional section timestamps of wave 0 of workgroup 0 (diagnostic, RIFT_NAT_TS=1)
-  // compacted launch (hist != nullptr): the level runs on the sequences hist marks (agent_encoder.py:77-80 runs the history encoder on
-  // agent_feature[valid_agent_mask]; the ego row is replaced at :87), ranked per residue class of the slot (common.h: SeqCount) -- rank r is
-  // sequence r of this and the next levels' buffers.  Every workgroup ranks the marks itself in its prologue (under the weight image's DMA),
-  // keeps the agent slots of its own tiles in LDS and publishes them (aidx[r], one writer per rank) and the three class counts (cnt[0..2],
-  // workgroup 0) for the kernels behind it
-  const uint8_t* hist; int* aidx; int* cnt;
+  // compacted launch (aidx, cnt from nat_rank_kernel below): the level runs on the sequences the history encoder's output is read of
+  // (agent_encoder.py:77-80 runs it on agent_feature[valid_agent_mask]; the ego row is replaced at :87), ranked per residue class of the
+  // agent slot (common.h: SeqCount) -- rank r is sequence r of this and the next levels' buffers and reads the features of slot aidx[r]
+  const int* aidx; const int* cnt;
   DropStats ds;                            // diagnostic build only (dropstats.h)
 };
 
@@ -154,49 +151,18 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
   decw_dma_share(reinterpret_cast<const unsigned char*>(p.img), (uint32_t)lane * 16u, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw), L0W_NFRAG,
                  __builtin_amdgcn_readfirstlane(wave), L0W_NWV);
   for (int i = tid; i < L0W_NPAR / 4; i += NTHR) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
-  int sq_n = p.nseq, sq_c0 = 0x7fffffff, sq_c1 = 0x7fffffff, sq_c2 = 0x7fffffff;       // common.h: SeqCount
-  int* lidx = reinterpret_cast<int*>(stg + L0W_NWV * 80 * L0W_ST);           // [round][wave][4] agent slots (compacted launch)
-  if (p.hist) {
-    // thread t ranks the marks of slots [t K, (t + 1) K) per residue class (common.h: SeqCount): counts (three 21-bit fields of one word),
-    // workgroup-wide exclusive scan, then the ranks in order
-    unsigned long long* wsum = reinterpret_cast<unsigned long long*>(stg);    // (the staging tiles are idle until the first tile's downsample)
-    const int K = (p.nseq + NTHR - 1) / NTHR, s0 = tid * K;
-    unsigned long long mine = 0ull;
-    for (int j = 0, c = s0 % 3; j < K; ++j, c = (c == 2) ? 0 : c + 1) mine += (s0 + j < p.nseq && p.hist[s0 + j]) ? (1ull << (21 * c)) : 0ull;
-    unsigned long long incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned long long base = 0ull, total = 0ull;
-#pragma unroll
-    for (int w = 0; w < L0W_NWV; ++w) { const unsigned long long sw = wsum[w]; base += (w < wave) ? sw : 0ull; total += sw; }
-    sq_c0 = (int)(total & 0x1fffffu); sq_c1 = (int)((total >> 21) & 0x1fffffu); sq_c2 = (int)((total >> 42) & 0x1fffffu);
-    sq_n = 3 * max(sq_c0, max(sq_c1, sq_c2));
-    const unsigned long long off = base + incl - mine;
-    int nx0 = (int)(off & 0x1fffffu), nx1 = (int)((off >> 21) & 0x1fffffu), nx2 = (int)((off >> 42) & 0x1fffffu);
-    const int grid = (int)gridDim.x;
-    for (int j = 0, c = s0 % 3; j < K; ++j, c = (c == 2) ? 0 : c + 1) {
-      if (s0 + j < p.nseq && p.hist[s0 + j]) {
-        const int i = (c == 0) ? nx0 : (c == 1) ? nx1 : nx2;
-        nx0 += (c == 0); nx1 += (c == 1); nx2 += (c == 2);
-        const int r = 3 * i + c, tile = r >> 2, g = tile / L0W_NWV, k = g / grid;             // tile r / 4 belongs to workgroup g % grid, its round k
-        if (g - k * grid == (int)blockIdx.x) { lidx[(k * L0W_NWV + tile % L0W_NWV) * 4 + (r & 3)] = s0 + j; p.aidx[r] = s0 + j; }
-      }
-    }
-    if (blockIdx.x == 0 && tid == 0) { p.cnt[0] = sq_c0; p.cnt[1] = sq_c1; p.cnt[2] = sq_c2; }
-  }
+  RIFT_SEQ_COUNT(p.cnt, p.nseq);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   unsigned short* st = stg + wave * 80 * L0W_ST;
   auto W = [&](int f) { return *reinterpret_cast<const h16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
   const int a = l15 >> 2, s = l15 & 3;
   const int ntiles = (sq_n + 3) >> 2;
-  int tsn = 0, lround = 0;
+  int tsn = 0;
 #define L0TS() do { if (p.ts && blockIdx.x == 0 && tid == 0 && tsn < 60) p.ts[tsn++] = clock64(); } while (0)
   L0TS();
 
-  for (int tile = blockIdx.x * L0W_NWV + wave; tile < ntiles; tile += gridDim.x * L0W_NWV, ++lround) {
+  for (int tile = blockIdx.x * L0W_NWV + wave; tile < ntiles; tile += gridDim.x * L0W_NWV) {
     const int seq = tile * 4 + a;
     const bool seq_ok = RIFT_SEQ_LIVE(seq);
     f32x4 x[5][2];
@@ -208,7 +174,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
       // the window of step t = feature rows t-1, t, t+1 = 27 contiguous floats; lane l4 takes values 8 l4 .. +7 with two UNCONDITIONAL
       // 16-byte loads (4-byte aligned; the engine pads the feature buffer in front) and masks what lies outside the sequence afterwards
       typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-      const int sq = !seq_ok ? 0 : p.hist ? lidx[(lround * L0W_NWV + wave) * 4 + a] : seq;      // the agent slot whose features this row reads
+      const int sq = !seq_ok ? 0 : p.aidx ? p.aidx[seq] : seq;      // the agent slot whose features this row reads
       unsigned m_all = 0u, m_tap0 = 0u, m_tap2 = 0u;          // bit j: window value 8 l4 + j exists / belongs to tap 0 / to tap 2
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -429,6 +395,42 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
       }
     }
   }
+}
+
+// Ranks the marked agent slots for the compacted launch: aidx[3 i + c] = the i-th marked slot of residue class c = slot % 3, cnt[c] = the
+// class counts (common.h: SeqCount).  ONE workgroup of 1024 threads: thread t counts the marks of slots [t K, (t + 1) K) per class (three
+// 21-bit fields of one word), a workgroup-wide exclusive scan, then the ranks in order.  Behind the input preparation on whatever stream
+// that runs on (the prepare stream of the update loop: beside the previous step).  (First version: every workgroup of nat_l0w_kernel ranked
+// the marks itself in its prologue -- no launch, but 14 us on each of 256 CUs.)
+__global__ __launch_bounds__(1024) void nat_rank_kernel(const uint8_t* __restrict__ hist, int n, int* __restrict__ aidx, int* __restrict__ cnt) {
+  __shared__ unsigned long long wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = (n + 1023) / 1024, s0 = tid * K;
+  // the marks of this thread: one 16-byte load when its slots are 16 aligned bytes (the benchmark's 16384 slots), byte loads otherwise
+  const bool vec = K == 16 && (n & 15) == 0;
+  uint32_t mk[4] = {0u, 0u, 0u, 0u};
+  if (vec) { const uint4 v = *reinterpret_cast<const uint4*>(hist + s0); mk[0] = v.x; mk[1] = v.y; mk[2] = v.z; mk[3] = v.w; }
+  auto mark = [&](int j) -> bool { return vec ? ((mk[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0u : (s0 + j < n && hist[s0 + j] != 0); };
+  unsigned long long mine = 0ull;
+  for (int j = 0, c = s0 % 3; j < K; ++j, c = (c == 2) ? 0 : c + 1) mine += mark(j) ? (1ull << (21 * c)) : 0ull;
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned long long base = 0ull, total = 0ull;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const unsigned long long sw = wsum[w]; base += (w < wave) ? sw : 0ull; total += sw; }
+  const unsigned long long off = base + incl - mine;
+  int nx0 = (int)(off & 0x1fffffu), nx1 = (int)((off >> 21) & 0x1fffffu), nx2 = (int)((off >> 42) & 0x1fffffu);
+  for (int j = 0, c = s0 % 3; j < K; ++j, c = (c == 2) ? 0 : c + 1) {
+    if (mark(j)) {
+      const int i = (c == 0) ? nx0 : (c == 1) ? nx1 : nx2;
+      nx0 += (c == 0); nx1 += (c == 1); nx2 += (c == 2);
+      aidx[3 * i + c] = s0 + j;
+    }
+  }
+  if (tid == 0) { cnt[0] = (int)(total & 0x1fffffu); cnt[1] = (int)((total >> 21) & 0x1fffffu); cnt[2] = (int)((total >> 42) & 0x1fffffu); }
 }
 
 }  // namespace RIFT_NS
