@@ -406,8 +406,8 @@ __global__ __launch_bounds__(1024) void nat_rank_kernel(const uint8_t* __restric
   __shared__ unsigned long long wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = (n + 1023) / 1024, s0 = tid * K;
-  // the marks of this thread: one 16-byte load when its slots are 16 aligned bytes (the benchmark's 16384 slots), byte loads otherwise
-  const bool vec = K == 16 && (n & 15) == 0;
+  // the marks of this thread: one 16-byte load when its slots are 16 aligned bytes inside the array (the benchmark's 16384 slots), byte loads otherwise
+  const bool vec = K == 16 && s0 + 16 <= n;
   uint32_t mk[4] = {0u, 0u, 0u, 0u};
   if (vec) { const uint4 v = *reinterpret_cast<const uint4*>(hist + s0); mk[0] = v.x; mk[1] = v.y; mk[2] = v.z; mk[3] = v.w; }
   auto mark = [&](int j) -> bool { return vec ? ((mk[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0u : (s0 + j < n && hist[s0 + j] != 0); };
