@@ -192,7 +192,8 @@ int rift_set_dp(RiftCtx* ctx, const RiftDp* dp);
  * beside the current step's kernels instead of between two steps (12 + 12 us of a 0.7 ms step at 256 scenes, 7 + 6 of 0.39 at 32).  The
  * caller orders `prepare_stream` behind whatever last read the batch buffers and the activation arena of this forward (with
  * RIFT_F_DEFER_HEAD: the head / loss of the forward RIFT_DEFER_SLOTS calls back).  NULL (the default) keeps the preparation on the forward's stream; the
- * data-parallel path and the per-kernel profile ignore the setting.  Results do not depend on it. */
+ * per-kernel profile ignores the setting, and with rift_set_dp only gather and preparation move (the history and map encoders stay behind
+ * the caller's queue: the exchanges of consecutive forwards share one buffer).  Results do not depend on it. */
 int rift_set_prepare_stream(RiftCtx* ctx, void* prepare_stream);
 
 /* The reference asserts torch.isfinite(q).all() on the decoder queries after every decoder layer (planning_decoder.py:175).  Here the

@@ -871,7 +871,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     int tot = 0;
     for (int i = 0; i < 7; ++i) tot += q.nb[i];
     // on the caller's prepare stream if there is one (rift_set_prepare_stream): behind the gather of the batch, beside the previous step
-    prefetched = c->prep_set && !c->dp.on && !c->prof_on && !c->dry && !getenv("RIFT_POISON_ARENA");
+    prefetched = c->prep_set && !c->prof_on && !c->dry && !getenv("RIFT_POISON_ARENA");
     if (prefetched) {
       if (!c->ev_prep) HIPCHK(c, hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
       hipStream_t own = c->stream;
@@ -934,7 +934,10 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     // and no further hardware queue for the history chain (on a stream of its own every cross-queue wait of the step got slower: 0.372).
     // RIFT_SIDE_GATE=1 keeps the fronts behind the caller's queue (the event record costs that queue ~5 us), RIFT_NAT_ASIDE=0 the history
     // chain on it.
-    const bool gate = c->side_gate > 0;
+    // (data parallel: the fronts stay behind the caller's queue -- the mask slots of this forward go into the exchange buffer on the
+    // caller's stream, behind the previous forward's join, and the map chain's exchanges must follow them; only gather and preparation
+    // are prefetched there.  The history chain alone ahead of the queue, measured with one rank and forced exchanges: 0.736 ms against 0.69.)
+    const bool gate = c->side_gate > 0 || c->dp.on;
     if (prefetched) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_prep, 0));
     if (!prefetched || gate) {
       HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));

@@ -418,10 +418,7 @@ class RLFTTrainer:
 
     @property
     def prefetch_stream(self):
-        """The stream the next batch is gathered on (pass it to DeviceReplay.collate(stream=)), or None: gather on the current stream.  None
-        on the data-parallel path, whose forwards exchange through one buffer in step order."""
-        if self._prefetch is None or (self.exchange is not None and (self.world > 1 or self.force_exchange)):
-            return None
+        """The stream the next batch is gathered on (pass it to DeviceReplay.collate(stream=)), or None: gather on the current stream."""
         return self._prefetch
 
     def next_slot(self, prefetch: bool = False) -> int:
