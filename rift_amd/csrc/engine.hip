@@ -96,7 +96,7 @@ struct RiftCtx {
   bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true;
   hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = 0;      // rift_set_prepare_stream
   hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr; bool nat_aside = true;
-  int side_prio = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
   bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
   unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // weight stream / parameter blocks of the decoder kernel (dec_w.h)
@@ -924,7 +924,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   const bool forked = c->two_streams && fused && !c->prof_on && !c->dry;
   bool nat_aside = false;
   if (forked) {
-    if (!c->side) { HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, c->side_prio)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
+    if (!c->side) { HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
     // With the preparation prefetched, neither front chain of step k + 1 needs anything of step k: the map chain (side stream) waits for
     // the preparation only, the agent-history chain follows it on the prepare stream, and the caller's queue holds token assembly ->
     // encoder -> decoder of step k, then of step k + 1 -- the fronts run beside the previous step's one-workgroup-per-scene encoder /
@@ -1453,7 +1453,6 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_PE_LIVE"); if (ev) c->pe_live = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
-  { const char* ev = getenv("RIFT_SIDE_PRIO"); if (ev) c->side_prio = atoi(ev); }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }
