@@ -465,9 +465,11 @@ class RLFTTrainer:
             slot = self._slot
             if self._slot_prefetch:
                 self.engine.set_prepare_stream(self.prefetch_stream)
-            self.forward_trunk(fb, shard)
-            if self._slot_prefetch:
-                self.engine.set_prepare_stream(None)
+            try:
+                self.forward_trunk(fb, shard)
+            finally:                          # (a forward that raises must not leave later forwards preparing on the prefetch stream)
+                if self._slot_prefetch:
+                    self.engine.set_prepare_stream(None)
             main = torch.cuda.current_stream()
             self._ev_loss.record(main)
             with torch.cuda.stream(self._side):
