@@ -297,6 +297,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(first, first + count):
                 last = step(i)
+            trainer.wait_update()          # (data parallel: the last step's tail is held back until the next forward is issued -- issue it)
             torch.cuda.synchronize()
             if pg is not None:
                 torch.distributed.barrier()

@@ -161,6 +161,10 @@ int rift_forward(RiftCtx* ctx, const RiftFeatureBatch* batch, const RiftOutputs*
 /* The policy head of the last RIFT_F_DEFER_HEAD forward (cat_x_proj -> pi_head -> masked logits -> `probability`, and the trajectory heads
  * when they were requested), launched on `stream`; the caller orders it behind that forward (event).  rift_loss_backward then refers to it. */
 int rift_forward_head(RiftCtx* ctx, void* stream);
+/* The same for the deferred forward `back` rift_forward calls before the latest one (0 = the latest; back < RIFT_DEFER_SLOTS): a host that
+ * issues forward k + 1 ahead of the head / loss of step k -- the data-parallel update loop does, so that the BatchNorm all-reduces of step k + 1
+ * are not queued behind the loss all-reduce of step k on the communicator -- names the forward it means. */
+int rift_forward_head_back(RiftCtx* ctx, int back, void* stream);
 
 /* ---- data parallelism (absent in the reference: one device, custom_lightning.yaml:26,43) ----
  * A minibatch of `global_bs` scenes is split contiguously over the ranks; this rank's rift_forward receives scenes
@@ -192,8 +196,8 @@ int rift_set_dp(RiftCtx* ctx, const RiftDp* dp);
  * beside the current step's kernels instead of between two steps (12 + 12 us of a 0.7 ms step at 256 scenes, 7 + 6 of 0.39 at 32).  The
  * caller orders `prepare_stream` behind whatever last read the batch buffers and the activation arena of this forward (with
  * RIFT_F_DEFER_HEAD: the head / loss of the forward RIFT_DEFER_SLOTS calls back).  NULL (the default) keeps the preparation on the forward's stream; the
- * per-kernel profile ignores the setting, and with rift_set_dp only gather and preparation move (the history and map encoders stay behind
- * the caller's queue: the exchanges of consecutive forwards share one buffer).  Results do not depend on it. */
+ * per-kernel profile ignores the setting.  Results do not depend on it.  (With rift_set_dp the forward's slots of the exchange buffer are
+ * filled on the map encoder's stream, behind the previous forward's exchanges.) */
 int rift_set_prepare_stream(RiftCtx* ctx, void* prepare_stream);
 
 /* The reference asserts torch.isfinite(q).all() on the decoder queries after every decoder layer (planning_decoder.py:175).  Here the

@@ -84,7 +84,7 @@ class RiftRolloutIO(C.Structure):
 
 OPERANDS = {"bf16": 0, "fp16": 1}       # RIFT_OPERANDS_* of include/rift_hip.h: the 16-bit MFMA operand format of a context's fused kernels
 EXPORTS = [
-    "rift_ctx_create", "rift_ctx_create_ex", "rift_ctx_operand_format", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_forward_head", "rift_loss_backward",
+    "rift_ctx_create", "rift_ctx_create_ex", "rift_ctx_operand_format", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_forward_head", "rift_forward_head_back", "rift_loss_backward",
     "rift_loss_finalize", "rift_loss_finalize_clip", "rift_set_param_event", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
@@ -122,6 +122,7 @@ def load_library(variant: str = "") -> C.CDLL:
     lib.rift_model_load.argtypes = [vp, C.POINTER(RiftTensorDesc), C.c_int, vp]
     lib.rift_forward.argtypes = [vp, C.POINTER(RiftFeatureBatch), C.POINTER(RiftOutputs), C.c_int, C.c_uint32, vp]
     lib.rift_forward_head.argtypes = [vp, vp]
+    lib.rift_forward_head_back.argtypes = [vp, C.c_int, vp]
     lib.rift_loss_backward.argtypes = [vp, C.c_int, C.POINTER(RiftLossIn), C.POINTER(RiftLossOut), vp]
     lib.rift_loss_finalize.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, vp]
     lib.rift_set_param_event.argtypes = [vp, vp]
@@ -324,9 +325,10 @@ class Engine:
         if rc != 0:
             self._check(rc, "rift_set_prepare_stream")
 
-    def forward_head(self):
-        """The policy head of the last F_DEFER_HEAD forward, on the current stream (the caller has ordered it behind that forward)."""
-        rc = self.lib.rift_forward_head(self.ctx, _stream())
+    def forward_head(self, back: int = 0):
+        """The policy head of the last F_DEFER_HEAD forward -- or of the one `back` forwards before it -- on the current stream (the caller
+        has ordered it behind that forward)."""
+        rc = self.lib.rift_forward_head_back(self.ctx, back, _stream())
         if rc != 0:
             self._check(rc, "rift_forward_head")
 

@@ -893,9 +893,12 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     f.dp = true; f.kb = c->dp.gbs * R; f.kpm_pending = true;
     f.g_rkpm = A_alloc<uint8_t>(c, (size_t)f.kb);
     if ((long long)f.kb + 2 * 513 > c->dp.len || c->dp.off < 0 || c->dp.off + bs > c->dp.gbs) { c->err = "rift_set_dp: exchange buffer too small or shard outside the global minibatch"; return RIFT_ERR_ARG; }
-    launch(c, "dp_kpm_fill_kernel", dp_kpm_fill_kernel, dim3(cdiv(f.kb, 256)), dim3(256), 0, (const uint8_t*)r_kpm, nL, c->dp.off * R, f.kb, c->dp.xchg);
+    // (with the preparation prefetched the fill waits for the head of the map chain: the exchange buffer is the one the previous forward's
+    // map chain exchanged through, and that chain's stream is what orders the two)
+    if (!prefetched) launch(c, "dp_kpm_fill_kernel", dp_kpm_fill_kernel, dim3(cdiv(f.kb, 256)), dim3(256), 0, (const uint8_t*)r_kpm, nL, c->dp.off * R, f.kb, c->dp.xchg);
     q_kpm = f.g_rkpm; q_bs = c->dp.gbs; q_off = c->dp.off;
   }
+  const bool dp_fill_late = c->dp.on && prefetched;
 #if RIFT_DROP_STATS      // diagnostic build (dropstats.h): the counters of this forward's stochastic decisions, readable as taps afterwards
   DropStats ds; memset(&ds, 0, sizeof(ds));
   if (f.drop) {
@@ -934,10 +937,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     // and no further hardware queue for the history chain (on a stream of its own every cross-queue wait of the step got slower: 0.372).
     // RIFT_SIDE_GATE=1 keeps the fronts behind the caller's queue (the event record costs that queue ~5 us), RIFT_NAT_ASIDE=0 the history
     // chain on it.
-    // (data parallel: the fronts stay behind the caller's queue -- the mask slots of this forward go into the exchange buffer on the
-    // caller's stream, behind the previous forward's join, and the map chain's exchanges must follow them; only gather and preparation
-    // are prefetched there.  The history chain alone ahead of the queue, measured with one rank and forced exchanges: 0.736 ms against 0.69.)
-    const bool gate = c->side_gate > 0 || c->dp.on;
+    const bool gate = c->side_gate > 0;
     if (prefetched) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_prep, 0));
     if (!prefetched || gate) {
       HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
@@ -1068,6 +1068,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     else if (c->nat_on_main) c->stream = c->side;
     else { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
   }
+  if (dp_fill_late)      // (on the map chain's stream if there is one, else on the caller's: behind the previous forward's exchanges either way)
+    launch(c, "dp_kpm_fill_kernel", dp_kpm_fill_kernel, dim3(cdiv(f.kb, 256)), dim3(256), 0, (const uint8_t*)r_kpm, nL, c->dp.off * R, f.kb, c->dp.xchg);
   tap(c, "nat_out", nat_out, (int64_t)nA * 128);
 
   // ego state token (StateAttentionEncoder, agent_encoder.py:99-140)
@@ -1761,21 +1763,24 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   return RIFT_OK;
 }
 
-int rift_forward_head(RiftCtx* c, void* stream) {
-  if (!c) return RIFT_ERR_ARG;
+int rift_forward_head_back(RiftCtx* c, int back, void* stream) {
+  if (!c || back < 0 || back >= RIFT_DEFER_SLOTS) return RIFT_ERR_ARG;
   c->err.clear();
-  if (!c->head[c->parity].valid) { c->err = "rift_forward_head without a RIFT_F_DEFER_HEAD forward"; return RIFT_ERR_STATE; }
+  const int slot = (c->parity - back + RIFT_DEFER_SLOTS) % RIFT_DEFER_SLOTS;
+  if (!c->head[slot].valid) { c->err = "rift_forward_head without a RIFT_F_DEFER_HEAD forward"; return RIFT_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   const hipStream_t trunk_stream = c->stream;
   c->stream = (hipStream_t)stream; c->dry = false;
-  const int rc = head_impl(c, c->head[c->parity]);
-  c->head[c->parity].valid = false;
+  const int rc = head_impl(c, c->head[slot]);
+  c->head[slot].valid = false;
   c->stream = trunk_stream;
   if (rc != RIFT_OK) return rc;
   if (!c->err.empty()) return RIFT_ERR_ARG;
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }
+
+int rift_forward_head(RiftCtx* c, void* stream) { return abi::rift_forward_head_back(c, 0, stream); }
 
 int rift_loss_backward(RiftCtx* c, int kind, const RiftLossIn* in, const RiftLossOut* out, void* stream) {
   if (!c || !in || !out || !out->stats || !out->flat_grad_sum) return RIFT_ERR_ARG;

@@ -238,6 +238,7 @@ class RLFTTrainer:
         # gather and frozen trunk (rift_forward with RIFT_F_DEFER_HEAD + rift_forward_head; DEFER_SLOTS activation arenas and batch-buffer sets).
         self.pipeline = self.overlap_update and os.environ.get("RIFT_PIPELINE", "1") == "1" and kind in ("rift", "grpo", "reinforce")
         self._slot, self._slot_taken, self._slot_prefetch = 0, False, False
+        self._pending_tail = None
         self._prefetch = None
         if self.pipeline:
             self._ev_tail = [torch.cuda.Event() for _ in range(_ffi.DEFER_SLOTS)]      # end of the tail that read slot / arena i
@@ -313,6 +314,7 @@ class RLFTTrainer:
 
     def close(self):
         """Detach the data-parallel hooks from the (model-owned) engine."""
+        self._flush_tail()
         if self.dp_buf is not None:
             self.engine.clear_dp()
             self.dp_buf = None
@@ -471,19 +473,37 @@ class RLFTTrainer:
                 if self._slot_prefetch:
                     self.engine.set_prepare_stream(None)
             main = torch.cuda.current_stream()
-            self._ev_loss.record(main)
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(self._ev_loss)
-                self.engine.forward_head()
-                for t in extras.values():         # per-step tensors (buffer-wide extras indexed by the minibatch) are read on this stream:
-                    if torch.is_tensor(t) and t.is_cuda:      # keep the caching allocator from recycling them under it
-                        t.record_stream(self._side)
-                self.set_loss_inputs(extras)
-                self.engine.loss_backward_raw(self.kind_id, self.li, self.lo)
-                self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
-                self._optimizer_step()
-                self._ev_param.record(self._side)
-                self._ev_tail[slot].record(self._side)
+            loss_t, loss_ptr = self.loss, self.lo.loss
+
+            def tail(back):
+                """Head, loss, backward, exchange, finalize + clip, AdamW of THIS step on the update stream (`back`: forwards issued since)."""
+                self.loss, self.lo.loss = loss_t, loss_ptr
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(self._ev_loss)          # (the record behind this step's trunk: the latest one when the tail is issued)
+                    self.engine.forward_head(back)
+                    for t in extras.values():         # per-step tensors (buffer-wide extras indexed by the minibatch) are read on this stream:
+                        if torch.is_tensor(t) and t.is_cuda:      # keep the caching allocator from recycling them under it
+                            t.record_stream(self._side)
+                    self.set_loss_inputs(extras)
+                    self.engine.loss_backward_raw(self.kind_id, self.li, self.lo)
+                    self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
+                    self._optimizer_step()
+                    self._ev_param.record(self._side)
+                    self._ev_tail[slot].record(self._side)
+
+            if self.exchange is not None and (self.world > 1 or self.force_exchange) and self._slot_prefetch:
+                # data parallel: the tail is ISSUED one step late -- behind the next step's forward.  The all-reduces of a process group
+                # execute in the order they are issued; with the tail issued at once, the BatchNorm exchanges of step k + 1 (early in its
+                # front) would sit behind the loss exchange of step k, i.e. behind all of step k, and the fronts could not run ahead
+                prev, self._pending_tail = self._pending_tail, tail
+                if prev is not None:
+                    prev(1)
+                    self.loss, self.lo.loss = loss_t, loss_ptr
+                self._ev_loss.record(main)
+            else:
+                self._flush_tail()
+                self._ev_loss.record(main)
+                tail(0)
             self.loss_n += 1
             return self.loss
         if self.pipeline:                   # a step without next_slot(): the buffers are the caller's single set -- let the last tail finish first
@@ -508,8 +528,17 @@ class RLFTTrainer:
         self.loss_n += 1
         return loss
 
+    def _flush_tail(self):
+        """Issue the tail of the last data-parallel step if it is still held back (see training_step)."""
+        prev, self._pending_tail = getattr(self, "_pending_tail", None), None
+        if prev is not None:
+            keep = (self.loss, self.lo.loss)
+            prev(0)
+            self.loss, self.lo.loss = keep
+
     def wait_update(self):
         """Make the current stream wait for the last parameter update (needed before reading loss / parameters / .grad on it)."""
+        self._flush_tail()
         if self.overlap_update:
             torch.cuda.current_stream().wait_event(self._ev_param)
 

@@ -180,24 +180,35 @@ def test_rccl_transport_with_one_rank():
         for k in plain.params:
             assert torch.equal(plain.params[k], dp.params[k]), k
         dp.close()
-        # the deferred tail with the exchanges in flight on two streams (BatchNorm sums inside the trunk on the caller's stream, the loss
-        # sums on the update stream) over the same communicator: six steps equal six steps without a group, bit for bit
+        # the deferred tail with the exchanges in flight on several streams (BatchNorm sums inside the map chain, the loss sums on the update
+        # stream) over the same communicator: nine steps equal nine steps without a group, bit for bit -- gathered on the caller's stream
+        # (next_slot) and on the prefetch stream (gather: the data-parallel tail is then issued one step late, behind the next forward, and
+        # the fronts run ahead), with a host read of the loss in the middle (the held-back tail is flushed)
         g = torch.Generator().manual_seed(5)
-        order = [torch.randperm(16, generator=g)[:8].to(torch.int32).to("cuda:0") for _ in range(6)]
+        order = [torch.randperm(16, generator=g)[:8].to(torch.int32).to("cuda:0") for _ in range(9)]
+        torch.cuda.synchronize()
         res = []
-        for grp in (None, dist.group.WORLD):
+        for grp, pre in ((None, False), (dist.group.WORLD, False), (dist.group.WORLD, True), (None, True)):
             tr = RLFTTrainer(_model("bf16"), kind="rift", process_group=grp)
             tr.force_exchange = grp is not None
             assert tr.pipeline
-            for ix in order:
-                fb, b = replay.collate(tr.engine, ix, slot=tr.next_slot())
+            mid = None
+            for n, ix in enumerate(order):
+                if pre:
+                    fb, b = tr.gather(replay, ix)
+                else:
+                    fb, b = replay.collate(tr.engine, ix, slot=tr.next_slot())
                 tr.training_step(fb, b)
-            tr.wait_update()
+                if n == 4:
+                    mid = tr.step_loss()
+            mean = tr.pop_mean_loss()
             torch.cuda.synchronize()
-            res.append({k: v.detach().clone() for k, v in tr.params.items()})
+            res.append((mid, mean, {k: v.detach().clone() for k, v in tr.params.items()}))
             tr.close()
-        for k in res[0]:
-            assert torch.equal(res[0][k], res[1][k]), k
+        for other in res[1:]:
+            assert other[0] == res[0][0] and other[1] == res[0][1], (other[:2], res[0][:2])
+            for k in res[0][2]:
+                assert torch.equal(res[0][2][k], other[2][k]), k
     finally:
         dist.destroy_process_group()
 
