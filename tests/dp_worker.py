@@ -49,14 +49,41 @@ def main():
     for k in sd1:
         if "running_" in k:
             worst = max(worst, float((sd1[k] - sd2[k]).abs().max() / (1e-6 + sd1[k].abs().max())))
-    t = torch.tensor([worst], device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dp.close()
+    # the step pipeline on the data-parallel path (fused bf16 kernels, batches gathered on the prefetch stream, the tail issued one step late
+    # behind the next forward): six steps on changing minibatches with a host read in the middle against the single-process pipeline
+    def fused():
+        m = model()
+        m.compute_precision = "bf16"
+        return m
+    g = torch.Generator().manual_seed(11)
+    order = [torch.randperm(n, generator=g).to(torch.int32).to(dev) for _ in range(6)]
+    torch.cuda.synchronize()
+    runs = []
+    for grp in (None, dist.group.WORLD):
+        tr = RLFTTrainer(fused(), kind="rift", process_group=grp)
+        tr.force_exchange = grp is not None and world == 1
+        mid = None
+        for k, ix in enumerate(order):
+            part = ix[lo:hi] if grp is not None else ix
+            fb, b = tr.gather(replay, part)
+            tr.training_step(fb, b, shard=(lo, n) if grp is not None else None)
+            if k == 2:
+                mid = tr.step_loss()
+        mean = tr.pop_mean_loss()
+        torch.cuda.synchronize()
+        runs.append((mid, mean, {k: v.detach().clone() for k, v in tr.params.items()}))
+        tr.close()
+    # (bf16: the shards' BatchNorm partial sums group differently, a rare bf16 flip downstream; AdamW moves an element by <= lr = 1e-4 per step)
+    worst2 = max(abs(runs[0][0] - runs[1][0]), abs(runs[0][1] - runs[1][1]))
+    wp = max(float((runs[0][2][k] - runs[1][2][k]).abs().max()) for k in runs[0][2])
+    t = torch.tensor([worst, worst2, wp], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     dist.destroy_process_group()
-    assert float(t) < 1e-5, float(t)
+    assert float(t[0]) < 1e-5 and float(t[1]) < 2e-4 and float(t[2]) < 2.5e-4, t.tolist()
     if rank == 0:
-        print("DP_WORKER_OK", float(t), flush=True)
+        print("DP_WORKER_OK", t.tolist(), flush=True)
 
 
 if __name__ == "__main__":
