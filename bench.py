@@ -291,6 +291,7 @@ def main():
 
         def timed(first, count):
             """`count` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+            trainer.wait_update()          # (data parallel: a tail still held back from the warm-up belongs in front of the timed region)
             if pg is not None:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
