@@ -66,6 +66,7 @@ struct RiftCtx {
   // policy head / loss / backward of step k (rift_forward_head, rift_loss_backward on another stream) read step k's activations while the
   // frozen trunk of step k + 1 already writes its own.
   char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
+  long long dry_key[10] = {}; size_t dry_need = 0;      // the arena size of the last sized forward and what it depended on
   char* arenas[RIFT_DEFER_SLOTS] = {}; size_t arena_caps[RIFT_DEFER_SLOTS] = {}; int parity = 0;     // (parity: the arena of the current forward)
   struct Head {   // what the policy head of a forward needs (pi_forward .. trajectory heads); kept per arena for the deferred form
     bool valid = false, fp32 = false, need_traj = false;
@@ -1736,12 +1737,20 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // over, i.e. that this arena is free again); every other forward runs in arena 0
   c->parity = (flags & RIFT_F_DEFER_HEAD) ? (c->parity + 1) % RIFT_DEFER_SLOTS : 0;
   c->arena = c->arenas[c->parity]; c->arena_cap = c->arena_caps[c->parity];
-  // pass 1 (dry): size the activation arena; pass 2: launch
-  c->dry = true; c->arena_off = 0;
-  int rc = forward_impl(c, B, out, flags, seed);
-  c->stream = (hipStream_t)stream;              // (forward_impl forks onto its side stream; an early error return leaves it selected)
-  if (rc != RIFT_OK) { c->dry = false; return rc; }
-  const size_t need = c->arena_off;
+  // pass 1 (dry): size the activation arena; pass 2: launch.  The sizes depend on the batch dimensions, the flags and the data-parallel
+  // descriptor only: a forward like the previous one skips pass 1 (it is half of the call's host time, which bounds a small-batch step)
+  long long omask = 0;      // which outputs are wanted
+  { const void* const* op = reinterpret_cast<const void* const*>(out); for (size_t i = 0; i < sizeof(RiftOutputs) / sizeof(void*); ++i) omask |= (long long)(op[i] != nullptr) << i; }
+  const long long dkey[10] = {B->bs, B->A, B->Mp, B->R, B->S, B->T, flags, c->dp.on ? 1 : 0, c->dp.on ? c->dp.gbs : 0, omask};
+  int rc = RIFT_OK;
+  if (c->dry_need == 0 || memcmp(dkey, c->dry_key, sizeof(dkey)) != 0) {
+    c->dry = true; c->arena_off = 0; c->dry_need = 0;
+    rc = forward_impl(c, B, out, flags, seed);
+    c->stream = (hipStream_t)stream;              // (forward_impl forks onto its side stream; an early error return leaves it selected)
+    if (rc != RIFT_OK) { c->dry = false; return rc; }
+    memcpy(c->dry_key, dkey, sizeof(dkey)); c->dry_need = c->arena_off;
+  }
+  const size_t need = c->dry_need;
   if (need > c->arena_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->arena) HIPCHK(c, hipFree(c->arena));

@@ -467,18 +467,19 @@ class RLFTTrainer:
             slot = self._slot
             if self._slot_prefetch:
                 self.engine.set_prepare_stream(self.prefetch_stream)
+            main = torch.cuda.current_stream()
             try:
-                self.forward_trunk(fb, shard)
+                with _ffi.known_stream(main):
+                    self.forward_trunk(fb, shard)
             finally:                          # (a forward that raises must not leave later forwards preparing on the prefetch stream)
                 if self._slot_prefetch:
                     self.engine.set_prepare_stream(None)
-            main = torch.cuda.current_stream()
             loss_t, loss_ptr = self.loss, self.lo.loss
 
             def tail(back):
                 """Head, loss, backward, exchange, finalize + clip, AdamW of THIS step on the update stream (`back`: forwards issued since)."""
                 self.loss, self.lo.loss = loss_t, loss_ptr
-                with torch.cuda.stream(self._side):
+                with torch.cuda.stream(self._side), _ffi.known_stream(self._side):
                     self._side.wait_event(self._ev_loss)          # (the record behind this step's trunk: the latest one when the tail is issued)
                     self.engine.forward_head(back)
                     for t in extras.values():         # per-step tensors (buffer-wide extras indexed by the minibatch) are read on this stream:

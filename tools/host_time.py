@@ -32,6 +32,7 @@ pr = cProfile.Profile(); pr.enable()
 for i in range(100): step(i)
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 # true host cost: one step issued into an empty queue (no back-pressure), averaged
 import statistics
 ts = []
