@@ -322,6 +322,7 @@ class RLFTTrainer:
     def forward_loss(self, *args, **kwargs):
         """forward + objective (+ pi_head backward into .grad) on the current stream.  Returns the device f64 loss scalar.  With `clip_val`
         (and no critic, i.e. pi_head is the only trainable module) the gradient-norm clip rides in the finalize launch."""
+        self._flush_tail()                   # (a data-parallel tail still held back names its forward relative to the latest one)
         try:
             return self._forward_loss(*args, **kwargs)
         finally:
