@@ -206,6 +206,11 @@ def main():
         self_launch(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    # (diagnostic, RIFT_BENCH_SAME_GPU=1 under a launcher: every rank on GPU 0 over gloo -- RCCL refuses two ranks on one device -- to walk the
+    # N > 1 code of this file and the data-parallel step pipeline on a one-GPU box; the numbers of such a run mean nothing)
+    same_gpu = os.environ.get("RIFT_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; start N ranks for --gpus N "
@@ -231,7 +236,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if same_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
 
     from rift_amd import synthetic as syn

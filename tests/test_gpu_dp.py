@@ -221,3 +221,31 @@ def test_two_rccl_ranks_equal_single_process():
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DP_WORKER_OK" in out.stdout
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_real_ranks_sharing_one_gpu_over_gloo(ranks):
+    """Two / three REAL ranks -- processes of their own, every one on GPU 0, exchanging over gloo (RCCL refuses two ranks on one device) --
+    run tests/dp_worker.py: the sharded fp32 update against the single-process one, and the data-parallel step pipeline (batches gathered on
+    the prefetch stream, the tail issued one step late behind the next forward, host reads in between) against the single-process pipeline.
+    What one rank cannot show: that the order in which the ranks issue their all-reduces is the same everywhere and free of cycles."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29640 + ranks), os.path.join(REPO, "tests", "dp_worker.py")], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, RIFT_DP_SAME_GPU="1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "DP_WORKER_OK" in out.stdout
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    """bench.py's N > 1 code (both scaling legs, the max-over-ranks timing, the JSON line of rank 0) with two ranks on GPU 0 over gloo: it
+    completes and reports both legs.  (The numbers of such a run mean nothing: the all-reduces go through the host.)"""
+    import json
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29657", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--replay", "1024"],
+                         capture_output=True, text=True, timeout=1200, env=dict(os.environ, RIFT_BENCH_SAME_GPU="1"))
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 6
+    for leg in ("weak", "strong"):
+        assert line[leg]["ms_per_step"] > 0 and line[leg]["global_batch"] == (512 if leg == "weak" else 256)
+    assert line["value"] == pytest.approx(line["weak"]["value"])
