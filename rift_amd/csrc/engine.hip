@@ -1752,7 +1752,8 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   }
   const size_t need = c->dry_need;
   if (need > c->arena_cap) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (the whole device: with the deferred head and the prepare stream the arena's last readers sit on streams other than the caller's)
+    HIPCHK(c, hipDeviceSynchronize());
     if (c->arena) HIPCHK(c, hipFree(c->arena));
     c->arena = nullptr; c->arena_cap = 0;
     const size_t cap = need + (need >> 3);

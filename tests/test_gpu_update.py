@@ -223,3 +223,43 @@ def test_validation_between_prefetched_training_steps(monkeypatch):
         assert runs[other][0] == runs["serial"][0] and runs[other][1] == runs["serial"][1], (other, runs[other][:2], runs["serial"][:2])
         for k, v in runs["serial"][2].items():
             assert torch.equal(v, runs[other][2][k]), (other, k)
+
+
+def test_pipeline_with_changing_batch_shapes(monkeypatch):
+    """Consecutive pipelined steps whose batches differ in size and in reference-line count (8 x R 2, 96 x R 6, 24 x R 4, ...): the arena-sizing
+    pass of rift_forward is skipped only between forwards of one shape, an arena that has to grow does so behind a device-wide synchronize (its
+    last readers sit on the update / prepare streams), every (size, R) keeps its own batch buffers and outputs.  Parameters and the mean loss
+    equal the serial run bit for bit."""
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+    from rift_amd.replay import DeviceReplay
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    scenes = [syn.make_scene(2600 + i) for i in range(128)]
+    sd = H.weights()
+    g = torch.Generator().manual_seed(9)
+    plan = [(8, 2), (96, 6), (24, 4), (96, 6), (8, 2), (128, 5), (24, 4), (128, 6), (8, 3), (96, 6), (96, 6), (24, 4)]
+    picks = [torch.randperm(128, generator=g)[:n].to(torch.int32).to(dev) for n, _ in plan]
+    torch.cuda.synchronize()
+    runs = {}
+    for mode, (pipeline, prefetch) in {"serial": ("0", "0"), "pipeline": ("1", "1")}.items():
+        monkeypatch.setenv("RIFT_PIPELINE", pipeline)
+        monkeypatch.setenv("RIFT_PREFETCH", prefetch)
+        replay = DeviceReplay(scenes, dev, rcap=6)
+        model = PlanningModel(radius=120)
+        model.load_state_dict({k: v.clone() for k, v in sd.items()})
+        model = model.to(dev)
+        model.need_traj = False
+        model.train()
+        tr = RLFTTrainer(model, kind="rift", seed=5)
+        for ix, (_, R) in zip(picks, plan):
+            fb, b = tr.gather(replay, ix, R)
+            tr.training_step(fb, b)
+        mean = tr.pop_mean_loss()
+        torch.cuda.synchronize()
+        runs[mode] = (mean, {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k.startswith(PI)})
+        tr.close()
+        model.release_engine()
+    assert runs["pipeline"][0] == runs["serial"][0], (runs["pipeline"][0], runs["serial"][0])
+    for k, v in runs["serial"][1].items():
+        assert torch.equal(v, runs["pipeline"][1][k]), k
