@@ -475,11 +475,12 @@ class RLFTTrainer:
             finally:                          # (a forward that raises must not leave later forwards preparing on the prefetch stream)
                 if self._slot_prefetch:
                     self.engine.set_prepare_stream(None)
-            loss_t, loss_ptr = self.loss, self.lo.loss
+            loss_t, loss_ptr, amax_ptr = self.loss, self.lo.loss, self.lo.argmax_rm      # (what of the loss descriptor belongs to THIS step: a tail
+                                                                                         # issued late runs behind the next step's _outputs() / _loss_slot())
 
             def tail(back):
                 """Head, loss, backward, exchange, finalize + clip, AdamW of THIS step on the update stream (`back`: forwards issued since)."""
-                self.loss, self.lo.loss = loss_t, loss_ptr
+                self.loss, self.lo.loss, self.lo.argmax_rm = loss_t, loss_ptr, amax_ptr
                 with torch.cuda.stream(self._side), _ffi.known_stream(self._side):
                     self._side.wait_event(self._ev_loss)          # (the record behind this step's trunk: the latest one when the tail is issued)
                     self.engine.forward_head(back)
@@ -500,7 +501,7 @@ class RLFTTrainer:
                 prev, self._pending_tail = self._pending_tail, tail
                 if prev is not None:
                     prev(1)
-                    self.loss, self.lo.loss = loss_t, loss_ptr
+                    self.loss, self.lo.loss, self.lo.argmax_rm = loss_t, loss_ptr, amax_ptr
                 self._ev_loss.record(main)
             else:
                 self._flush_tail()
@@ -534,9 +535,9 @@ class RLFTTrainer:
         """Issue the tail of the last data-parallel step if it is still held back (see training_step)."""
         prev, self._pending_tail = getattr(self, "_pending_tail", None), None
         if prev is not None:
-            keep = (self.loss, self.lo.loss)
+            keep = (self.loss, self.lo.loss, self.lo.argmax_rm)
             prev(0)
-            self.loss, self.lo.loss = keep
+            self.loss, self.lo.loss, self.lo.argmax_rm = keep
 
     def wait_update(self):
         """Make the current stream wait for the last parameter update (needed before reading loss / parameters / .grad on it)."""

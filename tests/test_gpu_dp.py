@@ -185,7 +185,11 @@ def test_rccl_transport_with_one_rank():
         # (next_slot) and on the prefetch stream (gather: the data-parallel tail is then issued one step late, behind the next forward, and
         # the fronts run ahead), with a host read of the loss in the middle (the held-back tail is flushed)
         g = torch.Generator().manual_seed(5)
-        order = [torch.randperm(16, generator=g)[:8].to(torch.int32).to("cuda:0") for _ in range(9)]
+        # (minibatches of changing size and reference-line count: a tail issued late must carry its own step's loss descriptor)
+        sizes = [8, 12, 6, 8, 16, 6, 12, 8, 10]
+        order = [torch.randperm(16, generator=g)[:n].to(torch.int32).to("cuda:0") for n in sizes]
+        rmax = [int(replay.r_count_cpu[ix.cpu().long()].max()) for ix in order]
+        assert len(set(rmax)) > 1
         torch.cuda.synchronize()
         res = []
         for grp, pre in ((None, False), (dist.group.WORLD, False), (dist.group.WORLD, True), (None, True)):
@@ -195,9 +199,9 @@ def test_rccl_transport_with_one_rank():
             mid = None
             for n, ix in enumerate(order):
                 if pre:
-                    fb, b = tr.gather(replay, ix)
+                    fb, b = tr.gather(replay, ix, rmax[n])
                 else:
-                    fb, b = replay.collate(tr.engine, ix, slot=tr.next_slot())
+                    fb, b = replay.collate(tr.engine, ix, rmax[n], slot=tr.next_slot())
                 tr.training_step(fb, b)
                 if n == 4:
                     mid = tr.step_loss()
