@@ -309,7 +309,11 @@ class RLFTTrainer:
         lo, gbs = shard if shard is not None else (self.rank * fb.bs, self.world * fb.bs)
         need = gbs * fb.R + 1026
         if self.dp_buf is None or self.dp_buf.numel() < need:
-            self.dp_buf = torch.zeros(max(need, 4096), dtype=torch.float64, device=self.engine.device)
+            # (sized for the largest reference-line count the kernels take, 16: the buffer must not be replaced while exchanges of earlier
+            # steps are in flight on the side / update streams, and a larger global minibatch arrives only behind a host sync)
+            self.wait_update()
+            torch.cuda.synchronize(self.engine.device)
+            self.dp_buf = torch.zeros(max(need, gbs * 16 + 1026, 4096), dtype=torch.float64, device=self.engine.device)
         self.engine.set_dp(lo, gbs, self.dp_buf, self.exchange)
 
     def close(self):
