@@ -96,7 +96,7 @@ struct RiftCtx {
   bool dec_fused = true;
   bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true;
   hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = 0;      // rift_set_prepare_stream
-  hipStream_t side2 = nullptr; hipEvent_t ev_join2 = nullptr; bool nat_aside = true;
+  hipEvent_t ev_join2 = nullptr; bool nat_aside = true;      // (the history chain behind the preparation on the prepare stream: its join event)
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
   bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
@@ -947,8 +947,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     nat_aside = prefetched && !gate && c->nat_aside;
     if (nat_aside) {
       if (!c->ev_join2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
-      c->side2 = c->prep_stream;
-      c->stream = c->side2;
+      c->stream = c->prep_stream;
     } else if (!c->nat_on_main) c->stream = c->side;
   }
   static const int Ll[3] = {20, 10, 5}, Cl[3] = {32, 64, 128}, Hl[3] = {2, 4, 8}, Kl[3] = {3, 3, 5};
@@ -1065,7 +1064,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // the longer chain (agent history: ~310 of the front's ~510 us at 256 scenes) stays on the caller's queue, so neither its start nor the
   // join pays a cross-queue hop (12-15 us each by the kernel trace); the map / reference-line chain is the one that forks
   if (forked) {
-    if (nat_aside) { HIPCHK(c, hipEventRecord(c->ev_join2, c->side2)); c->stream = c->side; }
+    if (nat_aside) { HIPCHK(c, hipEventRecord(c->ev_join2, c->prep_stream)); c->stream = c->side; }
     else if (c->nat_on_main) c->stream = c->side;
     else { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
   }
