@@ -184,13 +184,28 @@ def test_decoder_on_few_and_many_reference_lines(ffi, r_max):
     eng.close()
 
 
-@pytest.mark.parametrize("agents,nscenes", [(5, 1), (7, 3), (64, 2), (33, 5)])
+@pytest.mark.parametrize("agents,nscenes", [(5, 1), (7, 3), (64, 2), (33, 5), (1, 2), (2, 3), (3, 4)])
 def test_agent_counts_off_the_tile_grid(ffi, agents, nscenes):
-    """The NAT kernels tile agents in fours (levels 0, 1) and threes (level 2, 8 tiles per round): agent counts that leave partial tiles, a
-    partial last round and idle waves -- against the oracle, eval and BatchNorm batch statistics."""
+    """The NAT kernels tile the ranked history sequences (valid agents other than the ego) in fours (levels 0, 1) and threes (level 2, 8 tiles
+    per round): agent counts that leave partial tiles, a partial last round and idle waves, a residue class without a member, no sequence at
+    all (one agent per scene: the ego) -- against the oracle, eval and BatchNorm batch statistics."""
     scenes = [syn.make_scene(9100 + i, num_agents=agents, num_polygons=7, r_min=1, r_max=3) for i in range(nscenes)]
     _check(ffi, scenes, train=False)
     _check(ffi, scenes, train=True)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_history_encoder_with_nothing_or_everything_to_run_on(ffi, train):
+    """Batches in which NO scene has a valid agent besides the ego (the ranked launch has zero sequences: every level kernel and the FPN tail
+    find nothing to do) and in which EVERY agent slot is valid at every step (no hole in the ranking)."""
+    none = [syn.make_scene(9200 + i, num_agents=12, num_polygons=9, r_min=2, r_max=4) for i in range(3)]
+    for s in none:
+        s["feature"]["agent"]["valid_mask"][1:] = False
+    _check(ffi, none, train)
+    full = [syn.make_scene(9210 + i, num_agents=13, num_polygons=9, r_min=2, r_max=4) for i in range(3)]
+    for s in full:
+        s["feature"]["agent"]["valid_mask"][:] = True
+    _check(ffi, full, train)
 
 
 def test_train_mode_forward_is_bit_reproducible(ffi):
