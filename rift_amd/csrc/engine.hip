@@ -872,7 +872,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     int tot = 0;
     for (int i = 0; i < 7; ++i) tot += q.nb[i];
     // on the caller's prepare stream if there is one (rift_set_prepare_stream): behind the gather of the batch, beside the previous step
-    prefetched = c->prep_set && !c->prof_on && !c->dry && !getenv("RIFT_POISON_ARENA");
+    prefetched = c->prep_set && !c->prof_on && !c->dry;
     if (prefetched) {
       if (!c->ev_prep) HIPCHK(c, hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
       hipStream_t own = c->stream;
@@ -1763,7 +1763,8 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   c->dry = false; c->arena_off = 0; c->taps.clear();
   // diagnostic: RIFT_POISON_ARENA=<byte> fills the scratch arena before every forward (0xFF = NaN pattern), so that a kernel reading
   // scratch it never wrote shows up as NaN / as run-to-run differences instead of depending on what the memory held before
-  { const char* pe = getenv("RIFT_POISON_ARENA"); if (pe && c->arena) HIPCHK(c, hipMemsetAsync(c->arena, (int)strtol(pe, nullptr, 0) & 0xff, c->arena_cap, c->stream)); }
+  // (on the prepare stream if the preparation runs there: every other stream of the forward waits for the preparation)
+  { const char* pe = getenv("RIFT_POISON_ARENA"); if (pe && c->arena) HIPCHK(c, hipMemsetAsync(c->arena, (int)strtol(pe, nullptr, 0) & 0xff, c->arena_cap, c->prep_set && !c->prof_on ? c->prep_stream : c->stream)); }
   rc = forward_impl(c, B, out, flags, seed);
   c->stream = (hipStream_t)stream;
   if (rc != RIFT_OK) return rc;
