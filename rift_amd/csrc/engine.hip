@@ -932,7 +932,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     // With the preparation prefetched, neither front chain of step k + 1 needs anything of step k: the map chain (side stream) waits for
     // the preparation only, the agent-history chain follows it on the prepare stream, and the caller's queue holds token assembly ->
     // encoder -> decoder of step k, then of step k + 1 -- the fronts run beside the previous step's one-workgroup-per-scene encoder /
-    // decoder (which leave most of the chip idle below 256 scenes, and SIMD slots at 256).  ms per step, fronts behind the caller's queue
+    // decoder (which leave most of the chip idle below 256 scenes; at 256 they hold every CU whole, and what is gained is that the fronts
+    // start the moment CUs come free, with gather and preparation long done -- profiles/r03_timeline_256.txt).  ms per step, fronts behind the caller's queue
     // / beside it: 32 scenes 0.372 / 0.237, 64 0.394 / 0.245, 128 0.462 / 0.389, 192 0.597 / 0.524, 256 0.701 / 0.678.  What it took:
     // RIFT_DEFER_SLOTS = 4 arenas (with two, tail k - 1 -> front k + 1 -> encoder / decoder k + 1 -> tail k + 1 is a cycle two steps long)
     // and no further hardware queue for the history chain (on a stream of its own every cross-queue wait of the step got slower: 0.372).
