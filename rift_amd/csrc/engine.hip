@@ -878,13 +878,13 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       hipStream_t own = c->stream;
       c->stream = c->prep_stream;
       launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
-      if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(1024), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
+      if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(NAT_RANK_THREADS), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
       c->stream = own;
       HIPCHK(c, hipEventRecord(c->ev_prep, c->prep_stream));
       HIPCHK(c, hipStreamWaitEvent(own, c->ev_prep, 0));
     } else {
       launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
-      if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(1024), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
+      if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(NAT_RANK_THREADS), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
     }
   }
   // data parallel: the r2r mask quirk indexes padding rows of the GLOBAL minibatch -> gather them (slots in the exchange buffer; the

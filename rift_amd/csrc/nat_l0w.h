@@ -398,21 +398,34 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
 }
 
 // Ranks the marked agent slots for the compacted launch: aidx[3 i + c] = the i-th marked slot of residue class c = slot % 3, cnt[c] = the
-// class counts (common.h: SeqCount).  ONE workgroup of 1024 threads: thread t counts the marks of slots [t K, (t + 1) K) per class (three
+// class counts (common.h: SeqCount).  ONE workgroup: thread t counts the marks of slots [t K, (t + 1) K) per class (three
 // 21-bit fields of one word), a workgroup-wide exclusive scan, then the ranks in order.  Behind the input preparation on whatever stream
 // that runs on (the prepare stream of the update loop: beside the previous step).  (First version: every workgroup of nat_l0w_kernel ranked
 // the marks itself in its prologue -- no launch, but 14 us on each of 256 CUs.)
-__global__ __launch_bounds__(1024) void nat_rank_kernel(const uint8_t* __restrict__ hist, int n, int* __restrict__ aidx, int* __restrict__ cnt) {
-  __shared__ unsigned long long wsum[16];
+#define NAT_RANK_THREADS 256      // four waves of <= 64 VGPRs: a workgroup that fits beside the decoder's on a CU (224 VGPRs x 2 waves per SIMD leave 64), so
+                                  // that the ranking of step k + 1 finishes INSIDE the decoder of step k at a chip-filling batch instead of behind it
+__global__ __launch_bounds__(NAT_RANK_THREADS) void nat_rank_kernel(const uint8_t* __restrict__ hist, int n, int* __restrict__ aidx, int* __restrict__ cnt) {
+  constexpr int NW = NAT_RANK_THREADS / 64;
+  __shared__ unsigned long long wsum[NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = (n + 1023) / 1024, s0 = tid * K;
-  // the marks of this thread: one 16-byte load when its slots are 16 aligned bytes inside the array (the benchmark's 16384 slots), byte loads otherwise
-  const bool vec = K == 16 && s0 + 16 <= n;
-  uint32_t mk[4] = {0u, 0u, 0u, 0u};
-  if (vec) { const uint4 v = *reinterpret_cast<const uint4*>(hist + s0); mk[0] = v.x; mk[1] = v.y; mk[2] = v.z; mk[3] = v.w; }
-  auto mark = [&](int j) -> bool { return vec ? ((mk[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0u : (s0 + j < n && hist[s0 + j] != 0); };
+  const int K = (((n + NAT_RANK_THREADS - 1) / NAT_RANK_THREADS) + 15) & ~15, s0 = tid * K;      // slots per thread, a multiple of 16
+  // sixteen marks at a time: one 16-byte load when they lie inside the array (hist is 16-byte aligned), byte loads otherwise
+  auto marks16 = [&](int j0, uint32_t (&mk)[4]) {
+    const int p = s0 + j0;
+    if (p + 16 <= n) { const uint4 v = *reinterpret_cast<const uint4*>(hist + p); mk[0] = v.x; mk[1] = v.y; mk[2] = v.z; mk[3] = v.w; }
+    else {
+      mk[0] = mk[1] = mk[2] = mk[3] = 0u;
+      for (int j = 0; j < 16; ++j) if (p + j < n && hist[p + j]) mk[j >> 2] |= 1u << (8 * (j & 3));
+    }
+  };
   unsigned long long mine = 0ull;
-  for (int j = 0, c = s0 % 3; j < K; ++j, c = (c == 2) ? 0 : c + 1) mine += mark(j) ? (1ull << (21 * c)) : 0ull;
+  int c = s0 % 3;
+  for (int j0 = 0; j0 < K; j0 += 16) {
+    uint32_t mk[4];
+    marks16(j0, mk);
+#pragma unroll
+    for (int j = 0; j < 16; ++j, c = (c == 2) ? 0 : c + 1) mine += ((mk[j >> 2] >> (8 * (j & 3))) & 0xffu) ? (1ull << (21 * c)) : 0ull;
+  }
   unsigned long long incl = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
@@ -420,14 +433,20 @@ __global__ __launch_bounds__(1024) void nat_rank_kernel(const uint8_t* __restric
   __syncthreads();
   unsigned long long base = 0ull, total = 0ull;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) { const unsigned long long sw = wsum[w]; base += (w < wave) ? sw : 0ull; total += sw; }
+  for (int w = 0; w < NW; ++w) { const unsigned long long sw = wsum[w]; base += (w < wave) ? sw : 0ull; total += sw; }
   const unsigned long long off = base + incl - mine;
   int nx0 = (int)(off & 0x1fffffu), nx1 = (int)((off >> 21) & 0x1fffffu), nx2 = (int)((off >> 42) & 0x1fffffu);
-  for (int j = 0, c = s0 % 3; j < K; ++j, c = (c == 2) ? 0 : c + 1) {
-    if (mark(j)) {
-      const int i = (c == 0) ? nx0 : (c == 1) ? nx1 : nx2;
-      nx0 += (c == 0); nx1 += (c == 1); nx2 += (c == 2);
-      aidx[3 * i + c] = s0 + j;
+  c = s0 % 3;
+  for (int j0 = 0; j0 < K; j0 += 16) {
+    uint32_t mk[4];
+    marks16(j0, mk);
+#pragma unroll
+    for (int j = 0; j < 16; ++j, c = (c == 2) ? 0 : c + 1) {
+      if ((mk[j >> 2] >> (8 * (j & 3))) & 0xffu) {
+        const int i = (c == 0) ? nx0 : (c == 1) ? nx1 : nx2;
+        nx0 += (c == 0); nx1 += (c == 1); nx2 += (c == 2);
+        aidx[3 * i + c] = s0 + j0 + j;
+      }
     }
   }
   if (tid == 0) { cnt[0] = (int)(total & 0x1fffffu); cnt[1] = (int)((total >> 21) & 0x1fffffu); cnt[2] = (int)((total >> 42) & 0x1fffffu); }
