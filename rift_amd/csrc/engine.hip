@@ -96,7 +96,7 @@ struct RiftCtx {
   bool dec_fused = true;
   bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true;
   hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = 0;      // rift_set_prepare_stream
-  hipEvent_t ev_join2 = nullptr; bool nat_aside = true;      // (the history chain behind the preparation on the prepare stream: its join event)
+  hipEvent_t ev_join2 = nullptr; bool nat_aside = true; int join_once = -1;      // (the history chain behind the preparation on the prepare stream: its join event)
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
   bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
@@ -1172,9 +1172,14 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     return RIFT_OK;
   };
   if (forked && rpe_done) { const int rc0 = build_q0(); if (rc0 != RIFT_OK) return rc0; }
+  // join: the agent tokens need both chains.  Small batches: the map chain waits for the history chain first, so that the caller's queue --
+  // token assembly, encoder, decoder: the step, below a chip-filling batch -- takes ONE cross-queue wait per forward (32 scenes: 0.233 ->
+  // 0.226 ms); at 128 scenes it makes no difference and at 256 it costs 1-3 % (the map chain of the step after next stalls behind the wait)
+  const bool join_once = nat_aside && (c->join_once >= 0 ? c->join_once != 0 : bs <= 64);
+  if (join_once) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_join2, 0));
   if (forked && (c->nat_on_main || nat_aside)) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
-  if (forked) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));      // join: the agent tokens need both chains
-  if (nat_aside) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join2, 0));
+  if (forked) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+  if (nat_aside && !join_once) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join2, 0));
   {
     TokenP q;
     q.nat = nat_out; q.x_ego = x_ego; q.valid_agent = (const uint8_t*)valid_agent; q.category = B->agent_category; q.a_type_emb = fptr(c, "agent_encoder.type_emb.weight");
@@ -1456,6 +1461,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_PE_LIVE"); if (ev) c->pe_live = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_JOIN_ONCE"); if (ev) c->join_once = atoi(ev); }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }
