@@ -2231,23 +2231,28 @@ int rift_collate(RiftCtx* c, const RiftReplayArena* ar, const int32_t* scene_idx
                  const RiftFeatureBatch* ob, float* out_old_logits, float* out_ref_logits, double* out_advantage,
                  uint8_t* out_valid_mask, void* stream) {
   if (!c || !ar || !scene_idx || !ob || bs <= 0 || R_out <= 0 || R_out > ar->Rcap) return RIFT_ERR_ARG;
+  // the arena's rows are stored padded to its capacities (ar->A, Mp, Rcap, S); the batch is padded to the dimensions of `ob`, which
+  // may be smaller (a host arena that grows by doubling keeps capacities above the largest stored scene): every ragged dimension
+  // leads its per-scene block, so the crop is a prefix copy
+  if (ob->A > ar->A || ob->Mp > ar->Mp || ob->S > ar->S || ob->A <= 0 || ob->T != ar->T) return RIFT_ERR_ARG;
   const RiftFeatureBatch& s = ar->scenes;
   const int A = ar->A, Mp = ar->Mp, Rc = ar->Rcap, S = ar->S, T = ar->T;
+  const int oA = ob->A, oMp = ob->Mp, oS = ob->S;
   CollateP p; memset(&p, 0, sizeof(p));
   int k = 0;
   auto add = [&](const void* src, void* dst, long long src_bytes, long long dst_bytes) {
     if (!src || !dst || dst_bytes <= 0) return;
     p.src[k] = (const unsigned char*)src; p.dst[k] = (unsigned char*)dst; p.src_bytes[k] = (int)src_bytes; p.dst_bytes[k] = (int)dst_bytes; ++k;
   };
-#define FIX(field, bytes) add(s.field, (void*)ob->field, (bytes), (bytes))
-  FIX(agent_position, (long long)A * T * 8); FIX(agent_heading, (long long)A * T * 4); FIX(agent_velocity, (long long)A * T * 8);
-  FIX(agent_shape, (long long)A * T * 8); FIX(agent_category, A); FIX(agent_valid_mask, (long long)A * T);
-  FIX(map_point_position, (long long)Mp * 3 * 20 * 8); FIX(map_point_vector, (long long)Mp * 3 * 20 * 8);
-  FIX(map_point_orientation, (long long)Mp * 3 * 20 * 4); FIX(map_polygon_center, (long long)Mp * 12);
-  FIX(map_polygon_type, Mp); FIX(map_polygon_on_route, Mp); FIX(map_polygon_tl_status, Mp);
-  FIX(map_polygon_has_speed_limit, Mp); FIX(map_polygon_speed_limit, (long long)Mp * 4); FIX(map_valid_mask, (long long)Mp * 20);
-  FIX(static_position, (long long)S * 8); FIX(static_heading, (long long)S * 4); FIX(static_shape, (long long)S * 8);
-  FIX(static_category, S); FIX(static_valid_mask, S); FIX(current_state, (long long)ar->cs_ld * 4);
+#define FIX(field, n_src, n_dst, per) add(s.field, (void*)ob->field, (long long)(n_src) * (per), (long long)(n_dst) * (per))
+  FIX(agent_position, A, oA, T * 8); FIX(agent_heading, A, oA, T * 4); FIX(agent_velocity, A, oA, T * 8);
+  FIX(agent_shape, A, oA, T * 8); FIX(agent_category, A, oA, 1); FIX(agent_valid_mask, A, oA, T);
+  FIX(map_point_position, Mp, oMp, 3 * 20 * 8); FIX(map_point_vector, Mp, oMp, 3 * 20 * 8);
+  FIX(map_point_orientation, Mp, oMp, 3 * 20 * 4); FIX(map_polygon_center, Mp, oMp, 12);
+  FIX(map_polygon_type, Mp, oMp, 1); FIX(map_polygon_on_route, Mp, oMp, 1); FIX(map_polygon_tl_status, Mp, oMp, 1);
+  FIX(map_polygon_has_speed_limit, Mp, oMp, 1); FIX(map_polygon_speed_limit, Mp, oMp, 4); FIX(map_valid_mask, Mp, oMp, 20);
+  FIX(static_position, S, oS, 8); FIX(static_heading, S, oS, 4); FIX(static_shape, S, oS, 8);
+  FIX(static_category, S, oS, 1); FIX(static_valid_mask, S, oS, 1); FIX(current_state, 1, 1, ar->cs_ld * 4);
 #undef FIX
 #define RAG(srcp, dstp, per_line) add((srcp), (void*)(dstp), (long long)Rc * (per_line), (long long)R_out * (per_line))
   RAG(s.ref_position, ob->ref_position, 120 * 8); RAG(s.ref_vector, ob->ref_vector, 120 * 8);

@@ -13,6 +13,11 @@ Semantics kept from the reference (they decide which transitions reach the updat
   * the episodes finished by ONE `store()` call are committed together, and dropped together when they hold <= 5 transitions in total
     (cbv_rollout_buffer.py:80);
   * committing stops at `buffer_capacity`; the buffer counts as full as soon as a commit reaches or would pass it (:81-90).
+
+Streaming (round 4): a committed row whose observation is a PlutoFeature is ALSO laid into a page-locked structure-of-arrays mirror of the
+HBM arena right away (`rift_amd.replay.HostReplay`, one per streamed observation key: 'CBVs_obs' always, 'CBVs_next_obs' when a policy
+asks for it -- PPO's second sweep), i.e. during the rollout.  `RLFTPluto.train` then uploads that mirror with ~30 asynchronous copies
+instead of walking 4096 x 25 Python objects (`host_replay(key)`); the row store stays what `sample` / `get_key_data` serve.
 """
 from typing import Dict, Hashable, Iterable, List, Sequence
 
@@ -56,6 +61,11 @@ class CBVRolloutBuffer:
         self.num_scenario, self.mode, self.logger = num_scenario, mode, logger
         self.buffer_capacity = int(cbv_config['buffer_capacity'])
         self.data_keys = list(cbv_config['data_keys'])
+        obs_cfg = cbv_config.get('obs') or {}
+        self._host_caps = {"A": int(obs_cfg['max_agent']) + 1} if 'max_agent' in obs_cfg else {}    # rift_pluto.yaml:35: the CBV + max_agent others
+        self._host_caps.update(cbv_config.get('host_caps') or {})       # initial capacities of the ragged dimensions (they double on demand)
+        self._host: Dict[str, object] = {}          # observation key -> HostReplay (False: rows of this key are not PlutoFeatures)
+        self._host_keys = [k for k in ('CBVs_obs',) if k in self.data_keys and cbv_config.get('stream_to_host', True)]
         self.reset_buffer()
 
     # ---- state ------------------------------------------------------------------------------------------------------
@@ -64,6 +74,55 @@ class CBVRolloutBuffer:
         self._open: Dict[Hashable, List[dict]] = {}
         self.buffer_full = False
         self.buffer_data = _Columns(self._rows, self.data_keys)
+        for h in self._host.values():
+            if h:
+                h.reset()
+
+    # ---- the pinned host mirror of the HBM arena ---------------------------------------------------------------------------
+    def attach_host_replay(self, obs_keys: Iterable[str]):
+        """Stream these observation keys as well (rows already committed are laid in now)."""
+        for k in obs_keys:
+            if k in self.data_keys and k not in self._host_keys:
+                self._host_keys.append(k)
+                self._stream(0, self._rows, only=k)
+
+    def host_replay(self, key: str = 'CBVs_obs'):
+        """The HostReplay holding the committed rows of `key`, or None (not streamed / not PlutoFeature observations)."""
+        h = self._host.get(key)
+        return h if h else None
+
+    @staticmethod
+    def _row_scene(row: dict, key: str):
+        """(per-scene feature dict, RLFT extras) of a committed row, or None when the observation is not a PlutoFeature."""
+        obs = row.get(key)
+        pf = obs.get('raw_pluto_feature') if isinstance(obs, dict) else None
+        data = getattr(pf, 'data', None)
+        if not isinstance(data, dict) or 'agent' not in data or 'reference_line' not in data:
+            return None
+        ex = {}
+        if key == 'CBVs_obs':
+            a, o, r = row.get('CBVs_group_advantage'), row.get('CBVs_actions_old_group_logits'), row.get('CBVs_actions_ref_group_logits')
+            if isinstance(a, dict):
+                ex["group_advantage"], ex["group_advantage_mask"] = np.asarray(a['advantage']), np.asarray(a['valid_mask'])
+            if isinstance(o, dict):
+                ex["old_group_logits"] = np.asarray(o['logits'])
+            if isinstance(r, dict):
+                ex["ref_group_logits"] = np.asarray(r['logits'])
+        return data, ex
+
+    def _stream(self, start: int, block: List[dict], only: str = None):
+        for key in ([only] if only else self._host_keys):
+            if self._host.get(key) is False:
+                continue
+            for j, row in enumerate(block):
+                scene = self._row_scene(row, key)
+                if scene is None:
+                    self._host[key] = False
+                    break
+                if key not in self._host:
+                    from rift_amd.replay import HostReplay
+                    self._host[key] = HostReplay(self.buffer_capacity, caps=self._host_caps)
+                self._host[key].put(start + j, *scene)
 
     @property
     def buffer_pos(self) -> int:
@@ -99,7 +158,9 @@ class CBVRolloutBuffer:
         if len(block) >= room:
             block = block[:max(room, 0)]
             self.buffer_full = True
+        start = len(self._rows)
         self._rows += block
+        self._stream(start, block)
 
     def add_extra_data(self, data_dict: dict):
         """Attach whole extra columns (PPO / REINFORCE preprocessing results), one entry per committed transition."""

@@ -89,9 +89,29 @@ class RLFTPluto(PLUTO):
             self.logger.log(msg, color) if color else self.logger.log(msg)
 
     # ---- API surface of rlft_pluto.py ---------------------------------------------------------------
+    STREAM_KEYS = ('CBVs_obs',)         # observation columns the rollout buffer mirrors into pinned host arenas as it commits them
+
     def set_buffer(self, buffer, total_routes=None):
         self.buffer = buffer
         self.total_routes = total_routes
+        if hasattr(buffer, 'attach_host_replay'):
+            buffer.attach_host_replay(self.STREAM_KEYS)
+
+    def _arena(self, key: str = 'CBVs_obs') -> DeviceReplay:
+        """The replay in HBM.  Product path: the pinned structure-of-arrays mirror the buffer filled at store() time goes up as it lies
+        (DeviceReplay.upload: <= 30 asynchronous copies, the update starts behind them; the device arena is kept across updates).
+        A buffer without that mirror (foreign buffer class, non-PlutoFeature rows, stream_to_host: False) is packed scene by scene."""
+        host = self.buffer.host_replay(key) if hasattr(self.buffer, 'host_replay') else None
+        if host is None:
+            if key == 'CBVs_obs':
+                return DeviceReplay(buffer_to_scenes(self.buffer), self.device)
+            return DeviceReplay([{"feature": o['raw_pluto_feature'].data, "extras": replay_dummy_extras(o['raw_pluto_feature'].data)}
+                                 for o in self.buffer.get_key_data(key)], self.device)
+        cache = self.__dict__.setdefault("_arenas", {})
+        if key not in cache:
+            cache[key] = DeviceReplay(None, self.device)
+        cache[key].upload(host, self.buffer.buffer_capacity)
+        return cache[key]
 
     def set_mode(self, mode):
         self.mode = mode
@@ -179,7 +199,7 @@ class RLFTPluto(PLUTO):
                               process_group=process_group, seed=int(e_i) + 1)
         rank, world = trainer.rank, trainer.world
         eng = trainer.engine
-        replay = DeviceReplay(buffer_to_scenes(self.buffer), self.device)
+        replay = self._arena()
         extras = self.preprocess_buffer(trainer, replay)
         n = replay.n
         g = torch.Generator().manual_seed(int(e_i) + 1234)          # same split and order on every rank
@@ -342,6 +362,7 @@ class ReinforcePluto(RLFTPluto):   # fine_tuner/rlft/reinforce_pluto/reinforce_p
 
 class PPOPluto(RLFTPluto):         # fine_tuner/rlft/ppo_pluto/ppo_pluto.py:40-120
     name, type, kind = 'ppo_pluto', 'learnable', 'ppo'
+    STREAM_KEYS = ('CBVs_obs', 'CBVs_next_obs')          # the second buffer sweep reads the next observations (ppo_datamodule.py:141-150)
 
     def __init__(self, config, logger):
         super().__init__(config, logger)
@@ -388,9 +409,7 @@ class PPOPluto(RLFTPluto):         # fine_tuner/rlft/ppo_pluto/ppo_pluto.py:40-1
         old_log_prob = torch.as_tensor(np.stack(buf.get_key_data('CBVs_actions_old_log_prob'), axis=0)).float().view(-1)
         action_mode = torch.as_tensor(np.stack(buf.get_key_data('CBVs_actions_mode'), axis=0)).long().view(-1, 2)
         state, value = self._sweep(trainer, replay, 1 << 20)
-        next_scenes = [{"feature": o['raw_pluto_feature'].data, "extras": replay_dummy_extras(o['raw_pluto_feature'].data)}
-                       for o in buf.get_key_data('CBVs_next_obs')]
-        _, next_value = self._sweep(trainer, DeviceReplay(next_scenes, self.device), 1 << 21)
+        _, next_value = self._sweep(trainer, self._arena('CBVs_next_obs'), 1 << 21)
         adv = eng.gae(rewards, undones, value, next_value, unterm, self.cfg["gamma"], self.cfg["lambda_gae_adv"])
         reward_sum = adv + value
         adv = eng.normalize_advantage_(adv.clone())

@@ -7,8 +7,9 @@ rift_datamodule.py:33-49): every scene is stored once in HBM, padded to
 (A, Mp, Rcap, S), and a minibatch is ONE gather kernel (``rift_collate``).
 """
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from rift_amd import _ffi
@@ -47,11 +48,139 @@ def _pad_stack(ts: List[torch.Tensor], n: int, dtype) -> torch.Tensor:
     return out
 
 
-class DeviceReplay:
-    """Replay arena in HBM.  `scenes` = list of {'feature': per-scene PlutoFeature.data, 'extras': {...}}."""
+_EXTRA_FIELDS = (("old_group_logits", _F32), ("group_advantage", torch.float64), ("group_valid_mask", _U8), ("ref_group_logits", _F32))
+_GROUP_OF = {name: grp for name, grp, *_ in _FIELDS}
+_DIM_OF = {"agent": "A", "map": "Mp", "reference_line": "R", "static_objects": "S"}
 
-    def __init__(self, scenes: List[Dict], device, rcap: Optional[int] = None):
+
+def _np(t):
+    """numpy view of a per-scene tensor (torch CPU tensor or ndarray); no copy for contiguous inputs."""
+    return t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+class HostReplay:
+    """The replay as ONE pinned host structure-of-arrays, written a committed transition at a time.
+
+    The reference keeps a replay entry as Python objects and pays for it in every training step (256 x `CBVRolloutBuffer.sample` +
+    ~40 `pad_sequence`, cbv_rollout_buffer.py:124-138, rift_datamodule.py:33-49).  Rounds 1-3 of this build moved that cost to one Python
+    pass per update (`DeviceReplay(scenes)`: 25 fields x 4096 copies inside `RLFTPluto.train`, seconds).  Here the transition is laid
+    into the arena's layout WHEN IT IS COMMITTED (`CBVRolloutBuffer.store`, during the rollout, where the simulator is the bottleneck):
+    one preallocated page-locked array per feature key, scene-major, every ragged leading dimension (agents, polygons, reference lines,
+    static objects) padded to a capacity that doubles when a scene exceeds it.  `DeviceReplay.upload` then moves the arena to HBM as
+    ~30 asynchronous host-to-device copies of contiguous row ranges and the update starts behind them.
+
+    `caps`: initial capacities {"A", "Mp", "R", "S"} (rift_pluto.yaml:35-36: max_agent 48 -> A <= 49 with the CBV itself; the map
+    crop of radius 120 gives Mp of a few dozen polygons; R <= 6 reference lines)."""
+
+    DEFAULT_CAPS = {"A": 49, "Mp": 64, "R": 6, "S": 8}
+
+    def __init__(self, capacity: int, caps: Optional[Dict[str, int]] = None, pin: Optional[bool] = None):
+        self.capacity = int(capacity)
+        self.caps = dict(self.DEFAULT_CAPS)
+        self.caps.update(caps or {})
+        self.pin = torch.cuda.is_available() if pin is None else bool(pin)
+        self.T: Optional[int] = None            # time extent of the agent tensors, fixed by the first scene
+        self.cs_ld: Optional[int] = None
+        self.t: Dict[str, torch.Tensor] = {}    # name -> (capacity, cap, ...) page-locked tensor
+        self.v: Dict[str, np.ndarray] = {}      # name -> numpy view of the same memory (what put() writes through)
+        self.dims = {"A": 0, "Mp": 0, "R": 0, "S": 0}       # maxima over the stored scenes = the padded sizes of a collated batch
+        self.r_count = torch.zeros(self.capacity, dtype=torch.int32)
+        self._rc = self.r_count.numpy()
+        self.has_ref_logits = False
+        self.version = 0                        # bumped by every write: DeviceReplay.upload skips an arena it already holds
+        self.grown = 0
+
+    # ---- storage -----------------------------------------------------------------------------------------------------------
+    def _alloc(self, name: str, tail: Sequence[int], dtype, cap: Optional[int]):
+        shape = (self.capacity,) + ((cap,) if cap is not None else ()) + tuple(tail)
+        t = torch.zeros(shape, dtype=dtype, pin_memory=self.pin)
+        self.t[name] = t
+        self.v[name] = t.numpy() if dtype != torch.bool else t.view(torch.uint8).numpy()
+
+    def _grow(self, dim: str, need: int):
+        """Double the capacity of one ragged dimension (rare: a scene with more agents / polygons / lines than any before)."""
+        new = max(2 * self.caps[dim], need)
+        for name in [n for n in self.t if self._dim_of(n) == dim]:
+            old = self.t[name]
+            self._alloc(name, old.shape[2:], old.dtype, new)
+            self.t[name][:, :old.shape[1]] = old
+        self.caps[dim] = new
+        self.grown += 1
+
+    @staticmethod
+    def _dim_of(name: str) -> Optional[str]:
+        if name in _GROUP_OF:
+            return _DIM_OF[_GROUP_OF[name]]
+        return "R" if name in ("old_group_logits", "group_advantage", "group_valid_mask", "ref_group_logits") else None
+
+    def _put(self, i: int, name: str, a: np.ndarray, dtype, dim: Optional[str]):
+        if dim is None:
+            if name not in self.t:
+                self._alloc(name, a.shape, dtype, None)
+            self.v[name][i] = a
+            return
+        n = a.shape[0]
+        if n > self.caps[dim]:
+            self._grow(dim, n)
+        if name not in self.t:
+            self._alloc(name, a.shape[1:], dtype, self.caps[dim])
+        row = self.v[name][i]
+        if n:
+            row[:n] = a                 # numpy casts on assignment (fp64 -> fp32 as PlutoFeature.to_feature_tensor does, bool -> u8)
+        row[n:] = 0                     # pad_sequence's zeros; also clears what an earlier update left in this slot
+        if n > self.dims[dim]:
+            self.dims[dim] = n
+
+    def put(self, i: int, feature: Dict, extras: Optional[Dict] = None):
+        """Lay scene `i` (a per-scene PlutoFeature.data dict + the RLFT extras of `buffer_to_scenes`) into the arena."""
+        if not 0 <= i < self.capacity:
+            raise IndexError(i)
+        if self.T is None:
+            self.T = int(feature["agent"]["position"].shape[1])
+        for name, grp, key, dt, _ in _FIELDS:
+            g = feature.get(grp)
+            if g is None or key not in g:
+                continue
+            self._put(i, name, _np(g[key]), dt, _DIM_OF[grp])
+        cs = _np(feature["current_state"])
+        self.cs_ld = int(cs.shape[0])
+        self._put(i, "current_state", cs, _F32, None)
+        R = int(feature["reference_line"]["position"].shape[0])
+        self._rc[i] = R
+        ex = extras or {}
+        adv = ex.get("group_advantage")
+        self._put(i, "group_advantage", _np(adv) if adv is not None else np.zeros((R, 12)), torch.float64, "R")
+        msk = ex.get("group_advantage_mask")
+        self._put(i, "group_valid_mask", _np(msk) if msk is not None else np.ones((R, 12), dtype=np.bool_), _U8, "R")
+        old = ex.get("old_group_logits")
+        self._put(i, "old_group_logits", _np(old) if old is not None else np.zeros((R, 12), dtype=np.float32), _F32, "R")
+        ref = ex.get("ref_group_logits")
+        if ref is not None:
+            self.has_ref_logits = True
+            self._put(i, "ref_group_logits", _np(ref), _F32, "R")
+        self.version += 1
+
+    def reset(self):
+        """New replay generation: the slots are overwritten (each put() clears its own padding), the batch dimensions start over."""
+        self.dims = {"A": 0, "Mp": 0, "R": 0, "S": 0}
+        self.has_ref_logits = False
+        self.version += 1
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.t.values())
+
+
+class DeviceReplay:
+    """Replay arena in HBM.  `scenes` = list of {'feature': per-scene PlutoFeature.data, 'extras': {...}} (tests, dumps, bench), or
+    -- the product path -- `DeviceReplay.from_host(HostReplay)`: the arena the rollout buffer filled, uploaded as it lies."""
+
+    def __init__(self, scenes: Optional[List[Dict]], device, rcap: Optional[int] = None):
         self.device = torch.device(device)
+        self._out = {}
+        self.t: Dict[str, torch.Tensor] = {}
+        self._host_version = None
+        if scenes is None:
+            return
         feats = [s["feature"] for s in scenes]
         ex = [s["extras"] for s in scenes]
         n = len(scenes)
@@ -63,7 +192,6 @@ class DeviceReplay:
         self.r_count_cpu = torch.tensor([f["reference_line"]["position"].shape[0] for f in feats], dtype=torch.int32)
         self.Rcap = int(rcap or self.r_count_cpu.max())
         dims = {"agent": self.A, "map": self.Mp, "reference_line": self.Rcap, "static_objects": self.S}
-        self.t: Dict[str, torch.Tensor] = {}
         for name, grp, key, dt, _ in _FIELDS:
             if grp == "static_objects" and self.S == 0:
                 continue
@@ -76,9 +204,15 @@ class DeviceReplay:
         if "ref_group_logits" in ex[0]:
             self.t["ref_group_logits"] = _pad_stack([e["ref_group_logits"] for e in ex], self.Rcap, _F32).to(self.device)
         self.r_count = self.r_count_cpu.to(self.device)
+        self._describe(self.A, self.Mp, self.Rcap, self.S)
+
+    def _describe(self, capA: int, capMp: int, capR: int, capS: int):
+        """The RiftReplayArena descriptor: capacities of the stored rows (the gather's source strides).  The batch a gather writes is
+        padded to (self.A, self.Mp, R_out, self.S) <= the capacities: every ragged dimension leads its per-scene block, so cropping is
+        a prefix copy (rift_collate)."""
         ar = _ffi.RiftReplayArena()
-        ar.n_scenes, ar.A, ar.Mp, ar.Rcap, ar.S, ar.T, ar.cs_ld = n, self.A, self.Mp, self.Rcap, self.S, self.T, self.cs_ld
-        ar.scenes.bs, ar.scenes.A, ar.scenes.Mp, ar.scenes.R, ar.scenes.S, ar.scenes.T = n, self.A, self.Mp, self.Rcap, self.S, self.T
+        ar.n_scenes, ar.A, ar.Mp, ar.Rcap, ar.S, ar.T, ar.cs_ld = self.n, capA, capMp, capR, capS, self.T, self.cs_ld
+        ar.scenes.bs, ar.scenes.A, ar.scenes.Mp, ar.scenes.R, ar.scenes.S, ar.scenes.T = self.n, capA, capMp, capR, capS, self.T
         for name, *_ in _FIELDS:
             setattr(ar.scenes, name, self.t[name].data_ptr() if name in self.t else None)
         ar.scenes.current_state = self.t["current_state"].data_ptr()
@@ -89,7 +223,48 @@ class DeviceReplay:
         ar.group_advantage = self.t["group_advantage"].data_ptr()
         ar.group_valid_mask = self.t["group_valid_mask"].data_ptr()
         self.arena = ar
-        self._out = {}
+
+    # ---- the product path: the arena comes up from the rollout buffer's pinned host mirror ----------------------------------------
+    @classmethod
+    def from_host(cls, host: HostReplay, device, n: Optional[int] = None) -> "DeviceReplay":
+        self = cls(None, device)
+        self.upload(host, n)
+        return self
+
+    def upload(self, host: HostReplay, n: Optional[int] = None):
+        """Bring the first `n` scenes of `host` to HBM: one asynchronous copy per stored key (<= 30) on the current stream, out of
+        page-locked memory -- the host returns at once, and whatever is queued behind (index uploads, the prefetch stream's first gather
+        through its `ready` event, PPO's sweeps) runs when the bytes are there.  Device tensors are kept across updates as long as the
+        host arena keeps its capacities; the batch-buffer sets are kept as long as the batch dimensions do."""
+        n = host.capacity if n is None else int(n)
+        if host.T is None:
+            raise ValueError("the host replay is empty")
+        if self._host_version == (id(host), host.version, n):
+            return
+        caps, dims = host.caps, host.dims
+        geom = (n, caps["A"], caps["Mp"], caps["R"], caps["S"], host.T, host.cs_ld, host.has_ref_logits, dims["S"] > 0)
+        if getattr(self, "_geom", None) != geom:
+            self.t = {}
+            for name, src in host.t.items():
+                if name == "ref_group_logits" and not host.has_ref_logits:
+                    continue
+                if _GROUP_OF.get(name) == "static_objects" and dims["S"] == 0:
+                    continue
+                self.t[name] = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=self.device)
+            self.r_count = torch.empty(n, dtype=torch.int32, device=self.device)
+            self._geom = geom
+        out_dims = (dims["A"], dims["Mp"], dims["S"])
+        if getattr(self, "_out_dims", None) != out_dims:
+            self._out = {}
+            self._out_dims = out_dims
+        self.n, self.T, self.cs_ld = n, host.T, host.cs_ld
+        self.A, self.Mp, self.S, self.Rcap = dims["A"], dims["Mp"], dims["S"], caps["R"]
+        for name, dst in self.t.items():
+            dst.copy_(host.t[name][:n], non_blocking=True)
+        self.r_count.copy_(host.r_count[:n], non_blocking=True)
+        self.r_count_cpu = host.r_count[:n].clone()
+        self._describe(caps["A"], caps["Mp"], caps["R"], caps["S"] if dims["S"] else 0)
+        self._host_version = (id(host), host.version, n)
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.t.values())

@@ -1,5 +1,7 @@
 """Host mirror of the update-loop driver: replay buffer staging, PlutoFeature collation, policy registry (CPU);
 a miniature RLFTPluto.train() on the HIP engine (GPU)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -215,6 +217,185 @@ def _filled_buffer(n, with_ref):
             buf.store(d)
             t += 1
     return buf
+
+
+def _ragged_rift_buffer(capacity, seed0, caps=None, dims=((9, 5, 2), (16, 10, 4), (3, 7, 1), (12, 2, 3), (16, 9, 4), (5, 10, 2), (1, 1, 1)), with_ref=False):
+    """A rift_pluto buffer filled through store() with scenes of ragged agent / polygon / reference-line counts (7-step episodes of two CBVs)."""
+    keys = [k for k in KEYS if with_ref or k != 'CBVs_actions_ref_group_logits']
+    buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': capacity, 'data_keys': keys, 'host_caps': caps or {}})
+    t = 0
+    while not buf.buffer_full:
+        for k in range(7):
+            d = {'CBV_ids': [[3, 8]], 'CBVs_obs': [{}], 'CBVs_reward': [{}], 'CBVs_done': [{}], 'CBVs_actions_old_group_logits': [{}],
+                 'CBVs_group_advantage': [{}]}
+            if with_ref:
+                d['CBVs_actions_ref_group_logits'] = [{}]
+            for c in (3, 8):
+                A, Mp, R = dims[(t + c) % len(dims)]
+                s = syn.make_scene(seed0 + 2 * t + (c == 8), A, Mp, R, R)
+                ex = s["extras"]
+                d['CBVs_obs'][0][c] = {'raw_pluto_feature': PlutoFeature(data=s["feature"])}
+                d['CBVs_reward'][0][c], d['CBVs_done'][0][c] = float(ex["return"]), k == 6
+                d['CBVs_actions_old_group_logits'][0][c] = {'logits': ex["old_group_logits"].numpy(), 'valid_mask': ex["old_group_logits_mask"].numpy()}
+                d['CBVs_group_advantage'][0][c] = {'advantage': ex["group_advantage"].numpy(), 'valid_mask': ex["group_advantage_mask"].numpy()}
+                if with_ref:
+                    d['CBVs_actions_ref_group_logits'][0][c] = {'logits': ex["ref_group_logits"].numpy()}
+            buf.store(d)
+            t += 1
+    return buf
+
+
+def _assert_host_arena_is_the_packed_arena(buf):
+    """HostReplay (filled row by row at store() time) == what DeviceReplay(buffer_to_scenes(buffer)) packs in one pass, bit for bit; the
+    capacity padding beyond the largest scene is zero."""
+    from rift_amd import replay as rp
+    from rift_amd.planning.fine_tuner.rlft.rlft_pluto import buffer_to_scenes
+    host = buf.host_replay()
+    assert host is not None and host.T == 21
+    scenes = buffer_to_scenes(buf)
+    feats, ex = [s["feature"] for s in scenes], [s["extras"] for s in scenes]
+    dims = {"agent": max(f["agent"]["position"].shape[0] for f in feats), "map": max(f["map"]["point_position"].shape[0] for f in feats),
+            "reference_line": max(f["reference_line"]["position"].shape[0] for f in feats), "static_objects": 0}
+    assert (host.dims["A"], host.dims["Mp"], host.dims["R"]) == (dims["agent"], dims["map"], dims["reference_line"])
+    n = 0
+    for name, grp, key, dt, _ in rp._FIELDS:
+        if grp == "static_objects":
+            continue
+        want = rp._pad_stack([f[grp][key] for f in feats], dims[grp], dt)
+        got = host.t[name]
+        assert got.dtype == want.dtype and torch.equal(got[:, :dims[grp]], want), name
+        assert not got[:, dims[grp]:].any(), name
+        n += 1
+    assert n == 20
+    assert torch.equal(host.t["current_state"], torch.stack([f["current_state"] for f in feats]).float())
+    R = dims["reference_line"]
+    for name, key, dt in (("old_group_logits", "old_group_logits", torch.float32), ("group_advantage", "group_advantage", torch.float64),
+                          ("group_valid_mask", "group_advantage_mask", torch.bool)) + ((("ref_group_logits", "ref_group_logits", torch.float32),)
+                                                                                         if "ref_group_logits" in ex[0] else ()):
+        want = rp._pad_stack([e[key] for e in ex], R, dt)
+        assert host.t[name].dtype == dt and torch.equal(host.t[name][:, :R], want) and not host.t[name][:, R:].any(), name
+    assert host.r_count.tolist() == [f["reference_line"]["position"].shape[0] for f in feats]
+    return host
+
+
+def test_store_lays_committed_rows_into_the_host_arena():
+    """Round 4: CBVRolloutBuffer.store() writes every committed transition into the pinned structure-of-arrays mirror of the HBM arena
+    (rift_amd.replay.HostReplay) -- the layout DeviceReplay used to build in a 4096 x 25 Python pass inside RLFTPluto.train.  Checked
+    against that pass on ragged scenes, with capacities that have to double on the way, after a reset + refill with other (smaller)
+    scenes (stale rows and stale padding must be gone), and for the GRPO reference logits."""
+    buf = _ragged_rift_buffer(45, 7000, caps={"A": 4, "Mp": 4, "R": 2})
+    host = _assert_host_arena_is_the_packed_arena(buf)
+    assert host.grown >= 3 and host.caps["A"] >= 16 and host.caps["Mp"] >= 10 and host.caps["R"] >= 4
+    buf.reset_buffer()
+    assert len(buf) == 0 and buf.host_replay() is host and host.dims["A"] == 0
+    buf2 = buf
+    t = 0
+    while not buf2.buffer_full:                      # refill the SAME buffer with smaller scenes
+        for k in range(6):
+            s = syn.make_scene(9000 + t, 5, 3, 1, 2)
+            ex = s["extras"]
+            buf2.store({'CBV_ids': [[1]], 'CBVs_obs': [{1: {'raw_pluto_feature': PlutoFeature(data=s["feature"])}}], 'CBVs_reward': [{1: 0.0}],
+                        'CBVs_done': [{1: k == 5}],
+                        'CBVs_actions_old_group_logits': [{1: {'logits': ex["old_group_logits"].numpy(), 'valid_mask': ex["old_group_logits_mask"].numpy()}}],
+                        'CBVs_group_advantage': [{1: {'advantage': ex["group_advantage"].numpy(), 'valid_mask': ex["group_advantage_mask"].numpy()}}]})
+            t += 1
+    h2 = _assert_host_arena_is_the_packed_arena(buf2)
+    assert h2 is host and h2.dims["A"] == 5 and h2.dims["Mp"] == 3
+    _assert_host_arena_is_the_packed_arena(_ragged_rift_buffer(30, 7100, with_ref=True))
+    # rows that are not PlutoFeature observations (the staging tests above store integers) are simply not mirrored
+    plain = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': 10, 'data_keys': KEYS})
+    for t in range(8):
+        plain.store(_step([1], [1] if t == 7 else [], t))
+    assert len(plain) == 8 and plain.host_replay() is None
+    # numpy float64 features (what the CARLA-side builder hands over before to_feature_tensor) are cast like PlutoFeature.to_feature_tensor
+    from rift_amd.replay import HostReplay
+    s = syn.make_scene(1, 6, 4, 2, 2)
+    f64 = {g: ({k: (v.double().numpy() if v.dtype == torch.float32 else v.numpy()) for k, v in d.items()} if isinstance(d, dict) else d.double().numpy())
+           for g, d in s["feature"].items()}
+    h = HostReplay(2)
+    h.put(0, f64)
+    h.put(1, s["feature"])
+    for name in ("agent_position", "map_point_orientation", "ref_vector", "current_state", "agent_valid_mask"):
+        assert torch.equal(h.t[name][0], h.t[name][1]), name
+
+
+@pytest.mark.gpu
+def test_streamed_arena_collates_like_the_packed_one_and_the_reference_fixture():
+    """The arena uploaded from the host mirror (capacities above the batch dimensions: rift_collate crops every ragged dimension by a
+    prefix copy) gathers the SAME batch as the packed arena and as tests/golden/collate.npz = the reference's RIFTCollate output."""
+    from rift_amd import _ffi
+    from rift_amd.replay import DeviceReplay, HostReplay
+    torch.cuda.set_device(0)
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "collate.npz")))
+    scenes = H.collate_scenes_ragged()
+    host = HostReplay(len(scenes), caps={"A": 20, "Mp": 12, "R": 6, "S": 2})
+    for i, s in enumerate(scenes):
+        host.put(i, s["feature"], s["extras"])
+    eng = _ffi.Engine("cuda:0")
+    rp, packed = DeviceReplay.from_host(host, "cuda:0"), DeviceReplay(scenes, "cuda:0")
+    assert (rp.A, rp.Mp, rp.Rcap) == (16, 10, 6) and rp.arena.A == 20 and rp.arena.Mp == 12
+    for pick in (list(range(len(scenes))), [4, 0, 6, 4, 2]):
+        idx = torch.tensor(pick, dtype=torch.int32, device="cuda:0")
+        R_out = int(rp.r_count_cpu.max())
+        _, b = rp.collate(eng, idx, R_out)
+        _, bp = packed.collate(eng, idx, R_out)
+        torch.cuda.synchronize()
+        for k, v in syn.flatten_dict(rp.batch_dict(b)).items():
+            ref = gold["feature/" + k.replace(".", "/")][pick]
+            got = v.cpu().numpy()
+            assert got.shape == ref.shape and got.dtype == ref.dtype and np.array_equal(got, ref), k
+        for k in b:
+            if b[k] is not None:
+                assert torch.equal(b[k], bp[k]), k
+        assert np.array_equal(b["group_advantage"].cpu().numpy(), gold["group_advantage_torch"][pick])
+        assert np.array_equal(b["old_group_logits"].cpu().numpy(), gold["old_group_logits_torch"][pick])
+    # a second replay generation in the same slots: the device arena is re-used, the batch buffers follow the new batch dimensions
+    host.reset()
+    small = [syn.make_scene(300 + i, 6, 4, 1, 2) for i in range(len(scenes))]
+    for i, s in enumerate(small):
+        host.put(i, s["feature"], s["extras"])
+    keep = rp.t["agent_position"].data_ptr()
+    rp.upload(host)
+    assert rp.t["agent_position"].data_ptr() == keep and (rp.A, rp.Mp) == (6, 4)
+    idx = torch.arange(len(small), dtype=torch.int32, device="cuda:0")
+    _, b = rp.collate(eng, idx, int(rp.r_count_cpu.max()))
+    _, bp = DeviceReplay(small, "cuda:0").collate(eng, idx, int(rp.r_count_cpu.max()))
+    torch.cuda.synchronize()
+    for k in b:
+        if b[k] is not None:
+            assert torch.equal(b[k], bp[k]), k
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_update_from_the_streamed_arena_equals_the_update_from_the_packed_one(tmp_path):
+    """RLFTPluto.train() on the arena the buffer streamed at store() time writes the SAME checkpoint (every tensor bit for bit) as on the
+    arena packed scene by scene inside train() (`stream_to_host: False`, the round-3 path)."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    out = {}
+    for mode in ("streamed", "packed"):
+        cfg = {'num_scenario': 1, 'ROOT_DIR': str(tmp_path / mode), 'model_path': 'ckpt', 'device': 'cuda:0',
+               'rlft': {'epochs': 2, 'warmup_epochs': 1, 'train_batch_size': 16, 'val_batch_size': 16, 'lr': 1e-3}}
+        pol = CBV_POLICY_LIST['rift_pluto'](cfg, None)
+        torch.manual_seed(0)
+        with torch.no_grad():
+            for p in pol.pluto_model.parameters():
+                if p.dim() > 1:
+                    p.normal_(0, 0.05)
+        pol.load_model(resume=True)
+        pol.set_mode('train')
+        buf = _ragged_rift_buffer(45, 7000, caps={"A": 4})
+        if mode == "packed":
+            buf._host = {'CBVs_obs': False}
+        pol.set_buffer(buf)
+        assert (buf.host_replay() is not None) == (mode == "streamed")
+        fit = pol.train(3)
+        assert ("_arenas" in pol.__dict__) == (mode == "streamed")
+        out[mode] = (torch.load(fit["checkpoint"], weights_only=False)["state_dict"], fit["history"])
+    a, b = out["streamed"], out["packed"]
+    assert [h["val_loss"] for h in a[1]] == [h["val_loss"] for h in b[1]] and [h["train_loss"] for h in a[1]] == [h["train_loss"] for h in b[1]]
+    assert a[0].keys() == b[0].keys() and all(torch.equal(a[0][k], b[0][k]) for k in a[0])
 
 
 @pytest.mark.gpu
