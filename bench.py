@@ -197,6 +197,7 @@ def main():
                     help="which scaling mode is the headline with N > 1 (the other one is reported beside it). weak: 256 scenes per GPU per "
                          "step (global minibatch 256 x N); strong: the reference's 256-scene minibatch split over the N GPUs (SURVEY.md 8(e))")
     ap.add_argument("--no-full-update", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip full_update_e2e (RIFTPluto.train() from a full CBVRolloutBuffer to the reloaded inference model)")
     ap.add_argument("--batch", type=int, default=256, help="scenes per minibatch (diagnostic: 32 = what one of 8 ranks runs under strong scaling)")
     args = ap.parse_args()
     global BATCH
@@ -415,6 +416,61 @@ def main():
         model.release_engine()       # (the context's side stream goes with it: a later leg's streams must not end up sharing hardware queues)
         yield res
 
+    def full_update_e2e():
+        """What the user of `scripts/run.py --mode train_cbv` waits for between two rollout phases: RIFTPluto.train(e_i) from a FULL
+        CBVRolloutBuffer (4096 transitions committed through store(), which lays each one into the pinned host arena as the rollout
+        produces it) to the reloaded inference model -- checkpoint load, trainer, arena upload, 16 epochs x (15 training + 2 validation
+        steps), top-1 checkpoint on disk, inference-model reload + re-bind, buffer reset.  Two updates: the first also builds the
+        training model and its context."""
+        import shutil
+        import tempfile
+        from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
+        from rift_amd.planning import CBV_POLICY_LIST
+        from rift_amd.planning.pluto.feature_builder.pluto_feature import PlutoFeature
+        root = tempfile.mkdtemp(prefix="rift_e2e_")
+        try:
+            pol = CBV_POLICY_LIST['rift_pluto']({'num_scenario': 1, 'ROOT_DIR': root, 'model_path': 'ckpt', 'device': str(dev),
+                                                 'compute_precision': args.precision}, None)
+            pol.pluto_model.load_state_dict(sd_cpu)
+            pol.load_model(resume=True)
+            pol.set_mode('train')
+            keys = ['CBVs_obs', 'CBVs_reward', 'CBVs_done', 'CBVs_actions_old_group_logits', 'CBVs_group_advantage']
+            buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': args.replay, 'data_keys': keys, 'obs': {'max_agent': 63},
+                                                    'host_caps': {'Mp': 20, 'R': 6}})
+            pol.set_buffer(buf)
+            res = {}
+            for upd in range(2):
+                t_store, i = 0.0, 0
+                while not buf.buffer_full:                      # 8-step episodes of one CBV, as the rollout would commit them
+                    for k in range(8):
+                        s = scenes[i % len(scenes)]
+                        ex = s["extras"]
+                        d = {'CBV_ids': [[3]], 'CBVs_obs': [{3: {'raw_pluto_feature': PlutoFeature(data=s["feature"])}}],
+                             'CBVs_reward': [{3: 0.0}], 'CBVs_done': [{3: k == 7}],
+                             'CBVs_actions_old_group_logits': [{3: {'logits': ex["old_group_logits"].numpy(), 'valid_mask': ex["old_group_logits_mask"].numpy()}}],
+                             'CBVs_group_advantage': [{3: {'advantage': ex["group_advantage"].numpy(), 'valid_mask': ex["group_advantage_mask"].numpy()}}]}
+                        t0 = time.perf_counter()
+                        buf.store(d)
+                        t_store += time.perf_counter() - t0
+                        i += 1
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fit = pol.train(upd)
+                pol.pluto_model.engine()                        # the reloaded inference model bound to its context: ready for the next tick
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                res["first_update" if upd == 0 else "steady"] = {
+                    "seconds": dt, "store_us_per_transition": t_store / max(i, 1) * 1e6,
+                    "host_timeline_s": {k: round(v, 4) for k, v in fit["timing"].items()}, "best_val_loss": fit["best_val_loss"]}
+            out = dict(res["steady"])
+            out["first_update"] = res["first_update"]
+            out["note"] = ("RIFTPluto.train(e_i) on a full 4096-transition CBVRolloutBuffer -> reloaded inference model: checkpoint load, arena upload from the pinned host "
+                           "mirror filled at store() time, 16 epochs x (15 training + 2 validation steps), top-1 checkpoint on disk, reload, buffer reset; "
+                           "`seconds` = the second update of the process (the first also builds the training model and its context); store() cost is paid during the rollout")
+            return out
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
+
     head_scaling = args.scaling if world > 1 else "weak"
     # the companion legs run first, the headline leg last, every leg built before the first one runs (see leg())
     def built(*a, **kw):
@@ -437,6 +493,7 @@ def main():
         for p, g in todo:
             r = next(g)
             precisions[p] = {k: r[k] for k in keep}
+    e2e = full_update_e2e() if (world == 1 and rank == 0 and not args.no_e2e and not args.no_full_update and BATCH == 256) else None
     head = next(head_leg)
     if precisions is not None:
         precisions[args.precision] = {k: head[k] for k in keep}
@@ -472,6 +529,8 @@ def main():
             line["weak"]["note"] = "256 scenes per GPU per step: the reference's update with train_batch_size = 256 N (fewer, larger optimizer steps per epoch)"
         if "full_update" in head:
             line["full_update"] = head["full_update"]
+        if e2e is not None:
+            line["full_update_e2e"] = e2e
         if precisions is not None:
             line["precisions"] = precisions
         if "roofline" in head:

@@ -12,6 +12,7 @@ state source (rift_amd.planning.pluto.pluto.CBVStateSource).
 """
 import math
 import re
+import time
 from pathlib import Path
 from typing import Any, Dict, List, Optional
 
@@ -117,6 +118,7 @@ class RLFTPluto(PLUTO):
         self.mode = mode
         if mode == 'train':
             self.train_model = PlanningModel(radius=self.radius).to(self.device)
+            self.train_model.compute_precision = self.compute_precision
             self.train_model.train()
             self.pluto_model.eval()
         elif mode == 'eval':
@@ -157,6 +159,7 @@ class RLFTPluto(PLUTO):
             if not Path(self.checkpoint).exists():
                 raise FileNotFoundError(f"{self.name}: checkpoint {self.checkpoint} does not exist")
             self.pluto_model.load_state_dict(self.load_infer_checkpoint(self.checkpoint, self.device))
+            self._infer_bound = (self.checkpoint, self.pluto_model._tensor_version())
 
     def update_training_ckpt(self):
         load_dir = self.model_path / self.load_agent_info
@@ -165,6 +168,20 @@ class RLFTPluto(PLUTO):
         self.current_epoch = len(files)
         if files:
             self.checkpoint = files[0].as_posix()
+
+    @staticmethod
+    def _moving_keys(model) -> List[str]:
+        """state_dict keys an update changes: the trainable parameters (after RLFTTrainer's freeze) and every buffer (BatchNorm running
+        statistics and batch counters of the train-mode forward)."""
+        return [n for n, p in model.named_parameters() if p.requires_grad] + [n for n, _ in model.named_buffers()]
+
+    def _write_checkpoint(self, path: Path, base_cpu: Dict[str, torch.Tensor], snapshot: Dict[str, torch.Tensor], epoch: int, e_i):
+        """{'state_dict': {'model.<key>': tensor}} (pluto.py:130-137): the frozen tensors from the CPU copy the update started from, the
+        moving ones from the best epoch's snapshot."""
+        sd = dict(base_cpu)
+        sd.update({k: v.cpu() for k, v in snapshot.items()})
+        torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "epoch": epoch, "carla_episode": e_i}, path)
+        base_cpu.update({k: sd[k] for k in snapshot})
 
     # ---- the policy update (rlft_pluto.py:206-247) ---------------------------------------------------
     def preprocess_buffer(self, trainer: RLFTTrainer, replay: DeviceReplay) -> Dict[str, torch.Tensor]:
@@ -180,18 +197,34 @@ class RLFTPluto(PLUTO):
         the exchanges of RLFTTrainer make the sharded step equal the single-process one -- same losses, gradients, BatchNorm running
         statistics and therefore the same checkpoint on every rank; rank 0 writes it."""
         assert self.buffer is not None and self.buffer.buffer_full, 'The buffer should be full before training'
+        marks = [("start", time.perf_counter())]          # host-side timeline of the update (last_fit["timing"]; bench.py: full_update_e2e)
+        mark = lambda name: marks.append((name, time.perf_counter()))  # noqa: E731
         if self.train_model is None:
             self.set_mode('train')
         cfg = self.cfg
         lr = max(self.initial_lr * (cfg["cl_lr_decay"] ** self.current_epoch), cfg["min_lr"])   # rlft_pluto.py:212
-        if self.checkpoint:
+        # Where the training model's weights come from (rlft_pluto.py:214-222: the latest checkpoint).  Only the trainable layers and the
+        # BatchNorm running statistics move during an update (`_moving_keys`); when the checkpoint to load is the one THIS process wrote at
+        # the end of its previous update, the frozen trunk is already in place and the moving tensors are restored from the device
+        # snapshot kept with it -- no 17 MB read + 438 host-to-device copies per update.
+        mem = self.__dict__.get("_mem_ckpt")
+        base_cpu = None                       # CPU copy of the whole state_dict the update starts from (the frozen part of the next checkpoint)
+        if self.checkpoint and mem is not None and mem["path"] == self.checkpoint and Path(self.checkpoint).exists():
+            with torch.no_grad():
+                own = self.train_model.state_dict()
+                for k, v in mem["moving"].items():
+                    own[k].copy_(v)
+            base_cpu = mem["base_cpu"]
+        elif self.checkpoint:
             if not Path(self.checkpoint).exists():
                 raise FileNotFoundError(f"{self.name}: checkpoint {self.checkpoint} does not exist")
-            sd = torch.load(self.checkpoint, map_location=self.device, weights_only=False)["state_dict"]
-            self.train_model.load_state_dict({k.replace("model.", "", 1): v for k, v in sd.items()}, strict=False)
+            sd = torch.load(self.checkpoint, map_location="cpu", weights_only=False)["state_dict"]
+            base_cpu = {k.replace("model.", "", 1): v for k, v in sd.items()}
+            self.train_model.load_state_dict(base_cpu, strict=False)
         else:
             self.train_model.load_state_dict(self.pluto_model.state_dict(), strict=False)
-        self.train_model.need_traj = False
+        infer_in_sync = (not self.checkpoint) or self.__dict__.get("_infer_bound") == (self.checkpoint, self.pluto_model._tensor_version())
+        mark("load_checkpoint")
         trainer = RLFTTrainer(self.train_model, kind=self.kind, lr=lr, cl_lr_decay=cfg["cl_lr_decay"],
                               weight_decay=cfg["weight_decay"], epochs=cfg["epochs"], warmup_epochs=cfg["warmup_epochs"],
                               trainable_layers=tuple(cfg["trainable_layers"]), gradient_clip_val=cfg["gradient_clip_val"],
@@ -199,8 +232,11 @@ class RLFTPluto(PLUTO):
                               process_group=process_group, seed=int(e_i) + 1)
         rank, world = trainer.rank, trainer.world
         eng = trainer.engine
+        mark("trainer")
         replay = self._arena()
+        mark("arena")
         extras = self.preprocess_buffer(trainer, replay)
+        mark("preprocess")
         n = replay.n
         g = torch.Generator().manual_seed(int(e_i) + 1234)          # same split and order on every rank
         perm = torch.randperm(n, generator=g)                      # random_split(dataset, [0.9, 0.1]), rift_datamodule.py:93
@@ -208,7 +244,8 @@ class RLFTPluto(PLUTO):
         train_idx, val_idx = perm[:n_train], perm[n_train:]
         save_dir = self.model_path / self.load_agent_info
         save_dir.mkdir(parents=True, exist_ok=True)
-        best, best_path, history = None, None, []
+        best, best_path, best_epoch, snapshot, history = None, None, None, None, []
+        moving = self._moving_keys(self.train_model)
 
         def minibatches(idx, bs, shuffle):
             """(device index slice of this rank, R of the whole minibatch, shard descriptor) per minibatch; one upload per pass."""
@@ -246,21 +283,46 @@ class RLFTPluto(PLUTO):
                 history.append({"epoch": epoch, "train_loss": train_loss, "val_loss": val_loss,
                                 "lr": trainer.optimizer.param_groups[0]["lr"]})
                 if best is None or val_loss < best:                    # ModelCheckpoint(save_top_k=1, monitor loss/val_loss)
+                    # Lightning writes the file at every improvement and deletes the previous best; what survives an update is ONE file,
+                    # the best epoch's.  Here an improvement snapshots the tensors that move (a few device-to-device copies) and the file
+                    # is written once, after the last epoch -- same name, same content (`checkpoint_every_improvement: True` restores the
+                    # write per improvement for those who want the intermediate files to survive a crash mid-update)
                     if rank == 0 and best_path is not None and best_path.exists():
                         best_path.unlink()
-                    best = val_loss
+                    best, best_epoch = val_loss, epoch
                     best_path = save_dir / f"carla_episode={e_i}-epoch={epoch}-val_loss={val_loss:.3f}.ckpt"   # training_builder.py:133
-                    if rank == 0:
-                        torch.save({"state_dict": {"model." + k: v.detach().cpu() for k, v in self.train_model.state_dict().items()},
-                                    "epoch": epoch, "carla_episode": e_i}, best_path)
+                    own = self.train_model.state_dict()
+                    snapshot = {k: own[k].detach().clone() for k in moving}
+                    if rank == 0 and cfg.get("checkpoint_every_improvement", False):
+                        self._write_checkpoint(best_path, base_cpu, snapshot, epoch, e_i)
         finally:
             trainer.close()             # the data-parallel hooks sit on the model-owned engine: detach them also when an epoch raises
+        mark("epochs")
+        if base_cpu is None:               # first update of a policy without a checkpoint: the frozen part comes off the device once
+            base_cpu = {k: v.detach().cpu() for k, v in self.train_model.state_dict().items()}
+        if rank == 0 and not cfg.get("checkpoint_every_improvement", False):
+            self._write_checkpoint(best_path, base_cpu, snapshot, best_epoch, e_i)
+        mark("write_checkpoint")
         if process_group is not None:
             torch.distributed.barrier(group=process_group)         # the checkpoint of rank 0 is on disk before anyone reloads
         self.last_fit = {"history": history, "best_val_loss": best, "checkpoint": best_path.as_posix(), "lr": lr}
         self.update_training_ckpt()
-        self.pluto_model.load_state_dict(self.load_infer_checkpoint(self.checkpoint, self.device))
+        self._mem_ckpt = {"path": self.checkpoint, "moving": snapshot, "base_cpu": base_cpu}
+        # refresh the inference model (rlft_pluto.py:244-246).  Its frozen trunk equals the training model's when both came from the same
+        # checkpoint (or the training model was copied from it) and nobody has touched it since: then only the moving tensors are copied,
+        # in place, device to device -- and the engine reads exactly those through their pointers, so no re-bind either
+        if infer_in_sync and self.checkpoint == best_path.as_posix():
+            with torch.no_grad():
+                own = self.pluto_model.state_dict()
+                for k, v in snapshot.items():
+                    if k in own:
+                        own[k].copy_(v)
+        else:
+            self.pluto_model.load_state_dict(self.load_infer_checkpoint(self.checkpoint, self.device))
+        self._infer_bound = (self.checkpoint, self.pluto_model._tensor_version())
+        mark("reload")
         self.buffer.reset_buffer()
+        self.last_fit["timing"] = {b[0] + "_s": b[1] - a[1] for a, b in zip(marks, marks[1:])}
         return self.last_fit
 
 
@@ -329,6 +391,7 @@ class GRPOPluto(_GroupRelativePluto):        # fine_tuner/rlft/grpo_pluto/grpo_p
     def __init__(self, config, logger):
         super().__init__(config, logger)
         self.ref_model = PlanningModel(radius=self.radius).to(self.device)      # frozen reference policy of the KL term (:24-28)
+        self.ref_model.compute_precision = self.compute_precision
         if self._ckpt_path:
             self.ref_model.load_state_dict(self.load_infer_checkpoint(self._ckpt_path, self.device))
         self.ref_model.eval()
@@ -379,6 +442,7 @@ class PPOPluto(RLFTPluto):         # fine_tuner/rlft/ppo_pluto/ppo_pluto.py:40-1
             self.train_model = PPOPlutoModel(radius=self.radius, state_dim=self.state_dim, action_dim=self.action_dim,
                                              hidden_dim=self.hidden_dim, clip_epsilon=self.clip_epsilon,
                                              lambda_entropy=self.lambda_entropy).to(self.device)
+            self.train_model.compute_precision = self.compute_precision
             self.train_model.train()
             self.pluto_model.eval()
         elif mode == 'eval':

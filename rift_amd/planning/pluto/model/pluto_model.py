@@ -262,8 +262,13 @@ class PlanningModel(TorchModuleWrapper):
 
     # ---- engine binding -----------------------------------------------------------------------
     def _tensor_version(self):
-        return tuple((p.data_ptr(), p._version) for n, p in list(self.named_parameters()) + list(self.named_buffers())
-                     if not n.startswith("planning_decoder.pi_head.") and not n.startswith("value_net."))
+        """What the engine's packed weight images depend on: storage and content version of every tensor it PACKS.  pi_head, the critic and
+        the BatchNorm running statistics are read / written in place through their pointers at launch time (Engine.load_state_dict), so
+        an in-place update of those (an optimizer step, RLFTPluto.train's refresh of the inference model) needs no re-bind: storage only."""
+        def live(n):
+            return n.startswith("planning_decoder.pi_head.") or n.startswith("value_net.") or \
+                n.endswith(".running_mean") or n.endswith(".running_var") or n.endswith(".num_batches_tracked")
+        return tuple((p.data_ptr(), 0 if live(n) else p._version) for n, p in list(self.named_parameters()) + list(self.named_buffers()))
 
     def engine(self):
         """Bind (or re-bind after load_state_dict / .to()) the parameter storage to the HIP context.

@@ -207,6 +207,9 @@ class PLUTO(CBVBasePolicy):
         self._step_interval = 1.0 / self._frame_rate
         self.device = torch.device(config.get('device', 'cuda:0'))
         self.pluto_model = PlanningModel(radius=self.radius).to(self.device)       # the inference model
+        # MFMA operand format of the policy's engines ("fp16" | "bf16" | "fp32"; PlanningModel.compute_precision explains)
+        self.compute_precision = config.get('compute_precision', self.pluto_model.compute_precision)
+        self.pluto_model.compute_precision = self.compute_precision
         self.pluto_model.eval()
         self.controllers = defaultdict(lambda: defaultdict(lambda: PIDController(sample_interval=self._frame_rate)))
         self._state_source: Optional[CBVStateSource] = config.get('state_source')
