@@ -10,6 +10,7 @@ the replay columns the update consumes: old log-prob + chosen (r, m) (PPO / REIN
 group-relative advantage of every candidate (RIFT / GRPO; TrajEvaluator on the device).  Live CARLA state comes through the injected
 state source (rift_amd.planning.pluto.pluto.CBVStateSource).
 """
+import contextlib
 import math
 import re
 import time
@@ -25,10 +26,31 @@ from rift_amd.planning.pluto.model.pluto_model import PlanningModel
 from rift_amd.planning.pluto.pluto import PLUTO, CBVBasePolicy, CBVStateSource, Candidates, CenterState, NoFlagSource   # noqa: F401 (re-exported)
 from rift_amd.replay import DeviceReplay
 
+@contextlib.contextmanager
+def capped_host_threads(limit: int):
+    """Cap torch's intra-op thread pool for the duration of an update.  The update's host side is one thread issuing launches plus a few
+    tiny CPU tensor ops per epoch (permutations, index slices); every one of those that enters the intra-op pool wakes ALL its workers,
+    which then spin-wait between regions.  Measured on the GPU box (256 logical CPUs, torch default 128 threads, container quota 16
+    cores): 129 busy threads, 8.9 CPU-seconds inside a 0.5 s update, the cgroup throttled in every 100 ms period -- the launching thread
+    frozen for 60-70 ms five times per update (GPU idle, host stuck inside hipLaunchKernel).  With 4 threads: 0.55 CPU-seconds, no
+    throttling, update 0.52 -> 0.26 s.  The reference runs with torch.set_num_threads(4) throughout (scripts/run.py:133,164); a
+    process that already did the same is left alone."""
+    cur = torch.get_num_threads()
+    capped = bool(limit) and cur > limit
+    if capped:
+        torch.set_num_threads(int(limit))
+    try:
+        yield
+    finally:
+        if capped:
+            torch.set_num_threads(cur)
+
+
 DEFAULT_CFG = {   # fine_tuner/rlft/config/{rift,grpo,ppo,reinforce}_training.yaml + datamodule/*.yaml + lightning/custom_lightning.yaml
     "epochs": 16, "warmup_epochs": 3, "lr": 1e-4, "cl_lr_decay": 0.9, "min_lr": 1e-6, "weight_decay": 1e-5,
     "trainable_layers": ["planning_decoder.pi_head"], "train_batch_size": 256, "val_batch_size": 256, "shuffle": True,
     "train_ratio": 0.9, "gamma": 0.98, "lambda_gae_adv": 0.98, "gradient_clip_val": 0.5,
+    "host_threads": 4,          # cap of torch's intra-op pool during an update (capped_host_threads; 0 = leave it alone)
 }
 
 
@@ -197,6 +219,10 @@ class RLFTPluto(PLUTO):
         the exchanges of RLFTTrainer make the sharded step equal the single-process one -- same losses, gradients, BatchNorm running
         statistics and therefore the same checkpoint on every rank; rank 0 writes it."""
         assert self.buffer is not None and self.buffer.buffer_full, 'The buffer should be full before training'
+        with capped_host_threads(self.cfg.get("host_threads", 4)):
+            return self._train(e_i, process_group)
+
+    def _train(self, e_i, process_group=None):
         marks = [("start", time.perf_counter())]          # host-side timeline of the update (last_fit["timing"]; bench.py: full_update_e2e)
         mark = lambda name: marks.append((name, time.perf_counter()))  # noqa: E731
         if self.train_model is None:
@@ -247,19 +273,27 @@ class RLFTPluto(PLUTO):
         best, best_path, best_epoch, snapshot, history = None, None, None, None, []
         moving = self._moving_keys(self.train_model)
 
-        def minibatches(idx, bs, shuffle):
-            """(device index slice of this rank, R of the whole minibatch, shard descriptor) per minibatch; one upload per pass."""
-            if shuffle:
-                idx = idx[torch.randperm(idx.numel(), generator=g)]
-            idx_dev = idx.to(torch.int32).to(self.device)
-            up = torch.cuda.Event()           # the upload is queued on this stream; the prefetch stream's gathers wait for it
-            up.record()
+        # every epoch's minibatch order is drawn up front (the same generator sequence as a draw per epoch: validation draws nothing) and goes
+        # to the device in ONE upload, with the reference-line count of every minibatch taken off the host copy
+        passes = [train_idx[torch.randperm(train_idx.numel(), generator=g)] if cfg["shuffle"] else train_idx for _ in range(cfg["epochs"])]
+        passes.append(val_idx)
+        flat_dev = torch.cat(passes).to(torch.int32).to(self.device)
+        up = torch.cuda.Event()               # the upload is queued on this stream; the prefetch stream's gathers wait for it
+        up.record()
+        starts = [0]
+        for p_ in passes:
+            starts.append(starts[-1] + p_.numel())
+
+        def minibatches(which, bs):
+            """(device index slice of this rank, R of the whole minibatch, shard descriptor) per minibatch of pass `which`."""
+            idx, idx_dev = passes[which], flat_dev[starts[which]:starts[which + 1]]
+            r_all = replay.r_count_cpu[idx]
             for s in range(0, idx.numel(), bs):
                 m = min(bs, idx.numel() - s)
                 if m < world:       # a tail with fewer scenes than ranks cannot give every rank a scene (each one has to join the
                     continue        # exchanges of the forward): dropped on ALL ranks alike -- at most world - 1 scenes per pass
                 lo, hi = split_minibatch(m, rank, world) if world > 1 else (0, m)
-                yield idx_dev[s + lo:s + hi], int(replay.r_count_cpu[idx[s:s + m]].max()), ((lo, m) if world > 1 else None), up
+                yield idx_dev[s + lo:s + hi], int(r_all[s:s + m].max()), ((lo, m) if world > 1 else None), up
 
         def run(batch, train):
             idx_dev, R_out, shard, up = batch
@@ -274,10 +308,10 @@ class RLFTPluto(PLUTO):
 
         try:
             for epoch in range(cfg["epochs"]):
-                for mb in minibatches(train_idx, cfg["train_batch_size"], cfg["shuffle"]):
+                for mb in minibatches(epoch, cfg["train_batch_size"]):
                     run(mb, True)
                 train_loss = trainer.pop_mean_loss()    # mean of the step losses; also joins the update stream (parameters are final)
-                vl = [run(mb, False).clone() for mb in minibatches(val_idx, cfg["val_batch_size"], False)]
+                vl = [run(mb, False).clone() for mb in minibatches(cfg["epochs"], cfg["val_batch_size"])]
                 trainer.on_epoch_end()
                 val_loss = float(torch.stack(vl).mean().item()) if vl else train_loss
                 history.append({"epoch": epoch, "train_loss": train_loss, "val_loss": val_loss,
