@@ -4,6 +4,7 @@ The product path has NO CPU fallback: if the shared library is missing or fails
 to load, importing the engine raises immediately.
 """
 import ctypes as C
+import threading
 import os
 from typing import Dict, Optional
 
@@ -168,13 +169,19 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-_KNOWN_STREAM = []
+class _KnownStreams(threading.local):        # per host thread: a policy driven from one thread must not hand its stream to another thread's calls
+    def __init__(self):
+        self.stack = []
+
+
+_KNOWN_STREAM = _KnownStreams()
 
 
 def _stream():
     """The stream handle the C-ABI calls are given: torch's current stream -- or the one a caller has declared current (known_stream)."""
-    if _KNOWN_STREAM:
-        return _KNOWN_STREAM[-1]
+    st = _KNOWN_STREAM.stack
+    if st:
+        return st[-1]
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -187,11 +194,13 @@ class known_stream:
         self.h = C.c_void_p(s.cuda_stream)
 
     def __enter__(self):
-        _KNOWN_STREAM.append(self.h)
+        if os.environ.get("RIFT_DEBUG_STREAMS") == "1":      # the declaration must be true
+            assert self.h.value == torch.cuda.current_stream().cuda_stream, "known_stream(s): s is not torch's current stream"
+        _KNOWN_STREAM.stack.append(self.h)
         return self
 
     def __exit__(self, *exc):
-        _KNOWN_STREAM.pop()
+        _KNOWN_STREAM.stack.pop()
         return False
 
 

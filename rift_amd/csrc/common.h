@@ -310,4 +310,10 @@ __device__ __forceinline__ bool seq_live(int n, int c0, int c1, int c2, int seq)
   return seq < n && i < (c == 0 ? c0 : c == 1 ? c1 : c2);
 }
 
+// Finiteness by bit pattern: a float is NaN / +-Inf iff its exponent field is all ones.  Integer compares, so the test also holds in the
+// translation units built with -fno-honor-nans (where x != x folds to false) -- used for the device flag behind the reference's
+// `assert torch.isfinite(q).all()` (planning_decoder.py:175).  exp_or accumulates the largest exponent field seen; nonfinite_exp tests it.
+__device__ __forceinline__ uint32_t exp_max(uint32_t acc, float v) { const uint32_t e = __float_as_uint(v) & 0x7f800000u; return acc > e ? acc : e; }
+__device__ __forceinline__ bool nonfinite_exp(uint32_t acc) { return acc == 0x7f800000u; }
+
 }  // namespace RIFT_NS

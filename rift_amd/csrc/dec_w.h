@@ -70,6 +70,7 @@ struct DecWP {
   float dropout; uint32_t seed, stream;
   int dbg;                      // diagnostic: 1 = skip all compute (weight stream + barriers only), 8 = no stream, 16 = all eight waves carry the stream
   long long* ts;                // optional: clock of wave 0 of workgroup 0 at every group boundary (diagnostic, RIFT_DEC_TS)
+  int* nonfinite;               // device flag: raised when a query row leaves the last layer with a NaN / Inf (planning_decoder.py:175)
   DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 

@@ -500,6 +500,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         DSITE(7);
         residual(res, acc2);
+        if (li == 3) {        // the reference asserts torch.isfinite(q).all() behind every block (planning_decoder.py:175); a NaN / Inf stays in
+          uint32_t ex = 0;    // the residual stream, so the rows leaving the last block are tested -- by bit pattern (this unit is built -fno-honor-nans)
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) { ex = exp_max(ex, res[nt][0]); ex = exp_max(ex, res[nt][1]); ex = exp_max(ex, res[nt][2]); ex = exp_max(ex, res[nt][3]); }
+          if (__builtin_amdgcn_ballot_w64(b_ok && nonfinite_exp(ex)) != 0ull && lane == 0 && p.nonfinite) atomicOr(p.nonfinite, 1);
+        }
         if (DENSE || li + 1 < 4) write_xs(res, b_row, b_ok);
         else if (b_ok) {
 #pragma unroll

@@ -33,6 +33,7 @@ struct EncFusedP {
   const float* norm_g; const float* norm_b;
   uint32_t seed, stream;
   long long* ts;                // optional phase timestamps of workgroup 0 (diagnostic)
+  int* nonfinite;               // device flag: raised when a valid token row leaves the encoder with a NaN / Inf
   // ---- optional tail: the planning decoder's cross-attention K | V projections of this scene's encoder output, all four layers
   // (planning_decoder.py:74-79, nn.MultiheadAttention in_proj rows 128:384), written as bf16 operands of the decoder kernel
   const unsigned short* wkv;    // fragment-major bf16 [4 * 256][128]: per layer (k 128 rows | v 128 rows)
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
   {
     const int lr = lane & 31, rsub = lane >> 5;
     const float4 g4 = *reinterpret_cast<const float4*>(p.norm_g + lr * 4), b4 = *reinterpret_cast<const float4*>(p.norm_b + lr * 4);
+    uint32_t ex = 0;                                   // non-finite flag by bit pattern (common.h: exp_max)
     for (int r = wave * 2 + rsub; r < ROWS; r += 2 * NW) {
       const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
       float s = (v.x + v.y) + (v.z + v.w);
@@ -363,8 +365,10 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
       const float4 o = make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
       if (r < N) *reinterpret_cast<float4*>(p.Y + (grow0 + r) * C + lr * 4) = o;
+      if (r < N) { ex = exp_max(ex, o.x); ex = exp_max(ex, o.y); ex = exp_max(ex, o.z); ex = exp_max(ex, o.w); }
       if (p.KT) *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) = pack_h4(o.x, o.y, o.z, o.w);
     }
+    if (__builtin_amdgcn_ballot_w64(nonfinite_exp(ex)) != 0ull && lane == 0 && p.nonfinite) atomicOr(p.nonfinite, 1);
   }
   if (p.KT && p.x0p) {   // the ego-token half of the decoder's cat_x_proj: one row per scene
     EFrags<4, 1> Wx;

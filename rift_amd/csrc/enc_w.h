@@ -51,6 +51,7 @@ struct EncWP {
                                 // dense layout), projected from the final output while it is still in registers (planning_decoder.py:74-79)
   const unsigned short* img; const float* par;
   float droppath[4]; uint32_t seed, stream;
+  int* nonfinite;               // device flag: raised when a valid token row leaves the encoder with a NaN / Inf
   DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 

@@ -285,7 +285,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) res[nt] += acc2[nt] * dp2;
-        if (li == 3) layer_norm(res, xb, par + ENCW_P_FN, true);   // the encoder's final LayerNorm (xb: its bf16 operand rows)
+        if (li == 3) {
+          layer_norm(res, xb, par + ENCW_P_FN, true);   // the encoder's final LayerNorm (xb: its bf16 operand rows)
+          uint32_t ex = 0;                              // non-finite flag by bit pattern (common.h: exp_max)
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) { ex = exp_max(ex, res[nt][0]); ex = exp_max(ex, res[nt][1]); ex = exp_max(ex, res[nt][2]); ex = exp_max(ex, res[nt][3]); }
+          if (__builtin_amdgcn_ballot_w64(rok && nonfinite_exp(ex)) != 0ull && lane == 0 && p.nonfinite) atomicOr(p.nonfinite, 1);
+        }
         store_rows(res);
         if (li == 3 && p.DKV) {                                 // ---- the decoder's K | V^T fragments of its four layers from these rows
 #pragma unroll 1

@@ -66,7 +66,7 @@ struct RiftCtx {
   // policy head / loss / backward of step k (rift_forward_head, rift_loss_backward on another stream) read step k's activations while the
   // frozen trunk of step k + 1 already writes its own.
   char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
-  long long dry_key[10] = {}; size_t dry_need = 0;      // the arena size of the last sized forward and what it depended on
+  long long dry_key[11] = {}; size_t dry_need = 0;      // the arena size of the last sized forward and what it depended on
   char* arenas[RIFT_DEFER_SLOTS] = {}; size_t arena_caps[RIFT_DEFER_SLOTS] = {}; int parity = 0;     // (parity: the arena of the current forward)
   struct Head {   // what the policy head of a forward needs (pi_forward .. trajectory heads); kept per arena for the deferred form
     bool valid = false, fp32 = false, need_traj = false;
@@ -1217,7 +1217,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       w.w2 = (const unsigned short*)c->pw[p + ".mlp.fc2"].bf; w.b2 = c->pw[p + ".mlp.fc2"].bias;
       w.droppath = f.drop ? edpr[i] : 0.f;
     }
-    ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias");
+    ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias"); ep.nonfinite = c->nonfinite;
     RIFT_SET_DS(ep);
     if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
@@ -1234,7 +1234,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     EncWP eq; memset(&eq, 0, sizeof(eq));
     eq.X = X; eq.Y = ENC; eq.kpm = kpm; eq.bs = bs; eq.N = N; eq.seed = f.seed; eq.stream = f.next_stream(); f.stream_id += 8;
     eq.KVs = A_alloc<unsigned short>(c, (size_t)bs * 96 * 512);
-    eq.img = c->encw_img; eq.par = c->encw_par;
+    eq.img = c->encw_img; eq.par = c->encw_par; eq.nonfinite = c->nonfinite;
     if (c->dec_fused && R <= 16) { enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * 96 * 512); eq.DKV = enc_KT; }   // the decoder's (dense-variant) operands
     for (int i = 0; i < 4; ++i) eq.droppath[i] = f.drop ? edpr[i] : 0.f;
     RIFT_SET_DS(eq);
@@ -1316,7 +1316,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     DecWP dq; memset(&dq, 0, sizeof(dq));
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
     dq.stream = f.next_stream(); f.stream_id += 64;
-    dq.KV = enc_KT; dq.img = c->decw_img; dq.par = c->decw_par;
+    dq.KV = enc_KT; dq.img = c->decw_img; dq.par = c->decw_par; dq.nonfinite = c->nonfinite;
     RIFT_SET_DS(dq);
     if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
     { const char* ev = getenv("RIFT_DEC_DBG"); dq.dbg = ev ? atoi(ev) : 0; }
@@ -1512,6 +1512,7 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
   HIPCHK(c, hipSetDevice(c->device));
   for (void* p : c->owned) (void)hipFree(p);
   c->owned.clear(); c->pw.clear(); c->params.clear(); c->wconst.clear();
+  c->dry_need = 0;                      // (the first forward on new weights sizes its arena again: it also computes the weight-only products)
   for (int i = 0; i < n; ++i) {
     Param p; p.data = params[i].data; p.numel = params[i].numel; p.ndim = params[i].ndim;
     for (int d = 0; d < 4; ++d) p.shape[d] = params[i].shape[d];
@@ -1747,7 +1748,10 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // descriptor only: a forward like the previous one skips pass 1 (it is half of the call's host time, which bounds a small-batch step)
   long long omask = 0;      // which outputs are wanted
   { const void* const* op = reinterpret_cast<const void* const*>(out); for (size_t i = 0; i < sizeof(RiftOutputs) / sizeof(void*); ++i) omask |= (long long)(op[i] != nullptr) << i; }
-  const long long dkey[10] = {B->bs, B->A, B->Mp, B->R, B->S, B->T, flags, c->dp.on ? 1 : 0, c->dp.on ? c->dp.gbs : 0, omask};
+  // (everything forward_impl's A_alloc sequence depends on: batch dimensions, flags, the data-parallel descriptor, the wanted outputs and the
+  // profiler switch; the environment-driven diagnostic taps are read per call and allocate at most a few KB, which the 1/8 slack of the
+  // arena covers -- and the launch pass is checked against the capacity below)
+  const long long dkey[11] = {B->bs, B->A, B->Mp, B->R, B->S, B->T, flags, c->dp.on ? 1 : 0, c->dp.on ? c->dp.gbs : 0, omask, c->prof_on ? 1 : 0};
   int rc = RIFT_OK;
   if (c->dry_need == 0 || memcmp(dkey, c->dry_key, sizeof(dkey)) != 0) {
     c->dry = true; c->arena_off = 0; c->dry_need = 0;
@@ -1776,6 +1780,12 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   c->stream = (hipStream_t)stream;
   if (rc != RIFT_OK) return rc;
   if (!c->err.empty()) return RIFT_ERR_ARG;
+  if (c->arena_off > c->arena_cap) {     // the launch pass allocated more than the sizing pass it was matched with: kernels were given scratch beyond the arena
+    c->dry_need = 0;
+    c->err = "activation arena overrun: the forward allocated " + std::to_string(c->arena_off) + " B of a " + std::to_string(c->arena_cap) + " B arena (stale sizing pass)";
+    (void)hipDeviceSynchronize();
+    return RIFT_ERR_STATE;
+  }
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }
@@ -2065,6 +2075,7 @@ int rift_critic_finalize(RiftCtx* c, const float* flat, const double* stats, flo
 int rift_prof_enable(RiftCtx* c, int on) {
   if (!c) return RIFT_ERR_ARG;
   c->prof_on = on != 0;
+  c->dry_need = 0;                      // the next forward sizes its arena again
   const char* ev = getenv("RIFT_PROF_SHAPES");
   c->prof_shapes = ev && ev[0] == '1';
   if (on) { c->prof_recs.clear(); c->prof_used = 0; }

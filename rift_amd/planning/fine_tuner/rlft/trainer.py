@@ -165,6 +165,8 @@ class RLFTTrainer:
         self.scheduler = WarmupCosLR(self.optimizer, lr=lr, min_lr=lr * cl_lr_decay, warmup_epochs=warmup_epochs,
                                      epochs=epochs)
         self.engine = model.engine()
+        if hasattr(model, "_engine_users"):
+            model._engine_users.add(self)          # (PlanningModel.engine() refuses to swap the context under a live trainer)
         dev = self.engine.device
         head = dict(model.named_modules())[PI_HEAD]
         self.params = {k: dict(head.named_parameters())[k] for k in PI_KEYS}
@@ -322,11 +324,17 @@ class RLFTTrainer:
         if self.dp_buf is not None:
             self.engine.clear_dp()
             self.dp_buf = None
+        if hasattr(self.model, "_engine_users"):
+            self.model._engine_users.discard(self)
 
     def forward_loss(self, *args, **kwargs):
         """forward + objective (+ pi_head backward into .grad) on the current stream.  Returns the device f64 loss scalar.  With `clip_val`
         (and no critic, i.e. pi_head is the only trainable module) the gradient-norm clip rides in the finalize launch."""
         self._flush_tail()                   # (a data-parallel tail still held back names its forward relative to the latest one)
+        if self.pipeline:
+            # a whole step on the caller's stream runs in activation arena 0 and rewrites the shared (bs, R) output buffers: tails of earlier
+            # pipelined steps still running on the update stream read both -- wait for them (an event wait, free when nothing is in flight)
+            torch.cuda.current_stream().wait_event(self._ev_param)
         try:
             return self._forward_loss(*args, **kwargs)
         finally:
@@ -473,6 +481,11 @@ class RLFTTrainer:
             if self._slot_prefetch:
                 self.engine.set_prepare_stream(self.prefetch_stream)
             main = torch.cuda.current_stream()
+            late = self.exchange is not None and (self.world > 1 or self.force_exchange) and self._slot_prefetch
+            if not late:
+                # a tail held back by an earlier late-path step names its forward relative to the LATEST one: it has to be issued before this
+                # step's trunk, or its head would pick up this step's forward (a caller alternating gather() with next_slot(prefetch=False))
+                self._flush_tail()
             try:
                 with _ffi.known_stream(main):
                     self.forward_trunk(fb, shard)
@@ -498,7 +511,7 @@ class RLFTTrainer:
                     self._ev_param.record(self._side)
                     self._ev_tail[slot].record(self._side)
 
-            if self.exchange is not None and (self.world > 1 or self.force_exchange) and self._slot_prefetch:
+            if late:
                 # data parallel: the tail is ISSUED one step late -- behind the next step's forward.  The all-reduces of a process group
                 # execute in the order they are issued; with the tail issued at once, the BatchNorm exchanges of step k + 1 (early in its
                 # front) would sit behind the loss exchange of step k, i.e. behind all of step k, and the fronts could not run ahead

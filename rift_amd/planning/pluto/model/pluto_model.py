@@ -9,6 +9,7 @@ grouping by module type (rift_trainer.py:279-362) behave exactly as in the refer
 None of their ``forward`` methods is ever called; there is no CPU fallback.
 """
 import math
+import weakref
 from typing import Dict
 
 import torch
@@ -240,9 +241,11 @@ class PlanningModel(TorchModuleWrapper):
 
         self._engine = None
         self._bound_version = None
-        # "bf16" (bf16 MFMA operands, fp32 accumulate: the benchmarked default) | "fp16" (fp16 operands: same rate, 8x finer rounding --
-        # the mode that holds the 1e-4 loss tolerance on small batches) | "fp32" (exact fp32 MFMA, layer by layer: the reference's precision)
-        self.compute_precision = "bf16"
+        self._engine_users = weakref.WeakSet()     # live RLFTTrainers that hold self._engine (they register / unregister themselves)
+        # "fp16" (fp16 MFMA operands, fp32 accumulate: the default -- the 16-bit mode that holds north_star's 1e-4 on the losses, at the
+        # bf16 step time) | "bf16" (bf16 operands: what BASELINE.json names and bench.py's headline runs; RIFT loss within 1e-4 at the
+        # benchmark batch only, tests/test_gpu_parity.py header) | "fp32" (exact fp32 MFMA, layer by layer: the reference's `precision: 32`)
+        self.compute_precision = "fp16"
         self.need_traj = True                # trajectory heads are dead work for the RLFT losses; trainers switch it off
         self._seed = 0
 
@@ -282,6 +285,9 @@ class PlanningModel(TorchModuleWrapper):
         operands = "fp16" if self.compute_precision == "fp16" else "bf16"
         if self._engine is None or self._engine.device != dev or (self._engine.operands != operands and self.compute_precision != "fp32"):
             if self._engine is not None:
+                if len(self._engine_users):
+                    raise RuntimeError("compute_precision / device changed while an RLFTTrainer holds this model's engine: close() the trainer "
+                                       "first (its context, data-parallel hooks and parameter event would be left on a destroyed context)")
                 self._engine.close()
             self._engine = _ffi.Engine(dev, operands=operands)
             self._bound_version = None

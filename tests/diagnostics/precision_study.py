@@ -21,7 +21,12 @@ from rift_amd import synthetic as syn
 from tests import helpers as H
 
 
+RANGE = None        # {region: max |operand|} when set to a dict: every contraction operand that passes rnd() is recorded (operand_range())
+
+
 def rnd(x, fmt):
+    if RANGE is not None and x.numel():
+        RANGE[Ctl.region] = max(RANGE.get(Ctl.region, 0.0), float(x.detach().abs().max()))
     if "/" in fmt:
         fmt = fmt.split("/")[0]
     if fmt == "fp32":
@@ -129,6 +134,7 @@ _orig = {}
 
 
 def install():
+    _orig["mha"], _orig["na1d"], _orig["planning_decoder"] = pluto_ref.mha, pluto_ref.neighborhood_attention_1d, pluto_ref.planning_decoder
     pluto_ref.F = FProxy()
     pluto_ref.mha = mha_r
     pluto_ref.neighborhood_attention_1d = na1d_r
@@ -154,6 +160,37 @@ def run(sd, batch, fmt, default="fp32"):
     data = batch["cur_pluto_feature_torch"]
     out, _, taps = pluto_ref.planning_model_forward(sd, H.clone_tree(data), train_bn=True, need_traj=False, want_taps=True)
     return out["probability"], taps["q_final"]
+
+
+def operand_range(sd, batch, train_bn=False):
+    """max |operand| of every contraction of the oracle forward (both operands of every F.linear / F.conv1d, the attention q / k / v and
+    probabilities), per region of the model -- what the 16-bit kernels convert to their MFMA operand format.  Installs the hooks on first use."""
+    global RANGE
+    if "decoder_layer" not in _orig:
+        install()
+    RANGE = {}
+    try:
+        out = run(sd, batch, {}, "fp32") if train_bn else None
+        if out is None:
+            Ctl.fmt, Ctl.default = {}, "fp32"
+            out_d, _, taps = pluto_ref.planning_model_forward(sd, H.clone_tree(batch["cur_pluto_feature_torch"]), need_traj=True, want_taps=True)
+            out = (out_d["probability"], taps["q_final"])
+        return dict(RANGE), out
+    finally:
+        RANGE = None
+
+
+def uninstall():
+    """Put the oracle's own functions back (tests that share a process with other oracle users)."""
+    if "decoder_layer" not in _orig:
+        return
+    import torch.nn.functional as F_
+    pluto_ref.F = F_
+    pluto_ref.mha, pluto_ref.neighborhood_attention_1d = _orig.pop("mha"), _orig.pop("na1d")
+    pluto_ref.planning_decoder = _orig.pop("planning_decoder")
+    for name, fn in list(_orig.items()):
+        setattr(pluto_ref, name, fn)
+    _orig.clear()
 
 
 def loss_grads(sd, qf, batch, r_pad):

@@ -45,6 +45,34 @@ def load_case(case):
     return gold, batch, sd
 
 
+def carla_magnitude_batch(n=3, seed0=8800, A=49, Mp=40):
+    """Scenes at the magnitudes a CARLA rollout produces BEFORE PlutoFeature.normalize's map crop (the range study of the fp16 operand
+    format): agent and map coordinates out to +-500 m (the generator's N(0, 30^2) / N(0, 40^2) m stretched and clipped), speeds up to
+    40 m/s, speed limits U(0, 40), reference lines running 0.5 - 4 m per point (up to ~480 m), shapes of rift_pluto.yaml:35-36 (49 agents)."""
+    scenes = []
+    for i in range(n):
+        s = syn.make_scene(seed0 + i, A, Mp, 1, 6)
+        f = s["feature"]
+        g = torch.Generator().manual_seed(seed0 + 100 + i)
+        ag, mp, rl = f["agent"], f["map"], f["reference_line"]
+        ag["position"] = (ag["position"] * (500.0 / 90.0)).clamp(-500, 500)
+        ag["position"][0] -= ag["position"][0, -1:].clone()                          # the CBV itself stays at the origin of its frame
+        sp = ag["velocity"].norm(dim=-1, keepdim=True).clamp_min(1e-3)
+        ag["velocity"] = ag["velocity"] / sp * (sp * (40.0 / 15.0)).clamp(max=40.0)
+        shift = mp["polygon_center"][:, None, None, :2] * (500.0 / 120.0 - 1.0)
+        mp["point_position"] = (mp["point_position"] + shift).clamp(-500, 500)
+        mp["polygon_center"][:, :2] = (mp["polygon_center"][:, :2] * (500.0 / 120.0)).clamp(-500, 500)
+        mp["polygon_speed_limit"] = torch.rand(mp["polygon_speed_limit"].shape, generator=g) * 40.0
+        step = 0.5 + 3.5 * torch.rand(rl["position"].shape[0], 1, 1, generator=g)
+        rl["position"] = rl["position"] * step
+        rl["vector"] = rl["vector"] * step
+        f["current_state"][3:5] = torch.tensor([38.0, -3.0])                         # longitudinal / lateral speed of the CBV
+        scenes.append(s)
+    batch = syn.collate_scenes(scenes)
+    batch["advantage_torch"] = torch.randn(n, generator=torch.Generator().manual_seed(seed0))
+    return batch
+
+
 def clone_tree(d):
     return {k: clone_tree(v) if isinstance(v, dict) else (v.clone() if torch.is_tensor(v) else v)
             for k, v in d.items()}

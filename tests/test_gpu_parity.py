@@ -4,7 +4,8 @@ golden fixtures.  Needs a real MI355X: `pytest -m gpu`.
 Tolerances (written here, per the parity contract):
   fp32 mode  (v_mfma_f32_16x16x4_f32, exact fp32 fma chains): logits / activations 1e-4 abs, losses 1e-5,
              pi_head grads 1e-5 + 1e-4 rel; integer indices bit-exact.
-  bf16 mode  (v_mfma_f32_16x16x32_bf16, fp32 accumulate; the benchmarked precision).  Every MFMA operand of ~50 chained contractions
+  bf16 mode  (v_mfma_f32_16x16x32_bf16, fp32 accumulate; the precision BASELINE.json names and bench.py's headline runs; NOT the product
+             default since round 4 -- that is fp16, below).  Every MFMA operand of ~50 chained contractions
              is rounded to 8 mantissa bits, which puts ~1.5e-2 on the logits whatever the kernel does
              (tests/diagnostics/precision_study.py reproduces it on the CPU from operand rounding alone: bf16 2.3e-2 / 1.8e-2 on
              small / full, fp16 2.7e-3, three-pass bf16 3e-5).  Bars are ~2.5x what MI355X measures:
@@ -20,9 +21,12 @@ Tolerances (written here, per the parity contract):
                logits 2.5e-3 / 1.8e-3 (small / full), 4.1e-3 on the 256-scene batch                      bar 8e-3
                RIFT loss 4.5e-5 / 2.8e-5 / 8.2e-6 (small / full / 256 scenes)                           bar 1e-4 (north_star)
                GRPO / REINFORCE / PPO: 256 scenes 4.0e-5 / 2.3e-5 / 1.7e-5                              bar 1e-4
-                                       6-scene fixture 1.4e-4 / 1.4e-4 / 9.3e-5 (a 6-scene loss responds to 2e-3 of logit noise with
-                                       ~1e-4 whatever the kernel does; precision_study.py FP16=1 shows no region dominating)   bar 3.5e-4
-               pi_head gradient ||dg|| / ||g||: fixtures <= 1.1e-2, 256 scenes 0.6e-2 .. 4.5e-2 (piecewise objective: boundary flips)  bar 8e-2
+                                       6-scene fixture 1.4e-4 / 1.4e-4 / 9.3e-5                          bar 3.5e-4
+               over 8 seeded draws per fixture shape (round 4, FP16_DRAW_BARS below): RIFT 6.3e-5 (6 scenes) / 1.4e-4 (2 scenes: ABOVE
+               1e-4 on one draw of eight), GRPO / REINFORCE / PPO up to 3.5e-4 / 2.8e-4 / 1.1e-4 (6 scenes) and 3.9e-4 / 1.0e-3 /
+               8.7e-4 (2 scenes) -- a 2-6-scene loss answers 2e-3 of logit noise with 1e-4 .. 1e-3 whatever the kernel does
+               (precision_study.py FP16=1 shows no region dominating); every bar >= 1.5x its measured maximum
+               pi_head gradient ||dg|| / ||g||: fixtures <= 1.1e-2, 8 draws <= 0.143, 256 scenes 0.6e-2 .. 4.5e-2 (piecewise objective: boundary flips)
              A caller that needs 1e-4 on every objective of a 2-6-scene batch, or 1e-4-relative gradients, sets compute_precision = "fp32".
 """
 import os
@@ -164,7 +168,7 @@ def test_loss_kernels_bf16_trunk(ffi, kind, mode):
     # 1e-4 and 2e-3 across objectives AND across kernel variants with identical rounding points (measured on MI355X, old LDS-resident /
     # wave-private decoder kernel: rift 1.5e-4 / 4.3e-4, grpo 6.8e-4 / 4.8e-4, reinforce 8.8e-4 / 1.7e-3, ppo 1.9e-3 / 5.0e-4).
     # fp16: RIFT (the north-star objective) within north_star's 1e-4 (4.5e-5 measured); the other three 1.4e-4 / 1.4e-4 / 9.3e-5 on this
-    # 6-scene fixture -- 2.5e-3 of logit noise -- and <= 4e-5 at the benchmark batch (test_benchmark_batch_objectives_in_fp16).
+    # 6-scene fixture -- 2.5e-3 of logit noise -- and <= 4e-5 at the benchmark batch (test_benchmark_batch_objectives_in_16bit_modes).
     # fp32 mode meets 1e-5 (test_losses_and_pi_head_grads).
     if mode == "bf16":
         assert lerr < 3.5e-3
@@ -191,11 +195,23 @@ def test_rift_loss_of_the_full_fixture_in_fp16(ffi):
     eng.close()
 
 
-def test_benchmark_batch_objectives_in_fp16(ffi):
-    """fp16 mode at the BENCHMARKED batch (256 scenes, train-mode BatchNorm, drops disabled): all four objectives within north_star's
-    1e-4 of the CPU oracle end to end, and the pi_head gradient that drives AdamW within ||dg|| / ||g|| <= 8e-2 of the fp32 oracle's
-    (measured on MI355X: losses 8.2e-6 / 4.0e-5 / 2.3e-5 / 1.7e-5, gradients 4.5e-2 / 3.0e-2 / 4.5e-2 / 5.9e-3 for
-    RIFT / GRPO / REINFORCE / PPO; bf16: 6.7e-5 / 3.4e-4 / 1.9e-4 / 3.1e-4 and 0.13 .. 0.24)."""
+# Bars of the four objectives at the BENCHMARKED batch, per 16-bit mode: (loss bar per objective, gradient bar).  fp16 holds north_star's
+# 1e-4 on all four; bf16 -- the mode BASELINE.json names and bench.py's headline runs -- holds it on the RIFT loss only: GRPO / REINFORCE /
+# PPO sit at 3.4e-4 / 1.9e-4 / 3.1e-4, OUTSIDE 1e-4 (their bars are 2.5x the measurement, not the contract), gradients 0.13 .. 0.24.
+BENCH_BATCH_BARS = {
+    "fp16": ({"rift": 1e-4, "grpo": 1e-4, "reinforce": 1e-4, "ppo": 1e-4}, 8e-2),
+    "bf16": ({"rift": 1e-4, "grpo": 8.5e-4, "reinforce": 5e-4, "ppo": 8e-4}, 0.45),
+}
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_benchmark_batch_objectives_in_16bit_modes(ffi, mode):
+    """The four objectives at the BENCHMARKED batch (256 scenes, train-mode BatchNorm, drops disabled) against the CPU oracle end to end,
+    and the pi_head gradient that drives AdamW against the fp32 oracle's, in both 16-bit operand modes.
+    fp16 (the product default): all four losses within north_star's 1e-4 (measured on MI355X 8.2e-6 / 4.0e-5 / 2.3e-5 / 1.7e-5 for
+    RIFT / GRPO / REINFORCE / PPO), gradients ||dg|| / ||g|| 4.5e-2 / 3.0e-2 / 4.5e-2 / 5.9e-3.
+    bf16 (bench.py's headline, because BASELINE.json names it): RIFT 6.7e-5 -- inside 1e-4 --, GRPO / REINFORCE / PPO 3.4e-4 / 1.9e-4 /
+    3.1e-4 -- NOT inside 1e-4: this test holds them to 2.5x what is measured and says so --, gradients 0.13 .. 0.24."""
     sd = H.weights()
     batch = syn.collate_scenes([syn.make_scene(1000 + i) for i in range(256)])
     batch["advantage_torch"] = torch.randn(256, generator=torch.Generator().manual_seed(99))     # PPO's per-scene (normalised) GAE advantage
@@ -203,9 +219,10 @@ def test_benchmark_batch_objectives_in_fp16(ffi):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     _, _, taps = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=False, want_taps=True)
     r_pad = ~data["reference_line"]["valid_mask"].any(-1)
-    eng = _engine(ffi, "fp16")
+    eng = _engine(ffi, mode)
     eng.load_state_dict({k: v.clone() for k, v in sd.items()})
     eng.forward(data, train=True, no_drop=True, bn_update=False)
+    lbar, gbar = BENCH_BATCH_BARS[mode]
     for kind in ("rift", "grpo", "reinforce", "ppo"):
         lo, go, _ = losses.pi_head_loss_and_grads(sd, taps["q_final"], kind, H.clone_tree(batch), r_pad)
         stats, flat, _ = eng.loss_backward(kind, H.clone_tree(batch))
@@ -213,9 +230,150 @@ def test_benchmark_batch_objectives_in_fp16(ffi):
         lh = float(eng.loss_finalize(stats, flat, grads).item())
         num = sum(float(((grads[k].cpu() - go[k]).double() ** 2).sum()) for k in go) ** 0.5
         den = sum(float((go[k].double() ** 2).sum()) for k in go) ** 0.5
-        print(f"fp16 vs fp32 oracle, 256 scenes, {kind}: loss err {abs(lh - float(lo)):.2e}, ||dg|| / ||g|| {num / den:.3e}")
-        assert abs(lh - float(lo)) < 1e-4, kind
-        assert num / den < 8e-2, kind
+        print(f"{mode} vs fp32 oracle, 256 scenes, {kind}: loss err {abs(lh - float(lo)):.2e} (bar {lbar[kind]:.1e}), ||dg|| / ||g|| {num / den:.3e} (bar {gbar})")
+        assert abs(lh - float(lo)) < lbar[kind], kind
+        assert num / den < gbar, kind
+    eng.close()
+
+
+# ---- fp16 bars with air: the worst case over seeded draws and kernel variants ---------------------------------------------------------
+# Round 3 held the fp16 bars on ONE draw of each fixture size, for ONE arithmetic order (30-step loss 8.7e-5 against 1e-4): any kernel
+# change that is not bit-identical re-rolled the noise.  Here every bar is evaluated as the MAXIMUM over 8 seeded draws of the 6-scene
+# and of the 2-scene fixture shapes and over the engine's variants with a different summation order (history encoder on all agent slots
+# instead of the ranked ones, RIFT_NAT_COMPACT=0; one stream, RIFT_TWO_STREAMS=0), and the bar sits at >= 1.5x that maximum
+# (tests/diagnostics/fp16_margin.py prints the table).  What the table says about north_star's 1e-4 on small batches is in FP16_DRAW_BARS.
+FP16_DRAWS = {"6-scene": [(list(range(2000 + 10 * d, 2006 + 10 * d)), 12, 8, 1, 4) for d in range(8)],
+              "2-scene": [([3000 + 10 * d, 3001 + 10 * d], 64, 20, 1, 6) for d in range(8)]}
+FP16_VARIANTS = ({}, {"RIFT_NAT_COMPACT": "0"}, {"RIFT_TWO_STREAMS": "0"})
+# Measured maxima on MI355X (fp16, 8 draws x 3 variants; the variants are bit-identical to the default in eval mode, so the spread is the
+# draws'), and the bars at >= 1.5x:
+#   6-scene: logits 3.1e-3, RIFT 6.3e-5, GRPO 3.5e-4, REINFORCE 2.8e-4, PPO 1.1e-4, RIFT gradient ||dg|| / ||g|| 0.143
+#   2-scene: logits 2.4e-3, RIFT 1.4e-4, GRPO 3.9e-4, REINFORCE 1.0e-3, PPO 8.7e-4, gradient 0.092
+# i.e. on 2 - 6-scene batches fp16 does NOT hold north_star's 1e-4 on every draw: the RIFT loss stays inside it on all eight 6-scene draws
+# (worst 6.3e-5) and on seven of eight 2-scene draws (worst 1.4e-4); GRPO / REINFORCE / PPO scatter between 1e-5 and 1e-3 (one or two
+# scenes' clip decisions carry the loss).  The 1e-4 claim is for the benchmark batch (test_benchmark_batch_objectives_in_16bit_modes: all
+# four objectives <= 4e-5 at 256 scenes); compute_precision = "fp32" is the mode that holds it on any batch.
+FP16_DRAW_BARS = {
+    "6-scene": {"logit": 5e-3, "rift": 1.0e-4, "grpo": 5.5e-4, "reinforce": 4.5e-4, "ppo": 1.8e-4, "grad": 0.22},
+    "2-scene": {"logit": 4e-3, "rift": 2.2e-4, "grpo": 6.0e-4, "reinforce": 1.6e-3, "ppo": 1.4e-3, "grad": 0.14},
+}
+
+
+def fp16_margin_table(ffi, mode="fp16", verbose=True):
+    """{shape: {metric: max over draws x variants}} of |HIP - fp32 oracle|: logits on valid lines, the four losses, RIFT gradient ||dg|| / ||g||."""
+    sd = H.weights()
+    table = {}
+    saved = {k: os.environ.get(k) for v in FP16_VARIANTS for k in v}
+    try:
+        for shape, draws in FP16_DRAWS.items():
+            worst = {}
+            for d, (idx, A, Mp, r0, r1) in enumerate(draws):
+                batch = syn.collate_scenes([syn.make_scene(i, A, Mp, r0, r1) for i in idx])
+                batch["advantage_torch"] = torch.randn(len(idx), generator=torch.Generator().manual_seed(700 + d))
+                data = batch["cur_pluto_feature_torch"]
+                ref, _, taps = pluto_ref.planning_model_forward(sd, H.clone_tree(data), want_taps=True)
+                rv = data["reference_line"]["valid_mask"].any(-1)
+                want = {k: losses.pi_head_loss_and_grads(sd, taps["q_final"], k, H.clone_tree(batch), ~rv) for k in ("rift", "grpo", "reinforce", "ppo")}
+                for var in FP16_VARIANTS:
+                    for k in saved:
+                        os.environ.pop(k, None)
+                    os.environ.update(var)
+                    eng = _engine(ffi, mode)
+                    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+                    out = eng.forward(data, need_traj=False)
+                    row = {"logit": err(out["probability"].cpu()[rv], ref["probability"][rv])}
+                    for kind, (lo, go, _) in want.items():
+                        stats, flat, _ = eng.loss_backward(kind, H.clone_tree(batch))
+                        grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
+                        row[kind] = abs(float(eng.loss_finalize(stats, flat, grads).item()) - float(lo))
+                        if kind == "rift":
+                            num = sum(float(((grads[k].cpu() - go[k]).double() ** 2).sum()) for k in go) ** 0.5
+                            row["grad"] = num / sum(float((go[k].double() ** 2).sum()) for k in go) ** 0.5
+                    eng.close()
+                    if verbose:
+                        print(f"  {mode} {shape} draw {d} {var or 'default'}: " + "  ".join(f"{k} {v:.2e}" for k, v in row.items()))
+                    for k, v in row.items():
+                        worst[k] = max(worst.get(k, 0.0), v)
+            table[shape] = worst
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    return table
+
+
+def test_fp16_bars_hold_with_margin_over_seeded_draws_and_kernel_variants(ffi):
+    table = fp16_margin_table(ffi, "fp16", verbose=False)
+    for shape, worst in table.items():
+        print(f"fp16 worst case over 8 draws x 3 variants, {shape}: " + "  ".join(f"{k} {v:.2e} (bar {FP16_DRAW_BARS[shape][k]:.1e})" for k, v in worst.items()))
+    for shape, worst in table.items():
+        for k, v in worst.items():
+            assert v < FP16_DRAW_BARS[shape][k], (shape, k, v)
+            assert v < FP16_DRAW_BARS[shape][k] / 1.5 + 1e-12, f"{shape} {k}: {v:.2e} is within 1.5x of its bar {FP16_DRAW_BARS[shape][k]:.1e} -- measure again and move the bar"
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_16bit_operands_stay_in_range_on_carla_magnitudes(ffi, mode):
+    """Range study of the 16-bit operand formats on the magnitudes `train_cbv` really feeds (H.carla_magnitude_batch: coordinates to
+    +-500 m before the map crop, 40 m/s, speed limits to 40, reference lines to ~480 m; 49 agents + 40 polygons = 89 tokens).
+    (1) The oracle, with a recorder on BOTH operands of every contraction (tests/diagnostics/precision_study.operand_range: every
+    F.linear / conv1d, attention q / k / v / probabilities, per region of the model): the largest value any 16-bit kernel ever converts is
+    the raw coordinate itself (500: Fourier x column, PointsEncoder features ~410 m); everything behind the first layer is O(10).  Bar:
+    0.25 x 65504 (the fp16 maximum) -- two binades of head room.  (2) The HIP engine in this mode on the same batch, eval and train
+    (BatchNorm batch statistics, no drops): every output finite, the non-finite flag -- now raised by the encoder and decoder kernels
+    themselves by exponent bit pattern as well as by the policy head -- stays down, logits within the mode's bar of the oracle."""
+    from tests.diagnostics import precision_study as PS
+    sd = H.weights()
+    batch = H.carla_magnitude_batch()
+    data = batch["cur_pluto_feature_torch"]
+    try:
+        rng, (prob_o, _) = PS.operand_range(sd, batch)
+    finally:
+        PS.uninstall()
+    print(f"max |operand| per region on CARLA magnitudes: " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(rng.items())))
+    assert max(rng.values()) < 0.25 * 65504 and all(np.isfinite(v) for v in rng.values())
+    assert max(v for k, v in rng.items() if k not in ("fourier", "pe", "ego", "dec_misc")) < 64      # behind the input layers: normalised activations
+    rv = data["reference_line"]["valid_mask"].any(-1)
+    eng = _engine(ffi, mode)
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    out = eng.forward(data, need_traj=True)
+    eng.check_finite()
+    for k, v in out.items():
+        sel = v.cpu()[rv] if k in ("probability", "trajectory") else v.cpu()
+        assert torch.isfinite(sel).all(), k
+    e = err(out["probability"].cpu()[rv], prob_o[rv])
+    print(f"{mode} on CARLA magnitudes: max |logit - oracle| = {e:.3e}")
+    assert e < {"fp16": 2.5e-2, "bf16": 1.5e-1}[mode]          # (coordinates of hundreds of metres cost 3 - 4 bits of the 11 / 8)
+    out_t = eng.forward(data, train=True, no_drop=True, bn_update=False)
+    eng.check_finite()
+    assert torch.isfinite(out_t["probability"].cpu()[rv]).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("site", ["encoder_blocks.3.mlp.fc2.bias", "planning_decoder.decoder_blocks.3.ffn.3.bias", "planning_decoder.decoder_blocks.0.norm1.bias"])
+def test_trunk_kernels_raise_the_non_finite_flag_themselves(ffi, mode, site):
+    """The reference asserts torch.isfinite(q).all() behind every decoder block (planning_decoder.py:175).  Rounds 1-3 raised the device
+    flag in the policy-head kernels only (a NaN / Inf in the residual stream reaches q_final); round 4 adds an exponent-bit-pattern test
+    -- integer compares, immune to the -fno-honor-nans build of those translation units -- where the rows leave the scene encoder and the
+    decoder.  Checked with the policy head NOT run (a deferred-head forward stops in front of it): the flag is up after the trunk alone."""
+    gold, batch, sd = H.load_case("small")
+    data = batch["cur_pluto_feature_torch"]
+    eng = _engine(ffi, mode)
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad[site][7] = float("inf") if "norm1" not in site else float("nan")
+    eng.load_state_dict(bad)
+    fb, keep = ffi.feature_batch(data, eng.device)
+    o = ffi.RiftOutputs()
+    prob = torch.empty(fb.bs, fb.R, 12, device=eng.device)
+    o.probability = prob.data_ptr()
+    eng.forward_raw(fb, o, ffi.F_TRAIN | ffi.F_NO_DROP | ffi.F_DEFER_HEAD | ffi.F_NO_BN_UPDATE, 1)      # trunk only: the policy head is not issued
+    with pytest.raises(RuntimeError, match="non-finite"):
+        eng.check_finite()
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    eng.forward_raw(fb, o, ffi.F_TRAIN | ffi.F_NO_DROP | ffi.F_DEFER_HEAD | ffi.F_NO_BN_UPDATE, 1)
+    eng.check_finite()
     eng.close()
 
 
