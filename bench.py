@@ -13,9 +13,11 @@ objective sum, valid count) make the sharded step equal the single-process step 
 Workload = BASELINE.json configs[2]/[3]: 4096-scene synthetic replay, 64 agents x 20 polygons x R~U{1..6}
 reference lines x 12 modes.
 
-Scaling.  The headline line is WEAK scaling (the replay is sharded, 256 scenes / GPU / step, global minibatch 256 N); with N > 1 the
-same run also times STRONG scaling -- the reference's 256-scene minibatch split over the ranks (32 scenes per GPU at
-N = 8) -- and reports it in the `strong` object (`--scaling strong` makes it the headline instead).
+Scaling.  With N > 1 the headline is STRONG scaling, the partition SURVEY.md 8(e) / north_star state: the reference's 256-scene minibatch
+(train_batch_size: 256, fine_tuner/rlft/config/datamodule/rift_datamodule.yaml:2) split contiguously over the ranks -- 256 / N scenes per GPU
+per step, global batch 256, the reference's 15 optimizer steps per epoch; every rank holds the whole replay.  The same run also times WEAK
+scaling (256 scenes per GPU per step, global minibatch 256 N, the replay sharded) and reports it in the `weak` object (`--scaling weak`
+makes it the headline instead).  The driver's per-N efficiency is therefore steps/s (N) / steps/s (1) on a FIXED 256-scene step.
 Precision.  The headline runs bf16 MFMA operands (BASELINE.json); at N = 1 the `precisions` object carries the same steps in fp16
 operands (same kernels built for v_mfma_f32_16x16x32_f16) and in exact fp32 (layer by layer, the reference's `precision: 32`).
 """
@@ -193,9 +195,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-precisions", action="store_true", help="skip the fp16 / fp32 companion legs (N = 1)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="which scaling mode is the headline with N > 1 (the other one is reported beside it). weak: 256 scenes per GPU per "
-                         "step (global minibatch 256 x N); strong: the reference's 256-scene minibatch split over the N GPUs (SURVEY.md 8(e))")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="which scaling mode is the headline with N > 1 (the other one is reported beside it). strong (default): the reference's "
+                         "256-scene minibatch split over the N GPUs (SURVEY.md 8(e)); weak: 256 scenes per GPU per step (global minibatch 256 x N)")
     ap.add_argument("--no-full-update", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip full_update_e2e (RIFTPluto.train() from a full CBVRolloutBuffer to the reloaded inference model)")
     ap.add_argument("--batch", type=int, default=256, help="scenes per minibatch (diagnostic: 32 = what one of 8 ranks runs under strong scaling)")
@@ -242,6 +244,9 @@ def main():
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
+        if dist.get_world_size() != world:
+            sys.stderr.write(f"bench.py: the process group has {dist.get_world_size()} ranks, WORLD_SIZE says {world}.\n")
+            sys.exit(2)
 
     from rift_amd import synthetic as syn
     from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
@@ -261,6 +266,7 @@ def main():
     if world > 1:
         replays["strong"] = DeviceReplay([scene_of[i] for i in range(args.replay)], dev, rcap=6)
     scenes = [scene_of[i] for i in ids_weak]
+    scenes_cpu = [scene_of[i] for i in sorted(scene_of)][:6 * BATCH]       # the CPU baseline's sample: whole 256-scene minibatches
     t_gen = time.perf_counter() - t_gen
 
     torch.manual_seed(20250515)   # identical random-init policy on every rank
@@ -397,6 +403,9 @@ def main():
                                           ": (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from separate rocprofv3 --pmc passes of this bench "
                                           "(tools/profile_round.sh); committed measurement, not collected in this run",
                         "avg_launch_us": dom[1]["ms"] * 1e3 / dom[1]["count"], "launches_per_step": dom[1]["count"] / nprof,
+                        "launch_mode": "per-kernel HIP-event times of a SERIAL-launch leg (the profiler puts the forward's chains on one stream and "
+                                       "this leg switches the deferred tail off): each kernel alone on the device; the timed region above runs "
+                                       "them overlapped (step pipeline), so its step time is below the sum of these",
                         "algorithmic_flops_per_launch": dom[1]["flops"] / dom[1]["count"],
                         "kernel_share_of_gpu_time": dom[1]["ms"] / tot_ms,
                         "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
@@ -471,7 +480,7 @@ def main():
         finally:
             shutil.rmtree(root, ignore_errors=True)
 
-    head_scaling = args.scaling if world > 1 else "weak"
+    head_scaling = args.scaling if world > 1 else "weak"      # (one GPU: the two coincide -- 256 scenes per step on the one rank)
     # the companion legs run first, the headline leg last, every leg built before the first one runs (see leg())
     def built(*a, **kw):
         g = leg(*a, **kw)
@@ -507,7 +516,9 @@ def main():
             "value": head["value"], "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "steps_per_sec": head["steps_per_sec"], "rccl_ranks": world if pg is not None else 0,
+            "steps_per_sec": head["steps_per_sec"],
+            "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 0,          # ranks of the process group the exchanges ran over
+            "collective_backend": (torch.distributed.get_backend() if pg is not None else None),
             "config": {"workload": "BASELINE configs[2]/[3]: full rift_pluto CBV policy, 4096-scene synthetic replay "
                                    "(64 agents x 21 steps, 20 polygons x 3 x 20 pts, R~U{1..6} x 120 ref pts, 12 modes), "
                                    "RIFT loss, pi_head trainable",
@@ -525,7 +536,7 @@ def main():
         if world > 1:
             for name, r in ((head_scaling, head), other):
                 line[name] = {k: r[k] for k in ("ms_per_step", "value", "steps_per_sec", "per_gpu_batch", "global_batch", "replay_scenes_per_gpu")}
-            line["strong"]["note"] = "SURVEY.md 8(e): the reference's 256-scene minibatch split contiguously over the ranks; steps/s is the reference's optimizer-step rate"
+            line["strong"]["note"] = "SURVEY.md 8(e): the reference's 256-scene minibatch split contiguously over the ranks (15 optimizer steps per epoch of the 4096-scene replay, as the reference); steps/s is the reference's optimizer-step rate"
             line["weak"]["note"] = "256 scenes per GPU per step: the reference's update with train_batch_size = 256 N (fewer, larger optimizer steps per epoch)"
         if "full_update" in head:
             line["full_update"] = head["full_update"]
@@ -535,8 +546,9 @@ def main():
             line["precisions"] = precisions
         if "roofline" in head:
             line["roofline"] = head["roofline"]
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scenes, sd_cpu)
+        if not args.no_cpu_baseline:
+            # (rank 0's host cores; the other ranks wait at the closing barrier.  A 256-scene CPU step whatever N is: the reference is single-device)
+            line["cpu_baseline"] = cpu_baseline(scenes_cpu, sd_cpu)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

@@ -252,4 +252,8 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 6
     for leg in ("weak", "strong"):
         assert line[leg]["ms_per_step"] > 0 and line[leg]["global_batch"] == (512 if leg == "weak" else 256)
-    assert line["value"] == pytest.approx(line["weak"]["value"])
+    # the headline is SURVEY.md 8(e)'s partition: the 256-scene minibatch split over the ranks (strong scaling), with the roofline and the
+    # CPU baseline in the line whatever N is
+    assert line["scaling"] == "strong" and line["value"] == pytest.approx(line["strong"]["value"])
+    assert line["config"]["global_batch"] == 256 and line["config"]["per_gpu_batch"] == 128
+    assert line["roofline"]["kernel"] and line["cpu_baseline"]["value"] > 0
