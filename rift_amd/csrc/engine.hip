@@ -94,7 +94,7 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
-  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true;
+  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true; bool pe_pack = true;
   hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = 0;      // rift_set_prepare_stream
   hipEvent_t ev_join2 = nullptr; bool nat_aside = true; int join_once = -1;      // (the history chain behind the preparation on the prepare stream: its join event)
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
@@ -437,6 +437,7 @@ struct Fwd {   // per-forward context
   uint32_t next_stream() { return stream_id++; }
   // data parallel (rift_set_dp): xchg[0, kb) = quirk-mask slots of the global minibatch, xchg[kb, ...) = BatchNorm sums of the current point
   bool dp = false, kpm_pending = false; int kb = 0; uint8_t* g_rkpm = nullptr;
+  uint8_t* r_tiles = nullptr;                        // tiles of every reference line up to its last valid point (prep_kernel), for pe_w_kernel's packed rounds
 };
 
 // All-reduce xchg[kb, kb + n) over the ranks (BatchNorm sums); the first exchange of a forward also carries the mask slots [0, kb)
@@ -578,6 +579,18 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
   const int nt = q.a.ntiles + q.b.ntiles;
   const double rows = (double)q.a.rows + q.b.rows, groups = (double)gm + gr;
   const bool stats_p = f.train && c->pe_w;          // persistent pass A: one partial per workgroup (pe_fused.h)
+  // reference lines packed at tile granularity (pe_fused.h: pe_pack_body): table + round count in device memory, built by one extra block
+  // of pass A's launch (eval mode: a launch of its own)
+  const bool packb = c->pe_w && c->pe_pack && gr > 0 && f.r_tiles != nullptr;
+  int* pk_tab = nullptr; int* pk_hdr = nullptr;
+  PePackP pk; memset(&pk, 0, sizeof(pk));
+  if (packb) {
+    const int maxr = cdiv(q.b.rows, PEW_ROUND_ROWS);
+    pk_tab = A_alloc<int>(c, (size_t)std::max(maxr, 1) * PEW_TAB_INTS); pk_hdr = A_alloc<int>(c, 4);
+    pk.tiles = f.r_tiles; pk.nlines = gr; pk.tab = pk_tab; pk.hdr = pk_hdr; pk.max_rounds = maxr;
+    tap(c, "pe_pack_hdr", (float*)pk_hdr, 4); tap(c, "pe_pack_tab", (float*)pk_tab, (int64_t)std::max(maxr, 1) * PEW_TAB_INTS);
+    if (!stats_p) { c->prof_flops = 0.0; launch(c, "pe_pack_lines_kernel", pe_pack_lines_kernel, dim3(1), dim3(256), (size_t)gr * 2 * sizeof(int), pk); }
+  }
   if (stats_p) {
     int g = std::min(nt, 4 * c->nat_grid);          // four 256-thread workgroups per CU
     int ga = (int)(((long long)g * q.a.ntiles + nt / 2) / nt);
@@ -589,7 +602,7 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
     PeP* sd[2] = {&q.a, &q.b};
     for (int i = 0; i < 2; ++i) { sd[i]->part1w = A_alloc<float>(c, (size_t)2 * 128 * std::max(sd[i]->nwg1, 1)); sd[i]->cnt1w = A_alloc<int>(c, std::max(sd[i]->nwg1, 1)); }
     c->prof_flops = 2.0 * 128.0 * (q.a.rows * 10.0 + q.b.rows * 6.0);
-    launch(c, "pe_stats1_kernel", pe_stats1p_kernel, dim3(q.a.nwg1 + q.b.nwg1), dim3(256), 0, q);
+    launch(c, "pe_stats1_kernel", pe_stats1p_kernel, dim3(q.a.nwg1 + q.b.nwg1 + (packb ? 1 : 0)), dim3(256), packb ? (size_t)gr * 2 * sizeof(int) : 0, q, pk);
   } else if (f.train) {
     c->prof_flops = 2.0 * 128.0 * (q.a.rows * 10.0 + q.b.rows * 6.0);
     launch(c, "pe_stats1_kernel", pe_stats1_kernel, dim3(nt), dim3(256), 0, q);
@@ -601,19 +614,22 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
   const bool live = stats_p && c->pe_live;
   int pew_grid = c->nat_grid, pew_ga = 0;
   if (c->pe_w) pew_split(cdiv(q.a.rows, PEW_ROUND_ROWS), cdiv(q.b.rows, PEW_ROUND_ROWS), &pew_grid, &pew_ga);
-  if (live) {
+  if (live || packb) {
     const PeP* sd[2] = {&q.a, &q.b};
     for (int i = 0; i < 2; ++i) {
-      lv.cnt[i] = sd[i]->cnt; lv.nt[i] = sd[i]->ntiles; lv.nr[i] = cdiv(sd[i]->rows, PEW_ROUND_ROWS);
+      lv.cnt[i] = live ? sd[i]->cnt : nullptr; lv.nt[i] = sd[i]->ntiles; lv.nr[i] = cdiv(sd[i]->rows, PEW_ROUND_ROWS);
       lv.live[i] = A_alloc<int>(c, std::max(lv.nr[i], 1));
     }
     lv.grid = pew_grid; lv.hdr = A_alloc<int>(c, 4);
+    lv.packed_b = pk_hdr;
+    tap(c, "pe_live_hdr", (float*)lv.hdr, 4);
   }
+  const bool lvblock = live || packb;       // the extra block of the BatchNorm-1 finalize launch
   for (int mode = dpx ? 1 : 0; mode <= (dpx ? 2 : 0); ++mode) {
     BnFinP f1a = bn_fin(c, q.a, pm + ".first_mlp.1", 128, q.a.part1, q.a.s1, q.a.t1, xs, mode);
     BnFinP f1b = bn_fin(c, q.b, pr + ".first_mlp.1", 128, q.b.part1, q.b.s1, q.b.t1, xs ? xs + 257 : nullptr, mode);
     if (stats_p) { f1a.part = q.a.part1w; f1a.cnt = q.a.cnt1w; f1a.nblk = q.a.nwg1; f1b.part = q.b.part1w; f1b.cnt = q.b.cnt1w; f1b.nblk = q.b.nwg1; }
-    const bool with_lv = live && mode == (dpx ? 2 : 0);
+    const bool with_lv = lvblock && mode == (dpx ? 2 : 0);
     PeLiveP none; memset(&none, 0, sizeof(none));
     launch(c, "bn_finalize_t_kernel", bn_finalize_t_kernel, dim3(256 + (with_lv ? 1 : 0)), dim3(256), 0, f1a, f1b, f.train ? 1 : 0, f.bn_update ? 1 : 0, 1e-5f,
            with_lv ? lv : none);
@@ -627,22 +643,23 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
     PeWSide* dst[2] = {&w.a, &w.b};
     const int npts[2] = {20, 120};
     const int grid = pew_grid, ga = pew_ga;
-    const int nwg[2] = {live ? grid : ga, live ? grid : grid - ga};       // (live: the split is made on the device; room for either extreme)
+    const int nwg[2] = {lvblock ? grid : ga, lvblock ? grid : grid - ga};       // (live / packed: the split is made on the device; room for either extreme)
     for (int i = 0; i < 2; ++i) {
       const PeP& o = *src[i]; PeWSide& d = *dst[i];
       d.F = o.F; d.Cin = o.Cin; d.valid = o.valid; d.rows = o.rows; d.npts = npts[i]; d.nrounds = cdiv(o.rows, PEW_ROUND_ROWS);
       d.img = c->pew_img[i]; d.w3b = o.w3b; d.b1 = o.b1; d.b2 = o.b2; d.b3 = o.b3; d.s1 = o.s1; d.t1 = o.t1;
-      d.live = live ? lv.live[i] : nullptr;
+      d.live = (live && !(i == 1 && packb)) ? lv.live[i] : nullptr;
+      if (i == 1) { d.ptab = pk_tab; d.phdr = pk_hdr; }
       d.part2 = A_alloc<float>(c, (size_t)2 * 256 * std::max(nwg[i], 1)); d.cnt2 = A_alloc<int>(c, std::max(nwg[i], 1));
       d.Fmid = o.Fmid;
     }
-    w.ga = ga; w.hdr = live ? lv.hdr : nullptr;
+    w.ga = ga; w.hdr = lvblock ? lv.hdr : nullptr;
     w.do_stats = f.train ? 1 : 0;
     { const char* ev = getenv("RIFT_PEW_DBG"); w.dbg = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("RIFT_PEW_TS"); if (ev && ev[0] == '1') { w.ts = A_alloc<long long>(c, 128); tap(c, "pew_ts", (float*)w.ts, 256); } }
     launch_call(c, "pe_w_kernel", [&] { pew_launch(w, grid, c->stream); });
-    fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, w.a.part2, q.a.s2, q.a.t2, xs, 0); fa.cnt = w.a.cnt2; fa.nblk = nwg[0]; fa.nblk_dev = live ? lv.hdr + 2 : nullptr;
-    fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, w.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0); fb.cnt = w.b.cnt2; fb.nblk = nwg[1]; fb.nblk_dev = live ? lv.hdr + 3 : nullptr;
+    fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, w.a.part2, q.a.s2, q.a.t2, xs, 0); fa.cnt = w.a.cnt2; fa.nblk = nwg[0]; fa.nblk_dev = lvblock ? lv.hdr + 2 : nullptr;
+    fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, w.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0); fb.cnt = w.b.cnt2; fb.nblk = nwg[1]; fb.nblk_dev = lvblock ? lv.hdr + 3 : nullptr;
   } else {
     launch(c, "pe_mid_kernel", pe_mid_kernel, dim3(nt), dim3(512), (size_t)PE_MID_LDS, q);
     fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, q.a.part2, q.a.s2, q.a.t2, xs, 0);
@@ -857,6 +874,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
   uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
   bool prefetched = false;
+  f.r_tiles = A_alloc<uint8_t>(c, (size_t)std::max(nL, 1));
   {
     PrepP q; memset(&q, 0, sizeof(q));
     q.agent_pos = B->agent_position; q.agent_head = B->agent_heading; q.agent_vel = B->agent_velocity; q.agent_shape = B->agent_shape;
@@ -864,7 +882,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     q.map_pp = B->map_point_position; q.map_pv = B->map_point_vector; q.map_po = B->map_point_orientation; q.map_center = B->map_polygon_center;
     q.nPoly = nP; q.F10 = F10;
     q.ref_pos = B->ref_position; q.ref_vec = B->ref_vector; q.ref_ori = B->ref_orientation; q.ref_valid = B->ref_valid_mask; q.nLine = nL;
-    q.F6 = F6; q.r_pos = r_pos; q.r_kpm = r_kpm;
+    q.F6 = F6; q.r_pos = r_pos; q.r_kpm = r_kpm; q.r_tiles = f.r_tiles;
     q.map_valid = B->map_valid_mask; q.static_valid = B->static_valid_mask; q.st_pos = B->static_position; q.st_head = B->static_heading;
     q.bs = bs; q.A = A; q.Mp = Mp; q.S = S; q.kpm = kpm; q.pos = pos;
     q.nb[0] = cdiv((long long)nA * 20, 256); q.nb[1] = cdiv((long long)nP * 20, 256); q.nb[2] = cdiv((long long)nL * 120, 256);
@@ -1459,6 +1477,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_MAIN"); if (ev) c->nat_on_main = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_NAT_COMPACT"); if (ev) c->nat_compact = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_PE_LIVE"); if (ev) c->pe_live = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_PE_PACK"); if (ev) c->pe_pack = atoi(ev) != 0; }      // (0: reference lines in rounds of two whole lines, the round-3 form)
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_JOIN_ONCE"); if (ev) c->join_once = atoi(ev); }

@@ -519,12 +519,15 @@ __global__ void token_mask_kernel(const uint8_t* __restrict__ valid_agent, const
 }
 
 // ref-line key padding: r_kpm[b*R + r] = !any(valid[b,r,:120])
-__device__ __forceinline__ void refline_mask_body(const uint8_t* __restrict__ rvalid, int nLine, uint8_t* __restrict__ r_kpm, const int vblk) {
+// (r_tiles, optional: the 16-row tiles of the line up to its LAST valid point, 0 .. 8 -- what pe_w_kernel's packed rounds hold of it, pe_fused.h)
+__device__ __forceinline__ void refline_mask_body(const uint8_t* __restrict__ rvalid, int nLine, uint8_t* __restrict__ r_kpm, const int vblk,
+                                                  uint8_t* __restrict__ r_tiles = nullptr) {
   const int l = vblk * (int)blockDim.x + (int)threadIdx.x;
   if (l >= nLine) return;
-  bool any = false;
-  for (int i = 0; i < 120; ++i) any |= (rvalid[(size_t)l * 120 + i] != 0);
-  r_kpm[l] = !any;
+  int last = -1;
+  for (int i = 0; i < 120; ++i) if (rvalid[(size_t)l * 120 + i] != 0) last = i;
+  r_kpm[l] = last < 0;
+  if (r_tiles) r_tiles[l] = (uint8_t)((last + 16) >> 4);
 }
 __global__ void refline_mask_kernel(const uint8_t* __restrict__ rvalid, int nLine, uint8_t* __restrict__ r_kpm) {
   refline_mask_body(rvalid, nLine, r_kpm, blockIdx.x);
@@ -704,7 +707,7 @@ struct PrepP {
   const float *agent_pos, *agent_head, *agent_vel, *agent_shape; const uint8_t* agent_valid; int nA, Tfull;
   float* F9; uint8_t* valid_agent; uint8_t* hist_agent;
   const float *map_pp, *map_pv, *map_po, *map_center; int nPoly; float* F10;
-  const float *ref_pos, *ref_vec, *ref_ori; const uint8_t* ref_valid; int nLine; float* F6; float* r_pos; uint8_t* r_kpm;
+  const float *ref_pos, *ref_vec, *ref_ori; const uint8_t* ref_valid; int nLine; float* F6; float* r_pos; uint8_t* r_kpm; uint8_t* r_tiles;
   const uint8_t *map_valid, *static_valid; const float *st_pos, *st_head; int bs, A, Mp, S; uint8_t* kpm; float* pos;
   int nb[7];
 };
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepP q) {
   blk -= q.nb[2];
   if (blk < q.nb[3]) { refline_pos_body(q.ref_pos, q.ref_ori, q.nLine, q.r_pos, blk); return; }
   blk -= q.nb[3];
-  if (blk < q.nb[4]) { refline_mask_body(q.ref_valid, q.nLine, q.r_kpm, blk); return; }
+  if (blk < q.nb[4]) { refline_mask_body(q.ref_valid, q.nLine, q.r_kpm, blk, q.r_tiles); return; }
   blk -= q.nb[4];
   if (blk < q.nb[5]) { token_mask_body(nullptr, q.map_valid, q.static_valid, q.bs, q.A, q.Mp, q.S, q.kpm, blk, q.agent_valid, q.Tfull); return; }
   blk -= q.nb[5];

@@ -40,6 +40,111 @@ struct PeP {
   int ts_tile;
 };
 
+// ---- reference lines packed at tile granularity (round 4) --------------------------------------------------------------------------------
+// pe_w_kernel used to walk the reference-line rows in rounds of two whole 120-point lines (240 rows = 15 tiles) whatever the lines' valid
+// lengths -- at the benchmark's ragged lines (valid prefix ~ U{30..120}) 7.5 tiles per line where ~5.2 hold a valid point.  Here every
+// line contributes only the 16-row tiles up to its LAST valid point, and a round is filled with whole lines (next-fit, in line order) up
+// to 16 tiles / 16 lines: 512 -> ~300 rounds at the benchmark.  A tile then belongs to ONE line (no segment boundary inside a tile), only a
+// line's eighth tile has rows that do not exist (points 120..127), and a line with dropped tiles takes 0 into its max as the reference's
+// zero rows of invalid points do (embedding.py:282-293: invalid points are zero rows of the max; a row past the last valid point is one).
+// Round record: 32 ints -- [T] (T < 16) tile descriptor (first point row of the tile << 8) | (tile index within its line << 4) | line slot of
+// the round, or -1; [16 + s] line slot s: first tile | last tile << 8 | (tiles dropped) << 16 | (exists) << 17.
+#define PEW_TAB_INTS 32
+struct PePackP {
+  const uint8_t* tiles; int nlines;     // (nlines) tiles of every line up to its last valid point (prep_kernel: refline_mask_body)
+  int* tab;                             // out: [max rounds][PEW_TAB_INTS]
+  int* hdr;                             // out: [0] packed rounds
+  int max_rounds;
+};
+// Packing = bounded-space first fit (three open rounds; a line goes into the first open round with room, else the oldest round is closed
+// and a new one opened): 16-tile rounds come out ~14.2 tiles full at the benchmark's lengths (plain next-fit: 13.6; ~330 rounds instead
+// of 512 two-line rounds).  It sits on the map chain, i.e. on the step's critical path, so it has to be short: the tiles per line come from
+// the preparation (prep_kernel reads the masks anyway), the line sequence is cut into up to 32 segments packed independently by 32 lanes
+// in lock step (one sequential loop over all 1536 lines: > 100 us; 8 segments: 80 us; the segment ends cost ~10 rounds), the segments'
+// rounds are numbered one after the other, and the whole thing runs in the extra block the BatchNorm-1 finalize launch already has for
+// rounds are numbered one after the other.  WHERE it runs decided whether it paid: as a launch of its own at the head of the map chain
+// (24 us of one workgroup) or as part of the BatchNorm-1 finalize launch (+15 us) it cost the step what the shorter pass B returned
+// (0.662 / 0.655 against 0.651 ms), behind the ranking on the prepare stream more (0.673: the history chain is the step's longest); as
+// one extra block of pass A's launch -- ~40 us of ~1000 blocks, the map chain's first big kernel -- it costs the chain nothing.
+// the BatchNorm layers of the two encoders (same position in their pipelines) in one launch: blocks [0, a.C) are a's channels
+// The rounds of pe_w_kernel (240 rows = two of pass A's 120-row tiles) that hold a valid point, per encoder, in ascending order, and the split
+// of pe_w_kernel's persistent workgroups over the two encoders in proportion to those counts: built by one extra block of the BatchNorm-1
+// finalize launch (it sits between pass A and pass B anyway).  A workgroup then walks list positions wg, wg + G, ...: every workgroup of an
+// encoder gets the same number of live rounds to within one.  (Before: the split went by ALL rounds and a workgroup skipped its empty ones,
+// so the reference-line workgroups -- a third of their rounds empty at the benchmark's ragged R -- finished at two thirds of the map
+// encoder's five rounds.)
+struct PeLiveP {
+  const int* cnt[2]; int nt[2];    // pass A's valid-point counts per 120-row tile
+  int nr[2];                       // rounds per encoder
+  int grid;                        // pe_w_kernel's workgroups
+  int* live[2];                    // out: live rounds
+  int* hdr;                        // out: n_live a, n_live b, workgroups of a, workgroups of b
+  const int* packed_b;             // if set: encoder b's rounds are PACKED (pe_pack_body): their number comes from here, no live list for b
+};
+
+#define PEW_PACK_SEGS 32
+// (runs as one extra block of pe_stats1p_kernel, or as pe_pack_lines_kernel in eval mode: 256 threads; `pk_lds`: 2 * nlines ints)
+__device__ __forceinline__ void pe_pack_body(const PePackP& q, int* __restrict__ pk_lds, int* __restrict__ seg_rounds /*[PEW_PACK_SEGS + 1]*/) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  int* const enc = pk_lds + q.nlines;   // (segment-local round << 16) | (tiles << 8) | (first tile << 4) | slot
+  for (int l = tid; l < q.nlines; l += NT) pk_lds[l] = q.tiles[l];
+  __syncthreads();
+  const int nseg = min(PEW_PACK_SEGS, max(1, q.nlines / 32));
+  const int per = (q.nlines + nseg - 1) / nseg;
+  if (tid < PEW_PACK_SEGS) {
+    int nround = 0;
+    if (tid < nseg) {
+      int bt0 = 0, bt1 = 0, bt2 = 0, bs0 = 0, bs1 = 0, bs2 = 0, br0 = 0, br1 = 0, br2 = 0, nopen = 0;
+      const int lbeg = tid * per, lend = min(q.nlines, lbeg + per);
+      for (int l = lbeg; l < lend; ++l) {
+        const int t = pk_lds[l];
+        if (t == 0) { enc[l] = -1; continue; }
+        bool f0 = nopen > 0 && bt0 + t <= 16 && bs0 < 16;
+        bool f1 = !f0 && nopen > 1 && bt1 + t <= 16 && bs1 < 16;
+        bool f2 = !f0 && !f1 && nopen > 2 && bt2 + t <= 16 && bs2 < 16;
+        if (!(f0 || f1 || f2)) {
+          if (nopen == 3) { bt0 = bt1; bs0 = bs1; br0 = br1; bt1 = bt2; bs1 = bs2; br1 = br2; nopen = 2; }
+          f0 = nopen == 0; f1 = nopen == 1; f2 = nopen == 2;
+          if (f0) { bt0 = 0; bs0 = 0; br0 = nround; }
+          if (f1) { bt1 = 0; bs1 = 0; br1 = nround; }
+          if (f2) { bt2 = 0; bs2 = 0; br2 = nround; }
+          ++nround; ++nopen;
+        }
+        const int bt = f0 ? bt0 : (f1 ? bt1 : bt2), bsl = f0 ? bs0 : (f1 ? bs1 : bs2), br = f0 ? br0 : (f1 ? br1 : br2);
+        enc[l] = (br << 16) | (t << 8) | (bt << 4) | bsl;
+        bt0 += f0 ? t : 0; bt1 += f1 ? t : 0; bt2 += f2 ? t : 0;
+        bs0 += f0 ? 1 : 0; bs1 += f1 ? 1 : 0; bs2 += f2 ? 1 : 0;
+      }
+    }
+    seg_rounds[tid + 1] = nround;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    seg_rounds[0] = 0;
+    for (int i = 1; i <= PEW_PACK_SEGS; ++i) seg_rounds[i] += seg_rounds[i - 1];
+    q.hdr[0] = seg_rounds[PEW_PACK_SEGS];
+  }
+  __syncthreads();
+  const int nr = seg_rounds[PEW_PACK_SEGS];
+  for (int i = tid; i < nr * PEW_TAB_INTS; i += NT) q.tab[i] = (i & 31) < 16 ? -1 : 0;      // unused tiles / line slots
+  __syncthreads();                       // (the same block writes the records below: ordered by the barrier)
+  for (int l = tid; l < q.nlines; l += NT) {
+    const int e = enc[l];
+    if (e < 0) continue;
+    const int round = (e >> 16) + seg_rounds[l / per], t = (e >> 8) & 0xff, t0 = (e >> 4) & 15, slot = e & 15;
+    int* rec = q.tab + (size_t)round * PEW_TAB_INTS;
+    for (int k = 0; k < t; ++k) rec[t0 + k] = ((l * 120 + 16 * k) << 8) | (k << 4) | slot;
+    rec[16 + slot] = t0 | ((t0 + t - 1) << 8) | ((t < 8 ? 1 : 0) << 16) | (1 << 17);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void pe_pack_lines_kernel(PePackP q) {      // (eval mode: no pass A to ride on)
+  extern __shared__ int pack_dyn[];
+  __shared__ int seg_rounds[PEW_PACK_SEGS + 1];
+  pe_pack_body(q, pack_dyn, seg_rounds);
+}
+
 template <int KS, int NTW>
 struct PFrags { h16x8 f[KS][NTW]; };
 
@@ -273,9 +378,18 @@ __device__ __forceinline__ void pe_stats1p_body(const PeP& p, const int wg, cons
   if (tid == 0) p.cnt1w[wg] = nvw;
 }
 
-__global__ __launch_bounds__(256) void pe_stats1p_kernel(PeP2 q) {
-  if ((int)blockIdx.x < q.a.nwg1) pe_stats1p_body(q.a, blockIdx.x, q.a.nwg1);
-  else pe_stats1p_body(q.b, blockIdx.x - q.a.nwg1, q.b.nwg1);
+__global__ __launch_bounds__(256) void pe_stats1p_kernel(PeP2 q, PePackP pk) {
+  // one extra block when pk is filled: the packed rounds of pass B.  It is block 0 -- dispatched first, so that its ~18 us run beside the
+  // other blocks' ~20 us (as the LAST block it started when the first of the resident ones had finished: pass A 25 -> 38 us)
+  const int blk = (int)blockIdx.x - (pk.tiles ? 1 : 0);
+  if (blk < 0) {
+    extern __shared__ int pack_dyn[];
+    __shared__ int seg_rounds[PEW_PACK_SEGS + 1];
+    pe_pack_body(pk, pack_dyn, seg_rounds);
+    return;
+  }
+  if (blk < q.a.nwg1) pe_stats1p_body(q.a, blk, q.a.nwg1);
+  else pe_stats1p_body(q.b, blk - q.a.nwg1, q.b.nwg1);
 }
 
 __global__ __launch_bounds__(256) void pe_stats1_kernel(PeP2 q) {
@@ -652,25 +766,14 @@ __device__ __forceinline__ void bn_finalize_t_body(const BnFinP& p, int train, i
   }
 }
 
-// the BatchNorm layers of the two encoders (same position in their pipelines) in one launch: blocks [0, a.C) are a's channels
-// The rounds of pe_w_kernel (240 rows = two of pass A's 120-row tiles) that hold a valid point, per encoder, in ascending order, and the split
-// of pe_w_kernel's persistent workgroups over the two encoders in proportion to those counts: built by one extra block of the BatchNorm-1
-// finalize launch (it sits between pass A and pass B anyway).  A workgroup then walks list positions wg, wg + G, ...: every workgroup of an
-// encoder gets the same number of live rounds to within one.  (Before: the split went by ALL rounds and a workgroup skipped its empty ones,
-// so the reference-line workgroups -- a third of their rounds empty at the benchmark's ragged R -- finished at two thirds of the map
-// encoder's five rounds.)
-struct PeLiveP {
-  const int* cnt[2]; int nt[2];    // pass A's valid-point counts per 120-row tile
-  int nr[2];                       // rounds per encoder
-  int grid;                        // pe_w_kernel's workgroups
-  int* live[2];                    // out: live rounds
-  int* hdr;                        // out: n_live a, n_live b, workgroups of a, workgroups of b
-};
+
 __device__ __forceinline__ void pe_live_body(const PeLiveP& q) {
   __shared__ int sc[256];
   __shared__ int tot[2];
   const int tid = threadIdx.x;
   for (int e = 0; e < 2; ++e) {
+    if (e == 1 && q.packed_b) { if (tid == 255) tot[1] = *q.packed_b; __syncthreads(); continue; }
+    if (!q.cnt[e]) { if (tid == 255) tot[e] = q.nr[e]; __syncthreads(); continue; }      // (eval mode: no pass A, every round of this encoder)
     const int R = q.nr[e], K = (R + 255) / 256, r0 = tid * K;
     auto is_live = [&](int r) { return r < R && (q.cnt[e][2 * r] + (2 * r + 1 < q.nt[e] ? q.cnt[e][2 * r + 1] : 0)) > 0; };
     int mine = 0;

@@ -36,6 +36,7 @@ struct PeWSide {
   const unsigned short* w3b;              // second_mlp.0 pool half, fragment-major bf16 image [256][256] (engine pack_cols)
   const float *b1, *b2, *b3, *s1, *t1;    // biases; BatchNorm-1 folded to y = x s1 + t1
   const int* live;                        // the rounds that hold a valid point, ascending (pe_fused.h: PeLiveP), or null: all nrounds rounds
+  const int* ptab; const int* phdr;       // (side b) the packed rounds of pe_pack_lines_kernel (pe_fused.h): records and their number; null: unpacked
   float* part2;                           // [2][256][nwg] sums of g, g^2 over the valid rows of a workgroup's rounds (nwg = its share of the grid)
   int* cnt2;                              // [nwg] valid rows of a workgroup's rounds
   unsigned short* Fmid;                   // (rows, 256) fp16 bits of g

@@ -115,8 +115,12 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
 #endif
 
   // this workgroup's rounds: positions wg, wg + G, ... of the live list (train mode) or of 0 .. R - 1
-  const int NL = s.live ? __builtin_amdgcn_readfirstlane(p.hdr[map20 ? 0 : 1]) : R;
-  auto round_at = [&](int pos) { return pos >= NL ? R : (s.live ? __builtin_amdgcn_readfirstlane(s.live[pos]) : pos); };
+  // (side b with packed rounds, pe_fused.h: pe_pack_lines_kernel -- round = record `pos` of the table, NL of them)
+  const bool packed = !map20 && s.ptab != nullptr;
+  const int NL = packed ? __builtin_amdgcn_readfirstlane(s.phdr[0]) : (s.live ? __builtin_amdgcn_readfirstlane(p.hdr[map20 ? 0 : 1]) : R);
+  auto round_at = [&](int pos) { return pos >= NL ? R : ((s.live && !packed) ? __builtin_amdgcn_readfirstlane(s.live[pos]) : pos); };
+  // tile descriptor of tile T of packed round ri: (first point row << 8) | (tile index within its line << 4) | line slot, or -1
+  auto tdesc = [&](int ri, int T) { return __builtin_amdgcn_readfirstlane(s.ptab[(size_t)ri * 32 + T]); };
   int li = wg;
   auto dma = [&](const unsigned char* src, uint32_t dst, int nfrag) {
     if (PWDBG(2)) return;                     // (diagnostic: no weight stream -- compute on whatever the ring holds)
@@ -139,9 +143,15 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     const int row0 = ri * PEW_ROUND_ROWS, nex = min(PEW_ROUND_ROWS, s.rows - row0);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int r = 32 * wv + 16 * mt + l15;
-      const bool ex = r < nex;
-      const int rr = min(row0 + r, s.rows - 1);                      // every lane loads (clamped address), then selects: no branch, no wait between the loads
+      int r = 32 * wv + 16 * mt + l15, rbase = row0;
+      bool ex = r < nex;
+      if (!map20 && packed) {                                        // this tile's sixteen rows: points 16 k .. of its line (the eighth tile ends at point 119)
+        const int d = tdesc(ri, 2 * wv + mt);
+        rbase = d >> 8; r = l15;
+        ex = d >= 0 && 16 * ((d >> 4) & 15) + l15 < 120;
+        if (d < 0) rbase = 0;
+      }
+      const int rr = min(rbase + r, s.rows - 1);                     // every lane loads (clamped address), then selects: no branch, no wait between the loads
       const unsigned v = s.valid[rr];
       float t[3];
 #pragma unroll
@@ -183,13 +193,13 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
   // g of a group leaves one boundary late (a store issued just ahead of a boundary would be waited for there: vmcnt counts stores too)
   uint32_t hold[2][8];
   bool hex[2] = {false, false};               // rows of the held tiles are valid points
-  int hrow0 = 0;
+  int hrow[2] = {0, 0};                       // first point row of the held tiles
   auto store_hold = [&](int q) {
     if (PWDBG(1)) return;                     // (diagnostic: no g stores)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       if (hex[mt]) {
-        unsigned short* dst = s.Fmid + (size_t)(hrow0 + 32 * wv + 16 * mt + l15) * 256 + 64 * q + 16 * l4;
+        unsigned short* dst = s.Fmid + (size_t)(hrow[mt] + l15) * 256 + 64 * q + 16 * l4;
         *reinterpret_cast<uint4*>(dst) = make_uint4(hold[mt][0], hold[mt][1], hold[mt][2], hold[mt][3]);
         *reinterpret_cast<uint4*>(dst + 8) = make_uint4(hold[mt][4], hold[mt][5], hold[mt][6], hold[mt][7]);
       }
@@ -208,12 +218,14 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     const int nex = min(PEW_ROUND_ROWS, s.rows - row0);            // rows of the round that exist
     // row flags: 0 = no such row, 1 = valid point, 2 = invalid point (a zero row that takes part in the max)
     int fl[2], poly[2];
+    int td[2] = {-1, -1};                      // (packed) descriptors of this wave's two tiles
     float okf[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       fl[mt] = vb[mt] == 0xffu ? 0 : (vb[mt] ? 1 : 2);
       okf[mt] = fl[mt] == 1 ? 1.0f : 0.0f;
       poly[mt] = pdiv(32 * wv + 16 * mt + l15);
+      if (!map20 && packed) { td[mt] = tdesc(ri, 2 * wv + mt); poly[mt] = td[mt] & 15; }
     }
     const bool wact = __builtin_amdgcn_ballot_w64(fl[0] == 1 || fl[1] == 1) != 0;        // a valid point among this wave's 32 rows
     const int nval = __builtin_popcountll(__builtin_amdgcn_ballot_w64(fl[0] == 1 && l4 == 0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(fl[1] == 1 && l4 == 0));
@@ -242,7 +254,17 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       for (int u = 0; u < 2; ++u) {                                // wave wv: polylines 2 wv, 2 wv + 1 (uniform tile loop); a lane: channel pairs lane, lane + 64
         const int pl = 2 * wv + u;
         float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
-        if (pl < npoly) {
+        if (!map20 && packed) {                                     // line slot pl of the packed round: tiles t0 .. t1, each wholly this line's
+          const int li = __builtin_amdgcn_readfirstlane(s.ptab[(size_t)ri * 32 + 16 + pl]);
+          if (li & (1 << 17)) {
+            a0 = b0 = a1 = b1 = (li & (1 << 16)) ? 0.f : -INFINITY;   // dropped tiles = zero rows of invalid points in the reference's max
+            for (int T = li & 0xff; T <= ((li >> 8) & 0xff); ++T) {
+              const uint32_t* src = pmax + (T * 2) * 128;
+              const uint32_t w0 = src[lane], w1 = src[lane + 64];
+              a0 = fmaxf(a0, h_lo(w0)); b0 = fmaxf(b0, h_hi(w0)); a1 = fmaxf(a1, h_lo(w1)); b1 = fmaxf(b1, h_hi(w1));
+            }
+          }
+        } else if (pl < npoly) {
           a0 = b0 = a1 = b1 = -INFINITY;
           const int r0 = pl * NPTS, T1 = (r0 + NPTS - 1) >> 4;
           for (int T = r0 >> 4; T <= T1; ++T) {                    // a tile that starts ahead of the polyline holds it as its second segment
@@ -273,8 +295,10 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
     };
     // rows [0, B) of a tile belong to its first polyline, rows [B, 16) to the next one, B in {4, 8, 12, 16} (rows that do not exist only
     // ever fall into polylines that do not exist: a round ends on a polyline boundary): maxima of the four 4-row blocks, combined per segment
-    auto tile_max = [&](int T, int h) {
-      const int B = min(16, (pdiv(16 * T) + 1) * NPTS - 16 * T);
+    auto tile_max = [&](int T, int h, int d) {
+      // (packed: the whole tile is ONE line's -- B = its existing rows: 8 in a line's eighth tile (points 112..119), else 16; blocks past B
+      // fall into the unused second segment)
+      const int B = (!map20 && packed) ? (((d >> 4) & 15) == 7 ? 8 : 16) : min(16, (pdiv(16 * T) + 1) * NPTS - 16 * T);
       uint32_t w[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) w[r] = *reinterpret_cast<const uint32_t*>(scr + r * TRS + lane * 4);
@@ -364,7 +388,7 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
           for (int q = 0; q < 4; ++q)          // n-tiles 2 q (elements 0..3) and 2 q + 1 (elements 4..7) of this half, row l15
             *reinterpret_cast<h16x8*>(scr + l15 * TRS + q * 64 + l4 * 16) = fb[mt][4 * h + q];
           // rows in-lane: lane t owns two channels of the 16 rows just written (same wave: LDS operations stay in order)
-          tile_max(2 * wv + mt, h);
+          tile_max(2 * wv + mt, h, td[mt]);
         }
         ++gc;
       }
@@ -376,7 +400,12 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
       for (int q = 0; q < 4; ++q) {
         // (the held stores go out AHEAD of the request: behind it they queue in the texture path after the group's 32 requests)
         boundary(3 + q, [&] { if (q == 1 && nri < R) { to_operand(nxv, xb); vb[0] = nvb[0]; vb[1] = nvb[1]; } if (q > 0) store_hold(q - 1); });
-        if (q == 0) { hex[0] = fl[0] == 1; hex[1] = fl[1] == 1; hrow0 = row0; pooled_gp(wb); }      // (g of an invalid point is never read: pass C masks the row)
+        if (q == 0) {                                          // (g of an invalid point is never read: pass C masks the row)
+          hex[0] = fl[0] == 1; hex[1] = fl[1] == 1;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) hrow[mt] = (!map20 && packed) ? (td[mt] >> 8) : row0 + 32 * wv + 16 * mt;
+          pooled_gp(wb);
+        }
         if (q == 0 && nri < R) load_rows(nri, nvb, nxv);      // the next round's rows: in flight under this group
         f32x4 c0[4], c1[4];
 #pragma unroll
@@ -433,7 +462,8 @@ __device__ __forceinline__ void pe_w_body(const PeWSide& s0, const PeWP& p, cons
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int T = 2 * wv + mt;
-        const int ext = max(0, min(16, nex - 16 * T)), B = min(16, (pdiv(16 * T) + 1) * NPTS - 16 * T);
+        int ext = max(0, min(16, nex - 16 * T)), B = min(16, (pdiv(16 * T) + 1) * NPTS - 16 * T);
+        if (!map20 && packed) { ext = td[mt] >= 0 ? 16 : 0; B = 16; }     // a tile in use whose points are all invalid: zero rows; an unused tile: no line reads it
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           pmax[(T * 2 + 0) * 128 + 64 * u + lane] = ext > 0 ? 0u : RIFT_H_NEG_INF2;
