@@ -113,8 +113,13 @@ def test_sharded_step_equals_single_process_step(precision, sizes, dense):
     # operand rounding (2^-9 relative on one activation), measured 3.7e-5 on this 12-scene loss -- and a logit that moves by that much can
     # carry one of the ~500 candidates across a clip boundary of the piecewise RIFT objective, which switches its whole gradient
     # contribution (measured 9.5 % of the largest gradient entry).  Hence two bars; the aligned split stays bit-identical in both modes.
+    # (Round 4: the reference-line rounds of pe_w_kernel are PACKED from the lines' valid-prefix tiles, so which lines share a round -- and
+    # with it the grouping of the BatchNorm-2 partial sums -- depends on the batch a rank holds: no split of a 16-bit-operand step is
+    # bit-identical to the single-process step any more, every one is "equal up to the fp32 summation order of the statistics", as the
+    # unaligned splits -- among them 256 scenes over 8 ranks, 32 x 20 polygons = 53.3 rounds -- always were.  RIFT_PE_PACK=0 restores the
+    # bit-identical aligned split.)
     n_poly = 40 if dense else 20
-    aligned = all((sum(sizes[:r]) * n_poly) % 12 == 0 for r in range(world))     # shards start on a PointsEncoder round (12 polygons of 20 points)
+    aligned = os.environ.get("RIFT_PE_PACK") == "0" and all((sum(sizes[:r]) * n_poly) % 12 == 0 for r in range(world))     # shards start on a PointsEncoder round (12 polygons of 20 points)
     tol, gtol = (1e-6, 1e-4) if (precision == "fp32" or aligned) else (2e-4, 0.25)
     for r, tr in enumerate(ranks):
         assert abs(float(tr.loss.item()) - want_loss) < tol, (r, float(tr.loss.item()), want_loss)
