@@ -26,6 +26,10 @@ struct EncBlockW {
 
 struct EncFusedP {
   const float* X;               // (bs*N, 128) tokens + positional embedding
+  // (round 4, RIFT_TOKEN_FUSED=1; measured slower, off by default -- engine.hip) or: the token assembly itself -- with tok_on the kernel
+  // builds its scene's token rows in its prologue from what token_kernel reads (kernels.h: agent_token_value / polygon_token_value, the
+  // same arithmetic); Xout (diagnostic, RIFT_KEEP_TOKENS=1): the rows are also written out
+  TokenP tok; int tok_on; float* Xout;
   float* Y;                     // (bs*N, 128) encoder output after the final LayerNorm
   const uint8_t* kpm;           // (bs*N) key padding mask (1 = padded)
   int bs, N;
@@ -157,7 +161,15 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
   for (int i = tid; i < ROWS * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < N) v = *reinterpret_cast<const float4*>(p.X + (grow0 + r) * C + c4);
+    if (r < N) {
+      if (p.tok_on) {
+        const TokenP& t = p.tok;
+        v = r < t.A ? agent_token_value(b, r, c4, t.nat, t.x_ego, t.valid_agent, t.category, t.a_type_emb, t.A, t.N, t.pe)
+                    : polygon_token_value(b, r - t.A, c4, t.pooled, t.ptype, t.on_route, t.tl, t.has_sl, t.speed_emb, t.p_type_emb, t.route_emb, t.tl_emb, t.unk_emb,
+                                          t.A, t.Mp, t.N, t.pe);
+        if (p.Xout) *reinterpret_cast<float4*>(p.Xout + (grow0 + r) * C + c4) = v;
+      } else v = *reinterpret_cast<const float4*>(p.X + (grow0 + r) * C + c4);
+    }
     *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
   }
   for (int i = tid; i < ROWS; i += NTH) smaskf[i] = ((i >= N) || p.kpm[grow0 + i]) ? -INFINITY : 0.f;

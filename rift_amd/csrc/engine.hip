@@ -94,7 +94,7 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
-  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true; bool pe_pack = true;
+  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true; bool pe_pack = true; bool tok_fused = false; bool keep_tokens = false;
   hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = 0;      // rift_set_prepare_stream
   hipEvent_t ev_join2 = nullptr; bool nat_aside = true; int join_once = -1;      // (the history chain behind the preparation on the prepare stream: its join event)
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
@@ -1198,15 +1198,19 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (forked && (c->nat_on_main || nat_aside)) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); c->stream = main_stream; }
   if (forked) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
   if (nat_aside && !join_once) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join2, 0));
+  // token assembly: fused into the scene encoder's prologue where that kernel runs (N <= 96, no static objects, position embedding from
+  // the one-launch Fourier pass), a launch of its own otherwise
+  const bool tok_fused = c->tok_fused && c->enc_fused && !f.fp32 && N <= 96 && S == 0 && fo3 && PEtok != nullptr;
+  TokenP tokq; memset(&tokq, 0, sizeof(tokq));
   {
-    TokenP q;
+    TokenP& q = tokq;
     q.nat = nat_out; q.x_ego = x_ego; q.valid_agent = (const uint8_t*)valid_agent; q.category = B->agent_category; q.a_type_emb = fptr(c, "agent_encoder.type_emb.weight");
     q.pooled = poly; q.ptype = B->map_polygon_type; q.on_route = B->map_polygon_on_route; q.tl = B->map_polygon_tl_status; q.has_sl = B->map_polygon_has_speed_limit;
     q.speed_emb = speed_emb; q.p_type_emb = fptr(c, "map_encoder.type_emb.weight"); q.route_emb = fptr(c, "map_encoder.on_route_emb.weight");
     q.tl_emb = fptr(c, "map_encoder.traffic_light_emb.weight"); q.unk_emb = fptr(c, "map_encoder.unknown_speed_emb.weight");
     q.bs = bs; q.A = A; q.Mp = Mp; q.N = N; q.X = X; q.pe = PEtok;
     q.nblk_a = cdiv((long long)nA * 32, 256);
-    launch(c, "token_kernel", token_kernel, dim3(q.nblk_a + cdiv((long long)nP * 32, 256)), dim3(256), 0, q);
+    if (!tok_fused) launch(c, "token_kernel", token_kernel, dim3(q.nblk_a + cdiv((long long)nP * 32, 256)), dim3(256), 0, q);
   }
   if (S > 0) {
     float* semb = fourier(f, B->static_shape, 2, bs * S, 2, "static_objects_encoder.obj_encoder", -1);
@@ -1224,6 +1228,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (c->enc_fused && !f.fp32 && N <= 96) {
     EncFusedP ep; memset(&ep, 0, sizeof(ep));
     ep.X = X; ep.Y = ENC; ep.kpm = kpm; ep.bs = bs; ep.N = N; ep.seed = f.seed; ep.stream = f.next_stream(); f.stream_id += 8;
+    if (tok_fused) { ep.tok = tokq; ep.tok_on = 1; ep.Xout = c->keep_tokens ? X : nullptr; }
     for (int i = 0; i < 4; ++i) {
       const std::string p = "encoder_blocks." + std::to_string(i);
       EncBlockW& w = ep.blk[i];
@@ -1477,7 +1482,12 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_MAIN"); if (ev) c->nat_on_main = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_NAT_COMPACT"); if (ev) c->nat_compact = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_PE_LIVE"); if (ev) c->pe_live = atoi(ev) != 0; }
-  { const char* ev = getenv("RIFT_PE_PACK"); if (ev) c->pe_pack = atoi(ev) != 0; }      // (0: reference lines in rounds of two whole lines, the round-3 form)
+  { const char* ev = getenv("RIFT_PE_PACK"); if (ev) c->pe_pack = atoi(ev) != 0; }
+  // (1: the scene encoder assembles its token rows in its prologue instead of token_kernel.  Measured and NOT kept as the default: one ~10 us
+  // launch less between the join and the encoder, but the step is 15 us LONGER (0.659 against 0.643 ms) -- six dependent gathers per
+  // thread in the prologue of a kernel that holds every CU whole, where token_kernel's 5000 small blocks ran beside the fronts' tails)
+  { const char* ev = getenv("RIFT_TOKEN_FUSED"); if (ev) c->tok_fused = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_KEEP_TOKENS"); c->keep_tokens = ev && ev[0] == '1'; }      // (diagnostic: the fused assembly also writes the token rows, for the x_tokens tap)      // (0: reference lines in rounds of two whole lines, the round-3 form)
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_JOIN_ONCE"); if (ev) c->join_once = atoi(ev); }

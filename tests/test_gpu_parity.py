@@ -729,6 +729,7 @@ def test_fused_fourier_embedding_matches_layerwise_path(ffi, monkeypatch):
     outs = {}
     for name, env, fp32 in (("fused", "0", False), ("lds", "0", False), ("layerwise", "1", False), ("fp32", "1", True)):
         monkeypatch.setenv("RIFT_FOURIER_UNFUSED", env)
+        monkeypatch.setenv("RIFT_KEEP_TOKENS", "1")                        # (the encoder's fused token assembly writes the rows out for the tap)
         monkeypatch.setenv("RIFT_FO_W", "0" if name == "lds" else "1")     # "lds": the LDS-resident fourier_fused_kernel instead of fo_w_kernel
         eng = ffi.Engine("cuda:0")
         eng.load_state_dict({k: v.clone() for k, v in sd.items()})
