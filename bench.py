@@ -199,6 +199,7 @@ def main():
                     help="which scaling mode is the headline with N > 1 (the other one is reported beside it). strong (default): the reference's "
                          "256-scene minibatch split over the N GPUs (SURVEY.md 8(e)); weak: 256 scenes per GPU per step (global minibatch 256 x N)")
     ap.add_argument("--no-full-update", action="store_true")
+    ap.add_argument("--no-carla", action="store_true", help="skip the CARLA-shaped companion step (49 agents, 60 polygons: the shapes train_cbv really produces)")
     ap.add_argument("--no-e2e", action="store_true", help="skip full_update_e2e (RIFTPluto.train() from a full CBVRolloutBuffer to the reloaded inference model)")
     ap.add_argument("--batch", type=int, default=256, help="scenes per minibatch (diagnostic: 32 = what one of 8 ranks runs under strong scaling)")
     args = ap.parse_args()
@@ -503,6 +504,17 @@ def main():
             r = next(g)
             precisions[p] = {k: r[k] for k in keep}
     e2e = full_update_e2e() if (world == 1 and rank == 0 and not args.no_e2e and not args.no_full_update and BATCH == 256) else None
+    carla = None
+    if world == 1 and rank == 0 and not args.no_carla and BATCH == 256:
+        # companion figure: the update step at the shapes `scripts/run.py --mode train_cbv` really produces (rift_pluto.yaml:35-36: max_agent 48 ->
+        # <= 49 agents with the CBV, ~60 polygons inside radius 120, R ~ U{1..6}): N = 109 token slots > 96, i.e. the
+        # dense-traffic variants of the scene encoder and decoder (enc_w_kernel, dec_w_kernel<., true>) instead of the 96-token kernels
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import shape_step
+        carla = {}
+        for shp in ("carla", "carla-ragged"):
+            r = shape_step.run(shp, bs=BATCH, precision=args.precision, steps=60, verbose=False)
+            carla[shp] = {k: r[k] for k in ("A", "Mp", "tokens", "ms_per_step", "scenes_per_s", "us_per_scene", "per_kernel_ms")}
     head = next(head_leg)
     if precisions is not None:
         precisions[args.precision] = {k: head[k] for k in keep}
@@ -542,6 +554,12 @@ def main():
             line["full_update"] = head["full_update"]
         if e2e is not None:
             line["full_update_e2e"] = e2e
+        if carla is not None:
+            for shp in carla:
+                carla[shp]["step_time_vs_benchmark_shape"] = carla[shp]["ms_per_step"] / (head.get("steady_state", head)["ms_per_step"])
+            carla["note"] = ("the same 256-scene update step at the shapes train_cbv produces (49 agent slots, 60 polygon slots, 109 token slots; 'carla-ragged': "
+                             "per-scene agent / polygon counts drawn below those caps, as a rollout yields them); token ratio to the benchmark shape 109 / 84 = 1.30")
+            line["carla_shape"] = carla
         if precisions is not None:
             line["precisions"] = precisions
         if "roofline" in head:

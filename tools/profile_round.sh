@@ -32,10 +32,15 @@ python $REPO/tools/pmc_traffic.py $OUT $OUT/pmc_traffic.json
 { echo "# step time against the minibatch on one GPU (python bench.py --batch B --steps 200): what one of N ranks runs under strong scaling"
   for b in 32 64 128 256; do python $REPO/bench.py --batch $b --steps 200 --no-cpu-baseline --no-full-update --no-precisions --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch %4d: %.4f ms/step, %.0f scenes/s' % ($b, d['ms_per_step'], d['value']))"; done; } > $OUT/batch_sweep.txt
 python $REPO/tools/dense_step.py > $OUT/dense_step.txt 2>/dev/null
+python $REPO/tools/shape_step.py bench carla carla-ragged > $OUT/carla_step.txt 2>/dev/null
+{ echo "# one rank over RCCL with the three exchanges forced (RIFT_BENCH_FORCE_PG=1 python bench.py --steps 200): the data-parallel step pipeline on one GPU"
+  RIFT_BENCH_FORCE_PG=1 python $REPO/bench.py --steps 200 --no-cpu-baseline --no-full-update --no-precisions --no-roofline --no-carla 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('forced exchanges: %.4f ms/step (rccl_ranks %d)' % (d['ms_per_step'], d['rccl_ranks']))"
+  python $REPO/bench.py --steps 200 --no-cpu-baseline --no-full-update --no-precisions --no-roofline --no-carla 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('no group:         %.4f ms/step' % d['ms_per_step'])"; } > $OUT/forced_pg.txt
 if [ -n "$TAG" ]; then
   P=$REPO/gpurun_out/profiles_$TAG; mkdir -p $P
   cp $OUT/bench.json $P/${TAG}_bench.json; cp $OUT/kt_summary.txt $P/${TAG}_rocprof_kernel_stats.txt; cp $OUT/pmc_traffic.json $P/${TAG}_pmc_traffic.json
   for t in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT; do cp $OUT/pmc_$t.txt $P/${TAG}_pmc_$t.txt; done
   cp $OUT/batch_sweep.txt $P/${TAG}_batch_sweep.txt; cp $OUT/dense_step.txt $P/${TAG}_dense_step.txt
+  cp $OUT/carla_step.txt $P/${TAG}_carla_step.txt; cp $OUT/forced_pg.txt $P/${TAG}_forced_pg.txt
 fi
 ls -la $OUT | tail -30
