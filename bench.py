@@ -474,6 +474,9 @@ def main():
                     "host_timeline_s": {k: round(v, 4) for k, v in fit["timing"].items()}, "best_val_loss": fit["best_val_loss"]}
             out = dict(res["steady"])
             out["first_update"] = res["first_update"]
+            pol.pluto_model.release_engine()
+            if pol.train_model is not None:
+                pol.train_model.release_engine()
             out["note"] = ("RIFTPluto.train(e_i) on a full 4096-transition CBVRolloutBuffer -> reloaded inference model: checkpoint load, arena upload from the pinned host "
                            "mirror filled at store() time, 16 epochs x (15 training + 2 validation steps), top-1 checkpoint on disk, reload, buffer reset; "
                            "`seconds` = the second update of the process (the first also builds the training model and its context); store() cost is paid during the rollout")
@@ -503,6 +506,9 @@ def main():
         for p, g in todo:
             r = next(g)
             precisions[p] = {k: r[k] for k in keep}
+    head = next(head_leg)
+    # the companions that build policies / contexts of their own run BEHIND the headline leg: every further live context adds streams that
+    # share hardware queues with the headline trainer's (measured: headline 0.66 -> 0.75 ms per step with the end-to-end update ahead of it)
     e2e = full_update_e2e() if (world == 1 and rank == 0 and not args.no_e2e and not args.no_full_update and BATCH == 256) else None
     carla = None
     if world == 1 and rank == 0 and not args.no_carla and BATCH == 256:
@@ -515,7 +521,6 @@ def main():
         for shp in ("carla", "carla-ragged"):
             r = shape_step.run(shp, bs=BATCH, precision=args.precision, steps=60, verbose=False)
             carla[shp] = {k: r[k] for k in ("A", "Mp", "tokens", "ms_per_step", "scenes_per_s", "us_per_scene", "per_kernel_ms")}
-    head = next(head_leg)
     if precisions is not None:
         precisions[args.precision] = {k: head[k] for k in keep}
         precisions["note"] = ("the same update steps per compute precision: bf16 / fp16 = the fused kernels on bf16 / fp16 MFMA operands; fp32 = exact "

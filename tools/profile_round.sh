@@ -17,20 +17,20 @@ tail -c 600 $OUT/bench.err
 # (the kernel trace and the counter passes run with the forward's two chains on ONE stream and the step's tail behind its trunk: per-kernel
 # times and counters of serial launches)
 export RIFT_TWO_STREAMS=0 RIFT_PIPELINE=0
-rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-full-update --no-precisions > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-full-update --no-precisions --no-carla > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 DB=$(find /tmp/kt -name '*.db' | head -1)
 python $REPO/tools/rocpd_summary.py "$DB" > $OUT/kt_summary.txt 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $pass | cut -d' ' -f1)
   rm -rf /tmp/pmc_$tag
-  timeout 600 rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_$tag -o pmc -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-full-update --no-precisions > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_$tag -o pmc -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-full-update --no-precisions --no-carla > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err
   DB=$(find /tmp/pmc_$tag -name '*.db' | head -1)
   python $REPO/tools/rocpd_pmc.py "$DB" > $OUT/pmc_$tag.txt 2>&1
 done
 unset RIFT_TWO_STREAMS RIFT_PIPELINE
 python $REPO/tools/pmc_traffic.py $OUT $OUT/pmc_traffic.json
 { echo "# step time against the minibatch on one GPU (python bench.py --batch B --steps 200): what one of N ranks runs under strong scaling"
-  for b in 32 64 128 256; do python $REPO/bench.py --batch $b --steps 200 --no-cpu-baseline --no-full-update --no-precisions --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch %4d: %.4f ms/step, %.0f scenes/s' % ($b, d['ms_per_step'], d['value']))"; done; } > $OUT/batch_sweep.txt
+  for b in 32 64 128 256; do python $REPO/bench.py --batch $b --steps 200 --no-cpu-baseline --no-full-update --no-precisions --no-roofline --no-carla 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch %4d: %.4f ms/step, %.0f scenes/s' % ($b, d['ms_per_step'], d['value']))"; done; } > $OUT/batch_sweep.txt
 python $REPO/tools/dense_step.py > $OUT/dense_step.txt 2>/dev/null
 python $REPO/tools/shape_step.py bench carla carla-ragged > $OUT/carla_step.txt 2>/dev/null
 { echo "# one rank over RCCL with the three exchanges forced (RIFT_BENCH_FORCE_PG=1 python bench.py --steps 200): the data-parallel step pipeline on one GPU"
