@@ -80,7 +80,9 @@ __device__ __forceinline__ uint32_t decw_step(uint32_t x, uint32_t c) {
 // once per round; the residual changes tiling through the query array in global memory (release / acquire fences around the group barrier)
 // instead of the 96-row LDS buffer, the parameter blocks of two layers are resident (double-buffered by layer parity), and the scene's
 // K | V^T operands come as four per-head groups of 12 key tiles (dec_kv.h writes them).
-template <bool DROP, bool DENSE>
+// NKE (DENSE only): key tiles the cross attention walks -- 8 when the batch has N <= 128 token slots (the CARLA shapes, 109), else all 12 of
+// the scene's K | V^T image; the tiles beyond the batch's own are zero fragments behind -inf masks (exact zeros in both sums)
+template <bool DROP, bool DENSE, int NKE = (DENSE ? 12 : 6)>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dec_w_kernel(DecWP p) {
   constexpr int M = 12, XS = DECW_XS;
   constexpr int NS = DENSE ? 16 : 8;             // reference-line slots of an r2r tile
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int hh = 0; hh < nh; ++hh) {
       const int h = h0 + hh;
       f32x4 s[NKT];
-      constexpr int NK0 = DENSE ? NKT : 5;         // (not DENSE: keys 80..95 exist only in batches with more than 80 tokens)
+      constexpr int NK0 = DENSE ? NKE : 5;         // (not DENSE: keys 80..95 exist only in batches with more than 80 tokens)
 #pragma unroll
       for (int kt = 0; kt < NK0; ++kt) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float lsum = rows_sum((l4s[0] + l4s[1]) + (l4s[2] + l4s[3]));
       f32x4 o0 = Z, o1 = Z;
 #pragma unroll
-      for (int pt = 0; pt < NKT / 2; ++pt) {
+      for (int pt = 0; pt < (DENSE ? NKE : NKT) / 2; ++pt) {
         const h16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
         o0 = mfma_h(W(slot, NKT * nh + (hh * 2 + 0) * (NKT / 2) + pt), pf, o0, 0, 0, 0);
         o1 = mfma_h(W(slot, NKT * nh + (hh * 2 + 1) * (NKT / 2) + pt), pf, o1, 0, 0, 0);
@@ -539,6 +541,8 @@ int decw_set_attributes() {
   if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_BYTES);
   if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
   if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
+  if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
+  if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
   return e;
 }
 void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t stream) {
@@ -547,7 +551,10 @@ void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t 
 }
 void decw_launch(const DecWP& p, hipStream_t stream) {
   const bool dense = p.R > 8 || p.N > 96;        // the dense-traffic variant: rounds of eight tiles, hand-over through the query array
-  if (dense) {
+  if (dense && p.N <= 128) {
+    if (p.dropout > 0.f) hipLaunchKernelGGL((dec_w_kernel<true, true, 8>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_DENSE_BYTES, stream, p);
+    else hipLaunchKernelGGL((dec_w_kernel<false, true, 8>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_DENSE_BYTES, stream, p);
+  } else if (dense) {
     if (p.dropout > 0.f) hipLaunchKernelGGL((dec_w_kernel<true, true>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_DENSE_BYTES, stream, p);
     else hipLaunchKernelGGL((dec_w_kernel<false, true>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_DENSE_BYTES, stream, p);
   } else {

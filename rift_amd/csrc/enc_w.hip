@@ -51,6 +51,9 @@ __global__ void pack_encw_kernel(EncWSrc s, unsigned short* __restrict__ img, fl
   }
 }
 
+// NKE: key tiles the attention walks -- 8 when the batch has N <= 128 token slots (the CARLA shapes of rift_pluto.yaml:35-36: 109), else all
+// 12 of the image; the tiles beyond the batch's own are zero fragments behind -inf masks either way (exact zeros in both sums)
+template <int NKE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_w_kernel(EncWP p) {
   constexpr int NKT = 12;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -149,24 +152,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto attend = [&](int slot, const h16x8 qh, h16x8& aoh) {
     f32x4 s[NKT];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NKE; ++kt) {
       const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
       s[kt] = mfma_h(W(slot, kt), qh, (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
     }
     float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-    for (int kt = 1; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+    for (int kt = 1; kt < NKE; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
     m = rows_max(m);
     f32x4 l4s = Z;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NKE; ++kt) {
       s[kt] = (f32x4){__builtin_amdgcn_exp2f(s[kt][0] - m), __builtin_amdgcn_exp2f(s[kt][1] - m), __builtin_amdgcn_exp2f(s[kt][2] - m), __builtin_amdgcn_exp2f(s[kt][3] - m)};
       l4s += s[kt];
     }
     const float inv = __builtin_amdgcn_rcpf(rows_sum((l4s[0] + l4s[1]) + (l4s[2] + l4s[3])));
     f32x4 o0 = Z, o1 = Z;
 #pragma unroll
-    for (int pt = 0; pt < NKT / 2; ++pt) {
+    for (int pt = 0; pt < NKE / 2; ++pt) {
       const h16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
       o0 = mfma_h(W(slot, 12 + pt), pf, o0, 0, 0, 0);
       o1 = mfma_h(W(slot, 18 + pt), pf, o1, 0, 0, 0);
@@ -323,14 +326,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 int encw_set_attributes() {
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ENCW_LDS);
+  int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_w_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ENCW_LDS);
+  if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_w_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, ENCW_LDS);
+  return e;
 }
 void encw_pack(const EncWSrc& src, unsigned short* img, float* par, hipStream_t stream) {
   const int n = (4 * ENCW_LAYER_FRAGS + ENCW_TAIL_FRAGS) * 512;
   hipLaunchKernelGGL(pack_encw_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, img, par);
 }
 void encw_launch(const EncWP& p, hipStream_t stream) {
-  hipLaunchKernelGGL(enc_w_kernel, dim3(p.bs), dim3(512), (size_t)ENCW_LDS, stream, p);
+  if (p.N <= 128) hipLaunchKernelGGL(enc_w_kernel<8>, dim3(p.bs), dim3(512), (size_t)ENCW_LDS, stream, p);
+  else hipLaunchKernelGGL(enc_w_kernel<12>, dim3(p.bs), dim3(512), (size_t)ENCW_LDS, stream, p);
 }
 
 }  // namespace RIFT_NS
