@@ -197,10 +197,12 @@ def test_rift_loss_of_the_full_fixture_in_fp16(ffi):
 
 # Bars of the four objectives at the BENCHMARKED batch, per 16-bit mode: (loss bar per objective, gradient bar).  fp16 holds north_star's
 # 1e-4 on all four; bf16 -- the mode BASELINE.json names and bench.py's headline runs -- holds it on the RIFT loss only: GRPO / REINFORCE /
-# PPO sit at 3.4e-4 / 1.9e-4 / 3.1e-4, OUTSIDE 1e-4 (their bars are 2.5x the measurement, not the contract), gradients 0.13 .. 0.24.
+# PPO sit at 3.4e-4 / 1.9e-4 / 3.1e-4 (reference lines in two-line rounds) and 2.3e-4 / 4.0e-4 / 4.2e-4 (packed rounds, round 4: another
+# summation order of the BatchNorm-2 statistics re-rolls them) -- OUTSIDE 1e-4 either way; their bars are >= 1.7x the larger figure, not
+# the contract.  Gradients 0.12 .. 0.24.
 BENCH_BATCH_BARS = {
     "fp16": ({"rift": 1e-4, "grpo": 1e-4, "reinforce": 1e-4, "ppo": 1e-4}, 8e-2),
-    "bf16": ({"rift": 1e-4, "grpo": 8.5e-4, "reinforce": 5e-4, "ppo": 8e-4}, 0.45),
+    "bf16": ({"rift": 1e-4, "grpo": 8.5e-4, "reinforce": 7e-4, "ppo": 8e-4}, 0.45),
 }
 
 
@@ -210,8 +212,9 @@ def test_benchmark_batch_objectives_in_16bit_modes(ffi, mode):
     and the pi_head gradient that drives AdamW against the fp32 oracle's, in both 16-bit operand modes.
     fp16 (the product default): all four losses within north_star's 1e-4 (measured on MI355X 8.2e-6 / 4.0e-5 / 2.3e-5 / 1.7e-5 for
     RIFT / GRPO / REINFORCE / PPO), gradients ||dg|| / ||g|| 4.5e-2 / 3.0e-2 / 4.5e-2 / 5.9e-3.
-    bf16 (bench.py's headline, because BASELINE.json names it): RIFT 6.7e-5 -- inside 1e-4 --, GRPO / REINFORCE / PPO 3.4e-4 / 1.9e-4 /
-    3.1e-4 -- NOT inside 1e-4: this test holds them to 2.5x what is measured and says so --, gradients 0.13 .. 0.24."""
+    bf16 (bench.py's headline, because BASELINE.json names it): RIFT 5.9e-5 .. 6.7e-5 -- inside 1e-4 --, GRPO / REINFORCE / PPO up to 3.4e-4 /
+    4.0e-4 / 4.2e-4 over the two pass-B variants -- NOT inside 1e-4: this test holds them to >= 1.7x what is measured and says so --,
+    gradients 0.12 .. 0.24."""
     sd = H.weights()
     batch = syn.collate_scenes([syn.make_scene(1000 + i) for i in range(256)])
     batch["advantage_torch"] = torch.randn(256, generator=torch.Generator().manual_seed(99))     # PPO's per-scene (normalised) GAE advantage
@@ -344,7 +347,7 @@ def test_16bit_operands_stay_in_range_on_carla_magnitudes(ffi, mode):
         assert torch.isfinite(sel).all(), k
     e = err(out["probability"].cpu()[rv], prob_o[rv])
     print(f"{mode} on CARLA magnitudes: max |logit - oracle| = {e:.3e}")
-    assert e < {"fp16": 2.5e-2, "bf16": 1.5e-1}[mode]          # (coordinates of hundreds of metres cost 3 - 4 bits of the 11 / 8)
+    assert e < {"fp16": 8e-3, "bf16": 4e-2}[mode]              # the modes' logit bars (measured 2.3e-3 / 1.4e-2: no worse than on the fixtures)
     out_t = eng.forward(data, train=True, no_drop=True, bn_update=False)
     eng.check_finite()
     assert torch.isfinite(out_t["probability"].cpu()[rv]).all()
