@@ -20,15 +20,19 @@ struct EgoP {
   DropStats ds;                      // diagnostic build only (dropstats.h)
 };
 
-__global__ __launch_bounds__(256) void ego_fused_kernel(EgoP p) {
-  constexpr int ES = 136, KS_ = 260;
-  __shared__ __attribute__((aligned(16))) unsigned short e[16 * ES];
-  __shared__ __attribute__((aligned(16))) unsigned short ao[16 * ES];
-  __shared__ __attribute__((aligned(16))) float kvs[6 * KS_];
-  __shared__ unsigned char msk[8];
+#define EGO_ES 136
+#define EGO_KS 260
+#define EGO_LDS_BYTES (2 * 16 * EGO_ES * 2 + 6 * EGO_KS * 4 + 16)
+// (smem: EGO_LDS_BYTES of 16-byte aligned LDS)
+__device__ __forceinline__ void ego_body(const EgoP& p, const int b, unsigned char* smem) {
+  constexpr int ES = EGO_ES, KS_ = EGO_KS;
+  unsigned short* e = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* ao = e + 16 * ES;
+  float* kvs = reinterpret_cast<float*>(ao + 16 * ES);
+  unsigned char* msk = reinterpret_cast<unsigned char*>(kvs + 6 * KS_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int b = blockIdx.x;
-  EFrags<4, 4> Wkv;
+  // (K | V weights in two halves of 128 output columns: 32 fragment registers at a time instead of 64, so that the kernel stays within 64 VGPRs)
+  EFrags<4, 2> Wkv;
   e_load_b(Wkv, p.wkv, 128, 0, 0, wave, l15, l4);
   float tv[3];
 #pragma unroll
@@ -44,15 +48,17 @@ __global__ __launch_bounds__(256) void ego_fused_kernel(EgoP p) {
   if (tid < 6) msk[tid] = (p.drop_p > 0.f && tid >= 3 && uniform01(p.seed, p.stream, (uint32_t)(b * 6 + tid)) < p.drop_p) ? 1 : 0;
   if (tid < 6 && p.drop_p > 0.f) ds_sample(p.ds, RIFT_DS_EGO, b * 6 + tid, msk[tid] ? 0.f : 1.f);      // (a masked key, no rescaling: agent_encoder.py:119-129)
   __syncthreads();
-  {
-    f32x4 acc[1][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    e_mma<1, 4, 4>(acc, e, ES, Wkv, l15, l4);
+  for (int hf = 0; hf < 2; ++hf) {
+    if (hf) e_load_b(Wkv, p.wkv, 128, 128, 0, wave, l15, l4);
+    f32x4 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    e_mma<1, 4, 2>(acc, e, ES, Wkv, l15, l4);
     if (l15 < 6) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = (j * 4 + wave) * 16 + l4 * 4;
+      for (int j = 0; j < 2; ++j) {
+        const int col = 128 * hf + (j * 4 + wave) * 16 + l4 * 4;
         const float4 b4 = *reinterpret_cast<const float4*>(p.bkv + col);
         *reinterpret_cast<float4*>(kvs + l15 * KS_ + col) = make_float4(acc[0][j][0] + b4.x, acc[0][j][1] + b4.y, acc[0][j][2] + b4.z, acc[0][j][3] + b4.w);
       }
@@ -89,6 +95,12 @@ __global__ __launch_bounds__(256) void ego_fused_kernel(EgoP p) {
       }
     }
   }
+}
+// (64 VGPRs: a workgroup that fits on a CU BESIDE the decoder's -- 224 VGPRs x 2 waves per SIMD leave 64 -- so that the ego tokens of step k + 1 are
+// done inside the decoder of step k instead of opening the map chain behind it, like the preparation and the ranking)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void ego_fused_kernel(EgoP p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[EGO_LDS_BYTES];
+  ego_body(p, blockIdx.x, smem);
 }
 
 }  // namespace RIFT_NS

@@ -32,6 +32,7 @@
 #include "critic.h"
 #include "fpn_fused.h"
 #include "ego_fused.h"
+#include "front.h"
 #include "heads_fused.h"
 #include "pi_fused.h"
 #include "rollout.h"
@@ -94,7 +95,7 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
-  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true; bool pe_pack = true; bool tok_fused = false; bool keep_tokens = false;
+  bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true; bool pe_pack = true; bool tok_fused = false; bool keep_tokens = false; bool front_fused = false; bool front_ego = false; bool ego_nofit = false;
   hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = 0;      // rift_set_prepare_stream
   hipEvent_t ev_join2 = nullptr; bool nat_aside = true; int join_once = -1;      // (the history chain behind the preparation on the prepare stream: its join event)
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
@@ -874,6 +875,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   float* r_pos = A_alloc<float>(c, (size_t)nL * 3);
   uint8_t* r_kpm = A_alloc<uint8_t>(c, nL);
   bool prefetched = false;
+  bool front_fused = false; float* x_ego_front = nullptr; EgoP ego_front; memset(&ego_front, 0, sizeof(ego_front));
   f.r_tiles = A_alloc<uint8_t>(c, (size_t)std::max(nL, 1));
   {
     PrepP q; memset(&q, 0, sizeof(q));
@@ -889,20 +891,48 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     q.nb[3] = cdiv(nL, 256); q.nb[4] = cdiv(nL, 256); q.nb[5] = cdiv(nT, 256); q.nb[6] = cdiv(nT, 256);
     int tot = 0;
     for (int i = 0; i < 7; ++i) tot += q.nb[i];
+    // (round 4) the ranking and the ego token as blocks of the preparation's own launch (front.h): neither reads anything the preparation writes
+    front_fused = c->front_fused && !f.fp32 && c->ego_fused && !RIFT_DROP_STATS;      // (the diagnostic twin sets its counters up behind the preparation: it keeps the three launches)
+    FrontP fq; memset(&fq, 0, sizeof(fq));
+    if (front_fused) {
+      const std::string EG = "agent_encoder.ego_state_emb";
+      bool fill_eq;
+      float* eq = wconst_get(c, "ego_q", 128, f.fp32, &fill_eq);
+      if (fill_eq) gemm(c, mk(fptr(c, EG + ".query"), 128, 1, c->pw[EG + ".attn.q"], eq, 128), c->pw[EG + ".attn.q"], f.fp32);
+      x_ego_front = A_alloc<float>(c, (size_t)bs * 128);
+      EgoP& e = fq.ego;
+      e.cs = B->current_state; e.cs_ld = B->cs_ld; e.lw = c->ego_w; e.lb = c->ego_b; e.pos = fptr(c, EG + ".pos_embed");
+      e.wkv = (const unsigned short*)c->pw[EG + ".attn.kv"].bf; e.bkv = c->pw[EG + ".attn.kv"].bias; e.q = eq;
+      e.wo = (const unsigned short*)c->pw[EG + ".attn.out_proj"].bf; e.bo = c->pw[EG + ".attn.out_proj"].bias;
+      e.out = x_ego_front; e.bs = bs; e.drop_p = f.drop ? 0.75f : 0.f; e.seed = f.seed; e.stream = 0x45474Fu;      // (a stream id of its own: every other kernel keeps the id it had)
+      ego_front = e;
+      fq.n_ego = c->front_ego ? bs : 0;
+      fq.rank_on = nat_compact ? 1 : 0; fq.aidx = nat_aidx; fq.cnt = nat_cnt;
+      if (nat_compact) q.hist_agent = nullptr;          // (the ranking block derives the marks itself)
+      fq.prep = q;
+    }
+    auto launch_front = [&]() {
+      if (front_fused) {
+        c->prof_flops = 2.0 * bs * (6.0 * 128 * 256 + 128.0 * 128);
+        if (fq.n_ego) launch(c, "front_kernel", front_kernel<true>, dim3(tot + fq.n_ego + fq.rank_on), dim3(256), 0, fq);
+        else launch(c, "front_kernel", front_kernel<false>, dim3(tot + fq.rank_on), dim3(256), 0, fq);
+      } else {
+        launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
+        if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(NAT_RANK_THREADS), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
+      }
+    };
     // on the caller's prepare stream if there is one (rift_set_prepare_stream): behind the gather of the batch, beside the previous step
     prefetched = c->prep_set && !c->prof_on && !c->dry;
     if (prefetched) {
       if (!c->ev_prep) HIPCHK(c, hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
       hipStream_t own = c->stream;
       c->stream = c->prep_stream;
-      launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
-      if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(NAT_RANK_THREADS), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
+      launch_front();
       c->stream = own;
       HIPCHK(c, hipEventRecord(c->ev_prep, c->prep_stream));
       HIPCHK(c, hipStreamWaitEvent(own, c->ev_prep, 0));
     } else {
-      launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
-      if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(NAT_RANK_THREADS), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
+      launch_front();
     }
   }
   // data parallel: the r2r mask quirk indexes padding rows of the GLOBAL minibatch -> gather them (slots in the exchange buffer; the
@@ -1096,16 +1126,21 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   bool fill_eq;
   float* eq = wconst_get(c, "ego_q", 128, f.fp32, &fill_eq);
   if (fill_eq) gemm(c, mk(fptr(c, EG + ".query"), 128, 1, c->pw[EG + ".attn.q"], eq, 128), c->pw[EG + ".attn.q"], f.fp32);
-  float* x_ego = A_alloc<float>(c, (size_t)bs * 128);
-  if (!f.fp32 && c->ego_fused) {
+  float* x_ego = front_fused ? x_ego_front : A_alloc<float>(c, (size_t)bs * 128);
+  if (front_fused && c->front_ego) {
+    if (f.drop) (void)f.next_stream();          // (the id the ego token's own launch used to take: the kernels behind it keep theirs)
+  } else if (!f.fp32 && c->ego_fused) {
     EgoP q; memset(&q, 0, sizeof(q));
+    if (front_fused) { q = ego_front; q.stream = f.drop ? f.next_stream() : 0; } else {
     q.cs = B->current_state; q.cs_ld = B->cs_ld; q.lw = c->ego_w; q.lb = c->ego_b; q.pos = fptr(c, EG + ".pos_embed");
     q.wkv = (const unsigned short*)c->pw[EG + ".attn.kv"].bf; q.bkv = c->pw[EG + ".attn.kv"].bias; q.q = eq;
     q.wo = (const unsigned short*)c->pw[EG + ".attn.out_proj"].bf; q.bo = c->pw[EG + ".attn.out_proj"].bias;
     q.out = x_ego; q.bs = bs; q.drop_p = f.drop ? 0.75f : 0.f; q.seed = f.seed; q.stream = f.drop ? f.next_stream() : 0;
+    }
     RIFT_SET_DS(q);
     c->prof_flops = 2.0 * bs * (6.0 * 128 * 256 + 128.0 * 128);
-    launch(c, "ego_fused_kernel", ego_fused_kernel, dim3(bs), dim3(256), 0, q);
+    // (diagnostic RIFT_EGO_NOFIT=1: 40 KB of unused dynamic LDS keep the workgroup from fitting beside the decoder's -- the round-3 behaviour, for A/B)
+    launch(c, "ego_fused_kernel", ego_fused_kernel, dim3(bs), dim3(256), (size_t)(c->ego_nofit ? 40960 : 0), q);
   } else {
   float* E = A_alloc<float>(c, (size_t)bs * 6 * 128);
   launch(c, "ego_token_kernel", ego_token_kernel, dim3(cdiv((long long)bs * 6 * 128, 256)), dim3(256), 0, B->current_state, B->cs_ld,
@@ -1487,7 +1522,14 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   // launch less between the join and the encoder, but the step is 15 us LONGER (0.659 against 0.643 ms) -- six dependent gathers per
   // thread in the prologue of a kernel that holds every CU whole, where token_kernel's 5000 small blocks ran beside the fronts' tails)
   { const char* ev = getenv("RIFT_TOKEN_FUSED"); if (ev) c->tok_fused = atoi(ev) != 0; }
-  { const char* ev = getenv("RIFT_KEEP_TOKENS"); c->keep_tokens = ev && ev[0] == '1'; }      // (diagnostic: the fused assembly also writes the token rows, for the x_tokens tap)      // (0: reference lines in rounds of two whole lines, the round-3 form)
+  { const char* ev = getenv("RIFT_KEEP_TOKENS"); c->keep_tokens = ev && ev[0] == '1'; }
+  // (1: preparation and ranking in one launch, front.h.  Measured and NOT kept as the default: at 256 scenes both already run INSIDE the previous
+  // step's decoder (<= 64 VGPRs), so the launch saved is not on any chain -- 0.640 against 0.642 ms, noise -- while the ranking block, which then has
+  // to derive the marks from the raw validity (344 KB through one workgroup), makes the merged launch 34 us where the two took 24: a loss wherever
+  // the forward runs serially (get_action, small batches))
+  { const char* ev = getenv("RIFT_FRONT_FUSED"); if (ev) c->front_fused = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_EGO_NOFIT"); c->ego_nofit = ev && ev[0] == '1'; }
+  { const char* ev = getenv("RIFT_FRONT_EGO"); if (ev) c->front_ego = atoi(ev) != 0; }        // (1: the ego token as blocks of that launch too -- 116 VGPRs: it no longer fits beside the decoder's workgroups)      // (diagnostic: the fused assembly also writes the token rows, for the x_tokens tap)      // (0: reference lines in rounds of two whole lines, the round-3 form)
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_JOIN_ONCE"); if (ev) c->join_once = atoi(ev); }

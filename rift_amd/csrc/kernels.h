@@ -724,8 +724,7 @@ struct PrepP {
   int nb[7];
 };
 
-__global__ __launch_bounds__(256) void prep_kernel(PrepP q) {
-  int blk = blockIdx.x;
+__device__ __forceinline__ void prep_body(const PrepP& q, int blk) {
   if (blk < q.nb[0]) { agent_feature_body(q.agent_pos, q.agent_head, q.agent_vel, q.agent_shape, q.agent_valid, q.nA, q.Tfull, q.F9, q.valid_agent, blk, q.hist_agent, q.A); return; }
   blk -= q.nb[0];
   if (blk < q.nb[1]) { map_feature_body(q.map_pp, q.map_pv, q.map_po, q.map_center, q.nPoly, q.F10, blk); return; }
@@ -740,5 +739,6 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepP q) {
   blk -= q.nb[5];
   token_pos_body(q.agent_pos, q.agent_head, q.Tfull, q.map_center, q.st_pos, q.st_head, q.bs, q.A, q.Mp, q.S, q.pos, blk);
 }
+__global__ __launch_bounds__(256) void prep_kernel(PrepP q) { prep_body(q, blockIdx.x); }
 
 }  // namespace RIFT_NS

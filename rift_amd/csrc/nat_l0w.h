@@ -404,14 +404,52 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
 // the marks itself in its prologue -- no launch, but 14 us on each of 256 CUs.)
 #define NAT_RANK_THREADS 256      // four waves of <= 64 VGPRs: a workgroup that fits beside the decoder's on a CU (224 VGPRs x 2 waves per SIMD leave 64), so
                                   // that the ranking of step k + 1 finishes INSIDE the decoder of step k at a chip-filling batch instead of behind it
-__global__ __launch_bounds__(NAT_RANK_THREADS) void nat_rank_kernel(const uint8_t* __restrict__ hist, int n, int* __restrict__ aidx, int* __restrict__ cnt) {
+// `raw` (optional, with Tfull, A): the (agent, time) validity the marks derive from -- mark = any of the first 21 samples && slot % A != 0, the rule of
+// agent_feature_body (kernels.h).  With it the ranking does not wait for the preparation: front_kernel (front.h) runs it as a block of the
+// preparation's own launch.
+__device__ __forceinline__ void nat_rank_body(const uint8_t* __restrict__ hist, int n, int* __restrict__ aidx, int* __restrict__ cnt, unsigned long long* wsum,
+                                              const uint8_t* __restrict__ raw = nullptr, int Tfull = 21, int A = 1) {
   constexpr int NW = NAT_RANK_THREADS / 64;
-  __shared__ unsigned long long wsum[NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = (((n + NAT_RANK_THREADS - 1) / NAT_RANK_THREADS) + 15) & ~15, s0 = tid * K;      // slots per thread, a multiple of 16
-  // sixteen marks at a time: one 16-byte load when they lie inside the array (hist is 16-byte aligned), byte loads otherwise
+  // sixteen marks at a time: one 16-byte load when they lie inside the array (hist is 16-byte aligned), byte loads otherwise; with `raw`
+  // straight from the (agent, time) validity
   auto marks16 = [&](int j0, uint32_t (&mk)[4]) {
     const int p = s0 + j0;
+    if (raw) {
+      mk[0] = mk[1] = mk[2] = mk[3] = 0u;
+      if (Tfull == 21 && p + 16 <= n) {      // four agents' samples are 84 contiguous bytes (4-byte aligned: p is a multiple of 4): 21 dword loads per quad
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {          // (a quad at a time: 21 live registers -- this body shares a launch with the preparation and must stay small)
+          uint32_t w[21];
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(raw + (size_t)(p + 4 * g) * 21);
+#pragma unroll
+          for (int i = 0; i < 21; ++i) w[i] = src[i];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            uint32_t any = 0;
+#pragma unroll
+            for (int d = (21 * j) / 4; d <= (21 * j + 20) / 4; ++d) {     // bytes 21 j .. 21 j + 20 of the quad
+              const int lo = 21 * j - 4 * d, hi = 21 * j + 20 - 4 * d;   // first / last byte of the agent inside dword d (may lie outside 0..3)
+              const uint32_t m = (hi >= 3 ? 0xffffffffu : (0xffffffffu >> (8 * (3 - hi)))) & (lo <= 0 ? 0xffffffffu : (0xffffffffu << (8 * lo)));
+              any |= w[d] & m;
+            }
+            if (any && ((p + 4 * g + j) % A) != 0) mk[g] |= 1u << (8 * j);
+          }
+        }
+        return;
+      }
+      for (int j = 0; j < 16; ++j) {
+        const int a = p + j;
+        uint32_t any = 0;
+        if (a < n) {
+          const uint8_t* v = raw + (size_t)a * Tfull;
+          for (int i = 0; i < 21; ++i) any |= v[i];
+        }
+        if (any && (a % A) != 0) mk[j >> 2] |= 1u << (8 * (j & 3));
+      }
+      return;
+    }
     if (p + 16 <= n) { const uint4 v = *reinterpret_cast<const uint4*>(hist + p); mk[0] = v.x; mk[1] = v.y; mk[2] = v.z; mk[3] = v.w; }
     else {
       mk[0] = mk[1] = mk[2] = mk[3] = 0u;
@@ -419,12 +457,18 @@ __global__ __launch_bounds__(NAT_RANK_THREADS) void nat_rank_kernel(const uint8_
     }
   };
   unsigned long long mine = 0ull;
+  unsigned long long seen0 = 0ull, seen1 = 0ull;        // (raw) the marks of this thread's first 128 slots: the second pass does not scan the validity again
+  const bool cached = raw != nullptr && K <= 128;
   int c = s0 % 3;
   for (int j0 = 0; j0 < K; j0 += 16) {
     uint32_t mk[4];
     marks16(j0, mk);
 #pragma unroll
-    for (int j = 0; j < 16; ++j, c = (c == 2) ? 0 : c + 1) mine += ((mk[j >> 2] >> (8 * (j & 3))) & 0xffu) ? (1ull << (21 * c)) : 0ull;
+    for (int j = 0; j < 16; ++j, c = (c == 2) ? 0 : c + 1) {
+      const bool on = ((mk[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0;
+      mine += on ? (1ull << (21 * c)) : 0ull;
+      if (cached && on) { if (j0 < 64) seen0 |= 1ull << ((j0 + j) & 63); else seen1 |= 1ull << ((j0 + j) & 63); }
+    }
   }
   unsigned long long incl = mine;
 #pragma unroll
@@ -439,7 +483,11 @@ __global__ __launch_bounds__(NAT_RANK_THREADS) void nat_rank_kernel(const uint8_
   c = s0 % 3;
   for (int j0 = 0; j0 < K; j0 += 16) {
     uint32_t mk[4];
-    marks16(j0, mk);
+    if (cached) {
+      const uint32_t b16 = (uint32_t)(((j0 < 64 ? seen0 : seen1) >> (j0 & 63)) & 0xffffull);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mk[q] = ((b16 >> (4 * q)) & 1u) | (((b16 >> (4 * q + 1)) & 1u) << 8) | (((b16 >> (4 * q + 2)) & 1u) << 16) | (((b16 >> (4 * q + 3)) & 1u) << 24);
+    } else marks16(j0, mk);
 #pragma unroll
     for (int j = 0; j < 16; ++j, c = (c == 2) ? 0 : c + 1) {
       if ((mk[j >> 2] >> (8 * (j & 3))) & 0xffu) {
@@ -450,6 +498,10 @@ __global__ __launch_bounds__(NAT_RANK_THREADS) void nat_rank_kernel(const uint8_
     }
   }
   if (tid == 0) { cnt[0] = (int)(total & 0x1fffffu); cnt[1] = (int)((total >> 21) & 0x1fffffu); cnt[2] = (int)((total >> 42) & 0x1fffffu); }
+}
+__global__ __launch_bounds__(NAT_RANK_THREADS) void nat_rank_kernel(const uint8_t* __restrict__ hist, int n, int* __restrict__ aidx, int* __restrict__ cnt) {
+  __shared__ unsigned long long wsum[NAT_RANK_THREADS / 64];
+  nat_rank_body(hist, n, aidx, cnt, wsum);
 }
 
 }  // namespace RIFT_NS
