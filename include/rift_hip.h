@@ -180,7 +180,8 @@ int rift_forward_head_back(RiftCtx* ctx, int back, void* stream);
  * and calls `exchange`, which must enqueue an in-place SUM all-reduce of that range over the ranks on `stream` (RCCL through
  * torch.distributed in the host layer; any transport works) and return 0.  Every rank must call rift_forward with the same R and flags.
  * xchg_len >= global_bs * R + 1026.  The loss exchange (RiftLossOut.exchange) stays with the host between rift_loss_backward and
- * rift_loss_finalize.  dp == NULL (or global_bs <= 0) switches data parallelism off. */
+ * rift_loss_finalize.  dp == NULL (or global_bs <= 0) switches data parallelism off.  exchange == NULL is accepted behind rift_comm_init
+ * (below): the library's own communicator carries the exchanges. */
 typedef int (*RiftExchangeFn)(void* user, int64_t offset, int64_t count, void* stream);
 typedef struct RiftDp {
   int32_t scene_offset, global_bs;
@@ -188,6 +189,18 @@ typedef struct RiftDp {
   RiftExchangeFn exchange; void* user;
 } RiftDp;
 int rift_set_dp(RiftCtx* ctx, const RiftDp* dp);
+
+/* A library-owned communicator (`rift_comm_init(ctx, ncclUniqueId, rank, world)`) for hosts that have none of their own: RCCL
+ * (librccl.so, opened with dlopen the first time one of these is called -- an RCCL already in the process, e.g. torch's, is reused) over xGMI.
+ * rift_comm_unique_id fills 128 bytes (an ncclUniqueId) on ONE rank; the launcher hands them to every rank out of band; rift_comm_init joins
+ * the communicator (collective: every rank calls it).  With a communicator in place rift_set_dp accepts `exchange == NULL` -- the forward's
+ * exchanges are then ncclAllReduce(sum, f64) on the forward's own streams -- and rift_comm_all_reduce does the same for the caller's loss
+ * exchange buffer (RiftLossOut.exchange) between rift_loss_backward and rift_loss_finalize.  A host WITH a communicator (the Python layer:
+ * torch.distributed's) keeps passing its callback; the two routes produce the same sums. */
+int rift_comm_unique_id(RiftCtx* ctx, void* unique_id_out /*host, 128 bytes*/);
+int rift_comm_init(RiftCtx* ctx, const void* unique_id /*host, 128 bytes*/, int rank, int world);
+int rift_comm_all_reduce(RiftCtx* ctx, double* buf /*device f64, in place*/, int64_t count, void* stream);
+int rift_comm_destroy(RiftCtx* ctx);
 
 /* Input prefetch.  Everything a forward does before its first encoder kernel depends on the batch alone: the caller's gather of the batch
  * (rift_collate) and the forward's own input-only preparation (difference features, masks, positions: one launch).  With a prepare stream

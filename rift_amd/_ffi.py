@@ -91,6 +91,7 @@ EXPORTS = [
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
     "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout", "rift_sft_teacher_mode",
     "rift_check_finite", "rift_set_dp", "rift_set_prepare_stream",
+    "rift_comm_unique_id", "rift_comm_init", "rift_comm_all_reduce", "rift_comm_destroy",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -130,6 +131,10 @@ def load_library(variant: str = "") -> C.CDLL:
     lib.rift_check_finite.argtypes = [vp, vp]
     lib.rift_set_dp.argtypes = [vp, C.POINTER(RiftDp)]
     lib.rift_set_prepare_stream.argtypes = [vp, vp]
+    lib.rift_comm_unique_id.argtypes = [vp, vp]
+    lib.rift_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.rift_comm_all_reduce.argtypes = [vp, vp, C.c_int64, vp]
+    lib.rift_comm_destroy.argtypes = [vp]
     lib.rift_loss_finalize_clip.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, C.c_float, vp, vp]
     lib.rift_tap.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), vp]
     lib.rift_critic_forward.argtypes = [vp, C.POINTER(RiftCritic), vp, C.c_int, vp, vp]
@@ -403,6 +408,35 @@ class Engine:
             self._dp_keep = (xchg, exchange)
         d = RiftDp()
         d.scene_offset, d.global_bs, d.xchg, d.xchg_len, d.exchange, d.user = scene_offset, global_bs, xchg.data_ptr(), xchg.numel(), self._dp_cb, None
+        self._check(self.lib.rift_set_dp(self.ctx, C.byref(d)), "rift_set_dp")
+
+    # ---- the library-owned communicator (rift_comm_*: RCCL through dlopen; hosts without torch.distributed) ---------------------------------
+    def comm_unique_id(self) -> bytes:
+        """128 bytes (an ncclUniqueId) from ONE rank; hand them to every rank out of band."""
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.rift_comm_unique_id(self.ctx, C.cast(buf, vp)), "rift_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        buf = C.create_string_buffer(unique_id, 128)
+        self._check(self.lib.rift_comm_init(self.ctx, C.cast(buf, vp), rank, world), "rift_comm_init")
+
+    def comm_all_reduce(self, t: torch.Tensor):
+        """In-place SUM all-reduce of a device f64 tensor over the library's communicator, on the current stream."""
+        assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous()
+        self._check(self.lib.rift_comm_all_reduce(self.ctx, _ptr(t), t.numel(), _stream()), "rift_comm_all_reduce")
+
+    def comm_destroy(self):
+        self._check(self.lib.rift_comm_destroy(self.ctx), "rift_comm_destroy")
+
+    def set_dp_library_comm(self, scene_offset: int, global_bs: int, xchg: torch.Tensor):
+        """rift_set_dp with exchange = NULL: the forward's exchanges go over the communicator of comm_init()."""
+        assert xchg.dtype == torch.float64 and xchg.is_cuda and xchg.is_contiguous()
+        d = RiftDp()
+        d.scene_offset, d.global_bs, d.xchg, d.xchg_len, d.exchange, d.user = scene_offset, global_bs, xchg.data_ptr(), xchg.numel(), EXCHANGE_FN(0), None
+        self._dp_keep = (xchg, None)
+        self._dp_key = None
         self._check(self.lib.rift_set_dp(self.ctx, C.byref(d)), "rift_set_dp")
 
     def clear_dp(self):

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <string>
 #include <unordered_map>
+#include <dlfcn.h>
 #include <vector>
 
 #include "../../include/rift_hip.h"
@@ -105,6 +106,7 @@ struct RiftCtx {
   double* clip_part = nullptr;
   struct Dp { bool on = false; int off = 0, gbs = 0; double* xchg = nullptr; long long len = 0; RiftExchangeFn fn = nullptr; void* user = nullptr; } dp;   // rift_set_dp
   int* nonfinite = nullptr;              // device flag set by the policy-head kernels when the decoder output is not finite
+  void* comm = nullptr; int comm_rank = 0, comm_world = 1;      // library-owned RCCL communicator (rift_comm_init), or null
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
   bool pe_fused = true; bool fo_fused = true; int nat_grid = 256; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
   bool loaded = false;
@@ -441,6 +443,48 @@ struct Fwd {   // per-forward context
   uint8_t* r_tiles = nullptr;                        // tiles of every reference line up to its last valid point (prep_kernel), for pe_w_kernel's packed rounds
 };
 
+// RCCL through dlopen (rift_comm_*): the library has no link-time dependency on a communication library; an RCCL that is already in the
+// process (torch's) is reused so that one process does not run two of them.
+struct RcclApi {
+  struct UniqueId { char internal[128]; };
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+static RcclApi& rccl_api(std::string* why) {
+  static RcclApi api;
+  static bool tried = false;
+  static std::string err;
+  if (!tried) {
+    tried = true;
+    void* h = nullptr;
+    const char* names[] = {getenv("RIFT_RCCL_LIB"), "librccl.so", "librccl.so.1"};
+    for (const char* n : names) if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);      // one that is loaded already
+    for (const char* n : names) if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) err = std::string("librccl.so not found (set RIFT_RCCL_LIB): ") + (dlerror() ? dlerror() : "");
+    else {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+      api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+      api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy;
+      if (!api.ok) err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+    }
+  }
+  if (why) *why = err;
+  return api;
+}
+static int comm_sum_f64(RiftCtx* c, double* buf, long long count, hipStream_t stream) {
+  RcclApi& r = rccl_api(nullptr);
+  if (!c->comm || !r.ok) return -1;
+  return r.AllReduce(buf, buf, (size_t)count, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, stream);
+}
+
 // All-reduce xchg[kb, kb + n) over the ranks (BatchNorm sums); the first exchange of a forward also carries the mask slots [0, kb)
 // and is followed by their conversion into the gathered padding mask.  Dry (arena sizing) passes exchange nothing.
 void dp_exchange(Fwd& f, long long n) {
@@ -450,7 +494,10 @@ void dp_exchange(Fwd& f, long long n) {
   f.kpm_pending = false;
   if (c->dry) return;
   const long long off = with_kpm ? 0 : f.kb, cnt = with_kpm ? f.kb + n : n;
-  if (cnt > 0 && c->dp.fn(c->dp.user, off, cnt, (void*)c->stream) != 0 && c->err.empty()) c->err = "data-parallel exchange callback failed";
+  if (cnt > 0) {
+    const int rc = c->dp.fn ? c->dp.fn(c->dp.user, off, cnt, (void*)c->stream) : comm_sum_f64(c, c->dp.xchg + off, cnt, c->stream);      // (no callback: the library's own communicator)
+    if (rc != 0 && c->err.empty()) c->err = c->dp.fn ? "data-parallel exchange callback failed" : "data-parallel exchange over the library communicator failed";
+  }
   if (with_kpm) launch(c, "dp_kpm_read_kernel", dp_kpm_read_kernel, dim3(cdiv(f.kb, 256)), dim3(256), 0, (const double*)c->dp.xchg, f.kb, f.g_rkpm);
 }
 
@@ -1548,6 +1595,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
 
 void rift_ctx_destroy(RiftCtx* c) {
   if (!c) return;
+  if (c->comm) { (void)rccl_api(nullptr).CommDestroy(c->comm); c->comm = nullptr; }
   for (void* p : c->owned) (void)hipFree(p);
   for (int i = 0; i < RIFT_DEFER_SLOTS; ++i) if (c->arenas[i]) (void)hipFree(c->arenas[i]);
   if (c->l_S) (void)hipFree(c->l_S);
@@ -1988,9 +2036,57 @@ int rift_sft_teacher_mode(RiftCtx* c, const float* trajectory, const float* teac
 int rift_set_dp(RiftCtx* c, const RiftDp* dp) {
   if (!c) return RIFT_ERR_ARG;
   if (!dp || dp->global_bs <= 0) { c->dp = RiftCtx::Dp(); return RIFT_OK; }
-  if (!dp->xchg || !dp->exchange || dp->scene_offset < 0 || dp->xchg_len <= 0) { c->err = "rift_set_dp: bad descriptor"; return RIFT_ERR_ARG; }
+  if (!dp->xchg || dp->scene_offset < 0 || dp->xchg_len <= 0) { c->err = "rift_set_dp: bad descriptor"; return RIFT_ERR_ARG; }
+  if (!dp->exchange && !c->comm) { c->err = "rift_set_dp: no exchange callback and no library communicator (rift_comm_init)"; return RIFT_ERR_ARG; }
   c->dp.on = true; c->dp.off = dp->scene_offset; c->dp.gbs = dp->global_bs; c->dp.xchg = dp->xchg; c->dp.len = dp->xchg_len;
   c->dp.fn = dp->exchange; c->dp.user = dp->user;
+  return RIFT_OK;
+}
+
+int rift_comm_unique_id(RiftCtx* c, void* unique_id_out) {
+  if (!c || !unique_id_out) return RIFT_ERR_ARG;
+  std::string why;
+  RcclApi& r = rccl_api(&why);
+  if (!r.ok) { c->err = "rift_comm_unique_id: " + why; return RIFT_ERR_STATE; }
+  RcclApi::UniqueId id;
+  const int rc = r.GetUniqueId(&id);
+  if (rc != 0) { c->err = std::string("ncclGetUniqueId: ") + (r.GetErrorString ? r.GetErrorString(rc) : "failed"); return RIFT_ERR_HIP; }
+  memcpy(unique_id_out, &id, sizeof(id));
+  return RIFT_OK;
+}
+
+int rift_comm_init(RiftCtx* c, const void* unique_id, int rank, int world) {
+  if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return RIFT_ERR_ARG;
+  if (c->comm) { c->err = "rift_comm_init: the context has a communicator already (rift_comm_destroy first)"; return RIFT_ERR_STATE; }
+  std::string why;
+  RcclApi& r = rccl_api(&why);
+  if (!r.ok) { c->err = "rift_comm_init: " + why; return RIFT_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  RcclApi::UniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  void* comm = nullptr;
+  const int rc = r.CommInitRank(&comm, world, id, rank);
+  if (rc != 0 || !comm) { c->err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "failed"); return RIFT_ERR_HIP; }
+  c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+  return RIFT_OK;
+}
+
+int rift_comm_all_reduce(RiftCtx* c, double* buf, int64_t count, void* stream) {
+  if (!c || !buf || count <= 0) return RIFT_ERR_ARG;
+  if (!c->comm) { c->err = "rift_comm_all_reduce before rift_comm_init"; return RIFT_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rc = comm_sum_f64(c, buf, count, (hipStream_t)stream);
+  if (rc != 0) { RcclApi& r = rccl_api(nullptr); c->err = std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(rc) : "failed"); return RIFT_ERR_HIP; }
+  return RIFT_OK;
+}
+
+int rift_comm_destroy(RiftCtx* c) {
+  if (!c) return RIFT_ERR_ARG;
+  if (c->comm) {
+    if (c->dp.on && !c->dp.fn) c->dp = RiftCtx::Dp();      // (forwards must not reach for a communicator that is gone)
+    (void)rccl_api(nullptr).CommDestroy(c->comm);
+    c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
+  }
   return RIFT_OK;
 }
 

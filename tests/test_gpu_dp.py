@@ -262,3 +262,49 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert line["scaling"] == "strong" and line["value"] == pytest.approx(line["strong"]["value"])
     assert line["config"]["global_batch"] == 256 and line["config"]["per_gpu_batch"] == 128
     assert line["roofline"]["kernel"] and line["cpu_baseline"]["value"] > 0
+
+
+def test_library_owned_communicator_with_one_rank():
+    """`rift_comm_init(ctx, ncclUniqueId, rank, world)` -- a communicator the LIBRARY owns (RCCL through dlopen), for hosts without
+    torch.distributed.  One rank on this one-GPU box: the unique id round trip, ncclCommInitRank, an all-reduce of the loss exchange buffer
+    (identity with one rank) and a sharded-descriptor training forward whose three exchanges go over that communicator (rift_set_dp with
+    exchange = NULL) -- loss and gradients equal the step without a group, bit for bit.  A second rift_comm_init on the same context and a
+    descriptor without callback or communicator are refused."""
+    from rift_amd import _ffi
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.replay import DeviceReplay
+    n = 6
+    scenes = [syn.make_scene(300 + i) for i in range(n)]
+    replay = DeviceReplay(scenes, "cuda:0")
+    idx = torch.arange(n, dtype=torch.int32, device="cuda:0")
+    R = replay.Rcap
+    single = RLFTTrainer(_model("fp16"), kind="rift")
+    fb, b = replay.collate(single.engine, idx, R)
+    want = float(single.forward_loss(fb, b, train=True).item())
+    want_grads = {k: p.grad.clone() for k, p in single.params.items()}
+    single.close()
+
+    tr = RLFTTrainer(_model("fp16"), kind="rift")
+    eng = tr.engine
+    xchg = torch.zeros(n * 16 + 1026, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(RuntimeError, match="no exchange callback and no library communicator"):
+        eng.set_dp_library_comm(0, n, xchg)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(uid, 0, 1)
+    with pytest.raises(RuntimeError, match="has a communicator already"):
+        eng.comm_init(uid, 0, 1)
+    t = torch.arange(16899, dtype=torch.float64, device="cuda:0")
+    eng.comm_all_reduce(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(16899, dtype=torch.float64))
+    eng.set_dp_library_comm(0, n, xchg)
+    fb, b = replay.collate(eng, idx, R)
+    got = float(tr.forward_loss(fb, b, train=True).item())          # (the trainer has no exchange of its own: the loss sums stay local -- one rank)
+    assert got == want
+    for k, p in tr.params.items():
+        assert torch.equal(p.grad, want_grads[k]), k
+    eng.clear_dp()
+    eng.comm_destroy()
+    eng.comm_destroy()                                               # idempotent
+    tr.close()
