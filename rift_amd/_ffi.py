@@ -280,6 +280,40 @@ class Engine:
         self._params = None
         self._names = None
         self._keep = []
+        self._stage_host = self._stage_dev = None
+        self._stage_off = 0
+
+    # ---- small host inputs (the rollout tick's per-CBV readings) ---------------------------------
+    _STAGE_BYTES = 8 << 20
+    _NP_OF = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8,
+              torch.bool: np.bool_}
+
+    def stage(self, a, dtype: torch.dtype) -> torch.Tensor:
+        """Host array / CPU tensor -> device tensor of `dtype` through a pinned arena and an ASYNCHRONOUS copy on the current stream.
+        `tensor.to(device)` from pageable memory waits for everything the stream holds; a tick's evaluation chain makes ~15 such uploads
+        per CBV, each between kernel launches, and that wait -- not the copies -- was a third of the tick (tools/tick_latency.py).  The
+        arena advances by the call and wraps behind a stream synchronisation, so a staged tensor is valid until 8 MiB of later uploads:
+        it is for the inputs of the call at hand, not for keeping.  Large (> 2 MiB) and empty inputs take the ordinary path."""
+        if torch.is_tensor(a):
+            if a.is_cuda:
+                return _dev(a, dtype, self.device)
+            a = a.detach().numpy()
+        a = np.ascontiguousarray(a, dtype=self._NP_OF[dtype])
+        n = a.nbytes
+        if n == 0 or n > self._STAGE_BYTES // 4:
+            return torch.from_numpy(a).to(self.device)
+        if self._stage_host is None:
+            self._stage_host = torch.empty(self._STAGE_BYTES, dtype=torch.uint8).pin_memory()
+            self._stage_dev = torch.empty(self._STAGE_BYTES, dtype=torch.uint8, device=self.device)
+        off = (self._stage_off + 255) & ~255
+        if off + n > self._STAGE_BYTES:
+            torch.cuda.current_stream(self.device).synchronize()      # every consumer of the slots about to be rewritten is done
+            off = 0
+        self._stage_host.numpy()[off:off + n] = a.reshape(-1).view(np.uint8)
+        d = self._stage_dev[off:off + n]
+        d.copy_(self._stage_host[off:off + n], non_blocking=True)
+        self._stage_off = off + n
+        return d.view(dtype).view(a.shape)
 
     def close(self):
         if self.ctx:
@@ -570,13 +604,24 @@ class Engine:
         R, M, Tfull, Cc = traj.shape
         assert Cc == 6
         Pmax = max(p.shape[0] for p in ref_pos_list)
-        rp = torch.zeros(R, Pmax, 2, device=dev)
-        ra = torch.zeros(R, Pmax, device=dev)
-        for r in range(R):
-            n = ref_pos_list[r].shape[0]
-            rp[r, :n] = ref_pos_list[r].to(dev)
-            ra[r, :n] = ref_angle_list[r].to(dev)
-        rl = torch.tensor([p.shape[0] for p in ref_pos_list], dtype=torch.int32, device=dev)
+        if all(not (torch.is_tensor(p) and p.is_cuda) for p in ref_pos_list):
+            # host-side lines (the rollout tick: straight from the observation): padded on the host, ONE upload -- [x, y, angle] planes + lengths
+            host = np.zeros((R, Pmax, 3), dtype=np.float32)
+            for r in range(R):
+                n = ref_pos_list[r].shape[0]
+                host[r, :n, :2] = np.asarray(ref_pos_list[r], dtype=np.float32)
+                host[r, :n, 2] = np.asarray(ref_angle_list[r], dtype=np.float32)
+            hp = np.concatenate([host[..., :2].reshape(-1), host[..., 2].reshape(-1)])      # [positions (R, Pmax, 2) | angles (R, Pmax)]
+            up = self.stage(hp, torch.float32)
+            rp, ra = up[:R * Pmax * 2].view(R, Pmax, 2), up[R * Pmax * 2:].view(R, Pmax)
+        else:
+            rp = torch.zeros(R, Pmax, 2, device=dev)
+            ra = torch.zeros(R, Pmax, device=dev)
+            for r in range(R):
+                n = ref_pos_list[r].shape[0]
+                rp[r, :n] = ref_pos_list[r].to(dev)
+                ra[r, :n] = ref_angle_list[r].to(dev)
+        rl = self.stage(np.array([p.shape[0] for p in ref_pos_list], dtype=np.int32), torch.int32)
         G = R * M
         dd = torch.empty(G, Ts, device=dev)
         da = torch.empty(G, Ts, device=dev)
@@ -598,7 +643,7 @@ class Engine:
         dev = self.device
         traj = _dev(trajectories, torch.float32, dev)
         G, Tfull, _ = traj.shape
-        cs = _dev(center_state, torch.float32, dev).view(-1, 6)
+        cs = self.stage(center_state, torch.float32).view(-1, 6)
         gper = g_per_group or G // cs.shape[0]
         io = RiftRolloutIO()
         io.trajectories, io.G, io.Tfull, io.G_per_group, io.center_state = traj.data_ptr(), G, Tfull, gper, cs.data_ptr()
@@ -620,12 +665,16 @@ class Engine:
                               near_lane_change: bool = True, bbox_inflation_ratio: float = 1.1):
         """get_other_vehicle_rollout on the device: per-actor arrays (see rift_hip.h) -> (N, T, 4, 2) float64 device tensor."""
         dev = self.device
-        f64 = lambda a: _dev(torch.as_tensor(np.asarray(a, dtype=np.float64)), torch.float64, dev)
-        act = f64(np.stack([np.asarray(steer, dtype=np.float64), np.asarray(throttle, dtype=np.float64), np.asarray(brake, dtype=np.float64)], -1))
-        N = act.shape[0]
+        f64 = lambda a: np.asarray(a.cpu() if torch.is_tensor(a) else a, dtype=np.float64)    # noqa: E731
+        act_h = np.stack([f64(steer), f64(throttle), f64(brake)], -1)
+        N = act_h.shape[0]
         out = torch.empty(N, num_future_frames, 4, 2, dtype=torch.float64, device=dev)
         if N:
-            sp, loc, yaw, ext = f64(speed), f64(location), f64(yaw_deg), f64(extent)
+            # the five per-actor arrays in ONE upload: [controls (N,3) | speed (N) | location (N,3) | yaw (N) | extent (N,2)] as blocks of one buffer
+            blocks = [act_h.reshape(-1), f64(speed).reshape(-1), f64(location).reshape(-1), f64(yaw_deg).reshape(-1), f64(extent).reshape(-1)]
+            assert [b.size for b in blocks] == [3 * N, N, 3 * N, N, 2 * N], "per-actor arrays of different lengths"
+            up = self.stage(np.concatenate(blocks), torch.float64)
+            act, sp, loc, yaw, ext = up[:3 * N], up[3 * N:4 * N], up[4 * N:7 * N], up[7 * N:8 * N], up[8 * N:]
             self._check(self.lib.rift_other_vehicle_rollout(self.ctx, _ptr(act), _ptr(sp), _ptr(loc), _ptr(yaw), _ptr(ext), N, num_future_frames,
                                                             1 if near_lane_change else 0, float(bbox_inflation_ratio), _ptr(out), _stream()),
                         "rift_other_vehicle_rollout")
@@ -663,7 +712,7 @@ class Engine:
         dev = self.device
         rc = _dev(rollout_center, torch.float32, dev)
         G, T = rc.shape[:2]
-        m = _dev(torch.as_tensor(off_road_mask), torch.uint8, dev)
+        m = self.stage(off_road_mask, torch.uint8)
         H, W = m.shape
         out = torch.empty(G, T, dtype=torch.uint8, device=dev)
         self._check(self.lib.rift_off_road_matrix(self.ctx, _ptr(rc), G * T, _ptr(m), H, W, float(origin[0]), float(origin[1]), float(heading),
@@ -752,7 +801,7 @@ class Engine:
     def rollout_return(self, delta_dis, delta_angle, speed, acc, ang_vel, ang_acc, collision, off_road, gamma=0.98):
         dev = self.device
         f = [_dev(t, torch.float32, dev) for t in (delta_dis, delta_angle, speed, acc, ang_vel, ang_acc)]
-        col, off = _dev(collision, torch.bool, dev), _dev(off_road, torch.bool, dev)
+        col, off = self.stage(collision, torch.bool), self.stage(off_road, torch.bool)
         G, Ts = f[1].shape
         out = torch.empty(G, dtype=torch.float64, device=dev)
         self._check(self.lib.rift_rollout_return(self.ctx, *[_ptr(t) for t in f], _ptr(col), col.shape[1], _ptr(off),

@@ -1576,7 +1576,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   // the forward runs serially (get_action, small batches))
   { const char* ev = getenv("RIFT_FRONT_FUSED"); if (ev) c->front_fused = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_EGO_NOFIT"); c->ego_nofit = ev && ev[0] == '1'; }
-  { const char* ev = getenv("RIFT_FRONT_EGO"); if (ev) c->front_ego = atoi(ev) != 0; }        // (1: the ego token as blocks of that launch too -- 116 VGPRs: it no longer fits beside the decoder's workgroups)      // (diagnostic: the fused assembly also writes the token rows, for the x_tokens tap)      // (0: reference lines in rounds of two whole lines, the round-3 form)
+  { const char* ev = getenv("RIFT_FRONT_EGO"); if (ev) c->front_ego = atoi(ev) != 0; }        // (1: the ego token as blocks of that launch too -- 116 VGPRs: it no longer fits beside the decoder's workgroups)
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_JOIN_ONCE"); if (ev) c->join_once = atoi(ev); }

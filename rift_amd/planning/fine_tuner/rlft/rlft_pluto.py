@@ -23,28 +23,9 @@ import torch
 from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
 from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer, split_minibatch
 from rift_amd.planning.pluto.model.pluto_model import PlanningModel
-from rift_amd.planning.pluto.pluto import PLUTO, CBVBasePolicy, CBVStateSource, Candidates, CenterState, NoFlagSource   # noqa: F401 (re-exported)
+from rift_amd.planning.pluto.pluto import (PLUTO, CBVBasePolicy, CBVStateSource, Candidates, CenterState, NoFlagSource,   # noqa: F401 (re-exported)
+                                            capped_host_threads)
 from rift_amd.replay import DeviceReplay
-
-@contextlib.contextmanager
-def capped_host_threads(limit: int):
-    """Cap torch's intra-op thread pool for the duration of an update.  The update's host side is one thread issuing launches plus a few
-    tiny CPU tensor ops per epoch (permutations, index slices); every one of those that enters the intra-op pool wakes ALL its workers,
-    which then spin-wait between regions.  Measured on the GPU box (256 logical CPUs, torch default 128 threads, container quota 16
-    cores): 129 busy threads, 8.9 CPU-seconds inside a 0.5 s update, the cgroup throttled in every 100 ms period -- the launching thread
-    frozen for 60-70 ms five times per update (GPU idle, host stuck inside hipLaunchKernel).  With 4 threads: 0.55 CPU-seconds, no
-    throttling, update 0.52 -> 0.26 s.  The reference runs with torch.set_num_threads(4) throughout (scripts/run.py:133,164); a
-    process that already did the same is left alone."""
-    cur = torch.get_num_threads()
-    capped = bool(limit) and cur > limit
-    if capped:
-        torch.set_num_threads(int(limit))
-    try:
-        yield
-    finally:
-        if capped:
-            torch.set_num_threads(cur)
-
 
 DEFAULT_CFG = {   # fine_tuner/rlft/config/{rift,grpo,ppo,reinforce}_training.yaml + datamodule/*.yaml + lightning/custom_lightning.yaml
     "epochs": 16, "warmup_epochs": 3, "lr": 1e-4, "cl_lr_decay": 0.9, "min_lr": 1e-6, "weight_decay": 1e-5,
@@ -376,20 +357,23 @@ class _GroupRelativePluto(RLFTPluto):
             self._traj_evaluator = TrajEvaluator(self.pluto_model.engine(), dt=self._step_interval)
         return self._traj_evaluator
 
-    def _valid_lines(self, data, index):
-        valid = data["reference_line"]["valid_mask"][index]                     # (R, 120)
-        return valid, valid.any(-1)
-
-    def _group_columns(self, env_id, cbv_id, data, out, index, state, decision) -> Dict[str, Any]:
-        valid, r_valid = self._valid_lines(data, index)
-        pos = data["reference_line"]["position"][index][r_valid]
-        ang = data["reference_line"]["orientation"][index][r_valid]
-        ref_pos = [p[m] for p, m in zip(pos, valid[r_valid])]                   # ragged: only the valid points of each valid line
-        ref_ang = [a[m] for a, m in zip(ang, valid[r_valid])]
+    def _group_columns(self, env_id, cbv_id, obs, data, out, index, state, decision) -> Dict[str, Any]:
+        # the CBV's reference lines come from its own observation (host memory: the rows the collated batch was built from), so the ragged
+        # valid points of every valid line are cut on the host and go up in one piece -- the device-side boolean indexing of the collated
+        # batch was a synchronisation per line
+        rl = obs['raw_pluto_feature'].data["reference_line"]
+        valid = np.asarray(rl["valid_mask"]).astype(np.bool_)                   # (R of this CBV, 120)
+        keep = valid.any(-1)
+        pos, ang = np.asarray(rl["position"]), np.asarray(rl["orientation"])
+        lines = np.nonzero(keep)[0]
+        ref_pos = [pos[r][valid[r]] for r in lines]                             # ragged: only the valid points of each valid line
+        ref_ang = [ang[r][valid[r]] for r in lines]
+        r_valid = np.zeros(out["trajectory"].shape[1], dtype=np.bool_)          # rows of the collated batch (padded to the tick's longest CBV)
+        r_valid[:keep.shape[0]] = keep
         src = self.state_source
         raster = src.off_road_raster(env_id, cbv_id)
         actors = src.nearby_actor_states(env_id, cbv_id)
-        G = int(r_valid.sum()) * 12
+        G = int(keep.sum()) * 12
         kw = {}
         # (a source without these inputs raises NotImplementedError: the reference's advantage always carries both penalties; zeros
         # only when the source says so explicitly or, for collisions, when the CBV has no neighbours right now)
@@ -403,15 +387,27 @@ class _GroupRelativePluto(RLFTPluto):
             kw["collision_matrix"] = np.zeros((G, 40), dtype=np.bool_)
         else:
             kw["nearby_actor_states"] = actors
-        adv = self.traj_evaluator.get_grpo_advantage(state.rollout_tuple(), out["trajectory"][index][r_valid], ref_pos, ref_ang, **kw)
-        logits = decision.probability[r_valid.cpu().numpy()]
+        traj = out["trajectory"][index]
+        if not keep.all() or keep.shape[0] != r_valid.shape[0]:
+            traj = traj[lines.tolist()]
+        # the advantage stays on the device until the tick's last CBV is issued (PLUTO._finish_columns reads every column back then)
+        adv = self.traj_evaluator.get_grpo_advantage(state.rollout_tuple(), traj, ref_pos, ref_ang, to_host=False, **kw)
+        logits = decision.probability[r_valid]
         return {'CBVs_actions_old_group_logits': {'logits': logits, 'valid_mask': np.ones_like(logits, dtype=np.bool_)},
                 'CBVs_group_advantage': adv}
+
+    @staticmethod
+    def _host_line_mask(obs, out) -> np.ndarray:
+        """Valid reference lines of one CBV as a mask over the rows of the tick's collated batch."""
+        keep = np.asarray(obs['raw_pluto_feature'].data["reference_line"]["valid_mask"]).astype(np.bool_).any(-1)
+        mask = np.zeros(out["probability"].shape[1], dtype=np.bool_)
+        mask[:keep.shape[0]] = keep
+        return mask
 
     def _per_cbv(self, env_id, cbv_id, obs, data, out, index, state, decision):
         if self.mode != 'train':
             return {k: None for k in self.EXTRA_COLUMNS}
-        return self._group_columns(env_id, cbv_id, data, out, index, state, decision)
+        return self._group_columns(env_id, cbv_id, obs, data, out, index, state, decision)
 
 
 class RIFTPluto(_GroupRelativePluto):        # fine_tuner/rlft/rift_pluto/rift_pluto.py:18
@@ -440,8 +436,8 @@ class GRPOPluto(_GroupRelativePluto):        # fine_tuner/rlft/grpo_pluto/grpo_p
     def _per_cbv(self, env_id, cbv_id, obs, data, out, index, state, decision):
         cols = super()._per_cbv(env_id, cbv_id, obs, data, out, index, state, decision)
         if self.mode == 'train':
-            r_valid = self._valid_lines(data, index)[1].cpu().numpy()
-            logits = out["ref_probability"][index].cpu().numpy()[r_valid]
+            r_valid = self._host_line_mask(obs, out)
+            logits = self._host(out, "ref_probability")[index][r_valid]
             cols['CBVs_actions_ref_group_logits'] = {'logits': logits, 'valid_mask': np.ones_like(logits, dtype=np.bool_)}
         return cols
 

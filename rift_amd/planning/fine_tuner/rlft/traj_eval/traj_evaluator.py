@@ -27,7 +27,7 @@ class TrajEvaluator:
 
     def get_grpo_advantage(self, center_state, trajectories: torch.Tensor, ref_line_pos: List[torch.Tensor],
                            ref_line_angle: List[torch.Tensor], collision_matrix=None, off_road_matrix=None, gamma: float = 0.98,
-                           other_vehicle_vertices=None, off_road_mask=None, center_pose=None, nearby_actor_states=None):
+                           other_vehicle_vertices=None, off_road_mask=None, center_pose=None, nearby_actor_states=None, to_host: bool = True):
         """center_state: (x, y, heading, speed, width, length) of the CBV rear axle / footprint.
         trajectories: (R, M, 80, 6) raw model output of the valid reference lines.
         collision_matrix (G, >=40) / off_road_matrix (G, >=40): bool flags per candidate and frame, OR
@@ -57,4 +57,5 @@ class TrajEvaluator:
                                  ro["ang_vel"][:, :T].contiguous(), ro["ang_acc"][:, :T].contiguous(),
                                  torch.as_tensor(collision_matrix), torch.as_tensor(off_road_matrix), gamma)
         adv = eng.group_advantage(ret.view(1, G)).view(R, M)
-        return {"advantage": adv.cpu().numpy(), "valid_mask": np.ones((R, M), dtype=np.bool_)}
+        # (to_host=False: the advantage stays a device tensor -- a rollout tick reads all its CBVs' columns back at once)
+        return {"advantage": adv.cpu().numpy() if to_host else adv, "valid_mask": np.ones((R, M), dtype=np.bool_)}

@@ -8,6 +8,7 @@ The reference reads the CBV's pose, speed and footprint, its neighbours and the 
 adapter over its data provider (`CarlaStateSource`), tests and offline replays pass recorded states -- the policy itself never imports
 CARLA, and nothing below the source differs between the two.
 """
+import contextlib
 from collections import defaultdict
 from typing import Any, Dict, List, NamedTuple, Optional
 
@@ -192,6 +193,26 @@ class Candidates(NamedTuple):
     probability: np.ndarray        # (R, M) raw logits of this CBV
 
 
+@contextlib.contextmanager
+def capped_host_threads(limit: int):
+    """Cap torch's intra-op thread pool for the duration of an update or a rollout tick.  The update's host side is one thread issuing launches plus a few
+    tiny CPU tensor ops per epoch (permutations, index slices); every one of those that enters the intra-op pool wakes ALL its workers,
+    which then spin-wait between regions.  Measured on the GPU box (256 logical CPUs, torch default 128 threads, container quota 16
+    cores): 129 busy threads, 8.9 CPU-seconds inside a 0.5 s update, the cgroup throttled in every 100 ms period -- the launching thread
+    frozen for 60-70 ms five times per update (GPU idle, host stuck inside hipLaunchKernel).  With 4 threads: 0.55 CPU-seconds, no
+    throttling, update 0.52 -> 0.26 s.  The reference runs with torch.set_num_threads(4) throughout (scripts/run.py:133,164); a
+    process that already did the same is left alone."""
+    cur = torch.get_num_threads()
+    capped = bool(limit) and cur > limit
+    if capped:
+        torch.set_num_threads(int(limit))
+    try:
+        yield
+    finally:
+        if capped:
+            torch.set_num_threads(cur)
+
+
 class PLUTO(CBVBasePolicy):
     name = 'pluto'
     type = 'il'
@@ -214,6 +235,7 @@ class PLUTO(CBVBasePolicy):
         self.controllers = defaultdict(lambda: defaultdict(lambda: PIDController(sample_interval=self._frame_rate)))
         self._state_source: Optional[CBVStateSource] = config.get('state_source')
         self._render = config.get('need_video_render', False)
+        self._host_threads = config.get('host_threads', 4)     # torch intra-op threads during a tick (capped_host_threads; 0: leave them alone)
         self.mode = 'eval'
         if self._render:
             self.reset_render_data()
@@ -276,11 +298,20 @@ class PLUTO(CBVBasePolicy):
             model.need_traj = need
         return data, out
 
+    @staticmethod
+    def _host(out: Dict[str, Any], key: str) -> np.ndarray:
+        """The whole batch of one output on the host, read back ONCE per tick (the per-CBV `.cpu()` of the reference's loop is a device
+        synchronisation each: three to four per CBV and tick)."""
+        cache = out.setdefault("_host", {})
+        if key not in cache:
+            cache[key] = out[key].cpu().numpy()
+        return cache[key]
+
     def _decide(self, out: Dict[str, torch.Tensor], index: int, env_id, cbv_id, state: CenterState) -> Candidates:
         """pluto.py:142-194: trim, choose by learned score, PID control."""
-        cand = out["candidate_trajectories"][index].cpu().numpy().astype(np.float64)
-        prob = out["probability"][index].cpu().numpy()
-        rf = out["output_ref_free_trajectory"][index].cpu().numpy().astype(np.float64) if "output_ref_free_trajectory" in out else None
+        cand = self._host(out, "candidate_trajectories")[index].astype(np.float64)
+        prob = self._host(out, "probability")[index]
+        rf = self._host(out, "output_ref_free_trajectory")[index].astype(np.float64) if "output_ref_free_trajectory" in out else None
         origin = np.array([state.x, state.y], dtype=np.float64)
         kept, score, flat, _, n_mode = trim_candidates(cand, prob, origin, float(state.heading), rf, self._topk)
         best = int(score.argmax())
@@ -298,7 +329,7 @@ class PLUTO(CBVBasePolicy):
         rd["planning_trajectory_list"].append(decision.trajectory)
         rd["candidate_trajectories_list"].append(decision.kept)
         rd["candidate_index_list"].append(decision.best)
-        rd["predictions_list"].append(out["output_prediction"][index].cpu().numpy() if self._use_prediction else None)
+        rd["predictions_list"].append(self._host(out, "output_prediction")[index].copy() if self._use_prediction else None)
 
     def _per_cbv(self, env_id, cbv_id, obs, data, out, index, state: CenterState, decision: Candidates) -> Dict[str, Any]:
         """Extra per-CBV outputs of a policy variant, keyed by the replay-buffer column they fill (none for plain PLUTO)."""
@@ -307,6 +338,14 @@ class PLUTO(CBVBasePolicy):
     EXTRA_COLUMNS: tuple = ()
 
     def get_action(self, CBVs_obs_list, infos, deterministic=False) -> Dict[str, List[Dict[Any, Any]]]:
+        # A tick is small CPU tensor work: torch's full intra-op pool spinning on it eats the container's CPU quota (capped_host_threads).
+        # The cap is set ONCE, at the first tick, and stays (switching the pool size per tick costs more than it saves: measured 88 ms
+        # stalls in one tick of ten); the reference runs under torch.set_num_threads(4) from its entry script (scripts/run.py:133,164).
+        if self._host_threads and torch.get_num_threads() > self._host_threads:
+            torch.set_num_threads(int(self._host_threads))
+        return self._get_action(CBVs_obs_list, infos, deterministic)
+
+    def _get_action(self, CBVs_obs_list, infos, deterministic=False) -> Dict[str, List[Dict[Any, Any]]]:
         result = {key: [{} for _ in range(self.num_scenario)] for key in ('CBVs_actions',) + tuple(self.EXTRA_COLUMNS)}
         for info, CBVs_obs in zip(infos, CBVs_obs_list):
             if not CBVs_obs:
@@ -321,9 +360,22 @@ class PLUTO(CBVBasePolicy):
                     result[key][env_id][cbv_id] = value
                 if self._render:
                     self._record_render(env_id, cbv_id, obs, state, decision, out, index)
+        self._finish_columns(result)
         self.pluto_model.engine().check_finite()            # the reference's isfinite assert on the decoder queries
         self._clean_CBVs(infos, CBVs_obs_list)
         return result
+
+    @staticmethod
+    def _finish_columns(result):
+        """Per-CBV columns a policy variant left on the device (`_per_cbv`) become host arrays here, after the last CBV of the tick was
+        issued: one wait for the whole tick instead of one per CBV."""
+        for envs in result.values():
+            for per_env in envs:
+                for value in per_env.values():
+                    if isinstance(value, dict):
+                        for k, v in value.items():
+                            if torch.is_tensor(v):
+                                value[k] = v.cpu().numpy()
 
     def _clean_CBVs(self, infos, CBVs_obs_list):
         """Drop the PID state of CBVs that left the scene (pluto.py:112-123)."""

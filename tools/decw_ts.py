@@ -9,7 +9,8 @@ import torch
 from rift_amd import _ffi, synthetic as syn
 from tests import helpers as H
 sd = H.weights()
-scenes = [syn.make_scene(i) for i in range(256)]
+RMAX = int(os.environ.get('DEC_TS_R', '6'))          # (reference-line slots of the batch: how the group times move with the tiles of a workgroup)
+scenes = [syn.make_scene(i, r_max=RMAX) for i in range(256)]
 batch = syn.collate_scenes(scenes)
 eng = _ffi.Engine("cuda:0")
 eng.load_state_dict({k: v.clone() for k, v in sd.items()})
@@ -19,7 +20,9 @@ torch.cuda.synchronize()
 ts = eng.tap("dec_ts").view(torch.int64).cpu().numpy()
 ts = ts[ts != 0]
 d = ts[1:] - ts[:-1]
-print("n stamps", len(ts), "total", ts[-1] - ts[0])
+print("n stamps", len(ts), "total", ts[-1] - ts[0], "dbg", os.environ.get("RIFT_DEC_DBG", "0"))
+if os.environ.get("DEC_TS_BRIEF"):
+    sys.exit(0)
 per = ["r2r q (+LN1, xs read)", "r2r k", "r2r v + attn", "r2r out + res + xs write", "m2m q (+LN2, xs read)", "m2m k", "m2m v + attn",
        "m2m out + res + LN3", "cross q", "cross heads 0,1", "cross heads 2,3", "cross out + res + LN4",
        "fc1_0", "fc2_0", "fc1_1", "fc2_1", "fc1_2", "fc2_2", "fc1_3", "fc2_3 + res"]
