@@ -74,7 +74,16 @@ struct RiftCtx {
     bool valid = false, fp32 = false, need_traj = false;
     float *Q = nullptr, *x0p = nullptr, *QF = nullptr, *Hpi = nullptr, *prob = nullptr, *traj = nullptr, *o3[3] = {nullptr, nullptr, nullptr}, *oT[3] = {nullptr, nullptr, nullptr};
     uint8_t* r_kpm = nullptr; int bs = 0, R = 0, nQ = 0;
+    bool dec_pending = false; DecWP dec;      // the planning decoder deferred along with the head (small batches, see dec_defer_max)
   } head[RIFT_DEFER_SLOTS];
+  // (round 4) Below a chip-filling batch a step is the LATENCY of token assembly -> encoder -> decoder on the caller's queue (one workgroup per
+  // scene whatever the batch) while most CUs idle.  Nothing behind the encoder belongs to the frozen trunk's critical path of the NEXT
+  // step, so with the head deferred the decoder goes with it: rift_forward_head_back launches decoder -> head on the caller's update
+  // stream, and the caller's queue holds token assembly -> encoder of step k + 1 beside them.  All its operands live in the forward's
+  // arena (four slots).  dec_defer_max: largest batch it applies to (RIFT_DEC_DEFER; 0 = never).
+  int dec_defer_max = 64;
+  // (Measured and not kept: the deferred decoder on a third stream of the engine's own, so that decoder k would also run beside tail k - 1 --
+  // 0.21 -> 0.40 ms at 32 scenes, with 4 or 8 hardware queues; every stream beyond the four the step uses has made cross-queue waits slower.)
   bool dry = false;
   hipStream_t stream = nullptr;
   std::unordered_map<std::string, Tap> taps;
@@ -1407,6 +1416,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (!Q) { const int rc0 = build_q0(); if (rc0 != RIFT_OK) return rc0; }
   tap(c, "q0", Q, (int64_t)nQ * 128);
 
+  bool dec_deferred = false; DecWP dec_later; memset(&dec_later, 0, sizeof(dec_later));
   dp_exchange(f, 0);                      // (eval forward under data parallelism: the mask slots have not travelled yet)
   const float dp = f.drop ? 0.1f : 0.f;   // pluto_model.py:35,93
   const bool dec_dense = (R > 8 || N > 96) && R <= 16 && N <= 192;      // dense-traffic shapes: the kernel's round-of-eight-tiles variant
@@ -1426,7 +1436,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
     { const char* ev = getenv("RIFT_DEC_DBG"); dq.dbg = ev ? atoi(ev) : 0; }
     c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
-    launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
+    dec_deferred = (flags & RIFT_F_DEFER_HEAD) && bs <= c->dec_defer_max && !c->dry && !c->prof_on && !dq.ts;
+    if (dec_deferred) dec_later = dq;
+    else launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
   } else {
   float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
   float* DAO = A_alloc<float>(c, (size_t)nQ * 128);
@@ -1521,6 +1533,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   hs.prob = out->probability ? out->probability : A_alloc<float>(c, nQ);
   if (hs.need_traj && (f.fp32 || !c->heads_fused))      // layer-wise trajectory heads: their buffers come out of this forward's arena
     for (int i = 0; i < 3; ++i) { hs.oT[i] = A_alloc<float>(c, (size_t)nQ * 256); hs.o3[i] = A_alloc<float>(c, (size_t)nQ * 160); }
+  hs.dec_pending = dec_deferred; hs.dec = dec_later;
   if (flags & RIFT_F_DEFER_HEAD) { if (!c->dry) c->head[c->parity] = hs; }
   else TRY(head_impl(c, hs));
   // hidden_proj / ref_free_decoder on the ego token (pluto_model.py:173-180)
@@ -1580,6 +1593,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
   { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_JOIN_ONCE"); if (ev) c->join_once = atoi(ev); }
+  { const char* ev = getenv("RIFT_DEC_DEFER"); if (ev) c->dec_defer_max = atoi(ev); }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }
@@ -1917,6 +1931,11 @@ int rift_forward_head_back(RiftCtx* c, int back, void* stream) {
   HIPCHK(c, hipSetDevice(c->device));
   const hipStream_t trunk_stream = c->stream;
   c->stream = (hipStream_t)stream; c->dry = false;
+  if (c->head[slot].dec_pending) {          // (the forward left its planning decoder to this call: dec_defer_max)
+    const DecWP dq = c->head[slot].dec;
+    launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
+    c->head[slot].dec_pending = false;
+  }
   const int rc = head_impl(c, c->head[slot]);
   c->head[slot].valid = false;
   c->stream = trunk_stream;

@@ -356,11 +356,13 @@ def test_16bit_operands_stay_in_range_on_carla_magnitudes(ffi, mode):
 
 @pytest.mark.parametrize("mode", ["fp16", "bf16"])
 @pytest.mark.parametrize("site", ["encoder_blocks.3.mlp.fc2.bias", "planning_decoder.decoder_blocks.3.ffn.3.bias", "planning_decoder.decoder_blocks.0.norm1.bias"])
-def test_trunk_kernels_raise_the_non_finite_flag_themselves(ffi, mode, site):
+def test_trunk_kernels_raise_the_non_finite_flag_themselves(ffi, mode, site, monkeypatch):
     """The reference asserts torch.isfinite(q).all() behind every decoder block (planning_decoder.py:175).  Rounds 1-3 raised the device
     flag in the policy-head kernels only (a NaN / Inf in the residual stream reaches q_final); round 4 adds an exponent-bit-pattern test
     -- integer compares, immune to the -fno-honor-nans build of those translation units -- where the rows leave the scene encoder and the
-    decoder.  Checked with the policy head NOT run (a deferred-head forward stops in front of it): the flag is up after the trunk alone."""
+    decoder.  Checked with the policy head NOT run (a deferred-head forward stops in front of it): the flag is up after the trunk alone.
+    (RIFT_DEC_DEFER=0: at this batch size a deferred-head forward would leave the decoder to the head call as well.)"""
+    monkeypatch.setenv("RIFT_DEC_DEFER", "0")
     gold, batch, sd = H.load_case("small")
     data = batch["cur_pluto_feature_torch"]
     eng = _engine(ffi, mode)

@@ -182,12 +182,14 @@ def test_mean_loss_accounting_across_slot_folds(monkeypatch):
     assert tr.pop_mean_loss() == 0.0
 
 
-def test_validation_between_prefetched_training_steps(monkeypatch):
+@pytest.mark.parametrize("nscene", [128, 48])
+def test_validation_between_prefetched_training_steps(monkeypatch, nscene):
     """Training steps whose batch is gathered on the prefetch stream (RLFTTrainer.gather, four batch-buffer sets / activation arenas), with a
     validation step on the caller's stream -- batch-buffer set 0, activation arena 0 -- after every third one, as the update loop interleaves
     them: the host runs ahead, so the gather of the step behind a validation is issued while that validation is still running and must wait
     for it (the trainer's serial-step event).  Losses and parameters equal the run without the prefetch stream bit for bit, and the run
-    without any second stream; 128-scene batches, so that a validation forward is long enough to be overrun."""
+    without any second stream; 128-scene batches, so that a validation forward is long enough to be overrun, and 48-scene batches, where the
+    pipelined steps leave their planning decoder to the deferred head (engine.hip: dec_defer_max) and the validation forwards do not."""
     from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
     from rift_amd.planning.pluto.model.pluto_model import PlanningModel
     from rift_amd.replay import DeviceReplay
@@ -196,8 +198,8 @@ def test_validation_between_prefetched_training_steps(monkeypatch):
     scenes = [syn.make_scene(2000 + i) for i in range(160)]
     sd = H.weights()
     g = torch.Generator().manual_seed(7)
-    train_ix = [torch.randperm(160, generator=g)[:128].to(torch.int32).to(dev) for _ in range(12)]
-    val_ix = torch.arange(128, dtype=torch.int32, device=dev)
+    train_ix = [torch.randperm(160, generator=g)[:nscene].to(torch.int32).to(dev) for _ in range(12)]
+    val_ix = torch.arange(nscene, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     runs = {}
     for mode, (pipeline, prefetch) in {"serial": ("0", "0"), "tail": ("1", "0"), "prefetch": ("1", "1")}.items():
