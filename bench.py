@@ -199,6 +199,7 @@ def main():
                     help="which scaling mode is the headline with N > 1 (the other one is reported beside it). strong (default): the reference's "
                          "256-scene minibatch split over the N GPUs (SURVEY.md 8(e)); weak: 256 scenes per GPU per step (global minibatch 256 x N)")
     ap.add_argument("--no-full-update", action="store_true")
+    ap.add_argument("--no-tick", action="store_true", help="skip the rollout-tick companion (get_action latency for 1 and 8 CBVs)")
     ap.add_argument("--no-carla", action="store_true", help="skip the CARLA-shaped companion step (49 agents, 60 polygons: the shapes train_cbv really produces)")
     ap.add_argument("--no-e2e", action="store_true", help="skip full_update_e2e (RIFTPluto.train() from a full CBVRolloutBuffer to the reloaded inference model)")
     ap.add_argument("--batch", type=int, default=256, help="scenes per minibatch (diagnostic: 32 = what one of 8 ranks runs under strong scaling)")
@@ -521,6 +522,15 @@ def main():
         for shp in ("carla", "carla-ragged"):
             r = shape_step.run(shp, bs=BATCH, precision=args.precision, steps=60, verbose=False)
             carla[shp] = {k: r[k] for k in ("A", "Mp", "tokens", "ms_per_step", "scenes_per_s", "us_per_scene", "per_kernel_ms")}
+    tick = None
+    if world == 1 and rank == 0 and not args.no_tick and BATCH == 256:
+        # companion figure of the rollout side: what the simulator loop waits for every tick
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import tick_latency
+        tick = tick_latency.run(ticks=30, cbvs=(1, 8))
+        tick["note"] = ("host wall time of one `get_action` for K CBVs of one environment at the CARLA shapes (fp16 operands, the policies' default): "
+                        "'pluto/eval' = eval forward with every output -> candidate trimming -> PID; 'rift_pluto/train' = that + the device-side "
+                        "group advantage of every CBV (rollout, neighbour forecast, collision / off-road flags, return, z-score); tools/tick_latency.py")
     if precisions is not None:
         precisions[args.precision] = {k: head[k] for k in keep}
         precisions["note"] = ("the same update steps per compute precision: bf16 / fp16 = the fused kernels on bf16 / fp16 MFMA operands; fp32 = exact "
@@ -565,6 +575,8 @@ def main():
             carla["note"] = ("the same 256-scene update step at the shapes train_cbv produces (49 agent slots, 60 polygon slots, 109 token slots; 'carla-ragged': "
                              "per-scene agent / polygon counts drawn below those caps, as a rollout yields them); token ratio to the benchmark shape 109 / 84 = 1.30")
             line["carla_shape"] = carla
+        if tick is not None:
+            line["rollout_tick"] = tick
         if precisions is not None:
             line["precisions"] = precisions
         if "roofline" in head:

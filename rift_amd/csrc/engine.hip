@@ -1436,7 +1436,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
     { const char* ev = getenv("RIFT_DEC_DBG"); dq.dbg = ev ? atoi(ev) : 0; }
     c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
-    dec_deferred = (flags & RIFT_F_DEFER_HEAD) && bs <= c->dec_defer_max && !c->dry && !c->prof_on && !dq.ts;
+    // (with the trajectory heads on, the tail behind the decoder is longer and the caller's queue carries the prediction head too: measured
+    // worth it up to twice the batch -- 128 scenes 0.419 -> 0.391 ms, 256 scenes 0.707 -> 0.713)
+    dec_deferred = (flags & RIFT_F_DEFER_HEAD) && bs <= c->dec_defer_max * (f.need_traj ? 2 : 1) && !c->dry && !c->prof_on && !dq.ts;
     if (dec_deferred) dec_later = dq;
     else launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
   } else {
