@@ -28,7 +28,7 @@ FAST = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 SPILL_SAFE = ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"]
 UNITS = [("engine", []), ("dec_w", FAST), ("nat_l2w", FAST), ("enc_w", FAST), ("pe_w", FAST), ("fo_w", FAST)]
 FORMATS = [("bf", 0), ("hf", 1)]
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("HIPCC_EXTRA", "").split()      # (HIPCC_EXTRA: diagnostic defines, e.g. -DRIFT_DEC_ARR=1)
 
 
 def hipcc() -> str:

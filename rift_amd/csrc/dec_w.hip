@@ -126,6 +126,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
   int tsn = 0;
 #define DTS() do { if (p.ts && b == 0 && tid == 0 && tsn < 120) p.ts[tsn++] = clock64(); } while (0)
+#ifndef RIFT_DEC_ARR
+#define RIFT_DEC_ARR 0                           // (diagnostic build, tools/decw_arrivals.py: -DRIFT_DEC_ARR=1 -- ten more live registers)
+#endif
+#if RIFT_DEC_ARR
+  int asn = 0;                                   // when each wave ARRIVES at a group boundary: [128 + wave * 112 + boundary]
+#define DTS_ARR() do { if (p.ts && b == 0 && (tid & 63) == 0 && asn < 112) p.ts[128 + (tid >> 6) * 112 + asn++] = clock64(); } while (0)
+#else
+#define DTS_ARR()
+#endif
 
   // a contiguous source of nfrag fragments -> LDS byte offset dst.  Who loads: with R <= 6 waves 6 and 7 own no tile in either tiling, and
   // waves 2 and 3 are alone on their SIMDs among the working waves (6 tiles on 4 SIMDs): those four carry the stream, the waves of the
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     decw_dma_share(reinterpret_cast<const unsigned char*>(src), voff, lds0 + dst, nfrag, lw, ln);   // (one rolled loop: every boundary site carries it)
   };
   // group boundary: my share of the next group has landed; after the barrier everybody's has, and nobody reads the other slot any more
-  auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); DTS(); };
+  auto sync = [&]() { DTS_ARR(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); DTS(); };
   auto W = [&](int slot, int f) { return *reinterpret_cast<const h16x8*>(ring + slot * 32768 + f * 1024 + lane * 16); };
 
   const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.img);
@@ -523,6 +532,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   DTS();
 #undef DTS
+#undef DTS_ARR
 #undef DSITE
 #if RIFT_DROP_STATS
   if (DROP && p.ds.elem) {

@@ -1433,7 +1433,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     dq.stream = f.next_stream(); f.stream_id += 64;
     dq.KV = enc_KT; dq.img = c->decw_img; dq.par = c->decw_par; dq.nonfinite = c->nonfinite;
     RIFT_SET_DS(dq);
-    if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 256); tap(c, "dec_ts", (float*)dq.ts, 512); }
+    if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 1024); tap(c, "dec_ts", (float*)dq.ts, 2048); }      // [0, 128): boundaries of wave 0; [128 + 112 w, ...): arrivals of wave w
     { const char* ev = getenv("RIFT_DEC_DBG"); dq.dbg = ev ? atoi(ev) : 0; }
     c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
     // (with the trajectory heads on, the tail behind the decoder is longer and the caller's queue carries the prediction head too: measured

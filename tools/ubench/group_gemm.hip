@@ -1,5 +1,5 @@
 // What one group GEMM of the wave-private kernels costs (decw_gemm of wp_stream.h: 32 fragments from LDS under 32 MFMAs, eight reads in
-// flight) against the number of waves of a workgroup that run it at once -- separates the MFMA pipe (16 cycles per instruction and SIMD),
+// flight) against the number of waves of a workgroup that run it at once (per cell: wave 0 / the slowest working wave) -- separates the MFMA pipe (16 cycles per instruction and SIMD),
 // the LDS read path and the per-wave latency chain.  Prints s_memtime ticks per GEMM of wave 0, for 1..8 working waves, with and without a
 // workgroup barrier between GEMMs, and for the 16-fragment halves (wp_gemm_half.h).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRIFT_OP_F16=0 -Irift_amd/csrc tools/ubench/group_gemm.hip -o tools/ubench/group_gemm.bin && tools/ubench/group_gemm.bin
@@ -22,11 +22,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int i = 0; i < 8; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const uint32_t base = (uint32_t)(uintptr_t)smem + (uint32_t)lane * 16u;
   const long long t0 = clock64();
+  if (MODE == 4) {          // the first eight reads of GEMM r + 1 issued ahead of the barrier behind GEMM r (a ring that has the next group complete one barrier early)
+    h16x8 w[8];
+    if (wv < nwork) decw_gemm_pre(base, w);
+#pragma unroll 1
+    for (int r = 0; r < reps; ++r) {
+      if (wv < nwork) {
+        decw_gemm_post(base + (uint32_t)(r & 1) * 32768u, w, x, c);
+        decw_gemm_pre(base + (uint32_t)((r + 1) & 1) * 32768u, w);
+      }
+      if (barrier) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else
 #pragma unroll 1
   for (int r = 0; r < reps; ++r) {
+    if (MODE >= 6 && wv >= 4) {          // the second wave of every SIMD starts late: 6: s_sleep 1 (64 cycles), 7: s_sleep 3, 8: s_sleep 6
+      if (MODE == 6) asm volatile("s_sleep 1");
+      if (MODE == 7) asm volatile("s_sleep 3");
+      if (MODE == 8) asm volatile("s_sleep 6");
+    }
     if (wv < nwork) {
       const uint32_t a = base + (uint32_t)(r & 1) * 32768u;
-      if (MODE == 0) decw_gemm<false>(a, x, c);
+      if (MODE == 0 || MODE >= 5) decw_gemm<false>(a, x, c);
       if (MODE == 1) { f32x4 (&c4)[4] = reinterpret_cast<f32x4 (&)[4]>(c); decw_gemm_nhalf(a, x, c4); }
       if (MODE == 2) { h16x8 (&x2)[2] = reinterpret_cast<h16x8 (&)[2]>(x); decw_gemm_khalf(a, x2, c); }
       if (MODE == 3) {        // the shared-FFN arrangement: waves 0-3 a full GEMM, waves 4-7 a k-half each
@@ -34,7 +51,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         else { h16x8 (&x2)[2] = reinterpret_cast<h16x8 (&)[2]>(x); decw_gemm_khalf(a + (uint32_t)((wv >> 1) & 1) * 16384u, x2, c); }
       }
     }
-    if (barrier) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (barrier && (MODE != 5 || (r & 1))) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (MODE 5: a barrier per TWO group GEMMs)
   }
   const long long t1 = clock64();
   float s = 0.f;
@@ -56,7 +73,9 @@ int main() {
         hipDeviceSynchronize();
         std::vector<long long> h(8);
         hipMemcpy(h.data(), out, 64, hipMemcpyDeviceToHost);
-        printf("  %d waves %5.0f", nwork, (double)h[0] / reps);
+        long long mx = 0;
+        for (int w = 0; w < nwork; ++w) mx = h[w] > mx ? h[w] : mx;      // (without a barrier the waves of a SIMD do not finish together: the older one is served first)
+        printf("  %d: %4.0f / %4.0f", nwork, (double)h[0] / reps, (double)mx / reps);
       }
       printf("\n");
     }
@@ -65,5 +84,10 @@ int main() {
   run(k<1>, "n-half 16 fragments");
   run(k<2>, "k-half 16 fragments");
   run(k<3>, "4 full + k-halves  ");
+  run(k<4>, "full, head prefetched");
+  run(k<5>, "full, barrier per 2  ");
+  run(k<6>, "full, skew s_sleep 1 ");
+  run(k<7>, "full, skew s_sleep 3 ");
+  run(k<8>, "full, skew s_sleep 6 ");
   return 0;
 }
