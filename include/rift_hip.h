@@ -345,6 +345,32 @@ typedef struct RiftRolloutIO {
 } RiftRolloutIO;
 int rift_rollout(RiftCtx* ctx, const RiftRolloutIO* io, void* stream);
 
+/* The group-relative advantage of every CBV of one rollout tick in ONE call (RIFTPluto / GRPOPluto.get_action in train mode,
+ * rift_pluto.py:113-135 -> TrajEvaluator.get_grpo_advantage, traj_evaluator.py:422-475): per CBV, in list order (the PID state is shared and
+ * never reset, as in the reference), rift_ref_line_info -> rift_rollout -> rift_other_vehicle_rollout -> rift_collision_matrix ->
+ * rift_off_road_matrix -> rift_rollout_return -> rift_group_advantage on the library's own scratch, i.e. exactly the launches of the seven
+ * calls above without a host round trip between them (the Python tick was ~12 C-ABI calls and ~0.55 ms of host time per CBV).
+ * Every pointer inside RiftTickCBV is a DEVICE pointer (the caller stages a tick's readings in one upload). */
+typedef struct RiftTickCBV {
+  int32_t batch_index;         /* row of `trajectory` (the tick's collated batch) */
+  int32_t R;                   /* this CBV's valid reference lines: candidates (r, m), r < R, of that row (the valid lines are a prefix) */
+  int32_t Pmax;                /* padded points per line of ref_pos / ref_angle */
+  int32_t n_actors;            /* nearby actors (0: none -- no collision flags) */
+  const float* center_state;   /* (6) x, y, heading, speed, width, length (rear axle / footprint) */
+  const float* ref_pos;        /* (R, Pmax, 2) valid points of each valid line, zero padded */
+  const float* ref_angle;      /* (R, Pmax) */
+  const int32_t* ref_len;      /* (R) */
+  const double* actors;        /* [actions (N,3) | speed (N) | location (N,3) | yaw_deg (N) | extent (N,2)] as blocks of one array; NULL with n_actors 0 */
+  const uint8_t* off_road_mask;/* (H, W), 1 = not drivable; NULL: no off-road flags */
+  int32_t H, W;
+  double pose[3];              /* origin x, y and heading of the raster (footprint centre) */
+} RiftTickCBV;
+/* trajectory: (bs, Rb, 12, Tfull, 6) raw model output of the tick's forward; pid: the six BatchPIDTorch arrays of RiftRolloutIO with at least
+ * 12 * max R rows; advantage: (K, Rb, 12) f64, rows r >= R of a CBV are left untouched.  `cbvs` is a HOST array of K entries. */
+int rift_group_advantage_tick(RiftCtx* ctx, const float* trajectory, int Rb, int Tfull, const RiftTickCBV* cbvs, int K,
+                              float* turn_buf, int32_t* turn_ptr, int32_t* turn_len, float* speed_buf, int32_t* speed_ptr, int32_t* speed_len,
+                              double gamma, double* advantage, void* stream);
+
 /* Device-side collation (PlutoFeature.collate, pluto_feature.py:83-94 + RIFTCollate,
  * rift_datamodule.py:33-49): gather `bs` scenes by index from a replay arena whose tensors
  * are stored padded to (A, Mp, Rcap, S) per scene, writing a batch padded to R = batch max. */

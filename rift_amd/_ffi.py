@@ -83,6 +83,12 @@ class RiftRolloutIO(C.Structure):
                 ("closest_index", vp), ("aim_idx", vp)]
 
 
+class RiftTickCBV(C.Structure):        # include/rift_hip.h: one CBV of rift_group_advantage_tick (every pointer a device pointer)
+    _fields_ = [("batch_index", C.c_int32), ("R", C.c_int32), ("Pmax", C.c_int32), ("n_actors", C.c_int32), ("center_state", vp),
+                ("ref_pos", vp), ("ref_angle", vp), ("ref_len", vp), ("actors", vp), ("off_road_mask", vp), ("H", C.c_int32), ("W", C.c_int32),
+                ("pose", C.c_double * 3)]
+
+
 OPERANDS = {"bf16": 0, "fp16": 1}       # RIFT_OPERANDS_* of include/rift_hip.h: the 16-bit MFMA operand format of a context's fused kernels
 EXPORTS = [
     "rift_ctx_create", "rift_ctx_create_ex", "rift_ctx_operand_format", "rift_ctx_destroy", "rift_last_error", "rift_model_load", "rift_forward", "rift_forward_head", "rift_forward_head_back", "rift_loss_backward",
@@ -91,7 +97,7 @@ EXPORTS = [
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
     "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout", "rift_sft_teacher_mode",
     "rift_check_finite", "rift_set_dp", "rift_set_prepare_stream",
-    "rift_comm_unique_id", "rift_comm_init", "rift_comm_all_reduce", "rift_comm_destroy",
+    "rift_comm_unique_id", "rift_comm_init", "rift_comm_all_reduce", "rift_comm_destroy", "rift_group_advantage_tick",
 ]
 CRITIC_NPARAM = 99331
 CRITIC_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -134,6 +140,7 @@ def load_library(variant: str = "") -> C.CDLL:
     lib.rift_comm_unique_id.argtypes = [vp, vp]
     lib.rift_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.rift_comm_all_reduce.argtypes = [vp, vp, C.c_int64, vp]
+    lib.rift_group_advantage_tick.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(RiftTickCBV), C.c_int, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp]
     lib.rift_comm_destroy.argtypes = [vp]
     lib.rift_loss_finalize_clip.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, C.c_float, vp, vp]
     lib.rift_tap.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), vp]
@@ -678,6 +685,82 @@ class Engine:
             self._check(self.lib.rift_other_vehicle_rollout(self.ctx, _ptr(act), _ptr(sp), _ptr(loc), _ptr(yaw), _ptr(ext), N, num_future_frames,
                                                             1 if near_lane_change else 0, float(bbox_inflation_ratio), _ptr(out), _stream()),
                         "rift_other_vehicle_rollout")
+        return out
+
+    def group_advantage_tick(self, trajectory, cbvs, pid_state, gamma: float = 0.98):
+        """The group advantages of one tick's CBVs in one C-ABI call (rift_group_advantage_tick): `trajectory` (bs, Rb, 12, Tfull, 6) the tick's
+        model output (device), `cbvs` a list of dicts in tick order --
+            batch_index, center_state (6), ref_pos / ref_angle (lists of the valid lines' valid points, host), actors (None or the dict of
+            nearby-actor readings of other_vehicle_rollout), off_road (None or (mask (H, W) uint8, (x, y, heading)))
+        -- whose valid reference lines are a prefix of their rows.  Everything host-side goes up in ONE staged copy.  Returns the (K, Rb, 12) f64
+        device tensor; rows r >= R of a CBV are zero."""
+        dev = self.device
+        traj = _dev(trajectory, torch.float32, dev)
+        bs, Rb, M, Tfull, Cc = traj.shape
+        assert M == 12 and Cc == 6
+        K = len(cbvs)
+        # one blob: float64 block | float32 block | int32 block | uint8 block, offsets in BYTES from the blob's start
+        plan = []
+        o64 = o32 = oi = o8 = 0
+        b64, b32, bi, b8 = [], [], [], []
+        for v in cbvs:
+            R = len(v["ref_pos"])
+            Pmax = max(int(p.shape[0]) for p in v["ref_pos"])
+            rp = np.zeros((R, Pmax, 2), dtype=np.float32); ra = np.zeros((R, Pmax), dtype=np.float32)
+            for r in range(R):
+                n = v["ref_pos"][r].shape[0]
+                rp[r, :n] = np.asarray(v["ref_pos"][r], dtype=np.float32); ra[r, :n] = np.asarray(v["ref_angle"][r], dtype=np.float32)
+            rl = np.array([p.shape[0] for p in v["ref_pos"]], dtype=np.int32)
+            cs = np.asarray(v["center_state"], dtype=np.float32).reshape(6)
+            e = {"R": R, "Pmax": Pmax, "cs": o32, "rp": o32 + 6, "ra": o32 + 6 + rp.size, "rl": oi, "N": 0, "act": None, "mask": None}
+            b32 += [cs, rp.reshape(-1), ra.reshape(-1)]; o32 += 6 + rp.size + ra.size
+            pad = (-o32) % 4                     # keep every float32 piece 16-byte aligned
+            if pad: b32.append(np.zeros(pad, dtype=np.float32)); o32 += pad
+            bi.append(rl); oi += R
+            a = v.get("actors")
+            if a is not None:
+                g = lambda x: np.asarray(x.cpu() if torch.is_tensor(x) else x, dtype=np.float64)      # noqa: E731
+                act = np.stack([g(a["steer"]), g(a["throttle"]), g(a["brake"])], -1)
+                N = act.shape[0]
+                blocks = [act.reshape(-1), g(a["speed"]).reshape(-1), g(a["location"]).reshape(-1), g(a["yaw_deg"]).reshape(-1), g(a["extent"]).reshape(-1)]
+                assert [b.size for b in blocks] == [3 * N, N, 3 * N, N, 2 * N], "per-actor arrays of different lengths"
+                if N:
+                    e["N"], e["act"] = N, o64
+                    b64 += blocks; o64 += 10 * N
+            m = v.get("off_road")
+            if m is not None:
+                mask = np.ascontiguousarray(m[0], dtype=np.uint8)
+                e["mask"], e["H"], e["W"], e["pose"] = o8, mask.shape[0], mask.shape[1], [float(m[1][0]), float(m[1][1]), float(m[1][2])]
+                b8.append(mask.reshape(-1)); o8 += mask.size
+                pad = (-o8) % 16
+                if pad: b8.append(np.zeros(pad, dtype=np.uint8)); o8 += pad
+            plan.append(e)
+        n64 = o64 * 8
+        n32 = o32 * 4
+        ni = oi * 4
+        ni_pad = (-(n64 + n32 + ni)) % 16
+        blob = np.concatenate([np.concatenate(b64).view(np.uint8) if b64 else np.zeros(0, np.uint8),
+                               np.concatenate(b32).view(np.uint8), np.concatenate(bi).view(np.uint8), np.zeros(ni_pad, np.uint8)] + b8)
+        up = self.stage(blob, torch.uint8)
+        base = up.data_ptr()
+        base32, basei, base8 = base + n64, base + n64 + n32, base + n64 + n32 + ni + ni_pad
+        arr = (RiftTickCBV * K)()
+        for k, (v, e) in enumerate(zip(cbvs, plan)):
+            t = arr[k]
+            t.batch_index, t.R, t.Pmax, t.n_actors = int(v["batch_index"]), e["R"], e["Pmax"], e["N"]
+            t.center_state, t.ref_pos, t.ref_angle, t.ref_len = base32 + 4 * e["cs"], base32 + 4 * e["rp"], base32 + 4 * e["ra"], basei + 4 * e["rl"]
+            t.actors = (base + 8 * e["act"]) if e["act"] is not None else None
+            if e["mask"] is not None:
+                t.off_road_mask, t.H, t.W = base8 + e["mask"], e["H"], e["W"]
+                t.pose[0], t.pose[1], t.pose[2] = e["pose"]
+        Gmax = 12 * max(e["R"] for e in plan)
+        for k in ("turn_buf", "turn_ptr", "turn_len", "speed_buf", "speed_ptr", "speed_len"):
+            assert pid_state[k].shape[0] >= Gmax
+        out = torch.zeros(K, Rb, 12, dtype=torch.float64, device=dev)
+        self._check(self.lib.rift_group_advantage_tick(self.ctx, _ptr(traj), Rb, Tfull, arr, K, _ptr(pid_state["turn_buf"]), _ptr(pid_state["turn_ptr"]),
+                                                       _ptr(pid_state["turn_len"]), _ptr(pid_state["speed_buf"]), _ptr(pid_state["speed_ptr"]),
+                                                       _ptr(pid_state["speed_len"]), float(gamma), _ptr(out), _stream()), "rift_group_advantage_tick")
+        self._keep_tick = (traj, up)
         return out
 
     def sft_teacher_mode(self, trajectory, teacher_infos, frame_rate: int = 10):

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void rollout_return_kernel(const float* __rest
                                       const float* __restrict__ ang_vel, const float* __restrict__ ang_acc,
                                       const uint8_t* __restrict__ collision, int col_ld,
                                       const uint8_t* __restrict__ off_road, int off_ld, int G, int Ts, double gamma,
-                                      double* __restrict__ ret) {
+                                      double* __restrict__ ret, int ro_ld) {          // ro_ld: row stride of speed / acc / ang_acc (Ts, or the rollout's 80)
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= G) return;
@@ -126,14 +126,14 @@ __global__ __launch_bounds__(256) void rollout_return_kernel(const float* __rest
   for (int j0 = 0; j0 < Ts; j0 += 64) {                     // one round for Ts <= 64
     const int j = j0 + lane;
     const bool live = j < Ts;
-    const size_t o = (size_t)i * Ts + (live ? j : 0);
+    const size_t o = (size_t)i * Ts + (live ? j : 0), o2 = (size_t)i * ro_ld + (live ? j : 0);
     const int col = (live && collision[(size_t)i * col_ld + j]) ? 1 : 0;
     const int off = (live && off_road[(size_t)i * off_ld + j]) ? 1 : 0;
     const unsigned long long hit = __ballot(col);
     const int first = hit ? __ffsll((long long)hit) - 1 : 64;          // lane of the first collision of this round
     double term = 0.0;
     if (live && lane <= first)
-      term = dense_reward(fabsf(delta_dis[o]), fabsf(delta_angle[o]), speed[o], acc[o], ang_acc[o], col, off) * pow(gamma, (double)j);
+      term = dense_reward(fabsf(delta_dis[o]), fabsf(delta_angle[o]), speed[o2], acc[o2], ang_acc[o2], col, off) * pow(gamma, (double)j);
     r += wave_sum_d(term);
     if (hit) break;
   }

@@ -82,6 +82,8 @@ struct RiftCtx {
   // stream, and the caller's queue holds token assembly -> encoder of step k + 1 beside them.  All its operands live in the forward's
   // arena (four slots).  dec_defer_max: largest batch it applies to (RIFT_DEC_DEFER; 0 = never).
   int dec_defer_max = 64;
+  float* ro_raw = nullptr; size_t ro_cap = 0;              // rift_rollout: the unsmoothed speed history handed from the closed-loop kernel to the kinematics kernel
+  char* tick_scratch = nullptr; size_t tick_cap = 0;       // rift_group_advantage_tick: per-CBV intermediates (reused CBV by CBV in stream order)
   // (Measured and not kept: the deferred decoder on a third stream of the engine's own, so that decoder k would also run beside tail k - 1 --
   // 0.21 -> 0.40 ms at 32 scenes, with 4 or 8 hardware queues; every stream beyond the four the step uses has made cross-queue waits slower.)
   bool dry = false;
@@ -1612,6 +1614,8 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
 void rift_ctx_destroy(RiftCtx* c) {
   if (!c) return;
   if (c->comm) { (void)rccl_api(nullptr).CommDestroy(c->comm); c->comm = nullptr; }
+  if (c->tick_scratch) (void)hipFree(c->tick_scratch);
+  if (c->ro_raw) (void)hipFree(c->ro_raw);
   for (void* p : c->owned) (void)hipFree(p);
   for (int i = 0; i < RIFT_DEFER_SLOTS; ++i) if (c->arenas[i]) (void)hipFree(c->arenas[i]);
   if (c->l_S) (void)hipFree(c->l_S);
@@ -2399,7 +2403,7 @@ int rift_rollout_return(RiftCtx* c, const float* delta_dis, const float* delta_a
                         const uint8_t* off_road, int off_road_ld, int G, int Ts, double gamma, double* returns, void* stream) {
   if (!c || G <= 0 || Ts <= 0) return RIFT_ERR_ARG;
   hipLaunchKernelGGL(rollout_return_kernel, dim3(cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, delta_dis, delta_angle, speed,
-                     acc, ang_vel, ang_acc, collision, collision_ld, off_road, off_road_ld, G, Ts, gamma, returns);
+                     acc, ang_vel, ang_acc, collision, collision_ld, off_road, off_road_ld, G, Ts, gamma, returns, Ts);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
 }
@@ -2421,8 +2425,78 @@ int rift_rollout(RiftCtx* c, const RiftRolloutIO* io, void* stream) {
   p.speed_buf = io->speed_buf; p.speed_ptr = (int*)io->speed_ptr; p.speed_len = (int*)io->speed_len;
   p.center = io->center; p.angle = io->angle; p.speed = io->speed; p.acc = io->acc; p.ang_vel = io->ang_vel; p.ang_acc = io->ang_acc;
   p.vertices = io->vertices; p.closest_index = (int*)io->closest_index; p.aim_idx = (int*)io->aim_idx;
+  if ((size_t)io->G * RIFT_RO_LEN * 4 > c->ro_cap) {          // the raw speed history between the two kernels (grown behind a device-wide wait)
+    if (c->ro_raw) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->ro_raw); c->ro_raw = nullptr; c->ro_cap = 0; }
+    const size_t cap = std::max((size_t)io->G * 2, (size_t)256) * RIFT_RO_LEN * 4;
+    HIPCHK(c, hipMalloc((void**)&c->ro_raw, cap));
+    c->ro_cap = cap;
+  }
+  p.raw_speed = c->ro_raw;
+  if (!p.center || !p.angle || !p.speed || !p.acc || !p.ang_vel || !p.ang_acc || !p.vertices || !p.closest_index || !p.aim_idx) return RIFT_ERR_ARG;
   hipLaunchKernelGGL(rollout_kernel, dim3(cdiv(io->G, 64)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(rollout_kinematics_kernel, dim3(cdiv(io->G * RIFT_RO_LEN, 256)), dim3(256), 0, (hipStream_t)stream, p);
   HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
+// One rollout tick's group advantages (rift_hip.h): the launches of the per-CBV chain, CBV by CBV in list order, on scratch the context owns
+// (stream-ordered reuse: CBV k + 1's kernels run behind CBV k's on `stream`).
+int rift_group_advantage_tick(RiftCtx* c, const float* trajectory, int Rb, int Tfull, const RiftTickCBV* cbvs, int K,
+                              float* turn_buf, int32_t* turn_ptr, int32_t* turn_len, float* speed_buf, int32_t* speed_ptr, int32_t* speed_len,
+                              double gamma, double* advantage, void* stream) {
+  if (!c || !trajectory || !cbvs || K <= 0 || Rb <= 0 || Tfull < 80 || !advantage || !turn_buf || !turn_ptr || !turn_len || !speed_buf || !speed_ptr || !speed_len) return RIFT_ERR_ARG;
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  constexpr int M = 12, Ts = 40, TR = 80;
+  int Gmax = 0, Nmax = 0;
+  for (int k = 0; k < K; ++k) {
+    const RiftTickCBV& v = cbvs[k];
+    if (v.R <= 0 || v.R > Rb || v.batch_index < 0 || v.Pmax <= 0 || v.n_actors < 0 || !v.center_state || !v.ref_pos || !v.ref_angle || !v.ref_len ||
+        (v.n_actors > 0 && !v.actors) || (v.off_road_mask && (v.H <= 0 || v.W <= 0))) { c->err = "rift_group_advantage_tick: bad entry"; return RIFT_ERR_ARG; }
+    Gmax = std::max(Gmax, v.R * M); Nmax = std::max(Nmax, v.n_actors);
+  }
+  // scratch layout (bytes, 256-aligned pieces)
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t G = (size_t)Gmax;
+  const size_t o_dd = take(G * Ts * 4), o_da = take(G * Ts * 4), o_ci = take(G * Ts * 4);
+  const size_t o_center = take(G * TR * 2 * 4), o_angle = take(G * TR * 4), o_speed = take(G * TR * 4), o_acc = take(G * TR * 4), o_av = take(G * TR * 4),
+               o_aa = take(G * TR * 4), o_vert = take(G * TR * 8 * 4), o_cl = take(G * 79 * 4), o_aim = take(G * 79 * 4);
+  const size_t o_ov = take((size_t)std::max(Nmax, 1) * Ts * 8 * 8), o_col = take(G * Ts), o_offr = take(G * TR), o_ret = take(G * 8);
+  if (off > c->tick_cap) {
+    if (c->tick_scratch) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->tick_scratch); c->tick_scratch = nullptr; c->tick_cap = 0; }
+    HIPCHK(c, hipMalloc((void**)&c->tick_scratch, off * 2));
+    c->tick_cap = off * 2;
+  }
+  char* S = c->tick_scratch;
+  const hipStream_t st = (hipStream_t)stream;
+  for (int k = 0; k < K; ++k) {
+    const RiftTickCBV& v = cbvs[k];
+    const int Gk = v.R * M;
+    const float* traj = trajectory + (size_t)v.batch_index * Rb * M * Tfull * 6;
+    TRY(abi::rift_ref_line_info(c, traj, Gk, Tfull, Ts, M, v.ref_pos, v.ref_angle, v.ref_len, v.Pmax, (float*)(S + o_dd), (float*)(S + o_da), (int32_t*)(S + o_ci), stream));
+    RiftRolloutIO io; memset(&io, 0, sizeof(io));
+    io.trajectories = traj; io.G = Gk; io.Tfull = Tfull; io.G_per_group = Gk; io.center_state = v.center_state;
+    io.turn_buf = turn_buf; io.turn_ptr = turn_ptr; io.turn_len = turn_len; io.speed_buf = speed_buf; io.speed_ptr = speed_ptr; io.speed_len = speed_len;
+    io.center = (float*)(S + o_center); io.angle = (float*)(S + o_angle); io.speed = (float*)(S + o_speed); io.acc = (float*)(S + o_acc);
+    io.ang_vel = (float*)(S + o_av); io.ang_acc = (float*)(S + o_aa); io.vertices = (float*)(S + o_vert);
+    io.closest_index = (int32_t*)(S + o_cl); io.aim_idx = (int32_t*)(S + o_aim);
+    TRY(abi::rift_rollout(c, &io, stream));
+    const int N = v.n_actors;
+    if (N > 0) {
+      const double* a = v.actors;
+      TRY(abi::rift_other_vehicle_rollout(c, a, a + 3 * (size_t)N, a + 4 * (size_t)N, a + 7 * (size_t)N, a + 8 * (size_t)N, N, Ts, 1, 1.1, (double*)(S + o_ov), stream));
+      TRY(abi::rift_collision_matrix(c, io.vertices, Gk, TR, (const double*)(S + o_ov), N, Ts, (uint8_t*)(S + o_col), stream));
+    } else HIPCHK(c, hipMemsetAsync(S + o_col, 0, (size_t)Gk * Ts, st));
+    if (v.off_road_mask)
+      TRY(abi::rift_off_road_matrix(c, io.center, Gk * TR, v.off_road_mask, v.H, v.W, v.pose[0], v.pose[1], v.pose[2], 0.5, -0.5, 200.0, 200.0, (uint8_t*)(S + o_offr), stream));
+    else HIPCHK(c, hipMemsetAsync(S + o_offr, 0, (size_t)Gk * TR, st));
+    hipLaunchKernelGGL(rollout_return_kernel, dim3(cdiv(Gk, 4)), dim3(256), 0, st, (const float*)(S + o_dd), (const float*)(S + o_da), (const float*)io.speed,
+                       (const float*)io.acc, (const float*)io.ang_vel, (const float*)io.ang_acc, (const uint8_t*)(S + o_col), Ts, (const uint8_t*)(S + o_offr), TR,
+                       Gk, Ts, gamma, (double*)(S + o_ret), TR);
+    HIPCHK(c, hipGetLastError());
+    TRY(abi::rift_group_advantage(c, (const double*)(S + o_ret), 1, Gk, advantage + (size_t)k * Rb * M, stream));
+  }
   return RIFT_OK;
 }
 

@@ -2,8 +2,9 @@
 // traj_eval/track_propogate.py:16-780) for gfx950: reference-line deviation of every candidate trajectory and
 // the 79-step closed-loop PID + kinematic-bicycle rollout with Savitzky-Golay kinematics and box corners.
 // One lane = one candidate; the 79 steps are sequential per lane (registers + a per-wave LDS slab holding the
-// candidate's 40-point reference path, its PID ring buffers and its speed / heading history), so a group of
-// G = R*12 candidates is one or two wavefronts.  Replaces 79 x ~40 tiny torch launches per CBV per tick.
+// candidate's 40-point reference path and its PID ring buffers), so a group of G = R*12 candidates is one or two
+// wavefronts; the smoothed kinematics and box corners of the 80 frames are a second kernel, one thread per
+// (candidate, frame).  Replaces 79 x ~40 tiny torch launches per CBV per tick.
 #pragma once
 #include "common.h"
 
@@ -46,11 +47,12 @@ struct RolloutP {
   float* vertices;          // (G,80,4,2)
   int* closest_index;       // (G,79) closest reference index after every step (track_propogate.py:778)
   int* aim_idx;             // (G,79) PID aim waypoint index (track_propogate.py:468)
+  float* raw_speed;         // (G,80) scratch: the unsmoothed speed history, from the closed-loop kernel to the kinematics kernel
 };
 
 #define RIFT_RO_T 40
 #define RIFT_RO_LEN 80
-#define RIFT_RO_LDS_BYTES ((2 * RIFT_RO_T + 2 * RIFT_RO_LEN + 40) * 64 * 4)
+#define RIFT_RO_LDS_BYTES ((2 * RIFT_RO_T + 40) * 64 * 4)
 
 __device__ __forceinline__ float pid_step(float* buf /*[20][64] lane-interleaved*/, int& ptr, int& len, float err, int lane,
                                           float kp, float ki, float kd) {
@@ -69,9 +71,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // RIFT_RO_LDS_BYTES
   float* s_rx = reinterpret_cast<float*>(smem_raw);          // [40][64] reference path x (lane-interleaved: conflict-free)
   float* s_ry = s_rx + RIFT_RO_T * 64;
-  float* s_spd = s_ry + RIFT_RO_T * 64;                      // [80][64] speed history
-  float* s_ang = s_spd + RIFT_RO_LEN * 64;                   // [80][64] heading history
-  float* s_tb = s_ang + RIFT_RO_LEN * 64;                    // [20][64] turn-PID ring buffer
+  float* s_tb = s_ry + RIFT_RO_T * 64;                       // [20][64] turn-PID ring buffer
   float* s_sb = s_tb + 20 * 64;                              // [20][64] speed-PID ring buffer
   const int lane = threadIdx.x;
   const int g = blockIdx.x * 64 + lane;
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutP p) {
   float px = s_rx[lane], py = s_ry[lane], hd = head0, spd = v0;
   int closest = 0;
   if (live) { p.center[((size_t)g * RIFT_RO_LEN) * 2] = px; p.center[((size_t)g * RIFT_RO_LEN) * 2 + 1] = py; }
-  s_spd[lane] = spd; s_ang[lane] = hd;
+  // (the speed / heading histories go to memory: the Savitzky-Golay kinematics and the box corners of all 80 frames are a kernel of their
+  // own, one thread per (candidate, frame) -- as the tail of this kernel they were 80 serial iterations of the one wave it runs as)
+  if (live) { p.raw_speed[(size_t)g * RIFT_RO_LEN] = spd; p.angle[(size_t)g * RIFT_RO_LEN] = hd; }
   const float Lf = -0.090769015f, Lr = 1.4178275f, gain = 0.36848336f, dt = 0.1f;
   for (int step = 0; step < RIFT_RO_LEN - 1; ++step) {
     // ---- local waypoints 9, 19, 29 ahead of the closest reference point (get_local_traj_pos + [9::10])
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutP p) {
       if (d < best) { best = d; bi = j; }
     }
     closest = bi;
-    s_spd[(step + 1) * 64 + lane] = spd; s_ang[(step + 1) * 64 + lane] = hd;
     if (live) {
+      p.raw_speed[(size_t)g * RIFT_RO_LEN + step + 1] = spd; p.angle[(size_t)g * RIFT_RO_LEN + step + 1] = hd;
       p.center[((size_t)g * RIFT_RO_LEN + step + 1) * 2] = px; p.center[((size_t)g * RIFT_RO_LEN + step + 1) * 2 + 1] = py;
       p.closest_index[(size_t)g * (RIFT_RO_LEN - 1) + step] = bi;
       p.aim_idx[(size_t)g * (RIFT_RO_LEN - 1) + step] = aidx;
@@ -169,49 +171,50 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutP p) {
     p.turn_ptr[g] = tptr; p.turn_len[g] = tlen; p.speed_ptr[g] = sptr; p.speed_len[g] = slen;
     for (int i = 0; i < 20; ++i) { p.turn_buf[(size_t)g * 20 + i] = s_tb[i * 64 + lane]; p.speed_buf[(size_t)g * 20 + i] = s_sb[i * 64 + lane]; }
   }
-  // ---- derive_kinematics (track_propogate.py:500-596): SG(5,2) smoothing with reflect padding, central differences
+}
+
+// ---- derive_kinematics (track_propogate.py:500-596): SG(5,2) smoothing with reflect padding, central differences; box corners FL, RL, RR, FR
+// (track_propogate.py:16-74).  One thread per (candidate, frame): every output is a pure function of the two histories.
+__global__ __launch_bounds__(256) void rollout_kinematics_kernel(RolloutP p) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= p.G * RIFT_RO_LEN) return;
+  const int g = e / RIFT_RO_LEN, t = e - g * RIFT_RO_LEN;
+  const float* spd = p.raw_speed + (size_t)g * RIFT_RO_LEN;
+  const float* ang = p.angle + (size_t)g * RIFT_RO_LEN;          // (the heading output IS the raw history)
+  const float* st = p.state + (size_t)(g / p.Gper) * 6;
+  const float width = st[4], length = st[5], dt = 0.1f;
   auto refl = [](int i) { return i < 0 ? -i : (i >= RIFT_RO_LEN ? 2 * (RIFT_RO_LEN - 1) - i : i); };
   const float k0 = -3.0f / 35.0f, k1 = 12.0f / 35.0f, k2 = 17.0f / 35.0f;
-  auto sg = [&](const float* a, int t) {
-    return k0 * a[refl(t - 2) * 64 + lane] + k1 * a[refl(t - 1) * 64 + lane] + k2 * a[t * 64 + lane] +
-           k1 * a[refl(t + 1) * 64 + lane] + k0 * a[refl(t + 2) * 64 + lane];
+  auto sg = [&](const float* a, int i) {
+    return k0 * a[refl(i - 2)] + k1 * a[refl(i - 1)] + k2 * a[i] + k1 * a[refl(i + 1)] + k0 * a[refl(i + 2)];
   };
   auto wrapf = [](float d) { return atan2f(sinf(d), cosf(d)); };
-  // the smoothed series are recomputed on the fly from the LDS histories (5 taps each)
-  if (live) {
-    const float hw = 0.5f * width, hl = 0.5f * length;
-    float yr_prev = 0.f, yr_cur = 0.f, yr_next = 0.f;
-    auto yaw_rate = [&](int t) {
-      if (t == 0) return wrapf(sg(s_ang, 1) - sg(s_ang, 0)) / dt;
-      if (t == RIFT_RO_LEN - 1) return wrapf(sg(s_ang, RIFT_RO_LEN - 1) - sg(s_ang, RIFT_RO_LEN - 2)) / dt;
-      return wrapf(sg(s_ang, t + 1) - sg(s_ang, t - 1)) / (2.0f * dt);
-    };
-    yr_cur = yaw_rate(0); yr_next = yaw_rate(1);
-    for (int t = 0; t < RIFT_RO_LEN; ++t) {
-      const float sp = sg(s_spd, t);
-      float ac;
-      if (t == 0) ac = (sg(s_spd, 1) - sp) / dt;
-      else if (t == RIFT_RO_LEN - 1) ac = (sp - sg(s_spd, t - 1)) / dt;
-      else ac = (sg(s_spd, t + 1) - sg(s_spd, t - 1)) / (2.0f * dt);
-      float ya;
-      if (t == 0) ya = (yr_next - yr_cur) / dt;
-      else if (t == RIFT_RO_LEN - 1) ya = (yr_cur - yr_prev) / dt;
-      else ya = (yr_next - yr_prev) / (2.0f * dt);
-      const size_t o = (size_t)g * RIFT_RO_LEN + t;
-      const float h = s_ang[t * 64 + lane];
-      p.angle[o] = h; p.speed[o] = sp; p.acc[o] = ac; p.ang_vel[o] = yr_cur; p.ang_acc[o] = ya;
-      // box corners FL, RL, RR, FR (track_propogate.py:16-74)
-      const float cc = cosf(h), ss = sinf(h);
-      const float ctx = p.center[o * 2], cty = p.center[o * 2 + 1];
-      const float dxs[4] = {hl, -hl, -hl, hl}, dys[4] = {hw, hw, -hw, -hw};
+  auto yaw_rate = [&](int i) {
+    if (i == 0) return wrapf(sg(ang, 1) - sg(ang, 0)) / dt;
+    if (i == RIFT_RO_LEN - 1) return wrapf(sg(ang, RIFT_RO_LEN - 1) - sg(ang, RIFT_RO_LEN - 2)) / dt;
+    return wrapf(sg(ang, i + 1) - sg(ang, i - 1)) / (2.0f * dt);
+  };
+  const float sp = sg(spd, t);
+  float ac;
+  if (t == 0) ac = (sg(spd, 1) - sp) / dt;
+  else if (t == RIFT_RO_LEN - 1) ac = (sp - sg(spd, t - 1)) / dt;
+  else ac = (sg(spd, t + 1) - sg(spd, t - 1)) / (2.0f * dt);
+  const float yr_cur = yaw_rate(t);
+  float ya;
+  if (t == 0) ya = (yaw_rate(1) - yr_cur) / dt;
+  else if (t == RIFT_RO_LEN - 1) ya = (yr_cur - yaw_rate(t - 1)) / dt;
+  else ya = (yaw_rate(t + 1) - yaw_rate(t - 1)) / (2.0f * dt);
+  const size_t o = (size_t)g * RIFT_RO_LEN + t;
+  const float h = ang[t];
+  p.speed[o] = sp; p.acc[o] = ac; p.ang_vel[o] = yr_cur; p.ang_acc[o] = ya;
+  const float hw = 0.5f * width, hl = 0.5f * length;
+  const float cc = cosf(h), ss = sinf(h);
+  const float ctx = p.center[o * 2], cty = p.center[o * 2 + 1];
+  const float dxs[4] = {hl, -hl, -hl, hl}, dys[4] = {hw, hw, -hw, -hw};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        p.vertices[(o * 4 + k) * 2] = (dxs[k] * cc - dys[k] * ss) + ctx;
-        p.vertices[(o * 4 + k) * 2 + 1] = (dxs[k] * ss + dys[k] * cc) + cty;
-      }
-      yr_prev = yr_cur; yr_cur = yr_next;
-      yr_next = (t + 2 < RIFT_RO_LEN) ? yaw_rate(t + 2) : yr_cur;
-    }
+  for (int k = 0; k < 4; ++k) {
+    p.vertices[(o * 4 + k) * 2] = (dxs[k] * cc - dys[k] * ss) + ctx;
+    p.vertices[(o * 4 + k) * 2 + 1] = (dxs[k] * ss + dys[k] * cc) + cty;
   }
 }
 

@@ -360,13 +360,16 @@ class PLUTO(CBVBasePolicy):
                     result[key][env_id][cbv_id] = value
                 if self._render:
                     self._record_render(env_id, cbv_id, obs, state, decision, out, index)
+            self._finish_env(env_id, data, out)
         self._finish_columns(result)
         self.pluto_model.engine().check_finite()            # the reference's isfinite assert on the decoder queries
         self._clean_CBVs(infos, CBVs_obs_list)
         return result
 
-    @staticmethod
-    def _finish_columns(result):
+    def _finish_env(self, env_id, data, out):
+        """Hook behind the last CBV of an environment (a policy variant that evaluates its per-CBV columns for the whole environment at once)."""
+
+    def _finish_columns(self, result):
         """Per-CBV columns a policy variant left on the device (`_per_cbv`) become host arrays here, after the last CBV of the tick was
         issued: one wait for the whole tick instead of one per CBV."""
         for envs in result.values():

@@ -717,6 +717,49 @@ class _RecordedStates:
         return mask, (10.0 + cbv_id, -5.0, 0.3)
 
 
+@pytest.mark.gpu
+def test_fused_tick_equals_the_per_cbv_evaluator_chain(tmp_path):
+    """rift_group_advantage_tick (one C-ABI call and one staged upload per environment and tick) against the per-CBV chain of
+    TrajEvaluator.get_grpo_advantage (config['fused_tick'] = False): the same kernels in the same order on the same inputs, so every
+    column of every tick is equal bit for bit -- over ticks with one to five CBVs, ragged reference-line counts, the shared never-reset
+    PID state carried from tick to tick, and a source that reports no neighbours for some CBVs and no raster for others."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    from rift_amd.planning.pluto.pluto import NoFlagSource
+    torch.cuda.set_device(0)
+
+    class Mixed(_RecordedStates):
+        def nearby_actor_states(self, env_id, cbv_id):
+            if cbv_id % 3 == 0:
+                return None
+            return NoFlagSource.ALL_CLEAR if cbv_id % 5 == 4 else super().nearby_actor_states(env_id, cbv_id)
+
+        def off_road_raster(self, env_id, cbv_id):
+            return NoFlagSource.ALL_CLEAR if cbv_id % 4 == 1 else super().off_road_raster(env_id, cbv_id)
+
+    sd = H.weights()
+    runs = {}
+    for fused in (True, False):
+        cfg = {'num_scenario': 1, 'ROOT_DIR': str(tmp_path), 'model_path': 'ckpt', 'device': 'cuda:0', 'state_source': Mixed(), 'fused_tick': fused}
+        pol = CBV_POLICY_LIST['rift_pluto'](cfg, None)
+        pol.pluto_model.load_state_dict(sd)
+        pol.set_mode('train')
+        cols = []
+        for t, ids in enumerate([[1], [2, 3, 4], [5, 6, 7, 8, 9], [1, 4], [3, 5, 9, 2]]):
+            feats = {c: syn.make_scene(5000 + 16 * t + c, num_agents=12, num_polygons=8, r_min=1, r_max=5)["feature"] for c in ids}
+            obs = {c: {'raw_pluto_feature': PlutoFeature(data=feats[c])} for c in ids}
+            act = pol.get_action([obs], [{'env_id': 0}], deterministic=False)
+            for c in ids:
+                R = int(np.asarray(feats[c]["reference_line"]["valid_mask"]).any(-1).sum())
+                adv = act['CBVs_group_advantage'][0][c]
+                assert adv['advantage'].shape == (R, 12) and adv['advantage'].dtype == np.float64 and adv['valid_mask'].shape == (R, 12)
+                assert np.isfinite(adv['advantage']).all()
+                cols.append((adv['advantage'], act['CBVs_actions_old_group_logits'][0][c]['logits'], np.asarray(act['CBVs_actions'][0][c])))
+        runs[fused] = cols
+        pol.pluto_model.release_engine()
+    for (a0, l0, c0), (a1, l1, c1) in zip(runs[True], runs[False]):
+        assert np.array_equal(a0, a1) and np.array_equal(l0, l1) and np.array_equal(c0, c1)
+
+
 def test_state_source_contract():
     """The group advantage never runs on silently missing inputs: a source that does not implement the neighbour / raster readings fails
     the train-mode tick (the reference always feeds both, rift_pluto.py:113-135); the PID gets the CENTRE speed (pluto.py:252), the
