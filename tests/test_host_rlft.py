@@ -760,6 +760,71 @@ def test_fused_tick_equals_the_per_cbv_evaluator_chain(tmp_path):
         assert np.array_equal(a0, a1) and np.array_equal(l0, l1) and np.array_equal(c0, c1)
 
 
+@pytest.mark.gpu
+def test_staging_arena_wraps_and_large_inputs_take_the_ordinary_path():
+    """Engine.stage (pinned arena + asynchronous copies for a tick's small host inputs): contents and dtypes survive the trip, the arena
+    wraps behind a stream synchronisation once its 8 MiB are used up (40 x 300 KB here), inputs above a quarter of it and empty ones take
+    the ordinary upload, device tensors pass through."""
+    from rift_amd import _ffi
+    torch.cuda.set_device(0)
+    eng = _ffi.Engine("cuda:0")
+    g = np.random.default_rng(3)
+    for k in range(40):
+        a = g.normal(size=(75, 1000)).astype(np.float32)             # 300 KB
+        b = (g.random(1000) < 0.5)
+        c = g.integers(-5, 5, size=(17, 3)).astype(np.int32)
+        da, db, dc = eng.stage(a, torch.float32), eng.stage(b, torch.bool), eng.stage(torch.from_numpy(c), torch.int32)
+        assert da.dtype == torch.float32 and db.dtype == torch.bool and dc.dtype == torch.int32 and da.is_cuda
+        assert np.array_equal(da.cpu().numpy(), a) and np.array_equal(db.cpu().numpy(), b) and np.array_equal(dc.cpu().numpy(), c), k
+    assert eng._stage_off < eng._STAGE_BYTES
+    big = g.normal(size=(3 << 20,)).astype(np.float32)               # 12 MB: not through the arena
+    off = eng._stage_off
+    assert np.array_equal(eng.stage(big, torch.float32).cpu().numpy(), big) and eng._stage_off == off
+    assert eng.stage(np.zeros((0, 4), np.float64), torch.float64).shape == (0, 4)
+    d64 = eng.stage(np.arange(7, dtype=np.float32), torch.float64)   # conversion on the host
+    assert d64.dtype == torch.float64 and np.array_equal(d64.cpu().numpy(), np.arange(7, dtype=np.float64))
+    t = torch.arange(5, device="cuda:0", dtype=torch.float32)
+    assert eng.stage(t, torch.float32).data_ptr() == t.data_ptr()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_tick_with_a_gap_in_the_valid_lines_falls_back_to_the_chain(tmp_path):
+    """The fused tick call takes CBVs whose valid reference lines are a prefix of their rows (what PlutoFeature produces).  A CBV with an
+    all-invalid line BETWEEN valid ones sends the whole environment through the per-CBV chain, in tick order; both policies agree bit for
+    bit, and a 12-CBV tick (its rasters exceed the staged-upload limit) goes through the fused call on the ordinary upload path."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    sd = H.weights()
+    runs = {}
+    for fused in (True, False):
+        cfg = {'num_scenario': 1, 'ROOT_DIR': str(tmp_path), 'model_path': 'ckpt', 'device': 'cuda:0', 'state_source': _RecordedStates(), 'fused_tick': fused}
+        pol = CBV_POLICY_LIST['rift_pluto'](cfg, None)
+        pol.pluto_model.load_state_dict(sd)
+        pol.set_mode('train')
+        calls = []
+        eng = pol.traj_evaluator.engine
+        orig = eng.group_advantage_tick
+        eng.group_advantage_tick = lambda *a, **k: (calls.append(len(a[1])), orig(*a, **k))[1]
+        cols = []
+        for t, ids in enumerate([[1, 2, 3], list(range(1, 13))]):
+            feats = {c: syn.make_scene(6100 + 16 * t + c, num_agents=12, num_polygons=8, r_min=3, r_max=5)["feature"] for c in ids}
+            if t == 0:
+                feats[2]["reference_line"]["valid_mask"][1] = False          # a gap: lines 0 and 2.. stay valid
+            obs = {c: {'raw_pluto_feature': PlutoFeature(data=feats[c])} for c in ids}
+            act = pol.get_action([obs], [{'env_id': 0}], deterministic=False)
+            for c in ids:
+                R = int(np.asarray(feats[c]["reference_line"]["valid_mask"]).any(-1).sum())
+                adv = act['CBVs_group_advantage'][0][c]['advantage']
+                assert adv.shape == (R, 12) and np.isfinite(adv).all()
+                cols.append(adv)
+        assert calls == ([12] if fused else []), calls                    # the gap tick never reached the fused call
+        runs[fused] = cols
+        pol.pluto_model.release_engine()
+    for a0, a1 in zip(runs[True], runs[False]):
+        assert np.array_equal(a0, a1)
+
+
 def test_state_source_contract():
     """The group advantage never runs on silently missing inputs: a source that does not implement the neighbour / raster readings fails
     the train-mode tick (the reference always feeds both, rift_pluto.py:113-135); the PID gets the CENTRE speed (pluto.py:252), the
