@@ -293,7 +293,15 @@ class Engine:
     # ---- small host inputs (the rollout tick's per-CBV readings) ---------------------------------
     _STAGE_BYTES = 8 << 20
     _NP_OF = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8,
-              torch.bool: np.bool_}
+              torch.int8: np.int8, torch.bool: np.bool_}
+
+    def stage_tree(self, data):
+        """A nested dict of CPU tensors (a collated feature batch) -> the same dict on the device, every leaf through stage()."""
+        if isinstance(data, dict):
+            return {k: self.stage_tree(v) for k, v in data.items()}
+        if torch.is_tensor(data):
+            return self.stage(data, data.dtype) if data.dtype in self._NP_OF else data.to(self.device)
+        raise NotImplementedError(type(data))
 
     def stage(self, a, dtype: torch.dtype) -> torch.Tensor:
         """Host array / CPU tensor -> device tensor of `dtype` through a pinned arena and an ASYNCHRONOUS copy on the current stream.

@@ -362,6 +362,9 @@ class _GroupRelativePluto(RLFTPluto):
         if self._traj_evaluator is None:
             from rift_amd.planning.fine_tuner.rlft.traj_eval.traj_evaluator import TrajEvaluator
             self._traj_evaluator = TrajEvaluator(self.pluto_model.engine(), dt=self._step_interval)
+        eng = self.pluto_model._engine
+        if eng is not None and self._traj_evaluator.engine is not eng:      # the model re-bound (precision / device change): the PID state is torch's, it carries over
+            self._traj_evaluator.engine = eng
         return self._traj_evaluator
 
     def _group_columns(self, env_id, cbv_id, obs, data, out, index, state, decision) -> Dict[str, Any]:

@@ -268,32 +268,35 @@ class PlanningModel(TorchModuleWrapper):
         """What the engine's packed weight images depend on: storage and content version of every tensor it PACKS.  pi_head, the critic and
         the BatchNorm running statistics are read / written in place through their pointers at launch time (Engine.load_state_dict), so
         an in-place update of those (an optimizer step, RLFTPluto.train's refresh of the inference model) needs no re-bind: storage only."""
-        tensors = self._packed_tensors()
-        return tuple([t.data_ptr() for _, _, t, _ in tensors] + [t._version for _, _, t, is_live in tensors if not is_live])
+        every, packed = self._packed_tensors()
+        return tuple([t.data_ptr() for t in every] + [t._version for t in packed])
 
     def _packed_tensors(self):
-        """[(owning dict, key, tensor, live)] of every parameter and buffer, cached: the module walk of named_parameters() / named_buffers()
-        was 1.8 ms per call, twice per rollout tick (tools/tick_latency.py).  The cache is re-validated on every call against the module
-        tree itself -- each module still holds the same number of parameters / buffers / children, every child and every tensor is still
-        the same object in its owner's dict -- so a replaced Parameter (load_state_dict(assign=True), setattr) or sub-module rebuilds it."""
+        """(every parameter / buffer, those of them the engine packs), cached: the module walk of named_parameters() / named_buffers() was
+        1.8 ms per call, twice per rollout tick (tools/tick_latency.py).  The cache is re-validated on every call against the module tree
+        itself -- each module still holds the same number of parameters / buffers / children, every child and every tensor is still the
+        same object in its owner's dict -- so a replaced Parameter (load_state_dict(assign=True), setattr) or sub-module rebuilds it."""
         c = self.__dict__.get("_tensor_cache")
         if c is not None:
-            mods, links, tensors = c
-            if all(len(m._parameters) == a and len(m._buffers) == b and len(m._modules) == k for m, a, b, k in mods) and \
-                    all(d.get(k) is ch for d, k, ch in links) and all(d.get(k) is t for d, k, t, _ in tensors):
-                return tensors
+            dicts, links, owners, every, packed, lens = c
+            if [len(d) for d in dicts] == lens and all([d.get(k) is ch for d, k, ch in links]) and all([d.get(k) is t for (d, k), t in zip(owners, every)]):
+                return every, packed
 
         def live(n):
             return n.startswith("planning_decoder.pi_head.") or n.startswith("value_net.") or \
                 n.endswith(".running_mean") or n.endswith(".running_var") or n.endswith(".num_batches_tracked")
-        mods, links, tensors = [], [], []
+        dicts, links, owners, every, packed = [], [], [], [], []
         for prefix, m in self.named_modules():
-            mods.append((m, len(m._parameters), len(m._buffers), len(m._modules)))
+            dicts += [m._parameters, m._buffers, m._modules]
             links += [(m._modules, k, ch) for k, ch in m._modules.items()]
             for d in (m._parameters, m._buffers):
-                tensors += [(d, k, t, live((prefix + "." if prefix else "") + k)) for k, t in d.items() if t is not None]
-        self.__dict__["_tensor_cache"] = (mods, links, tensors)
-        return tensors
+                for k, t in d.items():
+                    if t is not None:
+                        owners.append((d, k)); every.append(t)
+                        if not live((prefix + "." if prefix else "") + k):
+                            packed.append(t)
+        self.__dict__["_tensor_cache"] = (dicts, links, owners, every, packed, [len(d) for d in dicts])
+        return every, packed
 
     def engine(self):
         """Bind (or re-bind after load_state_dict / .to()) the parameter storage to the HIP context.
@@ -327,8 +330,10 @@ class PlanningModel(TorchModuleWrapper):
             self._engine = None
             self._bound_version = None
 
-    def forward(self, data: FeaturesType) -> TargetsType:
-        eng = self.engine()
+    def forward(self, data: FeaturesType, engine=None) -> TargetsType:
+        """`engine`: the result of a self.engine() call the caller made for THIS forward already (the rollout tick binds first, to stage
+        its inputs through the engine's pinned arena): skips the second walk over the parameters."""
+        eng = engine if engine is not None else self.engine()
         self._seed += 1
         out = eng.forward(data, train=self.training, need_traj=self.need_traj, fp32=self.compute_precision == "fp32",
                           no_drop=self._no_drop, seed=self._seed)

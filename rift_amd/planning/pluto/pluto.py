@@ -289,11 +289,12 @@ class PLUTO(CBVBasePolicy):
     @torch.no_grad()
     def _forward(self, CBVs_obs: Dict) -> (Dict, Dict[str, torch.Tensor]):
         """Collate the CBVs of one environment and run the inference model (eval mode, every output)."""
-        data = PlutoFeature.collate([o['raw_pluto_feature'] for o in CBVs_obs.values()]).to_device(self.device).data
         model = self.pluto_model
+        eng = model.engine()                     # bound first: the batch goes up through the engine's pinned staging arena (asynchronous copies
+        data = eng.stage_tree(PlutoFeature.collate([o['raw_pluto_feature'] for o in CBVs_obs.values()]).data)      # instead of ~36 blocking ones)
         need, model.need_traj = model.need_traj, True
         try:
-            out = model(data)
+            out = model(data, engine=eng)
         finally:
             model.need_traj = need
         return data, out
@@ -362,7 +363,8 @@ class PLUTO(CBVBasePolicy):
                     self._record_render(env_id, cbv_id, obs, state, decision, out, index)
             self._finish_env(env_id, data, out)
         self._finish_columns(result)
-        self.pluto_model.engine().check_finite()            # the reference's isfinite assert on the decoder queries
+        eng = self.pluto_model._engine                      # (bound by this tick's forward; engine() would walk the parameters once more)
+        (eng if eng is not None else self.pluto_model.engine()).check_finite()      # the reference's isfinite assert on the decoder queries
         self._clean_CBVs(infos, CBVs_obs_list)
         return result
 
