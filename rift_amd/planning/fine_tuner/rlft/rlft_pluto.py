@@ -350,12 +350,7 @@ class _GroupRelativePluto(RLFTPluto):
         super().__init__(config, logger)
         self._traj_evaluator = None
         self._fused_tick = bool(config.get('fused_tick', True))       # False: the per-CBV evaluator chain (the two are bit-identical, tested)
-        self._tick_pending, self._tick_reads = [], []
-
-    @torch.no_grad()
-    def _forward(self, CBVs_obs):
-        self._tick_pending = []                  # (a tick that raised half-way must not leave its CBVs to the next one)
-        return super()._forward(CBVs_obs)
+        self._tick_columns, self._tick_reads = {}, []
 
     @property
     def traj_evaluator(self):
@@ -367,44 +362,48 @@ class _GroupRelativePluto(RLFTPluto):
             self._traj_evaluator.engine = eng
         return self._traj_evaluator
 
-    def _group_columns(self, env_id, cbv_id, obs, data, out, index, state, decision) -> Dict[str, Any]:
-        """The old-policy logits of the CBV's valid lines now; its group advantage is only RECORDED here (host inputs) and evaluated for all
-        CBVs of the environment at once in _finish_env (rift_group_advantage_tick: one C-ABI call, one staged upload)."""
-        # the CBV's reference lines come from its own observation (host memory: the rows the collated batch was built from), so the ragged
-        # valid points of every valid line are cut on the host -- the device-side boolean indexing of the collated batch was a
-        # synchronisation per line
-        rl = obs['raw_pluto_feature'].data["reference_line"]
-        valid = np.asarray(rl["valid_mask"]).astype(np.bool_)                   # (R of this CBV, 120)
-        keep = valid.any(-1)
-        pos, ang = np.asarray(rl["position"]), np.asarray(rl["orientation"])
-        lines = np.nonzero(keep)[0]
-        r_valid = np.zeros(out["trajectory"].shape[1], dtype=np.bool_)          # rows of the collated batch (padded to the tick's longest CBV)
-        r_valid[:keep.shape[0]] = keep
-        src = self.state_source
-        raster = src.off_road_raster(env_id, cbv_id)
-        actors = src.nearby_actor_states(env_id, cbv_id)
-        # (a source without these inputs raises NotImplementedError: the reference's advantage always carries both penalties; zeros
-        # only when the source says so explicitly or, for collisions, when the CBV has no neighbours right now)
-        if raster is None:
-            raise RuntimeError(f"{type(src).__name__}.off_road_raster returned None: return (mask, pose) or NoFlagSource.ALL_CLEAR")
-        adv = {"advantage": None, "valid_mask": np.ones((int(keep.sum()), 12), dtype=np.bool_)}
-        self._tick_pending.append({
-            "batch_index": index, "center_state": state.rollout_tuple(), "lines": lines,
-            "ref_pos": [pos[r][valid[r]] for r in lines], "ref_angle": [ang[r][valid[r]] for r in lines],     # ragged: only the valid points of each valid line
-            "actors": None if (actors is None or actors is NoFlagSource.ALL_CLEAR) else actors,
-            "off_road": None if raster is NoFlagSource.ALL_CLEAR else raster, "column": adv})
-        logits = decision.probability[r_valid]
-        return {'CBVs_actions_old_group_logits': {'logits': logits, 'valid_mask': np.ones_like(logits, dtype=np.bool_)},
-                'CBVs_group_advantage': adv}
+    def _get_action(self, CBVs_obs_list, infos, deterministic=False):
+        self._tick_reads = []                    # (a tick that raised half-way must not leave its read-backs to the next one)
+        return super()._get_action(CBVs_obs_list, infos, deterministic)
 
-    def _finish_env(self, env_id, data, out):
-        """Group advantages of the environment's CBVs, in tick order (the evaluator's PID state is shared and never reset, as the reference's):
-        one fused call when every CBV's valid reference lines are a prefix of its rows (they are: PlutoFeature pads behind them), else -- or with
-        config['fused_tick'] = False -- the per-CBV chain of TrajEvaluator.get_grpo_advantage.  The results stay on the device until
-        _finish_columns reads the tick back."""
-        pending, self._tick_pending = self._tick_pending, []
-        if not pending:
+    def _begin_env(self, env_id, CBVs_obs, data, out, states):
+        """Train mode: the group advantages of the environment's CBVs are ISSUED here, ahead of the per-CBV decisions, so that the device
+        evaluates them (0.3 ms per CBV, serial through the shared PID state) while the host trims candidates and runs the PIDs of the loop
+        behind it.  The model outputs that loop needs are read back first -- a read-back behind the evaluation would wait for it.  In tick
+        order (the evaluator's PID state is shared and never reset, as the reference's): one fused call (rift_group_advantage_tick: one C-ABI
+        call, one staged upload) when every CBV's valid reference lines are a prefix of its rows (they are: PlutoFeature pads behind them),
+        else -- or with config['fused_tick'] = False -- the per-CBV chain of TrajEvaluator.get_grpo_advantage.  The results stay on the
+        device until _finish_columns reads the tick back."""
+        self._tick_columns = {}
+        if self.mode != 'train':
             return
+        for key in ("candidate_trajectories", "probability", "output_ref_free_trajectory", "ref_probability") + (("output_prediction",) if self._render and self._use_prediction else ()):
+            if key in out:
+                self._host(out, key)
+        src = self.state_source
+        pending = []
+        for index, (cbv_id, obs) in enumerate(CBVs_obs.items()):
+            # the CBV's reference lines come from its own observation (host memory: the rows the collated batch was built from), so the
+            # ragged valid points of every valid line are cut on the host -- the device-side boolean indexing of the collated batch was a
+            # synchronisation per line
+            rl = obs['raw_pluto_feature'].data["reference_line"]
+            valid = np.asarray(rl["valid_mask"]).astype(np.bool_)                   # (R of this CBV, 120)
+            keep = valid.any(-1)
+            pos, ang = np.asarray(rl["position"]), np.asarray(rl["orientation"])
+            lines = np.nonzero(keep)[0]
+            raster = src.off_road_raster(env_id, cbv_id)
+            actors = src.nearby_actor_states(env_id, cbv_id)
+            # (a source without these inputs raises NotImplementedError: the reference's advantage always carries both penalties; zeros
+            # only when the source says so explicitly or, for collisions, when the CBV has no neighbours right now)
+            if raster is None:
+                raise RuntimeError(f"{type(src).__name__}.off_road_raster returned None: return (mask, pose) or NoFlagSource.ALL_CLEAR")
+            column = {"advantage": None, "valid_mask": np.ones((int(keep.sum()), 12), dtype=np.bool_)}
+            self._tick_columns[cbv_id] = column
+            pending.append({
+                "batch_index": index, "center_state": states[cbv_id].rollout_tuple(), "lines": lines,
+                "ref_pos": [pos[r][valid[r]] for r in lines], "ref_angle": [ang[r][valid[r]] for r in lines],     # ragged: only the valid points of each valid line
+                "actors": None if (actors is None or actors is NoFlagSource.ALL_CLEAR) else actors,
+                "off_road": None if raster is NoFlagSource.ALL_CLEAR else raster, "column": column})
         ev = self.traj_evaluator
         prefix = all(len(v["lines"]) and int(v["lines"][-1]) == len(v["lines"]) - 1 for v in pending)
         if self._fused_tick and prefix:
@@ -426,6 +425,12 @@ class _GroupRelativePluto(RLFTPluto):
             if len(v["lines"]) != traj.shape[0] or not prefix:
                 traj = traj[v["lines"].tolist()]
             v["column"]["advantage"] = ev.get_grpo_advantage(v["center_state"], traj, v["ref_pos"], v["ref_angle"], to_host=False, **kw)["advantage"]
+
+    def _group_columns(self, env_id, cbv_id, obs, data, out, index, state, decision) -> Dict[str, Any]:
+        """The old-policy logits of the CBV's valid lines; its group advantage was issued in _begin_env."""
+        logits = decision.probability[self._host_line_mask(obs, out)]
+        return {'CBVs_actions_old_group_logits': {'logits': logits, 'valid_mask': np.ones_like(logits, dtype=np.bool_)},
+                'CBVs_group_advantage': self._tick_columns[cbv_id]}
 
     def _finish_columns(self, result):
         for adv, cols in self._tick_reads:           # one read-back per environment of the tick

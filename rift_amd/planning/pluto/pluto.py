@@ -353,8 +353,10 @@ class PLUTO(CBVBasePolicy):
                 continue
             env_id = info['env_id']
             data, out = self._forward(CBVs_obs)
+            states = {cbv_id: self.state_source.center_state(env_id, cbv_id) for cbv_id in CBVs_obs}
+            self._begin_env(env_id, CBVs_obs, data, out, states)
             for index, (cbv_id, obs) in enumerate(CBVs_obs.items()):
-                state = self.state_source.center_state(env_id, cbv_id)
+                state = states[cbv_id]
                 decision = self._decide(out, index, env_id, cbv_id, state)
                 result['CBVs_actions'][env_id][cbv_id] = decision.control
                 for key, value in self._per_cbv(env_id, cbv_id, obs, data, out, index, state, decision).items():
@@ -367,6 +369,10 @@ class PLUTO(CBVBasePolicy):
         (eng if eng is not None else self.pluto_model.engine()).check_finite()      # the reference's isfinite assert on the decoder queries
         self._clean_CBVs(infos, CBVs_obs_list)
         return result
+
+    def _begin_env(self, env_id, CBVs_obs, data, out, states):
+        """Hook between an environment's forward and its per-CBV decisions (a policy variant that has device work of its own to issue for
+        the whole environment: it then runs beside the host-side candidate trimming and PID of the loop below)."""
 
     def _finish_env(self, env_id, data, out):
         """Hook behind the last CBV of an environment (a policy variant that evaluates its per-CBV columns for the whole environment at once)."""
