@@ -197,6 +197,9 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_DEBUG_STREAMS = os.environ.get("RIFT_DEBUG_STREAMS") == "1"      # (read once: known_stream is entered two or three times per update step)
+
+
 class known_stream:
     """`with known_stream(s):` -- the caller states that `s` IS torch's current stream for the duration (it entered `torch.cuda.stream(s)` or
     read `torch.cuda.current_stream()` itself), which saves the ~7 us lookup in every C-ABI call of the block: eight per update step, a
@@ -206,7 +209,7 @@ class known_stream:
         self.h = C.c_void_p(s.cuda_stream)
 
     def __enter__(self):
-        if os.environ.get("RIFT_DEBUG_STREAMS") == "1":      # the declaration must be true
+        if _DEBUG_STREAMS:                                    # the declaration must be true
             assert self.h.value == torch.cuda.current_stream().cuda_stream, "known_stream(s): s is not torch's current stream"
         _KNOWN_STREAM.stack.append(self.h)
         return self

@@ -71,6 +71,9 @@ struct DecWP {
   int dbg;                      // diagnostic: 1 = skip all compute (weight stream + barriers only), 8 = no stream, 16 = all eight waves carry the stream
   long long* ts;                // optional: clock of wave 0 of workgroup 0 at every group boundary (diagnostic, RIFT_DEC_TS)
   int* nonfinite;               // device flag: raised when a query row leaves the last layer with a NaN / Inf (planning_decoder.py:175)
+  int l0, l1;                   // layers [l0, l1) of the four (l0 even): a launch per half lets a small-batch step run the halves on two queues
+  uint32_t* rng_io;             // (bs, 512, 4) dropout stream states: written by a launch that stops before layer 4, read by one that starts behind layer 0
+                                // (the draws of the two halves are then the ones of a single launch)
   DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 

@@ -117,6 +117,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   DecWRng rng;
 #pragma unroll
   for (int i = 0; i < 4; ++i) rng.x[i] = hash32(p.seed, p.stream + i, (uint32_t)(b * 512 + tid)) | 1u;
+  if (DROP && p.l0 > 0 && p.rng_io) {          // the second half of a split launch carries on where the first one stopped
+    const uint4 st = *reinterpret_cast<const uint4*>(p.rng_io + ((size_t)b * 512 + tid) * 4);
+    rng.x[0] = st.x; rng.x[1] = st.y; rng.x[2] = st.z; rng.x[3] = st.w;
+  }
 #if RIFT_DROP_STATS
   int dsite = 0;                                 // which of the eight dropout sites of a layer the next keep4() calls belong to
   unsigned int dkept[RIFT_DS_DEC_SITES] = {0, 0, 0, 0, 0, 0, 0, 0}, ddrawn[RIFT_DS_DEC_SITES] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -154,9 +158,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const unsigned char* kvimg = reinterpret_cast<const unsigned char*>(p.KV) + (size_t)b * 4 * KVF * 1024;
   const uint32_t OFF_P = 2 * 32768 + (DENSE ? 0 : 96 * XS * 4), OFF_E = OFF_P, OFF_L = OFF_E + DECW_E_N * 4;
   // prologue: first group + the parameter block of layer 0 in flight, then the queries and masks
-  dma(wimg, 0, 32);
-  dma(p.par, OFF_E, 18);
-  dma(p.par + DECW_E_N, OFF_L, 6);
+  dma(wimg + (size_t)p.l0 * DECW_LAYER_FRAGS * 1024, 0, 32);
+  dma(p.par + (size_t)p.l0 * DECW_PAR_LAYER, OFF_E, 18);
+  dma(p.par + (size_t)p.l0 * DECW_PAR_LAYER + DECW_E_N, OFF_L, 6);
   if (!DENSE) {                                 // every query row requested before the first LDS store (as a rolled loop this was six dependent global round trips)
     float4 qv[6];
 #pragma unroll
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // position `pos` of layer li has sequence number li * GL + pos and lands in ring slot (pos & 1) (GL is even).
   auto request = [&](int li, int pos) {          // the group at (li, pos); pos == GL means the first group of the next layer
     if (pos >= GL) { pos = 0; ++li; }
-    if (li >= 4) return;
+    if (li >= p.l1) return;
     const unsigned char* wl = wimg + (size_t)li * DECW_LAYER_FRAGS * 1024;
     const unsigned char* kvl = kvimg + (size_t)li * KVF * 1024;
     const uint32_t dst = (uint32_t)(pos & 1) * 32768u;
@@ -373,15 +377,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sync();
     request(li, pos + 1);
     if (DENSE) {             // both regions of the NEXT layer into the other parity block, any time during this layer
-      if (pos == 0 && li + 1 < 4) dma(p.par + (size_t)(li + 1) * DECW_PAR_LAYER, OFF_P + (uint32_t)((li + 1) & 1) * DECW_PAR_LAYER * 4, 24);
+      if (pos == 0 && li + 1 < p.l1) dma(p.par + (size_t)(li + 1) * DECW_PAR_LAYER, OFF_P + (uint32_t)((li + 1) & 1) * DECW_PAR_LAYER * 4, 24);
     } else {
-      if (pos == 0 && li > 0) dma(p.par + (size_t)li * DECW_PAR_LAYER + DECW_E_N, OFF_L, 6);        // region L of this layer: the previous FFN epilogue is over
-      if (pos == 12 && li + 1 < 4) dma(p.par + (size_t)(li + 1) * DECW_PAR_LAYER, OFF_E, 18);       // region E of the next layer: r2r / m2m are over
+      if (pos == 0 && li > p.l0) dma(p.par + (size_t)li * DECW_PAR_LAYER + DECW_E_N, OFF_L, 6);        // region L of this layer: the previous FFN epilogue is over
+      if (pos == 12 && li + 1 < p.l1) dma(p.par + (size_t)(li + 1) * DECW_PAR_LAYER, OFF_E, 18);       // region E of the next layer: r2r / m2m are over
     }
   };
 
 #pragma unroll 1
-  for (int li = 0; li < 4; ++li) {
+  for (int li = p.l0; li < p.l1; ++li) {
     {   // the lane / wave indices pass through opaque zeros once per layer: otherwise every LDS and DMA address of the 20 groups is
         // hoisted out of this loop as a loop invariant and spilled around it
       int zv, zs;
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int nt = 0; nt < 8; ++nt) { ex = exp_max(ex, res[nt][0]); ex = exp_max(ex, res[nt][1]); ex = exp_max(ex, res[nt][2]); ex = exp_max(ex, res[nt][3]); }
           if (__builtin_amdgcn_ballot_w64(b_ok && nonfinite_exp(ex)) != 0ull && lane == 0 && p.nonfinite) atomicOr(p.nonfinite, 1);
         }
-        if (DENSE || li + 1 < 4) write_xs(res, b_row, b_ok);
+        if (DENSE || li + 1 < p.l1) write_xs(res, b_row, b_ok);
         else if (b_ok) {
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt)
@@ -530,6 +534,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     publish();
   }
+  if (DROP && p.l1 < 4 && p.rng_io)
+    *reinterpret_cast<uint4*>(p.rng_io + ((size_t)b * 512 + tid) * 4) = make_uint4(rng.x[0], rng.x[1], rng.x[2], rng.x[3]);
   DTS();
 #undef DTS
 #undef DTS_ARR

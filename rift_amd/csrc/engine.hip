@@ -81,7 +81,7 @@ struct RiftCtx {
   // step, so with the head deferred the decoder goes with it: rift_forward_head_back launches decoder -> head on the caller's update
   // stream, and the caller's queue holds token assembly -> encoder of step k + 1 beside them.  All its operands live in the forward's
   // arena (four slots).  dec_defer_max: largest batch it applies to (RIFT_DEC_DEFER; 0 = never).
-  int dec_defer_max = 64;
+  int dec_defer_max = 64; bool dec_split = true;            // (RIFT_DEC_SPLIT=0: the deferred decoder as one launch)
   float* ro_raw = nullptr; size_t ro_cap = 0;              // rift_rollout: the unsmoothed speed history handed from the closed-loop kernel to the kinematics kernel
   char* tick_scratch = nullptr; size_t tick_cap = 0;       // rift_group_advantage_tick: per-CBV intermediates (reused CBV by CBV in stream order)
   // (Measured and not kept: the deferred decoder on a third stream of the engine's own, so that decoder k would also run beside tail k - 1 --
@@ -105,6 +105,9 @@ struct RiftCtx {
   float* enc_bqkv[4] = {nullptr, nullptr, nullptr, nullptr};
   int* enc_idx = nullptr; bool enc_fused = true;
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
+  // the per-call diagnostic switches of the environment, read ONCE when the context is made (nine getenv calls per forward were ~10 us of a
+  // call whose host time bounds a small-batch step): RIFT_{PE,PEW,NAT,ENC,DEC}_TS, RIFT_{PEW,DEC}_DBG, RIFT_POISON_ARENA
+  struct { int pe_ts = -1, pew_dbg = 0, pew_ts = 0, nat_ts = 0, enc_ts = 0, dec_ts = 0, dec_dbg = 0, poison_arena = -1; } dg;
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
   bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true; bool pe_pack = true; bool tok_fused = false; bool keep_tokens = false; bool front_fused = false; bool front_ego = false; bool ego_nofit = false;
@@ -615,7 +618,7 @@ static void pe_fill(Fwd& f, PeP& q, const float* F, int Cin, int groups, int n, 
   q.gp = A_alloc<float>(c, (size_t)groups * 256);
   q.out = A_alloc<float>(c, (size_t)groups * 128);
   q.do_stats = f.train ? 1 : 0;
-  { const char* ev = getenv("RIFT_PE_TS"); if (ev && atoi(ev) == n) { q.ts = A_alloc<long long>(c, 64); q.ts_tile = 0; tap(c, "pe_ts", (float*)q.ts, 128); } }
+  { if (c->dg.pe_ts == n) { q.ts = A_alloc<long long>(c, 64); q.ts_tile = 0; tap(c, "pe_ts", (float*)q.ts, 128); } }
 }
 
 static BnFinP bn_fin(RiftCtx* c, const PeP& q, const std::string& name, int C, const float* part, const float* sc, const float* sh,
@@ -714,8 +717,8 @@ void points_encoder_pair(Fwd& f, const float* Fm, int gm, const uint8_t* vm, con
     }
     w.ga = ga; w.hdr = lvblock ? lv.hdr : nullptr;
     w.do_stats = f.train ? 1 : 0;
-    { const char* ev = getenv("RIFT_PEW_DBG"); w.dbg = ev ? atoi(ev) : 0; }
-    { const char* ev = getenv("RIFT_PEW_TS"); if (ev && ev[0] == '1') { w.ts = A_alloc<long long>(c, 128); tap(c, "pew_ts", (float*)w.ts, 256); } }
+    w.dbg = c->dg.pew_dbg;
+    { if (c->dg.pew_ts) { w.ts = A_alloc<long long>(c, 128); tap(c, "pew_ts", (float*)w.ts, 256); } }
     launch_call(c, "pe_w_kernel", [&] { pew_launch(w, grid, c->stream); });
     fa = bn_fin(c, q.a, pm + ".second_mlp.1", 256, w.a.part2, q.a.s2, q.a.t2, xs, 0); fa.cnt = w.a.cnt2; fa.nblk = nwg[0]; fa.nblk_dev = lvblock ? lv.hdr + 2 : nullptr;
     fb = bn_fin(c, q.b, pr + ".second_mlp.1", 256, w.b.part2, q.b.s2, q.b.t2, xs ? xs + 513 : nullptr, 0); fb.cnt = w.b.cnt2; fb.nblk = nwg[1]; fb.nblk_dev = lvblock ? lv.hdr + 3 : nullptr;
@@ -1073,7 +1076,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         NatL0WP q; memset(&q, 0, sizeof(q));
         q.aidx = nat_aidx; q.cnt = nat_cnt;
         q.F9 = F9; q.nseq = nA; q.img = c->l0w_img; q.par = c->l0w_par; q.Oc = Oc[0]; q.Ocb = Ocb[0]; q.Xnext = Xin[1];
-        { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 1) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
+        { if (c->dg.nat_ts == 1) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         q.droppath[0] = f.drop ? dpr[0] : 0.f; q.droppath[1] = f.drop ? dpr[1] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + 2.0 * rows * 27 * 32 + (rows / 2) * 2.0 * 3 * C * 2 * C;
@@ -1096,7 +1099,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         q.X = Xin[2]; q.nseq = nA; q.img = c->l2w_img; q.par = c->l2w_par; q.Oc = Oc[2]; q.Ocb = Ocb[2];
         q.droppath[0] = f.drop ? dpr[4] : 0.f; q.droppath[1] = f.drop ? dpr[5] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
-        { const char* ev = getenv("RIFT_NAT_TS"); if (ev && atoi(ev) == 3) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
+        { if (c->dg.nat_ts == 3) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C);
         const int l2grid = std::min(cdiv(cdiv(nA, 3), 8), c->nat_grid);
         launch_call(c, "nat_l2w_kernel", [&] { l2w_launch(q, l2grid, c->stream); });
@@ -1335,7 +1338,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     }
     ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias"); ep.nonfinite = c->nonfinite;
     RIFT_SET_DS(ep);
-    if (getenv("RIFT_ENC_TS")) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
+    if (c->dg.enc_ts) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
     if (c->dec_fused && R <= 8 && ENC_NW == 8) {   // the decoder kernel will run: emit its cross-attention K | V operand fragments here
       enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * DECW_KV_FRAGS * 512);
@@ -1435,14 +1438,28 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     dq.stream = f.next_stream(); f.stream_id += 64;
     dq.KV = enc_KT; dq.img = c->decw_img; dq.par = c->decw_par; dq.nonfinite = c->nonfinite;
     RIFT_SET_DS(dq);
-    if (getenv("RIFT_DEC_TS")) { dq.ts = A_alloc<long long>(c, 1024); tap(c, "dec_ts", (float*)dq.ts, 2048); }      // [0, 128): boundaries of wave 0; [128 + 112 w, ...): arrivals of wave w
-    { const char* ev = getenv("RIFT_DEC_DBG"); dq.dbg = ev ? atoi(ev) : 0; }
+    if (c->dg.dec_ts) { dq.ts = A_alloc<long long>(c, 1024); tap(c, "dec_ts", (float*)dq.ts, 2048); }      // [0, 128): boundaries of wave 0; [128 + 112 w, ...): arrivals of wave w
+    dq.dbg = c->dg.dec_dbg;
     c->prof_flops = 4.0 * bs * (R * M) * (2.0 * 128 * (384 + 128) * 2 + 2.0 * 128 * 128 * 2 + 4.0 * 128 * 512 + 4.0 * 128 * (N + R + M));
     // (with the trajectory heads on, the tail behind the decoder is longer and the caller's queue carries the prediction head too: measured
     // worth it up to twice the batch -- 128 scenes 0.419 -> 0.391 ms, 256 scenes 0.707 -> 0.713)
-    dec_deferred = (flags & RIFT_F_DEFER_HEAD) && bs <= c->dec_defer_max * (f.need_traj ? 2 : 1) && !c->dry && !c->prof_on && !dq.ts;
-    if (dec_deferred) dec_later = dq;
-    else launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
+    dq.l0 = 0; dq.l1 = 4;
+    const bool dec_may_defer = (flags & RIFT_F_DEFER_HEAD) && bs <= c->dec_defer_max * (f.need_traj ? 2 : 1) && !c->prof_on;      // (the same in the sizing pass)
+    // ... and split: layers 0 - 1 here, behind the encoder, layers 2 - 3 in front of the deferred head -- token assembly + encoder + half a decoder
+    // on the caller's queue against half a decoder + tail on the update stream (9 + 88 + 55 against 55 + 80 us at 32 scenes) instead of 97 against
+    // 190.  The dropout streams of the second launch carry on from the states the first one leaves (rng_io): the draws are a single launch's.
+    // Measured (ms per step, split / one launch): 64 scenes 0.217 / 0.229, 32 scenes 0.20 - 0.21 / 0.20 - 0.21 (the host issues a 32-scene step in 0.15 - 0.2 ms: it
+    // bounds that one now); with the trajectory heads on the caller's queue carries the prediction head as well and the split LOSES (0.30 / 0.26 at 64): off there.
+    uint32_t* rng_io = (dec_may_defer && c->dec_split && !f.need_traj) ? A_alloc<uint32_t>(c, (size_t)bs * 512 * 4) : nullptr;
+    dec_deferred = dec_may_defer && !c->dry && !dq.ts;
+    if (dec_deferred) {
+      dec_later = dq;
+      if (rng_io) {
+        dq.l1 = 2; dq.rng_io = rng_io;
+        launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
+        dec_later.l0 = 2; dec_later.rng_io = rng_io;
+      }
+    } else launch_call(c, "dec_w_kernel", [&] { decw_launch(dq, c->stream); });
   } else {
   float* DQKV = A_alloc<float>(c, (size_t)nQ * 384);
   float* DAO = A_alloc<float>(c, (size_t)nQ * 128);
@@ -1598,7 +1615,15 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_NAT_ASIDE"); if (ev) c->nat_aside = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_JOIN_ONCE"); if (ev) c->join_once = atoi(ev); }
   { const char* ev = getenv("RIFT_DEC_DEFER"); if (ev) c->dec_defer_max = atoi(ev); }
+  { const char* ev = getenv("RIFT_DEC_SPLIT"); if (ev) c->dec_split = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
+  { const char* ev = getenv("RIFT_POISON_ARENA"); if (ev) c->dg.poison_arena = (int)strtol(ev, nullptr, 0) & 0xff; }
+  { const char* ev = getenv("RIFT_PE_TS"); if (ev) c->dg.pe_ts = atoi(ev); }
+  { const char* ev = getenv("RIFT_PEW_DBG"); if (ev) c->dg.pew_dbg = atoi(ev); }
+  { const char* ev = getenv("RIFT_PEW_TS"); c->dg.pew_ts = ev && ev[0] == '1'; }
+  { const char* ev = getenv("RIFT_NAT_TS"); if (ev) c->dg.nat_ts = atoi(ev); }
+  c->dg.enc_ts = getenv("RIFT_ENC_TS") != nullptr; c->dg.dec_ts = getenv("RIFT_DEC_TS") != nullptr;
+  { const char* ev = getenv("RIFT_DEC_DBG"); if (ev) c->dg.dec_dbg = atoi(ev); }
   { const char* ev = getenv("RIFT_FOURIER_UNFUSED"); c->fo_fused = !(ev && ev[0] == '1'); }
   { const char* ev = getenv("RIFT_PE_W"); c->pe_w = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_FO_W"); c->fo_w = !(ev && ev[0] == '0'); }
@@ -1914,7 +1939,7 @@ int rift_forward(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   // diagnostic: RIFT_POISON_ARENA=<byte> fills the scratch arena before every forward (0xFF = NaN pattern), so that a kernel reading
   // scratch it never wrote shows up as NaN / as run-to-run differences instead of depending on what the memory held before
   // (on the prepare stream if the preparation runs there: every other stream of the forward waits for the preparation)
-  { const char* pe = getenv("RIFT_POISON_ARENA"); if (pe && c->arena) HIPCHK(c, hipMemsetAsync(c->arena, (int)strtol(pe, nullptr, 0) & 0xff, c->arena_cap, c->prep_set && !c->prof_on ? c->prep_stream : c->stream)); }
+  if (c->dg.poison_arena >= 0 && c->arena) { HIPCHK(c, hipMemsetAsync(c->arena, c->dg.poison_arena, c->arena_cap, c->prep_set && !c->prof_on ? c->prep_stream : c->stream)); }
   rc = forward_impl(c, B, out, flags, seed);
   c->stream = (hipStream_t)stream;
   if (rc != RIFT_OK) return rc;

@@ -501,9 +501,10 @@ class RLFTTrainer:
                 with torch.cuda.stream(self._side), _ffi.known_stream(self._side):
                     self._side.wait_event(self._ev_loss)          # (the record behind this step's trunk: the latest one when the tail is issued)
                     self.engine.forward_head(back)
-                    for t in extras.values():         # per-step tensors (buffer-wide extras indexed by the minibatch) are read on this stream:
-                        if torch.is_tensor(t) and t.is_cuda:      # keep the caching allocator from recycling them under it
-                            t.record_stream(self._side)
+                    if not getattr(extras, "persistent", False):      # (DeviceReplay's cached batch buffers outlive the step: replay.PersistentBatch)
+                        for t in extras.values():         # per-step tensors (buffer-wide extras indexed by the minibatch) are read on this stream:
+                            if torch.is_tensor(t) and t.is_cuda:      # keep the caching allocator from recycling them under it
+                                t.record_stream(self._side)
                     self.set_loss_inputs(extras)
                     self.engine.loss_backward_raw(self.kind_id, self.li, self.lo)
                     self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
