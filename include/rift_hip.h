@@ -40,9 +40,10 @@ enum {
                               rift_forward (the trunk of the next minibatch) is already under way.  Deferred forwards cycle through
                               RIFT_DEFER_SLOTS activation arenas; before the RIFT_DEFER_SLOTS-th forward after this one the caller must
                               know the deferred head and rift_loss_backward of this one to be finished (an event wait).
-                              Below a chip-filling batch (<= 64 scenes; RIFT_DEC_DEFER=<n> in the environment, 0 = never) the planning
-                              decoder -- frozen weights as well -- is left to rift_forward_head(_back) too: a step is then the latency of
-                              token assembly -> encoder on `stream` beside decoder -> head -> loss -> update on the other one */
+                              Below a chip-filling batch (a measured table of sizes up to 192 scenes; RIFT_DEC_DEFER=<n> in the
+                              environment: bs <= n, 0 = never) the planning decoder -- frozen weights as well -- or its second half is left
+                              to rift_forward_head(_back) too: a step is then the latency of token assembly -> encoder -> decoder layers
+                              0 - 1 on `stream` beside decoder layers 2 - 3 -> head -> loss -> update on the other one */
 };
 /* (four: the front of step k + 1 -- gather, preparation, history and map encoders -- can then run beside step k without waiting for the
  *  head / loss / update of step k - 1: with two arenas that wait closes a cycle of two steps' length through tail -> front -> encoder ->

@@ -80,8 +80,8 @@ struct RiftCtx {
   // scene whatever the batch) while most CUs idle.  Nothing behind the encoder belongs to the frozen trunk's critical path of the NEXT
   // step, so with the head deferred the decoder goes with it: rift_forward_head_back launches decoder -> head on the caller's update
   // stream, and the caller's queue holds token assembly -> encoder of step k + 1 beside them.  All its operands live in the forward's
-  // arena (four slots).  dec_defer_max: largest batch it applies to (RIFT_DEC_DEFER; 0 = never).
-  int dec_defer_max = 64; bool dec_split = true;            // (RIFT_DEC_SPLIT=0: the deferred decoder as one launch)
+  // arena (four slots).  Which batch sizes: forward_impl's measured table, or bs <= RIFT_DEC_DEFER (0 = never).
+  int dec_defer_max = -1; bool dec_split = true;   // (-1: the measured table in forward_impl; RIFT_DEC_DEFER=<n>: bs <= n)            // (RIFT_DEC_SPLIT=0: the deferred decoder as one launch)
   float* ro_raw = nullptr; size_t ro_cap = 0;              // rift_rollout: the unsmoothed speed history handed from the closed-loop kernel to the kinematics kernel
   char* tick_scratch = nullptr; size_t tick_cap = 0;       // rift_group_advantage_tick: per-CBV intermediates (reused CBV by CBV in stream order)
   // (Measured and not kept: the deferred decoder on a third stream of the engine's own, so that decoder k would also run beside tail k - 1 --
@@ -1444,7 +1444,11 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     // (with the trajectory heads on, the tail behind the decoder is longer and the caller's queue carries the prediction head too: measured
     // worth it up to twice the batch -- 128 scenes 0.419 -> 0.391 ms, 256 scenes 0.707 -> 0.713)
     dq.l0 = 0; dq.l1 = 4;
-    const bool dec_may_defer = (flags & RIFT_F_DEFER_HEAD) && bs <= c->dec_defer_max * (f.need_traj ? 2 : 1) && !c->prof_on;      // (the same in the sizing pass)
+    // Which batches: measured per size (profiles/r04_batch_sweep.txt; ms per step with / without): 32 0.18 / 0.23, 64 0.21 / 0.24, 80 0.253 / 0.264, 88 0.259 / 0.254,
+    // 96 0.315 / 0.300, 104 0.325 / 0.321, 112 0.338 / 0.359, 128 0.368 / 0.381, 160 0.433 / 0.440, 192 0.503 / 0.520, 256 0.656 / 0.65 -- a win except between 84 and 108
+    // scenes and at a chip-filling batch.  RIFT_DEC_DEFER=<n> replaces the table by bs <= n (0: never).
+    const bool dec_size_ok = c->dec_defer_max >= 0 ? bs <= c->dec_defer_max : (f.need_traj ? bs <= 128 : (bs <= 84 || (bs >= 108 && bs <= 192)));
+    const bool dec_may_defer = (flags & RIFT_F_DEFER_HEAD) && dec_size_ok && !c->prof_on;      // (the same in the sizing pass)
     // ... and split: layers 0 - 1 here, behind the encoder, layers 2 - 3 in front of the deferred head -- token assembly + encoder + half a decoder
     // on the caller's queue against half a decoder + tail on the update stream (9 + 88 + 55 against 55 + 80 us at 32 scenes) instead of 97 against
     // 190.  The dropout streams of the second launch carry on from the states the first one leaves (rng_io): the draws are a single launch's.
