@@ -93,6 +93,37 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_ffi.RiftTensorDesc) == 8 + 8 + 8 + 8 + 32
 
 
+def test_ctypes_structs_match_the_header_as_a_c_compiler_lays_it_out(tmp_path):
+    """include/rift_hip.h compiled by gcc as C: sizeof and every field offset of the structs the Python binding mirrors (a ctypes Structure
+    that drifts from the header corrupts arguments silently)."""
+    import shutil
+    import subprocess
+    from rift_amd import _ffi
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"RiftTickCBV": _ffi.RiftTickCBV, "RiftRolloutIO": _ffi.RiftRolloutIO, "RiftFeatureBatch": _ffi.RiftFeatureBatch,
+               "RiftOutputs": _ffi.RiftOutputs, "RiftLossIn": _ffi.RiftLossIn, "RiftLossOut": _ffi.RiftLossOut}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rift_hip.h"', 'int main(void) {']
+    for name, st in structs.items():
+        lines.append(f'  printf("{name} %zu", sizeof({name}));')
+        for field, *_ in st._fields_:
+            lines.append(f'  printf(" %zu", offsetof({name}, {field}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(repo, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    for line in out:
+        name, size, *offs = line.split()
+        st = structs[name]
+        assert ctypes.sizeof(st) == int(size), (name, ctypes.sizeof(st), size)
+        assert [getattr(st, f).offset for f, *_ in st._fields_] == [int(o) for o in offs], name
+
+
 def test_product_package_never_touches_the_oracle():
     """oracle/ is test infrastructure: nothing under rift_amd/ may import or reference it."""
     import pathlib
