@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void normalize_unbiased_kernel(float* __restri
 }
 
 // GRPO group z-score (traj_evaluator.py:467-470): one wave per group of G fp64 returns, ddof 0, +1e-5.
-__global__ void group_zscore_kernel(const double* __restrict__ ret, int n_groups, int G, double* __restrict__ adv) {
+__device__ __forceinline__ void group_zscore_body(const double* __restrict__ ret, int n_groups, int G, double* __restrict__ adv) {
   const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (g >= n_groups) return;
@@ -89,6 +89,7 @@ __global__ void group_zscore_kernel(const double* __restrict__ ret, int n_groups
   const double sd = sqrt(wave_sum_d(q) / (double)G) + 1e-5;
   for (int i = lane; i < G; i += 64) adv[(size_t)g * G + i] = (ret[(size_t)g * G + i] - mean) / sd;
 }
+__global__ void group_zscore_kernel(const double* __restrict__ ret, int n_groups, int G, double* __restrict__ adv) { group_zscore_body(ret, n_groups, G, adv); }
 
 // Dense reward (gym_carla/reward/reward_model.py:34-50) with the dtype promotion of the
 // reference environment (numpy 1.24: np.float32 scalar (op) python float -> float64; f32 (op) f32 -> f32).
@@ -112,7 +113,7 @@ __device__ __forceinline__ double dense_reward(float dd_abs, float da_abs, float
 // get_rollout_return (traj_evaluator.py:333-370): one WAVE per candidate, lane j = time step j (Ts <= 64): the 7-term dense reward
 // and gamma^j of every step in parallel, the first colliding step from a ballot (steps after it are dropped, the colliding step
 // itself counts), one wave sum in fp64.  (One lane per candidate walking 40 steps with a double pow each took 39 us per group.)
-__global__ __launch_bounds__(256) void rollout_return_kernel(const float* __restrict__ delta_dis, const float* __restrict__ delta_angle,
+__device__ __forceinline__ void rollout_return_body(const float* __restrict__ delta_dis, const float* __restrict__ delta_angle,
                                       const float* __restrict__ speed, const float* __restrict__ acc,
                                       const float* __restrict__ ang_vel, const float* __restrict__ ang_acc,
                                       const uint8_t* __restrict__ collision, int col_ld,
@@ -139,12 +140,20 @@ __global__ __launch_bounds__(256) void rollout_return_kernel(const float* __rest
   }
   if (lane == 0) ret[i] = r;
 }
+__global__ __launch_bounds__(256) void rollout_return_kernel(const float* __restrict__ delta_dis, const float* __restrict__ delta_angle,
+                                      const float* __restrict__ speed, const float* __restrict__ acc,
+                                      const float* __restrict__ ang_vel, const float* __restrict__ ang_acc,
+                                      const uint8_t* __restrict__ collision, int col_ld,
+                                      const uint8_t* __restrict__ off_road, int off_ld, int G, int Ts, double gamma,
+                                      double* __restrict__ ret, int ro_ld) {
+  rollout_return_body(delta_dis, delta_angle, speed, acc, ang_vel, ang_acc, collision, col_ld, off_road, off_ld, G, Ts, gamma, ret, ro_ld);
+}
 
 // get_other_vehicle_rollout (traj_evaluator.py:160-239): constant-control kinematic-bicycle forecast of the nearby actors
 // (KinematicBicycleModel.forecast_other_vehicles, rift/ego/pdm_lite/kinematic_bicycle_model.py:33-62, constants from
 // rift/ego/pdm_lite/config.py:186-199,336-347), speed-dependent footprint inflation, corners FL RL RR FR in the right-handed frame
 // (compute_agents_vertices, traj_evaluator.py:33-79).  One thread per actor, T sequential steps, all in fp64 as numpy computes it.
-__global__ __launch_bounds__(64) void other_vehicle_rollout_kernel(const double* __restrict__ actions /*(N,3) steer throttle brake*/,
+__device__ __forceinline__ void other_vehicle_rollout_body(const double* __restrict__ actions /*(N,3) steer throttle brake*/,
                                                                    const double* __restrict__ speed, const double* __restrict__ location /*(N,3)*/,
                                                                    const double* __restrict__ yaw_deg, const double* __restrict__ extent /*(N,2)*/,
                                                                    int N, int T, int near_lane_change, double inflation,
@@ -181,12 +190,17 @@ __global__ __launch_bounds__(64) void other_vehicle_rollout_kernel(const double*
     }
   }
 }
+__global__ __launch_bounds__(64) void other_vehicle_rollout_kernel(const double* __restrict__ actions, const double* __restrict__ speed, const double* __restrict__ location,
+                                                                   const double* __restrict__ yaw_deg, const double* __restrict__ extent, int N, int T, int near_lane_change,
+                                                                   double inflation, double* __restrict__ vertices) {
+  other_vehicle_rollout_body(actions, speed, location, yaw_deg, extent, N, T, near_lane_change, inflation, vertices);
+}
 
 // get_collision_matrix (traj_evaluator.py:241-275): the reference builds an STRtree of the other vehicles' footprints per step and
 // calls tree.query(ego_polygon) WITHOUT a predicate, which returns the geometries whose ENVELOPES intersect the candidate's
 // envelope (closed intervals: touching counts) -- so collision[g][j] = any_n AABB(center[g][j]) overlaps AABB(other[n][j]).
 // One thread per (candidate, step); candidate vertices fp32 (exact in fp64), other vertices fp64 as numpy holds them.
-__global__ __launch_bounds__(256) void collision_matrix_kernel(const float* __restrict__ cv /*(G,Tc,4,2)*/, int G, int Tc,
+__device__ __forceinline__ void collision_matrix_body(const float* __restrict__ cv /*(G,Tc,4,2)*/, int G, int Tc,
                                                                const double* __restrict__ ov /*(N,Ts,4,2)*/, int N, int Ts,
                                                                uint8_t* __restrict__ out /*(G,Ts)*/) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -206,10 +220,13 @@ __global__ __launch_bounds__(256) void collision_matrix_kernel(const float* __re
   }
   out[i] = hit;
 }
+__global__ __launch_bounds__(256) void collision_matrix_kernel(const float* __restrict__ cv, int G, int Tc, const double* __restrict__ ov, int N, int Ts, uint8_t* __restrict__ out) {
+  collision_matrix_body(cv, G, Tc, ov, N, Ts, out);
+}
 
 // get_off_road_matrix, lookup part (traj_evaluator.py:299-318): pixel = round(((p - origin) . rot) / resolution_hw + offset) in fp64
 // (np.round = half to even = rint), inside the raster and mask == 1 -> off road.  rot = [[c, -s], [s, c]] of the centre heading.
-__global__ __launch_bounds__(256) void off_road_kernel(const float* __restrict__ pts /*(n,2)*/, int n, const uint8_t* __restrict__ mask, int H,
+__device__ __forceinline__ void off_road_body(const float* __restrict__ pts /*(n,2)*/, int n, const uint8_t* __restrict__ mask, int H,
                                                        int W, double ox, double oy, double c, double s, double res_x, double res_y,
                                                        double off_x, double off_y, uint8_t* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -221,6 +238,10 @@ __global__ __launch_bounds__(256) void off_road_kernel(const float* __restrict__
   uint8_t off = 0;
   if (px >= 0.0 && px < (double)W && py >= 0.0 && py < (double)H) off = mask[(size_t)(int)py * W + (int)px] == 1;
   out[i] = off;
+}
+__global__ __launch_bounds__(256) void off_road_kernel(const float* __restrict__ pts, int n, const uint8_t* __restrict__ mask, int H, int W, double ox, double oy, double c, double s,
+                                                       double res_x, double res_y, double off_x, double off_y, uint8_t* __restrict__ out) {
+  off_road_body(pts, n, mask, H, W, ox, oy, c, s, res_x, res_y, off_x, off_y, out);
 }
 
 // ---------------------------------------------------------------------------

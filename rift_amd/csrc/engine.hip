@@ -37,6 +37,7 @@
 #include "heads_fused.h"
 #include "pi_fused.h"
 #include "rollout.h"
+#include "tick_multi.h"
 
 #define ENC_NW 8
 
@@ -2468,15 +2469,16 @@ int rift_rollout(RiftCtx* c, const RiftRolloutIO* io, void* stream) {
   return RIFT_OK;
 }
 
-// One rollout tick's group advantages (rift_hip.h): the launches of the per-CBV chain, CBV by CBV in list order, on scratch the context owns
-// (stream-ordered reuse: CBV k + 1's kernels run behind CBV k's on `stream`).
+// One rollout tick's group advantages (rift_hip.h).  Everything but the candidate rollouts is independent between the CBVs: one launch per
+// stage serves a chunk of up to RIFT_TICK_CHUNK of them (tick_multi.h) -- reference-line deviations and neighbour forecasts first, then the
+// rollouts CBV by CBV in list order (the shared PID state), then kinematics, flags, returns and z-scores: K + 7 launches instead of 9 K.
 int rift_group_advantage_tick(RiftCtx* c, const float* trajectory, int Rb, int Tfull, const RiftTickCBV* cbvs, int K,
                               float* turn_buf, int32_t* turn_ptr, int32_t* turn_len, float* speed_buf, int32_t* speed_ptr, int32_t* speed_len,
                               double gamma, double* advantage, void* stream) {
   if (!c || !trajectory || !cbvs || K <= 0 || Rb <= 0 || Tfull < 80 || !advantage || !turn_buf || !turn_ptr || !turn_len || !speed_buf || !speed_ptr || !speed_len) return RIFT_ERR_ARG;
   c->err.clear();
   HIPCHK(c, hipSetDevice(c->device));
-  constexpr int M = 12, Ts = 40, TR = 80;
+  constexpr int M = 12, Ts = 40, TR = RIFT_RO_LEN;
   int Gmax = 0, Nmax = 0;
   for (int k = 0; k < K; ++k) {
     const RiftTickCBV& v = cbvs[k];
@@ -2484,47 +2486,56 @@ int rift_group_advantage_tick(RiftCtx* c, const float* trajectory, int Rb, int T
         (v.n_actors > 0 && !v.actors) || (v.off_road_mask && (v.H <= 0 || v.W <= 0))) { c->err = "rift_group_advantage_tick: bad entry"; return RIFT_ERR_ARG; }
     Gmax = std::max(Gmax, v.R * M); Nmax = std::max(Nmax, v.n_actors);
   }
-  // scratch layout (bytes, 256-aligned pieces)
+  // per-CBV scratch (bytes, 256-aligned pieces), one set per CBV of a chunk
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t G = (size_t)Gmax;
   const size_t o_dd = take(G * Ts * 4), o_da = take(G * Ts * 4), o_ci = take(G * Ts * 4);
   const size_t o_center = take(G * TR * 2 * 4), o_angle = take(G * TR * 4), o_speed = take(G * TR * 4), o_acc = take(G * TR * 4), o_av = take(G * TR * 4),
-               o_aa = take(G * TR * 4), o_vert = take(G * TR * 8 * 4), o_cl = take(G * 79 * 4), o_aim = take(G * 79 * 4);
+               o_aa = take(G * TR * 4), o_vert = take(G * TR * 8 * 4), o_cl = take(G * 79 * 4), o_aim = take(G * 79 * 4), o_raw = take(G * TR * 4);
   const size_t o_ov = take((size_t)std::max(Nmax, 1) * Ts * 8 * 8), o_col = take(G * Ts), o_offr = take(G * TR), o_ret = take(G * 8);
-  if (off > c->tick_cap) {
+  const size_t per = off, need = per * (size_t)std::min(K, RIFT_TICK_CHUNK);
+  if (need > c->tick_cap) {
     if (c->tick_scratch) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->tick_scratch); c->tick_scratch = nullptr; c->tick_cap = 0; }
-    HIPCHK(c, hipMalloc((void**)&c->tick_scratch, off * 2));
-    c->tick_cap = off * 2;
+    HIPCHK(c, hipMalloc((void**)&c->tick_scratch, need * 2));
+    c->tick_cap = need * 2;
   }
-  char* S = c->tick_scratch;
   const hipStream_t st = (hipStream_t)stream;
-  for (int k = 0; k < K; ++k) {
-    const RiftTickCBV& v = cbvs[k];
-    const int Gk = v.R * M;
-    const float* traj = trajectory + (size_t)v.batch_index * Rb * M * Tfull * 6;
-    TRY(abi::rift_ref_line_info(c, traj, Gk, Tfull, Ts, M, v.ref_pos, v.ref_angle, v.ref_len, v.Pmax, (float*)(S + o_dd), (float*)(S + o_da), (int32_t*)(S + o_ci), stream));
-    RiftRolloutIO io; memset(&io, 0, sizeof(io));
-    io.trajectories = traj; io.G = Gk; io.Tfull = Tfull; io.G_per_group = Gk; io.center_state = v.center_state;
-    io.turn_buf = turn_buf; io.turn_ptr = turn_ptr; io.turn_len = turn_len; io.speed_buf = speed_buf; io.speed_ptr = speed_ptr; io.speed_len = speed_len;
-    io.center = (float*)(S + o_center); io.angle = (float*)(S + o_angle); io.speed = (float*)(S + o_speed); io.acc = (float*)(S + o_acc);
-    io.ang_vel = (float*)(S + o_av); io.ang_acc = (float*)(S + o_aa); io.vertices = (float*)(S + o_vert);
-    io.closest_index = (int32_t*)(S + o_cl); io.aim_idx = (int32_t*)(S + o_aim);
-    TRY(abi::rift_rollout(c, &io, stream));
-    const int N = v.n_actors;
-    if (N > 0) {
-      const double* a = v.actors;
-      TRY(abi::rift_other_vehicle_rollout(c, a, a + 3 * (size_t)N, a + 4 * (size_t)N, a + 7 * (size_t)N, a + 8 * (size_t)N, N, Ts, 1, 1.1, (double*)(S + o_ov), stream));
-      TRY(abi::rift_collision_matrix(c, io.vertices, Gk, TR, (const double*)(S + o_ov), N, Ts, (uint8_t*)(S + o_col), stream));
-    } else HIPCHK(c, hipMemsetAsync(S + o_col, 0, (size_t)Gk * Ts, st));
-    if (v.off_road_mask)
-      TRY(abi::rift_off_road_matrix(c, io.center, Gk * TR, v.off_road_mask, v.H, v.W, v.pose[0], v.pose[1], v.pose[2], 0.5, -0.5, 200.0, 200.0, (uint8_t*)(S + o_offr), stream));
-    else HIPCHK(c, hipMemsetAsync(S + o_offr, 0, (size_t)Gk * TR, st));
-    hipLaunchKernelGGL(rollout_return_kernel, dim3(cdiv(Gk, 4)), dim3(256), 0, st, (const float*)(S + o_dd), (const float*)(S + o_da), (const float*)io.speed,
-                       (const float*)io.acc, (const float*)io.ang_vel, (const float*)io.ang_acc, (const uint8_t*)(S + o_col), Ts, (const uint8_t*)(S + o_offr), TR,
-                       Gk, Ts, gamma, (double*)(S + o_ret), TR);
+  for (int k0 = 0; k0 < K; k0 += RIFT_TICK_CHUNK) {
+    TickArr a; memset(&a, 0, sizeof(a));
+    a.K = std::min(RIFT_TICK_CHUNK, K - k0); a.gamma = gamma;
+    int gmax = 0, nmax = 0;
+    for (int j = 0; j < a.K; ++j) {
+      const RiftTickCBV& v = cbvs[k0 + j];
+      char* S = c->tick_scratch + per * (size_t)j;
+      TickK& d = a.d[j];
+      d.traj = trajectory + (size_t)v.batch_index * Rb * M * Tfull * 6; d.G = v.R * M; d.Tfull = Tfull; d.Pmax = v.Pmax; d.N = v.n_actors; d.H = v.H; d.W = v.W;
+      d.ref_pos = v.ref_pos; d.ref_ang = v.ref_angle; d.ref_len = (const int*)v.ref_len;
+      d.dd = (float*)(S + o_dd); d.da = (float*)(S + o_da); d.ci = (int*)(S + o_ci);
+      d.actors = v.actors; d.ov = (double*)(S + o_ov);
+      RolloutP& p = d.ro;
+      p.traj = d.traj; p.G = d.G; p.Tfull = Tfull; p.Gper = d.G; p.state = v.center_state;
+      p.turn_buf = turn_buf; p.turn_ptr = (int*)turn_ptr; p.turn_len = (int*)turn_len; p.speed_buf = speed_buf; p.speed_ptr = (int*)speed_ptr; p.speed_len = (int*)speed_len;
+      p.center = (float*)(S + o_center); p.angle = (float*)(S + o_angle); p.speed = (float*)(S + o_speed); p.acc = (float*)(S + o_acc);
+      p.ang_vel = (float*)(S + o_av); p.ang_acc = (float*)(S + o_aa); p.vertices = (float*)(S + o_vert);
+      p.closest_index = (int*)(S + o_cl); p.aim_idx = (int*)(S + o_aim); p.raw_speed = (float*)(S + o_raw);
+      d.mask = v.off_road_mask; d.ox = v.pose[0]; d.oy = v.pose[1]; d.ch = std::cos(v.pose[2]); d.sh = std::sin(v.pose[2]);
+      d.col = (uint8_t*)(S + o_col); d.offr = (uint8_t*)(S + o_offr); d.ret = (double*)(S + o_ret);
+      d.adv = advantage + (size_t)(k0 + j) * Rb * M;
+      gmax = std::max(gmax, d.G); nmax = std::max(nmax, d.N);
+    }
+    const dim3 gy((unsigned)1, (unsigned)a.K);
+    hipLaunchKernelGGL(tick_multi_kernel<0>, dim3(cdiv(gmax * Ts, 128), a.K), dim3(128), 0, st, a);
+    if (nmax > 0) hipLaunchKernelGGL(tick_multi_kernel<1>, dim3(cdiv(nmax, 64), a.K), dim3(64), 0, st, a);
+    for (int j = 0; j < a.K; ++j)
+      hipLaunchKernelGGL(rollout_kernel, dim3(cdiv(a.d[j].G, 64)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, st, a.d[j].ro);
+    hipLaunchKernelGGL(tick_multi_kernel<2>, dim3(cdiv(gmax * TR, 256), a.K), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tick_multi_kernel<3>, dim3(cdiv(gmax * Ts, 256), a.K), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tick_multi_kernel<4>, dim3(cdiv(gmax * TR, 256), a.K), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tick_multi_kernel<5>, dim3(cdiv(gmax, 4), a.K), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tick_multi_kernel<6>, dim3(1, a.K), dim3(256), 0, st, a);
+    (void)gy;
     HIPCHK(c, hipGetLastError());
-    TRY(abi::rift_group_advantage(c, (const double*)(S + o_ret), 1, Gk, advantage + (size_t)k * Rb * M, stream));
   }
   return RIFT_OK;
 }

@@ -11,7 +11,7 @@
 namespace RIFT_NS {
 
 // ---- reference-line deviation: one thread per (candidate, frame), ragged reference lines ----
-__global__ void ref_line_info_kernel(const float* __restrict__ traj /*(G,Tfull,6)*/, int G, int Tfull, int Ts, int M,
+__device__ __forceinline__ void ref_line_info_body(const float* __restrict__ traj /*(G,Tfull,6)*/, int G, int Tfull, int Ts, int M,
                                      const float* __restrict__ ref_pos /*(R,Pmax,2)*/, const float* __restrict__ ref_ang /*(R,Pmax)*/,
                                      const int* __restrict__ ref_len /*(R)*/, int Pmax, float* __restrict__ delta_dis,
                                      float* __restrict__ delta_angle, int* __restrict__ closest_idx) {
@@ -35,6 +35,10 @@ __global__ void ref_line_info_kernel(const float* __restrict__ traj /*(G,Tfull,6
   const float rx = x - rp[bi * 2], ry = y - rp[bi * 2 + 1];
   delta_dis[idx] = -(rx * sinf(ca) - ry * cosf(ca));
   closest_idx[idx] = bi;
+}
+__global__ void ref_line_info_kernel(const float* __restrict__ traj, int G, int Tfull, int Ts, int M, const float* __restrict__ ref_pos, const float* __restrict__ ref_ang,
+                                     const int* __restrict__ ref_len, int Pmax, float* __restrict__ delta_dis, float* __restrict__ delta_angle, int* __restrict__ closest_idx) {
+  ref_line_info_body(traj, G, Tfull, Ts, M, ref_pos, ref_ang, ref_len, Pmax, delta_dis, delta_angle, closest_idx);
 }
 
 struct RolloutP {
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutP p) {
 
 // ---- derive_kinematics (track_propogate.py:500-596): SG(5,2) smoothing with reflect padding, central differences; box corners FL, RL, RR, FR
 // (track_propogate.py:16-74).  One thread per (candidate, frame): every output is a pure function of the two histories.
-__global__ __launch_bounds__(256) void rollout_kinematics_kernel(RolloutP p) {
+__device__ __forceinline__ void rollout_kinematics_body(const RolloutP& p) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= p.G * RIFT_RO_LEN) return;
   const int g = e / RIFT_RO_LEN, t = e - g * RIFT_RO_LEN;
@@ -217,5 +221,6 @@ __global__ __launch_bounds__(256) void rollout_kinematics_kernel(RolloutP p) {
     p.vertices[(o * 4 + k) * 2 + 1] = (dxs[k] * ss + dys[k] * cc) + cty;
   }
 }
+__global__ __launch_bounds__(256) void rollout_kinematics_kernel(RolloutP p) { rollout_kinematics_body(p); }
 
 }  // namespace RIFT_NS
