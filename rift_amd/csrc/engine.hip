@@ -83,6 +83,7 @@ struct RiftCtx {
   // stream, and the caller's queue holds token assembly -> encoder of step k + 1 beside them.  All its operands live in the forward's
   // arena (four slots).  Which batch sizes: forward_impl's measured table, or bs <= RIFT_DEC_DEFER (0 = never).
   int dec_defer_max = -1; bool dec_split = true;   // (-1: the measured table in forward_impl; RIFT_DEC_DEFER=<n>: bs <= n)            // (RIFT_DEC_SPLIT=0: the deferred decoder as one launch)
+  bool ro8 = true;                                         // candidate rollout with eight lanes per candidate (rollout.h; RIFT_RO8=0: one lane, the round-1 form)
   float* ro_raw = nullptr; size_t ro_cap = 0;              // rift_rollout: the unsmoothed speed history handed from the closed-loop kernel to the kinematics kernel
   char* tick_scratch = nullptr; size_t tick_cap = 0;       // rift_group_advantage_tick: per-CBV intermediates (reused CBV by CBV in stream order)
   // (Measured and not kept: the deferred decoder on a third stream of the engine's own, so that decoder k would also run beside tail k - 1 --
@@ -1621,6 +1622,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_JOIN_ONCE"); if (ev) c->join_once = atoi(ev); }
   { const char* ev = getenv("RIFT_DEC_DEFER"); if (ev) c->dec_defer_max = atoi(ev); }
   { const char* ev = getenv("RIFT_DEC_SPLIT"); if (ev) c->dec_split = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_RO8"); if (ev) c->ro8 = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_POISON_ARENA"); if (ev) c->dg.poison_arena = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_PE_TS"); if (ev) c->dg.pe_ts = atoi(ev); }
@@ -2463,7 +2465,8 @@ int rift_rollout(RiftCtx* c, const RiftRolloutIO* io, void* stream) {
   }
   p.raw_speed = c->ro_raw;
   if (!p.center || !p.angle || !p.speed || !p.acc || !p.ang_vel || !p.ang_acc || !p.vertices || !p.closest_index || !p.aim_idx) return RIFT_ERR_ARG;
-  hipLaunchKernelGGL(rollout_kernel, dim3(cdiv(io->G, 64)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, (hipStream_t)stream, p);
+  if (c->ro8) hipLaunchKernelGGL(rollout8_kernel, dim3(cdiv(io->G, 8)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(rollout_kernel, dim3(cdiv(io->G, 64)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, (hipStream_t)stream, p);
   hipLaunchKernelGGL(rollout_kinematics_kernel, dim3(cdiv(io->G * RIFT_RO_LEN, 256)), dim3(256), 0, (hipStream_t)stream, p);
   HIPCHK(c, hipGetLastError());
   return RIFT_OK;
@@ -2527,8 +2530,10 @@ int rift_group_advantage_tick(RiftCtx* c, const float* trajectory, int Rb, int T
     const dim3 gy((unsigned)1, (unsigned)a.K);
     hipLaunchKernelGGL(tick_multi_kernel<0>, dim3(cdiv(gmax * Ts, 128), a.K), dim3(128), 0, st, a);
     if (nmax > 0) hipLaunchKernelGGL(tick_multi_kernel<1>, dim3(cdiv(nmax, 64), a.K), dim3(64), 0, st, a);
-    for (int j = 0; j < a.K; ++j)
-      hipLaunchKernelGGL(rollout_kernel, dim3(cdiv(a.d[j].G, 64)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, st, a.d[j].ro);
+    for (int j = 0; j < a.K; ++j) {
+      if (c->ro8) hipLaunchKernelGGL(rollout8_kernel, dim3(cdiv(a.d[j].G, 8)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, st, a.d[j].ro);
+      else hipLaunchKernelGGL(rollout_kernel, dim3(cdiv(a.d[j].G, 64)), dim3(64), (size_t)RIFT_RO_LDS_BYTES, st, a.d[j].ro);
+    }
     hipLaunchKernelGGL(tick_multi_kernel<2>, dim3(cdiv(gmax * TR, 256), a.K), dim3(256), 0, st, a);
     hipLaunchKernelGGL(tick_multi_kernel<3>, dim3(cdiv(gmax * Ts, 256), a.K), dim3(256), 0, st, a);
     hipLaunchKernelGGL(tick_multi_kernel<4>, dim3(cdiv(gmax * TR, 256), a.K), dim3(256), 0, st, a);

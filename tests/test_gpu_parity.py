@@ -896,6 +896,34 @@ def test_candidate_rollout_and_ref_line_info(ffi):
     eng.close()
 
 
+def test_eight_lane_rollout_equals_the_one_lane_kernel_bit_for_bit(ffi, monkeypatch):
+    """rollout8_kernel (eight lanes per candidate: the 40-point closest-point search split over the group, everything else redundant) against
+    rollout_kernel (one lane per candidate, RIFT_RO8=0): every output and the PID state equal bit for bit over consecutive calls with
+    different group sizes -- the search's (distance, index) reduction keeps the sequential loop's first-minimum rule."""
+    keys = ("center", "angle", "speed", "acc", "ang_vel", "ang_acc", "vertices", "closest_index", "aim_idx")
+    runs = {}
+    for ro8 in ("1", "0"):
+        monkeypatch.setenv("RIFT_RO8", ro8)
+        eng = ffi.Engine("cuda:0")
+        pid = eng.new_pid_state(256)
+        got = []
+        for call, seed in enumerate((777, 778, 779, 780)):
+            traj, _, _, st = H.rollout_inputs(seed, R=6 if call % 2 == 0 else 5)       # 72 / 60 candidates: nine / eight waves of eight
+            flat = traj.reshape(-1, 80, 6).clone()
+            for c, (i0, i1) in enumerate(((4, 5), (9, 10), (14, 15), (20, 21), (39, 38), (0, 1))):      # repeated path points: ties in the search, within a
+                flat[c, i1, :2] = flat[c, i0, :2]                                                  # lane's five points and across two lanes'
+            cs = torch.tensor([[st["pos"][0], st["pos"][1], st["heading"], st["speed"] + 0.3 * call, st["width"], st["length"]]])
+            out = eng.rollout(flat, cs, pid)
+            torch.cuda.synchronize()
+            got.append({k: out[k].cpu().clone() for k in keys})
+        got.append({k: v.cpu().clone() for k, v in pid.items()})
+        runs[ro8] = got
+        eng.close()
+    for a, b in zip(runs["1"], runs["0"]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_ppo_critic_forward_and_value_loss_backward(ffi):
     """CriticPPO forward and the full PPO objective (SmoothL1 value loss + clipped actor loss + entropy) against the fixture
     generated from the reference's CriticPPO / get_ppo_loss: value, total loss, critic gradients (1e-5)."""
