@@ -217,6 +217,13 @@ int rift_comm_destroy(RiftCtx* ctx);
  * filled on the map encoder's stream, behind the previous forward's exchanges.) */
 int rift_set_prepare_stream(RiftCtx* ctx, void* prepare_stream);
 
+/* The forward's second stream (the map-encoder chain beside the history chain) is the library's own by default.  A host that manages
+ * the placement of its streams on the device's hardware queues -- streams created in a process share a few queues in creation order, and
+ * two streams of one update pipeline on one queue serialise what they are there to overlap (measured 0.65 -> 0.72 - 0.80 ms per step with two or
+ * three unrelated streams created first) -- hands the library a stream of its choice instead (RLFTTrainer probes for three streams that run
+ * concurrently with the caller's and with each other).  NULL returns to the library's own.  The stream must outlive the context's forwards. */
+int rift_set_side_stream(RiftCtx* ctx, void* side_stream);
+
 /* The reference asserts torch.isfinite(q).all() on the decoder queries after every decoder layer (planning_decoder.py:175).  Here the
  * policy-head kernels of rift_forward raise a device flag when the decoder output holds a NaN / Inf (either propagates through the
  * residual stream to the last layer); rift_forward itself stays asynchronous.  rift_check_finite is the sync point: it waits for

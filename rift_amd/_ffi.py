@@ -96,7 +96,7 @@ EXPORTS = [
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
     "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout", "rift_sft_teacher_mode",
-    "rift_check_finite", "rift_set_dp", "rift_set_prepare_stream",
+    "rift_check_finite", "rift_set_dp", "rift_set_prepare_stream", "rift_set_side_stream",
     "rift_comm_unique_id", "rift_comm_init", "rift_comm_all_reduce", "rift_comm_destroy", "rift_group_advantage_tick",
 ]
 CRITIC_NPARAM = 99331
@@ -137,6 +137,7 @@ def load_library(variant: str = "") -> C.CDLL:
     lib.rift_check_finite.argtypes = [vp, vp]
     lib.rift_set_dp.argtypes = [vp, C.POINTER(RiftDp)]
     lib.rift_set_prepare_stream.argtypes = [vp, vp]
+    lib.rift_set_side_stream.argtypes = [vp, vp]
     lib.rift_comm_unique_id.argtypes = [vp, vp]
     lib.rift_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.rift_comm_all_reduce.argtypes = [vp, vp, C.c_int64, vp]
@@ -405,6 +406,14 @@ class Engine:
         if rc != 0:
             self._check(rc, "rift_forward")
         self._bs = fb.bs
+
+    def set_side_stream(self, stream: Optional["torch.cuda.Stream"]):
+        """rift_set_side_stream: the forward's second chain runs on `stream` instead of a stream of the library's own (a host that places its
+        streams on the hardware queues itself: RLFTTrainer); None returns to the library's."""
+        self._side_stream = stream                     # keeps the torch stream object alive while the engine holds its handle
+        rc = self.lib.rift_set_side_stream(self.ctx, C.c_void_p(stream.cuda_stream if stream is not None else 0))
+        if rc != 0:
+            self._check(rc, "rift_set_side_stream")
 
     def set_prepare_stream(self, stream: Optional["torch.cuda.Stream"]):
         """rift_set_prepare_stream: the input-only preparation of the following forwards runs on `stream` (behind the gather of the batch

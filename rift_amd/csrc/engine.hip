@@ -115,7 +115,7 @@ struct RiftCtx {
   bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true; bool pe_pack = true; bool tok_fused = false; bool keep_tokens = false; bool front_fused = false; bool front_ego = false; bool ego_nofit = false;
   hipStream_t prep_stream = nullptr; bool prep_set = false; hipEvent_t ev_prep = nullptr; int side_gate = 0;      // rift_set_prepare_stream
   hipEvent_t ev_join2 = nullptr; bool nat_aside = true; int join_once = -1;      // (the history chain behind the preparation on the prepare stream: its join event)
-  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
+  hipStream_t side = nullptr; bool side_owned = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (RIFT_TWO_STREAMS=0 switches it off) the agent-history chain (NAT levels + FPN tail) on a second stream beside the map / reference-line chain
   bool fo_w = true; unsigned short* fow_img[3] = {nullptr, nullptr, nullptr}; float* fow_par[3] = {nullptr, nullptr, nullptr};   // wave-private Fourier embeddings (fo_w.h): tokens, speed limits, reference-line positions
   bool pe_w = true; unsigned short* pew_img[2] = {nullptr, nullptr};   // wave-private PointsEncoder pass B (pe_w.h): weight streams of the map / reference-line encoders
   unsigned short* decw_img = nullptr; float* decw_par = nullptr;   // weight stream / parameter blocks of the decoder kernel (dec_w.h)
@@ -1039,7 +1039,8 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   const bool forked = c->two_streams && fused && !c->prof_on && !c->dry;
   bool nat_aside = false;
   if (forked) {
-    if (!c->side) { HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
+    if (!c->side) { HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)); c->side_owned = true; }
+    if (!c->ev_fork) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
     // With the preparation prefetched, neither front chain of step k + 1 needs anything of step k: the map chain (side stream) waits for
     // the preparation only, the agent-history chain follows it on the prepare stream, and the caller's queue holds token assembly ->
     // encoder -> decoder of step k, then of step k + 1 -- the fronts run beside the previous step's one-workgroup-per-scene encoder /
@@ -1669,7 +1670,8 @@ void rift_ctx_destroy(RiftCtx* c) {
   for (int i = 0; i < 3; ++i) if (c->fow_img[i]) { (void)hipFree(c->fow_img[i]); (void)hipFree(c->fow_par[i]); }
   if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
-  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
+  if (c->side && c->side_owned) (void)hipStreamDestroy(c->side);
+  if (c->ev_fork) { (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
   for (int i = 0; i < 4; ++i) { if (c->enc_wqkv[i]) (void)hipFree(c->enc_wqkv[i]); if (c->enc_bqkv[i]) (void)hipFree(c->enc_bqkv[i]); }
   delete c;
 }
@@ -2150,6 +2152,15 @@ int rift_comm_destroy(RiftCtx* c) {
 int rift_set_prepare_stream(RiftCtx* c, void* prepare_stream) {
   if (!c) return RIFT_ERR_ARG;
   c->prep_stream = (hipStream_t)prepare_stream; c->prep_set = prepare_stream != nullptr;
+  return RIFT_OK;
+}
+
+int rift_set_side_stream(RiftCtx* c, void* side_stream) {
+  if (!c) return RIFT_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->side && c->side_owned) { HIPCHK(c, hipStreamSynchronize(c->side)); (void)hipStreamDestroy(c->side); }
+  else if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
+  c->side = (hipStream_t)side_stream; c->side_owned = false;
   return RIFT_OK;
 }
 

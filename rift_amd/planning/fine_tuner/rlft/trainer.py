@@ -123,6 +123,54 @@ def _shared_stream(dev, role: str) -> torch.cuda.Stream:
     return _STREAMS[key]
 
 
+def _runs_beside(a: torch.cuda.Stream, b: torch.cuda.Stream, dev, spin_cycles: int = 1_500_000) -> bool:
+    """Does work queued on `b` run while `a` is busy?  A spin kernel on a, a tiny kernel on b right behind it: on different hardware queues
+    b's kernel finishes almost at once (the spin ends most of its duration later), on one queue it finishes behind the spin."""
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0 = torch.cuda.Event(enable_timing=True)
+    x = torch.zeros(64, device=dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(a):
+        e0.record(a)
+        torch.cuda._sleep(spin_cycles)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        x.add_(1.0)
+        eb.record(b)
+    torch.cuda.synchronize(dev)
+    spin_ms = e0.elapsed_time(ea)
+    return eb.elapsed_time(ea) > 0.5 * spin_ms          # b's kernel ended more than half a spin BEFORE the spin did
+
+
+def _pipeline_streams(dev, main: torch.cuda.Stream):
+    """(update, prefetch, side): three streams that run concurrently with the caller's stream and with each other, chosen by probe from a pool
+    created here; one set per device for all trainers of the process.  HIP places streams on a few hardware queues in creation order, so
+    what a process created BEFORE its trainer decides whether the four streams of the update pipeline end up on four queues or share one
+    -- measured with n unrelated streams created first (tools/scratch/queue_map.py, 256 scenes): n = 0, 1, 4, 7: 0.65 ms per step, n = 2, 3,
+    5, 6: 0.72 - 0.80; the same effect made single legs of the round's profile runs 1.4 - 1.8x slow.  The probe removes direct queue sharing:
+    with it n = 0, 1, 3, 4, 5, 6 ran at 0.65 and n = 2, 7 still at 0.73 - 0.81 (queues that run beside each other in the probe can still
+    share a dispatch pipe; a probe with one stream parked in an event wait moved the bad cases to n = 2, 5 without removing them).
+    RIFT_STREAM_PROBE=0: three fresh streams (and the engine's own side stream), unprobed."""
+    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), "pipeline")
+    if key in _STREAMS:
+        return _STREAMS[key]
+    if os.environ.get("RIFT_STREAM_PROBE", "1") != "1" or not hasattr(torch.cuda, "_sleep"):
+        _STREAMS[key] = (_shared_stream(dev, "update"), _shared_stream(dev, "prefetch"), None)
+        return _STREAMS[key]
+    pool = [torch.cuda.Stream(device=dev) for _ in range(12)]
+    chosen = []
+    for s in pool:
+        if len(chosen) == 3:
+            break
+        if _runs_beside(main, s, dev) and _runs_beside(s, main, dev) and all(_runs_beside(c, s, dev) and _runs_beside(s, c, dev) for c in chosen):
+            chosen.append(s)
+    if len(chosen) < 3:                       # (fewer independent queues than the pipeline has streams: take what there is)
+        chosen += [s for s in pool if s not in chosen][:3 - len(chosen)]
+    _STREAMS[key] = tuple(chosen)
+    _STREAMS[(key[0], "pool")] = pool         # (the unused ones stay alive: destroying them would hand their queues to the next stream created)
+    return _STREAMS[key]
+
+
 class RLFTTrainer:
     """Update-step driver for kind in {'rift','grpo','ppo','reinforce'}.
 
@@ -230,7 +278,10 @@ class RLFTTrainer:
         self.loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)      # sum of training losses since pop_mean_loss()
         self.loss_n = 0
         if self.overlap_update:
-            self._side = _shared_stream(dev, "update")
+            upd, pre, side = _pipeline_streams(dev, torch.cuda.current_stream(dev))
+            self._side = upd
+            if side is not None:
+                self.engine.set_side_stream(side)
             self._ev_loss = torch.cuda.Event()
             self._ev_param = torch.cuda.Event()
             self._ev_param.record(torch.cuda.current_stream(dev))            # creates the handle; a passed event is a no-op wait
@@ -250,7 +301,7 @@ class RLFTTrainer:
             # the forward's input-only preparation (rift_set_prepare_stream) run on a stream of their own, beside the current step's kernels
             # instead of between two steps
             if os.environ.get("RIFT_PREFETCH", "1") == "1":
-                self._prefetch = _shared_stream(dev, "prefetch")
+                self._prefetch = _pipeline_streams(dev, torch.cuda.current_stream(dev))[1]
                 self._ev_serial = torch.cuda.Event()                          # end of the last whole step on the caller's stream (forward_loss)
                 self._ev_serial.record(torch.cuda.current_stream(dev))
 
