@@ -142,7 +142,7 @@ def _runs_beside(a: torch.cuda.Stream, b: torch.cuda.Stream, dev, spin_cycles: i
     return eb.elapsed_time(ea) > 0.5 * spin_ms          # b's kernel ended more than half a spin BEFORE the spin did
 
 
-def _pipeline_streams(dev, main: torch.cuda.Stream):
+def _pipeline_streams(dev, main: torch.cuda.Stream, probe: bool = True):
     """(update, prefetch, side): three streams that run concurrently with the caller's stream and with each other, chosen by probe from a pool
     created here; one set per device for all trainers of the process.  HIP places streams on a few hardware queues in creation order, so
     what a process created BEFORE its trainer decides whether the four streams of the update pipeline end up on four queues or share one
@@ -150,11 +150,13 @@ def _pipeline_streams(dev, main: torch.cuda.Stream):
     5, 6: 0.72 - 0.80; the same effect made single legs of the round's profile runs 1.4 - 1.8x slow.  The probe removes direct queue sharing:
     with it n = 0, 1, 3, 4, 5, 6 ran at 0.65 and n = 2, 7 still at 0.73 - 0.81 (queues that run beside each other in the probe can still
     share a dispatch pipe; a probe with one stream parked in an event wait moved the bad cases to n = 2, 5 without removing them).
-    RIFT_STREAM_PROBE=0: three fresh streams (and the engine's own side stream), unprobed."""
-    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), "pipeline")
+    RIFT_STREAM_PROBE=0: three fresh streams (and the engine's own side stream), unprobed.  `probe=False`: the same -- a trainer with a
+    process group takes that route: the communicator's streams come into being AFTER this choice (at the first collective), and a set
+    chosen without them measured worse than the unprobed streams (one rank over RCCL, forced exchanges: 0.690 against 0.665 ms)."""
+    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), "pipeline" if probe else "pipeline-unprobed")
     if key in _STREAMS:
         return _STREAMS[key]
-    if os.environ.get("RIFT_STREAM_PROBE", "1") != "1" or not hasattr(torch.cuda, "_sleep"):
+    if not probe or os.environ.get("RIFT_STREAM_PROBE", "1") != "1" or not hasattr(torch.cuda, "_sleep"):
         _STREAMS[key] = (_shared_stream(dev, "update"), _shared_stream(dev, "prefetch"), None)
         return _STREAMS[key]
     pool = [torch.cuda.Stream(device=dev) for _ in range(12)]
@@ -278,7 +280,8 @@ class RLFTTrainer:
         self.loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)      # sum of training losses since pop_mean_loss()
         self.loss_n = 0
         if self.overlap_update:
-            upd, pre, side = _pipeline_streams(dev, torch.cuda.current_stream(dev))
+            self._probe = self.exchange is None and os.environ.get("RIFT_BENCH_FORCE_PG") != "1"
+            upd, pre, side = _pipeline_streams(dev, torch.cuda.current_stream(dev), self._probe)
             self._side = upd
             if side is not None:
                 self.engine.set_side_stream(side)
@@ -301,7 +304,7 @@ class RLFTTrainer:
             # the forward's input-only preparation (rift_set_prepare_stream) run on a stream of their own, beside the current step's kernels
             # instead of between two steps
             if os.environ.get("RIFT_PREFETCH", "1") == "1":
-                self._prefetch = _pipeline_streams(dev, torch.cuda.current_stream(dev))[1]
+                self._prefetch = _pipeline_streams(dev, torch.cuda.current_stream(dev), self._probe)[1]
                 self._ev_serial = torch.cuda.Event()                          # end of the last whole step on the caller's stream (forward_loss)
                 self._ev_serial.record(torch.cuda.current_stream(dev))
 
