@@ -109,7 +109,7 @@ struct RiftCtx {
   int poison_lds = -1;                   // RIFT_POISON_LDS diagnostic (see lds_poison_kernel)
   // the per-call diagnostic switches of the environment, read ONCE when the context is made (nine getenv calls per forward were ~10 us of a
   // call whose host time bounds a small-batch step): RIFT_{PE,PEW,NAT,ENC,DEC}_TS, RIFT_{PEW,DEC}_DBG, RIFT_POISON_ARENA
-  struct { int pe_ts = -1, pew_dbg = 0, pew_ts = 0, nat_ts = 0, enc_ts = 0, dec_ts = 0, dec_dbg = 0, poison_arena = -1; } dg;
+  struct { std::string delay_label; long long delay_ticks = 0; int pe_ts = -1, pew_dbg = 0, pew_ts = 0, nat_ts = 0, enc_ts = 0, dec_ts = 0, dec_dbg = 0, poison_arena = -1; } dg;
   hipEvent_t param_event = nullptr;      // rift_set_param_event: the trainable parameters are valid once this event has passed
   bool dec_fused = true;
   bool two_streams = true; bool nat_on_main = true; bool nat_compact = true; bool pe_live = true; bool pe_pack = true; bool tok_fused = false; bool keep_tokens = false; bool front_fused = false; bool front_ego = false; bool ego_nofit = false;
@@ -177,6 +177,17 @@ __global__ __launch_bounds__(256) void lds_poison_kernel(unsigned int pattern) {
   if (lds_all[threadIdx.x] != pattern) asm volatile("s_nop 0");      // keep the stores
 }
 
+// diagnostic (RIFT_DELAY=<launch label>:<microseconds>): one lane spins for that long on the stream right behind every launch of that
+// label -- the successors of the kernel start later, no CU is taken from anybody.  d(step time) / d(delay) is the kernel's share of the
+// step's critical path: ~1 on it, ~0 where the step pipeline has slack (tools/critical_path.py).
+__global__ void delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+inline void delay_behind(RiftCtx* c, const char* label) {
+  if (c->dg.delay_ticks > 0 && c->dg.delay_label == label) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, c->stream, c->dg.delay_ticks);
+}
+
 template <class... KArgs, class... Args>
 void launch(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
   if (c->dry || grid.x == 0 || grid.y == 0) return;
@@ -195,6 +206,7 @@ void launch(RiftCtx* c, const char* label, void (*kern)(KArgs...), dim3 grid, di
     return;
   }
   hipLaunchKernelGGL(kern, grid, block, shmem, c->stream, static_cast<KArgs>(args)...);
+  delay_behind(c, label);
 }
 
 // same bookkeeping for a kernel that lives in another translation unit (its launch is the callable)
@@ -216,6 +228,7 @@ void launch_call(RiftCtx* c, const char* label, F&& f) {
     return;
   }
   f();
+  delay_behind(c, label);
 }
 
 template <class... KArgs>
@@ -1627,6 +1640,8 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_POISON_LDS"); if (ev) c->poison_lds = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_POISON_ARENA"); if (ev) c->dg.poison_arena = (int)strtol(ev, nullptr, 0) & 0xff; }
   { const char* ev = getenv("RIFT_PE_TS"); if (ev) c->dg.pe_ts = atoi(ev); }
+  { const char* ev = getenv("RIFT_DELAY"); const char* col = ev ? strrchr(ev, ':') : nullptr;      // wall_clock64: 100 MHz
+    if (col) { c->dg.delay_label.assign(ev, col - ev); c->dg.delay_ticks = (long long)(atof(col + 1) * 100.0); } }
   { const char* ev = getenv("RIFT_PEW_DBG"); if (ev) c->dg.pew_dbg = atoi(ev); }
   { const char* ev = getenv("RIFT_PEW_TS"); c->dg.pew_ts = ev && ev[0] == '1'; }
   { const char* ev = getenv("RIFT_NAT_TS"); if (ev) c->dg.nat_ts = atoi(ev); }

@@ -156,6 +156,10 @@ def _pipeline_streams(dev, main: torch.cuda.Stream, probe: bool = True):
     key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), "pipeline" if probe else "pipeline-unprobed")
     if key in _STREAMS:
         return _STREAMS[key]
+    prio = os.environ.get("RIFT_STREAM_PRIO")        # diagnostic: "u,p,s" = priorities of fresh update / prefetch (history chain) / side (map chain) streams
+    if prio:
+        _STREAMS[key] = tuple(torch.cuda.Stream(device=dev, priority=int(x)) for x in prio.split(","))
+        return _STREAMS[key]
     if not probe or os.environ.get("RIFT_STREAM_PROBE", "1") != "1" or not hasattr(torch.cuda, "_sleep"):
         _STREAMS[key] = (_shared_stream(dev, "update"), _shared_stream(dev, "prefetch"), None)
         return _STREAMS[key]
