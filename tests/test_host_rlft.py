@@ -992,3 +992,96 @@ def test_normalize_and_tensorisation_match_the_reference_generated_fixture():
     # round trip through numpy
     back = PlutoFeature.normalize(H.raw_feature_inputs(), first_time=True, radius=120).to_feature_tensor().to_numpy()
     assert isinstance(back.data["agent"]["position"], np.ndarray) and back.data["agent"]["position"].dtype == np.float32
+
+
+# ---- the SFT family's update side (fine_tuner/sft/{sft_pluto, rs_pluto/rs_pluto, rtr_pluto/rtr_pluto}.py + their datamodules) ----------------
+SFT_KEYS = {'sft_pluto': ['CBVs_actions', 'CBVs_teacher_infos', 'CBVs_obs', 'CBVs_next_obs', 'CBVs_reward', 'CBVs_terminated', 'CBVs_done'],
+            'rs_pluto': ['CBVs_actions', 'CBVs_teacher_rewards', 'CBVs_obs', 'CBVs_next_obs', 'CBVs_reward', 'CBVs_terminated', 'CBVs_done'],
+            'rtr_pluto': ['CBVs_actions', 'CBVs_actions_old_log_prob', 'CBVs_actions_mode', 'CBVs_teacher_infos', 'CBVs_obs', 'CBVs_next_obs',
+                          'CBVs_reward', 'CBVs_terminated', 'CBVs_done']}        # planning/config/{sft,rs,rtr}_pluto.yaml: data_keys
+
+
+def _filled_sft_buffer(policy, n):
+    """8-step episodes of one CBV with the teacher columns the reference's SFT-family rollouts store (sft_pluto.py:229-241: five floats, the
+    teacher's target speed first; rs_pluto.py:134-136: -|teacher speed - desired speed|)."""
+    buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': n, 'data_keys': SFT_KEYS[policy]})
+    g = torch.Generator().manual_seed(5)
+    t = 0
+    while not buf.buffer_full:
+        for k in range(8):
+            s, s2 = (syn.make_scene(t + j, num_agents=12, num_polygons=8, r_min=1, r_max=3) for j in (0, 1))
+            ex = s["extras"]
+            speed = float(2.0 + 6.0 * torch.rand((), generator=g))
+            d = {'CBV_ids': [[3]], 'CBVs_obs': [{3: {'raw_pluto_feature': PlutoFeature(data=s["feature"])}}],
+                 'CBVs_next_obs': [{3: {'raw_pluto_feature': PlutoFeature(data=s2["feature"])}}],
+                 'CBVs_actions': [{3: np.zeros(3, np.float32)}], 'CBVs_reward': [{3: float(ex["return"])}], 'CBVs_done': [{3: k == 7}],
+                 'CBVs_terminated': [{3: k == 7 and t % 16 == 7}],
+                 'CBVs_teacher_infos': [{3: torch.tensor([speed, 0.0, 0.0, 0.0, 5.0])}], 'CBVs_teacher_rewards': [{3: -abs(speed - 5.0)}],
+                 'CBVs_actions_old_log_prob': [{3: np.float32(ex["old_log_prob"])}], 'CBVs_actions_mode': [{3: ex["action_mode"].numpy()}]}
+            buf.store(d)
+            t += 1
+    return buf
+
+
+def test_sft_family_registry_and_reward_shaping_columns():
+    """The three SFT-family policies are in the registry under the reference's names with its types; RewardShapingPluto's reward column is
+    CBVs_reward + 0.2 * CBVs_teacher_rewards (rs_datamodule.py:109-114, datamodule/rs_datamodule.yaml) and its return the oracle's scan;
+    SFTPluto's teacher column is the (n, 5) stack SFTCollate yields."""
+    from oracle import advantage as oadv
+    from rift_amd.planning import CBV_POLICY_LIST
+    from rift_amd.planning.fine_tuner.sft.sft_pluto import teacher_column
+    assert {'sft_pluto', 'rs_pluto', 'rtr_pluto'} <= set(CBV_POLICY_LIST)
+    assert [CBV_POLICY_LIST[k].kind for k in ('sft_pluto', 'rs_pluto', 'rtr_pluto')] == ['sft', 'rs', 'rtr']
+    assert all(CBV_POLICY_LIST[k].type == 'learnable' for k in ('sft_pluto', 'rs_pluto', 'rtr_pluto'))
+    buf = _filled_sft_buffer('rs_pluto', 24)
+    pol = CBV_POLICY_LIST['rs_pluto']({'num_scenario': 1, 'device': 'cpu'}, None)
+    pol.set_buffer(buf)
+    r = pol.shaped_rewards()
+    want = np.asarray(buf.get_key_data('CBVs_reward'), np.float64) + 0.2 * np.asarray(buf.get_key_data('CBVs_teacher_rewards'), np.float64)
+    assert r.dtype == torch.float64 and np.array_equal(r.numpy(), want)
+    ret = oadv.compute_return(torch.as_tensor(want), torch.as_tensor(np.asarray(buf.get_key_data('CBVs_done'), np.float64)), 0.98).numpy()
+    assert abs(ret[7] - want[7]) < 1e-12 and abs(ret[6] - (want[6] + 0.98 * want[7])) < 1e-12          # episodes of 8: the scan restarts at a done
+    col = teacher_column(_filled_sft_buffer('sft_pluto', 16), 'cpu')
+    assert col.shape == (16, 5) and col.dtype == torch.float32 and torch.all(col[:, 4] == 5.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["sft_pluto", "rs_pluto", "rtr_pluto"])
+def test_sft_family_train_updates_the_configured_layers(policy, tmp_path):
+    """{SFT, RewardShaping, RTR}Pluto.train(e_i) on a buffer with the reference's data keys: the same update loop as the RLFT family (16-epoch
+    schedule shortened here), the teacher rows / shaped returns / PPO columns prepared on the device once per update; pi_head moves, for RTR
+    value_net too, nothing else; RS's returns are the oracle's scan of the shaped rewards."""
+    from oracle import advantage as oadv
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    cfg = {'num_scenario': 1, 'ROOT_DIR': str(tmp_path), 'model_path': 'ckpt', 'device': 'cuda:0',
+           'sft': {'epochs': 2, 'warmup_epochs': 1, 'train_batch_size': 16, 'val_batch_size': 16, 'lr': 1e-3}}
+    pol = CBV_POLICY_LIST[policy](cfg, None)
+    pol.load_model(resume=True)
+    pol.set_mode('train')
+    torch.manual_seed(0)
+    with torch.no_grad():
+        for p in pol.train_model.parameters():
+            if p.dim() > 1:
+                p.normal_(0, 0.05)
+    pol.pluto_model.load_state_dict({k: v for k, v in pol.train_model.state_dict().items() if not k.startswith("value_net")})
+    before = {k: v.detach().clone() for k, v in pol.train_model.state_dict().items()}
+    buf = _filled_sft_buffer(policy, 48)
+    pol.set_buffer(buf)
+    if policy == 'rs_pluto':
+        from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+        want = oadv.compute_return(pol.shaped_rewards(), torch.as_tensor(np.asarray(buf.get_key_data('CBVs_done'), np.float64)), 0.98).numpy()
+        tr = RLFTTrainer(pol.train_model, kind='rs')
+        got = pol.preprocess_buffer(tr, None)["returns"]
+        tr.close()
+        assert got.dtype == torch.float32 and np.allclose(got.cpu().numpy(), want, rtol=0, atol=1e-5 * max(1.0, np.abs(want).max()))
+    fit = pol.train(5)
+    assert len(fit["history"]) == 2 and all(np.isfinite(h["train_loss"]) and np.isfinite(h["val_loss"]) for h in fit["history"])
+    after = pol.train_model.state_dict()
+    changed = {k for k in before if not torch.equal(before[k].cpu(), after[k].cpu()) and "num_batches_tracked" not in k}
+    assert any(k.startswith("planning_decoder.pi_head") for k in changed)
+    for k in changed:
+        assert k.startswith("planning_decoder.pi_head") or "running_" in k or (policy == 'rtr_pluto' and k.startswith("value_net.")), k
+    if policy == 'rtr_pluto':
+        assert "value_net.net.0.weight" in changed
+    assert len(buf) == 0 and pol.current_epoch == 1
