@@ -936,7 +936,7 @@ def test_pluto_policy_and_ppo_columns(tmp_path):
     (r, m) -- integers recomputed here from the emitted logits)."""
     from rift_amd.planning import CBV_POLICY_LIST
     torch.cuda.set_device(0)
-    assert set(CBV_POLICY_LIST) == {'pluto', 'rift_pluto', 'grpo_pluto', 'reinforce_pluto', 'ppo_pluto'}
+    assert set(CBV_POLICY_LIST) == {'pluto', 'rift_pluto', 'grpo_pluto', 'reinforce_pluto', 'ppo_pluto', 'sft_pluto', 'rs_pluto', 'rtr_pluto'}
     sd = H.weights()
     ck = tmp_path / "pluto.ckpt"
     torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}}, ck)
