@@ -120,6 +120,7 @@ class RLFTPluto(PLUTO):
     def set_mode(self, mode):
         self.mode = mode
         if mode == 'train':
+            self._mem_ckpt = None           # (a fresh training model: its trunk is NOT the one the snapshot belongs to)
             self.train_model = PlanningModel(radius=self.radius).to(self.device)
             self.train_model.compute_precision = self.compute_precision
             self.train_model.train()
@@ -142,6 +143,7 @@ class RLFTPluto(PLUTO):
         pass
 
     def load_model(self, resume=True):
+        self._mem_ckpt = None               # whatever gets loaded below, the in-memory snapshot of the last update no longer describes it
         load_dir = self.model_path / self.load_agent_info
         files = list(load_dir.glob("*.ckpt"))
         if resume and files:
@@ -171,6 +173,13 @@ class RLFTPluto(PLUTO):
         self.current_epoch = len(files)
         if files:
             self.checkpoint = files[0].as_posix()
+
+    @staticmethod
+    def _trunk_version(model):
+        """Identity + in-place version of every FROZEN tensor of `model` (everything an update does not move): unchanged as long as
+        nobody loaded, re-initialised or re-allocated the trunk."""
+        moving = set(RLFTPluto._moving_keys(model)) if any(p.requires_grad for p in model.parameters()) else set()
+        return tuple((k, v.data_ptr(), v._version) for k, v in model.state_dict().items() if k not in moving)
 
     @staticmethod
     def _moving_keys(model) -> List[str]:
@@ -216,7 +225,8 @@ class RLFTPluto(PLUTO):
         # snapshot kept with it -- no 17 MB read + 438 host-to-device copies per update.
         mem = self.__dict__.get("_mem_ckpt")
         base_cpu = None                       # CPU copy of the whole state_dict the update starts from (the frozen part of the next checkpoint)
-        if self.checkpoint and mem is not None and mem["path"] == self.checkpoint and Path(self.checkpoint).exists():
+        if (self.checkpoint and mem is not None and mem["path"] == self.checkpoint and Path(self.checkpoint).exists()
+                and mem["model"] is self.train_model and mem["trunk"] == self._trunk_version(self.train_model)):
             with torch.no_grad():
                 own = self.train_model.state_dict()
                 for k, v in mem["moving"].items():
@@ -228,8 +238,14 @@ class RLFTPluto(PLUTO):
             sd = torch.load(self.checkpoint, map_location="cpu", weights_only=False)["state_dict"]
             base_cpu = {k.replace("model.", "", 1): v for k, v in sd.items()}
             self.train_model.load_state_dict(base_cpu, strict=False)
+            # the next checkpoint is the TRAINING MODEL's state_dict (Lightning saves the module, training_builder.py:131-140): keys the
+            # source file lacked (loaded with strict=False) come off the device, keys the model does not have are not carried forward
+            own = self.train_model.state_dict()
+            base_cpu = {k: (base_cpu[k] if k in base_cpu else v.detach().cpu()) for k, v in own.items()}
         else:
             self.train_model.load_state_dict(self.pluto_model.state_dict(), strict=False)
+            if cfg.get("checkpoint_every_improvement", False):      # (a file per improvement needs the frozen part before the first epoch ends)
+                base_cpu = {k: v.detach().cpu() for k, v in self.train_model.state_dict().items()}
         infer_in_sync = (not self.checkpoint) or self.__dict__.get("_infer_bound") == (self.checkpoint, self.pluto_model._tensor_version())
         mark("load_checkpoint")
         trainer = RLFTTrainer(self.train_model, kind=self.kind, lr=lr, cl_lr_decay=cfg["cl_lr_decay"],
@@ -322,7 +338,10 @@ class RLFTPluto(PLUTO):
             torch.distributed.barrier(group=process_group)         # the checkpoint of rank 0 is on disk before anyone reloads
         self.last_fit = {"history": history, "best_val_loss": best, "checkpoint": best_path.as_posix(), "lr": lr}
         self.update_training_ckpt()
-        self._mem_ckpt = {"path": self.checkpoint, "moving": snapshot, "base_cpu": base_cpu}
+        # the snapshot pairs with the file THIS update wrote and with this very training model (set_mode / load_model drop it; a
+        # checkpoint directory in which update_training_ckpt resolves to another file never takes the fast path)
+        self._mem_ckpt = {"path": best_path.as_posix(), "moving": snapshot, "base_cpu": base_cpu, "model": self.train_model,
+                          "trunk": self._trunk_version(self.train_model)}
         # refresh the inference model (rlft_pluto.py:244-246).  Its frozen trunk equals the training model's when both came from the same
         # checkpoint (or the training model was copied from it) and nobody has touched it since: then only the moving tensors are copied,
         # in place, device to device -- and the engine reads exactly those through their pointers, so no re-bind either
@@ -513,6 +532,7 @@ class PPOPluto(RLFTPluto):         # fine_tuner/rlft/ppo_pluto/ppo_pluto.py:40-1
         self.mode = mode
         if mode == 'train':
             from rift_amd.planning.fine_tuner.rlft.ppo_pluto.ppo_pluto import PPOPlutoModel
+            self._mem_ckpt = None
             self.train_model = PPOPlutoModel(radius=self.radius, state_dim=self.state_dim, action_dim=self.action_dim,
                                              hidden_dim=self.hidden_dim, clip_epsilon=self.clip_epsilon,
                                              lambda_entropy=self.lambda_entropy).to(self.device)

@@ -203,8 +203,11 @@ class RLFTTrainer:
         # loss kernels over the same forward, the second accumulated into .grad
         self.model, self.kind, self.kind_id = model, kind, _ffi.LOSS_KINDS["ppo" if kind == "rtr" else kind]
         self.lambda_rl = 5.0                                     # rtr_trainer.py:153
-        if kind in ("sft", "rtr"):      # the teacher label is read off the candidate trajectories (sft_trainer.py:186-199): the heads must run
-            model.need_traj = True
+        # The trajectory / prediction / ref-free heads feed none of the RLFT objectives (dead outputs), so the trainer
+        # switches them off for rift / grpo / ppo / reinforce -- whatever the model's default says -- and on for sft / rtr, whose teacher
+        # label is read off the candidate trajectories (sft_trainer.py:186-199).  close() restores the caller's setting.
+        self._need_traj_before = getattr(model, "need_traj", None)
+        model.need_traj = kind in ("sft", "rtr")
         self.lr, self.epochs, self.warmup_epochs = lr, epochs, warmup_epochs
         self.gradient_clip_val = gradient_clip_val
         self.pg = process_group
@@ -384,6 +387,8 @@ class RLFTTrainer:
             self.dp_buf = None
         if hasattr(self.model, "_engine_users"):
             self.model._engine_users.discard(self)
+        if self._need_traj_before is not None:          # the caller's output selection (the rollout side wants every head)
+            self.model.need_traj, self._need_traj_before = self._need_traj_before, None
 
     def forward_loss(self, *args, **kwargs):
         """forward + objective (+ pi_head backward into .grad) on the current stream.  Returns the device f64 loss scalar.  With `clip_val`
