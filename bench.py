@@ -167,6 +167,49 @@ def pmc_mfma(label, path=None):
     return None
 
 
+CONTRACT_KINDS = ("rift", "grpo", "reinforce", "ppo")
+
+
+def contract_batch():
+    """The 256-scene batch tests/test_gpu_parity.py::test_benchmark_batch_objectives_in_16bit_modes uses (scenes 1000..1255, PPO advantage seed 99)."""
+    from rift_amd import synthetic as syn
+    batch = syn.collate_scenes([syn.make_scene(1000 + i) for i in range(256)])
+    batch["advantage_torch"] = torch.randn(256, generator=torch.Generator().manual_seed(99))
+    return batch
+
+
+def _clone_tree(t):
+    return {k: _clone_tree(v) for k, v in t.items()} if isinstance(t, dict) else (t.clone() if torch.is_tensor(t) else t)
+
+
+def contract_device_losses(dev, sd, batch, precision):
+    """The four objectives of the contract batch on the HIP engine in one compute precision: train-mode forward (BatchNorm batch statistics,
+    every drop disabled -- the oracle has no RNG) -> rift_loss_backward -> rift_loss_finalize.  Product path only; no oracle here."""
+    from rift_amd import _ffi
+    from rift_amd.planning.fine_tuner.rlft.trainer import PI_KEYS
+    eng = _ffi.Engine(str(dev), operands="fp16" if precision == "fp16" else "bf16")
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    eng.forward(batch["cur_pluto_feature_torch"], train=True, no_drop=True, bn_update=False, fp32=precision == "fp32")
+    out = {}
+    for kind in CONTRACT_KINDS:
+        stats, flat, _ = eng.loss_backward(kind, _clone_tree(batch))
+        grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).to(dev) for k in PI_KEYS}
+        out[kind] = float(eng.loss_finalize(stats, flat, grads).item())
+    eng.close()
+    return out
+
+
+def contract_oracle_losses(sd, batch):
+    """The same four objectives from the CPU oracle (fp32 restatement of the reference, pinned to the reference-generated goldens by
+    tests/test_oracle_*.py).  The oracle is the CHECKER of the contract figures, exactly as in the parity test; it runs with the CPU baseline."""
+    from oracle import losses, pluto_ref
+    data = batch["cur_pluto_feature_torch"]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    _, _, taps = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=False, want_taps=True)
+    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
+    return {kind: float(losses.pi_head_loss_and_grads(sd, taps["q_final"], kind, _clone_tree(batch), r_pad)[0]) for kind in CONTRACT_KINDS}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a plain shell: re-execute under torch.distributed.run, one rank per GPU of this node."""
     have = torch.cuda.device_count()
@@ -507,6 +550,12 @@ def main():
         for p, g in todo:
             r = next(g)
             precisions[p] = {k: r[k] for k in keep}
+    contract = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and BATCH == 256:
+        # north_star's precision contract, machine-readable: the four objectives of the parity test's 256-scene batch per compute precision
+        # (device side here; the oracle side runs with the CPU baseline below and the errors are filled in there)
+        cb = contract_batch()
+        contract = {"batch": cb, "device": {p: contract_device_losses(dev, sd_cpu, cb, p) for p in ("bf16", "fp16", "fp32")}}
     head = next(head_leg)
     # the companions that build policies / contexts of their own run BEHIND the headline leg: every further live context adds streams that
     # share hardware queues with the headline trainer's (measured: headline 0.66 -> 0.75 ms per step with the end-to-end update ahead of it)
@@ -541,7 +590,7 @@ def main():
         line = {
             "metric": f"policy-update scenes/sec ({BATCH}-scene RIFT update steps on a 4096-scene replay)",
             "value": head["value"], "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": ("strong" if strong else "weak") if world > 1 else None, "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "steps_per_sec": head["steps_per_sec"],
             "rccl_ranks": torch.distributed.get_world_size() if pg is not None else 0,          # ranks of the process group the exchanges ran over
@@ -584,6 +633,22 @@ def main():
         if not args.no_cpu_baseline:
             # (rank 0's host cores; the other ranks wait at the closing barrier.  A 256-scene CPU step whatever N is: the reference is single-device)
             line["cpu_baseline"] = cpu_baseline(scenes_cpu, sd_cpu)
+            if contract is not None:
+                want = contract_oracle_losses(sd_cpu, contract["batch"])
+                pc = {"tolerance": 1e-4, "batch": "256 scenes (synthetic ids 1000..1255), train-mode BatchNorm batch statistics, drops disabled; "
+                                                  "the batch of tests/test_gpu_parity.py::test_benchmark_batch_objectives_in_16bit_modes",
+                      "checker": "oracle/ (PyTorch-CPU fp32 restatement of the reference, pinned to reference-generated goldens); computed in this run",
+                      "oracle_loss": want}
+                for prec, got in contract["device"].items():
+                    errs = {k: abs(got[k] - want[k]) for k in CONTRACT_KINDS}
+                    entry = {"loss_err_vs_oracle": errs, "max_loss_err_vs_oracle": max(errs.values()), "meets_north_star_1e-4": bool(max(errs.values()) < 1e-4),
+                             "objectives_inside_1e-4": [k for k in CONTRACT_KINDS if errs[k] < 1e-4]}
+                    pc[prec] = entry
+                    if precisions is not None and prec in precisions:
+                        precisions[prec].update({"max_loss_err_vs_oracle": entry["max_loss_err_vs_oracle"], "loss_err_vs_oracle": errs,
+                                                 "meets_north_star_1e-4": entry["meets_north_star_1e-4"]})
+                line["precision_contract"] = pc
+                line["headline_meets_north_star_1e-4"] = pc[args.precision]["meets_north_star_1e-4"]
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

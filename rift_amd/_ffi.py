@@ -112,6 +112,8 @@ def load_library(variant: str = "") -> C.CDLL:
     if variant in _libs:
         return _libs[variant]
     path = LIB_PATH if not variant else LIB_PATH.replace("librift_hip.so", f"librift_hip_{variant}.so")
+    if not variant and os.environ.get("RIFT_LIB"):       # diagnostic: an A/B build of the library (rift_amd.build.build_variant)
+        path = os.environ["RIFT_LIB"]
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -43,11 +43,14 @@ def sources():
                   + [os.path.join(os.path.dirname(HERE), "include", "rift_hip.h"), os.path.abspath(__file__)])
 
 
-def compile_commands(extra=(), stats=False):
+def compile_commands(extra=(), stats=False, variant=None):
     """[(object path, command)] of every translation unit of the library; `extra` is appended to each hipcc command.
-    stats=True: the diagnostic twin -- the bf16-operand build only, compiled with -DRIFT_DROP_STATS=1."""
+    stats=True: the diagnostic twin -- the bf16-operand build only, compiled with -DRIFT_DROP_STATS=1.
+    variant=(tag, [defines]): an A/B build of the whole library under another name (build_variant)."""
     cmds = []
     sfx, defs = ("_st", ["-DRIFT_DROP_STATS=1"]) if stats else ("", [])
+    if variant:
+        sfx, defs = "_" + variant[0], list(variant[1])
     for tag, f16 in (FORMATS[:1] if stats else FORMATS):
         for unit, flags in UNITS:
             o = os.path.join(OBJ, f"{unit}_{tag}{sfx}.o")
@@ -83,13 +86,20 @@ def build_stats(force: bool = False, verbose: bool = True) -> str:
     return build(force, verbose, stats=True)
 
 
-def build(force: bool = False, verbose: bool = True, jobs: int = 0, stats: bool = False) -> str:
+def build_variant(tag: str, defines, force: bool = False, verbose: bool = False) -> str:
+    """librift_hip_<tag>.so = the library compiled with extra defines, for same-box A/B runs (RIFT_LIB=<path> python bench.py ...)."""
+    return build(force, verbose, variant=(tag, list(defines)))
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int = 0, stats: bool = False, variant=None) -> str:
     srcs = sources()
     LIB = LIB_STATS if stats else globals()["LIB"]
+    if variant:
+        LIB = os.path.join(HERE, f"librift_hip_{variant[0]}.so")
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
-    cmds = compile_commands(extra=["-Rpass-analysis=kernel-resource-usage"], stats=stats)
+    cmds = compile_commands(extra=["-Rpass-analysis=kernel-resource-usage"], stats=stats, variant=variant)
 
     def run(item):
         o, cmd = item

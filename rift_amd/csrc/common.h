@@ -167,13 +167,106 @@ __device__ __forceinline__ f32x2_t unpack_h2(unsigned int u) {
   f32x2_t r; r.x = h_lo(u); r.y = h_hi(u); return r;
 }
 
-// bias + GELU + bf16 pack of one MFMA accumulator fragment (4 consecutive output columns), two packed pairs
+// ---- GELU at the precision its consumer keeps (round 5) ---------------------------------------------------------------------------
+// The GELU outputs of this model are MFMA operands: a bf16 word keeps 8 significand bits.  gelu(x) = relu(x) - h(|x|) with the bump
+// h(a) = a Phi(-a) (<= 0.17, -> 0 beyond a = 4) as a degree-7 polynomial in u = a / 2 - 1, evaluated in PACKED FP16 (v_pk_fma_f16: two
+// elements per full-rate instruction, 11 significand bits): both tails keep their relative accuracy (x < 0: the result IS -h; x > 0: x
+// minus a small term), the operand word's error against erf GELU in double is 1.76e-3 rms for N(0, 1.5) inputs against 1.70e-3 for the
+// correctly rounded bf16 word (tools/ubench/gelu_pk16.hip: max 1.76e-2 / 1.56e-2, rms 4.93e-3 / 4.81e-3 over [-8, 8]), and the epilogue is
+// 36 -> 28 issue slots per four elements of which none is a two-pass packed-fp32 instruction (97 -> 81 ticks per element in that
+// micro-benchmark).  Two pairs run in lock step: a v_pk_*_f16 result read by the NEXT instruction costs a wait state.  The fp16-operand
+// build keeps the fp32 rational form (its 11-bit consumer would see this evaluation: rms 3.3e-4 against 2.1e-4).
+typedef _Float16 gelu_h2 __attribute__((ext_vector_type(2)));
+#define RIFT_GELU_H0 0.04531748f
+#define RIFT_GELU_H1 -0.17138292f
+#define RIFT_GELU_H2 0.22257517f
+#define RIFT_GELU_H3 0.01231068f
+#define RIFT_GELU_H4 -0.32790318f
+#define RIFT_GELU_H5 0.24358234f
+#define RIFT_GELU_H6 0.05996109f
+#define RIFT_GELU_H7 -0.08454493f
+__device__ __forceinline__ void gelu_pk16x2(float x0, float x1, float x2, float x3, gelu_h2& g0, gelu_h2& g1) {
+  typedef gelu_h2 V;
+  // (the conversion is hipcc's own v_cvt_pk_f16_f32, NOT an asm statement: x may be a fresh MFMA result, and the wait states between an
+  // MFMA write and a VALU read are software's to insert -- hipcc pads its own instructions, never the inside of an asm statement; the
+  // first version read stale accumulators here and produced NaN)
+  f32x2_t fa, fb;
+  fa.x = x0; fa.y = x1; fb.x = x2; fb.y = x3;
+  const V xa = __builtin_convertvector(fa, V), xb = __builtin_convertvector(fb, V);
+  const V HALF = (V)(_Float16)0.5f, M1 = (V)(_Float16)-1.0f;
+  V aa, ab, ra, rb;
+  // (asm: hipcc's own min / max carry an IEEE canonicalisation -- v_pk_max_f16 x, x, x -- in the units built without -mno-amdgpu-ieee)
+  asm("v_and_b32 %0, 0x7fff7fff, %1" : "=v"(aa) : "v"(xa));
+  asm("v_and_b32 %0, 0x7fff7fff, %1" : "=v"(ab) : "v"(xb));
+  // (inline constants: the f16 constant sits in the low half of the operand, op_sel_hi 0 hands it to both halves -- no register)
+  asm("v_pk_min_f16 %0, %1, 4.0 op_sel_hi:[1,0]" : "=v"(aa) : "v"(aa));
+  asm("v_pk_min_f16 %0, %1, 4.0 op_sel_hi:[1,0]" : "=v"(ab) : "v"(ab));
+  asm("v_pk_max_f16 %0, %1, 0 op_sel_hi:[1,0]" : "=v"(ra) : "v"(xa));
+  asm("v_pk_max_f16 %0, %1, 0 op_sel_hi:[1,0]" : "=v"(rb) : "v"(xb));
+  const V ua = __builtin_elementwise_fma(aa, HALF, M1), ub = __builtin_elementwise_fma(ab, HALF, M1);
+  V pa = __builtin_elementwise_fma(ua, (V)(_Float16)RIFT_GELU_H7, (V)(_Float16)RIFT_GELU_H6);
+  V pb = __builtin_elementwise_fma(ub, (V)(_Float16)RIFT_GELU_H7, (V)(_Float16)RIFT_GELU_H6);
+#define RIFT_GELU_STEP(C) pa = __builtin_elementwise_fma(pa, ua, (V)(_Float16)C); pb = __builtin_elementwise_fma(pb, ub, (V)(_Float16)C);
+  RIFT_GELU_STEP(RIFT_GELU_H5) RIFT_GELU_STEP(RIFT_GELU_H4) RIFT_GELU_STEP(RIFT_GELU_H3)
+  RIFT_GELU_STEP(RIFT_GELU_H2) RIFT_GELU_STEP(RIFT_GELU_H1) RIFT_GELU_STEP(RIFT_GELU_H0)
+#undef RIFT_GELU_STEP
+  g0 = ra - pa; g1 = rb - pb;
+}
+
+// ---- MLP hidden-layer operands (opfmt.h: fp16 words whenever GELU is evaluated in packed fp16) ----
+__device__ __forceinline__ f32x4 mfma_hid(h16x8 a, h16x8 b, f32x4 c) {
+#if RIFT_GELU_PK16
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+#else
+  return mfma_h(a, b, c, 0, 0, 0);
+#endif
+}
+// fp32 -> hidden-layer operand word (weight packers: the fc2 fragments)
+__device__ __forceinline__ unsigned short f2h_hid(float f) {
+#if RIFT_GELU_PK16
+  unsigned int r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(f), "v"(0.f));
+  return (unsigned short)(r & 0xffffu);
+#else
+  return f2h(f);
+#endif
+}
+// fc1 accumulator -> hidden-layer operand words (4 consecutive hidden channels of one row).  Packed-fp16 build: the bias was the
+// accumulator's initial value (hid_init) and the words are fp16; otherwise the arithmetic of rounds 2 - 4, bit for bit (zero initial value,
+// bias added here): the fp16-operand build's results do not move with this round's change.
+__device__ __forceinline__ f32x4 hid_init(const float4 b) {
+#if RIFT_GELU_PK16
+  return (f32x4){b.x, b.y, b.z, b.w};
+#else
+  return (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+}
+__device__ __forceinline__ uint2 gelu4_pack(const f32x4 a, const float4 b);
+__device__ __forceinline__ uint2 gelu4_hid(const f32x4 a, const float4 b) {
+#if RIFT_GELU_PK16
+  gelu_h2 g0, g1;
+  gelu_pk16x2(a[0], a[1], a[2], a[3], g0, g1);
+  uint2 u; u.x = __builtin_bit_cast(unsigned int, g0); u.y = __builtin_bit_cast(unsigned int, g1);
+  return u;
+#else
+  return gelu4_pack(a, b);
+#endif
+}
+
+// bias + GELU + operand pack of one MFMA accumulator fragment (4 consecutive output columns)
 __device__ __forceinline__ uint2 gelu4_pack(const f32x4 a, const float4 b) {
+#if RIFT_OP_F16 || defined(RIFT_GELU_F32)
   f32x2_t lo, hi, bl, bh;
   lo.x = a[0]; lo.y = a[1]; hi.x = a[2]; hi.y = a[3];
   bl.x = b.x; bl.y = b.y; bh.x = b.z; bh.y = b.w;
   lo = gelu_fast2(lo + bl); hi = gelu_fast2(hi + bh);
   return pack_h4(lo.x, lo.y, hi.x, hi.y);
+#else
+  gelu_h2 g0, g1;
+  gelu_pk16x2(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w, g0, g1);
+  return pack_h4((float)g0[0], (float)g0[1], (float)g1[0], (float)g1[1]);
+#endif
 }
 
 // Workgroup barrier for phases that hand data over through LDS only.  __syncthreads() makes hipcc drain EVERY outstanding memory

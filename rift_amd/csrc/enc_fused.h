@@ -87,7 +87,8 @@ __device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned shor
 // -> epilogues are 8/16-byte row-contiguous LDS accesses (2 v_cvt_pk + 1 ds_write_b64 per tile) instead of four
 // scattered 2-byte stores.  NSWAP trailing n-tiles (j >= NTW - NSWAP... see call sites) may keep the plain order:
 //   plain: acc[r] = out[row = mt*16 + 4*(lane>>4) + r][col = ntile*16 + (lane&15)]   (4 consecutive ROWS: transposed stores)
-template <int MT, int KS, int NTW, int NPLAIN = 0>
+// HID: A rows and weight fragments are hidden-layer operand words (opfmt.h: fp16 in the packed-fp16-GELU build)
+template <int MT, int KS, int NTW, int NPLAIN = 0, bool HID = false>
 __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned short* A, int lda, const EFrags<KS, NTW>& B,
                                       int l15, int l4) {
 #pragma unroll
@@ -99,8 +100,9 @@ __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
-        acc[mt][j] = (j >= NTW - NPLAIN) ? mfma_h(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0)
-                                         : mfma_h(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+        acc[mt][j] = HID ? mfma_hid(B.f[ks][j], a[mt], acc[mt][j])
+                         : (j >= NTW - NPLAIN) ? mfma_h(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0)
+                                               : mfma_h(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
   }
 }
 
@@ -320,28 +322,30 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       for (int hc = 0; hc < 4; ++hc) {
         {
           f32x4 acc[MT][NTC];
+          float4 b4[NTC];
+#pragma unroll
+          for (int j = 0; j < NTC; ++j) b4[j] = *reinterpret_cast<const float4*>(par + P_B1 + hc * 128 + (j * NW + wave) * 16 + l4 * 4);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NTC; ++j) acc[mt][j] = hid_init(b4[j]);      // (packed-fp16 GELU: the bias is the accumulator's initial value)
           e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
           e_load_b(B2, w.w2, 512, 0, hc * 128, wave, l15, l4, EWaves<NW>());
           if (hc > 0) lds_barrier();   // previous chunk's fc2 reads of cb are complete
 #pragma unroll
           for (int j = 0; j < NTC; ++j) {
             const int col = (j * NW + wave) * 16 + l4 * 4;
-            const float4 b4 = *reinterpret_cast<const float4*>(par + P_B1 + hc * 128 + col);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
               *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
-                  gelu4_pack(acc[mt][j], b4);
+                  gelu4_hid(acc[mt][j], b4[j]);       // hidden-layer operand words (fc2's weight image matches: w.w2 = the `hid` image)
           }
         }
         if (hc + 1 < 4) e_load_b(Bw, w.w1, C, (hc + 1) * 128, 0, wave, l15, l4, EWaves<NW>());
         else if (bi + 1 < 4) e_load_b(Bqkv, p.blk[bi + 1].wqkv, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
         lds_barrier();
         TS();
-        e_mma<MT, 4, NTC>(acc2, cb, CB, B2, l15, l4);
+        e_mma<MT, 4, NTC, 0, true>(acc2, cb, CB, B2, l15, l4);
         TS();
       }
 #pragma unroll

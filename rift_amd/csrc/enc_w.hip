@@ -20,6 +20,7 @@ __global__ void pack_encw_kernel(EncWSrc s, unsigned short* __restrict__ img, fl
     const int ch = l0w_chan(l4, j, 2 * ks), o = nt * 16 + l15;
     const EncWSrc::L& L = s.l[li];
     float v;
+    const bool hid = g >= 4 && ((g - 4) & 1);                       // fc2 fragments: hidden-layer operand words (common.h: f2h_hid)
     if (g == 0) v = L.w_in[(128 + o) * 128 + ch];                  // k
     else if (g == 1) v = L.w_in[(256 + o) * 128 + ch];             // v
     else if (g == 2) v = L.w_in[o * 128 + ch] * SC;                // q
@@ -28,7 +29,7 @@ __global__ void pack_encw_kernel(EncWSrc s, unsigned short* __restrict__ img, fl
       const int c = (g - 4) >> 1;
       v = ((g - 4) & 1) ? L.w2[o * 512 + c * 128 + ch] : L.w1[(c * 128 + o) * 128 + ch];
     }
-    img[e] = f2h(v);
+    img[e] = hid ? f2h_hid(v) : f2h(v);
   }
   if (e < ENCW_NPAR) {
     float v;
@@ -274,17 +275,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int c = 0; c < 4; ++c) {                           // ---- fc1 chunk -> GELU -> fc2 partial
           bnd(li, p2 + 6 + 2 * c);
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt) acc[nt] = Z;
+          for (int nt = 0; nt < 8; ++nt) acc[nt] = hid_init(*reinterpret_cast<const float4*>(pl + ENCW_P_B1 + c * 128 + nt * 16 + l4 * 4));   // (packed-fp16 GELU: the bias is the initial value)
           gemm(0, xb, acc);
           h16x8 hb[4];
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             const float4 ba = *reinterpret_cast<const float4*>(pl + ENCW_P_B1 + c * 128 + (2 * ks) * 16 + l4 * 4);
             const float4 bb = *reinterpret_cast<const float4*>(pl + ENCW_P_B1 + c * 128 + (2 * ks + 1) * 16 + l4 * 4);
-            hb[ks] = l0w_from_u2(gelu4_pack(acc[2 * ks], ba), gelu4_pack(acc[2 * ks + 1], bb));
+            hb[ks] = l0w_from_u2(gelu4_hid(acc[2 * ks], ba), gelu4_hid(acc[2 * ks + 1], bb));
           }
           bnd(li, p2 + 7 + 2 * c);
-          gemm(1, hb, acc2);
+          decw_gemm<false, true>((uint32_t)(uintptr_t)ring + 32768u + voff, hb, acc2);      // fc2: hidden-layer operand words (opfmt.h)
         }
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) res[nt] += acc2[nt] * dp2;

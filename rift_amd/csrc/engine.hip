@@ -50,6 +50,7 @@ struct Param { void* data; int64_t numel; int ndim; int64_t shape[4]; };
 struct PW {   // packed weight image of one linear map Y = X W^T (+ b)
   void* bf = nullptr; float* f32 = nullptr; const float* bias = nullptr;
   int N = 0, K = 0, Kp = 0, Npad = 0;
+  void* hid = nullptr;          // (fc2 weights of the fused encoder only) the same image in hidden-layer operand words (opfmt.h); pack_hid
 };
 
 struct Tap { float* p; int64_t numel; };
@@ -280,6 +281,16 @@ int pack(RiftCtx* c, const std::string& key, const float* src, int n_src, int N,
   hipLaunchKernelGGL(pack_weight_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, src + src_col_off, (void*)w.f32,
                      n_src, K, w.Npad, w.Kp, conv_C, tap_lo, tap_n, src_row_off, src_ld);
   c->pw[key] = w;
+  return RIFT_OK;
+}
+
+// + the hidden-layer-operand image of an already packed weight (the fused scene encoder's fc2: its A rows are GELU outputs, common.h: gelu4_hid)
+int pack_hid(RiftCtx* c, const std::string& key) {
+  PW& w = c->pw[key];
+  const size_t cnt = (size_t)w.Npad * w.Kp;
+  HIPCHK(c, hipMalloc(&w.hid, cnt * 2));
+  c->owned.push_back(w.hid);
+  hipLaunchKernelGGL(pack_weight_hid_kernel, dim3(cdiv((long long)cnt, 256)), dim3(256), 0, c->stream, (const float*)w.f32, (unsigned short*)w.hid, w.Npad, w.Kp);
   return RIFT_OK;
 }
 
@@ -1349,7 +1360,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       w.wqkv = c->enc_wqkv[i]; w.bqkv = c->enc_bqkv[i];
       w.wo = (const unsigned short*)c->pw[p + ".attn.out_proj"].bf; w.bo = c->pw[p + ".attn.out_proj"].bias;
       w.w1 = (const unsigned short*)c->pw[p + ".mlp.fc1"].bf; w.b1 = c->pw[p + ".mlp.fc1"].bias;
-      w.w2 = (const unsigned short*)c->pw[p + ".mlp.fc2"].bf; w.b2 = c->pw[p + ".mlp.fc2"].bias;
+      w.w2 = (const unsigned short*)c->pw[p + ".mlp.fc2"].hid; w.b2 = c->pw[p + ".mlp.fc2"].bias;      // (hidden-layer operand words: pack_hid)
       w.droppath = f.drop ? edpr[i] : 0.f;
     }
     ep.norm_g = fptr(c, "norm.weight"); ep.norm_b = fptr(c, "norm.bias"); ep.nonfinite = c->nonfinite;
@@ -1790,7 +1801,7 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
   for (int i = 0; i < 4; ++i) {
     const std::string p = "encoder_blocks." + std::to_string(i);
     TRY(pack_self_mha(c, p + ".attn"));
-    TRY(pack_linear(c, p + ".mlp.fc1")); TRY(pack_linear(c, p + ".mlp.fc2"));
+    TRY(pack_linear(c, p + ".mlp.fc1")); TRY(pack_linear(c, p + ".mlp.fc2")); TRY(pack_hid(c, p + ".mlp.fc2"));
   }
   {  // chunked in_proj image for the fused encoder kernel: per 2-head chunk (q_h0 | k_h0 | q_h1 | k_h1 | v_h0 | v_h1)
     int idx[384];

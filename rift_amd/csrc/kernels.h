@@ -32,6 +32,13 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* dst, int
   if (BF16) reinterpret_cast<unsigned short*>(dst)[fm_index(n, k, Kp)] = f2h(v);   // fragment-major (common.h)
   else reinterpret_cast<float*>(dst)[idx] = v;
 }
+// the fragment-major image of an fc2 weight in hidden-layer operand words (opfmt.h: fp16 in the packed-fp16-GELU build), from the fp32 image
+__global__ void pack_weight_hid_kernel(const float* __restrict__ f32, unsigned short* __restrict__ dst, int Npad, int Kp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Npad * Kp) return;
+  const int n = idx / Kp, k = idx - n * Kp;
+  dst[fm_index(n, k, Kp)] = f2h_hid(f32[idx]);
+}
 
 // ---------------------------------------------------------------------------
 // feature builders

@@ -61,6 +61,7 @@ __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, f
   if (e < L0W_NFRAG * 512) {
     const int f = e >> 9, lane = (e >> 3) & 63, j = e & 7, l15 = lane & 15, l4 = lane >> 4;
     float v = 0.f;
+    bool hid = false;                              // fc2 fragments: hidden-layer operand words (common.h: f2h_hid)
     if (f < 2) {                                   // tokenizer: window index = tap * 9 + cin
       const int w = l4 * 8 + j, n = f * 16 + l15;
       if (w < 27) v = s.w_tok[(n * 9 + (w % 9)) * 3 + (w / 9)];
@@ -70,12 +71,12 @@ __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, f
       if (g < 6) v = k.wqkv[(g * 16 + l15) * 32 + l0w_chan(l4, j, 0)] * (g < 2 ? 0.25f : 1.0f);        // q scaled by head_dim^-0.5
       else if (g < 8) v = k.wproj[((g - 6) * 16 + l15) * 32 + l0w_chan(l4, j, 0)];
       else if (g < 14) v = k.w1[((g - 8) * 16 + l15) * 32 + l0w_chan(l4, j, 0)];
-      else { const int ks = (g - 14) >> 1, nt = (g - 14) & 1; v = k.w2[(nt * 16 + l15) * 96 + l0w_chan(l4, j, 2 * ks)]; }
+      else { const int ks = (g - 14) >> 1, nt = (g - 14) & 1; v = k.w2[(nt * 16 + l15) * 96 + l0w_chan(l4, j, 2 * ks)]; hid = true; }
     } else {
       const int tap = (f - L0W_F_DS) >> 2, nt = (f - L0W_F_DS) & 3;
       v = s.w_ds[((nt * 16 + l15) * 32 + l4 * 8 + j) * 3 + tap];
     }
-    img[e] = f2h(v);
+    img[e] = hid ? f2h_hid(v) : f2h(v);
   }
   if (e < L0W_NPAR) {
     float v = 0.f;
@@ -293,11 +294,11 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
           const float4 bb = *reinterpret_cast<const float4*>(pb + L0W_PB_B1 + (2 * ks + 1) * 16 + l4 * 4);
 #pragma unroll
           for (int mt = 0; mt < 5; ++mt) {
-            const f32x4 ha = mfma_h(wa, xn[mt], Z, 0, 0, 0);
-            const f32x4 hb = mfma_h(wb, xn[mt], Z, 0, 0, 0);
-            const h16x8 hop = l0w_from_u2(gelu4_pack(ha, ba), gelu4_pack(hb, bb));
-            acc2[mt][0] = mfma_h(u0, hop, acc2[mt][0], 0, 0, 0);
-            acc2[mt][1] = mfma_h(u1, hop, acc2[mt][1], 0, 0, 0);
+            const f32x4 ha = mfma_h(wa, xn[mt], hid_init(ba), 0, 0, 0);      // (packed-fp16 GELU: the bias is the accumulator's initial value)
+            const f32x4 hb = mfma_h(wb, xn[mt], hid_init(bb), 0, 0, 0);
+            const h16x8 hop = l0w_from_u2(gelu4_hid(ha, ba), gelu4_hid(hb, bb));
+            acc2[mt][0] = mfma_hid(u0, hop, acc2[mt][0]);
+            acc2[mt][1] = mfma_hid(u1, hop, acc2[mt][1]);
           }
         }
         const float4 b0 = *reinterpret_cast<const float4*>(pb + L0W_PB_B2 + l4 * 4), b1 = *reinterpret_cast<const float4*>(pb + L0W_PB_B2 + 16 + l4 * 4);

@@ -49,18 +49,19 @@ __global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, f
   if (e < L1W_NFRAG * 512) {
     const int f = e >> 9, lane = (e >> 3) & 63, j = e & 7, l15 = lane & 15, l4 = lane >> 4;
     float v;
+    bool hid = false;                              // fc2 fragments: hidden-layer operand words (common.h: f2h_hid)
     if (f < 2 * L1W_BLK_FRAGS) {
       const int b = f / L1W_BLK_FRAGS, g = f % L1W_BLK_FRAGS;
       const NatL1WSrc::Blk& k = s.blk[b];
       if (g < 24) { const int nt = g >> 1, ks = g & 1; v = k.wqkv[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)] * (nt < 4 ? 0.25f : 1.0f); }
       else if (g < 32) { const int nt = (g - 24) >> 1, ks = (g - 24) & 1; v = k.wproj[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)]; }
       else if (g < 56) { const int nt = (g - 32) >> 1, ks = (g - 32) & 1; v = k.w1[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)]; }
-      else { const int ks = (g - 56) >> 2, nt = (g - 56) & 3; v = k.w2[(nt * 16 + l15) * 192 + l0w_chan(l4, j, 2 * ks)]; }
+      else { const int ks = (g - 56) >> 2, nt = (g - 56) & 3; v = k.w2[(nt * 16 + l15) * 192 + l0w_chan(l4, j, 2 * ks)]; hid = true; }
     } else {
       const int g = f - 2 * L1W_BLK_FRAGS, nt = g & 7, ks = (g >> 3) & 1, tap = g >> 4;
       v = s.w_ds[((nt * 16 + l15) * 64 + ks * 32 + l4 * 8 + j) * 3 + tap];
     }
-    img[e] = f2h(v);
+    img[e] = hid ? f2h_hid(v) : f2h(v);
   }
   if (e < L1W_NPAR) {
     float v = 0.f;
@@ -258,13 +259,13 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
           const float4 bb = *reinterpret_cast<const float4*>(pb + L1W_PB_B1 + (2 * ks + 1) * 16 + l4 * 4);
 #pragma unroll
           for (int mt = 0; mt < 3; ++mt) {
-            f32x4 ha = mfma_h(wa0, xn[mt][0], Z, 0, 0, 0);
+            f32x4 ha = mfma_h(wa0, xn[mt][0], hid_init(ba), 0, 0, 0);      // (packed-fp16 GELU: the bias is the accumulator's initial value)
             ha = mfma_h(wa1, xn[mt][1], ha, 0, 0, 0);
-            f32x4 hb = mfma_h(wb0, xn[mt][0], Z, 0, 0, 0);
+            f32x4 hb = mfma_h(wb0, xn[mt][0], hid_init(bb), 0, 0, 0);
             hb = mfma_h(wb1, xn[mt][1], hb, 0, 0, 0);
-            const h16x8 hop = l0w_from_u2(gelu4_pack(ha, ba), gelu4_pack(hb, bb));
+            const h16x8 hop = l0w_from_u2(gelu4_hid(ha, ba), gelu4_hid(hb, bb));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = mfma_h(u[nt], hop, acc2[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) acc2[mt][nt] = mfma_hid(u[nt], hop, acc2[mt][nt]);
           }
         }
         float dp2 = 1.f;

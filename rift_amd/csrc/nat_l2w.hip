@@ -16,13 +16,14 @@ __global__ void pack_l2w_kernel(NatL2WSrc s, unsigned short* __restrict__ img, f
     const int ch = l0w_chan(l4, j, 2 * ks), o = nt * 16 + l15;
     const NatL2WSrc::Blk& k = s.blk[bi];
     float v;
+    const bool hid = g >= 4 && ((g - 4) & 1);      // fc2 fragments: hidden-layer operand words (common.h: f2h_hid)
     if (g < 3) v = k.wqkv[(g * 128 + o) * 128 + ch] * (g == 0 ? SC : 1.0f);
     else if (g == 3) v = k.wproj[o * 128 + ch];
     else {
       const int c = (g - 4) >> 1;
       v = ((g - 4) & 1) ? k.w2[o * 384 + c * 128 + ch] : k.w1[(c * 128 + o) * 128 + ch];
     }
-    img[e] = f2h(v);
+    img[e] = hid ? f2h_hid(v) : f2h(v);
   }
   if (e < L2W_NPAR) {
     float v = 0.f;
@@ -205,18 +206,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       init8(acc2, pb + L2W_PB_B2);
 #pragma unroll 1
       for (int c = 0; c < 3; ++c) {
-        boundary(s);
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) acc[nt] = Z;
+        for (int nt = 0; nt < 8; ++nt) acc[nt] = hid_init(*reinterpret_cast<const float4*>(pb + L2W_PB_B1 + c * 128 + nt * 16 + l4 * 4));   // (packed-fp16 GELU: the bias is the initial value)
+        boundary(s);
         gemm(slot_off(s), xb, acc); ++s;
         h16x8 hb[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const float4 ba = *reinterpret_cast<const float4*>(pb + L2W_PB_B1 + c * 128 + (2 * ks) * 16 + l4 * 4);
           const float4 bb = *reinterpret_cast<const float4*>(pb + L2W_PB_B1 + c * 128 + (2 * ks + 1) * 16 + l4 * 4);
-          hb[ks] = l0w_from_u2(gelu4_pack(acc[2 * ks], ba), gelu4_pack(acc[2 * ks + 1], bb));
+          hb[ks] = l0w_from_u2(gelu4_hid(acc[2 * ks], ba), gelu4_hid(acc[2 * ks + 1], bb));
         }
-        boundary(s); gemm(slot_off(s), hb, acc2); ++s;
+        boundary(s); decw_gemm<false, true>((uint32_t)(uintptr_t)ring + slot_off(s) + voff, hb, acc2); ++s;
       }
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) res[nt] += acc2[nt] * dp2;

@@ -22,3 +22,18 @@
 #define RIFT_MFMA_H_ASM "v_mfma_f32_16x16x32_bf16"
 #define RIFT_CVT_PK_H_ASM "v_cvt_pk_bf16_f32"
 #endif
+
+// ---- the MLP hidden layer of the history encoder (NAT levels) is an fp16 operand in BOTH builds (round 5) -------------------------------
+// GELU is evaluated in packed fp16 in the bf16 build (common.h: gelu_pk16x2) and its result is left as it comes out: an fp16 operand word
+// (11 significand bits against bf16's 8; same MFMA rate) -- no conversion back to bf16, and the fc2 weight fragments are packed as fp16 to
+// match (|w| < 10: far inside the format's range).  RIFT_GELU_F32 (diagnostic build define) restores the fp32 rational GELU and bf16 words.
+#if !RIFT_OP_F16 && !defined(RIFT_GELU_F32)
+#define RIFT_GELU_PK16 1
+#else
+#define RIFT_GELU_PK16 0
+#endif
+#if RIFT_OP_F16 || RIFT_GELU_PK16
+#define RIFT_MFMA_HID_ASM "v_mfma_f32_16x16x32_f16"
+#else
+#define RIFT_MFMA_HID_ASM "v_mfma_f32_16x16x32_bf16"
+#endif

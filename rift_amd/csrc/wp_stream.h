@@ -48,7 +48,106 @@ __device__ __forceinline__ void decw_dma_share(const unsigned char* src, uint32_
 // One group GEMM (16 rows x K = 128 against the 32 fragments at LDS address `addr` + 1024 f) as a hand-scheduled stream: the 8 fragments of
 // k-step ks + 1 are requested under the 8 MFMAs of k-step ks (lgkmcnt(8) = the fragment 8 requests back has landed), so an MFMA never waits a
 // full LDS round trip; hipcc's own schedule of the same loop kept 1-2 reads in flight.  PLAIN = activations as the A operand (V^T tiles).
-template <bool PLAIN>
+// HID: the weight fragments and x are operands of the MLP hidden layer (common.h: RIFT_MFMA_HID_ASM -- fp16 words in the bf16 build)
+#define DECW_GEMM_SWAPPED_ASM(MN) \
+        "ds_read_b128 %[w0], %[a] offset:0\n\t" \
+        "ds_read_b128 %[w1], %[a] offset:1024\n\t" \
+        "ds_read_b128 %[w2], %[a] offset:2048\n\t" \
+        "ds_read_b128 %[w3], %[a] offset:3072\n\t" \
+        "ds_read_b128 %[w4], %[a] offset:4096\n\t" \
+        "ds_read_b128 %[w5], %[a] offset:5120\n\t" \
+        "ds_read_b128 %[w6], %[a] offset:6144\n\t" \
+        "ds_read_b128 %[w7], %[a] offset:7168\n\t" \
+        "ds_read_b128 %[w8], %[a] offset:8192\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c0], %[w0], %[x0], %[c0]\n\t" \
+        "ds_read_b128 %[w9], %[a] offset:9216\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c1], %[w1], %[x0], %[c1]\n\t" \
+        "ds_read_b128 %[w10], %[a] offset:10240\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c2], %[w2], %[x0], %[c2]\n\t" \
+        "ds_read_b128 %[w11], %[a] offset:11264\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c3], %[w3], %[x0], %[c3]\n\t" \
+        "ds_read_b128 %[w12], %[a] offset:12288\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c4], %[w4], %[x0], %[c4]\n\t" \
+        "ds_read_b128 %[w13], %[a] offset:13312\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c5], %[w5], %[x0], %[c5]\n\t" \
+        "ds_read_b128 %[w14], %[a] offset:14336\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c6], %[w6], %[x0], %[c6]\n\t" \
+        "ds_read_b128 %[w15], %[a] offset:15360\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c7], %[w7], %[x0], %[c7]\n\t" \
+        "ds_read_b128 %[w0], %[a] offset:16384\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c0], %[w8], %[x1], %[c0]\n\t" \
+        "ds_read_b128 %[w1], %[a] offset:17408\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c1], %[w9], %[x1], %[c1]\n\t" \
+        "ds_read_b128 %[w2], %[a] offset:18432\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c2], %[w10], %[x1], %[c2]\n\t" \
+        "ds_read_b128 %[w3], %[a] offset:19456\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c3], %[w11], %[x1], %[c3]\n\t" \
+        "ds_read_b128 %[w4], %[a] offset:20480\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c4], %[w12], %[x1], %[c4]\n\t" \
+        "ds_read_b128 %[w5], %[a] offset:21504\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c5], %[w13], %[x1], %[c5]\n\t" \
+        "ds_read_b128 %[w6], %[a] offset:22528\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c6], %[w14], %[x1], %[c6]\n\t" \
+        "ds_read_b128 %[w7], %[a] offset:23552\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c7], %[w15], %[x1], %[c7]\n\t" \
+        "ds_read_b128 %[w8], %[a] offset:24576\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c0], %[w0], %[x2], %[c0]\n\t" \
+        "ds_read_b128 %[w9], %[a] offset:25600\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c1], %[w1], %[x2], %[c1]\n\t" \
+        "ds_read_b128 %[w10], %[a] offset:26624\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c2], %[w2], %[x2], %[c2]\n\t" \
+        "ds_read_b128 %[w11], %[a] offset:27648\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c3], %[w3], %[x2], %[c3]\n\t" \
+        "ds_read_b128 %[w12], %[a] offset:28672\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c4], %[w4], %[x2], %[c4]\n\t" \
+        "ds_read_b128 %[w13], %[a] offset:29696\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c5], %[w5], %[x2], %[c5]\n\t" \
+        "ds_read_b128 %[w14], %[a] offset:30720\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c6], %[w6], %[x2], %[c6]\n\t" \
+        "ds_read_b128 %[w15], %[a] offset:31744\n\t" \
+        "s_waitcnt lgkmcnt(8)\n\t" \
+        MN " %[c7], %[w7], %[x2], %[c7]\n\t" \
+        "s_waitcnt lgkmcnt(7)\n\t" \
+        MN " %[c0], %[w8], %[x3], %[c0]\n\t" \
+        "s_waitcnt lgkmcnt(6)\n\t" \
+        MN " %[c1], %[w9], %[x3], %[c1]\n\t" \
+        "s_waitcnt lgkmcnt(5)\n\t" \
+        MN " %[c2], %[w10], %[x3], %[c2]\n\t" \
+        "s_waitcnt lgkmcnt(4)\n\t" \
+        MN " %[c3], %[w11], %[x3], %[c3]\n\t" \
+        "s_waitcnt lgkmcnt(3)\n\t" \
+        MN " %[c4], %[w12], %[x3], %[c4]\n\t" \
+        "s_waitcnt lgkmcnt(2)\n\t" \
+        MN " %[c5], %[w13], %[x3], %[c5]\n\t" \
+        "s_waitcnt lgkmcnt(1)\n\t" \
+        MN " %[c6], %[w14], %[x3], %[c6]\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        MN " %[c7], %[w15], %[x3], %[c7]\n\t" \
+        "s_nop 15\n\t"
+template <bool PLAIN, bool HID = false>
 __device__ __forceinline__ void decw_gemm(uint32_t addr, const h16x8 (&x)[4], f32x4 (&c)[8]) {
   h16x8 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;
   if (PLAIN) {
@@ -155,107 +254,15 @@ __device__ __forceinline__ void decw_gemm(uint32_t addr, const h16x8 (&x)[4], f3
         : "memory");
   }
   if (!PLAIN) {
-    asm volatile(
-        "ds_read_b128 %[w0], %[a] offset:0\n\t"
-        "ds_read_b128 %[w1], %[a] offset:1024\n\t"
-        "ds_read_b128 %[w2], %[a] offset:2048\n\t"
-        "ds_read_b128 %[w3], %[a] offset:3072\n\t"
-        "ds_read_b128 %[w4], %[a] offset:4096\n\t"
-        "ds_read_b128 %[w5], %[a] offset:5120\n\t"
-        "ds_read_b128 %[w6], %[a] offset:6144\n\t"
-        "ds_read_b128 %[w7], %[a] offset:7168\n\t"
-        "ds_read_b128 %[w8], %[a] offset:8192\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c0], %[w0], %[x0], %[c0]\n\t"
-        "ds_read_b128 %[w9], %[a] offset:9216\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c1], %[w1], %[x0], %[c1]\n\t"
-        "ds_read_b128 %[w10], %[a] offset:10240\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c2], %[w2], %[x0], %[c2]\n\t"
-        "ds_read_b128 %[w11], %[a] offset:11264\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c3], %[w3], %[x0], %[c3]\n\t"
-        "ds_read_b128 %[w12], %[a] offset:12288\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c4], %[w4], %[x0], %[c4]\n\t"
-        "ds_read_b128 %[w13], %[a] offset:13312\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c5], %[w5], %[x0], %[c5]\n\t"
-        "ds_read_b128 %[w14], %[a] offset:14336\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c6], %[w6], %[x0], %[c6]\n\t"
-        "ds_read_b128 %[w15], %[a] offset:15360\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c7], %[w7], %[x0], %[c7]\n\t"
-        "ds_read_b128 %[w0], %[a] offset:16384\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c0], %[w8], %[x1], %[c0]\n\t"
-        "ds_read_b128 %[w1], %[a] offset:17408\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c1], %[w9], %[x1], %[c1]\n\t"
-        "ds_read_b128 %[w2], %[a] offset:18432\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c2], %[w10], %[x1], %[c2]\n\t"
-        "ds_read_b128 %[w3], %[a] offset:19456\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c3], %[w11], %[x1], %[c3]\n\t"
-        "ds_read_b128 %[w4], %[a] offset:20480\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c4], %[w12], %[x1], %[c4]\n\t"
-        "ds_read_b128 %[w5], %[a] offset:21504\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c5], %[w13], %[x1], %[c5]\n\t"
-        "ds_read_b128 %[w6], %[a] offset:22528\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c6], %[w14], %[x1], %[c6]\n\t"
-        "ds_read_b128 %[w7], %[a] offset:23552\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c7], %[w15], %[x1], %[c7]\n\t"
-        "ds_read_b128 %[w8], %[a] offset:24576\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c0], %[w0], %[x2], %[c0]\n\t"
-        "ds_read_b128 %[w9], %[a] offset:25600\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c1], %[w1], %[x2], %[c1]\n\t"
-        "ds_read_b128 %[w10], %[a] offset:26624\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c2], %[w2], %[x2], %[c2]\n\t"
-        "ds_read_b128 %[w11], %[a] offset:27648\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c3], %[w3], %[x2], %[c3]\n\t"
-        "ds_read_b128 %[w12], %[a] offset:28672\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c4], %[w4], %[x2], %[c4]\n\t"
-        "ds_read_b128 %[w13], %[a] offset:29696\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c5], %[w5], %[x2], %[c5]\n\t"
-        "ds_read_b128 %[w14], %[a] offset:30720\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c6], %[w6], %[x2], %[c6]\n\t"
-        "ds_read_b128 %[w15], %[a] offset:31744\n\t"
-        "s_waitcnt lgkmcnt(8)\n\t"
-        RIFT_MFMA_H_ASM " %[c7], %[w7], %[x2], %[c7]\n\t"
-        "s_waitcnt lgkmcnt(7)\n\t"
-        RIFT_MFMA_H_ASM " %[c0], %[w8], %[x3], %[c0]\n\t"
-        "s_waitcnt lgkmcnt(6)\n\t"
-        RIFT_MFMA_H_ASM " %[c1], %[w9], %[x3], %[c1]\n\t"
-        "s_waitcnt lgkmcnt(5)\n\t"
-        RIFT_MFMA_H_ASM " %[c2], %[w10], %[x3], %[c2]\n\t"
-        "s_waitcnt lgkmcnt(4)\n\t"
-        RIFT_MFMA_H_ASM " %[c3], %[w11], %[x3], %[c3]\n\t"
-        "s_waitcnt lgkmcnt(3)\n\t"
-        RIFT_MFMA_H_ASM " %[c4], %[w12], %[x3], %[c4]\n\t"
-        "s_waitcnt lgkmcnt(2)\n\t"
-        RIFT_MFMA_H_ASM " %[c5], %[w13], %[x3], %[c5]\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
-        RIFT_MFMA_H_ASM " %[c6], %[w14], %[x3], %[c6]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        RIFT_MFMA_H_ASM " %[c7], %[w15], %[x3], %[c7]\n\t"
-        "s_nop 15\n\t"
+    if (HID) asm volatile(DECW_GEMM_SWAPPED_ASM(RIFT_MFMA_HID_ASM)
         : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [w5] "=&v"(w5), [w6] "=&v"(w6), [w7] "=&v"(w7), [w8] "=&v"(w8), [w9] "=&v"(w9), [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [w14] "=&v"(w14), [w15] "=&v"(w15)
         : [a] "v"(addr), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3])
         : "memory");
+    else asm volatile(DECW_GEMM_SWAPPED_ASM(RIFT_MFMA_H_ASM)
+        : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [w5] "=&v"(w5), [w6] "=&v"(w6), [w7] "=&v"(w7), [w8] "=&v"(w8), [w9] "=&v"(w9), [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [w14] "=&v"(w14), [w15] "=&v"(w15)
+        : [a] "v"(addr), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3])
+        : "memory");
+
   }
 }
 

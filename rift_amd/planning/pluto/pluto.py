@@ -342,7 +342,11 @@ class PLUTO(CBVBasePolicy):
         # A tick is small CPU tensor work: torch's full intra-op pool spinning on it eats the container's CPU quota (capped_host_threads).
         # The cap is set ONCE, at the first tick, and stays (switching the pool size per tick costs more than it saves: measured 88 ms
         # stalls in one tick of ten); the reference runs under torch.set_num_threads(4) from its entry script (scripts/run.py:133,164).
+        # PROCESS-WIDE, like the reference's own setting; said once in the log; config['host_threads'] = 0 leaves the pool alone.
         if self._host_threads and torch.get_num_threads() > self._host_threads:
+            if self.logger is not None and hasattr(self.logger, "log"):
+                self.logger.log(f">> {self.name}: torch intra-op threads {torch.get_num_threads()} -> {int(self._host_threads)} for the whole "
+                                f"process (the reference's scripts/run.py does the same; config['host_threads'] = 0 keeps the pool)", 'yellow')
             torch.set_num_threads(int(self._host_threads))
         return self._get_action(CBVs_obs_list, infos, deterministic)
 
