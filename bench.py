@@ -53,7 +53,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(scenes, sd):
+def cpu_baseline(scenes, sd, contract=None):
     """The reference update step restated on the host cores (oracle = PyTorch-CPU fp32 port of the reference algorithm): CPU collate
     (pad_sequence) -> forward (BatchNorm batch stats, drop p=0) -> RIFT loss -> autograd pi_head backward -> clip 0.5 -> AdamW.
     Bounded sample (~25 s): 5 steps at 32 threads (the fastest count measured on the 256-core GPU box: 4 -> 76, 8 -> 117, 16 -> 131,
@@ -99,7 +99,16 @@ def cpu_baseline(scenes, sd):
     threads = min(32, hw)
     n, dt = run(threads, 5)
     n4, dt4 = run(min(4, hw), 2)
-    return {"value": n * BATCH / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
+    contract_oracle = None
+    if contract is not None:
+        # the precision contract's checker side (main(): precision_contract): the four objectives of the parity test's 256-scene batch from the
+        # oracle, exactly as tests/test_gpu_parity.py::test_benchmark_batch_objectives_in_16bit_modes computes them -- checker only, not timed
+        torch.set_num_threads(threads)
+        cdata = contract["cur_pluto_feature_torch"]
+        _, _, ctaps = pluto_ref.planning_model_forward(sd, cdata, train_bn=True, need_traj=False, want_taps=True)
+        c_pad = ~cdata["reference_line"]["valid_mask"].any(-1)
+        contract_oracle = {kind: float(losses.pi_head_loss_and_grads(sd, ctaps["q_final"], kind, _clone_tree(contract), c_pad)[0]) for kind in CONTRACT_KINDS}
+    return {"contract_oracle": contract_oracle, "value": n * BATCH / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
             "sample": f"{n} update steps x {BATCH} scenes (collate+fwd all outputs+RIFT loss+bwd+clip+AdamW), PyTorch-CPU fp32 oracle, "
                       f"train-mode BatchNorm batch statistics with every drop probability 0 (the GPU step runs dropout / DropPath / "
                       f"state-dropout: the oracle has no RNG work to do), {dt:.1f}s at {threads} threads; {n4} steps, {dt4:.1f}s at 4 threads",
@@ -197,17 +206,6 @@ def contract_device_losses(dev, sd, batch, precision):
         out[kind] = float(eng.loss_finalize(stats, flat, grads).item())
     eng.close()
     return out
-
-
-def contract_oracle_losses(sd, batch):
-    """The same four objectives from the CPU oracle (fp32 restatement of the reference, pinned to the reference-generated goldens by
-    tests/test_oracle_*.py).  The oracle is the CHECKER of the contract figures, exactly as in the parity test; it runs with the CPU baseline."""
-    from oracle import losses, pluto_ref
-    data = batch["cur_pluto_feature_torch"]
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    _, _, taps = pluto_ref.planning_model_forward(sd, data, train_bn=True, need_traj=False, want_taps=True)
-    r_pad = ~data["reference_line"]["valid_mask"].any(-1)
-    return {kind: float(losses.pi_head_loss_and_grads(sd, taps["q_final"], kind, _clone_tree(batch), r_pad)[0]) for kind in CONTRACT_KINDS}
 
 
 def self_launch(args):
@@ -632,9 +630,9 @@ def main():
             line["roofline"] = head["roofline"]
         if not args.no_cpu_baseline:
             # (rank 0's host cores; the other ranks wait at the closing barrier.  A 256-scene CPU step whatever N is: the reference is single-device)
-            line["cpu_baseline"] = cpu_baseline(scenes_cpu, sd_cpu)
+            line["cpu_baseline"] = cpu_baseline(scenes_cpu, sd_cpu, contract["batch"] if contract is not None else None)
+            want = line["cpu_baseline"].pop("contract_oracle")
             if contract is not None:
-                want = contract_oracle_losses(sd_cpu, contract["batch"])
                 pc = {"tolerance": 1e-4, "batch": "256 scenes (synthetic ids 1000..1255), train-mode BatchNorm batch statistics, drops disabled; "
                                                   "the batch of tests/test_gpu_parity.py::test_benchmark_batch_objectives_in_16bit_modes",
                       "checker": "oracle/ (PyTorch-CPU fp32 restatement of the reference, pinned to reference-generated goldens); computed in this run",

@@ -21,6 +21,18 @@ __device__ __forceinline__ f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c, int, int, int
 #endif
 }
 
+// K = 16 form (v_mfma_f32_16x16x16_{bf16,f16}): operands are 4 words = 2 VGPRs, lane (l15, l4) holds k = 4 l4 + j -- the natural fit of a
+// 16-dim attention head: a projection's C/D fragment (4 consecutive channels of row l15) IS its operand, no zero half, no permutation.
+typedef __attribute__((ext_vector_type(4))) short h16x4;
+__device__ __forceinline__ f32x4 mfma_h16(h16x4 a, h16x4 b, f32x4 c) {
+#if RIFT_OP_F16
+  typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+#endif
+}
+
 // two fp32 -> packed operand pair (round-to-nearest-even) in ONE instruction (gfx950 v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).  The `s_nop 0`
 // is part of the contract: an MFMA that reads a VALU-written VGPR as an operand needs TWO wait states behind the write
 // (tools/ubench/cvt_mfma_hazard.hip on MI355X: 0 or 1 states -> the MFMA reads the register's previous content in 95-100 % of the issues,
@@ -71,6 +83,25 @@ __device__ __forceinline__ unsigned int h_pair_exact(float lo, float hi) {
 __device__ __forceinline__ uint2 pack_h4(float a, float b, float c, float d) {
   uint2 u; u.x = pack_h2(a, b); u.y = pack_h2(c, d); return u;
 }
+// The same conversion as hipcc's OWN instruction (fptrunc <2 x float> lowers to v_cvt_pk_{bf16,f16}_f32 on gfx950).  Use this form whenever
+// an input may be a fresh MFMA result: the wait states between an MFMA write and a VALU read are software's to insert, hipcc pads its own
+// instructions and never the inside of an asm statement (round 5: an asm conversion fed by an accumulator read stale registers -> NaN).
+// The two wait states ahead of a consuming MFMA are hipcc's to pad as well.
+__device__ __forceinline__ unsigned int pack_h2c(float lo, float hi) {
+  f32x2_t v; v.x = lo; v.y = hi;
+#if RIFT_OP_F16
+  typedef _Float16 hc2 __attribute__((ext_vector_type(2)));
+#else
+  typedef __bf16 hc2 __attribute__((ext_vector_type(2)));
+#endif
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hc2));
+}
+__device__ __forceinline__ h16x4 pack_h16x4(float a, float b, float c, float d) {
+  uint2 u; u.x = pack_h2c(a, b); u.y = pack_h2c(c, d);
+  return __builtin_bit_cast(h16x4, u);
+}
+__device__ __forceinline__ h16x4 h16x4_lo(const h16x8 w) { return (h16x4){w[0], w[1], w[2], w[3]}; }
+__device__ __forceinline__ h16x4 h16x4_hi(const h16x8 w) { return (h16x4){w[4], w[5], w[6], w[7]}; }
 
 // ---- bf16 weight images are stored FRAGMENT-MAJOR ---------------------------------------------------------------------
 // A weight matrix W[N][Kp] (N padded to 16, Kp to 32) is cut into MFMA operand fragments: fragment (nt, ks) = rows

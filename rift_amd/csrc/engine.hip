@@ -469,8 +469,8 @@ int set_lds_attrs(RiftCtx* c) {
   SETATTR_N(fpn_tail_kernel, FPN_LDS);
   SETATTR_N(heads3_fused_kernel, HD_LDS);
   SETATTR_N(pi_forward_kernel, PI_LDS);
-  SETATTR_N(nat_l0w_kernel, L0W_LDS);
-  SETATTR_N(nat_l1w_kernel, L1W_LDS);
+  HIPCHK(c, (hipError_t)l0w_set_attributes());
+  HIPCHK(c, (hipError_t)l1w_set_attributes());
 #undef SETATTR_N
   return RIFT_OK;
 }
@@ -1107,7 +1107,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         q.droppath[0] = f.drop ? dpr[0] : 0.f; q.droppath[1] = f.drop ? dpr[1] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + 2.0 * rows * 27 * 32 + (rows / 2) * 2.0 * 3 * C * 2 * C;
-        launch(c, "nat_l0w_kernel", nat_l0w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid)), dim3(64 * L0W_NWV), (size_t)L0W_LDS, q);
+        { const int g0 = std::min(cdiv(cdiv(nA, 4), L0W_NWV), c->nat_grid); launch_call(c, "nat_l0w_kernel", [&] { l0w_launch(q, g0, c->stream); }); }
         continue;
       }
       if (lv == 1) {   // level 1 likewise (weights swapped through LDS between the two layers): nat_l1w.h
@@ -1117,7 +1117,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         q.droppath[0] = f.drop ? dpr[2] : 0.f; q.droppath[1] = f.drop ? dpr[3] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (rows / 2) * 2.0 * 3 * C * 2 * C;
-        launch(c, "nat_l1w_kernel", nat_l1w_kernel, dim3(std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid)), dim3(512), (size_t)L1W_LDS, q);
+        { const int g1 = std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid); launch_call(c, "nat_l1w_kernel", [&] { l1w_launch(q, g1, c->stream); }); }
         continue;
       }
       {   // level 2: wave-private tiles of 3 agents, the two layers' weights streamed through LDS (nat_l2w.h)
@@ -1743,7 +1743,7 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     q.w_ds = fptr(c, HE + ".levels.0.downsample.reduction.weight"); q.ds_g = fptr(c, HE + ".levels.0.downsample.norm.weight"); q.ds_b = fptr(c, HE + ".levels.0.downsample.norm.bias");
     if (!c->err.empty()) return RIFT_ERR_ARG;
     if (!c->l0w_img) { HIPCHK(c, hipMalloc((void**)&c->l0w_img, (size_t)L0W_NFRAG * 1024)); HIPCHK(c, hipMalloc((void**)&c->l0w_par, (size_t)L0W_NPAR * 4)); }
-    hipLaunchKernelGGL(pack_l0w_kernel, dim3(cdiv(L0W_NFRAG * 512, 256)), dim3(256), 0, c->stream, q, c->l0w_img, c->l0w_par);
+    l0w_pack(q, c->l0w_img, c->l0w_par, c->stream);
   }
   {  // wave-private level-1 kernel (nat_l1w.h)
     NatL1WSrc q; memset(&q, 0, sizeof(q));
@@ -1759,7 +1759,7 @@ int rift_model_load(RiftCtx* c, const RiftTensorDesc* params, int n, void* strea
     q.w_ds = fptr(c, HE + ".levels.1.downsample.reduction.weight"); q.ds_g = fptr(c, HE + ".levels.1.downsample.norm.weight"); q.ds_b = fptr(c, HE + ".levels.1.downsample.norm.bias");
     if (!c->err.empty()) return RIFT_ERR_ARG;
     if (!c->l1w_img) { HIPCHK(c, hipMalloc((void**)&c->l1w_img, (size_t)L1W_NFRAG * 1024)); HIPCHK(c, hipMalloc((void**)&c->l1w_par, (size_t)L1W_NPAR * 4)); }
-    hipLaunchKernelGGL(pack_l1w_kernel, dim3(cdiv(L1W_NFRAG * 512, 256)), dim3(256), 0, c->stream, q, c->l1w_img, c->l1w_par);
+    l1w_pack(q, c->l1w_img, c->l1w_par, c->stream);
   }
   {  // wave-private level-2 kernel (nat_l2w.h)
     NatL2WSrc q; memset(&q, 0, sizeof(q));

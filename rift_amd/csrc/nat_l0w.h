@@ -41,12 +41,36 @@ namespace RIFT_NS {
 #define L0W_PB_B2 368
 #define L0W_P_FN 832
 #define L0W_P_DS 896
-#define L0W_NPAR 1024
+// (RIFT_NAT_MFMA_ATTN) score-accumulator table [block 2][head 2][tile class 3: first / middle / last][row 5: quad lane s of the query, 4 = "another
+// agent's keys"][8: prev tile's key 3 | own tile's keys 0..3 | next tile's key 0 | pad 2] = rpb[h][key step - query step + 2] * log2 e for the
+// keys inside the query's window (start clamp(t - 1, 0, L - 3)), L0W_NEG for every other key
+#define L0W_P_TBL 1024
+#define L0W_NEG (-1.0e30f)
+#define L0W_NPAR (1024 + 2 * 2 * 3 * 5 * 8)
 #define L0W_ST 40                         // staging tile row stride (bf16): 80 B rows, 16-byte aligned fragments
 #ifndef L0W_NWV
 #define L0W_NWV 8                        // waves per workgroup (= per CU: the LDS image allows one workgroup); 12 -> 168 VGPRs per wave
 #endif
 #define L0W_LDS (L0W_NFRAG * 1024 + L0W_NPAR * 4 + L0W_NWV * 80 * L0W_ST * 2)
+
+#if RIFT_NAT_MFMA_ATTN
+#define L0W_QSCALE (0.25f * 1.4426950408889634f)
+#else
+#define L0W_QSCALE 0.25f
+#endif
+// One entry of the score-accumulator table of the MFMA neighbourhood attention (kernel 3) of a level with L steps in row tiles of 4 steps:
+// query = quad lane `row` of tile mt (row 4: a lane that holds another agent's keys), slot 0 = key 3 of tile mt - 1, 1..4 = keys 0..3 of
+// tile mt, 5 = key 0 of tile mt + 1.  natten's window of step t starts at clamp(t - 1, 0, L - 3); rpb index = key - query + 2.  A query step
+// beyond the sequence (level 1's tile 2 has two of them per agent) sees itself only: a row without any key would turn NaN, and a NaN key
+// row poisons every query through the score MFMA.
+__host__ __device__ __forceinline__ float nat_band_entry(const float* rpb, int L, int mt, int row, int slot, float neg) {
+  if (row >= 4 || slot >= 6) return neg;
+  const int qt = 4 * mt + row, kt = slot == 0 ? 4 * mt - 1 : slot == 5 ? 4 * mt + 4 : 4 * mt + slot - 1;
+  if (qt >= L) return kt == qt ? rpb[2] * 1.4426950408889634f : neg;
+  if (kt < 0 || kt >= L) return neg;
+  const int w0 = qt - 1 < 0 ? 0 : qt - 1 > L - 3 ? L - 3 : qt - 1;
+  return (kt >= w0 && kt <= w0 + 2) ? rpb[kt - qt + 2] * 1.4426950408889634f : neg;
+}
 
 struct NatL0WSrc {    // raw fp32 parameters (views onto the state_dict) for pack_l0w_kernel
   const float* w_tok; const float* b_tok;                                   // embed.proj (32, 9, 3), (32)
@@ -56,6 +80,7 @@ struct NatL0WSrc {    // raw fp32 parameters (views onto the state_dict) for pac
 };
 
 
+#ifdef RIFT_NAT_L01_IMPL
 __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, float* __restrict__ par) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < L0W_NFRAG * 512) {
@@ -68,7 +93,7 @@ __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, f
     } else if (f < L0W_F_DS) {
       const int b = (f - 2) / 20, g = (f - 2) % 20;
       const NatL0WSrc::Blk& k = s.blk[b];
-      if (g < 6) v = k.wqkv[(g * 16 + l15) * 32 + l0w_chan(l4, j, 0)] * (g < 2 ? 0.25f : 1.0f);        // q scaled by head_dim^-0.5
+      if (g < 6) v = k.wqkv[(g * 16 + l15) * 32 + l0w_chan(l4, j, 0)] * (g < 2 ? L0W_QSCALE : 1.0f);        // q scaled by head_dim^-0.5 (x log2 e: MFMA attention)
       else if (g < 8) v = k.wproj[((g - 6) * 16 + l15) * 32 + l0w_chan(l4, j, 0)];
       else if (g < 14) v = k.w1[((g - 8) * 16 + l15) * 32 + l0w_chan(l4, j, 0)];
       else { const int ks = (g - 14) >> 1, nt = (g - 14) & 1; v = k.w2[(nt * 16 + l15) * 96 + l0w_chan(l4, j, 2 * ks)]; hid = true; }
@@ -86,7 +111,7 @@ __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, f
       const NatL0WSrc::Blk& k = s.blk[b];
       if (o < 32) v = k.ln1_g[o];
       else if (o < 64) v = k.ln1_b[o - 32];
-      else if (o < 160) v = k.bqkv[o - 64] * (o - 64 < 32 ? 0.25f : 1.0f);
+      else if (o < 160) v = k.bqkv[o - 64] * (o - 64 < 32 ? L0W_QSCALE : 1.0f);
       else if (o < 176) v = (o - 160 < 10) ? k.rpb[o - 160] : 0.f;
       else if (o < 208) v = k.bproj[o - 176];
       else if (o < 240) v = k.ln2_g[o - 208];
@@ -94,10 +119,15 @@ __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, f
       else if (o < 368) v = k.b1[o - 272];
       else v = k.b2[o - 368];
     } else if (e < L0W_P_DS) v = (e - L0W_P_FN < 32) ? s.fn_g[e - L0W_P_FN] : s.fn_b[e - L0W_P_FN - 32];
-    else v = (e - L0W_P_DS < 64) ? s.ds_g[e - L0W_P_DS] : s.ds_b[e - L0W_P_DS - 64];
+    else if (e < L0W_P_TBL) v = (e - L0W_P_DS < 64) ? s.ds_g[e - L0W_P_DS] : s.ds_b[e - L0W_P_DS - 64];
+    else {
+      const int t = e - L0W_P_TBL, slot = t & 7, row = (t >> 3) % 5, cls = (t / 40) % 3, h = (t / 120) % 2, bi = t / 240;
+      v = nat_band_entry(s.blk[bi].rpb + h * 5, 20, cls == 0 ? 0 : cls == 2 ? 4 : 2, row, slot, L0W_NEG);
+    }
     par[e] = v;
   }
 }
+#endif
 
 struct NatL0WP {
   const float* F9; int nseq;               // (nseq * 20, 9) agent features
@@ -114,6 +144,11 @@ struct NatL0WP {
   DropStats ds;                            // diagnostic build only (dropstats.h)
 };
 
+int l0w_set_attributes();
+void l0w_pack(const NatL0WSrc& src, unsigned short* img, float* par, hipStream_t stream);
+void l0w_launch(const NatL0WP& p, int grid, hipStream_t stream);
+
+#ifdef RIFT_NAT_L01_IMPL      // the kernels live in nat_l01w.hip (their own translation unit, built like nat_l2w.hip: -fno-honor-nans -mno-amdgpu-ieee)
 template <int CTRL>
 __device__ __forceinline__ f32x4 l0w_dpp4(const f32x4 v) {
   return (f32x4){dpp_f<CTRL>(v[0]), dpp_f<CTRL>(v[1]), dpp_f<CTRL>(v[2]), dpp_f<CTRL>(v[3])};
@@ -215,6 +250,59 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
       if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
       if (p.droppath[bi] > 0.f) ds_sample(p.ds, RIFT_DS_NAT(0, bi, 0), seq_ok ? seq : -1, dps);
       const h16x8 wp0 = W(fb + 6), wp1 = W(fb + 7);
+#if RIFT_NAT_MFMA_ATTN
+      // 1-D neighbourhood attention (kernel 3, window start clamp(t - 1, 0, L - 3)) on the matrix pipe, K = 16 MFMAs (a head is 16 dims: a
+      // projection's C/D fragment IS the operand).  A lane row is (agent a, step 4 mt + s): the score tile S^T = K Q^T of row tile mt against
+      // key tile mt' holds, in lane (query l15, l4), the four keys of AGENT l4 in tile mt' -- so every key a query may see sits in the ONE
+      // lane l4 = a: its own tile's four, key 3 of the tile before, key 0 of the tile behind.  The band mask and rpb are the score
+      // accumulator's initial value (a table row picked by (l4 == a ? s : "other agent"); L0W_NEG, not -inf: the other agents' lanes must come
+      // out as P = 0, not NaN -- the row maximum is floored at -1e20 and 1 / sum is taken of max(sum, tiny)), so the softmax has no cross-lane
+      // step at all; O^T = V^T P^T takes V^T out of a plain-order MFMA (level 2's scheme); DropPath rides on 1 / sum and proj (the head's 16
+      // input channels = one half of the K = 32 weight fragment) accumulates straight into the residual.  ~40 VALU instructions per head and row
+      // tile against ~150 of the DPP form below.
+      const int trow = (l4 == a) ? s : 4;
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        h16x4 kop[5], vt[5];
+        const h16x8 wq = W(fb + h);
+        {
+          const h16x8 wk = W(fb + 2 + h), wv = W(fb + 4 + h);
+          const float4 bk = *reinterpret_cast<const float4*>(pb + L0W_PB_BQKV + 32 + h * 16 + l4 * 4);
+          const float bv = pb[L0W_PB_BQKV + 64 + h * 16 + l15];
+#pragma unroll
+          for (int mt = 0; mt < 5; ++mt) {
+            const f32x4 kk = mfma_h(wk, xn[mt], (f32x4){bk.x, bk.y, bk.z, bk.w}, 0, 0, 0);      // 4 head dims of row l15: the A operand of S^T
+            kop[mt] = pack_h16x4(kk[0], kk[1], kk[2], kk[3]);
+            const f32x4 vv = mfma_h(xn[mt], wv, (f32x4){bv, bv, bv, bv}, 0, 0, 0);             // plain order: the 4 keys of agent l4 in this tile, head dim l15 = a V^T fragment
+            vt[mt] = pack_h16x4(vv[0], vv[1], vv[2], vv[3]);
+          }
+        }
+        const float4 bq = *reinterpret_cast<const float4*>(pb + L0W_PB_BQKV + h * 16 + l4 * 4);
+        const float* tb = par + L0W_P_TBL + ((bi * 2 + h) * 15 + trow) * 8;
+        const h16x4 wpa = h == 0 ? h16x4_lo(wp0) : h16x4_hi(wp0), wpb = h == 0 ? h16x4_lo(wp1) : h16x4_hi(wp1);
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+          const int cls = mt == 0 ? 0 : mt == 4 ? 2 : 1;
+          const float4 ca = *reinterpret_cast<const float4*>(tb + cls * 40), cb = *reinterpret_cast<const float4*>(tb + cls * 40 + 4);
+          const f32x4 qq = mfma_h(wq, xn[mt], (f32x4){bq.x, bq.y, bq.z, bq.w}, 0, 0, 0);
+          const h16x4 qop = pack_h16x4(qq[0], qq[1], qq[2], qq[3]);
+          const f32x4 so = mfma_h16(kop[mt], qop, (f32x4){ca.y, ca.z, ca.w, cb.x});
+          float sp = L0W_NEG, sn = L0W_NEG;
+          if (mt > 0) sp = mfma_h16(kop[mt - 1], qop, (f32x4){L0W_NEG, L0W_NEG, L0W_NEG, ca.x})[3];
+          if (mt < 4) sn = mfma_h16(kop[mt + 1], qop, (f32x4){cb.y, L0W_NEG, L0W_NEG, L0W_NEG})[0];
+          const float m = fmaxf(fmaxf(fmaxf(so[0], so[1]), fmaxf(so[2], so[3])), fmaxf(fmaxf(sp, sn), -1.0e20f));
+          const float e0 = __builtin_amdgcn_exp2f(so[0] - m), e1 = __builtin_amdgcn_exp2f(so[1] - m), e2 = __builtin_amdgcn_exp2f(so[2] - m), e3 = __builtin_amdgcn_exp2f(so[3] - m);
+          const float ep = mt > 0 ? __builtin_amdgcn_exp2f(sp - m) : 0.f, en = mt < 4 ? __builtin_amdgcn_exp2f(sn - m) : 0.f;
+          const float inv = __builtin_amdgcn_rcpf(fmaxf(((e0 + e1) + (e2 + e3)) + (ep + en), 1.0e-30f)) * dps;
+          f32x4 o = mfma_h16(vt[mt], pack_h16x4(e0 * inv, e1 * inv, e2 * inv, e3 * inv), Z);
+          if (mt > 0) o = mfma_h16(vt[mt - 1], pack_h16x4(0.f, 0.f, 0.f, ep * inv), o);
+          if (mt < 4) o = mfma_h16(vt[mt + 1], pack_h16x4(en * inv, 0.f, 0.f, 0.f), o);
+          const h16x4 ao = pack_h16x4(o[0], o[1], o[2], o[3]);
+          x[mt][0] = mfma_h16(wpa, ao, x[mt][0]);
+          x[mt][1] = mfma_h16(wpb, ao, x[mt][1]);
+        }
+      }
+#else
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
         f32x4 k[5], v[5];
@@ -273,6 +361,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
           x[mt][1] += mfma_h(wp1, ao, Z, 0, 0, 0) * dps;
         }
       }
+#endif
       {   // proj bias
         const float4 b0 = *reinterpret_cast<const float4*>(pb + L0W_PB_BP + l4 * 4), b1 = *reinterpret_cast<const float4*>(pb + L0W_PB_BP + 16 + l4 * 4);
 #pragma unroll
@@ -398,6 +487,8 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
   }
 }
 
+#endif
+
 // Ranks the marked agent slots for the compacted launch: aidx[3 i + c] = the i-th marked slot of residue class c = slot % 3, cnt[c] = the
 // class counts (common.h: SeqCount).  ONE workgroup: thread t counts the marks of slots [t K, (t + 1) K) per class (three
 // 21-bit fields of one word), a workgroup-wide exclusive scan, then the ranks in order.  Behind the input preparation on whatever stream
@@ -500,9 +591,11 @@ __device__ __forceinline__ void nat_rank_body(const uint8_t* __restrict__ hist, 
   }
   if (tid == 0) { cnt[0] = (int)(total & 0x1fffffu); cnt[1] = (int)((total >> 21) & 0x1fffffu); cnt[2] = (int)((total >> 42) & 0x1fffffu); }
 }
+#ifndef RIFT_NAT_L01_IMPL      // (engine.hip owns this one)
 __global__ __launch_bounds__(NAT_RANK_THREADS) void nat_rank_kernel(const uint8_t* __restrict__ hist, int n, int* __restrict__ aidx, int* __restrict__ cnt) {
   __shared__ unsigned long long wsum[NAT_RANK_THREADS / 64];
   nat_rank_body(hist, n, aidx, cnt, wsum);
 }
+#endif
 
 }  // namespace RIFT_NS

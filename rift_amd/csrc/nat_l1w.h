@@ -34,7 +34,10 @@ namespace RIFT_NS {
 #define L1W_PB_B2 736
 #define L1W_P_FN 1600
 #define L1W_P_DS 1728
-#define L1W_NPAR 2048
+// (RIFT_NAT_MFMA_ATTN) score-accumulator table [block 2][head 4][row tile 3][row 5][8] (nat_l0w.h: nat_band_entry; tile 2 holds steps 8, 9 and two
+// rows beyond the sequence per agent, which see themselves only)
+#define L1W_P_TBL 2048
+#define L1W_NPAR (2048 + 2 * 4 * 3 * 5 * 8)
 #define L1W_ST 72               // staging row stride (bf16): 144 B
 #define L1W_LDS (L1W_BLK_FRAGS * 1024 + L1W_NPAR * 4 + 8 * 40 * L1W_ST * 2)
 
@@ -44,6 +47,7 @@ struct NatL1WSrc {
   const float* w_ds; const float* ds_g; const float* ds_b;                  // levels.1.downsample.reduction (128, 64, 3), norm (128)
 };
 
+#ifdef RIFT_NAT_L01_IMPL
 __global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, float* __restrict__ par) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < L1W_NFRAG * 512) {
@@ -53,7 +57,7 @@ __global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, f
     if (f < 2 * L1W_BLK_FRAGS) {
       const int b = f / L1W_BLK_FRAGS, g = f % L1W_BLK_FRAGS;
       const NatL1WSrc::Blk& k = s.blk[b];
-      if (g < 24) { const int nt = g >> 1, ks = g & 1; v = k.wqkv[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)] * (nt < 4 ? 0.25f : 1.0f); }
+      if (g < 24) { const int nt = g >> 1, ks = g & 1; v = k.wqkv[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)] * (nt < 4 ? L0W_QSCALE : 1.0f); }
       else if (g < 32) { const int nt = (g - 24) >> 1, ks = (g - 24) & 1; v = k.wproj[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)]; }
       else if (g < 56) { const int nt = (g - 32) >> 1, ks = (g - 32) & 1; v = k.w1[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)]; }
       else { const int ks = (g - 56) >> 2, nt = (g - 56) & 3; v = k.w2[(nt * 16 + l15) * 192 + l0w_chan(l4, j, 2 * ks)]; hid = true; }
@@ -70,7 +74,7 @@ __global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, f
       const NatL1WSrc::Blk& k = s.blk[b];
       if (o < 64) v = k.ln1_g[o];
       else if (o < 128) v = k.ln1_b[o - 64];
-      else if (o < 320) v = k.bqkv[o - 128] * (o - 128 < 64 ? 0.25f : 1.0f);
+      else if (o < 320) v = k.bqkv[o - 128] * (o - 128 < 64 ? L0W_QSCALE : 1.0f);
       else if (o < 352) v = (o - 320 < 20) ? k.rpb[o - 320] : 0.f;
       else if (o < 416) v = k.bproj[o - 352];
       else if (o < 480) v = k.ln2_g[o - 416];
@@ -79,9 +83,14 @@ __global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, f
       else v = k.b2[o - 736];
     } else if (e < L1W_P_DS) v = (e - L1W_P_FN < 64) ? s.fn_g[e - L1W_P_FN] : s.fn_b[e - L1W_P_FN - 64];
     else if (e < L1W_P_DS + 256) v = (e - L1W_P_DS < 128) ? s.ds_g[e - L1W_P_DS] : s.ds_b[e - L1W_P_DS - 128];
+    else if (e >= L1W_P_TBL) {
+      const int t = e - L1W_P_TBL, slot = t & 7, row = (t >> 3) % 5, mt = (t / 40) % 3, h = (t / 120) % 4, bi = t / 480;
+      v = nat_band_entry(s.blk[bi].rpb + h * 5, 10, mt, row, slot, L0W_NEG);
+    }
     par[e] = v;
   }
 }
+#endif
 
 struct NatL1WP {
   const float* X; int nseq;                // (nseq * 10, 64) level input (level 0's downsample output)
@@ -95,6 +104,11 @@ struct NatL1WP {
 };
 
 // LayerNorm over the 64 channels of every row (16 per lane, 4 lanes per row) -> bf16 operands of the two k-steps
+int l1w_set_attributes();
+void l1w_pack(const NatL1WSrc& src, unsigned short* img, float* par, hipStream_t stream);
+void l1w_launch(const NatL1WP& p, int grid, hipStream_t stream);
+
+#ifdef RIFT_NAT_L01_IMPL      // the kernels live in nat_l01w.hip
 __device__ __forceinline__ void l1w_layer_norm(const f32x4 (&x)[3][4], h16x8 (&xn)[3][2], const float* g, const float* b, int l4) {
   float4 gg[4], bb[4];
 #pragma unroll
@@ -173,6 +187,56 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
       float dps = 1.f;
       if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
       if (p.droppath[bi] > 0.f) ds_sample(p.ds, RIFT_DS_NAT(1, bi, 0), seq_ok ? seq : -1, dps);
+#if RIFT_NAT_MFMA_ATTN
+      // neighbourhood attention on the matrix pipe (nat_l0w.h describes the scheme): 4 heads x 3 row tiles, K = 16 MFMAs
+      const int trow = (l4 == a) ? s : 4;
+#pragma unroll 1
+      for (int h = 0; h < 4; ++h) {
+        h16x4 kop[3], vt[3];
+        {
+          const h16x8 wk0 = W(L1W_F_QKV(4 + h, 0)), wk1 = W(L1W_F_QKV(4 + h, 1)), wv0 = W(L1W_F_QKV(8 + h, 0)), wv1 = W(L1W_F_QKV(8 + h, 1));
+          const float4 bk = *reinterpret_cast<const float4*>(pb + L1W_PB_BQKV + 64 + h * 16 + l4 * 4);
+          const float bv = pb[L1W_PB_BQKV + 128 + h * 16 + l15];
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) {
+            f32x4 kk = mfma_h(wk0, xn[mt][0], (f32x4){bk.x, bk.y, bk.z, bk.w}, 0, 0, 0);
+            kk = mfma_h(wk1, xn[mt][1], kk, 0, 0, 0);
+            kop[mt] = pack_h16x4(kk[0], kk[1], kk[2], kk[3]);
+            f32x4 vv = mfma_h(xn[mt][0], wv0, (f32x4){bv, bv, bv, bv}, 0, 0, 0);      // plain order: the 4 keys of agent l4 in this tile, head dim l15
+            vv = mfma_h(xn[mt][1], wv1, vv, 0, 0, 0);
+            vt[mt] = pack_h16x4(vv[0], vv[1], vv[2], vv[3]);
+          }
+        }
+        const h16x8 wq0 = W(L1W_F_QKV(h, 0)), wq1 = W(L1W_F_QKV(h, 1));
+        const float4 bq = *reinterpret_cast<const float4*>(pb + L1W_PB_BQKV + h * 16 + l4 * 4);
+        const int pks = h >> 1;                                    // proj k-step that holds this head's 16 channels (its lower / upper half)
+        h16x4 wp[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { const h16x8 w = W(L1W_F_PROJ(nt, pks)); wp[nt] = (h & 1) ? h16x4_hi(w) : h16x4_lo(w); }
+        const float* tb = par + L1W_P_TBL + ((bi * 4 + h) * 15 + trow) * 8;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+          const float4 ca = *reinterpret_cast<const float4*>(tb + mt * 40), cb = *reinterpret_cast<const float4*>(tb + mt * 40 + 4);
+          f32x4 qq = mfma_h(wq0, xn[mt][0], (f32x4){bq.x, bq.y, bq.z, bq.w}, 0, 0, 0);
+          qq = mfma_h(wq1, xn[mt][1], qq, 0, 0, 0);
+          const h16x4 qop = pack_h16x4(qq[0], qq[1], qq[2], qq[3]);
+          const f32x4 so = mfma_h16(kop[mt], qop, (f32x4){ca.y, ca.z, ca.w, cb.x});
+          float sp = L0W_NEG, sn = L0W_NEG;
+          if (mt > 0) sp = mfma_h16(kop[mt - 1], qop, (f32x4){L0W_NEG, L0W_NEG, L0W_NEG, ca.x})[3];
+          if (mt < 2) sn = mfma_h16(kop[mt + 1], qop, (f32x4){cb.y, L0W_NEG, L0W_NEG, L0W_NEG})[0];
+          const float m = fmaxf(fmaxf(fmaxf(so[0], so[1]), fmaxf(so[2], so[3])), fmaxf(fmaxf(sp, sn), -1.0e20f));
+          const float e0 = __builtin_amdgcn_exp2f(so[0] - m), e1 = __builtin_amdgcn_exp2f(so[1] - m), e2 = __builtin_amdgcn_exp2f(so[2] - m), e3 = __builtin_amdgcn_exp2f(so[3] - m);
+          const float ep = mt > 0 ? __builtin_amdgcn_exp2f(sp - m) : 0.f, en = mt < 2 ? __builtin_amdgcn_exp2f(sn - m) : 0.f;
+          const float inv = __builtin_amdgcn_rcpf(fmaxf(((e0 + e1) + (e2 + e3)) + (ep + en), 1.0e-30f)) * dps;
+          f32x4 o = mfma_h16(vt[mt], pack_h16x4(e0 * inv, e1 * inv, e2 * inv, e3 * inv), Z);
+          if (mt > 0) o = mfma_h16(vt[mt - 1], pack_h16x4(0.f, 0.f, 0.f, ep * inv), o);
+          if (mt < 2) o = mfma_h16(vt[mt + 1], pack_h16x4(en * inv, 0.f, 0.f, 0.f), o);
+          const h16x4 ao = pack_h16x4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) x[mt][nt] = mfma_h16(wp[nt], ao, x[mt][nt]);
+        }
+      }
+#else
 #pragma unroll 1
       for (int h = 0; h < 4; ++h) {
         f32x4 k[3], v[3];
@@ -235,6 +299,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
           for (int nt = 0; nt < 4; ++nt) x[mt][nt] += mfma_h(wp[nt], ao, Z, 0, 0, 0) * dps;
         }
       }
+#endif
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const float4 b4 = *reinterpret_cast<const float4*>(pb + L1W_PB_BP + nt * 16 + l4 * 4);
@@ -371,5 +436,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
     }
   }
 }
+
+#endif
 
 }  // namespace RIFT_NS

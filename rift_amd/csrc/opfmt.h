@@ -37,3 +37,13 @@
 #else
 #define RIFT_MFMA_HID_ASM "v_mfma_f32_16x16x32_bf16"
 #endif
+
+// ---- neighbourhood attention of NAT levels 0 / 1 on the matrix pipe (round 5; nat_l0w.h, nat_l1w.h) ------------------------------------
+// bf16 build: q, k, v and the attention weights are 16-bit MFMA operands (as in level 2 and in the scene encoder / decoder); the fp16
+// build keeps the fp32 VALU attention of rounds 2 - 4 bit for bit (its bars are measured on that arithmetic).  RIFT_NAT_VALU_ATTN
+// (diagnostic build define) restores the VALU form in the bf16 build.
+#if !RIFT_OP_F16 && !defined(RIFT_NAT_VALU_ATTN)
+#define RIFT_NAT_MFMA_ATTN 1
+#else
+#define RIFT_NAT_MFMA_ATTN 0
+#endif

@@ -6,7 +6,7 @@ sys.path.insert(0, REPO)
 from rift_amd import build as b
 
 out = ""
-for tu, extra in (("engine.hip", []), ("dec_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l2w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
+for tu, extra in (("engine.hip", []), ("dec_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l2w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l01w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
                           ("enc_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
                           ("pe_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
                           ("fo_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
