@@ -12,6 +12,15 @@ no tests or fixtures for them.  What is restated is the published behaviour of t
     result is non-empty (R/:268-271), so collision == any envelope overlap.
   * the raster lookup after the mask has been drawn (R/:299-318) is plain numpy and is restated line by line; drawing the mask
     (cv2.fillPoly over HD-map polygons, R/:284-297,323-325) needs CARLA map data and stays with the caller.
+
+Round 5, the attempt to pin them (round-4 review, "next" 4c): neither library can be had in the build container -- `import shapely` /
+`import cv2` fail under /usr/bin/python3 and under /opt/conda/bin/python (3.9), `pip download shapely` finds no distribution (no index, no
+network), no wheel, libgeos or OpenCV shared object exists anywhere on the filesystem (`find / -name "libgeos*" -o -name "*.whl" | grep -i
+-E "geos|shapely|opencv"`: empty; the one hit for "opencv" is a cascade XML inside scikit-image's data directory).  scikit-image's
+`draw.polygon` is present in the conda environment but is a DIFFERENT rasteriser (even-odd point-in-polygon at pixel centres against
+cv2.fillPoly's scan conversion with its own edge rule), so a fixture made with it would pin the wrong semantics.  The row stays "parity
+unpinned"; what holds the two kernels is the 42 hand-derived known answers of tests/golden/traj_flags_kat.json (envelope ties, half-pixel
+ties, raster edges, flipped y, rotation).
 """
 import numpy as np
 

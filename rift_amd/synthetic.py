@@ -32,8 +32,10 @@ def _gen(seed: int) -> torch.Generator:
 
 
 def make_scene(scene_idx: int, num_agents: int = 64, num_polygons: int = 20,
-               r_min: int = 1, r_max: int = 6) -> Dict:
-    """One replay entry: feature dict + RIFT/GRPO/PPO/REINFORCE extras."""
+               r_min: int = 1, r_max: int = 6, max_static: int = 0) -> Dict:
+    """One replay entry: feature dict + RIFT/GRPO/PPO/REINFORCE extras.
+    max_static > 0: S ~ U{1..max_static} static objects (static_objects_encoder.py:17-40; CARLA produces none, nuPlan scenes do), drawn from
+    a generator of their own so that every other tensor of the scene is the one the S = 0 scene has."""
     g = _gen(SCENE_SEED0 + scene_idx)
     A, Mp, T = num_agents, num_polygons, HIST_STEPS
 
@@ -126,6 +128,16 @@ def make_scene(scene_idx: int, num_agents: int = 64, num_polygons: int = 20,
         "position": torch.zeros(0, 2), "heading": torch.zeros(0), "shape": torch.zeros(0, 2),
         "category": torch.zeros(0, dtype=torch.int8), "valid_mask": torch.zeros(0, dtype=torch.bool),
     }
+    if max_static > 0:
+        gs = _gen(SCENE_SEED0 + 1_000_003 + scene_idx)
+        S = int(torch.randint(1, max_static + 1, (1,), generator=gs).item())
+        svalid = torch.rand(S, generator=gs) < 0.8
+        svalid[0] = True
+        static = {
+            "position": (torch.randn(S, 2, generator=gs) * 30.0).float(), "heading": ((torch.rand(S, generator=gs) * 4 - 2) * math.pi).float(),   # beyond +-pi: the encoder wraps it
+            "shape": (0.5 + 2.5 * torch.rand(S, 2, generator=gs)).float(), "category": torch.randint(0, 4, (S,), generator=gs).to(torch.int8),
+            "valid_mask": svalid,
+        }
     cur = randn(7).float()
     cur[:3] = 0.0
     feature = {

@@ -27,15 +27,26 @@ from rift_amd import synthetic as syn  # noqa: E402
 from tests.golden import ref_loader  # noqa: E402
 
 CASES = {
-    # name: (scene indices, num_agents, num_polygons, r_min, r_max)
+    # name: (scene indices, num_agents, num_polygons, r_min, r_max[, max_static])
     "small": (list(range(100, 106)), 12, 8, 1, 4),
     "full": ([7, 8], 64, 20, 1, 6),
+    # round 5 (`python -m tests.golden.gen_golden shapes`): the shapes that run the OTHER kernel variants, pinned to the reference itself --
+    # BASELINE configs[4] (168 token slots, R up to 16: enc_w_kernel / dec_w_kernel<., true>), the shapes train_cbv produces (rift_pluto.yaml:35-36:
+    # 49 agent slots + 60 polygons = 109 token slots) and scenes WITH static objects (static_objects_encoder.py:17-40; S = 0 everywhere else)
+    "dense": ([300, 301, 302], 128, 40, 8, 16),
+    "carla": ([310, 311, 312], 49, 60, 1, 6),
+    "static": ([320, 321, 322, 323], 12, 8, 1, 4, 5),
 }
+SHAPE_CASES = ("dense", "carla", "static")
+# what the shape cases keep (the dense trajectory tensors alone would be megabytes): the policy's outputs the losses read, the hooks that localise
+# a disagreement, the RIFT loss and its pi_head gradients, the train-mode BatchNorm forward
+SHAPE_KEYS = ("eval.probability", "eval.hidden", "eval.ref_free_trajectory", "eval.tap.x_agent", "eval.tap.x_polygon", "eval.tap.enc_out", "eval.tap.q_final",
+              "trainbn.probability", "trainbn.hidden", "weight_digest", "input_digest")
 
 
 def build_batch(case):
-    idx, A, Mp, r0, r1 = CASES[case]
-    scenes = [syn.make_scene(i, A, Mp, r0, r1) for i in idx]
+    idx, A, Mp, r0, r1, *rest = CASES[case]
+    scenes = [syn.make_scene(i, A, Mp, r0, r1, *rest) for i in idx]
     return syn.collate_scenes(scenes)
 
 
@@ -47,7 +58,7 @@ def to_np(t):
     return t.detach().cpu().numpy()
 
 
-def main():
+def main(cases=("small", "full")):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_loader.install()
@@ -65,7 +76,7 @@ def main():
     # ppo_trainer imports hydra-bound PPOPlutoModel; its loss needs only these attributes:
     import torch.nn as nn
 
-    for case in CASES:
+    for case in cases:
         batch = build_batch(case)
         data = batch["cur_pluto_feature_torch"]
         out = {"weight_digest": weight_digest, "input_digest": syn.digest(syn.flatten_dict(batch))}
@@ -156,10 +167,12 @@ def main():
             if "running_" in k or "num_batches" in k:
                 out["trainbn.stat." + k] = to_np(v)
 
+        if case in SHAPE_CASES:
+            out = {k: v for k, v in out.items() if k in SHAPE_KEYS or k.startswith("rift.") or k == "eval.trajectory" and case != "dense"}
         path = os.path.join(HERE, f"pluto_{case}.npz")
         np.savez_compressed(path, **out)
         print(case, "->", path, f"{os.path.getsize(path) / 1e6:.2f} MB",
-              {k: float(out[k + '.loss']) for k in ('rift', 'grpo', 'reinforce', 'ppo')})
+              {k: float(out[k + '.loss']) for k in ('rift', 'grpo', 'reinforce', 'ppo') if k + '.loss' in out})
 
 
 def _load_ppo_loss_fn():
@@ -675,7 +688,9 @@ def gen_buffer():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "buffer":
+    if len(sys.argv) > 1 and sys.argv[1] == "shapes":
+        main(SHAPE_CASES)
+    elif len(sys.argv) > 1 and sys.argv[1] == "buffer":
         gen_buffer()
     elif len(sys.argv) > 1 and sys.argv[1] == "feature_builder":
         gen_feature_builder()

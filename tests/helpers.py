@@ -14,7 +14,12 @@ GOLDEN = os.path.join(HERE, "golden")
 CASES = {
     "small": (list(range(100, 106)), 12, 8, 1, 4),
     "full": ([7, 8], 64, 20, 1, 6),
+    # round 5 (gen_golden.py `shapes`): reference-generated fixtures at the shapes of the other kernel variants, and with static objects
+    "dense": ([300, 301, 302], 128, 40, 8, 16),
+    "carla": ([310, 311, 312], 49, 60, 1, 6),
+    "static": ([320, 321, 322, 323], 12, 8, 1, 4, 5),
 }
+SHAPE_CASES = ("dense", "carla", "static")
 
 
 def manifest():
@@ -32,8 +37,16 @@ def weights():
 
 
 def build_batch(case):
-    idx, A, Mp, r0, r1 = CASES[case]
-    return syn.collate_scenes([syn.make_scene(i, A, Mp, r0, r1) for i in idx])
+    idx, A, Mp, r0, r1, *rest = CASES[case]
+    return syn.collate_scenes([syn.make_scene(i, A, Mp, r0, r1, *rest) for i in idx])
+
+
+def token_padding(data):
+    """(bs, A + Mp + S) key-padding mask of the scene tokens (pluto_model.py:133-147)."""
+    parts = [~data["agent"]["valid_mask"].any(-1), ~data["map"]["valid_mask"].any(-1)]
+    if data["static_objects"]["valid_mask"].shape[1] > 0:
+        parts.append(~data["static_objects"]["valid_mask"])
+    return torch.cat(parts, dim=-1)
 
 
 def load_case(case):

@@ -126,6 +126,57 @@ def test_forward_eval(ffi, case, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("case", H.SHAPE_CASES)
+@pytest.mark.parametrize("mode", MODES)
+def test_forward_at_the_other_kernel_variants_shapes_against_the_reference(ffi, case, mode):
+    """HIP against fixtures the REFERENCE produced (not only the oracle) at the shapes that leave the benchmark's kernels: `dense` = BASELINE
+    configs[4] (168 token slots, R up to 16 -> enc_w_kernel, dec_w_kernel<., true>), `carla` = rift_pluto.yaml:35-36 (109 token slots),
+    `static` = scenes with static objects (static_objects_encoder.py:17-40: the device path of engine.hip `static_token_kernel`, the
+    two-dimensional Fourier embedding and the unfused token assembly -- no other test runs S > 0).  Eval forward, train-mode BatchNorm
+    forward, RIFT loss + pi_head gradients (fp32: the contract's 1e-5 / 1e-4; 16-bit modes: the bars of test_forward_eval)."""
+    gold, batch, sd = H.load_case(case)
+    data = batch["cur_pluto_feature_torch"]
+    fp32 = mode == "fp32"
+    tol = {"fp32": 1e-4, "bf16": 4e-2, "fp16": 8e-3}[mode]
+    eng = _engine(ffi, mode)
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    eng.prof_enable(True)
+    out = eng.forward(data, need_traj=True, fp32=fp32)
+    torch.cuda.synchronize()
+    ran = set(eng.prof_report())
+    eng.prof_enable(False)
+    if not fp32:
+        if case == "dense":
+            assert "enc_w_kernel" in ran and "dec_w_kernel" in ran, sorted(ran)
+        if case == "static":
+            assert "static_token_kernel" in ran, sorted(ran)
+    kpm, rv = H.token_padding(data), data["reference_line"]["valid_mask"].any(-1)
+    bs, N, R = kpm.shape[0], kpm.shape[1], rv.shape[1]
+    eo = eng.tap("enc_out").view(bs, N, 128).cpu()
+    assert err(eo[~kpm], torch.from_numpy(gold["eval.tap.enc_out"])[~kpm]) < tol
+    qf = eng.tap("q_final").view(bs, R, 12, 128).cpu()
+    assert err(qf[rv], torch.from_numpy(gold["eval.tap.q_final"])[rv]) < {"fp32": 2e-4, "bf16": 2e-1, "fp16": 4e-2}[mode]
+    print(f"{case}[{mode}]: max |logit - reference| = {err(out['probability'], gold['eval.probability']):.3e}")
+    assert err(out["probability"], gold["eval.probability"]) < tol
+    assert err(out["hidden"], gold["eval.hidden"]) < tol
+    assert err(out["ref_free_trajectory"], gold["eval.ref_free_trajectory"]) < tol
+    if "eval.trajectory" in gold:
+        assert err(out["trajectory"].cpu()[rv], torch.from_numpy(gold["eval.trajectory"])[rv]) < tol
+    stats, flat, _ = eng.loss_backward("rift", H.clone_tree(batch))
+    grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
+    loss = float(eng.loss_finalize(stats, flat, grads).item())
+    print(f"{case}[{mode}]: |RIFT loss - reference| = {abs(loss - float(gold['rift.loss'])):.3e}")
+    assert abs(loss - float(gold["rift.loss"])) < {"fp32": 1e-5, "bf16": 3.5e-3, "fp16": 3.5e-4}[mode]
+    if fp32:
+        for k in grads:
+            ref = gold[f"rift.grad.{k}"]
+            assert err(grads[k], ref) < 1e-5 + 1e-4 * float(np.abs(ref).max()), k
+    out_t = eng.forward(data, train=True, no_drop=True, bn_update=False, fp32=fp32)
+    assert err(out_t["probability"], gold["trainbn.probability"]) < tol
+    assert err(out_t["hidden"], gold["trainbn.hidden"]) < tol
+    eng.close()
+
+
 @pytest.mark.parametrize("case", ["small", "full"])
 @pytest.mark.parametrize("kind", ["rift", "grpo", "reinforce", "ppo"])
 def test_losses_and_pi_head_grads(ffi, case, kind):

@@ -1,7 +1,7 @@
 #!/bin/bash
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-for b in 256 128; do
+for b in ${BATCHES:-256 128}; do
   rm -rf /tmp/tl_$b
   rocprofv3 --kernel-trace -d /tmp/tl_$b -o tl -- python $REPO/bench.py --batch $b --steps 60 --warmup 5 --no-cpu-baseline --no-roofline --no-full-update --no-precisions --no-carla --no-tick --no-e2e > /tmp/tl_$b.json 2> /tmp/tl_$b.err
   DB=$(find /tmp/tl_$b -name '*.db' | head -1)
