@@ -176,6 +176,64 @@ def pmc_mfma(label, path=None):
     return None
 
 
+def collect_counters(label, precision):
+    """Roofline counters of the kernel behind `label`, collected in THIS run: three short child runs of this file (4 profiled update steps each,
+    serial launches like the roofline leg) under `rocprofv3 --kernel-trace --pmc ...` -- one pass per counter group, kernel-trace only, as
+    MI355X_MICROARCH.md's rocprofv3 section prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass) -- read back from the rocpd database.
+    Returns None when rocprofv3 is not on the box (the caller then falls back to the committed tables and says so)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None or os.environ.get("RIFT_BENCH_NO_PMC") == "1":
+        return None
+    key = kernel_of(label)
+    passes = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"]]
+    got, launches = {}, 0
+    env = dict(os.environ, RIFT_TWO_STREAMS="0", RIFT_PIPELINE="0", TMPDIR="/tmp")
+    root = tempfile.mkdtemp(prefix="rift_pmc_", dir="/tmp")
+    try:
+        for i, ctrs in enumerate(passes):
+            out = os.path.join(root, f"p{i}")
+            cmd = [rp, "--kernel-trace", "--pmc"] + ctrs + ["-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2",
+                   "--replay", "512", "--precision", precision, "--no-cpu-baseline", "--no-roofline", "--no-full-update", "--no-precisions", "--no-carla",
+                   "--no-tick", "--no-e2e"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                sys.stderr.write(f"bench.py: counter pass {ctrs} failed (rc {r.returncode}): {r.stderr[-300:]}\n")
+                return None
+            con = sqlite3.connect(dbs[0])
+            cols = [c[1] for c in con.execute("pragma table_info('counters_collection')")]
+            kcol = "kernel_name" if "kernel_name" in cols else "name"
+            ncol = "counter_name" if "counter_name" in cols else "pmc_name"
+            vcol = "value" if "value" in cols else "counter_value"
+            did = "dispatch_id" if "dispatch_id" in cols else None
+            q = f"select {kcol}, {ncol}, sum({vcol}), {'count(distinct ' + did + ')' if did else 'count(*)'} from counters_collection group by {kcol}, {ncol}"
+            for kname, cname, total, n in con.execute(q):
+                if key in kname:
+                    got[cname] = got.get(cname, 0.0) + float(total)
+                    launches = max(launches, int(n))
+            con.close()
+    except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as e:
+        sys.stderr.write(f"bench.py: counter collection failed: {e}\n")
+        return None
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES")
+    if launches == 0 or any(k not in got for k in need):
+        sys.stderr.write(f"bench.py: no counters for {label!r} (kernel key {key!r}; got {sorted(got)})\n")
+        return None
+    # per launch; gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> x2 (MI355X_MICROARCH.md, HBM); KB -> B
+    # (each pass profiles the same launches, so per-pass sums divide by the same count)
+    n = float(launches)
+    return {"traffic": (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0 / n, "fetch_kb": got["FETCH_SIZE"] / n, "write_kb": got["WRITE_SIZE"] / n,
+            "mfma_flops": got["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0 / n,
+            "mfma_busy_frac": got["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * got["SQ_BUSY_CU_CYCLES"]) if got["SQ_BUSY_CU_CYCLES"] else None,
+            "launches_profiled": launches}
+
+
 CONTRACT_KINDS = ("rift", "grpo", "reinforce", "ppo")
 
 
@@ -235,6 +293,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"], help="precision of the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="roofline counters from the committed profiles/ tables instead of three rocprofv3 --pmc child runs of this command")
     ap.add_argument("--no-precisions", action="store_true", help="skip the fp16 / fp32 companion legs (N = 1)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="which scaling mode is the headline with N > 1 (the other one is reported beside it). strong (default): the reference's "
@@ -438,13 +497,17 @@ def main():
                 gemm_ms = sum(v["ms"] for k, v in rep.items() if k.startswith("gemm_"))
                 gemm_fl = sum(v["flops"] for k, v in rep.items() if k.startswith("gemm_"))
                 ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12 if dom[1]["ms"] > 0 else 0.0
-                traffic = pmc_traffic(dom[0])
+                live = collect_counters(dom[0], precision) if (world == 1 and not args.no_pmc) else None
+                traffic = live["traffic"] if live else pmc_traffic(dom[0])
                 tfile = pmc_traffic_file()
                 roof = {"bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-                        "traffic_source": (os.path.relpath(tfile, REPO) if tfile else "none") +
-                                          ": (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from separate rocprofv3 --pmc passes of this bench "
-                                          "(tools/profile_round.sh); committed measurement, not collected in this run",
+                        "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_collected": bool(live),
+                        "traffic_source": ("collected in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch of this kernel from child runs of this command under "
+                                           "rocprofv3 --kernel-trace --pmc (one pass per counter group, 4 profiled steps each; x2 on FETCH_SIZE = the gfx950 "
+                                           "correction of MI355X_MICROARCH.md)") if live else
+                                          ((os.path.relpath(tfile, REPO) if tfile else "none") +
+                                           ": (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from separate rocprofv3 --pmc passes of this bench "
+                                           "(tools/profile_round.sh); committed measurement, NOT collected in this run (rocprofv3 unavailable or the pass failed)"),
                         "avg_launch_us": dom[1]["ms"] * 1e3 / dom[1]["count"], "launches_per_step": dom[1]["count"] / nprof,
                         "launch_mode": "per-kernel HIP-event times of a SERIAL-launch leg (the profiler puts the forward's chains on one stream and "
                                        "this leg switches the deferred tail off): each kernel alone on the device; the timed region above runs "
@@ -458,7 +521,9 @@ def main():
                 if traffic is None:       # loud: a renamed kernel must not turn the traffic figure into a silent null
                     roof["traffic_missing"] = f"no entry for {dom[0]!r} in {os.path.relpath(tfile, REPO) if tfile else 'profiles/ (no table)'}"
                     sys.stderr.write(f"bench.py: WARNING: roofline.traffic is null: {roof['traffic_missing']} -- re-run tools/profile_round.sh\n")
-                mf = pmc_mfma(dom[0])
+                if live:
+                    roof["fetch_kb_per_launch"], roof["write_kb_per_launch"], roof["launches_profiled"] = live["fetch_kb"], live["write_kb"], live["launches_profiled"]
+                mf = (live["mfma_flops"], live["mfma_busy_frac"], "collected in this run") if live else pmc_mfma(dom[0])
                 if mf is not None and roof["algorithmic_flops_per_launch"]:
                     roof["executed_over_algorithmic_mops"] = mf[0] / roof["algorithmic_flops_per_launch"]
                     roof["mfma_busy_frac"] = mf[1]

@@ -642,6 +642,17 @@ class RLFTTrainer:
         self.loss_acc.zero_()
         return v
 
+    def pop_mean_loss_async(self, out: torch.Tensor):
+        """pop_mean_loss() without the host: the mean training loss since the last call is written into the device f64 scalar `out` on the
+        current stream (which first joins the update stream: the epoch's parameters are final for whatever is queued behind).  The caller reads
+        its epochs back in ONE copy at the end of the update and calls check_finite() there (the flag is sticky)."""
+        self.wait_update()
+        n, self.loss_n = self.loss_n, 0
+        used = n % self.LOSS_SLOTS or (self.LOSS_SLOTS if n else 0)
+        torch.add(self.loss_acc[0], self.loss_hist[:used].sum(), out=out)
+        out.div_(max(n, 1))
+        self.loss_acc.zero_()
+
     def check_finite(self):
         """The engine's non-finite flag is per shard: under data parallelism every rank learns whether ANY rank saw a non-finite
         decoder query (one scalar exchange), so that all of them raise together instead of one raising and the others waiting in the

@@ -88,14 +88,47 @@ def main():
     d0 = torch.cat([(runs[0][2][k].cpu() - init["planning_decoder.pi_head." + k]).flatten() for k in runs[0][2]]).double()
     d1 = torch.cat([(runs[1][2][k].cpu() - init["planning_decoder.pi_head." + k]).flatten() for k in runs[1][2]]).double()
     wp = 1.0 - float((d0 @ d1) / (d0.norm() * d1.norm()))
-    t = torch.tensor([worst, worst2, wp], device=dev)
+    # the LIBRARY-owned communicator (rift_comm_init(ctx, ncclUniqueId, rank, world)) with world > 1 -- real RCCL ranks only
+    # (RCCL refuses two ranks on one device, so the same-GPU gloo variant skips it): rank 0's unique id goes to everybody over the process
+    # group, every rank joins, an all-reduce over it sums what torch.distributed's sums, and one sharded fp32 training forward whose three
+    # exchanges go over it (rift_set_dp with exchange = NULL) reproduces the loss of the torch.distributed exchange
+    worst3 = 0.0
+    if not same and world > 1:
+        a = RLFTTrainer(model(), kind="rift", process_group=dist.group.WORLD)
+        fb, b = replay.collate(a.engine, idx[lo:hi])
+        want = float(a.forward_loss(fb, b, train=True, shard=(lo, n)).item())
+        want_g = {k: p.grad.clone() for k, p in a.params.items()}
+        a.close()
+        tr = RLFTTrainer(model(), kind="rift")
+        eng = tr.engine
+        box = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.comm_init(box[0], rank, world)
+        v = torch.full((16899,), float(rank + 1), dtype=torch.float64, device=dev)
+        eng.comm_all_reduce(v)
+        torch.cuda.synchronize()
+        assert float((v - world * (world + 1) / 2).abs().max()) == 0.0
+        tr.exchange = eng.comm_all_reduce                      # the loss exchange of the step over the library's communicator as well
+        tr.xchg = torch.zeros(16899, dtype=torch.float64, device=dev)
+        tr.lo.exchange = tr.xchg.data_ptr()
+        tr.rank, tr.world = rank, world
+        xchg = torch.zeros(n * 16 + 1026, dtype=torch.float64, device=dev)
+        eng.set_dp_library_comm(lo, n, xchg)
+        tr._set_shard = lambda *a, **k: None                  # (keep the descriptor set above: exchange = NULL, the library's communicator)
+        fb, b = replay.collate(eng, idx[lo:hi])
+        got = float(tr.forward_loss(fb, b, train=True).item())
+        worst3 = abs(got - want) + max(float((tr.params[k].grad - want_g[k]).abs().max()) for k in want_g)
+        eng.clear_dp()
+        eng.comm_destroy()
+        tr.close()
+    t = torch.tensor([worst, worst2, wp, worst3], device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     dist.destroy_process_group()
     # (fp32 part: 1e-5 held with the emulated ranks of tests/test_gpu_dp.py on gradients; after three AdamW steps with real ranks 1.3e-5)
     # (the cosine: AdamW's first steps move EVERY element by lr * sign(gradient), also the ~1 % whose gradient is rounding noise: 0.9906 with two
     # and 0.9908 with three real ranks; the losses are the statement)
-    assert float(t[0]) < 5e-5 and float(t[1]) < 2e-4 and float(t[2]) < 2e-2, t.tolist()
+    assert float(t[0]) < 5e-5 and float(t[1]) < 2e-4 and float(t[2]) < 2e-2 and float(t[3]) < 1e-6, t.tolist()
     if rank == 0:
         print("DP_WORKER_OK", t.tolist(), flush=True)
 

@@ -478,6 +478,43 @@ def test_rlft_train_updates_only_pi_head_and_checkpoints(policy, tmp_path):
 
 
 @pytest.mark.gpu
+def test_deferred_top1_decision_writes_the_checkpoint_of_the_per_epoch_decision(tmp_path):
+    """Round 5: the update keeps every epoch's losses and moving tensors on the device and decides top-1 ONCE, behind the last epoch (one host
+    read per update instead of two per epoch).  It must choose what Lightning's per-epoch `ModelCheckpoint(save_top_k=1, monitor=loss/val_loss)`
+    chooses (training_builder.py:131-140; here: `checkpoint_every_improvement: True`, the per-epoch path): the same file name (epoch and
+    val_loss), bit-identical tensors, the same history -- fp32 mode, drops disabled by seeding both runs alike (same e_i -> same seeds)."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    results = {}
+    for mode, every in (("deferred", False), ("per_epoch", True)):
+        root = tmp_path / mode
+        cfg = {'num_scenario': 1, 'ROOT_DIR': str(root), 'model_path': 'ckpt', 'device': 'cuda:0', 'compute_precision': 'fp32',
+               'rlft': {'epochs': 6, 'warmup_epochs': 1, 'train_batch_size': 16, 'val_batch_size': 16, 'lr': 3e-3, 'checkpoint_every_improvement': every}}
+        pol = CBV_POLICY_LIST['rift_pluto'](cfg, None)
+        torch.manual_seed(0)
+        with torch.no_grad():
+            for p in pol.pluto_model.parameters():
+                if p.dim() > 1:
+                    p.normal_(0, 0.05)
+        pol.load_model(resume=True)
+        pol.set_mode('train')
+        pol.set_buffer(_filled_buffer(48, with_ref=False))
+        fit = pol.train(5)
+        ck = list((root / 'ckpt' / pol.load_agent_info).glob("*.ckpt"))
+        assert len(ck) == 1
+        results[mode] = (fit, ck[0].name, torch.load(ck[0], weights_only=False)["state_dict"])
+    (fa, na, sa), (fb, nb, sb) = results["deferred"], results["per_epoch"]
+    assert na == nb, (na, nb)
+    assert [h["val_loss"] for h in fa["history"]] == [h["val_loss"] for h in fb["history"]]
+    assert [h["train_loss"] for h in fa["history"]] == pytest.approx([h["train_loss"] for h in fb["history"]], rel=1e-12, abs=1e-12)
+    assert [h["lr"] for h in fa["history"]] == [h["lr"] for h in fb["history"]]
+    assert fa["best_val_loss"] == fb["best_val_loss"]
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert torch.equal(sa[k].cpu(), sb[k].cpu()), k
+
+
+@pytest.mark.gpu
 def test_rollout_side_inference_step():
     """PlutoInference: eval-mode HIP forward with every output, then top-k candidate trimming (integer flat indices identical to
     those from the oracle's logits in exact-fp32 mode), frame transforms and the waypoint PID."""

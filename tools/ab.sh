@@ -11,7 +11,7 @@ for r in $(seq $REPS); do
   done
 done
 for L in $A $B; do
-  RIFT_LIB=$REPO/$L python bench.py $FAST "$@" 2>/dev/null | python -c "
+  RIFT_LIB=$REPO/$L python bench.py $FAST --no-pmc "$@" 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']
 print('$L', 'ms/step %.4f' % d['ms_per_step'], 'sum of kernels %.1f us' % (1e3*r.get('gpu_ms_per_step_sum_of_kernels',0)))
 for k,v in sorted(r.get('per_kernel_ms_per_step',{}).items(), key=lambda kv:-kv[1])[:14]: print('   %-28s %8.2f us' % (k,1e3*v))"
