@@ -613,13 +613,15 @@ def main():
         for p, g in todo:
             r = next(g)
             precisions[p] = {k: r[k] for k in keep}
+    head = next(head_leg)
     contract = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline and BATCH == 256:
         # north_star's precision contract, machine-readable: the four objectives of the parity test's 256-scene batch per compute precision
-        # (device side here; the oracle side runs with the CPU baseline below and the errors are filled in there)
+        # (device side here -- BEHIND the headline leg: three short-lived contexts in front of it leave the device idle for tenths of a second
+        # and the headline's 20 steps then run at ramping clocks, measured +0.05 ms per step; the oracle side runs with the CPU baseline below
+        # and the errors are filled in there)
         cb = contract_batch()
         contract = {"batch": cb, "device": {p: contract_device_losses(dev, sd_cpu, cb, p) for p in ("bf16", "fp16", "fp32")}}
-    head = next(head_leg)
     # the companions that build policies / contexts of their own run BEHIND the headline leg: every further live context adds streams that
     # share hardware queues with the headline trainer's (measured: headline 0.66 -> 0.75 ms per step with the end-to-end update ahead of it)
     e2e = full_update_e2e() if (world == 1 and rank == 0 and not args.no_e2e and not args.no_full_update and BATCH == 256) else None

@@ -12,6 +12,7 @@ state source (rift_amd.planning.pluto.pluto.CBVStateSource).
 """
 import contextlib
 import math
+import os
 import re
 import time
 from pathlib import Path

@@ -490,6 +490,7 @@ def test_deferred_top1_decision_writes_the_checkpoint_of_the_per_epoch_decision(
         root = tmp_path / mode
         cfg = {'num_scenario': 1, 'ROOT_DIR': str(root), 'model_path': 'ckpt', 'device': 'cuda:0', 'compute_precision': 'fp32',
                'rlft': {'epochs': 6, 'warmup_epochs': 1, 'train_batch_size': 16, 'val_batch_size': 16, 'lr': 3e-3, 'checkpoint_every_improvement': every}}
+        torch.manual_seed(0)            # ahead of the constructor: the Conv1d biases keep their default (random) initialisation
         pol = CBV_POLICY_LIST['rift_pluto'](cfg, None)
         torch.manual_seed(0)
         with torch.no_grad():
@@ -504,6 +505,8 @@ def test_deferred_top1_decision_writes_the_checkpoint_of_the_per_epoch_decision(
         assert len(ck) == 1
         results[mode] = (fit, ck[0].name, torch.load(ck[0], weights_only=False)["state_dict"])
     (fa, na, sa), (fb, nb, sb) = results["deferred"], results["per_epoch"]
+    for h1, h2 in zip(fa["history"], fb["history"]):
+        print(f"epoch {h1['epoch']}: deferred train {h1['train_loss']:.9f} val {h1['val_loss']:.9f} | per-epoch train {h2['train_loss']:.9f} val {h2['val_loss']:.9f}")
     assert na == nb, (na, nb)
     assert [h["val_loss"] for h in fa["history"]] == [h["val_loss"] for h in fb["history"]]
     assert [h["train_loss"] for h in fa["history"]] == pytest.approx([h["train_loss"] for h in fb["history"]], rel=1e-12, abs=1e-12)

@@ -35,6 +35,11 @@ def main():
         tr.wait_update(); torch.cuda.synchronize()
         return time.perf_counter() - t0, t_issue
 
+    # what the driver's run sees: W = 5 warm-up steps on a fresh trainer, then ONE 20-step region -- against the same region repeated
+    for i in range(5):
+        step(i)
+    first = [region(20)[0] for _ in range(6)]
+    print("fresh trainer, 5 warm-up steps, then six consecutive 20-step regions (ms/step): " + " ".join(f"{t / 20 * 1e3:.4f}" for t in first))
     for i in range(30):
         step(i)
     rows = []
