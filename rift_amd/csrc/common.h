@@ -43,6 +43,8 @@ __device__ __forceinline__ unsigned int pack_h2(float lo, float hi) {
   asm(RIFT_CVT_PK_H_ASM " %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+// (round 5, measured and not kept: hipcc's own conversion -- pack_h2c below -- in place of this statement everywhere.  ~100 s_nop fewer per level-0
+// tile, 0.1 % of the step; pe_w_kernel / enc_w_kernel / mha_mfma_kernel start spilling under the freer schedule, and the fp16 build's results move)
 __device__ __forceinline__ unsigned short f2h(float f) {   // round-to-nearest-even fp32 -> operand word: the same instruction, one lane used
   return (unsigned short)(pack_h2(f, 0.f) & 0xffffu);
 }

@@ -2,6 +2,9 @@
   * a VALU write of a VGPR followed within fewer than 2 wait states by an MFMA reading it as A / B / C, by v_permlane*_swap or by a DPP
     instruction reading it (tools/ubench/cvt_mfma_hazard.hip: the MFMA case measured on MI355X -- 0 or 1 states read the OLD register);
   * v_readfirstlane writing an SGPR followed within fewer than 5 wait states by global_load_lds / buffer / global instructions using it.
+  * (round 5) an MFMA result read by a VALU instruction INSIDE an asm statement within fewer than 12 wait states: the states between an MFMA
+    write and a VALU read are software's to insert, hipcc pads its own instructions only (a packed-fp16 GELU that converted accumulators in an
+    asm statement read stale registers -> NaN).  Conversions fed by accumulators go through common.h: pack_h2c (hipcc's own instruction).
 The wave-private kernels hide `v_cvt_pk_bf16_f32` / `v_cvt_pk_f16_f32`, the LDS-DMA and the group GEMM in asm statements; this scan is how their padding is checked.
     python tools/checks/isa_hazard_scan.py            # compiles (no GPU needed) and scans; exit status 1 on a finding"""
 import os, re, subprocess, sys, tempfile
@@ -25,9 +28,31 @@ def states(l):
 
 
 def scan(path):
-    ins = [l.strip() for l in open(path).read().split("\n")
-           if l.startswith("\t") and l.strip() and not l.strip().startswith(";") and not l.strip().startswith(".")]
+    ins, in_asm_of, in_asm = [], [], False
+    for l in open(path).read().split("\n"):
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        if l.startswith("\t") and t and not t.startswith(";") and not t.startswith("."):
+            ins.append(t); in_asm_of.append(in_asm)
     bad = []
+    for k, l in enumerate(ins):          # MFMA result -> VALU read inside an asm statement
+        toks = l.split()
+        if not toks[0].startswith("v_mfma") or len(toks) < 2:
+            continue
+        dst, st = regs(toks[1]), 0
+        for d in range(1, 14):
+            if k + d >= len(ins) or st >= 12:
+                break
+            l2 = ins[k + d]
+            op2, t2 = l2.split()[0], l2.split()[1:]
+            if in_asm_of[k + d] and op2.startswith("v_") and not op2.startswith("v_mfma") and dst & set().union(*[regs(t) for t in t2[1:]] or [set()]):
+                bad.append(("mfma->asm-valu", st, l, l2))
+            if op2.startswith("v_") and dst & regs(t2[0] if t2 else ""):      # the register is rewritten: the MFMA's value is gone
+                break
+            st += states(l2)
     for k, l in enumerate(ins):
         toks = l.split()
         op = toks[0]
