@@ -59,6 +59,8 @@ struct DecWSrc {
 struct DecWP {
   float* Q;                     // (bs*R*12, 128) fp32 decoder queries, updated in place
   const uint8_t* kpm;           // (bs*N) encoder key padding
+  int compact;                  // 1: the K | V^T fragments come from an encoder that compacted its rows (enc_fused.h, RIFT_ENC_COMPACT): kpm is that kernel's
+                                // kpm_c (bs, 96) -- a scene's valid keys are a PREFIX, so the sixth key tile exists exactly when key 80 is valid
   const uint8_t* r_kpm;         // (bs*R) reference-line padding
   const uint8_t* q_kpm;         // (q_bs*R) padding rows the r2r quirk indexes (see DecFusedP)
   int q_bs, q_off;

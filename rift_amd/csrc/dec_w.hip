@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6);
   int wv = wv0;
   const int b = blockIdx.x, N = p.N, R = p.R, NQ = R * M;
-  const bool six = N > 80;
+  const bool six_all = N > 80;                   // slot-ordered keys: whether the BATCH has a sixth key tile; compacted keys: per scene, read off the mask below
   const int RB = DENSE ? (R > 8 ? 2 : 1) : 1;    // rounds of eight tiles in the reference-line tiling
   const int GL = 4 * RA + GB * RB;               // groups of a layer (even)
   const size_t qrow0 = (size_t)b * NQ;
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int h = h0 + hh;
       f32x4 s[NKT];
       constexpr int NK0 = DENSE ? NKE : 5;         // (not DENSE: keys 80..95 exist only in batches with more than 80 tokens)
+      const bool six = (!DENSE && p.compact) ? (smaskf[80] == 0.f) : six_all;      // (workgroup-uniform: one scene per workgroup)
 #pragma unroll
       for (int kt = 0; kt < NK0; ++kt) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);

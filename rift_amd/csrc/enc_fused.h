@@ -46,6 +46,8 @@ struct EncFusedP {
                                 // keys >= N undefined, masked by the decoder)
   const unsigned short* wx0;    // cat_x_proj columns 128:256 (planning_decoder.py:177-179), applied to the scene's ego token (row 0)
   float* x0p;                   // (bs, 128)
+  uint8_t* kpm_c;               // (RIFT_ENC_COMPACT) out, (bs, 96): the key padding of the COMPACTED rows (row i padded <=> i >= the scene's valid count) --
+                                // what the decoder's cross attention masks with when it reads this kernel's K | V^T fragments
   DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 
@@ -90,19 +92,21 @@ __device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned shor
 // HID: A rows and weight fragments are hidden-layer operand words (opfmt.h: fp16 in the packed-fp16-GELU build)
 template <int MT, int KS, int NTW, int NPLAIN = 0, bool HID = false>
 __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned short* A, int lda, const EFrags<KS, NTW>& B,
-                                      int l15, int l4) {
+                                      int l15, int l4, int mtn = MT) {      // mtn (workgroup-uniform): row tiles that hold a valid row; the rest are skipped
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     h16x8 a[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const h16x8*>(A + (mt * 16 + l15) * lda + ks * 32 + l4 * 8);
+    for (int mt = 0; mt < MT; ++mt) if (mt < mtn) a[mt] = *reinterpret_cast<const h16x8*>(A + (mt * 16 + l15) * lda + ks * 32 + l4 * 8);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
+      if (mt < mtn) {
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)
-        acc[mt][j] = HID ? mfma_hid(B.f[ks][j], a[mt], acc[mt][j])
-                         : (j >= NTW - NPLAIN) ? mfma_h(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0)
-                                               : mfma_h(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+        for (int j = 0; j < NTW; ++j)
+          acc[mt][j] = HID ? mfma_hid(B.f[ks][j], a[mt], acc[mt][j])
+                           : (j >= NTW - NPLAIN) ? mfma_h(a[mt], B.f[ks][j], acc[mt][j], 0, 0, 0)
+                                                 : mfma_h(B.f[ks][j], a[mt], acc[mt][j], 0, 0, 0);
+      }
   }
 }
 
@@ -111,14 +115,19 @@ __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
 // fragment reads are bank-conflict free (4 LDS cycles; 136 costs 8, tools/lds_conflicts.py).  ao / cb keep 136 / 200: the 160 KB are full.
 #define RIFT_ENC_XN 144
 #define RIFT_ENC_XA 136
-#define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * (RIFT_ENC_XN + RIFT_ENC_XA) * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 96 * 4 + RIFT_ENC_NPAR * 4)
+#define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * (RIFT_ENC_XN + RIFT_ENC_XA) * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 96 * 4 + RIFT_ENC_NPAR * 4 + 128)      // (+ 96 row -> slot bytes of the compacted layout)
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
-  constexpr int ROWS = 96, MT = 6, C = 128;
+// MTC row (= key) tiles of 16 tokens: 6 = the 96-row layout; 5 = a compacted scene with at most 80 valid tokens (its sixth tile would hold
+// padded rows only: every loop over row / key tiles is a sixth shorter).  COMPILE-TIME on purpose: the first version of the compaction tested
+// a run-time tile count inside the unrolled loops and ran 275 us instead of 97 (each guarded tile became a basic block of its own, so no
+// operand load could move above the MFMAs of the tile before it).  enc_fused_kernel below picks the body per scene.
+template <int NW, int MTC>
+__device__ __forceinline__ void enc_fused_body(const EncFusedP& p, const bool ok, const unsigned long long vmask, const int c0, const int nvv, const bool keep_order) {
+  constexpr int ROWS = 96, MT = MTC, C = 128;
+  constexpr int mtn = MT;
   constexpr int NTH = 64 * NW, NTQ = 12 / NW + (12 % NW ? 1 : 0), NTC = 8 / NW;   // n-tiles per wave: qkv chunk (12), 128-wide output (8)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  constexpr int XS = 132, XN = RIFT_ENC_XN, XA = RIFT_ENC_XA, CB = 200, VS = 104, NKT = 6;
+  constexpr int XS = 132, XN = RIFT_ENC_XN, XA = RIFT_ENC_XA, CB = 200, VS = 104, NKT = MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* xs = reinterpret_cast<float*>(smem_raw);
   unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
@@ -160,21 +169,49 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
   EFrags<4, NTC> B2;     // fc2 partial (128 output columns, K = 128-wide hidden chunk)
   e_load_b(Bqkv, p.blk[0].wqkv, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
 
+  // ---- (RIFT_ENC_COMPACT) the scene's valid tokens first: srow[i] = the token slot LDS row i holds (valid slots in ascending order, then the
+  // padded ones), nv = the valid count, mtn = the row (= key) tiles that hold a valid row: every loop over row tiles below stops there.
+  // Slot 0 is the ego token, whose row the tail's cat_x_proj half reads as row 0: a scene whose slot 0 is padded (none in practice: the
+  // CBV itself) keeps the slot order (nv = -1).
+  unsigned char* srow = reinterpret_cast<unsigned char*>(par + RIFT_ENC_NPAR);        // [96], lives to the end of the kernel (the output rows go back to their slots)
+  int nv = -1;
+#if RIFT_ENC_COMPACT
+  if (tid < ROWS) {
+    const int rk = __builtin_popcountll(vmask & ((1ull << lane) - 1ull)) + (wave == 1 ? c0 : 0);      // valid slots before slot tid
+    const int row = keep_order ? tid : ok ? rk : (tid < N ? nvv + (tid - rk) : tid);                 // (rows at or beyond N hold no slot: loaded as zeros)
+    srow[row] = (unsigned char)tid;
+  }
+  lds_barrier();
+  if (!keep_order) nv = nvv;
+#else
+  if (tid < ROWS) srow[tid] = (unsigned char)tid;      // slot order (read behind the barrier below)
+#endif
+  auto slot_padded = [&](int i) { return (i >= N) || p.kpm[grow0 + (i < N ? i : 0)]; };
   for (int i = tid; i < ROWS * 32; i += NTH) {
     const int r = i >> 5, c4 = (i & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < N) {
+#if RIFT_ENC_COMPACT
+      const int sl = srow[r];
+#else
+      const int sl = r;
+#endif
       if (p.tok_on) {
         const TokenP& t = p.tok;
-        v = r < t.A ? agent_token_value(b, r, c4, t.nat, t.x_ego, t.valid_agent, t.category, t.a_type_emb, t.A, t.N, t.pe)
-                    : polygon_token_value(b, r - t.A, c4, t.pooled, t.ptype, t.on_route, t.tl, t.has_sl, t.speed_emb, t.p_type_emb, t.route_emb, t.tl_emb, t.unk_emb,
-                                          t.A, t.Mp, t.N, t.pe);
-        if (p.Xout) *reinterpret_cast<float4*>(p.Xout + (grow0 + r) * C + c4) = v;
-      } else v = *reinterpret_cast<const float4*>(p.X + (grow0 + r) * C + c4);
+        v = sl < t.A ? agent_token_value(b, sl, c4, t.nat, t.x_ego, t.valid_agent, t.category, t.a_type_emb, t.A, t.N, t.pe)
+                     : polygon_token_value(b, sl - t.A, c4, t.pooled, t.ptype, t.on_route, t.tl, t.has_sl, t.speed_emb, t.p_type_emb, t.route_emb, t.tl_emb, t.unk_emb,
+                                           t.A, t.Mp, t.N, t.pe);
+        if (p.Xout) *reinterpret_cast<float4*>(p.Xout + (grow0 + sl) * C + c4) = v;
+      } else v = *reinterpret_cast<const float4*>(p.X + (grow0 + sl) * C + c4);
     }
     *reinterpret_cast<float4*>(xs + r * XS + c4) = v;
   }
-  for (int i = tid; i < ROWS; i += NTH) smaskf[i] = ((i >= N) || p.kpm[grow0 + i]) ? -INFINITY : 0.f;
+  // key padding of the LDS rows as 0 / -inf (compacted: row i is padded <=> i >= nv); the same mask, as bytes, is what the decoder reads
+  for (int i = tid; i < ROWS; i += NTH) {
+    const bool pad = nv >= 0 ? i >= nv : slot_padded(i);
+    smaskf[i] = pad ? -INFINITY : 0.f;
+    if (p.kpm_c) p.kpm_c[(size_t)b * ROWS + i] = pad;
+  }
   lds_barrier();
   TS();
 
@@ -182,7 +219,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
     const float4 g0 = *reinterpret_cast<const float4*>(g + l15 * 4), g1 = *reinterpret_cast<const float4*>(g + 64 + l15 * 4);
     const float4 b0 = *reinterpret_cast<const float4*>(be + l15 * 4), b1 = *reinterpret_cast<const float4*>(be + 64 + l15 * 4);
 #pragma unroll
-    for (int r = wave * 4 + l4; r < ROWS; r += 4 * NW) ln128_row16(xs + r * XS, xn + r * XN, g0, g1, b0, b1, l15);
+    for (int r = wave * 4 + l4; r < 16 * mtn; r += 4 * NW) ln128_row16(xs + r * XS, xn + r * XN, g0, g1, b0, b1, l15);
   };
 
   for (int bi = 0; bi < 4; ++bi) {
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int j = 0; j < NTQ; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        e_mma<MT, 4, NTQ, 1>(acc, xn, XN, Bqkv, l15, l4);   // q|k tiles swapped (row-major stores), V tile (last j) plain (transposed stores)
+        e_mma<MT, 4, NTQ, 1>(acc, xn, XN, Bqkv, l15, l4, mtn);   // q|k tiles swapped (row-major stores), V tile (last j) plain (transposed stores)
         if (ch == 0) e_load_b(Bqkv, w.wqkv, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
         else e_load_b(Bw, w.wo, C, 0, 0, wave, l15, l4, EWaves<NW>());
 #pragma unroll
@@ -218,8 +255,9 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
           const float sc = ((nt & 3) < 2) ? 0.17677669529663687f * 1.4426950408889634f : 1.0f;   // q pre-scaled by 32^-0.5 log2 e: the softmax runs on v_exp_f32 = 2^x
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
-                pack_h4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
+            if (mt < mtn)
+              *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+                  pack_h4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
         }
         if (wave < 4) {                     // n-tiles 8..11: V -> vt[head][d][key..key+3]
           const int nt = 8 + wave;
@@ -229,33 +267,41 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
           for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + mt * 16 + l4 * 4) =
                 pack_h4(acc[mt][NTQ - 1][0] + bias, acc[mt][NTQ - 1][1] + bias, acc[mt][NTQ - 1][2] + bias, acc[mt][NTQ - 1][3] + bias);
+          // (an odd tile count leaves the second half of the last key PAIR's V^T tile unwritten: zeros there -- P is zero, but 0 x stale NaN is not)
+          if (MT & 1) *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + MT * 16 + l4 * 4) = make_uint2(0u, 0u);
         }
       }
       lds_barrier();
       TS();
       // ---- MFMA attention: 2 heads x 6 query tiles = 12 (head, tile) pairs, 3 per wave (see mha_mfma_kernel)
-      for (int pr = wave; pr < 12; pr += NW) {
-        const int hh = pr / 6, qt = pr - hh * 6;
+      constexpr int nkp = (MT + 1) >> 1;                // key tile PAIRS of the P V product
+      for (int pr = wave; pr < 2 * MT; pr += NW) {      // (head, query tile) pairs
+        const int hh = pr >= MT ? 1 : 0, qt = pr - hh * MT;
         const h16x8 qf = *reinterpret_cast<const h16x8*>(cb + (qt * 16 + l15) * CB + hh * 64 + l4 * 8);
-        f32x4 s[NKT];
+        f32x4 s[2 * nkp];
+        if (MT & 1) s[MT] = (f32x4){0.f, 0.f, 0.f, 0.f};      // (the empty half of the last key pair: P = 0)
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-          const h16x8 kf = *reinterpret_cast<const h16x8*>(cb + (kt * 16 + l15) * CB + hh * 64 + 32 + l4 * 8);
-          const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
-          s[kt] = mfma_h(kf, qf, (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
-          m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+          if (kt < mtn) {
+            const h16x8 kf = *reinterpret_cast<const h16x8*>(cb + (kt * 16 + l15) * CB + hh * 64 + 32 + l4 * 8);
+            const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
+            s[kt] = mfma_h(kf, qf, (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+            m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+          } else s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};      // (a key tile without a valid key: P = 0)
         }
         m = rows_max(m);
         float lsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
+          if (kt < mtn) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - m); lsum += e; s[kt][r] = e; }
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - m); lsum += e; s[kt][r] = e; }
+          }
         lsum = rows_sum(lsum);
         f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
-        for (int pt = 0; pt < NKT / 2; ++pt) {
+        for (int pt = 0; pt < nkp; ++pt) {
           h16x8 pf;
           const unsigned int p0 = pack_h2(s[2 * pt][0], s[2 * pt][1]), p1 = pack_h2(s[2 * pt][2], s[2 * pt][3]);
           const unsigned int p2 = pack_h2(s[2 * pt + 1][0], s[2 * pt + 1][1]), p3 = pack_h2(s[2 * pt + 1][2], s[2 * pt + 1][3]);
@@ -290,7 +336,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      e_mma<MT, 4, NTC>(acc, ao, XA, Bw, l15, l4);
+      e_mma<MT, 4, NTC>(acc, ao, XA, Bw, l15, l4, mtn);
       e_load_b(Bw, w.w1, C, 0, 0, wave, l15, l4, EWaves<NW>());             // fc1 weights of hidden chunk 0
 #pragma unroll
       for (int j = 0; j < NTC; ++j) {
@@ -298,6 +344,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         const float4 b4 = *reinterpret_cast<const float4*>(par + P_BO + col);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          if (mt >= mtn) break;
           float4* xp = reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col);
           float4 x = *xp;
           x.x += (acc[mt][j][0] + b4.x) * dpscale; x.y += (acc[mt][j][1] + b4.y) * dpscale;
@@ -329,7 +376,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < NTC; ++j) acc[mt][j] = hid_init(b4[j]);      // (packed-fp16 GELU: the bias is the accumulator's initial value)
-          e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4);
+          e_mma<MT, 4, NTC>(acc, xn, XN, Bw, l15, l4, mtn);
           e_load_b(B2, w.w2, 512, 0, hc * 128, wave, l15, l4, EWaves<NW>());
           if (hc > 0) lds_barrier();   // previous chunk's fc2 reads of cb are complete
 #pragma unroll
@@ -337,15 +384,16 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
             const int col = (j * NW + wave) * 16 + l4 * 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-              *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
-                  gelu4_hid(acc[mt][j], b4[j]);       // hidden-layer operand words (fc2's weight image matches: w.w2 = the `hid` image)
+              if (mt < mtn)
+                *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+                    gelu4_hid(acc[mt][j], b4[j]);       // hidden-layer operand words (fc2's weight image matches: w.w2 = the `hid` image)
           }
         }
         if (hc + 1 < 4) e_load_b(Bw, w.w1, C, (hc + 1) * 128, 0, wave, l15, l4, EWaves<NW>());
         else if (bi + 1 < 4) e_load_b(Bqkv, p.blk[bi + 1].wqkv, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
         lds_barrier();
         TS();
-        e_mma<MT, 4, NTC, 0, true>(acc2, cb, CB, B2, l15, l4);
+        e_mma<MT, 4, NTC, 0, true>(acc2, cb, CB, B2, l15, l4, mtn);
         TS();
       }
 #pragma unroll
@@ -354,6 +402,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         const float4 b4 = *reinterpret_cast<const float4*>(par + P_B2 + col);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          if (mt >= mtn) break;
           float4* xp = reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col);
           float4 x = *xp;
           x.x += (acc2[mt][j][0] + b4.x) * dpscale2; x.y += (acc2[mt][j][1] + b4.y) * dpscale2;
@@ -371,6 +420,10 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
     const float4 g4 = *reinterpret_cast<const float4*>(p.norm_g + lr * 4), b4 = *reinterpret_cast<const float4*>(p.norm_b + lr * 4);
     uint32_t ex = 0;                                   // non-finite flag by bit pattern (common.h: exp_max)
     for (int r = wave * 2 + rsub; r < ROWS; r += 2 * NW) {
+      if (r >= 16 * mtn) {      // a row tile that was skipped: its slots (all padded) get zero rows -- the reference computes something there that nobody reads
+        if (r < N) *reinterpret_cast<float4*>(p.Y + (grow0 + srow[r]) * C + lr * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
       const float4 v = *reinterpret_cast<const float4*>(xs + r * XS + lr * 4);
       float s = (v.x + v.y) + (v.z + v.w);
       s = group_sum<32>(s);
@@ -380,7 +433,7 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       q = group_sum<32>(q);
       const float rstd = rsqrtf(q * (1.0f / C) + 1e-5f);
       const float4 o = make_float4(d0 * rstd * g4.x + b4.x, d1 * rstd * g4.y + b4.y, d2 * rstd * g4.z + b4.z, d3 * rstd * g4.w + b4.w);
-      if (r < N) *reinterpret_cast<float4*>(p.Y + (grow0 + r) * C + lr * 4) = o;
+      if (r < N) *reinterpret_cast<float4*>(p.Y + (grow0 + srow[r]) * C + lr * 4) = o;
       if (r < N) { ex = exp_max(ex, o.x); ex = exp_max(ex, o.y); ex = exp_max(ex, o.z); ex = exp_max(ex, o.w); }
       if (p.KT) *reinterpret_cast<uint2*>(xn + r * XN + lr * 4) = pack_h4(o.x, o.y, o.z, o.w);
     }
@@ -409,17 +462,20 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      e_mma<MT, 4, 2, 1>(acc, xn, XN, Wk, l15, l4);
+      e_mma<MT, 4, 2, 1>(acc, xn, XN, Wk, l15, l4, mtn);
       if (l + 1 < 4) e_load_b(Wk, p.wkv, C, (l + 1) * 256, 0, wave, l15, l4, EWaves<NW>());
       {   // K: channels wave*16 + 4*l4 .. +3 of key mt*16 + l15
         const int col = wave * 16 + l4 * 4;
         const float4 b4 = *reinterpret_cast<const float4*>(p.bkv + l * 256 + col);
         // fragment image: head h = wave >> 1 holds dims 32 h + 16 (j / 4) + 4 l4 + j % 4 in k slot j: this wave supplies j / 4 = wave & 1
         unsigned short* kt = p.KT + (((size_t)b * 4 + l) * 48 + (wave >> 2) * 24 + ((wave >> 1) & 1)) * 512 + lane * 8 + (wave & 1) * 4;
+        // (key tiles without a valid key: the decoder walks five tiles whatever the scene holds and the sixth when key 80 is valid -- zeros
+        // for the ones skipped here: masked scores of finite operands, and P = 0 against finite V^T)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          *reinterpret_cast<uint2*>(kt + mt * 2 * 512) =
-              pack_h4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
+          *reinterpret_cast<uint2*>(kt + mt * 2 * 512) = pack_h4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
+#pragma unroll
+        for (int mt = MT; mt < 6; ++mt) *reinterpret_cast<uint2*>(kt + mt * 2 * 512) = make_uint2(0u, 0u);
       }
       {   // V^T: channel wave*16 + l15, keys mt*16 + 4*l4 .. +3
         const int d = wave * 16 + l15;
@@ -428,11 +484,34 @@ __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
         unsigned short* vt = p.KT + (((size_t)b * 4 + l) * 48 + (wave >> 2) * 24 + 12 + (((wave >> 1) & 1) * 2 + (wave & 1)) * 3) * 512 + lane * 8;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          *reinterpret_cast<uint2*>(vt + (mt >> 1) * 512 + (mt & 1) * 4) =
-              pack_h4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
+          *reinterpret_cast<uint2*>(vt + (mt >> 1) * 512 + (mt & 1) * 4) = pack_h4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
+#pragma unroll
+        for (int mt = MT; mt < 6; ++mt) *reinterpret_cast<uint2*>(vt + (mt >> 1) * 512 + (mt & 1) * 4) = make_uint2(0u, 0u);
       }
     }
   }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {
+#if RIFT_ENC_COMPACT
+  // the scene's valid-token count first (two ballots and one LDS hand-over), then the body built for its tile count
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_cnt[];
+  int* cnt = reinterpret_cast<int*>(smem_cnt);          // (the head of the fp32 row buffer: rewritten by the body's row loads behind its first barrier)
+  const int tid = threadIdx.x, wave = tid >> 6, N = p.N;
+  const size_t grow0 = (size_t)blockIdx.x * N;
+  const bool ok = tid < N && !p.kpm[grow0 + (tid < N ? tid : 0)];
+  const unsigned long long vmask = __builtin_amdgcn_ballot_w64(ok);      // waves 0 / 1: slots 0..63 / 64..127
+  if (wave < 2 && (tid & 63) == 0) cnt[wave] = __builtin_popcountll(vmask);
+  lds_barrier();
+  const int c0 = __builtin_amdgcn_readfirstlane(cnt[0]), nvv = __builtin_amdgcn_readfirstlane(cnt[0] + cnt[1]);
+  const bool keep_order = p.kpm[grow0] != 0;            // padded ego slot (none in practice): slot order, all six tiles
+  lds_barrier();                                        // (everybody has read the counts before the body's row loads overwrite them)
+  if (!keep_order && nvv <= 80) enc_fused_body<NW, 5>(p, ok, vmask, c0, nvv, false);
+  else enc_fused_body<NW, 6>(p, ok, vmask, c0, nvv, keep_order);
+#else
+  enc_fused_body<NW, 6>(p, false, 0ull, 0, 0, true);
+#endif
 }
 
 }  // namespace RIFT_NS

@@ -1347,6 +1347,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   static const float edpr[4] = {0.f, 0.2f / 3.f, 0.4f / 3.f, 0.2f};   // linspace(0, 0.2, 4), pluto_model.py:80-83
   float* ENC = A_alloc<float>(c, (size_t)nT * 128);
   unsigned short* enc_KT = nullptr;   // the decoder's cross-attention K | V^T operand fragments, written by the encoder kernel's tail
+  uint8_t* kpm_c = nullptr;           // (RIFT_ENC_COMPACT) the key padding of the compacted encoder rows (bs, 96): what the decoder masks those fragments with
   float* enc_x0p = nullptr;   // cat_x_proj's ego-token half, written by the encoder kernel's tail
   if (c->enc_fused && !f.fp32 && N <= 96) {
     EncFusedP ep; memset(&ep, 0, sizeof(ep));
@@ -1371,6 +1372,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * DECW_KV_FRAGS * 512);
       ep.wkv = (const unsigned short*)c->pw["planning_decoder.kv_all"].bf; ep.bkv = c->pw["planning_decoder.kv_all"].bias;
       ep.KT = enc_KT;
+#if RIFT_ENC_COMPACT
+      kpm_c = A_alloc<uint8_t>(c, (size_t)bs * 96); ep.kpm_c = kpm_c;
+#endif
       enc_x0p = A_alloc<float>(c, (size_t)bs * 128);
       ep.wx0 = (const unsigned short*)c->pw["planning_decoder.cat_x_proj.x"].bf; ep.x0p = enc_x0p;
       c->prof_flops += 2.0 * bs * N * 128.0 * 1024;
@@ -1462,6 +1466,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (c->dec_fused && !f.fp32 && ((R <= 8 && N <= 96) || dec_dense) && enc_KT) {
     DecWP dq; memset(&dq, 0, sizeof(dq));
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
+    if (kpm_c) { dq.kpm = kpm_c; dq.N = 96; dq.compact = 1; }      // (the encoder compacted its rows: its own key padding, valid keys a prefix)
     dq.stream = f.next_stream(); f.stream_id += 64;
     dq.KV = enc_KT; dq.img = c->decw_img; dq.par = c->decw_par; dq.nonfinite = c->nonfinite;
     RIFT_SET_DS(dq);

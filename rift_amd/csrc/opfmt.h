@@ -47,3 +47,13 @@
 #else
 #define RIFT_NAT_MFMA_ATTN 0
 #endif
+
+// ---- valid-token compaction inside the scene encoder (round 5; enc_fused.h) ------------------------------------------------------------
+// bf16 build: a scene's valid tokens are moved to the front of its LDS rows (stable order), row / key tiles behind the last valid token
+// are skipped, the output rows go back to their slots.  Another key order = another fp32 summation order, so the fp16 build (whose bars
+// are measured on the arithmetic of rounds 2 - 4) keeps the slot order.  RIFT_ENC_SLOT_ORDER (diagnostic define) does the same for bf16.
+#if !RIFT_OP_F16 && !defined(RIFT_ENC_SLOT_ORDER)
+#define RIFT_ENC_COMPACT 1
+#else
+#define RIFT_ENC_COMPACT 0
+#endif
