@@ -126,6 +126,58 @@ def test_forward_eval(ffi, case, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_compacted_scene_encoder_over_every_tile_count_and_the_padded_ego_fallback(ffi, mode):
+    """Round 5: in the bf16 build `enc_fused_kernel` moves a scene's valid tokens to the front, runs a 5-tile body when at most 80 are valid and
+    writes the rows back to their slots; the decoder reads that kernel's compacted key padding.  One batch that walks the cases: valid
+    counts of 84 (all), 81, 80, 65, 64, 33, 17 and 3 tokens (scattered over the slots: the compaction is a real permutation), and a scene
+    whose EGO slot is padded (the kernel keeps the slot order there).  Encoder rows and decoder queries of valid tokens / lines, logits and
+    the RIFT loss against the oracle (the fp16 build keeps the slot order: the same test is its regression)."""
+    sd = H.weights()
+    scenes = [syn.make_scene(4100 + i) for i in range(9)]
+    g = torch.Generator().manual_seed(77)
+    for i, want in enumerate((84, 81, 80, 65, 64, 33, 17, 3, 70)):
+        f = scenes[i]["feature"]
+        f["agent"]["valid_mask"][:] = True
+        f["map"]["valid_mask"][:] = True
+        slots = torch.randperm(83, generator=g)[: 84 - want] + 1          # slots 1..83 to pad (slot 0 = the ego stays)
+        for sl in slots.tolist():
+            if sl < 64:
+                f["agent"]["valid_mask"][sl] = False
+            else:
+                f["map"]["valid_mask"][sl - 64] = False
+    scenes[8]["feature"]["agent"]["valid_mask"][0] = False                  # a padded ego slot: slot order, all six tiles
+    batch = syn.collate_scenes(scenes)
+    data = batch["cur_pluto_feature_torch"]
+    ref, _, taps = pluto_ref.planning_model_forward(sd, H.clone_tree(data), want_taps=True)
+    kpm, rv = H.token_padding(data), data["reference_line"]["valid_mask"].any(-1)
+    assert [int((~kpm[i]).sum()) for i in range(8)] == [84, 81, 80, 65, 64, 33, 17, 3]
+    eng = _engine(ffi, mode)
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    eng.prof_enable(True)
+    out = eng.forward(data, need_traj=True)
+    torch.cuda.synchronize()
+    assert "enc_fused_kernel" in eng.prof_report() and "dec_w_kernel" in eng.prof_report()
+    eng.prof_enable(False)
+    tol = {"bf16": 4e-2, "fp16": 8e-3}[mode]
+    bs, N, R = kpm.shape[0], kpm.shape[1], rv.shape[1]
+    eo = eng.tap("enc_out").view(bs, N, 128).cpu()
+    assert torch.isfinite(eo).all()                                          # padded slots: zero rows or computed rows, never stale memory
+    for i in range(bs):
+        assert err(eo[i][~kpm[i]], taps["enc_out"][i][~kpm[i]]) < tol, i
+    qf = eng.tap("q_final").view(bs, R, 12, 128).cpu()
+    assert err(qf[rv], taps["q_final"][rv]) < {"bf16": 2e-1, "fp16": 4e-2}[mode]
+    assert err(out["probability"], ref["probability"]) < tol
+    va = data["agent"]["valid_mask"].any(-1)[:, 1:]
+    assert err(out["prediction"].cpu()[va], ref["prediction"][va]) < tol
+    stats, flat, _ = eng.loss_backward("rift", H.clone_tree(batch))
+    grads = {k: torch.zeros_like(sd["planning_decoder.pi_head." + k]).cuda() for k in losses.PI_KEYS}
+    loss = float(eng.loss_finalize(stats, flat, grads).item())
+    want_loss, _, _ = losses.pi_head_loss_and_grads(sd, taps["q_final"], "rift", H.clone_tree(batch), ~rv)
+    assert abs(loss - float(want_loss)) < {"bf16": 3.5e-3, "fp16": 3.5e-4}[mode]
+    eng.close()
+
+
 @pytest.mark.parametrize("case", H.SHAPE_CASES)
 @pytest.mark.parametrize("mode", MODES)
 def test_forward_at_the_other_kernel_variants_shapes_against_the_reference(ffi, case, mode):
