@@ -410,6 +410,17 @@ int rift_adamw_step(RiftCtx* ctx, int n_tensors /*<= 16*/, float* const* params,
                     float* const* exp_avg_sq, float* const* steps, const int64_t* numels /*host*/, const double* lr /*host*/,
                     const double* weight_decay /*host*/, double step_new, double beta1, double beta2, double eps, void* stream);
 
+/* The step's last three launches in ONE (round 5): rift_loss_finalize_clip (loss = -S / count, gradients = -sums / count into the six pi_head .grad
+ * tensors, gradient-norm clip) and rift_adamw_step on exactly those six tensors, in a single single-workgroup launch -- a thread updates the
+ * parameters whose gradients it has just formed, so nothing but the clip coefficient crosses threads.  Same arithmetic, bit for bit, as the two
+ * calls it replaces (tests/test_gpu_update.py).  The AdamW arrays are those of rift_adamw_step and must list the six tensors whose gradients
+ * `out` names (any order, n_tensors == 6): the update of the reference's `trainable_layers: [planning_decoder.pi_head]` configuration
+ * (rift_training.yaml:26-27); other trainable sets (PPO's critic) use the separate calls. */
+int rift_update_tail(RiftCtx* ctx, const RiftLossOut* out, int accumulate, float max_norm, float* total_norm, int n_tensors /*== 6*/,
+                     float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, float* const* steps,
+                     const double* lr /*host*/, const double* weight_decay /*host*/, double step_new, double beta1, double beta2, double eps,
+                     void* stream);
+
 /* ---- PPO critic (CriticPPO, rift/gym_carla/utils/net.py:420-431 with CriticBase :355-371; built with dims [256, 256],
  * state_dim 128 by PPOPlutoModel, ppo_pluto.py:37 and planning/config/ppo_pluto.yaml:43-45).  All pointers are device fp32
  * views onto the caller's parameters: net.{0,2,4}.{weight,bias}, state_avg / state_std (128), value_avg / value_std (1). */

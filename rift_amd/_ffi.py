@@ -95,7 +95,7 @@ EXPORTS = [
     "rift_loss_finalize", "rift_loss_finalize_clip", "rift_set_param_event", "rift_tap", "rift_op_linear", "rift_gae", "rift_discounted_return",
     "rift_normalize_advantage", "rift_group_advantage", "rift_rollout_return", "rift_collate",
     "rift_prof_enable", "rift_prof_report", "rift_op_linear_bench", "rift_ref_line_info", "rift_rollout",
-    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout", "rift_sft_teacher_mode",
+    "rift_critic_forward", "rift_critic_loss_backward", "rift_critic_finalize", "rift_clip_grad_norm", "rift_adamw_step", "rift_update_tail", "rift_collision_matrix", "rift_off_road_matrix", "rift_other_vehicle_rollout", "rift_sft_teacher_mode",
     "rift_check_finite", "rift_set_dp", "rift_set_prepare_stream", "rift_set_side_stream",
     "rift_comm_unique_id", "rift_comm_init", "rift_comm_all_reduce", "rift_comm_destroy", "rift_group_advantage_tick",
 ]
@@ -151,6 +151,8 @@ def load_library(variant: str = "") -> C.CDLL:
     lib.rift_critic_loss_backward.argtypes = [vp, C.POINTER(RiftCritic), vp, vp, C.c_int, vp, vp, vp]
     lib.rift_critic_finalize.argtypes = [vp] * 14
     lib.rift_clip_grad_norm.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), C.c_int, C.c_float, vp, vp]
+    lib.rift_update_tail.argtypes = [vp, C.POINTER(RiftLossOut), C.c_int, C.c_float, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                     C.POINTER(vp), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.c_double, vp]
     lib.rift_adamw_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                     C.c_double, C.c_double, vp]
@@ -533,6 +535,16 @@ class Engine:
                                       float(eps), _stream())
         if rc != 0:
             self._check(rc, "rift_adamw_step")
+
+    def update_tail_raw(self, lo: RiftLossOut, accumulate: int, max_norm: float, total_norm, al, lrs, wds, step_new: float, beta1: float,
+                        beta2: float, eps: float):
+        """rift_update_tail: finalize + gradient-norm clip + AdamW of the six pi_head tensors, one launch (al: make_adam_list of exactly those)."""
+        n = al["n"]
+        rc = self.lib.rift_update_tail(self.ctx, C.byref(lo), accumulate, float(max_norm), _ptr(total_norm) if total_norm is not None else None, n,
+                                       al["p"], al["g"], al["m"], al["v"], al["s"], (C.c_double * n)(*lrs), (C.c_double * n)(*wds), float(step_new),
+                                       float(beta1), float(beta2), float(eps), _stream())
+        if rc != 0:
+            self._check(rc, "rift_update_tail")
 
     def prof_enable(self, on: bool):
         self._check(self.lib.rift_prof_enable(self.ctx, 1 if on else 0), "rift_prof_enable")

@@ -2266,6 +2266,33 @@ int rift_adamw_step(RiftCtx* c, int n, float* const* params, const float* const*
   return RIFT_OK;
 }
 
+int rift_update_tail(RiftCtx* c, const RiftLossOut* out, int accumulate, float max_norm, float* total_norm, int n, float* const* params,
+                     const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, float* const* steps, const double* lr,
+                     const double* weight_decay, double step_new, double beta1, double beta2, double eps, void* stream) {
+  if (!c || !out || !out->stats || !out->flat_grad_sum || !(max_norm > 0.f) || n != 6) return RIFT_ERR_ARG;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !lr || !weight_decay || !(step_new >= 1.0)) return RIFT_ERR_ARG;
+  float* const gseg[6] = {out->grad_w1, out->grad_b1, out->grad_ln_w, out->grad_ln_b, out->grad_w2, out->grad_b2};
+  c->err.clear();
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stream = (hipStream_t)stream; c->dry = false;
+  TailAdam A; memset(&A, 0, sizeof(A));
+  const double bc1 = 1.0 - std::pow(beta1, step_new), bc2 = 1.0 - std::pow(beta2, step_new);
+  for (int sgi = 0; sgi < 6; ++sgi) {
+    int j = -1;
+    for (int t = 0; t < 6; ++t) if (gseg[sgi] && grads[t] == gseg[sgi]) j = t;
+    if (j < 0 || !params[j] || !exp_avg[j] || !exp_avg_sq[j] || !steps[j]) { c->err = "rift_update_tail: the AdamW list does not hold the six pi_head gradient tensors"; return RIFT_ERR_ARG; }
+    A.p[sgi] = params[j]; A.m[sgi] = exp_avg[j]; A.v[sgi] = exp_avg_sq[j]; A.step[sgi] = steps[j];
+    A.step_size[sgi] = (float)(lr[j] / bc1); A.decay[sgi] = (float)(1.0 - lr[j] * weight_decay[j]);
+  }
+  A.step_new = (float)step_new; A.beta2 = (float)beta2; A.omb1 = (float)(1.0 - beta1); A.omb2 = (float)(1.0 - beta2);
+  A.bc2_sqrt = (float)std::sqrt(bc2); A.eps = (float)eps;
+  launch(c, "update_tail_kernel", update_tail_kernel, dim3(1), dim3(1024), 0, (const float*)out->flat_grad_sum, (const double*)out->stats,
+         out->grad_w1, out->grad_b1, out->grad_ln_w, out->grad_ln_b, out->grad_w2, out->grad_b2, out->loss, accumulate,
+         (const double*)out->exchange, out->stats, max_norm, total_norm, A);
+  HIPCHK(c, hipGetLastError());
+  return RIFT_OK;
+}
+
 // ---- PPO critic ------------------------------------------------------------------------------------
 static int critic_scratch(RiftCtx* c, int n) {
   const size_t need = (size_t)((n + 15) / 16 * 16) * (128 + 4 * 256 + 1 + 2 * 128 + 2);

@@ -511,4 +511,72 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamList L) {
   }
 }
 
+// ---- finalize + clip + AdamW of the six pi_head tensors in ONE single-workgroup launch (rift_update_tail).  The first half is
+// loss_finalize_clip_kernel line for line (same thread <-> element mapping, same f64 reduction order), the second half adamw_kernel's
+// arithmetic on the element the thread holds: bit-identical to the two launches.
+struct TailAdam {            // per gradient segment, in the flat order W1 | b1 | ln_w | ln_b | w2 | b2
+  float* p[6]; float* m[6]; float* v[6]; float* step[6];
+  float step_size[6], decay[6], step_new;
+  float beta2, omb1, omb2, bc2_sqrt, eps;
+};
+__global__ __launch_bounds__(1024) void update_tail_kernel(const float* __restrict__ flat, const double* __restrict__ stats_in,
+                                                           float* gW1, float* gb1, float* gg, float* gbe, float* gw2, float* gb2,
+                                                           double* __restrict__ loss_out, int accumulate, const double* __restrict__ xchg,
+                                                           double* __restrict__ stats_out, float max_norm, float* __restrict__ total_norm, TailAdam A) {
+  constexpr int NU = (RIFT_PI_NPARAM + 1023) / 1024;
+  const int tid = threadIdx.x;
+  const double* stats = xchg ? xchg + RIFT_PI_NPARAM : stats_in;
+  const double s0 = stats[0], cnt = stats[1];
+  const float sc = cnt > 0.0 ? (float)(-1.0 / cnt) : 0.f;
+  float v[NU]; float* dp[NU]; int seg[NU], off[NU];
+  double ss = 0.0;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = tid + u * 1024;
+    float* dst = nullptr; int o = 0, sg = 0;
+    if (i < 16384) { dst = gW1; o = i; sg = 0; }
+    else if (i < 16384 + 128) { dst = gb1; o = i - 16384; sg = 1; }
+    else if (i < 16384 + 256) { dst = gg; o = i - 16384 - 128; sg = 2; }
+    else if (i < 16384 + 384) { dst = gbe; o = i - 16384 - 256; sg = 3; }
+    else if (i < 16384 + 512) { dst = gw2; o = i - 16384 - 384; sg = 4; }
+    else if (i < RIFT_PI_NPARAM) { dst = gb2; o = 0; sg = 5; }
+    dp[u] = dst ? dst + o : nullptr; seg[u] = sg; off[u] = o;
+    v[u] = 0.f;
+    if (dp[u]) {
+      v[u] = (xchg ? (float)xchg[i] : flat[i]) * sc;
+      if (accumulate) v[u] += *dp[u];
+      ss += (double)v[u] * (double)v[u];
+    }
+  }
+  ss = wave_sum_d(ss);
+  __shared__ double ws[16];
+  if ((tid & 63) == 0) ws[tid >> 6] = ss;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += ws[w];
+  const float total = (float)sqrt(tot);
+  const float coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+  if (tid == 0) {
+    if (total_norm) *total_norm = total;
+    if (loss_out) loss_out[0] = cnt > 0.0 ? -s0 / cnt : 0.0;
+    if (xchg && stats_out) { stats_out[0] = s0; stats_out[1] = cnt; }
+  }
+  if (tid < 6) A.step[tid][0] = A.step_new;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (!dp[u]) continue;
+    const float g = v[u] * coef;
+    *dp[u] = g;
+    const int sg = seg[u], o = off[u];
+    float pv = A.p[sg][o] * A.decay[sg];
+    const float m0 = A.m[sg][o], v0 = A.v[sg][o];
+    const float m = m0 + (g - m0) * A.omb1;
+    const float vv = v0 * A.beta2 + A.omb2 * g * g;
+    const float denom = sqrtf(vv) / A.bc2_sqrt + A.eps;
+    pv -= A.step_size[sg] * (m / denom);
+    A.p[sg][o] = pv; A.m[sg][o] = m; A.v[sg][o] = vv;
+  }
+}
+
 }  // namespace RIFT_NS

@@ -274,6 +274,7 @@ class RLFTTrainer:
         self.training = True
         self._clip_list = None
         self._fast_groups = None
+        self.fused_tail = os.environ.get("RIFT_FUSED_TAIL", "1") != "0"     # finalize + clip + AdamW in one launch (rift_update_tail)
         self.force_exchange = os.environ.get("RIFT_BENCH_FORCE_PG") == "1"   # run the all-reduce even with one rank (path check)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         # Only pi_head is trainable, so the frozen trunk of step k+1 does not depend on the update of step k: exchange + finalize +
@@ -455,8 +456,17 @@ class RLFTTrainer:
         self.step_count += 1
         self.engine.forward_raw(fb, self.out, flags, (self.seed_base + self.step_count) & 0xFFFFFFFF)
 
+    def _finalize_and_step(self, fused_clip: bool):
+        """The tail behind the backward pass: exchange, loss / gradient finalization + clip, AdamW.  Once torch has created the optimizer
+        state (first step) and the trainable set is exactly pi_head under the fused clip, the last two are ONE launch (rift_update_tail)."""
+        if fused_clip and self._fast_groups and self._adam_list["n"] == 6 and self.fused_tail:
+            self._exchange_and_finalize(True, self.gradient_clip_val, fuse_adam=True)
+            return
+        self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
+        self._optimizer_step()
+
     def _exchange_and_finalize(self, backward: bool, clip_val: Optional[float], accumulate: int = 0, with_critic: bool = True,
-                               count_scale: float = 1.0):
+                               count_scale: float = 1.0, fuse_adam: bool = False):
         eng = self.engine
         with_critic = with_critic and self.critic is not None
         if self.exchange is not None and (self.world > 1 or self.force_exchange):
@@ -466,7 +476,12 @@ class RLFTTrainer:
         if count_scale != 1.0:
             (self.xchg[_ffi.PI_NPARAM + 1:] if (self.xchg is not None and self.lo.exchange) else self.stats[1:]).mul_(count_scale)
         if backward:
-            if clip_val and self.critic is None:
+            if clip_val and self.critic is None and fuse_adam:
+                self._adam_step += 1
+                g0 = self.optimizer.param_groups[0]
+                eng.update_tail_raw(self.lo, accumulate, float(clip_val), self.grad_norm, self._adam_list, [g["lr"] for g in self._adam_owner],
+                                    [g["weight_decay"] for g in self._adam_owner], float(self._adam_step), g0["betas"][0], g0["betas"][1], g0["eps"])
+            elif clip_val and self.critic is None:
                 eng.loss_finalize_clip_raw(self.lo, accumulate, float(clip_val), self.grad_norm)
             else:
                 eng.loss_finalize_raw(self.lo, accumulate)
@@ -570,8 +585,7 @@ class RLFTTrainer:
                                 t.record_stream(self._side)
                     self.set_loss_inputs(extras)
                     self.engine.loss_backward_raw(self.kind_id, self.li, self.lo)
-                    self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
-                    self._optimizer_step()
+                    self._finalize_and_step(fused_clip)
                     self._ev_param.record(self._side)
                     self._ev_tail[slot].record(self._side)
 
@@ -598,8 +612,7 @@ class RLFTTrainer:
             self._ev_loss.record(main)
             with torch.cuda.stream(self._side):
                 self._side.wait_event(self._ev_loss)
-                self._exchange_and_finalize(True, self.gradient_clip_val if fused_clip else None)
-                self._optimizer_step()
+                self._finalize_and_step(fused_clip)
                 self._ev_param.record(self._side)
             self.loss_n += 1
             return self.loss

@@ -269,3 +269,58 @@ def test_pipeline_with_changing_batch_shapes(monkeypatch):
     assert runs["pipeline"][0] == runs["serial"][0], (runs["pipeline"][0], runs["serial"][0])
     for k, v in runs["serial"][1].items():
         assert torch.equal(v, runs["pipeline"][1][k]), k
+
+
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_fused_update_tail_equals_the_two_launch_tail_bit_for_bit(monkeypatch, pipeline):
+    """rift_update_tail (finalize + gradient-norm clip + AdamW of the six pi_head tensors in ONE launch) against rift_loss_finalize_clip followed by
+    rift_adamw_step: after 14 steps over two learning rates -- the first one through torch's own optimizer.step(), which creates the state --
+    the parameters, the clipped .grad tensors, exp_avg / exp_avg_sq / the device step counters, the gradient norm and the mean loss are
+    identical bit for bit, and the fused run did issue the fused launch (prof names)."""
+    from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer
+    from rift_amd.planning.pluto.model.pluto_model import PlanningModel
+    from rift_amd.replay import DeviceReplay
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    monkeypatch.setenv("RIFT_PIPELINE", pipeline)
+    monkeypatch.setenv("RIFT_PREFETCH", pipeline)
+    scenes = [syn.make_scene(3100 + i) for i in range(64)]
+    sd = H.weights()
+    g = torch.Generator().manual_seed(11)
+    picks = [torch.randperm(64, generator=g)[:32].to(torch.int32).to(dev) for _ in range(14)]
+    torch.cuda.synchronize()
+    runs = {}
+    for mode in ("two", "fused"):
+        monkeypatch.setenv("RIFT_FUSED_TAIL", "1" if mode == "fused" else "0")
+        replay = DeviceReplay(scenes, dev, rcap=6)
+        model = PlanningModel(radius=120)
+        model.load_state_dict({k: v.clone() for k, v in sd.items()})
+        model = model.to(dev)
+        model.need_traj = False
+        model.train()
+        tr = RLFTTrainer(model, kind="rift", seed=5)
+        assert tr.fused_tail == (mode == "fused")
+        for k, ix in enumerate(picks):
+            if k == 7:
+                tr.wait_update()
+                tr.on_epoch_end()          # the scheduler moves param_groups['lr']: the fused call reads it per step like the separate one
+            fb, b = tr.gather(replay, ix)
+            tr.training_step(fb, b)
+        mean = tr.pop_mean_loss()
+        tr.wait_update()
+        torch.cuda.synchronize()
+        state = {}
+        for name, p in model.named_parameters():
+            if name.startswith(PI):
+                st = tr.optimizer.state[p]
+                state[name] = (p.detach().cpu().clone(), p.grad.detach().cpu().clone(), st["exp_avg"].cpu().clone(), st["exp_avg_sq"].cpu().clone(),
+                               st["step"].cpu().clone())
+        runs[mode] = (mean, float(tr.grad_norm.item()), state, tr._adam_step)
+        tr.close()
+        model.release_engine()
+    assert runs["fused"][0] == runs["two"][0] and runs["fused"][1] == runs["two"][1] and runs["fused"][3] == runs["two"][3] == 14
+    assert len(runs["two"][2]) == 6
+    for name, ref in runs["two"][2].items():
+        for what, a, b in zip(("param", "grad", "exp_avg", "exp_avg_sq", "step"), ref, runs["fused"][2][name]):
+            assert torch.equal(a, b), (name, what, float((a - b).abs().max()))
+        assert float(ref[4]) == 14.0
