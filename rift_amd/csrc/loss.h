@@ -495,17 +495,25 @@ struct AdamList {
   int count; float beta1, beta2, omb1, omb2, bc2_sqrt, eps;           // omb = 1 - beta (double subtraction, then rounded, as torch does)
 };
 
+// one element's update -- ONE definition for both kernels that apply it (adamw_kernel, update_tail_kernel): which products the compiler
+// contracts into FMAs is decided per expression tree, and the two have to agree to the last bit
+__device__ __forceinline__ void adamw_elem(const float g, float& p, float& m, float& v, const float step_size, const float decay,
+                                           const float omb1, const float beta2, const float omb2, const float bc2_sqrt, const float eps) {
+  float pv = p * decay;
+  const float mn = m + (g - m) * omb1;
+  const float vn = v * beta2 + omb2 * g * g;
+  const float denom = sqrtf(vn) / bc2_sqrt + eps;
+  pv -= step_size * (mn / denom);
+  p = pv; m = mn; v = vn;
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(AdamList L) {
   for (int t = 0; t < L.count; ++t) {
     const float step_size = L.step_size[t], decay = L.decay[t];
     if (blockIdx.x == 0 && threadIdx.x == 0) L.step[t][0] = L.step_new[t];
     for (long long i = blockIdx.x * 256 + threadIdx.x; i < L.n[t]; i += (long long)gridDim.x * 256) {
-      const float g = L.g[t][i];
-      float pv = L.p[t][i] * decay;
-      const float m = L.m[t][i] + (g - L.m[t][i]) * L.omb1;
-      const float v = L.v[t][i] * L.beta2 + L.omb2 * g * g;
-      const float denom = sqrtf(v) / L.bc2_sqrt + L.eps;
-      pv -= step_size * (m / denom);
+      float pv = L.p[t][i], m = L.m[t][i], v = L.v[t][i];
+      adamw_elem(L.g[t][i], pv, m, v, step_size, decay, L.omb1, L.beta2, L.omb2, L.bc2_sqrt, L.eps);
       L.p[t][i] = pv; L.m[t][i] = m; L.v[t][i] = v;
     }
   }
@@ -566,15 +574,12 @@ __global__ __launch_bounds__(1024) void update_tail_kernel(const float* __restri
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     if (!dp[u]) continue;
-    const float g = v[u] * coef;
+    float g = v[u] * coef;
+    asm volatile("" : "+v"(g));          // the ROUNDED clipped gradient (what the separate AdamW launch reads back from .grad): no FMA across this point
     *dp[u] = g;
     const int sg = seg[u], o = off[u];
-    float pv = A.p[sg][o] * A.decay[sg];
-    const float m0 = A.m[sg][o], v0 = A.v[sg][o];
-    const float m = m0 + (g - m0) * A.omb1;
-    const float vv = v0 * A.beta2 + A.omb2 * g * g;
-    const float denom = sqrtf(vv) / A.bc2_sqrt + A.eps;
-    pv -= A.step_size[sg] * (m / denom);
+    float pv = A.p[sg][o], m = A.m[sg][o], vv = A.v[sg][o];
+    adamw_elem(g, pv, m, vv, A.step_size[sg], A.decay[sg], A.omb1, A.beta2, A.omb2, A.bc2_sqrt, A.eps);
     A.p[sg][o] = pv; A.m[sg][o] = m; A.v[sg][o] = vv;
   }
 }

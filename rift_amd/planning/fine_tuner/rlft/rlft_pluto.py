@@ -25,7 +25,7 @@ from rift_amd.gym_carla.buffer.cbv_rollout_buffer import CBVRolloutBuffer
 from rift_amd.planning.fine_tuner.rlft.trainer import RLFTTrainer, split_minibatch
 from rift_amd.planning.pluto.model.pluto_model import PlanningModel
 from rift_amd.planning.pluto.pluto import (PLUTO, CBVBasePolicy, CBVStateSource, Candidates, CenterState, NoFlagSource,   # noqa: F401 (re-exported)
-                                            capped_host_threads)
+                                            capped_host_threads, paused_cyclic_gc)
 from rift_amd.replay import DeviceReplay
 
 DEFAULT_CFG = {   # fine_tuner/rlft/config/{rift,grpo,ppo,reinforce}_training.yaml + datamodule/*.yaml + lightning/custom_lightning.yaml
@@ -33,6 +33,7 @@ DEFAULT_CFG = {   # fine_tuner/rlft/config/{rift,grpo,ppo,reinforce}_training.ya
     "trainable_layers": ["planning_decoder.pi_head"], "train_batch_size": 256, "val_batch_size": 256, "shuffle": True,
     "train_ratio": 0.9, "gamma": 0.98, "lambda_gae_adv": 0.98, "gradient_clip_val": 0.5,
     "host_threads": 4,          # cap of torch's intra-op pool during an update (capped_host_threads; 0 = leave it alone)
+    "pause_gc": True,           # no cyclic-GC pass inside an update (paused_cyclic_gc: a full collection there is a 100 ms stall)
 }
 
 
@@ -179,8 +180,12 @@ class RLFTPluto(PLUTO):
     def _trunk_version(model):
         """Identity + in-place version of every FROZEN tensor of `model` (everything an update does not move): unchanged as long as
         nobody loaded, re-initialised or re-allocated the trunk."""
-        moving = set(RLFTPluto._moving_keys(model)) if any(p.requires_grad for p in model.parameters()) else set()
-        return tuple((k, v.data_ptr(), v._version) for k, v in model.state_dict().items() if k not in moving)
+        # (walks the modules' own tables: named_parameters() + state_dict() of the 438 tensors cost 4.5 ms a call, twice per update)
+        mods = list(model.modules())
+        frozen = [p for m in mods for p in m._parameters.values() if p is not None and not p.requires_grad]
+        if len(frozen) == sum(1 for m in mods for p in m._parameters.values() if p is not None):      # nothing trainable: the buffers do not move either
+            frozen += [b for m in mods for b in m._buffers.values() if b is not None]
+        return tuple((id(t), t.data_ptr(), t._version) for t in frozen)
 
     @staticmethod
     def _moving_keys(model) -> List[str]:
@@ -210,7 +215,7 @@ class RLFTPluto(PLUTO):
         the exchanges of RLFTTrainer make the sharded step equal the single-process one -- same losses, gradients, BatchNorm running
         statistics and therefore the same checkpoint on every rank; rank 0 writes it."""
         assert self.buffer is not None and self.buffer.buffer_full, 'The buffer should be full before training'
-        with capped_host_threads(self.cfg.get("host_threads", 4)):
+        with capped_host_threads(self.cfg.get("host_threads", 4)), paused_cyclic_gc(self.cfg.get("pause_gc", True)):
             return self._train(e_i, process_group)
 
     def _train(self, e_i, process_group=None):
@@ -225,6 +230,7 @@ class RLFTPluto(PLUTO):
         # the end of its previous update, the frozen trunk is already in place and the moving tensors are restored from the device
         # snapshot kept with it -- no 17 MB read + 438 host-to-device copies per update.
         mem = self.__dict__.get("_mem_ckpt")
+        loaded_from = "file" if self.checkpoint else "inference model"
         base_cpu = None                       # CPU copy of the whole state_dict the update starts from (the frozen part of the next checkpoint)
         if (self.checkpoint and mem is not None and mem["path"] == self.checkpoint and Path(self.checkpoint).exists()
                 and mem["model"] is self.train_model and mem["trunk"] == self._trunk_version(self.train_model)):
@@ -233,6 +239,7 @@ class RLFTPluto(PLUTO):
                 for k, v in mem["moving"].items():
                     own[k].copy_(v)
             base_cpu = mem["base_cpu"]
+            loaded_from = "device snapshot"
         elif self.checkpoint:
             if not Path(self.checkpoint).exists():
                 raise FileNotFoundError(f"{self.name}: checkpoint {self.checkpoint} does not exist")
@@ -311,14 +318,16 @@ class RLFTPluto(PLUTO):
         # epoch; top-1 = the FIRST epoch with the minimal validation loss, exactly what the strict `<` of the per-epoch decision selects, and
         # the checkpoint is written from that epoch's snapshot.  The non-finite flag is sticky and checked at that one read.
         deferred = world == 1 and not cfg.get("checkpoint_every_improvement", False)
+        trunk_after, buffer_reset = None, False
         try:
             if deferred:
                 own = self.train_model.state_dict()
                 src = [own[k] for k in moving]
-                snaps = [[torch.empty_like(t) for t in src] for _ in range(cfg["epochs"])]
+                snaps = []
                 table = torch.zeros(cfg["epochs"], 2, dtype=torch.float64, device=self.device)
                 lrs = []
                 for epoch in range(cfg["epochs"]):
+                    snaps.append([torch.empty_like(t) for t in src])   # (per epoch, behind the steps issued so far: 0.4 ms of host time each, hidden)
                     for mb in minibatches(epoch, cfg["train_batch_size"]):
                         run(mb, True)
                     trainer.pop_mean_loss_async(table[epoch, 0])
@@ -327,6 +336,12 @@ class RLFTPluto(PLUTO):
                     trainer.on_epoch_end()
                     lrs.append(trainer.optimizer.param_groups[0]["lr"])
                     torch._foreach_copy_(snaps[epoch], src)          # (behind the validation steps on this stream; the next epoch's updates are ordered behind it)
+                # the host is ~100 ms ahead of the device here: what the end of the update needs from the host and does not depend on the
+                # outcome happens now, in the device's shadow -- the frozen trunk's identity (nothing queued writes it) and the buffer reset
+                # (4096 committed rows to free, 9 ms; the arena was uploaded from the pinned mirror before the first epoch)
+                trunk_after = self._trunk_version(self.train_model)
+                self.buffer.reset_buffer()
+                buffer_reset = True
                 host = table.cpu()                                     # the update's one host read
                 trainer.check_finite()
                 for epoch in range(cfg["epochs"]):
@@ -372,7 +387,7 @@ class RLFTPluto(PLUTO):
         # the snapshot pairs with the file THIS update wrote and with this very training model (set_mode / load_model drop it; a
         # checkpoint directory in which update_training_ckpt resolves to another file never takes the fast path)
         self._mem_ckpt = {"path": best_path.as_posix(), "moving": snapshot, "base_cpu": base_cpu, "model": self.train_model,
-                          "trunk": self._trunk_version(self.train_model)}
+                          "trunk": trunk_after if trunk_after is not None else self._trunk_version(self.train_model)}
         # refresh the inference model (rlft_pluto.py:244-246).  Its frozen trunk equals the training model's when both came from the same
         # checkpoint (or the training model was copied from it) and nobody has touched it since: then only the moving tensors are copied,
         # in place, device to device -- and the engine reads exactly those through their pointers, so no re-bind either
@@ -386,8 +401,11 @@ class RLFTPluto(PLUTO):
             self.pluto_model.load_state_dict(self.load_infer_checkpoint(self.checkpoint, self.device))
         self._infer_bound = (self.checkpoint, self.pluto_model._tensor_version())
         mark("reload")
-        self.buffer.reset_buffer()
+        if not buffer_reset:
+            self.buffer.reset_buffer()
+        mark("reset_buffer")
         self.last_fit["timing"] = {b[0] + "_s": b[1] - a[1] for a, b in zip(marks, marks[1:])}
+        self.last_fit["loaded_from"] = loaded_from
         return self.last_fit
 
 
