@@ -300,8 +300,15 @@ class RLFTPluto(PLUTO):
                 lo, hi = split_minibatch(m, rank, world) if world > 1 else (0, m)
                 yield idx_dev[s + lo:s + hi], int(r_all[s:s + m].max()), ((lo, m) if world > 1 else None), up
 
-        def run(batch, train):
+        def run(batch, train, out=None):
             idx_dev, R_out, shard, up = batch
+            if out is not None:       # validation through the step pipeline (RLFTTrainer.validation_step): its batch is gathered like a training batch
+                fb, b = trainer.gather(replay, idx_dev, R_out, ready=up)
+                if extras:
+                    b = dict(b)
+                    for k, v in extras.items():
+                        b[k] = v[idx_dev.long()].contiguous()
+                return trainer.validation_step(fb, b, shard=shard, out=out)
             # training steps cycle through _ffi.DEFER_SLOTS batch-buffer sets: the tail of step k (policy head .. AdamW) runs beside the trunk of step
             # k + 1, whose batch is gathered on the prefetch stream (RLFTTrainer.gather); validation joins the update stream first and uses slot 0
             fb, b = trainer.gather(replay, idx_dev, R_out, ready=up) if train else replay.collate(eng, idx_dev, R_out, slot=0)
@@ -326,16 +333,38 @@ class RLFTPluto(PLUTO):
                 snaps = []
                 table = torch.zeros(cfg["epochs"], 2, dtype=torch.float64, device=self.device)
                 lrs = []
+                # validation through the step pipeline: the epoch's validation trunks follow its last training trunk on this stream without
+                # waiting for that step's update, their heads / objectives and the epoch's bookkeeping (mean losses, the snapshot of the trained
+                # parameters) sit on the update stream between the tails -- this stream never waits for the update stream inside an update.
+                # BatchNorm statistics are written by the training trunks on THIS stream: their snapshot stays here
+                piped = trainer.pipelined_validation
+                val_mbs = list(minibatches(cfg["epochs"], cfg["val_batch_size"]))
+                vtab = torch.zeros(cfg["epochs"], max(len(val_mbs), 1), dtype=torch.float64, device=self.device)
+                tp = {n for n, p_ in self.train_model.named_parameters() if p_.requires_grad}      # (state_dict() tensors are detached: ask the parameters)
+                trained = [i for i, k in enumerate(moving) if k in tp]           # written by AdamW on the update stream
+                buffers = [i for i, k in enumerate(moving) if k not in tp]       # BatchNorm running statistics, written by the training trunks
                 for epoch in range(cfg["epochs"]):
                     snaps.append([torch.empty_like(t) for t in src])   # (per epoch, behind the steps issued so far: 0.4 ms of host time each, hidden)
                     for mb in minibatches(epoch, cfg["train_batch_size"]):
                         run(mb, True)
-                    trainer.pop_mean_loss_async(table[epoch, 0])
-                    vl = [run(mb, False).clone() for mb in minibatches(cfg["epochs"], cfg["val_batch_size"])]
-                    table[epoch, 1].copy_(torch.stack(vl).mean() if vl else table[epoch, 0])
+                    if piped:
+                        for j, mb in enumerate(val_mbs):
+                            run(mb, False, out=vtab[epoch, j:j + 1])
+                        with trainer.update_stream():
+                            trainer.pop_mean_loss_async(table[epoch, 0], in_update_stream=True)
+                            table[epoch, 1].copy_(vtab[epoch].mean() if val_mbs else table[epoch, 0])
+                            if trained:
+                                torch._foreach_copy_([snaps[epoch][i] for i in trained], [src[i] for i in trained])
+                        if buffers:
+                            torch._foreach_copy_([snaps[epoch][i] for i in buffers], [src[i] for i in buffers])
+                    else:
+                        trainer.pop_mean_loss_async(table[epoch, 0])
+                        vl = [run(mb, False).clone() for mb in val_mbs]
+                        table[epoch, 1].copy_(torch.stack(vl).mean() if vl else table[epoch, 0])
+                        torch._foreach_copy_(snaps[epoch], src)      # (behind the validation steps on this stream; the next epoch's updates are ordered behind it)
                     trainer.on_epoch_end()
                     lrs.append(trainer.optimizer.param_groups[0]["lr"])
-                    torch._foreach_copy_(snaps[epoch], src)          # (behind the validation steps on this stream; the next epoch's updates are ordered behind it)
+                trainer.wait_update()                                  # (the table and the snapshots of the trained parameters come off the update stream)
                 # the host is ~100 ms ahead of the device here: what the end of the update needs from the host and does not depend on the
                 # outcome happens now, in the device's shadow -- the frozen trunk's identity (nothing queued writes it) and the buffer reset
                 # (4096 committed rows to free, 9 ms; the arena was uploaded from the pinned mirror before the first epoch)

@@ -7,6 +7,7 @@ One step = train-mode forward (HIP) -> objective + analytic pi_head backward (HI
 -> clip_grad_norm_(0.5) -> AdamW.  The optimizer and the collective stay in
 PyTorch-ROCm, as the reference's optimizer does (rift_trainer.py:279-362).
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -445,13 +446,13 @@ class RLFTTrainer:
         self._exchange_and_finalize(backward, clip_val)
         return self.loss
 
-    def forward_trunk(self, fb: "_ffi.RiftFeatureBatch", shard=None):
-        """The frozen part of a training forward (everything up to the decoder output) on the current stream; the policy head follows through
-        Engine.forward_head() wherever the caller orders it."""
+    def forward_trunk(self, fb: "_ffi.RiftFeatureBatch", shard=None, train: bool = True):
+        """The frozen part of a forward (everything up to the decoder output) on the current stream; the policy head follows through
+        Engine.forward_head() wherever the caller orders it.  `train` False: the validation forward (BatchNorm running statistics, no drops)."""
         self._A = fb.A
         self._outputs(fb.bs, fb.R)
         self._set_shard(fb, shard)
-        flags = _ffi.F_TRAIN | _ffi.F_DEFER_HEAD | (_ffi.F_NEED_TRAJ if getattr(self.model, "need_traj", False) else 0) | \
+        flags = (_ffi.F_TRAIN if train else 0) | _ffi.F_DEFER_HEAD | (_ffi.F_NEED_TRAJ if getattr(self.model, "need_traj", False) else 0) | \
             (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0)
         self.step_count += 1
         self.engine.forward_raw(fb, self.out, flags, (self.seed_base + self.step_count) & 0xFFFFFFFF)
@@ -655,11 +656,13 @@ class RLFTTrainer:
         self.loss_acc.zero_()
         return v
 
-    def pop_mean_loss_async(self, out: torch.Tensor):
+    def pop_mean_loss_async(self, out: torch.Tensor, in_update_stream: bool = False):
         """pop_mean_loss() without the host: the mean training loss since the last call is written into the device f64 scalar `out` on the
         current stream (which first joins the update stream: the epoch's parameters are final for whatever is queued behind).  The caller reads
-        its epochs back in ONE copy at the end of the update and calls check_finite() there (the flag is sticky)."""
-        self.wait_update()
+        its epochs back in ONE copy at the end of the update and calls check_finite() there (the flag is sticky).  `in_update_stream`: called
+        inside `with update_stream():` -- the current stream IS the update stream, nothing to join."""
+        if not in_update_stream:
+            self.wait_update()
         n, self.loss_n = self.loss_n, 0
         used = n % self.LOSS_SLOTS or (self.LOSS_SLOTS if n else 0)
         torch.add(self.loss_acc[0], self.loss_hist[:used].sum(), out=out)
@@ -724,10 +727,67 @@ class RLFTTrainer:
         self.engine.adamw_step_raw(self._adam_list, [g["lr"] for g in self._adam_owner], [g["weight_decay"] for g in self._adam_owner],
                                    float(self._adam_step), g0["betas"][0], g0["betas"][1], g0["eps"])
 
-    def validation_step(self, fb, extras, shard=None):
+    @property
+    def pipelined_validation(self) -> bool:
+        """Whether validation_step(out=...) on a batch taken through gather() rides the step pipeline (single process; under data parallelism
+        the tails are issued a step late around the all-reduces and validation stays a whole step on the caller's stream)."""
+        return bool(self.pipeline) and not (self.exchange is not None and (self.world > 1 or self.force_exchange)) \
+            and os.environ.get("RIFT_PIPELINE_VAL", "1") == "1"
+
+    def validation_step(self, fb, extras, shard=None, out: Optional[torch.Tensor] = None):
+        """LightningTrainer.validation_step: the objective in eval mode, no gradients.  Returns the device f64 loss scalar.
+        `out` (a one-element f64 device tensor that outlives the update) + a batch taken through gather() + `pipelined_validation`: the step
+        runs like a training step without its update -- frozen trunk on the caller's stream in the next activation arena, policy head +
+        objective on the update stream behind the tails already queued there (so it sees the parameters of the last update without the caller's
+        stream waiting for them), loss written to `out` on that stream: read it behind wait_update() / inside update_stream()."""
+        if out is not None and self._slot_taken and self.pipelined_validation:
+            self._slot_taken = False
+            slot = self._slot
+            if self._slot_prefetch:
+                self.engine.set_prepare_stream(self.prefetch_stream)
+            main = torch.cuda.current_stream()
+            self._flush_tail()
+            try:
+                with _ffi.known_stream(main):
+                    self.forward_trunk(fb, shard, train=False)
+            finally:
+                if self._slot_prefetch:
+                    self.engine.set_prepare_stream(None)
+            self._ev_loss.record(main)
+            self.loss, self.lo.loss = out, out.data_ptr()
+            with torch.cuda.stream(self._side), _ffi.known_stream(self._side):
+                self._side.wait_event(self._ev_loss)
+                self.engine.forward_head(0)
+                if not getattr(extras, "persistent", False):
+                    for t in extras.values():
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(self._side)
+                self.set_loss_inputs(extras)
+                self.engine.loss_backward_raw(self.kind_id, self.li, self.lo)
+                self._exchange_and_finalize(False, None)
+                self._ev_param.record(self._side)
+                self._ev_tail[slot].record(self._side)
+            return out
         self.wait_update()              # (a deferred tail may still be reading the activations this forward is about to overwrite)
         self._loss_slot(None)
-        return self.forward_loss(fb, extras, train=False, backward=False, shard=shard)
+        loss = self.forward_loss(fb, extras, train=False, backward=False, shard=shard)
+        if out is not None:
+            out.copy_(loss.reshape(out.shape))
+            return out
+        return loss
+
+    @contextlib.contextmanager
+    def update_stream(self):
+        """Device work issued inside (epoch bookkeeping that reads the step losses or the trained parameters) is queued on the update stream,
+        behind the tails issued so far and ahead of the next one, WITHOUT the caller's stream waiting for them; wait_update() afterwards
+        covers it.  Without an update stream: the caller's stream, behind wait_update()."""
+        self._flush_tail()
+        if not self.overlap_update:
+            yield
+            return
+        with torch.cuda.stream(self._side):
+            yield
+            self._ev_param.record(self._side)
 
     def on_epoch_end(self):
         self.scheduler.step()
