@@ -54,6 +54,8 @@ def compile_commands(extra=(), stats=False, variant=None):
     for tag, f16 in (FORMATS[:1] if stats else FORMATS):
         for unit, flags in UNITS:
             o = os.path.join(OBJ, f"{unit}_{tag}{sfx}.o")
+            if stats and unit == "dec_w":      # the decision counters push the train-mode decoder past 256 VGPRs: the diagnostic twin takes the safe spill path (spill rule above)
+                flags = flags + SPILL_SAFE
             cmds.append((o, [hipcc()] + COMMON + defs + [f"-DRIFT_OP_F16={f16}", "-c"] + flags + [os.path.join(CSRC, unit + ".hip"), "-o", o] + list(extra)))
     o = os.path.join(OBJ, f"abi{sfx}.o")
     cmds.append((o, [hipcc()] + COMMON + (["-DRIFT_ABI_BF16_ONLY=1"] if stats else []) + ["-x", "hip", "-c", os.path.join(CSRC, "abi.cpp"), "-o", o] + list(extra)))

@@ -43,6 +43,7 @@ namespace RIFT_NS {
 #define DECW_PAR_LAYER (DECW_E_N + DECW_L_N)
 #define DECW_XS 132
 #define DECW_LDS_BYTES (2 * 32768 + 96 * DECW_XS * 4 + DECW_PAR_LAYER * 4 + 96 * 4 + 96 * 4 + 16)
+#define DECW_LDS_MID_BYTES (DECW_LDS_BYTES + 32 * 4)                   // eight key tiles: 128 mask entries
 #define DECW_LDS_DENSE_BYTES (2 * 32768 + 2 * DECW_PAR_LAYER * 4 + 192 * 4 + 12 * 16 * 4 + 16)
 #define DECW_ROWS 96                            // dropout counter stride per scene
 
@@ -79,6 +80,8 @@ struct DecWP {
   DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 
+// batches the standard kernel serves with EIGHT key tiles out of the dense K | V^T image (dec_kv.h): R <= 8 lines, 96 < N <= 128 token slots
+inline bool decw_mid_shape(int R, int N) { return R <= 8 && N > 96 && N <= 128; }
 // host entry points of the dec_w.hip translation unit (see build.py)
 int decw_set_attributes();
 void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t stream);

@@ -60,19 +60,42 @@ __global__ void pack_decw_kernel(DecWSrc s, unsigned short* __restrict__ img, fl
   }
 }
 
-// Dropout decisions of this kernel: four per-lane 24-bit linear congruential streams, one FULL-RATE instruction per decision
-// (v_mad_u32_u24: x <- x[23:0] * A + C_i; the decision compares bits 31..16 of the result -- the middle of the 42-bit product, where
-// every state bit has mixed in -- with the 16-bit threshold p * 65536).  The round-2 form drew two decisions from one xorshift32 step (six
-// instructions, three per decision); the counter hash of common.h before it costs three quarter-rate 32-bit multiplies per two decisions.
-// At 384 decisions per lane and layer the generator was a third of this kernel's VALU work.  Same Bernoulli(p) decisions at 2^-16
-// resolution and the same 1/(1-p) scaling (tests/test_gpu_dropstats.py checks rates, scaling and independence in the kernel); the mask is a
-// deterministic function of (seed, stream, scene, lane, draw order).  A = 214013 (a = 1 mod 4: full period 2^24 with an odd increment);
-// the four states of a lane use four different odd increments, so their sequences are different affine images of the cycle, and every
-// lane starts its four at hashed positions.
+// Dropout decisions of this kernel: four per-lane 24-bit linear congruential streams, one FULL-RATE instruction per TWO decisions
+// (v_mad_u32_u24: x <- x[23:0] * A + C_i; the 32-bit result is a word of two 16-bit uniforms: bits 31..16 -- the middle of the 42-bit
+// product, where every state bit has mixed in -- and bits 15..0, which by themselves are the full-period 16-bit generator x[15:0] * A + C_i).
+// History: the counter hash of common.h costs three quarter-rate 32-bit multiplies per two decisions; round 2 drew two decisions from one
+// xorshift32 step (six instructions); rounds 3 / 4 one decision per LCG step (upper half only).  Round 5 uses both halves and applies the
+// decision where the data already is a PAIR of 16-bit operand words (softmax weights, the FFN hidden layer: 256 of a lane's 384 decisions
+// per layer): d = sat_i16((tau - 1) - s) per half (v_pk_sub_i16 clamp; s = the half as a signed integer, tau = p * 65536 - 32768) is
+// negative exactly where s >= tau, v_pk_ashrrev_i16 turns that into 0xffff / 0, one v_and_b32 applies both -- 2 instructions per decision
+// where the fp32 form (step, compare, select, multiply) took 3.5; the 1/(1-p) factor rides on 1/sum of the softmax and on the FFN's output.
+// The residual-branch sites stay fp32 (compare + select on each half of the word: 3 per decision).  What the lower half is worth
+// (tools/checks/lcg_halves.py, over the full period, p = 0.1): single rates 0.09999, pairs of one step's two decisions and of successive
+// decisions within 0.3 % of p^2, triples within 11 % of p^3, the count of drops among 12 successive draws within 0.3 % absolute of the
+// binomial -- first- and second-order statistics of independent Bernoulli(p) decisions; tests/test_gpu_dropstats.py checks rates and
+// scaling in the kernel.  The mask is a deterministic function of (seed, stream, scene, lane, draw order).  A = 214013 (a = 1 mod 4: full
+// period 2^24 with an odd increment, and A mod 2^16 = 17405 = 1 mod 4 likewise for the lower half); the four states of a lane use four
+// different odd increments, so their sequences are different affine images of the cycle, and every lane starts its four at hashed positions.
 struct DecWRng { uint32_t x[4]; };
 __device__ __forceinline__ uint32_t decw_step(uint32_t x, uint32_t c) {
   return (x & 0xffffffu) * 214013u + c;          // both factors below 2^24: hipcc selects v_mad_u32_u24 and drops the mask (the ISA test of tools/checks counts them)
 }
+typedef short decw_s16x2 __attribute__((ext_vector_type(2)));
+// a word of two uniforms -> 0xffff where the half is KEPT (tm1 = the pair (tau - 1, tau - 1))
+__device__ __forceinline__ uint32_t decw_keep2(uint32_t w, uint32_t tm1) {
+  const decw_s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(decw_s16x2, tm1), __builtin_bit_cast(decw_s16x2, w));
+  return __builtin_bit_cast(uint32_t, d >> (decw_s16x2){15, 15});
+}
+// ... -> the sign bit of the half set where it is DROPPED (tau2 = the pair (tau, tau)), everything else clear
+__device__ __forceinline__ uint32_t decw_drop_sign2(uint32_t w, uint32_t tau2) {
+  const decw_s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(decw_s16x2, w), __builtin_bit_cast(decw_s16x2, tau2));
+  return __builtin_bit_cast(uint32_t, d) & 0x80008000u;
+}
+// ReLU of a pair of operand words: a negative bf16 / fp16 word is a negative 16-bit integer (v_pk_max_i16); relu(round(x)) == round(relu(x))
+__device__ __forceinline__ uint32_t decw_relu2(uint32_t w) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(decw_s16x2, w), (decw_s16x2){0, 0}));
+}
+__device__ __forceinline__ h16x8 decw_words(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return l0w_from_u2(make_uint2(a, b), make_uint2(c, d)); }
 // DROP: train mode (dropout 0.1 at eight sites of every layer) -- a template parameter, so that the per-site tests are not sixteen uniform
 // branches per epilogue
 // DENSE: the dense-traffic shapes (BASELINE configs[4]: up to 16 reference lines, up to 192 tokens).  r2r tiles hold ONE mode x 16 lines
@@ -80,13 +103,18 @@ __device__ __forceinline__ uint32_t decw_step(uint32_t x, uint32_t c) {
 // once per round; the residual changes tiling through the query array in global memory (release / acquire fences around the group barrier)
 // instead of the 96-row LDS buffer, the parameter blocks of two layers are resident (double-buffered by layer parity), and the scene's
 // K | V^T operands come as four per-head groups of 12 key tiles (dec_kv.h writes them).
-// NKE (DENSE only): key tiles the cross attention walks -- 8 when the batch has N <= 128 token slots (the CARLA shapes, 109), else all 12 of
-// the scene's K | V^T image; the tiles beyond the batch's own are zero fragments behind -inf masks (exact zeros in both sums)
+// NKE (DENSE): key tiles the cross attention walks -- 8 when the batch has N <= 128 token slots, else all 12 of the scene's K | V^T image;
+// the tiles beyond the batch's own are zero fragments behind -inf masks (exact zeros in both sums).
+// NKE = 8 without DENSE (round 5, "MID"): the standard kernel -- one round of tiles, LDS hand-over, one parameter block -- for batches with
+// R <= 8 reference lines and 96 < N <= 128 token slots: what `train_cbv` really collates (49 agents + 60 polygons = 109 slots), which the
+// dense variant served at 1.5 x the standard kernel's time.  Eight key tiles make a head pair's K | V^T group exactly 32 fragments, one
+// ring slot; they are gathered out of the dense per-head image (dec_kv.h) in runs of four fragments.
 template <bool DROP, bool DENSE, int NKE = (DENSE ? 12 : 6)>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dec_w_kernel(DecWP p) {
   constexpr int M = 12, XS = DECW_XS;
   constexpr int NS = DENSE ? 16 : 8;             // reference-line slots of an r2r tile
-  constexpr int NKT = DENSE ? 12 : 6;            // key tiles of the cross attention
+  constexpr int NKT = DENSE ? 12 : NKE;          // key tiles of the cross attention
+  constexpr bool MID = !DENSE && NKE == 8;
   constexpr int NTA = DENSE ? 12 : 6;            // r2r tiles: one mode each / one mode pair each
   constexpr int RA = DENSE ? 2 : 1;              // rounds of eight tiles in the r2r tiling
   constexpr int GB = DENSE ? 18 : 16;            // groups of the reference-line tiling: m2m 4 | cross q | K|V^T 4 or 2 | cross out | FFN 8
@@ -109,7 +137,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int GL = 4 * RA + GB * RB;               // groups of a layer (even)
   const size_t qrow0 = (size_t)b * NQ;
   const float dp = p.dropout, dpk = dp > 0.f ? 1.0f / (1.0f - dp) : 1.0f;
-  const uint32_t thr16 = drop_thr16(dp);
+  const uint32_t thr16 = drop_thr16(dp);                                     // a half u (unsigned) is dropped where u < thr16 (fp32 sites) ...
+  const uint32_t tau16 = (thr16 - 32768u) & 0xffffu, tau2 = tau16 | (tau16 << 16);           // ... or, read as a signed integer, below tau (packed sites)
+  const uint32_t tm1 = ((tau16 - 1u) & 0xffffu) | (((tau16 - 1u) & 0xffffu) << 16);
   const uint32_t lds00 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw);
   uint32_t lds0 = lds00;
   uint32_t voff = (uint32_t)lane * 16u;
@@ -149,12 +179,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lw = ld_few ? (wv & 1) + ((wv >> 2) << 1) : wv, ln = ld_few ? 4 : 8;
     decw_dma_share(reinterpret_cast<const unsigned char*>(src), voff, lds0 + dst, nfrag, lw, ln);   // (one rolled loop: every boundary site carries it)
   };
+  // (MID) head pair g of a layer's dense K | V^T image (per head: 12 K fragments, 12 V^T fragments (dim tile d) x 6 + pt) -> one ring slot,
+  // per head hh 16 fragments: K key tiles 0..7 | V^T (d, pt < 4) at 8 + 4 d + pt -- eight runs of four consecutive fragments
+  auto dma_kv_mid = [&](const unsigned char* kvl, int g, uint32_t dst) {
+    if ((ld_few && !(wv & 2)) || (p.dbg & 8)) return;
+    const int lw = ld_few ? (wv & 1) + ((wv >> 2) << 1) : wv, nr = ld_few ? 2 : 1;
+#pragma unroll 1
+    for (int r = lw * nr; r < lw * nr + nr; ++r) {
+      const int hh = r >> 2, q = r & 3;
+      const int so = (2 * g + hh) * 24 + (q < 2 ? q * 4 : 12 + (q - 2) * 6);
+      decw_glds4(kvl + (size_t)so * 1024, voff, lds0 + dst + (uint32_t)r * 4096u);
+    }
+  };
   // group boundary: my share of the next group has landed; after the barrier everybody's has, and nobody reads the other slot any more
   auto sync = [&]() { DTS_ARR(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); DTS(); };
   auto W = [&](int slot, int f) { return *reinterpret_cast<const h16x8*>(ring + slot * 32768 + f * 1024 + lane * 16); };
 
   const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.img);
-  constexpr int KVF = DENSE ? 96 : DECW_KV_FRAGS;                              // K | V^T fragments per (scene, layer)
+  constexpr int KVF = (DENSE || MID) ? 96 : DECW_KV_FRAGS;                     // K | V^T fragments per (scene, layer)
   const unsigned char* kvimg = reinterpret_cast<const unsigned char*>(p.KV) + (size_t)b * 4 * KVF * 1024;
   const uint32_t OFF_P = 2 * 32768 + (DENSE ? 0 : 96 * XS * 4), OFF_E = OFF_P, OFF_L = OFF_E + DECW_E_N * 4;
   // prologue: first group + the parameter block of layer 0 in flight, then the queries and masks
@@ -268,16 +310,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_h4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]), make_uint2(0u, 0u));   // k slots 4..7 unused
   };
-  // dropout multipliers of four consecutive draws: 1/(1-p) or 0
-  auto keep4 = [&](int) -> f32x4 {
-    const uint32_t h0 = rng.x[0] = decw_step(rng.x[0], 2531011u), h1 = rng.x[1] = decw_step(rng.x[1], 1013904223u & 0xffffffu);
-    const uint32_t h2 = rng.x[2] = decw_step(rng.x[2], 12345u), h3 = rng.x[3] = decw_step(rng.x[3], 7046029u);
-    const unsigned short t = (unsigned short)thr16;         // 16-bit compares on the upper register halves: no extraction instructions
+  // one step of stream i: a word of two 16-bit uniforms
+  auto draw2 = [&](int i) -> uint32_t {
+    constexpr uint32_t C[4] = {2531011u, 1013904223u & 0xffffffu, 12345u, 7046029u};
+    return rng.x[i] = decw_step(rng.x[i], C[i]);
+  };
 #if RIFT_DROP_STATS
-    ddrawn[dsite] += 4;
-    dkept[dsite] += ((unsigned short)(h0 >> 16) < t ? 0 : 1) + ((unsigned short)(h1 >> 16) < t ? 0 : 1) + ((unsigned short)(h2 >> 16) < t ? 0 : 1) + ((unsigned short)(h3 >> 16) < t ? 0 : 1);
+  auto dcount = [&](uint32_t keepmask, int n) { ddrawn[dsite] += n; dkept[dsite] += __builtin_popcount(keepmask & 0x00010001u); };
+#else
+  auto dcount = [&](uint32_t, int) {};
 #endif
-    return (f32x4){((unsigned short)(h0 >> 16) < t) ? 0.f : dpk, ((unsigned short)(h1 >> 16) < t) ? 0.f : dpk, ((unsigned short)(h2 >> 16) < t) ? 0.f : dpk, ((unsigned short)(h3 >> 16) < t) ? 0.f : dpk};
+  // 0xffff / 0 per half of the next word of stream i: kept / dropped
+  auto keep2 = [&](int i) -> uint32_t { const uint32_t m = decw_keep2(draw2(i), tm1); dcount(m, 2); return m; };
+  // fp32 multipliers of four consecutive draws (streams i, i + 1): ks or 0
+  auto keep4 = [&](int i, float ks) -> f32x4 {
+    const uint32_t h0 = draw2(i), h1 = draw2(i + 1);
+    const unsigned short t = (unsigned short)thr16;         // 16-bit compares on the register halves: no extraction instructions
+    const bool d0 = (unsigned short)(h0 & 0xffffu) < t, d1 = (unsigned short)(h0 >> 16) < t, d2 = (unsigned short)(h1 & 0xffffu) < t, d3 = (unsigned short)(h1 >> 16) < t;
+#if RIFT_DROP_STATS
+    ddrawn[dsite] += 4; dkept[dsite] += (d0 ? 0 : 1) + (d1 ? 0 : 1) + (d2 ? 0 : 1) + (d3 ? 0 : 1);
+#endif
+    return (f32x4){d0 ? 0.f : ks, d1 ? 0.f : ks, d2 ? 0.f : ks, d3 ? 0.f : ks};
   };
   // 16 x 16 self-attention of the tile, per head, entirely in registers: S^T = K Q^T (lane: 4 keys of query l15), O^T = V^T P^T.
   // `mask4`: 0 / -inf of this lane's four keys, entering as the accumulator of the score MFMA; scores are in log2 units (q carries log2 e).
@@ -288,19 +341,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float m = rows_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
       f32x4 ev = {__builtin_amdgcn_exp2f(s[0] - m), __builtin_amdgcn_exp2f(s[1] - m), __builtin_amdgcn_exp2f(s[2] - m), __builtin_amdgcn_exp2f(s[3] - m)};
       const float lsum = rows_sum((ev[0] + ev[1]) + (ev[2] + ev[3]));
-      if (DROP) ev *= keep4(h);
-      const h16x8 pf = l0w_from_u2(pack_h4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
+      uint2 pw = pack_h4(ev[0], ev[1], ev[2], ev[3]);
+      if (DROP) { pw.x &= keep2(2 * (h & 1)); pw.y &= keep2(2 * (h & 1) + 1); }      // dropped weights are zero words; 1/(1-p) rides on 1/sum
+      const h16x8 pf = l0w_from_u2(pw, make_uint2(0u, 0u));
       const f32x4 o0 = mfma_h(vf[2 * h], pf, Z, 0, 0, 0);
       const f32x4 o1 = mfma_h(vf[2 * h + 1], pf, Z, 0, 0, 0);
-      const float inv = __builtin_amdgcn_rcpf(lsum);
+      const float inv = __builtin_amdgcn_rcpf(lsum) * (DROP ? dpk : 1.0f);
       ao[h] = l0w_pack8(o0 * inv, o1 * inv);
     }
   };
   // x += dropout(acc)   (acc already holds the bias)
-  auto residual = [&](f32x4 (&res)[8], const f32x4 (&acc)[8]) {
+  auto residual = [&](f32x4 (&res)[8], const f32x4 (&acc)[8], float ks) {       // ks: 1/(1-p) x whatever factor acc still lacks
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      if (DROP) res[nt] += acc[nt] * keep4(nt);
+      if (DROP) res[nt] += acc[nt] * keep4(2 * (nt & 1), ks);
       else res[nt] += acc[nt];
     }
   };
@@ -312,19 +366,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int hh = 0; hh < nh; ++hh) {
       const int h = h0 + hh;
       f32x4 s[NKT];
-      constexpr int NK0 = DENSE ? NKE : 5;         // (not DENSE: keys 80..95 exist only in batches with more than 80 tokens)
-      const bool six = (!DENSE && p.compact) ? (smaskf[80] == 0.f) : six_all;      // (workgroup-uniform: one scene per workgroup)
+      constexpr int NK0 = (DENSE || MID) ? NKE : 5;         // (standard: keys 80..95 exist only in batches with more than 80 tokens)
+      const bool six = (!DENSE && !MID) && (p.compact ? (smaskf[80] == 0.f) : six_all);      // (workgroup-uniform: one scene per workgroup)
+      auto KF = [&](int kt) { return MID ? hh * 16 + kt : kt * nh + hh; };                    // fragment of the slot: K (key tile kt, head hh) ...
+      auto VF = [&](int d, int pt) { return MID ? hh * 16 + 8 + d * 4 + pt : NKT * nh + (hh * 2 + d) * (NKT / 2) + pt; };     // ... V^T (dim tile d, key pair pt)
 #pragma unroll
       for (int kt = 0; kt < NK0; ++kt) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + kt * 16 + l4 * 4);
-        s[kt] = mfma_h(W(slot, kt * nh + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+        s[kt] = mfma_h(W(slot, KF(kt)), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
       }
       float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
       for (int kt = 1; kt < NK0; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-      if (!DENSE && six) {
+      if (!DENSE && !MID && six) {
         const float4 mk = *reinterpret_cast<const float4*>(smaskf + 80 + l4 * 4);
-        s[NKT - 1] = mfma_h(W(slot, 5 * nh + hh), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
+        s[NKT - 1] = mfma_h(W(slot, KF(5)), qf[h], (f32x4){mk.x, mk.y, mk.z, mk.w}, 0, 0, 0);
         m = fmaxf(fmaxf(m, fmaxf(s[NKT - 1][0], s[NKT - 1][1])), fmaxf(s[NKT - 1][2], s[NKT - 1][3]));
       }
       m = rows_max(m);
@@ -333,24 +389,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int kt = 0; kt < NK0; ++kt) {
         s[kt] = (f32x4){__builtin_amdgcn_exp2f(s[kt][0] - m), __builtin_amdgcn_exp2f(s[kt][1] - m), __builtin_amdgcn_exp2f(s[kt][2] - m), __builtin_amdgcn_exp2f(s[kt][3] - m)};
         l4s += s[kt];
-        if (DROP) s[kt] *= keep4(kt);
       }
-      if (!DENSE) {
+      if (!DENSE && !MID) {
         if (six) {
           s[5] = (f32x4){__builtin_amdgcn_exp2f(s[5][0] - m), __builtin_amdgcn_exp2f(s[5][1] - m), __builtin_amdgcn_exp2f(s[5][2] - m), __builtin_amdgcn_exp2f(s[5][3] - m)};
           l4s += s[5];
-          if (DROP) s[5] *= keep4(5);
         } else s[5] = Z;
       }
       const float lsum = rows_sum((l4s[0] + l4s[1]) + (l4s[2] + l4s[3]));
       f32x4 o0 = Z, o1 = Z;
 #pragma unroll
-      for (int pt = 0; pt < (DENSE ? NKE : NKT) / 2; ++pt) {
-        const h16x8 pf = l0w_pack8(s[2 * pt], s[2 * pt + 1]);
-        o0 = mfma_h(W(slot, NKT * nh + (hh * 2 + 0) * (NKT / 2) + pt), pf, o0, 0, 0, 0);
-        o1 = mfma_h(W(slot, NKT * nh + (hh * 2 + 1) * (NKT / 2) + pt), pf, o1, 0, 0, 0);
+      for (int pt = 0; pt < ((DENSE || MID) ? NKE : NKT) / 2; ++pt) {
+        uint2 pa = pack_h4(s[2 * pt][0], s[2 * pt][1], s[2 * pt][2], s[2 * pt][3]), pb2 = pack_h4(s[2 * pt + 1][0], s[2 * pt + 1][1], s[2 * pt + 1][2], s[2 * pt + 1][3]);
+        if (DROP) { pa.x &= keep2(0); pa.y &= keep2(1); pb2.x &= keep2(2); pb2.y &= keep2(3); }
+        const h16x8 pf = l0w_from_u2(pa, pb2);
+        o0 = mfma_h(W(slot, VF(0, pt)), pf, o0, 0, 0, 0);
+        o1 = mfma_h(W(slot, VF(1, pt)), pf, o1, 0, 0, 0);
       }
-      const float inv = __builtin_amdgcn_rcpf(lsum);
+      const float inv = __builtin_amdgcn_rcpf(lsum) * (DROP ? dpk : 1.0f);
       ao[h] = l0w_pack8(o0 * inv, o1 * inv);
     }
   };
@@ -368,7 +424,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int q = (pos - 4 * RA) % GB;
     constexpr int NKV = DENSE ? 4 : 2;           // K | V^T groups, 24 fragments each
     if (q < 5) dma(wl + (size_t)(4 + q) * 32768, dst, 32);
-    else if (q < 5 + NKV) dma(kvl + (size_t)(q - 5) * 24 * 1024, dst, 24);
+    else if (q < 5 + NKV) { if (MID) dma_kv_mid(kvl, q - 5, dst); else dma(kvl + (size_t)(q - 5) * 24 * 1024, dst, 24); }
     else dma(wl + (size_t)(9 + q - 5 - NKV) * 32768, dst, 32);
   };
   // group boundary that opens position `pos` of layer li: my share of the group has landed; after the barrier everybody's has, and nobody
@@ -434,7 +490,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bnd(li, pa + 3);                                        // ---- r2r out_proj, residual, hand-over to the reference-line tiling
         gemm(1, ao, acc);
         DSITE(1);
-        residual(res, acc);
+        residual(res, acc, dpk);
         write_xs(res, a_row, a_ok);
       } else {
 #pragma unroll 1
@@ -470,7 +526,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bnd(li, pb + 3);                                        // ---- m2m out_proj, residual, padded lines zeroed (:70-72), LayerNorm
         gemm(1, ao, acc);
         DSITE(3);
-        residual(res, acc);
+        residual(res, acc, dpk);
         if (rz[tileB]) zero8(res);
         layer_norm(res, xb, parL + DECW_L_LN3);
         init8(acc, parL + DECW_L_BCQ);
@@ -489,11 +545,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bnd(li, pb + KO);                                       // ---- cross out_proj, residual, LayerNorm for the FFN
         gemm(KO & 1, ao, acc);
         DSITE(5);
-        residual(res, acc);
+        residual(res, acc, dpk);
         layer_norm(res, xb, parL + DECW_L_LN4);
         DSITE(6);
         f32x4 acc2[8];
         init8(acc2, parL + DECW_L_BF2);
+        if (DROP) {            // the hidden layer's kept units go into ffn.3 unscaled: acc2 = (b2 + y) / dpk, the branch site multiplies by dpk^2
+          const float idpk = 1.0f - dp;
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) acc2[nt] *= idpk;
+        }
 #pragma unroll 1
         for (int hc = 0; hc < 4; ++hc) {                        // ---- ffn.0 chunk -> ReLU, dropout -> ffn.3 partial
           init8(acc, parL + DECW_L_BF1 + hc * 128);
@@ -501,21 +562,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           gemm((KO + 1) & 1, xb, acc);
           h16x8 hb[4];
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            f32x4 v[2];
+          for (int ks = 0; ks < 4; ++ks) {     // ReLU (and dropout: a dropped unit gets the sign bit first) on the packed operand words
+            uint32_t w[4];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
               const f32x4 a = acc[2 * ks + q];
-              v[q] = (f32x4){fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)};
-              if (DROP) v[q] *= keep4(2 * ks + q);
+              const uint2 u = pack_h4(a[0], a[1], a[2], a[3]);
+              w[2 * q] = u.x; w[2 * q + 1] = u.y;
             }
-            hb[ks] = l0w_pack8(v[0], v[1]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (DROP) { const uint32_t sg = decw_drop_sign2(draw2(q), tau2); dcount(~(sg >> 15), 2); w[q] |= sg; }
+              w[q] = decw_relu2(w[q]);
+            }
+            hb[ks] = decw_words(w[0], w[1], w[2], w[3]);
           }
           bnd(li, pb + KO + 2 + 2 * hc);
           gemm(KO & 1, hb, acc2);
         }
         DSITE(7);
-        residual(res, acc2);
+        residual(res, acc2, dpk * dpk);
         if (li == 3) {        // the reference asserts torch.isfinite(q).all() behind every block (planning_decoder.py:175); a NaN / Inf stays in
           uint32_t ex = 0;    // the residual stream, so the rows leaving the last block are tested -- by bit pattern (this unit is built -fno-honor-nans)
 #pragma unroll
@@ -560,6 +626,8 @@ int decw_set_attributes() {
   if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
   if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
   if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_DENSE_BYTES);
+  if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<false, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_MID_BYTES);
+  if (!e) e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_w_kernel<true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DECW_LDS_MID_BYTES);
   return e;
 }
 void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t stream) {
@@ -568,7 +636,10 @@ void decw_pack(const DecWSrc& src, unsigned short* img, float* par, hipStream_t 
 }
 void decw_launch(const DecWP& p, hipStream_t stream) {
   const bool dense = p.R > 8 || p.N > 96;        // the dense-traffic variant: rounds of eight tiles, hand-over through the query array
-  if (dense && p.N <= 128) {
+  if (decw_mid_shape(p.R, p.N) && !(p.dbg & 32)) {      // eight key tiles on the standard kernel (dbg 32: the dense variant instead)
+    if (p.dropout > 0.f) hipLaunchKernelGGL((dec_w_kernel<true, false, 8>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_MID_BYTES, stream, p);
+    else hipLaunchKernelGGL((dec_w_kernel<false, false, 8>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_MID_BYTES, stream, p);
+  } else if (dense && p.N <= 128) {
     if (p.dropout > 0.f) hipLaunchKernelGGL((dec_w_kernel<true, true, 8>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_DENSE_BYTES, stream, p);
     else hipLaunchKernelGGL((dec_w_kernel<false, true, 8>), dim3(p.bs), dim3(512), (size_t)DECW_LDS_DENSE_BYTES, stream, p);
   } else if (dense) {
