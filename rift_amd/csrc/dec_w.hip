@@ -17,15 +17,16 @@ __global__ void pack_decw_kernel(DecWSrc s, unsigned short* __restrict__ img, fl
     const int ch = l0w_chan(l4, j, 2 * ks), o = nt * 16 + l15;
     const DecWSrc::L& L = s.l[li];
     float v;
-    if (g < 3) v = L.r2r_w[(g * 128 + o) * 128 + ch] * (g == 0 ? SC : 1.0f);
+    auto lg = [&](int n) { return RIFT_LN_FOLD ? L.ln[2 * n][ch] : 1.0f; };       // gamma of norm n + 1 folded into the GEMM it feeds (opfmt.h: RIFT_LN_FOLD)
+    if (g < 3) v = L.r2r_w[(g * 128 + o) * 128 + ch] * (g == 0 ? SC : 1.0f) * lg(0);
     else if (g == 3) v = L.r2ro_w[o * 128 + ch];
-    else if (g < 7) v = L.m2m_w[((g - 4) * 128 + o) * 128 + ch] * (g == 4 ? SC : 1.0f);
+    else if (g < 7) v = L.m2m_w[((g - 4) * 128 + o) * 128 + ch] * (g == 4 ? SC : 1.0f) * lg(1);
     else if (g == 7) v = L.m2mo_w[o * 128 + ch];
-    else if (g == 8) v = L.c_w[o * 128 + ch] * SC;
+    else if (g == 8) v = L.c_w[o * 128 + ch] * SC * lg(2);
     else if (g == 9) v = L.co_w[o * 128 + ch];
     else {
       const int hc = (g - 10) >> 1;
-      v = ((g - 10) & 1) ? L.f2_w[o * 512 + hc * 128 + ch] : L.f1_w[(hc * 128 + o) * 128 + ch];
+      v = ((g - 10) & 1) ? L.f2_w[o * 512 + hc * 128 + ch] : L.f1_w[(hc * 128 + o) * 128 + ch] * lg(3);
     }
     img[e] = f2h(v);
   }
@@ -33,9 +34,11 @@ __global__ void pack_decw_kernel(DecWSrc s, unsigned short* __restrict__ img, fl
     const int li = e / DECW_PAR_LAYER, o = e % DECW_PAR_LAYER;
     const DecWSrc::L& L = s.l[li];
     float v = 0.f;
+    // (RIFT_LN_FOLD) beta of norm n + 1 through the rows of W into the bias: b + W beta
+    auto wb = [&](const float* Wm, int row, int n) { float a = 0.f; if (RIFT_LN_FOLD) for (int k = 0; k < 128; ++k) a += Wm[(size_t)row * 128 + k] * L.ln[2 * n + 1][k]; return a; };
     if (o < DECW_E_N) {
       if (o < 256) v = L.ln[o >> 7][o & 127];
-      else if (o < 640) v = L.r2r_b[o - 256] * (o - 256 < 128 ? SC : 1.0f);
+      else if (o < 640) v = (L.r2r_b[o - 256] + wb(L.r2r_w, o - 256, 0)) * (o - 256 < 128 ? SC : 1.0f);
       else if (o < 768) v = L.r2ro_b[o - 640];
       else if (o < 1024) v = L.ln[2 + ((o - 768) >> 7)][o & 127];
       else if (o < DECW_E_BM2MV) {
@@ -43,17 +46,17 @@ __global__ void pack_decw_kernel(DecWSrc s, unsigned short* __restrict__ img, fl
         if (c < 256) {
           float acc = 0.f;
           for (int k = 0; k < 128; ++k) acc += s.m_pos[m * 128 + k] * L.m2m_w[c * 128 + k];
-          v = (acc + L.m2m_b[c]) * (c < 128 ? SC : 1.0f);
+          v = (acc + L.m2m_b[c] + wb(L.m2m_w, c, 1)) * (c < 128 ? SC : 1.0f);
         }
-      } else if (o < DECW_E_BM2MO) v = L.m2m_b[256 + o - DECW_E_BM2MV];
+      } else if (o < DECW_E_BM2MO) v = L.m2m_b[256 + o - DECW_E_BM2MV] + wb(L.m2m_w, 256 + o - DECW_E_BM2MV, 1);
       else if (o < DECW_E_BM2MO + 128) v = L.m2mo_b[o - DECW_E_BM2MO];
     } else {
       const int q = o - DECW_E_N;
       if (q < 256) v = L.ln[4 + (q >> 7)][q & 127];
-      else if (q < 384) v = L.c_b[q - 256] * SC;
+      else if (q < 384) v = (L.c_b[q - 256] + wb(L.c_w, q - 256, 2)) * SC;
       else if (q < 512) v = L.co_b[q - 384];
       else if (q < 768) v = L.ln[6 + ((q - 512) >> 7)][q & 127];
-      else if (q < 1280) v = L.f1_b[q - 768];
+      else if (q < 1280) v = L.f1_b[q - 768] + wb(L.f1_w, q - 768, 3);
       else if (q < 1408) v = L.f2_b[q - 1280];
     }
     par[e] = v;
@@ -275,6 +278,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
     s4 += (res[4] + res[5]) + (res[6] + res[7]);
     const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
+    if (RIFT_LN_FOLD && true) {     // (opfmt.h: gamma / beta live in the consuming GEMM's weights and bias; one-pass statistics)
+      f32x4 q4 = res[0] * res[0];
+#pragma unroll
+      for (int nt = 1; nt < 8; ++nt) q4 += res[nt] * res[nt];
+      const float ex2 = rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f);
+      const float r = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + 1e-5f), c = -mean * r;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xb[ks] = l0w_pack8(res[2 * ks] * r + c, res[2 * ks + 1] * r + c);
+      return;
+    }
     f32x4 d[8];
     f32x4 q4 = Z;
 #pragma unroll

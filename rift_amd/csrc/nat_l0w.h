@@ -93,9 +93,10 @@ __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, f
     } else if (f < L0W_F_DS) {
       const int b = (f - 2) / 20, g = (f - 2) % 20;
       const NatL0WSrc::Blk& k = s.blk[b];
-      if (g < 6) v = k.wqkv[(g * 16 + l15) * 32 + l0w_chan(l4, j, 0)] * (g < 2 ? L0W_QSCALE : 1.0f);        // q scaled by head_dim^-0.5 (x log2 e: MFMA attention)
+      const float fg1 = RIFT_LN_FOLD ? k.ln1_g[l0w_chan(l4, j, 0)] : 1.0f, fg2 = RIFT_LN_FOLD ? k.ln2_g[l0w_chan(l4, j, 0)] : 1.0f;      // (opfmt.h: RIFT_LN_FOLD)
+      if (g < 6) v = k.wqkv[(g * 16 + l15) * 32 + l0w_chan(l4, j, 0)] * (g < 2 ? L0W_QSCALE : 1.0f) * fg1;  // q scaled by head_dim^-0.5 (x log2 e: MFMA attention)
       else if (g < 8) v = k.wproj[((g - 6) * 16 + l15) * 32 + l0w_chan(l4, j, 0)];
-      else if (g < 14) v = k.w1[((g - 8) * 16 + l15) * 32 + l0w_chan(l4, j, 0)];
+      else if (g < 14) v = k.w1[((g - 8) * 16 + l15) * 32 + l0w_chan(l4, j, 0)] * fg2;
       else { const int ks = (g - 14) >> 1, nt = (g - 14) & 1; v = k.w2[(nt * 16 + l15) * 96 + l0w_chan(l4, j, 2 * ks)]; hid = true; }
     } else {
       const int tap = (f - L0W_F_DS) >> 2, nt = (f - L0W_F_DS) & 3;
@@ -111,12 +112,19 @@ __global__ void pack_l0w_kernel(NatL0WSrc s, unsigned short* __restrict__ img, f
       const NatL0WSrc::Blk& k = s.blk[b];
       if (o < 32) v = k.ln1_g[o];
       else if (o < 64) v = k.ln1_b[o - 32];
-      else if (o < 160) v = k.bqkv[o - 64] * (o - 64 < 32 ? L0W_QSCALE : 1.0f);
+      else if (o < 160) {
+        v = k.bqkv[o - 64];
+        if (RIFT_LN_FOLD) for (int ch = 0; ch < 32; ++ch) v += k.wqkv[(o - 64) * 32 + ch] * k.ln1_b[ch];
+        v *= (o - 64 < 32 ? L0W_QSCALE : 1.0f);
+      }
       else if (o < 176) v = (o - 160 < 10) ? k.rpb[o - 160] : 0.f;
       else if (o < 208) v = k.bproj[o - 176];
       else if (o < 240) v = k.ln2_g[o - 208];
       else if (o < 272) v = k.ln2_b[o - 240];
-      else if (o < 368) v = k.b1[o - 272];
+      else if (o < 368) {
+        v = k.b1[o - 272];
+        if (RIFT_LN_FOLD) for (int ch = 0; ch < 32; ++ch) v += k.w1[(o - 272) * 32 + ch] * k.ln2_b[ch];
+      }
       else v = k.b2[o - 368];
     } else if (e < L0W_P_DS) v = (e - L0W_P_FN < 32) ? s.fn_g[e - L0W_P_FN] : s.fn_b[e - L0W_P_FN - 32];
     else if (e < L0W_P_TBL) v = (e - L0W_P_DS < 64) ? s.ds_g[e - L0W_P_DS] : s.ds_b[e - L0W_P_DS - 64];
@@ -158,7 +166,21 @@ __device__ __forceinline__ f32x4 l0w_sel(bool c, const f32x4 a, const f32x4 b) {
 }
 
 // LayerNorm over the 32 channels of every row of x (8 per lane, 4 lanes per row) -> bf16 B operands (two-pass statistics, as torch)
+// FOLDED (opfmt.h: RIFT_LN_FOLD): gamma / beta live in the consuming layer's weights; the final / downsample norms keep the affine form
+template <bool FOLDED = false>
 __device__ __forceinline__ void l0w_layer_norm(const f32x4 (&x)[5][2], h16x8 (&xn)[5], const float* g, const float* b, int l4) {
+  if (FOLDED) {
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+      const f32x4 u = x[mt][0], w = x[mt][1];
+      const f32x4 s4 = u + w, q4 = u * u + w * w;
+      const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 32.0f);
+      const float ex2 = rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 32.0f);
+      const float r = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + 1e-5f), c = -mean * r;
+      xn[mt] = l0w_pack8(u * r + c, w * r + c);
+    }
+    return;
+  }
   const float4 g0 = *reinterpret_cast<const float4*>(g + l4 * 4), g1 = *reinterpret_cast<const float4*>(g + 16 + l4 * 4);
   const float4 b0 = *reinterpret_cast<const float4*>(b + l4 * 4), b1 = *reinterpret_cast<const float4*>(b + 16 + l4 * 4);
 #pragma unroll
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
       const int fb = L0W_F_BLK(bi);
       h16x8 xn[5];
       // ================= attention half =================
-      l0w_layer_norm(x, xn, pb + L0W_PB_LN1G, pb + L0W_PB_LN1B, l4);
+      l0w_layer_norm<RIFT_LN_FOLD != 0>(x, xn, pb + L0W_PB_LN1G, pb + L0W_PB_LN1B, l4);
       // one head at a time (rolled loop: the live set is the residual, the LayerNorm operands and ONE head's k / v): its proj contribution
       // goes straight into the residual -- proj(concat(o_0, o_1)) = W[:, head 0] o_0 + W[:, head 1] o_1, each as a K = 32 step whose
       // other half is zero
@@ -371,7 +393,7 @@ __global__ __launch_bounds__(64 * L0W_NWV) void nat_l0w_kernel(NatL0WP p) {
       }
       L0TS();
       // ================= MLP half: fc1 (32 -> 96) -> GELU -> fc2 (96 -> 32), the hidden layer 32 channels (one k-step) at a time =================
-      l0w_layer_norm(x, xn, pb + L0W_PB_LN2G, pb + L0W_PB_LN2B, l4);
+      l0w_layer_norm<RIFT_LN_FOLD != 0>(x, xn, pb + L0W_PB_LN2G, pb + L0W_PB_LN2B, l4);
       {
         f32x4 acc2[5][2];
 #pragma unroll

@@ -57,9 +57,9 @@ __global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, f
     if (f < 2 * L1W_BLK_FRAGS) {
       const int b = f / L1W_BLK_FRAGS, g = f % L1W_BLK_FRAGS;
       const NatL1WSrc::Blk& k = s.blk[b];
-      if (g < 24) { const int nt = g >> 1, ks = g & 1; v = k.wqkv[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)] * (nt < 4 ? L0W_QSCALE : 1.0f); }
+      if (g < 24) { const int nt = g >> 1, ks = g & 1, ch = l0w_chan(l4, j, 2 * ks); v = k.wqkv[(nt * 16 + l15) * 64 + ch] * (nt < 4 ? L0W_QSCALE : 1.0f) * (RIFT_LN_FOLD ? k.ln1_g[ch] : 1.0f); }
       else if (g < 32) { const int nt = (g - 24) >> 1, ks = (g - 24) & 1; v = k.wproj[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)]; }
-      else if (g < 56) { const int nt = (g - 32) >> 1, ks = (g - 32) & 1; v = k.w1[(nt * 16 + l15) * 64 + l0w_chan(l4, j, 2 * ks)]; }
+      else if (g < 56) { const int nt = (g - 32) >> 1, ks = (g - 32) & 1, ch = l0w_chan(l4, j, 2 * ks); v = k.w1[(nt * 16 + l15) * 64 + ch] * (RIFT_LN_FOLD ? k.ln2_g[ch] : 1.0f); }
       else { const int ks = (g - 56) >> 2, nt = (g - 56) & 3; v = k.w2[(nt * 16 + l15) * 192 + l0w_chan(l4, j, 2 * ks)]; hid = true; }
     } else {
       const int g = f - 2 * L1W_BLK_FRAGS, nt = g & 7, ks = (g >> 3) & 1, tap = g >> 4;
@@ -74,12 +74,19 @@ __global__ void pack_l1w_kernel(NatL1WSrc s, unsigned short* __restrict__ img, f
       const NatL1WSrc::Blk& k = s.blk[b];
       if (o < 64) v = k.ln1_g[o];
       else if (o < 128) v = k.ln1_b[o - 64];
-      else if (o < 320) v = k.bqkv[o - 128] * (o - 128 < 64 ? L0W_QSCALE : 1.0f);
+      else if (o < 320) {             // (opfmt.h: RIFT_LN_FOLD -- beta through the weights into the bias)
+        v = k.bqkv[o - 128];
+        if (RIFT_LN_FOLD) for (int ch = 0; ch < 64; ++ch) v += k.wqkv[(o - 128) * 64 + ch] * k.ln1_b[ch];
+        v *= (o - 128 < 64 ? L0W_QSCALE : 1.0f);
+      }
       else if (o < 352) v = (o - 320 < 20) ? k.rpb[o - 320] : 0.f;
       else if (o < 416) v = k.bproj[o - 352];
       else if (o < 480) v = k.ln2_g[o - 416];
       else if (o < 544) v = k.ln2_b[o - 480];
-      else if (o < 736) v = k.b1[o - 544];
+      else if (o < 736) {
+        v = k.b1[o - 544];
+        if (RIFT_LN_FOLD) for (int ch = 0; ch < 64; ++ch) v += k.w1[(o - 544) * 64 + ch] * k.ln2_b[ch];
+      }
       else v = k.b2[o - 736];
     } else if (e < L1W_P_DS) v = (e - L1W_P_FN < 64) ? s.fn_g[e - L1W_P_FN] : s.fn_b[e - L1W_P_FN - 64];
     else if (e < L1W_P_DS + 256) v = (e - L1W_P_DS < 128) ? s.ds_g[e - L1W_P_DS] : s.ds_b[e - L1W_P_DS - 128];
@@ -109,7 +116,21 @@ void l1w_pack(const NatL1WSrc& src, unsigned short* img, float* par, hipStream_t
 void l1w_launch(const NatL1WP& p, int grid, hipStream_t stream);
 
 #ifdef RIFT_NAT_L01_IMPL      // the kernels live in nat_l01w.hip
+template <bool FOLDED = false>      // (nat_l0w.h: l0w_layer_norm)
 __device__ __forceinline__ void l1w_layer_norm(const f32x4 (&x)[3][4], h16x8 (&xn)[3][2], const float* g, const float* b, int l4) {
+  if (FOLDED) {
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      const f32x4 s4 = (x[mt][0] + x[mt][1]) + (x[mt][2] + x[mt][3]);
+      const f32x4 q4 = (x[mt][0] * x[mt][0] + x[mt][1] * x[mt][1]) + (x[mt][2] * x[mt][2] + x[mt][3] * x[mt][3]);
+      const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 64.0f);
+      const float ex2 = rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 64.0f);
+      const float r = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + 1e-5f), c = -mean * r;
+      xn[mt][0] = l0w_pack8(x[mt][0] * r + c, x[mt][1] * r + c);
+      xn[mt][1] = l0w_pack8(x[mt][2] * r + c, x[mt][3] * r + c);
+    }
+    return;
+  }
   float4 gg[4], bb[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) { gg[nt] = *reinterpret_cast<const float4*>(g + nt * 16 + l4 * 4); bb[nt] = *reinterpret_cast<const float4*>(b + nt * 16 + l4 * 4); }
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
       const float* pb = par + L1W_P_BLK(bi);
       h16x8 xn[3][2];
       // ================= attention half =================
-      l1w_layer_norm(x, xn, pb + L1W_PB_LN1G, pb + L1W_PB_LN1B, l4);
+      l1w_layer_norm<RIFT_LN_FOLD != 0>(x, xn, pb + L1W_PB_LN1G, pb + L1W_PB_LN1B, l4);
       float dps = 1.f;
       if (p.droppath[bi] > 0.f) dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
       if (p.droppath[bi] > 0.f) ds_sample(p.ds, RIFT_DS_NAT(1, bi, 0), seq_ok ? seq : -1, dps);
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
         for (int mt = 0; mt < 3; ++mt) x[mt][nt] += (f32x4){b4.x, b4.y, b4.z, b4.w} * dps;
       }
       // ================= MLP half: fc1 (64 -> 192) -> GELU -> fc2 (192 -> 64), 32 hidden channels (one fc2 k-step) at a time =================
-      l1w_layer_norm(x, xn, pb + L1W_PB_LN2G, pb + L1W_PB_LN2B, l4);
+      l1w_layer_norm<RIFT_LN_FOLD != 0>(x, xn, pb + L1W_PB_LN2G, pb + L1W_PB_LN2B, l4);
       {
         f32x4 acc2[3][4];
 #pragma unroll

@@ -17,11 +17,11 @@ __global__ void pack_l2w_kernel(NatL2WSrc s, unsigned short* __restrict__ img, f
     const NatL2WSrc::Blk& k = s.blk[bi];
     float v;
     const bool hid = g >= 4 && ((g - 4) & 1);      // fc2 fragments: hidden-layer operand words (common.h: f2h_hid)
-    if (g < 3) v = k.wqkv[(g * 128 + o) * 128 + ch] * (g == 0 ? SC : 1.0f);
+    if (g < 3) v = k.wqkv[(g * 128 + o) * 128 + ch] * (g == 0 ? SC : 1.0f) * (RIFT_LN_FOLD ? k.ln1_g[ch] : 1.0f);
     else if (g == 3) v = k.wproj[o * 128 + ch];
     else {
       const int c = (g - 4) >> 1;
-      v = ((g - 4) & 1) ? k.w2[o * 384 + c * 128 + ch] : k.w1[(c * 128 + o) * 128 + ch];
+      v = ((g - 4) & 1) ? k.w2[o * 384 + c * 128 + ch] : k.w1[(c * 128 + o) * 128 + ch] * (RIFT_LN_FOLD ? k.ln2_g[ch] : 1.0f);
     }
     img[e] = hid ? f2h_hid(v) : f2h(v);
   }
@@ -32,12 +32,19 @@ __global__ void pack_l2w_kernel(NatL2WSrc s, unsigned short* __restrict__ img, f
       const NatL2WSrc::Blk& k = s.blk[bi];
       if (o < 128) v = k.ln1_g[o];
       else if (o < 256) v = k.ln1_b[o - 128];
-      else if (o < 640) v = k.bqkv[o - 256] * (o - 256 < 128 ? SC : 1.0f);
+      else if (o < 640) {             // (opfmt.h: RIFT_LN_FOLD -- beta through the weights into the bias)
+        v = k.bqkv[o - 256];
+        if (RIFT_LN_FOLD) for (int ch = 0; ch < 128; ++ch) v += k.wqkv[(o - 256) * 128 + ch] * k.ln1_b[ch];
+        v *= (o - 256 < 128 ? SC : 1.0f);
+      }
       else if (o < 768) v = (o - 640 < 72) ? k.rpb[o - 640] * 1.4426950408889634f : 0.f;
       else if (o < 896) v = k.bproj[o - 768];
       else if (o < 1024) v = k.ln2_g[o - 896];
       else if (o < 1152) v = k.ln2_b[o - 1024];
-      else if (o < 1536) v = k.b1[o - 1152];
+      else if (o < 1536) {
+        v = k.b1[o - 1152];
+        if (RIFT_LN_FOLD) for (int ch = 0; ch < 128; ++ch) v += k.w1[(o - 1152) * 128 + ch] * k.ln2_b[ch];
+      }
       else v = k.b2[o - 1536];
     } else if (e < L2W_P_FN + 256) v = (e - L2W_P_FN < 128) ? s.fn_g[e - L2W_P_FN] : s.fn_b[e - L2W_P_FN - 128];
     par[e] = v;
@@ -94,6 +101,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
     s4 += (res[4] + res[5]) + (res[6] + res[7]);
     const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
+    if (RIFT_LN_FOLD && true) {     // (opfmt.h: gamma / beta live in the consuming GEMM's weights and bias; one-pass statistics)
+      f32x4 q4 = res[0] * res[0];
+#pragma unroll
+      for (int nt = 1; nt < 8; ++nt) q4 += res[nt] * res[nt];
+      const float ex2 = rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f);
+      const float r = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + 1e-5f), c = -mean * r;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xb[ks] = l0w_pack8(res[2 * ks] * r + c, res[2 * ks + 1] * r + c);
+      return;
+    }
     f32x4 d[8];
     f32x4 q4 = Z;
 #pragma unroll

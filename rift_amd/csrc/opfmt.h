@@ -57,3 +57,17 @@
 #else
 #define RIFT_ENC_COMPACT 0
 #endif
+
+// ---- LayerNorm in front of a linear layer: affine part folded into that layer, one-pass statistics (round 5) ---------------------------
+// Every LayerNorm of the pre-norm blocks (NAT levels, scene encoder, planning decoder) feeds linear layers only, and its gamma / beta are
+// frozen (only pi_head trains): W (g * n + b) + c = (W diag g) n + (W b + c), so the packers fold gamma into the weight image and beta into
+// the bias, and the kernel computes n = x * r - mean * r with r = rsqrt(E[x^2] - mean^2 + eps) -- both sums in one pass over the row, one
+// packed FMA per two elements behind them: ~3.5 issue slots per element where the two-pass form with its affine part took ~5.5, and the
+// two cross-lane reductions no longer wait for each other.  E[x^2] - mean^2 in fp32 loses log2(1 + mean^2 / var) of 24 bits -- nothing
+// against the 8 / 11 bits the result is rounded to -- and is clamped at 0.  bf16 build only (the fp16 build keeps the arithmetic of
+// rounds 2 - 4); RIFT_LN_TWO_PASS (diagnostic define) restores it for bf16 as well.
+#if !RIFT_OP_F16 && !defined(RIFT_LN_TWO_PASS)
+#define RIFT_LN_FOLD 1
+#else
+#define RIFT_LN_FOLD 0
+#endif
