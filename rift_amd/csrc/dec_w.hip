@@ -84,6 +84,11 @@ __device__ __forceinline__ uint32_t decw_step(uint32_t x, uint32_t c) {
   return (x & 0xffffffu) * 214013u + c;          // both factors below 2^24: hipcc selects v_mad_u32_u24 and drops the mask (the ISA test of tools/checks counts them)
 }
 typedef short decw_s16x2 __attribute__((ext_vector_type(2)));
+#if RIFT_ATTN_K16
+typedef h16x4 DecwVf;            // V^T of a 16-key tile: a K = 16 operand (opfmt.h: RIFT_ATTN_K16)
+#else
+typedef h16x8 DecwVf;
+#endif
 // a word of two uniforms -> 0xffff where the half is KEPT (tm1 = the pair (tau - 1, tau - 1))
 __device__ __forceinline__ uint32_t decw_keep2(uint32_t w, uint32_t tm1) {
   const decw_s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(decw_s16x2, tm1), __builtin_bit_cast(decw_s16x2, w));
@@ -256,12 +261,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // the group barrier, read behind an acquire fence.  WORKGROUP scope: writer and reader waves sit on one CU and share its write-through
   // vector L1, so the fences are waits, not cache maintenance (agent scope writes back / invalidates the XCD's whole L2: measured 40-60 us
   // per hand-over)
-  auto read_xs = [&](f32x4 (&res)[8], int row, bool ok) {
+  // (a lane row without a query -- reference-line slot >= R, mode slot >= 12 -- reads row 0: `row` is 0 there.  Its keys are masked, its V
+  // row meets P = 0 and is finite, its results are never written: selecting zeros instead cost a divergent branch per hand-over)
+  auto read_xs = [&](f32x4 (&res)[8], int row, bool) {
     const float* src = DENSE ? p.Q + (qrow0 + row) * 128 + l4 * 4 : xs + row * XS + l4 * 4;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
       const float4 v = *reinterpret_cast<const float4*>(src + nt * 16);
-      res[nt] = ok ? (f32x4){v.x, v.y, v.z, v.w} : Z;
+      res[nt] = (f32x4){v.x, v.y, v.z, v.w};
     }
   };
   auto write_xs = [&](const f32x4 (&res)[8], int row, bool ok) {
@@ -315,13 +322,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int h = 0; h < 4; ++h) out[h] = l0w_pack8(acc[2 * h], acc[2 * h + 1]);
   };
   // V of the tile in the plain operand order (A = activations): lane = 4 consecutive KEYS (rows 4*l4..) of dim nt*16 + l15 = the V^T operand
-  auto gemm_v = [&](int slot, const h16x8 (&xb)[4], h16x8 (&vf)[8], const float* bias) {
+  auto gemm_v = [&](int slot, const h16x8 (&xb)[4], DecwVf (&vf)[8], const float* bias) {
     f32x4 acc[8];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) { const float bv = bias[nt * 16 + l15]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
     decw_gemm<true>((uint32_t)(uintptr_t)ring + (uint32_t)slot * 32768u + voff, xb, acc);
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_h4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]), make_uint2(0u, 0u));   // k slots 4..7 unused
+    for (int nt = 0; nt < 8; ++nt) {
+#if RIFT_ATTN_K16
+      vf[nt] = __builtin_bit_cast(h16x4, pack_h4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+#else
+      vf[nt] = l0w_from_u2(pack_h4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]), make_uint2(0u, 0u));   // k slots 4..7 unused
+#endif
+    }
   };
   // one step of stream i: a word of two 16-bit uniforms
   auto draw2 = [&](int i) -> uint32_t {
@@ -347,7 +360,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   // 16 x 16 self-attention of the tile, per head, entirely in registers: S^T = K Q^T (lane: 4 keys of query l15), O^T = V^T P^T.
   // `mask4`: 0 / -inf of this lane's four keys, entering as the accumulator of the score MFMA; scores are in log2 units (q carries log2 e).
-  auto self_attention = [&](const f32x4 mask4, const h16x8 (&qf)[4], const h16x8 (&kf)[4], const h16x8 (&vf)[8], h16x8 (&ao)[4]) {
+  auto self_attention = [&](const f32x4 mask4, const h16x8 (&qf)[4], const h16x8 (&kf)[4], const DecwVf (&vf)[8], h16x8 (&ao)[4]) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const f32x4 s = mfma_h(kf[h], qf[h], mask4, 0, 0, 0);
@@ -356,9 +369,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float lsum = rows_sum((ev[0] + ev[1]) + (ev[2] + ev[3]));
       uint2 pw = pack_h4(ev[0], ev[1], ev[2], ev[3]);
       if (DROP) { pw.x &= keep2(2 * (h & 1)); pw.y &= keep2(2 * (h & 1) + 1); }      // dropped weights are zero words; 1/(1-p) rides on 1/sum
+#if RIFT_ATTN_K16
+      const h16x4 pf = __builtin_bit_cast(h16x4, pw);
+      const f32x4 o0 = mfma_h16(vf[2 * h], pf, Z);
+      const f32x4 o1 = mfma_h16(vf[2 * h + 1], pf, Z);
+#else
       const h16x8 pf = l0w_from_u2(pw, make_uint2(0u, 0u));
       const f32x4 o0 = mfma_h(vf[2 * h], pf, Z, 0, 0, 0);
       const f32x4 o1 = mfma_h(vf[2 * h + 1], pf, Z, 0, 0, 0);
+#endif
       const float inv = __builtin_amdgcn_rcpf(lsum) * (DROP ? dpk : 1.0f);
       ao[h] = l0w_pack8(o0 * inv, o1 * inv);
     }
@@ -475,7 +494,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (actA) {
         f32x4 res[8], acc[8];
         h16x8 xb[4], qf[4], kf[4], ao[4];
-        h16x8 vf[8];
+        DecwVf vf[8];
         bnd(li, pa + 0);                                        // ---- r2r q
         if (ra == 0) acquire();
         read_xs(res, a_row, a_ok);
@@ -520,7 +539,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (actB) {
         f32x4 res[8], acc[8];
         h16x8 xb[4], qf[4], kf[4], ao[4];
-        h16x8 vf[8];
+        DecwVf vf[8];
         bnd(li, pb + 0);                                        // ---- m2m q (+ m_pos)
         if (rb == 0) acquire();
         read_xs(res, b_row, b_ok);

@@ -163,7 +163,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int bi = 0; bi < 2; ++bi) {
       const float* pb = par + L2W_P_BLK(bi);
       f32x4 acc[8];
-      h16x8 xb[4], qf[4], kp[4], ao[4], vf[8];
+      h16x8 xb[4], qf[4], kp[4], ao[4];
+#if RIFT_ATTN_K16
+      h16x4 vf[8];
+#else
+      h16x8 vf[8];
+#endif
       float dps = 1.f, dp2 = 1.f;
       if (p.droppath[bi] > 0.f) {
         dps = (uniform01(p.seed, p.stream + 2 * bi, (uint32_t)seq) < p.droppath[bi]) ? 0.f : 1.0f / (1.0f - p.droppath[bi]);
@@ -189,7 +194,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int nt = 0; nt < 8; ++nt) { const float bv = pb[L2W_PB_BQKV + 256 + nt * 16 + l15]; av[nt] = (f32x4){bv, bv, bv, bv}; }
         boundary(s); decw_gemm<true>((uint32_t)(uintptr_t)ring + slot_off(s) + voff, xb, av); ++s;
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) vf[nt] = l0w_from_u2(pack_h4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]), make_uint2(0u, 0u));
+        for (int nt = 0; nt < 8; ++nt) {
+#if RIFT_ATTN_K16
+          vf[nt] = __builtin_bit_cast(h16x4, pack_h4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]));
+#else
+          vf[nt] = l0w_from_u2(pack_h4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]), make_uint2(0u, 0u));
+#endif
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -200,15 +211,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           f32x4 mb;
 #pragma unroll
           for (int i = 0; i < 4; ++i) mb[i] = ridx[i] >= 0 ? pb[L2W_PB_RPB + h * 9 + ridx[i]] : -INFINITY;
+#if RIFT_ATTN_K16
+          // head h's 16 dims are one half of the projection's fragment: a K = 16 operand as it is
+          const f32x4 sc = mfma_h16(u == 0 ? h16x4_lo(kp[j]) : h16x4_hi(kp[j]), u == 0 ? h16x4_lo(qf[j]) : h16x4_hi(qf[j]), mb);
+#else
           // head h's 16 dims are one half of the k-step: the other half of the K operand is zero
           h16x8 kh = kp[j];
           if (u == 0) { kh[4] = 0; kh[5] = 0; kh[6] = 0; kh[7] = 0; } else { kh[0] = 0; kh[1] = 0; kh[2] = 0; kh[3] = 0; }
           const f32x4 sc = mfma_h(kh, qf[j], mb, 0, 0, 0);
+#endif
           const float m = rows_max(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
           const f32x4 ev = {__builtin_amdgcn_exp2f(sc[0] - m), __builtin_amdgcn_exp2f(sc[1] - m), __builtin_amdgcn_exp2f(sc[2] - m), __builtin_amdgcn_exp2f(sc[3] - m)};
           const float inv = __builtin_amdgcn_rcpf(rows_sum((ev[0] + ev[1]) + (ev[2] + ev[3])));
+#if RIFT_ATTN_K16
+          o[u] = mfma_h16(vf[h], __builtin_bit_cast(h16x4, pack_h4(ev[0], ev[1], ev[2], ev[3])), Z) * inv;
+#else
           const h16x8 pf = l0w_from_u2(pack_h4(ev[0], ev[1], ev[2], ev[3]), make_uint2(0u, 0u));
           o[u] = mfma_h(vf[h], pf, Z, 0, 0, 0) * inv;
+#endif
         }
         ao[j] = l0w_pack8(o[0], o[1]);
       }

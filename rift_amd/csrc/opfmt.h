@@ -71,3 +71,13 @@
 #else
 #define RIFT_LN_FOLD 0
 #endif
+
+// ---- 16-key / 16-dim contractions of the register-resident attentions as K = 16 MFMAs (round 5; nat_l2w.hip, dec_w.hip) -----------------
+// Level 2's heads have 16 dims and its tiles (like the decoder's self-attention tiles) 16 keys: as operands of the K = 32 MFMA they were
+// half zeros -- two v_mov per fragment, a copy with a zeroed half per head, and twice the registers (V^T: 32 -> 16).  The K = 16 form
+// (common.h: mfma_h16) takes the projection's C/D words as they are.  bf16 build only; RIFT_ATTN_K32 (diagnostic define) restores the padding.
+#if !RIFT_OP_F16 && !defined(RIFT_ATTN_K32)
+#define RIFT_ATTN_K16 1
+#else
+#define RIFT_ATTN_K16 0
+#endif
