@@ -36,6 +36,15 @@ def main():
         return time.perf_counter() - t0, t_issue
 
     # what the driver's run sees: W = 5 warm-up steps on a fresh trainer, then ONE 20-step region -- against the same region repeated
+    # (RIFT_FD_SPIN_MS=<ms>: that many milliseconds of chip-filling GEMMs first -- separates a clock / power-state ramp of the device
+    # from a warm-up of the trainer: the ramp would be gone, the trainer's would not)
+    spin_ms = float(os.environ.get("RIFT_FD_SPIN_MS", "0"))
+    if spin_ms > 0:
+        a = torch.randn(8192, 8192, device=dev, dtype=torch.float16); bm = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
+        while (time.perf_counter() - t0) * 1e3 < spin_ms:
+            (a @ bm); torch.cuda.synchronize(); n += 1
+        print(f"{n} 8192^3 fp16 GEMMs in {(time.perf_counter() - t0) * 1e3:.1f} ms ahead of the warm-up steps")
     for i in range(5):
         step(i)
     first = [region(20)[0] for _ in range(6)]
