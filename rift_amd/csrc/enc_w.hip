@@ -21,13 +21,14 @@ __global__ void pack_encw_kernel(EncWSrc s, unsigned short* __restrict__ img, fl
     const EncWSrc::L& L = s.l[li];
     float v;
     const bool hid = g >= 4 && ((g - 4) & 1);                       // fc2 fragments: hidden-layer operand words (common.h: f2h_hid)
-    if (g == 0) v = L.w_in[(128 + o) * 128 + ch];                  // k
-    else if (g == 1) v = L.w_in[(256 + o) * 128 + ch];             // v
-    else if (g == 2) v = L.w_in[o * 128 + ch] * SC;                // q
+    const float g1 = RIFT_LN_FOLD ? L.ln1_g[ch] : 1.0f, g2 = RIFT_LN_FOLD ? L.ln2_g[ch] : 1.0f;     // (opfmt.h: gamma of the norm in front folded into the weights)
+    if (g == 0) v = L.w_in[(128 + o) * 128 + ch] * g1;             // k
+    else if (g == 1) v = L.w_in[(256 + o) * 128 + ch] * g1;        // v
+    else if (g == 2) v = L.w_in[o * 128 + ch] * SC * g1;           // q
     else if (g == 3) v = L.wo[o * 128 + ch];
     else {
       const int c = (g - 4) >> 1;
-      v = ((g - 4) & 1) ? L.w2[o * 512 + c * 128 + ch] : L.w1[(c * 128 + o) * 128 + ch];
+      v = ((g - 4) & 1) ? L.w2[o * 512 + c * 128 + ch] : L.w1[(c * 128 + o) * 128 + ch] * g2;
     }
     img[e] = hid ? f2h_hid(v) : f2h(v);
   }
@@ -36,15 +37,17 @@ __global__ void pack_encw_kernel(EncWSrc s, unsigned short* __restrict__ img, fl
     if (e < ENCW_P_FN) {
       const int li = e / ENCW_P_LAYER, o = e % ENCW_P_LAYER;
       const EncWSrc::L& L = s.l[li];
+      // (RIFT_LN_FOLD) beta of the norm in front through the rows of W into the bias: b + W beta
+      auto wb = [&](const float* Wm, int row, const float* beta) { float a = 0.f; if (RIFT_LN_FOLD) for (int k = 0; k < 128; ++k) a += Wm[(size_t)row * 128 + k] * beta[k]; return a; };
       if (o < 128) v = L.ln1_g[o];
       else if (o < 256) v = L.ln1_b[o - 128];
-      else if (o < 384) v = L.b_in[o - 256] * SC;
-      else if (o < 512) v = L.b_in[128 + o - 384];
-      else if (o < 640) v = L.b_in[256 + o - 512];
+      else if (o < 384) v = (L.b_in[o - 256] + wb(L.w_in, o - 256, L.ln1_b)) * SC;
+      else if (o < 512) v = L.b_in[128 + o - 384] + wb(L.w_in, 128 + o - 384, L.ln1_b);
+      else if (o < 640) v = L.b_in[256 + o - 512] + wb(L.w_in, 256 + o - 512, L.ln1_b);
       else if (o < 768) v = L.bo[o - 640];
       else if (o < 896) v = L.ln2_g[o - 768];
       else if (o < 1024) v = L.ln2_b[o - 896];
-      else if (o < 1536) v = L.b1[o - 1024];
+      else if (o < 1536) v = L.b1[o - 1024] + wb(L.w1, o - 1024, L.ln2_b);
       else v = L.b2[o - 1536];
     } else if (e < ENCW_P_BKV) v = (e - ENCW_P_FN < 128) ? s.fn_g[e - ENCW_P_FN] : s.fn_b[e - ENCW_P_FN - 128];
     else { const int q = e - ENCW_P_BKV; v = s.dkv_b[q >> 8][128 + (q & 255)]; }
@@ -111,6 +114,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 s4 = (res[0] + res[1]) + (res[2] + res[3]);
     s4 += (res[4] + res[5]) + (res[6] + res[7]);
     const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 128.0f);
+    if (RIFT_LN_FOLD && !out) {     // (opfmt.h: gamma / beta live in the consuming GEMM's weights and bias; one-pass statistics.  The final norm keeps its affine part)
+      f32x4 q4 = res[0] * res[0];
+#pragma unroll
+      for (int nt = 1; nt < 8; ++nt) q4 += res[nt] * res[nt];
+      const float ex2 = rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f);
+      const float r = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + 1e-5f), c = -mean * r;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xb[ks] = l0w_pack8(res[2 * ks] * r + c, res[2 * ks + 1] * r + c);
+      return;
+    }
     f32x4 d[8];
     f32x4 q4 = Z;
 #pragma unroll
