@@ -51,6 +51,11 @@ def main():
         step(i)
     first = [region(20)[0] for _ in range(6)]
     print("fresh trainer, 5 warm-up steps, then six consecutive 20-step regions (ms/step): " + " ".join(f"{t / 20 * 1e3:.4f}" for t in first))
+    # is the slow first region the TRAINER's (gone for good) or the idle DEVICE's (back after every pause, e.g. between two updates of train_cbv)?
+    for pause in (0.05, 0.5, 2.0):
+        time.sleep(pause)
+        again = [region(20)[0] for _ in range(4)]
+        print(f"after {pause:.2f} s of idleness, four 20-step regions (ms/step): " + " ".join(f"{t / 20 * 1e3:.4f}" for t in again))
     for i in range(30):
         step(i)
     rows = []
