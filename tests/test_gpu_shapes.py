@@ -257,3 +257,36 @@ def test_two_stream_forward_equals_the_serial_forward(monkeypatch, train):
         eng.close()
     assert torch.isfinite(outs["1"][0][outs["1"][0] > -1e5]).all()
     assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_eight_key_tile_decoder_matches_the_dense_variant(monkeypatch, mode):
+    """Batches with R <= 8 reference lines and 96 < N <= 128 token slots (what train_cbv collates: 49 agents + 60 polygons = 109) run the standard
+    decoder kernel with eight key tiles gathered out of the dense K | V^T image (dec_w.hip: dec_w_kernel<., false, 8>); RIFT_DEC_DBG=32 sends
+    them to the dense-traffic variant instead, as until round 5 (tools/shape_step.py carla shows the switch in the decoder's time: 119 against
+    161 us).  Same rounding points, same key order, an exact residual hand-over either way (LDS here, global memory there): the eval outputs are
+    BIT-IDENTICAL (measured on MI355X in both operand formats)."""
+    from rift_amd import _ffi as ffi, synthetic as syn
+    from tests import helpers as H
+    sd = H.weights()
+    scenes = [syn.make_scene(900 + i, num_agents=49, num_polygons=60, r_min=1, r_max=6) for i in range(5)]
+    data = syn.collate_scenes(scenes)["cur_pluto_feature_torch"]
+    outs = []
+    for dbg in (None, "32"):
+        if dbg is None:
+            monkeypatch.delenv("RIFT_DEC_DBG", raising=False)
+        else:
+            monkeypatch.setenv("RIFT_DEC_DBG", dbg)
+        eng = ffi.Engine("cuda:0", operands="fp16" if mode == "fp16" else "bf16")
+        eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+        out = eng.forward(data, train=False, need_traj=True, bn_update=False)
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().clone() for k, v in out.items() if torch.is_tensor(v)})
+        outs[-1]["q_final"] = eng.tap("q_final").cpu().clone()
+        eng.close()
+    rv = data["reference_line"]["valid_mask"].any(-1).cpu()
+    dq = float((outs[0]["q_final"] - outs[1]["q_final"]).abs().max())
+    dp = float((outs[0]["probability"] - outs[1]["probability"])[rv].abs().max())
+    print(f"{mode}: eight-key-tile kernel against the dense variant: max |dq_final| {dq:.2e}, max |dlogit| {dp:.2e}")
+    assert dq == 0.0 and dp == 0.0
