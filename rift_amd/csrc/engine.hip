@@ -855,7 +855,7 @@ void heads3_fused(Fwd& f, const float* X, int ldx, int rows, int g_per, int g_st
     q.lng[i] = fptr(c, names[i] + ".mlp.1.weight"); q.lnb[i] = fptr(c, names[i] + ".mlp.1.bias");
   }
   c->prof_flops = 3.0 * 2.0 * rows * (128.0 * 256 + 256.0 * 160);
-  launch(c, "heads3_fused_kernel", heads3_fused_kernel, dim3(3 * cdiv(rows, HD_ROWS)), dim3(512), (size_t)HD_LDS, q);
+  launch(c, "heads3_fused_kernel", heads3_fused_kernel, dim3(24 * cdiv(cdiv(rows, HD_ROWS), 8)), dim3(512), (size_t)HD_LDS, q);      // (groups of 8 tiles x 3 heads: heads_fused.h)
 }
 
 void mlp_layer(Fwd& f, const float* X, int ldx, int rows, const std::string& p, float* out, int ldo, bool fp32) {

@@ -31,8 +31,13 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
   float* wpart = reinterpret_cast<float*>(hn + HD_ROWS * HD_HS);             // [8 waves][128 rows][2]: per-wave row sums (x, x^2)
   float* par = wpart + 8 * HD_ROWS * 2;                                      // per head: b1 256 | ln g 256 | ln b 256, then b2 160 x 3
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  // one (row tile, head) pair per workgroup: 144 + 126 row tiles alone would leave half of the 256 CUs idle
-  const int row0 = (blockIdx.x / 3) * HD_ROWS, h0 = blockIdx.x % 3;
+  // one (row tile, head) pair per workgroup: 144 + 126 row tiles alone would leave half of the 256 CUs idle.  The three heads of a tile write
+  // 8-byte pieces of the same 24-byte (step) records: their workgroups are numbered 8 apart, so that they run on ONE XCD (workgroups go to
+  // the XCDs round-robin) and its L2 merges the pieces into whole lines -- as neighbours (blockIdx % 3) they sat on three XCDs, every line
+  // left three L2s partially written and the launch moved 97 MB for a 31 MB output
+  const int grp = blockIdx.x / 24, rem = blockIdx.x % 24;
+  const int row0 = (grp * 8 + (rem & 7)) * HD_ROWS, h0 = rem >> 3;
+  if (row0 >= p.rows) return;
   PFrags<4, 2> W1;
   p_load_w<NW, 4, 2>(W1, p.w1[h0], 128, 0, wave, l15, l4);
   {
