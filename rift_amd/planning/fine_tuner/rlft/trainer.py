@@ -9,8 +9,10 @@ PyTorch-ROCm, as the reference's optimizer does (rift_trainer.py:279-362).
 """
 import contextlib
 import ctypes as C
+import itertools
 import math
 import os
+import sys
 from typing import Dict, List, Optional
 
 import torch
@@ -143,6 +145,34 @@ def _runs_beside(a: torch.cuda.Stream, b: torch.cuda.Stream, dev, spin_cycles: i
     return eb.elapsed_time(ea) > 0.5 * spin_ms          # b's kernel ended more than half a spin BEFORE the spin did
 
 
+_PROBE_BUF = {}
+
+
+def _dispatches_beside(a: torch.cuda.Stream, b: torch.cuda.Stream, dev) -> float:
+    """Does a launch on `b` get DISPATCHED while `a` is dispatching?  ONE chip-filling elementwise kernel on a (512 MB: its grid is being dispatched
+    for its whole duration, ~0.25 ms; several smaller kernels would not do -- the pipe takes b's packet between two of them: the first version
+    of this probe chose a slow set in 24 processes of 24), a tiny kernel on b right behind it; returns the fraction of a's kernel that was still
+    ahead when b's finished.  Measured on MI355X (tools/stream_sets.py, 8 hardware queues on 4 dispatch pipes): ~0.8 for queues on different pipes,
+    ~0.1 for two queues of ONE pipe (b's kernel waits until a's grids are through the pipe), ~0 for one queue -- and the update pipeline runs at
+    0.573 - 0.577 ms per 256-scene step when all six pairs of its four streams are of the first kind, at 0.60 - 0.73 ms otherwise.  The
+    one-block spin of `_runs_beside` cannot tell the first two apart (its grid is through the pipe at once)."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _PROBE_BUF:
+        _PROBE_BUF[key] = (torch.zeros(128 * 1024 * 1024, device=dev), torch.zeros(64, device=dev))
+    big, x = _PROBE_BUF[key]
+    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(a):
+        e0.record(a)
+        big.mul_(1.0)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        x.add_(1.0)
+        eb.record(b)
+    torch.cuda.synchronize(dev)
+    return eb.elapsed_time(ea) / max(e0.elapsed_time(ea), 1e-6)
+
+
 def _pipeline_streams(dev, main: torch.cuda.Stream, probe: bool = True):
     """(update, prefetch, side): three streams that run concurrently with the caller's stream and with each other, chosen by probe from a pool
     created here; one set per device for all trainers of the process.  HIP places streams on a few hardware queues in creation order, so
@@ -161,18 +191,42 @@ def _pipeline_streams(dev, main: torch.cuda.Stream, probe: bool = True):
     if prio:
         _STREAMS[key] = tuple(torch.cuda.Stream(device=dev, priority=int(x)) for x in prio.split(","))
         return _STREAMS[key]
-    if not probe or os.environ.get("RIFT_STREAM_PROBE", "1") != "1" or not hasattr(torch.cuda, "_sleep"):
+    if not probe or os.environ.get("RIFT_STREAM_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
         _STREAMS[key] = (_shared_stream(dev, "update"), _shared_stream(dev, "prefetch"), None)
         return _STREAMS[key]
     pool = [torch.cuda.Stream(device=dev) for _ in range(12)]
-    chosen = []
-    for s in pool:
-        if len(chosen) == 3:
-            break
-        if _runs_beside(main, s, dev) and _runs_beside(s, main, dev) and all(_runs_beside(c, s, dev) and _runs_beside(s, c, dev) for c in chosen):
-            chosen.append(s)
-    if len(chosen) < 3:                       # (fewer independent queues than the pipeline has streams: take what there is)
-        chosen += [s for s in pool if s not in chosen][:3 - len(chosen)]
+    # Round 5: the probe that decides is `_dispatches_beside` (dispatch PIPES, not just queues): the residual slow mode of the queue probe --
+    # 1 fresh process of 14 at 0.72 instead of 0.58 ms per step, and whole legs of earlier rounds' profile runs -- was two of the four streams
+    # on one pipe.  RIFT_STREAM_PROBE=queue restores the one-block probe.
+    if os.environ.get("RIFT_STREAM_PROBE", "1") == "queue":
+        ok = lambda a, b: _runs_beside(a, b, dev) and _runs_beside(b, a, dev)
+        chosen = []
+        for s in pool:
+            if len(chosen) == 3:
+                break
+            if ok(main, s) and all(ok(c, s) for c in chosen):
+                chosen.append(s)
+        if len(chosen) < 3:                       # (fewer independent queues than the pipeline has streams: take what there is)
+            chosen += [s for s in pool if s not in chosen][:3 - len(chosen)]
+    else:
+        # the whole matrix first (13 x 12 probes of ~0.3 ms; a throw-away pass ahead of it: the first launches of a process or after a pause
+        # measure its warm-up), then the triple whose worst pair -- either direction, the caller's stream included -- is best; ties go to the
+        # earliest streams.  (A greedy walk over the pool with probes on demand picked conflicting sets: its first probes of each stream were off.)
+        allst = [main] + pool
+        for b_ in pool:
+            _dispatches_beside(main, b_, dev)
+        m = [[1.0 if a_ is b_ else _dispatches_beside(a_, b_, dev) for b_ in allst] for a_ in allst]
+        pair = lambda i, j: min(m[i][j], m[j][i])
+        best, chosen = -1.0, list(pool[:3])
+        for i, j, k in itertools.combinations(range(1, len(allst)), 3):
+            v = min(pair(0, i), pair(0, j), pair(0, k), pair(i, j), pair(i, k), pair(j, k))
+            if v > best + 0.05:
+                best, chosen = v, [allst[i], allst[j], allst[k]]
+        if os.environ.get("RIFT_STREAM_DEBUG"):
+            print(f"[rift] pipeline streams: pool indices {[pool.index(c) for c in chosen]}, worst pair {best:.2f}", file=sys.stderr)
+            for r in m:
+                print("[rift]   " + " ".join(f"{v:5.2f}" for v in r), file=sys.stderr)
+    _PROBE_BUF.clear()                        # (the 512 MB probe buffer goes back to the allocator)
     _STREAMS[key] = tuple(chosen)
     _STREAMS[(key[0], "pool")] = pool         # (the unused ones stay alive: destroying them would hand their queues to the next stream created)
     return _STREAMS[key]
