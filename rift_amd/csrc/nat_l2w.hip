@@ -37,7 +37,10 @@ __global__ void pack_l2w_kernel(NatL2WSrc s, unsigned short* __restrict__ img, f
         if (RIFT_LN_FOLD) for (int ch = 0; ch < 128; ++ch) v += k.wqkv[(o - 256) * 128 + ch] * k.ln1_b[ch];
         v *= (o - 256 < 128 ? SC : 1.0f);
       }
-      else if (o < 768) v = (o - 640 < 72) ? k.rpb[o - 640] * 1.4426950408889634f : 0.f;
+      else if (o < 768) {             // [head 8][16]: rpb[h][0..8] x log2 e, then -inf (slot 9 = "a key of another agent": the lanes read it unconditionally)
+        const int h = (o - 640) >> 4, r = (o - 640) & 15;
+        v = r < 9 ? k.rpb[h * 9 + r] * 1.4426950408889634f : -INFINITY;
+      }
       else if (o < 896) v = k.bproj[o - 768];
       else if (o < 1024) v = k.ln2_g[o - 896];
       else if (o < 1152) v = k.ln2_b[o - 1024];
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int key = l4 * 4 + i, ka = key / L, kt = key - ka * L;
-      ridx[i] = (ka == qa) ? kt - qt + 4 : -1;
+      ridx[i] = (ka == qa) ? kt - qt + 4 : 9;           // slot 9 of a head's table row: -inf
     }
 #pragma unroll 1
     for (int bi = 0; bi < 2; ++bi) {
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const int h = 2 * j + u;
           f32x4 mb;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) mb[i] = ridx[i] >= 0 ? pb[L2W_PB_RPB + h * 9 + ridx[i]] : -INFINITY;
+          for (int i = 0; i < 4; ++i) mb[i] = pb[L2W_PB_RPB + h * 16 + ridx[i]];      // (a select here became four exec-masked loads per head)
 #if RIFT_ATTN_K16
           // head h's 16 dims are one half of the projection's fragment: a K = 16 operand as it is
           const f32x4 sc = mfma_h16(u == 0 ? h16x4_lo(kp[j]) : h16x4_hi(kp[j]), u == 0 ? h16x4_lo(qf[j]) : h16x4_hi(qf[j]), mb);
