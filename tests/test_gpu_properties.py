@@ -102,3 +102,24 @@ def test_all_invalid_agents_and_polygons_do_not_change_the_outputs(engine, fp32,
         assert torch.equal(pf > -1e5, valid)
         assert float((pf - pt)[valid].abs().max()) < (1e-4 if fp32 else 5e-2)
         assert float((tf - tt)[valid].abs().max()) < (2e-3 if fp32 else 0.5) * max(1.0, float(tt[valid].abs().max()))
+
+
+@pytest.mark.gpu
+def test_pipeline_streams_sit_on_different_dispatch_pipes():
+    """The update pipeline's three streams and the caller's stream must dispatch beside each other: two hardware queues of one dispatch pipe hand
+    out one grid at a time, and a trainer with such a pair ran the 256-scene step at 0.60 - 0.73 instead of 0.575 ms (1 fresh process in ~14
+    before round 5's probe; profiles/NOTES_r05.md).  `_dispatches_beside` = the fraction of a chip-filling kernel on a that is still ahead when a
+    tiny kernel on b finishes: ~0.8 on different pipes, ~0.1 on one pipe, ~0 on one queue."""
+    import itertools
+    import torch
+    from rift_amd.planning.fine_tuner.rlft import trainer as T
+    dev = torch.device("cuda", 0)
+    main = torch.cuda.current_stream(dev)
+    chosen = T._pipeline_streams(dev, main, probe=True)
+    assert len(chosen) == 3 and len({s.cuda_stream for s in chosen} | {main.cuda_stream}) == 4
+    for _ in range(3):
+        T._dispatches_beside(main, chosen[0], dev)                 # (warm-up: the first probes of a process are off)
+    worst = min(min(T._dispatches_beside(a, b, dev), T._dispatches_beside(b, a, dev)) for a, b in itertools.combinations([main] + list(chosen), 2))
+    T._PROBE_BUF.clear()
+    print(f"worst pair of the pipeline's four streams: {worst:.2f} of the chip-filling kernel still ahead")
+    assert worst > 0.5
