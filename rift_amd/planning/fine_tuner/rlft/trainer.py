@@ -343,7 +343,7 @@ class RLFTTrainer:
         self.loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)      # sum of training losses since pop_mean_loss()
         self.loss_n = 0
         if self.overlap_update:
-            self._probe = self.exchange is None and os.environ.get("RIFT_BENCH_FORCE_PG") != "1"
+            self._probe = (self.exchange is None and os.environ.get("RIFT_BENCH_FORCE_PG") != "1") or os.environ.get("RIFT_STREAM_PROBE_PG") == "1"
             upd, pre, side = _pipeline_streams(dev, torch.cuda.current_stream(dev), self._probe)
             self._side = upd
             if side is not None:
