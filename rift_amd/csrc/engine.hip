@@ -1594,6 +1594,18 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (flags & RIFT_F_DEFER_HEAD) { if (!c->dry) c->head[c->parity] = hs; }
   else TRY(head_impl(c, hs));
   // hidden_proj / ref_free_decoder on the ego token (pluto_model.py:173-180)
+  if (!f.fp32 && c->heads_fused && (out->hidden || (f.need_traj && out->ref_free_trajectory))) {      // one launch (heads_fused.h: ego_heads_kernel)
+    const PW &h0 = c->pw["hidden_proj.0"], &h2 = c->pw["hidden_proj.2"], &r0 = c->pw["ref_free_decoder.mlp.0"], &r3 = c->pw["ref_free_decoder.mlp.3"];
+    EgoHeadsP q; memset(&q, 0, sizeof(q));
+    q.X = ENC; q.ldx = N * 128; q.rows = bs;
+    q.wh0 = (const unsigned short*)h0.bf; q.wh2 = (const unsigned short*)h2.bf; q.wr0 = (const unsigned short*)r0.bf; q.wr3 = (const unsigned short*)r3.bf;
+    q.bh0 = h0.bias; q.bh2 = h2.bias; q.br0 = r0.bias; q.br3 = r3.bias;
+    q.lng = fptr(c, "ref_free_decoder.mlp.1.weight"); q.lnb = fptr(c, "ref_free_decoder.mlp.1.bias");
+    q.hidden = out->hidden; q.ref = (f.need_traj && out->ref_free_trajectory) ? out->ref_free_trajectory : nullptr;
+    c->prof_flops = 2.0 * bs * (2.0 * 128 * 128 + 128.0 * 256 + 256.0 * 320);
+    launch(c, "ego_heads_kernel", ego_heads_kernel, dim3(cdiv(bs, 16)), dim3(256), 0, q);
+    return RIFT_OK;
+  }
   if (out->hidden) {
     float* Th = A_alloc<float>(c, (size_t)bs * 128);
     GemmP g = mk(ENC, N * 128, bs, c->pw["hidden_proj.0"], Th, 128);

@@ -146,4 +146,110 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
   }
 }
 
+// ---- the two heads on the ego token (pluto_model.py:173-180), one launch ------------------------------------------------------------------------
+// hidden = hidden_proj(x) = Linear(128, 128) -> ReLU -> Linear(128, 128) and ref_free_trajectory = MLPLayer(128, 256, 320)(x) on the bs ego rows
+// of the encoder output.  As four gemm_rows launches these 75 MFLOP took 26 + 13 + 26 + 13 us of a queue of their own and 26 us of the
+// every-output step (0.637 -> 0.611 ms without them): latency, not work.  Here: 16 rows per workgroup of four waves, the same rounding points
+// as the layer-wise path (16-bit operands, fp32 accumulation, fp32 LayerNorm on the fp32 pre-activation, ReLU, 16-bit hidden operands).
+struct EgoHeadsP {
+  const float* X; int ldx; int rows;              // ego rows: X[r * ldx .. + 128]
+  const unsigned short *wh0, *wh2, *wr0, *wr3;    // fragment-major images: [128][128], [128][128], [256][128], [320][256]
+  const float *bh0, *bh2, *br0, *br3, *lng, *lnb;
+  float* hidden;                                  // (rows, 128) or null
+  float* ref;                                     // (rows, 320) or null
+};
+#define EH_XS 144
+#define EH_TS 272
+
+__global__ __launch_bounds__(256) void ego_heads_kernel(EgoHeadsP p) {
+  __shared__ __attribute__((aligned(16))) unsigned short xb[16 * EH_XS];       // x rows as operands
+  __shared__ __attribute__((aligned(16))) unsigned short h1[16 * EH_XS];       // relu(hidden_proj.0)
+  __shared__ __attribute__((aligned(16))) unsigned short t1[16 * EH_TS];       // relu(LN(ref mlp.0))
+  __shared__ float wpart[4][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  {
+    const int r = tid >> 4, c8 = (tid & 15) * 8, gr = min(row0 + r, p.rows - 1);
+    const float4 a = *reinterpret_cast<const float4*>(p.X + (size_t)gr * p.ldx + c8), b = *reinterpret_cast<const float4*>(p.X + (size_t)gr * p.ldx + c8 + 4);
+    *reinterpret_cast<uint2*>(xb + r * EH_XS + c8) = pack_h4(a.x, a.y, a.z, a.w);
+    *reinterpret_cast<uint2*>(xb + r * EH_XS + c8 + 4) = pack_h4(b.x, b.y, b.z, b.w);
+  }
+  __syncthreads();
+  const bool rok = row0 + l15 < p.rows;
+  const int li = l4 * 16 + l15;
+  // ---- first layers: hidden_proj.0 (n-tiles 2 wave, 2 wave + 1) and ref mlp.0 (n-tiles 4 wave .. + 3), K = 128
+  f32x4 ah[2], ar[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const float4 b = *reinterpret_cast<const float4*>(p.bh0 + (2 * wave + j) * 16 + l4 * 4); ah[j] = (f32x4){b.x, b.y, b.z, b.w}; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float4 b = *reinterpret_cast<const float4*>(p.br0 + (4 * wave + j) * 16 + l4 * 4); ar[j] = (f32x4){b.x, b.y, b.z, b.w}; }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const h16x8 a = *reinterpret_cast<const h16x8*>(xb + l15 * EH_XS + ks * 32 + l4 * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ah[j] = mfma_h(fm_load(p.wh0, 128, (2 * wave + j) * 16, ks * 32, li), a, ah[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ar[j] = mfma_h(fm_load(p.wr0, 128, (4 * wave + j) * 16, ks * 32, li), a, ar[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    *reinterpret_cast<uint2*>(h1 + l15 * EH_XS + (2 * wave + j) * 16 + l4 * 4) = pack_h4(fmaxf(ah[j][0], 0.f), fmaxf(ah[j][1], 0.f), fmaxf(ah[j][2], 0.f), fmaxf(ah[j][3], 0.f));
+  {   // LayerNorm statistics of the 256-wide pre-activation: this wave's 64 columns, then across the four waves
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sm += ar[j][r]; sq += ar[j][r] * ar[j][r]; }
+    sm = rows_sum(sm); sq = rows_sum(sq);
+    if (l4 == 0) { wpart[wave][l15][0] = sm; wpart[wave][l15][1] = sq; }
+  }
+  __syncthreads();
+  {
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sm += wpart[w][l15][0]; sq += wpart[w][l15][1]; }
+    const float mean = sm * (1.0f / 256.0f), rstd = rsqrtf(fmaxf(sq * (1.0f / 256.0f) - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = (4 * wave + j) * 16 + l4 * 4;
+      const float4 g = *reinterpret_cast<const float4*>(p.lng + col), e = *reinterpret_cast<const float4*>(p.lnb + col);
+      *reinterpret_cast<uint2*>(t1 + l15 * EH_TS + col) =
+          pack_h4(fmaxf((ar[j][0] - mean) * rstd * g.x + e.x, 0.f), fmaxf((ar[j][1] - mean) * rstd * g.y + e.y, 0.f),
+                  fmaxf((ar[j][2] - mean) * rstd * g.z + e.z, 0.f), fmaxf((ar[j][3] - mean) * rstd * g.w + e.w, 0.f));
+    }
+  }
+  __syncthreads();
+  // ---- second layers: hidden_proj.2 (K = 128 from h1, n-tiles 2 wave ..) and ref mlp.3 (K = 256 from t1, n-tiles 5 wave .. + 4 of 20)
+  if (p.hidden) {
+    f32x4 o[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const float4 b = *reinterpret_cast<const float4*>(p.bh2 + (2 * wave + j) * 16 + l4 * 4); o[j] = (f32x4){b.x, b.y, b.z, b.w}; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const h16x8 a = *reinterpret_cast<const h16x8*>(h1 + l15 * EH_XS + ks * 32 + l4 * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) o[j] = mfma_h(fm_load(p.wh2, 128, (2 * wave + j) * 16, ks * 32, li), a, o[j], 0, 0, 0);
+    }
+    if (rok)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<float4*>(p.hidden + (size_t)(row0 + l15) * 128 + (2 * wave + j) * 16 + l4 * 4) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+  }
+  if (p.ref) {
+    f32x4 o[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { const float4 b = *reinterpret_cast<const float4*>(p.br3 + (5 * wave + j) * 16 + l4 * 4); o[j] = (f32x4){b.x, b.y, b.z, b.w}; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const h16x8 a = *reinterpret_cast<const h16x8*>(t1 + l15 * EH_TS + ks * 32 + l4 * 8);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) o[j] = mfma_h(fm_load(p.wr3, 256, (5 * wave + j) * 16, ks * 32, li), a, o[j], 0, 0, 0);
+    }
+    if (rok)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        *reinterpret_cast<float4*>(p.ref + (size_t)(row0 + l15) * 320 + (5 * wave + j) * 16 + l4 * 4) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+  }
+}
+
 }  // namespace RIFT_NS
