@@ -316,7 +316,8 @@ class Engine:
         `tensor.to(device)` from pageable memory waits for everything the stream holds; a tick's evaluation chain makes ~15 such uploads
         per CBV, each between kernel launches, and that wait -- not the copies -- was a third of the tick (tools/tick_latency.py).  The
         arena advances by the call and wraps behind a stream synchronisation, so a staged tensor is valid until 8 MiB of later uploads:
-        it is for the inputs of the call at hand, not for keeping.  Large (> 2 MiB) and empty inputs take the ordinary path."""
+        it is for the inputs of the call at hand, not for keeping (a policy's `data` dict is invalid after its tick), and the arena is one per
+        engine: not for concurrent callers.  Large (> 2 MiB) and empty inputs take the ordinary path."""
         if torch.is_tensor(a):
             if a.is_cuda:
                 return _dev(a, dtype, self.device)
@@ -330,7 +331,8 @@ class Engine:
             self._stage_dev = torch.empty(self._STAGE_BYTES, dtype=torch.uint8, device=self.device)
         off = (self._stage_off + 255) & ~255
         if off + n > self._STAGE_BYTES:
-            torch.cuda.current_stream(self.device).synchronize()      # every consumer of the slots about to be rewritten is done
+            torch.cuda.synchronize(self.device)      # every consumer of the slots about to be rewritten is done -- on ANY stream (a staged batch may
+                                                     # have been handed to a hook that reads it elsewhere); once per 8 MiB of uploads
             off = 0
         self._stage_host.numpy()[off:off + n] = a.reshape(-1).view(np.uint8)
         d = self._stage_dev[off:off + n]
