@@ -695,6 +695,14 @@ def main():
             line["precisions"] = precisions
         if "roofline" in head:
             line["roofline"] = head["roofline"]
+        # the companions the review reads, as flat scalars inside `config` (the driver's record keeps `config` and `roofline` whole and drops
+        # other top-level keys): the reference-equivalent step (every output of PlanningModel.forward: pluto_model.py:173-199) and the
+        # steady state (200 steps in one region)
+        line["config"]["all_outputs_ms_per_step"] = head["all_outputs"]["ms_per_step"]
+        line["config"]["all_outputs_value"] = head["all_outputs"]["value"]
+        if "steady_state" in head:
+            line["config"]["steady_state_ms_per_step"] = head["steady_state"]["ms_per_step"]
+            line["config"]["steady_state_value"] = head["steady_state"]["value"]
         if not args.no_cpu_baseline:
             # (rank 0's host cores; the other ranks wait at the closing barrier.  A 256-scene CPU step whatever N is: the reference is single-device)
             line["cpu_baseline"] = cpu_baseline(scenes_cpu, sd_cpu, contract["batch"] if contract is not None else None)
@@ -714,6 +722,14 @@ def main():
                                                  "meets_north_star_1e-4": entry["meets_north_star_1e-4"]})
                 line["precision_contract"] = pc
                 line["headline_meets_north_star_1e-4"] = pc[args.precision]["meets_north_star_1e-4"]
+                # the fastest 16-bit mode whose four objectives all sit inside north_star's 1e-4 on this batch, with its own step time
+                clean = [(precisions[q]["ms_per_step"], q) for q in ("bf16", "fp16") if precisions is not None and q in precisions and pc.get(q, {}).get("meets_north_star_1e-4")]
+                if clean:
+                    ms, q = min(clean)
+                    line["config"]["contract_clean_dtype"] = q
+                    line["config"]["contract_clean_ms_per_step"] = ms
+                    line["config"]["contract_clean_value"] = precisions[q]["value"]
+                    line["config"]["contract_clean_max_loss_err"] = pc[q]["max_loss_err_vs_oracle"]
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

@@ -1117,7 +1117,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         q.droppath[0] = f.drop ? dpr[2] : 0.f; q.droppath[1] = f.drop ? dpr[3] : 0.f; q.seed = f.seed; q.stream = f.next_stream(); f.stream_id += 4;
         RIFT_SET_DS(q);
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C) + (rows / 2) * 2.0 * 3 * C * 2 * C;
-        { const int g1 = std::min(cdiv(cdiv(nA, 4), 8), c->nat_grid); launch_call(c, "nat_l1w_kernel", [&] { l1w_launch(q, g1, c->stream); }); }
+        { const int g1 = std::min(cdiv(cdiv(nA, 4), L1W_NWV), c->nat_grid); launch_call(c, "nat_l1w_kernel", [&] { l1w_launch(q, g1, c->stream); }); }
         continue;
       }
       {   // level 2: wave-private tiles of 3 agents, the two layers' weights streamed through LDS (nat_l2w.h)

@@ -26,7 +26,7 @@ void l1w_pack(const NatL1WSrc& src, unsigned short* img, float* par, hipStream_t
   hipLaunchKernelGGL(pack_l1w_kernel, dim3((L1W_NFRAG * 512 + 255) / 256), dim3(256), 0, stream, src, img, par);
 }
 void l1w_launch(const NatL1WP& p, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(nat_l1w_kernel, dim3(grid), dim3(512), (size_t)L1W_LDS, stream, p);
+  hipLaunchKernelGGL(nat_l1w_kernel, dim3(grid), dim3(64 * L1W_NWV), (size_t)L1W_LDS, stream, p);
 }
 
 }  // namespace RIFT_NS

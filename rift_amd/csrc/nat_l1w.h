@@ -39,7 +39,10 @@ namespace RIFT_NS {
 #define L1W_P_TBL 2048
 #define L1W_NPAR (2048 + 2 * 4 * 3 * 5 * 8)
 #define L1W_ST 72               // staging row stride (bf16): 144 B
-#define L1W_LDS (L1W_BLK_FRAGS * 1024 + L1W_NPAR * 4 + 8 * 40 * L1W_ST * 2)
+#ifndef L1W_NWV
+#define L1W_NWV 8                // waves per workgroup (one workgroup per CU: the LDS image); 12 = three per SIMD at <= 168 VGPRs
+#endif
+#define L1W_LDS (L1W_BLK_FRAGS * 1024 + L1W_NPAR * 4 + L1W_NWV * 40 * L1W_ST * 2)
 
 struct NatL1WSrc {
   struct Blk { const float *ln1_g, *ln1_b, *wqkv, *bqkv, *rpb, *wproj, *bproj, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2; } blk[2];
@@ -157,14 +160,14 @@ __device__ __forceinline__ void l1w_layer_norm(const f32x4 (&x)[3][4], h16x8 (&x
   }
 }
 
-__global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
+__global__ __launch_bounds__(64 * L1W_NWV) void nat_l1w_kernel(NatL1WP p) {
   constexpr int L = 10;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* wl = reinterpret_cast<unsigned short*>(smem_raw);            // [80][64][8] weight fragments of the current phase
   float* par = reinterpret_cast<float*>(wl + L1W_BLK_FRAGS * 512);
   unsigned short* stg = reinterpret_cast<unsigned short*>(par + L1W_NPAR);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  for (int i = tid; i < L1W_NPAR / 4; i += 512) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
+  for (int i = tid; i < L1W_NPAR / 4; i += 64 * L1W_NWV) reinterpret_cast<float4*>(par)[i] = reinterpret_cast<const float4*>(p.par)[i];
   unsigned short* st = stg + wave * 40 * L1W_ST;
   auto W = [&](int f) { return *reinterpret_cast<const h16x8*>(wl + ((size_t)f * 64 + lane) * 8); };
   // workgroup-wide swap of the weight image (all waves are between phases), by LDS-DMA in runs of four fragments (wp_stream.h): the
@@ -173,17 +176,17 @@ __global__ __launch_bounds__(512) void nat_l1w_kernel(NatL1WP p) {
   auto load_weights = [&](int frag0, int nfrag) {
     __syncthreads();
     decw_dma_share(reinterpret_cast<const unsigned char*>(p.img) + (size_t)frag0 * 1024, (uint32_t)lane * 16u, wl_lds, nfrag,
-                   __builtin_amdgcn_readfirstlane(wave), 8);
+                   __builtin_amdgcn_readfirstlane(wave), L1W_NWV);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
   const int a = l15 >> 2, s = l15 & 3;
   RIFT_SEQ_COUNT(p.cnt, p.nseq);
   const int ntiles = (sq_n + 3) >> 2;
-  const int ngroups = (ntiles + 7) >> 3;
+  const int ngroups = (ntiles + L1W_NWV - 1) / L1W_NWV;
 
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int tile = grp * 8 + wave;
+    const int tile = grp * L1W_NWV + wave;
     const int seq = tile * 4 + a;
     const bool seq_ok = RIFT_SEQ_LIVE(seq);
     f32x4 x[3][4];

@@ -426,6 +426,86 @@ def gen_other_vehicles():
     print("other vehicles ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", out["vertices"].shape, out["vertices"].dtype, out["config"])
 
 
+def gen_off_road():
+    """TrajEvaluator.get_off_road_matrix (traj_evaluator.py:277-317) with its callees global_to_pixel (:319-322) and fill_polygon (:323-325),
+    compiled in memory from the reference file and run as written.  What is stood in for: the CARLA map (CarlaDataProvider.get_map_api()
+    returns a few dummy drivable-area polygons) and cv2.fillPoly -- the stand-in does NOT rasterise, it writes a seeded pattern of `value`
+    into the mask it is handed and keeps a reference to it.  Everything the reference does once the mask exists -- the pose's rotation
+    matrix, global_to_pixel in float64 against the float32 resolution / offset vectors, np.round (half to even), the bounds test, the
+    [y, x] lookup and the == 1 test -- is the reference's own numpy; the device kernel and the oracle take exactly that mask as their input.
+    Cases: axis-aligned pose with exact half-pixel ties and raster-edge points, rotated / translated poses, points far outside the raster,
+    and a non-square raster (the reference's offset is [map_height / 2, map_width / 2] applied to (x, y): only visible when H != W)."""
+    import itertools
+    import types
+    TE = "rift/cbv/planning/fine_tuner/rlft/traj_eval/traj_evaluator.py"
+    LANE, CONNECTOR, OTHER = "lane", "lane_connector", "crosswalk"
+
+    class _Poly:
+        def __init__(self, xy):
+            self.exterior = types.SimpleNamespace(coords=types.SimpleNamespace(xy=(xy[:, 0].copy(), xy[:, 1].copy())))
+
+    out, n_case = {}, 0
+    cases = [  # (name, H, W, origin, heading, number of points (G, T), spread of the points in metres, seed)
+        ("axis_ties", 400, 400, (12.0, -7.0), 0.0, (6, 40), 70.0, 11),
+        ("rotated", 400, 400, (13.25, -7.5), 0.7, (16, 80), 60.0, 12),
+        ("rotated_far", 400, 400, (-250.125, 991.5), -2.4, (12, 80), 90.0, 13),
+        ("non_square", 200, 300, (3.5, 4.25), 1.1, (8, 40), 50.0, 14),
+    ]
+    for name, Hh, Ww, origin, heading, (G, T), spread, seed in cases:
+        rng = np.random.default_rng(seed)
+        held = {}
+
+        def fill_poly(mask, pts, value, _rng=rng, _held=held):
+            assert mask.dtype == np.uint8 and len(pts) == 1 and pts[0].dtype == np.int32 and pts[0].ndim == 2 and pts[0].shape[1] == 2
+            _held["mask"] = mask
+            _held["calls"] = _held.get("calls", 0) + 1
+            mask[_rng.random(mask.shape) < 0.22] = value          # a pattern, not a rasterisation: the lookup does not care what drew the mask
+
+        cv2 = types.SimpleNamespace(fillPoly=fill_poly)
+        polys = {LANE: [types.SimpleNamespace(polygon=_Poly(rng.normal(0, 30, (5, 2)) + origin)) for _ in range(2)],
+                 CONNECTOR: [types.SimpleNamespace(polygon=_Poly(rng.normal(0, 30, (4, 2)) + origin))],
+                 OTHER: [types.SimpleNamespace(polygon=_Poly(rng.normal(0, 30, (4, 2)) + origin))]}      # not a drivable-area layer: must not be drawn
+        seen = {}
+
+        class _MapApi:
+            def query_proximal_map_data(self, point, radius):
+                seen["point"], seen["radius"] = point, radius
+                return polys
+
+        provider = types.SimpleNamespace(get_map_api=lambda: _MapApi())
+        ns = {"itertools": itertools, "cv2": cv2, "Point": lambda *a: tuple(float(v) for v in a), "CarlaDataProvider": provider,
+              "DA": [LANE, CONNECTOR], "CarlaAgentState": object, "CarlaMap": object}
+        fake = types.SimpleNamespace(map_height=Hh, map_width=Ww, resolution=0.5,
+                                     resolution_hw=np.array([0.5, -0.5], dtype=np.float32),                 # traj_evaluator.py:100
+                                     offset=np.array([Hh / 2, Ww / 2], dtype=np.float32))                   # :101
+        fake.global_to_pixel = types.MethodType(_ref_function(TE, "global_to_pixel", ns), fake)
+        fake.fill_polygon = types.MethodType(_ref_function(TE, "fill_polygon", ns), fake)
+        off_road = _ref_function(TE, "get_off_road_matrix", ns)
+        pts = rng.normal(0, spread, (G, T, 2)).astype(np.float32) + np.asarray(origin, dtype=np.float32)
+        if heading == 0.0:
+            # exact half-pixel ties and raster edges (axis-aligned pose, dyadic coordinates: exact in float32 and in the float64 pipeline):
+            # pixel x = lx / 0.5 + H/2, pixel y = -ly / 0.5 + W/2
+            k = 0
+            for px in (-0.5, 0.5, 1.5, 10.5, 11.5, Ww - 1.5, Ww - 0.5, -0.75, Ww - 0.25, 0.0, Ww - 1.0, float(Ww)):
+                for py in (-0.5, 0.5, 2.5, Hh - 1.5, Hh - 0.5, 7.0):
+                    lx, ly = (px - Hh / 2) * 0.5, -(py - Ww / 2) * 0.5
+                    pts[k // T, k % T] = (origin[0] + lx, origin[1] + ly)
+                    k += 1
+        state = types.SimpleNamespace(center=types.SimpleNamespace(array=np.asarray(origin, dtype=np.float64), heading=float(heading)))
+        want = off_road(fake, pts, state)
+        assert held["calls"] == 3 and seen["radius"] == max(Hh, Ww) * 0.5 / 2 and want.shape == (G, T) and want.dtype == np.bool_
+        mask = held["mask"]
+        assert mask.shape == (Hh, Ww) and 0.3 < mask.mean() < 0.7
+        out.update({f"{n_case}.name": np.array(name), f"{n_case}.mask": mask.copy(), f"{n_case}.points": pts,
+                    f"{n_case}.pose": np.array([origin[0], origin[1], heading], dtype=np.float64), f"{n_case}.off_road": want})
+        print(f"  {name}: mask {mask.shape} mean {mask.mean():.3f}, {G * T} points, off-road share {want.mean():.3f}")
+        n_case += 1
+    out["n_case"] = np.array(n_case)
+    path = os.path.join(HERE, "off_road.npz")
+    np.savez_compressed(path, **out)
+    print("off_road ->", path, f"{os.path.getsize(path) / 1e3:.1f} kB", n_case, "cases")
+
+
 def gen_sft():
     """SFT teacher objective as the reference computes it: LightningTrainer._compute_objectives / get_teacher_loss / generate_target_label
     (fine_tuner/sft/sft_trainer.py:123-199) compiled in memory, sft/utils.global_to_local and PIDController imported from the reference."""
@@ -704,6 +784,8 @@ if __name__ == "__main__":
         gen_sft()
     elif len(sys.argv) > 1 and sys.argv[1] == "other_vehicles":
         gen_other_vehicles()
+    elif len(sys.argv) > 1 and sys.argv[1] == "off_road":
+        gen_off_road()
     elif len(sys.argv) > 1 and sys.argv[1] == "inference":
         gen_inference()
     elif len(sys.argv) > 1 and sys.argv[1] == "rollout":
@@ -717,6 +799,7 @@ if __name__ == "__main__":
         gen_critic()
         gen_inference()
         gen_other_vehicles()
+        gen_off_road()
         gen_sft()
         gen_buffer()
         gen_rtr()

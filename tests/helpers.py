@@ -337,6 +337,14 @@ def traj_flag_kat():
     return col, mask, off
 
 
+def off_road_cases():
+    """tests/golden/off_road.npz (tests/golden/gen_golden.py off_road: the reference's own get_off_road_matrix / global_to_pixel run on a
+    mask that a cv2.fillPoly stand-in filled with a seeded pattern): [(name, mask (H,W) u8, points (G,T,2) f32, (x, y, heading), expected (G,T) bool)]."""
+    g = np.load(os.path.join(GOLDEN, "off_road.npz"))
+    return [(str(g[f"{i}.name"]), g[f"{i}.mask"], g[f"{i}.points"], tuple(float(v) for v in g[f"{i}.pose"]), g[f"{i}.off_road"])
+            for i in range(int(g["n_case"]))]
+
+
 # ---- recorded CARLA readings for the feature builder (tests/golden/feature_builder.npz) ---------------------------------------------------
 def _ns(**kw):
     import types

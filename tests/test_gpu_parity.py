@@ -1220,6 +1220,17 @@ def test_collision_and_off_road_flags_match_oracle(ffi):
     eng.close()
 
 
+def test_off_road_kernel_matches_reference_fixture(ffi):
+    """rift_off_road_matrix against tests/golden/off_road.npz: the reference's own get_off_road_matrix / global_to_pixel
+    (traj_evaluator.py:277-322) on four masks -- half-pixel ties, raster edges, rotated poses, a non-square raster -- bit-exact."""
+    eng = ffi.Engine("cuda:0")
+    for name, mask, pts, (x, y, heading), want in H.off_road_cases():
+        Hh, Ww = mask.shape
+        got = eng.off_road_matrix(torch.from_numpy(pts), torch.from_numpy(mask), (x, y), heading, offset=(Hh / 2, Ww / 2)).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got.astype(bool), want), name
+    eng.close()
+
+
 def test_device_flags_against_hand_derived_known_answers(ffi):
     """rift_collision_matrix / rift_off_road_matrix against tests/golden/traj_flags_kat.json (42 hand-derived cases: touching and
     merely-envelope-overlapping footprints, degenerate footprints, half-pixel ties, raster edges, the flipped y axis, rotation)."""

@@ -79,6 +79,24 @@ def test_traj_flag_oracle_against_hand_derived_known_answers():
         assert bool(otf.get_off_road_matrix(pt, mask, origin, heading)[0, 0]) == want, name
 
 
+def test_off_road_oracle_matches_reference_fixture():
+    """oracle/traj_flags.get_off_road_matrix against tests/golden/off_road.npz -- the output of the reference's own
+    TrajEvaluator.get_off_road_matrix + global_to_pixel (traj_evaluator.py:277-322) on the mask its fill loop left behind: bit-exact on
+    every point, including exact half-pixel ties (np.round: half to even), raster-edge and far-outside points, rotated poses and a
+    non-square raster (the reference's offset [map_height / 2, map_width / 2] is applied to (x, y))."""
+    from oracle import traj_flags as otf
+    cases = H.off_road_cases()
+    assert [c[0] for c in cases] == ["axis_ties", "rotated", "rotated_far", "non_square"]
+    for name, mask, pts, (x, y, heading), want in cases:
+        got = otf.get_off_road_matrix(pts, mask, (x, y), heading, map_width=mask.shape[1], map_height=mask.shape[0])
+        assert got.dtype == np.bool_ and np.array_equal(got, want), name
+        assert 0.1 < want.mean() < 0.6, name
+    # the tie rows of the axis-aligned case really are ties: pixel x = 10.5 reads column 10, 11.5 reads 12, 399.5 falls off the raster
+    name, mask, pts, (x, y, heading), want = cases[0]
+    px = (pts[..., 0].astype(np.float64) - x) / 0.5 + 200.0
+    assert (np.abs(px - np.floor(px) - 0.5) < 1e-12).sum() >= 36
+
+
 def test_other_vehicle_rollout_oracle_matches_reference_fixture():
     """oracle/traj_flags.get_other_vehicle_rollout against tests/golden/other_vehicles.npz, produced by running the reference's own
     TrajEvaluator.get_other_vehicle_rollout + KinematicBicycleModel + GlobalConfig on the seeded actors of H.other_vehicle_inputs."""
