@@ -447,11 +447,11 @@ def main():
         if want_all_outputs:
             # companion figure: the same K steps with EVERY output of PlanningModel.forward computed (trajectory / prediction /
             # ref-free heads -- outputs the RLFT losses never read; the reference's training_step computes them)
-            model.need_traj = True
+            trainer.need_traj = True                 # (the trainer's own output selection: RLFTTrainer.need_traj)
             for i in range(2):
                 step(i)
             dt_all, _ = timed(args.warmup, steps)
-            model.need_traj = False
+            trainer.need_traj = False
             res["all_outputs"] = {"ms_per_step": dt_all / steps * 1e3, "value": steps / dt_all * global_bs, "steps_per_sec": steps / dt_all,
                                   "whole_step_mfma_frac": steps / dt_all * global_bs / world * FLOPS_PER_SCENE / (PEAK_BF16_TFLOPS * 1e12),
                                   "note": "trajectory / prediction / ref-free heads computed as the reference's training_step does (1.335 GFLOP per scene)"}

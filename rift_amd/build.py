@@ -26,7 +26,7 @@ OBJ = os.path.join(HERE, "_obj")
 # remove the spills or build that unit with SPILL_SAFE (SGPR spills to scratch memory: correct, and measured 45 % slower on pe_w_kernel).
 FAST = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 SPILL_SAFE = ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"]
-UNITS = [("engine", []), ("dec_w", FAST), ("nat_l01w", FAST), ("nat_l2w", FAST), ("enc_w", FAST), ("pe_w", FAST), ("fo_w", FAST)]
+UNITS = [("engine", []), ("dec_w", FAST), ("nat_l01w", FAST), ("nat_l2w", FAST), ("enc_w", FAST), ("pe_w", FAST), ("fo_w", FAST), ("enc112", FAST)]
 FORMATS = [("bf", 0), ("hf", 1)]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("HIPCC_EXTRA", "").split()      # (HIPCC_EXTRA: diagnostic defines, e.g. -DRIFT_DEC_ARR=1)
 

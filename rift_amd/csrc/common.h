@@ -289,7 +289,7 @@ __device__ __forceinline__ uint2 gelu4_hid(const f32x4 a, const float4 b) {
 
 // bias + GELU + operand pack of one MFMA accumulator fragment (4 consecutive output columns)
 __device__ __forceinline__ uint2 gelu4_pack(const f32x4 a, const float4 b) {
-#if RIFT_OP_F16 || defined(RIFT_GELU_F32)
+#if !RIFT_GELU_PK16
   f32x2_t lo, hi, bl, bh;
   lo.x = a[0]; lo.y = a[1]; hi.x = a[2]; hi.y = a[3];
   bl.x = b.x; bl.y = b.y; bh.x = b.z; bh.y = b.w;
@@ -298,7 +298,12 @@ __device__ __forceinline__ uint2 gelu4_pack(const f32x4 a, const float4 b) {
 #else
   gelu_h2 g0, g1;
   gelu_pk16x2(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w, g0, g1);
+#if RIFT_OP_F16
+  uint2 u; u.x = __builtin_bit_cast(unsigned int, g0); u.y = __builtin_bit_cast(unsigned int, g1);      // (the result words ARE the build's operand format)
+  return u;
+#else
   return pack_h4((float)g0[0], (float)g0[1], (float)g1[0], (float)g1[1]);
+#endif
 #endif
 }
 
@@ -341,6 +346,19 @@ __device__ __forceinline__ float xmax32(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float rows_sum(float v) { return xadd32(xadd16(v)); }   // over the 4 lanes {l, l^16, l^32, l^48}
+// Guard of the one-pass LayerNorm statistics (opfmt.h: RIFT_LN_FOLD).  var = E[x^2] - mean^2 in fp32 loses log2(1 + mean^2 / var) of its 24
+// bits: nothing on the rows this model produces (|mean| of the order of the spread), but a row whose mean dwarfs its spread -- a
+// checkpoint with an outlier channel offset -- would get a variance of noise where torch's two-pass form is exact.  m2 = mean^2,
+// var1 = E[x^2] - m2: true (wave-uniform) when some row of the wave has lost more than 12 bits (|mean| > 64 sigma, or var1 <= 0 beside
+// a non-zero mean: at least 12 of fp32's 24 bits are left otherwise, one more than an fp16 operand keeps); the caller then takes the
+// variance of that LayerNorm from the centred values instead.  Two instructions and a scalar branch per row tile on the fast path.
+#ifdef RIFT_LN_NO_GUARD      // (diagnostic build define: the unguarded one-pass form of round 5, for A/B runs)
+__device__ __forceinline__ bool ln_row_cancels(float, float) { return false; }
+__device__ __forceinline__ bool ln_cancels(float, float) { return false; }
+#else
+__device__ __forceinline__ bool ln_row_cancels(float m2, float var1) { return m2 > 4096.0f * var1; }      // (per lane row; the caller ORs over its row tiles and ballots once)
+__device__ __forceinline__ bool ln_cancels(float m2, float var1) { return __builtin_amdgcn_ballot_w64(m2 > 4096.0f * var1) != 0ull; }
+#endif
 __device__ __forceinline__ float rows_max(float v) { return xmax32(xmax16(v)); }
 __device__ __forceinline__ float sum32(float v) { v = sum16(v); return xadd16(v); }
 // sum over groups of LPR consecutive lanes (LPR = 8, 16, 32, 64), result in every lane of the group

@@ -290,7 +290,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int nt = 1; nt < 8; ++nt) q4 += res[nt] * res[nt];
       const float ex2 = rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 128.0f);
-      const float r = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + 1e-5f), c = -mean * r;
+      const float m2 = mean * mean;
+      float var = ex2 - m2;
+      if (__builtin_expect(ln_cancels(m2, var), 0)) {      // (common.h: a row whose mean dwarfs its spread -- the centred form, as torch)
+        f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) { const f32x4 d = res[nt] - mean; d4 += d * d; }
+        var = rows_sum((d4[0] + d4[1]) + (d4[2] + d4[3])) * (1.0f / 128.0f);
+      }
+      const float r = rsqrtf(fmaxf(var, 0.f) + 1e-5f), c = -mean * r;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) xb[ks] = l0w_pack8(res[2 * ks] * r + c, res[2 * ks + 1] * r + c);
       return;

@@ -8,6 +8,7 @@
 #pragma once
 #include "common.h"
 #include "dropstats.h"
+#include "token.h"
 
 namespace RIFT_NS {
 
@@ -51,6 +52,7 @@ struct EncFusedP {
   DropStats ds;                 // diagnostic build only (dropstats.h)
 };
 
+#ifndef RIFT_ENC112_TU      // (engine.hip owns this one; enc112.hip includes this header for the 112-row kernel only)
 // row-gather weight packer: dst[r][k] = bf16(src[idx[r]][k]); bias_out[r] = bias[idx[r]]
 __global__ void pack_rows_indexed_kernel(const float* __restrict__ src, const float* __restrict__ bias,
                                          const int* __restrict__ idx, int nrows, int K,
@@ -61,11 +63,13 @@ __global__ void pack_rows_indexed_kernel(const float* __restrict__ src, const fl
   dst[fm_index(r, k, K)] = f2h(src[(size_t)idx[r] * K + k]);   // fragment-major image
   if (k == 0 && bias) bias_out[r] = bias[idx[r]];
 }
+#endif
 
 template <int KS, int NTW>
 struct EFrags { h16x8 f[KS][NTW]; };
 
 template <int NWV> struct EWaves {};
+template <int V> struct EInt { static constexpr int value = V; };      // a compile-time int as a (generic-lambda) argument
 // this wave's n-tiles are (j * NW + wave), j < NTW; tiles at or beyond `ntiles` are skipped (zero fragments)
 template <int KS, int NTW, int NW>
 __device__ __forceinline__ void e_load_b(EFrags<KS, NTW>& B, const unsigned short* W, int ldw, int n0, int k0, int wave,
@@ -116,26 +120,44 @@ __device__ __forceinline__ void e_mma(f32x4 (&acc)[MT][NTW], const unsigned shor
 #define RIFT_ENC_XN 144
 #define RIFT_ENC_XA 136
 #define RIFT_ENC_LDS_BYTES (96 * 132 * 4 + 96 * (RIFT_ENC_XN + RIFT_ENC_XA) * 2 + 96 * 200 * 2 + 2 * 32 * 104 * 2 + 96 * 4 + RIFT_ENC_NPAR * 4 + 128)      // (+ 96 row -> slot bytes of the compacted layout)
+// LDS layout of a scene held in R rows.  R = 96: the layout of rounds 2 - 5 (above).  R = 112 (round 6: the shapes train_cbv collates,
+// 49 + 60 = 109 token slots, left the two-pass enc_w_kernel for this kernel): seven row tiles do not fit beside the 96-row strides, so
+// the q | k / hidden chunk rows shrink to 136 words (they never held more than 128), the attention output keeps only the CURRENT chunk's
+// two heads (72-word rows) and out_proj runs per chunk -- W_o (a_h0 | a_h1 | a_h2 | a_h3) = W_o[:, :64] (a_h0 | a_h1) + W_o[:, 64:] (a_h2 | a_h3),
+// each half a K = 64 product accumulated straight into the residual rows -- and V^T rows hold four key pairs: 162 624 of 163 840 bytes.
+template <int R> struct EncLay {
+  static constexpr int ROWS = R, XS = 132, XN = RIFT_ENC_XN;
+  static constexpr int CB = R == 96 ? 200 : 136;
+  static constexpr int XA = R == 96 ? RIFT_ENC_XA : 72;
+  static constexpr int VS = R == 96 ? 104 : 136;
+  static constexpr bool AO_HALF = R != 96;
+  static constexpr int BYTES = R * XS * 4 + R * (XN + XA) * 2 + R * CB * 2 + 2 * 32 * VS * 2 + R * 4 + RIFT_ENC_NPAR * 4 + 128;
+};
+static_assert(EncLay<96>::BYTES == RIFT_ENC_LDS_BYTES, "the 96-row layout is the one of rounds 2 - 5");
+static_assert(EncLay<112>::BYTES <= 160 * 1024, "the 112-row layout fits the CU's LDS");
 
 // MTC row (= key) tiles of 16 tokens: 6 = the 96-row layout; 5 = a compacted scene with at most 80 valid tokens (its sixth tile would hold
 // padded rows only: every loop over row / key tiles is a sixth shorter).  COMPILE-TIME on purpose: the first version of the compaction tested
 // a run-time tile count inside the unrolled loops and ran 275 us instead of 97 (each guarded tile became a basic block of its own, so no
 // operand load could move above the MFMAs of the tile before it).  enc_fused_kernel below picks the body per scene.
-template <int NW, int MTC>
+template <int NW, int MTC, int ROWS_ = 96>
 __device__ __forceinline__ void enc_fused_body(const EncFusedP& p, const bool ok, const unsigned long long vmask, const int c0, const int nvv, const bool keep_order) {
-  constexpr int ROWS = 96, MT = MTC, C = 128;
+  typedef EncLay<ROWS_> Lay;
+  constexpr int ROWS = ROWS_, MT = MTC, C = 128;
   constexpr int mtn = MT;
   constexpr int NTH = 64 * NW, NTQ = 12 / NW + (12 % NW ? 1 : 0), NTC = 8 / NW;   // n-tiles per wave: qkv chunk (12), 128-wide output (8)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  constexpr int XS = 132, XN = RIFT_ENC_XN, XA = RIFT_ENC_XA, CB = 200, VS = 104, NKT = MT;
+  static_assert(16 * MTC <= ROWS_, "row tiles inside the LDS rows");
+  constexpr int XS = Lay::XS, XN = Lay::XN, XA = Lay::XA, CB = Lay::CB, VS = Lay::VS, NKT = MT;
+  constexpr bool AO_HALF = Lay::AO_HALF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* xs = reinterpret_cast<float*>(smem_raw);
   unsigned short* xn = reinterpret_cast<unsigned short*>(xs + ROWS * XS);
   unsigned short* cb = xn + ROWS * XN;
   unsigned short* ao = cb + ROWS * CB;
   unsigned short* vt = ao + ROWS * XA;            // [2][32][VS]
-  float* smaskf = reinterpret_cast<float*>(vt + 2 * 32 * VS);   // [96] key-padding mask as 0 / -inf: it enters the scores as the MFMA accumulator
-  float* par = smaskf + 96;                             // [RIFT_ENC_NPAR] this layer's bias / LayerNorm vectors
+  float* smaskf = reinterpret_cast<float*>(vt + 2 * 32 * VS);   // [ROWS] key-padding mask as 0 / -inf: it enters the scores as the MFMA accumulator
+  float* par = smaskf + ROWS;                           // [RIFT_ENC_NPAR] this layer's bias / LayerNorm vectors
   constexpr int P_LN1G = 0, P_LN1B = 128, P_LN2G = 256, P_LN2B = 384, P_BQKV = 512, P_BO = 896, P_B1 = 1024, P_B2 = 1536;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -167,13 +189,14 @@ __device__ __forceinline__ void enc_fused_body(const EncFusedP& p, const bool ok
   EFrags<4, NTQ> Bqkv;
   EFrags<4, NTC> Bw;     // out_proj / fc1 chunk (128 output columns, K = 128)
   EFrags<4, NTC> B2;     // fc2 partial (128 output columns, K = 128-wide hidden chunk)
+  EFrags<2, NTC> Bo;     // (AO_HALF) out_proj, the K = 64 half of the current chunk's two heads
   e_load_b(Bqkv, p.blk[0].wqkv, C, 0, 0, wave, l15, l4, EWaves<NW>(), 12);
 
   // ---- (RIFT_ENC_COMPACT) the scene's valid tokens first: srow[i] = the token slot LDS row i holds (valid slots in ascending order, then the
   // padded ones), nv = the valid count, mtn = the row (= key) tiles that hold a valid row: every loop over row tiles below stops there.
   // Slot 0 is the ego token, whose row the tail's cat_x_proj half reads as row 0: a scene whose slot 0 is padded (none in practice: the
   // CBV itself) keeps the slot order (nv = -1).
-  unsigned char* srow = reinterpret_cast<unsigned char*>(par + RIFT_ENC_NPAR);        // [96], lives to the end of the kernel (the output rows go back to their slots)
+  unsigned char* srow = reinterpret_cast<unsigned char*>(par + RIFT_ENC_NPAR);        // [ROWS <= 128], lives to the end of the kernel (the output rows go back to their slots)
   int nv = -1;
 #if RIFT_ENC_COMPACT
   if (tid < ROWS) {
@@ -239,37 +262,46 @@ __device__ __forceinline__ void enc_fused_body(const EncFusedP& p, const bool ok
     TS();
     for (int ch = 0; ch < 2; ++ch) {
       {
-        f32x4 acc[MT][NTQ];
+        // the chunk's q | k | v GEMM over row tiles [M0, M0 + MN): all of them in one pass, or -- seven tiles (the 112-row layout) -- in
+        // two (4 + 3): 56 accumulator and 28 operand registers at once spilled, 32 + 16 do not
+        auto qkv_pass = [&](auto m0c, auto mnc) {
+          constexpr int M0 = decltype(m0c)::value, MN = decltype(mnc)::value;
+          f32x4 acc[MN][NTQ];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MN; ++mt)
 #pragma unroll
-          for (int j = 0; j < NTQ; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        e_mma<MT, 4, NTQ, 1>(acc, xn, XN, Bqkv, l15, l4, mtn);   // q|k tiles swapped (row-major stores), V tile (last j) plain (transposed stores)
-        if (ch == 0) e_load_b(Bqkv, w.wqkv, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
-        else e_load_b(Bw, w.wo, C, 0, 0, wave, l15, l4, EWaves<NW>());
+            for (int j = 0; j < NTQ; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          e_mma<MN, 4, NTQ, 1>(acc, xn + M0 * 16 * XN, XN, Bqkv, l15, l4, MN);   // q|k tiles swapped (row-major stores), V tile (last j) plain (transposed stores)
+          if constexpr (M0 + MN == MT) {      // (behind the last pass: the weights of the next phase)
+            if (ch == 0) e_load_b(Bqkv, w.wqkv, C, 192, 0, wave, l15, l4, EWaves<NW>(), 12);
+            else if constexpr (!AO_HALF) e_load_b(Bw, w.wo, C, 0, 0, wave, l15, l4, EWaves<NW>());
+            if constexpr (AO_HALF) e_load_b(Bo, w.wo, C, 0, ch * 64, wave, l15, l4, EWaves<NW>());      // this chunk's K = 64 half of out_proj
+          }
 #pragma unroll
-        for (int j = 0; j < NTQ - 1; ++j) { // n-tiles 0..7: q|k of the two heads -> cb[row][col..col+3]
-          const int nt = j * NW + wave;
-          const int col = nt * 16 + l4 * 4;
-          const float4 b4 = *reinterpret_cast<const float4*>(par + P_BQKV + ch * 192 + col);
-          const float sc = ((nt & 3) < 2) ? 0.17677669529663687f * 1.4426950408889634f : 1.0f;   // q pre-scaled by 32^-0.5 log2 e: the softmax runs on v_exp_f32 = 2^x
+          for (int j = 0; j < NTQ - 1; ++j) { // n-tiles 0..7: q|k of the two heads -> cb[row][col..col+3]
+            const int nt = j * NW + wave;
+            const int col = nt * 16 + l4 * 4;
+            const float4 b4 = *reinterpret_cast<const float4*>(par + P_BQKV + ch * 192 + col);
+            const float sc = ((nt & 3) < 2) ? 0.17677669529663687f * 1.4426950408889634f : 1.0f;   // q pre-scaled by 32^-0.5 log2 e: the softmax runs on v_exp_f32 = 2^x
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            if (mt < mtn)
-              *reinterpret_cast<uint2*>(cb + (mt * 16 + l15) * CB + col) =
+            for (int mt = 0; mt < MN; ++mt)
+              *reinterpret_cast<uint2*>(cb + ((M0 + mt) * 16 + l15) * CB + col) =
                   pack_h4((acc[mt][j][0] + b4.x) * sc, (acc[mt][j][1] + b4.y) * sc, (acc[mt][j][2] + b4.z) * sc, (acc[mt][j][3] + b4.w) * sc);
-        }
-        if (wave < 4) {                     // n-tiles 8..11: V -> vt[head][d][key..key+3]
-          const int nt = 8 + wave;
-          const int hh = (nt - 8) >> 1, d = ((nt - 8) & 1) * 16 + l15;
-          const float bias = par[P_BQKV + ch * 192 + nt * 16 + l15];
+          }
+          if (wave < 4) {                     // n-tiles 8..11: V -> vt[head][d][key..key+3]
+            const int nt = 8 + wave;
+            const int hh = (nt - 8) >> 1, d = ((nt - 8) & 1) * 16 + l15;
+            const float bias = par[P_BQKV + ch * 192 + nt * 16 + l15];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + mt * 16 + l4 * 4) =
-                pack_h4(acc[mt][NTQ - 1][0] + bias, acc[mt][NTQ - 1][1] + bias, acc[mt][NTQ - 1][2] + bias, acc[mt][NTQ - 1][3] + bias);
-          // (an odd tile count leaves the second half of the last key PAIR's V^T tile unwritten: zeros there -- P is zero, but 0 x stale NaN is not)
-          if (MT & 1) *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + MT * 16 + l4 * 4) = make_uint2(0u, 0u);
-        }
+            for (int mt = 0; mt < MN; ++mt)
+              *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + (M0 + mt) * 16 + l4 * 4) =
+                  pack_h4(acc[mt][NTQ - 1][0] + bias, acc[mt][NTQ - 1][1] + bias, acc[mt][NTQ - 1][2] + bias, acc[mt][NTQ - 1][3] + bias);
+            // (an odd tile count leaves the second half of the last key PAIR's V^T tile unwritten: zeros there -- P is zero, but 0 x stale NaN is not)
+            if ((MT & 1) && M0 + MN == MT) *reinterpret_cast<uint2*>(vt + (hh * 32 + d) * VS + MT * 16 + l4 * 4) = make_uint2(0u, 0u);
+          }
+        };
+        if constexpr (MT > 6) { qkv_pass(EInt<0>(), EInt<4>()); qkv_pass(EInt<4>(), EInt<MT - 4>()); }
+        else qkv_pass(EInt<0>(), EInt<MT>());
       }
       lds_barrier();
       TS();
@@ -320,7 +352,7 @@ __device__ __forceinline__ void enc_fused_body(const EncFusedP& p, const bool ok
           o0 = mfma_h(b0, pf, o0, 0, 0, 0);
           o1 = mfma_h(b1, pf, o1, 0, 0, 0);
         }
-        const int head = ch * 2 + hh;
+        const int head = AO_HALF ? hh : ch * 2 + hh;      // (AO_HALF: the rows hold the current chunk's two heads only)
         const float inv = __builtin_amdgcn_rcpf(lsum);
         unsigned short* op = ao + (qt * 16 + l15) * XA + head * 32 + l4 * 4;
         *reinterpret_cast<uint2*>(op) = pack_h4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
@@ -328,9 +360,33 @@ __device__ __forceinline__ void enc_fused_body(const EncFusedP& p, const bool ok
       }
       lds_barrier();
       TS();
+      if constexpr (AO_HALF) {
+        // ---- this chunk's half of out_proj + residual (the next chunk's attention rewrites ao behind the barrier that follows its q | k | v GEMM)
+        f32x4 acc[MT][NTC];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < NTC; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        e_mma<MT, 2, NTC>(acc, ao, XA, Bo, l15, l4, mtn);
+        if (ch == 1) e_load_b(Bw, w.w1, C, 0, 0, wave, l15, l4, EWaves<NW>());             // fc1 weights of hidden chunk 0
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) {
+          const int col = (j * NW + wave) * 16 + l4 * 4;
+          float4 b4 = *reinterpret_cast<const float4*>(par + P_BO + col);
+          if (ch == 1) b4 = make_float4(0.f, 0.f, 0.f, 0.f);                               // (the bias rides on the first half)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            float4* xp = reinterpret_cast<float4*>(xs + (mt * 16 + l15) * XS + col);
+            float4 x = *xp;
+            x.x += (acc[mt][j][0] + b4.x) * dpscale; x.y += (acc[mt][j][1] + b4.y) * dpscale;
+            x.z += (acc[mt][j][2] + b4.z) * dpscale; x.w += (acc[mt][j][3] + b4.w) * dpscale;
+            *xp = x;
+          }
+        }
+      }
     }
     // ---- out_proj + residual
-    {
+    if constexpr (!AO_HALF) {
       f32x4 acc[MT][NTC];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -456,6 +512,41 @@ __device__ __forceinline__ void enc_fused_body(const EncFusedP& p, const bool ok
     e_load_b(Wk, p.wkv, C, 0, 0, wave, l15, l4, EWaves<NW>());
     lds_barrier();
     static_assert(NW == 8, "the K|V tail deals 16 n-tiles to 8 waves");
+    if constexpr (ROWS != 96) {
+      // the dense per-head image dec_w_kernel<., false, 8> gathers its eight key tiles from (dec_kv.h: per (scene, layer) 4 heads x
+      // (12 K fragments by key tile | 12 V^T fragments by (dim tile, key pair))); key tiles without a valid key: zeros (masked scores
+      // of finite operands, P = 0 against finite V^T).  Row tiles in two passes (4 + the rest), as the q | k | v GEMM above.
+      for (int l = 0; l < 4; ++l) {
+        const int h = wave >> 1;
+        unsigned short* base = p.KT + (((size_t)b * 4 + l) * 96 + h * 24) * 512 + lane * 8;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bkv + l * 256 + wave * 16 + l4 * 4);
+        const float bias = p.bkv[l * 256 + 128 + wave * 16 + l15];
+        auto kv_pass = [&](auto m0c, auto mnc) {
+          constexpr int M0 = decltype(m0c)::value, MN = decltype(mnc)::value;
+          f32x4 acc[MN][2];
+#pragma unroll
+          for (int mt = 0; mt < MN; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          e_mma<MN, 4, 2, 1>(acc, xn + M0 * 16 * XN, XN, Wk, l15, l4, MN);
+          if constexpr (M0 + MN == MT) { if (l + 1 < 4) e_load_b(Wk, p.wkv, C, (l + 1) * 256, 0, wave, l15, l4, EWaves<NW>()); }
+#pragma unroll
+          for (int mt = 0; mt < MN; ++mt) {
+            const int kt = M0 + mt;
+            *reinterpret_cast<uint2*>(base + kt * 512 + (wave & 1) * 4) = pack_h4(acc[mt][0][0] + b4.x, acc[mt][0][1] + b4.y, acc[mt][0][2] + b4.z, acc[mt][0][3] + b4.w);
+            *reinterpret_cast<uint2*>(base + (12 + (wave & 1) * 6 + (kt >> 1)) * 512 + (kt & 1) * 4) =
+                pack_h4(acc[mt][1][0] + bias, acc[mt][1][1] + bias, acc[mt][1][2] + bias, acc[mt][1][3] + bias);
+          }
+        };
+        if constexpr (MT > 4) { kv_pass(EInt<0>(), EInt<4>()); kv_pass(EInt<4>(), EInt<MT - 4>()); }
+        else kv_pass(EInt<0>(), EInt<MT>());
+#pragma unroll
+        for (int kt = MT; kt < 8; ++kt) {
+          *reinterpret_cast<uint2*>(base + kt * 512 + (wave & 1) * 4) = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(base + (12 + (wave & 1) * 6 + (kt >> 1)) * 512 + (kt & 1) * 4) = make_uint2(0u, 0u);
+        }
+      }
+    } else
     for (int l = 0; l < 4; ++l) {
       f32x4 acc[MT][2];
 #pragma unroll
@@ -491,6 +582,29 @@ __device__ __forceinline__ void enc_fused_body(const EncFusedP& p, const bool ok
     }
   }
 }
+
+// 97 .. 112 token slots per scene (round 6): the same body on the 112-row layout (EncLay<112>), always compacting -- 5, 6 or 7 row tiles by
+// the scene's valid-token count; K | V^T for the decoder's eight-key-tile variant (dense per-head image), kpm_c is (bs, 112).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void enc_fused112_kernel(EncFusedP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_cnt[];
+  int* cnt = reinterpret_cast<int*>(smem_cnt);
+  const int tid = threadIdx.x, wave = tid >> 6, N = p.N;
+  const size_t grow0 = (size_t)blockIdx.x * N;
+  const bool ok = tid < N && !p.kpm[grow0 + (tid < N ? tid : 0)];
+  const unsigned long long vmask = __builtin_amdgcn_ballot_w64(ok);
+  if (wave < 2 && (tid & 63) == 0) cnt[wave] = __builtin_popcountll(vmask);
+  lds_barrier();
+  const int c0 = __builtin_amdgcn_readfirstlane(cnt[0]), nvv = __builtin_amdgcn_readfirstlane(cnt[0] + cnt[1]);
+  const bool keep_order = p.kpm[grow0] != 0;
+  lds_barrier();
+  if (!keep_order && nvv <= 80) enc_fused_body<NW, 5, 112>(p, ok, vmask, c0, nvv, false);
+  else if (!keep_order && nvv <= 96) enc_fused_body<NW, 6, 112>(p, ok, vmask, c0, nvv, false);
+  else enc_fused_body<NW, 7, 112>(p, ok, vmask, c0, nvv, keep_order);
+}
+
+int enc112_set_attributes();                                   // enc112.hip
+void enc112_launch(const EncFusedP& p, hipStream_t stream);
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void enc_fused_kernel(EncFusedP p) {

@@ -123,6 +123,11 @@ struct RiftCtx {
   double* clip_part = nullptr;
   struct Dp { bool on = false; int off = 0, gbs = 0; double* xchg = nullptr; long long len = 0; RiftExchangeFn fn = nullptr; void* user = nullptr; } dp;   // rift_set_dp
   int* nonfinite = nullptr;              // device flag set by the policy-head kernels when the decoder output is not finite
+  // the in-launch ranking's published per-scene counts (kernels.h: rank_scene_body), one array per arena; they persist between launches
+  // (a word is valid when it carries the launch's epoch; zero at allocation, epochs start at 1)
+  unsigned long long* rk_pub[RIFT_DEFER_SLOTS] = {}; int rk_cap[RIFT_DEFER_SLOTS] = {}; unsigned int rk_epoch[RIFT_DEFER_SLOTS] = {};
+  bool enc112 = true;                    // RIFT_ENC112=0: scenes of 97 .. 112 token slots on enc_w_kernel (rounds 3 - 5) instead of the fused kernel's 112-row layout
+  bool rank_in_prep = true;              // RIFT_RANK_IN_PREP=0: the ranking as its own launch behind the preparation (nat_rank_kernel, rounds 3 - 5)
   void* comm = nullptr; int comm_rank = 0, comm_world = 1;      // library-owned RCCL communicator (rift_comm_init), or null
   float* cr_buf = nullptr; size_t cr_cap = 0; double* cr_part = nullptr;   // PPO critic scratch (rows x 1153 floats)
   bool pe_fused = true; bool fo_fused = true; int nat_grid = 256; bool fpn_fused = true; bool ego_fused = true; bool heads_fused = true; bool pi_fused = true;
@@ -446,6 +451,7 @@ int set_lds_attrs(RiftCtx* c) {
 #define SETATTR(K) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
   SETATTR(rollout_kernel);
   SETATTR(enc_fused_kernel<ENC_NW>);
+  HIPCHK(c, (hipError_t)enc112_set_attributes());
   HIPCHK(c, (hipError_t)decw_set_attributes());
   HIPCHK(c, (hipError_t)l2w_set_attributes());
   HIPCHK(c, (hipError_t)encw_set_attributes());
@@ -978,6 +984,25 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     q.nb[3] = cdiv(nL, 256); q.nb[4] = cdiv(nL, 256); q.nb[5] = cdiv(nT, 256); q.nb[6] = cdiv(nT, 256);
     int tot = 0;
     for (int i = 0; i < 7; ++i) tot += q.nb[i];
+    // (round 6) the ranking as the first bs blocks of this launch (kernels.h: rank_scene_body): no launch of its own on the history chain
+    const bool rank_in_prep = nat_compact && c->rank_in_prep && A <= 256 && !(c->front_fused && !f.fp32 && c->ego_fused);
+    if (rank_in_prep) {
+      const int sl = c->parity;
+      if (c->rk_cap[sl] < bs) {                          // (a batch beyond the arrays of rift_ctx_create: a fresh zeroed array, epochs start over)
+        HIPCHK(c, hipDeviceSynchronize());               // nothing in flight reads the old array; and the zeros below are in place before ANY stream's launch
+        if (c->rk_pub[sl]) { HIPCHK(c, hipFree(c->rk_pub[sl])); c->rk_pub[sl] = nullptr; c->rk_cap[sl] = 0; }
+        const int cap = std::max(2 * bs, 4096);
+        HIPCHK(c, hipMalloc((void**)&c->rk_pub[sl], (size_t)cap * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemset(c->rk_pub[sl], 0, (size_t)cap * sizeof(unsigned long long)));
+        HIPCHK(c, hipDeviceSynchronize());               // (hipMemset of device memory may return before the fill has run, and the preparation is launched on a non-blocking stream)
+        c->rk_cap[sl] = cap; c->rk_epoch[sl] = 0;
+      }
+      q.nrk = bs; q.rk_pub = c->rk_pub[sl]; q.aidx = nat_aidx; q.cnt = nat_cnt;
+      if (!c->dry) { if (++c->rk_epoch[sl] == 0u) c->rk_epoch[sl] = 1u; }      // (epoch 0 = "never written")
+      q.rk_epoch = c->rk_epoch[sl];
+      q.hist_agent = nullptr;                            // (the scene blocks derive the marks themselves)
+      tot += bs;
+    }
     // (round 4) the ranking and the ego token as blocks of the preparation's own launch (front.h): neither reads anything the preparation writes
     front_fused = c->front_fused && !f.fp32 && c->ego_fused && !RIFT_DROP_STATS;      // (the diagnostic twin sets its counters up behind the preparation: it keeps the three launches)
     FrontP fq; memset(&fq, 0, sizeof(fq));
@@ -1005,7 +1030,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         else launch(c, "front_kernel", front_kernel<false>, dim3(tot + fq.rank_on), dim3(256), 0, fq);
       } else {
         launch(c, "prep_kernel", prep_kernel, dim3(tot), dim3(256), 0, q);
-        if (nat_compact) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(NAT_RANK_THREADS), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
+        if (nat_compact && !rank_in_prep) launch(c, "nat_rank_kernel", nat_rank_kernel, dim3(1), dim3(NAT_RANK_THREADS), 0, (const uint8_t*)hist_agent, nA, nat_aidx, nat_cnt);
       }
     };
     // on the caller's prepare stream if there is one (rift_set_prepare_stream): behind the gather of the batch, beside the previous step
@@ -1055,6 +1080,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
 #else
 #define RIFT_SET_DS(x)
 #endif
+  if (nat_compact) { tap(c, "nat_aidx", (float*)nat_aidx, nA); tap(c, "nat_cnt", (float*)nat_cnt, 3); }      // (int32 words read back through the float tap)
   static const float dpr[6] = {0.f, 0.04f, 0.08f, 0.12f, 0.16f, 0.2f};   // linspace(0, 0.2, 6), embedding.py:30
   const bool fused = c->nat_fused && !f.fp32;
   // fork: the agent-history chain depends on prep_kernel only and joins at the token assembly; on its own stream it fills the CUs the
@@ -1349,7 +1375,10 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   unsigned short* enc_KT = nullptr;   // the decoder's cross-attention K | V^T operand fragments, written by the encoder kernel's tail
   uint8_t* kpm_c = nullptr;           // (RIFT_ENC_COMPACT) the key padding of the compacted encoder rows (bs, 96): what the decoder masks those fragments with
   float* enc_x0p = nullptr;   // cat_x_proj's ego-token half, written by the encoder kernel's tail
-  if (c->enc_fused && !f.fp32 && N <= 96) {
+  // 97 .. 112 token slots (what train_cbv collates: 49 + 60 = 109): the fused kernel on its 112-row layout (enc_fused.h: EncLay<112>) when the
+  // decoder's eight-key-tile variant consumes its K | V^T image; RIFT_ENC112=0 keeps those shapes on enc_w_kernel
+  const bool enc_wide = N > 96 && N <= 112 && c->enc112 && c->dec_fused && R <= 8 && ENC_NW == 8 && !tok_fused;
+  if (c->enc_fused && !f.fp32 && (N <= 96 || enc_wide)) {
     EncFusedP ep; memset(&ep, 0, sizeof(ep));
     ep.X = X; ep.Y = ENC; ep.kpm = kpm; ep.bs = bs; ep.N = N; ep.seed = f.seed; ep.stream = f.next_stream(); f.stream_id += 8;
     if (tok_fused) { ep.tok = tokq; ep.tok_on = 1; ep.Xout = c->keep_tokens ? X : nullptr; }
@@ -1369,17 +1398,20 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
     if (c->dg.enc_ts) { ep.ts = A_alloc<long long>(c, 256); tap(c, "enc_ts", (float*)ep.ts, 512); }
     c->prof_flops = 4.0 * bs * N * (2.0 * 128 * 384 + 4.0 * N * 128 + 2.0 * 128 * 128 + 4.0 * 128 * 512);
     if (c->dec_fused && R <= 8 && ENC_NW == 8) {   // the decoder kernel will run: emit its cross-attention K | V operand fragments here
-      enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * DECW_KV_FRAGS * 512);
+      enc_KT = A_alloc<unsigned short>(c, (size_t)bs * 4 * (enc_wide ? 96 : DECW_KV_FRAGS) * 512);      // (wide: the dense per-head image, dec_kv.h)
       ep.wkv = (const unsigned short*)c->pw["planning_decoder.kv_all"].bf; ep.bkv = c->pw["planning_decoder.kv_all"].bias;
       ep.KT = enc_KT;
 #if RIFT_ENC_COMPACT
-      kpm_c = A_alloc<uint8_t>(c, (size_t)bs * 96); ep.kpm_c = kpm_c;
+      kpm_c = A_alloc<uint8_t>(c, (size_t)bs * (enc_wide ? 112 : 96)); ep.kpm_c = kpm_c;
+#else
+      if (enc_wide) { kpm_c = A_alloc<uint8_t>(c, (size_t)bs * 112); ep.kpm_c = kpm_c; }
 #endif
       enc_x0p = A_alloc<float>(c, (size_t)bs * 128);
       ep.wx0 = (const unsigned short*)c->pw["planning_decoder.cat_x_proj.x"].bf; ep.x0p = enc_x0p;
       c->prof_flops += 2.0 * bs * N * 128.0 * 1024;
     }
-    launch(c, "enc_fused_kernel", enc_fused_kernel<ENC_NW>, dim3(bs), dim3(64 * ENC_NW), (size_t)RIFT_ENC_LDS_BYTES, ep);
+    if (enc_wide) launch_call(c, "enc_fused112_kernel", [&] { enc112_launch(ep, c->stream); });
+    else launch(c, "enc_fused_kernel", enc_fused_kernel<ENC_NW>, dim3(bs), dim3(64 * ENC_NW), (size_t)RIFT_ENC_LDS_BYTES, ep);
   } else if (c->enc_fused && !f.fp32 && N <= 192) {   // dense-traffic shapes: the wave-private, weight-streaming encoder (two passes per layer)
     EncWP eq; memset(&eq, 0, sizeof(eq));
     eq.X = X; eq.Y = ENC; eq.kpm = kpm; eq.bs = bs; eq.N = N; eq.seed = f.seed; eq.stream = f.next_stream(); f.stream_id += 8;
@@ -1466,7 +1498,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
   if (c->dec_fused && !f.fp32 && ((R <= 8 && N <= 96) || dec_dense) && enc_KT) {
     DecWP dq; memset(&dq, 0, sizeof(dq));
     dq.Q = Q; dq.kpm = kpm; dq.r_kpm = r_kpm; dq.q_kpm = q_kpm; dq.q_bs = q_bs; dq.q_off = q_off; dq.bs = bs; dq.N = N; dq.R = R; dq.dropout = dp; dq.seed = f.seed;
-    if (kpm_c) { dq.kpm = kpm_c; dq.N = 96; dq.compact = 1; }      // (the encoder compacted its rows: its own key padding, valid keys a prefix)
+    if (kpm_c) { dq.kpm = kpm_c; dq.N = enc_wide ? 112 : 96; dq.compact = 1; }      // (the encoder compacted its rows: its own key padding, valid keys a prefix)
     dq.stream = f.next_stream(); f.stream_id += 64;
     dq.KV = enc_KT; dq.img = c->decw_img; dq.par = c->decw_par; dq.nonfinite = c->nonfinite;
     RIFT_SET_DS(dq);
@@ -1657,6 +1689,8 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   // to derive the marks from the raw validity (344 KB through one workgroup), makes the merged launch 34 us where the two took 24: a loss wherever
   // the forward runs serially (get_action, small batches))
   { const char* ev = getenv("RIFT_FRONT_FUSED"); if (ev) c->front_fused = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_RANK_IN_PREP"); if (ev) c->rank_in_prep = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_ENC112"); if (ev) c->enc112 = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_EGO_NOFIT"); c->ego_nofit = ev && ev[0] == '1'; }
   { const char* ev = getenv("RIFT_FRONT_EGO"); if (ev) c->front_ego = atoi(ev) != 0; }        // (1: the ego token as blocks of that launch too -- 116 VGPRs: it no longer fits beside the decoder's workgroups)
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }
@@ -1681,6 +1715,11 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_TWO_STREAMS"); c->two_streams = !(ev && ev[0] == '0'); }
   { const char* ev = getenv("RIFT_GEMM_DBG"); c->gemm_dbg = ev ? atoi(ev) : 0; }
   if (hipMalloc((void**)&c->nonfinite, sizeof(int)) != hipSuccess || hipMemset(c->nonfinite, 0, sizeof(int)) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
+  for (int i = 0; i < RIFT_DEFER_SLOTS; ++i) {      // the in-launch ranking's published counts (kernels.h: rank_scene_body): zero = "never written"
+    if (hipMalloc((void**)&c->rk_pub[i], 4096 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->rk_pub[i], 0, 4096 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIFT_ERR_HIP; }
+    c->rk_cap[i] = 4096;
+  }
+  if (hipDeviceSynchronize() != hipSuccess) { delete c; return RIFT_ERR_HIP; }      // (the zeros are in place before any stream launches a kernel that reads them)
   int rc = set_lds_attrs(c);
   if (rc != RIFT_OK) { fprintf(stderr, "rift_ctx_create: %s\n", c->err.c_str()); delete c; return rc; }
   *ctx = c;
@@ -1704,6 +1743,7 @@ void rift_ctx_destroy(RiftCtx* c) {
   if (c->cr_buf) { (void)hipFree(c->cr_buf); (void)hipFree(c->cr_part); }
   if (c->clip_part) (void)hipFree(c->clip_part);
   if (c->nonfinite) (void)hipFree(c->nonfinite);
+  for (int i = 0; i < RIFT_DEFER_SLOTS; ++i) if (c->rk_pub[i]) (void)hipFree(c->rk_pub[i]);
   if (c->l0w_img) { (void)hipFree(c->l0w_img); (void)hipFree(c->l0w_par); }
   if (c->l1w_img) { (void)hipFree(c->l1w_img); (void)hipFree(c->l1w_par); }
   if (c->l2w_img) { (void)hipFree(c->l2w_img); (void)hipFree(c->l2w_par); }

@@ -4,6 +4,7 @@
 // (tiny arithmetic), so the rules that matter are coalesced rows and one pass.
 #pragma once
 #include "common.h"
+#include "token.h"
 
 namespace RIFT_NS {
 
@@ -603,19 +604,6 @@ __global__ void ego_dropmask_kernel(int bs, float p, uint32_t seed, uint32_t str
   mask[idx] = (i >= 3 && uniform01(seed, stream, (uint32_t)idx) < p) ? 1 : 0;
 }
 
-// agent tokens: x[b][a] = (a == 0 ? x_ego[b] : valid ? nat[b*A+a] : 0) + type_emb[cat] (+ positional embedding of token row b*N + a); four channels
-__device__ __forceinline__ float4 agent_token_value(const int b, const int a, const int c, const float* __restrict__ nat, const float* __restrict__ x_ego,
-                                                    const uint8_t* __restrict__ valid_agent, const int8_t* __restrict__ category,
-                                                    const float* __restrict__ type_emb, int A, int N, const float* __restrict__ pe) {
-  const int ag = b * A + a;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a == 0) v = *reinterpret_cast<const float4*>(x_ego + (size_t)b * 128 + c);
-  else if (valid_agent[ag]) v = *reinterpret_cast<const float4*>(nat + (size_t)ag * 128 + c);
-  const float4 t = *reinterpret_cast<const float4*>(type_emb + (int)category[ag] * 128 + c);
-  v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-  if (pe) { const float4 q = *reinterpret_cast<const float4*>(pe + ((size_t)b * N + a) * 128 + c); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-  return v;
-}
 __device__ __forceinline__ void agent_token_body(const int idx, const float* __restrict__ nat, const float* __restrict__ x_ego,
                                                  const uint8_t* __restrict__ valid_agent, const int8_t* __restrict__ category,
                                                  const float* __restrict__ type_emb, int bs, int A, int N, float* __restrict__ X,
@@ -625,23 +613,6 @@ __device__ __forceinline__ void agent_token_body(const int idx, const float* __r
   *reinterpret_cast<float4*>(X + ((size_t)b * N + a) * 128 + c) = agent_token_value(b, a, c, nat, x_ego, valid_agent, category, type_emb, A, N, pe);
 }
 
-// polygon tokens (map_encoder.py:82-91): x = pooled + type + on_route + tl + (has ? speed_emb : unknown) (+ positional embedding of row b*N + A + m)
-__device__ __forceinline__ float4 polygon_token_value(const int b, const int m, const int c, const float* __restrict__ pooled, const int8_t* __restrict__ ptype,
-                                                      const uint8_t* __restrict__ on_route, const int8_t* __restrict__ tl,
-                                                      const uint8_t* __restrict__ has_sl, const float* __restrict__ speed_emb,
-                                                      const float* __restrict__ type_emb, const float* __restrict__ route_emb,
-                                                      const float* __restrict__ tl_emb, const float* __restrict__ unk_emb,
-                                                      int A, int Mp, int N, const float* __restrict__ pe) {
-  const int pg = b * Mp + m;
-  auto ld = [&](const float* p) { return *reinterpret_cast<const float4*>(p + c); };
-  const float4 a0 = ld(pooled + (size_t)pg * 128), a1 = ld(type_emb + (int)ptype[pg] * 128), a2 = ld(route_emb + (on_route[pg] ? 1 : 0) * 128),
-               a3 = ld(tl_emb + (int)tl[pg] * 128), a4 = has_sl[pg] ? ld(speed_emb + (size_t)pg * 128) : ld(unk_emb);
-  // same association as the scalar form: ((pooled + type) + route) + tl, then + speed
-  float4 v = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w);
-  v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
-  if (pe) { const float4 q = *reinterpret_cast<const float4*>(pe + ((size_t)b * N + A + m) * 128 + c); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-  return v;
-}
 __device__ __forceinline__ void polygon_token_body(const int idx, const float* __restrict__ pooled, const int8_t* __restrict__ ptype,
                                                    const uint8_t* __restrict__ on_route, const int8_t* __restrict__ tl,
                                                    const uint8_t* __restrict__ has_sl, const float* __restrict__ speed_emb,
@@ -654,14 +625,7 @@ __device__ __forceinline__ void polygon_token_body(const int idx, const float* _
       polygon_token_value(b, m, c, pooled, ptype, on_route, tl, has_sl, speed_emb, type_emb, route_emb, tl_emb, unk_emb, A, Mp, N, pe);
 }
 
-// agent and polygon tokens of the scene encoder in one launch (blocks [0, nblk_a) build agent tokens): two ~5 us launches in a row cost their
-// fixed part twice
-struct TokenP {
-  const float *nat, *x_ego; const uint8_t* valid_agent; const int8_t* category; const float* a_type_emb;
-  const float* pooled; const int8_t* ptype; const uint8_t* on_route; const int8_t* tl; const uint8_t* has_sl;
-  const float *speed_emb, *p_type_emb, *route_emb, *tl_emb, *unk_emb;
-  int bs, A, Mp, N, nblk_a; float* X; const float* pe;
-};
+// (TokenP, agent_token_value, polygon_token_value: token.h)
 __global__ void token_kernel(TokenP p) {
   if ((int)blockIdx.x < p.nblk_a)
     agent_token_body(blockIdx.x * blockDim.x + threadIdx.x, p.nat, p.x_ego, p.valid_agent, p.category, p.a_type_emb, p.bs, p.A, p.N, p.X, p.pe);
@@ -729,9 +693,95 @@ struct PrepP {
   const float *ref_pos, *ref_vec, *ref_ori; const uint8_t* ref_valid; int nLine; float* F6; float* r_pos; uint8_t* r_kpm; uint8_t* r_tiles;
   const uint8_t *map_valid, *static_valid; const float *st_pos, *st_head; int bs, A, Mp, S; uint8_t* kpm; float* pos;
   int nb[7];
+  // (round 6) the ranking of the history encoder's sequences inside this launch (rank_scene_body below): nrk = bs blocks at the HEAD of the
+  // grid (0: the ranking is its own launch, nat_rank_kernel)
+  int nrk; unsigned long long* rk_pub; unsigned int rk_epoch; int* aidx; int* cnt;
 };
 
+// ---------------------------------------------------------------------------
+// The ranking of the compacted history-encoder launch (nat_l0w.h: aidx[3 i + c] = the i-th marked agent slot of residue class c = slot % 3
+// in ascending slot order, cnt[c] = the class counts) as blocks of the preparation's own launch.  Rounds 3 - 5 ran it as nat_rank_kernel:
+// ONE workgroup scanning all bs * A marks behind the preparation, 13 us on the history chain, most of it the launch and 16 K scattered
+// 4-byte stores out of one CU.  Here block b (one per scene, first in the grid) derives its scene's marks from the raw validity (mark =
+// any of the first 21 samples && slot % A != 0, the rule of agent_feature_body), PUBLISHES its three class counts as one 64-bit word
+// (epoch << 32 | three 9-bit counts: one atomic store carries flag and value), adds up the words of the scenes before it (decoupled
+// look-back: its 256 threads read up to 256 predecessors each pass, waiting for a word until it carries this launch's epoch -- workgroups
+// are dispatched in block order and a block only ever waits for lower ones, so the wait ends) and writes its own ranks: a scene's ranks
+// are consecutive per class, i.e. <= 64 x 12 bytes per store instruction instead of 64 cache lines.  Every scene block is done a few
+// microseconds into a launch that lasts ~12; the history chain no longer waits for a ranking at all.  Bit-identical to nat_rank_kernel's
+// output (the same order), any A <= 256.  rk_pub: bs words that PERSIST between launches (zero at allocation: epoch 0 is never used).
+// RELAXED agent-scope atomics on purpose: the published word carries value and flag together, nothing else travels between the blocks,
+// and on this chip an agent-scope release / acquire is an L2 write-back / invalidate (the eight XCDs' L2s are not coherent with each
+// other: `buffer_wbl2 sc1` / `buffer_inv sc1`) -- the first version (release store, acquire loads, and before it __threadfence + a
+// counter) made the preparation 34 us long instead of 12 (profiles/r06_ab_rank_in_prep.txt).  A monotonic sc1 store / load goes to the
+// coherent level and costs a memory round trip.
+// ---------------------------------------------------------------------------
+#define RIFT_RK_M0 0x9249249249249249ull      // bits j with j % 3 == 0 (bit 63 included: 63 % 3 == 0)
+#define RIFT_RK_M1 0x2492492492492492ull      // j % 3 == 1
+#define RIFT_RK_M2 0x4924924924924924ull      // j % 3 == 2
+__device__ __forceinline__ unsigned long long rk_class_mask(int r) { return r == 0 ? RIFT_RK_M0 : r == 1 ? RIFT_RK_M1 : RIFT_RK_M2; }
+__device__ __forceinline__ void rank_scene_body(const PrepP& q, const int b) {
+  __shared__ unsigned long long s_mask[4];
+  __shared__ unsigned long long s_part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, A = q.A;
+  bool mark = false;
+  if (tid < A && tid != 0) {                       // slot % A != 0: the ego row is replaced by the ego state token (agent_encoder.py:87)
+    const uint8_t* v = q.agent_valid + ((size_t)b * A + tid) * q.Tfull;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) any |= v[i];
+    mark = any != 0;
+  }
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(mark);
+  if (lane == 0) s_mask[wave] = m;
+  __syncthreads();
+  // class of bit j of ballot word w: (wbase[w] + j) % 3
+  int wbase[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wbase[w] = (int)(((long long)b * A + 64 * w) % 3);
+  int own[3] = {0, 0, 0};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const unsigned long long mw = s_mask[w];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) own[c] += __builtin_popcountll(mw & rk_class_mask((c - wbase[w] + 3) % 3));
+  }
+  if (tid == 0)
+    __hip_atomic_store(q.rk_pub + b, ((unsigned long long)q.rk_epoch << 32) | ((unsigned long long)own[2] << 18) | ((unsigned long long)own[1] << 9) | (unsigned long long)own[0],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (relaxed: the word IS the message; see below)
+  // ---- look-back: the class counts of the scenes before this one (three 21-bit fields)
+  unsigned long long acc = 0ull;
+  for (int j = tid; j < b; j += 256) {
+    unsigned long long w;
+    while (true) {
+      w = __hip_atomic_load(q.rk_pub + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned int)(w >> 32) == q.rk_epoch) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    acc += (w & 0x1ffull) | (((w >> 9) & 0x1ffull) << 21) | (((w >> 18) & 0x1ffull) << 42);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if (lane == 0) s_part[wave] = acc;
+  __syncthreads();
+  const unsigned long long base = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+  if (mark) {
+    const int c = (wbase[wave] + lane) % 3;
+    int r = (int)((base >> (21 * c)) & 0x1fffffull);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w > wave) break;
+      const unsigned long long sel = s_mask[w] & rk_class_mask((c - wbase[w] + 3) % 3);
+      r += __builtin_popcountll(w < wave ? sel : (sel & ((1ull << lane) - 1ull)));
+    }
+    q.aidx[3 * r + c] = b * A + tid;
+  }
+  if (b == q.nrk - 1 && tid < 3) q.cnt[tid] = (int)((base >> (21 * tid)) & 0x1fffffull) + own[tid];
+}
+
 __device__ __forceinline__ void prep_body(const PrepP& q, int blk) {
+  if (blk < q.nrk) { rank_scene_body(q, blk); return; }
+  blk -= q.nrk;
   if (blk < q.nb[0]) { agent_feature_body(q.agent_pos, q.agent_head, q.agent_vel, q.agent_shape, q.agent_valid, q.nA, q.Tfull, q.F9, q.valid_agent, blk, q.hist_agent, q.A); return; }
   blk -= q.nb[0];
   if (blk < q.nb[1]) { map_feature_body(q.map_pp, q.map_pv, q.map_po, q.map_center, q.nPoly, q.F10, blk); return; }

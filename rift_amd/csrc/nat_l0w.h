@@ -170,14 +170,31 @@ __device__ __forceinline__ f32x4 l0w_sel(bool c, const f32x4 a, const f32x4 b) {
 template <bool FOLDED = false>
 __device__ __forceinline__ void l0w_layer_norm(const f32x4 (&x)[5][2], h16x8 (&xn)[5], const float* g, const float* b, int l4) {
   if (FOLDED) {
+    // statistics of all five row tiles first, ONE cancellation test for the call (common.h: ln_cancels -- a branch per tile kept the
+    // scheduler from overlapping the tiles' reductions), then the normalisation
+    float mean[5], var[5];
+    bool bad = false;
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt) {
       const f32x4 u = x[mt][0], w = x[mt][1];
       const f32x4 s4 = u + w, q4 = u * u + w * w;
-      const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 32.0f);
+      mean[mt] = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 32.0f);
       const float ex2 = rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 32.0f);
-      const float r = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + 1e-5f), c = -mean * r;
-      xn[mt] = l0w_pack8(u * r + c, w * r + c);
+      const float m2 = mean[mt] * mean[mt];
+      var[mt] = ex2 - m2;
+      bad |= ln_row_cancels(m2, var[mt]);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0ull, 0)) {      // a row whose mean dwarfs its spread: the centred form, as torch
+#pragma unroll
+      for (int mt = 0; mt < 5; ++mt) {
+        const f32x4 du = x[mt][0] - mean[mt], dw = x[mt][1] - mean[mt], d4 = du * du + dw * dw;
+        var[mt] = rows_sum((d4[0] + d4[1]) + (d4[2] + d4[3])) * (1.0f / 32.0f);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+      const float r = rsqrtf(fmaxf(var[mt], 0.f) + 1e-5f), c = -mean[mt] * r;
+      xn[mt] = l0w_pack8(x[mt][0] * r + c, x[mt][1] * r + c);
     }
     return;
   }

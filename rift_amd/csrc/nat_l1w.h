@@ -122,13 +122,31 @@ void l1w_launch(const NatL1WP& p, int grid, hipStream_t stream);
 template <bool FOLDED = false>      // (nat_l0w.h: l0w_layer_norm)
 __device__ __forceinline__ void l1w_layer_norm(const f32x4 (&x)[3][4], h16x8 (&xn)[3][2], const float* g, const float* b, int l4) {
   if (FOLDED) {
+    // statistics of the three row tiles first, ONE cancellation test for the call (nat_l0w.h: l0w_layer_norm), then the normalisation
+    float mean[3], var[3];
+    bool bad = false;
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
       const f32x4 s4 = (x[mt][0] + x[mt][1]) + (x[mt][2] + x[mt][3]);
       const f32x4 q4 = (x[mt][0] * x[mt][0] + x[mt][1] * x[mt][1]) + (x[mt][2] * x[mt][2] + x[mt][3] * x[mt][3]);
-      const float mean = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 64.0f);
+      mean[mt] = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 64.0f);
       const float ex2 = rows_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / 64.0f);
-      const float r = rsqrtf(fmaxf(ex2 - mean * mean, 0.f) + 1e-5f), c = -mean * r;
+      const float m2 = mean[mt] * mean[mt];
+      var[mt] = ex2 - m2;
+      bad |= ln_row_cancels(m2, var[mt]);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0ull, 0)) {      // a row whose mean dwarfs its spread: the centred form, as torch
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { const f32x4 d = x[mt][nt] - mean[mt]; d4 += d * d; }
+        var[mt] = rows_sum((d4[0] + d4[1]) + (d4[2] + d4[3])) * (1.0f / 64.0f);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      const float r = rsqrtf(fmaxf(var[mt], 0.f) + 1e-5f), c = -mean[mt] * r;
       xn[mt][0] = l0w_pack8(x[mt][0] * r + c, x[mt][1] * r + c);
       xn[mt][1] = l0w_pack8(x[mt][2] * r + c, x[mt][3] * r + c);
     }

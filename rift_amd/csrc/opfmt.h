@@ -27,7 +27,10 @@
 // GELU is evaluated in packed fp16 in the bf16 build (common.h: gelu_pk16x2) and its result is left as it comes out: an fp16 operand word
 // (11 significand bits against bf16's 8; same MFMA rate) -- no conversion back to bf16, and the fc2 weight fragments are packed as fp16 to
 // match (|w| < 10: far inside the format's range).  RIFT_GELU_F32 (diagnostic build define) restores the fp32 rational GELU and bf16 words.
-#if !RIFT_OP_F16 && !defined(RIFT_GELU_F32)
+// Round 6: the fp16-operand build evaluates the same packed-fp16 form (it kept the fp32 rational GELU through round 5: 36 issue slots per four
+// elements against 26, the whole of its +12 % step time over the bf16 build).  RIFT_F16_GELU_F32 (diagnostic define) restores the rational
+// form in the fp16 build.
+#if !defined(RIFT_GELU_F32) && !(RIFT_OP_F16 && defined(RIFT_F16_GELU_F32))
 #define RIFT_GELU_PK16 1
 #else
 #define RIFT_GELU_PK16 0

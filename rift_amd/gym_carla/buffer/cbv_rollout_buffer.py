@@ -78,6 +78,25 @@ class CBVRolloutBuffer:
             if h:
                 h.reset()
 
+    def reset_buffer_reversibly(self):
+        """reset_buffer() that can be undone: the committed rows, the open episodes and the host mirrors' batch dimensions move into the
+        returned token instead of being dropped.  `restore(token)` puts them back (a failed update keeps its generation of rollout data, as
+        the reference does: its reset follows a successful fit, rlft_pluto.py:244-250); dropping the token is what frees the rows."""
+        token = {"rows": self._rows, "open": self._open, "full": self.buffer_full, "data": self.buffer_data,
+                 "host": {k: (dict(h.dims), h.has_ref_logits) for k, h in self._host.items() if h}}
+        self.reset_buffer()
+        return token
+
+    def restore(self, token):
+        """Undo reset_buffer_reversibly (nothing may have been stored in between: the pinned mirror's slots still hold the old generation)."""
+        assert not self._rows and not self._open, "rows were stored after the reset: the host mirror's slots are overwritten"
+        self._rows, self._open, self.buffer_full, self.buffer_data = token["rows"], token["open"], token["full"], token["data"]
+        for k, (dims, has_ref) in token["host"].items():
+            h = self._host.get(k)
+            if h:
+                h.dims, h.has_ref_logits = dict(dims), has_ref
+                h.version += 1
+
     # ---- the pinned host mirror of the HBM arena ---------------------------------------------------------------------------
     def attach_host_replay(self, obs_keys: Iterable[str]):
         """Stream these observation keys as well (rows already committed are laid in now)."""

@@ -325,7 +325,12 @@ class RLFTPluto(PLUTO):
         # epoch; top-1 = the FIRST epoch with the minimal validation loss, exactly what the strict `<` of the per-epoch decision selects, and
         # the checkpoint is written from that epoch's snapshot.  The non-finite flag is sticky and checked at that one read.
         deferred = world == 1 and not cfg.get("checkpoint_every_improvement", False)
-        trunk_after, buffer_reset = None, False
+        trunk_after, buffer_reset, undo_reset = None, False, None
+
+        def uncommitted():                  # the update did not commit: the rollout buffer keeps this generation's data
+            if undo_reset is not None:
+                self.buffer.restore(undo_reset)
+
         try:
             if deferred:
                 own = self.train_model.state_dict()
@@ -369,7 +374,10 @@ class RLFTPluto(PLUTO):
                 # outcome happens now, in the device's shadow -- the frozen trunk's identity (nothing queued writes it) and the buffer reset
                 # (4096 committed rows to free, 9 ms; the arena was uploaded from the pinned mirror before the first epoch)
                 trunk_after = self._trunk_version(self.train_model)
-                self.buffer.reset_buffer()
+                # (reversibly: the rows move into a token.  A non-finite flag at the read below, or a checkpoint that cannot be written,
+                # puts them back -- the generation's rollout data survives a failed update, as in the reference, whose reset follows the
+                # fit; the token is dropped -- the 9 ms of freeing -- by a helper thread once the checkpoint is on disk)
+                undo_reset = self.buffer.reset_buffer_reversibly()
                 buffer_reset = True
                 host = table.cpu()                                     # the update's one host read
                 trainer.check_finite()
@@ -401,14 +409,25 @@ class RLFTPluto(PLUTO):
                     snapshot = {k: own[k].detach().clone() for k in moving}
                     if rank == 0 and cfg.get("checkpoint_every_improvement", False):
                         self._write_checkpoint(best_path, base_cpu, snapshot, epoch, e_i)
+        except BaseException:
+            uncommitted()
+            raise
         finally:
             trainer.close()             # the data-parallel hooks sit on the model-owned engine: detach them also when an epoch raises
         mark("epochs")
-        if base_cpu is None:               # first update of a policy without a checkpoint: the frozen part comes off the device once
-            base_cpu = {k: v.detach().cpu() for k, v in self.train_model.state_dict().items()}
-        if rank == 0 and not cfg.get("checkpoint_every_improvement", False):
-            self._write_checkpoint(best_path, base_cpu, snapshot, best_epoch, e_i)
+        try:
+            if base_cpu is None:               # first update of a policy without a checkpoint: the frozen part comes off the device once
+                base_cpu = {k: v.detach().cpu() for k, v in self.train_model.state_dict().items()}
+            if rank == 0 and not cfg.get("checkpoint_every_improvement", False):
+                self._write_checkpoint(best_path, base_cpu, snapshot, best_epoch, e_i)
+        except BaseException:
+            uncommitted()
+            raise
         mark("write_checkpoint")
+        if undo_reset is not None:           # committed: the rows are freed off the critical path (the main thread goes on to the reload)
+            import threading
+            box, undo_reset = [undo_reset], None
+            threading.Thread(target=box.clear, daemon=True).start()
         if process_group is not None:
             torch.distributed.barrier(group=process_group)         # the checkpoint of rank 0 is on disk before anyone reloads
         self.last_fit = {"history": history, "best_val_loss": best, "checkpoint": best_path.as_posix(), "lr": lr}

@@ -259,10 +259,11 @@ class RLFTTrainer:
         self.model, self.kind, self.kind_id = model, kind, _ffi.LOSS_KINDS["ppo" if kind == "rtr" else kind]
         self.lambda_rl = 5.0                                     # rtr_trainer.py:153
         # The trajectory / prediction / ref-free heads feed none of the RLFT objectives (dead outputs), so the trainer
-        # switches them off for rift / grpo / ppo / reinforce -- whatever the model's default says -- and on for sft / rtr, whose teacher
-        # label is read off the candidate trajectories (sft_trainer.py:186-199).  close() restores the caller's setting.
-        self._need_traj_before = getattr(model, "need_traj", None)
-        model.need_traj = kind in ("sft", "rtr")
+        # computes them for sft / rtr only, whose teacher label is read off the candidate trajectories (sft_trainer.py:186-199).  The
+        # selection is the TRAINER's (F_NEED_TRAJ of its own forwards): the model's `need_traj` -- what PlanningModel.forward and the
+        # rollout side read -- is not touched, so a trainer that is never closed, or two trainers of different kinds on one model, leave
+        # every other consumer's outputs alone (round-5 advisor).
+        self.need_traj = kind in ("sft", "rtr")
         self.lr, self.epochs, self.warmup_epochs = lr, epochs, warmup_epochs
         self.gradient_clip_val = gradient_clip_val
         self.pg = process_group
@@ -388,7 +389,7 @@ class RLFTTrainer:
             self.out.probability = self._prob.data_ptr()
             self.lo.argmax_rm = self._argmax.data_ptr()
             self._traj = None
-        want_traj = bool(getattr(self.model, "need_traj", False))
+        want_traj = self.need_traj
         self.out.hidden = self._hidden.data_ptr() if (self.kind in ("ppo", "rtr") or want_traj) else None
         if want_traj:
             # every output of PlanningModel.forward (pluto_model.py:167-223), as the reference's training_step computes them
@@ -443,8 +444,6 @@ class RLFTTrainer:
             self.dp_buf = None
         if hasattr(self.model, "_engine_users"):
             self.model._engine_users.discard(self)
-        if self._need_traj_before is not None:          # the caller's output selection (the rollout side wants every head)
-            self.model.need_traj, self._need_traj_before = self._need_traj_before, None
 
     def forward_loss(self, *args, **kwargs):
         """forward + objective (+ pi_head backward into .grad) on the current stream.  Returns the device f64 loss scalar.  With `clip_val`
@@ -469,7 +468,7 @@ class RLFTTrainer:
         self._A = fb.A
         self._outputs(fb.bs, fb.R)
         self._set_shard(fb, shard)
-        flags = (_ffi.F_TRAIN if train else 0) | (_ffi.F_NEED_TRAJ if getattr(self.model, "need_traj", False) else 0) | \
+        flags = (_ffi.F_TRAIN if train else 0) | (_ffi.F_NEED_TRAJ if self.need_traj else 0) | \
                  (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | \
                 (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0) | flags_extra
         self.step_count += 1
@@ -506,7 +505,7 @@ class RLFTTrainer:
         self._A = fb.A
         self._outputs(fb.bs, fb.R)
         self._set_shard(fb, shard)
-        flags = (_ffi.F_TRAIN if train else 0) | _ffi.F_DEFER_HEAD | (_ffi.F_NEED_TRAJ if getattr(self.model, "need_traj", False) else 0) | \
+        flags = (_ffi.F_TRAIN if train else 0) | _ffi.F_DEFER_HEAD | (_ffi.F_NEED_TRAJ if self.need_traj else 0) | \
             (_ffi.F_FP32 if self.model.compute_precision == "fp32" else 0) | (_ffi.F_NO_DROP if getattr(self.model, "_no_drop", False) else 0)
         self.step_count += 1
         self.engine.forward_raw(fb, self.out, flags, (self.seed_base + self.step_count) & 0xFFFFFFFF)

@@ -142,10 +142,12 @@ def test_config0_grpo_step_on_dumped_carla_shaped_scenes(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("agents,polygons,rmax", [(76, 20, 6), (77, 20, 6), (64, 20, 7)])
+@pytest.mark.parametrize("agents,polygons,rmax", [(76, 20, 6), (77, 20, 6), (92, 20, 6), (93, 20, 6), (64, 20, 7)])
 def test_fused_kernel_size_limits(ffi, agents, polygons, rmax):
-    """At and just beyond what the standard one-scene-per-workgroup kernels hold: N = 96 tokens exactly fills the encoder / decoder-key
-    tiles (76 agents + 20 polygons); at N = 97 encoder and decoder run their dense-traffic variants (enc_w_kernel, dec_w_kernel<., true>); R = 7 runs the standard decoder (R <= 8) -- all three against the oracle, bf16 and fp32, eval and the loss."""
+    """At and just beyond what the one-scene-per-workgroup kernels hold: N = 96 tokens exactly fills the fused encoder's 96-row layout and the
+    decoder's six key tiles (76 agents + 20 polygons); N = 97 .. 112 run the fused encoder on its 112-row layout (round 6: enc_fused112_kernel)
+    and the decoder's eight-key-tile variant; at N = 113 the encoder is the two-pass dense-traffic kernel (enc_w_kernel); R = 7 runs the
+    standard decoder (R <= 8) -- all against the oracle, bf16 and fp32, eval and the loss."""
     scenes = [syn.make_scene(6000 + i, num_agents=agents, num_polygons=polygons, r_min=rmax, r_max=rmax) for i in range(3)]
     eng = ffi.Engine("cuda:0")
     eng.load_state_dict({k: v.clone() for k, v in H.weights().items()})
@@ -156,7 +158,8 @@ def test_fused_kernel_size_limits(ffi, agents, polygons, rmax):
     eng.close()
     assert ("enc_fused_kernel" in rep) == (agents + polygons <= 96)
     assert "dec_w_kernel" in rep
-    assert ("enc_w_kernel" in rep) == (agents + polygons > 96)        # the dense-traffic encoder, which also writes the decoder's K | V^T operands
+    assert ("enc_fused112_kernel" in rep) == (96 < agents + polygons <= 112)
+    assert ("enc_w_kernel" in rep) == (agents + polygons > 112)       # the dense-traffic encoder, which also writes the decoder's K | V^T operands
     _check(ffi, scenes, train=False)
 
 

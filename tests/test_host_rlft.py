@@ -518,6 +518,47 @@ def test_deferred_top1_decision_writes_the_checkpoint_of_the_per_epoch_decision(
 
 
 @pytest.mark.gpu
+def test_failed_update_keeps_the_rollout_buffer(tmp_path, monkeypatch):
+    """Round-5 advisor: the deferred top-1 path resets the buffer in the device's shadow, BEFORE the update's one host read, the finiteness
+    check and the checkpoint write.  The reset is reversible now (CBVRolloutBuffer.reset_buffer_reversibly): an update that raises at any
+    of those points leaves the buffer as it found it -- full, same rows, host mirror usable -- as the reference does (its reset follows a
+    successful fit, rlft_pluto.py:244-250); the next, successful update trains on that data and only then empties the buffer."""
+    from rift_amd.planning import CBV_POLICY_LIST
+    torch.cuda.set_device(0)
+    cfg = {'num_scenario': 1, 'ROOT_DIR': str(tmp_path), 'model_path': 'ckpt', 'device': 'cuda:0', 'compute_precision': 'fp32',
+           'rlft': {'epochs': 2, 'warmup_epochs': 1, 'train_batch_size': 16, 'val_batch_size': 16, 'lr': 1e-3}}
+    torch.manual_seed(0)
+    pol = CBV_POLICY_LIST['rift_pluto'](cfg, None)
+    pol.load_model(resume=True)
+    pol.set_mode('train')
+    buf = _filled_buffer(48, with_ref=False)
+    pol.set_buffer(buf)
+    n0, rows0 = buf.buffer_pos, list(buf._rows)
+    real_write = type(pol)._write_checkpoint
+
+    def failing_write(self, *a, **k):
+        raise OSError("disk full")
+
+    monkeypatch.setattr(type(pol), "_write_checkpoint", failing_write)
+    with pytest.raises(OSError):
+        pol.train(1)
+    assert buf.buffer_full and buf.buffer_pos == n0 and all(a is b for a, b in zip(buf._rows, rows0))
+    assert not list((tmp_path / 'ckpt').rglob("*.ckpt"))
+    # the finiteness check raising at the one host read (the sticky flag): same outcome
+    from rift_amd.planning.fine_tuner.rlft import trainer as T
+    monkeypatch.setattr(type(pol), "_write_checkpoint", real_write)
+    real_check = T.RLFTTrainer.check_finite
+    monkeypatch.setattr(T.RLFTTrainer, "check_finite", lambda self: (_ for _ in ()).throw(FloatingPointError("non-finite decoder queries")))
+    with pytest.raises(FloatingPointError):
+        pol.train(2)
+    assert buf.buffer_full and buf.buffer_pos == n0 and all(a is b for a, b in zip(buf._rows, rows0))
+    monkeypatch.setattr(T.RLFTTrainer, "check_finite", real_check)
+    fit = pol.train(3)                     # the same data, now committed
+    assert len(fit["history"]) == 2 and buf.buffer_pos == 0 and not buf.buffer_full
+    assert len(list((tmp_path / 'ckpt').rglob("*.ckpt"))) == 1
+
+
+@pytest.mark.gpu
 def test_rollout_side_inference_step():
     """PlutoInference: eval-mode HIP forward with every output, then top-k candidate trimming (integer flat indices identical to
     those from the oracle's logits in exact-fp32 mode), frame transforms and the waypoint PID."""

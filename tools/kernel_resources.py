@@ -9,7 +9,8 @@ out = ""
 for tu, extra in (("engine.hip", []), ("dec_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l2w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]), ("nat_l01w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
                           ("enc_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
                           ("pe_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
-                          ("fo_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
+                          ("fo_w.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"]),
+                          ("enc112.hip", ["-fno-honor-nans", "-mno-amdgpu-ieee"])):
     cmd = [b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage"] + extra + \
           [os.path.join(b.CSRC, tu), "-o", "/tmp/_kr.o"] + sys.argv[2:]
     out += subprocess.run(cmd, capture_output=True, text=True).stderr
