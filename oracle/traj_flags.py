@@ -4,7 +4,11 @@ R/ = rift/cbv/planning/fine_tuner/rlft/traj_eval/traj_evaluator.py
 
 PARITY: the other-vehicle forecast (get_other_vehicle_rollout and callees) IS pinned -- tests/golden/other_vehicles.npz holds the output of
 the reference's own code on seeded actor readings (tests/golden/gen_golden.py other_vehicles) and the restatement matches it bit for bit.
-UNPINNED: the two flag matrices -- the reference computes these with third-party code that is not importable here -- Shapely==2.0.6
+PINNED since round 6: the off-road LOOKUP (get_off_road_matrix from the point where the mask exists, global_to_pixel) --
+tests/golden/off_road.npz holds the output of the reference's own get_off_road_matrix / global_to_pixel / fill_polygon (R/:277-325), run
+as written on four poses with a cv2.fillPoly stand-in that writes a seeded pattern into the mask it is handed (gen_golden.py off_road);
+the restatement below and the device kernel match it bit for bit (tests/test_oracle_critic.py, tests/test_gpu_parity.py).
+UNPINNED: the collision matrix and the mask RASTERISATION -- the reference computes these with third-party code that is not importable here -- Shapely==2.0.6
 (requirements.txt:34; call sites R/:15-16,259-271) and opencv_python==4.10.0.84 (requirements.txt:21; call site R/:323-325) -- and it has
 no tests or fixtures for them.  What is restated is the published behaviour of the calls the reference makes:
   * `STRtree.query(geometry)` with no predicate (shapely 2.0 API): "the integer indices of all geometries in the tree whose extents

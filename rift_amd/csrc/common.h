@@ -207,8 +207,17 @@ __device__ __forceinline__ f32x2_t unpack_h2(unsigned int u) {
 // minus a small term), the operand word's error against erf GELU in double is 1.76e-3 rms for N(0, 1.5) inputs against 1.70e-3 for the
 // correctly rounded bf16 word (tools/ubench/gelu_pk16.hip: max 1.76e-2 / 1.56e-2, rms 4.93e-3 / 4.81e-3 over [-8, 8]), and the epilogue is
 // 36 -> 28 issue slots per four elements of which none is a two-pass packed-fp32 instruction (97 -> 81 ticks per element in that
-// micro-benchmark).  Two pairs run in lock step: a v_pk_*_f16 result read by the NEXT instruction costs a wait state.  The fp16-operand
-// build keeps the fp32 rational form (its 11-bit consumer would see this evaluation: rms 3.3e-4 against 2.1e-4).
+// micro-benchmark).  Two pairs run in lock step: a v_pk_*_f16 result read by the NEXT instruction costs a wait state.
+// Round 6: the fp16-operand build evaluates this form too (it kept the fp32 rational form through round 5).  What its 11-bit consumer
+// sees on N(0, 1.5) inputs: operand-word error 3.35e-4 rms against 2.12e-4 for the correctly rounded fp16 word -- of which 3.06e-4 is the
+// price of rounding the INPUT to fp16 (exact GELU of the fp16-rounded input), not of the polynomial -- and end to end nothing: the
+// benchmark batch's four objectives stay at 8e-6 .. 1e-5 of the oracle, the small-batch envelope is unchanged (tests/test_gpu_parity.py
+// header), and the build's step time falls from 0.627 to 0.580 ms (profiles/r06_ab_fp16_gelu.txt).  One instruction-level fact behind
+// the accounting (profiles/r06_valu_occupancy.txt): a v_pk_*_f16 instruction costs 1.6 plain VALU slots on this chip, not 1.
+// RANGE: the conversion to fp16 is not clamped (a clamp is two more packed instructions per four elements, 2 % of the NAT kernels): a
+// pre-activation beyond 65504 becomes inf, travels through fc2 into the residual stream and raises the non-finite flag
+// (rift_check_finite; tests/test_gpu_parity.py::test_hidden_layer_overflow_raises_the_non_finite_flag) -- the contract of every fp16
+// operand (opfmt.h), never silent garbage.
 typedef _Float16 gelu_h2 __attribute__((ext_vector_type(2)));
 #define RIFT_GELU_H0 0.04531748f
 #define RIFT_GELU_H1 -0.17138292f

@@ -1042,7 +1042,11 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
       launch_front();
       c->stream = own;
       HIPCHK(c, hipEventRecord(c->ev_prep, c->prep_stream));
-      HIPCHK(c, hipStreamWaitEvent(own, c->ev_prep, 0));
+      // (round 6) when the history chain stays on the prepare stream and the map chain forks onto the side stream (the update loop's case),
+      // the caller's queue gets nothing before the join, and both joined chains are behind the preparation already: its own wait for the
+      // preparation would be a third one on the same fact (one event operation costs the host what a launch does)
+      const bool join_covers = c->two_streams && c->nat_fused && !f.fp32 && c->nat_aside && c->side_gate <= 0 && !c->dp.on;
+      if (!join_covers) HIPCHK(c, hipStreamWaitEvent(own, c->ev_prep, 0));
     } else {
       launch_front();
     }

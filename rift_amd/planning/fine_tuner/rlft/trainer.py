@@ -158,7 +158,13 @@ def _dispatches_beside(a: torch.cuda.Stream, b: torch.cuda.Stream, dev) -> float
     one-block spin of `_runs_beside` cannot tell the first two apart (its grid is through the pipe at once)."""
     key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
     if key not in _PROBE_BUF:
-        _PROBE_BUF[key] = (torch.zeros(128 * 1024 * 1024, device=dev), torch.zeros(64, device=dev))
+        # 512 MB fill the chip for ~0.25 ms; on a device short of memory a smaller buffer still fills it for its (shorter) duration -- at
+        # most an eighth of what is free, at least 32 MB (below that the grid is through the pipe too soon: the caller falls back)
+        free = torch.cuda.mem_get_info(dev)[0]
+        n = min(128 * 1024 * 1024, int(free // 8) // 4)
+        if n < 8 * 1024 * 1024:
+            raise RuntimeError("not enough free device memory for the dispatch-pipe probe")
+        _PROBE_BUF[key] = (torch.zeros(n, device=dev), torch.zeros(64, device=dev))
     big, x = _PROBE_BUF[key]
     e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     torch.cuda.synchronize(dev)
@@ -191,14 +197,31 @@ def _pipeline_streams(dev, main: torch.cuda.Stream, probe: bool = True):
     if prio:
         _STREAMS[key] = tuple(torch.cuda.Stream(device=dev, priority=int(x)) for x in prio.split(","))
         return _STREAMS[key]
-    if not probe or os.environ.get("RIFT_STREAM_PROBE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
+    mode = os.environ.get("RIFT_STREAM_PROBE", "1")
+    if not probe or mode == "0" or (mode == "queue" and not hasattr(torch.cuda, "_sleep")):      # (torch.cuda._sleep is the QUEUE probe's spin kernel only)
         _STREAMS[key] = (_shared_stream(dev, "update"), _shared_stream(dev, "prefetch"), None)
         return _STREAMS[key]
     pool = [torch.cuda.Stream(device=dev) for _ in range(12)]
+    try:
+        chosen = _probe_pool(dev, main, pool, mode)
+    except Exception as e:      # noqa: BLE001 -- an out-of-memory probe buffer or any runtime error in ~170 diagnostic launches must not abort trainer construction
+        _PROBE_BUF.clear()
+        print(f"[rift] stream probe failed ({type(e).__name__}: {e}); using the shared unprobed streams", file=sys.stderr)
+        _STREAMS[key] = (_shared_stream(dev, "update"), _shared_stream(dev, "prefetch"), None)
+        return _STREAMS[key]
+    _PROBE_BUF.clear()                        # (the probe buffer goes back to the caching allocator ...
+    torch.cuda.empty_cache()                  # ... and from there to the device: half a gigabyte should not stay reserved for a one-time probe)
+    _STREAMS[key] = tuple(chosen)
+    _STREAMS[(key[0], "pool")] = pool         # (the unused ones stay alive: destroying them would hand their queues to the next stream created)
+    return _STREAMS[key]
+
+
+def _probe_pool(dev, main, pool, mode):
+    """The three streams of `pool` that dispatch beside the caller's stream and beside each other (see _pipeline_streams)."""
     # Round 5: the probe that decides is `_dispatches_beside` (dispatch PIPES, not just queues): the residual slow mode of the queue probe --
     # 1 fresh process of 14 at 0.72 instead of 0.58 ms per step, and whole legs of earlier rounds' profile runs -- was two of the four streams
     # on one pipe.  RIFT_STREAM_PROBE=queue restores the one-block probe.
-    if os.environ.get("RIFT_STREAM_PROBE", "1") == "queue":
+    if mode == "queue":
         ok = lambda a, b: _runs_beside(a, b, dev) and _runs_beside(b, a, dev)
         chosen = []
         for s in pool:
@@ -226,10 +249,7 @@ def _pipeline_streams(dev, main: torch.cuda.Stream, probe: bool = True):
             print(f"[rift] pipeline streams: pool indices {[pool.index(c) for c in chosen]}, worst pair {best:.2f}", file=sys.stderr)
             for r in m:
                 print("[rift]   " + " ".join(f"{v:5.2f}" for v in r), file=sys.stderr)
-    _PROBE_BUF.clear()                        # (the 512 MB probe buffer goes back to the allocator)
-    _STREAMS[key] = tuple(chosen)
-    _STREAMS[(key[0], "pool")] = pool         # (the unused ones stay alive: destroying them would hand their queues to the next stream created)
-    return _STREAMS[key]
+    return chosen
 
 
 class RLFTTrainer:

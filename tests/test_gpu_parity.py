@@ -906,6 +906,33 @@ def test_one_pass_layernorm_survives_rows_whose_mean_dwarfs_their_spread(ffi, mo
         assert e < 3e-2 * max(1.0, scale), (mode, c, e)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_hidden_layer_overflow_raises_the_non_finite_flag(ffi, mode):
+    """Round-5 advisor: the packed-fp16 GELU converts the fc1 pre-activation to fp16 without a clamp and the hidden layer stays an fp16
+    operand (both builds): a pre-activation beyond 65504 becomes inf.  That must not turn into silent garbage: the inf travels through fc2
+    into the residual stream and the encoder / decoder / policy-head kernels raise the sticky non-finite flag (exponent bit pattern), which
+    `check_finite` turns into an error at the next host read -- the same contract as every other fp16 operand (opfmt.h).  The overflow is
+    made by adding 1e5 to one NATLayer's fc1 bias; the unmodified weights pass the check."""
+    gold, batch, sd = H.load_case("full")
+    data = batch["cur_pluto_feature_torch"]
+    key = "agent_encoder.history_encoder.levels.0.blocks.0.mlp.fc1.bias"
+    assert key in sd
+    for bump, bad in ((0.0, False), (1.0e5, True)):
+        sdc = {k: v.clone() for k, v in sd.items()}
+        sdc[key] = sdc[key] + bump
+        eng = _engine(ffi, mode)
+        eng.load_state_dict(sdc)
+        out = eng.forward(data, need_traj=False)
+        if bad:
+            with pytest.raises(RuntimeError, match="finite"):
+                eng.check_finite()
+            eng.check_finite()            # (the flag is cleared by the read that reported it)
+        else:
+            eng.check_finite()
+            assert torch.isfinite(out["probability"]).all()
+        eng.close()
+
+
 def test_ranking_inside_the_preparation_launch_equals_the_ranking_kernel(ffi, monkeypatch):
     """Round 6: the ranks of the compacted history-encoder launch written by the first bs blocks of prep_kernel (kernels.h: rank_scene_body,
     last-block scan over per-scene class counts) against nat_rank_kernel behind the preparation (RIFT_RANK_IN_PREP=0) and against numpy:
