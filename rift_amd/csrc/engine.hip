@@ -1158,7 +1158,9 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         RIFT_SET_DS(q);
         { if (c->dg.nat_ts == 3) { q.ts = A_alloc<long long>(c, 64); tap(c, "nat_ts", (float*)q.ts, 128); } }
         c->prof_flops = 2.0 * rows * (20.0 * C * C + 4.0 * ksz * C);
-        const int l2grid = std::min(cdiv(cdiv(nA, 3), 8), c->nat_grid);
+        // (round 6: up to one tile per workgroup -- a launch that does not fill the chip deals its tiles wave-major and waves without a tile skip
+        // the arithmetic, so a small batch runs two or three waves on each of many CUs instead of eight on a few; nat_l2w.hip)
+        const int l2grid = std::min(cdiv(nA, 3), c->nat_grid);
         launch_call(c, "nat_l2w_kernel", [&] { l2w_launch(q, l2grid, c->stream); });
         continue;
       }

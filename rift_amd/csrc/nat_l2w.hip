@@ -67,8 +67,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   uint32_t lds0 = lds00, voff = (uint32_t)lane * 16u;
   const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
   RIFT_SEQ_COUNT(p.cnt, p.nseq);
-  const int ntiles = (sq_n + 2) / 3, nrounds = (ntiles + 7) >> 3;
-  const int my_rounds = blockIdx.x < nrounds ? (nrounds - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  // How the tiles are dealt.  A chip-filling launch (at least one full round of 8 G tiles): round r of workgroup b is tiles (r G + b) 8 + wave,
+  // as in rounds 2 - 5 -- the workgroups without a last round END EARLY and hand their CU to the neighbouring queues' kernels.  (Round 6 tried
+  // the leftover tiles WAVE-major over all workgroups with the tile-less waves skipping the arithmetic: the kernel alone 93 -> 84.5 us, the
+  // pipelined 256-scene step +10 us -- every CU is held to the end of the launch and the step is bound by CU-TIME, not by this kernel's
+  // latency: profiles/r06_ab_l2_dealing.txt.)  A launch far from filling the chip (at most 4 G tiles: batches up to ~50 scenes) deals
+  // its tiles wave-major -- tile = wave G + b -- so that every CU runs two or three waves, one per SIMD, instead of a few CUs eight: 33 -> 26 us
+  // at 32 scenes; waves without a tile only keep the operand stream's protocol.  Same tiles, same arithmetic: bit-identical either way.
+  const int ntiles = (sq_n + 2) / 3;
+  const int G = (int)gridDim.x, nrounds = (ntiles + 7) >> 3;
+#ifdef RIFT_L2_TILE_MAJOR      // (diagnostic build define: tile-major whatever the size)
+  const bool wave_major = false;
+#else
+  const bool wave_major = ntiles <= 4 * G;      // (at most one wave per SIMD; between 4 G and 8 G tiles -- 64 scenes -- wave-major measured slower: 0.195 against 0.185 ms per step)
+#endif
+  const int full = wave_major ? 0 : ((int)blockIdx.x < nrounds ? (nrounds - 1 - (int)blockIdx.x) / G + 1 : 0);
+  const int trem = wave_major ? ntiles : 0;
+  const int my_rounds = full + ((int)blockIdx.x < trem ? 1 : 0);
   const int total = 20 * my_rounds;                      // groups this workgroup consumes
   int tsn = 0;
 #define L2TS() do { if (p.ts && blockIdx.x == 0 && tid == 0 && tsn < 60) p.ts[tsn++] = clock64(); } while (0)
@@ -142,14 +157,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   int s = 0;                                             // sequence number of the next group to open
 #pragma unroll 1
-  for (int round = blockIdx.x; round < nrounds; round += gridDim.x) {
+  for (int rr = 0; rr < my_rounds; ++rr) {
     {   // opaque zeros (see dec_w.hip): keep the addresses of the 20 groups from being hoisted out of the loop
       int zv, zs;
       asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
       asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
       lane = (tid & 63) + zv; l15 = lane & 15; l4 = lane >> 4; voff = (uint32_t)lane * 16u; wv = wv0 + zs; lds0 = lds00 + (uint32_t)zs;
     }
-    const int tile = round * 8 + wv;
+    const int last_idx = wv * G + (int)blockIdx.x;
+    const int tile = rr < full ? (rr * G + (int)blockIdx.x) * 8 + wv : full * 8 * G + last_idx;
+    if (__builtin_amdgcn_readfirstlane((int)(rr >= full && last_idx >= trem))) {      // a wave without a tile in the last round: the stream's protocol only
+#pragma unroll 1
+      for (int g = 0; g < 20; ++g) { boundary(s); ++s; }
+      continue;
+    }
     const int qa = l15 / L, qt = l15 - qa * L;           // this lane row: agent qa (3 = the idle row 15), step qt
     const int seq = tile * 3 + qa;
     const bool row_ok = qa < 3 && RIFT_SEQ_LIVE(seq);

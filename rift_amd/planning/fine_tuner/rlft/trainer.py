@@ -210,7 +210,8 @@ def _pipeline_streams(dev, main: torch.cuda.Stream, probe: bool = True):
         _STREAMS[key] = (_shared_stream(dev, "update"), _shared_stream(dev, "prefetch"), None)
         return _STREAMS[key]
     _PROBE_BUF.clear()                        # (the probe buffer goes back to the caching allocator ...
-    torch.cuda.empty_cache()                  # ... and from there to the device: half a gigabyte should not stay reserved for a one-time probe)
+    if os.environ.get("RIFT_PROBE_KEEP_CACHE") != "1":
+        torch.cuda.empty_cache()              # ... and from there to the device: half a gigabyte should not stay reserved for a one-time probe)
     _STREAMS[key] = tuple(chosen)
     _STREAMS[(key[0], "pool")] = pool         # (the unused ones stay alive: destroying them would hand their queues to the next stream created)
     return _STREAMS[key]
