@@ -51,6 +51,35 @@ def test_buffer_staging_drop_short_and_fill():
         buf.get_key_data('CBVs_obs')
 
 
+def test_buffer_reset_can_be_undone():
+    """Round 6: `reset_buffer_reversibly` empties the buffer like `reset_buffer` but keeps what it held in a token; `restore(token)` puts the
+    committed rows, the open episodes, the full flag and the extra columns back (RLFTPluto.train resets in the device's shadow and restores
+    when the update fails to commit).  Rows are the same objects, the columns read as before, a store() after the restore carries on; a
+    restore onto a buffer that has stored again is refused."""
+    buf = CBVRolloutBuffer(1, 'train_cbv', {'buffer_capacity': 10, 'data_keys': KEYS})
+    for t in range(7):
+        buf.store(_step([1, 2], [1] if t == 6 else [], t))      # CBV 1 committed (7 rows), CBV 2 still open (7 staged steps)
+    rows = list(buf._rows)
+    token = buf.reset_buffer_reversibly()
+    assert len(buf) == 0 and not buf.buffer_full and not buf._open
+    buf.restore(token)
+    assert len(buf) == 7 and all(a is b for a, b in zip(buf._rows, rows)) and not buf.buffer_full
+    assert [o[1] for o in buf.buffer_data['CBVs_obs']] == [1] * 7
+    for t in range(7, 9):
+        buf.store(_step([2], [2] if t == 8 else [], t))          # the open episode of CBV 2 survived the round trip: 9 steps, 3 fit
+    assert len(buf) == 10 and buf.buffer_full and [o[1] for o in buf.get_key_data('CBVs_obs')] == [1] * 7 + [2] * 3
+    buf.add_extra_data({'extra': list(range(10))})
+    token = buf.reset_buffer_reversibly()
+    assert len(buf) == 0 and not buf.buffer_full and 'extra' not in buf.buffer_data
+    buf.restore(token)                                           # a full buffer with its extra columns
+    assert buf.buffer_full and len(buf) == 10 and buf.sample([0, 9])['extra'] == [0, 9]
+    token = buf.reset_buffer_reversibly()
+    for t in range(7):
+        buf.store(_step([3], [3] if t == 6 else [], t))          # a new generation has been stored: the old one cannot come back over it
+    with pytest.raises(AssertionError):
+        buf.restore(token)
+
+
 def test_buffer_matches_the_reference_class_on_seeded_store_sequences():
     """a14 pinned: tests/golden/buffer.npz holds what the REFERENCE's CBVRolloutBuffer (cbv_rollout_buffer.py:16-138, imported by
     gen_golden.gen_buffer) did on 120 seeded multi-CBV store sequences -- short episodes (dropped), episodes staged across calls,

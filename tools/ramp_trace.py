@@ -1,13 +1,15 @@
 """The idle-device ramp (round-5 review, weak #5): a fresh trainer's first 20-step regions are slower than the steady state, and 50 ms of
 idleness bring the ramp back.  Clocks (kernel durations shrink over the ramp) or dispatch (durations flat, gaps / overlap change)?
 
-    rocprofv3 --kernel-trace -d /tmp/ramp -o ramp -- python tools/ramp_trace.py [out.json]      (GPU box)
-    python tools/ramp_analyze.py <results.db> out.json
+    python tools/ramp_trace.py [out.json]                                                           (GPU box; in-kernel clock probes)
+    RAMP_NO_PROBE=1 RIFT_TWO_STREAMS=0 RIFT_PIPELINE=0 rocprofv3 --kernel-trace -d /tmp/ramp -o ramp -- python tools/ramp_trace.py out.json
+    python tools/ramp_analyze.py <results.db> out.json                                              (serial step: per-kernel durations per region)
 
-Protocol: 5 warm-up steps, six back-to-back 20-step regions, 0.5 s of host sleep, four more regions, 50 ms of sleep, four more.  A sampler
-thread reads the device's sclk / mclk / power out of sysfs as fast as it can (with host timestamps), the main thread records the host-side
-wall time of every region and the time.time_ns() epoch of its start (rocprofv3's kernel timestamps are on the same clock domain up to a
-constant offset that the analysis fits on the first kernel of each region)."""
+Protocol: 5 warm-up steps, six back-to-back 20-step regions, 0.5 s of host sleep, four more regions, 50 ms of sleep, four more, 200 steps.
+Beside every update step one wave on a stream of its own reads s_memtime (shader-clock ticks) against s_memrealtime (constant 100 MHz) over
+a 20 us window (tools/ubench/clock_probe.hip -> libclock_probe.so): the effective shader clock, per step, whatever the SIMD is busy with.
+Result (profiles/NOTES_r06.md): clocks -- 2.3 GHz on arrival, a dip to 2.15, 2.42 GHz after ~25 ms.  (The sysfs sampler of the first version
+read a card that was not the one in use -- 157 MHz throughout -- and was dropped.)"""
 import json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
