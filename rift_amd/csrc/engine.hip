@@ -997,7 +997,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         HIPCHK(c, hipDeviceSynchronize());               // (hipMemset of device memory may return before the fill has run, and the preparation is launched on a non-blocking stream)
         c->rk_cap[sl] = cap; c->rk_epoch[sl] = 0;
       }
-      q.nrk = bs; q.rk_pub = c->rk_pub[sl]; q.aidx = nat_aidx; q.cnt = nat_cnt;
+      q.nrk = bs; q.rk_pub = c->rk_pub[sl]; q.aidx = nat_aidx; q.cnt = nat_cnt; q.fail = c->nonfinite;
       if (!c->dry) { if (++c->rk_epoch[sl] == 0u) c->rk_epoch[sl] = 1u; }      // (epoch 0 = "never written")
       q.rk_epoch = c->rk_epoch[sl];
       q.hist_agent = nullptr;                            // (the scene blocks derive the marks themselves)
@@ -2261,7 +2261,9 @@ int rift_check_finite(RiftCtx* c, void* stream) {
   HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
   if (!flag) return RIFT_OK;
   HIPCHK(c, hipMemsetAsync(c->nonfinite, 0, sizeof(int), (hipStream_t)stream));
-  c->err = "non-finite decoder queries (the reference asserts torch.isfinite(q).all(), planning_decoder.py:175)";
+  c->err = (flag & 2) ? "the in-launch ranking of the history encoder's sequences gave up waiting for a predecessor (kernels.h: rank_scene_body): the forward's "
+                        "results are invalid; non-finite flag raised"
+                      : "non-finite decoder queries (the reference asserts torch.isfinite(q).all(), planning_decoder.py:175)";
   return RIFT_ERR_NONFINITE;
 }
 

@@ -696,6 +696,7 @@ struct PrepP {
   // (round 6) the ranking of the history encoder's sequences inside this launch (rank_scene_body below): nrk = bs blocks at the HEAD of the
   // grid (0: the ranking is its own launch, nat_rank_kernel)
   int nrk; unsigned long long* rk_pub; unsigned int rk_epoch; int* aidx; int* cnt;
+  int* fail;      // the context's sticky device flag (bit 1: the look-back gave up waiting -- rift_check_finite reports it)
 };
 
 // ---------------------------------------------------------------------------
@@ -753,9 +754,12 @@ __device__ __forceinline__ void rank_scene_body(const PrepP& q, const int b) {
   unsigned long long acc = 0ull;
   for (int j = tid; j < b; j += 256) {
     unsigned long long w;
-    while (true) {
+    // (bounded: ~2^21 polls of ~1 us each are a couple of seconds, five orders beyond the longest legitimate wait -- a predecessor that never
+    // publishes would otherwise hang the device; the launch then finishes with wrong ranks and the sticky flag says so)
+    for (int spins = 0;; ++spins) {
       w = __hip_atomic_load(q.rk_pub + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((unsigned int)(w >> 32) == q.rk_epoch) break;
+      if (spins > (1 << 21)) { if (q.fail) atomicOr(q.fail, 2); w = 0ull; break; }
       __builtin_amdgcn_s_sleep(2);
     }
     acc += (w & 0x1ffull) | (((w >> 9) & 0x1ffull) << 21) | (((w >> 18) & 0x1ffull) << 42);
