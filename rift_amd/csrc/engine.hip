@@ -126,6 +126,7 @@ struct RiftCtx {
   // the in-launch ranking's published per-scene counts (kernels.h: rank_scene_body), one array per arena; they persist between launches
   // (a word is valid when it carries the launch's epoch; zero at allocation, epochs start at 1)
   unsigned long long* rk_pub[RIFT_DEFER_SLOTS] = {}; int rk_cap[RIFT_DEFER_SLOTS] = {}; unsigned int rk_epoch[RIFT_DEFER_SLOTS] = {};
+  bool rank_fault = false;               // RIFT_RANK_FAULT=1 (diagnostic): the first scene block of the in-launch ranking never publishes its counts
   bool enc112 = true;                    // RIFT_ENC112=0: scenes of 97 .. 112 token slots on enc_w_kernel (rounds 3 - 5) instead of the fused kernel's 112-row layout
   bool rank_in_prep = true;              // RIFT_RANK_IN_PREP=0: the ranking as its own launch behind the preparation (nat_rank_kernel, rounds 3 - 5)
   void* comm = nullptr; int comm_rank = 0, comm_world = 1;      // library-owned RCCL communicator (rift_comm_init), or null
@@ -997,7 +998,7 @@ int forward_impl(RiftCtx* c, const RiftFeatureBatch* B, const RiftOutputs* out, 
         HIPCHK(c, hipDeviceSynchronize());               // (hipMemset of device memory may return before the fill has run, and the preparation is launched on a non-blocking stream)
         c->rk_cap[sl] = cap; c->rk_epoch[sl] = 0;
       }
-      q.nrk = bs; q.rk_pub = c->rk_pub[sl]; q.aidx = nat_aidx; q.cnt = nat_cnt; q.fail = c->nonfinite;
+      q.nrk = bs; q.rk_pub = c->rk_pub[sl]; q.aidx = nat_aidx; q.cnt = nat_cnt; q.fail = c->nonfinite; q.rk_fault = c->rank_fault ? 1 : 0;
       if (!c->dry) { if (++c->rk_epoch[sl] == 0u) c->rk_epoch[sl] = 1u; }      // (epoch 0 = "never written")
       q.rk_epoch = c->rk_epoch[sl];
       q.hist_agent = nullptr;                            // (the scene blocks derive the marks themselves)
@@ -1697,6 +1698,7 @@ int rift_ctx_create(int device, RiftCtx** ctx) {
   { const char* ev = getenv("RIFT_FRONT_FUSED"); if (ev) c->front_fused = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_RANK_IN_PREP"); if (ev) c->rank_in_prep = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_ENC112"); if (ev) c->enc112 = atoi(ev) != 0; }
+  { const char* ev = getenv("RIFT_RANK_FAULT"); if (ev) c->rank_fault = atoi(ev) != 0; }
   { const char* ev = getenv("RIFT_EGO_NOFIT"); c->ego_nofit = ev && ev[0] == '1'; }
   { const char* ev = getenv("RIFT_FRONT_EGO"); if (ev) c->front_ego = atoi(ev) != 0; }        // (1: the ego token as blocks of that launch too -- 116 VGPRs: it no longer fits beside the decoder's workgroups)
   { const char* ev = getenv("RIFT_SIDE_GATE"); if (ev) c->side_gate = atoi(ev); }

@@ -697,6 +697,7 @@ struct PrepP {
   // grid (0: the ranking is its own launch, nat_rank_kernel)
   int nrk; unsigned long long* rk_pub; unsigned int rk_epoch; int* aidx; int* cnt;
   int* fail;      // the context's sticky device flag (bit 1: the look-back gave up waiting -- rift_check_finite reports it)
+  int rk_fault;   // diagnostic (RIFT_RANK_FAULT=1): scene block 0 never publishes -- what the bounded wait is there for (tests)
 };
 
 // ---------------------------------------------------------------------------
@@ -747,7 +748,7 @@ __device__ __forceinline__ void rank_scene_body(const PrepP& q, const int b) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) own[c] += __builtin_popcountll(mw & rk_class_mask((c - wbase[w] + 3) % 3));
   }
-  if (tid == 0)
+  if (tid == 0 && !(q.rk_fault && b == 0))
     __hip_atomic_store(q.rk_pub + b, ((unsigned long long)q.rk_epoch << 32) | ((unsigned long long)own[2] << 18) | ((unsigned long long)own[1] << 9) | (unsigned long long)own[0],
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (relaxed: the word IS the message; see below)
   // ---- look-back: the class counts of the scenes before this one (three 21-bit fields)

@@ -972,6 +972,30 @@ def test_ranking_inside_the_preparation_launch_equals_the_ranking_kernel(ffi, mo
         assert torch.equal(got["1"]["enc"], got["0"]["enc"]) and torch.equal(got["1"]["prob"], got["0"]["prob"]), ci
 
 
+def test_ranking_look_back_gives_up_instead_of_hanging(ffi, monkeypatch):
+    """The scene blocks of the in-launch ranking wait for their predecessors' published counts (kernels.h: rank_scene_body).  A predecessor
+    that never publishes -- injected here: RIFT_RANK_FAULT=1 keeps block 0 silent -- must not hang the device: the wait is bounded (a couple
+    of seconds), the launch finishes, and the sticky flag turns the forward into an error at the next host read."""
+    import time
+    gold, batch, sd = H.load_case("full")
+    data = batch["cur_pluto_feature_torch"]
+    monkeypatch.setenv("RIFT_RANK_FAULT", "1")
+    eng = ffi.Engine("cuda:0")
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    t0 = time.perf_counter()
+    eng.forward(data, need_traj=False)
+    with pytest.raises(RuntimeError, match="ranking"):
+        eng.check_finite()
+    assert time.perf_counter() - t0 < 60.0
+    eng.close()
+    monkeypatch.delenv("RIFT_RANK_FAULT")
+    eng = ffi.Engine("cuda:0")
+    eng.load_state_dict({k: v.clone() for k, v in sd.items()})
+    eng.forward(data, need_traj=False)
+    eng.check_finite()
+    eng.close()
+
+
 def test_fused_encoder_matches_layerwise_path(ffi, monkeypatch):
     """The fused scene-encoder kernel (4 layers + final LN, one workgroup per scene) against the layer-wise
     GEMM/attention path and the exact-fp32 path, on the encoder output of every valid token."""
