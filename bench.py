@@ -377,7 +377,7 @@ def main():
     sd_cpu = syn.perturbed_state_dict({k: list(v.shape) for k, v in model.state_dict().items()})
     nsteps = args.warmup + args.steps + 8
 
-    def leg(scaling, precision, steps, want_all_outputs=False, want_full_update=False, want_roofline=False):
+    def leg(scaling, precision, steps, want_all_outputs=False, want_full_update=False, want_roofline=False, want_steady=False):
         """Time `steps` update steps in one (scaling, precision) configuration on fresh parameters / optimizer state.
         A generator: the first next() builds the leg (its own model, engine context, trainer, index tensors -- host work, tens of ms), the
         second one runs it and yields the result.  main() builds the headline leg BEFORE it runs the companion legs, so that the headline
@@ -435,7 +435,7 @@ def main():
                "per_gpu_batch": local_bs, "global_batch": global_bs, "replay_scenes_per_gpu": per_rank, "final_loss": float(loss.item())}
         eng.check_finite()
 
-        if want_all_outputs and steps < 200:
+        if (want_all_outputs or want_steady) and steps < 200:
             # companion figure: 200 steps behind the same barriers.  The step pipeline is four steps deep (gather / preparation / history and
             # map encoders of step k + 1 .. k + 3 beside encoder / decoder of step k, head / loss / update of step k behind them): a timed run
             # of K steps pays its fill and drain once (~1 ms), which a 20-step run sees as +0.04 .. 0.05 ms per step
@@ -608,11 +608,15 @@ def main():
     keep = ("ms_per_step", "value", "steps_per_sec", "steps", "final_loss")
     if world == 1 and not args.no_precisions:
         precisions = {}
-        todo = [(p, built("weak", p, args.steps if p != "fp32" else max(5, min(args.steps, 20))))      # (the layer-by-layer fp32 step is several times longer)
+        # (the 16-bit companion also runs its 200-step region: at the driver's K = 20 a leg sits on the device's clock ramp -- profiles/NOTES_r06.md --
+        # and the order of the legs decides who pays how much of it; the steady states are what compares the two 16-bit builds)
+        todo = [(p, built("weak", p, args.steps if p != "fp32" else max(5, min(args.steps, 20)), want_steady=p != "fp32"))      # (the layer-by-layer fp32 step is several times longer)
                 for p in ("fp32", "fp16", "bf16") if p != args.precision]
         for p, g in todo:
             r = next(g)
             precisions[p] = {k: r[k] for k in keep}
+            if "steady_state" in r:
+                precisions[p]["steady_ms_per_step"] = r["steady_state"]["ms_per_step"]
     head = next(head_leg)
     contract = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline and BATCH == 256:
@@ -647,6 +651,8 @@ def main():
                         "group advantage of every CBV (rollout, neighbour forecast, collision / off-road flags, return, z-score); tools/tick_latency.py")
     if precisions is not None:
         precisions[args.precision] = {k: head[k] for k in keep}
+        if "steady_state" in head:
+            precisions[args.precision]["steady_ms_per_step"] = head["steady_state"]["ms_per_step"]
         precisions["note"] = ("the same update steps per compute precision: bf16 / fp16 = the fused kernels on bf16 / fp16 MFMA operands; fp32 = exact "
                               "v_mfma_f32_16x16x4_f32 layer by layer (the reference's `precision: 32`).  Parity per mode: tests/test_gpu_parity.py header")
 
@@ -730,6 +736,8 @@ def main():
                     line["config"]["contract_clean_ms_per_step"] = ms
                     line["config"]["contract_clean_value"] = precisions[q]["value"]
                     line["config"]["contract_clean_max_loss_err"] = pc[q]["max_loss_err_vs_oracle"]
+                    if "steady_ms_per_step" in precisions[q]:      # (200 steps in one region: compare with config.steady_state_ms_per_step)
+                        line["config"]["contract_clean_steady_ms_per_step"] = precisions[q]["steady_ms_per_step"]
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
