@@ -72,15 +72,15 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
     f32x4 acc[MT][2];
     p_zero(acc);
     p_mma<MT, 4, 2>(acc, xb, HD_XS, 0, W1, l15, l4);
-    PFrags<4, 2> W2a, W2b;                              // second layer: 160 outputs = n-tiles 0..9, K = 256 in two halves
+    // second layer: 160 outputs = n-tiles 0..9, K = 256 in two halves.  Every wave owns n-tile `wave`; waves 0 and 1 own n-tiles 8 and 9 as well
+    // (round 6: the other six waves used to multiply zero fragments for a second n-tile that does not exist -- half of their MFMAs)
+    const bool two = wave < 2;                          // (wave-uniform)
+    PFrags<4, 1> W2a, W2b;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {                  // n-tiles >= 10 do not exist in the 160-row image
-        const bool ok = j * NW + wave < 10;
-        W2a.f[ks][j] = ok ? fm_load(p.w2[h], 256, (j * NW + wave) * 16, ks * 32, l4 * 16 + l15) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        W2b.f[ks][j] = ok ? fm_load(p.w2[h], 256, (j * NW + wave) * 16, 128 + ks * 32, l4 * 16 + l15) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      }
+    for (int ks = 0; ks < 4; ++ks) {
+      W2a.f[ks][0] = fm_load(p.w2[h], 256, wave * 16, ks * 32, l4 * 16 + l15);
+      W2b.f[ks][0] = fm_load(p.w2[h], 256, wave * 16, 128 + ks * 32, l4 * 16 + l15);
+    }
     float bsum[MT], bsq[MT];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -122,14 +122,7 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
     __syncthreads();
     // ---- out = hn W2^T + b2: 10 n-tiles (waves 0, 1 own two, the others one), scattered into (row, step, component)
     {
-      f32x4 o[MT][2];
-      p_zero(o);
-      p_mma<MT, 4, 2>(o, hn, HD_HS, 0, W2a, l15, l4);
-      p_mma<MT, 4, 2>(o, hn, HD_HS, 128, W2b, l15, l4);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int nt = j * NW + wave;
-        if (nt >= 10) continue;
+      auto store = [&](const f32x4 (&o)[MT][1], int nt) {
         const int col = nt * 16 + l4 * 4;              // head output column: step col / 2, component col % 2
         const float4 b4 = *reinterpret_cast<const float4*>(par + 3 * 768 + h * 160 + col);
 #pragma unroll
@@ -137,9 +130,28 @@ __global__ __launch_bounds__(512) void heads3_fused_kernel(Heads3P p) {
           const int gr = row0 + mt * 16 + l15;
           if (gr >= p.rows) continue;
           float* dst = p.out + (size_t)gr * 480 + (col >> 1) * 6 + h * 2;
-          *reinterpret_cast<float2*>(dst) = make_float2(o[mt][j][0] + b4.x, o[mt][j][1] + b4.y);
-          *reinterpret_cast<float2*>(dst + 6) = make_float2(o[mt][j][2] + b4.z, o[mt][j][3] + b4.w);
+          *reinterpret_cast<float2*>(dst) = make_float2(o[mt][0][0] + b4.x, o[mt][0][1] + b4.y);
+          *reinterpret_cast<float2*>(dst + 6) = make_float2(o[mt][0][2] + b4.z, o[mt][0][3] + b4.w);
         }
+      };
+      {
+        f32x4 o[MT][1];
+        p_zero(o);
+        p_mma<MT, 4, 1>(o, hn, HD_HS, 0, W2a, l15, l4);
+        p_mma<MT, 4, 1>(o, hn, HD_HS, 128, W2b, l15, l4);
+        store(o, wave);
+      }
+      if (two) {                                        // (its weights are fetched here: held across the first product they spilled)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          W2a.f[ks][0] = fm_load(p.w2[h], 256, (NW + wave) * 16, ks * 32, l4 * 16 + l15);
+          W2b.f[ks][0] = fm_load(p.w2[h], 256, (NW + wave) * 16, 128 + ks * 32, l4 * 16 + l15);
+        }
+        f32x4 o[MT][1];
+        p_zero(o);
+        p_mma<MT, 4, 1>(o, hn, HD_HS, 0, W2a, l15, l4);
+        p_mma<MT, 4, 1>(o, hn, HD_HS, 128, W2b, l15, l4);
+        store(o, NW + wave);
       }
     }
     __syncthreads();     // hn / wpart are rewritten by the next head
